@@ -1,0 +1,392 @@
+"""Plain-PyTorch (CPU, fp32/fp64) restatement of the GVL deformable-transformer hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product (gvl_amd/) never imports this module.
+
+Everything here is *functional* over a flat ``state_dict`` that uses the reference's parameter names, so
+that a reference checkpoint (or the golden fixtures' weights) drives it directly.  Each function names the
+reference lines (under /root/reference) whose arithmetic it restates.  The sampling core is the
+grid_sample formulation of the reference's own CPU fallback, with a selectable padding mode:
+``border`` = the fallback as shipped (func.py:61-62), ``zeros`` = the CUDA op's semantics (cuh:238-300).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------------
+# op level
+# --------------------------------------------------------------------------------------------------
+def as_shapes2d(shapes):
+    """(L,) temporal lengths -> (L,2) [(1,T_l)]   (ms_deform_attn.py:117); (L,2) passes through."""
+    shapes = torch.as_tensor(shapes, dtype=torch.long)
+    if shapes.dim() == 1:
+        shapes = torch.stack([torch.ones_like(shapes), shapes], -1)
+    return shapes
+
+
+def msda_core(value, shapes, loc, aw, pad_mode="border", return_value=False):
+    """ms_deform_attn_core_pytorch, pdvc/ops/functions/ms_deform_attn_func.py:44-71.
+
+    value (B,S,M,D); shapes (L,2) (H,W); loc (B,Q,M,L,P,2) in [0,1] (x,y); aw (B,Q,M,L,P).
+    Returns (B,Q,M*D), or the unweighted samples (B*M, D, Q, L, P) when return_value."""
+    B, S, M, D = value.shape
+    _, Q, _, L, P, _ = loc.shape
+    shapes = as_shapes2d(shapes)
+    sizes = [int(h) * int(w) for h, w in shapes.tolist()]
+    grids = 2 * loc - 1                                            # func.py:52
+    per_level = []
+    start = 0
+    for lvl, (H, W) in enumerate(shapes.tolist()):
+        v = value[:, start:start + sizes[lvl]]                    # (B, H*W, M, D)          func.py:51
+        start += sizes[lvl]
+        v = v.permute(0, 2, 3, 1).reshape(B * M, D, H, W)          # func.py:56
+        g = grids[:, :, :, lvl].permute(0, 2, 1, 3, 4).reshape(B * M, Q, P, 2)   # func.py:58
+        per_level.append(F.grid_sample(v, g, mode="bilinear", padding_mode=pad_mode,
+                                       align_corners=False))      # (B*M, D, Q, P)         func.py:61-62
+    samp = torch.stack(per_level, dim=-2)                          # (B*M, D, Q, L, P)
+    if return_value:
+        return samp                                                # func.py:67-68
+    a = aw.permute(0, 2, 1, 3, 4).reshape(B * M, 1, Q, L * P)      # func.py:65
+    out = (samp.flatten(-2) * a).sum(-1).view(B, M * D, Q)         # func.py:70
+    return out.transpose(1, 2).contiguous()
+
+
+def sampling_locations(ref, off, tshapes, n_points):
+    """ms_deform_attn.py:103-117: 1-D reference (+len) and scalar offsets -> (B,Q,M,L,P,2) with y = 0.5."""
+    if ref.shape[-1] == 1:
+        norm = tshapes.to(off.dtype)
+        x = ref[:, :, None, :, None, 0] + off / norm[None, None, None, :, None]
+    elif ref.shape[-1] == 2:
+        x = ref[:, :, None, :, None, 0] + off / n_points * ref[:, :, None, :, None, 1] * 0.5
+    else:
+        raise ValueError("Last dim of reference_points must be 1 or 2, but get {} instead.".format(ref.shape[-1]))
+    return torch.stack((x, torch.full_like(x, 0.5)), -1)
+
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+
+
+def msda_module(sd, pre, query, ref, inp, tshapes, mask=None, n_heads=8, n_levels=4, n_points=4,
+                pad_mode="zeros", cap=False):
+    """MSDeformAttn.forward (pdvc/ops/modules/ms_deform_attn.py:79-126) and, with cap=True,
+    MSDeformAttnCap.forward (pdvc/ops/modules/ms_deform_attn_for_caption.py:82-127: no weighting, no
+    output_proj, border padding, returns (B*M, D, Q, L, P))."""
+    B, Q, _ = query.shape
+    _, S, C = inp.shape
+    value = _lin(sd, pre + "value_proj", inp)
+    if mask is not None:
+        value = value.masked_fill(mask[..., None], 0.0)            # :96-97
+    value = value.view(B, S, n_heads, C // n_heads)
+    off = _lin(sd, pre + "sampling_offsets", query).view(B, Q, n_heads, n_levels, n_points)
+    aw = _lin(sd, pre + "attention_weights", query).view(B, Q, n_heads, n_levels * n_points)
+    aw = F.softmax(aw, -1).view(B, Q, n_heads, n_levels, n_points)
+    loc = sampling_locations(ref, off, tshapes, n_points)
+    shapes2d = as_shapes2d(tshapes)
+    if cap:
+        return msda_core(value, shapes2d, loc, aw, "border", return_value=True)
+    out = msda_core(value, shapes2d, loc, aw, pad_mode)
+    return _lin(sd, pre + "output_proj", out)
+
+
+# --------------------------------------------------------------------------------------------------
+# base encoder (feeds the path; pdvc/base_encoder.py:55-82, pdvc/position_encoding.py:38-64)
+# --------------------------------------------------------------------------------------------------
+def position_embedding(sd, pre, mask, duration, num_pos_feats=256, temperature=10000, max_duration=256):
+    not_mask = ~mask
+    x = not_mask.cumsum(1, dtype=torch.float32)
+    x = (x - 0.5) / (x[:, -1:] + 1e-6) * (2 * math.pi)
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    px = x[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    steps = torch.arange(max_duration)[None, :]
+    onehot = (steps < duration.int()[:, None]).float()             # position_encoding.py:58-63
+    dur = _lin(sd, pre + "duration_embed_layer", onehot)
+    dur = dur[:, None, :].expand(-1, px.shape[1], -1)
+    return torch.cat((px, dur), dim=2).permute(0, 2, 1)            # (B, 512, T)
+
+
+def base_encoder(sd, vf, mask, duration, n_levels=4, pre="base_encoder."):
+    x = vf.transpose(1, 2)
+    srcs, masks, poses = [], [], []
+    for l in range(n_levels):
+        p = f"{pre}input_proj.{l}."
+        if l == 0:
+            y = F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"])
+            m = mask
+        else:
+            src_in = x if l == 1 else srcs[-1]
+            y = F.conv1d(src_in, sd[p + "0.weight"], sd[p + "0.bias"], stride=2, padding=1)
+            m = F.interpolate(mask[None].float(), size=y.shape[-1:]).to(torch.bool)[0]
+        y = F.group_norm(y, 32, sd[p + "1.weight"], sd[p + "1.bias"])
+        srcs.append(y)
+        masks.append(m)
+        poses.append(position_embedding(sd, pre + "pos_embed.", m, duration).to(y.dtype))
+    return srcs, masks, poses
+
+
+# --------------------------------------------------------------------------------------------------
+# transformer (pdvc/deformable_transformer.py)
+# --------------------------------------------------------------------------------------------------
+def prepare_encoder_inputs(sd, srcs, masks, poses, pre="transformer."):
+    """deformable_transformer.py:85-115"""
+    src = torch.cat([s.transpose(1, 2) for s in srcs], 1)
+    mask = torch.cat(masks, 1)
+    pos = torch.cat([p.transpose(1, 2) + sd[pre + "level_embed"][l].view(1, 1, -1) for l, p in enumerate(poses)], 1)
+    tshapes = torch.as_tensor([s.shape[-1] for s in srcs], dtype=torch.long)
+    lsi = torch.cat((tshapes.new_zeros((1,)), tshapes.cumsum(0)[:-1]))
+    valid_ratios = torch.stack([(~m).sum(1).float() / m.shape[1] for m in masks], 1)    # :81-83
+    return src, tshapes, lsi, valid_ratios, pos, mask
+
+
+def encoder_reference_points(tshapes, valid_ratios):
+    """deformable_transformer.py:209-218 -> (B, S, L, 1)"""
+    refs = []
+    for lvl, T in enumerate(tshapes.tolist()):
+        r = torch.linspace(0.5, T - 0.5, T, dtype=torch.float32)
+        refs.append(r[None] / (valid_ratios[:, None, lvl] * T))
+    ref = torch.cat(refs, 1)
+    return (ref[:, :, None] * valid_ratios[:, None])[..., None]
+
+
+def _ln(sd, name, x):
+    return F.layer_norm(x, x.shape[-1:], sd[name + ".weight"], sd[name + ".bias"])
+
+
+def _ffn(sd, pre, x):
+    return _lin(sd, pre + "linear2", F.relu(_lin(sd, pre + "linear1", x)))
+
+
+def encoder(sd, src, tshapes, lsi, valid_ratios, pos, mask, n_layers, pad_mode="zeros", pre="transformer.encoder.",
+            **kw):
+    """deformable_transformer.py:189-226 (dropout = identity: eval mode)"""
+    ref = encoder_reference_points(tshapes, valid_ratios)
+    x = src
+    for i in range(n_layers):
+        p = f"{pre}layers.{i}."
+        x = _ln(sd, p + "norm1", x + msda_module(sd, p + "self_attn.", x + pos, ref, x, tshapes, mask,
+                                                  pad_mode=pad_mode, **kw))
+        x = _ln(sd, p + "norm2", x + _ffn(sd, p, x))
+    return x
+
+
+def mha(sd, pre, q_in, k_in, v_in, key_padding_mask, n_heads):
+    """nn.MultiheadAttention as used at deformable_transformer.py:266-268 (batch-first here)."""
+    B, Q, C = q_in.shape
+    W, b = sd[pre + "in_proj_weight"], sd[pre + "in_proj_bias"]
+    q = F.linear(q_in, W[:C], b[:C]).view(B, Q, n_heads, -1).transpose(1, 2)
+    k = F.linear(k_in, W[C:2 * C], b[C:2 * C]).view(B, Q, n_heads, -1).transpose(1, 2)
+    v = F.linear(v_in, W[2 * C:], b[2 * C:]).view(B, Q, n_heads, -1).transpose(1, 2)
+    att = (q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    if key_padding_mask is not None:
+        att = att.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    o = (F.softmax(att, -1) @ v).transpose(1, 2).reshape(B, Q, C)
+    return _lin(sd, pre + "out_proj", o)
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """misc/detr_utils/misc.py:582-586"""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def mlp3(sd, pre, x):
+    x = F.relu(_lin(sd, pre + "layers.0", x))
+    x = F.relu(_lin(sd, pre + "layers.1", x))
+    return _lin(sd, pre + "layers.2", x)
+
+
+def decoder(sd, tgt, ref, memory, tshapes, lsi, valid_ratios, query_pos, mask, query_mask, n_layers, n_heads=8,
+            pad_mode="zeros", refine=True, pre="transformer.decoder.", **kw):
+    """deformable_transformer.py:263-335; returns (hs (layers,B,Q,C), inter_refs (layers,B,Q,1|2))"""
+    x = tgt
+    hs, refs = [], []
+    for i in range(n_layers):
+        p = f"{pre}layers.{i}."
+        if ref.shape[-1] == 2:
+            ref_in = ref[:, :, None] * torch.stack([valid_ratios, valid_ratios], -1)[:, None]
+        else:
+            ref_in = ref[:, :, None] * valid_ratios[:, None, :, None]
+        qk = x + query_pos
+        x = _ln(sd, p + "norm2", x + mha(sd, p + "self_attn.", qk, qk, x, ~query_mask, n_heads))
+        x = _ln(sd, p + "norm1", x + msda_module(sd, p + "cross_attn.", x + query_pos, ref_in, memory, tshapes, mask,
+                                                  n_heads=n_heads, pad_mode=pad_mode, **kw))
+        x = _ln(sd, p + "norm3", x + _ffn(sd, p, x))
+        if refine and (pre + f"bbox_head.{i}.layers.0.weight") in sd:
+            tmp = mlp3(sd, pre + f"bbox_head.{i}.", x)
+            if ref.shape[-1] == 2:
+                new = (tmp + inverse_sigmoid(ref)).sigmoid()
+            else:
+                tmp = torch.cat([tmp[..., :1] + inverse_sigmoid(ref), tmp[..., 1:]], -1)   # :319-322
+                new = tmp.sigmoid()
+            ref = new.detach()
+        hs.append(x)
+        refs.append(ref)
+    return torch.stack(hs), torch.stack(refs)
+
+
+def prepare_decoder_input_query(sd, query_embed, B, pre="transformer."):
+    """deformable_transformer.py:128-135"""
+    qpos, tgt = torch.chunk(query_embed, 2, dim=1)
+    qpos = qpos.unsqueeze(0).expand(B, -1, -1)
+    tgt = tgt.unsqueeze(0).expand(B, -1, -1)
+    ref = _lin(sd, pre + "reference_points", qpos).sigmoid()
+    return ref, tgt, ref, qpos
+
+
+# --------------------------------------------------------------------------------------------------
+# captioner (pdvc/CaptioningHead/LSTM_DSA.py)
+# --------------------------------------------------------------------------------------------------
+def captioner_step(sd, pre, it, state, hs, ref_in, memory, tshapes, mask, n_levels=4, n_points=4):
+    """Captioner.get_logprobs_state + ShowAttendTellCore.forward (LSTM_DSA.py:120-124, :241-271), cap_nheads=1."""
+    B, Q, C = hs.shape
+    h, c = state                                                   # (B*Q, C)
+    xt = F.embedding(it, sd[pre + "embed.weight"])
+    jq = torch.cat((h.reshape(B, Q, -1), hs), 2)
+    clip = msda_module(sd, pre + "core.deformable_att.", jq, ref_in, memory, tshapes, mask, n_heads=1,
+                       n_levels=n_levels, n_points=n_points, cap=True)             # (B, C, Q, L, P)
+    K = n_levels * n_points
+    clip = clip.reshape(B, 1, C, Q, K).permute(0, 3, 1, 4, 2).reshape(B * Q, K, C)
+    att = _lin(sd, pre + "core.ctx2att", clip) + _lin(sd, pre + "core.h2att", h)[:, None, :]
+    e = _lin(sd, pre + "core.alpha_net", torch.tanh(att)).squeeze(-1)
+    alpha = F.softmax(e, dim=1)
+    att_res = torch.bmm(alpha.unsqueeze(1), clip).squeeze(1)       # (B*Q, C)
+    x = torch.cat([xt, att_res, hs.reshape(B * Q, C)], 1)
+    gates = F.linear(x, sd[pre + "core.rnn.weight_ih_l0"]) + F.linear(h, sd[pre + "core.rnn.weight_hh_l0"])
+    i, f, g, o = gates.chunk(4, 1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    logp = F.log_softmax(_lin(sd, pre + "logit", h2), dim=1)
+    return logp, (h2, c2)
+
+
+def captioner_ref_in(ref, valid_ratios):
+    """LSTM_DSA.py:137-141"""
+    if ref.shape[-1] == 2:
+        return ref[:, :, None] * torch.stack([valid_ratios] * 2, -1)[:, None]
+    return ref[:, :, None] * valid_ratios[:, None, :, None]
+
+
+def captioner_sample(sd, pre, hs, ref, memory, tshapes, mask, valid_ratios, max_len=30, **kw):
+    """Captioner.sample greedy branch (LSTM_DSA.py:126-194). Returns (seq (B*Q,<=max_len), logprobs)."""
+    B, Q, C = hs.shape
+    ref_in = captioner_ref_in(ref, valid_ratios)
+    n = B * Q
+    state = (hs.new_zeros(n, C), hs.new_zeros(n, C))
+    seq, seqlp = [], []
+    logp = None
+    for t in range(max_len + 1):
+        if t == 0:
+            it = torch.zeros(n, dtype=torch.long)
+        else:
+            lp, it = torch.max(logp, 1)
+        logp, state = captioner_step(sd, pre, it, state, hs, ref_in, memory, tshapes, mask, **kw)
+        if t >= 1:
+            unfinished = (it > 0) if t == 1 else unfinished & (it > 0)
+            if unfinished.sum() == 0:
+                break
+            seq.append(it * unfinished.type_as(it))
+            seqlp.append(lp)
+    if not seq:
+        return [], []
+    return torch.stack(seq, 1), torch.stack(seqlp, 1)
+
+
+# --------------------------------------------------------------------------------------------------
+# PDVC eval forward, 'queries' mode, contrastive off (pdvc/pdvc.py:250-314, :434-519)
+# --------------------------------------------------------------------------------------------------
+def pdvc_eval_forward(sd, dt, n_enc=2, n_dec=2, n_heads=8, n_levels=4, pad_mode="zeros", captioning=True,
+                      max_caption_len=30):
+    vf = dt["video_tensor"]
+    mask = ~dt["video_mask"]
+    duration = dt["video_length"][:, 1]
+    B = vf.shape[0]
+    srcs, masks, poses = base_encoder(sd, vf, mask, duration, n_levels)
+    src, tshapes, lsi, vr, pos, mflat = prepare_encoder_inputs(sd, srcs, masks, poses)
+    memory = encoder(sd, src, tshapes, lsi, vr, pos, mflat, n_enc, pad_mode=pad_mode, n_heads=n_heads)
+    qe = sd["query_embed.weight"]
+    init_ref, tgt, ref, qpos = prepare_decoder_input_query(sd, qe, B)
+    qmask = torch.ones(B, qe.shape[0], dtype=torch.bool)
+    hs, inter = decoder(sd, tgt, ref, memory, tshapes, lsi, vr, qpos, mflat, qmask, n_dec, n_heads=n_heads,
+                        pad_mode=pad_mode)
+    logits, counts, boxes = [], [], []
+    for l in range(n_dec):
+        reference = init_ref if l == 0 else inter[l - 1]
+        h = hs[l]
+        logits.append(_lin(sd, f"class_head.{l}", h))
+        counts.append(_lin(sd, f"count_head.{l}", h.max(dim=1)[0]))                 # pdvc.py:316-319
+        tmp = mlp3(sd, f"bbox_head.{l}.", h)
+        r = inverse_sigmoid(reference)
+        if r.shape[-1] == 2:
+            tmp = tmp + r
+        else:
+            tmp = torch.cat([tmp[..., :1] + r, tmp[..., 1:]], -1)
+        boxes.append(tmp.sigmoid())                                                  # pdvc.py:465-474
+    out = {"pred_logits": logits[-1], "pred_count": counts[-1], "pred_boxes": boxes[-1],
+           "aux_logits": logits[:-1], "aux_boxes": boxes[:-1], "aux_count": counts[:-1],
+           "event_feat": hs[-1], "memory": memory, "hs": hs, "inter_references": inter}
+    if captioning:
+        reference = init_ref if n_dec == 1 else inter[n_dec - 2]
+        seq, lp = captioner_sample(sd, f"caption_head.{n_dec - 1}.", hs[-1], reference, memory, tshapes, mflat, vr,
+                                   max_len=max_caption_len)
+        Q = qe.shape[0]
+        if len(seq):
+            seq = seq.reshape(-1, Q, seq.shape[-1])
+            lp = lp.reshape(-1, Q, lp.shape[-1])
+        out["seq"], out["cap_prob_eval"] = seq, lp
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# Hungarian matcher (pdvc/matcher.py:53-150, misc/detr_utils/box_ops.py:8-47)
+# --------------------------------------------------------------------------------------------------
+def box_cl_to_xy(x):
+    c, l = x.unbind(-1)
+    return torch.stack([c - 0.5 * l, c + 0.5 * l], dim=-1)
+
+
+def giou_1d(b1, b2):
+    a1 = b1[:, 1] - b1[:, 0]
+    a2 = b2[:, 1] - b2[:, 0]
+    inter = (torch.min(b1[:, None, 1], b2[:, 1]) - torch.max(b1[:, None, 0], b2[:, 0])).clamp(min=0)
+    union = a1[:, None] + a2 - inter
+    iou = inter / (union + 1e-5)
+    area = (torch.max(b1[:, None, 1], b2[:, 1]) - torch.min(b1[:, None, 0], b2[:, 0])).clamp(min=0)
+    return iou - (area - union) / (area + 1e-5)
+
+
+def matcher_cost(pred_logits, pred_boxes, tgt_labels, tgt_boxes, w_class=2.0, w_bbox=0.0, w_giou=4.0, alpha=0.25,
+                 gamma=2.0, w_cl=0.0, cl_match_mats=None):
+    """matcher.py:74-105 -> C (B, Q, sum nGT) float32"""
+    B, Q = pred_logits.shape[:2]
+    p = pred_logits.flatten(0, 1).sigmoid()
+    bx = pred_boxes.flatten(0, 1)
+    neg = (1 - alpha) * (p ** gamma) * (-(1 - p + 1e-8).log())
+    posc = alpha * ((1 - p) ** gamma) * (-(p + 1e-8).log())
+    cost_class = posc[:, tgt_labels] - neg[:, tgt_labels]
+    cost_bbox = torch.cdist(bx, tgt_boxes, p=1)
+    cost_giou = -giou_1d(box_cl_to_xy(bx), box_cl_to_xy(tgt_boxes))
+    if isinstance(cl_match_mats, torch.Tensor):
+        cost_cl = -1.0 * cl_match_mats[:, :cost_bbox.shape[1]]
+    else:
+        cost_cl = -1 * 0
+    C = w_bbox * cost_bbox + w_class * cost_class + w_giou * cost_giou + w_cl * cost_cl
+    return C.view(B, Q, -1)
+
+
+def hungarian(C, sizes, m2o_rate=4):
+    """matcher.py:120-131: scipy.optimize.linear_sum_assignment (the reference's own third-party solver; the
+    reference's requirement.txt leaves scipy unpinned, this image ships 1.15.3) on each video's column block,
+    and on the block tiled m2o_rate times with GT id = col % nGT."""
+    from scipy.optimize import linear_sum_assignment
+    C = C.cpu()
+    indices, rl = [], []
+    for i, c in enumerate(C.split(sizes, -1)):
+        r, k = linear_sum_assignment(c[i])
+        indices.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(k, dtype=torch.int64)))
+        r, k = linear_sum_assignment(torch.cat([c[i]] * m2o_rate, -1))
+        rl.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(k % sizes[i], dtype=torch.int64)))
+    return indices, rl

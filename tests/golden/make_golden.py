@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the *imported* reference on CPU (build container only).
+
+    cd /tmp && python /root/repo/tests/golden/make_golden.py           # writes next to this file
+
+The reference (zjr2000/GVL @ /root/reference) is imported in place through tests/golden/_refimport.py; nothing
+of it is copied.  Each fixture holds inputs (or the seeds that regenerate them through tests/golden/synth.py)
+and the reference's outputs.  Two padding semantics are recorded for the sampling op:
+
+  *_zeros   the CUDA op behind MSDeformAttnFunction (pdvc/ops/src/cuda/ms_deform_im2col_cuda.cuh:238-300): obtained
+            from the reference's own ms_deform_attn_core_pytorch with its grid_sample call switched to
+            padding_mode='zeros' for the duration of the call (the .cu sources cannot be compiled here);
+  *_border  ms_deform_attn_core_pytorch exactly as shipped (func.py:61-62) = the CPU fallback and the captioner path.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+
+FULL = "--no-pdvc" not in sys.argv
+_refimport.install(full=FULL)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import pdvc.ops.functions.ms_deform_attn_func as RF  # noqa: E402
+import pdvc.ops.modules.ms_deform_attn as RM  # noqa: E402
+from pdvc.ops.modules import MSDeformAttn, MSDeformAttnCap  # noqa: E402
+from pdvc.matcher import HungarianMatcher  # noqa: E402
+from synth import synth_array, synth_state_dict, level_lengths  # noqa: E402
+
+torch.set_num_threads(4)
+_orig_grid_sample = F.grid_sample
+_orig_core = RF.ms_deform_attn_core_pytorch
+
+
+def core_with_pad(pad):
+    """the reference core with its grid_sample padding switched (zeros = CUDA-op semantics)."""
+    def core(*a, **k):
+        def gs(*ga, **gk):
+            gk["padding_mode"] = pad
+            return _orig_grid_sample(*ga, **gk)
+        RF.F.grid_sample = gs
+        try:
+            return _orig_core(*a, **k)
+        finally:
+            RF.F.grid_sample = _orig_grid_sample
+    return core
+
+
+class cuda_semantics:
+    """Inside: MSDeformAttn's sampling core zero-pads (what MSDeformAttnFunction computes on a GPU), while
+    MSDeformAttnCap keeps calling the shipped (border) core -- exactly the reference's behaviour on a CUDA device."""
+    def __enter__(self):
+        RM.ms_deform_attn_core_pytorch = core_with_pad("zeros")
+
+    def __exit__(self, *a):
+        RM.ms_deform_attn_core_pytorch = _orig_core
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ----------------------------------------------------------------------------------------------- op level
+def op_case(name, shapes, B, M, D, Q, P, dtype, seed, loc_lo=-0.25, loc_hi=1.25, value_scale=1.0, normalise_w=False):
+    shapes = torch.as_tensor(shapes, dtype=torch.long)
+    L = shapes.shape[0]
+    S = int(shapes.prod(1).sum())
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    g = torch.Generator().manual_seed(seed)
+    value = (torch.randn(B, S, M, D, generator=g, dtype=torch.float64) * value_scale).to(dtype)
+    loc = (torch.rand(B, Q, M, L, P, 2, generator=g, dtype=torch.float64) * (loc_hi - loc_lo) + loc_lo).to(dtype)
+    if int(shapes[:, 0].max()) == 1:
+        loc[..., 1] = 0.5                                          # ms_deform_attn.py:115-116
+    if normalise_w:                                                # pdvc/ops/test.py:33-35 style
+        aw = torch.rand(B, Q, M, L, P, generator=g, dtype=torch.float64) + 1e-5
+        aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).to(dtype)
+    else:
+        aw = torch.softmax(torch.randn(B, Q, M, L * P, generator=g, dtype=torch.float64), -1).view(B, Q, M, L, P).to(dtype)
+    gout = torch.randn(B, Q, M * D, generator=g, dtype=torch.float64).to(dtype)
+    rec = dict(value=value, shapes=shapes, lsi=lsi, loc=loc, aw=aw, gout=gout)
+    for pad in ("zeros", "border"):
+        v, l_, a = (t.clone().requires_grad_() for t in (value, loc, aw))
+        out = core_with_pad(pad)(v, shapes, l_, a)
+        out.backward(gout)
+        rec.update({f"out_{pad}": out, f"gvalue_{pad}": v.grad, f"gloc_{pad}": l_.grad, f"gaw_{pad}": a.grad})
+    rec["sample_border"] = _orig_core(value, shapes, loc, aw, return_value=True)
+    save(name, **rec)
+
+
+def make_op():
+    t1d = [(1, t) for t in level_lengths(20)]                      # [20,10,5,3]
+    op_case("op_t1d_d64_f32", t1d, B=2, M=2, D=64, Q=6, P=4, dtype=torch.float32, seed=11)
+    op_case("op_t1d_d8_f64", t1d, B=2, M=3, D=8, Q=5, P=4, dtype=torch.float64, seed=12)
+    op_case("op_t1d_cap_d512_f32", t1d, B=1, M=1, D=512, Q=3, P=4, dtype=torch.float32, seed=13)
+    # the reference's own test geometry (pdvc/ops/test.py:21-28): 2-D levels (6,4),(3,2), N=1,M=2,Lq=2,L=2,P=2
+    ref2d = [(6, 4), (3, 2)]
+    for D in (2, 30, 32, 71):
+        op_case(f"op_test2d_d{D}_f64", ref2d, B=1, M=2, D=D, Q=2, P=2, dtype=torch.float64, seed=3 + D,
+                loc_lo=0.0, loc_hi=1.0, value_scale=0.01, normalise_w=True)
+    op_case("op_test2d_d64_f32", ref2d, B=1, M=2, D=64, Q=2, P=2, dtype=torch.float32, seed=3,
+            loc_lo=0.0, loc_hi=1.0, value_scale=0.01, normalise_w=True)
+    op_case("op_2d_edges_f32", [(5, 7), (3, 4), (1, 2)], B=2, M=2, D=16, Q=9, P=3, dtype=torch.float32, seed=21,
+            loc_lo=-0.4, loc_hi=1.4)
+
+
+# ------------------------------------------------------------------------------------------- module level
+def load_synth(module, seed, prefix=""):
+    shapes = {prefix + k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth_state_dict(shapes, seed)
+    module.load_state_dict({k[len(prefix):]: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return sd
+
+
+def make_module():
+    C, M, L, P = 512, 8, 4, 4
+    T = level_lengths(12)
+    S = sum(T)
+    tshapes = torch.as_tensor(T, dtype=torch.long)
+    lsi = torch.cat((tshapes.new_zeros(1), tshapes.cumsum(0)[:-1]))
+    B, Q = 2, 6
+    for refdim in (1, 2):
+        torch.manual_seed(0)
+        mod = MSDeformAttn(C, L, M, P).eval()
+        load_synth(mod, seed=100 + refdim, prefix="attn.")
+        query = torch.from_numpy(synth_array(f"mod{refdim}.query", (B, Q, C), 1))
+        inp = torch.from_numpy(synth_array(f"mod{refdim}.input", (B, S, C), 1))
+        ref = torch.from_numpy(synth_array(f"mod{refdim}.ref", (B, Q, L, refdim), 1, 0.05, 0.95))
+        if refdim == 2:
+            ref[..., 1] = ref[..., 1] * 0.5
+        mask = torch.zeros(B, S, dtype=torch.bool)
+        for l in range(L):                                          # video 1: last third of every level is padding
+            mask[1, int(lsi[l]) + (2 * T[l]) // 3: int(lsi[l]) + T[l]] = True
+        gout = torch.from_numpy(synth_array(f"mod{refdim}.gout", (B, Q, C), 1))
+        rec = dict(tshapes=tshapes, lsi=lsi, mask=mask, meta=np.array([B, Q, C, M, L, P, refdim]))
+        for pad in ("zeros", "border"):
+            RM.ms_deform_attn_core_pytorch = core_with_pad(pad)
+            try:
+                q, x = query.clone().requires_grad_(), inp.clone().requires_grad_()
+                mod.zero_grad()
+                out = mod(q, ref, x, tshapes, lsi, mask)
+                out.backward(gout)
+                rec.update({f"out_{pad}": out, f"gquery_{pad}": q.grad, f"ginput_{pad}": x.grad,
+                            f"g_off_w_{pad}": mod.sampling_offsets.weight.grad,
+                            f"g_aw_b_{pad}": mod.attention_weights.bias.grad,
+                            f"g_vproj_b_{pad}": mod.value_proj.bias.grad})
+            finally:
+                RM.ms_deform_attn_core_pytorch = _orig_core
+        save(f"module_ref{refdim}", **rec)
+
+    # captioner variant: query dim 2C, heads 1, returns unweighted samples
+    torch.manual_seed(0)
+    Qc = 3
+    cap = MSDeformAttnCap(C, L, 1, P).eval()
+    load_synth(cap, seed=200, prefix="cap.")
+    query = torch.from_numpy(synth_array("cap.query", (B, Qc, 2 * C), 1))
+    inp = torch.from_numpy(synth_array("cap.input", (B, S, C), 1))
+    ref = torch.from_numpy(synth_array("cap.ref", (B, Qc, L, 2), 1, 0.05, 0.95))
+    ref[..., 1] *= 0.5
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[1, S - 2:] = True
+    out = cap(query, ref, inp, tshapes, lsi, mask)
+    save("module_cap", tshapes=tshapes, lsi=lsi, mask=mask, out=out, meta=np.array([B, Qc, C, 1, L, P, 2]))
+
+
+# ---------------------------------------------------------------------------------------------- matcher
+def make_matcher():
+    rec = {}
+    m = HungarianMatcher(cost_class=2, cost_bbox=0, cost_giou=4, cost_alpha=0.25, cost_gamma=2, cost_cl=2.0)
+    g = torch.Generator().manual_seed(5)
+    B, Q = 3, 12
+    sizes = [3, 1, 5]
+    logits = torch.randn(B, Q, 1, generator=g)
+    boxes = torch.rand(B, Q, 2, generator=g) * 0.5 + 0.2
+    targets = [{"labels": torch.zeros(n, dtype=torch.long),
+                "boxes": torch.rand(n, 2, generator=g) * 0.5 + 0.25} for n in sizes]
+    indices, rl, C = m({"pred_logits": logits, "pred_boxes": boxes, "cl_match_mats": 0}, targets, return_C=True)
+    rec.update(logits=logits, boxes=boxes, sizes=np.array(sizes), tgt_boxes=torch.cat([t["boxes"] for t in targets]))
+    for i in range(B):
+        rec[f"C_{i}"] = C[i]
+        rec[f"idx_{i}"] = torch.stack(indices[i])
+        rec[f"rl_{i}"] = torch.stack(rl[i])
+    save("matcher_model", **rec)
+
+    # raw LSAP contract on explicit cost matrices incl. ties / near ties, float32 -> scipy
+    from scipy.optimize import linear_sum_assignment
+    rs = np.random.RandomState(7)
+    mats = {
+        "ones_5x2": np.ones((5, 2), np.float32),
+        "tie_3x2": np.array([[1, 1], [1, 1], [0, 1]], np.float32),
+        "rand_300x3": rs.rand(300, 3).astype(np.float32),
+        "rand_300x30": rs.rand(300, 30).astype(np.float32),
+        "rand_30x30": rs.rand(30, 30).astype(np.float32),
+        "rand_7x19": rs.rand(7, 19).astype(np.float32),
+        "quant_40x12": np.round(rs.rand(40, 12) * 4).astype(np.float32),          # many exact ties
+        "quant_12x40": np.round(rs.rand(12, 40) * 3).astype(np.float32),
+        "tiled_50x4x4": np.tile(rs.rand(50, 4).astype(np.float32), (1, 4)),       # the m2o tiling, matcher.py:125-126
+        "neg_20x6": (rs.rand(20, 6) - 0.5).astype(np.float32) * 10,
+        "const_rows_9x4": np.repeat(rs.rand(9, 1).astype(np.float32), 4, axis=1),
+        "single_col_6x1": rs.rand(6, 1).astype(np.float32),
+        "single_row_1x6": rs.rand(1, 6).astype(np.float32),
+    }
+    rec = {}
+    for k, c in mats.items():
+        r, cidx = linear_sum_assignment(torch.from_numpy(c))          # same call form as matcher.py:124
+        rec[f"{k}.C"] = c
+        rec[f"{k}.rows"] = np.asarray(r, np.int64)
+        rec[f"{k}.cols"] = np.asarray(cidx, np.int64)
+    import scipy
+    rec["scipy_version"] = np.array(scipy.__version__)
+    save("lsap_cases", **rec)
+
+
+# ------------------------------------------------------------------------------------ PDVC / transformer
+PDVC_OVERRIDES = dict(num_queries=8, feature_dim=64, vocab_size=40, max_caption_len=6, enable_contrastive=False,
+                      device="cpu")
+
+
+def build_pdvc():
+    import opts
+    import pdvc.pdvc as P
+    cwd = os.getcwd()
+    os.makedirs("/tmp/gvl_golden_scratch", exist_ok=True)
+    os.chdir("/tmp/gvl_golden_scratch")                              # parse_opts writes ./.tmp/opts.json
+    argv = sys.argv
+    sys.argv = ["x", "--cfg_path", os.path.join(_refimport.REF, "cfgs/anet_tsp_ssvg.yml")]
+    try:
+        opt = opts.parse_opts()
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    for k, v in PDVC_OVERRIDES.items():
+        setattr(opt, k, v)
+    torch.manual_seed(0)
+    model, criterion, cc, post = P.build(opt)
+    return opt, model.eval(), criterion, cc
+
+
+def synth_dt(B, T, feat, valid, n_gt, seed=1):
+    vt = torch.from_numpy(synth_array("dt.video_tensor", (B, T, feat), seed))
+    vmask = torch.zeros(B, T, dtype=torch.bool)
+    for i, v in enumerate(valid):
+        vmask[i, :v] = True
+        vt[i, v:] = 0
+    vlen = torch.tensor([[float(v), 60.0 + 30.0 * i, float(n)] for i, (v, n) in enumerate(zip(valid, n_gt))])
+    targets = []
+    for i, n in enumerate(n_gt):
+        c = torch.from_numpy(synth_array(f"dt.gt_c{i}", (n,), seed, 0.25, 0.75))
+        l_ = torch.from_numpy(synth_array(f"dt.gt_l{i}", (n,), seed, 0.1, 0.4))
+        targets.append({"boxes": torch.stack([c, l_], -1), "labels": torch.zeros(n, dtype=torch.long)})
+    return {"video_tensor": vt, "video_mask": vmask, "video_length": vlen,
+            "cap_raw": [["x"] * n for n in n_gt], "video_target": targets}
+
+
+def make_pdvc():
+    opt, model, criterion, cc = build_pdvc()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=300)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 2, 24
+    dt = synth_dt(B, T, opt.feature_dim, valid=[24, 17], n_gt=[3, 2])
+    rec = dict(meta_T=np.array(T), valid=np.array([24, 17]), n_gt=np.array([3, 2]),
+               param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+    for tag in ("cuda", "cpu"):
+        ctx = cuda_semantics() if tag == "cuda" else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            with torch.no_grad():
+                # stage-wise, following PDVC.forward (pdvc.py:250-275)
+                vf, mask, dur = dt["video_tensor"], ~dt["video_mask"], dt["video_length"][:, 1]
+                srcs, masks, pos = model.base_encoder(vf, mask, dur)
+                enc_in = model.transformer.prepare_encoder_inputs(srcs, masks, pos)
+                src_flatten, tshapes, lsi, vr, lvl_pos, mflat = enc_in
+                memory = model.transformer.forward_encoder(*enc_in)
+                qe = model.query_embed.weight
+                pmask = torch.ones(B, qe.shape[0]).bool()
+                init_ref, tgt, refp, qpos = model.transformer.prepare_decoder_input_query(memory, qe)
+                hs, inter = model.transformer.forward_decoder(tgt, refp, memory, tshapes, lsi, vr, qpos, mflat, pmask,
+                                                              False)
+                out, loss = model(dt, criterion, cc, "queries", eval_mode=True)
+            rec.update({f"{tag}.src_flatten": src_flatten, f"{tag}.lvl_pos": lvl_pos, f"{tag}.valid_ratios": vr,
+                        f"{tag}.mask_flatten": mflat, f"{tag}.memory": memory, f"{tag}.hs": hs,
+                        f"{tag}.inter_references": inter, f"{tag}.init_reference": init_ref,
+                        f"{tag}.pred_logits": out["pred_logits"], f"{tag}.pred_boxes": out["pred_boxes"],
+                        f"{tag}.pred_count": out["pred_count"], f"{tag}.seq": out["seq"],
+                        f"{tag}.cap_prob_eval": out["caption_probs"]["cap_prob_eval"],
+                        f"{tag}.aux_pred_logits": out["aux_outputs"][0]["pred_logits"],
+                        f"{tag}.aux_pred_boxes": out["aux_outputs"][0]["pred_boxes"]})
+            for i, (a, b) in enumerate(out["matched_indices"][0]):
+                rec[f"{tag}.match_{i}"] = torch.stack([a, b])
+            for i, (a, b) in enumerate(out["matched_indices"][1]):
+                rec[f"{tag}.rl_match_{i}"] = torch.stack([a, b])
+            for k, v in loss.items():
+                rec[f"{tag}.loss.{k}"] = torch.as_tensor(v)
+        finally:
+            if ctx:
+                ctx.__exit__()
+    rec["tshapes"], rec["lsi"] = tshapes, lsi
+    save("pdvc_eval", **rec)
+
+    # one captioner step in isolation (LSTM_DSA.py:120-124,241-271) on the cuda-semantics memory
+    cap = model.caption_head[-1]
+    with torch.no_grad():
+        Q = qe.shape[0]
+        hs_last = hs[-1]
+        ref_in = inter[0][:, :, None] * torch.stack([vr] * 2, -1)[:, None]
+        g = torch.Generator().manual_seed(9)
+        h0 = torch.randn(1, B * Q, 512, generator=g) * 0.3
+        c0 = torch.randn(1, B * Q, 512, generator=g) * 0.3
+        it = torch.randint(0, opt.vocab_size + 1, (B * Q,), generator=g)
+        logp, (h1, c1) = cap.get_logprobs_state(it, (h0, c0), hs_last, ref_in, memory, tshapes, lsi, mflat)
+    save("captioner_step", it=it, h0=h0[0], c0=c0[0], hs=hs_last, ref_in=ref_in, memory=memory, mask=mflat,
+         tshapes=tshapes, lsi=lsi, logp=logp, h1=h1[0], c1=c1[0])
+
+
+if __name__ == "__main__":
+    make_op()
+    make_module()
+    make_matcher()
+    if FULL:
+        make_pdvc()

@@ -1,0 +1,148 @@
+"""CPU: pin the oracle (oracle/msda_ref.c + oracle/torch_ref.py) against the golden vectors that
+tests/golden/make_golden.py produced by importing the reference.  No GPU, no reference access."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load, t, module_state, pdvc_state, pdvc_dt, maxerr
+from oracle import msda_oracle as O
+from oracle import torch_ref as R
+
+OP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "op_*.npz")))
+
+
+@pytest.mark.parametrize("case", OP_CASES)
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_c_oracle_op_matches_reference(case, pad):
+    f = load(case)
+    tol = 1e-11 if f["value"].dtype == np.float64 else 2e-5
+    scale = max(1.0, float(np.abs(f[f"gloc_{pad}"]).max()))
+    out = O.msda_forward(f["value"], f["shapes"], f["lsi"], f["loc"], f["aw"], pad)
+    assert maxerr(out, f[f"out_{pad}"]) <= tol
+    gv, gl, gw = O.msda_backward(f["value"], f["shapes"], f["lsi"], f["loc"], f["aw"], f["gout"], pad)
+    assert maxerr(gv, f[f"gvalue_{pad}"]) <= tol
+    assert maxerr(gl, f[f"gloc_{pad}"]) <= tol * scale
+    assert maxerr(gw, f[f"gaw_{pad}"]) <= tol * scale
+
+
+@pytest.mark.parametrize("case", OP_CASES)
+def test_c_oracle_sample_matches_reference(case):
+    f = load(case)
+    tol = 1e-11 if f["value"].dtype == np.float64 else 2e-5
+    s = O.msda_sample(f["value"], f["shapes"], f["lsi"], f["loc"], "border")
+    assert maxerr(s, f["sample_border"]) <= tol
+
+
+@pytest.mark.parametrize("case", OP_CASES)
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_torch_oracle_core_matches_reference(case, pad):
+    f = load(case)
+    tol = 1e-11 if f["value"].dtype == np.float64 else 2e-5
+    out = R.msda_core(t(f["value"]), t(f["shapes"]), t(f["loc"]), t(f["aw"]), pad)
+    assert maxerr(out, f[f"out_{pad}"]) <= tol
+
+
+def test_grad_loc_y_identity_h1():
+    """H=1, y=0.5: zeros-mode grad_loc_y = -w * grad_w; border-mode grad_loc_y = 0."""
+    f = load("op_t1d_d8_f64")
+    assert maxerr(f["gloc_zeros"][..., 1], -f["aw"] * f["gaw_zeros"]) < 1e-11
+    assert float(np.abs(f["gloc_border"][..., 1]).max()) == 0.0
+
+
+@pytest.mark.parametrize("refdim", [1, 2])
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_torch_oracle_module(refdim, pad):
+    from helpers import synth_array
+    f = load(f"module_ref{refdim}")
+    B, Q, C, M, L, P, _ = [int(v) for v in f["meta"]]
+    S = int(f["tshapes"].sum())
+    sd = module_state("attn.", seed=100 + refdim)
+    query = t(synth_array(f"mod{refdim}.query", (B, Q, C), 1)).requires_grad_()
+    inp = t(synth_array(f"mod{refdim}.input", (B, S, C), 1)).requires_grad_()
+    ref = t(synth_array(f"mod{refdim}.ref", (B, Q, L, refdim), 1, 0.05, 0.95))
+    if refdim == 2:
+        ref[..., 1] = ref[..., 1] * 0.5
+    gout = t(synth_array(f"mod{refdim}.gout", (B, Q, C), 1))
+    out = R.msda_module(sd, "attn.", query, ref, inp, t(f["tshapes"]), t(f["mask"]), M, L, P, pad_mode=pad)
+    assert maxerr(out, f[f"out_{pad}"]) < 5e-5
+    out.backward(gout)
+    assert maxerr(query.grad, f[f"gquery_{pad}"]) < 5e-4
+    assert maxerr(inp.grad, f[f"ginput_{pad}"]) < 5e-4
+
+
+def test_torch_oracle_cap_module():
+    from helpers import synth_array
+    f = load("module_cap")
+    B, Q, C, M, L, P, _ = [int(v) for v in f["meta"]]
+    S = int(f["tshapes"].sum())
+    sd = module_state("cap.", M=1, qdim=2 * C, seed=200)
+    query = t(synth_array("cap.query", (B, Q, 2 * C), 1))
+    inp = t(synth_array("cap.input", (B, S, C), 1))
+    ref = t(synth_array("cap.ref", (B, Q, L, 2), 1, 0.05, 0.95))
+    ref[..., 1] *= 0.5
+    out = R.msda_module(sd, "cap.", query, ref, inp, t(f["tshapes"]), t(f["mask"]), 1, L, P, cap=True)
+    assert maxerr(out, f["out"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag,pad", [("cuda", "zeros"), ("cpu", "border")])
+def test_torch_oracle_pdvc_eval(tag, pad):
+    f = load("pdvc_eval")
+    sd = pdvc_state(f)
+    dt = pdvc_dt(f)
+    with torch.no_grad():
+        out = R.pdvc_eval_forward(sd, dt, pad_mode=pad, max_caption_len=6)
+    assert maxerr(out["memory"], f[f"{tag}.memory"]) < 2e-4
+    assert maxerr(out["hs"], f[f"{tag}.hs"]) < 5e-4
+    assert maxerr(out["inter_references"], f[f"{tag}.inter_references"]) < 1e-4
+    assert maxerr(out["pred_logits"], f[f"{tag}.pred_logits"]) < 5e-4
+    assert maxerr(out["pred_boxes"], f[f"{tag}.pred_boxes"]) < 1e-4
+    assert maxerr(out["pred_count"], f[f"{tag}.pred_count"]) < 5e-4
+    assert maxerr(out["aux_boxes"][0], f[f"{tag}.aux_pred_boxes"]) < 1e-4
+    assert torch.equal(out["seq"], t(f[f"{tag}.seq"]))
+    assert maxerr(out["cap_prob_eval"], f[f"{tag}.cap_prob_eval"]) < 5e-4
+    # matcher index path: bit-exact
+    tg = dt["video_target"]
+    C = R.matcher_cost(out["pred_logits"], out["pred_boxes"], torch.cat([x["labels"] for x in tg]),
+                       torch.cat([x["boxes"] for x in tg]))
+    idx, rl = R.hungarian(C, [len(x["boxes"]) for x in tg])
+    for i in range(len(tg)):
+        assert torch.equal(torch.stack(idx[i]), t(f[f"{tag}.match_{i}"]))
+        assert torch.equal(torch.stack(rl[i]), t(f[f"{tag}.rl_match_{i}"]))
+
+
+def test_torch_oracle_captioner_step():
+    f = load("captioner_step")
+    sd = pdvc_state(load("pdvc_eval"))
+    with torch.no_grad():
+        logp, (h1, c1) = R.captioner_step(sd, "caption_head.1.", t(f["it"]), (t(f["h0"]), t(f["c0"])), t(f["hs"]),
+                                          t(f["ref_in"]), t(f["memory"]), t(f["tshapes"]), t(f["mask"]))
+    assert maxerr(logp, f["logp"]) < 2e-4
+    assert maxerr(h1, f["h1"]) < 5e-5
+    assert maxerr(c1, f["c1"]) < 5e-5
+
+
+def test_torch_oracle_matcher_model_fixture():
+    f = load("matcher_model")
+    sizes = [int(s) for s in f["sizes"]]
+    C = R.matcher_cost(t(f["logits"]), t(f["boxes"]), torch.zeros(sum(sizes), dtype=torch.long), t(f["tgt_boxes"]),
+                       w_cl=2.0, cl_match_mats=0)
+    for i, c in enumerate(C.split(sizes, -1)):
+        assert torch.equal(c[i], t(f[f"C_{i}"]))          # same fp32 op sequence -> bit-identical cost
+    idx, rl = R.hungarian(C, sizes)
+    for i in range(len(sizes)):
+        assert torch.equal(torch.stack(idx[i]), t(f[f"idx_{i}"]))
+        assert torch.equal(torch.stack(rl[i]), t(f[f"rl_{i}"]))
+
+
+def test_scipy_lsap_contract():
+    """the golden (cost -> indices) pairs were produced with scipy 1.15.3; the oracle solver must reproduce them"""
+    from scipy.optimize import linear_sum_assignment
+    f = load("lsap_cases")
+    names = sorted({k.split(".")[0] for k in f if "." in k})
+    assert len(names) >= 10
+    for n in names:
+        r, c = linear_sum_assignment(f[f"{n}.C"])
+        assert np.array_equal(r, f[f"{n}.rows"]) and np.array_equal(c, f[f"{n}.cols"]), n
