@@ -1,0 +1,66 @@
+"""ctypes binding of libgvl_msda.so (C ABI: include/gvl_msda.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
+_lock = threading.Lock()
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_I64 = ctypes.c_int64
+_SZ = ctypes.c_size_t
+
+# name -> (restype, argtypes); also the authoritative list of exported symbols for tests/test_abi.py
+SIGNATURES = {
+    "gvl_msda_abi_version": (_I, []),
+    "gvl_last_error": (ctypes.c_char_p, []),
+    "gvl_msda_set_impl": (None, [_I]),
+    "gvl_msda_last_impl": (_I, []),
+    "gvl_msda_forward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
+    "gvl_msda_forward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
+    "gvl_msda_sample_f32": (_I, [_P] * 4 + [_I] * 8 + [_P, _P]),
+    "gvl_msda_sample_f64": (_I, [_P] * 4 + [_I] * 8 + [_P, _P]),
+    "gvl_msda_backward_workspace_bytes": (_SZ, [_I] * 8),
+    "gvl_msda_backward_f32": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gvl_msda_backward_f64": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
+    "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),
+    "gvl_hungarian_batch_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I]),
+}
+
+
+class GvlLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises GvlLibraryError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise GvlLibraryError(
+                        f"{LIB_PATH} is missing: build it with `python -m gvl_amd.build` "
+                        "(hipcc --offload-arch=gfx950).  gvl_amd has no CPU / PyTorch fallback.")
+                try:
+                    handle = ctypes.CDLL(LIB_PATH)
+                except OSError as e:  # pragma: no cover
+                    raise GvlLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                if handle.gvl_msda_abi_version() != 1:
+                    raise GvlLibraryError("libgvl_msda.so ABI version mismatch; rebuild")
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gvl_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

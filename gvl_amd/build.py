@@ -1,0 +1,45 @@
+"""Build libgvl_msda.so (HIP, gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and `python -m gvl_amd.build`."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", "gvl_msda.hip"), os.path.join(HERE, "csrc", "gvl_lsap.cpp")]
+OUT = os.path.join(HERE, "libgvl_msda.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-pthread",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    deps = [s for s in SRC if os.path.exists(s)] + [os.path.join(ROOT, "include", "gvl_msda.h"), __file__]
+    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+
+
+def build(force=False, verbose=False, save_temps=None):
+    if not force and not needs_build():
+        return OUT
+    srcs = [s for s in SRC if os.path.exists(s)]
+    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", OUT] + srcs
+    if save_temps:
+        os.makedirs(save_temps, exist_ok=True)
+        cmd += [f"-save-temps={save_temps}", "-Rpass-analysis=kernel-resource-usage"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=save_temps or ROOT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True,
+                save_temps=os.path.join(ROOT, "build", "temps") if "--save-temps" in sys.argv else None))

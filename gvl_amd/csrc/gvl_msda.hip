@@ -1,0 +1,717 @@
+// gvl_msda.hip -- multi-scale deformable attention for GVL on MI355X (gfx950, CDNA4).
+//
+// Written for wave64 / LDS / DPP directly; no CUDA compatibility layer.  Two kernel families:
+//
+//   generic   any D, any HxW levels, fp32 / fp64, zeros / border padding.  Forward: one lane per output
+//             scalar.  Backward: one wavefront per (b,q,m), lanes stride the channels, wave reduction of
+//             grad_loc / grad_attn with cross-lane shuffles, grad_value through hardware float atomics.
+//
+//   t1d_d64   GVL's case: temporal levels (H = 1), D = 64, fp32, L*P <= 16.  One workgroup owns one
+//             (batch, head) value slab [S][64] staged in LDS and a chunk of the queries.  A 16-lane DPP row
+//             owns one (b,q,m): lane j holds channels 4j..4j+3 (float4) AND computes the interpolation
+//             coefficients of sample j, which are broadcast inside the row with DPP row_newbcast.  Rows are
+//             256 B, so one ds_read_b128 per lane reads a whole row per DPP row, bank-conflict free.
+//             The backward keeps a private grad_value slab in LDS (ds_add_f32) and flushes it once per
+//             workgroup (plain stores; partial slabs are summed by a second tiny kernel when a slab is
+//             shared by several workgroups), so it issues no global atomics and is bitwise reproducible.
+//
+// Arithmetic follows /root/reference/pdvc/ops/src/cuda/ms_deform_im2col_cuda.cuh (cited per function) for
+// pad_mode = zeros and ATen's grid_sampler(border, align_corners=False) for pad_mode = border.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gvl_msda.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local int g_last_impl = 0;
+int g_impl = -1;  // -1 = read the environment on first use
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int impl_mode() {
+  if (g_impl < 0) {
+    const char *e = getenv("GVL_MSDA_IMPL");
+    g_impl = 0;
+    if (e && !strcmp(e, "generic")) g_impl = 1;
+    if (e && !strcmp(e, "fast")) g_impl = 2;
+  }
+  return g_impl;
+}
+
+int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+constexpr int kPadZeros = GVL_PAD_ZEROS;
+constexpr int kPadBorder = GVL_PAD_BORDER;
+
+// ------------------------------------------------------------------------------------------------------
+// shared scalar math
+// ------------------------------------------------------------------------------------------------------
+__device__ inline float gfloor(float x) { return floorf(x); }
+__device__ inline double gfloor(double x) { return floor(x); }
+
+// Pixel coordinate of a normalised location and d(pixel)/d(loc).
+// zeros : cuh:286-287 (loc*size - 0.5).   border: grid_sampler unnormalise + clip_coordinates_set_grad.
+template <typename T>
+__device__ inline T pixel_coord(T loc, int size, int pad, T &dmul) {
+  if (pad == kPadZeros) {
+    dmul = (T)size;
+    return loc * (T)size - (T)0.5;
+  }
+  T g = (T)2 * loc - (T)1;
+  T x = ((g + (T)1) * (T)size - (T)1) / (T)2;
+  T mx = (T)(size - 1);
+  if (!(x > (T)0)) { dmul = (T)0; return (T)0; }   // also catches NaN
+  if (x >= mx) { dmul = (T)0; return mx; }
+  dmul = (T)size;
+  return x;
+}
+
+// Four bilinear taps (cuh:39-82).  Row indices are -1 where the tap is outside the level.
+template <typename T>
+struct Taps {
+  int i00, i01, i10, i11;
+  T w00, w01, w10, w11, lh, lw;
+  bool valid;
+};
+
+template <typename T>
+__device__ inline Taps<T> make_taps(T h, T w, int H, int W, int pad) {
+  Taps<T> t;
+  t.i00 = t.i01 = t.i10 = t.i11 = -1;
+  t.w00 = t.w01 = t.w10 = t.w11 = t.lh = t.lw = (T)0;
+  t.valid = (pad == kPadBorder) || (h > (T)-1 && w > (T)-1 && h < (T)H && w < (T)W);   // cuh:289
+  if (!t.valid) return t;
+  int hl = (int)gfloor(h), wl = (int)gfloor(w);
+  int hh_ = hl + 1, wh = wl + 1;
+  T lh = h - (T)hl, lw = w - (T)wl, hh = (T)1 - lh, hw = (T)1 - lw;
+  t.lh = lh; t.lw = lw;
+  t.w00 = hh * hw; t.w01 = hh * lw; t.w10 = lh * hw; t.w11 = lh * lw;
+  bool hl_ok = hl >= 0 && hl <= H - 1, hh_ok = hh_ >= 0 && hh_ <= H - 1;
+  bool wl_ok = wl >= 0 && wl <= W - 1, wh_ok = wh >= 0 && wh <= W - 1;
+  if (hl_ok && wl_ok) t.i00 = hl * W + wl;
+  if (hl_ok && wh_ok) t.i01 = hl * W + wh;
+  if (hh_ok && wl_ok) t.i10 = hh_ * W + wl;
+  if (hh_ok && wh_ok) t.i11 = hh_ * W + wh;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// generic forward: one lane per (b,q,m,d); d fastest so a wave reads contiguous channels of a value row.
+// SAMPLE=false: out (B,Q,M*D) (cuh:238-300).  SAMPLE=true: unweighted samples (B*M, D, Q, L, P) (func.py:56-68).
+// ------------------------------------------------------------------------------------------------------
+template <typename T, bool SAMPLE>
+__global__ void __launch_bounds__(256) k_fwd_generic(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lsi, const T *__restrict__ loc,
+                                                     const T *__restrict__ attn, int B, int S, int M, int D, int L,
+                                                     int Q, int P, int pad, T *__restrict__ out) {
+  const int64_t n = (int64_t)B * Q * M * D;
+  const int64_t row = (int64_t)M * D;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % D);
+    const int64_t tup = idx / D;
+    const int m = (int)(tup % M);
+    const int64_t bq = tup / M;
+    const int q = (int)(bq % Q);
+    const int b = (int)(bq / Q);
+    const int64_t wb = tup * L * P;
+    T acc = (T)0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const T *vl = value + ((int64_t)b * S + lsi[l]) * row + (int64_t)m * D + d;
+      for (int p = 0; p < P; ++p) {
+        const int64_t si = wb + l * P + p;
+        T dm;
+        const T w_im = pixel_coord(loc[si * 2], W, pad, dm);
+        const T h_im = pixel_coord(loc[si * 2 + 1], H, pad, dm);
+        const Taps<T> t = make_taps(h_im, w_im, H, W, pad);
+        T val = (T)0;
+        if (t.valid) {
+          const T v1 = t.i00 >= 0 ? vl[(int64_t)t.i00 * row] : (T)0;
+          const T v2 = t.i01 >= 0 ? vl[(int64_t)t.i01 * row] : (T)0;
+          const T v3 = t.i10 >= 0 ? vl[(int64_t)t.i10 * row] : (T)0;
+          const T v4 = t.i11 >= 0 ? vl[(int64_t)t.i11 * row] : (T)0;
+          val = t.w00 * v1 + t.w01 * v2 + t.w10 * v3 + t.w11 * v4;   // cuh:82
+        }
+        if (SAMPLE)
+          out[(((((int64_t)b * M + m) * D + d) * Q + q) * L + l) * P + p] = val;
+        else
+          acc += val * attn[si];                                       // cuh:291
+      }
+    }
+    if (!SAMPLE) out[idx] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// generic backward: one wavefront per (b,q,m) (cuh:407-511 uses a D-thread block + shared-memory tree; with
+// wave64 the reduction is a cross-lane butterfly and needs no LDS or barrier).
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ inline T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_bwd_generic(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lsi, const T *__restrict__ loc,
+                                                     const T *__restrict__ attn, const T *__restrict__ gout, int B,
+                                                     int S, int M, int D, int L, int Q, int P, int pad,
+                                                     T *__restrict__ gvalue, T *__restrict__ gloc,
+                                                     T *__restrict__ gattn) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int64_t ntup = (int64_t)B * Q * M;
+  const int64_t row = (int64_t)M * D;
+  for (int64_t tup = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); tup < ntup; tup += (int64_t)gridDim.x * wpb) {
+    const int m = (int)(tup % M);
+    const int64_t bq = tup / M;
+    const int b = (int)(bq / Q);
+    const T *go = gout + tup * D;
+    const int64_t wb = tup * L * P;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const int64_t voff = ((int64_t)b * S + lsi[l]) * row + (int64_t)m * D;
+      const T *vl = value + voff;
+      T *gvl = gvalue + voff;
+      for (int p = 0; p < P; ++p) {
+        const int64_t si = wb + l * P + p;
+        T dmx, dmy;
+        const T w_im = pixel_coord(loc[si * 2], W, pad, dmx);
+        const T h_im = pixel_coord(loc[si * 2 + 1], H, pad, dmy);
+        const T wgt = attn[si];
+        const Taps<T> t = make_taps(h_im, w_im, H, W, pad);
+        T acc_w = (T)0, acc_x = (T)0, acc_y = (T)0;
+        if (t.valid) {
+          const T hh = (T)1 - t.lh, hw = (T)1 - t.lw;
+          for (int d = lane; d < D; d += 64) {
+            const T tg = go[d], tgv = tg * wgt;                       // cuh:111
+            T gh = (T)0, gw = (T)0, v1 = (T)0, v2 = (T)0, v3 = (T)0, v4 = (T)0;
+            if (t.i00 >= 0) { v1 = vl[(int64_t)t.i00 * row + d]; gh -= hw * v1; gw -= hh * v1;
+                              atomicAdd(gvl + (int64_t)t.i00 * row + d, t.w00 * tgv); }
+            if (t.i01 >= 0) { v2 = vl[(int64_t)t.i01 * row + d]; gh -= t.lw * v2; gw += hh * v2;
+                              atomicAdd(gvl + (int64_t)t.i01 * row + d, t.w01 * tgv); }
+            if (t.i10 >= 0) { v3 = vl[(int64_t)t.i10 * row + d]; gh += hw * v3; gw -= t.lh * v3;
+                              atomicAdd(gvl + (int64_t)t.i10 * row + d, t.w10 * tgv); }
+            if (t.i11 >= 0) { v4 = vl[(int64_t)t.i11 * row + d]; gh += t.lw * v4; gw += t.lh * v4;
+                              atomicAdd(gvl + (int64_t)t.i11 * row + d, t.w11 * tgv); }
+            const T val = t.w00 * v1 + t.w01 * v2 + t.w10 * v3 + t.w11 * v4;
+            acc_w += tg * val;                                         // cuh:156-157
+            acc_x += dmx * gw * tgv;                                   // cuh:158
+            acc_y += dmy * gh * tgv;                                   // cuh:159
+          }
+        }
+        acc_w = wave_sum(acc_w);
+        acc_x = wave_sum(acc_x);
+        acc_y = wave_sum(acc_y);
+        if (lane == 0) {
+          gattn[si] = acc_w;
+          gloc[si * 2] = acc_x;
+          gloc[si * 2 + 1] = acc_y;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DPP helpers (a DPP "row" = 16 lanes = one (b,q,m) in the t1d_d64 kernels)
+// ------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ inline int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ inline float dpp_f(float v) {
+  return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v)));
+}
+// broadcast lane SRC of every 16-lane row to the whole row (row_newbcast, gfx90a+)
+template <int SRC>
+__device__ inline int row_bcast_i(int v) { return dpp_i<0x150 + SRC>(v); }
+template <int SRC>
+__device__ inline float row_bcast_f(float v) { return dpp_f<0x150 + SRC>(v); }
+// all-reduce (sum) inside every 16-lane row
+__device__ inline float row_allsum(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x124>(v);   // row_ror:4
+  v += dpp_f<0x128>(v);   // row_ror:8
+  return v;
+}
+
+// Interpolation coefficients of ONE temporal sample against the LDS slab, expressed on the row pair (r, r+1):
+//   sample = c_lo * V[r] + c_hi * V[r+1]           (c's already include the vertical weight wy, not attn)
+//   d sample / d loc_x = dx_lo * V[r] + dx_hi * V[r+1]
+//   d sample / d loc_y = dy * (horizontal interpolation)   (H = 1: cuh:124-159 collapses to +-1)
+// r is clamped so that both rows are inside the slab allocation (S+1 rows) for ANY input, incl. NaN.
+struct Coef1D {
+  int r;        // level-local row
+  float c_lo, c_hi, dx_lo, dx_hi, wy, dy;
+};
+
+template <int PAD>
+__device__ inline Coef1D coef_1d(float lx, float ly, int T) {
+  Coef1D c;
+  c.r = 0; c.c_lo = c.c_hi = c.dx_lo = c.dx_hi = c.wy = c.dy = 0.f;
+  float dmx, dmy;
+  const float x = pixel_coord<float>(lx, T, PAD, dmx);
+  const float y = pixel_coord<float>(ly, 1, PAD, dmy);
+  bool valid = true;
+  if (PAD == kPadZeros) valid = (y > -1.f && x > -1.f && y < 1.f && x < (float)T);   // cuh:289 with H = 1
+  if (!valid) return c;
+  // vertical: H = 1 -> only row 0 exists.  y in (-1,1): hl = -1 -> weight lh on row 0, else weight 1-lh.
+  const float yf = floorf(y);
+  const float lh = y - yf;
+  const bool low_is_row0 = (yf == 0.f);
+  c.wy = low_is_row0 ? (1.f - lh) : lh;
+  c.dy = dmy * (low_is_row0 ? -1.f : 1.f);
+  // horizontal
+  const float xf = floorf(x);
+  const int x0 = (int)xf;
+  const float a = x - xf;
+  const float t0 = (x0 >= 0 && x0 <= T - 1) ? (1.f - a) : 0.f;      // weight of tap x0      (cuh:57-61)
+  const float t1 = (x0 + 1 >= 0 && x0 + 1 <= T - 1) ? a : 0.f;      // weight of tap x0 + 1  (cuh:62-67)
+  const float s0 = (x0 >= 0 && x0 <= T - 1) ? -1.f : 0.f;           // d/dx of the two taps  (cuh:125,134)
+  const float s1 = (x0 + 1 >= 0 && x0 + 1 <= T - 1) ? 1.f : 0.f;
+  int r = x0;
+  const int rmax = T >= 2 ? T - 2 : 0;
+  r = r < 0 ? 0 : (r > rmax ? rmax : r);
+  c.r = r;
+  const bool lo0 = (x0 == r), lo1 = (x0 + 1 == r), hi0 = (x0 == r + 1), hi1 = (x0 + 1 == r + 1);
+  c.c_lo = (lo0 ? t0 : 0.f) + (lo1 ? t1 : 0.f);
+  c.c_hi = (hi0 ? t0 : 0.f) + (hi1 ? t1 : 0.f);
+  c.dx_lo = dmx * ((lo0 ? s0 : 0.f) + (lo1 ? s1 : 0.f));
+  c.dx_hi = dmx * ((hi0 ? s0 : 0.f) + (hi1 ? s1 : 0.f));
+  return c;
+}
+
+__device__ inline float4 fma4(float a, float4 v, float4 acc) {
+  acc.x = fmaf(a, v.x, acc.x); acc.y = fmaf(a, v.y, acc.y);
+  acc.z = fmaf(a, v.z, acc.z); acc.w = fmaf(a, v.w, acc.w);
+  return acc;
+}
+__device__ inline float dot4(float4 a, float4 b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+// stage the (b,m) value slab [S][64] into LDS as float4[S*16]; row S is zero padding
+__device__ inline void stage_slab(float4 *slab4, const float *value, int b, int m, int S, int M) {
+  const float4 *src = reinterpret_cast<const float4 *>(value) + ((int64_t)b * S * M + m) * 16;
+  for (int i = threadIdx.x; i < S * 16; i += blockDim.x) {
+    const int s = i >> 4, j = i & 15;
+    slab4[i] = src[(int64_t)s * M * 16 + j];
+  }
+  if (threadIdx.x < 16) slab4[S * 16 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
+// ------------------------------------------------------------------------------------------------------
+template <int PAD>
+__global__ void __launch_bounds__(256) k_fwd_t1d_d64(const float *__restrict__ value,
+                                                     const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
+                                                     const float *__restrict__ attn, int B, int S, int M, int L, int Q,
+                                                     int P, int nchunk, float *__restrict__ out) {
+  extern __shared__ float4 slab4[];
+  const int BM = B * M;
+  const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
+  const int b = bm / M, m = bm % M;
+  stage_slab(slab4, value, b, m, S, M);
+
+  const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int LP = L * P;
+  int Tl = 1, st = 0;
+  if (j < LP) {
+    const int l = j / P;
+    Tl = (int)shapes[2 * l + 1];
+    st = (int)lsi[l];
+  }
+  const int qper = (Q + nchunk - 1) / nchunk;
+  const int q0 = chunk * qper;
+  const int q1 = min(Q, q0 + qper);
+  __syncthreads();
+
+  for (int qb = q0 + wave * 4; qb < q1; qb += nw * 4) {
+    const int q = qb + tq;
+    const bool act = q < q1;
+    const int qq = act ? q : q1 - 1;
+    const int64_t tb = (((int64_t)b * Q + qq) * M + m) * LP;
+    int roff = 0;
+    float clo = 0.f, chi = 0.f;
+    if (j < LP) {
+      const float2 xy = reinterpret_cast<const float2 *>(loc)[tb + j];
+      const float w = attn[tb + j];
+      const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
+      roff = (st + c.r) * 16;
+      const float ww = w * c.wy;
+      clo = c.c_lo * ww;
+      chi = c.c_hi * ww;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#define GVL_FWD_STEP(SI)                                   \
+  if (SI < LP) {                                           \
+    const int ro = row_bcast_i<SI>(roff) + j;              \
+    const float a = row_bcast_f<SI>(clo);                  \
+    const float c = row_bcast_f<SI>(chi);                  \
+    const float4 v0 = slab4[ro];                           \
+    const float4 v1 = slab4[ro + 16];                      \
+    acc = fma4(a, v0, acc);                                \
+    acc = fma4(c, v1, acc);                                \
+  }
+    GVL_FWD_STEP(0) GVL_FWD_STEP(1) GVL_FWD_STEP(2) GVL_FWD_STEP(3)
+    GVL_FWD_STEP(4) GVL_FWD_STEP(5) GVL_FWD_STEP(6) GVL_FWD_STEP(7)
+    GVL_FWD_STEP(8) GVL_FWD_STEP(9) GVL_FWD_STEP(10) GVL_FWD_STEP(11)
+    GVL_FWD_STEP(12) GVL_FWD_STEP(13) GVL_FWD_STEP(14) GVL_FWD_STEP(15)
+#undef GVL_FWD_STEP
+    if (act) reinterpret_cast<float4 *>(out)[(((int64_t)b * Q + q) * M + m) * 16 + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// t1d_d64 backward.  LDS: value slab (S+1 rows) + private grad_value slab (S+1 rows, channel c = 4j+k stored at
+// column k*16 + j so that the four ds_add_f32 of a DPP row hit 16 distinct banks; rows of a wave stagger k).
+// ------------------------------------------------------------------------------------------------------
+template <int PAD>
+__global__ void __launch_bounds__(512) k_bwd_t1d_d64(const float *__restrict__ value,
+                                                     const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
+                                                     const float *__restrict__ attn, const float *__restrict__ gout,
+                                                     int B, int S, int M, int L, int Q, int P, int nchunk,
+                                                     float *__restrict__ gvalue_part, float *__restrict__ gloc,
+                                                     float *__restrict__ gattn) {
+  extern __shared__ float4 slab4[];
+  float *gslab = reinterpret_cast<float *>(slab4 + (S + 1) * 16);
+  const int BM = B * M;
+  const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
+  const int b = bm / M, m = bm % M;
+  stage_slab(slab4, value, b, m, S, M);
+  for (int i = threadIdx.x; i < (S + 1) * 64; i += blockDim.x) gslab[i] = 0.f;
+
+  const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int LP = L * P;
+  int Tl = 1, st = 0;
+  if (j < LP) {
+    const int l = j / P;
+    Tl = (int)shapes[2 * l + 1];
+    st = (int)lsi[l];
+  }
+  const int qper = (Q + nchunk - 1) / nchunk;
+  const int q0 = chunk * qper;
+  const int q1 = min(Q, q0 + qper);
+  // staggered column blocks of this DPP row: step k0 touches column block (k0 + tq) & 3
+  const int col0 = (((0 + tq) & 3) << 4) + j, col1 = (((1 + tq) & 3) << 4) + j;
+  const int col2 = (((2 + tq) & 3) << 4) + j, col3 = (((3 + tq) & 3) << 4) + j;
+  __syncthreads();
+
+  for (int qb = q0 + wave * 4; qb < q1; qb += nw * 4) {
+    const int q = qb + tq;
+    const bool act = q < q1;
+    const int qq = act ? q : q1 - 1;
+    const int64_t tup = ((int64_t)b * Q + qq) * M + m;
+    const int64_t tb = tup * LP;
+    int roff = 0;
+    float clo = 0.f, chi = 0.f, dxlo = 0.f, dxhi = 0.f, dylo = 0.f, dyhi = 0.f, w = 0.f;
+    if (j < LP) {
+      const float2 xy = reinterpret_cast<const float2 *>(loc)[tb + j];
+      w = attn[tb + j];
+      const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
+      roff = st + c.r;
+      clo = c.c_lo * c.wy;                 // sample      = clo * V[r] + chi * V[r+1]
+      chi = c.c_hi * c.wy;
+      dxlo = c.dx_lo * c.wy * w;           // d out/d x   = dxlo * V[r] + dxhi * V[r+1]   (cuh:158)
+      dxhi = c.dx_hi * c.wy * w;
+      dylo = c.c_lo * c.dy * w;            // d out/d y   (cuh:159; H = 1)
+      dyhi = c.c_hi * c.dy * w;
+    }
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) g = reinterpret_cast<const float4 *>(gout)[tup * 16 + j];
+    // g rotated by tq so that component index k0 addresses channel 4j + ((k0 + tq) & 3)
+    float g0 = g.x, g1 = g.y, g2 = g.z, g3 = g.w;
+    if (tq & 1) { const float t_ = g0; g0 = g1; g1 = g2; g2 = g3; g3 = t_; }
+    if (tq & 2) { float t_ = g0; g0 = g2; g2 = t_; t_ = g1; g1 = g3; g3 = t_; }
+    float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;
+#define GVL_BWD_STEP(SI)                                                      \
+  if (SI < LP) {                                                              \
+    const int rr = row_bcast_i<SI>(roff);                                     \
+    const float a = row_bcast_f<SI>(clo);                                     \
+    const float c = row_bcast_f<SI>(chi);                                     \
+    const float ws = row_bcast_f<SI>(w);                                      \
+    const float4 v0 = slab4[rr * 16 + j];                                     \
+    const float4 v1 = slab4[rr * 16 + 16 + j];                                \
+    const float d0 = row_allsum(dot4(g, v0));                                 \
+    const float d1 = row_allsum(dot4(g, v1));                                 \
+    if (j == SI) {                                                            \
+      keep_w = fmaf(clo, d0, chi * d1);                                       \
+      keep_x = fmaf(dxlo, d0, dxhi * d1);                                     \
+      keep_y = fmaf(dylo, d0, dyhi * d1);                                     \
+    }                                                                         \
+    const float alo = a * ws, ahi = c * ws;                                   \
+    float *gr = gslab + rr * 64;                                              \
+    atomicAdd(gr + col0, alo * g0); atomicAdd(gr + 64 + col0, ahi * g0);      \
+    atomicAdd(gr + col1, alo * g1); atomicAdd(gr + 64 + col1, ahi * g1);      \
+    atomicAdd(gr + col2, alo * g2); atomicAdd(gr + 64 + col2, ahi * g2);      \
+    atomicAdd(gr + col3, alo * g3); atomicAdd(gr + 64 + col3, ahi * g3);      \
+  }
+    GVL_BWD_STEP(0) GVL_BWD_STEP(1) GVL_BWD_STEP(2) GVL_BWD_STEP(3)
+    GVL_BWD_STEP(4) GVL_BWD_STEP(5) GVL_BWD_STEP(6) GVL_BWD_STEP(7)
+    GVL_BWD_STEP(8) GVL_BWD_STEP(9) GVL_BWD_STEP(10) GVL_BWD_STEP(11)
+    GVL_BWD_STEP(12) GVL_BWD_STEP(13) GVL_BWD_STEP(14) GVL_BWD_STEP(15)
+#undef GVL_BWD_STEP
+    if (act && j < LP) {
+      gattn[tb + j] = keep_w;                                                  // cuh:156-157
+      reinterpret_cast<float2 *>(gloc)[tb + j] = make_float2(keep_x, keep_y);
+    }
+  }
+  __syncthreads();
+  // flush the private slab: (chunk, b, s, m, 64) partial layout == gvalue layout when nchunk == 1
+  float4 *dst = reinterpret_cast<float4 *>(gvalue_part) + ((int64_t)chunk * B * S * M) * 16 + ((int64_t)b * S * M + m) * 16;
+  for (int i = threadIdx.x; i < S * 16; i += blockDim.x) {
+    const int s = i >> 4, jj = i & 15;
+    const float *gr = gslab + s * 64 + jj;
+    float4 v;
+    v.x = gr[0]; v.y = gr[16]; v.z = gr[32]; v.w = gr[48];
+    dst[(int64_t)s * M * 16 + jj] = v;
+  }
+}
+
+// sum `n` partial slabs (each `count4` float4 long) into dst
+__global__ void __launch_bounds__(256) k_sum_partials(const float4 *__restrict__ part, int n, int64_t count4,
+                                                      float4 *__restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = part[i];
+    for (int k = 1; k < n; ++k) {
+      const float4 v = part[(int64_t)k * count4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    dst[i] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+constexpr size_t kLdsMax = 160 * 1024;
+
+int check_dims(int B, int S, int M, int D, int L, int Q, int P, int pad) {
+  if (B < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Q < 0 || P <= 0)
+    return fail(GVL_EINVAL, "gvl_msda: bad dims B=%d S=%d M=%d D=%d L=%d Q=%d P=%d", B, S, M, D, L, Q, P);
+  if (pad != kPadZeros && pad != kPadBorder) return fail(GVL_EINVAL, "gvl_msda: bad pad_mode %d", pad);
+  return 0;
+}
+
+bool temporal_host(const int64_t *shapes_host, const int64_t *lsi_host, int L, int S) {
+  if (!shapes_host || !lsi_host) return false;
+  int64_t run = 0;
+  for (int l = 0; l < L; ++l) {
+    if (shapes_host[2 * l] != 1 || shapes_host[2 * l + 1] < 1 || lsi_host[l] != run) return false;
+    run += shapes_host[2 * l + 1];
+  }
+  return run == S;
+}
+
+int launch_status(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "gvl_msda: %s launch failed: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+int pick_chunks(const char *env, int BM, int Q, int target_wgs) {
+  int n = env_int(env, 0);
+  if (n <= 0) n = (target_wgs + BM - 1) / BM;
+  const int maxn = (Q + 15) / 16;   // keep >= 16 queries per workgroup
+  if (n > maxn) n = maxn;
+  if (n < 1) n = 1;
+  return n;
+}
+
+template <typename K>
+int ensure_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail((int)e, "gvl_msda: cannot raise dynamic LDS to %zu: %s", bytes, hipGetErrorString(e));
+  return 0;
+}
+
+template <typename T>
+int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *attn, int B, int S,
+                 int M, int D, int L, int Q, int P, int pad, const int64_t *shapes_host, const int64_t *lsi_host,
+                 T *out, hipStream_t st) {
+  if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
+  if (!value || !shapes || !lsi || !loc || !attn || !out) return fail(GVL_EINVAL, "gvl_msda_forward: null pointer");
+  const int64_t n = (int64_t)B * Q * M * D;
+  if (n == 0) return 0;
+  const int mode = impl_mode();
+  const size_t lds = (size_t)(S + 1) * 64 * sizeof(float);
+  const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && S > 0 &&
+                       temporal_host(shapes_host, lsi_host, L, S);
+  if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_forward: fast kernels not eligible for this call");
+  if (fast_ok && mode != 1) {
+    if constexpr (sizeof(T) == 4) {
+      const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 768);
+      auto kern = pad == kPadZeros ? k_fwd_t1d_d64<kPadZeros> : k_fwd_t1d_d64<kPadBorder>;
+      if (int rc = ensure_lds(kern, lds)) return rc;
+      hipLaunchKernelGGL(kern, dim3(nchunk * B * M), dim3(256), lds, st, (const float *)value, shapes, lsi,
+                         (const float *)loc, (const float *)attn, B, S, M, L, Q, P, nchunk, (float *)out);
+      g_last_impl = 2;
+      return launch_status("k_fwd_t1d_d64");
+    }
+  }
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL((k_fwd_generic<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi, loc, attn,
+                     B, S, M, D, L, Q, P, pad, out);
+  g_last_impl = 1;
+  return launch_status("k_fwd_generic");
+}
+
+template <typename T>
+int sample_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, int B, int S, int M, int D,
+                int L, int Q, int P, int pad, T *sample, hipStream_t st) {
+  if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
+  if (!value || !shapes || !lsi || !loc || !sample) return fail(GVL_EINVAL, "gvl_msda_sample: null pointer");
+  const int64_t n = (int64_t)B * Q * M * D;
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL((k_fwd_generic<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi, loc,
+                     (const T *)nullptr, B, S, M, D, L, Q, P, pad, sample);
+  g_last_impl = 1;
+  return launch_status("k_fwd_generic<sample>");
+}
+
+int bwd_chunks(int B, int M, int Q) { return pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256); }
+
+template <typename T>
+int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *attn,
+                  const T *gout, int B, int S, int M, int D, int L, int Q, int P, int pad, const int64_t *shapes_host,
+                  const int64_t *lsi_host, T *gvalue, T *gloc, T *gattn, void *ws, size_t ws_bytes, hipStream_t st) {
+  if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
+  if (!value || !shapes || !lsi || !loc || !attn || !gout || !gvalue || !gloc || !gattn)
+    return fail(GVL_EINVAL, "gvl_msda_backward: null pointer");
+  const size_t gv_bytes = (size_t)B * S * M * D * sizeof(T);
+  const int64_t ntup = (int64_t)B * Q * M;
+  if (ntup == 0) {
+    if (gv_bytes) {
+      hipError_t e = hipMemsetAsync(gvalue, 0, gv_bytes, st);
+      if (e != hipSuccess) return fail((int)e, "gvl_msda_backward: memset failed: %s", hipGetErrorString(e));
+    }
+    return 0;
+  }
+  const int mode = impl_mode();
+  const size_t lds = (size_t)(S + 1) * 64 * sizeof(float) * 2;
+  const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && S > 0 &&
+                       temporal_host(shapes_host, lsi_host, L, S);
+  if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_backward: fast kernels not eligible for this call");
+  if (fast_ok && mode != 1) {
+    if constexpr (sizeof(T) == 4) {
+      const int nchunk = bwd_chunks(B, M, Q);
+      float *part = (float *)gvalue;
+      if (nchunk > 1) {
+        const size_t need = gv_bytes * nchunk;
+        if (!ws || ws_bytes < need)
+          return fail(GVL_ENOSPC, "gvl_msda_backward: workspace %zu < required %zu bytes", ws_bytes, need);
+        part = (float *)ws;
+      }
+      auto kern = pad == kPadZeros ? k_bwd_t1d_d64<kPadZeros> : k_bwd_t1d_d64<kPadBorder>;
+      if (int rc = ensure_lds(kern, lds)) return rc;
+      hipLaunchKernelGGL(kern, dim3(nchunk * B * M), dim3(512), lds, st, (const float *)value, shapes, lsi,
+                         (const float *)loc, (const float *)attn, (const float *)gout, B, S, M, L, Q, P, nchunk, part,
+                         (float *)gloc, (float *)gattn);
+      if (int rc = launch_status("k_bwd_t1d_d64")) return rc;
+      if (nchunk > 1) {
+        const int64_t count4 = (int64_t)B * S * M * 16;
+        int64_t blocks = (count4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)part, nchunk,
+                           count4, (float4 *)gvalue);
+        if (int rc = launch_status("k_sum_partials")) return rc;
+      }
+      g_last_impl = 2;
+      return 0;
+    }
+  }
+  hipError_t e = hipMemsetAsync(gvalue, 0, gv_bytes, st);
+  if (e != hipSuccess) return fail((int)e, "gvl_msda_backward: memset failed: %s", hipGetErrorString(e));
+  int64_t blocks = (ntup + 3) / 4;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL((k_bwd_generic<T>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi, loc, attn, gout,
+                     B, S, M, D, L, Q, P, pad, gvalue, gloc, gattn);
+  g_last_impl = 1;
+  return launch_status("k_bwd_generic");
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvl_msda_abi_version(void) { return GVL_MSDA_ABI_VERSION; }
+const char *gvl_last_error(void) { return g_err; }
+void gvl_msda_set_impl(int impl) { g_impl = (impl >= 0 && impl <= 2) ? impl : 0; }
+int gvl_msda_last_impl(void) { return g_last_impl; }
+
+int gvl_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                         const float *attn, int B, int S, int M, int D, int L, int Q, int P, int pad_mode,
+                         const int64_t *shapes_host, const int64_t *lsi_host, float *out, void *stream) {
+  return forward_impl<float>(value, shapes, lsi, loc, attn, B, S, M, D, L, Q, P, pad_mode, shapes_host, lsi_host, out,
+                             (hipStream_t)stream);
+}
+int gvl_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc,
+                         const double *attn, int B, int S, int M, int D, int L, int Q, int P, int pad_mode,
+                         const int64_t *shapes_host, const int64_t *lsi_host, double *out, void *stream) {
+  return forward_impl<double>(value, shapes, lsi, loc, attn, B, S, M, D, L, Q, P, pad_mode, shapes_host, lsi_host, out,
+                              (hipStream_t)stream);
+}
+int gvl_msda_sample_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, int B, int S,
+                        int M, int D, int L, int Q, int P, int pad_mode, float *sample, void *stream) {
+  return sample_impl<float>(value, shapes, lsi, loc, B, S, M, D, L, Q, P, pad_mode, sample, (hipStream_t)stream);
+}
+int gvl_msda_sample_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc, int B,
+                        int S, int M, int D, int L, int Q, int P, int pad_mode, double *sample, void *stream) {
+  return sample_impl<double>(value, shapes, lsi, loc, B, S, M, D, L, Q, P, pad_mode, sample, (hipStream_t)stream);
+}
+
+size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes) {
+  if (elem_bytes != 4 || D != 64 || L * P > 16) return 0;
+  if ((size_t)(S + 1) * 64 * sizeof(float) * 2 > kLdsMax) return 0;
+  const int n = bwd_chunks(B, M, Q);
+  return n > 1 ? (size_t)n * B * S * M * D * sizeof(float) : 0;
+}
+
+int gvl_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                          const float *attn, const float *grad_out, int B, int S, int M, int D, int L, int Q, int P,
+                          int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *grad_value,
+                          float *grad_loc, float *grad_attn, void *workspace, size_t workspace_bytes, void *stream) {
+  return backward_impl<float>(value, shapes, lsi, loc, attn, grad_out, B, S, M, D, L, Q, P, pad_mode, shapes_host,
+                              lsi_host, grad_value, grad_loc, grad_attn, workspace, workspace_bytes,
+                              (hipStream_t)stream);
+}
+int gvl_msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc,
+                          const double *attn, const double *grad_out, int B, int S, int M, int D, int L, int Q, int P,
+                          int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, double *grad_value,
+                          double *grad_loc, double *grad_attn, void *workspace, size_t workspace_bytes, void *stream) {
+  return backward_impl<double>(value, shapes, lsi, loc, attn, grad_out, B, S, M, D, L, Q, P, pad_mode, shapes_host,
+                               lsi_host, grad_value, grad_loc, grad_attn, workspace, workspace_bytes,
+                               (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+"""Autograd boundary of the op -- mirrors pdvc/ops/functions/ms_deform_attn_func.py:23-41.
+
+``MSDeformAttnFunction.apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+attention_weights, im2col_step)`` keeps the reference's signature, saved tensors, once_differentiable backward and
+6-tuple of gradients; it computes the reference CUDA op's zero-padding semantics on the HIP kernels.
+``MSDeformAttnPadFunction`` is the same op with an explicit ``pad_mode`` ("border" reproduces the arithmetic of the
+reference's CPU fallback ms_deform_attn_core_pytorch, func.py:44-71, on the GPU).  There is deliberately no
+PyTorch fallback here: without libgvl_msda.so or a ROCm device the call raises.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ... import MultiScaleDeformableAttention as MSDA
+
+
+class MSDeformAttnPadFunction(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step, pad_mode):
+        ctx.im2col_step = im2col_step
+        ctx.pad_mode = pad_mode
+        ctx.host = MSDA.host_shapes(value_spatial_shapes, value_level_start_index)
+        output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                             sampling_locations, attention_weights, im2col_step, pad_mode)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, attn = ctx.saved_tensors
+        if getattr(shapes, "_gvl_host", None) is None:
+            shapes._gvl_host = ctx.host
+        gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, grad_output.contiguous(),
+                                                  ctx.im2col_step, ctx.pad_mode)
+        return gv, None, None, gl, ga, None, None
+
+
+class MSDeformAttnFunction(Function):
+    """Exact reference signature (func.py:23-41); zero padding == the reference CUDA kernels."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.host = MSDA.host_shapes(value_spatial_shapes, value_level_start_index)
+        output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                             sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, attn = ctx.saved_tensors
+        if getattr(shapes, "_gvl_host", None) is None:
+            shapes._gvl_host = ctx.host
+        grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
+            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None

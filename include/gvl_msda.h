@@ -1,0 +1,114 @@
+/*
+ * gvl_msda.h -- C ABI of libgvl_msda.so: MI355X (gfx950) multi-scale deformable attention for GVL.
+ *
+ * This is the drop-in boundary for the reference's native extension `MultiScaleDeformableAttention`
+ * (/root/reference/pdvc/ops/src/vision.cpp:13-16).  Each entry point names the reference interface it replaces.
+ * Plain pointers and sizes only: no torch / ATen types.  All data pointers are DEVICE pointers unless the
+ * parameter name ends in `_host`.  Every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ * NULL = the default stream), allocates nothing, never synchronises, and is safe to capture in a hipGraph.
+ * Calls are stateless and re-entrant (autograd worker threads call the backward).
+ *
+ * Return value: 0 on success, otherwise a negative GVL_E* code (argument errors) or a positive hipError_t
+ * (launch errors -- the reference only printf()s those, cuh:949-953; here they are returned).
+ * gvl_last_error() returns a thread-local human readable message for the last failing call.
+ *
+ * Tensor layouts (row-major, contiguous, as in the reference op):
+ *   value   (B, S, M, D)           S = sum_l H_l*W_l
+ *   shapes  (L, 2) int64  (H_l, W_l);  for GVL's temporal features H_l = 1, W_l = T_l (ms_deform_attn.py:117)
+ *   lsi     (L)    int64  first row of level l inside S
+ *   loc     (B, Q, M, L, P, 2)     normalised (x, y) in [0,1]; GVL always passes y = 0.5 (ms_deform_attn.py:115)
+ *   attn    (B, Q, M, L, P)
+ *   out     (B, Q, M*D)
+ *   sample  (B*M, D, Q, L, P)      unweighted samples, the layout of ms_deform_attn_core_pytorch(return_value=True)
+ *
+ * pad_mode: GVL_PAD_ZEROS  = semantics of the reference CUDA op (ms_deform_im2col_cuda.cuh:238-300, :407-511)
+ *           GVL_PAD_BORDER = semantics of the reference's PyTorch fallback / captioner path
+ *                            (ms_deform_attn_func.py:61-62, F.grid_sample(padding_mode='border')).
+ *
+ * shapes_host / lsi_host (optional, may be NULL): a HOST copy of `shapes` / `lsi`.  When given, and every level
+ * has H_l == 1, fp32, D == 64 and L*P <= 16, the LDS-staged temporal kernels are used; otherwise the generic
+ * kernels (any D, any HxW, fp32/fp64) run.  Results are identical up to fp32 summation order.
+ */
+#ifndef GVL_MSDA_H
+#define GVL_MSDA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVL_MSDA_ABI_VERSION 1
+
+#define GVL_PAD_ZEROS 0
+#define GVL_PAD_BORDER 1
+
+#define GVL_EINVAL (-1)   /* bad size / null pointer / unsupported combination */
+#define GVL_ENOSPC (-2)   /* workspace too small */
+
+int gvl_msda_abi_version(void);
+const char *gvl_last_error(void);
+
+/* Force a kernel family for A/B testing: 0 = auto (default), 1 = generic only, 2 = fast where eligible.
+ * (Also settable through the environment variable GVL_MSDA_IMPL=auto|generic|fast before first use.) */
+void gvl_msda_set_impl(int impl);
+/* Which family the most recent forward/backward call on this thread used: 1 generic, 2 fast. */
+int gvl_msda_last_impl(void);
+
+/* -- forward: replaces ms_deform_attn_forward (pdvc/ops/src/ms_deform_attn.h:20-39 ->
+ *    ms_deform_attn_cuda_forward, pdvc/ops/src/cuda/ms_deform_attn_cuda.cu:20-80).  `out` is fully overwritten
+ *    (the reference zero-fills then accumulates, cu:54); im2col_step batching (cu:50-75) is an artefact of the
+ *    reference launcher and has no equivalent here -- any B is processed in one launch. */
+int gvl_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                         const float *attn, int B, int S, int M, int D, int L, int Q, int P, int pad_mode,
+                         const int64_t *shapes_host, const int64_t *lsi_host, float *out, void *stream);
+int gvl_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc,
+                         const double *attn, int B, int S, int M, int D, int L, int Q, int P, int pad_mode,
+                         const int64_t *shapes_host, const int64_t *lsi_host, double *out, void *stream);
+
+/* -- unweighted samples: replaces ms_deform_attn_core_pytorch(..., return_value=True)
+ *    (pdvc/ops/functions/ms_deform_attn_func.py:44-68) as used by MSDeformAttnCap
+ *    (pdvc/ops/modules/ms_deform_attn_for_caption.py:124-125).  sample layout (B*M, D, Q, L, P). */
+int gvl_msda_sample_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, int B,
+                        int S, int M, int D, int L, int Q, int P, int pad_mode, float *sample, void *stream);
+int gvl_msda_sample_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc, int B,
+                        int S, int M, int D, int L, int Q, int P, int pad_mode, double *sample, void *stream);
+
+/* -- backward: replaces ms_deform_attn_backward (pdvc/ops/src/ms_deform_attn.h:41-61 ->
+ *    ms_deform_attn_cuda_backward, pdvc/ops/src/cuda/ms_deform_attn_cuda.cu:83-153).
+ *    grad_value (B,S,M,D), grad_loc (B,Q,M,L,P,2), grad_attn (B,Q,M,L,P) are fully (over)written: the callee
+ *    zero-fills what it accumulates into (the reference allocates zeros, cu:121-123), so the caller may pass
+ *    uninitialised buffers.  `workspace` must hold gvl_msda_backward_workspace_bytes(...) bytes (may be NULL
+ *    when that is 0). */
+size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes);
+int gvl_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                          const float *attn, const float *grad_out, int B, int S, int M, int D, int L, int Q, int P,
+                          int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *grad_value,
+                          float *grad_loc, float *grad_attn, void *workspace, size_t workspace_bytes, void *stream);
+int gvl_msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc,
+                          const double *attn, const double *grad_out, int B, int S, int M, int D, int L, int Q,
+                          int P, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
+                          double *grad_value, double *grad_loc, double *grad_attn, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* -- Hungarian matcher index path (HOST pointers, host code).  Replaces scipy.optimize.linear_sum_assignment as
+ *    called at pdvc/matcher.py:124,126; results are bit-identical to scipy 1.15.3 (same augmenting-path order and
+ *    tie-breaking, float32 costs promoted to float64).  row_ind / col_ind have length min(nr, nc); row_ind is
+ *    ascending.  Returns 0, or GVL_EINVAL for bad arguments and for NaN / -inf costs or an infeasible matrix
+ *    (scipy raises ValueError there). */
+int gvl_lsap_solve_f64(const double *cost, int64_t nr, int64_t nc, int64_t *row_ind, int64_t *col_ind);
+int gvl_lsap_solve_f32(const float *cost, int64_t nr, int64_t nc, int64_t *row_ind, int64_t *col_ind);
+
+/* The whole of matcher.py:120-131 for one decoder layer: C is the HOST cost tensor (B, Q, G), G = sum(sizes);
+ * video i owns columns [off_i, off_i + sizes[i]).  Writes, concatenated over videos, the one-to-one indices
+ * (idx_*: sum_i min(Q, n_i) entries) and the many-to-one indices on the block tiled m2o_rate times with
+ * GT id = col % n_i (rl_*: sum_i min(Q, m2o_rate*n_i) entries).  Videos are solved on num_threads host threads
+ * (<= 0: hardware concurrency). */
+int gvl_hungarian_batch_f32(const float *C, int B, int Q, int G, const int *sizes, int m2o_rate, int64_t *idx_rows,
+                            int64_t *idx_cols, int64_t *rl_rows, int64_t *rl_cols, int num_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVL_MSDA_H */

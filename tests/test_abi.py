@@ -1,0 +1,139 @@
+"""CPU: the C-ABI library loads, exports every symbol include/gvl_msda.h declares, and its host-side Hungarian
+index path is bit-identical to the scipy goldens.  No GPU compute is invoked."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import load
+from gvl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gvl_amd import build
+    build.build()
+    return _lib.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gvl_msda.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gvl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/gvl_msda.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "python binding table out of sync with the header"
+    assert lib.gvl_msda_abi_version() == 1
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    rc = lib.gvl_msda_forward_f32(None, None, None, None, None, 1, 4, 1, 64, 1, 1, 1, 0, None, None, None, None)
+    assert rc == -1 and b"null pointer" in lib.gvl_last_error()
+    rc = lib.gvl_msda_forward_f32(None, None, None, None, None, 1, 4, 0, 64, 1, 1, 1, 0, None, None, None, None)
+    assert rc == -1 and b"bad dims" in lib.gvl_last_error()
+    rc = lib.gvl_msda_forward_f32(None, None, None, None, None, 1, 4, 1, 64, 1, 1, 1, 7, None, None, None, None)
+    assert rc == -1 and b"pad_mode" in lib.gvl_last_error()
+    assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 64, 4, 300, 4, 4) % (16 * 188 * 8 * 64 * 4) == 0
+    assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 30, 4, 300, 4, 8) == 0
+
+
+def _solve(lib, C):
+    C = np.ascontiguousarray(C)
+    nr, nc = C.shape
+    k = min(nr, nc)
+    r = np.empty(k, np.int64)
+    c = np.empty(k, np.int64)
+    fn = lib.gvl_lsap_solve_f32 if C.dtype == np.float32 else lib.gvl_lsap_solve_f64
+    rc = fn(C.ctypes.data_as(ctypes.c_void_p), nr, nc, r.ctypes.data_as(ctypes.c_void_p),
+            c.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return r, c
+
+
+def test_lsap_matches_scipy_goldens(lib):
+    f = load("lsap_cases")
+    names = sorted({k.split(".")[0] for k in f if "." in k})
+    for n in names:
+        r, c = _solve(lib, f[f"{n}.C"])
+        assert np.array_equal(r, f[f"{n}.rows"]), n
+        assert np.array_equal(c, f[f"{n}.cols"]), n
+
+
+def test_lsap_matches_scipy_random_and_ties(lib):
+    from scipy.optimize import linear_sum_assignment
+    rs = np.random.RandomState(123)
+    for trial in range(300):
+        nr, nc = rs.randint(1, 40), rs.randint(1, 40)
+        kind = trial % 4
+        if kind == 0:
+            C = rs.rand(nr, nc)
+        elif kind == 1:
+            C = np.round(rs.rand(nr, nc) * 3)                 # heavy ties
+        elif kind == 2:
+            C = rs.rand(nr, nc).astype(np.float32)
+        else:
+            C = np.tile(rs.rand(nr, max(1, nc // 4)).astype(np.float32), (1, 4))   # m2o tiling pattern
+        r, c = _solve(lib, C)
+        er, ec = linear_sum_assignment(C)
+        assert np.array_equal(r, er) and np.array_equal(c, ec), (trial, C.shape)
+
+
+def test_lsap_rejects_nan(lib):
+    C = np.array([[1.0, np.nan], [0.0, 1.0]])
+    r = np.empty(2, np.int64)
+    rc = lib.gvl_lsap_solve_f64(C.ctypes.data_as(ctypes.c_void_p), 2, 2, r.ctypes.data_as(ctypes.c_void_p),
+                                r.ctypes.data_as(ctypes.c_void_p))
+    assert rc == -1
+
+
+def test_hungarian_batch_matches_reference_matcher_fixture(lib):
+    f = load("matcher_model")
+    sizes = [int(s) for s in f["sizes"]]
+    B, Q = f["logits"].shape[:2]
+    G = sum(sizes)
+    # rebuild the (B,Q,G) cost tensor from the per-video blocks stored by the reference (return_C=True)
+    C = np.zeros((B, Q, G), np.float32)
+    off = 0
+    for i, n in enumerate(sizes):
+        C[i, :, off:off + n] = f[f"C_{i}"]
+        off += n
+    n1 = sum(min(Q, n) for n in sizes)
+    n4 = sum(min(Q, 4 * n) for n in sizes)
+    ir, ic = np.empty(n1, np.int64), np.empty(n1, np.int64)
+    rr, rcol = np.empty(n4, np.int64), np.empty(n4, np.int64)
+    sz = np.asarray(sizes, np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.gvl_hungarian_batch_f32(p(C), B, Q, G, p(sz), 4, p(ir), p(ic), p(rr), p(rcol), 0)
+    assert rc == 0
+    o1 = o4 = 0
+    for i, n in enumerate(sizes):
+        k1, k4 = min(Q, n), min(Q, 4 * n)
+        assert np.array_equal(np.stack([ir[o1:o1 + k1], ic[o1:o1 + k1]]), f[f"idx_{i}"])
+        assert np.array_equal(np.stack([rr[o4:o4 + k4], rcol[o4:o4 + k4]]), f[f"rl_{i}"])
+        o1 += k1
+        o4 += k4
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from gvl_amd.ops.functions import MSDeformAttnFunction
+    from gvl_amd.ops.modules import MSDeformAttn
+    v = torch.zeros(1, 4, 1, 64)
+    sh = torch.tensor([[1, 4]])
+    ls = torch.tensor([0])
+    loc = torch.zeros(1, 1, 1, 1, 1, 2)
+    aw = torch.ones(1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDeformAttnFunction.apply(v, sh, ls, loc, aw, 64)
+    m = MSDeformAttn(64, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 64), torch.zeros(1, 1, 1, 1), torch.zeros(1, 4, 64), torch.tensor([4]), ls)
