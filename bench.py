@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Contract benchmark: videos/sec of the GVL (PDVC) eval forward -- or train-step ms -- on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode eval|train] [--T 100] [--queries 300]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch of synthetic input: ``PDVC.forward(dt, criterion, None,
+'queries', eval_mode=True)`` (eval_utils.py:203) on B=16 videos per GPU of the ANet-TSP model
+(cfgs/anet_tsp_ssvg.yml with num_queries=300, T=100, random-init weights, synthetic features).
+Videos are independent, so ranks shard by video with no data-path collective ("weak" scaling: 16 videos per GPU).
+Rank 0 prints ONE JSON line; it carries the `roofline` object of the deformable-attention kernel (measured live with
+HIP events on the launch stream) and, at N=1, the `cpu_baseline` object (the oracle's CPU restatement of the same
+forward with the reference's CPU-fallback sampling semantics, timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_TBS = 8.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def synth_batch(B, T, feat, vocab, n_gt, device, seed=1):
+    """SURVEY.md section 8d synthetic `dt` (keys of pdvc.py:250-258 + targets for the criterion)."""
+    g = torch.Generator().manual_seed(seed)
+    vt = torch.randn(B, T, feat, generator=g)
+    vmask = torch.ones(B, T, dtype=torch.bool)
+    vlen = torch.tensor([[float(T), 120.0, float(n_gt)]] * B)
+    targets = []
+    for _ in range(B):
+        c = torch.rand(n_gt, generator=g) * 0.5 + 0.25
+        l_ = torch.rand(n_gt, generator=g) * 0.3 + 0.1
+        targets.append({"boxes": torch.stack([c, l_], -1).to(device), "labels": torch.zeros(n_gt, dtype=torch.long,
+                                                                                           device=device)})
+    cap_len = 12
+    caps = torch.randint(1, vocab, (B * n_gt, cap_len), generator=g)
+    caps[:, 0] = 0
+    caps[:, -1] = 0
+    return {"video_tensor": vt.to(device), "video_mask": vmask.to(device), "video_length": vlen.to(device),
+            "video_target": targets, "cap_raw": [["x"] * n_gt] * B, "cap_tensor": caps.to(device),
+            "cap_mask": torch.ones(B * n_gt, cap_len, device=device),
+            "gt_boxes_mask": torch.ones(B, n_gt, dtype=torch.bool, device=device)}
+
+
+def msda_bytes(B, S, Q, M=8, L=4, P=4, C=512):
+    """algorithmic bytes of one forward launch: value + loc(2) + weight + output, fp32"""
+    return 4 * B * (S * C + 3 * Q * M * L * P + Q * C)
+
+
+def kernel_times(entries):
+    """group the in-library dispatch timings (gvl_prof_collect) by (kernel, meta_a, meta_b) -> (mean us, count)"""
+    acc = {}
+    for tag, ma, mb, us in entries:
+        acc.setdefault((tag, ma, mb), []).append(us)
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def cpu_baseline(model, opt, T, seconds_budget=25.0):
+    """The oracle's CPU port (reference CPU-fallback semantics: grid_sample border) on a bounded sample."""
+    from oracle import torch_ref as R
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    # a few hundred tiny ops per token step: more than ~32 threads only adds fork/join overhead on a big host
+    ncores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    nvid = 2
+    dt = synth_batch(nvid, T, opt.feature_dim, opt.vocab_size, 3, "cpu", seed=1)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        R.pdvc_eval_forward(sd, dt, n_enc=opt.enc_layers, n_dec=opt.dec_layers, pad_mode="border",
+                            max_caption_len=opt.max_caption_len)
+    el = time.perf_counter() - t0
+    done = nvid
+    # one more, larger batch if the budget allows (amortises per-call overheads the way eval_batch_size=16 does)
+    if el < seconds_budget / 5:
+        nvid2 = min(16, max(2, int(nvid * (seconds_budget * 0.6) / max(el, 1e-3))))
+        dt = synth_batch(nvid2, T, opt.feature_dim, opt.vocab_size, 3, "cpu", seed=1)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            R.pdvc_eval_forward(sd, dt, n_enc=opt.enc_layers, n_dec=opt.dec_layers, pad_mode="border",
+                                max_caption_len=opt.max_caption_len)
+        el = time.perf_counter() - t0
+        done = nvid2
+    return {"value": done / el, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} synthetic videos, one eval forward incl. {opt.max_caption_len + 1} greedy caption "
+                      f"steps, oracle/torch_ref.py (grid_sample border = reference CPU fallback), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="eval", choices=["eval", "train"])
+    ap.add_argument("--T", type=int, default=100)
+    ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--batch", type=int, default=16, help="videos per GPU")
+    ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gvl_amd.config import make_opt
+    from gvl_amd.pdvc import build
+    opt = make_opt("anet_tsp_ssvg", num_queries=a.queries, frame_embedding_num=a.T,
+                   eval_disable_captioning=bool(a.no_captioner), device="cuda")
+    torch.manual_seed(0)
+    model, criterion, _, _ = build(opt)
+    model = model.to(dev)
+    B = a.batch
+    dt = synth_batch(B, a.T, opt.feature_dim, opt.vocab_size, 3, dev, seed=1 + rank)
+
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+
+    if a.mode == "eval":
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model(dt, criterion, None, "queries", eval_mode=True)
+    else:
+        from gvl_amd.parallel import TrainStep
+        model.train()
+        trainer = TrainStep(model, criterion, opt, world_size=world)
+
+        def step():
+            return trainer(dt)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    MSDA.profile_enable(True)          # per-dispatch begin/end stamps of the library's kernels (hipExtLaunchKernel)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    MSDA.profile_enable(False)
+    ktimes = kernel_times(MSDA.profile_collect())
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = elapsed * 1e3 / a.steps
+    videos_per_s = world * B * a.steps / elapsed
+
+    # roofline of the deformable-attention forward kernel (decoder cross-attention launch shape = the larger one)
+    lens = [a.T]
+    for _ in range(opt.num_feature_levels - 1):
+        lens.append((lens[-1] - 1) // 2 + 1)
+    S = sum(lens)
+    roof = None
+    fwd = {k: v for k, v in ktimes.items() if k[0] in ("fwd_t1d_d64", "fwd_generic")}
+    dec_key = next((k for k in fwd if k[1] == a.queries and k[2] == B), None)
+    if dec_key is not None:
+        us, n = fwd[dec_key]
+        nbytes = msda_bytes(B, S, a.queries)
+        achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
+        roof = {"bound": "hbm", "kernel": f"k_{dec_key[0]} (decoder cross-attention launch, Lq={a.queries})",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                "frac": round(achieved / (HBM_PEAK_TBS * 1e3), 4), "traffic": None,
+                "kernel_us": round(us, 2), "launches_timed": n, "algorithmic_bytes": nbytes}
+        enc_key = next((k for k in fwd if k[1] == S and k[2] == B), None)
+        if enc_key is not None:
+            eus, en = fwd[enc_key]
+            eb = msda_bytes(B, S, S)
+            roof["encoder_launch"] = {"kernel_us": round(eus, 2), "launches_timed": en, "algorithmic_bytes": eb,
+                                      "frac": round(eb / (eus * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
+    other = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in ktimes.items() if k not in fwd}
+
+    line = {
+        "metric": "videos/sec (eval fwd)" if a.mode == "eval" else "train-step ms",
+        "value": round(videos_per_s, 3) if a.mode == "eval" else round(ms_per_step, 3),
+        "unit": "videos/s" if a.mode == "eval" else "ms",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": a.mode == "eval", "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"cfgs/anet_tsp_ssvg.yml PDVC {'eval forward' if a.mode == 'eval' else 'train step'}"
+                               f" B={B}/GPU T={a.T} L=4 Q={a.queries}, "
+                               + ("captioner off (diagnostic)" if a.no_captioner else
+                                  f"LSTM-DSA greedy captioning {opt.max_caption_len + 1} steps")
+                               + ", set criterion + Hungarian matcher on 3 GT/video",
+                   "global_batch": world * B, "parallelism": f"dp{world} (videos sharded, no data-path collective)"
+                   if a.mode == "eval" else f"dp{world} (RCCL gradient all-reduce)"},
+        "roofline": roof,
+        "kernels_us": other,
+    }
+    if a.mode == "train":
+        line["videos_per_s"] = round(videos_per_s, 3)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "eval":
+        line["cpu_baseline"] = cpu_baseline(model, opt, a.T)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

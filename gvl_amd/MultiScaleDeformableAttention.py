@@ -125,3 +125,79 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 ws.data_ptr() if ws is not None else None, nbytes, stream)
     _lib.check(rc, "ms_deform_attn_backward")
     return grad_value, grad_loc, grad_attn
+
+
+def ms_deform_attn_sample_backward(value, spatial_shapes, level_start_index, sampling_loc, grad_sample,
+                                   pad_mode="border"):
+    """autograd of ms_deform_attn_sample: grad_sample (B*M, D, Q, L, P) -> (grad_value, grad_loc)."""
+    B, S, M, D, L, Q, P = _common_checks(value, spatial_shapes, level_start_index, sampling_loc, None, 1 << 30)
+    _require(grad_sample.is_contiguous() and tuple(grad_sample.shape) == (B * M, D, Q, L, P),
+             "grad_sample must be contiguous (B*M, D, Q, L, P)")
+    grad_value = torch.empty_like(value)
+    grad_loc = torch.empty_like(sampling_loc)
+    fn = getattr(_lib.lib(), "gvl_msda_sample_backward_" + _SUFFIX[value.dtype])
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                grad_sample.data_ptr(), B, S, M, D, L, Q, P, PAD_MODES[pad_mode], grad_value.data_ptr(),
+                grad_loc.data_ptr(), stream)
+    _lib.check(rc, "ms_deform_attn_sample_backward")
+    return grad_value, grad_loc
+
+
+def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off_h, att_h, alpha_w, alpha_b,
+               n_levels, n_points, debug=False):
+    """Fused deformable soft attention of one captioner token step (include/gvl_msda.h: gvl_cap_attend_f32).
+    slab (B,S,2C) | ref_in (B,Q,L,1|2) | off_hs (B,Q,L*P) | h, att_h (B*Q,C) | w_off_h (L*P,C) | alpha_w (C,)"""
+    for name, t_ in (("slab", slab), ("ref_in", ref_in), ("off_hs", off_hs), ("h", h), ("w_off_h", w_off_h),
+                     ("att_h", att_h), ("alpha_w", alpha_w)):
+        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
+                 f"cap_attend: {name} must be a contiguous fp32 CUDA tensor")
+    B, S, C2 = slab.shape
+    C = C2 // 2
+    Q = ref_in.shape[1]
+    RD = ref_in.shape[-1]
+    att_res = torch.empty((B * Q, C), device=slab.device, dtype=torch.float32)
+    dbg_a = torch.empty((B * Q, n_levels * n_points), device=slab.device) if debug else None
+    dbg_l = torch.empty((B * Q, n_levels * n_points), device=slab.device) if debug else None
+    with torch.cuda.device(slab.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().gvl_cap_attend_f32(
+            slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
+            off_hs.data_ptr(), h.data_ptr(), w_off_h.data_ptr(), att_h.data_ptr(), alpha_w.data_ptr(),
+            float(alpha_b), B, S, C, n_levels, Q, n_points, RD, att_res.data_ptr(),
+            dbg_a.data_ptr() if debug else None, dbg_l.data_ptr() if debug else None, stream)
+    _lib.check(rc, "cap_attend")
+    return (att_res, dbg_a, dbg_l) if debug else att_res
+
+
+def row_argmax_lse(logits):
+    """(R, V) fp32 -> (argmax int64 (R,), log_softmax value at the argmax (R,)); first maximal index on ties."""
+    _require(logits.is_cuda and logits.is_contiguous() and logits.dtype == torch.float32 and logits.dim() == 2,
+             "row_argmax_lse: logits must be a contiguous fp32 CUDA matrix")
+    R, V = logits.shape
+    idx = torch.empty(R, dtype=torch.int64, device=logits.device)
+    lp = torch.empty(R, dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        rc = _lib.lib().gvl_row_argmax_lse_f32(logits.data_ptr(), R, V, idx.data_ptr(), lp.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "row_argmax_lse")
+    return idx, lp
+
+
+PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
+             7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse"}
+
+
+def profile_enable(on=True):
+    _lib.lib().gvl_prof_enable(1 if on else 0)
+
+
+def profile_collect(capacity=1 << 16):
+    """-> list of (kernel tag name, meta_a, meta_b, microseconds) for every launch since the last collect."""
+    us = np.empty(capacity, np.float32)
+    tag = np.empty(capacity, np.int32)
+    ma = np.empty(capacity, np.int32)
+    mb = np.empty(capacity, np.int32)
+    n = _lib.lib().gvl_prof_collect(_hp(us), _hp(tag), _hp(ma), _hp(mb), capacity)
+    return [(PROF_TAGS.get(int(tag[i]), str(tag[i])), int(ma[i]), int(mb[i]), float(us[i])) for i in range(n)]

@@ -1,0 +1,403 @@
+// gvl_cap.hip -- captioner-side kernels of the GVL hot path on MI355X (gfx950).
+//
+//   k_cap_attend      the deformable soft attention of one LSTM-DSA token step, fused into one launch
+//                     (reference: ShowAttendTellCore.forward, pdvc/CaptioningHead/LSTM_DSA.py:241-266, with
+//                     MSDeformAttnCap.forward, pdvc/ops/modules/ms_deform_attn_for_caption.py:82-127, inside it):
+//                       off   = sampling_offsets([h | hs])                      (16 scalar offsets per query)
+//                       x_k   = ref + off_k / T_l   |  ref_c + off_k / P * ref_len * 0.5
+//                       clip_k = border-padded linear sample of value_proj(memory) at x_k          (C floats)
+//                       e_k   = alpha_net(tanh(ctx2att(clip_k) + h2att(h)))      softmax over the 16 samples
+//                       att   = sum_k alpha_k clip_k
+//                     ctx2att is linear and border interpolation weights sum to 1, hence ctx2att(clip_k) is a
+//                     sample of ctx2att(value); the kernel reads a [value | ctx2att(value)] slab built once per
+//                     forward.  One wavefront owns one (video, query) row: lane holds 8 of the 512 channels, the
+//                     16 offset dot-products and the 16 attention logits are reduced with a 17-step butterfly
+//                     reduce-scatter (xor shuffles) that leaves sample k on lanes 4k..4k+3, row addresses travel to
+//                     SGPRs with v_readlane so every gather is a coalesced 1 KiB wave load.
+//   k_row_argmax_lse  greedy decoding epilogue: per row of the logits argmax and log-softmax at the argmax
+//                     (LSTM_DSA.py:123 log_softmax + :166 torch.max) in one read of the logits.
+//   k_sample_bwd      backward of the unweighted sampler (autograd of ms_deform_attn_core_pytorch(return_value=True),
+//                     func.py:44-68, used by the teacher-forced captioner in training).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gvl_common.hpp"
+#include "gvl_msda.h"
+
+namespace {
+
+using gvl::fail;
+
+__device__ inline float fast_tanh(float x) {
+  // 1 - 2/(1+e^{2x}); saturates correctly for |x| large, abs error ~1e-7
+  const float e = __expf(2.f * x);
+  return 1.f - 2.f / (1.f + e);
+}
+
+// reduce-scatter of v[16] over the 64 lanes: afterwards every lane holds the full sum of v[k], k = lane >> 2.
+__device__ inline float butterfly16(float (&v)[16], int lane) {
+  float a8[8];
+  const bool up5 = lane & 32;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float mine = up5 ? v[8 + i] : v[i];
+    const float send = up5 ? v[i] : v[8 + i];
+    a8[i] = mine + __shfl_xor(send, 32, 64);
+  }
+  float a4[4];
+  const bool up4 = lane & 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float mine = up4 ? a8[4 + i] : a8[i];
+    const float send = up4 ? a8[i] : a8[4 + i];
+    a4[i] = mine + __shfl_xor(send, 16, 64);
+  }
+  float a2[2];
+  const bool up3 = lane & 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float mine = up3 ? a4[2 + i] : a4[i];
+    const float send = up3 ? a4[i] : a4[2 + i];
+    a2[i] = mine + __shfl_xor(send, 8, 64);
+  }
+  const bool up2 = lane & 4;
+  float r = (up2 ? a2[1] : a2[0]) + __shfl_xor(up2 ? a2[0] : a2[1], 4, 64);
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+
+// all-reduce over lane groups that differ in bits 2..5 (values are already uniform inside each group of 4 lanes)
+__device__ inline float groups_max(float v) {
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline float groups_sum(float v) {
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ inline void fma8(float a, const float4 &x0, const float4 &x1, float (&acc)[8]) {
+  acc[0] = fmaf(a, x0.x, acc[0]); acc[1] = fmaf(a, x0.y, acc[1]); acc[2] = fmaf(a, x0.z, acc[2]);
+  acc[3] = fmaf(a, x0.w, acc[3]); acc[4] = fmaf(a, x1.x, acc[4]); acc[5] = fmaf(a, x1.y, acc[5]);
+  acc[6] = fmaf(a, x1.z, acc[6]); acc[7] = fmaf(a, x1.w, acc[7]);
+}
+
+constexpr int kC = 512;      // channels of the value half and of the ctx2att half (hidden_dim = att_hid_size = 512)
+constexpr int kLP = 16;      // samples per query (cap_num_feature_levels * cap_dec_n_points)
+constexpr int kWaves = 8;    // rows (wavefronts) per workgroup
+
+// border-mode coefficients of one temporal sample (grid_sampler border, align_corners=False), row pair (r, r+1)
+__device__ inline void border_coef(float loc, int T, int &r, float &c_lo, float &c_hi) {
+  const float g = 2.f * loc - 1.f;
+  float x = ((g + 1.f) * (float)T - 1.f) * 0.5f;
+  const float mx = (float)(T - 1);
+  x = !(x > 0.f) ? 0.f : (x >= mx ? mx : x);
+  const float xf = floorf(x);
+  const int x0 = (int)xf;
+  const float a = x - xf;
+  const int rmax = T >= 2 ? T - 2 : 0;
+  r = x0 > rmax ? rmax : x0;
+  const float t0 = 1.f - a;
+  const float t1 = (x0 + 1 <= T - 1) ? a : 0.f;
+  c_lo = (x0 == r ? t0 : 0.f) + (x0 + 1 == r ? t1 : 0.f);
+  c_hi = (x0 == r + 1 ? t0 : 0.f) + (x0 + 1 == r + 1 ? t1 : 0.f);
+}
+
+__global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
+    const float *__restrict__ slab,      // (B, S, 2C)  [value_proj(memory) | ctx2att(value_proj(memory))]
+    const int64_t *__restrict__ shapes,  // (L, 2)
+    const int64_t *__restrict__ lsi,     // (L)
+    const float *__restrict__ ref,       // (B, Q, L, RD) reference points scaled by the valid ratios
+    const float *__restrict__ off_hs,    // (B*Q, 16)   sampling_offsets bias + hs part
+    const float *__restrict__ h,         // (B*Q, C)    previous hidden state
+    const float *__restrict__ w_off_h,   // (16, C)     sampling_offsets.weight[:, :C]
+    const float *__restrict__ att_h,     // (B*Q, C)    h2att(h)
+    const float *__restrict__ alpha_w,   // (C)
+    float alpha_b, int B, int S, int L, int Q, int P, int RD, int rows_per_xcd_group,
+    float *__restrict__ att_res,         // (B*Q, C)
+    float *__restrict__ dbg_alpha,       // optional (B*Q, 16)
+    float *__restrict__ dbg_loc) {       // optional (B*Q, 16)
+  __shared__ float4 wo4[kLP * kC / 4];   // 32 KiB: the h part of the offsets projection
+  for (int i = threadIdx.x; i < kLP * kC / 4; i += blockDim.x) wo4[i] = reinterpret_cast<const float4 *>(w_off_h)[i];
+
+  // XCD-aware row mapping: workgroups b and b+8 share an XCD (round-robin dispatch), so give every XCD a
+  // contiguous group of videos; its L2 then holds only those videos' slabs.
+  const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = jblk * kWaves + wave;
+  const int64_t row = (int64_t)xcd * rows_per_xcd_group + lr;
+  const bool active = lr < rows_per_xcd_group && row < (int64_t)B * Q;
+  __syncthreads();
+  if (!active) return;
+  const int b = (int)(row / Q);
+
+  // own channels: [4*lane, 4*lane+4) and [256 + 4*lane, 256 + 4*lane + 4)
+  const float4 *h4 = reinterpret_cast<const float4 *>(h + row * kC);
+  const float4 ha = h4[lane], hb = h4[64 + lane];
+  float part[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float4 wa = wo4[k * (kC / 4) + lane], wb = wo4[k * (kC / 4) + 64 + lane];
+    part[k] = wa.x * ha.x + wa.y * ha.y + wa.z * ha.z + wa.w * ha.w + wb.x * hb.x + wb.y * hb.y + wb.z * hb.z +
+              wb.w * hb.w;
+  }
+  const int k_own = lane >> 2;                       // the sample this lane group owns after the butterfly
+  float off = butterfly16(part, lane);
+  int roff = 0;
+  float c_lo = 0.f, c_hi = 0.f, locx = 0.f;
+  const int LP = L * P;
+  if (k_own < LP) {
+    off += off_hs[row * LP + k_own];
+    const int l = k_own / P;
+    const int T = (int)shapes[2 * l + 1];
+    const float *rp = ref + (row * L + l) * RD;
+    if (RD == 1) locx = rp[0] + off / (float)T;                              // ms_deform_attn_for_caption.py:108-109
+    else locx = rp[0] + off / (float)P * rp[1] * 0.5f;                       // :110-112
+    int r;
+    border_coef(locx, T, r, c_lo, c_hi);
+    roff = (int)lsi[l] + r;
+  }
+  if (dbg_loc && (lane & 3) == 0 && k_own < LP) dbg_loc[row * LP + k_own] = locx;
+
+  // ---- pass 1: attention logits from the ctx2att half ------------------------------------------------------
+  const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * kC);
+  const float4 ta = ah4[lane], tb = ah4[64 + lane];
+  const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
+  const float4 *slab4 = reinterpret_cast<const float4 *>(slab) + (int64_t)b * S * (2 * kC / 4);
+  float e[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    e[k] = 0.f;
+    if (k < LP) {
+      const int rr = __builtin_amdgcn_readlane(roff, 4 * k);
+      const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_lo), 4 * k));
+      const float ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_hi), 4 * k));
+      const int rr1 = min(rr + 1, S - 1);           // c_hi == 0 whenever rr + 1 leaves the level (T_l == 1)
+      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4) + kC / 4;       // ctx2att half of row rr
+      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4) + kC / 4;
+      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      float s = 0.f;
+      s = fmaf(qa.x, fast_tanh(fmaf(cl, l0.x, fmaf(ch, u0.x, ta.x))), s);
+      s = fmaf(qa.y, fast_tanh(fmaf(cl, l0.y, fmaf(ch, u0.y, ta.y))), s);
+      s = fmaf(qa.z, fast_tanh(fmaf(cl, l0.z, fmaf(ch, u0.z, ta.z))), s);
+      s = fmaf(qa.w, fast_tanh(fmaf(cl, l0.w, fmaf(ch, u0.w, ta.w))), s);
+      s = fmaf(qb.x, fast_tanh(fmaf(cl, l1.x, fmaf(ch, u1.x, tb.x))), s);
+      s = fmaf(qb.y, fast_tanh(fmaf(cl, l1.y, fmaf(ch, u1.y, tb.y))), s);
+      s = fmaf(qb.z, fast_tanh(fmaf(cl, l1.z, fmaf(ch, u1.z, tb.z))), s);
+      s = fmaf(qb.w, fast_tanh(fmaf(cl, l1.w, fmaf(ch, u1.w, tb.w))), s);
+      e[k] = s;
+    }
+  }
+  float ek = butterfly16(e, lane) + alpha_b;
+  if (k_own >= LP) ek = -INFINITY;
+  const float m = groups_max(ek);
+  const float pexp = (k_own < LP) ? __expf(ek - m) : 0.f;
+  const float alpha = pexp / groups_sum(pexp);
+  if (dbg_alpha && (lane & 3) == 0 && k_own < LP) dbg_alpha[row * LP + k_own] = alpha;
+  const float a_lo = alpha * c_lo, a_hi = alpha * c_hi;
+
+  // ---- pass 2: weighted sum of the value half --------------------------------------------------------------
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < LP) {
+      const int rr = __builtin_amdgcn_readlane(roff, 4 * k);
+      const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_lo), 4 * k));
+      const float ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_hi), 4 * k));
+      const int rr1 = min(rr + 1, S - 1);
+      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4);                // value half of row rr
+      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4);
+      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      fma8(cl, l0, l1, acc);
+      fma8(ch, u0, u1, acc);
+    }
+  }
+  float4 *o4 = reinterpret_cast<float4 *>(att_res + row * kC);
+  o4[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  o4[64 + lane] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// greedy-decoding epilogue: one workgroup per row: argmax (first maximal index) and log_softmax at the argmax
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_row_argmax_lse(const float *__restrict__ logits, int R, int V,
+                                                        int64_t *__restrict__ idx, float *__restrict__ logp) {
+  __shared__ float s_m[4], s_s[4];
+  __shared__ int s_i[4];
+  const int row = blockIdx.x;
+  const float *x = logits + (int64_t)row * V;
+  float m = -INFINITY, s = 0.f;
+  int am = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    const float v = x[i];
+    if (v > m) { s = s * __expf(m - v) + 1.f; m = v; am = i; }
+    else { s += __expf(v - m); }
+  }
+  // wave reduction of (m, s, am)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const int a2 = __shfl_xor(am, o, 64);
+    const float mn = fmaxf(m, m2);
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    am = (m2 > m || (m2 == m && a2 < am)) ? a2 : am;
+    m = mn;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { s_m[w] = m; s_s[w] = s; s_i[w] = am; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float M = s_m[0], Ssum = s_s[0];
+    int A = s_i[0];
+    for (int k = 1; k < 4; ++k) {
+      const float mn = fmaxf(M, s_m[k]);
+      Ssum = Ssum * __expf(M - mn) + s_s[k] * __expf(s_m[k] - mn);
+      A = (s_m[k] > M || (s_m[k] == M && s_i[k] < A)) ? s_i[k] : A;
+      M = mn;
+    }
+    idx[row] = A;
+    logp[row] = -logf(Ssum);          // x_max - (x_max + log sum exp(x - x_max))
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward of the unweighted sampler: gsamp (B*M, D, Q, L, P) -> grad_value (atomics), grad_loc (B,Q,M,L,P,2)
+// one wavefront per (b,q,m); generic D / HxW / fp32,fp64 (the teacher-forced captioner touches few rows)
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ inline T gfloor_(T x);
+template <>
+__device__ inline float gfloor_<float>(float x) { return floorf(x); }
+template <>
+__device__ inline double gfloor_<double>(double x) { return floor(x); }
+
+template <typename T>
+__device__ inline T pix_(T loc, int size, int pad, T &dmul) {
+  if (pad == GVL_PAD_ZEROS) { dmul = (T)size; return loc * (T)size - (T)0.5; }
+  T g = (T)2 * loc - (T)1;
+  T x = ((g + (T)1) * (T)size - (T)1) / (T)2;
+  T mx = (T)(size - 1);
+  if (!(x > (T)0)) { dmul = (T)0; return (T)0; }
+  if (x >= mx) { dmul = (T)0; return mx; }
+  dmul = (T)size;
+  return x;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_sample_bwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                    const int64_t *__restrict__ lsi, const T *__restrict__ loc,
+                                                    const T *__restrict__ gsamp, int B, int S, int M, int D, int L,
+                                                    int Q, int P, int pad, T *__restrict__ gvalue,
+                                                    T *__restrict__ gloc) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int64_t ntup = (int64_t)B * Q * M;
+  const int64_t rowstride = (int64_t)M * D;
+  for (int64_t tup = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); tup < ntup; tup += (int64_t)gridDim.x * wpb) {
+    const int m = (int)(tup % M);
+    const int64_t bq = tup / M;
+    const int q = (int)(bq % Q), b = (int)(bq / Q);
+    const int64_t wb = tup * L * P;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const int64_t voff = ((int64_t)b * S + lsi[l]) * rowstride + (int64_t)m * D;
+      for (int p = 0; p < P; ++p) {
+        const int64_t si = wb + l * P + p;
+        T dmx, dmy;
+        const T w_im = pix_(loc[si * 2], W, pad, dmx), h_im = pix_(loc[si * 2 + 1], H, pad, dmy);
+        const bool valid = pad == GVL_PAD_BORDER || (h_im > (T)-1 && w_im > (T)-1 && h_im < (T)H && w_im < (T)W);
+        T ax = (T)0, ay = (T)0;
+        if (valid) {
+          const int hl = (int)gfloor_<T>(h_im), wl = (int)gfloor_<T>(w_im);
+          const T lh = h_im - (T)hl, lw = w_im - (T)wl, hh = (T)1 - lh, hw = (T)1 - lw;
+          const bool hl_ok = hl >= 0 && hl <= H - 1, hh_ok = hl + 1 >= 0 && hl + 1 <= H - 1;
+          const bool wl_ok = wl >= 0 && wl <= W - 1, wh_ok = wl + 1 >= 0 && wl + 1 <= W - 1;
+          const int64_t i00 = (int64_t)(hl * W + wl) * rowstride, i01 = (int64_t)(hl * W + wl + 1) * rowstride;
+          const int64_t i10 = (int64_t)((hl + 1) * W + wl) * rowstride, i11 = (int64_t)((hl + 1) * W + wl + 1) * rowstride;
+          for (int d = lane; d < D; d += 64) {
+            const T g = gsamp[(((((int64_t)b * M + m) * D + d) * Q + q) * L + l) * P + p];
+            T gh = (T)0, gw = (T)0;
+            if (hl_ok && wl_ok) { const T v = value[voff + i00 + d]; gh -= hw * v; gw -= hh * v; atomicAdd(gvalue + voff + i00 + d, hh * hw * g); }
+            if (hl_ok && wh_ok) { const T v = value[voff + i01 + d]; gh -= lw * v; gw += hh * v; atomicAdd(gvalue + voff + i01 + d, hh * lw * g); }
+            if (hh_ok && wl_ok) { const T v = value[voff + i10 + d]; gh += hw * v; gw -= lh * v; atomicAdd(gvalue + voff + i10 + d, lh * hw * g); }
+            if (hh_ok && wh_ok) { const T v = value[voff + i11 + d]; gh += lw * v; gw += lh * v; atomicAdd(gvalue + voff + i11 + d, lh * lw * g); }
+            ax += dmx * gw * g;
+            ay += dmy * gh * g;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); }
+        if (lane == 0) { gloc[si * 2] = ax; gloc[si * 2 + 1] = ay; }
+      }
+    }
+  }
+}
+
+template <typename T>
+int sample_bwd_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *gsamp, int B,
+                    int S, int M, int D, int L, int Q, int P, int pad, T *gvalue, T *gloc, hipStream_t st) {
+  if (B < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Q < 0 || P <= 0 || (pad != 0 && pad != 1))
+    return fail(GVL_EINVAL, "gvl_msda_sample_backward: bad arguments");
+  const size_t gv_bytes = (size_t)B * S * M * D * sizeof(T);
+  if (gv_bytes) {
+    if (!gvalue) return fail(GVL_EINVAL, "gvl_msda_sample_backward: null pointer");
+    hipError_t e = hipMemsetAsync(gvalue, 0, gv_bytes, st);
+    if (e != hipSuccess) return fail((int)e, "gvl_msda_sample_backward: memset failed: %s", hipGetErrorString(e));
+  }
+  const int64_t ntup = (int64_t)B * Q * M;
+  if (ntup == 0) return 0;
+  if (!value || !shapes || !lsi || !loc || !gsamp || !gloc)
+    return fail(GVL_EINVAL, "gvl_msda_sample_backward: null pointer");
+  int64_t blocks = (ntup + 3) / 4;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  return gvl::launch(GVL_PROF_SAMPLE_BWD, Q, B, "k_sample_bwd", k_sample_bwd<T>, dim3((unsigned)blocks), dim3(256), 0,
+                     st, value, shapes, lsi, loc, gsamp, B, S, M, D, L, Q, P, pad, gvalue, gloc);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                       const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
+                       const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
+                       float *att_res, float *dbg_alpha, float *dbg_loc, void *stream) {
+  if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
+    return fail(GVL_EINVAL, "gvl_cap_attend_f32: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", C, L,
+                P, RD);
+  if ((int64_t)B * Q == 0) return 0;
+  if (!slab || !shapes || !lsi || !ref || !off_hs || !h || !w_off_h || !att_h || !alpha_w || !att_res)
+    return fail(GVL_EINVAL, "gvl_cap_attend_f32: null pointer");
+  const int vids_per_group = (B + 7) / 8;
+  const int rows_per_group = vids_per_group * Q;
+  const int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
+  return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", k_cap_attend, dim3(8 * blocks_per_group),
+                     dim3(kWaves * 64), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
+                     alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_res, dbg_alpha, dbg_loc);
+}
+
+int gvl_row_argmax_lse_f32(const float *logits, int R, int V, int64_t *idx, float *logp, void *stream) {
+  if (R < 0 || V <= 0) return fail(GVL_EINVAL, "gvl_row_argmax_lse_f32: bad sizes");
+  if (R == 0) return 0;
+  if (!logits || !idx || !logp) return fail(GVL_EINVAL, "gvl_row_argmax_lse_f32: null pointer");
+  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_row_argmax_lse", k_row_argmax_lse, dim3(R), dim3(256), 0,
+                     (hipStream_t)stream, logits, R, V, idx, logp);
+}
+
+int gvl_msda_sample_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                                 const float *grad_sample, int B, int S, int M, int D, int L, int Q, int P,
+                                 int pad_mode, float *grad_value, float *grad_loc, void *stream) {
+  return sample_bwd_impl<float>(value, shapes, lsi, loc, grad_sample, B, S, M, D, L, Q, P, pad_mode, grad_value,
+                                grad_loc, (hipStream_t)stream);
+}
+int gvl_msda_sample_backward_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc,
+                                 const double *grad_sample, int B, int S, int M, int D, int L, int Q, int P,
+                                 int pad_mode, double *grad_value, double *grad_loc, void *stream) {
+  return sample_bwd_impl<double>(value, shapes, lsi, loc, grad_sample, B, S, M, D, L, Q, P, pad_mode, grad_value,
+                                 grad_loc, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// gvl_common.hpp -- internals shared by the translation units of libgvl_msda.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <mutex>
+#include <vector>
+
+#include "gvl_msda.h"
+
+namespace gvl {
+
+inline thread_local char g_err[512] = "";
+
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---- in-library kernel timing: exact begin/end stamps of individual dispatches (hipExtLaunchKernel events) ----
+struct ProfEntry {
+  hipEvent_t start, stop;
+  int tag, a, b;
+};
+struct Profiler {
+  std::mutex mu;
+  bool on = false;
+  std::vector<ProfEntry> entries;
+};
+inline Profiler &profiler() {
+  static Profiler p;
+  return p;
+}
+
+template <typename K, typename... Args>
+inline int launch(int tag, int meta_a, int meta_b, const char *what, K kernel, dim3 grid, dim3 block, size_t lds,
+                  hipStream_t st, Args... args) {
+  Profiler &p = profiler();
+  if (p.on) {
+    ProfEntry e;
+    e.tag = tag; e.a = meta_a; e.b = meta_b;
+    if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess)
+      return fail(GVL_EINVAL, "gvl: cannot create profiling events");
+    hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, e.start, e.stop, 0, args...);
+    std::lock_guard<std::mutex> g(p.mu);
+    p.entries.push_back(e);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail((int)err, "gvl: %s launch failed: %s", what, hipGetErrorString(err));
+  return 0;
+}
+
+template <typename K>
+inline int ensure_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail((int)e, "gvl: cannot raise dynamic LDS to %zu: %s", bytes, hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace gvl

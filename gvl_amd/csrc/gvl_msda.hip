@@ -18,27 +18,21 @@
 // Arithmetic follows /root/reference/pdvc/ops/src/cuda/ms_deform_im2col_cuda.cuh (cited per function) for
 // pad_mode = zeros and ATen's grid_sampler(border, align_corners=False) for pad_mode = border.
 #include <hip/hip_runtime.h>
-#include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include "gvl_common.hpp"
 #include "gvl_msda.h"
 
 namespace {
 
-thread_local char g_err[512] = "";
+using gvl::fail;
+using gvl::ensure_lds;
+
 thread_local int g_last_impl = 0;
 int g_impl = -1;  // -1 = read the environment on first use
-
-int fail(int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
 
 int impl_mode() {
   if (g_impl < 0) {
@@ -528,12 +522,6 @@ bool temporal_host(const int64_t *shapes_host, const int64_t *lsi_host, int L, i
   return run == S;
 }
 
-int launch_status(const char *what) {
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail((int)e, "gvl_msda: %s launch failed: %s", what, hipGetErrorString(e));
-  return 0;
-}
-
 int pick_chunks(const char *env, int BM, int Q, int target_wgs) {
   int n = env_int(env, 0);
   if (n <= 0) n = (target_wgs + BM - 1) / BM;
@@ -543,23 +531,14 @@ int pick_chunks(const char *env, int BM, int Q, int target_wgs) {
   return n;
 }
 
-template <typename K>
-int ensure_lds(K kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return 0;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return fail((int)e, "gvl_msda: cannot raise dynamic LDS to %zu: %s", bytes, hipGetErrorString(e));
-  return 0;
-}
-
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *attn, int B, int S,
                  int M, int D, int L, int Q, int P, int pad, const int64_t *shapes_host, const int64_t *lsi_host,
                  T *out, hipStream_t st) {
   if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
-  if (!value || !shapes || !lsi || !loc || !attn || !out) return fail(GVL_EINVAL, "gvl_msda_forward: null pointer");
   const int64_t n = (int64_t)B * Q * M * D;
-  if (n == 0) return 0;
+  if (n == 0) return 0;                                  // empty query set / batch: nothing to write
+  if (!value || !shapes || !lsi || !loc || !attn || !out) return fail(GVL_EINVAL, "gvl_msda_forward: null pointer");
   const int mode = impl_mode();
   const size_t lds = (size_t)(S + 1) * 64 * sizeof(float);
   const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && S > 0 &&
@@ -570,33 +549,31 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
       const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 768);
       auto kern = pad == kPadZeros ? k_fwd_t1d_d64<kPadZeros> : k_fwd_t1d_d64<kPadBorder>;
       if (int rc = ensure_lds(kern, lds)) return rc;
-      hipLaunchKernelGGL(kern, dim3(nchunk * B * M), dim3(256), lds, st, (const float *)value, shapes, lsi,
-                         (const float *)loc, (const float *)attn, B, S, M, L, Q, P, nchunk, (float *)out);
       g_last_impl = 2;
-      return launch_status("k_fwd_t1d_d64");
+      return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(256), lds, st,
+                         (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn, B, S, M, L, Q, P,
+                         nchunk, (float *)out);
     }
   }
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL((k_fwd_generic<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi, loc, attn,
-                     B, S, M, D, L, Q, P, pad, out);
   g_last_impl = 1;
-  return launch_status("k_fwd_generic");
+  return gvl::launch(GVL_PROF_FWD_GENERIC, Q, B, "k_fwd_generic", k_fwd_generic<T, false>, dim3((unsigned)blocks),
+                     dim3(256), 0, st, value, shapes, lsi, loc, attn, B, S, M, D, L, Q, P, pad, out);
 }
 
 template <typename T>
 int sample_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, int B, int S, int M, int D,
                 int L, int Q, int P, int pad, T *sample, hipStream_t st) {
   if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
-  if (!value || !shapes || !lsi || !loc || !sample) return fail(GVL_EINVAL, "gvl_msda_sample: null pointer");
   const int64_t n = (int64_t)B * Q * M * D;
   if (n == 0) return 0;
+  if (!value || !shapes || !lsi || !loc || !sample) return fail(GVL_EINVAL, "gvl_msda_sample: null pointer");
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL((k_fwd_generic<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi, loc,
-                     (const T *)nullptr, B, S, M, D, L, Q, P, pad, sample);
   g_last_impl = 1;
-  return launch_status("k_fwd_generic<sample>");
+  return gvl::launch(GVL_PROF_SAMPLE, Q, B, "k_fwd_generic<sample>", k_fwd_generic<T, true>, dim3((unsigned)blocks),
+                     dim3(256), 0, st, value, shapes, lsi, loc, (const T *)nullptr, B, S, M, D, L, Q, P, pad, sample);
 }
 
 int bwd_chunks(int B, int M, int Q) { return pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256); }
@@ -606,10 +583,9 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                   const T *gout, int B, int S, int M, int D, int L, int Q, int P, int pad, const int64_t *shapes_host,
                   const int64_t *lsi_host, T *gvalue, T *gloc, T *gattn, void *ws, size_t ws_bytes, hipStream_t st) {
   if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
-  if (!value || !shapes || !lsi || !loc || !attn || !gout || !gvalue || !gloc || !gattn)
-    return fail(GVL_EINVAL, "gvl_msda_backward: null pointer");
   const size_t gv_bytes = (size_t)B * S * M * D * sizeof(T);
   const int64_t ntup = (int64_t)B * Q * M;
+  if (gv_bytes && !gvalue) return fail(GVL_EINVAL, "gvl_msda_backward: null pointer");
   if (ntup == 0) {
     if (gv_bytes) {
       hipError_t e = hipMemsetAsync(gvalue, 0, gv_bytes, st);
@@ -617,6 +593,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
     }
     return 0;
   }
+  if (!value || !shapes || !lsi || !loc || !attn || !gout || !gvalue || !gloc || !gattn)
+    return fail(GVL_EINVAL, "gvl_msda_backward: null pointer");
   const int mode = impl_mode();
   const size_t lds = (size_t)(S + 1) * 64 * sizeof(float) * 2;
   const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && S > 0 &&
@@ -634,17 +612,17 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       }
       auto kern = pad == kPadZeros ? k_bwd_t1d_d64<kPadZeros> : k_bwd_t1d_d64<kPadBorder>;
       if (int rc = ensure_lds(kern, lds)) return rc;
-      hipLaunchKernelGGL(kern, dim3(nchunk * B * M), dim3(512), lds, st, (const float *)value, shapes, lsi,
-                         (const float *)loc, (const float *)attn, (const float *)gout, B, S, M, L, Q, P, nchunk, part,
-                         (float *)gloc, (float *)gattn);
-      if (int rc = launch_status("k_bwd_t1d_d64")) return rc;
+      if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(512), lds, st,
+                               (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn,
+                               (const float *)gout, B, S, M, L, Q, P, nchunk, part, (float *)gloc, (float *)gattn))
+        return rc;
       if (nchunk > 1) {
         const int64_t count4 = (int64_t)B * S * M * 16;
         int64_t blocks = (count4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)part, nchunk,
-                           count4, (float4 *)gvalue);
-        if (int rc = launch_status("k_sum_partials")) return rc;
+        if (int rc = gvl::launch(GVL_PROF_SUM_PARTIALS, Q, B, "k_sum_partials", k_sum_partials, dim3((unsigned)blocks),
+                                 dim3(256), 0, st, (const float4 *)part, nchunk, count4, (float4 *)gvalue))
+          return rc;
       }
       g_last_impl = 2;
       return 0;
@@ -654,10 +632,9 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   if (e != hipSuccess) return fail((int)e, "gvl_msda_backward: memset failed: %s", hipGetErrorString(e));
   int64_t blocks = (ntup + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;
-  hipLaunchKernelGGL((k_bwd_generic<T>), dim3((unsigned)blocks), dim3(256), 0, st, value, shapes, lsi, loc, attn, gout,
-                     B, S, M, D, L, Q, P, pad, gvalue, gloc, gattn);
   g_last_impl = 1;
-  return launch_status("k_bwd_generic");
+  return gvl::launch(GVL_PROF_BWD_GENERIC, Q, B, "k_bwd_generic", k_bwd_generic<T>, dim3((unsigned)blocks), dim3(256),
+                     0, st, value, shapes, lsi, loc, attn, gout, B, S, M, D, L, Q, P, pad, gvalue, gloc, gattn);
 }
 
 }  // namespace
@@ -665,9 +642,37 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
 extern "C" {
 
 int gvl_msda_abi_version(void) { return GVL_MSDA_ABI_VERSION; }
-const char *gvl_last_error(void) { return g_err; }
+const char *gvl_last_error(void) { return gvl::g_err; }
 void gvl_msda_set_impl(int impl) { g_impl = (impl >= 0 && impl <= 2) ? impl : 0; }
 int gvl_msda_last_impl(void) { return g_last_impl; }
+
+int gvl_prof_enable(int on) {
+  gvl::Profiler &p = gvl::profiler();
+  std::lock_guard<std::mutex> g(p.mu);
+  p.on = on != 0;
+  return 0;
+}
+
+int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity) {
+  gvl::Profiler &p = gvl::profiler();
+  std::lock_guard<std::mutex> g(p.mu);
+  int n = 0;
+  for (auto &e : p.entries) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.stop) == hipSuccess && hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess &&
+        n < capacity && us) {
+      us[n] = ms * 1000.f;
+      if (tag) tag[n] = e.tag;
+      if (meta_a) meta_a[n] = e.a;
+      if (meta_b) meta_b[n] = e.b;
+      ++n;
+    }
+    hipEventDestroy(e.start);
+    hipEventDestroy(e.stop);
+  }
+  p.entries.clear();
+  return n;
+}
 
 int gvl_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                          const float *attn, int B, int S, int M, int D, int L, int Q, int P, int pad_mode,

@@ -1,0 +1,278 @@
+"""Temporal deformable transformer -- host-side mirror of pdvc/deformable_transformer.py on the HIP MSDA op.
+
+The public surface is the reference's: ``DeformableTransformer`` with ``prepare_encoder_inputs`` (:85),
+``forward_encoder`` (:117), ``prepare_decoder_input_query`` (:128), ``prepare_decoder_input_proposal`` (:137),
+``forward_decoder`` (:154), and ``build_deforamble_transformer(args)`` (:353; the reference's spelling is kept).
+Sub-module / parameter names match the reference so that its checkpoints load with ``strict=True``:
+``encoder.layers.N.{self_attn,norm1,linear1,linear2,norm2}``, ``decoder.layers.N.{cross_attn,norm1,self_attn,
+norm2,linear1,linear2,norm3}``, ``decoder.bbox_head`` (set by PDVC), ``level_embed, pos_trans, pos_trans_norm,
+reference_points``.
+
+MI355X notes: level lengths are Python ints here, so the (L,)-shaped ``temporal_shapes`` / ``level_start_index``
+tensors carry a host copy (``_gvl_host_lengths``) and nothing on the path reads the device back
+(the reference's ``assert input_spatial_shapes.sum() == Len_in`` synchronises every layer).
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .ops.modules import MSDeformAttn
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    """misc/detr_utils/misc.py:582-586"""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _activation(name):
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    if name == "glu":
+        return F.glu
+    raise RuntimeError(F"activation should be relu/gelu, not {name}.")
+
+
+def make_level_tensors(lengths, device):
+    """(temporal_shapes (L,), level_start_index (L,)) int64 on `device`, each carrying host copies."""
+    lengths = [int(x) for x in lengths]
+    starts = [0]
+    for x in lengths[:-1]:
+        starts.append(starts[-1] + x)
+    ts = torch.tensor(lengths, dtype=torch.long, device=device)
+    ls = torch.tensor(starts, dtype=torch.long, device=device)
+    ts._gvl_host_lengths = (lengths, starts)
+    ls._gvl_host_lengths = (lengths, starts)
+    return ts, ls
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    """:159-199 -- x = LN(x + drop(MSDA(x + pos, ref, x)));  x = LN(x + drop(W2 drop(act(W1 x))))"""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, src):
+        return self.norm2(src + self.dropout3(self.linear2(self.dropout2(self.activation(self.linear1(src))))))
+
+    def forward(self, src, pos, reference_points, temporal_shapes, level_start_index, padding_mask=None):
+        attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, temporal_shapes,
+                              level_start_index, padding_mask)
+        return self.forward_ffn(self.norm1(src + self.dropout1(attn)))
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(temporal_shapes, valid_ratios, device):
+        """:209-218 -- centre of every frame of every level, normalised by that level's valid length and re-scaled
+        to every target level: (B, S, L, 1)."""
+        host = getattr(temporal_shapes, "_gvl_host_lengths", None)
+        lengths = host[0] if host is not None else [int(x) for x in temporal_shapes.tolist()]
+        per_level = []
+        for lvl, T in enumerate(lengths):
+            centres = torch.linspace(0.5, T - 0.5, T, dtype=torch.float32, device=device)
+            per_level.append(centres[None] / (valid_ratios[:, None, lvl] * T))
+        ref = torch.cat(per_level, 1)
+        return (ref[:, :, None] * valid_ratios[:, None])[..., None]
+
+    def forward(self, src, temporal_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
+        ref = self.get_reference_points(temporal_shapes, valid_ratios, device=src.device)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, ref, temporal_shapes, level_start_index, padding_mask)
+        return out
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    """:229-280 -- MHA over the queries, MSDA cross-attention into the memory, FFN; post-norm."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, tgt):
+        return self.norm3(tgt + self.dropout4(self.linear2(self.dropout3(self.activation(self.linear1(tgt))))))
+
+    def forward(self, tgt, query_pos, reference_points, src, src_temporal_shapes, level_start_index,
+                src_padding_mask=None, query_mask=None):
+        qk = self.with_pos_embed(tgt, query_pos).transpose(0, 1)
+        sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask)[0].transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(sa))
+        ca = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_temporal_shapes,
+                             level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(ca))
+        return self.forward_ffn(tgt)
+
+
+class DeformableTransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = _clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.bbox_head = None          # set by PDVC when with_box_refine (pdvc.py:134-140)
+
+    def forward(self, tgt, reference_points, src, src_temporal_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None, query_padding_mask=None, disable_iterative_refine=False):
+        out = tgt
+        hs, refs = [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 2:                                       # (centre, length): :302-304
+                ref_in = reference_points[:, :, None] * torch.stack([src_valid_ratios] * 2, -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 1
+                ref_in = reference_points[:, :, None] * src_valid_ratios[:, None, :, None]
+            out = layer(out, query_pos, ref_in, src, src_temporal_shapes, src_level_start_index, src_padding_mask,
+                        query_padding_mask)
+            if not disable_iterative_refine and self.bbox_head is not None:           # :314-324
+                delta = self.bbox_head[lid](out)
+                prior = inverse_sigmoid(reference_points)
+                if reference_points.shape[-1] == 2:
+                    new_ref = (delta + prior).sigmoid()
+                else:
+                    new_ref = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
+                reference_points = new_ref.detach()
+            if self.return_intermediate:
+                hs.append(out)
+                refs.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(hs), torch.stack(refs)
+        return out, reference_points
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4, dec_n_points=4,
+                 enc_n_points=4):
+        super().__init__()
+        self.d_model = d_model
+        self.nhead = nhead
+        self.no_encoder = (num_encoder_layers == 0)
+        self.num_feature_levels = num_feature_levels
+        enc_layer = DeformableTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, enc_n_points)
+        self.encoder = DeformableTransformerEncoder(enc_layer, num_encoder_layers)
+        dec_layer = DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, dec_n_points)
+        self.decoder = DeformableTransformerDecoder(dec_layer, num_decoder_layers, return_intermediate_dec)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.pos_trans = nn.Linear(d_model, d_model * 2)
+        self.pos_trans_norm = nn.LayerNorm(d_model * 2)
+        self.reference_points = nn.Linear(d_model, 1)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """:54-63 (same order of RNG consumption): xavier every matrix, then the MSDeformAttn-specific init."""
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.xavier_uniform_(self.reference_points.weight.data, gain=1.0)
+        nn.init.constant_(self.reference_points.bias.data, 0.)
+        nn.init.normal_(self.level_embed)
+
+    # -- proposal -> query embedding (:66-79, :137-151) --------------------------------------------------------
+    def get_proposal_pos_embed(self, proposals):
+        num_pos_feats, temperature, scale = 256, 10000, 2 * math.pi
+        dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=proposals.device)
+        dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+        pos = (proposals.sigmoid() * scale)[:, :, :, None] / dim_t
+        return torch.stack((pos[:, :, :, 0::2].sin(), pos[:, :, :, 1::2].cos()), dim=4).flatten(2)
+
+    def get_valid_ratio(self, mask):
+        return torch.sum(~mask, 1).float() / mask.shape[1]
+
+    def prepare_encoder_inputs(self, srcs, masks, pos_embeds):
+        """:85-115.  srcs[l] (B,C,T_l), masks[l] (B,T_l) True=pad, pos_embeds[l] (B,C,T_l)."""
+        lengths = [int(s.shape[-1]) for s in srcs]
+        src_flatten = torch.cat([s.transpose(1, 2) for s in srcs], 1)
+        mask_flatten = torch.cat(masks, 1)
+        lvl_pos = torch.cat([p.transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)],
+                            1)
+        temporal_shapes, level_start_index = make_level_tensors(lengths, src_flatten.device)
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        return src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos, mask_flatten
+
+    def forward_encoder(self, src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,
+                        mask_flatten):
+        if self.no_encoder:
+            return src_flatten
+        return self.encoder(src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,
+                            mask_flatten)
+
+    def prepare_decoder_input_query(self, memory, query_embed):
+        """:128-135 -- query_embed (Q, 2C) is chunked into (query_pos, tgt) in that order."""
+        bs = memory.shape[0]
+        query_pos, tgt = torch.chunk(query_embed, 2, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        return reference_points, tgt, reference_points, query_pos
+
+    def prepare_decoder_input_proposal(self, gt_reference_points, inversed_input=False):
+        if inversed_input:
+            unact = gt_reference_points
+            gt_reference_points = torch.sigmoid(gt_reference_points)
+        else:
+            unact = inverse_sigmoid(gt_reference_points)
+        emb = self.pos_trans_norm(self.pos_trans(self.get_proposal_pos_embed(unact)))
+        query_pos, tgt = torch.chunk(emb, 2, dim=2)
+        return gt_reference_points, tgt, gt_reference_points, query_pos
+
+    def convert_proposal_to_query(self, gt_reference_points):
+        return self.pos_trans_norm(self.pos_trans(self.get_proposal_pos_embed(inverse_sigmoid(gt_reference_points))))
+
+    def forward_decoder(self, *kargs):
+        return self.decoder(*kargs)
+
+
+def build_deforamble_transformer(args):
+    return DeformableTransformer(
+        d_model=args.hidden_dim, nhead=args.nheads, num_encoder_layers=args.enc_layers,
+        num_decoder_layers=args.dec_layers, dim_feedforward=args.transformer_ff_dim,
+        dropout=args.transformer_dropout_prob, activation="relu", return_intermediate_dec=True,
+        num_feature_levels=args.num_feature_levels, dec_n_points=args.dec_n_points, enc_n_points=args.enc_n_points)

@@ -1,1 +1,1 @@
-from .ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnPadFunction  # noqa: F401
+from .ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnPadFunction, MSDASampleFunction  # noqa: F401

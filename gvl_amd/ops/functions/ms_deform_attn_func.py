@@ -61,3 +61,24 @@ class MSDeformAttnFunction(Function):
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+class MSDASampleFunction(Function):
+    """Differentiable unweighted sampler: ms_deform_attn_core_pytorch(..., return_value=True) (func.py:44-68) with
+    the gradients F.grid_sample would give (w.r.t. value and sampling locations)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, pad_mode):
+        ctx.pad_mode = pad_mode
+        ctx.host = MSDA.host_shapes(value_spatial_shapes, value_level_start_index)
+        out = MSDA.ms_deform_attn_sample(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                         pad_mode)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_sample):
+        value, shapes, lsi, loc = ctx.saved_tensors
+        gv, gl = MSDA.ms_deform_attn_sample_backward(value, shapes, lsi, loc, grad_sample.contiguous(), ctx.pad_mode)
+        return gv, None, None, gl, None

@@ -1,0 +1,349 @@
+"""PDVC orchestrator -- the ``pdvc.pdvc`` contract (``build(args)``, ``PDVC.forward``) on the MI355X hot path.
+
+Mirrors pdvc/pdvc.py:41-314 (model + forward), :434-519 (eval: parallel_prediction_full), :540-660 (train:
+parallel_prediction_matched), :699-884 (caption_prediction / caption_prediction_eval) and :1181-1238 (build), for the
+configuration space of BASELINE.json: ``transformer_input_type='queries'``, LSTM-DSA captioner
+(``caption_decoder_type: standard``), ``enable_contrastive=False`` (the contrastive branch needs the frozen RoBERTa
+text encoder, which SURVEY.md section 2 row 15 places outside the accelerated path -- requesting it raises).
+Sub-module and parameter names equal the reference's (``base_encoder, transformer, caption_head.N, query_embed,
+class_head.N, count_head.N, bbox_head.N.layers.K``) so reference checkpoints load with ``strict=True``;
+``PDVC.forward(dt, criterion, contrastive_criterion, transformer_input_type, eval_mode)`` returns the same
+``(out, loss)`` dictionaries.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .base_encoder import build_base_encoder
+from .CaptioningHead import build_captioner
+from .criterion import SetCriterion
+from .deformable_transformer import build_deforamble_transformer, inverse_sigmoid
+from .matcher import build_matcher
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class MLP(nn.Module):
+    """pdvc.py:1166-1178"""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+class PDVC(nn.Module):
+    def __init__(self, base_encoder, text_encoder, transformer, captioner, num_classes, num_queries,
+                 num_feature_levels, aux_loss=True, with_box_refine=False, opt=None, translator=None):
+        super().__init__()
+        if opt.enable_contrastive or text_encoder is not None:
+            raise NotImplementedError("gvl_amd.PDVC: the contrastive text branch (frozen RoBERTa) is outside the "
+                                      "accelerated path; build with enable_contrastive=False")
+        self.opt = opt
+        self.enable_contrastive = False
+        self.base_encoder = base_encoder
+        self.transformer = transformer
+        self.caption_head = captioner
+        hidden_dim = transformer.d_model
+        self.query_embed = nn.Embedding(num_queries, hidden_dim * 2)
+        if vars(opt).get('support_mlp_class_head', False):
+            self.class_head = MLP(hidden_dim, hidden_dim, num_classes, 3)
+        else:
+            self.class_head = nn.Linear(hidden_dim, num_classes)
+        self.count_head = nn.Linear(hidden_dim, opt.max_eseq_length + 1)
+        self.bbox_head = MLP(hidden_dim, hidden_dim, 2, 3)
+        self.num_feature_levels = num_feature_levels
+        self.aux_loss = aux_loss
+        self.with_box_refine = with_box_refine
+        self.share_caption_head = opt.share_caption_head
+
+        # initialisation, pdvc.py:115-146
+        prior_prob = 0.01
+        if not vars(opt).get('support_mlp_class_head', False):
+            self.class_head.bias.data = torch.ones(num_classes) * (-math.log((1 - prior_prob) / prior_prob))
+        nn.init.constant_(self.bbox_head.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_head.layers[-1].bias.data, 0)
+        num_pred = transformer.decoder.num_layers
+        if self.share_caption_head:
+            self.caption_head = nn.ModuleList([self.caption_head for _ in range(num_pred)])
+        else:
+            self.caption_head = _clones(self.caption_head, num_pred)
+        init_bias = vars(opt).get('box_head_init_bias', -2.0)
+        if with_box_refine:
+            self.class_head = _clones(self.class_head, num_pred)
+            self.count_head = _clones(self.count_head, num_pred)
+            self.bbox_head = _clones(self.bbox_head, num_pred)
+            nn.init.constant_(self.bbox_head[0].layers[-1].bias.data[1:], init_bias)
+            self.transformer.decoder.bbox_head = self.bbox_head          # iterative refinement shares these heads
+        else:
+            nn.init.constant_(self.bbox_head.layers[-1].bias.data[1:], init_bias)
+            self.class_head = nn.ModuleList([self.class_head for _ in range(num_pred)])
+            self.count_head = nn.ModuleList([self.count_head for _ in range(num_pred)])
+            self.bbox_head = nn.ModuleList([self.bbox_head for _ in range(num_pred)])
+            self.transformer.decoder.bbox_head = None
+        self.translator = translator
+        self.disable_mid_caption_heads = opt.disable_mid_caption_heads
+        self.background_embed = None
+
+    # -- parameter groups used by train.py (pdvc.py:170-209) ---------------------------------------------------
+    def get_filter_rule_for_encoder(self):
+        return lambda x: ('input_proj' in x or 'transformer.encoder' in x or 'transformer.level_embed' in x
+                          or 'base_encoder' in x)
+
+    def _named(self, key):
+        return [v for n, v in self.named_parameters() if key in n and v.requires_grad]
+
+    def class_head_paramenters(self):
+        return self._named('class_head')
+
+    def captioner_parameters(self):
+        return self._named('caption_head')
+
+    def bbox_head_parameters(self):
+        return self._named('bbox_head')
+
+    def encoder_decoder_parameters(self):
+        rule = self.get_filter_rule_for_encoder()
+        enc, dec = [], []
+        for name, p in self.named_parameters():
+            (enc if rule(name) else dec).append(p)
+        return enc, dec
+
+    # -- the hot path ---------------------------------------------------------------------------------------------
+    def encode(self, dt):
+        """base encoder -> deformable encoder -> decoder; returns everything the heads need (pdvc.py:250-300)."""
+        vf = dt['video_tensor']
+        mask = ~dt['video_mask']
+        duration = dt['video_length'][:, 1]
+        srcs, masks, pos = self.base_encoder(vf, mask, duration)
+        src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat = self.transformer.prepare_encoder_inputs(srcs, masks, pos)
+        memory = self.transformer.forward_encoder(src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat)
+        return memory, tshapes, lsi, valid_ratios, mask_flat
+
+    def forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
+        N = dt['video_tensor'].shape[0]
+        memory, tshapes, lsi, valid_ratios, mask_flat = self.encode(dt)
+        if transformer_input_type == 'gt_proposals':                              # misc/utils.py:32-43
+            proposals_mask = dt['gt_boxes_mask']
+            criterion.matcher.cost_caption = 0
+            for q_k in ['loss_length', 'loss_ce', 'loss_bbox', 'loss_giou']:
+                for key in criterion.weight_dict.keys():
+                    if q_k in key:
+                        criterion.weight_dict[key] = 0
+            disable_refine = True
+            init_reference, tgt, reference_points, query_embed = \
+                self.transformer.prepare_decoder_input_proposal(dt['gt_boxes'])
+        elif transformer_input_type == 'queries':
+            disable_refine = False
+            query_embed = self.query_embed.weight
+            proposals_mask = torch.ones(N, query_embed.shape[0], device=query_embed.device).bool()
+            init_reference, tgt, reference_points, query_embed = \
+                self.transformer.prepare_decoder_input_query(memory, query_embed)
+        else:
+            raise ValueError('Wrong value of transformer_input_type, got {}'.format(transformer_input_type))
+        hs, inter_references = self.transformer.forward_decoder(tgt, reference_points, memory, tshapes, lsi,
+                                                                valid_ratios, query_embed, mask_flat, proposals_mask,
+                                                                disable_refine)
+        others = {'memory': memory, 'mask_flatten': mask_flat, 'spatial_shapes': tshapes, 'level_start_index': lsi,
+                  'valid_ratios': valid_ratios, 'proposals_mask': proposals_mask, 'text_embed': None,
+                  'event_embed': hs, 'pre_proj_text_embed': None}
+        if eval_mode or self.opt.caption_loss_coef == 0:
+            return self.parallel_prediction_full(dt, criterion, contrastive_criterion, hs, query_embed,
+                                                 init_reference, inter_references, others, disable_refine,
+                                                 self.opt.eval_disable_captioning)
+        if self.opt.set_cost_caption > 0:
+            raise NotImplementedError("set_cost_caption > 0 (caption cost inside the matcher) is not used by any "
+                                      "reference config and is not built")
+        return self.parallel_prediction_matched(dt, criterion, contrastive_criterion, hs, query_embed,
+                                                init_reference, inter_references, others, disable_refine)
+
+    def predict_event_num(self, counter, hs_lid):
+        return counter(torch.max(hs_lid, dim=1, keepdim=False)[0])
+
+    def _layer_heads(self, l_id, hs_lid, reference, disable_refine):
+        """class / count / box heads of one decoder layer (pdvc.py:452-474)."""
+        cls = self.class_head[l_id](hs_lid)
+        cnt = self.predict_event_num(self.count_head[l_id], hs_lid)
+        delta = self.bbox_head[l_id](hs_lid)
+        if disable_refine:
+            coord = reference
+        else:
+            prior = inverse_sigmoid(reference)
+            if prior.shape[-1] == 2:
+                coord = (delta + prior).sigmoid()
+            else:
+                assert prior.shape[-1] == 1
+                coord = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
+        return cls, cnt, coord
+
+    @staticmethod
+    def _no_caption(hs):
+        N_, N_q = hs.shape[:2]
+        probs = {'cap_prob_train': torch.zeros(1, device=hs.device),
+                 'cap_prob_eval': torch.zeros(N_, N_q, 3, device=hs.device)}
+        return probs, torch.zeros(N_, N_q, 3, device=hs.device)
+
+    def _pack(self, hs, classes, counts, coords, cap_probs, seqs):
+        num_pred = hs.shape[0]
+        all_out = {'pred_logits': torch.stack(classes), 'pred_count': torch.stack(counts),
+                   'pred_boxes': torch.stack(coords), 'caption_probs': cap_probs, 'seq': seqs,
+                   'cl_match_mats': [0] * num_pred}
+        return all_out
+
+    def parallel_prediction_full(self, dt, criterion, contrastive_criterion, hs, query_embed, init_reference,
+                                 inter_references, others, disable_iterative_refine, disable_captioning=False):
+        num_pred = hs.shape[0]
+        classes, counts, coords, cap_probs, seqs = [], [], [], [], []
+        for l_id in range(num_pred):
+            reference = init_reference if l_id == 0 else inter_references[l_id - 1]
+            hs_lid = hs[l_id]
+            cls, cnt, coord = self._layer_heads(l_id, hs_lid, reference, disable_iterative_refine)
+            hs_cap = torch.cat([hs_lid, query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
+                                                                                    False) else hs_lid
+            if l_id != num_pred - 1 or disable_captioning:
+                probs, seq = self._no_caption(hs_cap)
+            else:
+                probs, seq = self.caption_prediction_eval(self.caption_head[l_id], dt, hs_cap, reference, others,
+                                                          self.opt.caption_decoder_type)
+            classes.append(cls); counts.append(cnt); coords.append(coord); cap_probs.append(probs); seqs.append(seq)
+        all_out = self._pack(hs, classes, counts, coords, cap_probs, seqs)
+        all_out['event_embed'] = others['event_embed']
+        all_out['event_feat'] = hs
+        out = {k: v[-1] for k, v in all_out.items()}
+        if self.aux_loss:
+            keys = list(all_out.keys())
+            out['aux_outputs'] = [{k: all_out[k][j] for k in keys} for j in range(num_pred - 1)]
+        if criterion is None:                                   # pure-inference use (bench / graph capture)
+            return out, {}
+        loss, last_indices, *_ = criterion(out, dt['video_target'])
+        return out, loss
+
+    def caption_prediction_eval(self, cap_head, dt, hs, reference, others, decoder_type, indices=None):
+        """pdvc.py:885-930 for the 'none' and 'standard' heads."""
+        assert indices is None
+        N_, N_q, C = hs.shape
+        if decoder_type == 'none':
+            return self._no_caption(hs)
+        if decoder_type != 'standard':
+            raise ValueError(f"caption_decoder_type {decoder_type!r} is not built by gvl_amd")
+        with torch.no_grad():
+            seq, cap_prob_eval = cap_head.sample(hs, reference, others)
+            if len(seq):
+                seq = seq.reshape(-1, N_q, seq.shape[-1])
+                cap_prob_eval = cap_prob_eval.reshape(-1, N_q, cap_prob_eval.shape[-1])
+        return {'cap_prob_eval': cap_prob_eval}, seq
+
+    def parallel_prediction_matched(self, dt, criterion, contrastive_criterion, hs, query_embed, init_reference,
+                                    inter_references, others, disable_iterative_refine):
+        """Train step heads (pdvc.py:540-660): set losses on all queries, captioning only on the matched ones."""
+        num_pred = hs.shape[0]
+        classes, counts, coords, cap_probs, seqs = [], [], [], [], []
+        for l_id in range(num_pred):
+            reference = init_reference if l_id == 0 else inter_references[l_id - 1]
+            cls, cnt, coord = self._layer_heads(l_id, hs[l_id], reference, disable_iterative_refine)
+            probs, seq = self._no_caption(hs[l_id])
+            classes.append(cls); counts.append(cnt); coords.append(coord); cap_probs.append(probs); seqs.append(seq)
+        all_out = self._pack(hs, classes, counts, coords, cap_probs, seqs)
+        out = {k: v[-1] for k, v in all_out.items()}
+        if self.aux_loss:
+            keys = list(all_out.keys())
+            out['aux_outputs'] = [{k: all_out[k][j] for k in keys} for j in range(num_pred - 1)]
+            loss, last_indices, aux_indices = criterion(out, dt['video_target'])
+            layers = range(num_pred)
+        else:
+            loss, last_indices = criterion(out, dt['video_target'])
+            aux_indices = None
+            layers = [num_pred - 1]
+        for l_id in layers:
+            reference = init_reference if l_id == 0 else inter_references[l_id - 1]
+            indices = last_indices[0] if l_id == num_pred - 1 else aux_indices[l_id][0]
+            hs_cap = torch.cat([hs[l_id], query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
+                                                                                      False) else hs[l_id]
+            cap_loss, probs, seq = self.caption_prediction(self.caption_head[l_id], dt, hs_cap, reference, others,
+                                                           indices)
+            key = 'loss_caption' if l_id == num_pred - 1 else f'loss_caption_{l_id}'
+            loss[key] = cap_loss
+        out.update({'caption_probs': probs, 'seq': seq})
+        return out, loss
+
+    def caption_prediction(self, cap_head, dt, hs, reference, others, indices):
+        """Teacher-forced caption loss on the matched (query, caption) pairs (pdvc.py:743-884, 'standard' head):
+        per video the matched queries are packed to the front of a (N, max_pairs, .) tensor, padded rows carry an
+        all-False mask and contribute 0 to the mean exactly as in the reference."""
+        N_, N_q, C = hs.shape
+        dev = hs.device
+        gt_nums = dt['gt_boxes_mask'].sum(1).cpu().tolist()
+        cap_base = [0]
+        for n in gt_nums[:-1]:
+            cap_base.append(cap_base[-1] + int(n))
+        max_pairs = max(len(f_) for f_, _ in indices)
+        cap_len = dt['cap_tensor'].shape[-1]
+        hs_m = hs.new_zeros(N_, max_pairs, C)
+        ref_m = hs.new_zeros(N_, max_pairs, reference.shape[-1])
+        seq_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.long, device=dev)
+        mask_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.bool, device=dev)
+        all_caps = []
+        for i, (feat_ids, cap_ids) in enumerate(indices):
+            k = len(feat_ids)
+            f_dev = feat_ids.to(dev)
+            caps = (cap_base[i] + cap_ids).to(dev)
+            hs_m[i, :k] = hs[i, f_dev]
+            ref_m[i, :k] = reference[i, f_dev]
+            seq_m[i, :k] = dt['cap_tensor'][caps]
+            mask_m[i, :k] = dt['cap_mask'][caps].bool()
+            all_caps.append(caps)
+        seq_flat, mask_flat = seq_m.flatten(0, 1), mask_m.flatten(0, 1)
+        if self.training:
+            cap_prob = cap_head(hs_m, ref_m, others, seq_flat)
+            probs, seq = {}, dt['cap_tensor'][torch.cat(all_caps)]
+        else:
+            with torch.no_grad():
+                cap_prob = cap_head(hs_m, ref_m, others, seq_flat)
+                seq, cap_prob_eval = cap_head.sample(hs, reference, others)
+                if len(seq):
+                    seq = seq.reshape(-1, N_q, seq.shape[-1])
+                    cap_prob_eval = cap_prob_eval.reshape(-1, N_q, cap_prob_eval.shape[-1])
+                probs = {'cap_prob_eval': cap_prob_eval}
+        cap_prob = cap_prob.reshape(-1, cap_prob.shape[-2], cap_prob.shape[-1])
+        cap_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
+        return cap_loss.mean(), probs, seq
+
+
+def build(args):
+    """pdvc.py:1181-1238 -> (model, criterion, contrastive_criterion, postprocessors)."""
+    if args.enable_contrastive:
+        raise NotImplementedError("gvl_amd.pdvc.build: enable_contrastive=True needs the frozen RoBERTa text encoder "
+                                  "(out of the accelerated path); set enable_contrastive=False")
+    base_encoder = build_base_encoder(args)
+    transformer = build_deforamble_transformer(args)
+    captioner = build_captioner(args)
+    model = PDVC(base_encoder, None, transformer, captioner, num_classes=args.num_classes,
+                 num_queries=args.num_queries, num_feature_levels=args.num_feature_levels, aux_loss=args.aux_loss,
+                 with_box_refine=args.with_box_refine, opt=args)
+    matcher = build_matcher(args)
+    weight_dict = {'loss_ce': args.cls_loss_coef, 'loss_bbox': args.bbox_loss_coef, 'loss_giou': args.giou_loss_coef,
+                   'loss_counter': args.count_loss_coef, 'loss_caption': args.caption_loss_coef,
+                   'contrastive_loss': vars(args).get('contrastive_loss_start_coef', 0.0)}
+    if args.aux_loss:
+        aux = {}
+        for i in range(args.dec_layers - 1):
+            aux.update({k + f'_{i}': v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    criterion = SetCriterion(args.num_classes, matcher, weight_dict, ['labels', 'boxes', 'cardinality'],
+                             focal_alpha=args.focal_alpha, focal_gamma=args.focal_gamma, opt=args)
+    criterion.to(torch.device(args.device))
+    postprocessors = {}
+    return model, criterion, None, postprocessors

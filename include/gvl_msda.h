@@ -56,6 +56,24 @@ void gvl_msda_set_impl(int impl);
 /* Which family the most recent forward/backward call on this thread used: 1 generic, 2 fast. */
 int gvl_msda_last_impl(void);
 
+/* -- kernel timing inside the library (measurement only; no reference equivalent).  While enabled, every kernel the
+ *    library launches is dispatched with hipExtLaunchKernel start/stop events on the launch stream, i.e. the
+ *    begin/end stamps of that one dispatch (what rocprofv3 --kernel-trace reports), independent of host launch gaps.
+ *    gvl_prof_collect synchronises the recorded events, writes up to `capacity` (duration in microseconds, tag,
+ *    meta_a = Q (rows for the captioner kernels), meta_b = B) tuples in launch order, clears the log and returns the
+ *    count.  Not for use during hipGraph capture. */
+#define GVL_PROF_FWD_T1D 1
+#define GVL_PROF_FWD_GENERIC 2
+#define GVL_PROF_BWD_T1D 3
+#define GVL_PROF_BWD_GENERIC 4
+#define GVL_PROF_SAMPLE 5
+#define GVL_PROF_SUM_PARTIALS 6
+#define GVL_PROF_SAMPLE_BWD 7
+#define GVL_PROF_CAP_ATTEND 8
+#define GVL_PROF_ROW_ARGMAX 9
+int gvl_prof_enable(int on);
+int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
+
 /* -- forward: replaces ms_deform_attn_forward (pdvc/ops/src/ms_deform_attn.h:20-39 ->
  *    ms_deform_attn_cuda_forward, pdvc/ops/src/cuda/ms_deform_attn_cuda.cu:20-80).  `out` is fully overwritten
  *    (the reference zero-fills then accumulates, cu:54); im2col_step batching (cu:50-75) is an artefact of the
@@ -91,6 +109,35 @@ int gvl_msda_backward_f64(const double *value, const int64_t *shapes, const int6
                           int P, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
                           double *grad_value, double *grad_loc, double *grad_attn, void *workspace,
                           size_t workspace_bytes, void *stream);
+
+/* -- backward of gvl_msda_sample: autograd of ms_deform_attn_core_pytorch(return_value=True) (func.py:44-68; the
+ *    reference differentiates through F.grid_sample).  grad_sample (B*M, D, Q, L, P) -> grad_value (B,S,M,D)
+ *    (zero-filled by the callee) and grad_loc (B,Q,M,L,P,2).  Used by the teacher-forced captioner in training. */
+int gvl_msda_sample_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                                 const float *grad_sample, int B, int S, int M, int D, int L, int Q, int P,
+                                 int pad_mode, float *grad_value, float *grad_loc, void *stream);
+int gvl_msda_sample_backward_f64(const double *value, const int64_t *shapes, const int64_t *lsi, const double *loc,
+                                 const double *grad_sample, int B, int S, int M, int D, int L, int Q, int P,
+                                 int pad_mode, double *grad_value, double *grad_loc, void *stream);
+
+/* -- one LSTM-DSA token step's deformable soft attention, fused (inference): replaces, per decoding step,
+ *    MSDeformAttnCap.forward (pdvc/ops/modules/ms_deform_attn_for_caption.py:82-127) + the additive attention of
+ *    ShowAttendTellCore.forward (pdvc/CaptioningHead/LSTM_DSA.py:247-266).
+ *      slab     (B, S, 2C)  [value_proj(memory) (padded rows zeroed) | ctx2att(value_proj(memory))], C = 512
+ *      ref      (B, Q, L, RD) reference points already multiplied by the valid ratios (LSTM_DSA.py:137-141)
+ *      off_hs   (B*Q, L*P)  sampling_offsets bias + the part of the projection that multiplies hs
+ *      h        (B*Q, C)    previous hidden state;  w_off_h (L*P, C) = sampling_offsets.weight[:, :C]
+ *      att_h    (B*Q, C)    h2att(h);  alpha_w (C), alpha_b: alpha_net
+ *      att_res  (B*Q, C)    sum_k softmax_k(alpha_net(tanh(ctx2att(clip_k) + att_h))) * clip_k
+ *    dbg_alpha / dbg_loc (B*Q, L*P) are optional outputs (may be NULL) used by the parity tests. */
+int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                       const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
+                       const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
+                       float *att_res, float *dbg_alpha, float *dbg_loc, void *stream);
+
+/* -- greedy decoding epilogue: idx[r] = argmax_v logits[r, v] (first maximal index), logp[r] = log_softmax(logits[r])
+ *    at that index (LSTM_DSA.py:123 + :166-167), one read of the logits. */
+int gvl_row_argmax_lse_f32(const float *logits, int R, int V, int64_t *idx, float *logp, void *stream);
 
 /* -- Hungarian matcher index path (HOST pointers, host code).  Replaces scipy.optimize.linear_sum_assignment as
  *    called at pdvc/matcher.py:124,126; results are bit-identical to scipy 1.15.3 (same augmenting-path order and

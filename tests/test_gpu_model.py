@@ -1,0 +1,179 @@
+"""GPU parity of the model-level mirror (gvl_amd.pdvc / deformable_transformer / captioner / matcher) against the
+golden vectors the imported reference produced with CUDA-op semantics (zero padding in MSDeformAttn, border in the
+captioner's MSDeformAttnCap) -- tests/golden/pdvc_eval.npz, captioner_step.npz."""
+import pytest
+import torch
+
+from helpers import load, t, pdvc_state, pdvc_dt, maxerr
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(dt, dev):
+    out = dict(dt)
+    for k in ("video_tensor", "video_mask", "video_length"):
+        out[k] = dt[k].to(dev)
+    out["video_target"] = [{k: v.to(dev) for k, v in tg.items()} for tg in dt["video_target"]]
+    return out
+
+
+@pytest.fixture(scope="module")
+def built():
+    from gvl_amd.config import make_opt
+    from gvl_amd.pdvc import build
+    dev = torch.device("cuda:0")
+    f = load("pdvc_eval")
+    opt = make_opt(num_queries=8, feature_dim=64, vocab_size=40, max_caption_len=6, device="cuda")
+    model, criterion, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f), strict=True)
+    model = model.to(dev).eval()
+    return f, model, criterion, dev
+
+
+def test_pdvc_eval_forward_matches_reference(built):
+    f, model, criterion, dev = built
+    dt = to_dev(pdvc_dt(f), dev)
+    with torch.no_grad():
+        memory, tshapes, lsi, vr, mflat = model.encode(dt)
+        out, loss = model(dt, criterion, None, "queries", eval_mode=True)
+    assert maxerr(memory, f["cuda.memory"]) < 2e-4
+    assert maxerr(vr, f["cuda.valid_ratios"]) < 1e-6
+    assert torch.equal(mflat.cpu(), t(f["cuda.mask_flatten"]))
+    assert maxerr(out["event_feat"], f["cuda.hs"][-1]) < 5e-4
+    assert maxerr(out["pred_logits"], f["cuda.pred_logits"]) < 5e-4
+    assert maxerr(out["pred_boxes"], f["cuda.pred_boxes"]) < 1e-4
+    assert maxerr(out["pred_count"], f["cuda.pred_count"]) < 5e-4
+    assert maxerr(out["aux_outputs"][0]["pred_boxes"], f["cuda.aux_pred_boxes"]) < 1e-4
+    assert maxerr(out["aux_outputs"][0]["pred_logits"], f["cuda.aux_pred_logits"]) < 5e-4
+    # greedy captions: token ids identical, log-probs close
+    assert torch.equal(out["seq"].cpu(), t(f["cuda.seq"]))
+    assert maxerr(out["caption_probs"]["cap_prob_eval"], f["cuda.cap_prob_eval"]) < 5e-4
+    # Hungarian index path: bit-exact
+    idx, rl = out["matched_indices"]
+    for i in range(len(idx)):
+        assert torch.equal(torch.stack(idx[i]), t(f[f"cuda.match_{i}"]))
+        assert torch.equal(torch.stack(rl[i]), t(f[f"cuda.rl_match_{i}"]))
+    for k in ("loss_ce", "loss_counter", "loss_bbox", "loss_giou", "loss_self_iou", "cardinality_error",
+              "loss_ce_0", "loss_giou_0"):
+        assert maxerr(loss[k].reshape(()), f[f"cuda.loss.{k}"].reshape(())) < 5e-4, k
+
+
+def test_transformer_stages_match_reference(built):
+    f, model, criterion, dev = built
+    dt = to_dev(pdvc_dt(f), dev)
+    with torch.no_grad():
+        memory, tshapes, lsi, vr, mflat = model.encode(dt)
+        qe = model.query_embed.weight
+        init_ref, tgt, ref, qpos = model.transformer.prepare_decoder_input_query(memory, qe)
+        pmask = torch.ones(2, qe.shape[0], dtype=torch.bool, device=dev)
+        hs, inter = model.transformer.forward_decoder(tgt, ref, memory, tshapes, lsi, vr, qpos, mflat, pmask, False)
+    assert maxerr(init_ref, f["cuda.init_reference"]) < 1e-5
+    assert maxerr(hs, f["cuda.hs"]) < 5e-4
+    assert maxerr(inter, f["cuda.inter_references"]) < 1e-4
+    assert tshapes.tolist() == f["tshapes"].tolist() and lsi.tolist() == f["lsi"].tolist()
+
+
+def test_captioner_single_step_matches_reference(built):
+    f, model, criterion, dev = built
+    c = load("captioner_step")
+    cap = model.caption_head[-1]
+    from gvl_amd.deformable_transformer import make_level_tensors
+    tshapes, lsi = make_level_tensors(c["tshapes"].tolist(), dev)
+    with torch.no_grad():
+        logp, (h1, c1) = cap.get_logprobs_state(t(c["it"]).to(dev), (t(c["h0"])[None].to(dev), t(c["c0"])[None].to(dev)),
+                                                t(c["hs"]).to(dev), t(c["ref_in"]).to(dev), t(c["memory"]).to(dev),
+                                                tshapes, lsi, t(c["mask"]).to(dev))
+    assert maxerr(logp, c["logp"]) < 2e-4
+    assert maxerr(h1[0], c["h1"]) < 5e-5 and maxerr(c1[0], c["c1"]) < 5e-5
+
+
+def test_cap_attend_kernel_matches_unfused_reference_order():
+    """The fused token-step kernel (offset projection + border sampling + additive attention, with ctx2att pushed
+    through the interpolation) against the reference's order of operations restated on the CPU: sample first
+    (oracle C sampler, border), THEN ctx2att / tanh / alpha_net / softmax / weighted sum (LSTM_DSA.py:247-266)."""
+    import numpy as np
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd.deformable_transformer import make_level_tensors
+    from gvl_amd.ops.modules.ms_deform_attn import temporal_shapes_2d
+    from oracle import msda_oracle as O
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, Q, C, L, P = 3, 37, 512, 4, 4
+    lens = [50, 25, 13, 1]                          # includes a one-row level
+    S = sum(lens)
+    for RD in (1, 2):
+        value = torch.randn(B, S, C, generator=g)
+        Wc, bc = torch.randn(C, C, generator=g) / 22, torch.randn(C, generator=g) * 0.1
+        Wh, bh = torch.randn(C, C, generator=g) / 22, torch.randn(C, generator=g) * 0.1
+        Wo, bo = torch.randn(L * P, 2 * C, generator=g) / 16, torch.randn(L * P, generator=g)
+        aw, ab = torch.randn(C, generator=g) / 10, 0.3
+        h = torch.randn(B * Q, C, generator=g) * 0.5
+        hs = torch.randn(B, Q, C, generator=g)
+        ref = torch.rand(B, Q, L, RD, generator=g) * 1.2 - 0.1
+        if RD == 2:
+            ref[..., 1] = ref[..., 1] * 0.4
+        # ---- reference order on the CPU
+        off = torch.nn.functional.linear(torch.cat([h.view(B, Q, C), hs], -1), Wo, bo).view(B, Q, 1, L, P)
+        T = torch.tensor(lens, dtype=torch.float32)
+        if RD == 1:
+            x = ref[:, :, None, :, None, 0] + off / T[None, None, None, :, None]
+        else:
+            x = ref[:, :, None, :, None, 0] + off / P * ref[:, :, None, :, None, 1] * 0.5
+        loc = torch.stack((x, torch.full_like(x, 0.5)), -1)
+        shapes = np.array([(1, t_) for t_ in lens], np.int64)
+        lsi = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        samp = torch.from_numpy(O.msda_sample(value.view(B, S, 1, C).numpy(), shapes, lsi, loc.numpy(), "border"))
+        clip = samp.view(B, C, Q, L * P).permute(0, 2, 3, 1).reshape(B * Q, L * P, C)
+        att = torch.nn.functional.linear(clip, Wc, bc) + torch.nn.functional.linear(h, Wh, bh)[:, None, :]
+        e = torch.tanh(att) @ aw + ab
+        alpha = torch.softmax(e, 1)
+        want = torch.bmm(alpha.unsqueeze(1), clip).squeeze(1)
+        # ---- fused kernel
+        slab = torch.cat([value, torch.nn.functional.linear(value, Wc, bc)], -1).contiguous().to(dev)
+        tsh, lsi_d = make_level_tensors(lens, dev)
+        shapes2d = temporal_shapes_2d(tsh, lsi_d)
+        off_hs = torch.nn.functional.linear(hs, Wo[:, C:], bo).contiguous().to(dev)
+        got, ga, gl = MSDA.cap_attend(slab, shapes2d, lsi_d, ref.contiguous().to(dev), off_hs, h.to(dev),
+                                      Wo[:, :C].contiguous().to(dev),
+                                      torch.nn.functional.linear(h, Wh, bh).to(dev), aw.to(dev), ab, L, P, debug=True)
+        assert maxerr(gl, x.reshape(B * Q, L * P)) < 1e-4
+        assert maxerr(ga, alpha) < 1e-4
+        assert maxerr(got, want) < 1e-4
+
+
+def test_row_argmax_lse_matches_torch():
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(777, 8518, generator=g) * 3
+    x[5, 100] = x[5, 4000] = 50.0              # tie: the first maximal index wins (torch.max semantics)
+    x[6] = 1.0                                  # constant row
+    idx, lp = MSDA.row_argmax_lse(x.to(dev))
+    want_lp, want_idx = torch.max(torch.log_softmax(x.double(), 1), 1)
+    assert torch.equal(idx.cpu()[:5], want_idx[:5]) and int(idx[5]) == 100 and int(idx[6]) == 0
+    assert torch.equal(idx.cpu()[7:], want_idx[7:])
+    assert maxerr(lp, want_lp.float()) < 1e-4
+
+
+def test_sample_function_backward_matches_oracle_autograd():
+    """MSDASampleFunction (HIP sampler + its backward) vs autograd through the oracle's grid_sample restatement."""
+    from gvl_amd.ops.functions import MSDASampleFunction
+    from oracle import torch_ref as R
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    B, M, D, Q, L, P = 2, 1, 96, 5, 3, 4
+    lens = [9, 5, 1]
+    S = sum(lens)
+    value = torch.randn(B, S, M, D, generator=g)
+    loc = torch.rand(B, Q, M, L, P, 2, generator=g) * 1.4 - 0.2
+    loc[..., 1] = 0.5
+    shapes = torch.tensor([(1, t_) for t_ in lens])
+    lsi = torch.tensor([0, 9, 14])
+    gs = torch.randn(B * M, D, Q, L, P, generator=g)
+    v1, l1 = value.clone().requires_grad_(), loc.clone().requires_grad_()
+    R.msda_core(v1, shapes, l1, None, "border", return_value=True).backward(gs)
+    v2, l2 = value.to(dev).requires_grad_(), loc.to(dev).requires_grad_()
+    out = MSDASampleFunction.apply(v2, shapes.to(dev), lsi.to(dev), l2, "border")
+    out.backward(gs.to(dev))
+    assert maxerr(v2.grad, v1.grad) < 1e-4
+    assert maxerr(l2.grad, l1.grad) < 1e-3
