@@ -223,6 +223,9 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
 // ------------------------------------------------------------------------------------------------------
 // greedy-decoding epilogue: one workgroup per row: argmax (first maximal index) and log_softmax at the argmax
 // ------------------------------------------------------------------------------------------------------
+// exp(m - mn) for the running-max rescale; a lane that has seen no element yet carries m = -inf (and sum 0)
+__device__ inline float rescale(float m, float mn) { return m == -INFINITY ? 0.f : __expf(m - mn); }
+
 __global__ void __launch_bounds__(256) k_row_argmax_lse(const float *__restrict__ logits, int R, int V,
                                                         int64_t *__restrict__ idx, float *__restrict__ logp) {
   __shared__ float s_m[4], s_s[4];
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(256) k_row_argmax_lse(const float *__restrict_
     const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
     const int a2 = __shfl_xor(am, o, 64);
     const float mn = fmaxf(m, m2);
-    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    s = s * rescale(m, mn) + s2 * rescale(m2, mn);
     am = (m2 > m || (m2 == m && a2 < am)) ? a2 : am;
     m = mn;
   }
@@ -254,7 +257,7 @@ __global__ void __launch_bounds__(256) k_row_argmax_lse(const float *__restrict_
     int A = s_i[0];
     for (int k = 1; k < 4; ++k) {
       const float mn = fmaxf(M, s_m[k]);
-      Ssum = Ssum * __expf(M - mn) + s_s[k] * __expf(s_m[k] - mn);
+      Ssum = Ssum * rescale(M, mn) + s_s[k] * rescale(s_m[k], mn);
       A = (s_m[k] > M || (s_m[k] == M && s_i[k] < A)) ? s_i[k] : A;
       M = mn;
     }

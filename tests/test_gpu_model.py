@@ -148,6 +148,10 @@ def test_row_argmax_lse_matches_torch():
     x = torch.randn(777, 8518, generator=g) * 3
     x[5, 100] = x[5, 4000] = 50.0              # tie: the first maximal index wins (torch.max semantics)
     x[6] = 1.0                                  # constant row
+    xs = torch.randn(9, 41, generator=g)        # fewer columns than threads
+    i2, l2 = MSDA.row_argmax_lse(xs.to(dev))
+    w2, wi2 = torch.max(torch.log_softmax(xs.double(), 1), 1)
+    assert torch.equal(i2.cpu(), wi2) and maxerr(l2, w2.float()) < 1e-5
     idx, lp = MSDA.row_argmax_lse(x.to(dev))
     want_lp, want_idx = torch.max(torch.log_softmax(x.double(), 1), 1)
     assert torch.equal(idx.cpu()[:5], want_idx[:5]) and int(idx[5]) == 100 and int(idx[6]) == 0
