@@ -317,8 +317,8 @@ __device__ inline void stage_slab(float4 *slab4, const float *value, int b, int 
 // ------------------------------------------------------------------------------------------------------
 // t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
 // ------------------------------------------------------------------------------------------------------
-template <int PAD>
-__global__ void __launch_bounds__(256) k_fwd_t1d_d64(const float *__restrict__ value,
+template <int PAD, bool FULL16>
+__global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ value,
                                                      const int64_t *__restrict__ shapes,
                                                      const int64_t *__restrict__ lsi, const float *__restrict__ loc,
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
@@ -327,32 +327,47 @@ __global__ void __launch_bounds__(256) k_fwd_t1d_d64(const float *__restrict__ v
   const int BM = B * M;
   const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
   const int b = bm / M, m = bm % M;
-  stage_slab(slab4, value, b, m, S, M);
-
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int LP = L * P;
+  // FULL16: L*P == 16 is a compile-time fact, the 16 sample steps below have no branches between them and the
+  // scheduler can put all 32 ds_read_b128 of a pass in flight at once instead of one LDS round trip per step
+  const int LP = FULL16 ? 16 : L * P;
+  const int qper = (Q + nchunk - 1) / nchunk;
+  const int q0 = chunk * qper;
+  const int q1 = min(Q, q0 + qper);
+  // The kernel is a latency chain (launch -> slab -> LDS reads), so every global load that does not depend on LDS
+  // is issued before the slab staging, and each pass prefetches the sampling operands of the next one.
   int Tl = 1, st = 0;
   if (j < LP) {
     const int l = j / P;
     Tl = (int)shapes[2 * l + 1];
     st = (int)lsi[l];
   }
-  const int qper = (Q + nchunk - 1) / nchunk;
-  const int q0 = chunk * qper;
-  const int q1 = min(Q, q0 + qper);
+  int qb = q0 + wave * 4;
+  float2 xy_n = make_float2(0.f, 0.5f);
+  float w_n = 0.f;
+  if (qb < q1 && j < LP) {
+    const int64_t tbn = (((int64_t)b * Q + min(qb + tq, q1 - 1)) * M + m) * LP;
+    xy_n = reinterpret_cast<const float2 *>(loc)[tbn + j];
+    w_n = attn[tbn + j];
+  }
+  stage_slab(slab4, value, b, m, S, M);
   __syncthreads();
 
-  for (int qb = q0 + wave * 4; qb < q1; qb += nw * 4) {
+  for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
     const bool act = q < q1;
-    const int qq = act ? q : q1 - 1;
-    const int64_t tb = (((int64_t)b * Q + qq) * M + m) * LP;
+    const float2 xy = xy_n;
+    const float w = w_n;
+    const int qbn = qb + nw * 4;
+    if (qbn < q1 && j < LP) {
+      const int64_t tbn = (((int64_t)b * Q + min(qbn + tq, q1 - 1)) * M + m) * LP;
+      xy_n = reinterpret_cast<const float2 *>(loc)[tbn + j];
+      w_n = attn[tbn + j];
+    }
     int roff = 0;
     float clo = 0.f, chi = 0.f;
     if (j < LP) {
-      const float2 xy = reinterpret_cast<const float2 *>(loc)[tb + j];
-      const float w = attn[tb + j];
       const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
       roff = (st + c.r) * 16;
       const float ww = w * c.wy;
@@ -361,7 +376,7 @@ __global__ void __launch_bounds__(256) k_fwd_t1d_d64(const float *__restrict__ v
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GVL_FWD_STEP(SI)                                   \
-  if (SI < LP) {                                           \
+  if (FULL16 || SI < LP) {                                 \
     const int ro = row_bcast_i<SI>(roff) + j;              \
     const float a = row_bcast_f<SI>(clo);                  \
     const float c = row_bcast_f<SI>(chi);                  \
@@ -380,53 +395,103 @@ __global__ void __launch_bounds__(256) k_fwd_t1d_d64(const float *__restrict__ v
 }
 
 // ------------------------------------------------------------------------------------------------------
-// t1d_d64 backward.  LDS: value slab (S+1 rows) + private grad_value slab (S+1 rows, channel c = 4j+k stored at
-// column k*16 + j so that the four ds_add_f32 of a DPP row hit 16 distinct banks; rows of a wave stagger k).
+// t1d_d64 backward.  No float atomics anywhere: LDS float atomic adds execute at ~3 cycles PER LANE on gfx950
+// (tools/ubench/lds_atomics.hip: ds_add_f32 200 cycles per wave-instruction vs 35 for ds_add_u32), and global
+// float atomics are bounded at ~1.3 TB/s chip-wide.  grad_value is therefore produced by a GATHER:
+//   phase 1  DPP rows (16 lanes = one (b,q,m)) compute the interpolation coefficients, the two dot products per
+//            sample against the LDS value slab (DPP row all-reduce) -> grad_attn / grad_loc, and record for every
+//            sample an entry (slab row r, w*c_lo, w*c_hi); integer LDS atomics histogram the entries per slab row;
+//   phase 2  block-wide exclusive scan of the histogram, counting-sort of the entry ids by slab row (ds_add_rtn_u32),
+//            the grad_out rows of this workgroup's queries are staged into LDS over the (now dead) value slab;
+//   phase 3  one wavefront per slab row, lane = channel: the row's entries (those with r == s use c_lo, those with
+//            r == s-1 use c_hi) are loaded 64 at a time, (query, coefficient) are broadcast with v_readlane and the
+//            query's grad_out row is read conflict-free from LDS: grad_value[s] = sum coef * grad_out[q].
+// grad_value rows are written once with plain coalesced stores (partial slabs + k_sum_partials when a (b,m) slab
+// is shared by several workgroups).
 // ------------------------------------------------------------------------------------------------------
-template <int PAD>
-__global__ void __launch_bounds__(512) k_bwd_t1d_d64(const float *__restrict__ value,
-                                                     const int64_t *__restrict__ shapes,
-                                                     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
-                                                     const float *__restrict__ attn, const float *__restrict__ gout,
-                                                     int B, int S, int M, int L, int Q, int P, int nchunk,
-                                                     float *__restrict__ gvalue_part, float *__restrict__ gloc,
-                                                     float *__restrict__ gattn) {
+constexpr int kBwdThreads = 1024;
+constexpr int kEntStride = 16;       // entry slot = q_local * 16 + sample
+
+__host__ __device__ inline size_t bwd_lds_bytes(int S, int nq) {
+  const size_t regionA = (size_t)(S + 1 > nq ? S + 1 : nq) * 64 * sizeof(float);
+  const size_t hist = (size_t)(S + 2) * 2 * sizeof(int);
+  const size_t ents = (size_t)nq * kEntStride * 4 * sizeof(int);
+  return regionA + hist + ents;
+}
+
+template <int PAD, bool FULL16>
+__global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__restrict__ value,
+                                                             const int64_t *__restrict__ shapes,
+                                                             const int64_t *__restrict__ lsi,
+                                                             const float *__restrict__ loc,
+                                                             const float *__restrict__ attn,
+                                                             const float *__restrict__ gout, int B, int S, int M, int L,
+                                                             int Q, int P, int nchunk, int qper,
+                                                             float *__restrict__ gvalue_part,
+                                                             float *__restrict__ gloc, float *__restrict__ gattn) {
   extern __shared__ float4 slab4[];
-  float *gslab = reinterpret_cast<float *>(slab4 + (S + 1) * 16);
+  const int rowsA = (S + 1 > qper ? S + 1 : qper);
+  int *cnt = reinterpret_cast<int *>(slab4 + (size_t)rowsA * 16);     // [S+2] histogram, later the fill cursor
+  int *off = cnt + (S + 2);                                           // [S+2] exclusive prefix
+  int *ent_r = off + (S + 2);                                         // [qper*16] slab row or -1
+  float *ent_lo = reinterpret_cast<float *>(ent_r + qper * kEntStride);
+  float *ent_hi = ent_lo + qper * kEntStride;
+  int *sorted = reinterpret_cast<int *>(ent_hi + qper * kEntStride);
+
   const int BM = B * M;
   const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
   const int b = bm / M, m = bm % M;
-  stage_slab(slab4, value, b, m, S, M);
-  for (int i = threadIdx.x; i < (S + 1) * 64; i += blockDim.x) gslab[i] = 0.f;
-
+  const int q0 = chunk * qper;
+  const int q1 = min(Q, q0 + qper);
+  const int nq = q1 - q0;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int LP = L * P;
+  const int LP = FULL16 ? 16 : L * P;
   int Tl = 1, st = 0;
   if (j < LP) {
     const int l = j / P;
     Tl = (int)shapes[2 * l + 1];
     st = (int)lsi[l];
   }
-  const int qper = (Q + nchunk - 1) / nchunk;
-  const int q0 = chunk * qper;
-  const int q1 = min(Q, q0 + qper);
-  // staggered column blocks of this DPP row: step k0 touches column block (k0 + tq) & 3
-  const int col0 = (((0 + tq) & 3) << 4) + j, col1 = (((1 + tq) & 3) << 4) + j;
-  const int col2 = (((2 + tq) & 3) << 4) + j, col3 = (((3 + tq) & 3) << 4) + j;
+  // operands of the first pass are requested before the slab staging; every pass prefetches the next one's
+  int qb = q0 + wave * 4;
+  float2 xy_n = make_float2(0.f, 0.5f);
+  float w_n = 0.f;
+  float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (qb < q1) {
+    const int64_t tupn = ((int64_t)b * Q + min(qb + tq, q1 - 1)) * M + m;
+    if (j < LP) {
+      xy_n = reinterpret_cast<const float2 *>(loc)[tupn * LP + j];
+      w_n = attn[tupn * LP + j];
+    }
+    if (qb + tq < q1) g_n = reinterpret_cast<const float4 *>(gout)[tupn * 16 + j];
+  }
+  stage_slab(slab4, value, b, m, S, M);
+  for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
+  for (int i = threadIdx.x; i < qper * kEntStride; i += blockDim.x) ent_r[i] = -1;
   __syncthreads();
 
-  for (int qb = q0 + wave * 4; qb < q1; qb += nw * 4) {
+  // ---- phase 1 ---------------------------------------------------------------------------------------------
+  for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
     const bool act = q < q1;
     const int qq = act ? q : q1 - 1;
-    const int64_t tup = ((int64_t)b * Q + qq) * M + m;
-    const int64_t tb = tup * LP;
+    const int64_t tb = (((int64_t)b * Q + qq) * M + m) * LP;
+    const float2 xy = xy_n;
+    const float w = w_n;
+    const float4 g = g_n;
+    const int qbn = qb + nw * 4;
+    if (qbn < q1) {
+      const int64_t tupn = ((int64_t)b * Q + min(qbn + tq, q1 - 1)) * M + m;
+      if (j < LP) {
+        xy_n = reinterpret_cast<const float2 *>(loc)[tupn * LP + j];
+        w_n = attn[tupn * LP + j];
+      }
+      g_n = (qbn + tq < q1) ? reinterpret_cast<const float4 *>(gout)[tupn * 16 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     int roff = 0;
-    float clo = 0.f, chi = 0.f, dxlo = 0.f, dxhi = 0.f, dylo = 0.f, dyhi = 0.f, w = 0.f;
+    float clo = 0.f, chi = 0.f, dxlo = 0.f, dxhi = 0.f, dylo = 0.f, dyhi = 0.f;
     if (j < LP) {
-      const float2 xy = reinterpret_cast<const float2 *>(loc)[tb + j];
-      w = attn[tb + j];
       const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
       roff = st + c.r;
       clo = c.c_lo * c.wy;                 // sample      = clo * V[r] + chi * V[r+1]
@@ -435,22 +500,21 @@ __global__ void __launch_bounds__(512) k_bwd_t1d_d64(const float *__restrict__ v
       dxhi = c.dx_hi * c.wy * w;
       dylo = c.c_lo * c.dy * w;            // d out/d y   (cuh:159; H = 1)
       dyhi = c.c_hi * c.dy * w;
+      const float elo = clo * w, ehi = chi * w;
+      if (act && (elo != 0.f || ehi != 0.f)) {          // grad_value += elo * g on row r, ehi * g on row r+1
+        const int e = (q - q0) * kEntStride + j;
+        ent_r[e] = roff;
+        ent_lo[e] = elo;
+        ent_hi[e] = ehi;
+        atomicAdd(&cnt[roff], 1);
+      }
     }
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) g = reinterpret_cast<const float4 *>(gout)[tup * 16 + j];
-    // g rotated by tq so that component index k0 addresses channel 4j + ((k0 + tq) & 3)
-    float g0 = g.x, g1 = g.y, g2 = g.z, g3 = g.w;
-    if (tq & 1) { const float t_ = g0; g0 = g1; g1 = g2; g2 = g3; g3 = t_; }
-    if (tq & 2) { float t_ = g0; g0 = g2; g2 = t_; t_ = g1; g1 = g3; g3 = t_; }
     float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;
 #define GVL_BWD_STEP(SI)                                                      \
-  if (SI < LP) {                                                              \
-    const int rr = row_bcast_i<SI>(roff);                                     \
-    const float a = row_bcast_f<SI>(clo);                                     \
-    const float c = row_bcast_f<SI>(chi);                                     \
-    const float ws = row_bcast_f<SI>(w);                                      \
-    const float4 v0 = slab4[rr * 16 + j];                                     \
-    const float4 v1 = slab4[rr * 16 + 16 + j];                                \
+  if (FULL16 || SI < LP) {                                                    \
+    const int rr = row_bcast_i<SI>(roff) * 16 + j;                            \
+    const float4 v0 = slab4[rr];                                              \
+    const float4 v1 = slab4[rr + 16];                                         \
     const float d0 = row_allsum(dot4(g, v0));                                 \
     const float d1 = row_allsum(dot4(g, v1));                                 \
     if (j == SI) {                                                            \
@@ -458,12 +522,6 @@ __global__ void __launch_bounds__(512) k_bwd_t1d_d64(const float *__restrict__ v
       keep_x = fmaf(dxlo, d0, dxhi * d1);                                     \
       keep_y = fmaf(dylo, d0, dyhi * d1);                                     \
     }                                                                         \
-    const float alo = a * ws, ahi = c * ws;                                   \
-    float *gr = gslab + rr * 64;                                              \
-    atomicAdd(gr + col0, alo * g0); atomicAdd(gr + 64 + col0, ahi * g0);      \
-    atomicAdd(gr + col1, alo * g1); atomicAdd(gr + 64 + col1, ahi * g1);      \
-    atomicAdd(gr + col2, alo * g2); atomicAdd(gr + 64 + col2, ahi * g2);      \
-    atomicAdd(gr + col3, alo * g3); atomicAdd(gr + 64 + col3, ahi * g3);      \
   }
     GVL_BWD_STEP(0) GVL_BWD_STEP(1) GVL_BWD_STEP(2) GVL_BWD_STEP(3)
     GVL_BWD_STEP(4) GVL_BWD_STEP(5) GVL_BWD_STEP(6) GVL_BWD_STEP(7)
@@ -476,14 +534,77 @@ __global__ void __launch_bounds__(512) k_bwd_t1d_d64(const float *__restrict__ v
     }
   }
   __syncthreads();
-  // flush the private slab: (chunk, b, s, m, 64) partial layout == gvalue layout when nchunk == 1
-  float4 *dst = reinterpret_cast<float4 *>(gvalue_part) + ((int64_t)chunk * B * S * M) * 16 + ((int64_t)b * S * M + m) * 16;
-  for (int i = threadIdx.x; i < S * 16; i += blockDim.x) {
-    const int s = i >> 4, jj = i & 15;
-    const float *gr = gslab + s * 64 + jj;
-    float4 v;
-    v.x = gr[0]; v.y = gr[16]; v.z = gr[32]; v.w = gr[48];
-    dst[(int64_t)s * M * 16 + jj] = v;
+
+  // ---- phase 2: exclusive scan of cnt -> off, reset cnt as the fill cursor; stage grad_out rows over the slab ----
+  {
+    __shared__ int wave_tot[kBwdThreads / 64];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < S + 1; base += blockDim.x) {
+      const int i = base + threadIdx.x;
+      const int v = (i < S + 1) ? cnt[i] : 0;
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t_ = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t_;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
+      __syncthreads();
+      int pre = carry_s;
+      for (int k = 0; k < wave; ++k) pre += wave_tot[k];
+      if (i < S + 1) { off[i] = pre + incl - v; cnt[i] = 0; }
+      __syncthreads();
+      if (threadIdx.x == blockDim.x - 1) carry_s = pre + incl;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) off[S + 1] = carry_s;
+  }
+  float4 *G4 = slab4;                                                 // value slab is dead from here on
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(gout) + (((int64_t)b * Q + q0) * M + m) * 16;
+    for (int i = threadIdx.x; i < nq * 16; i += blockDim.x) G4[i] = src[(int64_t)(i >> 4) * M * 16 + (i & 15)];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nq * kEntStride; e += blockDim.x) {
+    const int r = ent_r[e];
+    if (r >= 0) sorted[off[r] + atomicAdd(&cnt[r], 1)] = e;
+  }
+  __syncthreads();
+
+  // ---- phase 3: gather.  A DPP row (16 lanes x float4) owns one slab row; the four rows of a wavefront are
+  // neighbours (similar list lengths).  Lane j fetches entry j of the batch, (query, coefficient) are broadcast
+  // inside the row with row_newbcast and the query's grad_out row is one conflict-free ds_read_b128 per lane.
+  float4 *dst4 = reinterpret_cast<float4 *>(gvalue_part) + ((int64_t)chunk * B * S * M) * 16 + ((int64_t)b * S * M + m) * 16;
+  const int ngroups = blockDim.x >> 4;
+  for (int s = threadIdx.x >> 4; s < S; s += ngroups) {
+    const int a1 = off[s], n1 = off[s + 1] - a1;                      // entries with r == s     -> c_lo
+    const int a0 = s > 0 ? off[s - 1] : 0, n0 = s > 0 ? a1 - a0 : 0;  // entries with r == s - 1 -> c_hi
+    const int n = n1 + n0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < n; base += 16) {
+      const int i = base + j;
+      int tl = 0;
+      float cf = 0.f;                                                 // past the end: (query 0, coefficient 0)
+      if (i < n) {
+        const bool first = i < n1;
+        const int e = sorted[first ? a1 + i : a0 + (i - n1)];
+        tl = e & ~15;                                                 // (e >> 4) * 16 float4 per grad_out row
+        cf = first ? ent_lo[e] : ent_hi[e];
+      }
+#define GVL_GATHER_STEP(SI) acc = fma4(row_bcast_f<SI>(cf), G4[row_bcast_i<SI>(tl) + j], acc);
+      GVL_GATHER_STEP(0) GVL_GATHER_STEP(1) GVL_GATHER_STEP(2) GVL_GATHER_STEP(3)
+      if (n - base > 4) {
+        GVL_GATHER_STEP(4) GVL_GATHER_STEP(5) GVL_GATHER_STEP(6) GVL_GATHER_STEP(7)
+      }
+      if (n - base > 8) {
+        GVL_GATHER_STEP(8) GVL_GATHER_STEP(9) GVL_GATHER_STEP(10) GVL_GATHER_STEP(11)
+        GVL_GATHER_STEP(12) GVL_GATHER_STEP(13) GVL_GATHER_STEP(14) GVL_GATHER_STEP(15)
+      }
+#undef GVL_GATHER_STEP
+    }
+    dst4[(int64_t)s * M * 16 + j] = acc;
   }
 }
 
@@ -546,11 +667,16 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_forward: fast kernels not eligible for this call");
   if (fast_ok && mode != 1) {
     if constexpr (sizeof(T) == 4) {
-      const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 768);
-      auto kern = pad == kPadZeros ? k_fwd_t1d_d64<kPadZeros> : k_fwd_t1d_d64<kPadBorder>;
+      // one 1024-thread workgroup per CU (measured best on MI355X: the 47 KB slab is staged once per CU and 16
+      // wavefronts hide the LDS latency); GVL_MSDA_FWD_{THREADS,CHUNKS} override for tuning sweeps
+      const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
+      const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
+      const bool full = L * P == 16;
+      auto kern = pad == kPadZeros ? (full ? k_fwd_t1d_d64<kPadZeros, true> : k_fwd_t1d_d64<kPadZeros, false>)
+                                   : (full ? k_fwd_t1d_d64<kPadBorder, true> : k_fwd_t1d_d64<kPadBorder, false>);
       if (int rc = ensure_lds(kern, lds)) return rc;
       g_last_impl = 2;
-      return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(256), lds, st,
+      return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(threads), lds, st,
                          (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn, B, S, M, L, Q, P,
                          nchunk, (float *)out);
     }
@@ -576,7 +702,13 @@ int sample_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const
                      dim3(256), 0, st, value, shapes, lsi, loc, (const T *)nullptr, B, S, M, D, L, Q, P, pad, sample);
 }
 
-int bwd_chunks(int B, int M, int Q) { return pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256); }
+// number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
+// queries per workgroup for the LDS carve-up; 0 = does not fit
+int bwd_chunks(int B, int M, int Q, int S) {
+  int n = pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256);
+  while (n <= Q && bwd_lds_bytes(S, (Q + n - 1) / n) > kLdsMax) ++n;
+  return n <= Q ? n : 0;
+}
 
 template <typename T>
 int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *attn,
@@ -596,13 +728,15 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   if (!value || !shapes || !lsi || !loc || !attn || !gout || !gvalue || !gloc || !gattn)
     return fail(GVL_EINVAL, "gvl_msda_backward: null pointer");
   const int mode = impl_mode();
-  const size_t lds = (size_t)(S + 1) * 64 * sizeof(float) * 2;
+  const int nchunk_f = bwd_chunks(B, M, Q, S);
+  const int qper_f = nchunk_f > 0 ? (Q + nchunk_f - 1) / nchunk_f : Q;
+  const size_t lds = nchunk_f > 0 ? bwd_lds_bytes(S, qper_f) : kLdsMax + 1;
   const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && S > 0 &&
                        temporal_host(shapes_host, lsi_host, L, S);
   if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_backward: fast kernels not eligible for this call");
   if (fast_ok && mode != 1) {
     if constexpr (sizeof(T) == 4) {
-      const int nchunk = bwd_chunks(B, M, Q);
+      const int nchunk = nchunk_f;
       float *part = (float *)gvalue;
       if (nchunk > 1) {
         const size_t need = gv_bytes * nchunk;
@@ -610,11 +744,14 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           return fail(GVL_ENOSPC, "gvl_msda_backward: workspace %zu < required %zu bytes", ws_bytes, need);
         part = (float *)ws;
       }
-      auto kern = pad == kPadZeros ? k_bwd_t1d_d64<kPadZeros> : k_bwd_t1d_d64<kPadBorder>;
+      const bool full = L * P == 16;
+      auto kern = pad == kPadZeros ? (full ? k_bwd_t1d_d64<kPadZeros, true> : k_bwd_t1d_d64<kPadZeros, false>)
+                                   : (full ? k_bwd_t1d_d64<kPadBorder, true> : k_bwd_t1d_d64<kPadBorder, false>);
       if (int rc = ensure_lds(kern, lds)) return rc;
-      if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(512), lds, st,
-                               (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn,
-                               (const float *)gout, B, S, M, L, Q, P, nchunk, part, (float *)gloc, (float *)gattn))
+      if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(kBwdThreads),
+                               lds, st, (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn,
+                               (const float *)gout, B, S, M, L, Q, P, nchunk, qper_f, part, (float *)gloc,
+                               (float *)gattn))
         return rc;
       if (nchunk > 1) {
         const int64_t count4 = (int64_t)B * S * M * 16;
@@ -697,8 +834,7 @@ int gvl_msda_sample_f64(const double *value, const int64_t *shapes, const int64_
 
 size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes) {
   if (elem_bytes != 4 || D != 64 || L * P > 16) return 0;
-  if ((size_t)(S + 1) * 64 * sizeof(float) * 2 > kLdsMax) return 0;
-  const int n = bwd_chunks(B, M, Q);
+  const int n = bwd_chunks(B, M, Q, S);
   return n > 1 ? (size_t)n * B * S * M * D * sizeof(float) : 0;
 }
 

@@ -325,9 +325,63 @@ def make_pdvc():
          tshapes=tshapes, lsi=lsi, logp=logp, h1=h1[0], c1=c1[0])
 
 
+def make_train():
+    """One training forward/backward of the reference (pdvc.py parallel_prediction_matched, train.py:403-406) with
+    every dropout probability set to 0 so that the step is deterministic; CUDA-op (zero padding) semantics."""
+    global PDVC_OVERRIDES
+    saved = dict(PDVC_OVERRIDES)
+    PDVC_OVERRIDES.update(transformer_dropout_prob=0.0, drop_prob=0.0)
+    try:
+        opt, model, criterion, cc = build_pdvc()
+    finally:
+        PDVC_OVERRIDES = saved
+    model.train()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=300)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 2, 24
+    n_gt = [3, 2]
+    dt = synth_dt(B, T, opt.feature_dim, valid=[24, 17], n_gt=n_gt)
+    g = torch.Generator().manual_seed(11)
+    cap_len = 7
+    caps = torch.randint(1, opt.vocab_size, (sum(n_gt), cap_len), generator=g)
+    caps[:, 0] = 0
+    caps[:, -1] = 0
+    caps[1, 4:] = 0                                                   # a shorter caption
+    cap_mask = (torch.arange(cap_len)[None] <= (caps != 0).sum(1)[:, None] + 0).float()
+    dt.update(cap_tensor=caps, cap_mask=cap_mask, gt_boxes_mask=torch.tensor([[1, 1, 1], [1, 1, 0]]).bool(),
+              gt_gather_idx=torch.tensor([0, 0, 0, 1, 1]))
+    with cuda_semantics():
+        out, loss = model(dt, criterion, cc, "queries")
+        wd = criterion.weight_dict
+        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        final.backward()
+    rec = dict(cap_tensor=caps, cap_mask=cap_mask, final_loss=final.detach())
+    for k, v in loss.items():
+        rec[f"loss.{k}"] = torch.as_tensor(v).detach()
+    names = sorted(n for n, p_ in model.named_parameters() if p_.grad is not None)
+    params = dict(model.named_parameters())
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = torch.stack([params[n].grad.norm() for n in names])
+    for n in ("transformer.encoder.layers.0.self_attn.sampling_offsets.bias",
+              "transformer.encoder.layers.1.self_attn.attention_weights.bias",
+              "transformer.decoder.layers.0.cross_attn.sampling_offsets.bias",
+              "transformer.decoder.layers.1.cross_attn.value_proj.bias",
+              "transformer.level_embed", "caption_head.0.core.deformable_att.sampling_offsets.bias",
+              "caption_head.0.core.alpha_net.weight", "base_encoder.input_proj.0.1.bias", "class_head.1.weight", "transformer.decoder.bbox_head.0.layers.2.bias"):
+        rec["grad." + n] = params[n].grad
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        rec[f"match_{i}"] = torch.stack([a, b])
+    save("pdvc_train", **rec)
+
+
 if __name__ == "__main__":
+    if "--only-train" in sys.argv:
+        make_train()
+        sys.exit(0)
     make_op()
     make_module()
     make_matcher()
     if FULL:
         make_pdvc()
+        make_train()

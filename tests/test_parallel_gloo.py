@@ -1,0 +1,111 @@
+"""CPU, world_size = 2, gloo: the data-parallel machinery of gvl_amd.parallel (flat-buffer gradient buckets with
+overlapped all-reduce, video sharding) and the criterion's all_reduce(num_boxes) (criterion.py:178-180).  The HIP
+kernels cannot run here, so the model in these tests is a small pure-PyTorch module; the machinery is model-agnostic."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                               torch.nn.Linear(32, 3))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gvl_amd.parallel import GradBuckets
+        from gvl_amd.criterion import SetCriterion
+        model = _make_model()
+        buckets = GradBuckets(list(model.parameters()), bucket_bytes=1024)       # several buckets
+        assert len(buckets.buckets) >= 2
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(8, 12, generator=g)
+        y = torch.randn(8, 3, generator=g)
+        xs, ys = x[rank::world], y[rank::world]
+        for _ in range(2):                                                       # second step: buffers are reused
+            buckets.zero()
+            loss = ((model(xs) - ys) ** 2).sum() / 8 * world                     # so that the rank-mean is the global loss
+            loss.backward()
+            buckets.finish()
+        grads = [p.grad.clone() for p in model.parameters()]
+        assert all(p.grad.data_ptr() >= buckets.flat.data_ptr() for p in model.parameters())
+
+        # criterion: num_boxes is summed over ranks then divided by world (criterion.py:178-181)
+        class M(torch.nn.Module):
+            def forward(self, outputs, targets):
+                n = [len(t_["boxes"]) for t_ in targets]
+                idx = [(torch.arange(k), torch.arange(k)) for k in n]
+                return idx, idx
+        import argparse
+        crit = SetCriterion(1, M(), {}, ['boxes'], opt=argparse.Namespace(lloss_gau_mask=1, lloss_beta=1))
+        nb = 3 if rank == 0 else 1
+        tg = [{"boxes": torch.tensor([[0.5, 0.2]] * nb), "labels": torch.zeros(nb, dtype=torch.long)}]
+        outs = {"pred_logits": torch.zeros(1, 4, 1), "pred_boxes": torch.tensor([[[0.4, 0.2]] * 4]),
+                "pred_count": torch.zeros(1, 11)}
+        losses, _ = crit(outs, tg)
+        q.put((rank, [g_.numpy() for g_ in grads], float(losses["loss_bbox"])))
+    except Exception:                                    # surface the failure instead of letting the parent time out
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_buckets_allreduce_equals_single_process():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    # single-process reference on the full batch
+    model = _make_model()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 12, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    (((model(x) - y) ** 2).sum() / 8).backward()
+    for i, p in enumerate(model.parameters()):
+        for r in range(world):
+            assert torch.allclose(torch.from_numpy(res[r][1][i]), p.grad, atol=1e-6), (r, i)
+    # loss_bbox = sum|src - tgt| / num_boxes, num_boxes = (3 + 1) / 2 = 2 on both ranks
+    assert abs(res[0][2] - 3 * 0.1 / 2) < 1e-6 and abs(res[1][2] - 1 * 0.1 / 2) < 1e-6
+
+
+def test_shard_batch_partitions_videos_and_captions():
+    from gvl_amd.parallel import shard_batch
+    B = 5
+    n_gt = [2, 1, 3, 1, 2]
+    dt = {"video_tensor": torch.arange(B)[:, None, None].float().expand(B, 4, 2),
+          "video_mask": torch.ones(B, 4, dtype=torch.bool), "video_length": torch.arange(B)[:, None].float().expand(B, 3),
+          "gt_boxes_mask": torch.ones(B, 3, dtype=torch.bool),
+          "video_target": [{"boxes": torch.zeros(n, 2), "labels": torch.zeros(n)} for n in n_gt],
+          "cap_raw": [["c"] * n for n in n_gt],
+          "cap_tensor": torch.arange(sum(n_gt))[:, None].expand(-1, 6), "cap_mask": torch.ones(sum(n_gt), 6)}
+    seen_v, seen_c = [], []
+    for r in range(2):
+        s = shard_batch(dt, r, 2)
+        seen_v += s["video_tensor"][:, 0, 0].tolist()
+        seen_c += s["cap_tensor"][:, 0].tolist()
+        assert len(s["video_target"]) == s["video_tensor"].shape[0] == len(s["cap_raw"])
+        assert s["cap_tensor"].shape[0] == sum(len(t_["boxes"]) for t_ in s["video_target"])
+    assert sorted(seen_v) == list(range(B)) and sorted(seen_c) == list(range(sum(n_gt)))

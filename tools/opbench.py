@@ -59,9 +59,19 @@ def main():
                     fn()
                 e1.record()
                 torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / a.iters
-                print(f"{name:3s} Q={Q:4d} {impl:7s} {what}: {us:8.2f} us/call  alg {nbytes / 1e6:6.2f} MB  "
-                      f"{nbytes / us / 1e6:7.3f} TB/s  ({nbytes / us / 1e6 / 8 * 100:5.1f}% of 8 TB/s)")
+                wall = e0.elapsed_time(e1) * 1e3 / a.iters
+                MSDA.profile_enable(True)
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize()
+                MSDA.profile_enable(False)
+                per = {}
+                for tag, ma, mb, t_us in MSDA.profile_collect():
+                    per.setdefault(tag, []).append(t_us)
+                ktxt = " + ".join(f"{k} {sorted(v)[len(v) // 2]:.2f}" for k, v in per.items())
+                us = sum(sorted(v)[len(v) // 2] for v in per.values())
+                print(f"{name:3s} Q={Q:4d} {impl:7s} {what}: wall {wall:7.2f} us/call | kernels {us:7.2f} us ({ktxt}) | "
+                      f"alg {nbytes / 1e6:6.2f} MB -> {nbytes / us / 1e6:6.3f} TB/s = {nbytes / us / 1e6 / 8 * 100:5.1f}% of 8 TB/s")
     _lib.lib().gvl_msda_set_impl(0)
 
 
