@@ -181,9 +181,16 @@ def main():
         us, n = fwd[dec_key]
         nbytes = msda_bytes(B, S, a.queries)
         achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and (B, a.T, a.queries) == (16, 100, 300):
+            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same launch shape (FETCH_SIZE and
+            # WRITE_SIZE in separate passes, gfx950 2x FETCH correction); counters cannot be read from inside the run
+            traffic = json.load(open(pmc))["k_fwd_t1d_d64_dec"]["hbm_bytes_corrected"]
+            traffic_src = "profiles/r01_pmc_traffic.json"
         roof = {"bound": "hbm", "kernel": f"k_{dec_key[0]} (decoder cross-attention launch, Lq={a.queries})",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
-                "frac": round(achieved / (HBM_PEAK_TBS * 1e3), 4), "traffic": None,
+                "frac": round(achieved / (HBM_PEAK_TBS * 1e3), 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_us": round(us, 2), "launches_timed": n, "algorithmic_bytes": nbytes}
         enc_key = next((k for k in fwd if k[1] == S and k[2] == B), None)
         if enc_key is not None:
