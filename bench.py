@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="videos per GPU")
     ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the caption decoding loop from a hipGraph")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -132,6 +133,8 @@ def main():
 
     if a.mode == "eval":
         model.eval()
+        for head in model.caption_head:
+            head.graph_decode = not a.no_graph
 
         def step():
             with torch.no_grad():

@@ -81,8 +81,13 @@ class ShowAttendTellCore(nn.Module):
             if getattr(self, "_alpha_b_version", None) != bias._version:
                 self._alpha_b = float(bias.detach().cpu())        # one host read per weight update, not per step
                 self._alpha_b_version = bias._version
+            E2 = self.input_encoding_size
             const.update(slab3=slab.view(B, S, -1), w_off_h=ow[:, :self.rnn_size].contiguous(),
-                         alpha_w=self.alpha_net.weight.reshape(-1).contiguous(), alpha_b=self._alpha_b)
+                         alpha_w=self.alpha_net.weight.reshape(-1).contiguous(), alpha_b=self._alpha_b,
+                         # one GEMM over h per step yields both h2att(h) and the recurrent gate pre-activations
+                         w_h_cat=torch.cat([self.h2att.weight, self.rnn.weight_hh_l0], 0),
+                         b_h_cat=torch.cat([self.h2att.bias, self.h2att.bias.new_zeros(4 * self.rnn_size)]),
+                         w_att_t=self.rnn.weight_ih_l0[:, E2:E2 + self.att_feat_size].t().contiguous())
         return const
 
     def step(self, xt_gates, state, query, reference_points, temporal_shapes, level_start_index, const):
@@ -98,15 +103,17 @@ class ShowAttendTellCore(nn.Module):
             if shapes2d is None:
                 shapes2d = const["shapes2d"] = temporal_shapes_2d(temporal_shapes, level_start_index)
                 const["ref_in"] = reference_points.contiguous()
+            A = self.att_hid_size
+            g_h = F.linear(h, const["w_h_cat"], const["b_h_cat"])           # (n, A + 4H): [h2att(h) | h W_hh^T]
             att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
-                                      h.contiguous(), const["w_off_h"], self.h2att(h), const["alpha_w"],
-                                      const["alpha_b"], self.n_levels, self.n_points)
-            gates = torch.addmm(xt_gates + const["gates_hs"], att_res, self.rnn.weight_ih_l0[:, E:E + C].t())
-            gates = torch.addmm(gates, h, self.rnn.weight_hh_l0.t())
-            i, f, g, o = gates.chunk(4, 1)
-            c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-            h2 = torch.sigmoid(o) * torch.tanh(c2)
+                                      h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
+                                      self.n_levels, self.n_points)
+            g_x = torch.addmm(const["gates_hs"], att_res, const["w_att_t"])  # hs part + attention part of W_ih x
+            emb_gates, it = xt_gates                                          # (table (V+1,4H), token ids)
+            h2, c2 = MSDA.lstm_cell(g_x, g_h[:, A:], emb_gates, it, c)
             return h2, (h2, c2)
+        if isinstance(xt_gates, tuple):                                   # (pre-multiplied table, token ids)
+            xt_gates = xt_gates[0].index_select(0, xt_gates[1])
         off = const["off_hs"] + F.linear(h, att.sampling_offsets.weight[:, :self.rnn_size]).view(B, Q, K)
         off = off.view(B, Q, 1, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 1:
@@ -135,8 +142,12 @@ class ShowAttendTellCore(nn.Module):
         """Reference call form (LSTM_DSA.py:241): state = (h (1,N,H), c (1,N,H)); returns (output, state)."""
         const = self.prepare(query, input_flatten, input_padding_mask)
         xt_gates = F.linear(xt.reshape(-1, xt.shape[-1]), self.rnn.weight_ih_l0[:, :self.input_encoding_size])
-        out, (h, c) = self.step(xt_gates, (state[0][-1], state[1][-1]), query, reference_points,
-                                input_spatial_shapes, input_level_start_index, const)
+        if "w_off_h" in const and not torch.is_grad_enabled():
+            # fused inference path: identity "embedding table" so that row i of xt_gates is its own token
+            n = xt_gates.shape[0]
+            xt_gates = (xt_gates.contiguous(), torch.arange(n, device=xt_gates.device))
+        out, (h, c) = self.step(xt_gates, (state[0][-1].contiguous(), state[1][-1].contiguous()), query,
+                                reference_points, input_spatial_shapes, input_level_start_index, const)
         return out, (h[None], c[None])
 
 
@@ -222,14 +233,11 @@ class Captioner(nn.Module):
             outputs.append(F.log_softmax(self.logit(self.dropout(out)), dim=1))
         return torch.stack(outputs, 1)
 
-    def sample(self, hs, reference, others, opt={}):
-        """Greedy / multinomial decoding (LSTM_DSA.py:126-194) -> (seq (B*Q, <=max_len), logprobs)."""
-        vid_num, query_num, _ = hs.shape
-        n = vid_num * query_num
-        sample_max = opt.get('sample_max', 1)
-        temperature = opt.get('temperature', 1.0)
-        ref_in = self._scaled_reference(reference, others)
-        memory, tshapes, lsi, mask, ref_in = self._level_inputs(others, ref_in)
+    def _decode_device(self, hs, reference, memory, mask, valid_ratios, tshapes, lsi, sample_max, temperature):
+        """The whole decoding loop on the device, no host interaction: -> (seq (n, T), logprob (n, T), alive (T,))
+        with T = max_caption_len.  Capturable in a hipGraph."""
+        n = hs.shape[0] * hs.shape[1]
+        ref_in = self._scaled_reference(reference, {'valid_ratios': valid_ratios})
         const = self.core.prepare(hs, memory, mask)
         # embedding rows pre-multiplied by their slice of W_ih: one gather per step instead of a GEMM
         emb_gates = F.linear(self.embed.weight, self.core.rnn.weight_ih_l0[:, :self.input_encoding_size])
@@ -248,19 +256,57 @@ class Captioner(nn.Module):
                     it = torch.multinomial(prev, 1)
                     lp = logprobs.gather(1, it).view(-1)
                     it = it.view(-1)
-            out, (h, c) = self.core.step(emb_gates.index_select(0, it), (h, c), hs, ref_in, tshapes, lsi, const)
+            out, (h, c) = self.core.step((emb_gates, it), (h, c), hs, ref_in, tshapes, lsi, const)
             logits = self.logit(self.dropout(out))
             if t >= 1:
                 unfinished = (it > 0) if t == 1 else (unfinished & (it > 0))
                 alive.append(unfinished.any())
                 seq.append(it * unfinished.type_as(it))
                 seq_lp.append(lp)
+        return torch.stack(seq, 1), torch.stack(seq_lp, 1), torch.stack(alive)
+
+    def _decode_graphed(self, hs, reference, memory, mask, valid_ratios, tshapes, lsi):
+        """Greedy decoding replayed from a hipGraph: the 31-step loop is ~800 kernel launches whose host-side issue
+        cost exceeds their run time; captured once per input shape, replayed with one launch."""
+        cache = self.__dict__.setdefault("_decode_graphs", {})
+        key = (tuple(hs.shape), tuple(reference.shape), tuple(memory.shape), str(hs.device),
+               tuple(tshapes._gvl_host_lengths[0]), self.core.alpha_net.bias._version)
+        entry = cache.get(key)
+        if entry is None:
+            static = [t_.clone() for t_ in (hs, reference, memory, mask, valid_ratios)]
+            side = torch.cuda.Stream(device=hs.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up off the capture (lazy inits, LDS attributes)
+                self._decode_device(*static, tshapes, lsi, 1, 1.0)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._decode_device(*static, tshapes, lsi, 1, 1.0)
+            entry = cache[key] = (graph, static, outs)
+        graph, static, outs = entry
+        for dst, src in zip(static, (hs, reference, memory, mask, valid_ratios)):
+            dst.copy_(src)
+        graph.replay()
+        return outs
+
+    def sample(self, hs, reference, others, opt={}):
+        """Greedy / multinomial decoding (LSTM_DSA.py:126-194) -> (seq (B*Q, <=max_len), logprobs)."""
+        sample_max = opt.get('sample_max', 1)
+        temperature = opt.get('temperature', 1.0)
+        memory, tshapes, lsi, mask, _ = self._level_inputs(others, reference)
+        use_graph = (getattr(self, "graph_decode", False) and sample_max and not torch.is_grad_enabled()
+                     and getattr(tshapes, "_gvl_host_lengths", None) is not None)
+        if use_graph:
+            seq, seq_lp, alive = self._decode_graphed(hs, reference, memory, mask, others['valid_ratios'], tshapes, lsi)
+        else:
+            seq, seq_lp, alive = self._decode_device(hs, reference, memory, mask, others['valid_ratios'], tshapes,
+                                                     lsi, sample_max, temperature)
         # the reference stops at the first step where every row has finished (:186-187): one host read here
-        alive = torch.stack(alive).cpu().tolist()
+        alive = alive.cpu().tolist()
         keep = alive.index(False) if False in alive else len(alive)
         if keep == 0:
             return [], []
-        return torch.stack(seq[:keep], 1), torch.stack(seq_lp[:keep], 1)
+        return seq[:, :keep].clone(), seq_lp[:, :keep].clone()
 
 
 class LSTMDSACaptioner(Captioner):

@@ -150,9 +150,11 @@ def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off
     """Fused deformable soft attention of one captioner token step (include/gvl_msda.h: gvl_cap_attend_f32).
     slab (B,S,2C) | ref_in (B,Q,L,1|2) | off_hs (B,Q,L*P) | h, att_h (B*Q,C) | w_off_h (L*P,C) | alpha_w (C,)"""
     for name, t_ in (("slab", slab), ("ref_in", ref_in), ("off_hs", off_hs), ("h", h), ("w_off_h", w_off_h),
-                     ("att_h", att_h), ("alpha_w", alpha_w)):
+                     ("alpha_w", alpha_w)):
         _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
                  f"cap_attend: {name} must be a contiguous fp32 CUDA tensor")
+    _require(att_h.is_cuda and att_h.dtype == torch.float32 and att_h.dim() == 2 and att_h.stride(1) == 1,
+             "cap_attend: att_h must be an fp32 CUDA matrix with unit column stride")
     B, S, C2 = slab.shape
     C = C2 // 2
     Q = ref_in.shape[1]
@@ -165,10 +167,27 @@ def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off
         rc = _lib.lib().gvl_cap_attend_f32(
             slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
             off_hs.data_ptr(), h.data_ptr(), w_off_h.data_ptr(), att_h.data_ptr(), alpha_w.data_ptr(),
-            float(alpha_b), B, S, C, n_levels, Q, n_points, RD, att_res.data_ptr(),
+            float(alpha_b), B, S, C, n_levels, Q, n_points, RD, att_h.stride(0), att_res.data_ptr(),
             dbg_a.data_ptr() if debug else None, dbg_l.data_ptr() if debug else None, stream)
     _lib.check(rc, "cap_attend")
     return (att_res, dbg_a, dbg_l) if debug else att_res
+
+
+def lstm_cell(gates_a, gates_b, emb_gates, it, c):
+    """fused LSTM cell pointwise step (include/gvl_msda.h: gvl_lstm_cell_f32) -> (h', c')"""
+    n, H = c.shape
+    for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b)):
+        _require(t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1
+                 and t_.shape == (n, 4 * H), f"lstm_cell: {name} must be an (n, 4H) fp32 CUDA matrix")
+    _require(emb_gates.is_contiguous() and c.is_contiguous() and it.is_contiguous() and it.dtype == torch.int64,
+             "lstm_cell: emb_gates / c / it must be contiguous (it int64)")
+    h_out, c_out = torch.empty_like(c), torch.empty_like(c)
+    with torch.cuda.device(c.device):
+        rc = _lib.lib().gvl_lstm_cell_f32(gates_a.data_ptr(), gates_a.stride(0), gates_b.data_ptr(), gates_b.stride(0),
+                                          emb_gates.data_ptr(), it.data_ptr(), c.data_ptr(), n, H, h_out.data_ptr(),
+                                          c_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "lstm_cell")
+    return h_out, c_out
 
 
 def row_argmax_lse(logits):
@@ -186,7 +205,7 @@ def row_argmax_lse(logits):
 
 
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
-             7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse"}
+             7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell"}
 
 
 def profile_enable(on=True):

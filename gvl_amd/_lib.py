@@ -30,7 +30,8 @@ SIGNATURES = {
     "gvl_prof_collect": (_I, [_P, _P, _P, _P, _I]),
     "gvl_msda_sample_backward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),
     "gvl_msda_sample_backward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),
-    "gvl_cap_attend_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 7 + [_P, _P, _P, _P]),
+    "gvl_cap_attend_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P]),
+    "gvl_lstm_cell_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "gvl_row_argmax_lse_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),

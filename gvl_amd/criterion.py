@@ -67,18 +67,40 @@ class SetCriterion(nn.Module):
         self.counter_class_rate = torch.tensor(COUNTER_CLASS_RATE)
 
     @staticmethod
-    def _src_idx(indices):
-        batch = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
-        return batch, torch.cat([src for (src, _) in indices])
+    def _pack(indices, targets, device):
+        """All the index bookkeeping of one layer's matching, moved to the device in ONE copy:
+        batch index and query index of every matched prediction (criterion.py:139-143), the row of its target in
+        the concatenated target tensors, and the per-video match counts (for the self-IoU normaliser)."""
+        sizes_t = [len(t_["labels"]) for t_ in targets]
+        offs = [0]
+        for n in sizes_t[:-1]:
+            offs.append(offs[-1] + n)
+        b = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        q = torch.cat([src for (src, _) in indices])
+        tg = torch.cat([J + offs[i] for i, (_, J) in enumerate(indices)])
+        cnt = torch.tensor([len(src) for (src, _) in indices], dtype=torch.int64)
+        packed = torch.cat([b, q, tg, cnt]).to(device, non_blocking=True)
+        n = b.numel()
+        return packed[:n], packed[n:2 * n], packed[2 * n:3 * n], packed[3 * n:]
+
+    def _layer_state(self, outputs, targets, indices):
+        """device-side index tensors + concatenated targets, computed once per layer and shared by the losses"""
+        key = id(indices)
+        st = self._state.get(key)
+        if st is None:
+            dev = outputs['pred_logits'].device
+            one2one, _ = indices
+            b, q, tg, cnt = self._pack(one2one, targets, dev)
+            st = {"b": b, "q": q, "tg": tg, "cnt": cnt, "labels": self._tgt_cat[0], "boxes": self._tgt_cat[1]}
+            self._state[key] = st
+        return st
 
     def loss_labels(self, outputs, targets, indices, num_boxes, log=True):
-        indices, _ = indices
+        st = self._layer_state(outputs, targets, indices)
         logits = outputs['pred_logits']
         dev = logits.device
-        b_idx, q_idx = self._src_idx(indices)
-        tgt_o = torch.cat([t["labels"][J.to(t["labels"].device)] for t, (_, J) in zip(targets, indices)])
         classes = torch.full(logits.shape[:2], self.num_classes, dtype=torch.int64, device=dev)
-        classes[b_idx.to(dev), q_idx.to(dev)] = tgt_o.to(dev)
+        classes[st["b"], st["q"]] = st["labels"][st["tg"]]
         onehot = torch.zeros([logits.shape[0], logits.shape[1], logits.shape[2] + 1], dtype=logits.dtype, device=dev)
         onehot.scatter_(2, classes.unsqueeze(-1), 1)
         onehot = onehot[:, :, :-1]
@@ -86,9 +108,8 @@ class SetCriterion(nn.Module):
                                                 gamma=self.focal_gamma) * logits.shape[1]}
         pred_count = outputs['pred_count']
         max_length = pred_count.shape[1] - 1
-        counts = torch.tensor([min(len(t_['boxes']), max_length) for t_ in targets], device=dev, dtype=torch.long)
         cnt_onehot = torch.zeros_like(pred_count)
-        cnt_onehot.scatter_(1, counts.unsqueeze(-1), 1)
+        cnt_onehot.scatter_(1, self._gt_counts.clamp(max=max_length).unsqueeze(-1), 1)
         weight = self.counter_class_rate[:max_length + 1].to(dev)
         losses['loss_counter'] = cross_entropy_with_gaussian_mask(pred_count, cnt_onehot, self.opt, weight)
         return losses
@@ -96,25 +117,30 @@ class SetCriterion(nn.Module):
     @torch.no_grad()
     def loss_cardinality(self, outputs, targets, indices, num_boxes):
         logits = outputs['pred_logits']
-        tgt_lengths = torch.as_tensor([len(v["labels"]) for v in targets], device=logits.device)
         card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
-        return {'cardinality_error': F.l1_loss(card_pred.float(), tgt_lengths.float())}
+        return {'cardinality_error': F.l1_loss(card_pred.float(), self._gt_counts.float())}
 
     def loss_boxes(self, outputs, targets, indices, num_boxes):
-        indices, _ = indices
-        dev = outputs['pred_boxes'].device
-        b_idx, q_idx = self._src_idx(indices)
-        src = outputs['pred_boxes'][b_idx.to(dev), q_idx.to(dev)]
-        tgt = torch.cat([t_['boxes'][i.to(t_['boxes'].device)] for t_, (_, i) in zip(targets, indices)], dim=0)
+        st = self._layer_state(outputs, targets, indices)
+        src = outputs['pred_boxes'][st["b"], st["q"]]
+        tgt = st["boxes"][st["tg"]]
         losses = {'loss_bbox': F.l1_loss(src, tgt, reduction='none').sum() / num_boxes}
-        giou = torch.diag(generalized_box_iou(box_cl_to_xy(src), box_cl_to_xy(tgt)))
+        sxy, txy = box_cl_to_xy(src), box_cl_to_xy(tgt)
+        # diagonal of the pairwise GIoU (criterion.py:117-119) computed pair by pair instead of n x n then diag
+        inter = (torch.min(sxy[:, 1], txy[:, 1]) - torch.max(sxy[:, 0], txy[:, 0])).clamp(min=0)
+        union = (sxy[:, 1] - sxy[:, 0]) + (txy[:, 1] - txy[:, 0]) - inter
+        area = (torch.max(sxy[:, 1], txy[:, 1]) - torch.min(sxy[:, 0], txy[:, 0])).clamp(min=0)
+        giou = inter / (union + 1e-5) - (area - union) / (area + 1e-5)
         losses['loss_giou'] = (1 - giou).sum() / num_boxes
-        self_iou = torch.triu(box_iou(box_cl_to_xy(src), box_cl_to_xy(src))[0], diagonal=1)
-        sizes = [len(v[0]) for v in indices]
-        total = 0
-        for i, c in enumerate(self_iou.split(sizes, -1)):
-            total = total + c.split(sizes, -2)[i].sum() / (0.5 * sizes[i] * (sizes[i] - 1))
-        losses['loss_self_iou'] = total
+        # self-IoU between the matched predictions of the same video (criterion.py:123-130): upper triangle of the
+        # per-video block, normalised by the number of pairs s(s-1)/2 (0/0 = nan for s = 1, as in the reference)
+        iou = box_iou(sxy, sxy)[0]
+        same = st["b"][:, None] == st["b"][None, :]
+        upper = torch.ones_like(iou, dtype=torch.bool).triu(diagonal=1)
+        per_pred = (iou * (same & upper)).sum(1)
+        per_video = torch.zeros(st["cnt"].numel(), dtype=iou.dtype, device=iou.device).index_add_(0, st["b"], per_pred)
+        cntf = st["cnt"].to(iou.dtype)
+        losses['loss_self_iou'] = (per_video / (0.5 * cntf * (cntf - 1))).sum()
         return losses
 
     def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
@@ -125,20 +151,34 @@ class SetCriterion(nn.Module):
     def forward(self, outputs, targets):
         """criterion.py:163-207 -> (losses, last_indices[, aux_indices])"""
         main = {k: v for k, v in outputs.items() if k not in ('aux_outputs', 'enc_outputs')}
-        last_indices = self.matcher(main, targets)
+        aux_list = outputs.get('aux_outputs', [])
+        dev = outputs['pred_logits'].device
+        self._state = {}
+        self._tgt_cat = (torch.cat([t_["labels"] for t_ in targets]).to(dev),
+                         torch.cat([t_["boxes"] for t_ in targets]).to(dev))
+        self._gt_counts = torch.tensor([len(t_["boxes"]) for t_ in targets], dtype=torch.long).to(dev, non_blocking=True)
+        batched = None
+        if hasattr(self.matcher, "match_layers"):
+            # same matchings as one matcher call per layer, but one device->host copy for all layers
+            batched = self.matcher.match_layers([main] + list(aux_list), targets)
+            last_indices = batched[0]
+        else:
+            last_indices = self.matcher(main, targets)
         outputs['matched_indices'] = last_indices
         num_boxes = sum(len(t_["labels"]) for t_ in targets)
-        num_boxes = torch.as_tensor([num_boxes], dtype=torch.float, device=outputs['pred_logits'].device)
-        if is_dist_avail_and_initialized():
-            dist.all_reduce(num_boxes)
-        num_boxes = torch.clamp(num_boxes / get_world_size(), min=1).item()
+        if is_dist_avail_and_initialized():                            # criterion.py:178-181
+            nb = torch.as_tensor([num_boxes], dtype=torch.float, device=outputs['pred_logits'].device)
+            dist.all_reduce(nb)
+            num_boxes = torch.clamp(nb / get_world_size(), min=1).item()
+        else:
+            num_boxes = max(float(num_boxes), 1.0)                     # same value, no device round trip
         losses = {}
         for loss in self.losses:
             losses.update(self.get_loss(loss, outputs, targets, last_indices, num_boxes))
         if 'aux_outputs' in outputs:
             aux_indices = []
             for i, aux in enumerate(outputs['aux_outputs']):
-                indices = self.matcher(aux, targets)
+                indices = batched[i + 1] if batched is not None else self.matcher(aux, targets)
                 aux_indices.append(indices)
                 for loss in self.losses:
                     if loss == 'masks':

@@ -114,9 +114,9 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     const float *__restrict__ off_hs,    // (B*Q, 16)   sampling_offsets bias + hs part
     const float *__restrict__ h,         // (B*Q, C)    previous hidden state
     const float *__restrict__ w_off_h,   // (16, C)     sampling_offsets.weight[:, :C]
-    const float *__restrict__ att_h,     // (B*Q, C)    h2att(h)
+    const float *__restrict__ att_h,     // (B*Q, C)    h2att(h), row stride att_h_ld floats
     const float *__restrict__ alpha_w,   // (C)
-    float alpha_b, int B, int S, int L, int Q, int P, int RD, int rows_per_xcd_group,
+    float alpha_b, int B, int S, int L, int Q, int P, int RD, int rows_per_xcd_group, int att_h_ld,
     float *__restrict__ att_res,         // (B*Q, C)
     float *__restrict__ dbg_alpha,       // optional (B*Q, 16)
     float *__restrict__ dbg_loc) {       // optional (B*Q, 16)
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
   if (dbg_loc && (lane & 3) == 0 && k_own < LP) dbg_loc[row * LP + k_own] = locx;
 
   // ---- pass 1: attention logits from the ctx2att half ------------------------------------------------------
-  const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * kC);
+  const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * (int64_t)att_h_ld);
   const float4 ta = ah4[lane], tb = ah4[64 + lane];
   const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
   const float4 *slab4 = reinterpret_cast<const float4 *>(slab) + (int64_t)b * S * (2 * kC / 4);
@@ -339,6 +339,45 @@ __global__ void __launch_bounds__(256) k_sample_bwd(const T *__restrict__ value,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// LSTM cell pointwise part of one token step (nn.LSTM single layer, bias-free; LSTM_DSA.py:216-217,269):
+//   gates = ga + gb + emb_table[it]   (three partial pre-activations: the GEMM over [att | hs], the GEMM over h,
+//                                      and the pre-multiplied embedding row of the input token)
+//   i,f,g,o = split(gates);  c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c')
+// one float4 of hidden units per lane
+// ------------------------------------------------------------------------------------------------------
+__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ inline float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+
+__global__ void __launch_bounds__(256) k_lstm_cell(const float *__restrict__ ga, int lda, const float *__restrict__ gb,
+                                                   int ldb, const float *__restrict__ emb, const int64_t *__restrict__ it,
+                                                   const float *__restrict__ c, int n, int H, float *__restrict__ h_out,
+                                                   float *__restrict__ c_out) {
+  const int H4 = H >> 2;
+  const int64_t total = (int64_t)n * H4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / H4), j = (int)(idx % H4);
+    const float4 *pa = reinterpret_cast<const float4 *>(ga + (int64_t)row * lda);
+    const float4 *pb = reinterpret_cast<const float4 *>(gb + (int64_t)row * ldb);
+    const float4 *pe = reinterpret_cast<const float4 *>(emb + it[row] * (int64_t)(4 * H));
+    float4 g4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 a = pa[k * H4 + j], b = pb[k * H4 + j], e = pe[k * H4 + j];
+      g4[k] = make_float4(a.x + b.x + e.x, a.y + b.y + e.y, a.z + b.z + e.z, a.w + b.w + e.w);
+    }
+    const float4 cp = reinterpret_cast<const float4 *>(c)[idx];
+    float4 cn, hn;
+#define GVL_CELL(X)                                                         \
+    cn.X = sigmoidf_(g4[1].X) * cp.X + sigmoidf_(g4[0].X) * tanhf_(g4[2].X); \
+    hn.X = sigmoidf_(g4[3].X) * tanhf_(cn.X);
+    GVL_CELL(x) GVL_CELL(y) GVL_CELL(z) GVL_CELL(w)
+#undef GVL_CELL
+    reinterpret_cast<float4 *>(c_out)[idx] = cn;
+    reinterpret_cast<float4 *>(h_out)[idx] = hn;
+  }
+}
+
 template <typename T>
 int sample_bwd_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *gsamp, int B,
                     int S, int M, int D, int L, int Q, int P, int pad, T *gvalue, T *gloc, hipStream_t st) {
@@ -367,7 +406,8 @@ extern "C" {
 int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                        const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
                        const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
-                       float *att_res, float *dbg_alpha, float *dbg_loc, void *stream) {
+                       int att_h_ld, float *att_res, float *dbg_alpha, float *dbg_loc, void *stream) {
+  if (att_h_ld < C || (att_h_ld & 3)) return fail(GVL_EINVAL, "gvl_cap_attend_f32: att_h_ld must be >= C and a multiple of 4");
   if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
     return fail(GVL_EINVAL, "gvl_cap_attend_f32: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", C, L,
                 P, RD);
@@ -379,7 +419,20 @@ int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *
   const int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
   return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", k_cap_attend, dim3(8 * blocks_per_group),
                      dim3(kWaves * 64), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
-                     alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_res, dbg_alpha, dbg_loc);
+                     alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_h_ld, att_res, dbg_alpha, dbg_loc);
+}
+
+int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
+                      const int64_t *it, const float *c, int n, int H, float *h_out, float *c_out, void *stream) {
+  if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3))
+    return fail(GVL_EINVAL, "gvl_lstm_cell_f32: bad sizes n=%d H=%d lda=%d ldb=%d", n, H, lda, ldb);
+  if (n == 0) return 0;
+  if (!gates_a || !gates_b || !emb_gates || !it || !c || !h_out || !c_out)
+    return fail(GVL_EINVAL, "gvl_lstm_cell_f32: null pointer");
+  int64_t blocks = ((int64_t)n * (H / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  return gvl::launch(GVL_PROF_LSTM_CELL, n, H, "k_lstm_cell", k_lstm_cell, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, c, n, H, h_out, c_out);
 }
 
 int gvl_row_argmax_lse_f32(const float *logits, int R, int V, int64_t *idx, float *logp, void *stream) {

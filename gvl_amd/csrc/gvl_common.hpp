@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "gvl_msda.h"
@@ -61,9 +62,20 @@ inline int launch(int tag, int meta_a, int meta_b, const char *what, K kernel, d
 template <typename K>
 inline int ensure_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return 0;
+  // remember the largest size already granted per kernel: the attribute call is made once, never per launch
+  // (and never again during a hipGraph capture after the warm-up launch)
+  static std::mutex mu;
+  static std::vector<std::pair<const void *, size_t>> granted;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto &kv : granted)
+      if (kv.first == reinterpret_cast<const void *>(kernel) && kv.second >= bytes) return 0;
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return fail((int)e, "gvl: cannot raise dynamic LDS to %zu: %s", bytes, hipGetErrorString(e));
+  std::lock_guard<std::mutex> g(mu);
+  granted.emplace_back(reinterpret_cast<const void *>(kernel), bytes);
   return 0;
 }
 

@@ -162,6 +162,9 @@ int gvl_hungarian_batch_f32(const float *C, int B, int Q, int G, const int *size
   };
   int nt = num_threads > 0 ? num_threads : (int)std::thread::hardware_concurrency();
   nt = std::max(1, std::min(nt, B));
+  // spawning threads costs ~30 us each: only worth it when the solves are not tiny (GVL: Q = 300, n_i <= 30 is
+  // ~10 us per video, so a whole batch is cheaper on the calling thread)
+  if (num_threads <= 0 && (int64_t)B * Q * G * m2o_rate < (int64_t)4 << 20) nt = 1;
   if (nt <= 1) {
     for (int i = 0; i < B; ++i) work(i);
   } else {

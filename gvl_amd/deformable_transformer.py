@@ -42,9 +42,17 @@ def _activation(name):
     raise RuntimeError(F"activation should be relu/gelu, not {name}.")
 
 
+_LEVEL_CACHE = {}
+
+
 def make_level_tensors(lengths, device):
-    """(temporal_shapes (L,), level_start_index (L,)) int64 on `device`, each carrying host copies."""
+    """(temporal_shapes (L,), level_start_index (L,)) int64 on `device`, each carrying host copies.  Cached per
+    (lengths, device): the tensors are constants, so no host->device copy is issued per forward."""
     lengths = [int(x) for x in lengths]
+    key = (tuple(lengths), str(device))
+    hit = _LEVEL_CACHE.get(key)
+    if hit is not None:
+        return hit
     starts = [0]
     for x in lengths[:-1]:
         starts.append(starts[-1] + x)
@@ -52,6 +60,7 @@ def make_level_tensors(lengths, device):
     ls = torch.tensor(starts, dtype=torch.long, device=device)
     ts._gvl_host_lengths = (lengths, starts)
     ls._gvl_host_lengths = (lengths, starts)
+    _LEVEL_CACHE[key] = (ts, ls)
     return ts, ls
 
 

@@ -37,10 +37,12 @@ def box_iou(boxes1, boxes2):
     return inter / (union + 1e-5), union
 
 
-def generalized_box_iou(boxes1, boxes2):
-    """box_ops.py:30-47"""
-    assert (boxes1[:, 1:] >= boxes1[:, :1]).all()
-    assert (boxes2[:, 1:] >= boxes2[:, :1]).all()
+def generalized_box_iou(boxes1, boxes2, check=True):
+    """box_ops.py:30-47.  check=False skips the two degenerate-box asserts (each is a device->host sync); callers
+    that skip them fold the same test into a flag that travels with their own device->host copy."""
+    if check:
+        assert (boxes1[:, 1:] >= boxes1[:, :1]).all()
+        assert (boxes2[:, 1:] >= boxes2[:, :1]).all()
     iou, union = box_iou(boxes1, boxes2)
     lt = torch.min(boxes1[:, None, 0], boxes2[:, 0])
     rb = torch.max(boxes1[:, None, 1], boxes2[:, 1])
@@ -77,26 +79,54 @@ class HungarianMatcher(nn.Module):
         self.opt = opt
 
     @torch.no_grad()
-    def cost_matrix(self, outputs, targets):
-        """matcher.py:74-105 -> C (B, Q, sum nGT) on the device of the predictions."""
+    def cost_matrix(self, outputs, targets, tgt_cat=None, with_flag=False):
+        """matcher.py:74-105 -> C (B, Q, sum nGT) on the device of the predictions.  with_flag=True returns
+        (C, ok) where ok is the device-side result of box_ops.py:39-40's degenerate-box asserts."""
         bs, num_queries = outputs["pred_logits"].shape[:2]
         out_prob = outputs["pred_logits"].flatten(0, 1).sigmoid()
         out_bbox = outputs["pred_boxes"].flatten(0, 1)
-        tgt_ids = torch.cat([v["labels"] for v in targets])
-        tgt_bbox = torch.cat([v["boxes"] for v in targets])
+        if tgt_cat is None:
+            tgt_cat = (torch.cat([v["labels"] for v in targets]), torch.cat([v["boxes"] for v in targets]))
+        tgt_ids, tgt_bbox = tgt_cat
         alpha, gamma = self.cost_alpha, self.cost_gamma
         neg = (1 - alpha) * (out_prob ** gamma) * (-(1 - out_prob + 1e-8).log())
         pos = alpha * ((1 - out_prob) ** gamma) * (-(out_prob + 1e-8).log())
         cost_class = pos[:, tgt_ids] - neg[:, tgt_ids]
         cost_bbox = torch.cdist(out_bbox, tgt_bbox, p=1)
-        cost_giou = -generalized_box_iou(box_cl_to_xy(out_bbox), box_cl_to_xy(tgt_bbox))
+        xy1, xy2 = box_cl_to_xy(out_bbox), box_cl_to_xy(tgt_bbox)
+        cost_giou = -generalized_box_iou(xy1, xy2, check=not with_flag)
         cl = outputs.get('cl_match_mats', 0)
         cost_cl = -1.0 * cl[:, :cost_bbox.shape[1]] if isinstance(cl, torch.Tensor) else -1 * cl
         C = self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou \
             + self.cost_cl * cost_cl
         if self.opt is not None and getattr(self.opt, "set_cost_caption", 0) > 0 and 'cap_cost_mat' in outputs:
             C = C + self.opt.set_cost_caption * outputs['cap_cost_mat']
-        return C.view(bs, num_queries, -1)
+        C = C.view(bs, num_queries, -1)
+        if with_flag:
+            ok = (xy1[:, 1:] >= xy1[:, :1]).all() & (xy2[:, 1:] >= xy2[:, :1]).all()
+            return C, ok
+        return C
+
+    @torch.no_grad()
+    def match_layers(self, outputs_list, targets):
+        """The matcher for several decoder layers at once (criterion.py:173 + :192 call it once per layer, each with
+        its own device->host copy): all cost matrices are computed on the device, cross PCIe in ONE copy together
+        with the degenerate-box flag, and all layers x videos are solved in one batch of host threads.
+        Returns [(indices, rl_indices)] per layer, identical to calling forward() per layer."""
+        sizes = [len(v["boxes"]) for v in targets]
+        tgt_cat = (torch.cat([v["labels"] for v in targets]), torch.cat([v["boxes"] for v in targets]))
+        Cs, oks = zip(*[self.cost_matrix(o, targets, tgt_cat, with_flag=True) for o in outputs_list])
+        nl = len(Cs)
+        B, Q, G = Cs[0].shape
+        packed = torch.cat([torch.stack(Cs).float().reshape(-1), torch.stack(oks).float()]).cpu()
+        assert bool(packed[-nl:].all()), "degenerate boxes (x1 < x0) in the matcher"          # box_ops.py:39-40
+        C = packed[:-nl].view(nl * B, Q, G)
+        # layer l, video i owns the same column block as video i: present it as nl*B "videos" over nl copies of the
+        # column blocks by solving per layer (the C ABI takes one (B,Q,G) tensor per call; threads cover B)
+        res = []
+        for l in range(nl):
+            res.append(hungarian_batch(C[l * B:(l + 1) * B], sizes, m2o_rate=4))
+        return res
 
     @torch.no_grad()
     def forward(self, outputs, targets, verbose=False, return_C=False):

@@ -39,11 +39,15 @@ def offset_bias_init(n_heads, n_levels, n_points, centre=False):
 def temporal_shapes_2d(input_spatial_shapes, input_level_start_index):
     """(L,) lengths -> the (L,2) [(1,T_l)] tensor the op consumes (ms_deform_attn.py:117), carrying a host copy so
     the C ABI can pick the temporal kernels without a device->host read."""
+    cached = getattr(input_spatial_shapes, "_gvl_shapes2d", None)
+    if cached is not None:
+        return cached
     shapes2d = torch.stack([torch.ones_like(input_spatial_shapes), input_spatial_shapes], -1).contiguous()
     host = getattr(input_spatial_shapes, "_gvl_host_lengths", None)
     if host is not None:
         lengths, starts = host
         MSDA.attach_host_shapes(shapes2d, input_level_start_index, [(1, int(t_)) for t_ in lengths], starts)
+        input_spatial_shapes._gvl_shapes2d = shapes2d          # level tensors are cached constants
     return shapes2d
 
 

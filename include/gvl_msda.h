@@ -71,6 +71,7 @@ int gvl_msda_last_impl(void);
 #define GVL_PROF_SAMPLE_BWD 7
 #define GVL_PROF_CAP_ATTEND 8
 #define GVL_PROF_ROW_ARGMAX 9
+#define GVL_PROF_LSTM_CELL 10
 int gvl_prof_enable(int on);
 int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
 
@@ -127,13 +128,21 @@ int gvl_msda_sample_backward_f64(const double *value, const int64_t *shapes, con
  *      ref      (B, Q, L, RD) reference points already multiplied by the valid ratios (LSTM_DSA.py:137-141)
  *      off_hs   (B*Q, L*P)  sampling_offsets bias + the part of the projection that multiplies hs
  *      h        (B*Q, C)    previous hidden state;  w_off_h (L*P, C) = sampling_offsets.weight[:, :C]
- *      att_h    (B*Q, C)    h2att(h);  alpha_w (C), alpha_b: alpha_net
+ *      att_h    (B*Q, C)    h2att(h), rows att_h_ld floats apart (>= C; lets it be a column block of a wider GEMM
+ *                           output);  alpha_w (C), alpha_b: alpha_net
  *      att_res  (B*Q, C)    sum_k softmax_k(alpha_net(tanh(ctx2att(clip_k) + att_h))) * clip_k
  *    dbg_alpha / dbg_loc (B*Q, L*P) are optional outputs (may be NULL) used by the parity tests. */
 int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                        const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
                        const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
-                       float *att_res, float *dbg_alpha, float *dbg_loc, void *stream);
+                       int att_h_ld, float *att_res, float *dbg_alpha, float *dbg_loc, void *stream);
+
+/* -- pointwise part of the captioner's LSTM cell (single layer, bias-free nn.LSTM, LSTM_DSA.py:216-217,269):
+ *    gates = gates_a + gates_b + emb_gates[it] (row strides lda / ldb floats, gate order i,f,g,o, 4H wide);
+ *    c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c').  emb_gates is the embedding table already
+ *    multiplied by its slice of W_ih ((V+1, 4H)); it (n) int64 token ids. */
+int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
+                      const int64_t *it, const float *c, int n, int H, float *h_out, float *c_out, void *stream);
 
 /* -- greedy decoding epilogue: idx[r] = argmax_v logits[r, v] (first maximal index), logp[r] = log_softmax(logits[r])
  *    at that index (LSTM_DSA.py:123 + :166-167), one read of the logits. */

@@ -218,3 +218,29 @@ def test_pdvc_train_step_matches_reference():
     for k in [k for k in g if k.startswith("grad.")]:
         want = g[k]
         assert maxerr(params[k[5:]].grad, want) <= 2e-3 * max(1.0, float(abs(want).max())), k
+
+
+def test_graph_replayed_decoding_equals_eager(built):
+    """The hipGraph replay of the greedy decoding loop returns exactly what the eager loop returns, also when the
+    inputs change between replays (static input buffers are refreshed)."""
+    f, model, criterion, dev = built
+    dt = to_dev(pdvc_dt(f), dev)
+    cap = model.caption_head[-1]
+    with torch.no_grad():
+        cap.graph_decode = False
+        out_e, _ = model(dt, None, None, "queries", eval_mode=True)
+        cap.graph_decode = True
+        try:
+            out_g, _ = model(dt, None, None, "queries", eval_mode=True)
+            assert torch.equal(out_g["seq"], out_e["seq"])
+            assert maxerr(out_g["caption_probs"]["cap_prob_eval"], out_e["caption_probs"]["cap_prob_eval"]) < 1e-5
+            dt2 = dict(dt)
+            dt2["video_tensor"] = dt["video_tensor"].flip(0).contiguous()
+            dt2["video_mask"] = dt["video_mask"].flip(0).contiguous()
+            out_g2, _ = model(dt2, None, None, "queries", eval_mode=True)       # replay with new inputs
+            cap.graph_decode = False
+            out_e2, _ = model(dt2, None, None, "queries", eval_mode=True)
+            assert torch.equal(out_g2["seq"], out_e2["seq"])
+            assert maxerr(out_g2["caption_probs"]["cap_prob_eval"], out_e2["caption_probs"]["cap_prob_eval"]) < 1e-5
+        finally:
+            cap.graph_decode = False
