@@ -127,6 +127,49 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return grad_value, grad_loc, grad_attn
 
 
+def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_levels, n_points, pad_mode="zeros"):
+    """include/gvl_msda.h: gvl_msda1d_fused_forward_f32.  value (B,S,M,64) | proj (B,Q,2*M*L*P) | ref (B,Q,L,1|2)"""
+    for name, t_ in (("value", value), ("proj", proj), ("ref", ref)):
+        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
+                 f"msda1d_fused: {name} must be a contiguous fp32 CUDA tensor")
+    B, S, M, D = value.shape
+    Q, RD = ref.shape[1], ref.shape[-1]
+    _require(tuple(proj.shape) == (B, Q, 2 * M * n_levels * n_points) and tuple(ref.shape) == (B, Q, n_levels, RD),
+             "msda1d_fused: proj / ref have wrong shapes")
+    sh, ls = host_shapes(spatial_shapes, level_start_index)
+    out = value.new_empty((B, Q, M * D))
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().gvl_msda1d_fused_forward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(), ref.data_ptr(),
+            B, S, M, D, n_levels, Q, n_points, RD, PAD_MODES[pad_mode], _hp(sh), _hp(ls), out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "msda1d_fused_forward")
+    return out
+
+
+def msda1d_fused_backward(value, spatial_shapes, level_start_index, proj, ref, grad_output, n_levels, n_points,
+                          pad_mode="zeros", need_ref_grad=False):
+    """-> (grad_value, grad_proj, grad_ref or None)"""
+    B, S, M, D = value.shape
+    Q, RD = ref.shape[1], ref.shape[-1]
+    _require(grad_output.is_contiguous() and grad_output.is_cuda, "grad_output must be a contiguous CUDA tensor")
+    sh, ls = host_shapes(spatial_shapes, level_start_index)
+    grad_value = torch.empty_like(value)
+    grad_proj = torch.empty_like(proj)
+    grad_ref_part = value.new_empty((B, Q, M, n_levels, RD)) if need_ref_grad else None
+    lib = _lib.lib()
+    nbytes = lib.gvl_msda1d_fused_backward_workspace_bytes(B, S, M, D, n_levels, Q, n_points)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
+    with torch.cuda.device(value.device):
+        rc = lib.gvl_msda1d_fused_backward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(), ref.data_ptr(),
+            grad_output.data_ptr(), B, S, M, D, n_levels, Q, n_points, RD, PAD_MODES[pad_mode], _hp(sh), _hp(ls),
+            grad_value.data_ptr(), grad_proj.data_ptr(), grad_ref_part.data_ptr() if need_ref_grad else None,
+            ws.data_ptr() if ws is not None else None, nbytes, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "msda1d_fused_backward")
+    return grad_value, grad_proj, (grad_ref_part.sum(2) if need_ref_grad else None)
+
+
 def ms_deform_attn_sample_backward(value, spatial_shapes, level_start_index, sampling_loc, grad_sample,
                                    pad_mode="border"):
     """autograd of ms_deform_attn_sample: grad_sample (B*M, D, Q, L, P) -> (grad_value, grad_loc)."""

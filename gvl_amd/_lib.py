@@ -33,6 +33,9 @@ SIGNATURES = {
     "gvl_cap_attend_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_lstm_cell_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "gvl_row_argmax_lse_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
+    "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7),
+    "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_hungarian_batch_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I]),

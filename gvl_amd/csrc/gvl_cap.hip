@@ -289,17 +289,20 @@ __device__ inline T pix_(T loc, int size, int pad, T &dmul) {
   return x;
 }
 
+// One workgroup per (b,q,m); its wavefronts split the D channels in slices of 64 (the teacher-forced captioner has
+// few tuples -- 48 at cfg A -- but D = 1024 channels, so the parallelism must come from the channels); the partial
+// grad_loc sums of the slices meet in LDS.
 template <typename T>
-__global__ void __launch_bounds__(256) k_sample_bwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
-                                                    const int64_t *__restrict__ lsi, const T *__restrict__ loc,
-                                                    const T *__restrict__ gsamp, int B, int S, int M, int D, int L,
-                                                    int Q, int P, int pad, T *__restrict__ gvalue,
-                                                    T *__restrict__ gloc) {
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
+__global__ void __launch_bounds__(1024) k_sample_bwd(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lsi, const T *__restrict__ loc,
+                                                     const T *__restrict__ gsamp, int B, int S, int M, int D, int L,
+                                                     int Q, int P, int pad, T *__restrict__ gvalue,
+                                                     T *__restrict__ gloc) {
+  __shared__ T red[16][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t ntup = (int64_t)B * Q * M;
   const int64_t rowstride = (int64_t)M * D;
-  for (int64_t tup = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); tup < ntup; tup += (int64_t)gridDim.x * wpb) {
+  for (int64_t tup = blockIdx.x; tup < ntup; tup += gridDim.x) {
     const int m = (int)(tup % M);
     const int64_t bq = tup / M;
     const int q = (int)(bq % Q), b = (int)(bq / Q);
@@ -320,7 +323,7 @@ __global__ void __launch_bounds__(256) k_sample_bwd(const T *__restrict__ value,
           const bool wl_ok = wl >= 0 && wl <= W - 1, wh_ok = wl + 1 >= 0 && wl + 1 <= W - 1;
           const int64_t i00 = (int64_t)(hl * W + wl) * rowstride, i01 = (int64_t)(hl * W + wl + 1) * rowstride;
           const int64_t i10 = (int64_t)((hl + 1) * W + wl) * rowstride, i11 = (int64_t)((hl + 1) * W + wl + 1) * rowstride;
-          for (int d = lane; d < D; d += 64) {
+          for (int d = wave * 64 + lane; d < D; d += nw * 64) {
             const T g = gsamp[(((((int64_t)b * M + m) * D + d) * Q + q) * L + l) * P + p];
             T gh = (T)0, gw = (T)0;
             if (hl_ok && wl_ok) { const T v = value[voff + i00 + d]; gh -= hw * v; gw -= hh * v; atomicAdd(gvalue + voff + i00 + d, hh * hw * g); }
@@ -333,7 +336,15 @@ __global__ void __launch_bounds__(256) k_sample_bwd(const T *__restrict__ value,
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); }
-        if (lane == 0) { gloc[si * 2] = ax; gloc[si * 2 + 1] = ay; }
+        if (lane == 0) { red[wave][0] = ax; red[wave][1] = ay; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          T sx = (T)0, sy = (T)0;
+          for (int k = 0; k < nw; ++k) { sx += red[k][0]; sy += red[k][1]; }
+          gloc[si * 2] = sx;
+          gloc[si * 2 + 1] = sy;
+        }
+        __syncthreads();
       }
     }
   }
@@ -393,10 +404,12 @@ int sample_bwd_impl(const T *value, const int64_t *shapes, const int64_t *lsi, c
   if (ntup == 0) return 0;
   if (!value || !shapes || !lsi || !loc || !gsamp || !gloc)
     return fail(GVL_EINVAL, "gvl_msda_sample_backward: null pointer");
-  int64_t blocks = (ntup + 3) / 4;
-  if (blocks > 256 * 64) blocks = 256 * 64;
-  return gvl::launch(GVL_PROF_SAMPLE_BWD, Q, B, "k_sample_bwd", k_sample_bwd<T>, dim3((unsigned)blocks), dim3(256), 0,
-                     st, value, shapes, lsi, loc, gsamp, B, S, M, D, L, Q, P, pad, gvalue, gloc);
+  int64_t blocks = ntup;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  int waves = (D + 63) / 64;
+  if (waves > 16) waves = 16;
+  return gvl::launch(GVL_PROF_SAMPLE_BWD, Q, B, "k_sample_bwd", k_sample_bwd<T>, dim3((unsigned)blocks),
+                     dim3(waves * 64), 0, st, value, shapes, lsi, loc, gsamp, B, S, M, D, L, Q, P, pad, gvalue, gloc);
 }
 
 }  // namespace

@@ -315,14 +315,70 @@ __device__ inline void stage_slab(float4 *slab4, const float *value, int b, int 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Sampling operands of sample j of one (b,q,m).  Two sources:
+//   FUSED = false   the op's own inputs: loc (B,Q,M,L,P,2) and attn (B,Q,M,L,P)           (ms_deform_attn_func.py:25)
+//   FUSED = true    what MSDeformAttn.forward derives them from (ms_deform_attn.py:99-117), so that neither
+//                   tensor ever exists in HBM: proj (B*Q, 2*M*L*P) = one GEMM against [sampling_offsets;
+//                   attention_weights] -> columns [0, M*LP) are the raw offsets, [M*LP, 2*M*LP) the attention
+//                   logits; ref (B,Q,L,RD) the reference points.  In-kernel: softmax over the DPP row (:100-101),
+//                   loc = ref + off / T_l  (RD = 1, :103-106)  or  ref_c + off / P * ref_len * 0.5  (RD = 2, :107-109),
+//                   y = 0.5 (:115).  Needs L*P == 16 (one sample per lane of the row).
+// ------------------------------------------------------------------------------------------------------
+struct RawOps {
+  float a, b, c, d;   // !FUSED: (x, y, w, -)     FUSED: (offset, logit, ref0, ref1)
+};
+
+template <bool FUSED>
+__device__ inline RawOps fetch_ops(const float *__restrict__ p0, const float *__restrict__ p1, int64_t bq, int m, int M,
+                                   int LP, int L, int RD, int j, int l) {
+  RawOps r;
+  if (!FUSED) {
+    const int64_t i = (bq * M + m) * LP + j;
+    const float2 xy = reinterpret_cast<const float2 *>(p0)[i];
+    r.a = xy.x; r.b = xy.y; r.c = p1[i]; r.d = 0.f;
+  } else {
+    const float *row = p0 + bq * (int64_t)(2 * M * LP);
+    r.a = row[m * LP + j];
+    r.b = row[M * LP + m * LP + j];
+    const float *rp = p1 + (bq * L + l) * RD;
+    r.c = rp[0];
+    r.d = RD == 2 ? rp[1] : 0.f;
+  }
+  return r;
+}
+
+__device__ inline float row_allmax(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x124>(v));
+  v = fmaxf(v, dpp_f<0x128>(v));
+  return v;
+}
+
+// -> (x, y, attention weight) of the lane's sample; FUSED also returns d loc_x / d offset in `dloc`
+template <bool FUSED>
+__device__ inline void resolve_ops(const RawOps &r, int Tl, int P, int RD, float &x, float &y, float &w, float &dloc) {
+  if (!FUSED) {
+    x = r.a; y = r.b; w = r.c; dloc = 0.f;
+  } else {
+    const float mx = row_allmax(r.b);
+    const float e = __expf(r.b - mx);
+    w = e / row_allsum(e);
+    if (RD == 1) { x = r.c + r.a / (float)Tl; dloc = 1.f / (float)Tl; }
+    else { x = r.c + r.a / (float)P * r.d * 0.5f; dloc = r.d * 0.5f / (float)P; }
+    y = 0.5f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
 // ------------------------------------------------------------------------------------------------------
-template <int PAD, bool FULL16>
+template <int PAD, bool FULL16, bool FUSED>
 __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ value,
                                                      const int64_t *__restrict__ shapes,
                                                      const int64_t *__restrict__ lsi, const float *__restrict__ loc,
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
-                                                     int P, int nchunk, float *__restrict__ out) {
+                                                     int P, int RD, int nchunk, float *__restrict__ out) {
   extern __shared__ float4 slab4[];
   const int BM = B * M;
   const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
@@ -338,33 +394,26 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
   // The kernel is a latency chain (launch -> slab -> LDS reads), so every global load that does not depend on LDS
   // is issued before the slab staging, and each pass prefetches the sampling operands of the next one.
   int Tl = 1, st = 0;
+  const int lvl = j < LP ? j / P : 0;
   if (j < LP) {
-    const int l = j / P;
-    Tl = (int)shapes[2 * l + 1];
-    st = (int)lsi[l];
+    Tl = (int)shapes[2 * lvl + 1];
+    st = (int)lsi[lvl];
   }
   int qb = q0 + wave * 4;
-  float2 xy_n = make_float2(0.f, 0.5f);
-  float w_n = 0.f;
-  if (qb < q1 && j < LP) {
-    const int64_t tbn = (((int64_t)b * Q + min(qb + tq, q1 - 1)) * M + m) * LP;
-    xy_n = reinterpret_cast<const float2 *>(loc)[tbn + j];
-    w_n = attn[tbn + j];
-  }
+  RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
+  if (qb < q1 && j < LP) r_n = fetch_ops<FUSED>(loc, attn, (int64_t)b * Q + min(qb + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
   stage_slab(slab4, value, b, m, S, M);
   __syncthreads();
 
   for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
     const bool act = q < q1;
-    const float2 xy = xy_n;
-    const float w = w_n;
+    const RawOps r = r_n;
     const int qbn = qb + nw * 4;
-    if (qbn < q1 && j < LP) {
-      const int64_t tbn = (((int64_t)b * Q + min(qbn + tq, q1 - 1)) * M + m) * LP;
-      xy_n = reinterpret_cast<const float2 *>(loc)[tbn + j];
-      w_n = attn[tbn + j];
-    }
+    if (qbn < q1 && j < LP) r_n = fetch_ops<FUSED>(loc, attn, (int64_t)b * Q + min(qbn + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
+    float2 xy;
+    float w, dloc_;
+    resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc_);
     int roff = 0;
     float clo = 0.f, chi = 0.f;
     if (j < LP) {
@@ -419,14 +468,16 @@ __host__ __device__ inline size_t bwd_lds_bytes(int S, int nq) {
   return regionA + hist + ents;
 }
 
-template <int PAD, bool FULL16>
+// FUSED: loc -> proj, attn -> ref (see fetch_ops); gloc -> grad_proj (B*Q, 2*M*LP), gattn -> grad_ref partials
+// (B,Q,M,L,RD) or nullptr.  The softmax / location backward of ms_deform_attn.py:99-109 is applied in the epilogue.
+template <int PAD, bool FULL16, bool FUSED>
 __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__restrict__ value,
                                                              const int64_t *__restrict__ shapes,
                                                              const int64_t *__restrict__ lsi,
                                                              const float *__restrict__ loc,
                                                              const float *__restrict__ attn,
                                                              const float *__restrict__ gout, int B, int S, int M, int L,
-                                                             int Q, int P, int nchunk, int qper,
+                                                             int Q, int P, int RD, int nchunk, int qper,
                                                              float *__restrict__ gvalue_part,
                                                              float *__restrict__ gloc, float *__restrict__ gattn) {
   extern __shared__ float4 slab4[];
@@ -448,23 +499,19 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int LP = FULL16 ? 16 : L * P;
   int Tl = 1, st = 0;
+  const int lvl = j < LP ? j / P : 0;
   if (j < LP) {
-    const int l = j / P;
-    Tl = (int)shapes[2 * l + 1];
-    st = (int)lsi[l];
+    Tl = (int)shapes[2 * lvl + 1];
+    st = (int)lsi[lvl];
   }
   // operands of the first pass are requested before the slab staging; every pass prefetches the next one's
   int qb = q0 + wave * 4;
-  float2 xy_n = make_float2(0.f, 0.5f);
-  float w_n = 0.f;
+  RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
   float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
   if (qb < q1) {
-    const int64_t tupn = ((int64_t)b * Q + min(qb + tq, q1 - 1)) * M + m;
-    if (j < LP) {
-      xy_n = reinterpret_cast<const float2 *>(loc)[tupn * LP + j];
-      w_n = attn[tupn * LP + j];
-    }
-    if (qb + tq < q1) g_n = reinterpret_cast<const float4 *>(gout)[tupn * 16 + j];
+    const int64_t bqn = (int64_t)b * Q + min(qb + tq, q1 - 1);
+    if (j < LP) r_n = fetch_ops<FUSED>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+    if (qb + tq < q1) g_n = reinterpret_cast<const float4 *>(gout)[(bqn * M + m) * 16 + j];
   }
   stage_slab(slab4, value, b, m, S, M);
   for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
@@ -477,18 +524,18 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
     const bool act = q < q1;
     const int qq = act ? q : q1 - 1;
     const int64_t tb = (((int64_t)b * Q + qq) * M + m) * LP;
-    const float2 xy = xy_n;
-    const float w = w_n;
+    const RawOps r = r_n;
     const float4 g = g_n;
     const int qbn = qb + nw * 4;
     if (qbn < q1) {
-      const int64_t tupn = ((int64_t)b * Q + min(qbn + tq, q1 - 1)) * M + m;
-      if (j < LP) {
-        xy_n = reinterpret_cast<const float2 *>(loc)[tupn * LP + j];
-        w_n = attn[tupn * LP + j];
-      }
-      g_n = (qbn + tq < q1) ? reinterpret_cast<const float4 *>(gout)[tupn * 16 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t bqn = (int64_t)b * Q + min(qbn + tq, q1 - 1);
+      if (j < LP) r_n = fetch_ops<FUSED>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+      g_n = (qbn + tq < q1) ? reinterpret_cast<const float4 *>(gout)[(bqn * M + m) * 16 + j]
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float2 xy;
+    float w, dloc;
+    resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc);
     int roff = 0;
     float clo = 0.f, chi = 0.f, dxlo = 0.f, dxhi = 0.f, dylo = 0.f, dyhi = 0.f;
     if (j < LP) {
@@ -528,9 +575,30 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
     GVL_BWD_STEP(8) GVL_BWD_STEP(9) GVL_BWD_STEP(10) GVL_BWD_STEP(11)
     GVL_BWD_STEP(12) GVL_BWD_STEP(13) GVL_BWD_STEP(14) GVL_BWD_STEP(15)
 #undef GVL_BWD_STEP
-    if (act && j < LP) {
-      gattn[tb + j] = keep_w;                                                  // cuh:156-157
-      reinterpret_cast<float2 *>(gloc)[tb + j] = make_float2(keep_x, keep_y);
+    if (!FUSED) {
+      if (act && j < LP) {
+        gattn[tb + j] = keep_w;                                                // cuh:156-157
+        reinterpret_cast<float2 *>(gloc)[tb + j] = make_float2(keep_x, keep_y);
+      }
+    } else {
+      // softmax backward (ms_deform_attn.py:100-101): d logit_j = w_j (g_j - sum_k w_k g_k), g = d out / d w
+      const float dsum = row_allsum(w * keep_w);
+      const float glogit = w * (keep_w - dsum);
+      const float goff = keep_x * dloc;                                        // d loc / d offset (:103-109)
+      // d loc / d ref: the P points of a level share its reference point -> sum over the quad (P == 4)
+      float gr0 = keep_x, gr1 = keep_x * r.a * (0.5f / (float)P);
+      gr0 += dpp_f<0xB1>(gr0); gr0 += dpp_f<0x4E>(gr0);
+      gr1 += dpp_f<0xB1>(gr1); gr1 += dpp_f<0x4E>(gr1);
+      if (act) {
+        float *grow = gloc + ((int64_t)b * Q + qq) * (int64_t)(2 * M * LP);
+        grow[m * LP + j] = goff;
+        grow[M * LP + m * LP + j] = glogit;
+        if (gattn && (j & 3) == 0) {
+          float *gr = gattn + ((((int64_t)b * Q + qq) * M + m) * L + lvl) * RD;
+          gr[0] = gr0;
+          if (RD == 2) gr[1] = gr1;
+        }
+      }
     }
   }
   __syncthreads();
@@ -672,13 +740,14 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
       const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
       const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
       const bool full = L * P == 16;
-      auto kern = pad == kPadZeros ? (full ? k_fwd_t1d_d64<kPadZeros, true> : k_fwd_t1d_d64<kPadZeros, false>)
-                                   : (full ? k_fwd_t1d_d64<kPadBorder, true> : k_fwd_t1d_d64<kPadBorder, false>);
+      auto kern = pad == kPadZeros
+                      ? (full ? k_fwd_t1d_d64<kPadZeros, true, false> : k_fwd_t1d_d64<kPadZeros, false, false>)
+                      : (full ? k_fwd_t1d_d64<kPadBorder, true, false> : k_fwd_t1d_d64<kPadBorder, false, false>);
       if (int rc = ensure_lds(kern, lds)) return rc;
       g_last_impl = 2;
       return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(threads), lds, st,
                          (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn, B, S, M, L, Q, P,
-                         nchunk, (float *)out);
+                         0, nchunk, (float *)out);
     }
   }
   int64_t blocks = (n + 255) / 256;
@@ -745,12 +814,13 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         part = (float *)ws;
       }
       const bool full = L * P == 16;
-      auto kern = pad == kPadZeros ? (full ? k_bwd_t1d_d64<kPadZeros, true> : k_bwd_t1d_d64<kPadZeros, false>)
-                                   : (full ? k_bwd_t1d_d64<kPadBorder, true> : k_bwd_t1d_d64<kPadBorder, false>);
+      auto kern = pad == kPadZeros
+                      ? (full ? k_bwd_t1d_d64<kPadZeros, true, false> : k_bwd_t1d_d64<kPadZeros, false, false>)
+                      : (full ? k_bwd_t1d_d64<kPadBorder, true, false> : k_bwd_t1d_d64<kPadBorder, false, false>);
       if (int rc = ensure_lds(kern, lds)) return rc;
       if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(kBwdThreads),
                                lds, st, (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn,
-                               (const float *)gout, B, S, M, L, Q, P, nchunk, qper_f, part, (float *)gloc,
+                               (const float *)gout, B, S, M, L, Q, P, 0, nchunk, qper_f, part, (float *)gloc,
                                (float *)gattn))
         return rc;
       if (nchunk > 1) {
@@ -853,6 +923,85 @@ int gvl_msda_backward_f64(const double *value, const int64_t *shapes, const int6
   return backward_impl<double>(value, shapes, lsi, loc, attn, grad_out, B, S, M, D, L, Q, P, pad_mode, shapes_host,
                                lsi_host, grad_value, grad_loc, grad_attn, workspace, workspace_bytes,
                                (hipStream_t)stream);
+}
+
+// ---- fused module path: MSDeformAttn.forward between the projection GEMM and output_proj (ms_deform_attn.py:99-124)
+static int fused_eligible(int B, int S, int M, int D, int L, int Q, int P, int RD, int pad, const int64_t *shapes_host,
+                          const int64_t *lsi_host) {
+  if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
+  if (D != 64 || L * P != 16 || P != 4 || (RD != 1 && RD != 2) || S <= 0)
+    return fail(GVL_EINVAL, "gvl_msda1d_fused: needs D=64, L*P=16, P=4, RD in {1,2} (got D=%d L=%d P=%d RD=%d)", D, L, P,
+                RD);
+  if (!temporal_host(shapes_host, lsi_host, L, S))
+    return fail(GVL_EINVAL, "gvl_msda1d_fused: needs host copies of temporal (H=1) level shapes");
+  return 0;
+}
+
+int gvl_msda1d_fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
+                                 const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
+                                 int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
+                                 void *stream) {
+  if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
+  if ((int64_t)B * Q == 0) return 0;
+  if (!value || !shapes || !lsi || !proj || !ref || !out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: null pointer");
+  const size_t lds = (size_t)(S + 1) * 64 * sizeof(float);
+  if (lds > kLdsMax) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: slab of %d rows does not fit LDS", S);
+  const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
+  const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
+  auto kern = pad_mode == kPadZeros ? k_fwd_t1d_d64<kPadZeros, true, true> : k_fwd_t1d_d64<kPadBorder, true, true>;
+  if (int rc = ensure_lds(kern, lds)) return rc;
+  g_last_impl = 3;
+  return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64<fused>", kern, dim3(nchunk * B * M), dim3(threads), lds,
+                     (hipStream_t)stream, value, shapes, lsi, proj, ref, B, S, M, L, Q, P, RD, nchunk, out);
+}
+
+size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P) {
+  return gvl_msda_backward_workspace_bytes(B, S, M, D, L, Q, P, 4);
+}
+
+int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
+                                  const float *ref, const float *grad_out, int B, int S, int M, int D, int L, int Q,
+                                  int P, int RD, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
+                                  float *grad_value, float *grad_proj, float *grad_ref, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t gv_bytes = (size_t)B * S * M * D * sizeof(float);
+  if (gv_bytes && !grad_value) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
+  if ((int64_t)B * Q == 0) {
+    if (gv_bytes && hipMemsetAsync(grad_value, 0, gv_bytes, st) != hipSuccess)
+      return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: memset failed");
+    return 0;
+  }
+  if (!value || !shapes || !lsi || !proj || !ref || !grad_out || !grad_proj)
+    return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
+  const int nchunk = bwd_chunks(B, M, Q, S);
+  if (nchunk <= 0) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: problem does not fit LDS");
+  const int qper = (Q + nchunk - 1) / nchunk;
+  const size_t lds = bwd_lds_bytes(S, qper);
+  float *part = grad_value;
+  if (nchunk > 1) {
+    if (!workspace || workspace_bytes < gv_bytes * nchunk)
+      return fail(GVL_ENOSPC, "gvl_msda1d_fused_backward: workspace %zu < required %zu bytes", workspace_bytes,
+                  gv_bytes * nchunk);
+    part = (float *)workspace;
+  }
+  auto kern = pad_mode == kPadZeros ? k_bwd_t1d_d64<kPadZeros, true, true> : k_bwd_t1d_d64<kPadBorder, true, true>;
+  if (int rc = ensure_lds(kern, lds)) return rc;
+  if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64<fused>", kern, dim3(nchunk * B * M), dim3(kBwdThreads),
+                           lds, st, value, shapes, lsi, proj, ref, grad_out, B, S, M, L, Q, P, RD, nchunk, qper, part,
+                           grad_proj, grad_ref))
+    return rc;
+  if (nchunk > 1) {
+    const int64_t count4 = (int64_t)B * S * M * 16;
+    int64_t blocks = (count4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (int rc = gvl::launch(GVL_PROF_SUM_PARTIALS, Q, B, "k_sum_partials", k_sum_partials, dim3((unsigned)blocks),
+                             dim3(256), 0, st, (const float4 *)part, nchunk, count4, (float4 *)grad_value))
+      return rc;
+  }
+  g_last_impl = 3;
+  return 0;
 }
 
 }  // extern "C"

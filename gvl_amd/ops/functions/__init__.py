@@ -1,1 +1,2 @@
-from .ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnPadFunction, MSDASampleFunction  # noqa: F401
+from .ms_deform_attn_func import (MSDeformAttnFunction, MSDeformAttnPadFunction, MSDASampleFunction,  # noqa: F401
+                                   MSDeformAttnFusedFunction)

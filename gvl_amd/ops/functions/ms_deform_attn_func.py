@@ -82,3 +82,29 @@ class MSDASampleFunction(Function):
         value, shapes, lsi, loc = ctx.saved_tensors
         gv, gl = MSDA.ms_deform_attn_sample_backward(value, shapes, lsi, loc, grad_sample.contiguous(), ctx.pad_mode)
         return gv, None, None, gl, None
+
+
+class MSDeformAttnFusedFunction(Function):
+    """MSDeformAttn.forward between its projection GEMM and output_proj (ms_deform_attn.py:99-124) as ONE op:
+    (value, proj = [raw offsets | attention logits], reference points) -> sampled output.  The softmax, the
+    location arithmetic and their backward live inside the HIP kernels; loc / attn never exist in HBM."""
+
+    @staticmethod
+    def forward(ctx, value, proj, reference_points, spatial_shapes, level_start_index, n_levels, n_points, pad_mode):
+        ctx.cfg = (n_levels, n_points, pad_mode)
+        ctx.host = MSDA.host_shapes(spatial_shapes, level_start_index)
+        out = MSDA.msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, reference_points, n_levels,
+                                        n_points, pad_mode)
+        ctx.save_for_backward(value, proj, reference_points, spatial_shapes, level_start_index)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, proj, ref, shapes, lsi = ctx.saved_tensors
+        if getattr(shapes, "_gvl_host", None) is None:
+            shapes._gvl_host = ctx.host
+        n_levels, n_points, pad_mode = ctx.cfg
+        gv, gp, gr = MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref, grad_output.contiguous(), n_levels,
+                                                n_points, pad_mode, need_ref_grad=ctx.needs_input_grad[2])
+        return gv, gp, gr, None, None, None, None, None

@@ -62,6 +62,7 @@ class MSDeformAttn(nn.Module):
         self.im2col_step = im2col_step
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
         self.pad_mode = pad_mode
+        self.fused = True              # use the fused projection-epilogue + sampling kernels when the shape allows
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
         self.value_proj = nn.Linear(d_model, d_model)
@@ -102,6 +103,26 @@ class MSDeformAttn(nn.Module):
                 reference_points.shape[-1]))
         return torch.stack((x, torch.full_like(x, 0.5)), -1)
 
+    def _fused_eligible(self, query, input_flatten, host_lengths):
+        """domain of the fused HIP path (include/gvl_msda.h: gvl_msda1d_fused_*)"""
+        return (self.fused and host_lengths is not None and query.dtype == torch.float32
+                and self.d_model // self.n_heads == 64 and self.n_levels * self.n_points == 16 and self.n_points == 4
+                and input_flatten.shape[1] <= 600)
+
+    def _forward_fused(self, query, reference_points, input_flatten, shapes2d, level_start_index, padding_mask):
+        N, Len_in, _ = input_flatten.shape
+        value = self.value_proj(input_flatten)
+        if padding_mask is not None:
+            value = value.masked_fill(padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        # one GEMM for both projections: columns [0,128) raw offsets, [128,256) attention logits
+        w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+        b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        proj = F.linear(query, w_cat, b_cat)
+        out = _fn.MSDeformAttnFusedFunction.apply(value, proj, reference_points.contiguous(), shapes2d,
+                                                  level_start_index, self.n_levels, self.n_points, self.pad_mode)
+        return self.output_proj(out)
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """query (N, Lq, C); reference_points (N, Lq, L, 1|2); input_flatten (N, sum T_l, C);
@@ -115,9 +136,15 @@ class MSDeformAttn(nn.Module):
             assert sum(host[0]) == input_flatten.shape[1]
         else:                                     # ms_deform_attn.py:93 (synchronises, as the reference does)
             assert input_spatial_shapes.sum() == input_flatten.shape[1]
+        if reference_points.shape[-1] not in (1, 2):
+            raise ValueError('Last dim of reference_points must be 1 or 2, but get {} instead.'.format(
+                reference_points.shape[-1]))
+        shapes2d = temporal_shapes_2d(input_spatial_shapes, input_level_start_index)
+        if self._fused_eligible(query, input_flatten, host):
+            return self._forward_fused(query, reference_points, input_flatten, shapes2d, input_level_start_index,
+                                       input_padding_mask)
         value, off, aw = self._project(query, input_flatten, input_padding_mask)
         loc = self._locations(reference_points, off, input_spatial_shapes)
-        shapes2d = temporal_shapes_2d(input_spatial_shapes, input_level_start_index)
         if self.pad_mode == "zeros":
             out = _fn.MSDeformAttnFunction.apply(value, shapes2d, input_level_start_index, loc, aw, self.im2col_step)
         else:

@@ -53,7 +53,7 @@ const char *gvl_last_error(void);
 /* Force a kernel family for A/B testing: 0 = auto (default), 1 = generic only, 2 = fast where eligible.
  * (Also settable through the environment variable GVL_MSDA_IMPL=auto|generic|fast before first use.) */
 void gvl_msda_set_impl(int impl);
-/* Which family the most recent forward/backward call on this thread used: 1 generic, 2 fast. */
+/* Which family the most recent forward/backward call on this thread used: 1 generic, 2 fast, 3 fused. */
 int gvl_msda_last_impl(void);
 
 /* -- kernel timing inside the library (measurement only; no reference equivalent).  While enabled, every kernel the
@@ -110,6 +110,29 @@ int gvl_msda_backward_f64(const double *value, const int64_t *shapes, const int6
                           int P, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
                           double *grad_value, double *grad_loc, double *grad_attn, void *workspace,
                           size_t workspace_bytes, void *stream);
+
+/* -- fused module path (temporal levels, fp32, D = 64, L*P = 16, P = 4): everything MSDeformAttn.forward does between
+ *    its projection GEMM and output_proj (pdvc/ops/modules/ms_deform_attn.py:99-124) in one launch, so that the
+ *    sampling locations and attention weights never exist in HBM.
+ *      proj  (B*Q, 2*M*L*P)  query @ [sampling_offsets.weight; attention_weights.weight]^T + bias:
+ *                            columns [0, M*L*P) raw offsets (m,l,p), [M*L*P, 2*M*L*P) attention logits (m, l*p)
+ *      ref   (B, Q, L, RD)   reference points, RD = 1 (centre) or 2 (centre, length)
+ *    forward:  softmax over L*P (:100-101); loc = ref + off / T_l (RD=1, :103-106) or ref_c + off/P*ref_len*0.5
+ *              (RD=2, :107-109); y = 0.5 (:115); then the op.  out (B, Q, M*D).
+ *    backward: grad_value (B,S,M,D); grad_proj (B*Q, 2*M*L*P) (offsets and logits, softmax backward applied);
+ *              grad_ref (B,Q,M,L,RD) per-head partials of d/d ref (may be NULL; the caller sums over M).
+ *    host copies of shapes / lsi are REQUIRED here (the temporal kernels are the only implementation).
+ *    Returns GVL_EINVAL when the shape is outside the fused kernels' domain (callers then use the unfused op). */
+int gvl_msda1d_fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
+                                 const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
+                                 int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
+                                 void *stream);
+size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P);
+int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
+                                  const float *ref, const float *grad_out, int B, int S, int M, int D, int L, int Q,
+                                  int P, int RD, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
+                                  float *grad_value, float *grad_proj, float *grad_ref, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 
 /* -- backward of gvl_msda_sample: autograd of ms_deform_attn_core_pytorch(return_value=True) (func.py:44-68; the
  *    reference differentiates through F.grid_sample).  grad_sample (B*M, D, Q, L, P) -> grad_value (B,S,M,D)

@@ -13,8 +13,13 @@ def strip(sd, prefix):
 
 @pytest.mark.parametrize("refdim", [1, 2])
 @pytest.mark.parametrize("pad", ["zeros", "border"])
-def test_msdeformattn_module_golden(refdim, pad):
+@pytest.mark.parametrize("fused", [False, True])
+def test_msdeformattn_module_golden(refdim, pad, fused):
+    """fused=True: level tensors carry host lengths -> the fused projection-epilogue + sampling kernels
+    (gvl_msda1d_fused_*); fused=False: plain device tensors as the reference passes -> unfused op."""
     from gvl_amd.ops.modules import MSDeformAttn
+    from gvl_amd.deformable_transformer import make_level_tensors
+    from gvl_amd import _lib
     dev = torch.device("cuda:0")
     f = load(f"module_ref{refdim}")
     B, Q, C, M, L, P, _ = [int(v) for v in f["meta"]]
@@ -28,7 +33,14 @@ def test_msdeformattn_module_golden(refdim, pad):
     if refdim == 2:
         ref[..., 1] = ref[..., 1] * 0.5
     gout = t(synth_array(f"mod{refdim}.gout", (B, Q, C), 1)).to(dev)
-    out = mod(query, ref.to(dev), inp, t(f["tshapes"]).to(dev), t(f["lsi"]).to(dev), t(f["mask"]).to(dev))
+    if fused:
+        tsh, lsi = make_level_tensors(f["tshapes"].tolist(), dev)
+        ref = ref.clone().requires_grad_()
+    else:
+        tsh, lsi = t(f["tshapes"]).to(dev), t(f["lsi"]).to(dev)
+    ref_d = ref.to(dev)
+    out = mod(query, ref_d, inp, tsh, lsi, t(f["mask"]).to(dev))
+    assert _lib.lib().gvl_msda_last_impl() == (3 if fused else 2)
     assert maxerr(out, f[f"out_{pad}"]) < 1e-4
     out.backward(gout)
     assert maxerr(query.grad, f[f"gquery_{pad}"]) < 1e-3
