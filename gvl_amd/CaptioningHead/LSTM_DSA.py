@@ -204,7 +204,7 @@ class Captioner(nn.Module):
                                   input_level_start_index, mask)
         return F.log_softmax(self.logit(self.dropout(output)), dim=1), state
 
-    def forward(self, hs, reference, others, cap_tensor):
+    def forward(self, hs, reference, others, cap_tensor, steps=None):
         """Teacher-forced log-probs (LSTM_DSA.py:63-117) -> (B*Q, steps, vocab+1)."""
         seq = cap_tensor.long()
         vid_num, query_num, _ = hs.shape
@@ -216,7 +216,14 @@ class Captioner(nn.Module):
         c = hs.new_zeros(n, self.rnn_size)
         w_x = self.core.rnn.weight_ih_l0[:, :self.input_encoding_size]
         outputs = []
-        for i in range(seq.size(1) - 1):
+        # the reference leaves the loop at the first step i >= 1 whose input column is all <pad> (:110-112), testing
+        # it on the host every step; the same cut computed with ONE read (or none: pass `steps` when the caller
+        # already knows the caption lengths, e.g. under graph capture)
+        if steps is None:
+            live = (seq[:, 1:] != 0).any(0).cpu().tolist()
+            steps = 1 + (live.index(False) if False in live else len(live))
+            steps = min(steps, seq.size(1) - 1)
+        for i in range(steps):
             if self.training and i >= 1 and self.ss_prob > 0.0:
                 prob = hs.new_zeros(n).uniform_(0, 1)
                 take = prob < self.ss_prob
@@ -227,8 +234,6 @@ class Captioner(nn.Module):
                     it.index_copy_(0, ind, torch.multinomial(prev, 1).view(-1).index_select(0, ind))
             else:
                 it = seq[:, i].clone()
-            if i >= 1 and seq[:, i].sum() == 0:
-                break
             out, (h, c) = self.core.step(F.linear(self.embed(it), w_x), (h, c), hs, ref_in, tshapes, lsi, const)
             outputs.append(F.log_softmax(self.logit(self.dropout(out)), dim=1))
         return torch.stack(outputs, 1)

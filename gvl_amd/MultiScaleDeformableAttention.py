@@ -248,7 +248,7 @@ def row_argmax_lse(logits):
 
 
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
-             7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell"}
+             7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap"}
 
 
 def profile_enable(on=True):

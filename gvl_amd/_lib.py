@@ -38,6 +38,7 @@ SIGNATURES = {
     "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),
+    "gvl_lsap_batch_device_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "gvl_hungarian_batch_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I]),
 }
 

@@ -65,6 +65,7 @@ class SetCriterion(nn.Module):
         self.focal_gamma = focal_gamma
         self.opt = opt
         self.counter_class_rate = torch.tensor(COUNTER_CLASS_RATE)
+        self.device_matching = True      # solve the Hungarian problems on the GPU (bit-identical to scipy)
 
     @staticmethod
     def _pack(indices, targets, device):
@@ -89,8 +90,11 @@ class SetCriterion(nn.Module):
         st = self._state.get(key)
         if st is None:
             dev = outputs['pred_logits'].device
-            one2one, _ = indices
-            b, q, tg, cnt = self._pack(one2one, targets, dev)
+            if hasattr(indices, "plan"):                               # LayerMatch: already on the device
+                b, q, tg, cnt = indices.plan.vid_of_entry, indices.q, indices.t_global, indices.plan.cnt
+            else:
+                one2one, _ = indices
+                b, q, tg, cnt = self._pack(one2one, targets, dev)
             st = {"b": b, "q": q, "tg": tg, "cnt": cnt, "labels": self._tgt_cat[0], "boxes": self._tgt_cat[1]}
             self._state[key] = st
         return st
@@ -158,7 +162,11 @@ class SetCriterion(nn.Module):
                          torch.cat([t_["boxes"] for t_ in targets]).to(dev))
         self._gt_counts = torch.tensor([len(t_["boxes"]) for t_ in targets], dtype=torch.long).to(dev, non_blocking=True)
         batched = None
-        if hasattr(self.matcher, "match_layers"):
+        if hasattr(self.matcher, "match_layers_device") and dev.type == "cuda" and self.device_matching:
+            # all layers x videos solved on the device in one launch: no device->host copy at all
+            batched = self.matcher.match_layers_device([main] + list(aux_list), targets)
+            last_indices = batched[0]
+        elif hasattr(self.matcher, "match_layers"):
             # same matchings as one matcher call per layer, but one device->host copy for all layers
             batched = self.matcher.match_layers([main] + list(aux_list), targets)
             last_indices = batched[0]

@@ -70,6 +70,103 @@ def hungarian_batch(C, sizes, m2o_rate=4, num_threads=0):
     return indices, rl
 
 
+def lsap_batch_device(C, problems, out_total, max_rows, max_cols):
+    """Solve assignment problems on the device (include/gvl_msda.h: gvl_lsap_batch_device_f32).
+    C: float32 CUDA tensor (any shape; problems index its storage); problems: int64 CUDA tensor (n, 8) of
+    {base, ld, Q, n, tile, out_off, 0, 0}.  -> (rows (out_total,), cols (out_total,), status (1,) int32)"""
+    assert C.is_cuda and C.dtype == torch.float32 and C.is_contiguous()
+    assert problems.is_cuda and problems.dtype == torch.int64 and problems.is_contiguous() and problems.shape[1] == 8
+    rows = torch.empty(out_total, dtype=torch.int64, device=C.device)
+    cols = torch.empty(out_total, dtype=torch.int64, device=C.device)
+    status = torch.zeros(1, dtype=torch.int32, device=C.device)
+    with torch.cuda.device(C.device):
+        rc = _lib.lib().gvl_lsap_batch_device_f32(C.data_ptr(), problems.data_ptr(), problems.shape[0], max_rows,
+                                                  max_cols, rows.data_ptr(), cols.data_ptr(), status.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "lsap_batch_device")
+    return rows, cols, status
+
+
+class MatchPlan:
+    """Static (host-known) layout of one step's assignment problems: sizes of the GT sets are known on the host, so
+    problem descriptors, output offsets and the per-entry bookkeeping (video of every match, row of its target in
+    the concatenated targets) are built once per (layers, B, Q, sizes) and reused -- nothing here depends on data."""
+
+    def __init__(self, nl, B, Q, sizes, device, m2o_rate):
+        self.nl, self.B, self.Q, self.sizes, self.m2o = nl, B, Q, sizes, m2o_rate
+        G = sum(sizes)
+        coff = [0]
+        for n in sizes[:-1]:
+            coff.append(coff[-1] + n)
+        self.n1 = [min(Q, n) for n in sizes]
+        self.n4 = [min(Q, n * m2o_rate) for n in sizes]
+        t1, t4 = sum(self.n1), sum(self.n4)
+        self.t1, self.t4 = t1, t4
+        desc = []
+        for l in range(nl):
+            o = l * t1
+            for i, n in enumerate(sizes):
+                desc.append([((l * B + i) * Q) * G + coff[i], G, Q, n, 1, o, 0, 0])
+                o += self.n1[i]
+        for l in range(nl):
+            o = nl * t1 + l * t4
+            for i, n in enumerate(sizes):
+                desc.append([((l * B + i) * Q) * G + coff[i], G, Q, n, m2o_rate, o, 0, 0])
+                o += self.n4[i]
+        desc = [d for d in desc if d[3] > 0]                       # videos without GT have no problem
+        self.problems = torch.tensor(desc, dtype=torch.int64, device=device).reshape(-1, 8)
+        self.out_total = nl * (t1 + t4)
+        self.max_rows = max([1] + [min(Q, n * m2o_rate) for n in sizes])
+        self.max_cols = max([1] + [max(Q, n * m2o_rate) for n in sizes])
+        vid1 = [i for i, k in enumerate(self.n1) for _ in range(k)]
+        self.vid_of_entry = torch.tensor(vid1, dtype=torch.int64, device=device)
+        self.slot_of_entry = torch.tensor([k for n in self.n1 for k in range(n)], dtype=torch.int64, device=device)
+        self.tgt_base = torch.tensor([coff[i] for i in vid1], dtype=torch.int64, device=device)
+        self.cnt = torch.tensor(self.n1, dtype=torch.int64, device=device)
+
+
+class LayerMatch:
+    """The matching of one decoder layer, resident on the device.  ``q`` / ``t``: matched query id and (video-local)
+    target id of every match, videos concatenated; ``t_global`` the target's row in the concatenated targets.
+    Indexing ([0] -> indices, [1] -> rl_indices) materialises the reference's host structure (one copy)."""
+
+    def __init__(self, plan, layer, rows, cols, status, ok):
+        self.plan, self.layer = plan, layer
+        a = layer * plan.t1
+        self.q, self.t = rows[a:a + plan.t1], cols[a:a + plan.t1]
+        b = plan.nl * plan.t1 + layer * plan.t4
+        self.rl_q, self.rl_t = rows[b:b + plan.t4], cols[b:b + plan.t4]
+        self.status, self.ok = status, ok
+        self._host = None
+
+    @property
+    def t_global(self):
+        return self.t + self.plan.tgt_base
+
+    def check(self):
+        """raises what the reference raises (scipy ValueError / box_ops assert); costs one tiny device->host read"""
+        if int(self.status) != 0:
+            raise ValueError("cost matrix is infeasible / contains invalid numeric entries")
+        assert bool(self.ok), "degenerate boxes (x1 < x0) in the matcher"
+
+    def host(self):
+        if self._host is None:
+            self.check()
+            q, t_, rq, rt = (x.cpu() for x in (self.q, self.t, self.rl_q, self.rl_t))
+            self._host = ([(a, b) for a, b in zip(q.split(self.plan.n1), t_.split(self.plan.n1))],
+                          [(a, b) for a, b in zip(rq.split(self.plan.n4), rt.split(self.plan.n4))])
+        return self._host
+
+    def __getitem__(self, k):
+        return self.host()[k]
+
+    def __iter__(self):
+        return iter(self.host())
+
+    def __len__(self):
+        return 2
+
+
 class HungarianMatcher(nn.Module):
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, cost_alpha=0.25,
                  cost_gamma=2, cost_cl=0, opt=None):
@@ -77,6 +174,7 @@ class HungarianMatcher(nn.Module):
         self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
         self.cost_alpha, self.cost_gamma, self.cost_cl = cost_alpha, cost_gamma, cost_cl
         self.opt = opt
+        self._plans = {}
 
     @torch.no_grad()
     def cost_matrix(self, outputs, targets, tgt_cat=None, with_flag=False):
@@ -107,12 +205,34 @@ class HungarianMatcher(nn.Module):
             return C, ok
         return C
 
+    # ---- on-device matching (no device->host copy; capturable in a hipGraph) ----------------------------------
+    def _plan(self, nl, B, Q, sizes, device, m2o_rate=4):
+        key = (nl, B, Q, tuple(sizes), str(device), m2o_rate)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = MatchPlan(nl, B, Q, list(sizes), device, m2o_rate)
+            self._plans[key] = plan
+        return plan
+
+    @torch.no_grad()
+    def match_layers_device(self, outputs_list, targets):
+        """All decoder layers x videos x {one-to-one, 4x-tiled} assignment problems of a step in ONE kernel launch on
+        the device (gvl_lsap_batch_device_f32; bit-identical to scipy).  Returns one LayerMatch per layer whose
+        index tensors stay on the device; LayerMatch[0] / [1] materialise the reference's (indices, rl_indices)."""
+        sizes = [len(v["boxes"]) for v in targets]
+        tgt_cat = (torch.cat([v["labels"] for v in targets]), torch.cat([v["boxes"] for v in targets]))
+        Cs, oks = zip(*[self.cost_matrix(o, targets, tgt_cat, with_flag=True) for o in outputs_list])
+        C = torch.stack(Cs).float().contiguous()                      # (nl, B, Q, G)
+        nl, B, Q, G = C.shape
+        plan = self._plan(nl, B, Q, sizes, C.device)
+        rows, cols, status = lsap_batch_device(C, plan.problems, plan.out_total, plan.max_rows, plan.max_cols)
+        ok = torch.stack(oks).all()
+        return [LayerMatch(plan, l, rows, cols, status, ok) for l in range(nl)]
+
     @torch.no_grad()
     def match_layers(self, outputs_list, targets):
-        """The matcher for several decoder layers at once (criterion.py:173 + :192 call it once per layer, each with
-        its own device->host copy): all cost matrices are computed on the device, cross PCIe in ONE copy together
-        with the degenerate-box flag, and all layers x videos are solved in one batch of host threads.
-        Returns [(indices, rl_indices)] per layer, identical to calling forward() per layer."""
+        """Host variant: all cost matrices cross PCIe in ONE copy (with the degenerate-box flag) and are solved by the
+        C++ solver.  Returns [(indices, rl_indices)] per layer, identical to calling forward() per layer."""
         sizes = [len(v["boxes"]) for v in targets]
         tgt_cat = (torch.cat([v["labels"] for v in targets]), torch.cat([v["boxes"] for v in targets]))
         Cs, oks = zip(*[self.cost_matrix(o, targets, tgt_cat, with_flag=True) for o in outputs_list])
@@ -121,12 +241,7 @@ class HungarianMatcher(nn.Module):
         packed = torch.cat([torch.stack(Cs).float().reshape(-1), torch.stack(oks).float()]).cpu()
         assert bool(packed[-nl:].all()), "degenerate boxes (x1 < x0) in the matcher"          # box_ops.py:39-40
         C = packed[:-nl].view(nl * B, Q, G)
-        # layer l, video i owns the same column block as video i: present it as nl*B "videos" over nl copies of the
-        # column blocks by solving per layer (the C ABI takes one (B,Q,G) tensor per call; threads cover B)
-        res = []
-        for l in range(nl):
-            res.append(hungarian_batch(C[l * B:(l + 1) * B], sizes, m2o_rate=4))
-        return res
+        return [hungarian_batch(C[l * B:(l + 1) * B], sizes, m2o_rate=4) for l in range(nl)]
 
     @torch.no_grad()
     def forward(self, outputs, targets, verbose=False, return_C=False):

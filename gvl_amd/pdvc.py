@@ -269,7 +269,8 @@ class PDVC(nn.Module):
             layers = [num_pred - 1]
         for l_id in layers:
             reference = init_reference if l_id == 0 else inter_references[l_id - 1]
-            indices = last_indices[0] if l_id == num_pred - 1 else aux_indices[l_id][0]
+            layer_match = last_indices if l_id == num_pred - 1 else aux_indices[l_id]
+            indices = layer_match if hasattr(layer_match, "plan") else layer_match[0]
             hs_cap = torch.cat([hs[l_id], query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
                                                                                       False) else hs[l_id]
             cap_loss, probs, seq = self.caption_prediction(self.caption_head[l_id], dt, hs_cap, reference, others,
@@ -285,33 +286,60 @@ class PDVC(nn.Module):
         all-False mask and contribute 0 to the mean exactly as in the reference."""
         N_, N_q, C = hs.shape
         dev = hs.device
-        gt_nums = dt['gt_boxes_mask'].sum(1).cpu().tolist()
-        cap_base = [0]
-        for n in gt_nums[:-1]:
-            cap_base.append(cap_base[-1] + int(n))
-        max_pairs = max(len(f_) for f_, _ in indices)
         cap_len = dt['cap_tensor'].shape[-1]
-        hs_m = hs.new_zeros(N_, max_pairs, C)
-        ref_m = hs.new_zeros(N_, max_pairs, reference.shape[-1])
-        seq_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.long, device=dev)
-        mask_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.bool, device=dev)
-        all_caps = []
-        for i, (feat_ids, cap_ids) in enumerate(indices):
-            k = len(feat_ids)
-            f_dev = feat_ids.to(dev)
-            caps = (cap_base[i] + cap_ids).to(dev)
-            hs_m[i, :k] = hs[i, f_dev]
-            ref_m[i, :k] = reference[i, f_dev]
-            seq_m[i, :k] = dt['cap_tensor'][caps]
-            mask_m[i, :k] = dt['cap_mask'][caps].bool()
-            all_caps.append(caps)
+        if hasattr(indices, "plan"):
+            # device-resident matching (LayerMatch): one scatter with host-known static positions, no host sync.
+            # (captions of video i occupy rows [sum n_gt[:i], ...) of dt['cap_tensor'] -- the same offsets as the
+            #  concatenated targets, i.e. LayerMatch.t_global)
+            plan = indices.plan
+            max_pairs = max(plan.n1)
+            vid, slot, caps = plan.vid_of_entry, plan.slot_of_entry, indices.t_global
+            hs_m = hs.new_zeros(N_, max_pairs, C)
+            ref_m = hs.new_zeros(N_, max_pairs, reference.shape[-1])
+            seq_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.long, device=dev)
+            mask_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.bool, device=dev)
+            hs_m[vid, slot] = hs[vid, indices.q]
+            ref_m[vid, slot] = reference[vid, indices.q]
+            seq_m[vid, slot] = dt['cap_tensor'][caps].long()
+            mask_m[vid, slot] = dt['cap_mask'][caps].bool()
+            all_caps = [caps]
+        else:
+            indices = indices[0] if not isinstance(indices, list) else indices
+            gt_nums = [len(t_['boxes']) for t_ in dt['video_target']]
+            cap_base = [0]
+            for n in gt_nums[:-1]:
+                cap_base.append(cap_base[-1] + int(n))
+            max_pairs = max(len(f_) for f_, _ in indices)
+            hs_m = hs.new_zeros(N_, max_pairs, C)
+            ref_m = hs.new_zeros(N_, max_pairs, reference.shape[-1])
+            seq_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.long, device=dev)
+            mask_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.bool, device=dev)
+            all_caps = []
+            for i, (feat_ids, cap_ids) in enumerate(indices):
+                k = len(feat_ids)
+                f_dev = feat_ids.to(dev)
+                caps = (cap_base[i] + cap_ids).to(dev)
+                hs_m[i, :k] = hs[i, f_dev]
+                ref_m[i, :k] = reference[i, f_dev]
+                seq_m[i, :k] = dt['cap_tensor'][caps]
+                mask_m[i, :k] = dt['cap_mask'][caps].bool()
+                all_caps.append(caps)
         seq_flat, mask_flat = seq_m.flatten(0, 1), mask_m.flatten(0, 1)
+        # teacher-forcing length: the reference stops at the first all-<pad> input column of the matched captions; when
+        # every caption is matched (Q >= #GT) that is a property of dt['cap_tensor'] alone -> read it once per batch
+        steps = None
+        if all(len(t_['boxes']) <= N_q for t_ in dt['video_target']):
+            steps = dt.get('_gvl_cap_steps')
+            if steps is None:
+                live = (dt['cap_tensor'][:, 1:] != 0).any(0).cpu().tolist()
+                steps = min(1 + (live.index(False) if False in live else len(live)), cap_len - 1)
+                dt['_gvl_cap_steps'] = steps
         if self.training:
-            cap_prob = cap_head(hs_m, ref_m, others, seq_flat)
+            cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=steps)
             probs, seq = {}, dt['cap_tensor'][torch.cat(all_caps)]
         else:
             with torch.no_grad():
-                cap_prob = cap_head(hs_m, ref_m, others, seq_flat)
+                cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=steps)
                 seq, cap_prob_eval = cap_head.sample(hs, reference, others)
                 if len(seq):
                     seq = seq.reshape(-1, N_q, seq.shape[-1])

@@ -72,6 +72,7 @@ int gvl_msda_last_impl(void);
 #define GVL_PROF_CAP_ATTEND 8
 #define GVL_PROF_ROW_ARGMAX 9
 #define GVL_PROF_LSTM_CELL 10
+#define GVL_PROF_LSAP 11
 int gvl_prof_enable(int on);
 int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
 
@@ -186,6 +187,19 @@ int gvl_lsap_solve_f32(const float *cost, int64_t nr, int64_t nc, int64_t *row_i
  * (<= 0: hardware concurrency). */
 int gvl_hungarian_batch_f32(const float *C, int B, int Q, int G, const int *sizes, int m2o_rate, int64_t *idx_rows,
                             int64_t *idx_cols, int64_t *rl_rows, int64_t *rl_cols, int num_threads);
+
+/* The same index path ON THE DEVICE: one wavefront per assignment problem, all problems of a step in one launch,
+ * no device->host copy (which is what lets a whole train / eval step be captured in a hipGraph).  Bit-identical
+ * to gvl_lsap_solve_* / scipy (same float64 arithmetic and tie-breaking; tests/test_gpu_lsap.py).
+ *   C         DEVICE float32 cost storage
+ *   problems  DEVICE int64 [n_problems][8]: {base, ld, Q, n, tile, out_off, 0, 0}; problem p is the Q x (n*tile)
+ *             matrix with element (q, k) = C[base + q*ld + (k % n)]  (tile = 1: one-to-one, tile = 4: the
+ *             many-to-one variant of matcher.py:125-127 with GT id = col % n)
+ *   rows_out / cols_out  DEVICE int64; problem p writes min(Q, n*tile) entries at out_off (rows ascending)
+ *   status    DEVICE int, set to 1 if any problem is infeasible / has NaN or -inf costs (caller zeroes it)
+ *   max_rows / max_cols: the largest min(Q, n*tile) and max(Q, n*tile) over the problems (<= 256 / <= 1024). */
+int gvl_lsap_batch_device_f32(const float *C, const int64_t *problems, int n_problems, int max_rows, int max_cols,
+                              int64_t *rows_out, int64_t *cols_out, int *status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--Q", type=int, default=300)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--cold", action="store_true", help="evict L2 / Infinity Cache (write 1 GiB) before every profiled launch")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, D, L, P = 8, 64, 4, 4
@@ -34,6 +35,7 @@ def main():
     lsi = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.long, device=dev)
     g = torch.Generator(device=dev).manual_seed(0)
     value = torch.randn(a.B, S, M, D, device=dev, generator=g)
+    evict = torch.zeros(1 << 28, device=dev) if a.cold else None
     for name, Q in (("enc", S), ("dec", a.Q)):
         loc = torch.rand(a.B, Q, M, L, P, 2, device=dev, generator=g) * 1.5 - 0.25
         loc[..., 1] = 0.5
@@ -62,6 +64,10 @@ def main():
                 wall = e0.elapsed_time(e1) * 1e3 / a.iters
                 MSDA.profile_enable(True)
                 for _ in range(20):
+                    if a.cold:
+                        MSDA.profile_enable(False)
+                        evict.add_(1.0)
+                        MSDA.profile_enable(True)
                     fn()
                 torch.cuda.synchronize()
                 MSDA.profile_enable(False)
@@ -73,6 +79,36 @@ def main():
                 print(f"{name:3s} Q={Q:4d} {impl:7s} {what}: wall {wall:7.2f} us/call | kernels {us:7.2f} us ({ktxt}) | "
                       f"alg {nbytes / 1e6:6.2f} MB -> {nbytes / us / 1e6:6.3f} TB/s = {nbytes / us / 1e6 / 8 * 100:5.1f}% of 8 TB/s")
     _lib.lib().gvl_msda_set_impl(0)
+    # fused module path: proj = [offsets | logits], ref points
+    for name, Q in (("enc", S), ("dec", a.Q)):
+        proj = torch.randn(a.B, Q, 2 * M * L * P, device=dev, generator=g)
+        ref = torch.rand(a.B, Q, L, 1, device=dev, generator=g)
+        gout = torch.randn(a.B, Q, M * D, device=dev, generator=g)
+        shapes._gvl_host = (np.array([(1, x) for x in lens], np.int64), np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64))
+        fbytes = 4 * a.B * (S * 512 + 3 * Q * M * L * P + Q * 512)
+        bbytes = 4 * a.B * (2 * S * 512 + 6 * Q * M * L * P + Q * 512)
+        for what, fn, nbytes in (
+                ("fwd", lambda: MSDA.msda1d_fused_forward(value, shapes, lsi, proj, ref, L, P), fbytes),
+                ("bwd", lambda: MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref, gout, L, P), bbytes)):
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            MSDA.profile_enable(True)
+            for _ in range(20):
+                if a.cold:
+                    MSDA.profile_enable(False)
+                    evict.add_(1.0)
+                    MSDA.profile_enable(True)
+                fn()
+            torch.cuda.synchronize()
+            MSDA.profile_enable(False)
+            per = {}
+            for tag, ma, mb, t_us in MSDA.profile_collect():
+                per.setdefault(tag, []).append(t_us)
+            us = sum(sorted(v)[len(v) // 2] for v in per.values())
+            ktxt = " + ".join(f"{k} {sorted(v)[len(v) // 2]:.2f}" for k, v in per.items())
+            print(f"{name:3s} Q={Q:4d} fused   {what}: kernels {us:7.2f} us ({ktxt}) | alg {nbytes / 1e6:6.2f} MB -> "
+                  f"{nbytes / us / 1e6 / 8 * 100:5.1f}% of 8 TB/s")
 
 
 if __name__ == "__main__":
