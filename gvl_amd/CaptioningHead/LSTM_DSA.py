@@ -109,6 +109,8 @@ class ShowAttendTellCore(nn.Module):
                                       h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
                                       self.n_levels, self.n_points)
             g_x = torch.addmm(const["gates_hs"], att_res, const["w_att_t"])  # hs part + attention part of W_ih x
+            if not isinstance(xt_gates, tuple):                               # per-row pre-activations given directly
+                xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
             emb_gates, it = xt_gates                                          # (table (V+1,4H), token ids)
             h2, c2 = MSDA.lstm_cell(g_x, g_h[:, A:], emb_gates, it, c)
             return h2, (h2, c2)
@@ -142,10 +144,6 @@ class ShowAttendTellCore(nn.Module):
         """Reference call form (LSTM_DSA.py:241): state = (h (1,N,H), c (1,N,H)); returns (output, state)."""
         const = self.prepare(query, input_flatten, input_padding_mask)
         xt_gates = F.linear(xt.reshape(-1, xt.shape[-1]), self.rnn.weight_ih_l0[:, :self.input_encoding_size])
-        if "w_off_h" in const and not torch.is_grad_enabled():
-            # fused inference path: identity "embedding table" so that row i of xt_gates is its own token
-            n = xt_gates.shape[0]
-            xt_gates = (xt_gates.contiguous(), torch.arange(n, device=xt_gates.device))
         out, (h, c) = self.step(xt_gates, (state[0][-1].contiguous(), state[1][-1].contiguous()), query,
                                 reference_points, input_spatial_shapes, input_level_start_index, const)
         return out, (h[None], c[None])

@@ -66,6 +66,7 @@ class SetCriterion(nn.Module):
         self.opt = opt
         self.counter_class_rate = torch.tensor(COUNTER_CLASS_RATE)
         self.device_matching = True      # solve the Hungarian problems on the GPU (bit-identical to scipy)
+        self._const_cache = {}
 
     @staticmethod
     def _pack(indices, targets, device):
@@ -114,7 +115,10 @@ class SetCriterion(nn.Module):
         max_length = pred_count.shape[1] - 1
         cnt_onehot = torch.zeros_like(pred_count)
         cnt_onehot.scatter_(1, self._gt_counts.clamp(max=max_length).unsqueeze(-1), 1)
-        weight = self.counter_class_rate[:max_length + 1].to(dev)
+        wkey = ("ccr", max_length, str(dev))
+        weight = self._const_cache.get(wkey)
+        if weight is None:
+            weight = self._const_cache[wkey] = self.counter_class_rate[:max_length + 1].to(dev)
         losses['loss_counter'] = cross_entropy_with_gaussian_mask(pred_count, cnt_onehot, self.opt, weight)
         return losses
 
@@ -160,7 +164,11 @@ class SetCriterion(nn.Module):
         self._state = {}
         self._tgt_cat = (torch.cat([t_["labels"] for t_ in targets]).to(dev),
                          torch.cat([t_["boxes"] for t_ in targets]).to(dev))
-        self._gt_counts = torch.tensor([len(t_["boxes"]) for t_ in targets], dtype=torch.long).to(dev, non_blocking=True)
+        sizes_key = (tuple(len(t_["boxes"]) for t_ in targets), str(dev))
+        cached = self._const_cache.get(sizes_key)
+        if cached is None:        # constants of this batch layout live on the device once (no per-step host->device copy)
+            cached = self._const_cache[sizes_key] = torch.tensor(sizes_key[0], dtype=torch.long, device=dev)
+        self._gt_counts = cached
         batched = None
         if hasattr(self.matcher, "match_layers_device") and dev.type == "cuda" and self.device_matching:
             # all layers x videos solved on the device in one launch: no device->host copy at all

@@ -397,8 +397,7 @@ int sample_bwd_impl(const T *value, const int64_t *shapes, const int64_t *lsi, c
   const size_t gv_bytes = (size_t)B * S * M * D * sizeof(T);
   if (gv_bytes) {
     if (!gvalue) return fail(GVL_EINVAL, "gvl_msda_sample_backward: null pointer");
-    hipError_t e = hipMemsetAsync(gvalue, 0, gv_bytes, st);
-    if (e != hipSuccess) return fail((int)e, "gvl_msda_sample_backward: memset failed: %s", hipGetErrorString(e));
+    if (int rc = gvl::zero_fill(gvalue, gv_bytes, st)) return rc;
   }
   const int64_t ntup = (int64_t)B * Q * M;
   if (ntup == 0) return 0;

@@ -59,6 +59,31 @@ inline int launch(int tag, int meta_a, int meta_b, const char *what, K kernel, d
   return 0;
 }
 
+// zero-fill as a KERNEL node.  hipMemsetAsync inside a captured stream did not re-execute reliably on hipGraph replay
+// (ROCm 7.2: gradients accumulated on top of the previous replay's values), a kernel launch always does.
+__global__ inline void k_zero_fill(uint4 *__restrict__ p, size_t n16, unsigned char *__restrict__ tail, int ntail) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+inline int zero_fill(void *ptr, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if (reinterpret_cast<uintptr_t>(ptr) & 15) {               // not 16-byte aligned: fall back (never the case for torch)
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, st);
+    return e == hipSuccess ? 0 : fail((int)e, "gvl: memset failed: %s", hipGetErrorString(e));
+  }
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)(bytes % 16);
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint4 *>(ptr), n16,
+                     reinterpret_cast<unsigned char *>(ptr) + n16 * 16, ntail);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail((int)e, "gvl: zero-fill launch failed: %s", hipGetErrorString(e));
+}
+
 template <typename K>
 inline int ensure_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return 0;

@@ -789,8 +789,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   if (gv_bytes && !gvalue) return fail(GVL_EINVAL, "gvl_msda_backward: null pointer");
   if (ntup == 0) {
     if (gv_bytes) {
-      hipError_t e = hipMemsetAsync(gvalue, 0, gv_bytes, st);
-      if (e != hipSuccess) return fail((int)e, "gvl_msda_backward: memset failed: %s", hipGetErrorString(e));
+      if (int rc = gvl::zero_fill(gvalue, gv_bytes, st)) return rc;
     }
     return 0;
   }
@@ -835,8 +834,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       return 0;
     }
   }
-  hipError_t e = hipMemsetAsync(gvalue, 0, gv_bytes, st);
-  if (e != hipSuccess) return fail((int)e, "gvl_msda_backward: memset failed: %s", hipGetErrorString(e));
+  if (int rc = gvl::zero_fill(gvalue, gv_bytes, st)) return rc;
   int64_t blocks = (ntup + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;
   g_last_impl = 1;
@@ -969,9 +967,7 @@ int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, con
   const size_t gv_bytes = (size_t)B * S * M * D * sizeof(float);
   if (gv_bytes && !grad_value) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
   if ((int64_t)B * Q == 0) {
-    if (gv_bytes && hipMemsetAsync(grad_value, 0, gv_bytes, st) != hipSuccess)
-      return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: memset failed");
-    return 0;
+    return gvl::zero_fill(grad_value, gv_bytes, st);
   }
   if (!value || !shapes || !lsi || !proj || !ref || !grad_out || !grad_proj)
     return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");

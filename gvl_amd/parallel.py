@@ -94,11 +94,12 @@ class GradBuckets:
 class TrainStep:
     """zero_grad -> forward -> weighted loss -> backward (+ overlapped all-reduce) -> clip -> Adam (train.py:385-409)"""
 
-    def __init__(self, model, criterion, opt, world_size=1, process_group=None):
+    def __init__(self, model, criterion, opt, world_size=1, process_group=None, capturable=False):
         self.model, self.criterion, self.opt = model, criterion, opt
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = GradBuckets(self.params, process_group=process_group)
-        self.optimizer = torch.optim.Adam(self.params, lr=opt.lr, weight_decay=opt.weight_decay)
+        self.optimizer = torch.optim.Adam(self.params, lr=opt.lr, weight_decay=opt.weight_decay,
+                                          capturable=capturable)
         self.world = world_size
 
     def __call__(self, dt):
@@ -111,3 +112,83 @@ class TrainStep:
         torch.nn.utils.clip_grad_norm_(self.params, self.opt.grad_clip)
         self.optimizer.step()
         return final.detach(), loss
+
+
+class GraphedTrainStep(TrainStep):
+    """The whole train step -- forward, on-device Hungarian matching, losses, backward, gradient exchange, clipping and
+    Adam -- captured ONCE per batch layout in a hipGraph and replayed with a single launch.  The eager step issues
+    ~5 000 kernel launches whose host-side cost (~55 ms) exceeds their GPU time (~30 ms); nothing in the step reads
+    the device back (gvl_amd.matcher.LayerMatch stays on the device), which is what makes the capture possible.
+
+    Inputs are copied into static buffers before every replay; the batch layout (tensor shapes, number of events per
+    video, teacher-forcing length) is the cache key."""
+
+    def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=3):
+        super().__init__(model, criterion, opt, world_size, process_group, capturable=True)
+        self.graphs = {}
+        # >= 1 real step must run before the capture (on a side stream): autograd's gradient accumulators, hipBLASLt
+        # workspaces and the library's lazily built constants have to exist before a stream is capturing
+        self.warmup = max(1, int(warmup))
+        # Adam creates its state lazily inside the first step(); if that first step were the captured one, the
+        # zero-fills of (step, exp_avg, exp_avg_sq) would become graph nodes and every replay would reset the moments.
+        # Create the state now, exactly as torch.optim.Adam._init_group does for capturable=True.
+        for p in self.params:
+            st = self.optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    @staticmethod
+    def _tensor_keys(dt):
+        return [k for k, v in dt.items() if isinstance(v, torch.Tensor)]
+
+    def _key(self, dt):
+        sig = tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in self._tensor_keys(dt))
+        n_gt = tuple(len(t_["boxes"]) for t_ in dt["video_target"])
+        if "_gvl_cap_steps" not in dt:                      # teacher-forcing length: one host read per NEW batch
+            live = (dt["cap_tensor"][:, 1:] != 0).any(0).cpu().tolist()
+            dt["_gvl_cap_steps"] = min(1 + (live.index(False) if False in live else len(live)),
+                                       dt["cap_tensor"].shape[-1] - 1)
+        return sig, n_gt, dt["_gvl_cap_steps"]
+
+    def _static_copy(self, dt):
+        st = dict(dt)
+        for k in self._tensor_keys(dt):
+            st[k] = dt[k].clone()
+        st["video_target"] = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in t_.items()}
+                              for t_ in dt["video_target"]]
+        return st
+
+    @staticmethod
+    def _refresh(st, dt):
+        for k, v in dt.items():
+            if isinstance(v, torch.Tensor):
+                st[k].copy_(v, non_blocking=True)
+        for a, b in zip(st["video_target"], dt["video_target"]):
+            for k, v in b.items():
+                if isinstance(v, torch.Tensor):
+                    a[k].copy_(v, non_blocking=True)
+
+    def _eager(self, dt):
+        return TrainStep.__call__(self, dt)
+
+    def __call__(self, dt):
+        key = self._key(dt)
+        entry = self.graphs.get(key)
+        if entry is None:
+            st = self._static_copy(dt)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):               # real optimisation steps (Adam state, lazy inits, LDS attrs)
+                    self._eager(st)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._eager(st)
+            entry = self.graphs[key] = (graph, st, outs)        # capture records, it does not execute: replay below
+        graph, st, outs = entry
+        self._refresh(st, dt)
+        graph.replay()
+        return outs
