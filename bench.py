@@ -142,7 +142,11 @@ def main():
     else:
         from gvl_amd.parallel import GraphedTrainStep, TrainStep
         model.train()
-        trainer = (TrainStep if a.no_graph else GraphedTrainStep)(model, criterion, opt, world_size=world)
+        # hipGraph replay of the whole step is validated on one GPU (tests/test_gpu_model.py); with RCCL collectives
+        # inside the capture it is opt-in (GVL_GRAPH_DP=1) until it has been exercised on a multi-GPU node
+        use_graph = not a.no_graph and (world == 1 or os.environ.get("GVL_GRAPH_DP") == "1")
+        a.no_graph = not use_graph
+        trainer = (GraphedTrainStep if use_graph else TrainStep)(model, criterion, opt, world_size=world)
 
         def step():
             return trainer(dt)

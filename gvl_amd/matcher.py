@@ -190,11 +190,13 @@ class HungarianMatcher(nn.Module):
         neg = (1 - alpha) * (out_prob ** gamma) * (-(1 - out_prob + 1e-8).log())
         pos = alpha * ((1 - out_prob) ** gamma) * (-(out_prob + 1e-8).log())
         cost_class = pos[:, tgt_ids] - neg[:, tgt_ids]
-        cost_bbox = torch.cdist(out_bbox, tgt_bbox, p=1)
+        # every reference config sets set_cost_bbox = 0; x + 0 * finite == x bit for bit, so the (4800 x nGT) L1 distance
+        # matrix is only built when it can influence the cost (matcher.py:85 computes it unconditionally)
+        cost_bbox = torch.cdist(out_bbox, tgt_bbox, p=1) if self.cost_bbox != 0 else 0.0
         xy1, xy2 = box_cl_to_xy(out_bbox), box_cl_to_xy(tgt_bbox)
         cost_giou = -generalized_box_iou(xy1, xy2, check=not with_flag)
         cl = outputs.get('cl_match_mats', 0)
-        cost_cl = -1.0 * cl[:, :cost_bbox.shape[1]] if isinstance(cl, torch.Tensor) else -1 * cl
+        cost_cl = -1.0 * cl[:, :tgt_bbox.shape[0]] if isinstance(cl, torch.Tensor) else -1 * cl
         C = self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou \
             + self.cost_cl * cost_cl
         if self.opt is not None and getattr(self.opt, "set_cost_caption", 0) > 0 and 'cap_cost_mat' in outputs:

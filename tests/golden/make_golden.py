@@ -375,7 +375,36 @@ def make_train():
     save("pdvc_train", **rec)
 
 
+def make_init():
+    """Seeded initialisation of the reference modules (MSDeformAttn._reset_parameters ms_deform_attn.py:62-77, the
+    captioner variant :72, DeformableTransformer._reset_parameters deformable_transformer.py:54-63, PDVC.__init__
+    pdvc.py:115-146): per-tensor (sum, sum of squares) after torch.manual_seed(0)."""
+    rec = {}
+
+    def stats(prefix, module):
+        for k, v in module.state_dict().items():
+            v = v.double()
+            rec[f"{prefix}|{k}"] = np.array([float(v.sum()), float((v * v).sum()), float(v.numel())])
+
+    torch.manual_seed(0)
+    stats("msda", MSDeformAttn(64, 4, 8, 4))
+    torch.manual_seed(0)
+    stats("cap", MSDeformAttnCap(64, 4, 1, 4))
+    from pdvc.deformable_transformer import DeformableTransformer
+    torch.manual_seed(0)
+    stats("transformer", DeformableTransformer(d_model=64, nhead=8, num_encoder_layers=2, num_decoder_layers=2,
+                                                dim_feedforward=32, dropout=0.1, return_intermediate_dec=True,
+                                                num_feature_levels=4, dec_n_points=4, enc_n_points=4))
+    if FULL:
+        opt, model, criterion, cc = build_pdvc()          # build_pdvc seeds with 0 before P.build
+        stats("pdvc", model)
+    save("init_stats", **rec)
+
+
 if __name__ == "__main__":
+    if "--only-init" in sys.argv:
+        make_init()
+        sys.exit(0)
     if "--only-train" in sys.argv:
         make_train()
         sys.exit(0)
@@ -385,3 +414,4 @@ if __name__ == "__main__":
     if FULL:
         make_pdvc()
         make_train()
+    make_init()

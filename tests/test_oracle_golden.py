@@ -146,3 +146,41 @@ def test_scipy_lsap_contract():
     for n in names:
         r, c = linear_sum_assignment(f[f"{n}.C"])
         assert np.array_equal(r, f[f"{n}.rows"]) and np.array_equal(c, f[f"{n}.cols"]), n
+
+
+def test_seeded_initialisation_matches_reference():
+    """gvl_amd modules consume the RNG in the reference's order and apply the same special initialisations
+    (offset-bias grid, zeroed attention weights, xavier passes, box-head biases): per-tensor (sum, sum of squares)
+    equal the reference's after torch.manual_seed(0).  Construction needs no GPU."""
+    import warnings
+    from gvl_amd.ops.modules import MSDeformAttn, MSDeformAttnCap
+    from gvl_amd.deformable_transformer import DeformableTransformer
+    from gvl_amd.config import make_opt
+    from gvl_amd.pdvc import build
+    f = load("init_stats")
+
+    def check(prefix, module):
+        sd = module.state_dict()
+        keys = [k.split("|", 1)[1] for k in f if k.startswith(prefix + "|")]
+        assert sorted(keys) == sorted(sd.keys())
+        for k in keys:
+            v = sd[k].double()
+            want = f[f"{prefix}|{k}"]
+            assert v.numel() == int(want[2]), k
+            assert abs(float(v.sum()) - want[0]) <= 1e-6 * max(1.0, abs(want[0])), (prefix, k)
+            assert abs(float((v * v).sum()) - want[1]) <= 1e-6 * max(1.0, abs(want[1])), (prefix, k)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(0)
+        check("msda", MSDeformAttn(64, 4, 8, 4))
+        torch.manual_seed(0)
+        check("cap", MSDeformAttnCap(64, 4, 1, 4))
+        torch.manual_seed(0)
+        check("transformer", DeformableTransformer(d_model=64, nhead=8, num_encoder_layers=2, num_decoder_layers=2,
+                                                    dim_feedforward=32, dropout=0.1, return_intermediate_dec=True,
+                                                    num_feature_levels=4, dec_n_points=4, enc_n_points=4))
+        opt = make_opt(num_queries=8, feature_dim=64, vocab_size=40, max_caption_len=6, device="cpu")
+        torch.manual_seed(0)
+        model, _, _, _ = build(opt)
+        check("pdvc", model)
