@@ -114,7 +114,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     lib = _lib.lib()
-    nbytes = lib.gvl_msda_backward_workspace_bytes(B, S, M, D, L, Q, P, value.element_size())
+    nbytes = lib.gvl_msda_backward_workspace_bytes(B, S, M, D, L, Q, P, value.element_size(), _hp(sh))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
     fn = getattr(lib, "gvl_msda_backward_" + _SUFFIX[value.dtype])
     with torch.cuda.device(value.device):
@@ -158,7 +158,7 @@ def msda1d_fused_backward(value, spatial_shapes, level_start_index, proj, ref, g
     grad_proj = torch.empty_like(proj)
     grad_ref_part = value.new_empty((B, Q, M, n_levels, RD)) if need_ref_grad else None
     lib = _lib.lib()
-    nbytes = lib.gvl_msda1d_fused_backward_workspace_bytes(B, S, M, D, n_levels, Q, n_points)
+    nbytes = lib.gvl_msda1d_fused_backward_workspace_bytes(B, S, M, D, n_levels, Q, n_points, _hp(sh))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
     with torch.cuda.device(value.device):
         rc = lib.gvl_msda1d_fused_backward_f32(

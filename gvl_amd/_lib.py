@@ -23,7 +23,7 @@ SIGNATURES = {
     "gvl_msda_forward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_msda_sample_f32": (_I, [_P] * 4 + [_I] * 8 + [_P, _P]),
     "gvl_msda_sample_f64": (_I, [_P] * 4 + [_I] * 8 + [_P, _P]),
-    "gvl_msda_backward_workspace_bytes": (_SZ, [_I] * 8),
+    "gvl_msda_backward_workspace_bytes": (_SZ, [_I] * 8 + [_P]),
     "gvl_msda_backward_f32": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_msda_backward_f64": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_prof_enable": (_I, [_I]),
@@ -34,7 +34,7 @@ SIGNATURES = {
     "gvl_lstm_cell_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "gvl_row_argmax_lse_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
-    "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7),
+    "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),
     "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),

@@ -304,14 +304,17 @@ __device__ inline float dot4(float4 a, float4 b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
-// stage the (b,m) value slab [S][64] into LDS as float4[S*16]; row S is zero padding
-__device__ inline void stage_slab(float4 *slab4, const float *value, int b, int m, int S, int M) {
+// stage rows [row0, S) of the (b,m) value slab [S][64] into LDS as float4[(S-row0)*16]; one zero row follows.
+// row0 > 0 ("L0G"): level 0 does not fit beside the other levels in the 160 KB LDS (long videos: T = 512 gives
+// S*256 B = 240 KB); its rows are then read straight from global memory / L2 by the sample steps of level 0.
+__device__ inline void stage_slab(float4 *slab4, const float *value, int b, int m, int S, int M, int row0 = 0) {
   const float4 *src = reinterpret_cast<const float4 *>(value) + ((int64_t)b * S * M + m) * 16;
-  for (int i = threadIdx.x; i < S * 16; i += blockDim.x) {
-    const int s = i >> 4, j = i & 15;
+  const int n = (S - row0) * 16;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int s = row0 + (i >> 4), j = i & 15;
     slab4[i] = src[(int64_t)s * M * 16 + j];
   }
-  if (threadIdx.x < 16) slab4[S * 16 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x < 16) slab4[n + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -373,7 +376,7 @@ __device__ inline void resolve_ops(const RawOps &r, int Tl, int P, int RD, float
 // ------------------------------------------------------------------------------------------------------
 // t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
 // ------------------------------------------------------------------------------------------------------
-template <int PAD, bool FULL16, bool FUSED>
+template <int PAD, bool FULL16, bool FUSED, bool L0G>
 __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ value,
                                                      const int64_t *__restrict__ shapes,
                                                      const int64_t *__restrict__ lsi, const float *__restrict__ loc,
@@ -402,7 +405,11 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
   int qb = q0 + wave * 4;
   RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
   if (qb < q1 && j < LP) r_n = fetch_ops<FUSED>(loc, attn, (int64_t)b * Q + min(qb + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
-  stage_slab(slab4, value, b, m, S, M);
+  // L0G: level 0 (rows [0, T_0)) stays in global memory, LDS holds rows [T_0, S); needs FULL16 and P == 4 so that
+  // "sample step SI belongs to level 0" is the compile-time test SI < 4
+  const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;
+  const float4 *vg4 = reinterpret_cast<const float4 *>(value) + ((int64_t)b * S * M + m) * 16 + j;
+  stage_slab(slab4, value, b, m, S, M, row0);
   __syncthreads();
 
   for (; qb < q1; qb += nw * 4) {
@@ -418,21 +425,27 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
     float clo = 0.f, chi = 0.f;
     if (j < LP) {
       const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
-      roff = (st + c.r) * 16;
+      roff = (L0G && lvl == 0) ? c.r : (st - row0 + c.r) * 16;     // global row index | LDS float4 index
       const float ww = w * c.wy;
       clo = c.c_lo * ww;
       chi = c.c_hi * ww;
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#define GVL_FWD_STEP(SI)                                   \
-  if (FULL16 || SI < LP) {                                 \
-    const int ro = row_bcast_i<SI>(roff) + j;              \
-    const float a = row_bcast_f<SI>(clo);                  \
-    const float c = row_bcast_f<SI>(chi);                  \
-    const float4 v0 = slab4[ro];                           \
-    const float4 v1 = slab4[ro + 16];                      \
-    acc = fma4(a, v0, acc);                                \
-    acc = fma4(c, v1, acc);                                \
+#define GVL_FWD_STEP(SI)                                                        \
+  if (FULL16 || SI < LP) {                                                      \
+    const int ro = row_bcast_i<SI>(roff);                                       \
+    const float a = row_bcast_f<SI>(clo);                                       \
+    const float c = row_bcast_f<SI>(chi);                                       \
+    float4 v0, v1;                                                              \
+    if (L0G && SI < 4) {                                                        \
+      v0 = vg4[(int64_t)ro * (M * 16)];                                         \
+      v1 = vg4[(int64_t)min(ro + 1, S - 1) * (M * 16)];                         \
+    } else {                                                                    \
+      v0 = slab4[ro + j];                                                       \
+      v1 = slab4[ro + 16 + j];                                                  \
+    }                                                                           \
+    acc = fma4(a, v0, acc);                                                     \
+    acc = fma4(c, v1, acc);                                                     \
   }
     GVL_FWD_STEP(0) GVL_FWD_STEP(1) GVL_FWD_STEP(2) GVL_FWD_STEP(3)
     GVL_FWD_STEP(4) GVL_FWD_STEP(5) GVL_FWD_STEP(6) GVL_FWD_STEP(7)
@@ -461,8 +474,9 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
 constexpr int kBwdThreads = 1024;
 constexpr int kEntStride = 16;       // entry slot = q_local * 16 + sample
 
-__host__ __device__ inline size_t bwd_lds_bytes(int S, int nq) {
-  const size_t regionA = (size_t)(S + 1 > nq ? S + 1 : nq) * 64 * sizeof(float);
+// rowsV = number of value rows staged in LDS (+1 pad): S + 1, or S - T_0 + 1 when level 0 stays in global memory
+__host__ __device__ inline size_t bwd_lds_bytes(int S, int nq, int rowsV) {
+  const size_t regionA = (size_t)(rowsV > nq ? rowsV : nq) * 64 * sizeof(float);
   const size_t hist = (size_t)(S + 2) * 2 * sizeof(int);
   const size_t ents = (size_t)nq * kEntStride * 4 * sizeof(int);
   return regionA + hist + ents;
@@ -470,7 +484,7 @@ __host__ __device__ inline size_t bwd_lds_bytes(int S, int nq) {
 
 // FUSED: loc -> proj, attn -> ref (see fetch_ops); gloc -> grad_proj (B*Q, 2*M*LP), gattn -> grad_ref partials
 // (B,Q,M,L,RD) or nullptr.  The softmax / location backward of ms_deform_attn.py:99-109 is applied in the epilogue.
-template <int PAD, bool FULL16, bool FUSED>
+template <int PAD, bool FULL16, bool FUSED, bool L0G>
 __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__restrict__ value,
                                                              const int64_t *__restrict__ shapes,
                                                              const int64_t *__restrict__ lsi,
@@ -481,7 +495,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
                                                              float *__restrict__ gvalue_part,
                                                              float *__restrict__ gloc, float *__restrict__ gattn) {
   extern __shared__ float4 slab4[];
-  const int rowsA = (S + 1 > qper ? S + 1 : qper);
+  const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;    // see k_fwd_t1d_d64
+  const int rowsV = S - row0 + 1;
+  const int rowsA = (rowsV > qper ? rowsV : qper);
   int *cnt = reinterpret_cast<int *>(slab4 + (size_t)rowsA * 16);     // [S+2] histogram, later the fill cursor
   int *off = cnt + (S + 2);                                           // [S+2] exclusive prefix
   int *ent_r = off + (S + 2);                                         // [qper*16] slab row or -1
@@ -513,7 +529,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
     if (j < LP) r_n = fetch_ops<FUSED>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
     if (qb + tq < q1) g_n = reinterpret_cast<const float4 *>(gout)[(bqn * M + m) * 16 + j];
   }
-  stage_slab(slab4, value, b, m, S, M);
+  const float4 *vg4 = reinterpret_cast<const float4 *>(value) + ((int64_t)b * S * M + m) * 16 + (threadIdx.x & 15);
+  stage_slab(slab4, value, b, m, S, M, row0);
   for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
   for (int i = threadIdx.x; i < qper * kEntStride; i += blockDim.x) ent_r[i] = -1;
   __syncthreads();
@@ -559,9 +576,15 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
     float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;
 #define GVL_BWD_STEP(SI)                                                      \
   if (FULL16 || SI < LP) {                                                    \
-    const int rr = row_bcast_i<SI>(roff) * 16 + j;                            \
-    const float4 v0 = slab4[rr];                                              \
-    const float4 v1 = slab4[rr + 16];                                         \
+    const int rr = row_bcast_i<SI>(roff);                                     \
+    float4 v0, v1;                                                            \
+    if (L0G && SI < 4) {                                                      \
+      v0 = vg4[(int64_t)rr * (M * 16)];                                       \
+      v1 = vg4[(int64_t)min(rr + 1, S - 1) * (M * 16)];                       \
+    } else {                                                                  \
+      v0 = slab4[(rr - row0) * 16 + j];                                       \
+      v1 = slab4[(rr - row0) * 16 + 16 + j];                                  \
+    }                                                                         \
     const float d0 = row_allsum(dot4(g, v0));                                 \
     const float d1 = row_allsum(dot4(g, v1));                                 \
     if (j == SI) {                                                            \
@@ -694,6 +717,21 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float4 *__restrict__
 // ------------------------------------------------------------------------------------------------------
 constexpr size_t kLdsMax = 160 * 1024;
 
+// How the (b,m) value slab is held on chip: all S rows in LDS, or (long videos) level 0 left in global memory
+struct SlabPlan {
+  bool ok, l0g;
+  int rowsV;   // rows staged in LDS including the zero pad row
+};
+SlabPlan slab_plan(int S, int L, int P, const int64_t *shapes_host) {
+  if ((size_t)(S + 1) * 64 * sizeof(float) <= kLdsMax) return {true, false, S + 1};
+  if (shapes_host && L >= 2 && L * P == 16 && P == 4) {
+    const int T0 = (int)shapes_host[1];
+    if ((size_t)(S - T0 + 1) * 64 * sizeof(float) <= kLdsMax) return {true, true, S - T0 + 1};
+  }
+  return {false, false, 0};
+}
+
+
 int check_dims(int B, int S, int M, int D, int L, int Q, int P, int pad) {
   if (B < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Q < 0 || P <= 0)
     return fail(GVL_EINVAL, "gvl_msda: bad dims B=%d S=%d M=%d D=%d L=%d Q=%d P=%d", B, S, M, D, L, Q, P);
@@ -729,9 +767,10 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   if (n == 0) return 0;                                  // empty query set / batch: nothing to write
   if (!value || !shapes || !lsi || !loc || !attn || !out) return fail(GVL_EINVAL, "gvl_msda_forward: null pointer");
   const int mode = impl_mode();
-  const size_t lds = (size_t)(S + 1) * 64 * sizeof(float);
-  const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && S > 0 &&
-                       temporal_host(shapes_host, lsi_host, L, S);
+  const bool temporal = S > 0 && temporal_host(shapes_host, lsi_host, L, S);
+  const SlabPlan plan = temporal ? slab_plan(S, L, P, shapes_host) : SlabPlan{false, false, 0};
+  const size_t lds = (size_t)plan.rowsV * 64 * sizeof(float);
+  const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && temporal && plan.ok;
   if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_forward: fast kernels not eligible for this call");
   if (fast_ok && mode != 1) {
     if constexpr (sizeof(T) == 4) {
@@ -740,9 +779,12 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
       const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
       const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
       const bool full = L * P == 16;
-      auto kern = pad == kPadZeros
-                      ? (full ? k_fwd_t1d_d64<kPadZeros, true, false> : k_fwd_t1d_d64<kPadZeros, false, false>)
-                      : (full ? k_fwd_t1d_d64<kPadBorder, true, false> : k_fwd_t1d_d64<kPadBorder, false, false>);
+      auto kern = pad == kPadZeros ? (plan.l0g ? k_fwd_t1d_d64<kPadZeros, true, false, true>
+                                                 : full ? k_fwd_t1d_d64<kPadZeros, true, false, false>
+                                                        : k_fwd_t1d_d64<kPadZeros, false, false, false>)
+                                   : (plan.l0g ? k_fwd_t1d_d64<kPadBorder, true, false, true>
+                                                 : full ? k_fwd_t1d_d64<kPadBorder, true, false, false>
+                                                        : k_fwd_t1d_d64<kPadBorder, false, false, false>);
       if (int rc = ensure_lds(kern, lds)) return rc;
       g_last_impl = 2;
       return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(threads), lds, st,
@@ -773,9 +815,9 @@ int sample_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
 // queries per workgroup for the LDS carve-up; 0 = does not fit
-int bwd_chunks(int B, int M, int Q, int S) {
+int bwd_chunks(int B, int M, int Q, int S, int rowsV) {
   int n = pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256);
-  while (n <= Q && bwd_lds_bytes(S, (Q + n - 1) / n) > kLdsMax) ++n;
+  while (n <= Q && bwd_lds_bytes(S, (Q + n - 1) / n, rowsV) > kLdsMax) ++n;
   return n <= Q ? n : 0;
 }
 
@@ -796,11 +838,12 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   if (!value || !shapes || !lsi || !loc || !attn || !gout || !gvalue || !gloc || !gattn)
     return fail(GVL_EINVAL, "gvl_msda_backward: null pointer");
   const int mode = impl_mode();
-  const int nchunk_f = bwd_chunks(B, M, Q, S);
+  const bool temporal = S > 0 && temporal_host(shapes_host, lsi_host, L, S);
+  const SlabPlan plan = temporal ? slab_plan(S, L, P, shapes_host) : SlabPlan{false, false, 0};
+  const int nchunk_f = plan.ok ? bwd_chunks(B, M, Q, S, plan.rowsV) : 0;
   const int qper_f = nchunk_f > 0 ? (Q + nchunk_f - 1) / nchunk_f : Q;
-  const size_t lds = nchunk_f > 0 ? bwd_lds_bytes(S, qper_f) : kLdsMax + 1;
-  const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && S > 0 &&
-                       temporal_host(shapes_host, lsi_host, L, S);
+  const size_t lds = nchunk_f > 0 ? bwd_lds_bytes(S, qper_f, plan.rowsV) : kLdsMax + 1;
+  const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && temporal && plan.ok;
   if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_backward: fast kernels not eligible for this call");
   if (fast_ok && mode != 1) {
     if constexpr (sizeof(T) == 4) {
@@ -813,9 +856,12 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         part = (float *)ws;
       }
       const bool full = L * P == 16;
-      auto kern = pad == kPadZeros
-                      ? (full ? k_bwd_t1d_d64<kPadZeros, true, false> : k_bwd_t1d_d64<kPadZeros, false, false>)
-                      : (full ? k_bwd_t1d_d64<kPadBorder, true, false> : k_bwd_t1d_d64<kPadBorder, false, false>);
+      auto kern = pad == kPadZeros ? (plan.l0g ? k_bwd_t1d_d64<kPadZeros, true, false, true>
+                                                 : full ? k_bwd_t1d_d64<kPadZeros, true, false, false>
+                                                        : k_bwd_t1d_d64<kPadZeros, false, false, false>)
+                                   : (plan.l0g ? k_bwd_t1d_d64<kPadBorder, true, false, true>
+                                                 : full ? k_bwd_t1d_d64<kPadBorder, true, false, false>
+                                                        : k_bwd_t1d_d64<kPadBorder, false, false, false>);
       if (int rc = ensure_lds(kern, lds)) return rc;
       if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(kBwdThreads),
                                lds, st, (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn,
@@ -900,9 +946,12 @@ int gvl_msda_sample_f64(const double *value, const int64_t *shapes, const int64_
   return sample_impl<double>(value, shapes, lsi, loc, B, S, M, D, L, Q, P, pad_mode, sample, (hipStream_t)stream);
 }
 
-size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes) {
-  if (elem_bytes != 4 || D != 64 || L * P > 16) return 0;
-  const int n = bwd_chunks(B, M, Q, S);
+size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes,
+                                         const int64_t *shapes_host) {
+  if (elem_bytes != 4 || D != 64 || L * P > 16 || S <= 0) return 0;
+  const SlabPlan plan = slab_plan(S, L, P, shapes_host);
+  if (!plan.ok) return 0;
+  const int n = bwd_chunks(B, M, Q, S, plan.rowsV);
   return n > 1 ? (size_t)n * B * S * M * D * sizeof(float) : 0;
 }
 
@@ -942,19 +991,23 @@ int gvl_msda1d_fused_forward_f32(const float *value, const int64_t *shapes, cons
   if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
   if ((int64_t)B * Q == 0) return 0;
   if (!value || !shapes || !lsi || !proj || !ref || !out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: null pointer");
-  const size_t lds = (size_t)(S + 1) * 64 * sizeof(float);
-  if (lds > kLdsMax) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: slab of %d rows does not fit LDS", S);
+  const SlabPlan plan = slab_plan(S, L, P, shapes_host);
+  if (!plan.ok) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: slab of %d rows does not fit LDS", S);
+  const size_t lds = (size_t)plan.rowsV * 64 * sizeof(float);
   const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
   const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
-  auto kern = pad_mode == kPadZeros ? k_fwd_t1d_d64<kPadZeros, true, true> : k_fwd_t1d_d64<kPadBorder, true, true>;
+  auto kern = pad_mode == kPadZeros
+                  ? (plan.l0g ? k_fwd_t1d_d64<kPadZeros, true, true, true> : k_fwd_t1d_d64<kPadZeros, true, true, false>)
+                  : (plan.l0g ? k_fwd_t1d_d64<kPadBorder, true, true, true> : k_fwd_t1d_d64<kPadBorder, true, true, false>);
   if (int rc = ensure_lds(kern, lds)) return rc;
   g_last_impl = 3;
   return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64<fused>", kern, dim3(nchunk * B * M), dim3(threads), lds,
                      (hipStream_t)stream, value, shapes, lsi, proj, ref, B, S, M, L, Q, P, RD, nchunk, out);
 }
 
-size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P) {
-  return gvl_msda_backward_workspace_bytes(B, S, M, D, L, Q, P, 4);
+size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P,
+                                                 const int64_t *shapes_host) {
+  return gvl_msda_backward_workspace_bytes(B, S, M, D, L, Q, P, 4, shapes_host);
 }
 
 int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
@@ -971,10 +1024,11 @@ int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, con
   }
   if (!value || !shapes || !lsi || !proj || !ref || !grad_out || !grad_proj)
     return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
-  const int nchunk = bwd_chunks(B, M, Q, S);
+  const SlabPlan plan = slab_plan(S, L, P, shapes_host);
+  const int nchunk = plan.ok ? bwd_chunks(B, M, Q, S, plan.rowsV) : 0;
   if (nchunk <= 0) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: problem does not fit LDS");
   const int qper = (Q + nchunk - 1) / nchunk;
-  const size_t lds = bwd_lds_bytes(S, qper);
+  const size_t lds = bwd_lds_bytes(S, qper, plan.rowsV);
   float *part = grad_value;
   if (nchunk > 1) {
     if (!workspace || workspace_bytes < gv_bytes * nchunk)
@@ -982,7 +1036,9 @@ int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, con
                   gv_bytes * nchunk);
     part = (float *)workspace;
   }
-  auto kern = pad_mode == kPadZeros ? k_bwd_t1d_d64<kPadZeros, true, true> : k_bwd_t1d_d64<kPadBorder, true, true>;
+  auto kern = pad_mode == kPadZeros
+                  ? (plan.l0g ? k_bwd_t1d_d64<kPadZeros, true, true, true> : k_bwd_t1d_d64<kPadZeros, true, true, false>)
+                  : (plan.l0g ? k_bwd_t1d_d64<kPadBorder, true, true, true> : k_bwd_t1d_d64<kPadBorder, true, true, false>);
   if (int rc = ensure_lds(kern, lds)) return rc;
   if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64<fused>", kern, dim3(nchunk * B * M), dim3(kBwdThreads),
                            lds, st, value, shapes, lsi, proj, ref, grad_out, B, S, M, L, Q, P, RD, nchunk, qper, part,

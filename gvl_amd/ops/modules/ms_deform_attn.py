@@ -107,7 +107,7 @@ class MSDeformAttn(nn.Module):
         """domain of the fused HIP path (include/gvl_msda.h: gvl_msda1d_fused_*)"""
         return (self.fused and host_lengths is not None and query.dtype == torch.float32
                 and self.d_model // self.n_heads == 64 and self.n_levels * self.n_points == 16 and self.n_points == 4
-                and input_flatten.shape[1] <= 600)
+                and (input_flatten.shape[1] <= 600 or input_flatten.shape[1] - host_lengths[0][0] <= 600))
 
     def _forward_fused(self, query, reference_points, input_flatten, shapes2d, level_start_index, padding_mask):
         N, Len_in, _ = input_flatten.shape

@@ -26,8 +26,10 @@
  *                            (ms_deform_attn_func.py:61-62, F.grid_sample(padding_mode='border')).
  *
  * shapes_host / lsi_host (optional, may be NULL): a HOST copy of `shapes` / `lsi`.  When given, and every level
- * has H_l == 1, fp32, D == 64 and L*P <= 16, the LDS-staged temporal kernels are used; otherwise the generic
- * kernels (any D, any HxW, fp32/fp64) run.  Results are identical up to fp32 summation order.
+ * has H_l == 1, fp32, D == 64 and L*P <= 16, the LDS-staged temporal kernels are used (all S rows in LDS up to
+ * S = 639; beyond that -- long videos, T = 512 -> S = 960 -- level 0 is read from global memory and levels 1.. are
+ * staged, which needs L*P == 16 and P == 4); otherwise the generic kernels (any D, any HxW, fp32/fp64) run.
+ * Results are identical up to fp32 summation order.
  */
 #ifndef GVL_MSDA_H
 #define GVL_MSDA_H
@@ -100,8 +102,9 @@ int gvl_msda_sample_f64(const double *value, const int64_t *shapes, const int64_
  *    grad_value (B,S,M,D), grad_loc (B,Q,M,L,P,2), grad_attn (B,Q,M,L,P) are fully (over)written: the callee
  *    zero-fills what it accumulates into (the reference allocates zeros, cu:121-123), so the caller may pass
  *    uninitialised buffers.  `workspace` must hold gvl_msda_backward_workspace_bytes(...) bytes (may be NULL
- *    when that is 0). */
-size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes);
+ *    when that is 0; pass the same shapes_host to the query as to the call). */
+size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes,
+                                         const int64_t *shapes_host);
 int gvl_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                           const float *attn, const float *grad_out, int B, int S, int M, int D, int L, int Q, int P,
                           int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *grad_value,
@@ -128,7 +131,8 @@ int gvl_msda1d_fused_forward_f32(const float *value, const int64_t *shapes, cons
                                  const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
                                  int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
                                  void *stream);
-size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P);
+size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P,
+                                                 const int64_t *shapes_host);
 int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
                                   const float *ref, const float *grad_out, int B, int S, int M, int D, int L, int Q,
                                   int P, int RD, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,

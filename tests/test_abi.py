@@ -42,8 +42,8 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert rc == -1 and b"bad dims" in lib.gvl_last_error()
     rc = lib.gvl_msda_forward_f32(None, None, None, None, None, 1, 4, 1, 64, 1, 1, 1, 7, None, None, None, None)
     assert rc == -1 and b"pad_mode" in lib.gvl_last_error()
-    assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 64, 4, 300, 4, 4) % (16 * 188 * 8 * 64 * 4) == 0
-    assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 30, 4, 300, 4, 8) == 0
+    assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 64, 4, 300, 4, 4, None) % (16 * 188 * 8 * 64 * 4) == 0
+    assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 30, 4, 300, 4, 8, None) == 0
 
 
 def _solve(lib, C):

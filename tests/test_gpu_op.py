@@ -228,3 +228,25 @@ def test_nan_and_far_locations_are_contained(dev, MSDA):
         assert float(gl[0, :2].abs().max()) == 0.0 and float(gw[0, :2].abs().max()) == 0.0
         assert torch.isfinite(gv).all()
     set_impl("auto")
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_long_video_level0_in_global_matches_oracle(pad, dev, MSDA):
+    """T = 512 (BASELINE config 5 / cfg L): S = 960 rows do not fit LDS; the temporal kernels keep level 0 in global
+    memory and stage levels 1..3 (include/gvl_msda.h).  Forward + backward vs the CPU oracle; fast == generic."""
+    from oracle import msda_oracle as O
+    value, shapes, lsi, loc, aw, gout = make_inputs(2, 512, 8, 64, 77, 4, seed=512)
+    args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
+    set_impl("fast")
+    try:
+        out = MSDA.ms_deform_attn_forward(*args, 64, pad_mode=pad)
+        assert last_impl() == "fast"
+        assert maxerr(out, O.msda_forward(value, shapes, lsi, loc, aw, pad)) <= 1e-4
+        gv, gl, gw = MSDA.ms_deform_attn_backward(*args, t(gout).to(dev), 64, pad_mode=pad)
+        assert last_impl() == "fast"
+        rv, rl, rw = O.msda_backward(value, shapes, lsi, loc, aw, gout, pad)
+        assert maxerr(gv, rv) <= 1e-4 * scale(rv)
+        assert maxerr(gl, rl) <= 1e-4 * scale(rl)
+        assert maxerr(gw, rw) <= 1e-4 * scale(rw)
+    finally:
+        set_impl("auto")
