@@ -63,6 +63,39 @@ def kernel_times(entries):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+def cfg_l_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20):
+    """The same kernel on the long-video launch shape (cfg L: T = 512, S = 960; level 0 read from global memory):
+    `iters` fused decoder-shaped launches on synthetic operands, timed with the library's per-dispatch stamps.  A
+    supplementary data point for DESIGN.md section 4.7 -- not part of the timed region, not part of `value`."""
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd.deformable_transformer import make_level_tensors
+    from gvl_amd.ops.modules.ms_deform_attn import temporal_shapes_2d
+    lens = [T]
+    for _ in range(L - 1):
+        lens.append((lens[-1] - 1) // 2 + 1)
+    S = sum(lens)
+    tsh, lsi = make_level_tensors(lens, dev)
+    shapes2d = temporal_shapes_2d(tsh, lsi)
+    g = torch.Generator(device=dev).manual_seed(7)
+    value = torch.randn(B, S, M, 64, device=dev, generator=g)
+    proj = torch.randn(B, Q, 2 * M * L * P, device=dev, generator=g)
+    ref = torch.rand(B, Q, L, 1, device=dev, generator=g)
+    for _ in range(3):
+        MSDA.msda1d_fused_forward(value, shapes2d, lsi, proj, ref, L, P)
+    torch.cuda.synchronize()
+    MSDA.profile_enable(True)
+    for _ in range(iters):
+        MSDA.msda1d_fused_forward(value, shapes2d, lsi, proj, ref, L, P)
+    torch.cuda.synchronize()
+    MSDA.profile_enable(False)
+    us = [e[3] for e in MSDA.profile_collect()]
+    us = sum(us) / len(us)
+    nbytes = msda_bytes(B, S, Q)
+    return {"T": T, "S": S, "kernel_us": round(us, 2), "launches_timed": iters, "algorithmic_bytes": nbytes,
+            "frac": round(nbytes / (us * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4),
+            "note": "back-to-back launches on synthetic operands after the timed region"}
+
+
 def cpu_baseline(model, opt, T, seconds_budget=25.0):
     """The oracle's CPU port (reference CPU-fallback semantics: grid_sample border) on a bounded sample."""
     from oracle import torch_ref as R
@@ -218,6 +251,8 @@ def main():
             roof["encoder_launch"] = {"kernel_us": round(eus, 2), "launches_timed": en, "algorithmic_bytes": eb,
                                       "frac": round(eb / (eus * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
     other = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in ktimes.items() if k not in fwd}
+    if roof is not None and rank == 0 and a.T != 512:
+        roof["cfg_L_launch"] = cfg_l_probe(dev, B)
 
     line = {
         "metric": "videos/sec (eval fwd)" if a.mode == "eval" else "train-step ms",
