@@ -237,7 +237,7 @@ def main():
         if os.path.exists(pmc) and (B, a.T, a.queries) == (16, 100, 300):
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same launch shape (FETCH_SIZE and
             # WRITE_SIZE in separate passes, gfx950 2x FETCH correction); counters cannot be read from inside the run
-            traffic = json.load(open(pmc))["k_fwd_t1d_d64_dec"]["hbm_bytes_corrected"]
+            traffic = json.load(open(pmc))["k_fwd_t1d_d64_fused_dec"]["hbm_bytes_corrected"]   # the variant the model launches
             traffic_src = "profiles/r01_pmc_traffic.json"
         roof = {"bound": "hbm", "kernel": f"k_{dec_key[0]} (decoder cross-attention launch, Lq={a.queries})",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
