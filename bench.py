@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the caption decoding loop from a hipGraph")
+    ap.add_argument("--no-tuned-gemm", action="store_true",
+                    help="keep hipBLASLt's default kernel choice instead of gvl_amd/tunableop_mi355x.csv")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -154,6 +156,8 @@ def main():
 
     from gvl_amd.config import make_opt
     from gvl_amd.pdvc import build
+    from gvl_amd.tuning import enable_tuned_gemms
+    tuned = (not a.no_tuned_gemm) and enable_tuned_gemms()
     opt = make_opt("anet_tsp_ssvg", num_queries=a.queries, frame_embedding_num=a.T,
                    eval_disable_captioning=bool(a.no_captioner), device="cuda")
     torch.manual_seed(0)
@@ -266,6 +270,7 @@ def main():
                                + ("captioner off (diagnostic)" if a.no_captioner else
                                   f"LSTM-DSA greedy captioning {opt.max_caption_len + 1} steps")
                                + ", set criterion + Hungarian matcher on 3 GT/video",
+                   "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
                    "global_batch": world * B, "parallelism": f"dp{world} (videos sharded, no data-path collective)"
                    if a.mode == "eval" else f"dp{world} (RCCL gradient all-reduce)"},
         "roofline": roof,
