@@ -22,6 +22,7 @@ from .CaptioningHead import build_captioner
 from .criterion import SetCriterion
 from .deformable_transformer import build_deforamble_transformer, inverse_sigmoid
 from .matcher import build_matcher
+from .postprocess import PostProcess
 
 
 def _clones(module, n):
@@ -373,5 +374,5 @@ def build(args):
     criterion = SetCriterion(args.num_classes, matcher, weight_dict, ['labels', 'boxes', 'cardinality'],
                              focal_alpha=args.focal_alpha, focal_gamma=args.focal_gamma, opt=args)
     criterion.to(torch.device(args.device))
-    postprocessors = {}
+    postprocessors = {'bbox': PostProcess(args)}
     return model, criterion, None, postprocessors

@@ -243,8 +243,12 @@ def build_pdvc():
     for k, v in PDVC_OVERRIDES.items():
         setattr(opt, k, v)
     torch.manual_seed(0)
-    model, criterion, cc, post = P.build(opt)
+    model, criterion, cc, post_ = P.build(opt)
+    globals()["post"] = post_
     return opt, model.eval(), criterion, cc
+
+
+post = None
 
 
 def synth_dt(B, T, feat, valid, n_gt, seed=1):
@@ -298,6 +302,23 @@ def make_pdvc():
                         f"{tag}.cap_prob_eval": out["caption_probs"]["cap_prob_eval"],
                         f"{tag}.aux_pred_logits": out["aux_outputs"][0]["pred_logits"],
                         f"{tag}.aux_pred_boxes": out["aux_outputs"][0]["pred_boxes"]})
+            if tag == "cuda":
+                # PostProcess (pdvc.py:1003-1089) on these outputs, with a stand-in translator (token ids -> string)
+                class _Tr:
+                    @staticmethod
+                    def rtranslate(s):
+                        return " ".join(str(int(x)) for x in s if x > 0)
+                loader = type("L", (), {"dataset": type("D", (), {"translator": _Tr})})
+                res = post["bbox"](out, dt["video_length"][:, 1], loader)
+                for i, r in enumerate(res):
+                    rec[f"post.{i}.scores"] = r["scores"]
+                    rec[f"post.{i}.labels"] = r["labels"]
+                    rec[f"post.{i}.boxes"] = r["boxes"]
+                    rec[f"post.{i}.query_id"] = r["query_id"]
+                    rec[f"post.{i}.raw_idx"] = r["raw_idx"]
+                    rec[f"post.{i}.pred_seq_len"] = r["pred_seq_len"]
+                    rec[f"post.{i}.caption_scores"] = np.asarray(r["caption_scores"], np.float64)
+                    rec[f"post.{i}.captions"] = np.array(r["captions"])
             for i, (a, b) in enumerate(out["matched_indices"][0]):
                 rec[f"{tag}.match_{i}"] = torch.stack([a, b])
             for i, (a, b) in enumerate(out["matched_indices"][1]):
@@ -402,6 +423,9 @@ def make_init():
 
 
 if __name__ == "__main__":
+    if "--only-pdvc" in sys.argv:
+        make_pdvc()
+        sys.exit(0)
     if "--only-init" in sys.argv:
         make_init()
         sys.exit(0)

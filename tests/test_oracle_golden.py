@@ -184,3 +184,32 @@ def test_seeded_initialisation_matches_reference():
         torch.manual_seed(0)
         model, _, _, _ = build(opt)
         check("pdvc", model)
+
+
+def test_postprocess_matches_reference():
+    """gvl_amd.postprocess.PostProcess (host glue, runs anywhere) on the reference's own eval outputs reproduces the
+    reference's PostProcess.forward (pdvc.py:1003-1089): ranking, clipped + scaled boxes, caption order and scores."""
+    from gvl_amd.config import make_opt
+    from gvl_amd.postprocess import PostProcess
+    f = load("pdvc_eval")
+    out = {"pred_logits": t(f["cuda.pred_logits"]), "pred_boxes": t(f["cuda.pred_boxes"]),
+           "pred_count": t(f["cuda.pred_count"]), "seq": t(f["cuda.seq"]),
+           "caption_probs": {"cap_prob_eval": t(f["cuda.cap_prob_eval"])}}
+
+    class _Tr:
+        @staticmethod
+        def rtranslate(s):
+            return " ".join(str(int(x)) for x in s if x > 0)
+    loader = type("L", (), {"dataset": type("D", (), {"translator": _Tr})})
+    dt = pdvc_dt(f)
+    res = PostProcess(make_opt(device="cpu"))(out, dt["video_length"][:, 1], loader)
+    assert len(res) == 2
+    for i, r in enumerate(res):
+        assert maxerr(r["scores"], f[f"post.{i}.scores"]) < 1e-6
+        assert torch.equal(r["labels"], t(f[f"post.{i}.labels"]))
+        assert torch.equal(r["query_id"], t(f[f"post.{i}.query_id"]))
+        assert torch.equal(r["raw_idx"], t(f[f"post.{i}.raw_idx"]))
+        assert maxerr(r["boxes"], f[f"post.{i}.boxes"]) < 1e-4
+        assert int(r["pred_seq_len"]) == int(f[f"post.{i}.pred_seq_len"])
+        assert list(r["captions"]) == [str(c) for c in f[f"post.{i}.captions"]]
+        assert np.allclose(np.asarray(r["caption_scores"], np.float64), f[f"post.{i}.caption_scores"], atol=1e-5)
