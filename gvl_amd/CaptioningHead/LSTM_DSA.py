@@ -221,17 +221,27 @@ class Captioner(nn.Module):
             live = (seq[:, 1:] != 0).any(0).cpu().tolist()
             steps = 1 + (live.index(False) if False in live else len(live))
             steps = min(steps, seq.size(1) - 1)
-        for i in range(steps):
-            if self.training and i >= 1 and self.ss_prob > 0.0:
+        if not (self.training and self.ss_prob > 0.0):
+            # Pure teacher forcing: the inputs of every step are known, only h/c carry the recurrence.  Everything that
+            # does not depend on it is batched over time -- the embedding part of the LSTM input GEMM before the loop,
+            # the vocabulary GEMM + log_softmax after it -- so their weights see ONE forward and ONE gradient GEMM
+            # instead of `steps` of each followed by `steps` accumulations of a 17 MB gradient.
+            xt_all = F.linear(self.embed(seq[:, :steps]), w_x)                    # (n, steps, 4H)
+            hidden = []
+            for i in range(steps):
+                out, (h, c) = self.core.step(xt_all[:, i], (h, c), hs, ref_in, tshapes, lsi, const)
+                hidden.append(out)
+            hidden = torch.stack(hidden, 1)                                       # (n, steps, H)
+            return F.log_softmax(self.logit(self.dropout(hidden)), dim=2)
+        for i in range(steps):                                                    # scheduled sampling (:92-105)
+            it = seq[:, i].clone()
+            if i >= 1:
                 prob = hs.new_zeros(n).uniform_(0, 1)
                 take = prob < self.ss_prob
-                it = seq[:, i].clone()
                 if take.any():
                     ind = take.nonzero().view(-1)
                     prev = torch.exp(outputs[-1].detach())
                     it.index_copy_(0, ind, torch.multinomial(prev, 1).view(-1).index_select(0, ind))
-            else:
-                it = seq[:, i].clone()
             out, (h, c) = self.core.step(F.linear(self.embed(it), w_x), (h, c), hs, ref_in, tshapes, lsi, const)
             outputs.append(F.log_softmax(self.logit(self.dropout(out)), dim=1))
         return torch.stack(outputs, 1)
