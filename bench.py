@@ -188,6 +188,7 @@ def main():
         def step():
             return trainer(dt)
 
+    step()            # set-up, not a warm-up step: one-time work (hipGraph capture, library handles, lazily built constants)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()

@@ -43,7 +43,12 @@ template <typename K, typename... Args>
 inline int launch(int tag, int meta_a, int meta_b, const char *what, K kernel, dim3 grid, dim3 block, size_t lds,
                   hipStream_t st, Args... args) {
   Profiler &p = profiler();
-  if (p.on) {
+  bool stamp = p.on;
+  if (stamp) {   // event-stamped launches cannot be recorded into a hipGraph: inside a capture launch plainly
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) stamp = false;
+  }
+  if (stamp) {
     ProfEntry e;
     e.tag = tag; e.a = meta_a; e.b = meta_b;
     if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess)
