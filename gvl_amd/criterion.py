@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
-from .matcher import box_cl_to_xy, box_iou, generalized_box_iou
+from .matcher import box_cl_to_xy, box_iou
 
 # Empirical distribution of the number of events per video used to re-weight the counter loss.
 # DATA taken verbatim from the reference (pdvc/criterion.py:39-45); it is a dataset statistic, not code.

@@ -7,7 +7,6 @@ attention_weights, im2col_step)`` keeps the reference's signature, saved tensors
 reference's CPU fallback ms_deform_attn_core_pytorch, func.py:44-71, on the GPU).  There is deliberately no
 PyTorch fallback here: without libgvl_msda.so or a ROCm device the call raises.
 """
-import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 

@@ -137,3 +137,19 @@ def test_ops_refuse_cpu_tensors():
     m = MSDeformAttn(64, 1, 1, 1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 1, 64), torch.zeros(1, 1, 1, 1), torch.zeros(1, 4, 64), torch.tensor([4]), ls)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: without libgvl_msda.so the product raises (it never routes to PyTorch or to the oracle)."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libgvl_msda.so"))
+    with pytest.raises(_lib.GvlLibraryError, match="no CPU / PyTorch fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under gvl_amd/ may import it."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "gvl_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path
