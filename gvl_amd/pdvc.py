@@ -172,7 +172,8 @@ class PDVC(nn.Module):
                                                 init_reference, inter_references, others, disable_refine)
 
     def predict_event_num(self, counter, hs_lid):
-        return counter(torch.max(hs_lid, dim=1, keepdim=False)[0])
+        # max over the queries (pdvc.py:316-319); amax = the same values without the argmax bookkeeping of torch.max
+        return counter(torch.amax(hs_lid, dim=1))
 
     def _layer_heads(self, l_id, hs_lid, reference, disable_refine):
         """class / count / box heads of one decoder layer (pdvc.py:452-474)."""

@@ -7,6 +7,8 @@ from bench import synth_batch
 from gvl_amd.config import make_opt
 from gvl_amd.pdvc import build
 
+from gvl_amd.tuning import enable_tuned_gemms
+enable_tuned_gemms()
 dev = torch.device("cuda:0")
 opt = make_opt("anet_tsp_ssvg", num_queries=300, device="cuda")
 torch.manual_seed(0)
