@@ -250,3 +250,56 @@ def test_long_video_level0_in_global_matches_oracle(pad, dev, MSDA):
         assert maxerr(gw, rw) <= 1e-4 * scale(rw)
     finally:
         set_impl("auto")
+
+
+def test_randomised_shape_sweep_fast_vs_oracle(dev, MSDA):
+    """Many small random temporal configurations (ragged Q, single query, single video/head, one-row levels, L*P < 16,
+    workgroup-chunk boundaries) through the temporal kernels, against the CPU oracle, both paddings."""
+    from oracle import msda_oracle as O
+    rs = np.random.RandomState(2024)
+    set_impl("fast")
+    try:
+        for trial in range(40):
+            L = int(rs.randint(1, 5))
+            P = int(rs.choice([p for p in (1, 2, 3, 4, 8, 16) if L * p <= 16]))
+            lens = [int(rs.randint(1, 40)) for _ in range(L)]
+            B, M, Q = int(rs.randint(1, 4)), int(rs.randint(1, 5)), int(rs.randint(1, 70))
+            shapes = np.array([(1, x) for x in lens], np.int64)
+            S = sum(lens)
+            lsi = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            value = rs.standard_normal((B, S, M, 64)).astype(np.float32)
+            loc = rs.uniform(-0.3, 1.3, (B, Q, M, L, P, 2)).astype(np.float32)
+            loc[..., 1] = 0.5
+            aw = rs.rand(B, Q, M, L, P).astype(np.float32)
+            aw /= aw.sum((-1, -2), keepdims=True)
+            gout = rs.standard_normal((B, Q, M * 64)).astype(np.float32)
+            pad = "zeros" if trial % 2 == 0 else "border"
+            args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
+            out = MSDA.ms_deform_attn_forward(*args, 64, pad_mode=pad)
+            assert last_impl() == "fast"
+            tag = (trial, B, M, Q, lens, P, pad)
+            assert maxerr(out, O.msda_forward(value, shapes, lsi, loc, aw, pad)) <= 1e-4, tag
+            gv, gl, gw = MSDA.ms_deform_attn_backward(*args, t(gout).to(dev), 64, pad_mode=pad)
+            rv, rl, rw = O.msda_backward(value, shapes, lsi, loc, aw, gout, pad)
+            assert maxerr(gv, rv) <= 1e-4 * scale(rv), tag
+            assert maxerr(gl, rl) <= 1e-4 * scale(rl), tag
+            assert maxerr(gw, rw) <= 1e-4 * scale(rw), tag
+    finally:
+        set_impl("auto")
+
+
+def test_general_y_coordinate_on_temporal_levels(dev, MSDA):
+    """The op's API allows any y in [0,1] even for H = 1 levels (GVL always passes 0.5): the temporal kernels apply
+    the vertical interpolation weight and its gradient like the reference kernel does (cuh:39-82 with H = 1)."""
+    from oracle import msda_oracle as O
+    value, shapes, lsi, loc, aw, gout = make_inputs(2, 30, 3, 64, 21, 4, seed=99)
+    loc[..., 1] = np.random.RandomState(5).uniform(-0.6, 1.6, loc[..., 1].shape).astype(np.float32)
+    args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
+    for impl in ("fast", "generic"):
+        set_impl(impl)
+        out = MSDA.ms_deform_attn_forward(*args, 64)
+        assert maxerr(out, O.msda_forward(value, shapes, lsi, loc, aw, "zeros")) <= 1e-4
+        gv, gl, gw = MSDA.ms_deform_attn_backward(*args, t(gout).to(dev), 64)
+        rv, rl, rw = O.msda_backward(value, shapes, lsi, loc, aw, gout, "zeros")
+        assert maxerr(gv, rv) <= 1e-4 * scale(rv) and maxerr(gl, rl) <= 1e-4 * scale(rl) and maxerr(gw, rw) <= 1e-4 * scale(rw)
+    set_impl("auto")
