@@ -1,6 +1,7 @@
 """GPU parity of the model-level mirror (gvl_amd.pdvc / deformable_transformer / captioner / matcher) against the
 golden vectors the imported reference produced with CUDA-op semantics (zero padding in MSDeformAttn, border in the
 captioner's MSDeformAttnCap) -- tests/golden/pdvc_eval.npz, captioner_step.npz."""
+import numpy as np
 import pytest
 import torch
 
@@ -290,3 +291,25 @@ def test_graphed_train_step_equals_eager():
     for pa, pb in zip(eager.params, graphed.params):
         assert float(sa[pa]["step"]) == float(sb[pb]["step"]) == 6.0
         assert maxerr(sa[pa]["exp_avg"], sb[pb]["exp_avg"]) <= 1e-4 * max(1.0, float(sa[pa]["exp_avg"].abs().max()))
+
+
+def test_graphed_train_step_dropout_advances_rng():
+    """With dropout on, successive replays of the captured step must draw new masks (PyTorch's graph-safe Philox
+    offsets): the loss on the same batch differs from replay to replay, and stays finite."""
+    from gvl_amd.config import make_opt
+    from gvl_amd.pdvc import build
+    from gvl_amd.parallel import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    f = load("pdvc_eval")
+    g = load("pdvc_train")
+    opt = make_opt(num_queries=8, feature_dim=64, vocab_size=40, max_caption_len=6, device="cuda", lr=1e-10,
+                   weight_decay=0.0)                      # default dropouts: transformer 0.1, captioner 0.5
+    model, crit, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f), strict=True)
+    model = model.to(dev).train()
+    dt = to_dev(pdvc_dt(f), dev)
+    dt.update(cap_tensor=t(g["cap_tensor"]).to(dev), cap_mask=t(g["cap_mask"]).to(dev),
+              gt_boxes_mask=torch.tensor([[1, 1, 1], [1, 1, 0]], dtype=torch.bool, device=dev))
+    step = GraphedTrainStep(model, crit, opt, warmup=1)
+    losses = [float(step(dt)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses)) and len({round(x, 5) for x in losses}) == 4, losses
