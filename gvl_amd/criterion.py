@@ -182,7 +182,9 @@ class SetCriterion(nn.Module):
             last_indices = self.matcher(main, targets)
         outputs['matched_indices'] = last_indices
         num_boxes = sum(len(t_["labels"]) for t_ in targets)
-        if is_dist_avail_and_initialized():                            # criterion.py:178-181
+        # criterion.py:178-181.  Only while training: the reference never evaluates under a process group, and an
+        # eval forward sharded by video must not synchronise the ranks (its losses are per-rank diagnostics)
+        if is_dist_avail_and_initialized() and torch.is_grad_enabled():
             nb = torch.as_tensor([num_boxes], dtype=torch.float, device=outputs['pred_logits'].device)
             dist.all_reduce(nb)
             num_boxes = torch.clamp(nb / get_world_size(), min=1).item()
