@@ -1,2 +1,2 @@
 from .ms_deform_attn_func import (MSDeformAttnFunction, MSDeformAttnPadFunction, MSDASampleFunction,  # noqa: F401
-                                   MSDeformAttnFusedFunction)
+                                   MSDeformAttnFusedFunction, ms_deform_attn_core_pytorch)

@@ -107,3 +107,23 @@ class MSDeformAttnFusedFunction(Function):
         gv, gp, gr = MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref, grad_output.contiguous(), n_levels,
                                                 n_points, pad_mode, need_ref_grad=ctx.needs_input_grad[2])
         return gv, gp, gr, None, None, None, None, None
+
+
+def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights, return_value=False):
+    """Same name, arguments and results as the reference's pure-PyTorch core (func.py:44-71: per-level bilinear
+    ``grid_sample`` with ``padding_mode='border'``, optionally returning the unweighted samples (B*M, D, Lq, L, P)) --
+    but computed by the HIP kernels on the GPU, differentiable w.r.t. value / locations / weights.  It is NOT a CPU
+    fallback: CPU tensors raise, like every other entry point of gvl_amd."""
+    import torch
+    if not value.is_cuda:
+        raise RuntimeError("gvl_amd.ms_deform_attn_core_pytorch runs on a ROCm device only (no CPU fallback)")
+    shapes = value_spatial_shapes.to(device=value.device, dtype=torch.int64).contiguous()
+    if shapes.dim() == 1:
+        shapes = torch.stack([torch.ones_like(shapes), shapes], -1).contiguous()
+    sizes = shapes[:, 0] * shapes[:, 1]
+    lsi = torch.cat((sizes.new_zeros(1), sizes.cumsum(0)[:-1])).contiguous()
+    value = value.contiguous()
+    loc = sampling_locations.contiguous()
+    if return_value:
+        return MSDASampleFunction.apply(value, shapes, lsi, loc, "border")
+    return MSDeformAttnPadFunction.apply(value, shapes, lsi, loc, attention_weights.contiguous(), 1 << 30, "border")

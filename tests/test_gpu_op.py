@@ -303,3 +303,24 @@ def test_general_y_coordinate_on_temporal_levels(dev, MSDA):
         rv, rl, rw = O.msda_backward(value, shapes, lsi, loc, aw, gout, "zeros")
         assert maxerr(gv, rv) <= 1e-4 * scale(rv) and maxerr(gl, rl) <= 1e-4 * scale(rl) and maxerr(gw, rw) <= 1e-4 * scale(rw)
     set_impl("auto")
+
+
+@pytest.mark.parametrize("case", ["op_t1d_d64_f32", "op_2d_edges_f32", "op_test2d_d30_f64"])
+def test_core_pytorch_named_entry_point(case, dev):
+    """gvl_amd.ops.functions.ms_deform_attn_core_pytorch keeps the reference function's name / arguments / results
+    (func.py:44-71, border padding, return_value) and its differentiability, on the GPU."""
+    from gvl_amd.ops.functions import ms_deform_attn_core_pytorch
+    f = load(case)
+    atol, rtol = tols(f["value"].dtype)
+    v, l_, a = (t(f[k]).to(dev).requires_grad_() for k in ("value", "loc", "aw"))
+    out = ms_deform_attn_core_pytorch(v, t(f["shapes"]).to(dev), l_, a)
+    assert maxerr(out, f["out_border"]) <= atol * scale(f["out_border"])
+    out.backward(t(f["gout"]).to(dev))
+    assert maxerr(v.grad, f["gvalue_border"]) <= rtol * scale(f["gvalue_border"])
+    assert maxerr(l_.grad, f["gloc_border"]) <= rtol * scale(f["gloc_border"])
+    assert maxerr(a.grad, f["gaw_border"]) <= rtol * scale(f["gaw_border"])
+    s = ms_deform_attn_core_pytorch(t(f["value"]).to(dev), t(f["shapes"]).to(dev), t(f["loc"]).to(dev), None,
+                                    return_value=True)
+    assert maxerr(s, f["sample_border"]) <= atol * scale(f["sample_border"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ms_deform_attn_core_pytorch(t(f["value"]), t(f["shapes"]), t(f["loc"]), t(f["aw"]))

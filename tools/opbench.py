@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--Q", type=int, default=300)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--cold", action="store_true", help="evict L2 / Infinity Cache (write 1 GiB) before every profiled launch")
+    ap.add_argument("--fresh", action="store_true", help="rewrite the kernel's inputs with another kernel right before every profiled launch")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, D, L, P = 8, 64, 4, 4
@@ -99,6 +100,8 @@ def main():
                     MSDA.profile_enable(False)
                     evict.add_(1.0)
                     MSDA.profile_enable(True)
+                if a.fresh:
+                    value.mul_(1.0); proj.mul_(1.0); ref.mul_(1.0); gout.mul_(1.0)
                 fn()
             torch.cuda.synchronize()
             MSDA.profile_enable(False)
