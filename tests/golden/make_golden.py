@@ -346,6 +346,49 @@ def make_pdvc():
          tshapes=tshapes, lsi=lsi, logp=logp, h1=h1[0], c1=c1[0])
 
 
+def gt_proposal_inputs(dt):
+    """dt['gt_boxes'] / dt['gt_boxes_mask'] as the reference's collate builds them (video_dataset.py: padded
+    (B, max_gt, 2) boxes + bool mask)."""
+    n = [len(tg["boxes"]) for tg in dt["video_target"]]
+    boxes = torch.zeros(len(n), max(n), 2)
+    mask = torch.zeros(len(n), max(n), dtype=torch.bool)
+    for i, tg in enumerate(dt["video_target"]):
+        boxes[i, :n[i]] = tg["boxes"]
+        mask[i, :n[i]] = True
+    return boxes, mask
+
+
+def make_gtprop():
+    """Evaluation with ground-truth proposals as decoder input (transformer_input_type='gt_proposals':
+    misc/utils.py:32-43 decide_two_stage, deformable_transformer.py:137-147 prepare_decoder_input_proposal,
+    iterative refinement disabled), CUDA-op semantics."""
+    import copy
+    opt, model, criterion, cc = build_pdvc()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=300)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 2, 24
+    dt = synth_dt(B, T, opt.feature_dim, valid=[24, 17], n_gt=[3, 2])
+    dt["gt_boxes"], dt["gt_boxes_mask"] = gt_proposal_inputs(dt)
+    crit = copy.deepcopy(criterion)                       # decide_two_stage zeroes weights / the caption cost in place
+    with cuda_semantics(), torch.no_grad():
+        out, loss = model(dt, crit, cc, "gt_proposals", eval_mode=True)
+    rec = dict(meta_T=np.array(T), valid=np.array([24, 17]), n_gt=np.array([3, 2]),
+               param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]),
+               gt_boxes=dt["gt_boxes"], gt_boxes_mask=dt["gt_boxes_mask"],
+               pred_logits=out["pred_logits"], pred_boxes=out["pred_boxes"], pred_count=out["pred_count"],
+               seq=out["seq"], cap_prob_eval=out["caption_probs"]["cap_prob_eval"],
+               aux_pred_boxes=out["aux_outputs"][0]["pred_boxes"],
+               aux_pred_logits=out["aux_outputs"][0]["pred_logits"])
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        rec[f"match_{i}"] = torch.stack([a, b])
+    for k, v in loss.items():
+        rec[f"loss.{k}"] = torch.as_tensor(v)
+    rec["weight_names"] = np.array(sorted(crit.weight_dict))
+    rec["weight_values"] = np.array([float(crit.weight_dict[k]) for k in sorted(crit.weight_dict)])
+    save("pdvc_gtprop", **rec)
+
+
 def make_train():
     """One training forward/backward of the reference (pdvc.py parallel_prediction_matched, train.py:403-406) with
     every dropout probability set to 0 so that the step is deterministic; CUDA-op (zero padding) semantics."""
@@ -429,6 +472,9 @@ if __name__ == "__main__":
     if "--only-init" in sys.argv:
         make_init()
         sys.exit(0)
+    if "--only-gtprop" in sys.argv:
+        make_gtprop()
+        sys.exit(0)
     if "--only-train" in sys.argv:
         make_train()
         sys.exit(0)
@@ -437,5 +483,6 @@ if __name__ == "__main__":
     make_matcher()
     if FULL:
         make_pdvc()
+        make_gtprop()
         make_train()
     make_init()

@@ -59,6 +59,34 @@ def test_pdvc_eval_forward_matches_reference(built):
         assert maxerr(loss[k].reshape(()), f[f"cuda.loss.{k}"].reshape(())) < 5e-4, k
 
 
+def test_pdvc_eval_with_gt_proposals_matches_reference(built):
+    """transformer_input_type='gt_proposals' (misc/utils.py:32-43; deformable_transformer.py:137-147): the decoder is
+    fed the ground-truth segments, refinement is off, box / class / count losses are weighted 0."""
+    import copy
+    _, model, criterion, dev = built
+    f = load("pdvc_gtprop")
+    dt = to_dev(pdvc_dt(f), dev)
+    dt["gt_boxes"], dt["gt_boxes_mask"] = t(f["gt_boxes"]).to(dev), t(f["gt_boxes_mask"]).to(dev)
+    crit = copy.deepcopy(criterion)
+    with torch.no_grad():
+        out, loss = model(dt, crit, None, "gt_proposals", eval_mode=True)
+    assert maxerr(out["pred_boxes"], f["pred_boxes"]) < 1e-5           # = the proposals themselves
+    assert maxerr(out["pred_logits"], f["pred_logits"]) < 5e-4
+    assert maxerr(out["pred_count"], f["pred_count"]) < 5e-4
+    assert maxerr(out["aux_outputs"][0]["pred_boxes"], f["aux_pred_boxes"]) < 1e-5
+    assert maxerr(out["aux_outputs"][0]["pred_logits"], f["aux_pred_logits"]) < 5e-4
+    assert torch.equal(out["seq"].cpu(), t(f["seq"]))
+    assert maxerr(out["caption_probs"]["cap_prob_eval"], f["cap_prob_eval"]) < 5e-4
+    for i in range(len(out["matched_indices"][0])):
+        assert torch.equal(torch.stack(out["matched_indices"][0][i]), t(f[f"match_{i}"]))
+    for k in ("loss_ce", "loss_counter", "loss_bbox", "loss_giou", "loss_self_iou", "loss_ce_0"):
+        assert maxerr(loss[k].reshape(()), f[f"loss.{k}"].reshape(())) < 5e-4, k
+    names = [str(n) for n in f["weight_names"]]
+    assert sorted(crit.weight_dict) == names
+    assert [float(crit.weight_dict[k]) for k in names] == [float(v) for v in f["weight_values"]]
+    assert crit.matcher.cost_caption == 0
+
+
 def test_transformer_stages_match_reference(built):
     f, model, criterion, dev = built
     dt = to_dev(pdvc_dt(f), dev)
