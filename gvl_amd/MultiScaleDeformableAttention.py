@@ -14,7 +14,8 @@ import torch
 from . import _lib
 
 PAD_MODES = {"zeros": 0, "border": 1, 0: 0, 1: 1}
-_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
+_BF16_WIDEN = (b"bf16 storage needs", b"does not fit LDS")     # bf16 entry points serve the temporal D=64 kernels only
 
 
 def _require(cond, msg):
@@ -54,7 +55,7 @@ def _common_checks(value, spatial_shapes, level_start_index, sampling_loc, attn_
         _require(t_.is_contiguous(), f"{name} tensor has to be contiguous")
         if not t_.is_cuda:
             raise RuntimeError("Not implemented on the CPU")                        # ms_deform_attn.h:38
-    _require(value.dtype in _SUFFIX, f"ms_deform_attn: unsupported dtype {value.dtype} (fp32 / fp64 only)")
+    _require(value.dtype in _SUFFIX, f"ms_deform_attn: unsupported dtype {value.dtype} (fp32 / fp64 / bf16 only)")
     _require(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
              "spatial_shapes / level_start_index must be int64")
     B, S, M, D = value.shape
@@ -63,8 +64,8 @@ def _common_checks(value, spatial_shapes, level_start_index, sampling_loc, attn_
     _require(tuple(sampling_loc.shape) == (B, Q, M, L, P, 2), "sampling_loc has wrong shape")
     if attn_weight is not None:
         _require(tuple(attn_weight.shape) == (B, Q, M, L, P), "attn_weight has wrong shape")
-        _require(attn_weight.dtype == value.dtype, "dtype mismatch")
-    _require(sampling_loc.dtype == value.dtype, "dtype mismatch")
+        _require(attn_weight.dtype == _arith_dtype(value), "dtype mismatch")
+    _require(sampling_loc.dtype == _arith_dtype(value), "dtype mismatch")
     step = min(B, int(im2col_step)) if B > 0 else 1
     _require(step > 0 and B % step == 0, f"batch({B}) must divide im2col_step({step})")   # cu:50-52
     return B, S, M, D, L, Q, P
@@ -72,6 +73,15 @@ def _common_checks(value, spatial_shapes, level_start_index, sampling_loc, attn_
 
 def _hp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _arith_dtype(value):
+    """bf16 is a STORAGE type here (include/gvl_msda.h "Element types"): locations / weights stay fp32."""
+    return torch.float32 if value.dtype == torch.bfloat16 else value.dtype
+
+
+def _bf16_unserved(rc):
+    return rc == -1 and any(m in (_lib.lib().gvl_last_error() or b"") for m in _BF16_WIDEN)
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
@@ -86,6 +96,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                 attn_weight.data_ptr(), B, S, M, D, L, Q, P, PAD_MODES[pad_mode], _hp(sh), _hp(ls), out.data_ptr(),
                 stream)
+    if value.dtype == torch.bfloat16 and _bf16_unserved(rc):     # other shapes: widen, same fp32 arithmetic, round once
+        return ms_deform_attn_forward(value.float(), spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                      im2col_step, pad_mode).to(torch.bfloat16)
     _lib.check(rc, "ms_deform_attn_forward")
     return out
 
@@ -93,6 +106,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 def ms_deform_attn_sample(value, spatial_shapes, level_start_index, sampling_loc, pad_mode="border"):
     """ms_deform_attn_core_pytorch(..., return_value=True) (func.py:67-68): (B*M, D, Q, L, P)."""
     B, S, M, D, L, Q, P = _common_checks(value, spatial_shapes, level_start_index, sampling_loc, None, 1 << 30)
+    if value.dtype == torch.bfloat16:
+        return ms_deform_attn_sample(value.float(), spatial_shapes, level_start_index, sampling_loc,
+                                     pad_mode).to(torch.bfloat16)
     out = value.new_empty((B * M, D, Q, L, P))
     fn = getattr(_lib.lib(), "gvl_msda_sample_" + _SUFFIX[value.dtype])
     with torch.cuda.device(value.device):
@@ -109,6 +125,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                                          im2col_step)
     _require(grad_output.is_contiguous(), "grad_output tensor has to be contiguous")   # cu:98
     _require(grad_output.is_cuda, "grad_output must be a CUDA tensor")
+    _require(grad_output.dtype == value.dtype, "grad_output dtype mismatch")
     sh, ls = host_shapes(spatial_shapes, level_start_index)
     grad_value = torch.empty_like(value)
     grad_loc = torch.empty_like(sampling_loc)
@@ -123,15 +140,21 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 attn_weight.data_ptr(), grad_output.data_ptr(), B, S, M, D, L, Q, P, PAD_MODES[pad_mode], _hp(sh),
                 _hp(ls), grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
                 ws.data_ptr() if ws is not None else None, nbytes, stream)
+    if value.dtype == torch.bfloat16 and _bf16_unserved(rc):
+        gv, gl, ga = ms_deform_attn_backward(value.float(), spatial_shapes, level_start_index, sampling_loc,
+                                             attn_weight, grad_output.float(), im2col_step, pad_mode)
+        return gv.to(torch.bfloat16), gl, ga
     _lib.check(rc, "ms_deform_attn_backward")
     return grad_value, grad_loc, grad_attn
 
 
 def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_levels, n_points, pad_mode="zeros"):
-    """include/gvl_msda.h: gvl_msda1d_fused_forward_f32.  value (B,S,M,64) | proj (B,Q,2*M*L*P) | ref (B,Q,L,1|2)"""
-    for name, t_ in (("value", value), ("proj", proj), ("ref", ref)):
-        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
-                 f"msda1d_fused: {name} must be a contiguous fp32 CUDA tensor")
+    """include/gvl_msda.h: gvl_msda1d_fused_forward_{f32,bf16}.  value (B,S,M,64) | proj (B,Q,2*M*L*P) | ref (B,Q,L,1|2);
+    value / proj fp32 or both bf16, ref always fp32."""
+    _require(value.dtype in (torch.float32, torch.bfloat16), "msda1d_fused: value must be fp32 or bf16")
+    for name, t_, dt_ in (("value", value, value.dtype), ("proj", proj, value.dtype), ("ref", ref, torch.float32)):
+        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == dt_,
+                 f"msda1d_fused: {name} must be a contiguous {dt_} CUDA tensor")
     B, S, M, D = value.shape
     Q, RD = ref.shape[1], ref.shape[-1]
     _require(tuple(proj.shape) == (B, Q, 2 * M * n_levels * n_points) and tuple(ref.shape) == (B, Q, n_levels, RD),
@@ -139,7 +162,7 @@ def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_
     sh, ls = host_shapes(spatial_shapes, level_start_index)
     out = value.new_empty((B, Q, M * D))
     with torch.cuda.device(value.device):
-        rc = _lib.lib().gvl_msda1d_fused_forward_f32(
+        rc = getattr(_lib.lib(), "gvl_msda1d_fused_forward_" + _SUFFIX[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(), ref.data_ptr(),
             B, S, M, D, n_levels, Q, n_points, RD, PAD_MODES[pad_mode], _hp(sh), _hp(ls), out.data_ptr(),
             torch.cuda.current_stream().cuda_stream)
@@ -152,16 +175,17 @@ def msda1d_fused_backward(value, spatial_shapes, level_start_index, proj, ref, g
     """-> (grad_value, grad_proj, grad_ref or None)"""
     B, S, M, D = value.shape
     Q, RD = ref.shape[1], ref.shape[-1]
-    _require(grad_output.is_contiguous() and grad_output.is_cuda, "grad_output must be a contiguous CUDA tensor")
+    _require(grad_output.is_contiguous() and grad_output.is_cuda and grad_output.dtype == value.dtype,
+             "grad_output must be a contiguous CUDA tensor of value's dtype")
     sh, ls = host_shapes(spatial_shapes, level_start_index)
     grad_value = torch.empty_like(value)
     grad_proj = torch.empty_like(proj)
-    grad_ref_part = value.new_empty((B, Q, M, n_levels, RD)) if need_ref_grad else None
+    grad_ref_part = ref.new_empty((B, Q, M, n_levels, RD)) if need_ref_grad else None
     lib = _lib.lib()
-    nbytes = lib.gvl_msda1d_fused_backward_workspace_bytes(B, S, M, D, n_levels, Q, n_points, _hp(sh))
+    nbytes = lib.gvl_msda_backward_workspace_bytes(B, S, M, D, n_levels, Q, n_points, value.element_size(), _hp(sh))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
     with torch.cuda.device(value.device):
-        rc = lib.gvl_msda1d_fused_backward_f32(
+        rc = getattr(lib, "gvl_msda1d_fused_backward_" + _SUFFIX[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(), ref.data_ptr(),
             grad_output.data_ptr(), B, S, M, D, n_levels, Q, n_points, RD, PAD_MODES[pad_mode], _hp(sh), _hp(ls),
             grad_value.data_ptr(), grad_proj.data_ptr(), grad_ref_part.data_ptr() if need_ref_grad else None,

@@ -5,6 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
+ABI_VERSION = 2          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -26,6 +27,8 @@ SIGNATURES = {
     "gvl_msda_backward_workspace_bytes": (_SZ, [_I] * 8 + [_P]),
     "gvl_msda_backward_f32": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_msda_backward_f64": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gvl_msda_forward_bf16": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
+    "gvl_msda_backward_bf16": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_prof_enable": (_I, [_I]),
     "gvl_prof_collect": (_I, [_P, _P, _P, _P, _I]),
     "gvl_msda_sample_backward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),
@@ -36,6 +39,8 @@ SIGNATURES = {
     "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),
     "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gvl_msda1d_fused_forward_bf16": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
+    "gvl_msda1d_fused_backward_bf16": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_batch_device_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
@@ -65,7 +70,7 @@ def lib():
                     fn = getattr(handle, name)
                     fn.restype = res
                     fn.argtypes = args
-                if handle.gvl_msda_abi_version() != 1:
+                if handle.gvl_msda_abi_version() != ABI_VERSION:
                     raise GvlLibraryError("libgvl_msda.so ABI version mismatch; rebuild")
                 _lib = handle
     return _lib

@@ -6,14 +6,16 @@
 //             scalar.  Backward: one wavefront per (b,q,m), lanes stride the channels, wave reduction of
 //             grad_loc / grad_attn with cross-lane shuffles, grad_value through hardware float atomics.
 //
-//   t1d_d64   GVL's case: temporal levels (H = 1), D = 64, fp32, L*P <= 16.  One workgroup owns one
-//             (batch, head) value slab [S][64] staged in LDS and a chunk of the queries.  A 16-lane DPP row
-//             owns one (b,q,m): lane j holds channels 4j..4j+3 (float4) AND computes the interpolation
+//   t1d_d64   GVL's case: temporal levels (H = 1), D = 64, L*P <= 16; fp32 arithmetic over fp32 or bf16 storage
+//             (value / out / grad_out / grad_value and, fused, the projection rows).  One workgroup owns one
+//             (batch, head) value slab [S][64] staged in LDS as fp32 and a chunk of the queries.  A 16-lane DPP
+//             row owns one (b,q,m): lane j holds channels 4j..4j+3 (float4) AND computes the interpolation
 //             coefficients of sample j, which are broadcast inside the row with DPP row_newbcast.  Rows are
 //             256 B, so one ds_read_b128 per lane reads a whole row per DPP row, bank-conflict free.
-//             The backward keeps a private grad_value slab in LDS (ds_add_f32) and flushes it once per
-//             workgroup (plain stores; partial slabs are summed by a second tiny kernel when a slab is
-//             shared by several workgroups), so it issues no global atomics and is bitwise reproducible.
+//             The backward produces grad_value by a counting sort + gather in LDS (no float atomics) and
+//             writes it with plain stores (partial slabs are summed by a second tiny kernel when a slab is
+//             shared by several workgroups): grad_loc / grad_attn are bitwise reproducible, grad_value up to the
+//             order of the entries of one slab row (integer LDS atomics fix it; ~1e-7 relative).
 //
 // Arithmetic follows /root/reference/pdvc/ops/src/cuda/ms_deform_im2col_cuda.cuh (cited per function) for
 // pad_mode = zeros and ATen's grid_sampler(border, align_corners=False) for pad_mode = border.
@@ -22,6 +24,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "gvl_common.hpp"
 #include "gvl_msda.h"
@@ -304,15 +308,32 @@ __device__ inline float dot4(float4 a, float4 b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+// ---- storage types: fp32 or bf16 in HBM, fp32 in registers / LDS.  `i4` indexes groups of 4 consecutive channels.
+using bf16_t = __bf16;
+struct alignas(8) bf16x4 { bf16_t a, b, c, d; };
+
+__device__ inline float4 ld4(const float *base, int64_t i4) { return reinterpret_cast<const float4 *>(base)[i4]; }
+__device__ inline float4 ld4(const bf16_t *base, int64_t i4) {
+  const bf16x4 v = reinterpret_cast<const bf16x4 *>(base)[i4];
+  return make_float4((float)v.a, (float)v.b, (float)v.c, (float)v.d);
+}
+__device__ inline void st4(float *base, int64_t i4, float4 v) { reinterpret_cast<float4 *>(base)[i4] = v; }
+__device__ inline void st4(bf16_t *base, int64_t i4, float4 v) {            // v_cvt_pk_bf16_f32: round-to-nearest-even
+  bf16x4 o;
+  o.a = (bf16_t)v.x; o.b = (bf16_t)v.y; o.c = (bf16_t)v.z; o.d = (bf16_t)v.w;
+  reinterpret_cast<bf16x4 *>(base)[i4] = o;
+}
+
 // stage rows [row0, S) of the (b,m) value slab [S][64] into LDS as float4[(S-row0)*16]; one zero row follows.
 // row0 > 0 ("L0G"): level 0 does not fit beside the other levels in the 160 KB LDS (long videos: T = 512 gives
 // S*256 B = 240 KB); its rows are then read straight from global memory / L2 by the sample steps of level 0.
-__device__ inline void stage_slab(float4 *slab4, const float *value, int b, int m, int S, int M, int row0 = 0) {
-  const float4 *src = reinterpret_cast<const float4 *>(value) + ((int64_t)b * S * M + m) * 16;
+template <typename VT>
+__device__ inline void stage_slab(float4 *slab4, const VT *value, int b, int m, int S, int M, int row0 = 0) {
+  const int64_t src = ((int64_t)b * S * M + m) * 16;
   const int n = (S - row0) * 16;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int s = row0 + (i >> 4), j = i & 15;
-    slab4[i] = src[(int64_t)s * M * 16 + j];
+    slab4[i] = ld4(value, src + (int64_t)s * M * 16 + j);
   }
   if (threadIdx.x < 16) slab4[n + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -331,8 +352,9 @@ struct RawOps {
   float a, b, c, d;   // !FUSED: (x, y, w, -)     FUSED: (offset, logit, ref0, ref1)
 };
 
-template <bool FUSED>
-__device__ inline RawOps fetch_ops(const float *__restrict__ p0, const float *__restrict__ p1, int64_t bq, int m, int M,
+// p0 = loc (fp32) | proj (storage type VT);  p1 = attn | ref (always fp32: positions must not be rounded to bf16)
+template <bool FUSED, typename VT>
+__device__ inline RawOps fetch_ops(const void *__restrict__ p0, const float *__restrict__ p1, int64_t bq, int m, int M,
                                    int LP, int L, int RD, int j, int l) {
   RawOps r;
   if (!FUSED) {
@@ -340,9 +362,9 @@ __device__ inline RawOps fetch_ops(const float *__restrict__ p0, const float *__
     const float2 xy = reinterpret_cast<const float2 *>(p0)[i];
     r.a = xy.x; r.b = xy.y; r.c = p1[i]; r.d = 0.f;
   } else {
-    const float *row = p0 + bq * (int64_t)(2 * M * LP);
-    r.a = row[m * LP + j];
-    r.b = row[M * LP + m * LP + j];
+    const VT *row = reinterpret_cast<const VT *>(p0) + bq * (int64_t)(2 * M * LP);
+    r.a = (float)row[m * LP + j];
+    r.b = (float)row[M * LP + m * LP + j];
     const float *rp = p1 + (bq * L + l) * RD;
     r.c = rp[0];
     r.d = RD == 2 ? rp[1] : 0.f;
@@ -376,12 +398,12 @@ __device__ inline void resolve_ops(const RawOps &r, int Tl, int P, int RD, float
 // ------------------------------------------------------------------------------------------------------
 // t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
 // ------------------------------------------------------------------------------------------------------
-template <int PAD, bool FULL16, bool FUSED, bool L0G>
-__global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ value,
+template <int PAD, bool FULL16, bool FUSED, bool L0G, typename VT>
+__global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ value,
                                                      const int64_t *__restrict__ shapes,
-                                                     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
+                                                     const int64_t *__restrict__ lsi, const void *__restrict__ loc,
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
-                                                     int P, int RD, int nchunk, float *__restrict__ out) {
+                                                     int P, int RD, int nchunk, VT *__restrict__ out) {
   extern __shared__ float4 slab4[];
   const int BM = B * M;
   const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
@@ -404,11 +426,11 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
   }
   int qb = q0 + wave * 4;
   RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
-  if (qb < q1 && j < LP) r_n = fetch_ops<FUSED>(loc, attn, (int64_t)b * Q + min(qb + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
+  if (qb < q1 && j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, (int64_t)b * Q + min(qb + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
   // L0G: level 0 (rows [0, T_0)) stays in global memory, LDS holds rows [T_0, S); needs FULL16 and P == 4 so that
   // "sample step SI belongs to level 0" is the compile-time test SI < 4
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;
-  const float4 *vg4 = reinterpret_cast<const float4 *>(value) + ((int64_t)b * S * M + m) * 16 + j;
+  const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;               // this lane's channels of row 0 of the slab
   stage_slab(slab4, value, b, m, S, M, row0);
   __syncthreads();
 
@@ -417,7 +439,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
     const bool act = q < q1;
     const RawOps r = r_n;
     const int qbn = qb + nw * 4;
-    if (qbn < q1 && j < LP) r_n = fetch_ops<FUSED>(loc, attn, (int64_t)b * Q + min(qbn + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
+    if (qbn < q1 && j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, (int64_t)b * Q + min(qbn + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
     float2 xy;
     float w, dloc_;
     resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc_);
@@ -438,8 +460,8 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
     const float c = row_bcast_f<SI>(chi);                                       \
     float4 v0, v1;                                                              \
     if (L0G && SI < 4) {                                                        \
-      v0 = vg4[(int64_t)ro * (M * 16)];                                         \
-      v1 = vg4[(int64_t)min(ro + 1, S - 1) * (M * 16)];                         \
+      v0 = ld4(value, vg + (int64_t)ro * (M * 16));                             \
+      v1 = ld4(value, vg + (int64_t)min(ro + 1, S - 1) * (M * 16));             \
     } else {                                                                    \
       v0 = slab4[ro + j];                                                       \
       v1 = slab4[ro + 16 + j];                                                  \
@@ -452,7 +474,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const float *__restrict__ 
     GVL_FWD_STEP(8) GVL_FWD_STEP(9) GVL_FWD_STEP(10) GVL_FWD_STEP(11)
     GVL_FWD_STEP(12) GVL_FWD_STEP(13) GVL_FWD_STEP(14) GVL_FWD_STEP(15)
 #undef GVL_FWD_STEP
-    if (act) reinterpret_cast<float4 *>(out)[(((int64_t)b * Q + q) * M + m) * 16 + j] = acc;
+    if (act) st4(out, (((int64_t)b * Q + q) * M + m) * 16 + j, acc);
   }
 }
 
@@ -484,16 +506,18 @@ __host__ __device__ inline size_t bwd_lds_bytes(int S, int nq, int rowsV) {
 
 // FUSED: loc -> proj, attn -> ref (see fetch_ops); gloc -> grad_proj (B*Q, 2*M*LP), gattn -> grad_ref partials
 // (B,Q,M,L,RD) or nullptr.  The softmax / location backward of ms_deform_attn.py:99-109 is applied in the epilogue.
-template <int PAD, bool FULL16, bool FUSED, bool L0G>
-__global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__restrict__ value,
+// Storage type VT (fp32 | bf16): value, grad_out and -- FUSED -- proj / grad_proj.  grad_value leaves this kernel in
+// fp32 (`gvalue_part`): the final tensor itself when VT = float and one workgroup owns the slab, else partial slabs.
+template <int PAD, bool FULL16, bool FUSED, bool L0G, typename VT>
+__global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restrict__ value,
                                                              const int64_t *__restrict__ shapes,
                                                              const int64_t *__restrict__ lsi,
-                                                             const float *__restrict__ loc,
+                                                             const void *__restrict__ loc,
                                                              const float *__restrict__ attn,
-                                                             const float *__restrict__ gout, int B, int S, int M, int L,
+                                                             const VT *__restrict__ gout, int B, int S, int M, int L,
                                                              int Q, int P, int RD, int nchunk, int qper,
                                                              float *__restrict__ gvalue_part,
-                                                             float *__restrict__ gloc, float *__restrict__ gattn) {
+                                                             void *__restrict__ gloc, float *__restrict__ gattn) {
   extern __shared__ float4 slab4[];
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;    // see k_fwd_t1d_d64
   const int rowsV = S - row0 + 1;
@@ -526,10 +550,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
   float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
   if (qb < q1) {
     const int64_t bqn = (int64_t)b * Q + min(qb + tq, q1 - 1);
-    if (j < LP) r_n = fetch_ops<FUSED>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-    if (qb + tq < q1) g_n = reinterpret_cast<const float4 *>(gout)[(bqn * M + m) * 16 + j];
+    if (j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+    if (qb + tq < q1) g_n = ld4(gout, (bqn * M + m) * 16 + j);
   }
-  const float4 *vg4 = reinterpret_cast<const float4 *>(value) + ((int64_t)b * S * M + m) * 16 + (threadIdx.x & 15);
+  const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;
   stage_slab(slab4, value, b, m, S, M, row0);
   for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
   for (int i = threadIdx.x; i < qper * kEntStride; i += blockDim.x) ent_r[i] = -1;
@@ -546,9 +570,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
     const int qbn = qb + nw * 4;
     if (qbn < q1) {
       const int64_t bqn = (int64_t)b * Q + min(qbn + tq, q1 - 1);
-      if (j < LP) r_n = fetch_ops<FUSED>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-      g_n = (qbn + tq < q1) ? reinterpret_cast<const float4 *>(gout)[(bqn * M + m) * 16 + j]
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+      g_n = (qbn + tq < q1) ? ld4(gout, (bqn * M + m) * 16 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float2 xy;
     float w, dloc;
@@ -579,8 +602,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
     const int rr = row_bcast_i<SI>(roff);                                     \
     float4 v0, v1;                                                            \
     if (L0G && SI < 4) {                                                      \
-      v0 = vg4[(int64_t)rr * (M * 16)];                                       \
-      v1 = vg4[(int64_t)min(rr + 1, S - 1) * (M * 16)];                       \
+      v0 = ld4(value, vg + (int64_t)rr * (M * 16));                           \
+      v1 = ld4(value, vg + (int64_t)min(rr + 1, S - 1) * (M * 16));           \
     } else {                                                                  \
       v0 = slab4[(rr - row0) * 16 + j];                                       \
       v1 = slab4[(rr - row0) * 16 + 16 + j];                                  \
@@ -601,7 +624,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
     if (!FUSED) {
       if (act && j < LP) {
         gattn[tb + j] = keep_w;                                                // cuh:156-157
-        reinterpret_cast<float2 *>(gloc)[tb + j] = make_float2(keep_x, keep_y);
+        reinterpret_cast<float2 *>(gloc)[tb + j] = make_float2(keep_x, keep_y);   // unfused: grad_loc is fp32
       }
     } else {
       // softmax backward (ms_deform_attn.py:100-101): d logit_j = w_j (g_j - sum_k w_k g_k), g = d out / d w
@@ -613,9 +636,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
       gr0 += dpp_f<0xB1>(gr0); gr0 += dpp_f<0x4E>(gr0);
       gr1 += dpp_f<0xB1>(gr1); gr1 += dpp_f<0x4E>(gr1);
       if (act) {
-        float *grow = gloc + ((int64_t)b * Q + qq) * (int64_t)(2 * M * LP);
-        grow[m * LP + j] = goff;
-        grow[M * LP + m * LP + j] = glogit;
+        VT *grow = reinterpret_cast<VT *>(gloc) + ((int64_t)b * Q + qq) * (int64_t)(2 * M * LP);
+        grow[m * LP + j] = (VT)goff;
+        grow[M * LP + m * LP + j] = (VT)glogit;
         if (gattn && (j & 3) == 0) {
           float *gr = gattn + ((((int64_t)b * Q + qq) * M + m) * L + lvl) * RD;
           gr[0] = gr0;
@@ -654,8 +677,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
   }
   float4 *G4 = slab4;                                                 // value slab is dead from here on
   {
-    const float4 *src = reinterpret_cast<const float4 *>(gout) + (((int64_t)b * Q + q0) * M + m) * 16;
-    for (int i = threadIdx.x; i < nq * 16; i += blockDim.x) G4[i] = src[(int64_t)(i >> 4) * M * 16 + (i & 15)];
+    const int64_t src = (((int64_t)b * Q + q0) * M + m) * 16;
+    for (int i = threadIdx.x; i < nq * 16; i += blockDim.x) G4[i] = ld4(gout, src + (int64_t)(i >> 4) * M * 16 + (i & 15));
   }
   __syncthreads();
   for (int e = threadIdx.x; e < nq * kEntStride; e += blockDim.x) {
@@ -699,16 +722,17 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const float *__rest
   }
 }
 
-// sum `n` partial slabs (each `count4` float4 long) into dst
+// sum `n` fp32 partial slabs (each `count4` float4 long) into dst (storage type VT)
+template <typename VT>
 __global__ void __launch_bounds__(256) k_sum_partials(const float4 *__restrict__ part, int n, int64_t count4,
-                                                      float4 *__restrict__ dst) {
+                                                      VT *__restrict__ dst) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 a = part[i];
     for (int k = 1; k < n; ++k) {
       const float4 v = part[(int64_t)k * count4 + i];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    dst[i] = a;
+    st4(dst, i, a);
   }
 }
 
@@ -758,6 +782,87 @@ int pick_chunks(const char *env, int BM, int Q, int target_wgs) {
   return n;
 }
 
+// ---- launchers of the t1d_d64 kernels, shared by the fp32 / bf16 and the plain / fused entry points ------------------
+template <typename VT, bool FUSED>
+int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, const void *p0, const float *p1, int B,
+                int S, int M, int L, int Q, int P, int RD, int pad, const SlabPlan &plan, VT *out, hipStream_t st) {
+  // one 1024-thread workgroup per CU (measured best on MI355X: the 47 KB slab is staged once per CU and 16
+  // wavefronts hide the LDS latency); GVL_MSDA_FWD_{THREADS,CHUNKS} override for tuning sweeps
+  const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
+  const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
+  const size_t lds = (size_t)plan.rowsV * 64 * sizeof(float);
+  const bool full = L * P == 16;
+  decltype(&k_fwd_t1d_d64<kPadZeros, true, FUSED, false, VT>) kern;
+  if (pad == kPadZeros)
+    kern = plan.l0g ? k_fwd_t1d_d64<kPadZeros, true, FUSED, true, VT>
+                    : (full || FUSED) ? k_fwd_t1d_d64<kPadZeros, true, FUSED, false, VT>
+                                      : k_fwd_t1d_d64<kPadZeros, false, false, false, VT>;
+  else
+    kern = plan.l0g ? k_fwd_t1d_d64<kPadBorder, true, FUSED, true, VT>
+                    : (full || FUSED) ? k_fwd_t1d_d64<kPadBorder, true, FUSED, false, VT>
+                                      : k_fwd_t1d_d64<kPadBorder, false, false, false, VT>;
+  if (int rc = ensure_lds(kern, lds)) return rc;
+  g_last_impl = FUSED ? 3 : 2;
+  return gvl::launch(GVL_PROF_FWD_T1D, Q, B, FUSED ? "k_fwd_t1d_d64<fused>" : "k_fwd_t1d_d64", kern,
+                     dim3(nchunk * B * M), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
+                     nchunk, out);
+}
+
+// number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
+// queries per workgroup for the LDS carve-up; 0 = does not fit
+int bwd_chunks(int B, int M, int Q, int S, int rowsV) {
+  int n = pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256);
+  while (n <= Q && bwd_lds_bytes(S, (Q + n - 1) / n, rowsV) > kLdsMax) ++n;
+  return n <= Q ? n : 0;
+}
+
+// fp32 workspace the t1d_d64 backward needs: partial slabs when a (b,m) slab is shared by several workgroups, and
+// always one fp32 slab set for bf16 storage (the gather accumulates and writes fp32; k_sum_partials rounds once)
+size_t bwd_workspace_bytes(int B, int S, int M, int nchunk, bool bf16) {
+  return (nchunk > 1 || bf16) ? (size_t)nchunk * B * S * M * 64 * sizeof(float) : 0;
+}
+
+template <typename VT, bool FUSED>
+int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, const void *p0, const float *p1,
+                const VT *gout, int B, int S, int M, int L, int Q, int P, int RD, int pad, const SlabPlan &plan,
+                int nchunk, VT *gvalue, void *g0, float *g1, void *ws, size_t ws_bytes, hipStream_t st) {
+  constexpr bool kBf16 = !std::is_same<VT, float>::value;
+  const int qper = (Q + nchunk - 1) / nchunk;
+  const size_t lds = bwd_lds_bytes(S, qper, plan.rowsV);
+  const size_t need = bwd_workspace_bytes(B, S, M, nchunk, kBf16);
+  float *part = reinterpret_cast<float *>(gvalue);
+  if (need) {
+    if (!ws || ws_bytes < need)
+      return fail(GVL_ENOSPC, "gvl_msda backward: workspace %zu < required %zu bytes", ws_bytes, need);
+    part = (float *)ws;
+  }
+  const bool full = L * P == 16;
+  decltype(&k_bwd_t1d_d64<kPadZeros, true, FUSED, false, VT>) kern;
+  if (pad == kPadZeros)
+    kern = plan.l0g ? k_bwd_t1d_d64<kPadZeros, true, FUSED, true, VT>
+                    : (full || FUSED) ? k_bwd_t1d_d64<kPadZeros, true, FUSED, false, VT>
+                                      : k_bwd_t1d_d64<kPadZeros, false, false, false, VT>;
+  else
+    kern = plan.l0g ? k_bwd_t1d_d64<kPadBorder, true, FUSED, true, VT>
+                    : (full || FUSED) ? k_bwd_t1d_d64<kPadBorder, true, FUSED, false, VT>
+                                      : k_bwd_t1d_d64<kPadBorder, false, false, false, VT>;
+  if (int rc = ensure_lds(kern, lds)) return rc;
+  if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, FUSED ? "k_bwd_t1d_d64<fused>" : "k_bwd_t1d_d64", kern,
+                           dim3(nchunk * B * M), dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M,
+                           L, Q, P, RD, nchunk, qper, part, g0, g1))
+    return rc;
+  if (need) {
+    const int64_t count4 = (int64_t)B * S * M * 16;
+    int64_t blocks = (count4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (int rc = gvl::launch(GVL_PROF_SUM_PARTIALS, Q, B, "k_sum_partials", k_sum_partials<VT>, dim3((unsigned)blocks),
+                             dim3(256), 0, st, (const float4 *)part, nchunk, count4, gvalue))
+      return rc;
+  }
+  g_last_impl = FUSED ? 3 : 2;
+  return 0;
+}
+
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc, const T *attn, int B, int S,
                  int M, int D, int L, int Q, int P, int pad, const int64_t *shapes_host, const int64_t *lsi_host,
@@ -769,28 +874,12 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   const int mode = impl_mode();
   const bool temporal = S > 0 && temporal_host(shapes_host, lsi_host, L, S);
   const SlabPlan plan = temporal ? slab_plan(S, L, P, shapes_host) : SlabPlan{false, false, 0};
-  const size_t lds = (size_t)plan.rowsV * 64 * sizeof(float);
   const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && temporal && plan.ok;
   if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_forward: fast kernels not eligible for this call");
   if (fast_ok && mode != 1) {
-    if constexpr (sizeof(T) == 4) {
-      // one 1024-thread workgroup per CU (measured best on MI355X: the 47 KB slab is staged once per CU and 16
-      // wavefronts hide the LDS latency); GVL_MSDA_FWD_{THREADS,CHUNKS} override for tuning sweeps
-      const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
-      const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
-      const bool full = L * P == 16;
-      auto kern = pad == kPadZeros ? (plan.l0g ? k_fwd_t1d_d64<kPadZeros, true, false, true>
-                                                 : full ? k_fwd_t1d_d64<kPadZeros, true, false, false>
-                                                        : k_fwd_t1d_d64<kPadZeros, false, false, false>)
-                                   : (plan.l0g ? k_fwd_t1d_d64<kPadBorder, true, false, true>
-                                                 : full ? k_fwd_t1d_d64<kPadBorder, true, false, false>
-                                                        : k_fwd_t1d_d64<kPadBorder, false, false, false>);
-      if (int rc = ensure_lds(kern, lds)) return rc;
-      g_last_impl = 2;
-      return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(threads), lds, st,
-                         (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn, B, S, M, L, Q, P,
-                         0, nchunk, (float *)out);
-    }
+    if constexpr (sizeof(T) == 4)
+      return run_fwd_t1d<float, false>((const float *)value, shapes, lsi, loc, (const float *)attn, B, S, M, L, Q, P, 0,
+                                       pad, plan, (float *)out, st);
   }
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
@@ -811,14 +900,6 @@ int sample_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const
   g_last_impl = 1;
   return gvl::launch(GVL_PROF_SAMPLE, Q, B, "k_fwd_generic<sample>", k_fwd_generic<T, true>, dim3((unsigned)blocks),
                      dim3(256), 0, st, value, shapes, lsi, loc, (const T *)nullptr, B, S, M, D, L, Q, P, pad, sample);
-}
-
-// number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
-// queries per workgroup for the LDS carve-up; 0 = does not fit
-int bwd_chunks(int B, int M, int Q, int S, int rowsV) {
-  int n = pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256);
-  while (n <= Q && bwd_lds_bytes(S, (Q + n - 1) / n, rowsV) > kLdsMax) ++n;
-  return n <= Q ? n : 0;
 }
 
 template <typename T>
@@ -846,39 +927,10 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   const bool fast_ok = sizeof(T) == 4 && D == 64 && L * P <= 16 && lds <= kLdsMax && temporal && plan.ok;
   if (mode == 2 && !fast_ok) return fail(GVL_EINVAL, "gvl_msda_backward: fast kernels not eligible for this call");
   if (fast_ok && mode != 1) {
-    if constexpr (sizeof(T) == 4) {
-      const int nchunk = nchunk_f;
-      float *part = (float *)gvalue;
-      if (nchunk > 1) {
-        const size_t need = gv_bytes * nchunk;
-        if (!ws || ws_bytes < need)
-          return fail(GVL_ENOSPC, "gvl_msda_backward: workspace %zu < required %zu bytes", ws_bytes, need);
-        part = (float *)ws;
-      }
-      const bool full = L * P == 16;
-      auto kern = pad == kPadZeros ? (plan.l0g ? k_bwd_t1d_d64<kPadZeros, true, false, true>
-                                                 : full ? k_bwd_t1d_d64<kPadZeros, true, false, false>
-                                                        : k_bwd_t1d_d64<kPadZeros, false, false, false>)
-                                   : (plan.l0g ? k_bwd_t1d_d64<kPadBorder, true, false, true>
-                                                 : full ? k_bwd_t1d_d64<kPadBorder, true, false, false>
-                                                        : k_bwd_t1d_d64<kPadBorder, false, false, false>);
-      if (int rc = ensure_lds(kern, lds)) return rc;
-      if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64", kern, dim3(nchunk * B * M), dim3(kBwdThreads),
-                               lds, st, (const float *)value, shapes, lsi, (const float *)loc, (const float *)attn,
-                               (const float *)gout, B, S, M, L, Q, P, 0, nchunk, qper_f, part, (float *)gloc,
-                               (float *)gattn))
-        return rc;
-      if (nchunk > 1) {
-        const int64_t count4 = (int64_t)B * S * M * 16;
-        int64_t blocks = (count4 + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        if (int rc = gvl::launch(GVL_PROF_SUM_PARTIALS, Q, B, "k_sum_partials", k_sum_partials, dim3((unsigned)blocks),
-                                 dim3(256), 0, st, (const float4 *)part, nchunk, count4, (float4 *)gvalue))
-          return rc;
-      }
-      g_last_impl = 2;
-      return 0;
-    }
+    if constexpr (sizeof(T) == 4)
+      return run_bwd_t1d<float, false>((const float *)value, shapes, lsi, loc, (const float *)attn, (const float *)gout,
+                                       B, S, M, L, Q, P, 0, pad, plan, nchunk_f, (float *)gvalue, gloc, (float *)gattn,
+                                       ws, ws_bytes, st);
   }
   if (int rc = gvl::zero_fill(gvalue, gv_bytes, st)) return rc;
   int64_t blocks = (ntup + 3) / 4;
@@ -886,6 +938,50 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   g_last_impl = 1;
   return gvl::launch(GVL_PROF_BWD_GENERIC, Q, B, "k_bwd_generic", k_bwd_generic<T>, dim3((unsigned)blocks), dim3(256),
                      0, st, value, shapes, lsi, loc, attn, gout, B, S, M, D, L, Q, P, pad, gvalue, gloc, gattn);
+}
+
+// ---- fused module path: MSDeformAttn.forward between the projection GEMM and output_proj (ms_deform_attn.py:99-124)
+int fused_eligible(int B, int S, int M, int D, int L, int Q, int P, int RD, int pad, const int64_t *shapes_host,
+                          const int64_t *lsi_host) {
+  if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
+  if (D != 64 || L * P != 16 || P != 4 || (RD != 1 && RD != 2) || S <= 0)
+    return fail(GVL_EINVAL, "gvl_msda1d_fused: needs D=64, L*P=16, P=4, RD in {1,2} (got D=%d L=%d P=%d RD=%d)", D, L, P,
+                RD);
+  if (!temporal_host(shapes_host, lsi_host, L, S))
+    return fail(GVL_EINVAL, "gvl_msda1d_fused: needs host copies of temporal (H=1) level shapes");
+  return 0;
+}
+
+template <typename VT>
+int fused_forward(const VT *value, const int64_t *shapes, const int64_t *lsi, const VT *proj, const float *ref,
+                         int B, int S, int M, int D, int L, int Q, int P, int RD, int pad_mode,
+                         const int64_t *shapes_host, const int64_t *lsi_host, VT *out, void *stream) {
+  if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
+  if ((int64_t)B * Q == 0) return 0;
+  if (!value || !shapes || !lsi || !proj || !ref || !out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: null pointer");
+  const SlabPlan plan = slab_plan(S, L, P, shapes_host);
+  if (!plan.ok) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: slab of %d rows does not fit LDS", S);
+  return run_fwd_t1d<VT, true>(value, shapes, lsi, proj, ref, B, S, M, L, Q, P, RD, pad_mode, plan, out,
+                               (hipStream_t)stream);
+}
+
+template <typename VT>
+int fused_backward(const VT *value, const int64_t *shapes, const int64_t *lsi, const VT *proj, const float *ref,
+                          const VT *grad_out, int B, int S, int M, int D, int L, int Q, int P, int RD, int pad_mode,
+                          const int64_t *shapes_host, const int64_t *lsi_host, VT *grad_value, VT *grad_proj,
+                          float *grad_ref, void *workspace, size_t workspace_bytes, void *stream) {
+  if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t gv_bytes = (size_t)B * S * M * D * sizeof(VT);
+  if (gv_bytes && !grad_value) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
+  if ((int64_t)B * Q == 0) return gvl::zero_fill(grad_value, gv_bytes, st);
+  if (!value || !shapes || !lsi || !proj || !ref || !grad_out || !grad_proj)
+    return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
+  const SlabPlan plan = slab_plan(S, L, P, shapes_host);
+  const int nchunk = plan.ok ? bwd_chunks(B, M, Q, S, plan.rowsV) : 0;
+  if (nchunk <= 0) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: problem does not fit LDS");
+  return run_bwd_t1d<VT, true>(value, shapes, lsi, proj, ref, grad_out, B, S, M, L, Q, P, RD, pad_mode, plan, nchunk,
+                               grad_value, grad_proj, grad_ref, workspace, workspace_bytes, st);
 }
 
 }  // namespace
@@ -918,8 +1014,8 @@ int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity
       if (meta_b) meta_b[n] = e.b;
       ++n;
     }
-    hipEventDestroy(e.start);
-    hipEventDestroy(e.stop);
+    (void)hipEventDestroy(e.start);
+    (void)hipEventDestroy(e.stop);
   }
   p.entries.clear();
   return n;
@@ -948,11 +1044,12 @@ int gvl_msda_sample_f64(const double *value, const int64_t *shapes, const int64_
 
 size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P, int elem_bytes,
                                          const int64_t *shapes_host) {
-  if (elem_bytes != 4 || D != 64 || L * P > 16 || S <= 0) return 0;
+  // elem_bytes = storage size of value / grad_value: 4 (fp32), 2 (bf16); 8 (fp64) never needs a workspace
+  if ((elem_bytes != 4 && elem_bytes != 2) || D != 64 || L * P > 16 || S <= 0) return 0;
   const SlabPlan plan = slab_plan(S, L, P, shapes_host);
   if (!plan.ok) return 0;
   const int n = bwd_chunks(B, M, Q, S, plan.rowsV);
-  return n > 1 ? (size_t)n * B * S * M * D * sizeof(float) : 0;
+  return n > 0 ? bwd_workspace_bytes(B, S, M, n, elem_bytes == 2) : 0;
 }
 
 int gvl_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
@@ -972,37 +1069,19 @@ int gvl_msda_backward_f64(const double *value, const int64_t *shapes, const int6
                                (hipStream_t)stream);
 }
 
-// ---- fused module path: MSDeformAttn.forward between the projection GEMM and output_proj (ms_deform_attn.py:99-124)
-static int fused_eligible(int B, int S, int M, int D, int L, int Q, int P, int RD, int pad, const int64_t *shapes_host,
-                          const int64_t *lsi_host) {
-  if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
-  if (D != 64 || L * P != 16 || P != 4 || (RD != 1 && RD != 2) || S <= 0)
-    return fail(GVL_EINVAL, "gvl_msda1d_fused: needs D=64, L*P=16, P=4, RD in {1,2} (got D=%d L=%d P=%d RD=%d)", D, L, P,
-                RD);
-  if (!temporal_host(shapes_host, lsi_host, L, S))
-    return fail(GVL_EINVAL, "gvl_msda1d_fused: needs host copies of temporal (H=1) level shapes");
-  return 0;
-}
-
 int gvl_msda1d_fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
                                  const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
                                  int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
                                  void *stream) {
-  if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
-  if ((int64_t)B * Q == 0) return 0;
-  if (!value || !shapes || !lsi || !proj || !ref || !out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: null pointer");
-  const SlabPlan plan = slab_plan(S, L, P, shapes_host);
-  if (!plan.ok) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: slab of %d rows does not fit LDS", S);
-  const size_t lds = (size_t)plan.rowsV * 64 * sizeof(float);
-  const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
-  const int nchunk = pick_chunks("GVL_MSDA_FWD_CHUNKS", B * M, Q, 256);
-  auto kern = pad_mode == kPadZeros
-                  ? (plan.l0g ? k_fwd_t1d_d64<kPadZeros, true, true, true> : k_fwd_t1d_d64<kPadZeros, true, true, false>)
-                  : (plan.l0g ? k_fwd_t1d_d64<kPadBorder, true, true, true> : k_fwd_t1d_d64<kPadBorder, true, true, false>);
-  if (int rc = ensure_lds(kern, lds)) return rc;
-  g_last_impl = 3;
-  return gvl::launch(GVL_PROF_FWD_T1D, Q, B, "k_fwd_t1d_d64<fused>", kern, dim3(nchunk * B * M), dim3(threads), lds,
-                     (hipStream_t)stream, value, shapes, lsi, proj, ref, B, S, M, L, Q, P, RD, nchunk, out);
+  return fused_forward<float>(value, shapes, lsi, proj, ref, B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host,
+                              out, stream);
+}
+int gvl_msda1d_fused_forward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                                  const uint16_t *proj, const float *ref, int B, int S, int M, int D, int L, int Q,
+                                  int P, int RD, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
+                                  uint16_t *out, void *stream) {
+  return fused_forward<bf16_t>((const bf16_t *)value, shapes, lsi, (const bf16_t *)proj, ref, B, S, M, D, L, Q, P, RD,
+                               pad_mode, shapes_host, lsi_host, (bf16_t *)out, stream);
 }
 
 size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P,
@@ -1015,45 +1094,61 @@ int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, con
                                   int P, int RD, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
                                   float *grad_value, float *grad_proj, float *grad_ref, void *workspace,
                                   size_t workspace_bytes, void *stream) {
-  if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  const size_t gv_bytes = (size_t)B * S * M * D * sizeof(float);
-  if (gv_bytes && !grad_value) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
-  if ((int64_t)B * Q == 0) {
-    return gvl::zero_fill(grad_value, gv_bytes, st);
-  }
-  if (!value || !shapes || !lsi || !proj || !ref || !grad_out || !grad_proj)
-    return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: null pointer");
-  const SlabPlan plan = slab_plan(S, L, P, shapes_host);
-  const int nchunk = plan.ok ? bwd_chunks(B, M, Q, S, plan.rowsV) : 0;
-  if (nchunk <= 0) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: problem does not fit LDS");
-  const int qper = (Q + nchunk - 1) / nchunk;
-  const size_t lds = bwd_lds_bytes(S, qper, plan.rowsV);
-  float *part = grad_value;
-  if (nchunk > 1) {
-    if (!workspace || workspace_bytes < gv_bytes * nchunk)
-      return fail(GVL_ENOSPC, "gvl_msda1d_fused_backward: workspace %zu < required %zu bytes", workspace_bytes,
-                  gv_bytes * nchunk);
-    part = (float *)workspace;
-  }
-  auto kern = pad_mode == kPadZeros
-                  ? (plan.l0g ? k_bwd_t1d_d64<kPadZeros, true, true, true> : k_bwd_t1d_d64<kPadZeros, true, true, false>)
-                  : (plan.l0g ? k_bwd_t1d_d64<kPadBorder, true, true, true> : k_bwd_t1d_d64<kPadBorder, true, true, false>);
-  if (int rc = ensure_lds(kern, lds)) return rc;
-  if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, "k_bwd_t1d_d64<fused>", kern, dim3(nchunk * B * M), dim3(kBwdThreads),
-                           lds, st, value, shapes, lsi, proj, ref, grad_out, B, S, M, L, Q, P, RD, nchunk, qper, part,
-                           grad_proj, grad_ref))
-    return rc;
-  if (nchunk > 1) {
-    const int64_t count4 = (int64_t)B * S * M * 16;
-    int64_t blocks = (count4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (int rc = gvl::launch(GVL_PROF_SUM_PARTIALS, Q, B, "k_sum_partials", k_sum_partials, dim3((unsigned)blocks),
-                             dim3(256), 0, st, (const float4 *)part, nchunk, count4, (float4 *)grad_value))
-      return rc;
-  }
-  g_last_impl = 3;
+  return fused_backward<float>(value, shapes, lsi, proj, ref, grad_out, B, S, M, D, L, Q, P, RD, pad_mode, shapes_host,
+                               lsi_host, grad_value, grad_proj, grad_ref, workspace, workspace_bytes, stream);
+}
+int gvl_msda1d_fused_backward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                                   const uint16_t *proj, const float *ref, const uint16_t *grad_out, int B, int S,
+                                   int M, int D, int L, int Q, int P, int RD, int pad_mode,
+                                   const int64_t *shapes_host, const int64_t *lsi_host, uint16_t *grad_value,
+                                   uint16_t *grad_proj, float *grad_ref, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
+  return fused_backward<bf16_t>((const bf16_t *)value, shapes, lsi, (const bf16_t *)proj, ref,
+                                (const bf16_t *)grad_out, B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host,
+                                (bf16_t *)grad_value, (bf16_t *)grad_proj, grad_ref, workspace, workspace_bytes,
+                                stream);
+}
+
+// ---- bf16 storage twins of the op (fp32 arithmetic; loc / attn and their gradients stay fp32).  Served by the
+// t1d_d64 kernels only: other shapes return GVL_EINVAL and the caller widens to the f32 entry points.
+static int bf16_plan(const char *what, int B, int S, int M, int D, int L, int Q, int P, int pad,
+                     const int64_t *shapes_host, const int64_t *lsi_host, SlabPlan &plan) {
+  if (int rc = check_dims(B, S, M, D, L, Q, P, pad)) return rc;
+  if (D != 64 || L * P > 16 || S <= 0 || !temporal_host(shapes_host, lsi_host, L, S))
+    return fail(GVL_EINVAL, "%s: bf16 storage needs temporal (H=1) levels with host shapes, D=64, L*P<=16", what);
+  plan = slab_plan(S, L, P, shapes_host);
+  if (!plan.ok) return fail(GVL_EINVAL, "%s: slab of %d rows does not fit LDS", what, S);
   return 0;
+}
+
+int gvl_msda_forward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                          const float *attn, int B, int S, int M, int D, int L, int Q, int P, int pad_mode,
+                          const int64_t *shapes_host, const int64_t *lsi_host, uint16_t *out, void *stream) {
+  SlabPlan plan;
+  if (int rc = bf16_plan("gvl_msda_forward_bf16", B, S, M, D, L, Q, P, pad_mode, shapes_host, lsi_host, plan)) return rc;
+  if ((int64_t)B * Q == 0) return 0;
+  if (!value || !shapes || !lsi || !loc || !attn || !out) return fail(GVL_EINVAL, "gvl_msda_forward_bf16: null pointer");
+  return run_fwd_t1d<bf16_t, false>((const bf16_t *)value, shapes, lsi, loc, attn, B, S, M, L, Q, P, 0, pad_mode, plan,
+                                    (bf16_t *)out, (hipStream_t)stream);
+}
+
+int gvl_msda_backward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                           const float *attn, const uint16_t *grad_out, int B, int S, int M, int D, int L, int Q, int P,
+                           int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, uint16_t *grad_value,
+                           float *grad_loc, float *grad_attn, void *workspace, size_t workspace_bytes, void *stream) {
+  SlabPlan plan;
+  if (int rc = bf16_plan("gvl_msda_backward_bf16", B, S, M, D, L, Q, P, pad_mode, shapes_host, lsi_host, plan)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t gv_bytes = (size_t)B * S * M * D * sizeof(uint16_t);
+  if (gv_bytes && !grad_value) return fail(GVL_EINVAL, "gvl_msda_backward_bf16: null pointer");
+  if ((int64_t)B * Q == 0) return gvl::zero_fill(grad_value, gv_bytes, st);
+  if (!value || !shapes || !lsi || !loc || !attn || !grad_out || !grad_loc || !grad_attn)
+    return fail(GVL_EINVAL, "gvl_msda_backward_bf16: null pointer");
+  const int nchunk = bwd_chunks(B, M, Q, S, plan.rowsV);
+  if (nchunk <= 0) return fail(GVL_EINVAL, "gvl_msda_backward_bf16: problem does not fit LDS");
+  return run_bwd_t1d<bf16_t, false>((const bf16_t *)value, shapes, lsi, loc, attn, (const bf16_t *)grad_out, B, S, M, L,
+                                    Q, P, 0, pad_mode, plan, nchunk, (bf16_t *)grad_value, grad_loc, grad_attn,
+                                    workspace, workspace_bytes, st);
 }
 
 }  // extern "C"

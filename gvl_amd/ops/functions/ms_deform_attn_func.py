@@ -10,7 +10,21 @@ PyTorch fallback here: without libgvl_msda.so or a ROCm device the call raises.
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+import torch
+
 from ... import MultiScaleDeformableAttention as MSDA
+
+
+def _arith(value, *tensors):
+    """bf16 autocast: value may arrive in bf16 (a Linear output) while locations / weights are kept -- or brought back
+    to -- fp32 (bf16 is a storage type for the op, see include/gvl_msda.h "Element types")."""
+    if value.dtype != torch.bfloat16:
+        return tensors
+    return tuple(t_ if t_.dtype == torch.float32 else t_.float() for t_ in tensors)
+
+
+def _like(grad, dtype):
+    return grad if grad is None or grad.dtype == dtype else grad.to(dtype)
 
 
 class MSDeformAttnPadFunction(Function):
@@ -20,6 +34,8 @@ class MSDeformAttnPadFunction(Function):
         ctx.im2col_step = im2col_step
         ctx.pad_mode = pad_mode
         ctx.host = MSDA.host_shapes(value_spatial_shapes, value_level_start_index)
+        ctx.in_dtypes = (sampling_locations.dtype, attention_weights.dtype)
+        sampling_locations, attention_weights = _arith(value, sampling_locations, attention_weights)
         output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                              sampling_locations, attention_weights, im2col_step, pad_mode)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -32,9 +48,10 @@ class MSDeformAttnPadFunction(Function):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
         if getattr(shapes, "_gvl_host", None) is None:
             shapes._gvl_host = ctx.host
-        gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, grad_output.contiguous(),
-                                                  ctx.im2col_step, ctx.pad_mode)
-        return gv, None, None, gl, ga, None, None
+        gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn,
+                                                  _like(grad_output, value.dtype).contiguous(), ctx.im2col_step,
+                                                  ctx.pad_mode)
+        return gv, None, None, _like(gl, ctx.in_dtypes[0]), _like(ga, ctx.in_dtypes[1]), None, None
 
 
 class MSDeformAttnFunction(Function):
@@ -45,6 +62,8 @@ class MSDeformAttnFunction(Function):
                 im2col_step):
         ctx.im2col_step = im2col_step
         ctx.host = MSDA.host_shapes(value_spatial_shapes, value_level_start_index)
+        ctx.in_dtypes = (sampling_locations.dtype, attention_weights.dtype)
+        sampling_locations, attention_weights = _arith(value, sampling_locations, attention_weights)
         output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                              sampling_locations, attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -58,8 +77,9 @@ class MSDeformAttnFunction(Function):
         if getattr(shapes, "_gvl_host", None) is None:
             shapes._gvl_host = ctx.host
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
-            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step)
-        return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+            value, shapes, lsi, loc, attn, _like(grad_output, value.dtype).contiguous(), ctx.im2col_step)
+        return (grad_value, None, None, _like(grad_sampling_loc, ctx.in_dtypes[0]),
+                _like(grad_attn_weight, ctx.in_dtypes[1]), None)
 
 
 class MSDASampleFunction(Function):
@@ -70,17 +90,21 @@ class MSDASampleFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, pad_mode):
         ctx.pad_mode = pad_mode
         ctx.host = MSDA.host_shapes(value_spatial_shapes, value_level_start_index)
+        ctx.in_dtypes = (value.dtype, sampling_locations.dtype)
+        if value.dtype == torch.bfloat16:            # D = 512 sampler: widened (fp32 arithmetic), rounded once
+            value, sampling_locations = value.float(), sampling_locations.float()
         out = MSDA.ms_deform_attn_sample(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                                          pad_mode)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations)
-        return out
+        return _like(out, ctx.in_dtypes[0])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_sample):
         value, shapes, lsi, loc = ctx.saved_tensors
-        gv, gl = MSDA.ms_deform_attn_sample_backward(value, shapes, lsi, loc, grad_sample.contiguous(), ctx.pad_mode)
-        return gv, None, None, gl, None
+        gv, gl = MSDA.ms_deform_attn_sample_backward(value, shapes, lsi, loc,
+                                                     _like(grad_sample, value.dtype).contiguous(), ctx.pad_mode)
+        return _like(gv, ctx.in_dtypes[0]), None, None, _like(gl, ctx.in_dtypes[1]), None
 
 
 class MSDeformAttnFusedFunction(Function):
@@ -92,6 +116,9 @@ class MSDeformAttnFusedFunction(Function):
     def forward(ctx, value, proj, reference_points, spatial_shapes, level_start_index, n_levels, n_points, pad_mode):
         ctx.cfg = (n_levels, n_points, pad_mode)
         ctx.host = MSDA.host_shapes(spatial_shapes, level_start_index)
+        ctx.in_dtypes = (proj.dtype, reference_points.dtype)
+        proj = _like(proj, value.dtype)                              # bf16 value <-> bf16 projection rows
+        reference_points = _like(reference_points, torch.float32)    # positions are never rounded to bf16
         out = MSDA.msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, reference_points, n_levels,
                                         n_points, pad_mode)
         ctx.save_for_backward(value, proj, reference_points, spatial_shapes, level_start_index)
@@ -104,9 +131,10 @@ class MSDeformAttnFusedFunction(Function):
         if getattr(shapes, "_gvl_host", None) is None:
             shapes._gvl_host = ctx.host
         n_levels, n_points, pad_mode = ctx.cfg
-        gv, gp, gr = MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref, grad_output.contiguous(), n_levels,
-                                                n_points, pad_mode, need_ref_grad=ctx.needs_input_grad[2])
-        return gv, gp, gr, None, None, None, None, None
+        gv, gp, gr = MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref,
+                                                _like(grad_output, value.dtype).contiguous(), n_levels, n_points,
+                                                pad_mode, need_ref_grad=ctx.needs_input_grad[2])
+        return gv, _like(gp, ctx.in_dtypes[0]), _like(gr, ctx.in_dtypes[1]), None, None, None, None, None
 
 
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights, return_value=False):

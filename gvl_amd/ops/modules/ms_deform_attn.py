@@ -105,7 +105,7 @@ class MSDeformAttn(nn.Module):
 
     def _fused_eligible(self, query, input_flatten, host_lengths):
         """domain of the fused HIP path (include/gvl_msda.h: gvl_msda1d_fused_*)"""
-        return (self.fused and host_lengths is not None and query.dtype == torch.float32
+        return (self.fused and host_lengths is not None and query.dtype in (torch.float32, torch.bfloat16)
                 and self.d_model // self.n_heads == 64 and self.n_levels * self.n_points == 16 and self.n_points == 4
                 and (input_flatten.shape[1] <= 600 or input_flatten.shape[1] - host_lengths[0][0] <= 600))
 

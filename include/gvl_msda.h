@@ -30,6 +30,13 @@
  * S = 639; beyond that -- long videos, T = 512 -> S = 960 -- level 0 is read from global memory and levels 1.. are
  * staged, which needs L*P == 16 and P == 4); otherwise the generic kernels (any D, any HxW, fp32/fp64) run.
  * Results are identical up to fp32 summation order.
+ *
+ * Element types: _f32 / _f64 entry points compute in the named type throughout.  _bf16 entry points (SURVEY.md
+ * section 8(b) "bf16 twins"; BASELINE config 4, long videos under bf16 autocast) keep value / out / grad_out /
+ * grad_value -- and, fused, proj / grad_proj -- as bfloat16 in HBM (passed as uint16_t bit patterns), while every
+ * sampling location, reference point, attention weight, their gradients and ALL arithmetic stay fp32 (a bf16
+ * location would quantise x*T_l to whole frames at T = 512); results are rounded to nearest-even once, on the
+ * final store.  They are served by the temporal D = 64 kernels only and return GVL_EINVAL for other shapes.
  */
 #ifndef GVL_MSDA_H
 #define GVL_MSDA_H
@@ -41,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 1
+#define GVL_MSDA_ABI_VERSION 2   /* 2: bf16 storage twins added (all version-1 entry points unchanged) */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -115,6 +122,17 @@ int gvl_msda_backward_f64(const double *value, const int64_t *shapes, const int6
                           double *grad_value, double *grad_loc, double *grad_attn, void *workspace,
                           size_t workspace_bytes, void *stream);
 
+/* -- bf16 storage twins of the two calls above (same reference interfaces; arithmetic fp32, see "Element types").
+ *    Workspace: gvl_msda_backward_workspace_bytes(..., elem_bytes = 2, ...) -- never 0 for bf16 (the gather writes
+ *    fp32 slabs that a second kernel sums and rounds once). */
+int gvl_msda_forward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                          const float *attn, int B, int S, int M, int D, int L, int Q, int P, int pad_mode,
+                          const int64_t *shapes_host, const int64_t *lsi_host, uint16_t *out, void *stream);
+int gvl_msda_backward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                           const float *attn, const uint16_t *grad_out, int B, int S, int M, int D, int L, int Q, int P,
+                           int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, uint16_t *grad_value,
+                           float *grad_loc, float *grad_attn, void *workspace, size_t workspace_bytes, void *stream);
+
 /* -- fused module path (temporal levels, fp32, D = 64, L*P = 16, P = 4): everything MSDeformAttn.forward does between
  *    its projection GEMM and output_proj (pdvc/ops/modules/ms_deform_attn.py:99-124) in one launch, so that the
  *    sampling locations and attention weights never exist in HBM.
@@ -138,6 +156,18 @@ int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, con
                                   int P, int RD, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
                                   float *grad_value, float *grad_proj, float *grad_ref, void *workspace,
                                   size_t workspace_bytes, void *stream);
+/*    bf16 storage: value, proj, out, grad_out, grad_value, grad_proj are bfloat16; ref / grad_ref fp32.  Workspace:
+ *    gvl_msda_backward_workspace_bytes(..., elem_bytes = 2, ...). */
+int gvl_msda1d_fused_forward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                                  const uint16_t *proj, const float *ref, int B, int S, int M, int D, int L, int Q,
+                                  int P, int RD, int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host,
+                                  uint16_t *out, void *stream);
+int gvl_msda1d_fused_backward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                                   const uint16_t *proj, const float *ref, const uint16_t *grad_out, int B, int S,
+                                   int M, int D, int L, int Q, int P, int RD, int pad_mode,
+                                   const int64_t *shapes_host, const int64_t *lsi_host, uint16_t *grad_value,
+                                   uint16_t *grad_proj, float *grad_ref, void *workspace, size_t workspace_bytes,
+                                   void *stream);
 
 /* -- backward of gvl_msda_sample: autograd of ms_deform_attn_core_pytorch(return_value=True) (func.py:44-68; the
  *    reference differentiates through F.grid_sample).  grad_sample (B*M, D, Q, L, P) -> grad_value (B,S,M,D)

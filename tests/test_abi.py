@@ -32,7 +32,8 @@ def test_header_symbols_all_exported(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/gvl_msda.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "python binding table out of sync with the header"
-    assert lib.gvl_msda_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "gvl_msda.h")).read()
+    assert lib.gvl_msda_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define GVL_MSDA_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_argument_errors_do_not_touch_the_gpu(lib):
@@ -44,6 +45,11 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert rc == -1 and b"pad_mode" in lib.gvl_last_error()
     assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 64, 4, 300, 4, 4, None) % (16 * 188 * 8 * 64 * 4) == 0
     assert lib.gvl_msda_backward_workspace_bytes(16, 188, 8, 30, 4, 300, 4, 8, None) == 0
+    # bf16 storage always needs the fp32 slab workspace, also when one workgroup owns a slab (B*M >= 256)
+    assert lib.gvl_msda_backward_workspace_bytes(32, 188, 8, 64, 4, 300, 4, 4, None) == 0
+    assert lib.gvl_msda_backward_workspace_bytes(32, 188, 8, 64, 4, 300, 4, 2, None) == 32 * 188 * 8 * 64 * 4
+    rc = lib.gvl_msda_forward_bf16(None, None, None, None, None, 1, 4, 1, 32, 1, 1, 1, 0, None, None, None, None)
+    assert rc == -1 and b"bf16 storage needs" in lib.gvl_last_error()
 
 
 def _solve(lib, C):

@@ -1,0 +1,177 @@
+"""bf16 STORAGE twins of the op (include/gvl_msda.h "Element types"; BASELINE.json config 4: long videos under bf16).
+
+Contract under test: value / out / grad_out / grad_value (and, fused, proj / grad_proj) live in HBM as bfloat16;
+locations, weights, reference points, their gradients and all arithmetic are fp32; one round-to-nearest-even on the
+final store.  Hence, on inputs that are already bf16-representable,
+    bf16 entry point  ==  round_bf16( fp32 entry point )          bit for bit,
+and the fp32 entry points are the ones pinned to the reference goldens / the CPU oracle (test_gpu_op.py).  The CPU
+oracle is also applied directly: |out - oracle(rounded inputs)| <= 2^-8 * max|oracle| (half a bf16 ulp at the top of
+the range, the tolerance of this storage type)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import t, maxerr
+from test_gpu_op import make_inputs, set_impl, last_impl, scale
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def MSDA():
+    from gvl_amd import MultiScaleDeformableAttention as m, _lib
+    _lib.lib()
+    return m
+
+
+CASES = [
+    # name, B, T, M, Q, P
+    ("cfgA_dec", 16, 100, 8, 300, 4),
+    ("cfgA_enc", 16, 100, 8, 188, 4),
+    ("cfgL_dec_level0_in_global", 2, 512, 8, 77, 4),
+    ("one_wg_per_slab", 32, 100, 8, 40, 4),        # B*M = 256 -> nchunk = 1: bf16 still goes through the fp32 slab
+    ("ragged_lp12", 3, 37, 5, 23, 3),
+]
+
+
+@pytest.mark.parametrize("name,B,T,M,Q,P", CASES)
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_bf16_storage_equals_rounded_fp32_and_oracle(name, B, T, M, Q, P, pad, dev, MSDA):
+    from oracle import msda_oracle as O
+    value, shapes, lsi, loc, aw, gout = make_inputs(B, T, M, 64, Q, P, seed=len(name) + T)
+    v_bf = t(value).to(dev).to(BF)
+    g_bf = t(gout).to(dev).to(BF)
+    sh, ls, lc, w = (t(x).to(dev) for x in (shapes, lsi, loc, aw))
+    out = MSDA.ms_deform_attn_forward(v_bf, sh, ls, lc, w, 64, pad_mode=pad)
+    assert out.dtype == BF and last_impl() == "fast"
+    out32 = MSDA.ms_deform_attn_forward(v_bf.float(), sh, ls, lc, w, 64, pad_mode=pad)
+    assert torch.equal(out, out32.to(BF))
+    v_r, g_r = v_bf.float().cpu().numpy(), g_bf.float().cpu().numpy()
+    ref = O.msda_forward(v_r, shapes, lsi, loc, aw, pad)
+    assert maxerr(out.float(), ref) <= 2.0 ** -8 * scale(ref)
+
+    gv, gl, gw = MSDA.ms_deform_attn_backward(v_bf, sh, ls, lc, w, g_bf, 64, pad_mode=pad)
+    assert gv.dtype == BF and gl.dtype == torch.float32 and gw.dtype == torch.float32 and last_impl() == "fast"
+    gv32, gl32, gw32 = MSDA.ms_deform_attn_backward(v_bf.float(), sh, ls, lc, w, g_bf.float(), 64, pad_mode=pad)
+    # grad_value: same fp32 gather, but the order of one slab row's entries may differ between two kernel
+    # instantiations -> equal before rounding up to fp32 summation order, i.e. within one bf16 ulp
+    assert maxerr(gv.float(), gv32) <= 2.0 ** -8 * scale(gv32.cpu().numpy())
+    assert float((gv != gv32.to(BF)).float().mean()) < 2e-3
+    assert torch.equal(gl, gl32) and torch.equal(gw, gw32)
+    rv, rl, rw = O.msda_backward(v_r, shapes, lsi, loc, aw, g_r, pad)
+    assert maxerr(gv.float(), rv) <= 2.0 ** -8 * scale(rv)
+    assert maxerr(gl, rl) <= 1e-4 * scale(rl)
+    assert maxerr(gw, rw) <= 1e-4 * scale(rw)
+
+
+@pytest.mark.parametrize("T,Q,RD", [(100, 300, 1), (100, 188, 2), (512, 100, 2)])
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_bf16_fused_equals_rounded_fp32(T, Q, RD, pad, dev, MSDA):
+    B, M, L, P = 4, 8, 4, 4
+    value, shapes, lsi, _, _, gout = make_inputs(B, T, M, 64, Q, P, seed=T + Q)
+    g = torch.Generator().manual_seed(T * 7 + RD)
+    proj = torch.randn(B, Q, 2 * M * L * P, generator=g)
+    proj[..., :M * L * P] *= 3.0
+    ref = torch.rand(B, Q, L, RD, generator=g)
+    if RD == 2:
+        ref[..., 1] = ref[..., 1] * 0.3 + 0.02
+    v_bf, p_bf, g_bf = (x.to(dev).to(BF) for x in (t(value), proj, t(gout)))
+    sh, ls, ref = t(shapes).to(dev), t(lsi).to(dev), ref.to(dev)
+    out = MSDA.msda1d_fused_forward(v_bf, sh, ls, p_bf, ref, L, P, pad)
+    out32 = MSDA.msda1d_fused_forward(v_bf.float(), sh, ls, p_bf.float(), ref, L, P, pad)
+    assert out.dtype == BF and torch.equal(out, out32.to(BF))
+    gv, gp, gr = MSDA.msda1d_fused_backward(v_bf, sh, ls, p_bf, ref, g_bf, L, P, pad, need_ref_grad=True)
+    gv32, gp32, gr32 = MSDA.msda1d_fused_backward(v_bf.float(), sh, ls, p_bf.float(), ref, g_bf.float(), L, P, pad,
+                                                  need_ref_grad=True)
+    assert gv.dtype == BF and gp.dtype == BF and gr.dtype == torch.float32
+    assert maxerr(gv.float(), gv32) <= 2.0 ** -8 * scale(gv32.cpu().numpy())
+    assert torch.equal(gp, gp32.to(BF)) and torch.equal(gr, gr32)
+
+
+def test_bf16_shapes_outside_the_temporal_kernels_are_widened(dev, MSDA):
+    """2-D levels / D != 64: the bf16 C entry points return GVL_EINVAL; the shim widens to the fp32 kernels (same
+    arithmetic, one rounding) instead of failing or leaving the GPU."""
+    from gvl_amd import _lib
+    value, shapes, lsi, loc, aw, gout = make_inputs(2, 0, 4, 32, 19, 4, seed=5, shapes2d=[(6, 4), (3, 2)])
+    v_bf, g_bf = t(value).to(dev).to(BF), t(gout).to(dev).to(BF)
+    sh, ls, lc, w = (t(x).to(dev) for x in (shapes, lsi, loc, aw))
+    rc = _lib.lib().gvl_msda_forward_bf16(v_bf.data_ptr(), sh.data_ptr(), ls.data_ptr(), lc.data_ptr(), w.data_ptr(),
+                                          2, 30, 4, 32, 2, 19, 4, 0, None, None, v_bf.data_ptr(), None)
+    assert rc == -1 and b"bf16 storage needs" in _lib.lib().gvl_last_error()
+    out = MSDA.ms_deform_attn_forward(v_bf, sh, ls, lc, w, 64)
+    assert out.dtype == BF and last_impl() == "generic"
+    assert torch.equal(out, MSDA.ms_deform_attn_forward(v_bf.float(), sh, ls, lc, w, 64).to(BF))
+    gv, gl, gw = MSDA.ms_deform_attn_backward(v_bf, sh, ls, lc, w, g_bf, 64)
+    assert gv.dtype == BF and gl.dtype == torch.float32
+    # generic backward accumulates with float atomics: order-dependent in the last fp32 bits -> compare before rounding
+    gv32, gl32, gw32 = MSDA.ms_deform_attn_backward(v_bf.float(), sh, ls, lc, w, g_bf.float(), 64)
+    assert maxerr(gv.float(), gv32) <= 2.0 ** -8 * scale(gv32.cpu().numpy())
+    assert maxerr(gl, gl32) <= 1e-4 * scale(gl32.cpu().numpy())
+
+
+@pytest.mark.parametrize("ref_dim", [1, 2])
+@pytest.mark.parametrize("fused", [True, False])
+def test_module_under_bf16_autocast(ref_dim, fused, dev):
+    """MSDeformAttn under torch.autocast(bfloat16): Linear layers in bf16 on MFMA, the op on bf16 storage with fp32
+    locations.  Against the same module in fp32: output within bf16 resolution of its scale; gradients that flow
+    through the value / output projections within 5 % of their norm.  Gradients that flow through the sampling
+    LOCATIONS (query, sampling_offsets) are piecewise constant in the location (d sample / d x jumps at every frame
+    boundary), so rounding the offsets to bf16 flips the interval of ~1-2 % of the samples and moves those gradients
+    by ~10 % in norm for ANY bf16 implementation (the unfused torch-op path shows the same figure): checked by
+    direction (cosine > 0.98) and norm (within 25 %)."""
+    from gvl_amd.ops.modules import MSDeformAttn
+    from helpers import level_lengths
+    torch.manual_seed(3)
+    T, B, Q = 100, 3, 41
+    lens = level_lengths(T)
+    S = sum(lens)
+    m = MSDeformAttn(512, 4, 8, 4).to(dev)
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.02)
+        m.attention_weights.weight.normal_(0, 0.05)
+    m.fused = fused
+    shapes = torch.tensor(lens, device=dev)
+    starts = [0] + [int(x) for x in np.cumsum(lens)[:-1]]
+    shapes._gvl_host_lengths = (tuple(lens), tuple(starts))
+    lsi = torch.tensor(starts, device=dev)
+    query = torch.randn(B, Q, 512, device=dev)
+    src = torch.randn(B, S, 512, device=dev)
+    ref = torch.rand(B, Q, 4, ref_dim, device=dev)
+    if ref_dim == 2:
+        ref[..., 1] = ref[..., 1] * 0.3 + 0.02
+    mask = torch.zeros(B, S, dtype=torch.bool, device=dev)
+    mask[1, 90:100] = True
+    gout = torch.randn(B, Q, 512, device=dev)
+
+    def run(autocast):
+        m.zero_grad()
+        q_ = query.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=BF, enabled=autocast):
+            out = m(q_, ref, src, shapes, lsi, mask)
+        out.float().backward(gout)
+        return out.float().detach(), q_.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    o32, gq32, gp32 = run(False)
+    o16, gq16, gp16 = run(True)
+    assert float((o16 - o32).abs().max()) <= 3e-2 * float(o32.abs().max())
+    def rel(a, b):
+        return float((a - b).norm()) / (float(b.norm()) + 1e-12)
+
+    def cos(a, b):
+        return float((a * b).sum()) / (float(a.norm()) * float(b.norm()) + 1e-12)
+
+    errs = {k: (rel(gp16[k], gp32[k]), cos(gp16[k], gp32[k])) for k in gp32}
+    errs["query"] = (rel(gq16, gq32), cos(gq16, gq32))
+    for k, (r, c) in errs.items():
+        if k.startswith(("value_proj", "output_proj")):
+            assert r <= 5e-2, (k, r)
+        else:
+            assert r <= 0.25 and c >= 0.98, (k, r, c)
