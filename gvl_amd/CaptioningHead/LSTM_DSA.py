@@ -149,6 +149,25 @@ class ShowAttendTellCore(nn.Module):
         return out, (h[None], c[None])
 
 
+def _fp32_island(fn):
+    """Mixed-precision policy of gvl_amd under torch.autocast(bfloat16) (BASELINE config 4): the transformer runs its
+    GEMMs / deformable attention on bf16 storage, the recurrent captioner stays fp32 -- its token-step kernels
+    (gvl_cap_attend_f32, gvl_lstm_cell_f32, gvl_row_argmax_lse_f32) are fp32, the recurrence feeds its own rounding
+    back 30 times, and greedy argmax over ~8.5k logits flips on bf16 near-ties.  Inputs arriving in bf16 are widened."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, hs, reference, others, *args, **kwargs):
+        if not torch.is_autocast_enabled():
+            return fn(self, hs, reference, others, *args, **kwargs)
+        others = dict(others)
+        for k in ("memory", "valid_ratios"):
+            others[k] = others[k].float()
+        with torch.autocast("cuda", enabled=False):
+            return fn(self, hs.float(), reference.float(), others, *args, **kwargs)
+    return wrapped
+
+
 class Captioner(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -202,6 +221,7 @@ class Captioner(nn.Module):
                                   input_level_start_index, mask)
         return F.log_softmax(self.logit(self.dropout(output)), dim=1), state
 
+    @_fp32_island
     def forward(self, hs, reference, others, cap_tensor, steps=None):
         """Teacher-forced log-probs (LSTM_DSA.py:63-117) -> (B*Q, steps, vocab+1)."""
         seq = cap_tensor.long()
@@ -302,6 +322,7 @@ class Captioner(nn.Module):
         graph.replay()
         return outs
 
+    @_fp32_island
     def sample(self, hs, reference, others, opt={}):
         """Greedy / multinomial decoding (LSTM_DSA.py:126-194) -> (seq (B*Q, <=max_len), logprobs)."""
         sample_max = opt.get('sample_max', 1)
