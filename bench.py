@@ -50,9 +50,10 @@ def synth_batch(B, T, feat, vocab, n_gt, device, seed=1):
             "gt_boxes_mask": torch.ones(B, n_gt, dtype=torch.bool, device=device)}
 
 
-def msda_bytes(B, S, Q, M=8, L=4, P=4, C=512):
-    """algorithmic bytes of one forward launch: value + loc(2) + weight + output, fp32"""
-    return 4 * B * (S * C + 3 * Q * M * L * P + Q * C)
+def msda_bytes(B, S, Q, M=8, L=4, P=4, C=512, value_bytes=4):
+    """algorithmic bytes of one forward launch: value + loc(2) + weight + output; fp32, or
+    bf16 value / output with fp32 locations and weights ("bf16 value/out halves the C terms")"""
+    return B * (value_bytes * S * C + 4 * 3 * Q * M * L * P + value_bytes * Q * C)
 
 
 def kernel_times(entries):
@@ -135,6 +136,10 @@ def main():
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--queries", type=int, default=300)
     ap.add_argument("--batch", type=int, default=16, help="videos per GPU")
+    ap.add_argument("--cfg", default="anet_tsp_ssvg", help="gvl_amd.config.CONFIGS entry (BASELINE config 4: "
+                    "--cfg yc2_tsn_dvc --T 512 --queries 100 --dtype bf16)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = torch.autocast(bfloat16): bf16 GEMMs + bf16-storage deformable attention, fp32 captioner")
     ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the caption decoding loop from a hipGraph")
@@ -158,7 +163,7 @@ def main():
     from gvl_amd.pdvc import build
     from gvl_amd.tuning import enable_tuned_gemms
     tuned = (not a.no_tuned_gemm) and enable_tuned_gemms()
-    opt = make_opt("anet_tsp_ssvg", num_queries=a.queries, frame_embedding_num=a.T,
+    opt = make_opt(a.cfg, num_queries=a.queries, frame_embedding_num=a.T,
                    eval_disable_captioning=bool(a.no_captioner), device="cuda")
     torch.manual_seed(0)
     model, criterion, _, _ = build(opt)
@@ -174,7 +179,7 @@ def main():
             head.graph_decode = not a.no_graph
 
         def step():
-            with torch.no_grad():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
                 return model(dt, criterion, None, "queries", eval_mode=True)
     else:
         from gvl_amd.parallel import GraphedTrainStep, TrainStep
@@ -184,6 +189,8 @@ def main():
         use_graph = not a.no_graph and (world == 1 or os.environ.get("GVL_GRAPH_DP") == "1")
         a.no_graph = not use_graph
         trainer = (GraphedTrainStep if use_graph else TrainStep)(model, criterion, opt, world_size=world)
+        if a.dtype == "bf16":
+            raise SystemExit("--dtype bf16 is wired for the eval forward; the train step is measured in fp32")
 
         def step():
             return trainer(dt)
@@ -235,11 +242,12 @@ def main():
     dec_key = next((k for k in fwd if k[1] == a.queries and k[2] == B), None)
     if dec_key is not None:
         us, n = fwd[dec_key]
-        nbytes = msda_bytes(B, S, a.queries)
+        vb = 2 if a.dtype == "bf16" else 4
+        nbytes = msda_bytes(B, S, a.queries, value_bytes=vb)
         achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and (B, a.T, a.queries) == (16, 100, 300):
+        if os.path.exists(pmc) and (B, a.T, a.queries, a.dtype) == (16, 100, 300, "f32"):
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same launch shape (FETCH_SIZE and
             # WRITE_SIZE in separate passes, gfx950 2x FETCH correction); counters cannot be read from inside the run
             traffic = json.load(open(pmc))["k_fwd_t1d_d64_fused_dec"]["hbm_bytes_corrected"]   # the variant the model launches
@@ -252,11 +260,11 @@ def main():
         enc_key = next((k for k in fwd if k[1] == S and k[2] == B), None)
         if enc_key is not None:
             eus, en = fwd[enc_key]
-            eb = msda_bytes(B, S, S)
+            eb = msda_bytes(B, S, S, value_bytes=vb)
             roof["encoder_launch"] = {"kernel_us": round(eus, 2), "launches_timed": en, "algorithmic_bytes": eb,
                                       "frac": round(eb / (eus * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
     other = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in ktimes.items() if k not in fwd}
-    if roof is not None and rank == 0 and a.T != 512:
+    if roof is not None and rank == 0 and a.T != 512 and a.dtype == "f32":
         roof["cfg_L_launch"] = cfg_l_probe(dev, B)
 
     line = {
@@ -264,9 +272,10 @@ def main():
         "value": round(videos_per_s, 3) if a.mode == "eval" else round(ms_per_step, 3),
         "unit": "videos/s" if a.mode == "eval" else "ms",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": a.mode == "eval", "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": a.mode == "eval", "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if a.dtype == "f32" else "bf16 storage + bf16 GEMMs, f32 accumulate / locations / captioner",
         "data": "synthetic",
-        "config": {"workload": f"cfgs/anet_tsp_ssvg.yml PDVC {'eval forward' if a.mode == 'eval' else 'train step'}"
+        "config": {"workload": f"cfgs/{a.cfg}.yml PDVC {'eval forward' if a.mode == 'eval' else 'train step'}"
                                f" B={B}/GPU T={a.T} L=4 Q={a.queries}, "
                                + ("captioner off (diagnostic)" if a.no_captioner else
                                   f"LSTM-DSA greedy captioning {opt.max_caption_len + 1} steps")
