@@ -90,6 +90,28 @@ class ShowAttendTellCore(nn.Module):
                          w_att_t=self.rnn.weight_ih_l0[:, E2:E2 + self.att_feat_size].t().contiguous())
         return const
 
+    def fused_train_eligible(self, query):
+        """domain of gvl_cap_attend_train_* (include/gvl_msda.h)"""
+        return (getattr(self, "fused_train", True) and query.is_cuda and query.dtype == torch.float32
+                and self.att_feat_size == 512 and self.att_hid_size == 512
+                and self.n_levels * self.n_points == 16)
+
+    def teacher_forced(self, xt_all, query, reference_points, temporal_shapes, level_start_index, const):
+        """every teacher-forced token step as one autograd node (TeacherForcedLoop) -> hidden (n, steps, H)"""
+        att = self.deformable_att
+        H, E, C = self.rnn_size, self.input_encoding_size, self.att_feat_size
+        K = self.n_levels * self.n_points
+        ow = att.sampling_offsets.weight
+        w_hcat = torch.cat([self.h2att.weight, self.rnn.weight_hh_l0, ow[:, :H]], 0)
+        b_hcat = torch.cat([self.h2att.bias, self.h2att.bias.new_zeros(4 * H + K)])
+        slab = const["slab"]
+        B, S = slab.shape[:2]
+        return TeacherForcedLoop.apply(
+            slab.view(B, S, -1), reference_points.contiguous(), const["off_hs"].reshape(-1, K), const["gates_hs"],
+            xt_all, w_hcat, b_hcat, self.rnn.weight_ih_l0[:, E:E + C].contiguous(), self.alpha_net.weight.reshape(-1),
+            self.alpha_net.bias.reshape(1), temporal_shapes_2d(temporal_shapes, level_start_index), level_start_index,
+            self.n_levels, self.n_points)
+
     def step(self, xt_gates, state, query, reference_points, temporal_shapes, level_start_index, const):
         """one token.  xt_gates = embed(it) @ W_ih[:, :E]^T  (B*Q, 4H)"""
         att = self.deformable_att
@@ -147,6 +169,84 @@ class ShowAttendTellCore(nn.Module):
         out, (h, c) = self.step(xt_gates, (state[0][-1].contiguous(), state[1][-1].contiguous()), query,
                                 reference_points, input_spatial_shapes, input_level_start_index, const)
         return out, (h[None], c[None])
+
+
+class TeacherForcedLoop(torch.autograd.Function):
+    """All teacher-forced token steps of the LSTM-DSA core (LSTM_DSA.py:63-117 loop over :241-271) as ONE autograd
+    node -> hidden states (n, steps, H).
+
+    Why: in training the captioner sees only the matched queries (n = 48 rows at cfg A), so the reference formulation is
+    ~64 launch-bound kernels per token forward and ~150 backward, and autograd re-accumulates the 12 MB gradient of
+    the [value | ctx2att(value)] slab after every token.  Here a token is GEMM, k_cap_train_fwd, GEMM,
+    k_lstm_train_fwd; its backward k_lstm_train_bwd, GEMM, k_cap_train_bwd, GEMM (gvl_amd/csrc/gvl_cap_train.hip);
+    slab / reference / alpha_net gradients accumulate in place across the steps, and every weight gradient is ONE
+    GEMM over all steps after the loop (the weights are constant across the loop, so sum_i dY_i^T X_i = dY^T X).
+
+    Inputs: slab (B,S,2C); ref_in (B,Q,L,RD); off_hs (n,16) and gates_hs (n,4H) the token-independent parts of the
+    offsets / gate pre-activations; xt_all (n,steps,4H) embedding part of the gates; w_hcat (A+4H+16, H) =
+    [h2att.weight; W_hh; sampling_offsets.weight[:, :H]] with bias b_hcat; w_att (4H, C) = W_ih[:, E:E+C];
+    alpha_w (A,), alpha_b (1,)."""
+
+    @staticmethod
+    def forward(ctx, slab, ref_in, off_hs, gates_hs, xt_all, w_hcat, b_hcat, w_att, alpha_w, alpha_b, shapes2d, lsi,
+                n_levels, n_points):
+        n, steps, H4 = xt_all.shape
+        H = H4 // 4
+        C = w_att.shape[1]
+        W = w_hcat.shape[0]
+        A = W - H4 - 16
+        new = lambda *shape: torch.empty(shape, device=slab.device, dtype=torch.float32)      # noqa: E731
+        xt_all = xt_all.contiguous()
+        g_h, h_all, c_all = new(steps, n, W), new(steps + 1, n, H), new(steps + 1, n, H)
+        att, alpha, act, g_x = new(steps, n, C), new(steps, n, 16), new(steps, n, H4), new(n, H4)
+        h_all[0].zero_()
+        c_all[0].zero_()
+        w_hcat_t, w_att_t = w_hcat.t(), w_att.t()
+        for i in range(steps):
+            torch.addmm(b_hcat, h_all[i], w_hcat_t, out=g_h[i])                   # [h2att(h) | h W_hh^T | offsets(h)]
+            MSDA.cap_attend_train_forward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
+                                          alpha_w, alpha_b, n_levels, n_points, att_res=att[i], alpha_out=alpha[i])
+            torch.addmm(gates_hs, att[i], w_att_t, out=g_x)                       # hs part + attention part of W_ih x
+            MSDA.lstm_cell_train_forward(g_x, g_h[i][:, A:A + H4], xt_all[:, i], c_all[i], act[i], h_all[i + 1],
+                                         c_all[i + 1])
+        ctx.save_for_backward(slab, ref_in, off_hs, w_hcat, w_att, alpha_w, shapes2d, lsi, g_h, h_all, c_all, att,
+                              alpha, act)
+        ctx.cfg = (n_levels, n_points, A)
+        return h_all[1:].permute(1, 0, 2).contiguous()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_hidden):
+        slab, ref_in, off_hs, w_hcat, w_att, alpha_w, shapes2d, lsi, g_h, h_all, c_all, att, alpha, act = \
+            ctx.saved_tensors
+        n_levels, n_points, A = ctx.cfg
+        steps, n, W = g_h.shape
+        H, C = h_all.shape[-1], att.shape[-1]
+        H4 = 4 * H
+        new = lambda *shape: torch.empty(shape, device=slab.device, dtype=torch.float32)      # noqa: E731
+        d_h = d_hidden.permute(1, 0, 2).contiguous()
+        dg = new(steps, n, W)                          # per step [d h2att(h) | d gates | d offsets]: fully overwritten
+        g_slab, g_ref = torch.zeros_like(slab), torch.zeros_like(ref_in)
+        g_aw, g_ab = torch.zeros_like(alpha_w), slab.new_zeros(1)
+        d_att, dh_carry, dc = new(n, C), None, None
+        dh_buf, dc_buf = (new(n, H), new(n, H)), (new(n, H), new(n, H))
+        for i in range(steps - 1, -1, -1):
+            dgates = dg[i][:, A:A + H4]
+            MSDA.lstm_cell_train_backward(d_h[i], dh_carry, dc, act[i], c_all[i], c_all[i + 1], dgates, dc_buf[i & 1])
+            dc = dc_buf[i & 1]
+            torch.mm(dgates, w_att, out=d_att)
+            MSDA.cap_attend_train_backward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
+                                           alpha_w, alpha[i], d_att, n_levels, n_points, g_slab, dg[i][:, :A],
+                                           dg[i][:, A + H4:], g_ref, g_aw, g_ab)
+            if i > 0:                                  # h_{-1} = 0 is a constant
+                dh_carry = torch.mm(dg[i], w_hcat, out=dh_buf[i & 1])
+        dgf = dg.view(steps * n, W)
+        d_w_hcat = dgf.t().mm(h_all[:steps].reshape(steps * n, H))
+        d_b_hcat = dgf.sum(0)
+        d_gates = dg[:, :, A:A + H4]
+        d_w_att = d_gates.reshape(steps * n, H4).t().mm(att.view(steps * n, C))
+        return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates.sum(0), d_gates.permute(1, 0, 2), d_w_hcat, d_b_hcat,
+                d_w_att, g_aw, g_ab, None, None, None, None)
 
 
 def _fp32_island(fn):
@@ -247,6 +347,9 @@ class Captioner(nn.Module):
             # the vocabulary GEMM + log_softmax after it -- so their weights see ONE forward and ONE gradient GEMM
             # instead of `steps` of each followed by `steps` accumulations of a 17 MB gradient.
             xt_all = F.linear(self.embed(seq[:, :steps]), w_x)                    # (n, steps, 4H)
+            if torch.is_grad_enabled() and self.core.fused_train_eligible(hs):
+                hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const)
+                return F.log_softmax(self.logit(self.dropout(hidden)), dim=2)
             hidden = []
             for i in range(steps):
                 out, (h, c) = self.core.step(xt_all[:, i], (h, c), hs, ref_in, tshapes, lsi, const)

@@ -240,6 +240,92 @@ def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off
     return (att_res, dbg_a, dbg_l) if debug else att_res
 
 
+def _f32_rows(name, t_, cols):
+    _require(t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1 and t_.shape[1] == cols,
+             f"{name} must be an fp32 CUDA matrix with {cols} unit-stride columns")
+
+
+def cap_attend_train_forward(slab, spatial_shapes, level_start_index, ref_in, off_hs, off_h, att_h, alpha_w, alpha_b,
+                             n_levels, n_points, att_res=None, alpha_out=None):
+    """include/gvl_msda.h: gvl_cap_attend_train_forward_f32 -> (att_res (n,C), alpha (n,16)); off_h / att_h may be
+    column blocks of one GEMM output (row strides are passed on)."""
+    B, S, C2 = slab.shape
+    C, Q, RD, K = C2 // 2, ref_in.shape[1], ref_in.shape[-1], n_levels * n_points
+    n = B * Q
+    for name, t_ in (("slab", slab), ("ref_in", ref_in), ("off_hs", off_hs), ("alpha_w", alpha_w), ("alpha_b", alpha_b)):
+        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
+                 f"cap_attend_train: {name} must be a contiguous fp32 CUDA tensor")
+    _f32_rows("cap_attend_train: off_h", off_h, K)
+    _f32_rows("cap_attend_train: att_h", att_h, C)
+    if att_res is None:
+        att_res = torch.empty((n, C), device=slab.device, dtype=torch.float32)
+    if alpha_out is None:
+        alpha_out = torch.empty((n, 16), device=slab.device, dtype=torch.float32)
+    with torch.cuda.device(slab.device):
+        rc = _lib.lib().gvl_cap_attend_train_forward_f32(
+            slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
+            off_hs.data_ptr(), off_h.data_ptr(), off_h.stride(0), att_h.data_ptr(), att_h.stride(0),
+            alpha_w.data_ptr(), alpha_b.data_ptr(), B, S, C, n_levels, Q, n_points, RD, att_res.data_ptr(),
+            alpha_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "cap_attend_train_forward")
+    return att_res, alpha_out
+
+
+def cap_attend_train_backward(slab, spatial_shapes, level_start_index, ref_in, off_hs, off_h, att_h, alpha_w, alpha,
+                              grad_att_res, n_levels, n_points, grad_slab, grad_att_h, grad_off, grad_ref,
+                              grad_alpha_w, grad_alpha_b):
+    """include/gvl_msda.h: gvl_cap_attend_train_backward_f32.  grad_att_h / grad_off are overwritten (may be column
+    blocks of one matrix); grad_slab / grad_ref / grad_alpha_w / grad_alpha_b are accumulated into."""
+    B, S, C2 = slab.shape
+    C, Q, RD, K = C2 // 2, ref_in.shape[1], ref_in.shape[-1], n_levels * n_points
+    _f32_rows("cap_attend_train: grad_att_res", grad_att_res, C)
+    _f32_rows("cap_attend_train: grad_att_h", grad_att_h, C)
+    _f32_rows("cap_attend_train: grad_off", grad_off, 16)
+    for name, t_, shape in (("grad_slab", grad_slab, slab.shape), ("grad_ref", grad_ref, ref_in.shape),
+                            ("grad_alpha_w", grad_alpha_w, (C,)), ("grad_alpha_b", grad_alpha_b, (1,))):
+        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and tuple(t_.shape) == tuple(shape),
+                 f"cap_attend_train: {name} must be a contiguous fp32 CUDA tensor of shape {tuple(shape)}")
+    with torch.cuda.device(slab.device):
+        rc = _lib.lib().gvl_cap_attend_train_backward_f32(
+            slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
+            off_hs.data_ptr(), off_h.data_ptr(), off_h.stride(0), att_h.data_ptr(), att_h.stride(0),
+            alpha_w.data_ptr(), alpha.data_ptr(), grad_att_res.data_ptr(), grad_att_res.stride(0), B, S, C, n_levels,
+            Q, n_points, RD, grad_slab.data_ptr(), grad_att_h.data_ptr(), grad_att_h.stride(0), grad_off.data_ptr(),
+            grad_off.stride(0), grad_ref.data_ptr(), grad_alpha_w.data_ptr(), grad_alpha_b.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "cap_attend_train_backward")
+
+
+def lstm_cell_train_forward(gates_a, gates_b, gates_c, c_prev, act, h_out, c_out):
+    n, H = c_prev.shape
+    for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b), ("gates_c", gates_c)):
+        _f32_rows("lstm_cell_train: " + name, t_, 4 * H)
+    for name, t_ in (("c_prev", c_prev), ("act", act), ("h_out", h_out), ("c_out", c_out)):
+        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32, f"lstm_cell_train: {name}")
+    with torch.cuda.device(c_prev.device):
+        rc = _lib.lib().gvl_lstm_cell_train_forward_f32(
+            gates_a.data_ptr(), gates_a.stride(0), gates_b.data_ptr(), gates_b.stride(0), gates_c.data_ptr(),
+            gates_c.stride(0), c_prev.data_ptr(), n, H, act.data_ptr(), h_out.data_ptr(), c_out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "lstm_cell_train_forward")
+
+
+def lstm_cell_train_backward(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, grad_gates, grad_c_prev):
+    n, H = c_prev.shape
+    _f32_rows("lstm_cell_train: grad_gates", grad_gates, 4 * H)
+    for name, t_ in (("grad_h_a", grad_h_a), ("grad_h_b", grad_h_b), ("grad_c", grad_c), ("act", act),
+                     ("c_prev", c_prev), ("c_new", c_new), ("grad_c_prev", grad_c_prev)):
+        _require(t_ is None or (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32),
+                 f"lstm_cell_train: {name} must be a contiguous fp32 CUDA tensor")
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()      # noqa: E731
+    with torch.cuda.device(c_prev.device):
+        rc = _lib.lib().gvl_lstm_cell_train_backward_f32(
+            ptr(grad_h_a), ptr(grad_h_b), ptr(grad_c), act.data_ptr(), c_prev.data_ptr(), c_new.data_ptr(), n, H,
+            grad_gates.data_ptr(), grad_gates.stride(0), grad_c_prev.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "lstm_cell_train_backward")
+
+
 def lstm_cell(gates_a, gates_b, emb_gates, it, c):
     """fused LSTM cell pointwise step (include/gvl_msda.h: gvl_lstm_cell_f32) -> (h', c')"""
     n, H = c.shape
@@ -272,7 +358,8 @@ def row_argmax_lse(logits):
 
 
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
-             7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap"}
+             7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
+             12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train"}
 
 
 def profile_enable(on=True):

@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 2          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 3          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -35,6 +35,11 @@ SIGNATURES = {
     "gvl_msda_sample_backward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),
     "gvl_cap_attend_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_lstm_cell_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "gvl_cap_attend_train_forward_f32": (_I, [_P] * 6 + [_I, _P, _I, _P, _P] + [_I] * 7 + [_P, _P, _P]),
+    "gvl_cap_attend_train_backward_f32": (_I, [_P] * 6 + [_I, _P, _I, _P, _P, _P, _I] + [_I] * 7
+                                          + [_P, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "gvl_lstm_cell_train_forward_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "gvl_lstm_cell_train_backward_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P]),
     "gvl_row_argmax_lse_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),

@@ -1,0 +1,426 @@
+// gvl_cap_train.hip -- TRAINING-time kernels of the LSTM-DSA captioner's token step (teacher forcing) on MI355X.
+//
+// Reference: ShowAttendTellCore.forward (pdvc/CaptioningHead/LSTM_DSA.py:241-271) with MSDeformAttnCap.forward
+// (pdvc/ops/modules/ms_deform_attn_for_caption.py:82-127) inside it, and their autograd.  In training the captioner
+// runs on the matched queries only (pdvc.py:743-760: ~3 rows per video), so every PyTorch kernel of the reference
+// formulation is launch-bound: ~64 launches forward and ~150 backward per token.  Here one token step is
+//     GEMM over h  ->  k_cap_train_fwd  ->  GEMM over att  ->  k_lstm_train_fwd
+// and its backward
+//     k_lstm_train_bwd  ->  GEMM  ->  k_cap_train_bwd  ->  GEMM,
+// with all weight gradients deferred to one GEMM per weight after the time loop (gvl_amd/CaptioningHead/LSTM_DSA.py).
+//
+//   k_cap_train_fwd   one wavefront per (video, matched query) row, lane = 8 of the 512 channels:
+//                       x_k    = ref + off_k / T_l   |   ref_c + off_k / P * ref_len * 0.5        (16 samples)
+//                       clip_k = border-padded linear sample of value_proj(memory) at x_k
+//                       e_k    = alpha_w . tanh(ctx2att(clip_k) + h2att(h)) + alpha_b ;  alpha = softmax_k(e)
+//                       att    = sum_k alpha_k clip_k
+//                     (ctx2att pushed through the interpolation: the slab is [value | ctx2att(value)], see gvl_cap.hip)
+//   k_cap_train_bwd   the exact gradient of the above w.r.t. the slab (scatter with hardware float atomics: rows of
+//                     one video collide), h2att(h), the offsets, the reference points, alpha_w and alpha_b.  Samples
+//                     are re-gathered instead of stored (32 KB per row per step would have to round-trip HBM).
+//   k_lstm_train_fwd / _bwd   pointwise LSTM cell (nn.LSTM single layer, bias-free; LSTM_DSA.py:216-217,269) and
+//                     its backward; the forward keeps the activated gates.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gvl_common.hpp"
+#include "gvl_msda.h"
+
+namespace {
+
+using gvl::fail;
+
+constexpr int kC = 512;
+constexpr int kLP = 16;
+
+__device__ inline float fast_tanh(float x) {
+  const float e = __expf(2.f * x);
+  return 1.f - 2.f / (1.f + e);
+}
+__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// reduce-scatter of v[16] over the 64 lanes: afterwards every lane holds the full sum of v[k], k = lane >> 2
+__device__ inline float butterfly16(float (&v)[16], int lane) {
+  float a8[8];
+  const bool up5 = lane & 32;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a8[i] = (up5 ? v[8 + i] : v[i]) + __shfl_xor(up5 ? v[i] : v[8 + i], 32, 64);
+  float a4[4];
+  const bool up4 = lane & 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a4[i] = (up4 ? a8[4 + i] : a8[i]) + __shfl_xor(up4 ? a8[i] : a8[4 + i], 16, 64);
+  float a2[2];
+  const bool up3 = lane & 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a2[i] = (up3 ? a4[2 + i] : a4[i]) + __shfl_xor(up3 ? a4[i] : a4[2 + i], 8, 64);
+  const bool up2 = lane & 4;
+  float r = (up2 ? a2[1] : a2[0]) + __shfl_xor(up2 ? a2[0] : a2[1], 4, 64);
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+__device__ inline float groups_max(float v) {
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline float groups_sum(float v) {
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float bcast(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+// border-mode sample geometry (grid_sampler border, align_corners=False) on the clamped row pair (r, r+1);
+// dmul = d pixel / d loc (T inside the level, 0 where the coordinate is clipped -- clip_coordinates_set_grad)
+struct Geo {
+  int r;
+  float c_lo, c_hi, dmul;
+};
+__device__ inline Geo border_geo(float loc, int T) {
+  Geo g;
+  float x = ((2.f * loc - 1.f + 1.f) * (float)T - 1.f) * 0.5f;
+  const float mx = (float)(T - 1);
+  g.dmul = (float)T;
+  if (!(x > 0.f)) { x = 0.f; g.dmul = 0.f; }
+  else if (x >= mx) { x = mx; g.dmul = 0.f; }
+  const float xf = floorf(x);
+  const int x0 = (int)xf;
+  const float a = x - xf;
+  const int rmax = T >= 2 ? T - 2 : 0;
+  g.r = x0 > rmax ? rmax : x0;
+  const float t0 = 1.f - a;
+  const float t1 = (x0 + 1 <= T - 1) ? a : 0.f;
+  g.c_lo = (x0 == g.r ? t0 : 0.f) + (x0 + 1 == g.r ? t1 : 0.f);
+  g.c_hi = (x0 == g.r + 1 ? t0 : 0.f) + (x0 + 1 == g.r + 1 ? t1 : 0.f);
+  return g;
+}
+
+struct RowSetup {
+  int roff;                 // slab row of the lane group's sample (level start + r)
+  float c_lo, c_hi, dmul;   // interpolation coefficients, d pixel / d loc
+  float doff;               // d loc / d offset
+  float off;                // total offset of the sample
+  int level;
+};
+
+__device__ inline RowSetup setup_row(const int64_t *shapes, const int64_t *lsi, const float *ref, const float *off_hs,
+                                     const float *off_h, int64_t row, int k_own, int L, int P, int RD) {
+  RowSetup s = {0, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+  const int LP = L * P;
+  if (k_own < LP) {
+    const int l = k_own / P;
+    const int T = (int)shapes[2 * l + 1];
+    const float *rp = ref + (row * L + l) * RD;
+    s.level = l;
+    s.off = off_hs[row * LP + k_own] + off_h[k_own];
+    float locx;
+    if (RD == 1) { locx = rp[0] + s.off / (float)T; s.doff = 1.f / (float)T; }               // for_caption.py:108-109
+    else { locx = rp[0] + s.off / (float)P * rp[1] * 0.5f; s.doff = rp[1] * 0.5f / (float)P; }  // :110-112
+    const Geo g = border_geo(locx, T);
+    s.roff = (int)lsi[l] + g.r;
+    s.c_lo = g.c_lo; s.c_hi = g.c_hi; s.dmul = g.dmul;
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_cap_train_fwd(
+    const float *__restrict__ slab, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ ref, const float *__restrict__ off_hs, const float *__restrict__ off_h, int off_h_ld,
+    const float *__restrict__ att_h, int att_h_ld, const float *__restrict__ alpha_w,
+    const float *__restrict__ alpha_b, int S, int L, int Q, int P, int RD, float *__restrict__ att_res,
+    float *__restrict__ alpha_out) {
+  const int64_t row = blockIdx.x;
+  const int lane = threadIdx.x, k_own = lane >> 2, LP = L * P;
+  const int b = (int)(row / Q);
+  const RowSetup rs = setup_row(shapes, lsi, ref, off_hs, off_h + row * (int64_t)off_h_ld, row, k_own, L, P, RD);
+  const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * (int64_t)att_h_ld);
+  const float4 ta = ah4[lane], tb = ah4[64 + lane];
+  const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
+  const float4 *slab4 = reinterpret_cast<const float4 *>(slab) + (int64_t)b * S * (2 * kC / 4);
+  float e[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    e[k] = 0.f;
+    if (k < LP) {
+      const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
+      const float cl = bcast(rs.c_lo, 4 * k), ch = bcast(rs.c_hi, 4 * k);
+      const int rr1 = min(rr + 1, S - 1);
+      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4) + kC / 4;
+      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4) + kC / 4;
+      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      float s = 0.f;
+      s = fmaf(qa.x, fast_tanh(fmaf(cl, l0.x, fmaf(ch, u0.x, ta.x))), s);
+      s = fmaf(qa.y, fast_tanh(fmaf(cl, l0.y, fmaf(ch, u0.y, ta.y))), s);
+      s = fmaf(qa.z, fast_tanh(fmaf(cl, l0.z, fmaf(ch, u0.z, ta.z))), s);
+      s = fmaf(qa.w, fast_tanh(fmaf(cl, l0.w, fmaf(ch, u0.w, ta.w))), s);
+      s = fmaf(qb.x, fast_tanh(fmaf(cl, l1.x, fmaf(ch, u1.x, tb.x))), s);
+      s = fmaf(qb.y, fast_tanh(fmaf(cl, l1.y, fmaf(ch, u1.y, tb.y))), s);
+      s = fmaf(qb.z, fast_tanh(fmaf(cl, l1.z, fmaf(ch, u1.z, tb.z))), s);
+      s = fmaf(qb.w, fast_tanh(fmaf(cl, l1.w, fmaf(ch, u1.w, tb.w))), s);
+      e[k] = s;
+    }
+  }
+  float ek = butterfly16(e, lane) + alpha_b[0];
+  if (k_own >= LP) ek = -INFINITY;
+  const float m = groups_max(ek);
+  const float pexp = (k_own < LP) ? __expf(ek - m) : 0.f;
+  const float alpha = pexp / groups_sum(pexp);
+  if ((lane & 3) == 0) alpha_out[row * kLP + k_own] = alpha;
+  const float a_lo = alpha * rs.c_lo, a_hi = alpha * rs.c_hi;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < LP) {
+      const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
+      const float cl = bcast(a_lo, 4 * k), ch = bcast(a_hi, 4 * k);
+      const int rr1 = min(rr + 1, S - 1);
+      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4);
+      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4);
+      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      acc[0] = fmaf(cl, l0.x, fmaf(ch, u0.x, acc[0])); acc[1] = fmaf(cl, l0.y, fmaf(ch, u0.y, acc[1]));
+      acc[2] = fmaf(cl, l0.z, fmaf(ch, u0.z, acc[2])); acc[3] = fmaf(cl, l0.w, fmaf(ch, u0.w, acc[3]));
+      acc[4] = fmaf(cl, l1.x, fmaf(ch, u1.x, acc[4])); acc[5] = fmaf(cl, l1.y, fmaf(ch, u1.y, acc[5]));
+      acc[6] = fmaf(cl, l1.z, fmaf(ch, u1.z, acc[6])); acc[7] = fmaf(cl, l1.w, fmaf(ch, u1.w, acc[7]));
+    }
+  }
+  float4 *o4 = reinterpret_cast<float4 *>(att_res + row * kC);
+  o4[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  o4[64 + lane] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+__device__ inline void atomic_add4(float *p, float s, const float4 &v) {
+  atomicAdd(p + 0, s * v.x); atomicAdd(p + 1, s * v.y); atomicAdd(p + 2, s * v.z); atomicAdd(p + 3, s * v.w);
+}
+__device__ inline float dot4d(const float4 &g, const float4 &u, const float4 &l) {
+  return g.x * (u.x - l.x) + g.y * (u.y - l.y) + g.z * (u.z - l.z) + g.w * (u.w - l.w);
+}
+__device__ inline float dot4(const float4 &a, const float4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+__global__ void __launch_bounds__(64) k_cap_train_bwd(
+    const float *__restrict__ slab, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ ref, const float *__restrict__ off_hs, const float *__restrict__ off_h, int off_h_ld,
+    const float *__restrict__ att_h, int att_h_ld, const float *__restrict__ alpha_w,
+    const float *__restrict__ alpha_saved, const float *__restrict__ g_att, int g_att_ld, int S, int L, int Q, int P,
+    int RD, float *__restrict__ g_slab, float *__restrict__ g_att_h, int g_att_h_ld, float *__restrict__ g_off,
+    int g_off_ld, float *__restrict__ g_ref, float *__restrict__ g_alpha_w, float *__restrict__ g_alpha_b) {
+  const int64_t row = blockIdx.x;
+  const int lane = threadIdx.x, k_own = lane >> 2, LP = L * P;
+  const int b = (int)(row / Q);
+  const RowSetup rs = setup_row(shapes, lsi, ref, off_hs, off_h + row * (int64_t)off_h_ld, row, k_own, L, P, RD);
+  const float alpha = k_own < LP ? alpha_saved[row * kLP + k_own] : 0.f;
+  const float4 *g4 = reinterpret_cast<const float4 *>(g_att + row * (int64_t)g_att_ld);
+  const float4 ga = g4[lane], gb = g4[64 + lane];
+  const float4 *slab4 = reinterpret_cast<const float4 *>(slab) + (int64_t)b * S * (2 * kC / 4);
+  float *gs = g_slab + (int64_t)b * S * (2 * kC);
+
+  // ---- value half: d alpha_k = g . clip_k ; d x_k (part 1) = alpha_k g . (V[r+1] - V[r]) ; scatter alpha_k c g -----
+  float pa[16], px[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    pa[k] = 0.f; px[k] = 0.f;
+    if (k < LP) {
+      const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
+      const float cl = bcast(rs.c_lo, 4 * k), ch = bcast(rs.c_hi, 4 * k), ak = bcast(alpha, 4 * k);
+      const int rr1 = min(rr + 1, S - 1);
+      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4);
+      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4);
+      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      pa[k] = cl * (dot4(ga, l0) + dot4(gb, l1)) + ch * (dot4(ga, u0) + dot4(gb, u1));
+      px[k] = ak * (dot4d(ga, u0, l0) + dot4d(gb, u1, l1));
+      float *d0 = gs + (int64_t)rr * (2 * kC), *d1 = gs + (int64_t)rr1 * (2 * kC);
+      if (cl != 0.f) { atomic_add4(d0 + 4 * lane, ak * cl, ga); atomic_add4(d0 + 256 + 4 * lane, ak * cl, gb); }
+      if (ch != 0.f) { atomic_add4(d1 + 4 * lane, ak * ch, ga); atomic_add4(d1 + 256 + 4 * lane, ak * ch, gb); }
+    }
+  }
+  const float dalpha = butterfly16(pa, lane);                       // lane group k: g . clip_k
+  const float dsum = groups_sum(alpha * dalpha);
+  const float de = alpha * (dalpha - dsum);                         // softmax backward: d e_k
+  const float de_total = groups_sum(de);                            // = 0 up to rounding: softmax is shift invariant
+  if (lane == 0) atomicAdd(g_alpha_b, de_total);
+
+  // ---- ctx2att half: t = tanh(att_ctx_k + att_h); d pre = de_k alpha_w (1 - t^2) -------------------------------
+  const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * (int64_t)att_h_ld);
+  const float4 ta = ah4[lane], tb = ah4[64 + lane];
+  const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
+  float4 dha = make_float4(0.f, 0.f, 0.f, 0.f), dhb = dha, dwa = dha, dwb = dha;
+  float px2[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    px2[k] = 0.f;
+    if (k < LP) {
+      const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
+      const float cl = bcast(rs.c_lo, 4 * k), ch = bcast(rs.c_hi, 4 * k), dek = bcast(de, 4 * k);
+      const int rr1 = min(rr + 1, S - 1);
+      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4) + kC / 4;
+      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4) + kC / 4;
+      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      float4 da, db;
+#define GVL_CH(X, Lo, Up, Tt, Qq, Dd, DH, DW)                                  \
+      {                                                                        \
+        const float t_ = fast_tanh(fmaf(cl, Lo.X, fmaf(ch, Up.X, Tt.X)));      \
+        const float d_ = dek * Qq.X * (1.f - t_ * t_);                         \
+        Dd.X = d_; DH.X += d_; DW.X = fmaf(dek, t_, DW.X);                     \
+      }
+      GVL_CH(x, l0, u0, ta, qa, da, dha, dwa) GVL_CH(y, l0, u0, ta, qa, da, dha, dwa)
+      GVL_CH(z, l0, u0, ta, qa, da, dha, dwa) GVL_CH(w, l0, u0, ta, qa, da, dha, dwa)
+      GVL_CH(x, l1, u1, tb, qb, db, dhb, dwb) GVL_CH(y, l1, u1, tb, qb, db, dhb, dwb)
+      GVL_CH(z, l1, u1, tb, qb, db, dhb, dwb) GVL_CH(w, l1, u1, tb, qb, db, dhb, dwb)
+#undef GVL_CH
+      px2[k] = dot4d(da, u0, l0) + dot4d(db, u1, l1);
+      float *d0 = gs + (int64_t)rr * (2 * kC) + kC, *d1 = gs + (int64_t)rr1 * (2 * kC) + kC;
+      if (cl != 0.f) { atomic_add4(d0 + 4 * lane, cl, da); atomic_add4(d0 + 256 + 4 * lane, cl, db); }
+      if (ch != 0.f) { atomic_add4(d1 + 4 * lane, ch, da); atomic_add4(d1 + 256 + 4 * lane, ch, db); }
+    }
+  }
+  float4 *oh = reinterpret_cast<float4 *>(g_att_h + row * (int64_t)g_att_h_ld);
+  oh[lane] = dha;
+  oh[64 + lane] = dhb;
+  atomic_add4(g_alpha_w + 4 * lane, 1.f, dwa);
+  atomic_add4(g_alpha_w + 256 + 4 * lane, 1.f, dwb);
+
+  // ---- d x_k -> offsets and reference points ------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < 16; ++k) px[k] += px2[k];
+  const float dx = butterfly16(px, lane);                            // lane group k: d loss / d pixel coordinate
+  const float dloc = dx * rs.dmul;
+  if ((lane & 3) == 0) {
+    g_off[row * (int64_t)g_off_ld + k_own] = k_own < LP ? dloc * rs.doff : 0.f;
+    if (k_own < LP) {
+      float *gr = g_ref + (row * L + rs.level) * RD;
+      atomicAdd(gr, dloc);
+      if (RD == 2) atomicAdd(gr + 1, dloc * rs.off * (0.5f / (float)P));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LSTM cell, training: gates = ga + gb + gc (three partial pre-activations, row strides in floats), order i,f,g,o
+__global__ void __launch_bounds__(256) k_lstm_train_fwd(const float *__restrict__ ga, int lda, const float *__restrict__ gb,
+                                                        int ldb, const float *__restrict__ gc, int ldc,
+                                                        const float *__restrict__ c_prev, int n, int H,
+                                                        float *__restrict__ act, float *__restrict__ h_out,
+                                                        float *__restrict__ c_out) {
+  const int64_t total = (int64_t)n * H;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / H), j = (int)(idx % H);
+    float g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      g[k] = ga[(int64_t)row * lda + k * H + j] + gb[(int64_t)row * ldb + k * H + j] + gc[(int64_t)row * ldc + k * H + j];
+    const float i_ = sigmoidf_(g[0]), f_ = sigmoidf_(g[1]), g_ = fast_tanh(g[2]), o_ = sigmoidf_(g[3]);
+    const float c = f_ * c_prev[idx] + i_ * g_;
+    float *a = act + (int64_t)row * 4 * H + j;
+    a[0] = i_; a[H] = f_; a[2 * H] = g_; a[3 * H] = o_;
+    c_out[idx] = c;
+    h_out[idx] = o_ * fast_tanh(c);
+  }
+}
+
+// dh = dh_a + dh_b (either may be null), dc_in may be null; writes d(pre-activation gates) (row stride ldg) and dc_prev
+__global__ void __launch_bounds__(256) k_lstm_train_bwd(const float *__restrict__ dh_a, const float *__restrict__ dh_b,
+                                                        const float *__restrict__ dc_in, const float *__restrict__ act,
+                                                        const float *__restrict__ c_prev, const float *__restrict__ c_new,
+                                                        int n, int H, float *__restrict__ dgates, int ldg,
+                                                        float *__restrict__ dc_prev) {
+  const int64_t total = (int64_t)n * H;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / H), j = (int)(idx % H);
+    const float *a = act + (int64_t)row * 4 * H + j;
+    const float i_ = a[0], f_ = a[H], g_ = a[2 * H], o_ = a[3 * H];
+    const float dh = (dh_a ? dh_a[idx] : 0.f) + (dh_b ? dh_b[idx] : 0.f);
+    const float tc = fast_tanh(c_new[idx]);
+    const float dc = (dc_in ? dc_in[idx] : 0.f) + dh * o_ * (1.f - tc * tc);
+    float *d = dgates + (int64_t)row * ldg + j;
+    d[0] = dc * g_ * i_ * (1.f - i_);
+    d[H] = dc * c_prev[idx] * f_ * (1.f - f_);
+    d[2 * H] = dc * i_ * (1.f - g_ * g_);
+    d[3 * H] = dh * tc * o_ * (1.f - o_);
+    dc_prev[idx] = dc * f_;
+  }
+}
+
+int check_cap(const char *what, int B, int S, int C, int L, int Q, int P, int RD) {
+  if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
+    return fail(GVL_EINVAL, "%s: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", what, C, L, P, RD);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvl_cap_attend_train_forward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                                     const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
+                                     int att_h_ld, const float *alpha_w, const float *alpha_b, int B, int S, int C,
+                                     int L, int Q, int P, int RD, float *att_res, float *alpha_out, void *stream) {
+  if (int rc = check_cap("gvl_cap_attend_train_forward_f32", B, S, C, L, Q, P, RD)) return rc;
+  if (att_h_ld < C || (att_h_ld & 3) || off_h_ld < L * P)
+    return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: bad leading dimensions");
+  if ((int64_t)B * Q == 0) return 0;
+  if (!slab || !shapes || !lsi || !ref || !off_hs || !off_h || !att_h || !alpha_w || !alpha_b || !att_res || !alpha_out)
+    return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: null pointer");
+  if (((uintptr_t)att_h & 15) || ((uintptr_t)att_res & 15))
+    return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: att_h / att_res must be 16-byte aligned");
+  return gvl::launch(GVL_PROF_CAP_TRAIN_FWD, B * Q, B, "k_cap_train_fwd", k_cap_train_fwd, dim3(B * Q), dim3(64), 0,
+                     (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld, alpha_w,
+                     alpha_b, S, L, Q, P, RD, att_res, alpha_out);
+}
+
+int gvl_cap_attend_train_backward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                                      const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
+                                      int att_h_ld, const float *alpha_w, const float *alpha_saved,
+                                      const float *grad_att_res, int grad_att_res_ld, int B, int S, int C, int L, int Q,
+                                      int P, int RD, float *grad_slab, float *grad_att_h, int grad_att_h_ld,
+                                      float *grad_off, int grad_off_ld, float *grad_ref, float *grad_alpha_w,
+                                      float *grad_alpha_b, void *stream) {
+  if (int rc = check_cap("gvl_cap_attend_train_backward_f32", B, S, C, L, Q, P, RD)) return rc;
+  if (att_h_ld < C || (att_h_ld & 3) || off_h_ld < L * P || grad_att_res_ld < C || (grad_att_res_ld & 3) ||
+      grad_att_h_ld < C || (grad_att_h_ld & 3) || grad_off_ld < kLP)
+    return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: bad leading dimensions");
+  if ((int64_t)B * Q == 0) return 0;
+  if (!slab || !shapes || !lsi || !ref || !off_hs || !off_h || !att_h || !alpha_w || !alpha_saved || !grad_att_res ||
+      !grad_slab || !grad_att_h || !grad_off || !grad_ref || !grad_alpha_w || !grad_alpha_b)
+    return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: null pointer");
+  if (((uintptr_t)att_h & 15) || ((uintptr_t)grad_att_res & 15) || ((uintptr_t)grad_att_h & 15))
+    return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: row pointers must be 16-byte aligned");
+  return gvl::launch(GVL_PROF_CAP_TRAIN_BWD, B * Q, B, "k_cap_train_bwd", k_cap_train_bwd, dim3(B * Q), dim3(64), 0,
+                     (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld, alpha_w,
+                     alpha_saved, grad_att_res, grad_att_res_ld, S, L, Q, P, RD, grad_slab, grad_att_h, grad_att_h_ld,
+                     grad_off, grad_off_ld, grad_ref, grad_alpha_w, grad_alpha_b);
+}
+
+int gvl_lstm_cell_train_forward_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *gates_c,
+                                    int ldc, const float *c_prev, int n, int H, float *act, float *h_out, float *c_out,
+                                    void *stream) {
+  if (n < 0 || H <= 0 || lda < 4 * H || ldb < 4 * H || ldc < 4 * H)
+    return fail(GVL_EINVAL, "gvl_lstm_cell_train_forward_f32: bad sizes n=%d H=%d", n, H);
+  if (n == 0) return 0;
+  if (!gates_a || !gates_b || !gates_c || !c_prev || !act || !h_out || !c_out)
+    return fail(GVL_EINVAL, "gvl_lstm_cell_train_forward_f32: null pointer");
+  int64_t blocks = ((int64_t)n * H + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  return gvl::launch(GVL_PROF_LSTM_TRAIN, n, H, "k_lstm_train_fwd", k_lstm_train_fwd, dim3((unsigned)blocks), dim3(256),
+                     0, (hipStream_t)stream, gates_a, lda, gates_b, ldb, gates_c, ldc, c_prev, n, H, act, h_out, c_out);
+}
+
+int gvl_lstm_cell_train_backward_f32(const float *grad_h_a, const float *grad_h_b, const float *grad_c, const float *act,
+                                     const float *c_prev, const float *c_new, int n, int H, float *grad_gates,
+                                     int grad_gates_ld, float *grad_c_prev, void *stream) {
+  if (n < 0 || H <= 0 || grad_gates_ld < 4 * H)
+    return fail(GVL_EINVAL, "gvl_lstm_cell_train_backward_f32: bad sizes n=%d H=%d", n, H);
+  if (n == 0) return 0;
+  if (!act || !c_prev || !c_new || !grad_gates || !grad_c_prev)
+    return fail(GVL_EINVAL, "gvl_lstm_cell_train_backward_f32: null pointer");
+  int64_t blocks = ((int64_t)n * H + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  return gvl::launch(GVL_PROF_LSTM_TRAIN, n, H, "k_lstm_train_bwd", k_lstm_train_bwd, dim3((unsigned)blocks), dim3(256),
+                     0, (hipStream_t)stream, grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, n, H, grad_gates,
+                     grad_gates_ld, grad_c_prev);
+}
+
+}  // extern "C"

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 2   /* 2: bf16 storage twins added (all version-1 entry points unchanged) */
+#define GVL_MSDA_ABI_VERSION 3   /* 2: + bf16 storage twins; 3: + training-time captioner step (earlier entry points unchanged) */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -82,6 +82,9 @@ int gvl_msda_last_impl(void);
 #define GVL_PROF_ROW_ARGMAX 9
 #define GVL_PROF_LSTM_CELL 10
 #define GVL_PROF_LSAP 11
+#define GVL_PROF_CAP_TRAIN_FWD 12
+#define GVL_PROF_CAP_TRAIN_BWD 13
+#define GVL_PROF_LSTM_TRAIN 14
 int gvl_prof_enable(int on);
 int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
 
@@ -201,6 +204,42 @@ int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *
  *    multiplied by its slice of W_ih ((V+1, 4H)); it (n) int64 token ids. */
 int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
                       const int64_t *it, const float *c, int n, int H, float *h_out, float *c_out, void *stream);
+
+/* -- TRAINING-time token step of the same captioner (teacher forcing; LSTM_DSA.py:63-117 loop, :241-271 step, and
+ *    their autograd).  The matched queries only (pdvc.py:743-760), so n = B*Q rows is small and the step is
+ *    launch-bound in PyTorch; here a step is  GEMM, gvl_cap_attend_train_forward, GEMM, gvl_lstm_cell_train_forward
+ *    and its backward  gvl_lstm_cell_train_backward, GEMM, gvl_cap_attend_train_backward, GEMM.
+ *      slab      (B, S, 2C)   [value_proj(memory) | ctx2att(value_proj(memory))], C = 512
+ *      ref       (B, Q, L, RD) reference points scaled by the valid ratios
+ *      off_hs    (B*Q, L*P)   sampling_offsets bias + hs part;  off_h (B*Q, L*P; row stride off_h_ld) its h part
+ *      att_h     (B*Q, C; row stride att_h_ld)   h2att(h)
+ *      alpha_w (C), alpha_b (1, DEVICE pointer)  alpha_net
+ *    forward  -> att_res (B*Q, C), alpha_out (B*Q, 16) (the softmax weights, kept for the backward)
+ *    backward <- grad_att_res (B*Q, C; row stride);  grad_att_h / grad_off are OVERWRITTEN (row strides given: they
+ *               may be column blocks of one gradient matrix); grad_slab (B,S,2C), grad_ref (B,Q,L,RD), grad_alpha_w
+ *               (C), grad_alpha_b (1) are ACCUMULATED INTO (float atomics; the caller zeroes them once per token
+ *               loop, so the per-step autograd accumulation of a 12 MB slab gradient disappears). */
+int gvl_cap_attend_train_forward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                                     const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
+                                     int att_h_ld, const float *alpha_w, const float *alpha_b, int B, int S, int C,
+                                     int L, int Q, int P, int RD, float *att_res, float *alpha_out, void *stream);
+int gvl_cap_attend_train_backward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                                      const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
+                                      int att_h_ld, const float *alpha_w, const float *alpha_saved,
+                                      const float *grad_att_res, int grad_att_res_ld, int B, int S, int C, int L, int Q,
+                                      int P, int RD, float *grad_slab, float *grad_att_h, int grad_att_h_ld,
+                                      float *grad_off, int grad_off_ld, float *grad_ref, float *grad_alpha_w,
+                                      float *grad_alpha_b, void *stream);
+/*    LSTM cell (nn.LSTM single layer, bias-free; gate order i,f,g,o): gates = gates_a + gates_b + gates_c (row strides
+ *    in floats).  forward keeps the ACTIVATED gates act (n, 4H); backward takes dh = grad_h_a + grad_h_b (either may
+ *    be NULL), grad_c (may be NULL) and writes the pre-activation gate gradients (row stride grad_gates_ld) and
+ *    grad_c_prev. */
+int gvl_lstm_cell_train_forward_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *gates_c,
+                                    int ldc, const float *c_prev, int n, int H, float *act, float *h_out, float *c_out,
+                                    void *stream);
+int gvl_lstm_cell_train_backward_f32(const float *grad_h_a, const float *grad_h_b, const float *grad_c, const float *act,
+                                     const float *c_prev, const float *c_new, int n, int H, float *grad_gates,
+                                     int grad_gates_ld, float *grad_c_prev, void *stream);
 
 /* -- greedy decoding epilogue: idx[r] = argmax_v logits[r, v] (first maximal index), logp[r] = log_softmax(logits[r])
  *    at that index (LSTM_DSA.py:123 + :166-167), one read of the logits. */

@@ -425,3 +425,54 @@ def test_yc2_long_video_eval_under_bf16_autocast(built_yc2):
     assert float((out["pred_boxes"].float().cpu() - t(f["pred_boxes"])).abs().mean()) <= 0.08
     assert out["seq"].shape[:2] == (2, int(f["num_queries"]))
     assert all(torch.isfinite(v.float()).all() for v in loss.values())
+
+
+@pytest.mark.parametrize("ref_dim", [2, 1])
+def test_teacher_forced_loop_fused_equals_step_by_step(built, ref_dim):
+    """TeacherForcedLoop (k_cap_train_* / k_lstm_train_* + deferred weight-gradient GEMMs) against the step-by-step
+    formulation built from the sampler op + PyTorch autograd (itself pinned to the reference by the train golden):
+    log-probs and the gradients of every captioner parameter and of hs / reference / memory."""
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    f, model, criterion, dev = built
+    cap = model.caption_head[-1]
+    torch.manual_seed(5)
+    B, Qm, steps = 2, 3, 5
+    dt = to_dev(pdvc_dt(f), dev)
+    with torch.no_grad():
+        memory, tshapes, lsi, vr, mflat = model.encode(dt)
+    memory = (memory + 0.05 * torch.randn_like(memory)).requires_grad_()
+    hs = torch.randn(B, Qm, 512, device=dev, requires_grad=True)
+    ref = (torch.rand(B, Qm, ref_dim, device=dev) * (0.5 if ref_dim == 2 else 1.0) + 0.1).requires_grad_()
+    others = {"memory": memory, "mask_flatten": mflat, "spatial_shapes": tshapes, "level_start_index": lsi,
+              "valid_ratios": vr}
+    seq = torch.randint(1, 40, (B * Qm, steps + 1), device=dev)
+    seq[:, 0] = 0
+    gout = None
+    res = {}
+    params = dict(cap.named_parameters())
+    for mode in (True, False):
+        cap.core.fused_train = mode
+        for p_ in list(params.values()) + [memory, hs, ref]:
+            p_.grad = None
+        MSDA.profile_enable(True)
+        out = cap(hs, ref, others, seq, steps=steps)
+        if gout is None:
+            gout = torch.randn_like(out)
+        (out * gout).sum().backward()
+        torch.cuda.synchronize()
+        MSDA.profile_enable(False)
+        tags = [e[0] for e in MSDA.profile_collect()]
+        assert tags.count("cap_train_fwd") == (steps if mode else 0) and tags.count("cap_train_bwd") == (steps if mode else 0)
+        assert tags.count("lstm_train") == (2 * steps if mode else 0)
+        res[mode] = (out.detach().clone(), {k: (v.grad.clone() if v.grad is not None else None)
+                                            for k, v in list(params.items()) + [("memory", memory), ("hs", hs), ("ref", ref)]})
+    cap.core.fused_train = True
+    assert maxerr(res[True][0], res[False][0]) < 2e-4
+    for k, g_ref in res[False][1].items():
+        g = res[True][1][k]
+        if g_ref is None:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        assert g is not None, k
+        scale_ = max(1e-3, float(g_ref.abs().max()))
+        assert float((g - g_ref).abs().max()) <= 2e-3 * scale_, (k, float((g - g_ref).abs().max()), scale_)
