@@ -43,6 +43,12 @@ class GradBuckets:
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # One process, nothing to exchange: leave .grad = None so that autograd hands every gradient over without the
+        # per-parameter accumulate kernel into a pre-existing buffer (133 launches per step; the step is launch-bound).
+        self.flat = None
+        self.buckets, self.bucket_of, self.ready, self.handles = [], {}, [], []
+        if self.world == 1:
+            return
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
@@ -75,6 +81,10 @@ class GradBuckets:
             self.handles.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
 
     def zero(self):
+        if self.flat is None:
+            for p in self.params:
+                p.grad = None
+            return
         self.flat.zero_()
         self.ready = [0] * len(self.buckets)
         self.handles = []

@@ -313,10 +313,15 @@ def test_graphed_train_step_equals_eager():
         assert abs(float(la) - float(lb)) < 1e-4 * max(1.0, abs(float(la))), (step, float(la), float(lb))
         seen.append(float(lb))
         for (n, pa), pb in zip(model_a.named_parameters(), model_b.parameters()):
+            assert (pa.grad is None) == (pb.grad is None), (step, n)      # dead parameters (e.g. the captioner's unused
+            if pa.grad is None:                                           # attention_weights / output_proj) get none
+                continue
             assert maxerr(pa.grad, pb.grad) <= 1e-4 * max(1.0, float(pa.grad.abs().max())), (step, n)
     assert abs(seen[0] - float(g["final_loss"])) < 2e-3 and abs(seen[0] - seen[2]) < 1e-4 and abs(seen[0] - seen[1]) > 1e-3
     sa, sb = eager.optimizer.state, graphed.optimizer.state
     for pa, pb in zip(eager.params, graphed.params):
+        if pa.grad is None:
+            continue
         assert float(sa[pa]["step"]) == float(sb[pb]["step"]) == 6.0
         assert maxerr(sa[pa]["exp_avg"], sb[pb]["exp_avg"]) <= 1e-4 * max(1.0, float(sa[pa]["exp_avg"].abs().max()))
 
