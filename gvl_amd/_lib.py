@@ -40,6 +40,9 @@ SIGNATURES = {
                                           + [_P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "gvl_lstm_cell_train_forward_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
     "gvl_lstm_cell_train_backward_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P]),
+    "gvl_match_cost_f32": (_I, [_P] * 4 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),
+    "gvl_set_criterion_forward_f32": (_I, [_P] * 12 + [_I] * 7 + [ctypes.c_float] * 4 + [_I, _P, _P]),
+    "gvl_set_criterion_backward_f32": (_I, [_P] * 12 + [_I] * 7 + [ctypes.c_float] * 4 + [_I, _P, _P, _P, _P, _P]),
     "gvl_row_argmax_lse_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),

@@ -10,6 +10,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
 from .matcher import box_cl_to_xy, box_iou
 
 # Empirical distribution of the number of events per video used to re-weight the counter loss.
@@ -54,6 +55,49 @@ def cross_entropy_with_gaussian_mask(inputs, targets, opt, weight):
     return (loss * coef).mean(1).mean()
 
 
+LOSS_KEYS = ('loss_ce', 'loss_counter', 'loss_bbox', 'loss_giou', 'loss_self_iou', 'cardinality_error')
+
+
+class SetCriterionFunction(torch.autograd.Function):
+    """labels / boxes / cardinality losses of ALL decoder layers as one autograd node on two HIP launches
+    (include/gvl_msda.h: gvl_set_criterion_forward_f32 / _backward_f32) -> losses (n_layers, 6) in LOSS_KEYS order.
+    The PyTorch formulation below (SetCriterion.loss_*) is ~190 launch-bound kernels per layer and direction."""
+
+    @staticmethod
+    def _call(fn, ctx_t, cfg, *outs):
+        logits, counts, boxes, mq, mt, vid, tbase, ent_start, labels, tboxes, gt_counts, ccr = ctx_t
+        nl, B, Q, NC = logits.shape
+        with torch.cuda.device(logits.device):
+            rc = fn(logits.data_ptr(), counts.data_ptr(), boxes.data_ptr(), mq.data_ptr(), mt.data_ptr(),
+                    vid.data_ptr(), tbase.data_ptr(), ent_start.data_ptr(), labels.data_ptr(), tboxes.data_ptr(),
+                    gt_counts.data_ptr(), ccr.data_ptr(), nl, B, Q, NC, counts.shape[-1], mq.shape[-1],
+                    labels.shape[0], *cfg, *[o.data_ptr() for o in outs], torch.cuda.current_stream().cuda_stream)
+        return rc
+
+    @staticmethod
+    def forward(ctx, logits, counts, boxes, mq, mt, vid, tbase, ent_start, labels, tboxes, gt_counts, ccr, num_boxes,
+                alpha, gamma, beta, gau_mask):
+        tensors = (logits.contiguous(), counts.contiguous(), boxes.contiguous(), mq.contiguous(), mt.contiguous(), vid,
+                   tbase, ent_start, labels.contiguous(), tboxes.float().contiguous(), gt_counts, ccr)
+        cfg = (float(num_boxes), float(alpha), float(gamma), float(beta), int(bool(gau_mask)))
+        losses = torch.empty((logits.shape[0], len(LOSS_KEYS)), dtype=torch.float32, device=logits.device)
+        _lib.check(SetCriterionFunction._call(_lib.lib().gvl_set_criterion_forward_f32, tensors, cfg, losses),
+                   "set_criterion_forward")
+        ctx.save_for_backward(*tensors)
+        ctx.cfg = cfg
+        return losses
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_losses):
+        tensors = ctx.saved_tensors
+        g_logits, g_counts, g_boxes = (torch.empty_like(t_) for t_ in tensors[:3])
+        _lib.check(SetCriterionFunction._call(_lib.lib().gvl_set_criterion_backward_f32, tensors, ctx.cfg,
+                                              grad_losses.contiguous(), g_logits, g_counts, g_boxes),
+                   "set_criterion_backward")
+        return (g_logits, g_counts, g_boxes) + (None,) * 14
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, losses, focal_alpha=0.25, focal_gamma=2, opt={}):
         super().__init__()
@@ -66,6 +110,7 @@ class SetCriterion(nn.Module):
         self.opt = opt
         self.counter_class_rate = torch.tensor(COUNTER_CLASS_RATE)
         self.device_matching = True      # solve the Hungarian problems on the GPU (bit-identical to scipy)
+        self.fused = True                # all layers' losses in one HIP launch per direction (SetCriterionFunction)
         self._const_cache = {}
 
     @staticmethod
@@ -151,6 +196,33 @@ class SetCriterion(nn.Module):
         losses['loss_self_iou'] = (per_video / (0.5 * cntf * (cntf - 1))).sum()
         return losses
 
+    def _fused_losses(self, layers, matches, num_boxes):
+        """every loss term of every decoder layer from ONE autograd node (SetCriterionFunction)"""
+        plan = matches[0].plan
+        nl = len(layers)
+        logits = torch.stack([o['pred_logits'] for o in layers])
+        counts = torch.stack([o['pred_count'] for o in layers])
+        boxes = torch.stack([o['pred_boxes'] for o in layers])
+        rows, cols = matches[0].rows_all, matches[0].cols_all           # (nl * t1 + ...) laid out layer-major
+        mq, mt = rows[:nl * plan.t1].view(nl, plan.t1), cols[:nl * plan.t1].view(nl, plan.t1)
+        dev = logits.device
+        max_length = counts.shape[-1] - 1
+        wkey = ("ccr", max_length, str(dev))
+        ccr = self._const_cache.get(wkey)
+        if ccr is None:
+            ccr = self._const_cache[wkey] = self.counter_class_rate[:max_length + 1].to(dev)
+        table = SetCriterionFunction.apply(
+            logits, counts, boxes, mq, mt, plan.vid_of_entry, plan.tgt_base, plan.ent_start, self._tgt_cat[0],
+            self._tgt_cat[1], self._gt_counts, ccr, num_boxes, self.focal_alpha, self.focal_gamma,
+            getattr(self.opt, "lloss_beta", 1), getattr(self.opt, "lloss_gau_mask", 1))
+        flat = table.flatten().unbind(0)
+        losses = {}
+        for l in range(nl):
+            suffix = "" if l == 0 else f"_{l - 1}"
+            for k, name in enumerate(LOSS_KEYS):
+                losses[name + suffix] = flat[l * len(LOSS_KEYS) + k]
+        return losses
+
     def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
         table = {'labels': self.loss_labels, 'cardinality': self.loss_cardinality, 'boxes': self.loss_boxes}
         assert loss in table, f'do you really want to compute {loss} loss?'
@@ -190,6 +262,13 @@ class SetCriterion(nn.Module):
             num_boxes = torch.clamp(nb / get_world_size(), min=1).item()
         else:
             num_boxes = max(float(num_boxes), 1.0)                     # same value, no device round trip
+        if (self.fused and batched is not None and hasattr(last_indices, "plan") and dev.type == "cuda"
+                and set(self.losses) == {'labels', 'boxes', 'cardinality'} and outputs['pred_logits'].dtype == torch.float32
+                and outputs['pred_logits'].shape[0] * outputs['pred_logits'].shape[1] <= 24576):
+            losses = self._fused_losses([main] + list(aux_list), batched, num_boxes)
+            if 'aux_outputs' in outputs:
+                return losses, last_indices, list(batched[1:])
+            return losses, last_indices
         losses = {}
         for loss in self.losses:
             losses.update(self.get_loss(loss, outputs, targets, last_indices, num_boxes))

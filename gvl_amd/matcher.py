@@ -123,6 +123,10 @@ class MatchPlan:
         self.slot_of_entry = torch.tensor([k for n in self.n1 for k in range(n)], dtype=torch.int64, device=device)
         self.tgt_base = torch.tensor([coff[i] for i in vid1], dtype=torch.int64, device=device)
         self.cnt = torch.tensor(self.n1, dtype=torch.int64, device=device)
+        starts = [0]
+        for k in self.n1:
+            starts.append(starts[-1] + k)
+        self.ent_start = torch.tensor(starts, dtype=torch.int64, device=device)       # first pair of every video
 
 
 class LayerMatch:
@@ -137,6 +141,7 @@ class LayerMatch:
         b = plan.nl * plan.t1 + layer * plan.t4
         self.rl_q, self.rl_t = rows[b:b + plan.t4], cols[b:b + plan.t4]
         self.status, self.ok = status, ok
+        self.rows_all, self.cols_all = rows, cols       # all layers, for consumers that process the layers together
         self._host = None
 
     @property
@@ -147,7 +152,7 @@ class LayerMatch:
         """raises what the reference raises (scipy ValueError / box_ops assert); costs one tiny device->host read"""
         if int(self.status) != 0:
             raise ValueError("cost matrix is infeasible / contains invalid numeric entries")
-        assert bool(self.ok), "degenerate boxes (x1 < x0) in the matcher"
+        assert bool(self.ok.all()), "degenerate boxes (x1 < x0) in the matcher"
 
     def host(self):
         if self._host is None:
@@ -223,13 +228,39 @@ class HungarianMatcher(nn.Module):
         index tensors stay on the device; LayerMatch[0] / [1] materialise the reference's (indices, rl_indices)."""
         sizes = [len(v["boxes"]) for v in targets]
         tgt_cat = (torch.cat([v["labels"] for v in targets]), torch.cat([v["boxes"] for v in targets]))
-        Cs, oks = zip(*[self.cost_matrix(o, targets, tgt_cat, with_flag=True) for o in outputs_list])
-        C = torch.stack(Cs).float().contiguous()                      # (nl, B, Q, G)
+        C, ok = self.cost_matrices(outputs_list, targets, tgt_cat)    # (nl, B, Q, G)
         nl, B, Q, G = C.shape
         plan = self._plan(nl, B, Q, sizes, C.device)
         rows, cols, status = lsap_batch_device(C, plan.problems, plan.out_total, plan.max_rows, plan.max_cols)
-        ok = torch.stack(oks).all()
         return [LayerMatch(plan, l, rows, cols, status, ok) for l in range(nl)]
+
+    @torch.no_grad()
+    def cost_matrices(self, outputs_list, targets, tgt_cat, fused=None):
+        """cost tensors of all decoder layers (nl, B, Q, G) + the degenerate-box flag.  One HIP launch
+        (gvl_match_cost_f32) when only the class / box / GIoU terms contribute; the PyTorch op sequence of
+        ``cost_matrix`` per layer otherwise (contrastive / caption cost terms)."""
+        first = outputs_list[0]
+        fused = getattr(self, "fused_cost", True) if fused is None else fused
+        extra = any(isinstance(o.get('cl_match_mats', 0), torch.Tensor) and self.cost_cl != 0 for o in outputs_list) \
+            or (self.opt is not None and getattr(self.opt, "set_cost_caption", 0) > 0
+                and any('cap_cost_mat' in o for o in outputs_list))
+        if fused and not extra and first["pred_logits"].is_cuda and first["pred_logits"].dtype == torch.float32:
+            logits = torch.stack([o["pred_logits"] for o in outputs_list]).contiguous()
+            boxes = torch.stack([o["pred_boxes"] for o in outputs_list]).contiguous()
+            nl, B, Q, NC = logits.shape
+            labels, tboxes = tgt_cat[0].contiguous(), tgt_cat[1].float().contiguous()
+            G = labels.shape[0]
+            C = torch.empty((nl, B, Q, G), dtype=torch.float32, device=logits.device)
+            ok = torch.ones(1, dtype=torch.int32, device=logits.device)
+            with torch.cuda.device(logits.device):
+                rc = _lib.lib().gvl_match_cost_f32(
+                    logits.data_ptr(), boxes.data_ptr(), labels.data_ptr(), tboxes.data_ptr(), nl, B, Q, NC, G,
+                    float(self.cost_class), float(self.cost_bbox), float(self.cost_giou), float(self.cost_alpha),
+                    float(self.cost_gamma), C.data_ptr(), ok.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "match_cost")
+            return C, ok
+        Cs, oks = zip(*[self.cost_matrix(o, targets, tgt_cat, with_flag=True) for o in outputs_list])
+        return torch.stack(Cs).float().contiguous(), torch.stack(oks).all()
 
     @torch.no_grad()
     def match_layers(self, outputs_list, targets):

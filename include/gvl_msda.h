@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 3   /* 2: + bf16 storage twins; 3: + training-time captioner step (earlier entry points unchanged) */
+#define GVL_MSDA_ABI_VERSION 3   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion (earlier entry points unchanged) */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -64,6 +64,44 @@ const char *gvl_last_error(void);
 void gvl_msda_set_impl(int impl);
 /* Which family the most recent forward/backward call on this thread used: 1 generic, 2 fast, 3 fused. */
 int gvl_msda_last_impl(void);
+
+/* -- matcher cost matrix for ALL decoder layers in one launch: replaces the tensor-op sequence of
+ *    HungarianMatcher.forward (pdvc/matcher.py:74-105 with misc/detr_utils/box_ops.py:8-47):
+ *      cost[l,b,q,g] = w_bbox * L1(box, tgt_box) + w_class * (focal_pos - focal_neg)[tgt_label] + w_giou * (-GIoU_1D)
+ *    pred_logits (nl,B,Q,NC), pred_boxes (nl,B,Q,2) (centre,length), tgt_labels (G) int64, tgt_boxes (G,2);
+ *    cost (nl,B,Q,G).  Evaluated with one rounding per operation in the reference's order (no FMA contraction): the
+ *    GIoU term is bit-identical to the PyTorch op sequence, the focal term within 1-2 ulp (device expf / logf).  *ok (device int, preset to 1 by the caller) is cleared when a box has
+ *    x1 < x0 (the asserts of box_ops.py:39-40). */
+int gvl_match_cost_f32(const float *pred_logits, const float *pred_boxes, const int64_t *tgt_labels,
+                       const float *tgt_boxes, int n_layers, int B, int Q, int n_classes, int G, float w_class,
+                       float w_bbox, float w_giou, float alpha, float gamma, float *cost, int *ok, void *stream);
+
+/* -- set criterion of ALL decoder layers: replaces SetCriterion.loss_labels / loss_boxes / loss_cardinality
+ *    (pdvc/criterion.py:48-132) with sigmoid_focal_loss (:232-257) and cross_entropy_with_gaussian_mask (:209-229).
+ *      pred_logits (nl,B,Q,NC), pred_count (nl,B,count_bins), pred_boxes (nl,B,Q,2)
+ *      match_q / match_t (nl, n_pairs) int64   matched query / video-local target of every pair (pairs sorted by video)
+ *      pair_video, pair_target_base (n_pairs)  video of the pair, first row of that video in the concatenated targets
+ *      video_pair_start (B+1)                  first pair of every video
+ *      tgt_labels (G), tgt_boxes (G,2), gt_counts (B) int64, counter_class_rate (count_bins)
+ *    forward : losses (nl, 6) = [loss_ce, loss_counter, loss_bbox, loss_giou, loss_self_iou, cardinality_error]
+ *    backward: grad_losses (nl, 6) -> grad_logits, grad_count, grad_boxes (same shapes as the predictions, fully
+ *              written), with PyTorch's subgradient conventions. */
+int gvl_set_criterion_forward_f32(const float *pred_logits, const float *pred_count, const float *pred_boxes,
+                                  const int64_t *match_q, const int64_t *match_t, const int64_t *pair_video,
+                                  const int64_t *pair_target_base, const int64_t *video_pair_start,
+                                  const int64_t *tgt_labels, const float *tgt_boxes, const int64_t *gt_counts,
+                                  const float *counter_class_rate, int n_layers, int B, int Q, int n_classes,
+                                  int count_bins, int n_pairs, int G, float num_boxes, float focal_alpha,
+                                  float focal_gamma, float lloss_beta, int lloss_gau_mask, float *losses,
+                                  void *stream);
+int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_count, const float *pred_boxes,
+                                   const int64_t *match_q, const int64_t *match_t, const int64_t *pair_video,
+                                   const int64_t *pair_target_base, const int64_t *video_pair_start,
+                                   const int64_t *tgt_labels, const float *tgt_boxes, const int64_t *gt_counts,
+                                   const float *counter_class_rate, int n_layers, int B, int Q, int n_classes,
+                                   int count_bins, int n_pairs, int G, float num_boxes, float focal_alpha,
+                                   float focal_gamma, float lloss_beta, int lloss_gau_mask, const float *grad_losses,
+                                   float *grad_logits, float *grad_count, float *grad_boxes, void *stream);
 
 /* -- kernel timing inside the library (measurement only; no reference equivalent).  While enabled, every kernel the
  *    library launches is dispatched with hipExtLaunchKernel start/stop events on the launch stream, i.e. the
@@ -85,6 +123,8 @@ int gvl_msda_last_impl(void);
 #define GVL_PROF_CAP_TRAIN_FWD 12
 #define GVL_PROF_CAP_TRAIN_BWD 13
 #define GVL_PROF_LSTM_TRAIN 14
+#define GVL_PROF_MATCH_COST 15
+#define GVL_PROF_CRITERION 16
 int gvl_prof_enable(int on);
 int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
 

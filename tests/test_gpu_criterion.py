@@ -1,0 +1,92 @@
+"""Fused matcher-cost / set-criterion kernels (gvl_criterion.hip) against the PyTorch op sequences that mirror the
+reference (gvl_amd.matcher.HungarianMatcher.cost_matrix, gvl_amd.criterion.SetCriterion.loss_* -- themselves pinned to
+the reference by the eval / train goldens in test_gpu_model.py)."""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make(B, Q, NC, sizes, nl, seed, dev, degenerate=False):
+    g = torch.Generator().manual_seed(seed)
+    layers = []
+    for _ in range(nl):
+        boxes = torch.stack([torch.rand(B, Q, generator=g), torch.rand(B, Q, generator=g) * 0.5 + 0.01], -1)
+        layers.append({"pred_logits": torch.randn(B, Q, NC, generator=g).to(dev).requires_grad_(),
+                       "pred_count": torch.randn(B, 11, generator=g).to(dev).requires_grad_(),
+                       "pred_boxes": boxes.to(dev).requires_grad_()})
+    targets = []
+    for n in sizes:
+        tb = torch.stack([torch.rand(n, generator=g) * 0.5 + 0.25, torch.rand(n, generator=g) * 0.3 + 0.1], -1)
+        targets.append({"boxes": tb.to(dev), "labels": torch.randint(0, NC, (n,), generator=g).to(dev)})
+    if degenerate:
+        # ties for the subgradient conventions: a prediction equal to its target, two identical predictions
+        with torch.no_grad():
+            for o in layers:
+                o["pred_boxes"][0, 0] = targets[0]["boxes"][0]
+                o["pred_boxes"][0, 1] = targets[0]["boxes"][0]
+                o["pred_boxes"][0, 2] = torch.tensor([0.1, 0.05], device=dev)      # disjoint from everything
+    return layers, targets
+
+
+def build_criterion(NC):
+    from gvl_amd.criterion import SetCriterion
+    from gvl_amd.matcher import HungarianMatcher
+    opt = argparse.Namespace(lloss_gau_mask=1, lloss_beta=1, set_cost_caption=0)
+    matcher = HungarianMatcher(cost_class=2, cost_bbox=0, cost_giou=4, cost_alpha=0.25, cost_gamma=2, cost_cl=2.0, opt=opt)
+    return SetCriterion(NC, matcher, {}, ['labels', 'boxes', 'cardinality'], focal_alpha=0.25, focal_gamma=2, opt=opt)
+
+
+@pytest.mark.parametrize("NC,w_bbox", [(1, 0.0), (3, 0.0), (1, 1.5)])
+def test_match_cost_kernel_equals_torch_sequence(NC, w_bbox):
+    dev = torch.device("cuda:0")
+    layers, targets = make(4, 37, NC, [3, 1, 5, 2], 2, 1, dev)
+    crit = build_criterion(NC)
+    m = crit.matcher
+    m.cost_bbox = w_bbox
+    tgt_cat = (torch.cat([v["labels"] for v in targets]), torch.cat([v["boxes"] for v in targets]))
+    Cf, okf = m.cost_matrices(layers, targets, tgt_cat, fused=True)
+    Ct, okt = m.cost_matrices(layers, targets, tgt_cat, fused=False)
+    assert bool(okf.all()) and bool(okt)
+    # same operations in the same order, one rounding each; what remains is the last bit of expf / logf between this
+    # library's device libm calls and PyTorch's kernels (the GIoU term alone is bit-identical)
+    assert float((Cf - Ct).abs().max()) <= 2e-6
+    m.cost_class, keep = 0.0, m.cost_class
+    a, _ = m.cost_matrices(layers, targets, tgt_cat, fused=True)
+    b, _ = m.cost_matrices(layers, targets, tgt_cat, fused=False)
+    m.cost_class = keep
+    if w_bbox == 0.0:
+        assert torch.equal(a, b)
+    layers[1]["pred_boxes"].data[2, 5, 1] = -0.2         # x1 < x0: the reference asserts (box_ops.py:39-40)
+    _, okf = m.cost_matrices(layers, targets, tgt_cat, fused=True)
+    assert not bool(okf.all())
+
+
+@pytest.mark.parametrize("NC,sizes,degenerate", [(1, [3, 2, 4, 3], False), (1, [3, 2, 4, 3], True),
+                                                 (3, [2, 5, 3], False), (1, [3, 1, 2], False)])
+def test_fused_criterion_equals_torch_formulation(NC, sizes, degenerate):
+    from gvl_amd.criterion import LOSS_KEYS
+    dev = torch.device("cuda:0")
+    B = len(sizes)
+    res = {}
+    for fused in (True, False):
+        layers, targets = make(B, 41, NC, sizes, 2, 7, dev, degenerate)
+        crit = build_criterion(NC)
+        crit.fused = fused
+        outputs = dict(layers[0])
+        outputs["aux_outputs"] = [layers[1]]
+        losses, last, aux = crit(outputs, targets)
+        assert sorted(losses) == sorted([k for k in LOSS_KEYS] + [k + "_0" for k in LOSS_KEYS])
+        g = torch.Generator().manual_seed(3)
+        wts = {k: float(torch.rand(1, generator=g)) + 0.5 for k in sorted(losses)}
+        total = sum(losses[k] * wts[k] for k in sorted(losses) if "cardinality" not in k and not torch.isnan(losses[k]))
+        total.backward()
+        res[fused] = ({k: float(v) for k, v in losses.items()},
+                      [o[k].grad.clone() for o in layers for k in ("pred_logits", "pred_count", "pred_boxes")])
+    for k, v in res[False][0].items():
+        f = res[True][0][k]
+        assert (v != v and f != f) or abs(f - v) <= 2e-6 * max(1.0, abs(v)), (k, f, v)     # nan == nan (single match)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))

@@ -82,6 +82,21 @@ for l in launches:
             if inside(l, r) and (node is None or r.duration_ns() < node.duration_ns()):
                 node = r
         bwd[node.name().split(": ")[1] if node else "?"] += 1
+ops = [e for e in evs if e.name().startswith("aten::")]
+detail = {st: collections.Counter() for st in sys.argv[1:]}
+for l in launches:
+    for st in detail:
+        rng = [r for r in stages if r.name() == "stage:" + st and inside(l, r)]
+        if rng:
+            op = None
+            for o in ops:                              # outermost aten op containing the launch
+                if inside(l, o) and inside(o, rng[0]) and (op is None or o.duration_ns() > op.duration_ns()):
+                    op = o
+            detail[st][op.name() if op else "?"] += 1
+for st, c in detail.items():
+    print(f"aten ops launching kernels inside stage {st}:")
+    for k, v in c.most_common(40):
+        print(f"  {k:40s} {v:5d}")
 print("kernel launches in one eager train step:", len(launches))
 for k, v in cnt.most_common():
     print(f"  {k:28s} {v:6d}")
