@@ -178,9 +178,18 @@ def main():
         for head in model.caption_head:
             head.graph_decode = not a.no_graph
 
-        def step():
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
-                return model(dt, criterion, None, "queries", eval_mode=True)
+        if a.no_graph or a.dtype == "bf16":
+            def step():
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
+                    return model(dt, criterion, None, "queries", eval_mode=True)
+        else:
+            # the whole forward (not only the decoding loop) replayed from one hipGraph; the kernel stamps of the
+            # roofline block come from instrumented eager forwards after the timed region (as in --mode train)
+            from gvl_amd.parallel import GraphedEvalForward
+            graphed_eval = GraphedEvalForward(model, criterion)
+
+            def step():
+                return graphed_eval(dt)
     else:
         from gvl_amd.parallel import GraphedTrainStep, TrainStep
         model.train()
@@ -214,12 +223,16 @@ def main():
     MSDA.profile_enable(False)
     ktimes = kernel_times(MSDA.profile_collect())
     roofline_source = "per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region"
-    if a.mode == "train" and not a.no_graph:
+    if not a.no_graph and (a.mode == "train" or a.dtype == "f32"):
         # the timed steps are hipGraph replays: the library launches nothing at replay time, so the kernel stamps come
         # from two instrumented eager steps run right after the timed region (same process, same inputs)
         MSDA.profile_enable(True)
         for _ in range(2):
-            trainer._eager(dt)
+            if a.mode == "train":
+                trainer._eager(dt)
+            else:
+                with torch.no_grad():
+                    model(dt, criterion, None, "queries", eval_mode=True)
         torch.cuda.synchronize()
         MSDA.profile_enable(False)
         ktimes = kernel_times(MSDA.profile_collect())

@@ -431,6 +431,12 @@ class Captioner(nn.Module):
         sample_max = opt.get('sample_max', 1)
         temperature = opt.get('temperature', 1.0)
         memory, tshapes, lsi, mask, _ = self._level_inputs(others, reference)
+        if getattr(self, "defer_trim", False):
+            # caller is capturing the whole forward in a hipGraph (gvl_amd.parallel.GraphedEvalForward): no host read
+            # here; the untrimmed sequences are returned and the caller cuts them at `last_alive` after the replay
+            seq, seq_lp, self.last_alive = self._decode_device(hs, reference, memory, mask, others['valid_ratios'],
+                                                               tshapes, lsi, sample_max, temperature)
+            return seq, seq_lp
         use_graph = (getattr(self, "graph_decode", False) and sample_max and not torch.is_grad_enabled()
                      and getattr(tshapes, "_gvl_host_lengths", None) is not None)
         if use_graph:

@@ -481,3 +481,30 @@ def test_teacher_forced_loop_fused_equals_step_by_step(built, ref_dim):
         assert g is not None, k
         scale_ = max(1e-3, float(g_ref.abs().max()))
         assert float((g - g_ref).abs().max()) <= 2e-3 * scale_, (k, float((g - g_ref).abs().max()), scale_)
+
+
+def test_graphed_eval_forward_equals_eager(built):
+    """GraphedEvalForward (whole eval forward replayed from one hipGraph, caption tensor trimmed after the replay) returns
+    what the eager forward returns, also on a second batch of the same layout and again on the first one."""
+    from gvl_amd.parallel import GraphedEvalForward
+    f, model, criterion, dev = built
+    g = GraphedEvalForward(model, criterion)
+    dts = [to_dev(pdvc_dt(f), dev), to_dev(pdvc_dt(f), dev)]
+    dts[1]["video_tensor"] = dts[1]["video_tensor"] * 0.7 + 0.05
+    for k in (0, 1, 0):
+        with torch.no_grad():
+            ref_out, ref_loss = model(dts[k], criterion, None, "queries", eval_mode=True)
+        out, loss = g(dts[k])
+        assert out["seq"].shape == ref_out["seq"].shape and torch.equal(out["seq"], ref_out["seq"])
+        assert maxerr(out["caption_probs"]["cap_prob_eval"], ref_out["caption_probs"]["cap_prob_eval"]) < 1e-5
+        for key in ("pred_logits", "pred_boxes", "pred_count"):
+            assert maxerr(out[key], ref_out[key]) < 1e-5, key
+        for key, v in ref_loss.items():
+            assert maxerr(loss[key].reshape(()), v.reshape(())) < 1e-5 or (v != v).all(), key
+        for a_, b_ in zip(out["matched_indices"][0], ref_out["matched_indices"][0]):
+            assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1])
+    assert len(g.graphs) == 1
+    # eval golden through the graph as well
+    out, loss = g(dts[0])
+    assert torch.equal(out["seq"].cpu(), t(f["cuda.seq"]))
+    assert maxerr(out["pred_boxes"], f["cuda.pred_boxes"]) < 1e-4
