@@ -291,7 +291,9 @@ def main():
         "config": {"workload": f"cfgs/{a.cfg}.yml PDVC {'eval forward' if a.mode == 'eval' else 'train step'}"
                                f" B={B}/GPU T={a.T} L=4 Q={a.queries}, "
                                + ("captioner off (diagnostic)" if a.no_captioner else
-                                  f"LSTM-DSA greedy captioning {opt.max_caption_len + 1} steps")
+                                  f"LSTM-DSA greedy captioning of {opt.max_caption_len} tokens ({opt.max_caption_len} token steps; the "
+                                  f"reference's extra step after the last token is dead code -- never read -- and is "
+                                  f"not evaluated)")
                                + ", set criterion + Hungarian matcher on 3 GT/video",
                    "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
                    "global_batch": world * B, "parallelism": f"dp{world} (videos sharded, no data-path collective)"

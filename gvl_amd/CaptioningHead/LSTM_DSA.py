@@ -392,8 +392,11 @@ class Captioner(nn.Module):
                     it = torch.multinomial(prev, 1)
                     lp = logprobs.gather(1, it).view(-1)
                     it = it.view(-1)
-            out, (h, c) = self.core.step((emb_gates, it), (h, c), hs, ref_in, tshapes, lsi, const)
-            logits = self.logit(self.dropout(out))
+            if t < self.max_caption_len:
+                # (the reference also evaluates the LSTM step + vocabulary logits of the LAST token, LSTM_DSA.py:189-190,
+                #  and then leaves the loop without reading them)
+                out, (h, c) = self.core.step((emb_gates, it), (h, c), hs, ref_in, tshapes, lsi, const)
+                logits = self.logit(self.dropout(out))
             if t >= 1:
                 unfinished = (it > 0) if t == 1 else (unfinished & (it > 0))
                 alive.append(unfinished.any())
