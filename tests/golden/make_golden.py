@@ -425,6 +425,40 @@ def make_yc2():
     save("pdvc_yc2", **rec)
 
 
+def make_anet_full():
+    """BASELINE.json configs 1-2 at the REAL model dimensions (cfgs/anet_tsp_ssvg.yml: 512-d TSP features, T = 100,
+    300 queries, vocabulary 8517, 30 caption tokens) on a padded 2-video batch: evaluation forward of the reference,
+    CUDA-op semantics."""
+    opt, model, criterion, cc = build_pdvc("cfgs/anet_tsp_ssvg.yml",
+                                           dict(enable_contrastive=False, device="cpu", num_queries=300,
+                                                frame_embedding_num=100))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=100)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 2, 100
+    valid, n_gt = [100, 73], [3, 5]
+    dt = synth_dt(B, T, opt.feature_dim, valid=valid, n_gt=n_gt, seed=6)
+    with cuda_semantics(), torch.no_grad():
+        vf, mask, dur = dt["video_tensor"], ~dt["video_mask"], dt["video_length"][:, 1]
+        srcs, masks, pos = model.base_encoder(vf, mask, dur)
+        enc_in = model.transformer.prepare_encoder_inputs(srcs, masks, pos)
+        memory = model.transformer.forward_encoder(*enc_in)
+        out, loss = model(dt, criterion, cc, "queries", eval_mode=True)
+    rec = dict(meta_T=np.array(T), valid=np.array(valid), n_gt=np.array(n_gt), feature_dim=np.array(opt.feature_dim),
+               num_queries=np.array(opt.num_queries), vocab_size=np.array(opt.vocab_size),
+               max_caption_len=np.array(opt.max_caption_len),
+               param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]),
+               memory_rows=memory[:, ::4], memory_sum=memory.double().sum(),
+               pred_logits=out["pred_logits"], pred_boxes=out["pred_boxes"], pred_count=out["pred_count"],
+               seq=out["seq"], cap_prob_eval=out["caption_probs"]["cap_prob_eval"],
+               aux_pred_boxes=out["aux_outputs"][0]["pred_boxes"], event_feat=out["event_feat"][:, ::8])
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        rec[f"match_{i}"] = torch.stack([a, b])
+    for k, v in loss.items():
+        rec[f"loss.{k}"] = torch.as_tensor(v)
+    save("pdvc_anet_full", **rec)
+
+
 def make_train():
     """One training forward/backward of the reference (pdvc.py parallel_prediction_matched, train.py:403-406) with
     every dropout probability set to 0 so that the step is deterministic; CUDA-op (zero padding) semantics."""
@@ -508,6 +542,9 @@ if __name__ == "__main__":
     if "--only-init" in sys.argv:
         make_init()
         sys.exit(0)
+    if "--only-anet-full" in sys.argv:
+        make_anet_full()
+        sys.exit(0)
     if "--only-yc2" in sys.argv:
         make_yc2()
         sys.exit(0)
@@ -524,5 +561,6 @@ if __name__ == "__main__":
         make_pdvc()
         make_gtprop()
         make_yc2()
+        make_anet_full()
         make_train()
     make_init()

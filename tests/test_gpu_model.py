@@ -508,3 +508,46 @@ def test_graphed_eval_forward_equals_eager(built):
     out, loss = g(dts[0])
     assert torch.equal(out["seq"].cpu(), t(f["cuda.seq"]))
     assert maxerr(out["pred_boxes"], f["cuda.pred_boxes"]) < 1e-4
+
+
+# ---- BASELINE.json configs 1-2 at the real model dimensions (300 queries, vocabulary 8517, 30 tokens) ------------
+
+def test_anet_full_dimension_eval_matches_reference():
+    """cfgs/anet_tsp_ssvg.yml at its real dimensions, eager and through GraphedEvalForward, against the reference run:
+    encoder memory, heads, matched indices, losses; greedy captions row by row (a near-tie flip changes the rest of
+    that row, so rows are compared where the token sequences agree; >= 95 % of the tokens must agree)."""
+    from gvl_amd.config import make_opt
+    from gvl_amd.parallel import GraphedEvalForward
+    from gvl_amd.pdvc import build
+    dev = torch.device("cuda:0")
+    f = load("pdvc_anet_full")
+    opt = make_opt("anet_tsp_ssvg", num_queries=300, frame_embedding_num=100, device="cuda")
+    assert (opt.feature_dim, opt.vocab_size, opt.max_caption_len) == (int(f["feature_dim"]), int(f["vocab_size"]),
+                                                                      int(f["max_caption_len"]))
+    model, criterion, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f, seed=100), strict=True)
+    model = model.to(dev).eval()
+    dt = to_dev(pdvc_dt(f, feat=int(f["feature_dim"]), seed=6), dev)
+    graphed = GraphedEvalForward(model, criterion)
+    for mode in ("eager", "graph"):
+        with torch.no_grad():
+            memory = model.encode(dt)[0]
+            out, loss = model(dt, criterion, None, "queries", eval_mode=True) if mode == "eager" else graphed(dt)
+        ms = float(np.abs(f["memory_rows"]).max())
+        assert maxerr(memory[:, ::4], f["memory_rows"]) <= 2e-4 * max(1.0, ms)
+        assert maxerr(out["pred_boxes"], f["pred_boxes"]) <= 2e-4
+        assert maxerr(out["aux_outputs"][0]["pred_boxes"], f["aux_pred_boxes"]) <= 2e-4
+        assert maxerr(out["pred_logits"], f["pred_logits"]) <= 1e-3
+        assert maxerr(out["pred_count"], f["pred_count"]) <= 1e-3
+        assert maxerr(out["event_feat"][:, ::8], f["event_feat"]) <= 1e-3 * max(1.0, float(np.abs(f["event_feat"]).max()))
+        for i in range(len(out["matched_indices"][0])):
+            assert torch.equal(torch.stack(out["matched_indices"][0][i]), t(f[f"match_{i}"]))
+        for k in ("loss_ce", "loss_giou", "loss_counter", "loss_self_iou"):
+            assert maxerr(loss[k].reshape(()), f[f"loss.{k}"].reshape(())) <= 1e-3, k
+        seq, ref_seq = out["seq"].cpu(), t(f["seq"])
+        assert seq.shape == ref_seq.shape == (2, 300, int(f["max_caption_len"]))
+        seq, ref_seq = seq.reshape(-1, seq.shape[-1]), ref_seq.reshape(-1, ref_seq.shape[-1])
+        row_same = (seq == ref_seq).all(1)
+        assert float((seq == ref_seq).float().mean()) >= 0.95 and float(row_same.float().mean()) >= 0.85
+        lp = out["caption_probs"]["cap_prob_eval"].float().cpu().reshape(-1, seq.shape[-1])
+        assert maxerr(lp[row_same], t(f["cap_prob_eval"]).reshape(-1, seq.shape[-1])[row_same]) <= 2e-3

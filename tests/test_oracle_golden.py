@@ -113,6 +113,31 @@ def test_torch_oracle_pdvc_eval(tag, pad):
         assert torch.equal(torch.stack(rl[i]), t(f[f"{tag}.rl_match_{i}"]))
 
 
+@pytest.mark.parametrize("name,seed,dt_seed,cap_len", [("pdvc_anet_full", 100, 6, 30), ("pdvc_yc2", 512, 4, 8)])
+def test_torch_oracle_full_dimension_configs(name, seed, dt_seed, cap_len):
+    """the CPU restatement at the REAL dimensions of BASELINE configs 1-2 (anet: 300 queries, vocabulary 8517) and
+    4 (yc2: 3072-d input, T = 512) against the reference's own run of those configs"""
+    f = load(name)
+    sd = pdvc_state(f, seed=seed)
+    dt = pdvc_dt(f, feat=int(f["feature_dim"]), seed=dt_seed)
+    with torch.no_grad():
+        out = R.pdvc_eval_forward(sd, dt, pad_mode="zeros", max_caption_len=cap_len)
+    stride = 4 if name == "pdvc_anet_full" else 8
+    assert maxerr(out["memory"][:, ::stride], f["memory_rows"]) < 2e-4 * max(1.0, float(np.abs(f["memory_rows"]).max()))
+    assert maxerr(out["pred_boxes"], f["pred_boxes"]) < 5e-4
+    assert maxerr(out["pred_logits"], f["pred_logits"]) < 5e-3
+    assert maxerr(out["pred_count"], f["pred_count"]) < 5e-3
+    seq, ref_seq = out["seq"].reshape(-1, out["seq"].shape[-1]), t(f["seq"]).reshape(-1, f["seq"].shape[-1])
+    n = min(seq.shape[1], ref_seq.shape[1])
+    assert float((seq[:, :n] == ref_seq[:, :n]).float().mean()) >= 0.95
+    tg = dt["video_target"]
+    C = R.matcher_cost(out["pred_logits"], out["pred_boxes"], torch.cat([x["labels"] for x in tg]),
+                       torch.cat([x["boxes"] for x in tg]))
+    idx, _ = R.hungarian(C, [len(x["boxes"]) for x in tg])
+    for i in range(len(tg)):
+        assert torch.equal(torch.stack(idx[i]), t(f[f"match_{i}"]))
+
+
 def test_torch_oracle_captioner_step():
     f = load("captioner_step")
     sd = pdvc_state(load("pdvc_eval"))
