@@ -295,10 +295,11 @@ class Captioner(nn.Module):
                 w.new_zeros(self.num_layers, batch_size, self.rnn_size))
 
     def build_loss(self, input, target, mask):
-        """LSTM_DSA.py:48-52"""
-        one_hot = F.one_hot(target, self.opt.vocab_size + 1)
+        """LSTM_DSA.py:48-52.  The reference multiplies by a materialised one-hot (n, len, vocab+1) tensor and sums the
+        vocabulary axis: a sum of one term and zeros, i.e. exactly the gathered log-prob -- taken directly here."""
         max_len = input.shape[1]
-        return -(one_hot[:, :max_len] * input * mask[:, :max_len, None]).sum(2).sum(1) / (mask.sum(1) + 1e-6)
+        picked = input.gather(2, target[:, :max_len, None]).squeeze(2)
+        return -(picked * mask[:, :max_len]).sum(1) / (mask.sum(1) + 1e-6)
 
     def _scaled_reference(self, reference, others):
         vr = others['valid_ratios']

@@ -99,6 +99,7 @@ __device__ inline Geo border_geo(float loc, int T) {
 }
 
 struct RowSetup {
+  bool with_len;            // reference point carries a length (RD = 2 and ref_len >= 0)
   int roff;                 // slab row of the lane group's sample (level start + r)
   float c_lo, c_hi, dmul;   // interpolation coefficients, d pixel / d loc
   float doff;               // d loc / d offset
@@ -108,7 +109,7 @@ struct RowSetup {
 
 __device__ inline RowSetup setup_row(const int64_t *shapes, const int64_t *lsi, const float *ref, const float *off_hs,
                                      const float *off_h, int64_t row, int k_own, int L, int P, int RD) {
-  RowSetup s = {0, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+  RowSetup s = {false, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
   const int LP = L * P;
   if (k_own < LP) {
     const int l = k_own / P;
@@ -117,7 +118,10 @@ __device__ inline RowSetup setup_row(const int64_t *shapes, const int64_t *lsi, 
     s.level = l;
     s.off = off_hs[row * LP + k_own] + off_h[k_own];
     float locx;
-    if (RD == 1) { locx = rp[0] + s.off / (float)T; s.doff = 1.f / (float)T; }               // for_caption.py:108-109
+    // RD = 2 rows with a NEGATIVE length are centre-only reference points stored in the two-component layout (lets
+    // one launch serve decoder layers with both reference forms)
+    s.with_len = RD == 2 && rp[1] >= 0.f;
+    if (!s.with_len) { locx = rp[0] + s.off / (float)T; s.doff = 1.f / (float)T; }           // for_caption.py:108-109
     else { locx = rp[0] + s.off / (float)P * rp[1] * 0.5f; s.doff = rp[1] * 0.5f / (float)P; }  // :110-112
     const Geo g = border_geo(locx, T);
     s.roff = (int)lsi[l] + g.r;
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(64) k_cap_train_bwd(
     if (k_own < LP) {
       float *gr = g_ref + (row * L + rs.level) * RD;
       atomicAdd(gr, dloc);
-      if (RD == 2) atomicAdd(gr + 1, dloc * rs.off * (0.5f / (float)P));
+      if (rs.with_len) atomicAdd(gr + 1, dloc * rs.off * (0.5f / (float)P));
     }
   }
 }

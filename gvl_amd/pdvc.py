@@ -269,6 +269,18 @@ class PDVC(nn.Module):
             loss, last_indices = criterion(out, dt['video_target'])
             aux_indices = None
             layers = [num_pred - 1]
+        layers = list(layers)
+        matches = [last_indices if l_id == num_pred - 1 else aux_indices[l_id] for l_id in layers]
+        refs = [init_reference if l_id == 0 else inter_references[l_id - 1] for l_id in layers]
+        if self._one_pass_captioning(layers, matches, hs, dt):
+            # every decoder layer's caption loss from ONE pass of the shared caption head over all layers' matched
+            # queries (the value / ctx2att slab, the token loop and every weight gradient are then computed once)
+            cap_losses, probs, seq = self.caption_prediction_layers(self.caption_head[layers[-1]], dt,
+                                                                    [hs[l_id] for l_id in layers], refs, others, matches)
+            for l_id, cap_loss in zip(layers, cap_losses):
+                loss['loss_caption' if l_id == num_pred - 1 else f'loss_caption_{l_id}'] = cap_loss
+            out.update({'caption_probs': probs, 'seq': seq})
+            return out, loss
         for l_id in layers:
             reference = init_reference if l_id == 0 else inter_references[l_id - 1]
             layer_match = last_indices if l_id == num_pred - 1 else aux_indices[l_id]
@@ -281,6 +293,58 @@ class PDVC(nn.Module):
             loss[key] = cap_loss
         out.update({'caption_probs': probs, 'seq': seq})
         return out, loss
+
+    def _one_pass_captioning(self, layers, matches, hs, dt):
+        head = self.caption_head[layers[-1]]
+        return (self.training and len(layers) > 1 and getattr(self, "one_pass_captioning", True)
+                and all(hasattr(m, "plan") for m in matches)
+                and all(self.caption_head[l_id] is head for l_id in layers)
+                and not vars(self.opt).get('enable_pos_emb_for_captioner', False)
+                and getattr(head, "ss_prob", 0.0) == 0.0 and hasattr(head, "core")
+                and head.core.fused_train_eligible(hs[0]) and torch.is_grad_enabled()
+                and all(len(t_['boxes']) <= hs.shape[2] for t_ in dt['video_target']))
+
+    def caption_prediction_layers(self, cap_head, dt, hs_layers, ref_layers, others, matches):
+        """caption_prediction for all decoder layers at once (shared head): the matched queries of layer k of video v
+        occupy rows [k * max_pairs, (k + 1) * max_pairs) of video v.  Layers whose reference points are centre-only
+        (decoder input, ref-dim 1) travel in the two-component layout with length -1 (include/gvl_msda.h)."""
+        nl = len(matches)
+        plan = matches[0].plan
+        N_, N_q, C = hs_layers[0].shape
+        dev = hs_layers[0].device
+        cap_len = dt['cap_tensor'].shape[-1]
+        mp = max(plan.n1)
+        cache = plan.__dict__.setdefault("_cap_rows", {})
+        rows = cache.get(nl)
+        if rows is None:          # static (host-known) positions, built once per matching plan
+            t1 = plan.vid_of_entry.numel()
+            rows = cache[nl] = (plan.vid_of_entry.repeat(nl),
+                                torch.cat([plan.slot_of_entry + k * mp for k in range(nl)]),
+                                torch.arange(nl, device=dev).repeat_interleave(t1))
+        vid_all, slot_all, lay_all = rows
+        q_all = torch.cat([m.q for m in matches])
+        caps_all = torch.cat([m.t_global for m in matches])
+        hs_stack = torch.stack(hs_layers)
+        ref_stack = torch.stack([r if r.shape[-1] == 2 else torch.cat([r, torch.full_like(r, -1.0)], -1)
+                                 for r in ref_layers])
+        hs_m = hs_stack.new_zeros(N_, nl * mp, C)
+        ref_m = hs_stack.new_zeros(N_, nl * mp, 2)
+        seq_m = torch.zeros(N_, nl * mp, cap_len, dtype=torch.long, device=dev)
+        mask_m = torch.zeros(N_, nl * mp, cap_len, dtype=torch.bool, device=dev)
+        hs_m[vid_all, slot_all] = hs_stack[lay_all, vid_all, q_all]
+        ref_m[vid_all, slot_all] = ref_stack[lay_all, vid_all, q_all]
+        seq_m[vid_all, slot_all] = dt['cap_tensor'][caps_all].long()
+        mask_m[vid_all, slot_all] = dt['cap_mask'][caps_all].bool()
+        seq_flat, mask_flat = seq_m.flatten(0, 1), mask_m.flatten(0, 1)
+        steps = dt.get('_gvl_cap_steps')
+        if steps is None:
+            live = (dt['cap_tensor'][:, 1:] != 0).any(0).cpu().tolist()
+            steps = min(1 + (live.index(False) if False in live else len(live)), cap_len - 1)
+            dt['_gvl_cap_steps'] = steps
+        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=steps)
+        row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
+        per_layer = row_loss.view(N_, nl, mp).mean(dim=(0, 2))
+        return per_layer.unbind(0), {}, dt['cap_tensor'][matches[-1].t_global]
 
     def caption_prediction(self, cap_head, dt, hs, reference, others, indices):
         """Teacher-forced caption loss on the matched (query, caption) pairs (pdvc.py:743-884, 'standard' head):

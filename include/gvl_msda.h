@@ -250,7 +250,9 @@ int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int l
  *    launch-bound in PyTorch; here a step is  GEMM, gvl_cap_attend_train_forward, GEMM, gvl_lstm_cell_train_forward
  *    and its backward  gvl_lstm_cell_train_backward, GEMM, gvl_cap_attend_train_backward, GEMM.
  *      slab      (B, S, 2C)   [value_proj(memory) | ctx2att(value_proj(memory))], C = 512
- *      ref       (B, Q, L, RD) reference points scaled by the valid ratios
+ *      ref       (B, Q, L, RD) reference points scaled by the valid ratios; with RD = 2 a row whose length component
+ *                is NEGATIVE is a centre-only point (RD = 1 arithmetic, no length gradient): one launch can then
+ *                serve decoder layers with both reference forms
  *      off_hs    (B*Q, L*P)   sampling_offsets bias + hs part;  off_h (B*Q, L*P; row stride off_h_ld) its h part
  *      att_h     (B*Q, C; row stride att_h_ld)   h2att(h)
  *      alpha_w (C), alpha_b (1, DEVICE pointer)  alpha_net
