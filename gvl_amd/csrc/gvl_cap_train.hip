@@ -9,7 +9,7 @@
 //     k_lstm_train_bwd  ->  GEMM  ->  k_cap_train_bwd  ->  GEMM,
 // with all weight gradients deferred to one GEMM per weight after the time loop (gvl_amd/CaptioningHead/LSTM_DSA.py).
 //
-//   k_cap_train_fwd   one wavefront per (video, matched query) row, lane = 8 of the 512 channels:
+//   k_cap_train_fwd   one workgroup (4 wavefronts x 4 samples) per (video, matched query) row, lane = 8 of the 512 channels:
 //                       x_k    = ref + off_k / T_l   |   ref_c + off_k / P * ref_len * 0.5        (16 samples)
 //                       clip_k = border-padded linear sample of value_proj(memory) at x_k
 //                       e_k    = alpha_w . tanh(ctx2att(clip_k) + h2att(h)) + alpha_b ;  alpha = softmax_k(e)
@@ -131,24 +131,39 @@ __device__ inline RowSetup setup_row(const int64_t *shapes, const int64_t *lsi, 
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_cap_train_fwd(
+// One WORKGROUP of 4 wavefronts per (video, matched query) row: wavefront w owns samples 4w..4w+3 (a row's work is a
+// chain of 16 dependent gather -> reduce steps, and only ~100 rows exist, so the parallelism has to come from inside
+// the row); lane = 8 of the 512 channels as in gvl_cap.hip.  Per-sample scalars meet in LDS.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRowWaves = 4;
+constexpr int kPerWave = kLP / kRowWaves;
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(kRowWaves * 64) k_cap_train_fwd(
     const float *__restrict__ slab, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ ref, const float *__restrict__ off_hs, const float *__restrict__ off_h, int off_h_ld,
     const float *__restrict__ att_h, int att_h_ld, const float *__restrict__ alpha_w,
     const float *__restrict__ alpha_b, int S, int L, int Q, int P, int RD, float *__restrict__ att_res,
     float *__restrict__ alpha_out) {
+  __shared__ float sh_e[kLP];
+  __shared__ float sh_acc[kRowWaves][64][8];
   const int64_t row = blockIdx.x;
-  const int lane = threadIdx.x, k_own = lane >> 2, LP = L * P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k_own = lane >> 2, LP = L * P;
   const int b = (int)(row / Q);
   const RowSetup rs = setup_row(shapes, lsi, ref, off_hs, off_h + row * (int64_t)off_h_ld, row, k_own, L, P, RD);
   const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * (int64_t)att_h_ld);
   const float4 ta = ah4[lane], tb = ah4[64 + lane];
   const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
   const float4 *slab4 = reinterpret_cast<const float4 *>(slab) + (int64_t)b * S * (2 * kC / 4);
-  float e[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    e[k] = 0.f;
+  for (int i = 0; i < kPerWave; ++i) {
+    const int k = wave * kPerWave + i;
+    float s = 0.f;
     if (k < LP) {
       const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
       const float cl = bcast(rs.c_lo, 4 * k), ch = bcast(rs.c_hi, 4 * k);
@@ -156,7 +171,6 @@ __global__ void __launch_bounds__(64) k_cap_train_fwd(
       const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4) + kC / 4;
       const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4) + kC / 4;
       const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
-      float s = 0.f;
       s = fmaf(qa.x, fast_tanh(fmaf(cl, l0.x, fmaf(ch, u0.x, ta.x))), s);
       s = fmaf(qa.y, fast_tanh(fmaf(cl, l0.y, fmaf(ch, u0.y, ta.y))), s);
       s = fmaf(qa.z, fast_tanh(fmaf(cl, l0.z, fmaf(ch, u0.z, ta.z))), s);
@@ -165,19 +179,21 @@ __global__ void __launch_bounds__(64) k_cap_train_fwd(
       s = fmaf(qb.y, fast_tanh(fmaf(cl, l1.y, fmaf(ch, u1.y, tb.y))), s);
       s = fmaf(qb.z, fast_tanh(fmaf(cl, l1.z, fmaf(ch, u1.z, tb.z))), s);
       s = fmaf(qb.w, fast_tanh(fmaf(cl, l1.w, fmaf(ch, u1.w, tb.w))), s);
-      e[k] = s;
     }
+    s = wave_sum(s);
+    if (lane == 0) sh_e[k] = s;
   }
-  float ek = butterfly16(e, lane) + alpha_b[0];
-  if (k_own >= LP) ek = -INFINITY;
+  __syncthreads();
+  float ek = k_own < LP ? sh_e[k_own] + alpha_b[0] : -INFINITY;     // lane group k holds e_k, as in the inference kernel
   const float m = groups_max(ek);
   const float pexp = (k_own < LP) ? __expf(ek - m) : 0.f;
   const float alpha = pexp / groups_sum(pexp);
-  if ((lane & 3) == 0) alpha_out[row * kLP + k_own] = alpha;
+  if (wave == 0 && (lane & 3) == 0) alpha_out[row * kLP + k_own] = alpha;
   const float a_lo = alpha * rs.c_lo, a_hi = alpha * rs.c_hi;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int i = 0; i < kPerWave; ++i) {
+    const int k = wave * kPerWave + i;
     if (k < LP) {
       const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
       const float cl = bcast(a_lo, 4 * k), ch = bcast(a_hi, 4 * k);
@@ -191,9 +207,20 @@ __global__ void __launch_bounds__(64) k_cap_train_fwd(
       acc[6] = fmaf(cl, l1.z, fmaf(ch, u1.z, acc[6])); acc[7] = fmaf(cl, l1.w, fmaf(ch, u1.w, acc[7]));
     }
   }
-  float4 *o4 = reinterpret_cast<float4 *>(att_res + row * kC);
-  o4[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  o4[64 + lane] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) sh_acc[wave][lane][c] = acc[c];
+  __syncthreads();
+  // wavefront w finishes channels pair (2w, 2w+1) of every lane: sum over the four partial wavefronts
+  {
+    const int c0 = 2 * wave;
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRowWaves; ++w) { r0 += sh_acc[w][lane][c0]; r1 += sh_acc[w][lane][c0 + 1]; }
+    // acc[0..3] -> channels 4*lane + 0..3, acc[4..7] -> channels 256 + 4*lane + 0..3
+    float *o = att_res + row * kC + (c0 < 4 ? 4 * lane + c0 : 256 + 4 * lane + (c0 - 4));
+    o[0] = r0;
+    o[1] = r1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -205,15 +232,17 @@ __device__ inline float dot4d(const float4 &g, const float4 &u, const float4 &l)
 }
 __device__ inline float dot4(const float4 &a, const float4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-__global__ void __launch_bounds__(64) k_cap_train_bwd(
+__global__ void __launch_bounds__(kRowWaves * 64) k_cap_train_bwd(
     const float *__restrict__ slab, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ ref, const float *__restrict__ off_hs, const float *__restrict__ off_h, int off_h_ld,
     const float *__restrict__ att_h, int att_h_ld, const float *__restrict__ alpha_w,
     const float *__restrict__ alpha_saved, const float *__restrict__ g_att, int g_att_ld, int S, int L, int Q, int P,
     int RD, float *__restrict__ g_slab, float *__restrict__ g_att_h, int g_att_h_ld, float *__restrict__ g_off,
     int g_off_ld, float *__restrict__ g_ref, float *__restrict__ g_alpha_w, float *__restrict__ g_alpha_b) {
+  __shared__ float sh_da[kLP], sh_dx[kLP];
+  __shared__ float sh_part[kRowWaves][64][16];
   const int64_t row = blockIdx.x;
-  const int lane = threadIdx.x, k_own = lane >> 2, LP = L * P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k_own = lane >> 2, LP = L * P;
   const int b = (int)(row / Q);
   const RowSetup rs = setup_row(shapes, lsi, ref, off_hs, off_h + row * (int64_t)off_h_ld, row, k_own, L, P, RD);
   const float alpha = k_own < LP ? alpha_saved[row * kLP + k_own] : 0.f;
@@ -223,10 +252,12 @@ __global__ void __launch_bounds__(64) k_cap_train_bwd(
   float *gs = g_slab + (int64_t)b * S * (2 * kC);
 
   // ---- value half: d alpha_k = g . clip_k ; d x_k (part 1) = alpha_k g . (V[r+1] - V[r]) ; scatter alpha_k c g -----
-  float pa[16], px[16];
+  float px[kPerWave];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    pa[k] = 0.f; px[k] = 0.f;
+  for (int i = 0; i < kPerWave; ++i) {
+    const int k = wave * kPerWave + i;
+    float pa = 0.f;
+    px[i] = 0.f;
     if (k < LP) {
       const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
       const float cl = bcast(rs.c_lo, 4 * k), ch = bcast(rs.c_hi, 4 * k), ak = bcast(alpha, 4 * k);
@@ -234,28 +265,31 @@ __global__ void __launch_bounds__(64) k_cap_train_bwd(
       const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4);
       const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4);
       const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
-      pa[k] = cl * (dot4(ga, l0) + dot4(gb, l1)) + ch * (dot4(ga, u0) + dot4(gb, u1));
-      px[k] = ak * (dot4d(ga, u0, l0) + dot4d(gb, u1, l1));
+      pa = cl * (dot4(ga, l0) + dot4(gb, l1)) + ch * (dot4(ga, u0) + dot4(gb, u1));
+      px[i] = ak * (dot4d(ga, u0, l0) + dot4d(gb, u1, l1));
       float *d0 = gs + (int64_t)rr * (2 * kC), *d1 = gs + (int64_t)rr1 * (2 * kC);
       if (cl != 0.f) { atomic_add4(d0 + 4 * lane, ak * cl, ga); atomic_add4(d0 + 256 + 4 * lane, ak * cl, gb); }
       if (ch != 0.f) { atomic_add4(d1 + 4 * lane, ak * ch, ga); atomic_add4(d1 + 256 + 4 * lane, ak * ch, gb); }
     }
+    pa = wave_sum(pa);
+    if (lane == 0) sh_da[k] = pa;
   }
-  const float dalpha = butterfly16(pa, lane);                       // lane group k: g . clip_k
+  __syncthreads();
+  const float dalpha = k_own < LP ? sh_da[k_own] : 0.f;             // lane group k: g . clip_k
   const float dsum = groups_sum(alpha * dalpha);
   const float de = alpha * (dalpha - dsum);                         // softmax backward: d e_k
   const float de_total = groups_sum(de);                            // = 0 up to rounding: softmax is shift invariant
-  if (lane == 0) atomicAdd(g_alpha_b, de_total);
+  if (threadIdx.x == 0) atomicAdd(g_alpha_b, de_total);
 
   // ---- ctx2att half: t = tanh(att_ctx_k + att_h); d pre = de_k alpha_w (1 - t^2) -------------------------------
   const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * (int64_t)att_h_ld);
   const float4 ta = ah4[lane], tb = ah4[64 + lane];
   const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
   float4 dha = make_float4(0.f, 0.f, 0.f, 0.f), dhb = dha, dwa = dha, dwb = dha;
-  float px2[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    px2[k] = 0.f;
+  for (int i = 0; i < kPerWave; ++i) {
+    const int k = wave * kPerWave + i;
+    float p2 = 0.f;
     if (k < LP) {
       const int rr = __builtin_amdgcn_readlane(rs.roff, 4 * k);
       const float cl = bcast(rs.c_lo, 4 * k), ch = bcast(rs.c_hi, 4 * k), dek = bcast(de, 4 * k);
@@ -275,24 +309,39 @@ __global__ void __launch_bounds__(64) k_cap_train_bwd(
       GVL_CH(x, l1, u1, tb, qb, db, dhb, dwb) GVL_CH(y, l1, u1, tb, qb, db, dhb, dwb)
       GVL_CH(z, l1, u1, tb, qb, db, dhb, dwb) GVL_CH(w, l1, u1, tb, qb, db, dhb, dwb)
 #undef GVL_CH
-      px2[k] = dot4d(da, u0, l0) + dot4d(db, u1, l1);
+      p2 = dot4d(da, u0, l0) + dot4d(db, u1, l1);
       float *d0 = gs + (int64_t)rr * (2 * kC) + kC, *d1 = gs + (int64_t)rr1 * (2 * kC) + kC;
       if (cl != 0.f) { atomic_add4(d0 + 4 * lane, cl, da); atomic_add4(d0 + 256 + 4 * lane, cl, db); }
       if (ch != 0.f) { atomic_add4(d1 + 4 * lane, ch, da); atomic_add4(d1 + 256 + 4 * lane, ch, db); }
     }
+    const float dxk = wave_sum(px[i] + p2);                          // d loss / d pixel coordinate of sample k
+    if (lane == 0) sh_dx[k] = dxk;
   }
-  float4 *oh = reinterpret_cast<float4 *>(g_att_h + row * (int64_t)g_att_h_ld);
-  oh[lane] = dha;
-  oh[64 + lane] = dhb;
-  atomic_add4(g_alpha_w + 4 * lane, 1.f, dwa);
-  atomic_add4(g_alpha_w + 256 + 4 * lane, 1.f, dwb);
-
-  // ---- d x_k -> offsets and reference points ------------------------------------------------------------------
+  {
+    float *pp = sh_part[wave][lane];
+    pp[0] = dha.x; pp[1] = dha.y; pp[2] = dha.z; pp[3] = dha.w; pp[4] = dhb.x; pp[5] = dhb.y; pp[6] = dhb.z; pp[7] = dhb.w;
+    pp[8] = dwa.x; pp[9] = dwa.y; pp[10] = dwa.z; pp[11] = dwa.w; pp[12] = dwb.x; pp[13] = dwb.y; pp[14] = dwb.z; pp[15] = dwb.w;
+  }
+  __syncthreads();
+  // wavefront w finishes slots 4w..4w+3 of every lane (slots 0-7: d h2att(h) channels, 8-15: d alpha_w channels)
+  {
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 16; ++k) px[k] += px2[k];
-  const float dx = butterfly16(px, lane);                            // lane group k: d loss / d pixel coordinate
-  const float dloc = dx * rs.dmul;
-  if ((lane & 3) == 0) {
+    for (int w = 0; w < kRowWaves; ++w)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) r[c] += sh_part[w][lane][4 * wave + c];
+    const int ch0 = (wave & 1) ? 256 + 4 * lane : 4 * lane;         // slots 0-3 / 8-11: channels 4*lane.., 4-7 / 12-15: 256 + 4*lane..
+    if (wave < 2) {
+      float4 *oh = reinterpret_cast<float4 *>(g_att_h + row * (int64_t)g_att_h_ld + ch0);
+      *oh = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+      atomicAdd(g_alpha_w + ch0 + 0, r[0]); atomicAdd(g_alpha_w + ch0 + 1, r[1]);
+      atomicAdd(g_alpha_w + ch0 + 2, r[2]); atomicAdd(g_alpha_w + ch0 + 3, r[3]);
+    }
+  }
+  // ---- d x_k -> offsets and reference points (wavefront 0, lane group k) ---------------------------------------
+  if (wave == 0 && (lane & 3) == 0) {
+    const float dloc = (k_own < LP ? sh_dx[k_own] : 0.f) * rs.dmul;
     g_off[row * (int64_t)g_off_ld + k_own] = k_own < LP ? dloc * rs.doff : 0.f;
     if (k_own < LP) {
       float *gr = g_ref + (row * L + rs.level) * RD;
@@ -370,7 +419,7 @@ int gvl_cap_attend_train_forward_f32(const float *slab, const int64_t *shapes, c
     return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: null pointer");
   if (((uintptr_t)att_h & 15) || ((uintptr_t)att_res & 15))
     return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: att_h / att_res must be 16-byte aligned");
-  return gvl::launch(GVL_PROF_CAP_TRAIN_FWD, B * Q, B, "k_cap_train_fwd", k_cap_train_fwd, dim3(B * Q), dim3(64), 0,
+  return gvl::launch(GVL_PROF_CAP_TRAIN_FWD, B * Q, B, "k_cap_train_fwd", k_cap_train_fwd, dim3(B * Q), dim3(256), 0,
                      (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld, alpha_w,
                      alpha_b, S, L, Q, P, RD, att_res, alpha_out);
 }
@@ -392,7 +441,7 @@ int gvl_cap_attend_train_backward_f32(const float *slab, const int64_t *shapes, 
     return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: null pointer");
   if (((uintptr_t)att_h & 15) || ((uintptr_t)grad_att_res & 15) || ((uintptr_t)grad_att_h & 15))
     return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: row pointers must be 16-byte aligned");
-  return gvl::launch(GVL_PROF_CAP_TRAIN_BWD, B * Q, B, "k_cap_train_bwd", k_cap_train_bwd, dim3(B * Q), dim3(64), 0,
+  return gvl::launch(GVL_PROF_CAP_TRAIN_BWD, B * Q, B, "k_cap_train_bwd", k_cap_train_bwd, dim3(B * Q), dim3(256), 0,
                      (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld, alpha_w,
                      alpha_saved, grad_att_res, grad_att_res_ld, S, L, Q, P, RD, grad_slab, grad_att_h, grad_att_h_ld,
                      grad_off, grad_off_ld, grad_ref, grad_alpha_w, grad_alpha_b);
