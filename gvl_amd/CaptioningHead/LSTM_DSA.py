@@ -381,21 +381,32 @@ class Captioner(nn.Module):
         h = hs.new_zeros(n, self.rnn_size)
         c = hs.new_zeros(n, self.rnn_size)
         it = torch.zeros(n, dtype=torch.long, device=hs.device)                       # <bos>
+        T = self.max_caption_len
+        if sample_max:
+            # greedy: argmax, log-prob and the per-step bookkeeping (unfinished / alive / seq / seq_lp) are one kernel
+            unfinished = torch.empty(n, dtype=torch.uint8, device=hs.device)
+            seq = torch.empty(n, T, dtype=torch.long, device=hs.device)
+            seq_lp = torch.empty(n, T, dtype=torch.float32, device=hs.device)
+            for t in range(T + 1):
+                if t > 0:
+                    it = MSDA.greedy_step(logits, t - 1, unfinished, seq, seq_lp)
+                if t < T:
+                    # (the reference also evaluates the LSTM step + vocabulary logits of the LAST token,
+                    #  LSTM_DSA.py:189-190, and then leaves the loop without reading them)
+                    out, (h, c) = self.core.step((emb_gates, it), (h, c), hs, ref_in, tshapes, lsi, const)
+                    logits = self.logit(self.dropout(out))
+            # a row is unfinished at step t exactly while its tokens are non-zero (seq = token * unfinished, :183-188)
+            return seq, seq_lp, (seq != 0).any(0)
         unfinished = torch.ones(n, dtype=torch.bool, device=hs.device)
         seq, seq_lp, alive = [], [], []
-        for t in range(self.max_caption_len + 1):
+        for t in range(T + 1):
             if t > 0:
-                if sample_max:
-                    it, lp = MSDA.row_argmax_lse(logits)       # argmax + log_softmax at the argmax, one pass
-                else:
-                    logprobs = F.log_softmax(logits, dim=1)
-                    prev = torch.exp(logprobs) if temperature == 1.0 else torch.exp(logprobs / temperature)
-                    it = torch.multinomial(prev, 1)
-                    lp = logprobs.gather(1, it).view(-1)
-                    it = it.view(-1)
-            if t < self.max_caption_len:
-                # (the reference also evaluates the LSTM step + vocabulary logits of the LAST token, LSTM_DSA.py:189-190,
-                #  and then leaves the loop without reading them)
+                logprobs = F.log_softmax(logits, dim=1)
+                prev = torch.exp(logprobs) if temperature == 1.0 else torch.exp(logprobs / temperature)
+                it = torch.multinomial(prev, 1)
+                lp = logprobs.gather(1, it).view(-1)
+                it = it.view(-1)
+            if t < T:
                 out, (h, c) = self.core.step((emb_gates, it), (h, c), hs, ref_in, tshapes, lsi, const)
                 logits = self.logit(self.dropout(out))
             if t >= 1:

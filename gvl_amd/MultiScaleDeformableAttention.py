@@ -357,6 +357,28 @@ def row_argmax_lse(logits):
     return idx, lp
 
 
+def greedy_step(logits, t_col, unfinished, seq, seq_lp):
+    """argmax + log-softmax-at-argmax of the (R, V) logits AND the greedy bookkeeping of decoding step t_col
+    (include/gvl_msda.h: gvl_greedy_step_f32): updates unfinished (R,) uint8 and seq / seq_lp (R, T) in place at
+    column t_col; -> raw argmax tokens (R,) int64"""
+    _require(logits.is_cuda and logits.is_contiguous() and logits.dtype == torch.float32 and logits.dim() == 2,
+             "greedy_step: logits must be a contiguous fp32 CUDA matrix")
+    R, V = logits.shape
+    _require(unfinished.dtype == torch.uint8 and seq.dtype == torch.int64
+             and seq_lp.dtype == torch.float32 and seq.is_contiguous() and seq_lp.is_contiguous()
+             and seq.shape == seq_lp.shape and seq.shape[0] == R, "greedy_step: bad bookkeeping tensors")
+    T = seq.shape[1]
+    tok = torch.empty(R, dtype=torch.int64, device=logits.device)
+    lp = torch.empty(R, dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        rc = _lib.lib().gvl_greedy_step_f32(
+            logits.data_ptr(), R, V, 1 if t_col == 0 else 0, tok.data_ptr(), lp.data_ptr(), unfinished.data_ptr(),
+            seq.data_ptr() + 8 * t_col, seq_lp.data_ptr() + 4 * t_col, T,
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "greedy_step")
+    return tok
+
+
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
              12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train"}

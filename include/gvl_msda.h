@@ -286,6 +286,13 @@ int gvl_lstm_cell_train_backward_f32(const float *grad_h_a, const float *grad_h_
 /* -- greedy decoding epilogue: idx[r] = argmax_v logits[r, v] (first maximal index), logp[r] = log_softmax(logits[r])
  *    at that index (LSTM_DSA.py:123 + :166-167), one read of the logits. */
 int gvl_row_argmax_lse_f32(const float *logits, int R, int V, int64_t *idx, float *logp, void *stream);
+/*    The same with the bookkeeping of one greedy decoding step (LSTM_DSA.py:180-190) fused in:
+ *      unfinished[r] = (first_step || unfinished[r]) && token[r] > 0
+ *      seq_col[r * seq_ld] = unfinished[r] ? token[r] : 0;   seq_lp_col[r * seq_ld] = logp[r]
+ *    seq_col / seq_lp_col point at column t of the (R, seq_ld) output tensors; token[] is the RAW argmax (what the
+ *    reference feeds to the next LSTM step). */
+int gvl_greedy_step_f32(const float *logits, int R, int V, int first_step, int64_t *token, float *logp,
+                        unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld, void *stream);
 
 /* -- Hungarian matcher index path (HOST pointers, host code).  Replaces scipy.optimize.linear_sum_assignment as
  *    called at pdvc/matcher.py:124,126; results are bit-identical to scipy 1.15.3 (same augmenting-path order and

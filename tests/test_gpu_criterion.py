@@ -65,7 +65,9 @@ def test_match_cost_kernel_equals_torch_sequence(NC, w_bbox):
 
 
 @pytest.mark.parametrize("NC,sizes,degenerate", [(1, [3, 2, 4, 3], False), (1, [3, 2, 4, 3], True),
-                                                 (3, [2, 5, 3], False), (1, [3, 1, 2], False)])
+                                                 (3, [2, 5, 3], False), (1, [3, 1, 2], False),
+                                                 (1, [2, 0, 3], False),            # a video without ground-truth events
+                                                 (1, [30, 12], False)])            # gt_proposal_sample_num = 30
 def test_fused_criterion_equals_torch_formulation(NC, sizes, degenerate):
     from gvl_amd.criterion import LOSS_KEYS
     dev = torch.device("cuda:0")
