@@ -130,11 +130,11 @@ class ShowAttendTellCore(nn.Module):
             att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
                                       h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
                                       self.n_levels, self.n_points)
-            g_x = torch.addmm(const["gates_hs"], att_res, const["w_att_t"])  # hs part + attention part of W_ih x
-            if not isinstance(xt_gates, tuple):                               # per-row pre-activations given directly
+            g_x = torch.mm(att_res, const["w_att_t"])                         # attention part of W_ih x (the hs part,
+            if not isinstance(xt_gates, tuple):                               # gates_hs, is added inside the cell kernel)
                 xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
             emb_gates, it = xt_gates                                          # (table (V+1,4H), token ids)
-            h2, c2 = MSDA.lstm_cell(g_x, g_h[:, A:], emb_gates, it, c)
+            h2, c2 = MSDA.lstm_cell(g_x, g_h[:, A:], emb_gates, it, c, gates_c=const["gates_hs"])
             return h2, (h2, c2)
         if isinstance(xt_gates, tuple):                                   # (pre-multiplied table, token ids)
             xt_gates = xt_gates[0].index_select(0, xt_gates[1])

@@ -326,10 +326,10 @@ def lstm_cell_train_backward(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, gra
     _lib.check(rc, "lstm_cell_train_backward")
 
 
-def lstm_cell(gates_a, gates_b, emb_gates, it, c):
+def lstm_cell(gates_a, gates_b, emb_gates, it, c, gates_c=None):
     """fused LSTM cell pointwise step (include/gvl_msda.h: gvl_lstm_cell_f32) -> (h', c')"""
     n, H = c.shape
-    for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b)):
+    for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b)) + ((("gates_c", gates_c),) if gates_c is not None else ()):
         _require(t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1
                  and t_.shape == (n, 4 * H), f"lstm_cell: {name} must be an (n, 4H) fp32 CUDA matrix")
     _require(emb_gates.is_contiguous() and c.is_contiguous() and it.is_contiguous() and it.dtype == torch.int64,
@@ -337,7 +337,9 @@ def lstm_cell(gates_a, gates_b, emb_gates, it, c):
     h_out, c_out = torch.empty_like(c), torch.empty_like(c)
     with torch.cuda.device(c.device):
         rc = _lib.lib().gvl_lstm_cell_f32(gates_a.data_ptr(), gates_a.stride(0), gates_b.data_ptr(), gates_b.stride(0),
-                                          emb_gates.data_ptr(), it.data_ptr(), c.data_ptr(), n, H, h_out.data_ptr(),
+                                          emb_gates.data_ptr(), it.data_ptr(),
+                                          gates_c.data_ptr() if gates_c is not None else None,
+                                          gates_c.stride(0) if gates_c is not None else 0, c.data_ptr(), n, H, h_out.data_ptr(),
                                           c_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "lstm_cell")
     return h_out, c_out

@@ -386,8 +386,9 @@ __global__ void __launch_bounds__(1024) k_sample_bwd(const T *__restrict__ value
 
 // ------------------------------------------------------------------------------------------------------
 // LSTM cell pointwise part of one token step (nn.LSTM single layer, bias-free; LSTM_DSA.py:216-217,269):
-//   gates = ga + gb + emb_table[it]   (three partial pre-activations: the GEMM over [att | hs], the GEMM over h,
-//                                      and the pre-multiplied embedding row of the input token)
+//   gates = ga + gb + emb_table[it] (+ gc)   (partial pre-activations: the GEMM over the attended feature, the GEMM
+//                                      over h, the pre-multiplied embedding row of the input token, and -- optional --
+//                                      the token-independent hs part, so that no GEMM needs a beta = 1 C operand)
 //   i,f,g,o = split(gates);  c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c')
 // one float4 of hidden units per lane
 // ------------------------------------------------------------------------------------------------------
@@ -396,8 +397,8 @@ __device__ inline float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f *
 
 __global__ void __launch_bounds__(256) k_lstm_cell(const float *__restrict__ ga, int lda, const float *__restrict__ gb,
                                                    int ldb, const float *__restrict__ emb, const int64_t *__restrict__ it,
-                                                   const float *__restrict__ c, int n, int H, float *__restrict__ h_out,
-                                                   float *__restrict__ c_out) {
+                                                   const float *__restrict__ gc, int ldc, const float *__restrict__ c,
+                                                   int n, int H, float *__restrict__ h_out, float *__restrict__ c_out) {
   const int H4 = H >> 2;
   const int64_t total = (int64_t)n * H4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -405,11 +406,15 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const float *__restrict__ ga,
     const float4 *pa = reinterpret_cast<const float4 *>(ga + (int64_t)row * lda);
     const float4 *pb = reinterpret_cast<const float4 *>(gb + (int64_t)row * ldb);
     const float4 *pe = reinterpret_cast<const float4 *>(emb + it[row] * (int64_t)(4 * H));
+    const float4 *pc = gc ? reinterpret_cast<const float4 *>(gc + (int64_t)row * ldc) : nullptr;
     float4 g4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float4 a = pa[k * H4 + j], b = pb[k * H4 + j], e = pe[k * H4 + j];
-      g4[k] = make_float4(a.x + b.x + e.x, a.y + b.y + e.y, a.z + b.z + e.z, a.w + b.w + e.w);
+      // (hs part + attention part) first: the same association as the reference's single W_ih GEMM over [att | hs]
+      float4 x = a;
+      if (pc) { const float4 cc = pc[k * H4 + j]; x = make_float4(cc.x + a.x, cc.y + a.y, cc.z + a.z, cc.w + a.w); }
+      g4[k] = make_float4(x.x + b.x + e.x, x.y + b.y + e.y, x.z + b.z + e.z, x.w + b.w + e.w);
     }
     const float4 cp = reinterpret_cast<const float4 *>(c)[idx];
     float4 cn, hn;
@@ -469,8 +474,10 @@ int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *
 }
 
 int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
-                      const int64_t *it, const float *c, int n, int H, float *h_out, float *c_out, void *stream) {
-  if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3))
+                      const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
+                      float *c_out, void *stream) {
+  if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3) ||
+      (gates_c && (ldc < 4 * H || (ldc & 3))))
     return fail(GVL_EINVAL, "gvl_lstm_cell_f32: bad sizes n=%d H=%d lda=%d ldb=%d", n, H, lda, ldb);
   if (n == 0) return 0;
   if (!gates_a || !gates_b || !emb_gates || !it || !c || !h_out || !c_out)
@@ -478,7 +485,7 @@ int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int l
   int64_t blocks = ((int64_t)n * (H / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   return gvl::launch(GVL_PROF_LSTM_CELL, n, H, "k_lstm_cell", k_lstm_cell, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, c, n, H, h_out, c_out);
+                     (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H, h_out, c_out);
 }
 
 int gvl_row_argmax_lse_f32(const float *logits, int R, int V, int64_t *idx, float *logp, void *stream) {

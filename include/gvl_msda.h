@@ -239,11 +239,13 @@ int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *
                        int att_h_ld, float *att_res, float *dbg_alpha, float *dbg_loc, void *stream);
 
 /* -- pointwise part of the captioner's LSTM cell (single layer, bias-free nn.LSTM, LSTM_DSA.py:216-217,269):
- *    gates = gates_a + gates_b + emb_gates[it] (row strides lda / ldb floats, gate order i,f,g,o, 4H wide);
- *    c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c').  emb_gates is the embedding table already
- *    multiplied by its slice of W_ih ((V+1, 4H)); it (n) int64 token ids. */
+ *    gates = (gates_c +) gates_a + gates_b + emb_gates[it] (row strides lda / ldb / ldc floats, gate order i,f,g,o,
+ *    4H wide; gates_c may be NULL: the token-independent part, kept out of the per-token GEMM so that it needs no
+ *    beta = 1 C operand);  c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c').  emb_gates is the
+ *    embedding table already multiplied by its slice of W_ih ((V+1, 4H)); it (n) int64 token ids. */
 int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
-                      const int64_t *it, const float *c, int n, int H, float *h_out, float *c_out, void *stream);
+                      const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
+                      float *c_out, void *stream);
 
 /* -- TRAINING-time token step of the same captioner (teacher forcing; LSTM_DSA.py:63-117 loop, :241-271 step, and
  *    their autograd).  The matched queries only (pdvc.py:743-760), so n = B*Q rows is small and the step is
