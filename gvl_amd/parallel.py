@@ -223,10 +223,12 @@ class GraphedEvalForward:
         self.warmup = max(1, int(warmup))
         self.graphs = {}
 
-    @staticmethod
-    def _key(dt):
+    def _key(self, dt):
         sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in dt.items() if isinstance(v, torch.Tensor))
-        return sig, tuple(len(t_["boxes"]) for t_ in dt["video_target"])
+        # operands derived from weights only (concatenated / pre-multiplied matrices of the captioner) are cached per
+        # parameter version and are constants of the captured graph: updated parameters => a new capture
+        epoch = sum(p_._version for p_ in self.model.parameters())
+        return sig, tuple(len(t_["boxes"]) for t_ in dt["video_target"]), epoch
 
     def _forward(self, dt):
         return self.model(dt, self.criterion, None, self.kind, eval_mode=True)

@@ -551,3 +551,29 @@ def test_anet_full_dimension_eval_matches_reference():
         assert float((seq == ref_seq).float().mean()) >= 0.95 and float(row_same.float().mean()) >= 0.85
         lp = out["caption_probs"]["cap_prob_eval"].float().cpu().reshape(-1, seq.shape[-1])
         assert maxerr(lp[row_same], t(f["cap_prob_eval"]).reshape(-1, seq.shape[-1])[row_same]) <= 2e-3
+
+
+def test_graphed_eval_forward_follows_parameter_updates(built):
+    """operands derived from weights are cached by parameter version and captured as graph constants: after an
+    in-place parameter update the graphed forward must agree with the eager one again (new capture)."""
+    from gvl_amd.parallel import GraphedEvalForward
+    f, model, criterion, dev = built
+    g = GraphedEvalForward(model, criterion)
+    dt = to_dev(pdvc_dt(f), dev)
+    g(dt)
+    cap = model.caption_head[-1]
+    saved = [p_.detach().clone() for p_ in (cap.core.h2att.weight, cap.embed.weight)]
+    try:
+        with torch.no_grad():
+            cap.core.h2att.weight.mul_(1.3)
+            cap.embed.weight.add_(0.05)
+            ref_out, _ = model(dt, criterion, None, "queries", eval_mode=True)
+        out, _ = g(dt)
+        assert torch.equal(out["seq"], ref_out["seq"])
+        assert maxerr(out["caption_probs"]["cap_prob_eval"], ref_out["caption_probs"]["cap_prob_eval"]) < 1e-5
+        assert not torch.equal(out["seq"].cpu(), t(f["cuda.seq"]))          # the update really changed the captions
+        assert len(g.graphs) == 2
+    finally:
+        with torch.no_grad():
+            cap.core.h2att.weight.copy_(saved[0])
+            cap.embed.weight.copy_(saved[1])
