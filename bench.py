@@ -97,6 +97,35 @@ def cfg_l_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20):
             "note": "back-to-back launches on synthetic operands after the timed region"}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA peak (no xf32 / TF32 on gfx950)
+
+
+def gemm_probe(model, dev, rows, iters=20):
+    """Where the eval forward's TIME goes is not the deformable-attention kernel but the captioner's library GEMMs
+    (hipBLASLt through PyTorch; 68 % of the kernel time, profiles/r01_eval_kernel_stats.txt).  The largest of them,
+    the vocabulary logits (rows x 512 x (V+1)) of every token step, is timed here with stream events around `iters`
+    back-to-back calls after the timed region, and priced against the fp32 MFMA peak."""
+    head = model.caption_head[-1]
+    w, b = head.logit.weight, head.logit.bias
+    x = torch.randn(rows, w.shape[1], device=dev)
+    for _ in range(3):
+        torch.nn.functional.linear(x, w, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.nn.functional.linear(x, w, b)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    flops = 2.0 * rows * w.shape[0] * w.shape[1]
+    tf = flops / (us * 1e-6) / 1e12
+    return {"kernel": f"hipBLASLt fp32 GEMM {rows}x{w.shape[1]}x{w.shape[0]} (vocabulary logits, once per token step)",
+            "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "kernel_us": round(us, 1), "calls_timed": iters,
+            "note": "library kernel, not hand-written; back-to-back calls after the timed region (torch events on "
+                    "the launch stream)"}
+
+
 def cpu_baseline(model, opt, T, seconds_budget=25.0):
     """The oracle's CPU port (reference CPU-fallback semantics: grid_sample border) on a bounded sample."""
     from oracle import torch_ref as R
@@ -303,6 +332,9 @@ def main():
     }
     if a.mode == "train":
         line["videos_per_s"] = round(videos_per_s, 3)
+    if rank == 0 and a.mode == "eval" and not a.no_captioner and a.dtype == "f32":
+        with torch.no_grad():
+            line["dominant_library_gemm"] = gemm_probe(model, dev, B * a.queries)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "eval":
         line["cpu_baseline"] = cpu_baseline(model, opt, a.T)
     if rank == 0:
