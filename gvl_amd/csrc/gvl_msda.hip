@@ -36,6 +36,7 @@ using gvl::fail;
 using gvl::ensure_lds;
 
 thread_local int g_last_impl = 0;
+unsigned long long *g_fwd_stamps = nullptr;   // diagnostics, see gvl_msda_debug_stamps
 int g_impl = -1;  // -1 = read the environment on first use
 
 int impl_mode() {
@@ -233,7 +234,9 @@ __global__ void __launch_bounds__(256) k_bwd_generic(const T *__restrict__ value
 // ------------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ inline int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+  // bound_ctrl = true: every control used here (row_newbcast, quad_perm, row_ror) reads a valid lane, and without it
+  // the compiler must materialise the `old` operand (a v_mov 0 per DPP instruction: 48 per forward pass)
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ inline float dpp_f(float v) {
@@ -244,6 +247,23 @@ template <int SRC>
 __device__ inline int row_bcast_i(int v) { return dpp_i<0x150 + SRC>(v); }
 template <int SRC>
 __device__ inline float row_bcast_f(float v) { return dpp_f<0x150 + SRC>(v); }
+// 64-bit row broadcast (v_mov_b64_dpp, gfx90a+ DP-ALU DPP supports exactly row_newbcast): two coefficients travel
+// in one instruction and arrive as an aligned register pair, whose halves v_pk_fma_f32 selects with op_sel -- no
+// copies to build packed operands
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int SRC>
+__device__ inline f2v row_bcast_f2(f2v v) {
+  const long long r = __builtin_amdgcn_update_dpp((long long)0, __builtin_bit_cast(long long, v), 0x150 + SRC, 0xF, 0xF, true);
+  return __builtin_bit_cast(f2v, r);
+}
+// acc (4 channels as two pairs) += c.x * v0 + c.y * v1
+__device__ inline void fma4x2(f2v c, const float4 &v0, const float4 &v1, f2v &a01, f2v &a23) {
+  const f2v lo = __builtin_shufflevector(c, c, 0, 0), hi = __builtin_shufflevector(c, c, 1, 1);
+  a01 = __builtin_elementwise_fma(lo, (f2v){v0.x, v0.y}, a01);
+  a23 = __builtin_elementwise_fma(lo, (f2v){v0.z, v0.w}, a23);
+  a01 = __builtin_elementwise_fma(hi, (f2v){v1.x, v1.y}, a01);
+  a23 = __builtin_elementwise_fma(hi, (f2v){v1.z, v1.w}, a23);
+}
 // all-reduce (sum) inside every 16-lane row
 __device__ inline float row_allsum(float v) {
   v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -403,8 +423,11 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
                                                      const int64_t *__restrict__ shapes,
                                                      const int64_t *__restrict__ lsi, const void *__restrict__ loc,
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
-                                                     int P, int RD, int nchunk, VT *__restrict__ out) {
+                                                     int P, int RD, int nchunk, VT *__restrict__ out,
+                                                     unsigned long long *__restrict__ stamps) {
   extern __shared__ float4 slab4[];
+  // diagnostics (gvl_msda_debug_stamps): 100 MHz wall-clock stamps per workgroup {start, slab staged, loop done}
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
   const int BM = B * M;
   const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
   const int b = bm / M, m = bm % M;
@@ -433,6 +456,9 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;               // this lane's channels of row 0 of the slab
   stage_slab(slab4, value, b, m, S, M, row0);
   __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
+  const char *slab_b = reinterpret_cast<const char *>(slab4);
+  const int lane_off = j * 16;
 
   for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
@@ -444,37 +470,41 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
     float w, dloc_;
     resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc_);
     int roff = 0;
-    float clo = 0.f, chi = 0.f;
+    f2v cc = {0.f, 0.f};
     if (j < LP) {
       const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
-      roff = (L0G && lvl == 0) ? c.r : (st - row0 + c.r) * 16;     // global row index | LDS float4 index
+      roff = (L0G && lvl == 0) ? c.r : (st - row0 + c.r) * 256;    // global row index | LDS byte offset of the row
       const float ww = w * c.wy;
-      clo = c.c_lo * ww;
-      chi = c.c_hi * ww;
+      cc = (f2v){c.c_lo * ww, c.c_hi * ww};
     }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    // per sample step: v_mov_b32_dpp (row), v_add (lane offset), v_mov_b64_dpp (both coefficients), 2 ds_read_b128,
+    // 4 v_pk_fma_f32 -- the loop is VALU-issue bound (tools/fwd_phase_stamps.py), every instruction counts
 #define GVL_FWD_STEP(SI)                                                        \
   if (FULL16 || SI < LP) {                                                      \
     const int ro = row_bcast_i<SI>(roff);                                       \
-    const float a = row_bcast_f<SI>(clo);                                       \
-    const float c = row_bcast_f<SI>(chi);                                       \
+    const f2v c2 = row_bcast_f2<SI>(cc);                                        \
     float4 v0, v1;                                                              \
     if (L0G && SI < 4) {                                                        \
       v0 = ld4(value, vg + (int64_t)ro * (M * 16));                             \
       v1 = ld4(value, vg + (int64_t)min(ro + 1, S - 1) * (M * 16));             \
     } else {                                                                    \
-      v0 = slab4[ro + j];                                                       \
-      v1 = slab4[ro + 16 + j];                                                  \
+      v0 = *reinterpret_cast<const float4 *>(slab_b + ro + lane_off);           \
+      v1 = *reinterpret_cast<const float4 *>(slab_b + ro + lane_off + 256);     \
     }                                                                           \
-    acc = fma4(a, v0, acc);                                                     \
-    acc = fma4(c, v1, acc);                                                     \
+    fma4x2(c2, v0, v1, a01, a23);                                               \
   }
     GVL_FWD_STEP(0) GVL_FWD_STEP(1) GVL_FWD_STEP(2) GVL_FWD_STEP(3)
     GVL_FWD_STEP(4) GVL_FWD_STEP(5) GVL_FWD_STEP(6) GVL_FWD_STEP(7)
     GVL_FWD_STEP(8) GVL_FWD_STEP(9) GVL_FWD_STEP(10) GVL_FWD_STEP(11)
     GVL_FWD_STEP(12) GVL_FWD_STEP(13) GVL_FWD_STEP(14) GVL_FWD_STEP(15)
 #undef GVL_FWD_STEP
+    const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
     if (act) st4(out, (((int64_t)b * Q + q) * M + m) * 16 + j, acc);
+  }
+  if (stamps) {
+    __syncthreads();
+    if (threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
   }
 }
 
@@ -805,7 +835,7 @@ int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
   g_last_impl = FUSED ? 3 : 2;
   return gvl::launch(GVL_PROF_FWD_T1D, Q, B, FUSED ? "k_fwd_t1d_d64<fused>" : "k_fwd_t1d_d64", kern,
                      dim3(nchunk * B * M), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
-                     nchunk, out);
+                     nchunk, out, g_fwd_stamps);
 }
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
@@ -992,6 +1022,8 @@ int gvl_msda_abi_version(void) { return GVL_MSDA_ABI_VERSION; }
 const char *gvl_last_error(void) { return gvl::g_err; }
 void gvl_msda_set_impl(int impl) { g_impl = (impl >= 0 && impl <= 2) ? impl : 0; }
 int gvl_msda_last_impl(void) { return g_last_impl; }
+
+void gvl_msda_debug_stamps(void *device_buffer) { g_fwd_stamps = (unsigned long long *)device_buffer; }
 
 int gvl_prof_enable(int on) {
   gvl::Profiler &p = gvl::profiler();

@@ -126,6 +126,9 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
 #define GVL_PROF_MATCH_COST 15
 #define GVL_PROF_CRITERION 16
 int gvl_prof_enable(int on);
+/* Phase stamps of the temporal forward kernel (diagnostics): while a DEVICE buffer of 4 uint64 per workgroup is set,
+ * every workgroup of k_fwd_t1d_d64 records the 100 MHz wall clock at {start, slab staged, loop done}.  NULL = off. */
+void gvl_msda_debug_stamps(void *device_buffer);
 int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
 
 /* -- forward: replaces ms_deform_attn_forward (pdvc/ops/src/ms_deform_attn.h:20-39 ->
