@@ -454,7 +454,47 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   // "sample step SI belongs to level 0" is the compile-time test SI < 4
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;
   const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;               // this lane's channels of row 0 of the slab
-  stage_slab(slab4, value, b, m, S, M, row0);
+  // sampling operands -> (slab row as LDS byte offset | global row index for L0G level 0, coefficient pair)
+  auto prep = [&](const RawOps &r, int &roff, f2v &cc) {
+    float2 xy;
+    float w, dloc_;
+    resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc_);
+    roff = 0;
+    cc = (f2v){0.f, 0.f};
+    if (j < LP) {
+      const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
+      roff = (L0G && lvl == 0) ? c.r : (st - row0 + c.r) * 256;
+      const float ww = w * c.wy;
+      cc = (f2v){c.c_lo * ww, c.c_hi * ww};
+    }
+  };
+  // Slab staging, software-pipelined against the first pass's coefficient arithmetic: the first (up to) four float4
+  // per thread are requested, the ~100 VALU instructions of prep() run while they are in flight (its own operands
+  // were requested earlier and return first), then the registers go to LDS.  Larger slabs finish with a plain loop.
+  constexpr int kPre = 4;
+  const int64_t src0 = ((int64_t)b * S * M + m) * 16;
+  const int nstage = (S - row0) * 16;
+  float4 pre[kPre];
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < nstage) pre[k] = ld4(value, src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15));
+  }
+  int roff_c;
+  f2v cc_c;
+  prep(r_n, roff_c, cc_c);
+  {
+    const int qb1 = qb + nw * 4;                                       // operands of the second pass
+    if (qb1 < q1 && j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, (int64_t)b * Q + min(qb1 + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
+  }
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < nstage) slab4[i] = pre[k];
+  }
+  for (int i = threadIdx.x + kPre * blockDim.x; i < nstage; i += blockDim.x)
+    slab4[i] = ld4(value, src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15));
+  if (threadIdx.x < 16) slab4[nstage + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
   const char *slab_b = reinterpret_cast<const char *>(slab4);
@@ -463,20 +503,13 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
     const bool act = q < q1;
-    const RawOps r = r_n;
-    const int qbn = qb + nw * 4;
+    const int roff = roff_c;
+    const f2v cc = cc_c;
+    // operands two passes ahead are requested now; the coefficients of the NEXT pass are computed at the end of this
+    // one, from operands requested one pass ago
+    const RawOps r_next = r_n;
+    const int qbn = qb + 2 * nw * 4;
     if (qbn < q1 && j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, (int64_t)b * Q + min(qbn + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
-    float2 xy;
-    float w, dloc_;
-    resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc_);
-    int roff = 0;
-    f2v cc = {0.f, 0.f};
-    if (j < LP) {
-      const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
-      roff = (L0G && lvl == 0) ? c.r : (st - row0 + c.r) * 256;    // global row index | LDS byte offset of the row
-      const float ww = w * c.wy;
-      cc = (f2v){c.c_lo * ww, c.c_hi * ww};
-    }
     f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
     // per sample step: v_mov_b32_dpp (row), v_add (lane offset), v_mov_b64_dpp (both coefficients), 2 ds_read_b128,
     // 4 v_pk_fma_f32 -- the loop is VALU-issue bound (tools/fwd_phase_stamps.py), every instruction counts
@@ -501,6 +534,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 #undef GVL_FWD_STEP
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
     if (act) st4(out, (((int64_t)b * Q + q) * M + m) * 16 + j, acc);
+    if (qb + nw * 4 < q1) prep(r_next, roff_c, cc_c);
   }
   if (stamps) {
     __syncthreads();
