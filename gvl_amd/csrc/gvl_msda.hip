@@ -401,16 +401,20 @@ __device__ inline float row_allmax(float v) {
 }
 
 // -> (x, y, attention weight) of the lane's sample; FUSED also returns d loc_x / d offset in `dloc`
+// Divisions: the sample loop is VALU-issue bound and an IEEE fp32 division is ~10 instructions, so the level length
+// and the point count enter as reciprocals computed ONCE per lane (invT = 1/T_l, invP = 1/P, correctly rounded) and
+// the softmax normaliser through v_rcp_f32 (1 ulp): locations / weights within 1-2 ulp of the divided form.
 template <bool FUSED>
-__device__ inline void resolve_ops(const RawOps &r, int Tl, int P, int RD, float &x, float &y, float &w, float &dloc) {
+__device__ inline void resolve_ops(const RawOps &r, float invT, float invP, int RD, float &x, float &y, float &w,
+                                   float &dloc) {
   if (!FUSED) {
     x = r.a; y = r.b; w = r.c; dloc = 0.f;
   } else {
     const float mx = row_allmax(r.b);
     const float e = __expf(r.b - mx);
-    w = e / row_allsum(e);
-    if (RD == 1) { x = r.c + r.a / (float)Tl; dloc = 1.f / (float)Tl; }
-    else { x = r.c + r.a / (float)P * r.d * 0.5f; dloc = r.d * 0.5f / (float)P; }
+    w = e * __builtin_amdgcn_rcpf(row_allsum(e));
+    if (RD == 1) { x = fmaf(r.a, invT, r.c); dloc = invT; }
+    else { dloc = r.d * 0.5f * invP; x = fmaf(r.a, dloc, r.c); }
     y = 0.5f;
   }
 }
@@ -454,11 +458,12 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   // "sample step SI belongs to level 0" is the compile-time test SI < 4
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;
   const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;               // this lane's channels of row 0 of the slab
+  const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
   // sampling operands -> (slab row as LDS byte offset | global row index for L0G level 0, coefficient pair)
   auto prep = [&](const RawOps &r, int &roff, f2v &cc) {
     float2 xy;
     float w, dloc_;
-    resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc_);
+    resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc_);
     roff = 0;
     cc = (f2v){0.f, 0.f};
     if (j < LP) {
@@ -608,6 +613,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     Tl = (int)shapes[2 * lvl + 1];
     st = (int)lsi[lvl];
   }
+  const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
   // operands of the first pass are requested before the slab staging; every pass prefetches the next one's
   int qb = q0 + wave * 4;
   RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
@@ -639,7 +645,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     }
     float2 xy;
     float w, dloc;
-    resolve_ops<FUSED>(r, Tl, P, RD, xy.x, xy.y, w, dloc);
+    resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc);
     int roff = 0;
     float clo = 0.f, chi = 0.f, dxlo = 0.f, dxhi = 0.f, dylo = 0.f, dyhi = 0.f;
     if (j < LP) {
@@ -696,7 +702,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
       const float glogit = w * (keep_w - dsum);
       const float goff = keep_x * dloc;                                        // d loc / d offset (:103-109)
       // d loc / d ref: the P points of a level share its reference point -> sum over the quad (P == 4)
-      float gr0 = keep_x, gr1 = keep_x * r.a * (0.5f / (float)P);
+      float gr0 = keep_x, gr1 = keep_x * r.a * (0.5f * invP);
       gr0 += dpp_f<0xB1>(gr0); gr0 += dpp_f<0x4E>(gr0);
       gr1 += dpp_f<0xB1>(gr1); gr1 += dpp_f<0x4E>(gr1);
       if (act) {
