@@ -238,3 +238,38 @@ def test_postprocess_matches_reference():
         assert int(r["pred_seq_len"]) == int(f[f"post.{i}.pred_seq_len"])
         assert list(r["captions"]) == [str(c) for c in f[f"post.{i}.captions"]]
         assert np.allclose(np.asarray(r["caption_scores"], np.float64), f[f"post.{i}.caption_scores"], atol=1e-5)
+
+
+def test_result_json_wire_format(tmp_path):
+    """gvl_amd.eval_utils: PostProcess results -> the reference's result-file records (eval_utils.py:216-239,136-141).
+    Built from the PostProcess golden (reference outputs), so field names, filtering and value types are the
+    reference's."""
+    import json
+    from gvl_amd import eval_utils as E
+    f = load("pdvc_eval")
+    results = []
+    for i in range(2):
+        results.append({"scores": t(f[f"post.{i}.scores"]), "labels": t(f[f"post.{i}.labels"]),
+                        "boxes": t(f[f"post.{i}.boxes"]), "raw_boxes": t(f[f"post.{i}.boxes"]),
+                        "captions": [str(c) for c in f[f"post.{i}.captions"]],
+                        "caption_scores": [float(x) for x in f[f"post.{i}.caption_scores"]],
+                        "cl_scores": [0.0] * len(f[f"post.{i}.scores"]), "query_id": t(f[f"post.{i}.query_id"]),
+                        "vid_duration": torch.tensor(60.0 + 30.0 * i), "pred_seq_len": t(f[f"post.{i}.pred_seq_len"])})
+    thr = float(np.median(f["post.0.scores"]))
+    batch = E.batch_result_json(results, ["v_a", "v_b"], score_threshold=thr)
+    assert list(batch) == ["v_a", "v_b"]
+    kept = int((f["post.0.scores"] > thr).sum())
+    assert len(batch["v_a"]) == kept > 0
+    rec = batch["v_a"][0]
+    assert list(rec) == ["timestamp", "raw_box", "label", "proposal_score", "sentence", "sentence_score", "cl_score",
+                         "query_id", "vid_duration", "pred_event_count"]
+    first = int(np.nonzero(f["post.0.scores"] > thr)[0][0])
+    assert rec["timestamp"] == [float(x) for x in f["post.0.boxes"][first]]
+    assert rec["sentence"] == str(f["post.0.captions"][first]) and isinstance(rec["proposal_score"], float)
+    out = E.new_result_file()
+    out["results"].update(batch)
+    path = tmp_path / "dvc.json"
+    E.save_dvc_json(out, str(path), verbose=True)
+    back = json.load(open(path))
+    assert back["version"] == "VERSION 1.0" and back["valid_video_num"] == 2
+    assert abs(back["avg_proposal_num"] - (len(batch["v_a"]) + len(batch["v_b"])) / 2) < 1e-12
