@@ -459,6 +459,22 @@ def make_anet_full():
     save("pdvc_anet_full", **rec)
 
 
+def make_collate():
+    """the reference's collate_fn (video_dataset.py:16-106) on synthetic samples (tests/golden/synth.py:synth_samples)"""
+    from itertools import chain as chain_
+    from synth import synth_samples
+    import video_dataset as VD
+    dt = VD.collate_fn(synth_samples())
+    rec = {k: v for k, v in dt.items() if isinstance(v, torch.Tensor)}
+    rec["video_key"] = np.array(dt["video_key"])
+    rec["gt_featstamps"] = np.array(dt["gt_featstamps"])
+    rec["cap_raw"] = np.array(list(chain_(*dt["cap_raw"])))
+    for i, tg in enumerate(dt["video_target"]):
+        rec[f"target.{i}.boxes"], rec[f"target.{i}.labels"] = tg["boxes"], tg["labels"]
+    rec["keys"] = np.array(sorted(dt))
+    save("collate", **rec)
+
+
 def make_train():
     """One training forward/backward of the reference (pdvc.py parallel_prediction_matched, train.py:403-406) with
     every dropout probability set to 0 so that the step is deterministic; CUDA-op (zero padding) semantics."""
@@ -542,6 +558,9 @@ if __name__ == "__main__":
     if "--only-init" in sys.argv:
         make_init()
         sys.exit(0)
+    if "--only-collate" in sys.argv:
+        make_collate()
+        sys.exit(0)
     if "--only-anet-full" in sys.argv:
         make_anet_full()
         sys.exit(0)
@@ -557,6 +576,7 @@ if __name__ == "__main__":
     make_op()
     make_module()
     make_matcher()
+    make_collate()
     if FULL:
         make_pdvc()
         make_gtprop()

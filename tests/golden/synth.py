@@ -49,3 +49,22 @@ def level_lengths(T, n_levels=4):
     for _ in range(n_levels - 1):
         out.append((out[-1] - 1) // 2 + 1)
     return out
+
+
+def synth_samples(seed=3):
+    """per-video samples in the layout of the reference dataset's __getitem__ (video_dataset.py:collate_fn input)"""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i, (T, n) in enumerate([(37, 3), (52, 1), (20, 4)]):
+        feats = rs.standard_normal((T, 16)).astype(np.float32)
+        dur = 40.0 + 13.5 * i
+        starts = np.sort(rs.uniform(0, dur * 0.7, n))
+        raw_ts = [[float(s_), float(min(dur, s_ + rs.uniform(2.0, dur * 0.3)))] for s_ in starts]
+        featstamps = [[int(a / dur * T), int(b / dur * T)] for a, b in raw_ts]
+        caps = [rs.randint(1, 50, size=rs.randint(3, 9)).astype(np.int64) for _ in range(n)]
+        for c in caps:
+            c[0] = 0
+            c[-1] = 0
+        raw = ["caption %d %d" % (i, k) for k in range(n)]
+        out.append((feats, featstamps, [0] * n, caps, raw_ts, dur, raw, "v_%03d" % i))
+    return out

@@ -273,3 +273,24 @@ def test_result_json_wire_format(tmp_path):
     back = json.load(open(path))
     assert back["version"] == "VERSION 1.0" and back["valid_video_num"] == 2
     assert abs(back["avg_proposal_num"] - (len(batch["v_a"]) + len(batch["v_b"])) / 2) < 1e-12
+
+
+def test_collate_fn_matches_reference():
+    """gvl_amd.video_dataset.collate_fn against the reference's collate_fn output on the same synthetic samples
+    (tests/golden/collate.npz): every tensor bit for bit, keys and list fields identical."""
+    from itertools import chain
+    from synth import synth_samples
+    from gvl_amd.video_dataset import collate_fn
+    f = load("collate")
+    dt = collate_fn(synth_samples())
+    assert sorted(dt) == [str(k) for k in f["keys"]]
+    for k, v in dt.items():
+        if isinstance(v, torch.Tensor):
+            ref = t(f[k])
+            assert v.dtype == ref.dtype and v.shape == ref.shape and torch.equal(v, ref), k
+    assert dt["video_key"] == [str(k) for k in f["video_key"]]
+    assert np.array_equal(np.array(dt["gt_featstamps"]), f["gt_featstamps"])
+    assert list(chain(*dt["cap_raw"])) == [str(c) for c in f["cap_raw"]]
+    for i, tg in enumerate(dt["video_target"]):
+        assert torch.equal(tg["boxes"], t(f[f"target.{i}.boxes"])) and torch.equal(tg["labels"], t(f[f"target.{i}.labels"]))
+        assert tg["masks"] is None and tg["image_id"] == dt["video_key"][i]
