@@ -383,7 +383,8 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp):
 
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
-             12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train"}
+             12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train", 15: "match_cost", 16: "criterion",
+             17: "pos_embed"}
 
 
 def profile_enable(on=True):

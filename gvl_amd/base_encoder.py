@@ -9,6 +9,30 @@ import torch.nn.functional as F
 from torch import nn
 
 
+class _SinePosFunction(torch.autograd.Function):
+    """PositionEmbeddingSine.forward of one level as ONE launch (include/gvl_msda.h: gvl_pos_embed_sine_f32) ->
+    (N, n_sine + n_dur, T); only the duration embedding carries gradient (sum over time)."""
+
+    @staticmethod
+    def forward(ctx, mask, dim_t, dur, scale):
+        from . import _lib
+        N, T = mask.shape
+        F_, Cd = dim_t.numel(), dur.shape[1]
+        mask_u8 = mask.contiguous().view(torch.uint8)
+        dur = dur.contiguous()
+        out = torch.empty((N, F_ + Cd, T), dtype=torch.float32, device=mask.device)
+        with torch.cuda.device(mask.device):
+            rc = _lib.lib().gvl_pos_embed_sine_f32(mask_u8.data_ptr(), dim_t.data_ptr(), dur.data_ptr(), N, T, F_, Cd,
+                                                   float(scale), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pos_embed_sine")
+        ctx.n_sine = F_
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return None, None, grad_out[:, ctx.n_sine:].sum(-1), None
+
+
 class PositionEmbeddingSine(nn.Module):
     """sine over the (normalised) frame index ++ a learned embedding of the video duration (position_encoding.py)."""
 
@@ -29,7 +53,18 @@ class PositionEmbeddingSine(nn.Module):
         onehot = (steps < durations.int()[:, None]).to(self.duration_embed_layer.weight.dtype)
         return self.duration_embed_layer(onehot)
 
-    def forward(self, x, mask, duration):
+    def _dim_t(self, device):
+        cached = getattr(self, "_dim_t_cache", None)
+        if cached is None or cached.device != device:
+            dim_t = torch.arange(self.num_pos_feats, dtype=torch.float32, device=device)
+            cached = self._dim_t_cache = (self.temperature ** (2 * (dim_t // 2) / self.num_pos_feats)).contiguous()
+        return cached
+
+    def forward(self, x, mask, duration, dur_embed=None):
+        if mask.is_cuda and self.normalize and self.duration_embed_layer.weight.dtype == torch.float32 \
+                and not torch.is_autocast_enabled():
+            dur = self.duration_embedding(duration) if dur_embed is None else dur_embed
+            return _SinePosFunction.apply(mask, self._dim_t(mask.device), dur, self.scale)
         not_mask = ~mask
         x_embed = not_mask.cumsum(1, dtype=torch.float32)
         if self.normalize:
@@ -38,7 +73,8 @@ class PositionEmbeddingSine(nn.Module):
         dim_t = self.temperature ** (2 * (dim_t // 2) / self.num_pos_feats)
         pos_x = x_embed[:, :, None] / dim_t
         pos_x = torch.stack((pos_x[:, :, 0::2].sin(), pos_x[:, :, 1::2].cos()), dim=3).flatten(2)
-        dur = self.duration_embedding(duration).reshape(-1, 1, self.max_duration).expand_as(pos_x)
+        dur = (self.duration_embedding(duration) if dur_embed is None else dur_embed)
+        dur = dur.reshape(-1, 1, self.max_duration).expand_as(pos_x)
         return torch.cat((pos_x, dur), dim=2).permute(0, 2, 1)
 
 
@@ -88,13 +124,14 @@ class BaseEncoder(nn.Module):
             return [self.input_proj[0](x)], [mask], [self.pos_embed(x, mask, duration)]
         srcs = [self._conv_as_gemm(self.input_proj[0], x)]
         masks = [mask]
-        poses = [self.pos_embed(x, mask, duration)]
+        dur = self.pos_embed.duration_embedding(duration)         # the same for every level: computed once
+        poses = [self.pos_embed(x, mask, duration, dur_embed=dur)]
         for l in range(1, self.num_feature_levels):
             src = self._conv_as_gemm(self.input_proj[l], x if l == 1 else srcs[-1])
             m = F.interpolate(mask[None].float(), size=src.shape[-1:]).to(torch.bool)[0]
             srcs.append(src)
             masks.append(m)
-            poses.append(self.pos_embed(src, m, duration).to(src.dtype))
+            poses.append(self.pos_embed(src, m, duration, dur_embed=dur).to(src.dtype))
         return srcs, masks, poses
 
 

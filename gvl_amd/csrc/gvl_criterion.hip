@@ -378,3 +378,67 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------
+// PositionEmbeddingSine.forward (pdvc/position_encoding.py:38-64) as one launch per pyramid level:
+//   x_t   = cumsum_t(valid)                     valid = !mask
+//   x_t   = (x_t - 0.5) / (x_last + 1e-6) * 2 pi
+//   out[n, 2i,   t] = sin(x_t / dim_t[2i]),  out[n, 2i+1, t] = cos(x_t / dim_t[2i+1])      (F sine channels)
+//   out[n, F + c, t] = dur[n, c]                                                              (duration embedding)
+// ~20 PyTorch kernels per level otherwise.  One workgroup per video; dim_t is passed in (computed once by torch.pow so
+// that the table is the reference's bit for bit).
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256) k_pos_embed_sine(const unsigned char *__restrict__ mask, const float *__restrict__ dim_t,
+                                                        const float *__restrict__ dur, int T, int F, int Cd, float scale,
+                                                        float *__restrict__ out) {
+  extern __shared__ float xs[];                     // normalised position of every frame
+  __shared__ int wave_tot[4];
+  __shared__ int carry;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < T; base += blockDim.x) {
+    const int t = base + threadIdx.x;
+    const int v = (t < T && !mask[(int64_t)n * T + t]) ? 1 : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int k = 0; k < wave; ++k) pre += wave_tot[k];
+    if (t < T) xs[t] = (float)(pre + incl);
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry = pre + incl;
+    __syncthreads();
+  }
+  const float last = xs[T - 1];
+  const float denom = last + 1e-6f;
+  float *o = out + (int64_t)n * (F + Cd) * T;
+  for (int idx = threadIdx.x; idx < F * T; idx += blockDim.x) {
+    const int c = idx / T, t = idx % T;
+    const float x = (xs[t] - 0.5f) / denom * scale;
+    const float p = x / dim_t[c];
+    o[idx] = (c & 1) ? cosf(p) : sinf(p);
+  }
+  for (int idx = threadIdx.x; idx < Cd * T; idx += blockDim.x) o[(int64_t)F * T + idx] = dur[(int64_t)n * Cd + idx / T];
+}
+
+}  // namespace
+
+extern "C" int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const float *dur_embed, int N, int T,
+                                      int n_sine, int n_dur, float scale, float *out, void *stream) {
+  if (N < 0 || T <= 0 || n_sine <= 0 || n_dur < 0 || (n_sine & 1))
+    return fail(GVL_EINVAL, "gvl_pos_embed_sine_f32: bad sizes");
+  if (N == 0) return 0;
+  if (!mask || !dim_t || !out || (n_dur > 0 && !dur_embed)) return fail(GVL_EINVAL, "gvl_pos_embed_sine_f32: null pointer");
+  const size_t lds = (size_t)T * sizeof(float);
+  if (int rc = gvl::ensure_lds(k_pos_embed_sine, lds)) return rc;
+  return gvl::launch(GVL_PROF_POS_EMBED, T, N, "k_pos_embed_sine", k_pos_embed_sine, dim3(N), dim3(256), lds,
+                     (hipStream_t)stream, mask, dim_t, dur_embed, T, n_sine, n_dur, scale, out);
+}

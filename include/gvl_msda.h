@@ -103,6 +103,14 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
                                    float focal_gamma, float lloss_beta, int lloss_gau_mask, const float *grad_losses,
                                    float *grad_logits, float *grad_count, float *grad_boxes, void *stream);
 
+/* -- PositionEmbeddingSine.forward of one pyramid level (pdvc/position_encoding.py:38-64; the step in front of the
+ *    path): normalised cumulative frame index -> interleaved sin / cos over `dim_t`, followed
+ *    by the duration embedding broadcast over time.
+ *      mask (N, T) bool/uint8, nonzero = padding;  dim_t (n_sine) = temperature ** (2 (i // 2) / n_sine);
+ *      dur_embed (N, n_dur) = duration_embed_layer(step one-hot);  scale = 2 pi;  out (N, n_sine + n_dur, T). */
+int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const float *dur_embed, int N, int T,
+                           int n_sine, int n_dur, float scale, float *out, void *stream);
+
 /* -- kernel timing inside the library (measurement only; no reference equivalent).  While enabled, every kernel the
  *    library launches is dispatched with hipExtLaunchKernel start/stop events on the launch stream, i.e. the
  *    begin/end stamps of that one dispatch (what rocprofv3 --kernel-trace reports), independent of host launch gaps.
@@ -125,6 +133,7 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
 #define GVL_PROF_LSTM_TRAIN 14
 #define GVL_PROF_MATCH_COST 15
 #define GVL_PROF_CRITERION 16
+#define GVL_PROF_POS_EMBED 17
 int gvl_prof_enable(int on);
 /* Phase stamps of the temporal forward kernel (diagnostics): while a DEVICE buffer of 4 uint64 per workgroup is set,
  * every workgroup of k_fwd_t1d_d64 records the 100 MHz wall clock at {start, slab staged, loop done}.  NULL = off. */

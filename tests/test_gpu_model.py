@@ -577,3 +577,31 @@ def test_graphed_eval_forward_follows_parameter_updates(built):
         with torch.no_grad():
             cap.core.h2att.weight.copy_(saved[0])
             cap.embed.weight.copy_(saved[1])
+
+
+def test_position_embedding_kernel_equals_torch_formulation(built):
+    """gvl_pos_embed_sine_f32 (one launch per pyramid level) against the PyTorch op sequence that mirrors
+    position_encoding.py:38-64, incl. the gradient of the duration embedding; ragged masks, T = 1 and T > blockDim."""
+    f, model, criterion, dev = built
+    pe = model.base_encoder.pos_embed
+    g = torch.Generator().manual_seed(2)
+    for T in (1, 13, 100, 700):
+        N = 3
+        valid = torch.randint(1, T + 1, (N,), generator=g)
+        mask = (torch.arange(T)[None] >= valid[:, None]).to(dev)
+        mask[0] = False
+        duration = torch.tensor([30.0, 200.0, 255.9], device=dev)
+        x = torch.zeros(N, 512, T, device=dev)
+        pe.zero_grad()
+        out = pe(x, mask, duration)
+        gout = torch.randn(out.shape, generator=g).to(dev)
+        (out * gout).sum().backward()
+        grads = [p_.grad.clone() for p_ in pe.parameters()]
+        pe.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float32):      # autocast on -> the module takes its PyTorch formulation
+            ref = pe(x, mask, duration)
+        (ref * gout).sum().backward()
+        assert out.shape == ref.shape == (N, 512, T)
+        assert maxerr(out, ref) <= 2e-6
+        for a_, p_ in zip(grads, pe.parameters()):
+            assert maxerr(a_, p_.grad) <= 1e-4 * max(1.0, float(p_.grad.abs().max()))
