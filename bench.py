@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the caption decoding loop from a hipGraph")
+    ap.add_argument("--split-exchange", action="store_true",
+                    help="--mode train on one GPU in the data-parallel form (two graphs + eager exchange point); diagnostic")
     ap.add_argument("--no-tuned-gemm", action="store_true",
                     help="keep hipBLASLt's default kernel choice instead of gvl_amd/tunableop_mi355x.csv")
     a = ap.parse_args()
@@ -222,11 +224,14 @@ def main():
     else:
         from gvl_amd.parallel import GraphedTrainStep, TrainStep
         model.train()
-        # hipGraph replay of the whole step is validated on one GPU (tests/test_gpu_model.py); with RCCL collectives
-        # inside the capture it is opt-in (GVL_GRAPH_DP=1) until it has been exercised on a multi-GPU node
-        use_graph = not a.no_graph and (world == 1 or os.environ.get("GVL_GRAPH_DP") == "1")
-        a.no_graph = not use_graph
-        trainer = (GraphedTrainStep if use_graph else TrainStep)(model, criterion, opt, world_size=world)
+        # one process: the whole step is ONE hipGraph; several processes: forward/backward graph, eager bucketed RCCL
+        # all-reduce of the flat gradient buffer, clip/Adam graph (no collective inside a graph) -- GraphedTrainStep
+        use_graph = not a.no_graph
+        if use_graph:
+            trainer = GraphedTrainStep(model, criterion, opt, world_size=world,
+                                       split_exchange=True if a.split_exchange else None)
+        else:
+            trainer = TrainStep(model, criterion, opt, world_size=world)
         if a.dtype == "bf16":
             raise SystemExit("--dtype bf16 is wired for the eval forward; the train step is measured in fp32")
 

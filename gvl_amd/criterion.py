@@ -111,6 +111,7 @@ class SetCriterion(nn.Module):
         self.counter_class_rate = torch.tensor(COUNTER_CLASS_RATE)
         self.device_matching = True      # solve the Hungarian problems on the GPU (bit-identical to scipy)
         self.fused = True                # all layers' losses in one HIP launch per direction (SetCriterionFunction)
+        self.num_boxes_override = None   # set by a caller that has already taken the cross-rank mean (graph capture)
         self._const_cache = {}
 
     @staticmethod
@@ -256,7 +257,9 @@ class SetCriterion(nn.Module):
         num_boxes = sum(len(t_["labels"]) for t_ in targets)
         # criterion.py:178-181.  Only while training: the reference never evaluates under a process group, and an
         # eval forward sharded by video must not synchronise the ranks (its losses are per-rank diagnostics)
-        if is_dist_avail_and_initialized() and torch.is_grad_enabled():
+        if self.num_boxes_override is not None:
+            num_boxes = float(self.num_boxes_override)
+        elif is_dist_avail_and_initialized() and torch.is_grad_enabled():
             nb = torch.as_tensor([num_boxes], dtype=torch.float, device=outputs['pred_logits'].device)
             dist.all_reduce(nb)
             num_boxes = torch.clamp(nb / get_world_size(), min=1).item()

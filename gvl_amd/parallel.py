@@ -39,7 +39,10 @@ def shard_batch(dt, rank, world):
 class GradBuckets:
     """Flat gradient storage + overlapped bucketed all-reduce."""
 
-    def __init__(self, params, bucket_bytes=25 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=25 << 20, process_group=None, flat=None, overlap=True):
+        """flat=None: flat buffer exactly when there is more than one process.  overlap=False: no autograd hooks --
+        the buckets are exchanged by an explicit ``exchange()`` after backward (what a captured forward/backward
+        needs: collectives stay outside the hipGraph)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -47,7 +50,8 @@ class GradBuckets:
         # per-parameter accumulate kernel into a pre-existing buffer (133 launches per step; the step is launch-bound).
         self.flat = None
         self.buckets, self.bucket_of, self.ready, self.handles = [], {}, [], []
-        if self.world == 1:
+        self.overlap = overlap
+        if not (self.world > 1 if flat is None else flat):
             return
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
@@ -69,7 +73,7 @@ class GradBuckets:
             self.buckets.append((cur_start, off, cur_n))
         self.ready = [0] * len(self.buckets)
         self.handles = []
-        if self.world > 1:
+        if self.world > 1 and overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
@@ -89,10 +93,21 @@ class GradBuckets:
         self.ready = [0] * len(self.buckets)
         self.handles = []
 
+    def exchange(self):
+        """non-overlapped variant: all-reduce every bucket now (on the current stream's ordering) and average"""
+        if self.world == 1 or self.flat is None:
+            return
+        handles = [dist.all_reduce(self.flat[s:e], group=self.group, async_op=True) for s, e, _ in self.buckets]
+        for h in handles:
+            h.wait()
+        self.flat.div_(self.world)
+
     def finish(self):
         """wait for the in-flight buckets, reduce the ones whose parameters got no gradient this step, average."""
-        if self.world == 1:
+        if self.world == 1 or self.flat is None:
             return
+        if not self.overlap:
+            return self.exchange()
         for b, (s, e, n) in enumerate(self.buckets):
             if self.ready[b] != n:                       # some parameter unused this step: reduce the bucket now
                 self.handles.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
@@ -104,10 +119,11 @@ class GradBuckets:
 class TrainStep:
     """zero_grad -> forward -> weighted loss -> backward (+ overlapped all-reduce) -> clip -> Adam (train.py:385-409)"""
 
-    def __init__(self, model, criterion, opt, world_size=1, process_group=None, capturable=False):
+    def __init__(self, model, criterion, opt, world_size=1, process_group=None, capturable=False, flat=None,
+                 overlap=True):
         self.model, self.criterion, self.opt = model, criterion, opt
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.buckets = GradBuckets(self.params, process_group=process_group)
+        self.buckets = GradBuckets(self.params, process_group=process_group, flat=flat, overlap=overlap)
         # fused=True: one multi-tensor kernel per ~100 parameters instead of ~15 foreach kernels each (321 -> ~10
         # launches per step; the step is launch-bound even inside a hipGraph).  Same update rule (train.py:286).
         fused = self.params[0].is_cuda
@@ -136,8 +152,15 @@ class GraphedTrainStep(TrainStep):
     Inputs are copied into static buffers before every replay; the batch layout (tensor shapes, number of events per
     video, teacher-forcing length) is the cache key."""
 
-    def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=3):
-        super().__init__(model, criterion, opt, world_size, process_group, capturable=True)
+    def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=3, split_exchange=None):
+        """split_exchange (default: exactly when there is more than one process): the step is captured as TWO graphs --
+        zero_grad + forward + backward into the flat gradient buffer, then clip + Adam -- with the bucketed RCCL
+        all-reduce issued eagerly between the two replays, so no collective is ever inside a hipGraph.  The criterion's
+        own ``all_reduce(num_boxes)`` (criterion.py:178-180) is taken before the first graph from the host-known
+        target counts."""
+        self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
+        super().__init__(model, criterion, opt, world_size, process_group, capturable=True,
+                         flat=True if self.split else None, overlap=not self.split)
         self.graphs = {}
         # >= 1 real step must run before the capture (on a side stream): autograd's gradient accumulators, hipBLASLt
         # workspaces and the library's lazily built constants have to exist before a stream is capturing
@@ -187,7 +210,61 @@ class GraphedTrainStep(TrainStep):
     def _eager(self, dt):
         return TrainStep.__call__(self, dt)
 
+    def _global_num_boxes(self, dt):
+        """criterion.py:178-181, outside any capture: mean over the ranks of the (host-known) number of targets"""
+        n = float(sum(len(t_["labels"]) for t_ in dt["video_target"]))
+        if dist.is_available() and dist.is_initialized() and self.world > 1:
+            nb = torch.tensor([n], dtype=torch.float32, device=self.params[0].device)
+            dist.all_reduce(nb)
+            n = float(nb.item()) / self.world
+        return max(n, 1.0)
+
+    def _forward_backward(self, dt):
+        self.buckets.zero()
+        out, loss = self.model(dt, self.criterion, None, self.opt.transformer_input_type)
+        wd = self.criterion.weight_dict
+        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        final.backward()
+        return final.detach(), loss
+
+    def _update(self):
+        torch.nn.utils.clip_grad_norm_(self.params, self.opt.grad_clip)
+        self.optimizer.step()
+
+    def _call_split(self, dt):
+        nb = self._global_num_boxes(dt)
+        key = self._key(dt) + (nb,)
+        entry = self.graphs.get(key)
+        self.criterion.num_boxes_override = nb                # a kernel argument of the captured criterion
+        try:
+            if entry is None:
+                st = GraphedTrainStep._static_copy(dt)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(self.warmup):
+                        self._forward_backward(st)
+                        self.buckets.exchange()
+                        self._update()
+                torch.cuda.current_stream().wait_stream(side)
+                g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb):
+                    outs = self._forward_backward(st)
+                with torch.cuda.graph(g_up, pool=g_fb.pool()):
+                    self._update()
+                entry = self.graphs[key] = (g_fb, g_up, st, outs)
+            g_fb, g_up, st, outs = entry
+            self._refresh(st, dt)
+            g_fb.replay()
+            self.buckets.exchange()                           # eager RCCL between the two replays
+            g_up.replay()
+        finally:
+            self.criterion.num_boxes_override = None
+        return outs
+
     def __call__(self, dt):
+        if self.split:
+            return self._call_split(dt)
         key = self._key(dt)
         entry = self.graphs.get(key)
         if entry is None:

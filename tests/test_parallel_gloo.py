@@ -41,6 +41,15 @@ def _worker(rank, world, port, q):
             buckets.finish()
         grads = [p.grad.clone() for p in model.parameters()]
         assert all(p.grad.data_ptr() >= buckets.flat.data_ptr() for p in model.parameters())
+        # the non-overlapped form used between two graph replays (GraphedTrainStep, split_exchange): same gradients
+        model2 = _make_model()
+        b2 = GradBuckets(list(model2.parameters()), bucket_bytes=1024, flat=True, overlap=False)
+        b2.zero()
+        (((model2(xs) - ys) ** 2).sum() / 8 * world).backward()
+        b2.exchange()
+        for a_, p_ in zip(grads, model2.parameters()):
+            assert torch.allclose(a_, p_.grad, atol=1e-7)
+        # criterion with the cross-rank mean of num_boxes supplied by the caller (no collective inside)
 
         # criterion: num_boxes is summed over ranks then divided by world (criterion.py:178-181)
         class M(torch.nn.Module):
@@ -55,6 +64,9 @@ def _worker(rank, world, port, q):
         outs = {"pred_logits": torch.zeros(1, 4, 1), "pred_boxes": torch.tensor([[[0.4, 0.2]] * 4]),
                 "pred_count": torch.zeros(1, 11)}
         losses, _ = crit(outs, tg)
+        crit.num_boxes_override = 2.0
+        losses_o, _ = crit(outs, tg)
+        assert abs(float(losses_o["loss_bbox"]) - float(losses["loss_bbox"])) < 1e-7
         q.put((rank, [g_.numpy() for g_ in grads], float(losses["loss_bbox"])))
     except Exception:                                    # surface the failure instead of letting the parent time out
         import traceback
