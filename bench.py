@@ -209,7 +209,7 @@ def main():
         for head in model.caption_head:
             head.graph_decode = not a.no_graph
 
-        if a.no_graph or a.dtype == "bf16":
+        if a.no_graph:
             def step():
                 with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
                     return model(dt, criterion, None, "queries", eval_mode=True)
@@ -217,7 +217,8 @@ def main():
             # the whole forward (not only the decoding loop) replayed from one hipGraph; the kernel stamps of the
             # roofline block come from instrumented eager forwards after the timed region (as in --mode train)
             from gvl_amd.parallel import GraphedEvalForward
-            graphed_eval = GraphedEvalForward(model, criterion)
+            graphed_eval = GraphedEvalForward(model, criterion,
+                                              autocast_dtype=torch.bfloat16 if a.dtype == "bf16" else None)
 
             def step():
                 return graphed_eval(dt)
@@ -257,7 +258,7 @@ def main():
     MSDA.profile_enable(False)
     ktimes = kernel_times(MSDA.profile_collect())
     roofline_source = "per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region"
-    if not a.no_graph and (a.mode == "train" or a.dtype == "f32"):
+    if not a.no_graph:
         # the timed steps are hipGraph replays: the library launches nothing at replay time, so the kernel stamps come
         # from two instrumented eager steps run right after the timed region (same process, same inputs)
         MSDA.profile_enable(True)
@@ -265,7 +266,7 @@ def main():
             if a.mode == "train":
                 trainer._eager(dt)
             else:
-                with torch.no_grad():
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
                     model(dt, criterion, None, "queries", eval_mode=True)
         torch.cuda.synchronize()
         MSDA.profile_enable(False)

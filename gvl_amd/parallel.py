@@ -295,8 +295,9 @@ class GraphedEvalForward:
     graph leaves on the device.  Returned tensors are the graph's static outputs: they are overwritten by the next
     call (clone what must survive)."""
 
-    def __init__(self, model, criterion, transformer_input_type="queries", warmup=1):
+    def __init__(self, model, criterion, transformer_input_type="queries", warmup=1, autocast_dtype=None):
         self.model, self.criterion, self.kind = model, criterion, transformer_input_type
+        self.autocast_dtype = autocast_dtype          # e.g. torch.bfloat16: capture the forward under torch.autocast
         self.warmup = max(1, int(warmup))
         self.graphs = {}
 
@@ -308,7 +309,8 @@ class GraphedEvalForward:
         return sig, tuple(len(t_["boxes"]) for t_ in dt["video_target"]), epoch
 
     def _forward(self, dt):
-        return self.model(dt, self.criterion, None, self.kind, eval_mode=True)
+        with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+            return self.model(dt, self.criterion, None, self.kind, eval_mode=True)
 
     @staticmethod
     def _matches(out):
