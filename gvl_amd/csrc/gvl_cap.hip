@@ -252,19 +252,26 @@ __global__ void __launch_bounds__(256) k_row_argmax_lse(const float *__restrict_
     if (v > m) { s = s * __expf(m - v) + 1.f; m = v; am = i; }
     else { s += __expf(v - m); }
   };
-  // 8-byte loads when the row starts 8-byte aligned (V even or row even): half the load instructions of the dword
-  // version for a kernel whose only job is to stream 163 MB once
-  if ((((uintptr_t)x) & 7) == 0) {
-    const int V2 = V >> 1;
-    const float2 *x2 = reinterpret_cast<const float2 *>(x);
-    for (int i = threadIdx.x; i < V2; i += blockDim.x) {
-      const float2 v = x2[i];
-      take(v.x, 2 * i);
-      take(v.y, 2 * i + 1);
+  // 16-byte loads over the 16-byte aligned body of the row (rows of V floats start at 4-, 8- or 16-byte boundaries):
+  // a kernel whose only job is to stream 163 MB once wants few, wide loads in flight.  Thread 0 takes the <= 3 leading
+  // and trailing elements, in index order (ties resolve to the first maximal index).
+  {
+    const int head = min(V, (int)(((16 - (((uintptr_t)x) & 15)) & 15) >> 2));
+    const int nbody = (V - head) >> 2;
+    const int tail0 = head + 4 * nbody;
+    if (threadIdx.x == 0)
+      for (int i = 0; i < head; ++i) take(x[i], i);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
+    for (int i = threadIdx.x; i < nbody; i += blockDim.x) {
+      const float4 v = x4[i];
+      const int base = head + 4 * i;
+      take(v.x, base);
+      take(v.y, base + 1);
+      take(v.z, base + 2);
+      take(v.w, base + 3);
     }
-    if ((V & 1) && threadIdx.x == 0) take(x[V - 1], V - 1);
-  } else {
-    for (int i = threadIdx.x; i < V; i += blockDim.x) take(x[i], i);
+    if (threadIdx.x == 0)
+      for (int i = tail0; i < V; ++i) take(x[i], i);
   }
   // wave reduction of (m, s, am)
 #pragma unroll
