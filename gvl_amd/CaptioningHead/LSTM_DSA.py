@@ -125,6 +125,27 @@ class ShowAttendTellCore(nn.Module):
             cached = self._inf_w = (key, w)
         return cached[1]
 
+    # -- the fused inference token step in two halves: the first does not depend on the input token -----------------
+    def attend_part(self, h, reference_points, temporal_shapes, level_start_index, const):
+        """h -> (attention part of the gate pre-activations (n, 4H), [h2att(h) | h W_hh^T] (n, A + 4H))"""
+        shapes2d = const.get("shapes2d")
+        if shapes2d is None:
+            shapes2d = const["shapes2d"] = temporal_shapes_2d(temporal_shapes, level_start_index)
+            const["ref_in"] = reference_points.contiguous()
+        A = self.att_hid_size
+        g_h = F.linear(h, const["w_h_cat"], const["b_h_cat"])           # (n, A + 4H): [h2att(h) | h W_hh^T]
+        att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
+                                  h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
+                                  self.n_levels, self.n_points)
+        return torch.mm(att_res, const["w_att_t"]), g_h                 # (the hs part, gates_hs, is added in the cell)
+
+    def cell_part(self, g_x, g_h, xt_gates, c, const):
+        """(gate parts, input token) -> (h', c')"""
+        if not isinstance(xt_gates, tuple):                             # per-row pre-activations given directly
+            xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
+        emb_gates, it = xt_gates                                        # (table (V+1,4H), token ids)
+        return MSDA.lstm_cell(g_x, g_h[:, self.att_hid_size:], emb_gates, it, c, gates_c=const["gates_hs"])
+
     def step(self, xt_gates, state, query, reference_points, temporal_shapes, level_start_index, const):
         """one token.  xt_gates = embed(it) @ W_ih[:, :E]^T  (B*Q, 4H)"""
         att = self.deformable_att
@@ -134,20 +155,8 @@ class ShowAttendTellCore(nn.Module):
         C = self.att_feat_size
         E = self.input_encoding_size
         if "w_off_h" in const and not torch.is_grad_enabled():
-            shapes2d = const.get("shapes2d")
-            if shapes2d is None:
-                shapes2d = const["shapes2d"] = temporal_shapes_2d(temporal_shapes, level_start_index)
-                const["ref_in"] = reference_points.contiguous()
-            A = self.att_hid_size
-            g_h = F.linear(h, const["w_h_cat"], const["b_h_cat"])           # (n, A + 4H): [h2att(h) | h W_hh^T]
-            att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
-                                      h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
-                                      self.n_levels, self.n_points)
-            g_x = torch.mm(att_res, const["w_att_t"])                         # attention part of W_ih x (the hs part,
-            if not isinstance(xt_gates, tuple):                               # gates_hs, is added inside the cell kernel)
-                xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
-            emb_gates, it = xt_gates                                          # (table (V+1,4H), token ids)
-            h2, c2 = MSDA.lstm_cell(g_x, g_h[:, A:], emb_gates, it, c, gates_c=const["gates_hs"])
+            g_x, g_h = self.attend_part(h, reference_points, temporal_shapes, level_start_index, const)
+            h2, c2 = self.cell_part(g_x, g_h, xt_gates, c, const)
             return h2, (h2, c2)
         if isinstance(xt_gates, tuple):                                   # (pre-multiplied table, token ids)
             xt_gates = xt_gates[0].index_select(0, xt_gates[1])
@@ -411,6 +420,9 @@ class Captioner(nn.Module):
             unfinished = torch.empty(n, dtype=torch.uint8, device=hs.device)
             seq = torch.empty(n, T, dtype=torch.long, device=hs.device)
             seq_lp = torch.empty(n, T, dtype=torch.float32, device=hs.device)
+            # (running the vocabulary GEMM + argmax of token t on a second stream beside the token-independent half of
+            #  step t+1 was tried -- fork / join inside the captured graph -- and measured no gain: 742-757 vs 750
+            #  videos/s; the GEMMs already occupy every CU)
             for t in range(T + 1):
                 if t > 0:
                     it = MSDA.greedy_step(logits, t - 1, unfinished, seq, seq_lp)
