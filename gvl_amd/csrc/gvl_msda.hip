@@ -36,7 +36,7 @@ using gvl::fail;
 using gvl::ensure_lds;
 
 thread_local int g_last_impl = 0;
-unsigned long long *g_fwd_stamps = nullptr;   // diagnostics, see gvl_msda_debug_stamps
+unsigned long long *g_fwd_stamps = nullptr, *g_bwd_stamps = nullptr;   // diagnostics, see gvl_msda_debug_stamps
 int g_impl = -1;  // -1 = read the environment on first use
 
 int impl_mode() {
@@ -271,6 +271,22 @@ __device__ inline float row_allsum(float v) {
   v += dpp_f<0x124>(v);   // row_ror:4
   v += dpp_f<0x128>(v);   // row_ror:8
   return v;
+}
+
+// Reduce-scatter of v[16] over the 16 lanes of every DPP row: afterwards lane j holds sum over the row's lanes of v[j].
+// Four halving stages whose partners differ in exactly the bit that selects the kept half (row_mirror: j <-> 15-j,
+// row_half_mirror: j <-> 7-j inside 8, quad_perm [3,2,1,0] and [1,0,3,2]) -- 15 DPP adds + 30 selects for 16 sums,
+// where 16 separate row all-reduces cost 64 DPP adds (and leave every sum on every lane, which nobody needs).
+__device__ inline float row_reduce_scatter16(const float (&v)[16], int j) {
+  float a8[8], a4[4], a2[2];
+  const bool b3 = j & 8, b2 = j & 4, b1 = j & 2, b0 = j & 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a8[i] = (b3 ? v[8 + i] : v[i]) + dpp_f<0x140>(b3 ? v[i] : v[8 + i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a4[i] = (b2 ? a8[4 + i] : a8[i]) + dpp_f<0x141>(b2 ? a8[i] : a8[4 + i]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a2[i] = (b1 ? a4[2 + i] : a4[i]) + dpp_f<0x1B>(b1 ? a4[i] : a4[2 + i]);
+  return (b0 ? a2[1] : a2[0]) + dpp_f<0xB1>(b0 ? a2[0] : a2[1]);
 }
 
 // Interpolation coefficients of ONE temporal sample against the LDS slab, expressed on the row pair (r, r+1):
@@ -586,8 +602,13 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
                                                              const VT *__restrict__ gout, int B, int S, int M, int L,
                                                              int Q, int P, int RD, int nchunk, int qper,
                                                              float *__restrict__ gvalue_part,
-                                                             void *__restrict__ gloc, float *__restrict__ gattn) {
+                                                             void *__restrict__ gloc, float *__restrict__ gattn,
+                                                             unsigned long long *__restrict__ stamps) {
   extern __shared__ float4 slab4[];
+  __shared__ int next_blk_s;
+  int *next_blk = &next_blk_s;
+  // diagnostics (gvl_msda_debug_stamps): {start, staged, phase 1 done, phase 2 done}; the kernel end closes phase 3
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;    // see k_fwd_t1d_d64
   const int rowsV = S - row0 + 1;
   const int rowsA = (rowsV > qper ? rowsV : qper);
@@ -628,6 +649,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
   for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
   for (int i = threadIdx.x; i < qper * kEntStride; i += blockDim.x) ent_r[i] = -1;
   __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
 
   // ---- phase 1 ---------------------------------------------------------------------------------------------
   for (; qb < q1; qb += nw * 4) {
@@ -666,7 +688,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
         atomicAdd(&cnt[roff], 1);
       }
     }
-    float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;
+    // per sample the two dot products g . V[r], g . V[r+1]: every lane accumulates its 4-channel part for all 16
+    // samples, then two DPP-row reduce-scatters leave sample j's sums on lane j (the lane that holds its coefficients)
+    float p0[16], p1[16];
 #define GVL_BWD_STEP(SI)                                                      \
   if (FULL16 || SI < LP) {                                                    \
     const int rr = row_bcast_i<SI>(roff);                                     \
@@ -678,19 +702,21 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
       v0 = slab4[(rr - row0) * 16 + j];                                       \
       v1 = slab4[(rr - row0) * 16 + 16 + j];                                  \
     }                                                                         \
-    const float d0 = row_allsum(dot4(g, v0));                                 \
-    const float d1 = row_allsum(dot4(g, v1));                                 \
-    if (j == SI) {                                                            \
-      keep_w = fmaf(clo, d0, chi * d1);                                       \
-      keep_x = fmaf(dxlo, d0, dxhi * d1);                                     \
-      keep_y = fmaf(dylo, d0, dyhi * d1);                                     \
-    }                                                                         \
+    p0[SI] = dot4(g, v0);                                                     \
+    p1[SI] = dot4(g, v1);                                                     \
+  } else {                                                                    \
+    p0[SI] = 0.f;                                                             \
+    p1[SI] = 0.f;                                                             \
   }
     GVL_BWD_STEP(0) GVL_BWD_STEP(1) GVL_BWD_STEP(2) GVL_BWD_STEP(3)
     GVL_BWD_STEP(4) GVL_BWD_STEP(5) GVL_BWD_STEP(6) GVL_BWD_STEP(7)
     GVL_BWD_STEP(8) GVL_BWD_STEP(9) GVL_BWD_STEP(10) GVL_BWD_STEP(11)
     GVL_BWD_STEP(12) GVL_BWD_STEP(13) GVL_BWD_STEP(14) GVL_BWD_STEP(15)
 #undef GVL_BWD_STEP
+    const float d0 = row_reduce_scatter16(p0, j), d1 = row_reduce_scatter16(p1, j);
+    const float keep_w = fmaf(clo, d0, chi * d1);
+    const float keep_x = fmaf(dxlo, d0, dxhi * d1);
+    const float keep_y = fmaf(dylo, d0, dyhi * d1);
     if (!FUSED) {
       if (act && j < LP) {
         gattn[tb + j] = keep_w;                                                // cuh:156-157
@@ -718,12 +744,13 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     }
   }
   __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
 
   // ---- phase 2: exclusive scan of cnt -> off, reset cnt as the fill cursor; stage grad_out rows over the slab ----
   {
     __shared__ int wave_tot[kBwdThreads / 64];
     __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    if (threadIdx.x == 0) { carry_s = 0; next_blk_s = 0; }
     __syncthreads();
     for (int base = 0; base < S + 1; base += blockDim.x) {
       const int i = base + threadIdx.x;
@@ -756,28 +783,52 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     if (r >= 0) sorted[off[r] + atomicAdd(&cnt[r], 1)] = e;
   }
   __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = wall_clock64();
 
   // ---- phase 3: gather.  A DPP row (16 lanes x float4) owns one slab row; the four rows of a wavefront are
   // neighbours (similar list lengths).  Lane j fetches entry j of the batch, (query, coefficient) are broadcast
   // inside the row with row_newbcast and the query's grad_out row is one conflict-free ds_read_b128 per lane.
   float4 *dst4 = reinterpret_cast<float4 *>(gvalue_part) + ((int64_t)chunk * B * S * M) * 16 + ((int64_t)b * S * M + m) * 16;
   const int ngroups = blockDim.x >> 4;
-  for (int s = threadIdx.x >> 4; s < S; s += ngroups) {
-    const int a1 = off[s], n1 = off[s + 1] - a1;                      // entries with r == s     -> c_lo
-    const int a0 = s > 0 ? off[s - 1] : 0, n0 = s > 0 ? a1 - a0 : 0;  // entries with r == s - 1 -> c_hi
-    const int n = n1 + n0;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const char *G_b = reinterpret_cast<const char *>(G4);
+  const int lane_off = j * 16;
+  // Rows are handed out dynamically, four adjacent rows per wavefront, from the LAST row down: the coarse levels at the
+  // end of the slab have the longest entry lists (the same 4 points per query over 13 instead of 100 rows), and a
+  // static row -> group map left most wavefronts idle while a few worked through them.
+  (void)ngroups;
+  for (;;) {
+    int blk = 0;
+    if (lane == 0) blk = atomicAdd(next_blk, 1);
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    if (blk * 4 >= S) break;
+    const int s = S - 1 - (blk * 4 + tq);
+    const bool live = s >= 0;
+    const int sc = live ? s : 0;
+    const int a1 = off[sc], n1 = live ? off[sc + 1] - a1 : 0;           // entries with r == s     -> c_lo
+    const int a0 = sc > 0 ? off[sc - 1] : 0, n0 = (live && sc > 0) ? a1 - a0 : 0;  // entries with r == s - 1 -> c_hi
+    const int n_own = n1 + n0;
+    // the four rows of the wavefront run in lockstep: loop to the longest of their lists
+    int n = max(n_own, __shfl_xor(n_own, 16, 64));
+    n = max(n, __shfl_xor(n, 32, 64));
+    f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
     for (int base = 0; base < n; base += 16) {
       const int i = base + j;
-      int tl = 0;
-      float cf = 0.f;                                                 // past the end: (query 0, coefficient 0)
-      if (i < n) {
+      // (byte offset of the query's grad_out row, coefficient) travel as ONE 64-bit row broadcast; past the end:
+      // (row 0, coefficient 0)
+      f2v tc = {0.f, 0.f};
+      if (i < n_own) {
         const bool first = i < n1;
         const int e = sorted[first ? a1 + i : a0 + (i - n1)];
-        tl = e & ~15;                                                 // (e >> 4) * 16 float4 per grad_out row
-        cf = first ? ent_lo[e] : ent_hi[e];
+        tc = (f2v){__builtin_bit_cast(float, (e & ~15) << 4), first ? ent_lo[e] : ent_hi[e]};
       }
-#define GVL_GATHER_STEP(SI) acc = fma4(row_bcast_f<SI>(cf), G4[row_bcast_i<SI>(tl) + j], acc);
+#define GVL_GATHER_STEP(SI)                                                                            \
+  {                                                                                                    \
+    const f2v t2 = row_bcast_f2<SI>(tc);                                                               \
+    const float4 gq = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t2.x) + lane_off); \
+    const f2v cf = __builtin_shufflevector(t2, t2, 1, 1);                                              \
+    a01 = __builtin_elementwise_fma(cf, (f2v){gq.x, gq.y}, a01);                                       \
+    a23 = __builtin_elementwise_fma(cf, (f2v){gq.z, gq.w}, a23);                                       \
+  }
       GVL_GATHER_STEP(0) GVL_GATHER_STEP(1) GVL_GATHER_STEP(2) GVL_GATHER_STEP(3)
       if (n - base > 4) {
         GVL_GATHER_STEP(4) GVL_GATHER_STEP(5) GVL_GATHER_STEP(6) GVL_GATHER_STEP(7)
@@ -788,7 +839,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
       }
 #undef GVL_GATHER_STEP
     }
-    dst4[(int64_t)s * M * 16 + j] = acc;
+    const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
+    if (live) dst4[(int64_t)s * M * 16 + j] = acc;
   }
 }
 
@@ -919,7 +971,7 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
   if (int rc = ensure_lds(kern, lds)) return rc;
   if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, FUSED ? "k_bwd_t1d_d64<fused>" : "k_bwd_t1d_d64", kern,
                            dim3(nchunk * B * M), dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M,
-                           L, Q, P, RD, nchunk, qper, part, g0, g1))
+                           L, Q, P, RD, nchunk, qper, part, g0, g1, g_bwd_stamps))
     return rc;
   if (need) {
     const int64_t count4 = (int64_t)B * S * M * 16;
@@ -1063,7 +1115,10 @@ const char *gvl_last_error(void) { return gvl::g_err; }
 void gvl_msda_set_impl(int impl) { g_impl = (impl >= 0 && impl <= 2) ? impl : 0; }
 int gvl_msda_last_impl(void) { return g_last_impl; }
 
-void gvl_msda_debug_stamps(void *device_buffer) { g_fwd_stamps = (unsigned long long *)device_buffer; }
+void gvl_msda_debug_stamps(void *device_buffer) {
+  g_fwd_stamps = (unsigned long long *)device_buffer;
+  g_bwd_stamps = g_fwd_stamps ? g_fwd_stamps + 4 * 4096 : nullptr;        // backward: second half of the buffer
+}
 
 int gvl_prof_enable(int on) {
   gvl::Profiler &p = gvl::profiler();

@@ -135,8 +135,9 @@ int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const 
 #define GVL_PROF_CRITERION 16
 #define GVL_PROF_POS_EMBED 17
 int gvl_prof_enable(int on);
-/* Phase stamps of the temporal forward kernel (diagnostics): while a DEVICE buffer of 4 uint64 per workgroup is set,
- * every workgroup of k_fwd_t1d_d64 records the 100 MHz wall clock at {start, slab staged, loop done}.  NULL = off. */
+/* Phase stamps of the temporal kernels (diagnostics): while a DEVICE buffer of 2 x 4096 x 4 uint64 is set, every
+ * workgroup of k_fwd_t1d_d64 records the 100 MHz wall clock at {start, slab staged, loop done} in the first half and
+ * every workgroup of k_bwd_t1d_d64 {start, staged, phase 1 done, phase 2 done} in the second half.  NULL = off. */
 void gvl_msda_debug_stamps(void *device_buffer);
 int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
 

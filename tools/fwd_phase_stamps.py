@@ -17,7 +17,7 @@ torch.manual_seed(0)
 model, criterion, _, _ = build(opt)
 model = model.to(dev).eval()
 dt = synth_batch(16, 100, 512, opt.vocab_size, 3, dev)
-buf = torch.zeros(4 * 4096, dtype=torch.int64, device=dev)
+buf = torch.zeros(2 * 4 * 4096, dtype=torch.int64, device=dev)
 lib = _lib.lib()
 
 
@@ -52,4 +52,17 @@ with torch.no_grad():
         MSDA.msda1d_fused_forward(value, sh2, lsi, proj, ref, 4, 4)
     torch.cuda.synchronize()
     report("back-to-back, same shape")
+    lib.gvl_msda_debug_stamps(None)
+
+    # ---- backward, back-to-back (decoder shape) ---------------------------------------------------------------
+    gout = torch.randn(16, 300, 512, device=dev)
+    lib.gvl_msda_debug_stamps(buf.data_ptr())
+    for _ in range(3):
+        MSDA.msda1d_fused_backward(value, sh2, lsi, proj, ref, gout, 4, 4, need_ref_grad=True)
+    torch.cuda.synchronize()
+    s_ = buf.view(-1, 4)[4096:4096 + 256].cpu().numpy().astype(np.int64)
+    us = (s_ - s_[:, 0].min()) / 100.0
+    print(f"backward, back-to-back: start skew max {us[:, 0].max():5.2f} | staging mean {np.mean(us[:, 1] - us[:, 0]):5.2f} | "
+          f"phase 1 mean {np.mean(us[:, 2] - us[:, 1]):5.2f} | phase 2 mean {np.mean(us[:, 3] - us[:, 2]):5.2f} | "
+          f"phase 2 done at max {us[:, 3].max():5.2f} us (phase 3 = the rest of the kernel)")
     lib.gvl_msda_debug_stamps(None)
