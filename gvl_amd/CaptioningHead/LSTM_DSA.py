@@ -460,6 +460,8 @@ class Captioner(nn.Module):
         # constants of the captured graph: a parameter update must therefore lead to a new capture
         key = (tuple(hs.shape), tuple(reference.shape), tuple(memory.shape), str(hs.device),
                tuple(tshapes._gvl_host_lengths[0]), sum(p_._version for p_ in self.parameters()))
+        if cache and next(iter(cache))[-1] != key[-1]:
+            cache.clear()                                    # parameters changed: graphs of the old weights are dead
         entry = cache.get(key)
         if entry is None:
             static = [t_.clone() for t_ in (hs, reference, memory, mask, valid_ratios)]

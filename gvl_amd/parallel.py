@@ -324,6 +324,8 @@ class GraphedEvalForward:
     @torch.no_grad()
     def __call__(self, dt):
         key = self._key(dt)
+        if self.graphs and next(iter(self.graphs))[-1] != key[-1]:
+            self.graphs.clear()                              # parameters changed: graphs of the old weights are dead
         entry = self.graphs.get(key)
         heads = list(self.model.caption_head)
         if entry is None:
