@@ -346,6 +346,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                    # rank 0 ran the supplementary probes; leave together
         dist.destroy_process_group()
 
 
