@@ -184,11 +184,17 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {a.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test knobs (tests/test_gpu_bench_dp.py): several ranks on ONE GPU over gloo exercise the N > 1 control flow
+    dev_index = int(os.environ.get("GVL_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("GVL_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gvl_amd.config import make_opt
     from gvl_amd.pdvc import build
