@@ -408,6 +408,26 @@ __device__ inline RawOps fetch_ops(const void *__restrict__ p0, const float *__r
   return r;
 }
 
+// the same loads from per-lane ELEMENT OFFSETS that the caller advances by a constant per pass (no index arithmetic
+// in the loop): o0 into p0 (FUSED: the lane's offset column, its logit is MLP further; else the lane's (x, y) pair and
+// weight), o1 into p1 (FUSED: the reference point of the lane's level)
+template <bool FUSED, typename VT>
+__device__ inline RawOps fetch_at(const void *__restrict__ p0, const float *__restrict__ p1, int64_t o0, int64_t o1,
+                                  int MLP, int RD) {
+  RawOps r;
+  if (!FUSED) {
+    const float2 xy = reinterpret_cast<const float2 *>(p0)[o0];
+    r.a = xy.x; r.b = xy.y; r.c = p1[o0]; r.d = 0.f;
+  } else {
+    const VT *row = reinterpret_cast<const VT *>(p0) + o0;
+    r.a = (float)row[0];
+    r.b = (float)row[MLP];
+    r.c = p1[o1];
+    r.d = RD == 2 ? p1[o1 + 1] : 0.f;
+  }
+  return r;
+}
+
 __device__ inline float row_allmax(float v) {
   v = fmaxf(v, dpp_f<0xB1>(v));
   v = fmaxf(v, dpp_f<0x4E>(v));
@@ -468,8 +488,21 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
     st = (int)lsi[lvl];
   }
   int qb = q0 + wave * 4;
-  RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
-  if (qb < q1 && j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, (int64_t)b * Q + min(qb + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
+  // operand cursor: query index of the next fetch and the lane's element offsets for it, advanced by a constant per pass
+  int qf = qb + tq;
+  const int MLP = M * LP;
+  int64_t o0 = FUSED ? ((int64_t)b * Q + qf) * (2 * MLP) + m * LP + j : (((int64_t)b * Q + qf) * M + m) * LP + j;
+  int64_t o1 = FUSED ? (((int64_t)b * Q + qf) * L + lvl) * RD : 0;
+  const int64_t step0 = (int64_t)nw * 4 * (FUSED ? 2 * MLP : MLP), step1 = FUSED ? (int64_t)nw * 4 * L * RD : 0;
+  auto fetch_next = [&]() {
+    RawOps r = {0.f, 0.5f, 0.f, 0.f};
+    if (qf < q1 && j < LP) r = fetch_at<FUSED, VT>(loc, attn, o0, o1, MLP, RD);
+    qf += nw * 4;
+    o0 += step0;
+    o1 += step1;
+    return r;
+  };
+  RawOps r_n = fetch_next();
   // L0G: level 0 (rows [0, T_0)) stays in global memory, LDS holds rows [T_0, S); needs FULL16 and P == 4 so that
   // "sample step SI belongs to level 0" is the compile-time test SI < 4
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;
@@ -504,10 +537,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   int roff_c;
   f2v cc_c;
   prep(r_n, roff_c, cc_c);
-  {
-    const int qb1 = qb + nw * 4;                                       // operands of the second pass
-    if (qb1 < q1 && j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, (int64_t)b * Q + min(qb1 + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
-  }
+  r_n = fetch_next();                                                  // operands of the second pass
 #pragma unroll
   for (int k = 0; k < kPre; ++k) {
     const int i = threadIdx.x + k * blockDim.x;
@@ -529,8 +559,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
     // operands two passes ahead are requested now; the coefficients of the NEXT pass are computed at the end of this
     // one, from operands requested one pass ago
     const RawOps r_next = r_n;
-    const int qbn = qb + 2 * nw * 4;
-    if (qbn < q1 && j < LP) r_n = fetch_ops<FUSED, VT>(loc, attn, (int64_t)b * Q + min(qbn + tq, q1 - 1), m, M, LP, L, RD, j, lvl);
+    r_n = fetch_next();
     f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
     // per sample step: v_mov_b32_dpp (row), v_add (lane offset), v_mov_b64_dpp (both coefficients), 2 ds_read_b128,
     // 4 v_pk_fma_f32 -- the loop is VALU-issue bound (tools/fwd_phase_stamps.py), every instruction counts
