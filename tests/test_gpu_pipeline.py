@@ -67,3 +67,55 @@ def test_samples_to_result_file(tmp_path):
                 assert a["sentence"] == b["sentence"] and a["query_id"] == b["query_id"]
                 assert abs(a["proposal_score"] - b["proposal_score"]) < 1e-5
                 assert max(abs(x - y) for x, y in zip(a["timestamp"], b["timestamp"])) < 1e-3
+
+
+@pytest.mark.parametrize("B,T,Q,n_gt", [(1, 37, 30, [2]), (3, 64, 7, [1, 0, 4]), (2, 129, 33, [5, 3]), (5, 20, 12, [1, 1, 2, 3, 1])])
+def test_shape_sweep_eval_and_train(B, T, Q, n_gt):
+    """odd shapes through the whole model: batch 1, query counts that are not multiples of 4, ragged video lengths,
+    a video without events, T where the level lengths are odd -- eager == graphed eval, and one captured train step
+    with finite losses and gradients."""
+    import numpy as np
+    from gvl_amd.config import make_opt
+    from gvl_amd.parallel import GraphedEvalForward, GraphedTrainStep
+    from gvl_amd.pdvc import build
+    dev = torch.device("cuda:0")
+    opt = make_opt(num_queries=Q, feature_dim=24, vocab_size=50, max_caption_len=6, frame_embedding_num=T, device="cuda")
+    torch.manual_seed(B * 100 + T)
+    model, criterion, _, _ = build(opt)
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(T)
+    valid = [T] + [int(x) for x in torch.randint(max(2, T // 3), T + 1, (B - 1,), generator=g)]
+    vt = torch.randn(B, T, 24, generator=g)
+    vmask = torch.zeros(B, T, dtype=torch.bool)
+    for i, v in enumerate(valid):
+        vmask[i, :v] = True
+        vt[i, v:] = 0
+    targets = []
+    for n in n_gt:
+        c = torch.rand(n, generator=g) * 0.5 + 0.25
+        l_ = torch.rand(n, generator=g) * 0.3 + 0.1
+        targets.append({"boxes": torch.stack([c, l_], -1).to(dev), "labels": torch.zeros(n, dtype=torch.long, device=dev)})
+    ncap = sum(n_gt)
+    caps = torch.randint(1, 50, (ncap, 6), generator=g)
+    caps[:, 0] = 0
+    caps[:, -1] = 0
+    dt = {"video_tensor": vt.to(dev), "video_mask": vmask.to(dev),
+          "video_length": torch.tensor([[float(v), 50.0 + i, float(n)] for i, (v, n) in enumerate(zip(valid, n_gt))]).to(dev),
+          "video_target": targets, "cap_raw": [["x"] * n for n in n_gt], "cap_tensor": caps.to(dev),
+          "cap_mask": (caps != 0).float().to(dev).index_fill_(1, torch.tensor([0], device=dev), 1.0),
+          "gt_boxes_mask": torch.ones(B, max(1, max(n_gt)), dtype=torch.bool, device=dev)}
+    model.eval()
+    with torch.no_grad():
+        ref_out, ref_loss = model(dt, criterion, None, "queries", eval_mode=True)
+    out, loss = GraphedEvalForward(model, criterion)(dt)
+    for k in ("pred_logits", "pred_boxes", "pred_count"):
+        assert torch.isfinite(ref_out[k]).all() and float((out[k] - ref_out[k]).abs().max()) < 1e-5, k
+    assert torch.equal(out["seq"], ref_out["seq"])
+    model.train()
+    step = GraphedTrainStep(model, criterion, opt, warmup=1)
+    for _ in range(2):
+        final, losses = step(dt)
+    assert bool(torch.isfinite(final))
+    bad = [k for k, v in losses.items() if not torch.isfinite(v).all() and not k.startswith("loss_self_iou")]
+    assert not bad, bad
+    assert all(torch.isfinite(p_.grad).all() for p_ in model.parameters() if p_.grad is not None)
