@@ -610,3 +610,19 @@ def test_position_embedding_kernel_equals_torch_formulation(built):
         assert maxerr(out, ref) <= 2e-6
         for a_, p_ in zip(grads, pe.parameters()):
             assert maxerr(a_, p_.grad) <= 1e-4 * max(1.0, float(p_.grad.abs().max()))
+
+
+def test_graphed_eval_under_autocast_equals_eager_autocast(built_yc2):
+    """the captured forward under torch.autocast(bfloat16) reproduces the eager autocast forward (same kernels, same
+    casts) on the long-video batch"""
+    from gvl_amd.parallel import GraphedEvalForward
+    f, model, criterion, dev = built_yc2
+    dt = to_dev(pdvc_dt(f, feat=int(f["feature_dim"]), seed=4), dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ref_out, ref_loss = model(dt, criterion, None, "queries", eval_mode=True)
+    g = GraphedEvalForward(model, criterion, autocast_dtype=torch.bfloat16)
+    for _ in range(2):
+        out, loss = g(dt)
+        for k in ("pred_logits", "pred_boxes", "pred_count"):
+            assert out[k].dtype == ref_out[k].dtype and maxerr(out[k].float(), ref_out[k].float()) < 1e-6, k
+        assert torch.equal(out["seq"], ref_out["seq"])
