@@ -74,14 +74,14 @@ class ShowAttendTellCore(nn.Module):
         # the offsets projection splits into an h part (per step) and an hs part (constant)
         ow = att.sampling_offsets.weight
         off_hs = F.linear(query, ow[:, self.rnn_size:], att.sampling_offsets.bias)     # (B,Q,16)
-        const = {"slab": slab, "gates_hs": gates_hs, "off_hs": off_hs.contiguous()}
+        const = {"slab": slab, "gates_hs": gates_hs, "off_hs": off_hs.float().contiguous()}    # offsets stay fp32
         if not torch.is_grad_enabled():
             # inference: everything the fused token-step kernel (gvl_cap_attend_f32) needs, laid out once
             bias = self.alpha_net.bias
             if getattr(self, "_alpha_b_version", None) != bias._version:
                 self._alpha_b = float(bias.detach().cpu())        # one host read per weight update, not per step
                 self._alpha_b_version = bias._version
-            const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **self._inference_weights())
+            const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **self._inference_weights(slab.dtype))
         return const
 
     def fused_train_eligible(self, query):
@@ -106,24 +106,29 @@ class ShowAttendTellCore(nn.Module):
             self.alpha_net.bias.reshape(1), temporal_shapes_2d(temporal_shapes, level_start_index), level_start_index,
             self.n_levels, self.n_points)
 
-    def _inference_weights(self):
+    def _inference_weights(self, gemm_dtype=torch.float32):
         """Weight-only operands of the fused token step (re-laid-out / concatenated weights): rebuilt only when a
-        parameter changes (its autograd version counter), not once per forward."""
+        parameter changes (its autograd version counter), not once per forward.  gemm_dtype = bfloat16 under autocast:
+        the GEMM operands are stored in that type once (autocast would re-cast these derived, non-parameter tensors on
+        every call); the operands of the attention kernel stay fp32."""
         params = (self.deformable_att.sampling_offsets.weight, self.h2att.weight, self.h2att.bias, self.rnn.weight_hh_l0,
                   self.rnn.weight_ih_l0, self.alpha_net.weight)
-        key = tuple((p_.data_ptr(), p_._version) for p_ in params)
-        cached = getattr(self, "_inf_w", None)
-        if cached is None or cached[0] != key:
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (gemm_dtype,)
+        cache = self.__dict__.setdefault("_inf_w", {})
+        if cache and next(iter(cache))[:-1] != key[:-1]:
+            cache.clear()
+        w = cache.get(key)
+        if w is None:
             ow, E = params[0], self.input_encoding_size
-            with torch.no_grad():
+            with torch.no_grad(), torch.autocast("cuda", enabled=False):
                 w = dict(w_off_h=ow[:, :self.rnn_size].contiguous(),
                          alpha_w=self.alpha_net.weight.reshape(-1).contiguous(),
                          # one GEMM over h per step yields both h2att(h) and the recurrent gate pre-activations
-                         w_h_cat=torch.cat([self.h2att.weight, self.rnn.weight_hh_l0], 0),
-                         b_h_cat=torch.cat([self.h2att.bias, self.h2att.bias.new_zeros(4 * self.rnn_size)]),
-                         w_att_t=self.rnn.weight_ih_l0[:, E:E + self.att_feat_size].t().contiguous())
-            cached = self._inf_w = (key, w)
-        return cached[1]
+                         w_h_cat=torch.cat([self.h2att.weight, self.rnn.weight_hh_l0], 0).to(gemm_dtype),
+                         b_h_cat=torch.cat([self.h2att.bias, self.h2att.bias.new_zeros(4 * self.rnn_size)]).to(gemm_dtype),
+                         w_att_t=self.rnn.weight_ih_l0[:, E:E + self.att_feat_size].t().contiguous().to(gemm_dtype))
+            cache[key] = w
+        return w
 
     # -- the fused inference token step in two halves: the first does not depend on the input token -----------------
     def attend_part(self, h, reference_points, temporal_shapes, level_start_index, const):
@@ -191,6 +196,26 @@ class ShowAttendTellCore(nn.Module):
         out, (h, c) = self.step(xt_gates, (state[0][-1].contiguous(), state[1][-1].contiguous()), query,
                                 reference_points, input_spatial_shapes, input_level_start_index, const)
         return out, (h[None], c[None])
+
+
+def _bf16_decode(fn):
+    """Greedy / multinomial decoding under torch.autocast(bfloat16): the token loop's GEMMs run in bf16 and the three
+    token-step kernels read their bf16 outputs directly (gvl_cap_attend_bf16, gvl_lstm_cell_bf16, gvl_greedy_step_bf16);
+    positions (reference points, valid ratios, offsets) and the recurrent state stay fp32.  Any other autocast type
+    falls back to the fp32 island."""
+    import functools
+    island = _fp32_island(fn)
+
+    @functools.wraps(fn)
+    def wrapped(self, hs, reference, others, *args, **kwargs):
+        if not torch.is_autocast_enabled():
+            return fn(self, hs, reference, others, *args, **kwargs)
+        if torch.get_autocast_dtype("cuda") != torch.bfloat16 or torch.is_grad_enabled():
+            return island(self, hs, reference, others, *args, **kwargs)
+        others = dict(others)
+        others["valid_ratios"] = others["valid_ratios"].float()
+        return fn(self, hs, reference.float(), others, *args, **kwargs)
+    return wrapped
 
 
 class TeacherForcedLoop(torch.autograd.Function):
@@ -394,13 +419,14 @@ class Captioner(nn.Module):
 
     def _embedding_gates(self):
         """embedding table pre-multiplied by its slice of W_ih ((V+1, 4H); a 17.9 GFLOP GEMM at vocabulary 8517):
-        depends on weights only -> rebuilt when they change, not per forward"""
+        depends on weights only -> rebuilt when they change (or the autocast type does), not per forward"""
         w_e, w_ih = self.embed.weight, self.core.rnn.weight_ih_l0
-        key = (w_e.data_ptr(), w_e._version, w_ih.data_ptr(), w_ih._version)
+        ac = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else torch.float32
+        key = (w_e.data_ptr(), w_e._version, w_ih.data_ptr(), w_ih._version, ac)
         cached = getattr(self, "_emb_gates", None)
         if cached is None or cached[0] != key:
             with torch.no_grad():
-                cached = self._emb_gates = (key, F.linear(w_e, w_ih[:, :self.input_encoding_size]))
+                cached = self._emb_gates = (key, F.linear(w_e, w_ih[:, :self.input_encoding_size]).contiguous())
         return cached[1]
 
     def _decode_device(self, hs, reference, memory, mask, valid_ratios, tshapes, lsi, sample_max, temperature):
@@ -411,8 +437,8 @@ class Captioner(nn.Module):
         const = self.core.prepare(hs, memory, mask)
         # embedding rows pre-multiplied by their slice of W_ih: one gather per step instead of a GEMM
         emb_gates = self._embedding_gates()
-        h = hs.new_zeros(n, self.rnn_size)
-        c = hs.new_zeros(n, self.rnn_size)
+        h = torch.zeros(n, self.rnn_size, dtype=torch.float32, device=hs.device)      # the recurrent state is fp32, also
+        c = torch.zeros(n, self.rnn_size, dtype=torch.float32, device=hs.device)      # under autocast
         it = torch.zeros(n, dtype=torch.long, device=hs.device)                       # <bos>
         T = self.max_caption_len
         if sample_max:
@@ -459,7 +485,9 @@ class Captioner(nn.Module):
         # weight-derived operands are cached per parameter version (_inference_weights, _embedding_gates) and become
         # constants of the captured graph: a parameter update must therefore lead to a new capture
         key = (tuple(hs.shape), tuple(reference.shape), tuple(memory.shape), str(hs.device),
-               tuple(tshapes._gvl_host_lengths[0]), sum(p_._version for p_ in self.parameters()))
+               tuple(tshapes._gvl_host_lengths[0]),
+               torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None,
+               sum(p_._version for p_ in self.parameters()))
         if cache and next(iter(cache))[-1] != key[-1]:
             cache.clear()                                    # parameters changed: graphs of the old weights are dead
         entry = cache.get(key)
@@ -480,7 +508,7 @@ class Captioner(nn.Module):
         graph.replay()
         return outs
 
-    @_fp32_island
+    @_bf16_decode
     def sample(self, hs, reference, others, opt={}):
         """Greedy / multinomial decoding (LSTM_DSA.py:126-194) -> (seq (B*Q, <=max_len), logprobs)."""
         sample_max = opt.get('sample_max', 1)

@@ -214,14 +214,17 @@ def ms_deform_attn_sample_backward(value, spatial_shapes, level_start_index, sam
 
 def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off_h, att_h, alpha_w, alpha_b,
                n_levels, n_points, debug=False):
-    """Fused deformable soft attention of one captioner token step (include/gvl_msda.h: gvl_cap_attend_f32).
-    slab (B,S,2C) | ref_in (B,Q,L,1|2) | off_hs (B,Q,L*P) | h, att_h (B*Q,C) | w_off_h (L*P,C) | alpha_w (C,)"""
-    for name, t_ in (("slab", slab), ("ref_in", ref_in), ("off_hs", off_hs), ("h", h), ("w_off_h", w_off_h),
-                     ("alpha_w", alpha_w)):
+    """Fused deformable soft attention of one captioner token step (include/gvl_msda.h: gvl_cap_attend_f32 / _bf16).
+    slab (B,S,2C) | ref_in (B,Q,L,1|2) | off_hs (B,Q,L*P) | h, att_h (B*Q,C) | w_off_h (L*P,C) | alpha_w (C,)
+    slab and att_h: both fp32 or both bf16 (GEMM outputs under autocast); everything else fp32."""
+    st = slab.dtype
+    _require(st in (torch.float32, torch.bfloat16), "cap_attend: slab must be fp32 or bf16")
+    for name, t_ in (("ref_in", ref_in), ("off_hs", off_hs), ("h", h), ("w_off_h", w_off_h), ("alpha_w", alpha_w)):
         _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
                  f"cap_attend: {name} must be a contiguous fp32 CUDA tensor")
-    _require(att_h.is_cuda and att_h.dtype == torch.float32 and att_h.dim() == 2 and att_h.stride(1) == 1,
-             "cap_attend: att_h must be an fp32 CUDA matrix with unit column stride")
+    _require(slab.is_cuda and slab.is_contiguous(), "cap_attend: slab must be a contiguous CUDA tensor")
+    _require(att_h.is_cuda and att_h.dtype == st and att_h.dim() == 2 and att_h.stride(1) == 1,
+             "cap_attend: att_h must be a CUDA matrix of the slab's dtype with unit column stride")
     B, S, C2 = slab.shape
     C = C2 // 2
     Q = ref_in.shape[1]
@@ -231,7 +234,7 @@ def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off
     dbg_l = torch.empty((B * Q, n_levels * n_points), device=slab.device) if debug else None
     with torch.cuda.device(slab.device):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = _lib.lib().gvl_cap_attend_f32(
+        rc = getattr(_lib.lib(), "gvl_cap_attend_" + _SUFFIX[st])(
             slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
             off_hs.data_ptr(), h.data_ptr(), w_off_h.data_ptr(), att_h.data_ptr(), alpha_w.data_ptr(),
             float(alpha_b), B, S, C, n_levels, Q, n_points, RD, att_h.stride(0), att_res.data_ptr(),
@@ -327,33 +330,36 @@ def lstm_cell_train_backward(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, gra
 
 
 def lstm_cell(gates_a, gates_b, emb_gates, it, c, gates_c=None):
-    """fused LSTM cell pointwise step (include/gvl_msda.h: gvl_lstm_cell_f32) -> (h', c')"""
+    """fused LSTM cell pointwise step (include/gvl_msda.h: gvl_lstm_cell_f32 / _bf16) -> (h', c').  The gate operands
+    are all fp32 or all bf16; the state c (and the outputs) fp32."""
     n, H = c.shape
+    gt = gates_a.dtype
+    _require(gt in (torch.float32, torch.bfloat16) and c.dtype == torch.float32, "lstm_cell: gates fp32 | bf16, c fp32")
     for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b)) + ((("gates_c", gates_c),) if gates_c is not None else ()):
-        _require(t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1
-                 and t_.shape == (n, 4 * H), f"lstm_cell: {name} must be an (n, 4H) fp32 CUDA matrix")
-    _require(emb_gates.is_contiguous() and c.is_contiguous() and it.is_contiguous() and it.dtype == torch.int64,
-             "lstm_cell: emb_gates / c / it must be contiguous (it int64)")
+        _require(t_.is_cuda and t_.dtype == gt and t_.dim() == 2 and t_.stride(1) == 1
+                 and t_.shape == (n, 4 * H), f"lstm_cell: {name} must be an (n, 4H) CUDA matrix of the gates' dtype")
+    _require(emb_gates.is_contiguous() and emb_gates.dtype == gt and c.is_contiguous() and it.is_contiguous()
+             and it.dtype == torch.int64, "lstm_cell: emb_gates / c / it must be contiguous (it int64)")
     h_out, c_out = torch.empty_like(c), torch.empty_like(c)
     with torch.cuda.device(c.device):
-        rc = _lib.lib().gvl_lstm_cell_f32(gates_a.data_ptr(), gates_a.stride(0), gates_b.data_ptr(), gates_b.stride(0),
-                                          emb_gates.data_ptr(), it.data_ptr(),
-                                          gates_c.data_ptr() if gates_c is not None else None,
-                                          gates_c.stride(0) if gates_c is not None else 0, c.data_ptr(), n, H, h_out.data_ptr(),
-                                          c_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rc = getattr(_lib.lib(), "gvl_lstm_cell_" + _SUFFIX[gt])(
+            gates_a.data_ptr(), gates_a.stride(0), gates_b.data_ptr(), gates_b.stride(0), emb_gates.data_ptr(),
+            it.data_ptr(), gates_c.data_ptr() if gates_c is not None else None,
+            gates_c.stride(0) if gates_c is not None else 0, c.data_ptr(), n, H, h_out.data_ptr(), c_out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "lstm_cell")
     return h_out, c_out
 
 
 def row_argmax_lse(logits):
-    """(R, V) fp32 -> (argmax int64 (R,), log_softmax value at the argmax (R,)); first maximal index on ties."""
-    _require(logits.is_cuda and logits.is_contiguous() and logits.dtype == torch.float32 and logits.dim() == 2,
-             "row_argmax_lse: logits must be a contiguous fp32 CUDA matrix")
+    """(R, V) fp32 | bf16 -> (argmax int64 (R,), log_softmax value at the argmax (R,)); first maximal index on ties."""
+    _require(logits.is_cuda and logits.is_contiguous() and logits.dtype in (torch.float32, torch.bfloat16)
+             and logits.dim() == 2, "row_argmax_lse: logits must be a contiguous fp32 / bf16 CUDA matrix")
     R, V = logits.shape
     idx = torch.empty(R, dtype=torch.int64, device=logits.device)
     lp = torch.empty(R, dtype=torch.float32, device=logits.device)
     with torch.cuda.device(logits.device):
-        rc = _lib.lib().gvl_row_argmax_lse_f32(logits.data_ptr(), R, V, idx.data_ptr(), lp.data_ptr(),
+        rc = getattr(_lib.lib(), "gvl_row_argmax_lse_" + _SUFFIX[logits.dtype])(logits.data_ptr(), R, V, idx.data_ptr(), lp.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "row_argmax_lse")
     return idx, lp
@@ -363,8 +369,8 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp):
     """argmax + log-softmax-at-argmax of the (R, V) logits AND the greedy bookkeeping of decoding step t_col
     (include/gvl_msda.h: gvl_greedy_step_f32): updates unfinished (R,) uint8 and seq / seq_lp (R, T) in place at
     column t_col; -> raw argmax tokens (R,) int64"""
-    _require(logits.is_cuda and logits.is_contiguous() and logits.dtype == torch.float32 and logits.dim() == 2,
-             "greedy_step: logits must be a contiguous fp32 CUDA matrix")
+    _require(logits.is_cuda and logits.is_contiguous() and logits.dtype in (torch.float32, torch.bfloat16)
+             and logits.dim() == 2, "greedy_step: logits must be a contiguous fp32 / bf16 CUDA matrix")
     R, V = logits.shape
     _require(unfinished.dtype == torch.uint8 and seq.dtype == torch.int64
              and seq_lp.dtype == torch.float32 and seq.is_contiguous() and seq_lp.is_contiguous()
@@ -373,7 +379,7 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp):
     tok = torch.empty(R, dtype=torch.int64, device=logits.device)
     lp = torch.empty(R, dtype=torch.float32, device=logits.device)
     with torch.cuda.device(logits.device):
-        rc = _lib.lib().gvl_greedy_step_f32(
+        rc = getattr(_lib.lib(), "gvl_greedy_step_" + _SUFFIX[logits.dtype])(
             logits.data_ptr(), R, V, 1 if t_col == 0 else 0, tok.data_ptr(), lp.data_ptr(), unfinished.data_ptr(),
             seq.data_ptr() + 8 * t_col, seq_lp.data_ptr() + 4 * t_col, T,
             torch.cuda.current_stream().cuda_stream)

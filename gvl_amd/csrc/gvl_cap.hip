@@ -106,15 +106,17 @@ __device__ inline void border_coef(float loc, int T, int &r, float &c_lo, float 
   c_hi = (x0 == r + 1 ? t0 : 0.f) + (x0 + 1 == r + 1 ? t1 : 0.f);
 }
 
+// ST: storage type of the slab and of att_h (fp32, or bf16 as a GEMM under autocast leaves them); arithmetic fp32
+template <typename ST>
 __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
-    const float *__restrict__ slab,      // (B, S, 2C)  [value_proj(memory) | ctx2att(value_proj(memory))]
+    const ST *__restrict__ slab,         // (B, S, 2C)  [value_proj(memory) | ctx2att(value_proj(memory))]
     const int64_t *__restrict__ shapes,  // (L, 2)
     const int64_t *__restrict__ lsi,     // (L)
     const float *__restrict__ ref,       // (B, Q, L, RD) reference points scaled by the valid ratios
     const float *__restrict__ off_hs,    // (B*Q, 16)   sampling_offsets bias + hs part
     const float *__restrict__ h,         // (B*Q, C)    previous hidden state
     const float *__restrict__ w_off_h,   // (16, C)     sampling_offsets.weight[:, :C]
-    const float *__restrict__ att_h,     // (B*Q, C)    h2att(h), row stride att_h_ld floats
+    const ST *__restrict__ att_h,        // (B*Q, C)    h2att(h), row stride att_h_ld elements
     const float *__restrict__ alpha_w,   // (C)
     float alpha_b, int B, int S, int L, int Q, int P, int RD, int rows_per_xcd_group, int att_h_ld,
     float *__restrict__ att_res,         // (B*Q, C)
@@ -163,10 +165,10 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
   if (dbg_loc && (lane & 3) == 0 && k_own < LP) dbg_loc[row * LP + k_own] = locx;
 
   // ---- pass 1: attention logits from the ctx2att half ------------------------------------------------------
-  const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * (int64_t)att_h_ld);
-  const float4 ta = ah4[lane], tb = ah4[64 + lane];
+  const ST *ah = att_h + row * (int64_t)att_h_ld;
+  const float4 ta = ld4(ah, lane), tb = ld4(ah, 64 + lane);
   const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
-  const float4 *slab4 = reinterpret_cast<const float4 *>(slab) + (int64_t)b * S * (2 * kC / 4);
+  const ST *slab_b = slab + (int64_t)b * S * (2 * kC);                // this video's slab; ld4 indexes groups of 4 elements
   float e[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -176,9 +178,9 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
       const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_lo), 4 * k));
       const float ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_hi), 4 * k));
       const int rr1 = min(rr + 1, S - 1);           // c_hi == 0 whenever rr + 1 leaves the level (T_l == 1)
-      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4) + kC / 4;       // ctx2att half of row rr
-      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4) + kC / 4;
-      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      const int64_t r0 = (int64_t)rr * (2 * kC / 4) + kC / 4, r1 = (int64_t)rr1 * (2 * kC / 4) + kC / 4;   // ctx2att half
+      const float4 l0 = ld4(slab_b, r0 + lane), l1 = ld4(slab_b, r0 + 64 + lane), u0 = ld4(slab_b, r1 + lane),
+                   u1 = ld4(slab_b, r1 + 64 + lane);
       float s = 0.f;
       s = fmaf(qa.x, fast_tanh(fmaf(cl, l0.x, fmaf(ch, u0.x, ta.x))), s);
       s = fmaf(qa.y, fast_tanh(fmaf(cl, l0.y, fmaf(ch, u0.y, ta.y))), s);
@@ -208,9 +210,9 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
       const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_lo), 4 * k));
       const float ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_hi), 4 * k));
       const int rr1 = min(rr + 1, S - 1);
-      const float4 *r0 = slab4 + (int64_t)rr * (2 * kC / 4);                // value half of row rr
-      const float4 *r1 = slab4 + (int64_t)rr1 * (2 * kC / 4);
-      const float4 l0 = r0[lane], l1 = r0[64 + lane], u0 = r1[lane], u1 = r1[64 + lane];
+      const int64_t r0 = (int64_t)rr * (2 * kC / 4), r1 = (int64_t)rr1 * (2 * kC / 4);                     // value half
+      const float4 l0 = ld4(slab_b, r0 + lane), l1 = ld4(slab_b, r0 + 64 + lane), u0 = ld4(slab_b, r1 + lane),
+                   u1 = ld4(slab_b, r1 + 64 + lane);
       fma8(cl, l0, l1, acc);
       fma8(ch, u0, u1, acc);
     }
@@ -239,39 +241,52 @@ struct GreedyBook {
   int seq_ld, first;
 };
 
-__global__ void __launch_bounds__(256) k_row_argmax_lse(const float *__restrict__ logits, int R, int V,
+template <typename LT>
+__global__ void __launch_bounds__(256) k_row_argmax_lse(const LT *__restrict__ logits, int R, int V,
                                                         int64_t *__restrict__ idx, float *__restrict__ logp,
                                                         GreedyBook book) {
   __shared__ float s_m[4], s_s[4];
   __shared__ int s_i[4];
   const int row = blockIdx.x;
-  const float *x = logits + (int64_t)row * V;
+  const LT *x = logits + (int64_t)row * V;
   float m = -INFINITY, s = 0.f;
   int am = 0x7fffffff;
   auto take = [&](float v, int i) {
     if (v > m) { s = s * __expf(m - v) + 1.f; m = v; am = i; }
     else { s += __expf(v - m); }
   };
-  // 16-byte loads over the 16-byte aligned body of the row (rows of V floats start at 4-, 8- or 16-byte boundaries):
-  // a kernel whose only job is to stream 163 MB once wants few, wide loads in flight.  Thread 0 takes the <= 3 leading
+  // 16-byte loads over the 16-byte aligned body of the row (rows of V elements start at any element boundary): a
+  // kernel whose only job is to stream the logits once wants few, wide loads in flight.  Thread 0 takes the leading
   // and trailing elements, in index order (ties resolve to the first maximal index).
   {
-    const int head = min(V, (int)(((16 - (((uintptr_t)x) & 15)) & 15) >> 2));
-    const int nbody = (V - head) >> 2;
-    const int tail0 = head + 4 * nbody;
+    constexpr int kPer = 16 / (int)sizeof(LT);                        // elements per 16-byte load: 4 (fp32) / 8 (bf16)
+    const int head = min(V, (int)(((16 - (((uintptr_t)x) & 15)) & 15) / sizeof(LT)));
+    const int nbody = (V - head) / kPer;
+    const int tail0 = head + kPer * nbody;
     if (threadIdx.x == 0)
-      for (int i = 0; i < head; ++i) take(x[i], i);
-    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
+      for (int i = 0; i < head; ++i) take((float)x[i], i);
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(x + head);
     for (int i = threadIdx.x; i < nbody; i += blockDim.x) {
-      const float4 v = x4[i];
-      const int base = head + 4 * i;
-      take(v.x, base);
-      take(v.y, base + 1);
-      take(v.z, base + 2);
-      take(v.w, base + 3);
+      const uint4 v = x4[i];
+      const int base = head + kPer * i;
+      if constexpr (sizeof(LT) == 4) {
+        take(__builtin_bit_cast(float, v.x), base);
+        take(__builtin_bit_cast(float, v.y), base + 1);
+        take(__builtin_bit_cast(float, v.z), base + 2);
+        take(__builtin_bit_cast(float, v.w), base + 3);
+      } else {                                                        // bf16 -> fp32 is a 16-bit shift
+        take(__builtin_bit_cast(float, v.x << 16), base);
+        take(__builtin_bit_cast(float, v.x & 0xffff0000u), base + 1);
+        take(__builtin_bit_cast(float, v.y << 16), base + 2);
+        take(__builtin_bit_cast(float, v.y & 0xffff0000u), base + 3);
+        take(__builtin_bit_cast(float, v.z << 16), base + 4);
+        take(__builtin_bit_cast(float, v.z & 0xffff0000u), base + 5);
+        take(__builtin_bit_cast(float, v.w << 16), base + 6);
+        take(__builtin_bit_cast(float, v.w & 0xffff0000u), base + 7);
+      }
     }
     if (threadIdx.x == 0)
-      for (int i = tail0; i < V; ++i) take(x[i], i);
+      for (int i = tail0; i < V; ++i) take((float)x[i], i);
   }
   // wave reduction of (m, s, am)
 #pragma unroll
@@ -402,25 +417,25 @@ __global__ void __launch_bounds__(1024) k_sample_bwd(const T *__restrict__ value
 __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ inline float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
 
-__global__ void __launch_bounds__(256) k_lstm_cell(const float *__restrict__ ga, int lda, const float *__restrict__ gb,
-                                                   int ldb, const float *__restrict__ emb, const int64_t *__restrict__ it,
-                                                   const float *__restrict__ gc, int ldc, const float *__restrict__ c,
+// GT: storage type of the four gate operands (fp32 / bf16 GEMM outputs); state c, h fp32
+template <typename GT>
+__global__ void __launch_bounds__(256) k_lstm_cell(const GT *__restrict__ ga, int lda, const GT *__restrict__ gb,
+                                                   int ldb, const GT *__restrict__ emb, const int64_t *__restrict__ it,
+                                                   const GT *__restrict__ gc, int ldc, const float *__restrict__ c,
                                                    int n, int H, float *__restrict__ h_out, float *__restrict__ c_out) {
   const int H4 = H >> 2;
   const int64_t total = (int64_t)n * H4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(idx / H4), j = (int)(idx % H4);
-    const float4 *pa = reinterpret_cast<const float4 *>(ga + (int64_t)row * lda);
-    const float4 *pb = reinterpret_cast<const float4 *>(gb + (int64_t)row * ldb);
-    const float4 *pe = reinterpret_cast<const float4 *>(emb + it[row] * (int64_t)(4 * H));
-    const float4 *pc = gc ? reinterpret_cast<const float4 *>(gc + (int64_t)row * ldc) : nullptr;
+    const GT *pa = ga + (int64_t)row * lda, *pb = gb + (int64_t)row * ldb, *pe = emb + it[row] * (int64_t)(4 * H);
+    const GT *pc = gc ? gc + (int64_t)row * ldc : nullptr;
     float4 g4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float4 a = pa[k * H4 + j], b = pb[k * H4 + j], e = pe[k * H4 + j];
+      const float4 a = ld4(pa, k * H4 + j), b = ld4(pb, k * H4 + j), e = ld4(pe, k * H4 + j);
       // (hs part + attention part) first: the same association as the reference's single W_ih GEMM over [att | hs]
       float4 x = a;
-      if (pc) { const float4 cc = pc[k * H4 + j]; x = make_float4(cc.x + a.x, cc.y + a.y, cc.z + a.z, cc.w + a.w); }
+      if (pc) { const float4 cc = ld4(pc, k * H4 + j); x = make_float4(cc.x + a.x, cc.y + a.y, cc.z + a.z, cc.w + a.w); }
       g4[k] = make_float4(x.x + b.x + e.x, x.y + b.y + e.y, x.z + b.z + e.z, x.w + b.w + e.w);
     }
     const float4 cp = reinterpret_cast<const float4 *>(c)[idx];
@@ -457,6 +472,52 @@ int sample_bwd_impl(const T *value, const int64_t *shapes, const int64_t *lsi, c
                      dim3(waves * 64), 0, st, value, shapes, lsi, loc, gsamp, B, S, M, D, L, Q, P, pad, gvalue, gloc);
 }
 
+
+template <typename ST>
+int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                    const float *off_hs, const float *h, const float *w_off_h, const ST *att_h, const float *alpha_w,
+                    float alpha_b, int B, int S, int C, int L, int Q, int P, int RD, int att_h_ld, float *att_res,
+                    float *dbg_alpha, float *dbg_loc, void *stream) {
+  if (att_h_ld < C || (att_h_ld & 3)) return fail(GVL_EINVAL, "%s: att_h_ld must be >= C and a multiple of 4", what);
+  if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
+    return fail(GVL_EINVAL, "%s: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", what, C, L, P, RD);
+  if ((int64_t)B * Q == 0) return 0;
+  if (!slab || !shapes || !lsi || !ref || !off_hs || !h || !w_off_h || !att_h || !alpha_w || !att_res)
+    return fail(GVL_EINVAL, "%s: null pointer", what);
+  const int vids_per_group = (B + 7) / 8;
+  const int rows_per_group = vids_per_group * Q;
+  const int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
+  return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", k_cap_attend<ST>, dim3(8 * blocks_per_group),
+                     dim3(kWaves * 64), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
+                     alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_h_ld, att_res, dbg_alpha, dbg_loc);
+}
+
+template <typename GT>
+int lstm_cell_impl(const char *what, const GT *gates_a, int lda, const GT *gates_b, int ldb, const GT *emb_gates,
+                   const int64_t *it, const GT *gates_c, int ldc, const float *c, int n, int H, float *h_out,
+                   float *c_out, void *stream) {
+  if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3) ||
+      (gates_c && (ldc < 4 * H || (ldc & 3))))
+    return fail(GVL_EINVAL, "%s: bad sizes n=%d H=%d lda=%d ldb=%d", what, n, H, lda, ldb);
+  if (n == 0) return 0;
+  if (!gates_a || !gates_b || !emb_gates || !it || !c || !h_out || !c_out) return fail(GVL_EINVAL, "%s: null pointer", what);
+  int64_t blocks = ((int64_t)n * (H / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  return gvl::launch(GVL_PROF_LSTM_CELL, n, H, "k_lstm_cell", k_lstm_cell<GT>, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H, h_out, c_out);
+}
+
+template <typename LT>
+int greedy_impl(const char *what, const LT *logits, int R, int V, int64_t *token, float *logp, const GreedyBook &book,
+                void *stream) {
+  if (R < 0 || V <= 0 || (book.unfinished && book.seq_ld <= 0)) return fail(GVL_EINVAL, "%s: bad sizes", what);
+  if (R == 0) return 0;
+  if (!logits || !token || !logp || (book.unfinished && (!book.seq || !book.seq_lp)))
+    return fail(GVL_EINVAL, "%s: null pointer", what);
+  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_row_argmax_lse", k_row_argmax_lse<LT>, dim3(R), dim3(256), 0,
+                     (hipStream_t)stream, logits, R, V, token, logp, book);
+}
+
 }  // namespace
 
 extern "C" {
@@ -465,54 +526,52 @@ int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *
                        const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
                        const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
                        int att_h_ld, float *att_res, float *dbg_alpha, float *dbg_loc, void *stream) {
-  if (att_h_ld < C || (att_h_ld & 3)) return fail(GVL_EINVAL, "gvl_cap_attend_f32: att_h_ld must be >= C and a multiple of 4");
-  if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
-    return fail(GVL_EINVAL, "gvl_cap_attend_f32: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", C, L,
-                P, RD);
-  if ((int64_t)B * Q == 0) return 0;
-  if (!slab || !shapes || !lsi || !ref || !off_hs || !h || !w_off_h || !att_h || !alpha_w || !att_res)
-    return fail(GVL_EINVAL, "gvl_cap_attend_f32: null pointer");
-  const int vids_per_group = (B + 7) / 8;
-  const int rows_per_group = vids_per_group * Q;
-  const int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
-  return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", k_cap_attend, dim3(8 * blocks_per_group),
-                     dim3(kWaves * 64), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
-                     alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_h_ld, att_res, dbg_alpha, dbg_loc);
+  return cap_attend_impl<float>("gvl_cap_attend_f32", slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h, alpha_w,
+                                alpha_b, B, S, C, L, Q, P, RD, att_h_ld, att_res, dbg_alpha, dbg_loc, stream);
+}
+int gvl_cap_attend_bf16(const uint16_t *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                        const float *off_hs, const float *h, const float *w_off_h, const uint16_t *att_h,
+                        const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
+                        int att_h_ld, float *att_res, float *dbg_alpha, float *dbg_loc, void *stream) {
+  return cap_attend_impl<bf16_t>("gvl_cap_attend_bf16", (const bf16_t *)slab, shapes, lsi, ref, off_hs, h, w_off_h,
+                                 (const bf16_t *)att_h, alpha_w, alpha_b, B, S, C, L, Q, P, RD, att_h_ld, att_res,
+                                 dbg_alpha, dbg_loc, stream);
 }
 
 int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
                       const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
                       float *c_out, void *stream) {
-  if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3) ||
-      (gates_c && (ldc < 4 * H || (ldc & 3))))
-    return fail(GVL_EINVAL, "gvl_lstm_cell_f32: bad sizes n=%d H=%d lda=%d ldb=%d", n, H, lda, ldb);
-  if (n == 0) return 0;
-  if (!gates_a || !gates_b || !emb_gates || !it || !c || !h_out || !c_out)
-    return fail(GVL_EINVAL, "gvl_lstm_cell_f32: null pointer");
-  int64_t blocks = ((int64_t)n * (H / 4) + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  return gvl::launch(GVL_PROF_LSTM_CELL, n, H, "k_lstm_cell", k_lstm_cell, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H, h_out, c_out);
+  return lstm_cell_impl<float>("gvl_lstm_cell_f32", gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H,
+                               h_out, c_out, stream);
+}
+int gvl_lstm_cell_bf16(const uint16_t *gates_a, int lda, const uint16_t *gates_b, int ldb, const uint16_t *emb_gates,
+                       const int64_t *it, const uint16_t *gates_c, int ldc, const float *c, int n, int H, float *h_out,
+                       float *c_out, void *stream) {
+  return lstm_cell_impl<bf16_t>("gvl_lstm_cell_bf16", (const bf16_t *)gates_a, lda, (const bf16_t *)gates_b, ldb,
+                                (const bf16_t *)emb_gates, it, (const bf16_t *)gates_c, ldc, c, n, H, h_out, c_out,
+                                stream);
 }
 
 int gvl_row_argmax_lse_f32(const float *logits, int R, int V, int64_t *idx, float *logp, void *stream) {
-  if (R < 0 || V <= 0) return fail(GVL_EINVAL, "gvl_row_argmax_lse_f32: bad sizes");
-  if (R == 0) return 0;
-  if (!logits || !idx || !logp) return fail(GVL_EINVAL, "gvl_row_argmax_lse_f32: null pointer");
   const GreedyBook none = {nullptr, nullptr, nullptr, 0, 0};
-  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_row_argmax_lse", k_row_argmax_lse, dim3(R), dim3(256), 0,
-                     (hipStream_t)stream, logits, R, V, idx, logp, none);
+  return greedy_impl<float>("gvl_row_argmax_lse_f32", logits, R, V, idx, logp, none, stream);
+}
+int gvl_row_argmax_lse_bf16(const uint16_t *logits, int R, int V, int64_t *idx, float *logp, void *stream) {
+  const GreedyBook none = {nullptr, nullptr, nullptr, 0, 0};
+  return greedy_impl<bf16_t>("gvl_row_argmax_lse_bf16", (const bf16_t *)logits, R, V, idx, logp, none, stream);
 }
 
 int gvl_greedy_step_f32(const float *logits, int R, int V, int first_step, int64_t *token, float *logp,
                         unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld, void *stream) {
-  if (R < 0 || V <= 0 || seq_ld <= 0) return fail(GVL_EINVAL, "gvl_greedy_step_f32: bad sizes");
-  if (R == 0) return 0;
-  if (!logits || !token || !logp || !unfinished || !seq_col || !seq_lp_col)
-    return fail(GVL_EINVAL, "gvl_greedy_step_f32: null pointer");
+  if (!unfinished) return fail(GVL_EINVAL, "gvl_greedy_step_f32: null pointer");
   const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0};
-  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_row_argmax_lse<greedy>", k_row_argmax_lse, dim3(R), dim3(256), 0,
-                     (hipStream_t)stream, logits, R, V, token, logp, book);
+  return greedy_impl<float>("gvl_greedy_step_f32", logits, R, V, token, logp, book, stream);
+}
+int gvl_greedy_step_bf16(const uint16_t *logits, int R, int V, int first_step, int64_t *token, float *logp,
+                         unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld, void *stream) {
+  if (!unfinished) return fail(GVL_EINVAL, "gvl_greedy_step_bf16: null pointer");
+  const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0};
+  return greedy_impl<bf16_t>("gvl_greedy_step_bf16", (const bf16_t *)logits, R, V, token, logp, book, stream);
 }
 
 int gvl_msda_sample_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,

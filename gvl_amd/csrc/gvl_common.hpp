@@ -110,3 +110,19 @@ inline int ensure_lds(K kernel, size_t bytes) {
 }
 
 }  // namespace gvl
+
+// ---- storage types: fp32 or bf16 in HBM, fp32 in registers / LDS.  `i4` indexes groups of 4 consecutive elements.
+using bf16_t = __bf16;
+struct alignas(8) bf16x4 { bf16_t a, b, c, d; };
+
+__device__ inline float4 ld4(const float *base, int64_t i4) { return reinterpret_cast<const float4 *>(base)[i4]; }
+__device__ inline float4 ld4(const bf16_t *base, int64_t i4) {
+  const bf16x4 v = reinterpret_cast<const bf16x4 *>(base)[i4];
+  return make_float4((float)v.a, (float)v.b, (float)v.c, (float)v.d);
+}
+__device__ inline void st4(float *base, int64_t i4, float4 v) { reinterpret_cast<float4 *>(base)[i4] = v; }
+__device__ inline void st4(bf16_t *base, int64_t i4, float4 v) {            // v_cvt_pk_bf16_f32: round-to-nearest-even
+  bf16x4 o;
+  o.a = (bf16_t)v.x; o.b = (bf16_t)v.y; o.c = (bf16_t)v.z; o.d = (bf16_t)v.w;
+  reinterpret_cast<bf16x4 *>(base)[i4] = o;
+}

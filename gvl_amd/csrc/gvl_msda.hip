@@ -344,22 +344,6 @@ __device__ inline float dot4(float4 a, float4 b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
-// ---- storage types: fp32 or bf16 in HBM, fp32 in registers / LDS.  `i4` indexes groups of 4 consecutive channels.
-using bf16_t = __bf16;
-struct alignas(8) bf16x4 { bf16_t a, b, c, d; };
-
-__device__ inline float4 ld4(const float *base, int64_t i4) { return reinterpret_cast<const float4 *>(base)[i4]; }
-__device__ inline float4 ld4(const bf16_t *base, int64_t i4) {
-  const bf16x4 v = reinterpret_cast<const bf16x4 *>(base)[i4];
-  return make_float4((float)v.a, (float)v.b, (float)v.c, (float)v.d);
-}
-__device__ inline void st4(float *base, int64_t i4, float4 v) { reinterpret_cast<float4 *>(base)[i4] = v; }
-__device__ inline void st4(bf16_t *base, int64_t i4, float4 v) {            // v_cvt_pk_bf16_f32: round-to-nearest-even
-  bf16x4 o;
-  o.a = (bf16_t)v.x; o.b = (bf16_t)v.y; o.c = (bf16_t)v.z; o.d = (bf16_t)v.w;
-  reinterpret_cast<bf16x4 *>(base)[i4] = o;
-}
-
 // stage rows [row0, S) of the (b,m) value slab [S][64] into LDS as float4[(S-row0)*16]; one zero row follows.
 // row0 > 0 ("L0G"): level 0 does not fit beside the other levels in the 160 KB LDS (long videos: T = 512 gives
 // S*256 B = 240 KB); its rows are then read straight from global memory / L2 by the sample steps of level 0.

@@ -175,3 +175,54 @@ def test_module_under_bf16_autocast(ref_dim, fused, dev):
             assert r <= 5e-2, (k, r)
         else:
             assert r <= 0.25 and c >= 0.98, (k, r, c)
+
+
+# ---- bf16-input twins of the inference token-step kernels ------------------------------------------------------------
+
+def test_bf16_captioner_kernels_equal_fp32_kernels_on_the_widened_inputs(dev, MSDA):
+    """gvl_cap_attend_bf16 / gvl_lstm_cell_bf16 / gvl_row_argmax_lse_bf16 / gvl_greedy_step_bf16 read bf16 operands and
+    compute in fp32: on the same (bf16-representable) values they must reproduce the _f32 kernels."""
+    from helpers import level_lengths
+    g = torch.Generator().manual_seed(11)
+    B, Q, C, L, P = 3, 37, 512, 4, 4
+    lens = level_lengths(64)
+    S = sum(lens)
+    from gvl_amd.deformable_transformer import make_level_tensors
+    from gvl_amd.ops.modules.ms_deform_attn import temporal_shapes_2d
+    tsh, lsi = make_level_tensors(lens, dev)
+    sh2 = temporal_shapes_2d(tsh, lsi)
+    slab = torch.randn(B, S, 2 * C, generator=g).to(dev).to(BF)
+    ref = torch.rand(B, Q, L, 2, generator=g).to(dev) * 0.5 + 0.1
+    off_hs = torch.randn(B, Q, L * P, generator=g).to(dev)
+    h = torch.randn(B * Q, C, generator=g).to(dev) * 0.3
+    w_off = torch.randn(L * P, C, generator=g).to(dev) * 0.05
+    g_h = torch.randn(B * Q, C + 4 * C, generator=g).to(dev).to(BF)          # [h2att(h) | gates]
+    alpha_w = torch.randn(C, generator=g).to(dev) * 0.1
+    a16 = MSDA.cap_attend(slab, sh2, lsi, ref, off_hs, h, w_off, g_h[:, :C], alpha_w, 0.25, L, P)
+    a32 = MSDA.cap_attend(slab.float(), sh2, lsi, ref, off_hs, h, w_off, g_h.float()[:, :C], alpha_w, 0.25, L, P)
+    assert a16.dtype == torch.float32 and maxerr(a16, a32) <= 1e-6 * scale(a32.cpu().numpy())
+    # LSTM cell
+    n, H, V = B * Q, 512, 97
+    g_x = torch.randn(n, 4 * H, generator=g).to(dev).to(BF)
+    g_c = torch.randn(n, 4 * H, generator=g).to(dev).to(BF)
+    emb = torch.randn(V, 4 * H, generator=g).to(dev).to(BF)
+    it = torch.randint(0, V, (n,), generator=g).to(dev)
+    c = torch.randn(n, H, generator=g).to(dev)
+    h16, c16 = MSDA.lstm_cell(g_x, g_h[:, C:], emb, it, c, gates_c=g_c)
+    h32, c32 = MSDA.lstm_cell(g_x.float(), g_h.float()[:, C:], emb.float(), it, c, gates_c=g_c.float())
+    assert maxerr(h16, h32) <= 1e-6 and maxerr(c16, c32) <= 1e-6 * scale(c32.cpu().numpy())
+    # argmax / greedy step, odd and even vocabulary sizes (row alignment 2 / 4 / ... bytes), ties
+    for Vv in (1607, 8518, 33):
+        lg = torch.randn(n, Vv, generator=g).to(dev).to(BF)
+        lg[0, 5] = lg[0].max() + 1
+        lg[0, 9] = lg[0, 5]                                              # tie -> first index
+        i16, l16 = MSDA.row_argmax_lse(lg)
+        i32, l32 = MSDA.row_argmax_lse(lg.float())
+        assert torch.equal(i16, i32) and int(i16[0]) == 5 and maxerr(l16, l32) <= 2e-6
+        unf = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
+        seq = [torch.zeros(n, 3, dtype=torch.long, device=dev) for _ in range(2)]
+        slp = [torch.zeros(n, 3, device=dev) for _ in range(2)]
+        t16 = MSDA.greedy_step(lg, 0, unf[0], seq[0], slp[0])
+        t32 = MSDA.greedy_step(lg.float(), 0, unf[1], seq[1], slp[1])
+        assert torch.equal(t16, t32) and torch.equal(seq[0], seq[1]) and torch.equal(unf[0], unf[1])
+        assert maxerr(slp[0], slp[1]) <= 2e-6
