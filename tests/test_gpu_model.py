@@ -416,7 +416,7 @@ def test_yc2_long_video_eval_matches_reference(built_yc2):
 
 def test_yc2_long_video_eval_under_bf16_autocast(built_yc2):
     """The same forward under torch.autocast(bfloat16) (BASELINE config 4 names bf16): GEMMs on bf16 MFMA, the
-    deformable attention on bf16 storage with fp32 locations, the captioner an fp32 island.
+    deformable attention on bf16 storage with fp32 locations, the decoding loop on the bf16-input token-step kernels.
     What can be pinned at model level: the encoder memory (two layers of rounded GEMMs: mean error < 0.5 % of its
     scale, max < 2 %).  Behind the decoder nothing tighter than statistics is meaningful with RANDOM weights: the
     sampling offsets come out of a bf16 GEMM (|off| of several frames -> ~0.1 frame of rounding at T = 512) and
