@@ -138,7 +138,8 @@ class ShowAttendTellCore(nn.Module):
             shapes2d = const["shapes2d"] = temporal_shapes_2d(temporal_shapes, level_start_index)
             const["ref_in"] = reference_points.contiguous()
         A = self.att_hid_size
-        g_h = F.linear(h, const["w_h_cat"], const["b_h_cat"])           # (n, A + 4H): [h2att(h) | h W_hh^T]
+        h_gemm = getattr(h, "_gvl_lowp", h)                              # bf16 copy left by the cell kernel (autocast)
+        g_h = F.linear(h_gemm, const["w_h_cat"], const["b_h_cat"])      # (n, A + 4H): [h2att(h) | h W_hh^T]
         att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
                                   h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
                                   self.n_levels, self.n_points)
@@ -456,7 +457,7 @@ class Captioner(nn.Module):
                     # (the reference also evaluates the LSTM step + vocabulary logits of the LAST token,
                     #  LSTM_DSA.py:189-190, and then leaves the loop without reading them)
                     out, (h, c) = self.core.step((emb_gates, it), (h, c), hs, ref_in, tshapes, lsi, const)
-                    logits = self.logit(self.dropout(out))
+                    logits = self.logit(self.dropout(getattr(out, "_gvl_lowp", out)))
             # a row is unfinished at step t exactly while its tokens are non-zero (seq = token * unfinished, :183-188)
             return seq, seq_lp, (seq != 0).any(0)
         unfinished = torch.ones(n, dtype=torch.bool, device=hs.device)

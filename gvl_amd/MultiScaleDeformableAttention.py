@@ -229,7 +229,7 @@ def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off
     C = C2 // 2
     Q = ref_in.shape[1]
     RD = ref_in.shape[-1]
-    att_res = torch.empty((B * Q, C), device=slab.device, dtype=torch.float32)
+    att_res = torch.empty((B * Q, C), device=slab.device, dtype=st)      # bf16 kernel: bf16 (A operand of a bf16 GEMM)
     dbg_a = torch.empty((B * Q, n_levels * n_points), device=slab.device) if debug else None
     dbg_l = torch.empty((B * Q, n_levels * n_points), device=slab.device) if debug else None
     with torch.cuda.device(slab.device):
@@ -341,13 +341,19 @@ def lstm_cell(gates_a, gates_b, emb_gates, it, c, gates_c=None):
     _require(emb_gates.is_contiguous() and emb_gates.dtype == gt and c.is_contiguous() and it.is_contiguous()
              and it.dtype == torch.int64, "lstm_cell: emb_gates / c / it must be contiguous (it int64)")
     h_out, c_out = torch.empty_like(c), torch.empty_like(c)
+    extra = ()
+    if gt == torch.bfloat16:                      # a bf16 copy of h' for the next GEMMs (returned as h_out._gvl_lowp)
+        h_lp = torch.empty((n, H), dtype=gt, device=c.device)
+        extra = (h_lp.data_ptr(),)
     with torch.cuda.device(c.device):
         rc = getattr(_lib.lib(), "gvl_lstm_cell_" + _SUFFIX[gt])(
             gates_a.data_ptr(), gates_a.stride(0), gates_b.data_ptr(), gates_b.stride(0), emb_gates.data_ptr(),
             it.data_ptr(), gates_c.data_ptr() if gates_c is not None else None,
             gates_c.stride(0) if gates_c is not None else 0, c.data_ptr(), n, H, h_out.data_ptr(), c_out.data_ptr(),
-            torch.cuda.current_stream().cuda_stream)
+            *extra, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "lstm_cell")
+    if extra:
+        h_out._gvl_lowp = h_lp
     return h_out, c_out
 
 

@@ -47,7 +47,7 @@ SIGNATURES = {
     "gvl_set_criterion_backward_f32": (_I, [_P] * 12 + [_I] * 7 + [ctypes.c_float] * 4 + [_I, _P, _P, _P, _P, _P]),
     "gvl_row_argmax_lse_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "gvl_cap_attend_bf16": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P]),
-    "gvl_lstm_cell_bf16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "gvl_lstm_cell_bf16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
     "gvl_row_argmax_lse_bf16": (_I, [_P, _I, _I, _P, _P, _P]),
     "gvl_greedy_step_bf16": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gvl_greedy_step_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     const ST *__restrict__ att_h,        // (B*Q, C)    h2att(h), row stride att_h_ld elements
     const float *__restrict__ alpha_w,   // (C)
     float alpha_b, int B, int S, int L, int Q, int P, int RD, int rows_per_xcd_group, int att_h_ld,
-    float *__restrict__ att_res,         // (B*Q, C)
+    ST *__restrict__ att_res,            // (B*Q, C), in the storage type: it is the A operand of the next GEMM
     float *__restrict__ dbg_alpha,       // optional (B*Q, 16)
     float *__restrict__ dbg_loc) {       // optional (B*Q, 16)
   __shared__ float4 wo4[kLP * kC / 4];   // 32 KiB: the h part of the offsets projection
@@ -217,9 +217,9 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
       fma8(ch, u0, u1, acc);
     }
   }
-  float4 *o4 = reinterpret_cast<float4 *>(att_res + row * kC);
-  o4[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  o4[64 + lane] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  ST *o = att_res + row * kC;
+  st4(o, lane, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  st4(o, 64 + lane, make_float4(acc[4], acc[5], acc[6], acc[7]));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -422,7 +422,8 @@ template <typename GT>
 __global__ void __launch_bounds__(256) k_lstm_cell(const GT *__restrict__ ga, int lda, const GT *__restrict__ gb,
                                                    int ldb, const GT *__restrict__ emb, const int64_t *__restrict__ it,
                                                    const GT *__restrict__ gc, int ldc, const float *__restrict__ c,
-                                                   int n, int H, float *__restrict__ h_out, float *__restrict__ c_out) {
+                                                   int n, int H, float *__restrict__ h_out, float *__restrict__ c_out,
+                                                   GT *__restrict__ h_gemm) {
   const int H4 = H >> 2;
   const int64_t total = (int64_t)n * H4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -447,6 +448,7 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const GT *__restrict__ ga, in
 #undef GVL_CELL
     reinterpret_cast<float4 *>(c_out)[idx] = cn;
     reinterpret_cast<float4 *>(h_out)[idx] = hn;
+    if (h_gemm) st4(h_gemm, idx, hn);        // h' once more in the gates' storage type: the A operand of the next GEMMs
   }
 }
 
@@ -476,7 +478,7 @@ int sample_bwd_impl(const T *value, const int64_t *shapes, const int64_t *lsi, c
 template <typename ST>
 int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                     const float *off_hs, const float *h, const float *w_off_h, const ST *att_h, const float *alpha_w,
-                    float alpha_b, int B, int S, int C, int L, int Q, int P, int RD, int att_h_ld, float *att_res,
+                    float alpha_b, int B, int S, int C, int L, int Q, int P, int RD, int att_h_ld, ST *att_res,
                     float *dbg_alpha, float *dbg_loc, void *stream) {
   if (att_h_ld < C || (att_h_ld & 3)) return fail(GVL_EINVAL, "%s: att_h_ld must be >= C and a multiple of 4", what);
   if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
@@ -495,7 +497,7 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
 template <typename GT>
 int lstm_cell_impl(const char *what, const GT *gates_a, int lda, const GT *gates_b, int ldb, const GT *emb_gates,
                    const int64_t *it, const GT *gates_c, int ldc, const float *c, int n, int H, float *h_out,
-                   float *c_out, void *stream) {
+                   float *c_out, GT *h_gemm, void *stream) {
   if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3) ||
       (gates_c && (ldc < 4 * H || (ldc & 3))))
     return fail(GVL_EINVAL, "%s: bad sizes n=%d H=%d lda=%d ldb=%d", what, n, H, lda, ldb);
@@ -504,7 +506,8 @@ int lstm_cell_impl(const char *what, const GT *gates_a, int lda, const GT *gates
   int64_t blocks = ((int64_t)n * (H / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   return gvl::launch(GVL_PROF_LSTM_CELL, n, H, "k_lstm_cell", k_lstm_cell<GT>, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H, h_out, c_out);
+                     (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H, h_out, c_out,
+                     h_gemm);
 }
 
 template <typename LT>
@@ -532,24 +535,24 @@ int gvl_cap_attend_f32(const float *slab, const int64_t *shapes, const int64_t *
 int gvl_cap_attend_bf16(const uint16_t *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                         const float *off_hs, const float *h, const float *w_off_h, const uint16_t *att_h,
                         const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
-                        int att_h_ld, float *att_res, float *dbg_alpha, float *dbg_loc, void *stream) {
+                        int att_h_ld, uint16_t *att_res, float *dbg_alpha, float *dbg_loc, void *stream) {
   return cap_attend_impl<bf16_t>("gvl_cap_attend_bf16", (const bf16_t *)slab, shapes, lsi, ref, off_hs, h, w_off_h,
-                                 (const bf16_t *)att_h, alpha_w, alpha_b, B, S, C, L, Q, P, RD, att_h_ld, att_res,
-                                 dbg_alpha, dbg_loc, stream);
+                                 (const bf16_t *)att_h, alpha_w, alpha_b, B, S, C, L, Q, P, RD, att_h_ld,
+                                 (bf16_t *)att_res, dbg_alpha, dbg_loc, stream);
 }
 
 int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
                       const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
                       float *c_out, void *stream) {
   return lstm_cell_impl<float>("gvl_lstm_cell_f32", gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H,
-                               h_out, c_out, stream);
+                               h_out, c_out, (float *)nullptr, stream);
 }
 int gvl_lstm_cell_bf16(const uint16_t *gates_a, int lda, const uint16_t *gates_b, int ldb, const uint16_t *emb_gates,
                        const int64_t *it, const uint16_t *gates_c, int ldc, const float *c, int n, int H, float *h_out,
-                       float *c_out, void *stream) {
+                       float *c_out, uint16_t *h_bf16, void *stream) {
   return lstm_cell_impl<bf16_t>("gvl_lstm_cell_bf16", (const bf16_t *)gates_a, lda, (const bf16_t *)gates_b, ldb,
                                 (const bf16_t *)emb_gates, it, (const bf16_t *)gates_c, ldc, c, n, H, h_out, c_out,
-                                stream);
+                                (bf16_t *)h_bf16, stream);
 }
 
 int gvl_row_argmax_lse_f32(const float *logits, int R, int V, int64_t *idx, float *logp, void *stream) {

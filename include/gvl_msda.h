@@ -313,14 +313,16 @@ int gvl_greedy_step_f32(const float *logits, int R, int V, int first_step, int64
  *    under torch.autocast the GEMMs of the token loop leave the slab, h2att(h), the gate pre-activations, the
  *    pre-multiplied embedding table and the logits in bfloat16; these entry points read them as they are (uint16_t bit
  *    patterns), compute in fp32 exactly as the _f32 kernels do on the widened values, and keep the recurrent state
- *    (h, c), offsets, reference points and outputs in fp32. */
+ *    (h, c), offsets and reference points in fp32.  att_res is written in bf16 (it is the A operand of the next bf16
+ *    GEMM) and gvl_lstm_cell_bf16 can leave a bf16 copy of h' (h_bf16, may be NULL) next to the fp32 state for the same
+ *    reason: one rounding either way, no separate cast kernels. */
 int gvl_cap_attend_bf16(const uint16_t *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                         const float *off_hs, const float *h, const float *w_off_h, const uint16_t *att_h,
                         const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
-                        int att_h_ld, float *att_res, float *dbg_alpha, float *dbg_loc, void *stream);
+                        int att_h_ld, uint16_t *att_res, float *dbg_alpha, float *dbg_loc, void *stream);
 int gvl_lstm_cell_bf16(const uint16_t *gates_a, int lda, const uint16_t *gates_b, int ldb, const uint16_t *emb_gates,
                        const int64_t *it, const uint16_t *gates_c, int ldc, const float *c, int n, int H, float *h_out,
-                       float *c_out, void *stream);
+                       float *c_out, uint16_t *h_bf16, void *stream);
 int gvl_row_argmax_lse_bf16(const uint16_t *logits, int R, int V, int64_t *idx, float *logp, void *stream);
 int gvl_greedy_step_bf16(const uint16_t *logits, int R, int V, int first_step, int64_t *token, float *logp,
                          unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld, void *stream);
