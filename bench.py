@@ -234,13 +234,12 @@ def main():
         # one process: the whole step is ONE hipGraph; several processes: forward/backward graph, eager bucketed RCCL
         # all-reduce of the flat gradient buffer, clip/Adam graph (no collective inside a graph) -- GraphedTrainStep
         use_graph = not a.no_graph
+        ac = torch.bfloat16 if a.dtype == "bf16" else None
         if use_graph:
             trainer = GraphedTrainStep(model, criterion, opt, world_size=world,
-                                       split_exchange=True if a.split_exchange else None)
+                                       split_exchange=True if a.split_exchange else None, autocast_dtype=ac)
         else:
-            trainer = TrainStep(model, criterion, opt, world_size=world)
-        if a.dtype == "bf16":
-            raise SystemExit("--dtype bf16 is wired for the eval forward; the train step is measured in fp32")
+            trainer = TrainStep(model, criterion, opt, world_size=world, autocast_dtype=ac)
 
         def step():
             return trainer(dt)

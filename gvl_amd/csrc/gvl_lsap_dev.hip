@@ -74,8 +74,16 @@ __global__ void __launch_bounds__(64) k_lsap(const float *__restrict__ C, const 
     const double c = cost(e / nc, e % nc);
     if (c != c || c == -INFINITY) bad = 1;
   }
-  if (wave_max_i(bad)) {
+  // On invalid / infeasible input scipy raises; here the status flag carries that to the host (LayerMatch.check) and
+  // the outputs get a harmless in-range assignment (query i <-> target i mod n), because consumers on the device
+  // (criterion, caption gather) index with them before anyone can look at the flag.
+  auto fail_safe = [&]() {
     if (lane == 0) atomicExch(status, 1);
+    int64_t *ro_ = rows_out + pr.out_off, *co_ = cols_out + pr.out_off;
+    for (int r = lane; r < nr; r += 64) { ro_[r] = r; co_[r] = r % n_; }
+  };
+  if (wave_max_i(bad)) {
+    fail_safe();
     return;
   }
   for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(64) k_lsap(const float *__restrict__ C, const 
       }
       const double lowest = wave_min(local_min);
       if (lowest == INFINITY) {                          // infeasible
-        if (lane == 0) atomicExch(status, 1);
+        fail_safe();
         return;
       }
       int last_unassigned = -1, first_any = 0x7fffffff;

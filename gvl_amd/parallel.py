@@ -120,8 +120,12 @@ class TrainStep:
     """zero_grad -> forward -> weighted loss -> backward (+ overlapped all-reduce) -> clip -> Adam (train.py:385-409)"""
 
     def __init__(self, model, criterion, opt, world_size=1, process_group=None, capturable=False, flat=None,
-                 overlap=True):
+                 overlap=True, autocast_dtype=None):
+        """autocast_dtype (e.g. torch.bfloat16): forward + losses under torch.autocast -- bf16 GEMMs and bf16-storage
+        deformable attention, fp32 master weights / Adam, fp32 islands for the teacher-forced captioner loop and the
+        criterion kernels."""
         self.model, self.criterion, self.opt = model, criterion, opt
+        self.autocast_dtype = autocast_dtype
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = GradBuckets(self.params, process_group=process_group, flat=flat, overlap=overlap)
         # fused=True: one multi-tensor kernel per ~100 parameters instead of ~15 foreach kernels each (321 -> ~10
@@ -131,11 +135,19 @@ class TrainStep:
                                           capturable=capturable, fused=fused)
         self.world = world_size
 
+    def _forward_loss(self, dt):
+        # cache_enabled=False: autocast's weight-cast cache must not live across a hipGraph capture (the cached bf16
+        # copies would be graph-pool tensors that the next replay overwrites while autograd still holds them) -- the
+        # same precaution torch.cuda.make_graphed_callables takes
+        with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None,
+                            cache_enabled=False):
+            out, loss = self.model(dt, self.criterion, None, self.opt.transformer_input_type)
+        wd = self.criterion.weight_dict
+        return sum(loss[k].float() * wd[k] for k in loss.keys() if k in wd), loss
+
     def __call__(self, dt):
         self.buckets.zero()                                                    # optimizer.zero_grad(), flat
-        out, loss = self.model(dt, self.criterion, None, self.opt.transformer_input_type)
-        wd = self.criterion.weight_dict
-        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        final, loss = self._forward_loss(dt)
         final.backward()
         self.buckets.finish()
         torch.nn.utils.clip_grad_norm_(self.params, self.opt.grad_clip)
@@ -152,7 +164,8 @@ class GraphedTrainStep(TrainStep):
     Inputs are copied into static buffers before every replay; the batch layout (tensor shapes, number of events per
     video, teacher-forcing length) is the cache key."""
 
-    def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=3, split_exchange=None):
+    def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=3, split_exchange=None,
+                 autocast_dtype=None):
         """split_exchange (default: exactly when there is more than one process): the step is captured as TWO graphs --
         zero_grad + forward + backward into the flat gradient buffer, then clip + Adam -- with the bucketed RCCL
         all-reduce issued eagerly between the two replays, so no collective is ever inside a hipGraph.  The criterion's
@@ -160,7 +173,7 @@ class GraphedTrainStep(TrainStep):
         target counts."""
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
         super().__init__(model, criterion, opt, world_size, process_group, capturable=True,
-                         flat=True if self.split else None, overlap=not self.split)
+                         flat=True if self.split else None, overlap=not self.split, autocast_dtype=autocast_dtype)
         self.graphs = {}
         # >= 1 real step must run before the capture (on a side stream): autograd's gradient accumulators, hipBLASLt
         # workspaces and the library's lazily built constants have to exist before a stream is capturing
@@ -221,9 +234,7 @@ class GraphedTrainStep(TrainStep):
 
     def _forward_backward(self, dt):
         self.buckets.zero()
-        out, loss = self.model(dt, self.criterion, None, self.opt.transformer_input_type)
-        wd = self.criterion.weight_dict
-        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        final, loss = self._forward_loss(dt)
         final.backward()
         return final.detach(), loss
 
@@ -248,9 +259,9 @@ class GraphedTrainStep(TrainStep):
                         self._update()
                 torch.cuda.current_stream().wait_stream(side)
                 g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb):
+                with torch.cuda.graph(g_fb, stream=side):
                     outs = self._forward_backward(st)
-                with torch.cuda.graph(g_up, pool=g_fb.pool()):
+                with torch.cuda.graph(g_up, pool=g_fb.pool(), stream=side):
                     self._update()
                 entry = self.graphs[key] = (g_fb, g_up, st, outs)
             g_fb, g_up, st, outs = entry
@@ -276,7 +287,10 @@ class GraphedTrainStep(TrainStep):
                     self._eager(st)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # capture ON the warm-up stream: autograd's AccumulateGrad nodes were created there and keep running there;
+            # captured from another stream they become a parallel branch of the graph that the optimizer kernels do not
+            # wait for (seen as NaN parameters after a few replays of the bf16 step)
+            with torch.cuda.graph(graph, stream=side):
                 outs = self._eager(st)
             entry = self.graphs[key] = (graph, st, outs)        # capture records, it does not execute: replay below
         graph, st, outs = entry
@@ -340,7 +354,7 @@ class GraphedEvalForward:
                         self._forward(st)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, stream=side):
                     out, loss = self._forward(st)
                 alive = getattr(heads[-1], "last_alive", None)
             finally:

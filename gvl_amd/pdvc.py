@@ -328,7 +328,7 @@ class PDVC(nn.Module):
         ref_stack = torch.stack([r if r.shape[-1] == 2 else torch.cat([r, torch.full_like(r, -1.0)], -1)
                                  for r in ref_layers])
         hs_m = hs_stack.new_zeros(N_, nl * mp, C)
-        ref_m = hs_stack.new_zeros(N_, nl * mp, 2)
+        ref_m = ref_stack.new_zeros(N_, nl * mp, 2)
         seq_m = torch.zeros(N_, nl * mp, cap_len, dtype=torch.long, device=dev)
         mask_m = torch.zeros(N_, nl * mp, cap_len, dtype=torch.bool, device=dev)
         hs_m[vid_all, slot_all] = hs_stack[lay_all, vid_all, q_all]
@@ -361,7 +361,7 @@ class PDVC(nn.Module):
             max_pairs = max(plan.n1)
             vid, slot, caps = plan.vid_of_entry, plan.slot_of_entry, indices.t_global
             hs_m = hs.new_zeros(N_, max_pairs, C)
-            ref_m = hs.new_zeros(N_, max_pairs, reference.shape[-1])
+            ref_m = reference.new_zeros(N_, max_pairs, reference.shape[-1])
             seq_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.long, device=dev)
             mask_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.bool, device=dev)
             hs_m[vid, slot] = hs[vid, indices.q]
@@ -377,7 +377,7 @@ class PDVC(nn.Module):
                 cap_base.append(cap_base[-1] + int(n))
             max_pairs = max(len(f_) for f_, _ in indices)
             hs_m = hs.new_zeros(N_, max_pairs, C)
-            ref_m = hs.new_zeros(N_, max_pairs, reference.shape[-1])
+            ref_m = reference.new_zeros(N_, max_pairs, reference.shape[-1])
             seq_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.long, device=dev)
             mask_m = torch.zeros(N_, max_pairs, cap_len, dtype=torch.bool, device=dev)
             all_caps = []
