@@ -500,7 +500,7 @@ class Captioner(nn.Module):
                 self._decode_device(*static, tshapes, lsi, 1, 1.0)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):           # capture on the warm-up stream (see gvl_amd.parallel)
                 outs = self._decode_device(*static, tshapes, lsi, 1, 1.0)
             entry = cache[key] = (graph, static, outs)
         graph, static, outs = entry
