@@ -31,7 +31,7 @@ using gvl::fail;
 __device__ inline float fast_tanh(float x) {
   // 1 - 2/(1+e^{2x}); saturates correctly for |x| large, abs error ~1e-7
   const float e = __expf(2.f * x);
-  return 1.f - 2.f / (1.f + e);
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);      // v_rcp_f32 (1 ulp), not a ~10-instruction IEEE division
 }
 
 // reduce-scatter of v[16] over the 64 lanes: afterwards every lane holds the full sum of v[k], k = lane >> 2.
@@ -107,7 +107,9 @@ __device__ inline void border_coef(float loc, int T, int &r, float &c_lo, float 
 }
 
 // ST: storage type of the slab and of att_h (fp32, or bf16 as a GEMM under autocast leaves them); arithmetic fp32
-template <typename ST>
+// FULL: L*P == 16 known at compile time -- the sample loops lose their guards and become straight-line code, so the
+// eight loads of a sample pair really are in flight together
+template <typename ST, bool FULL>
 __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     const ST *__restrict__ slab,         // (B, S, 2C)  [value_proj(memory) | ctx2att(value_proj(memory))]
     const int64_t *__restrict__ shapes,  // (L, 2)
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
   float off = butterfly16(part, lane);
   int roff = 0;
   float c_lo = 0.f, c_hi = 0.f, locx = 0.f;
-  const int LP = L * P;
+  const int LP = FULL ? kLP : L * P;
   if (k_own < LP) {
     off += off_hs[row * LP + k_own];
     const int l = k_own / P;
@@ -169,29 +171,43 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
   const float4 ta = ld4(ah, lane), tb = ld4(ah, 64 + lane);
   const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
   const ST *slab_b = slab + (int64_t)b * S * (2 * kC);                // this video's slab; ld4 indexes groups of 4 elements
+  // Samples are taken two at a time with all eight 16-byte loads requested before any arithmetic: a wavefront walks a
+  // chain of 32 dependent L2 round trips otherwise (4 loads in flight), and the kernel is bound by that latency
+  struct Rows { float4 l0, l1, u0, u1; };
+  auto load_rows = [&](int k, int half4, float &cl, float &ch) {
+    const int rr = __builtin_amdgcn_readlane(roff, 4 * k);
+    cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_lo), 4 * k));
+    ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_hi), 4 * k));
+    const int rr1 = min(rr + 1, S - 1);             // c_hi == 0 whenever rr + 1 leaves the level (T_l == 1)
+    const int64_t r0 = (int64_t)rr * (2 * kC / 4) + half4, r1 = (int64_t)rr1 * (2 * kC / 4) + half4;
+    Rows r;
+    r.l0 = ld4(slab_b, r0 + lane); r.l1 = ld4(slab_b, r0 + 64 + lane);
+    r.u0 = ld4(slab_b, r1 + lane); r.u1 = ld4(slab_b, r1 + 64 + lane);
+    return r;
+  };
+  auto logit_part = [&](const Rows &r, float cl, float ch) {
+    float s = 0.f;
+    s = fmaf(qa.x, fast_tanh(fmaf(cl, r.l0.x, fmaf(ch, r.u0.x, ta.x))), s);
+    s = fmaf(qa.y, fast_tanh(fmaf(cl, r.l0.y, fmaf(ch, r.u0.y, ta.y))), s);
+    s = fmaf(qa.z, fast_tanh(fmaf(cl, r.l0.z, fmaf(ch, r.u0.z, ta.z))), s);
+    s = fmaf(qa.w, fast_tanh(fmaf(cl, r.l0.w, fmaf(ch, r.u0.w, ta.w))), s);
+    s = fmaf(qb.x, fast_tanh(fmaf(cl, r.l1.x, fmaf(ch, r.u1.x, tb.x))), s);
+    s = fmaf(qb.y, fast_tanh(fmaf(cl, r.l1.y, fmaf(ch, r.u1.y, tb.y))), s);
+    s = fmaf(qb.z, fast_tanh(fmaf(cl, r.l1.z, fmaf(ch, r.u1.z, tb.z))), s);
+    s = fmaf(qb.w, fast_tanh(fmaf(cl, r.l1.w, fmaf(ch, r.u1.w, tb.w))), s);
+    return s;
+  };
   float e[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    e[k] = 0.f;
-    if (k < LP) {
-      const int rr = __builtin_amdgcn_readlane(roff, 4 * k);
-      const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_lo), 4 * k));
-      const float ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_hi), 4 * k));
-      const int rr1 = min(rr + 1, S - 1);           // c_hi == 0 whenever rr + 1 leaves the level (T_l == 1)
-      const int64_t r0 = (int64_t)rr * (2 * kC / 4) + kC / 4, r1 = (int64_t)rr1 * (2 * kC / 4) + kC / 4;   // ctx2att half
-      const float4 l0 = ld4(slab_b, r0 + lane), l1 = ld4(slab_b, r0 + 64 + lane), u0 = ld4(slab_b, r1 + lane),
-                   u1 = ld4(slab_b, r1 + 64 + lane);
-      float s = 0.f;
-      s = fmaf(qa.x, fast_tanh(fmaf(cl, l0.x, fmaf(ch, u0.x, ta.x))), s);
-      s = fmaf(qa.y, fast_tanh(fmaf(cl, l0.y, fmaf(ch, u0.y, ta.y))), s);
-      s = fmaf(qa.z, fast_tanh(fmaf(cl, l0.z, fmaf(ch, u0.z, ta.z))), s);
-      s = fmaf(qa.w, fast_tanh(fmaf(cl, l0.w, fmaf(ch, u0.w, ta.w))), s);
-      s = fmaf(qb.x, fast_tanh(fmaf(cl, l1.x, fmaf(ch, u1.x, tb.x))), s);
-      s = fmaf(qb.y, fast_tanh(fmaf(cl, l1.y, fmaf(ch, u1.y, tb.y))), s);
-      s = fmaf(qb.z, fast_tanh(fmaf(cl, l1.z, fmaf(ch, u1.z, tb.z))), s);
-      s = fmaf(qb.w, fast_tanh(fmaf(cl, l1.w, fmaf(ch, u1.w, tb.w))), s);
-      e[k] = s;
-    }
+  for (int k = 0; k < 16; k += 2) {
+    e[k] = 0.f; e[k + 1] = 0.f;
+    float cl0, ch0, cl1, ch1;
+    Rows ra, rb;
+    if (k < LP) ra = load_rows(k, kC / 4, cl0, ch0);                 // ctx2att half of the slab rows
+    if (k + 1 < LP) rb = load_rows(k + 1, kC / 4, cl1, ch1);
+    __builtin_amdgcn_sched_barrier(0);                               // keep the eight loads ahead of the arithmetic
+    if (k < LP) e[k] = logit_part(ra, cl0, ch0);
+    if (k + 1 < LP) e[k + 1] = logit_part(rb, cl1, ch1);
   }
   float ek = butterfly16(e, lane) + alpha_b;
   if (k_own >= LP) ek = -INFINITY;
@@ -203,19 +219,19 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
 
   // ---- pass 2: weighted sum of the value half --------------------------------------------------------------
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto coef = [&](int k, float &cl, float &ch) {
+    cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_lo), 4 * k));
+    ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_hi), 4 * k));
+  };
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < LP) {
-      const int rr = __builtin_amdgcn_readlane(roff, 4 * k);
-      const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_lo), 4 * k));
-      const float ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_hi), 4 * k));
-      const int rr1 = min(rr + 1, S - 1);
-      const int64_t r0 = (int64_t)rr * (2 * kC / 4), r1 = (int64_t)rr1 * (2 * kC / 4);                     // value half
-      const float4 l0 = ld4(slab_b, r0 + lane), l1 = ld4(slab_b, r0 + 64 + lane), u0 = ld4(slab_b, r1 + lane),
-                   u1 = ld4(slab_b, r1 + 64 + lane);
-      fma8(cl, l0, l1, acc);
-      fma8(ch, u0, u1, acc);
-    }
+  for (int k = 0; k < 16; k += 2) {
+    float d0, d1, cl0, ch0, cl1, ch1;
+    Rows ra, rb;
+    if (k < LP) ra = load_rows(k, 0, d0, d1);                        // value half of the slab rows
+    if (k + 1 < LP) rb = load_rows(k + 1, 0, d0, d1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k < LP) { coef(k, cl0, ch0); fma8(cl0, ra.l0, ra.l1, acc); fma8(ch0, ra.u0, ra.u1, acc); }
+    if (k + 1 < LP) { coef(k + 1, cl1, ch1); fma8(cl1, rb.l0, rb.l1, acc); fma8(ch1, rb.u0, rb.u1, acc); }
   }
   ST *o = att_res + row * kC;
   st4(o, lane, make_float4(acc[0], acc[1], acc[2], acc[3]));
@@ -414,8 +430,8 @@ __global__ void __launch_bounds__(1024) k_sample_bwd(const T *__restrict__ value
 //   i,f,g,o = split(gates);  c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c')
 // one float4 of hidden units per lane
 // ------------------------------------------------------------------------------------------------------
-__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ inline float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+__device__ inline float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ inline float tanhf_(float x) { return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)), 1.f); }
 
 // GT: storage type of the four gate operands (fp32 / bf16 GEMM outputs); state c, h fp32
 template <typename GT>
@@ -489,7 +505,8 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
   const int vids_per_group = (B + 7) / 8;
   const int rows_per_group = vids_per_group * Q;
   const int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
-  return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", k_cap_attend<ST>, dim3(8 * blocks_per_group),
+  auto kern = L * P == kLP ? k_cap_attend<ST, true> : k_cap_attend<ST, false>;
+  return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", kern, dim3(8 * blocks_per_group),
                      dim3(kWaves * 64), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
                      alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_h_ld, att_res, dbg_alpha, dbg_loc);
 }

@@ -35,9 +35,9 @@ constexpr int kLP = 16;
 
 __device__ inline float fast_tanh(float x) {
   const float e = __expf(2.f * x);
-  return 1.f - 2.f / (1.f + e);
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);      // v_rcp_f32 (1 ulp), not a ~10-instruction IEEE division
 }
-__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ inline float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // reduce-scatter of v[16] over the 64 lanes: afterwards every lane holds the full sum of v[k], k = lane >> 2
 __device__ inline float butterfly16(float (&v)[16], int lane) {
