@@ -256,6 +256,29 @@ __device__ inline f2v row_bcast_f2(f2v v) {
   const long long r = __builtin_amdgcn_update_dpp((long long)0, __builtin_bit_cast(long long, v), 0x150 + SRC, 0xF, 0xF, true);
   return __builtin_bit_cast(f2v, r);
 }
+// lane SRC's v broadcast over its row and added to this lane's `addend`, in ONE VALU instruction (v_add_u32_dpp).  The
+// compiler's DPP combiner does not fold the v_mov_dpp + v_add pair of the forward sample step (the broadcast is
+// hoisted over the exec-mask change of the guarded store), hence the asm.  v must not be written by the two preceding
+// VALU instructions (DPP read-after-write hazard; the assembler text is opaque to the hazard recogniser): `settle`
+// prepends the two wait states for the first use after v was produced.
+template <int SRC>
+__device__ inline int row_bcast_add(int v, int addend, bool settle = false) {
+  int r;
+  if (settle)
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=v"(r) : "v"(v), "v"(addend), "n"(SRC));
+  else
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=v"(r) : "v"(v), "v"(addend), "n"(SRC));
+  return r;
+}
+typedef __attribute__((address_space(3))) const char lds_cbyte;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f4v lds_cf4v;
+__device__ inline float4 lds_ld4(lds_cbyte *p) {                                 // ds_read_b128 at an LDS byte address
+  const f4v t = *reinterpret_cast<lds_cf4v *>(p);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
 // acc (4 channels as two pairs) += c.x * v0 + c.y * v1
 __device__ inline void fma4x2(f2v c, const float4 &v0, const float4 &v1, f2v &a01, f2v &a23) {
   const f2v lo = __builtin_shufflevector(c, c, 0, 0), hi = __builtin_shufflevector(c, c, 1, 1);
@@ -534,6 +557,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
   const char *slab_b = reinterpret_cast<const char *>(slab4);
   const int lane_off = j * 16;
+  const int lane_lds = (int)(uintptr_t)(lds_cbyte *)slab_b + lane_off;          // this lane's 16-byte column, LDS address
 
   for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
@@ -545,19 +569,20 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
     const RawOps r_next = r_n;
     r_n = fetch_next();
     f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-    // per sample step: v_mov_b32_dpp (row), v_add (lane offset), v_mov_b64_dpp (both coefficients), 2 ds_read_b128,
-    // 4 v_pk_fma_f32 -- the loop is VALU-issue bound (tools/fwd_phase_stamps.py), every instruction counts
+    // per sample step: v_add_u32_dpp (row broadcast + lane offset = LDS address), v_mov_b64_dpp (both coefficients),
+    // 2 ds_read_b128, 4 v_pk_fma_f32 -- the loop is VALU-issue bound (tools/fwd_phase_stamps.py), every instruction counts
 #define GVL_FWD_STEP(SI)                                                        \
   if (FULL16 || SI < LP) {                                                      \
-    const int ro = row_bcast_i<SI>(roff);                                       \
     const f2v c2 = row_bcast_f2<SI>(cc);                                        \
     float4 v0, v1;                                                              \
     if (L0G && SI < 4) {                                                        \
+      const int ro = row_bcast_i<SI>(roff);                                     \
       v0 = ld4(value, vg + (int64_t)ro * (M * 16));                             \
       v1 = ld4(value, vg + (int64_t)min(ro + 1, S - 1) * (M * 16));             \
     } else {                                                                    \
-      v0 = *reinterpret_cast<const float4 *>(slab_b + ro + lane_off);           \
-      v1 = *reinterpret_cast<const float4 *>(slab_b + ro + lane_off + 256);     \
+      lds_cbyte *row = (lds_cbyte *)(uintptr_t)(unsigned)row_bcast_add<SI>(roff, lane_lds, SI == (L0G ? 4 : 0)); \
+      v0 = lds_ld4(row);                                                        \
+      v1 = lds_ld4(row + 256);                                                  \
     }                                                                           \
     fma4x2(c2, v0, v1, a01, a23);                                               \
   }
