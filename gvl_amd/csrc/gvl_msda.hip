@@ -613,8 +613,10 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 //   phase 3  one wavefront per slab row, lane = channel: the row's entries (those with r == s use c_lo, those with
 //            r == s-1 use c_hi) are loaded 64 at a time, (query, coefficient) are broadcast with v_readlane and the
 //            query's grad_out row is read conflict-free from LDS: grad_value[s] = sum coef * grad_out[q].
-// grad_value rows are written once with plain coalesced stores (partial slabs + k_sum_partials when a (b,m) slab
-// is shared by several workgroups).
+// grad_value rows are written with plain coalesced stores.  When the queries of a slab do not fit one LDS carve-up they
+// are cut into chunks that the slab's workgroups walk in turn, adding each chunk's rows to what the earlier chunks
+// left (the row is private to the workgroup); only when a (b,m) slab is shared by several workgroups (B*M < 256) do
+// partial slabs + k_sum_partials remain, one per workgroup.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kBwdThreads = 1024;
 constexpr int kEntStride = 16;       // entry slot = q_local * 16 + sample
@@ -631,14 +633,14 @@ __host__ __device__ inline size_t bwd_lds_bytes(int S, int nq, int rowsV) {
 // (B,Q,M,L,RD) or nullptr.  The softmax / location backward of ms_deform_attn.py:99-109 is applied in the epilogue.
 // Storage type VT (fp32 | bf16): value, grad_out and -- FUSED -- proj / grad_proj.  grad_value leaves this kernel in
 // fp32 (`gvalue_part`): the final tensor itself when VT = float and one workgroup owns the slab, else partial slabs.
-template <int PAD, bool FULL16, bool FUSED, bool L0G, typename VT>
+template <int PAD, bool FULL16, bool FUSED, bool L0G, bool LOOP, typename VT>
 __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restrict__ value,
                                                              const int64_t *__restrict__ shapes,
                                                              const int64_t *__restrict__ lsi,
                                                              const void *__restrict__ loc,
                                                              const float *__restrict__ attn,
                                                              const VT *__restrict__ gout, int B, int S, int M, int L,
-                                                             int Q, int P, int RD, int nchunk, int qper,
+                                                             int Q, int P, int RD, int nchunk, int ngroup, int qper,
                                                              float *__restrict__ gvalue_part,
                                                              void *__restrict__ gloc, float *__restrict__ gattn,
                                                              unsigned long long *__restrict__ stamps) {
@@ -658,11 +660,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
   int *sorted = reinterpret_cast<int *>(ent_hi + qper * kEntStride);
 
   const int BM = B * M;
-  const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
+  const int bm = blockIdx.x % BM, wgc = blockIdx.x / BM;
   const int b = bm / M, m = bm % M;
-  const int q0 = chunk * qper;
-  const int q1 = min(Q, q0 + qper);
-  const int nq = q1 - q0;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int LP = FULL16 ? 16 : L * P;
@@ -673,6 +672,18 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     st = (int)lsi[lvl];
   }
   const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
+  // The queries of a (b,m) slab are cut into nchunk chunks that fit the LDS carve-up; the slab's `ngroup` workgroups
+  // take them round-robin and ACCUMULATE their grad_value rows in ONE slab per workgroup (first chunk stores, later
+  // chunks add: a row is read and written by waves of this workgroup only, barriers in between), so the number of
+  // partial slabs is ngroup (1 when B*M already covers the chip), not nchunk.
+  // (LOOP = false: every workgroup has exactly one chunk -- the compile-time single trip keeps the scalar registers of
+  // the common small-T case out of spill territory)
+  int chunk = wgc;
+  do {
+  if (LOOP && chunk != wgc) __syncthreads();          // the previous chunk's gather is done with the LDS
+  const int q0 = chunk * qper;
+  const int q1 = max(q0, min(Q, q0 + qper));
+  const int nq = q1 - q0;
   // operands of the first pass are requested before the slab staging; every pass prefetches the next one's
   int qb = q0 + wave * 4;
   RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
@@ -826,7 +837,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
   // ---- phase 3: gather.  A DPP row (16 lanes x float4) owns one slab row; the four rows of a wavefront are
   // neighbours (similar list lengths).  Lane j fetches entry j of the batch, (query, coefficient) are broadcast
   // inside the row with row_newbcast and the query's grad_out row is one conflict-free ds_read_b128 per lane.
-  float4 *dst4 = reinterpret_cast<float4 *>(gvalue_part) + ((int64_t)chunk * B * S * M) * 16 + ((int64_t)b * S * M + m) * 16;
+  float4 *dst4 = reinterpret_cast<float4 *>(gvalue_part) + ((int64_t)wgc * B * S * M) * 16 + ((int64_t)b * S * M + m) * 16;
+  const bool accumulate = LOOP && chunk != wgc;
   const int ngroups = blockDim.x >> 4;
   const char *G_b = reinterpret_cast<const char *>(G4);
   const int lane_off = j * 16;
@@ -849,6 +861,14 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     int n = max(n_own, __shfl_xor(n_own, 16, 64));
     n = max(n, __shfl_xor(n, 32, 64));
     f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    // later chunks leave the rows none of their samples touched alone (encoder self-attention: a chunk of neighbouring
+    // queries reaches a window of each level, not the whole slab)
+    const bool touch = live && (!accumulate || n_own > 0);
+    if (accumulate && touch) {                         // the row's sum over the earlier chunks; lands during the gather
+      const float4 prev = dst4[(int64_t)s * M * 16 + j];
+      a01 = (f2v){prev.x, prev.y};
+      a23 = (f2v){prev.z, prev.w};
+    }
     for (int base = 0; base < n; base += 16) {
       const int i = base + j;
       // (byte offset of the query's grad_out row, coefficient) travel as ONE 64-bit row broadcast; past the end:
@@ -878,8 +898,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
 #undef GVL_GATHER_STEP
     }
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
-    if (live) dst4[(int64_t)s * M * 16 + j] = acc;
+    if (touch) dst4[(int64_t)s * M * 16 + j] = acc;
   }
+  } while (LOOP && (chunk += ngroup) < nchunk);
 }
 
 // sum `n` fp32 partial slabs (each `count4` float4 long) into dst (storage type VT)
@@ -970,16 +991,26 @@ int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
 // queries per workgroup for the LDS carve-up; 0 = does not fit
+// workgroups per (b,m) slab: enough to cover the 256 CUs, never more than there are chunks
+int bwd_groups(int B, int M, int nchunk) {
+  const int g = (256 + B * M - 1) / (B * M);
+  return g < nchunk ? g : nchunk;
+}
 int bwd_chunks(int B, int M, int Q, int S, int rowsV) {
   int n = pick_chunks("GVL_MSDA_BWD_CHUNKS", B * M, Q, 256);
   while (n <= Q && bwd_lds_bytes(S, (Q + n - 1) / n, rowsV) > kLdsMax) ++n;
-  return n <= Q ? n : 0;
+  if (n > Q) return 0;
+  const int g = bwd_groups(B, M, n);                   // equal shares: a multiple of the group count
+  const int up = (n + g - 1) / g * g;
+  return up <= Q ? up : n;
 }
 
-// fp32 workspace the t1d_d64 backward needs: partial slabs when a (b,m) slab is shared by several workgroups, and
-// always one fp32 slab set for bf16 storage (the gather accumulates and writes fp32; k_sum_partials rounds once)
+// fp32 workspace the t1d_d64 backward needs: one partial slab per workgroup when a (b,m) slab is shared by several
+// workgroups, and always one fp32 slab set for bf16 storage (the gather accumulates and writes fp32; k_sum_partials
+// rounds once)
 size_t bwd_workspace_bytes(int B, int S, int M, int nchunk, bool bf16) {
-  return (nchunk > 1 || bf16) ? (size_t)nchunk * B * S * M * 64 * sizeof(float) : 0;
+  const int ngroup = bwd_groups(B, M, nchunk);
+  return (ngroup > 1 || bf16) ? (size_t)ngroup * B * S * M * 64 * sizeof(float) : 0;
 }
 
 template <typename VT, bool FUSED>
@@ -988,6 +1019,7 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
                 int nchunk, VT *gvalue, void *g0, float *g1, void *ws, size_t ws_bytes, hipStream_t st) {
   constexpr bool kBf16 = !std::is_same<VT, float>::value;
   const int qper = (Q + nchunk - 1) / nchunk;
+  const int ngroup = bwd_groups(B, M, nchunk);
   const size_t lds = bwd_lds_bytes(S, qper, plan.rowsV);
   const size_t need = bwd_workspace_bytes(B, S, M, nchunk, kBf16);
   float *part = reinterpret_cast<float *>(gvalue);
@@ -997,26 +1029,28 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
     part = (float *)ws;
   }
   const bool full = L * P == 16;
-  decltype(&k_bwd_t1d_d64<kPadZeros, true, FUSED, false, VT>) kern;
+  decltype(&k_bwd_t1d_d64<kPadZeros, true, FUSED, false, false, VT>) kern;
+  const bool loop = nchunk > ngroup;
+#define GVL_BWD_PICK(PADV, LOOPV)                                                                    \
+  (plan.l0g ? k_bwd_t1d_d64<PADV, true, FUSED, true, LOOPV, VT>                                      \
+            : (full || FUSED) ? k_bwd_t1d_d64<PADV, true, FUSED, false, LOOPV, VT>                   \
+                              : k_bwd_t1d_d64<PADV, false, false, false, LOOPV, VT>)
   if (pad == kPadZeros)
-    kern = plan.l0g ? k_bwd_t1d_d64<kPadZeros, true, FUSED, true, VT>
-                    : (full || FUSED) ? k_bwd_t1d_d64<kPadZeros, true, FUSED, false, VT>
-                                      : k_bwd_t1d_d64<kPadZeros, false, false, false, VT>;
+    kern = loop ? GVL_BWD_PICK(kPadZeros, true) : GVL_BWD_PICK(kPadZeros, false);
   else
-    kern = plan.l0g ? k_bwd_t1d_d64<kPadBorder, true, FUSED, true, VT>
-                    : (full || FUSED) ? k_bwd_t1d_d64<kPadBorder, true, FUSED, false, VT>
-                                      : k_bwd_t1d_d64<kPadBorder, false, false, false, VT>;
+    kern = loop ? GVL_BWD_PICK(kPadBorder, true) : GVL_BWD_PICK(kPadBorder, false);
+#undef GVL_BWD_PICK
   if (int rc = ensure_lds(kern, lds)) return rc;
   if (int rc = gvl::launch(GVL_PROF_BWD_T1D, Q, B, FUSED ? "k_bwd_t1d_d64<fused>" : "k_bwd_t1d_d64", kern,
-                           dim3(nchunk * B * M), dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M,
-                           L, Q, P, RD, nchunk, qper, part, g0, g1, g_bwd_stamps))
+                           dim3(ngroup * B * M), dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M,
+                           L, Q, P, RD, nchunk, ngroup, qper, part, g0, g1, g_bwd_stamps))
     return rc;
   if (need) {
     const int64_t count4 = (int64_t)B * S * M * 16;
     int64_t blocks = (count4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (int rc = gvl::launch(GVL_PROF_SUM_PARTIALS, Q, B, "k_sum_partials", k_sum_partials<VT>, dim3((unsigned)blocks),
-                             dim3(256), 0, st, (const float4 *)part, nchunk, count4, gvalue))
+                             dim3(256), 0, st, (const float4 *)part, ngroup, count4, gvalue))
       return rc;
   }
   g_last_impl = FUSED ? 3 : 2;
