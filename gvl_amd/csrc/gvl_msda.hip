@@ -680,7 +680,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
   // the common small-T case out of spill territory)
   int chunk = wgc;
   do {
-  if (LOOP && chunk != wgc) __syncthreads();          // the previous chunk's gather is done with the LDS
+  if (LOOP && chunk != wgc) {
+    __syncthreads();                                  // the previous chunk's gather is done with the LDS
+    if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();   // stamps describe the LAST chunk
+  }
   const int q0 = chunk * qper;
   const int q1 = max(q0, min(Q, q0 + qper));
   const int nq = q1 - q0;

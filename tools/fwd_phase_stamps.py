@@ -65,4 +65,21 @@ with torch.no_grad():
     print(f"backward, back-to-back: start skew max {us[:, 0].max():5.2f} | staging mean {np.mean(us[:, 1] - us[:, 0]):5.2f} | "
           f"phase 1 mean {np.mean(us[:, 2] - us[:, 1]):5.2f} | phase 2 mean {np.mean(us[:, 3] - us[:, 2]):5.2f} | "
           f"phase 2 done at max {us[:, 3].max():5.2f} us (phase 3 = the rest of the kernel)")
+    # ---- backward, long video (cfg L encoder shape, B = 64): the stamps describe each workgroup's LAST query chunk ----
+    from gvl_amd import _lib as _l
+    tsh, lsi = make_level_tensors([512, 256, 128, 64], dev)
+    sh2 = temporal_shapes_2d(tsh, lsi)
+    Bq, Sq = 64, 960
+    value = torch.randn(Bq, Sq, 8, 64, device=dev)
+    proj = torch.randn(Bq, Sq, 256, device=dev)
+    ref = torch.rand(Bq, Sq, 4, 1, device=dev)
+    gout = torch.randn(Bq, Sq, 512, device=dev)
+    for _ in range(3):
+        MSDA.msda1d_fused_backward(value, sh2, lsi, proj, ref, gout, 4, 4, need_ref_grad=True)
+    torch.cuda.synchronize()
+    s_ = buf.view(-1, 4)[4096:4096 + 512].cpu().numpy().astype(np.int64)
+    us = s_ / 100.0
+    print(f"backward cfg L enc B=64, last chunk of each workgroup: staging mean {np.mean(us[:, 1] - us[:, 0]):5.2f} | "
+          f"phase 1 mean {np.mean(us[:, 2] - us[:, 1]):5.2f} | phase 2 mean {np.mean(us[:, 3] - us[:, 2]):5.2f} | "
+          f"kernel span {(us[:, 3].max() - us[:, 0].min()):7.1f} us over {len(us)} workgroups")
     lib.gvl_msda_debug_stamps(None)
