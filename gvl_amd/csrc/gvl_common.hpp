@@ -121,8 +121,21 @@ __device__ inline float4 ld4(const bf16_t *base, int64_t i4) {
   return make_float4((float)v.a, (float)v.b, (float)v.c, (float)v.d);
 }
 __device__ inline void st4(float *base, int64_t i4, float4 v) { reinterpret_cast<float4 *>(base)[i4] = v; }
+// streaming form for outputs the kernel never reads back ("nt": written through instead of parked dirty in the XCD's L2
+// until the end-of-kernel release has to flush it)
+__device__ inline void st4_stream(float *base, int64_t i4, float4 v) {
+  typedef float f4n __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((f4n){v.x, v.y, v.z, v.w}, reinterpret_cast<f4n *>(base) + i4);
+}
+__device__ inline void st4_stream(bf16_t *base, int64_t i4, float4 v);
+__device__ inline void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void st_stream(float2 *p, float2 v) {
+  typedef float f2n __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store((f2n){v.x, v.y}, reinterpret_cast<f2n *>(p));
+}
 __device__ inline void st4(bf16_t *base, int64_t i4, float4 v) {            // v_cvt_pk_bf16_f32: round-to-nearest-even
   bf16x4 o;
   o.a = (bf16_t)v.x; o.b = (bf16_t)v.y; o.c = (bf16_t)v.z; o.d = (bf16_t)v.w;
   reinterpret_cast<bf16x4 *>(base)[i4] = o;
 }
+__device__ inline void st4_stream(bf16_t *base, int64_t i4, float4 v) { st4(base, i4, v); }

@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
     GVL_FWD_STEP(12) GVL_FWD_STEP(13) GVL_FWD_STEP(14) GVL_FWD_STEP(15)
 #undef GVL_FWD_STEP
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
-    if (act) st4(out, (((int64_t)b * Q + q) * M + m) * 16 + j, acc);
+    if (act) st4_stream(out, (((int64_t)b * Q + q) * M + m) * 16 + j, acc);
     if (qb + nw * 4 < q1) prep(r_next, roff_c, cc_c);
   }
   if (stamps) {
@@ -771,8 +771,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     const float keep_y = fmaf(dylo, d0, dyhi * d1);
     if (!FUSED) {
       if (act && j < LP) {
-        gattn[tb + j] = keep_w;                                                // cuh:156-157
-        reinterpret_cast<float2 *>(gloc)[tb + j] = make_float2(keep_x, keep_y);   // unfused: grad_loc is fp32
+        st_stream(gattn + tb + j, keep_w);                                     // cuh:156-157
+        st_stream(reinterpret_cast<float2 *>(gloc) + tb + j, make_float2(keep_x, keep_y));   // unfused: grad_loc is fp32
       }
     } else {
       // softmax backward (ms_deform_attn.py:100-101): d logit_j = w_j (g_j - sum_k w_k g_k), g = d out / d w
@@ -901,7 +901,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
 #undef GVL_GATHER_STEP
     }
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
-    if (touch) dst4[(int64_t)s * M * 16 + j] = acc;
+    if (touch) {
+      if (LOOP) dst4[(int64_t)s * M * 16 + j] = acc;                 // re-read by this workgroup's later chunks
+      else st4_stream(reinterpret_cast<float *>(dst4), (int64_t)s * M * 16 + j, acc);
+    }
   }
   } while (LOOP && (chunk += ngroup) < nchunk);
 }
@@ -916,7 +919,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float4 *__restrict__
       const float4 v = part[(int64_t)k * count4 + i];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    st4(dst, i, a);
+    st4_stream(dst, i, a);
   }
 }
 
