@@ -138,4 +138,8 @@ __device__ inline void st4(bf16_t *base, int64_t i4, float4 v) {            // v
   o.a = (bf16_t)v.x; o.b = (bf16_t)v.y; o.c = (bf16_t)v.z; o.d = (bf16_t)v.w;
   reinterpret_cast<bf16x4 *>(base)[i4] = o;
 }
-__device__ inline void st4_stream(bf16_t *base, int64_t i4, float4 v) { st4(base, i4, v); }
+__device__ inline void st4_stream(bf16_t *base, int64_t i4, float4 v) {
+  bf16x4 o;
+  o.a = (bf16_t)v.x; o.b = (bf16_t)v.y; o.c = (bf16_t)v.z; o.d = (bf16_t)v.w;
+  __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, o), reinterpret_cast<unsigned long long *>(base) + i4);
+}
