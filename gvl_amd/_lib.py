@@ -77,6 +77,10 @@ def lib():
                     raise GvlLibraryError(
                         f"{LIB_PATH} is missing: build it with `python -m gvl_amd.build` "
                         "(hipcc --offload-arch=gfx950).  gvl_amd has no CPU / PyTorch fallback.")
+                # libgvl_msda.so needs libamdhip64.so.7.  In a PyTorch process that must be the HIP runtime PyTorch ships
+                # and allocates with: loaded first it is found by SONAME; loaded after this library, the process would
+                # hold two runtimes and every launch here would fail with "no ROCm-capable device".
+                import torch  # noqa: F401
                 try:
                     handle = ctypes.CDLL(LIB_PATH)
                 except OSError as e:  # pragma: no cover

@@ -159,3 +159,21 @@ def test_product_never_imports_the_oracle():
     for path in glob.glob(os.path.join(ROOT, "gvl_amd", "**", "*.py"), recursive=True):
         src = open(path).read()
         assert "import oracle" not in src and "from oracle" not in src, path
+
+
+def test_library_binds_to_the_hip_runtime_pytorch_ships():
+    """Loading libgvl_msda.so before PyTorch used to leave TWO libamdhip64 in the process (the system one for this
+    library, PyTorch's own for its allocator) and every launch failed with "no ROCm-capable device"
+    (`__graft_entry__.build()` followed by `smoke()` in one interpreter).  gvl_amd._lib imports torch first."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from gvl_amd import _lib\n"
+        "_lib.lib()\n"
+        "import torch\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print(libs)\n"
+        "assert len(libs) == 1, libs\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
