@@ -66,7 +66,7 @@ inline int launch(int tag, int meta_a, int meta_b, const char *what, K kernel, d
 
 // zero-fill as a KERNEL node.  hipMemsetAsync inside a captured stream did not re-execute reliably on hipGraph replay
 // (ROCm 7.2: gradients accumulated on top of the previous replay's values), a kernel launch always does.
-__global__ inline void k_zero_fill(uint4 *__restrict__ p, size_t n16, unsigned char *__restrict__ tail, int ntail) {
+static __global__ void k_zero_fill(uint4 *__restrict__ p, size_t n16, unsigned char *__restrict__ tail, int ntail) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
     p[i] = make_uint4(0u, 0u, 0u, 0u);
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
