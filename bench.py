@@ -196,6 +196,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # a checkout without the (git-ignored) built library: compile it once, on one rank, before anyone loads it
+    from gvl_amd import build as lib_build
+    if not os.path.exists(lib_build.OUT):
+        if local_rank == 0:
+            lib_build.build()
+        if world > 1:
+            dist.barrier()
     from gvl_amd.config import make_opt
     from gvl_amd.pdvc import build
     from gvl_amd.tuning import enable_tuned_gemms
