@@ -17,10 +17,11 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"k_(fwd|bwd)_t1d_d64<(\d), (true|false), (true|false), (true|false), (\w+)>", r["Kernel_Name"])
+        m = re.search(r"k_(fwd|bwd)_t1d_d64<(\d), (true|false), (true|false), (true|false), (?:(true|false), )?(\w+)>",
+                      r["Kernel_Name"])
         if not m:
             continue
-        kind, pad, full, fused, l0g, vt = m.groups()
+        kind, pad, full, fused, l0g, _loop, vt = m.groups()
         if vt != "float" or l0g == "true":
             continue
         key = f"k_{kind}_t1d_d64" + ("_fused" if fused == "true" else "")
