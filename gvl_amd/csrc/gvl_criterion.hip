@@ -385,7 +385,7 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
 //   x_t   = (x_t - 0.5) / (x_last + 1e-6) * 2 pi
 //   out[n, 2i,   t] = sin(x_t / dim_t[2i]),  out[n, 2i+1, t] = cos(x_t / dim_t[2i+1])      (F sine channels)
 //   out[n, F + c, t] = dur[n, c]                                                              (duration embedding)
-// ~20 PyTorch kernels per level otherwise.  One workgroup per video; dim_t is passed in (computed once by torch.pow so
+// ~20 PyTorch kernels per level otherwise.  A few workgroups per video; dim_t is passed in (computed once by torch.pow so
 // that the table is the reference's bit for bit).
 // ------------------------------------------------------------------------------------------------------
 namespace {
@@ -420,13 +420,16 @@ __global__ void __launch_bounds__(256) k_pos_embed_sine(const unsigned char *__r
   const float last = xs[T - 1];
   const float denom = last + 1e-6f;
   float *o = out + (int64_t)n * (F + Cd) * T;
-  for (int idx = threadIdx.x; idx < F * T; idx += blockDim.x) {
+  // the table of one video is shared out over gridDim.y workgroups (each repeats the cheap scan above): 25 600 precise
+  // sinf / cosf per video on ONE workgroup took 30 us per level
+  const int stride = blockDim.x * gridDim.y, first = blockIdx.y * blockDim.x + threadIdx.x;
+  for (int idx = first; idx < F * T; idx += stride) {
     const int c = idx / T, t = idx % T;
     const float x = (xs[t] - 0.5f) / denom * scale;
     const float p = x / dim_t[c];
     o[idx] = (c & 1) ? cosf(p) : sinf(p);
   }
-  for (int idx = threadIdx.x; idx < Cd * T; idx += blockDim.x) o[(int64_t)F * T + idx] = dur[(int64_t)n * Cd + idx / T];
+  for (int idx = first; idx < Cd * T; idx += stride) o[(int64_t)F * T + idx] = dur[(int64_t)n * Cd + idx / T];
 }
 
 }  // namespace
@@ -439,6 +442,8 @@ extern "C" int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *di
   if (!mask || !dim_t || !out || (n_dur > 0 && !dur_embed)) return fail(GVL_EINVAL, "gvl_pos_embed_sine_f32: null pointer");
   const size_t lds = (size_t)T * sizeof(float);
   if (int rc = gvl::ensure_lds(k_pos_embed_sine, lds)) return rc;
-  return gvl::launch(GVL_PROF_POS_EMBED, T, N, "k_pos_embed_sine", k_pos_embed_sine, dim3(N), dim3(256), lds,
+  int slices = (int)(((int64_t)(n_sine + n_dur) * T + 2047) / 2048);          // ~8 outputs per thread
+  slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+  return gvl::launch(GVL_PROF_POS_EMBED, T, N, "k_pos_embed_sine", k_pos_embed_sine, dim3(N, slices), dim3(256), lds,
                      (hipStream_t)stream, mask, dim_t, dur_embed, T, n_sine, n_dur, scale, out);
 }
