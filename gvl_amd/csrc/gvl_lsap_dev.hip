@@ -23,6 +23,7 @@ using gvl::fail;
 
 constexpr int kMaxCols = 1024;   // max(nr, nc) of one problem after orientation
 constexpr int kMaxRows = 256;    // min(nr, nc)
+constexpr int kMaxStaged = 7168; // distinct costs (Q * n) kept in LDS; larger problems read them from global memory
 
 struct Problem {
   // view of one problem inside the cost tensor: element (q, k) = C[base + q * ld + (k % n)]   (k < n * tile);
@@ -54,6 +55,7 @@ __global__ void __launch_bounds__(64) k_lsap(const float *__restrict__ C, const 
   __shared__ double u[kMaxRows], v[kMaxCols], spc[kMaxCols];
   __shared__ int path[kMaxCols], row4col[kMaxCols], col4row[kMaxRows], remaining[kMaxCols];
   __shared__ unsigned char SR[kMaxRows], SC[kMaxCols];
+  __shared__ float Cs[kMaxStaged];
 
   const Problem pr = probs[blockIdx.x];
   const int lane = threadIdx.x;
@@ -63,10 +65,17 @@ __global__ void __launch_bounds__(64) k_lsap(const float *__restrict__ C, const 
   const int nr = transpose ? K : Q;
   const int nc = transpose ? Q : K;
   if (nr == 0 || nc == 0) return;
+  // The Q x n distinct costs of the problem are staged in LDS once (the 4x-tiled matrix repeats them): the column scan of
+  // every Dijkstra step otherwise waits for global loads in the middle of a chain of ~40 dependent steps per problem.
+  const bool staged = Q * n_ <= kMaxStaged;
+  if (staged) {
+    for (int e = lane; e < Q * n_; e += 64) Cs[e] = C[pr.base + (int64_t)(e / n_) * pr.ld + (e % n_)];
+    __syncthreads();
+  }
   // cost(i, j) of the oriented problem
   auto cost = [&](int i, int j) -> double {
     const int q = transpose ? j : i, k = transpose ? i : j;
-    return (double)C[pr.base + (int64_t)q * pr.ld + (k % n_)];
+    return staged ? (double)Cs[q * n_ + (k % n_)] : (double)C[pr.base + (int64_t)q * pr.ld + (k % n_)];
   };
   // validity (scipy raises on NaN / -inf)
   int bad = 0;
