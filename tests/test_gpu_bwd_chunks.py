@@ -1,0 +1,105 @@
+"""The backward's looping form (k_bwd_t1d_d64<..., LOOP = true>): when the queries of a (b,m) slab do not fit one LDS
+carve-up, the slab's workgroups walk several query chunks and accumulate the grad_value rows in place.  It is selected
+when there are more chunks than workgroups per slab (B*M >= 256 -> one workgroup per slab), which the other op tests
+(small B) never reach.  Checked against the CPU oracle and the generic kernel, both paddings, for
+  * a long video (T = 512: level 0 in global memory, chunks forced by the LDS budget),
+  * the cfg A shape with the chunk count forced through GVL_MSDA_BWD_CHUNKS,
+  * the fused module entry point against the autograd composition of the unfused op."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import t, maxerr
+from test_gpu_op import make_inputs, set_impl, last_impl, scale
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def MSDA():
+    from gvl_amd import MultiScaleDeformableAttention as m, _lib
+    _lib.lib()
+    return m
+
+
+def _check(MSDA, dev, B, T, Q, pad, seed, oracle_rows=4):
+    from oracle import msda_oracle as O
+    value, shapes, lsi, loc, aw, gout = make_inputs(B, T, 8, 64, Q, 4, seed=seed)
+    args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
+    g = t(gout).to(dev)
+    try:
+        set_impl("fast")
+        gv, gl, gw = MSDA.ms_deform_attn_backward(*args, g, 64, pad_mode=pad)
+        assert last_impl() == "fast"
+        set_impl("generic")
+        rv, rl, rw = MSDA.ms_deform_attn_backward(*args, g, 64, pad_mode=pad)
+    finally:
+        set_impl("auto")
+    sv = scale(rv.cpu().numpy())
+    assert maxerr(gv, rv.cpu().numpy()) <= 1e-4 * sv
+    assert maxerr(gl, rl.cpu().numpy()) <= 1e-4 * scale(rl.cpu().numpy())
+    assert maxerr(gw, rw.cpu().numpy()) <= 1e-4 * scale(rw.cpu().numpy())
+    # the first videos once more against the CPU oracle (the generic kernel is pinned to it elsewhere)
+    nb = min(B, oracle_rows)
+    ov, ol, ow = O.msda_backward(value[:nb], shapes, lsi, loc[:nb], aw[:nb], gout[:nb], pad)
+    assert maxerr(gv[:nb], ov) <= 1e-4 * scale(ov)
+    assert maxerr(gl[:nb], ol) <= 1e-4 * scale(ol)
+    assert maxerr(gw[:nb], ow) <= 1e-4 * scale(ow)
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_long_video_chunks_accumulate_in_place(pad, dev, MSDA):
+    # B*M = 256 slabs -> one workgroup each; 400 queries beside a 449-row slab need >= 3 chunks
+    _check(MSDA, dev, B=32, T=512, Q=400, pad=pad, seed=41)
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 5])
+def test_forced_chunk_counts_at_the_training_shape(chunks, dev, MSDA, monkeypatch):
+    monkeypatch.setenv("GVL_MSDA_BWD_CHUNKS", str(chunks))
+    _check(MSDA, dev, B=32, T=100, Q=300, pad="zeros", seed=7 + chunks)
+
+
+def test_ragged_last_chunk_and_two_workgroups_per_slab(dev, MSDA, monkeypatch):
+    # B*M = 128 -> two workgroups per slab; 6 chunks of 50 queries over Q = 277: three chunks each, the last one short
+    monkeypatch.setenv("GVL_MSDA_BWD_CHUNKS", "6")
+    _check(MSDA, dev, B=16, T=100, Q=277, pad="border", seed=99)
+
+
+@pytest.mark.parametrize("ref_dim", [1, 2])
+def test_fused_entry_point_with_chunks_matches_autograd_composition(ref_dim, dev, MSDA, monkeypatch):
+    from gvl_amd.ops.functions.ms_deform_attn_func import MSDeformAttnFunction
+    monkeypatch.setenv("GVL_MSDA_BWD_CHUNKS", "4")
+    B, M, D, L, P, Q = 32, 8, 64, 4, 4, 120
+    lens = [100, 50, 25, 13]
+    S = sum(lens)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    value = torch.randn(B, S, M, D, generator=gen).to(dev)
+    proj = (torch.randn(B, Q, 2 * M * L * P, generator=gen) * 0.7).to(dev)
+    ref = torch.rand(B, Q, L, ref_dim, generator=gen).to(dev)
+    if ref_dim == 2:
+        ref[..., 1] = ref[..., 1] * 0.3 + 0.05
+    gout = torch.randn(B, Q, M * D, generator=gen).to(dev)
+    shapes = torch.tensor([(1, x) for x in lens], dtype=torch.long, device=dev)
+    lsi = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.long, device=dev)
+    gv, gp, gr = MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref, gout, L, P, need_ref_grad=True)
+
+    v2, p2, r2 = value.clone().requires_grad_(), proj.clone().requires_grad_(), ref.clone().requires_grad_()
+    off = p2[..., :M * L * P].view(B, Q, M, L, P)
+    w = torch.softmax(p2[..., M * L * P:].view(B, Q, M, L * P), -1).view(B, Q, M, L, P)
+    T_l = torch.tensor(lens, dtype=torch.float32, device=dev)
+    if ref_dim == 1:                                     # ms_deform_attn.py:103-106
+        x = r2[:, :, None, :, None, 0] + off / T_l[None, None, None, :, None]
+    else:                                                # :107-109
+        x = r2[:, :, None, :, None, 0] + off / P * r2[:, :, None, :, None, 1] * 0.5
+    loc = torch.stack([x, torch.full_like(x, 0.5)], -1)
+    out = MSDeformAttnFunction.apply(v2, shapes, lsi, loc, w, 64)
+    out.backward(gout)
+    assert maxerr(gv, v2.grad.cpu().numpy()) <= 1e-4 * scale(v2.grad.cpu().numpy())
+    assert maxerr(gp, p2.grad.cpu().numpy()) <= 1e-4 * scale(p2.grad.cpu().numpy())
+    assert maxerr(gr, r2.grad.cpu().numpy()) <= 1e-4 * scale(r2.grad.cpu().numpy())
