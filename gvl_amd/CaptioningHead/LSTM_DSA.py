@@ -29,6 +29,7 @@ from ..ops.functions import MSDASampleFunction
 from ..ops.modules import MSDeformAttnCap
 from ..ops.modules.ms_deform_attn import temporal_shapes_2d
 from .. import MultiScaleDeformableAttention as MSDA
+from ..linear import Linear
 
 
 class ShowAttendTellCore(nn.Module):
@@ -290,7 +291,7 @@ class TeacherForcedLoop(torch.autograd.Function):
                 dh_carry = torch.mm(dg[i], w_hcat, out=dh_buf[i & 1])
         dgf = dg.view(steps * n, W)
         d_w_hcat = dgf.t().mm(h_all[:steps].reshape(steps * n, H))
-        d_b_hcat = dgf.sum(0)
+        d_b_hcat = MSDA.col_sum(dgf)
         d_gates = dg[:, :, A:A + H4]
         d_w_att = d_gates.reshape(steps * n, H4).t().mm(att.view(steps * n, C))
         return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates.sum(0), d_gates.permute(1, 0, 2), d_w_hcat, d_b_hcat,
@@ -328,7 +329,7 @@ class Captioner(nn.Module):
         self.max_caption_len = opt.max_caption_len
         self.ss_prob = 0.0
         self.embed = nn.Embedding(self.vocab_size + 1, self.input_encoding_size)
-        self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
+        self.logit = Linear(self.rnn_size, self.vocab_size + 1)
         self.dropout = nn.Dropout(self.drop_prob_lm)
         self.init_weights()
 

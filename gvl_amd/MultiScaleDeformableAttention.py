@@ -299,6 +299,21 @@ def cap_attend_train_backward(slab, spatial_shapes, level_start_index, ref_in, o
     _lib.check(rc, "cap_attend_train_backward")
 
 
+def col_sum_eligible(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] > 0
+
+
+def col_sum(x):
+    """x (R, C) fp32 -> (C,) column sums (include/gvl_msda.h: gvl_col_sum_f32)."""
+    _require(col_sum_eligible(x), "col_sum: x must be a 2-D fp32 CUDA matrix with unit column stride")
+    out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gvl_col_sum_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "col_sum")
+    return out
+
+
 def lstm_cell_train_forward(gates_a, gates_b, gates_c, c_prev, act, h_out, c_out):
     n, H = c_prev.shape
     for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b), ("gates_c", gates_c)):
@@ -396,7 +411,7 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp):
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
              12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train", 15: "match_cost", 16: "criterion",
-             17: "pos_embed"}
+             17: "pos_embed", 18: "col_sum"}
 
 
 def profile_enable(on=True):

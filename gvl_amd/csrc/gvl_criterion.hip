@@ -447,3 +447,64 @@ extern "C" int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *di
   return gvl::launch(GVL_PROF_POS_EMBED, T, N, "k_pos_embed_sine", k_pos_embed_sine, dim3(N, slices), dim3(256), lds,
                      (hipStream_t)stream, mask, dim_t, dur_embed, T, n_sine, n_dur, scale, out);
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Column sums of a row-major matrix: out[c] = sum_r x[r, c] -- the bias gradient of every nn.Linear on the path
+// (rows = B*Q or B*S tokens).  PyTorch's generic reduction over the slow axis takes 13-33 us on these shapes
+// (4800 x 512 ... 4800 x 2048), 48 times per train step.  Here: workgroup = (256-column block, 64-row chunk), each
+// wave streams 16 rows of 1 KB with every load in flight, partials meet in LDS and leave as one contiguous float
+// atomic per thread (2 cache lines per wave instruction) into the zero-filled output.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kCsRows = 64;
+
+__global__ void __launch_bounds__(256) k_col_sum(const float *__restrict__ x, int64_t ld, int R, int C,
+                                                 float *__restrict__ out) {
+  __shared__ float part[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 256 + 4 * lane;
+  const int r0 = blockIdx.y * kCsRows;
+  const int r1 = min(R, r0 + kCsRows);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c0 < C) {                                   // C is a multiple of 4 (checked by the caller)
+#pragma unroll 4
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)r * ld + c0);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[wave][4 * lane + 0] = acc.x; part[wave][4 * lane + 1] = acc.y;
+  part[wave][4 * lane + 2] = acc.z; part[wave][4 * lane + 3] = acc.w;
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// any width / row stride: one column per thread, 256 consecutive columns per workgroup
+__global__ void __launch_bounds__(256) k_col_sum_scalar(const float *__restrict__ x, int64_t ld, int R, int C,
+                                                        float *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * kCsRows, r1 = min(R, r0 + kCsRows);
+  float acc = 0.f;
+#pragma unroll 8
+  for (int r = r0; r < r1; ++r) acc += x[(int64_t)r * ld + c];
+  atomicAdd(out + c, acc);
+}
+
+}  // namespace
+
+extern "C" int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stream) {
+  if (R < 0 || C < 0 || ld < C) return fail(GVL_EINVAL, "gvl_col_sum_f32: bad sizes R=%d C=%d ld=%d", R, C, ld);
+  if (C == 0) return 0;
+  if (!out || (R > 0 && !x)) return fail(GVL_EINVAL, "gvl_col_sum_f32: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = gvl::zero_fill(out, (size_t)C * sizeof(float), st)) return rc;
+  if (R == 0) return 0;
+  const dim3 grid((C + 255) / 256, (R + kCsRows - 1) / kCsRows);
+  if (!(C & 3) && !(ld & 3) && !((uintptr_t)x & 15))       // rows of float4
+    return gvl::launch(GVL_PROF_COL_SUM, R, C, "k_col_sum", k_col_sum, grid, dim3(256), 0, st, x, (int64_t)ld, R, C, out);
+  return gvl::launch(GVL_PROF_COL_SUM, R, C, "k_col_sum_scalar", k_col_sum_scalar, grid, dim3(256), 0, st, x,
+                     (int64_t)ld, R, C, out);
+}

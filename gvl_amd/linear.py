@@ -1,0 +1,50 @@
+"""nn.Linear whose bias gradient is one column-sum kernel (include/gvl_msda.h: gvl_col_sum_f32).
+
+autograd differentiates F.linear as two GEMMs plus `grad_output.sum(0)`; PyTorch's generic reduction over the slow
+axis takes 10-20 us on the (B*Q | B*S, 256...2048) gradients of the path, ~40 times per train step.  `linear()` keeps
+the two GEMMs exactly as autograd issues them (same operand order, so the same tuned library kernels) and replaces
+only that reduction.  Anything it is not built for -- no bias, CPU, non-fp32, autocast -- goes through
+F.linear unchanged."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import MultiScaleDeformableAttention as MSDA
+
+
+class _LinearFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        g2 = grad_out.reshape(-1, grad_out.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g2.mm(weight).view(x.shape)                              # AddmmBackward: grad @ mat2^T
+        if ctx.needs_input_grad[1]:
+            # AddmmBackward sees mat2 = weight.t() (column-major) and takes the branch grad^T @ mat1: the gradient
+            # arrives contiguous in the weight's own layout and AccumulateGrad keeps it without a copy
+            gw = g2.t().mm(x.reshape(-1, x.shape[-1]))
+        if ctx.needs_input_grad[2]:
+            gb = MSDA.col_sum(g2) if MSDA.col_sum_eligible(g2) else g2.sum(0)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    if (bias is None or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32
+            or bias.dtype != torch.float32 or torch.is_autocast_enabled()
+            or not torch.is_grad_enabled() or not bias.requires_grad):
+        return F.linear(x, weight, bias)
+    return _LinearFunction.apply(x, weight, bias)
+
+
+class Linear(nn.Linear):
+    """Drop-in nn.Linear (same parameters, same state_dict keys)."""
+
+    def forward(self, input):                                             # noqa: A002
+        return linear(input, self.weight, self.bias)

@@ -14,6 +14,7 @@ from torch import nn
 
 from .. import functions as _fn
 from ... import MultiScaleDeformableAttention as MSDA
+from ...linear import Linear, linear
 
 
 def _power_of_two(n):
@@ -65,8 +66,8 @@ class MSDeformAttn(nn.Module):
         self.fused = True              # use the fused projection-epilogue + sampling kernels when the shape allows
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.output_proj = nn.Linear(d_model, d_model)
+        self.value_proj = Linear(d_model, d_model)
+        self.output_proj = Linear(d_model, d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -118,7 +119,7 @@ class MSDeformAttn(nn.Module):
         # one GEMM for both projections: columns [0,128) raw offsets, [128,256) attention logits
         w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
         b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        proj = F.linear(query, w_cat, b_cat)
+        proj = linear(query, w_cat, b_cat)
         out = _fn.MSDeformAttnFusedFunction.apply(value, proj, reference_points.contiguous(), shapes2d,
                                                   level_start_index, self.n_levels, self.n_points, self.pad_mode)
         return self.output_proj(out)

@@ -21,6 +21,7 @@ from .base_encoder import build_base_encoder
 from .CaptioningHead import build_captioner
 from .criterion import SetCriterion
 from .deformable_transformer import build_deforamble_transformer, inverse_sigmoid
+from .linear import Linear
 from .matcher import build_matcher
 from .postprocess import PostProcess
 
@@ -36,7 +37,7 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
-        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 3   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion (earlier entry points unchanged) */
+#define GVL_MSDA_ABI_VERSION 4   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32 (earlier entry points unchanged) */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -111,6 +111,12 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
 int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const float *dur_embed, int N, int T,
                            int n_sine, int n_dur, float scale, float *out, void *stream);
 
+/* -- column sums of a row-major fp32 matrix: out[c] = sum_r x[r * ld + c] -- the bias gradient of the nn.Linear layers on
+ *    the path (autograd's AddmmBackward: grad_bias = grad_output.sum(0)).  Any C and ld >= C (16-byte loads when C, ld
+ *    are multiples of 4 and x is 16-byte aligned); out is overwritten.  Summation order across row chunks is not
+ *    fixed (float atomics). */
+int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stream);
+
 /* -- kernel timing inside the library (measurement only; no reference equivalent).  While enabled, every kernel the
  *    library launches is dispatched with hipExtLaunchKernel start/stop events on the launch stream, i.e. the
  *    begin/end stamps of that one dispatch (what rocprofv3 --kernel-trace reports), independent of host launch gaps.
@@ -134,6 +140,7 @@ int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const 
 #define GVL_PROF_MATCH_COST 15
 #define GVL_PROF_CRITERION 16
 #define GVL_PROF_POS_EMBED 17
+#define GVL_PROF_COL_SUM 18
 int gvl_prof_enable(int on);
 /* Phase stamps of the temporal kernels (diagnostics): while a DEVICE buffer of 2 x 4096 x 4 uint64 is set, every
  * workgroup of k_fwd_t1d_d64 records the 100 MHz wall clock at {start, slab staged, loop done} in the first half and

@@ -92,3 +92,39 @@ def test_fused_criterion_equals_torch_formulation(NC, sizes, degenerate):
         assert (v != v and f != f) or abs(f - v) <= 2e-6 * max(1.0, abs(v)), (k, f, v)     # nan == nan (single match)
     for a, b in zip(res[True][1], res[False][1]):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("R,C,pad", [(4800, 512, 0), (4800, 2048, 0), (1056, 8519, 0), (96, 2576, 0), (1, 4, 0), (65, 7, 3),
+                                     (300, 260, 12), (2000, 1, 0)])
+def test_col_sum_matches_float64(R, C, pad):
+    """gvl_col_sum_f32 (the bias gradient of gvl_amd.linear) on 16-byte-row and odd-width / strided matrices."""
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    g = torch.Generator(device="cpu").manual_seed(R + C)
+    full = torch.randn(R, C + pad, generator=g).cuda()
+    x = full[:, :C]
+    got = MSDA.col_sum(x)
+    want = x.double().sum(0)
+    assert got.shape == (C,)
+    assert (got.double() - want).abs().max().item() <= 1e-5 * max(1.0, R ** 0.5) * 4
+
+
+def test_linear_gradients_equal_autograd_of_f_linear():
+    import torch.nn.functional as F
+    from gvl_amd.linear import Linear, linear
+    torch.manual_seed(3)
+    lin = Linear(512, 2048).cuda()
+    x = torch.randn(16, 300, 512, device="cuda", requires_grad=True)
+    gy = torch.randn(16, 300, 2048, device="cuda")
+    y = lin(x)
+    assert type(y.grad_fn).__name__ == "_LinearFunctionBackward"
+    y.backward(gy)
+    got = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad()
+    F.linear(x, lin.weight, lin.bias).backward(gy)
+    assert torch.equal(got[0], x.grad) and torch.equal(got[1], lin.weight.grad)      # the same two GEMM calls
+    assert (got[2] - lin.bias.grad).abs().max().item() <= 2e-4 * lin.bias.grad.abs().max().item()
+    # not applicable -> plain F.linear: no bias, no grad, autocast
+    assert type(linear(x, lin.weight, None).grad_fn).__name__ != "_LinearFunctionBackward"
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert type(lin(x).grad_fn).__name__ != "_LinearFunctionBackward"
