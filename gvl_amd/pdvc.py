@@ -253,11 +253,14 @@ class PDVC(nn.Module):
                                     inter_references, others, disable_iterative_refine):
         """Train step heads (pdvc.py:540-660): set losses on all queries, captioning only on the matched ones."""
         num_pred = hs.shape[0]
+        # the per-layer slices taken ONCE: every `hs[l]` of the stacked decoder output is a SelectBackward of its own
+        # (a zero-filled (layers, B, Q, C) tensor + a copy + an accumulation) -- unbind's backward is one stack
+        hs_l = hs.unbind(0)
         classes, counts, coords, cap_probs, seqs = [], [], [], [], []
         for l_id in range(num_pred):
             reference = init_reference if l_id == 0 else inter_references[l_id - 1]
-            cls, cnt, coord = self._layer_heads(l_id, hs[l_id], reference, disable_iterative_refine)
-            probs, seq = self._no_caption(hs[l_id])
+            cls, cnt, coord = self._layer_heads(l_id, hs_l[l_id], reference, disable_iterative_refine)
+            probs, seq = self._no_caption(hs_l[l_id])
             classes.append(cls); counts.append(cnt); coords.append(coord); cap_probs.append(probs); seqs.append(seq)
         all_out = self._pack(hs, classes, counts, coords, cap_probs, seqs)
         out = {k: v[-1] for k, v in all_out.items()}
@@ -277,7 +280,7 @@ class PDVC(nn.Module):
             # every decoder layer's caption loss from ONE pass of the shared caption head over all layers' matched
             # queries (the value / ctx2att slab, the token loop and every weight gradient are then computed once)
             cap_losses, probs, seq = self.caption_prediction_layers(self.caption_head[layers[-1]], dt,
-                                                                    [hs[l_id] for l_id in layers], refs, others, matches)
+                                                                    [hs_l[l_id] for l_id in layers], refs, others, matches)
             for l_id, cap_loss in zip(layers, cap_losses):
                 loss['loss_caption' if l_id == num_pred - 1 else f'loss_caption_{l_id}'] = cap_loss
             out.update({'caption_probs': probs, 'seq': seq})
@@ -286,8 +289,8 @@ class PDVC(nn.Module):
             reference = init_reference if l_id == 0 else inter_references[l_id - 1]
             layer_match = last_indices if l_id == num_pred - 1 else aux_indices[l_id]
             indices = layer_match if hasattr(layer_match, "plan") else layer_match[0]
-            hs_cap = torch.cat([hs[l_id], query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
-                                                                                      False) else hs[l_id]
+            hs_cap = torch.cat([hs_l[l_id], query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
+                                                                                        False) else hs_l[l_id]
             cap_loss, probs, seq = self.caption_prediction(self.caption_head[l_id], dt, hs_cap, reference, others,
                                                            indices)
             key = 'loss_caption' if l_id == num_pred - 1 else f'loss_caption_{l_id}'
