@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""Contract benchmark: videos/sec of the GVL (PDVC) eval forward -- or train-step ms -- on N MI355X GPUs.
+"""Contract benchmark: videos/sec of the GVL (PDVC) eval forward AND train-step ms on N MI355X GPUs, in one JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode eval|train] [--T 100] [--queries 300]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode both|eval|train] [--T 100] [--queries 300]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A *step* is one pass of the hot path over one batch of synthetic input: ``PDVC.forward(dt, criterion, None,
-'queries', eval_mode=True)`` (eval_utils.py:203) on B=16 videos per GPU of the ANet-TSP model
-(cfgs/anet_tsp_ssvg.yml with num_queries=300, T=100, random-init weights, synthetic features).
-Videos are independent, so ranks shard by video with no data-path collective ("weak" scaling: 16 videos per GPU).
-Rank 0 prints ONE JSON line; it carries the `roofline` object of the deformable-attention kernel (measured live with
-HIP events on the launch stream) and, at N=1, the `cpu_baseline` object (the oracle's CPU restatement of the same
-forward with the reference's CPU-fallback sampling semantics, timed on this host's cores on a bounded sample).
+'queries', eval_mode=True)`` (eval_utils.py:203) -- or, for the second half of BASELINE.json's metric, one training
+step (train.py:385-409: forward, Hungarian matching, losses, backward, clip, Adam) -- on B=16 videos per GPU of the
+ANet-TSP model (cfgs/anet_tsp_ssvg.yml with num_queries=300, T=100, random-init weights, synthetic features;
+SURVEY.md section 8d).  The timed region ROTATES through `--rotate` (default 8) different batches -- 0..10 events per
+video, different caption lengths and caption-tensor widths, as eval_utils.py:187-203 / train.py:385-398 feed them -- so
+that the captured hipGraphs are exercised the way a real loop exercises them (`graphs` in the line reports how many
+graphs exist and that none was captured inside the timed region).  `--fixed-layout` restores round 1's single
+3-events-per-video batch.
+Videos are independent, so ranks shard by video with no data-path collective in eval ("weak" scaling: 16 videos per
+GPU); the train step exchanges gradients over RCCL.
+Rank 0 prints ONE JSON line; it carries `value` (eval videos/s), `train_step_ms`, the `roofline` object of the
+deformable-attention forward kernel and `train_roofline` of the backward kernel (both measured live with HIP events
+on the launch stream), and, at N=1, the `cpu_baseline` object (the oracle's CPU restatement of the same forward with the
+reference's CPU-fallback sampling semantics, timed on this host's cores as BASELINE.md section 3 prescribes, on a
+bounded sample).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,34 +36,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_TBS = 8.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
-def synth_batch(B, T, feat, vocab, n_gt, device, seed=1):
-    """SURVEY.md section 8d synthetic `dt` (keys of pdvc.py:250-258 + targets for the criterion)."""
+def synth_batch(B, T, feat, vocab, n_gt, device, seed=1, cap_words=10):
+    """SURVEY.md section 8d synthetic `dt` (keys of pdvc.py:250-258 + targets for the criterion).
+    n_gt: events per video, an int (every video) or a list (per video, 0 allowed).  cap_words: words per caption, an
+    int or a (lo, hi) range drawn per caption; rows are <bos>=0, words, <eos>=0, <pad>=0 and the tensor is as wide as
+    the longest caption + 2, exactly what the reference's collate_fn builds (video_dataset.py:68-88)."""
     g = torch.Generator().manual_seed(seed)
+    ns = [int(n_gt)] * B if isinstance(n_gt, int) else [int(n) for n in n_gt]
     vt = torch.randn(B, T, feat, generator=g)
     vmask = torch.ones(B, T, dtype=torch.bool)
-    vlen = torch.tensor([[float(T), 120.0, float(n_gt)]] * B)
+    vlen = torch.tensor([[float(T), 120.0, float(n)] for n in ns])
     targets = []
-    for _ in range(B):
-        c = torch.rand(n_gt, generator=g) * 0.5 + 0.25
-        l_ = torch.rand(n_gt, generator=g) * 0.3 + 0.1
-        targets.append({"boxes": torch.stack([c, l_], -1).to(device), "labels": torch.zeros(n_gt, dtype=torch.long,
+    for n in ns:
+        c = torch.rand(n, generator=g) * 0.5 + 0.25
+        l_ = torch.rand(n, generator=g) * 0.3 + 0.1
+        targets.append({"boxes": torch.stack([c, l_], -1).to(device), "labels": torch.zeros(n, dtype=torch.long,
                                                                                            device=device)})
-    cap_len = 12
-    caps = torch.randint(1, vocab, (B * n_gt, cap_len), generator=g)
-    caps[:, 0] = 0
-    caps[:, -1] = 0
+    total = sum(ns)
+    if isinstance(cap_words, int):
+        words = [cap_words] * total
+    else:
+        words = torch.randint(cap_words[0], cap_words[1] + 1, (total,), generator=g).tolist()
+    width = max(words + [1]) + 2
+    caps = torch.zeros(total, width, dtype=torch.long)
+    cmask = torch.zeros(total, width)
+    for i, w in enumerate(words):
+        caps[i, 1:1 + w] = torch.randint(1, vocab, (w,), generator=g)
+        cmask[i, :w + 2] = 1
+    mx = max(ns + [1])
     return {"video_tensor": vt.to(device), "video_mask": vmask.to(device), "video_length": vlen.to(device),
-            "video_target": targets, "cap_raw": [["x"] * n_gt] * B, "cap_tensor": caps.to(device),
-            "cap_mask": torch.ones(B * n_gt, cap_len, device=device),
-            "gt_boxes_mask": torch.ones(B, n_gt, dtype=torch.bool, device=device)}
+            "video_target": targets, "cap_raw": [["x"] * n for n in ns], "cap_tensor": caps.to(device),
+            "cap_mask": cmask.to(device),
+            "gt_boxes_mask": torch.tensor([[k < n for k in range(mx)] for n in ns], dtype=torch.bool, device=device)}
+
+
+def rotating_batches(R, B, T, feat, vocab, device, seed):
+    """R batches whose layouts all differ: 0..10 events per video, caption lengths 3..(8..20) words."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    out = []
+    for r in range(R):
+        ns = torch.randint(0, 11, (B,), generator=g).tolist()
+        if r == 0:
+            ns[0], ns[1] = 0, 10                      # the extremes are always present
+        hi = 8 + (5 * r) % 13
+        out.append(synth_batch(B, T, feat, vocab, ns, device, seed=seed * 100 + r, cap_words=(3, hi)))
+    return out
 
 
 def msda_bytes(B, S, Q, M=8, L=4, P=4, C=512, value_bytes=4):
     """algorithmic bytes of one forward launch: value + loc(2) + weight + output; fp32, or
     bf16 value / output with fp32 locations and weights ("bf16 value/out halves the C terms")"""
     return B * (value_bytes * S * C + 4 * 3 * Q * M * L * P + value_bytes * Q * C)
+
+
+def msda_bwd_bytes(B, S, Q, M=8, L=4, P=4, C=512, value_bytes=4):
+    """backward launch: read value, loc, w, grad_out; write grad_value, grad_loc, grad_w (zero fill excluded)"""
+    return B * (2 * value_bytes * S * C + 4 * 6 * Q * M * L * P + value_bytes * Q * C)
 
 
 def kernel_times(entries):
@@ -126,54 +167,97 @@ def gemm_probe(model, dev, rows, iters=20):
                     "the launch stream)"}
 
 
-def cpu_baseline(model, opt, T, seconds_budget=25.0):
-    """The oracle's CPU port (reference CPU-fallback semantics: grid_sample border) on a bounded sample."""
+def cpu_baseline(model, opt, T, budget_s=30.0):
+    """the oracle's CPU port (reference CPU-fallback semantics: grid_sample border), on this
+    host's cores with torch.set_num_threads(os.cpu_count()) (count reported), 2 warm-up iterations and the median of
+    >= 5 timed ones, eval forward WITH and WITHOUT the captioner.  Bounded sample: the batch is sized from one probe
+    iteration so that the 7 iterations with the captioner fit `budget_s` (the full B = 16 forward takes ~11 s per
+    iteration on a 32-thread host); the batch actually used is stated in `sample`."""
     from oracle import torch_ref as R
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    # a few hundred tiny ops per token step: more than ~32 threads only adds fork/join overhead on a big host
-    ncores = min(32, os.cpu_count() or 1)
+    ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
-    nvid = 2
-    dt = synth_batch(nvid, T, opt.feature_dim, opt.vocab_size, 3, "cpu", seed=1)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        R.pdvc_eval_forward(sd, dt, n_enc=opt.enc_layers, n_dec=opt.dec_layers, pad_mode="border",
-                            max_caption_len=opt.max_caption_len)
-    el = time.perf_counter() - t0
-    done = nvid
-    # one more, larger batch if the budget allows (amortises per-call overheads the way eval_batch_size=16 does)
-    if el < seconds_budget / 5:
-        nvid2 = min(16, max(2, int(nvid * (seconds_budget * 0.6) / max(el, 1e-3))))
-        dt = synth_batch(nvid2, T, opt.feature_dim, opt.vocab_size, 3, "cpu", seed=1)
+
+    def run(nvid, captioning):
+        dt = synth_batch(nvid, T, opt.feature_dim, opt.vocab_size, 3, "cpu", seed=1)
         t0 = time.perf_counter()
         with torch.no_grad():
             R.pdvc_eval_forward(sd, dt, n_enc=opt.enc_layers, n_dec=opt.dec_layers, pad_mode="border",
-                                max_caption_len=opt.max_caption_len)
-        el = time.perf_counter() - t0
-        done = nvid2
-    return {"value": done / el, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} synthetic videos, one eval forward incl. {opt.max_caption_len + 1} greedy caption "
-                      f"steps, oracle/torch_ref.py (grid_sample border = reference CPU fallback), {el:.1f} s"}
+                                max_caption_len=opt.max_caption_len, captioning=captioning)
+        return time.perf_counter() - t0
+
+    def median_of(nvid, captioning, warm=2, timed=5):
+        for _ in range(warm):
+            run(nvid, captioning)
+        ts = [run(nvid, captioning) for _ in range(timed)]
+        return statistics.median(ts), ts
+
+    probe = run(1, True)                                       # one video, un-warmed: sizes the sample
+    per_iter = budget_s * 0.7 / 7.0
+    nvid = max(1, min(16, int(per_iter / max(probe, 1e-3))))
+    med, ts = median_of(nvid, True)
+    nvid_nc = 16
+    med_nc, ts_nc = median_of(nvid_nc, False)
+    return {"value": nvid / med, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nvid} synthetic videos per iteration (3 events each), eval forward incl. {opt.max_caption_len + 1} "
+                      f"greedy caption steps, oracle/torch_ref.py (grid_sample border = reference CPU fallback), "
+                      f"2 warm-ups + median of 5: {med:.2f} s (runs {', '.join(f'{x:.2f}' for x in ts)})",
+            "without_captioner": {"value": nvid_nc / med_nc, "unit": "videos/s",
+                                  "sample": f"{nvid_nc} videos per iteration, eval_disable_captioning, 2 warm-ups + "
+                                            f"median of 5: {med_nc:.2f} s"},
+            "host_cpu_count": ncores,
+            "train_step": None,
+            "train_step_note": "the CPU port covers the eval forward only (no CPU training path is shipped or timed)"}
+
+
+def timed_loop(step, batches, steps, warmup, world, dev):
+    """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize; -> elapsed seconds (max over
+    ranks), per-rank seconds"""
+    for i in range(warmup):
+        step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(x.item()) for x in every]
+        elapsed = max(per_rank)
+    return elapsed, per_rank
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="eval", choices=["eval", "train"])
+    ap.add_argument("--mode", default="both", choices=["both", "eval", "train"])
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--queries", type=int, default=300)
     ap.add_argument("--batch", type=int, default=16, help="videos per GPU")
+    ap.add_argument("--rotate", type=int, default=8, help="number of different batch layouts cycled through the timed region")
+    ap.add_argument("--fixed-layout", action="store_true", help="one batch, 3 events per video, 10-word captions (round 1's workload)")
     ap.add_argument("--cfg", default="anet_tsp_ssvg", help="gvl_amd.config.CONFIGS entry (BASELINE config 4: "
                     "--cfg yc2_tsn_dvc --T 512 --queries 100 --dtype bf16)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16 = torch.autocast(bfloat16): bf16 GEMMs + bf16-storage deformable attention, fp32 captioner")
     ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="do not replay the caption decoding loop from a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="eager steps (no hipGraph replay)")
+    ap.add_argument("--decode-chunk", type=int, default=5, help="tokens per captured decode segment (0: one graph)")
     ap.add_argument("--split-exchange", action="store_true",
-                    help="--mode train on one GPU in the data-parallel form (two graphs + eager exchange point); diagnostic")
+                    help="train on one GPU in the data-parallel form (two graphs + eager exchange point); diagnostic")
     ap.add_argument("--no-tuned-gemm", action="store_true",
                     help="keep hipBLASLt's default kernel choice instead of gvl_amd/tunableop_mi355x.csv")
     a = ap.parse_args()
@@ -196,16 +280,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # a checkout without the (git-ignored) built library: compile it once, on one rank, before anyone loads it
+    # a checkout without the (git-ignored) built library, or with stale sources: rank 0 decides and builds, every rank
+    # waits at the same unconditional barrier before anyone loads the library
     from gvl_amd import build as lib_build
-    if not os.path.exists(lib_build.OUT):
-        if local_rank == 0:
-            lib_build.build()
-        if world > 1:
-            dist.barrier()
+    if rank == 0 and lib_build.needs_build():
+        lib_build.build()
+    if world > 1:
+        dist.barrier()
     from gvl_amd.config import make_opt
     from gvl_amd.pdvc import build
     from gvl_amd.tuning import enable_tuned_gemms
+    from gvl_amd.parallel import GraphedEvalForward, GraphedTrainStep, TrainStep
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
     tuned = (not a.no_tuned_gemm) and enable_tuned_gemms()
     opt = make_opt(a.cfg, num_queries=a.queries, frame_embedding_num=a.T,
                    eval_disable_captioning=bool(a.no_captioner), device="cuda")
@@ -213,147 +299,191 @@ def main():
     model, criterion, _, _ = build(opt)
     model = model.to(dev)
     B = a.batch
-    dt = synth_batch(B, a.T, opt.feature_dim, opt.vocab_size, 3, dev, seed=1 + rank)
-
-    from gvl_amd import MultiScaleDeformableAttention as MSDA
-
-    if a.mode == "eval":
-        model.eval()
-        for head in model.caption_head:
-            head.graph_decode = not a.no_graph
-
-        if a.no_graph:
-            def step():
-                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
-                    return model(dt, criterion, None, "queries", eval_mode=True)
-        else:
-            # the whole forward (not only the decoding loop) replayed from one hipGraph; the kernel stamps of the
-            # roofline block come from instrumented eager forwards after the timed region (as in --mode train)
-            from gvl_amd.parallel import GraphedEvalForward
-            graphed_eval = GraphedEvalForward(model, criterion,
-                                              autocast_dtype=torch.bfloat16 if a.dtype == "bf16" else None)
-
-            def step():
-                return graphed_eval(dt)
+    if a.fixed_layout:
+        batches = [synth_batch(B, a.T, opt.feature_dim, opt.vocab_size, 3, dev, seed=1 + rank)]
     else:
-        from gvl_amd.parallel import GraphedTrainStep, TrainStep
-        model.train()
-        # one process: the whole step is ONE hipGraph; several processes: forward/backward graph, eager bucketed RCCL
-        # all-reduce of the flat gradient buffer, clip/Adam graph (no collective inside a graph) -- GraphedTrainStep
-        use_graph = not a.no_graph
-        ac = torch.bfloat16 if a.dtype == "bf16" else None
-        if use_graph:
-            trainer = GraphedTrainStep(model, criterion, opt, world_size=world,
-                                       split_exchange=True if a.split_exchange else None, autocast_dtype=ac)
-        else:
-            trainer = TrainStep(model, criterion, opt, world_size=world, autocast_dtype=ac)
-
-        def step():
-            return trainer(dt)
-
-    step()            # set-up, not a warm-up step: one-time work (hipGraph capture, library handles, lazily built constants)
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    MSDA.profile_enable(True)          # per-dispatch begin/end stamps of the library's kernels (hipExtLaunchKernel)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    MSDA.profile_enable(False)
-    ktimes = kernel_times(MSDA.profile_collect())
-    roofline_source = "per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region"
-    if not a.no_graph:
-        # the timed steps are hipGraph replays: the library launches nothing at replay time, so the kernel stamps come
-        # from two instrumented eager steps run right after the timed region (same process, same inputs)
-        MSDA.profile_enable(True)
-        for _ in range(2):
-            if a.mode == "train":
-                trainer._eager(dt)
-            else:
-                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
-                    model(dt, criterion, None, "queries", eval_mode=True)
-        torch.cuda.synchronize()
-        MSDA.profile_enable(False)
-        ktimes = kernel_times(MSDA.profile_collect())
-        roofline_source = "two instrumented eager steps right after the timed region (timed steps are hipGraph replays)"
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    ms_per_step = elapsed * 1e3 / a.steps
-    videos_per_s = world * B * a.steps / elapsed
-
-    # roofline of the deformable-attention forward kernel (decoder cross-attention launch shape = the larger one)
+        batches = rotating_batches(max(1, a.rotate), B, a.T, opt.feature_dim, opt.vocab_size, dev, seed=1 + rank)
+    ac = torch.bfloat16 if a.dtype == "bf16" else None
     lens = [a.T]
     for _ in range(opt.num_feature_levels - 1):
         lens.append((lens[-1] - 1) // 2 + 1)
     S = sum(lens)
-    roof = None
-    fwd = {k: v for k, v in ktimes.items() if k[0] in ("fwd_t1d_d64", "fwd_generic")}
-    dec_key = next((k for k in fwd if k[1] == a.queries and k[2] == B), None)
-    if dec_key is not None:
-        us, n = fwd[dec_key]
-        vb = 2 if a.dtype == "bf16" else 4
-        nbytes = msda_bytes(B, S, a.queries, value_bytes=vb)
-        achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    vb = 2 if a.dtype == "bf16" else 4
+    res = {}
+
+    def traffic_of(name):
+        pmc = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc) and (B, a.T, a.queries, a.dtype) == (16, 100, 300, "f32"):
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same launch shape (FETCH_SIZE and
             # WRITE_SIZE in separate passes, gfx950 2x FETCH correction); counters cannot be read from inside the run
-            traffic = json.load(open(pmc))["k_fwd_t1d_d64_fused_dec"]["hbm_bytes_corrected"]   # the variant the model launches
-            traffic_src = "profiles/r01_pmc_traffic.json"
+            rec = json.load(open(pmc)).get(name)
+            if rec:
+                return rec["hbm_bytes_corrected"], PMC_FILE
+        return None, None
+
+    def instrumented(fn, n=2):
+        """kernel stamps of `n` eager steps run right after a timed region whose steps were graph replays (the library
+        launches nothing at replay time)"""
+        MSDA.profile_enable(True)
+        for i in range(n):
+            fn(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        MSDA.profile_enable(False)
+        return kernel_times(MSDA.profile_collect())
+
+    # ---------------------------------------------------------------------------------------------- eval half
+    if a.mode in ("both", "eval"):
+        model.eval()
+        for head in model.caption_head:
+            head.graph_decode = False
+
+        def eager_eval(dt):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
+                return model(dt, criterion, None, "queries", eval_mode=True)
+        if a.no_graph:
+            graphed_eval, step = None, eager_eval
+        else:
+            graphed_eval = GraphedEvalForward(model, criterion, autocast_dtype=ac, decode_chunk=a.decode_chunk)
+            step = graphed_eval
+        for dt in batches:          # set-up, not warm-up: one-time work (hipGraph capture at the capacity every layout
+            step(dt)                # fits, library handles, lazily built constants)
+        caps0 = graphed_eval.captures if graphed_eval else 0
+        MSDA.profile_enable(a.no_graph)
+        elapsed, per_rank = timed_loop(step, batches, a.steps, a.warmup, world, dev)
+        MSDA.profile_enable(False)
+        ktimes = kernel_times(MSDA.profile_collect()) if a.no_graph else instrumented(eager_eval)
+        res["eval"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes,
+                       "graphs": None if graphed_eval is None else {
+                           "cached": len(graphed_eval.graphs), "captures_total": graphed_eval.captures,
+                           "captures_in_timed_region": graphed_eval.captures - caps0,
+                           "replays": graphed_eval.replays, "decode_segments_replayed": graphed_eval.segments_replayed,
+                           "decode_chunk": graphed_eval.decode_chunk,
+                           "padded_targets_slots": graphed_eval.capacity.slots}}
+        if graphed_eval is not None:
+            graphed_eval.graphs.clear()
+        del step, graphed_eval
+        torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------------------------------------- train half
+    if a.mode in ("both", "train"):
+        model.train()
+        # one process: the whole step is ONE hipGraph; several processes: forward/backward graph, eager bucketed RCCL
+        # all-reduce of the flat gradient buffer, clip/Adam graph (no collective inside a graph) -- GraphedTrainStep
+        if not a.no_graph:
+            trainer = GraphedTrainStep(model, criterion, opt, world_size=world,
+                                       split_exchange=True if a.split_exchange else None, autocast_dtype=ac)
+        else:
+            trainer = TrainStep(model, criterion, opt, world_size=world, autocast_dtype=ac)
+        for dt in batches:
+            trainer(dt)
+        caps0 = getattr(trainer, "captures", 0)
+        MSDA.profile_enable(a.no_graph)
+        elapsed, per_rank = timed_loop(trainer, batches, a.steps, a.warmup, world, dev)
+        MSDA.profile_enable(False)
+        if a.no_graph:
+            ktimes = kernel_times(MSDA.profile_collect())
+        else:
+            ktimes = instrumented(lambda dt: TrainStep.__call__(trainer, dt))
+        res["train"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes,
+                        "graphs": None if a.no_graph else {
+                            "cached": len(trainer.graphs), "captures_total": trainer.captures,
+                            "captures_in_timed_region": trainer.captures - caps0, "replays": trainer.replays,
+                            "padded_targets_slots": trainer.capacity.slots,
+                            "padded_caption_width": trainer.capacity.cap_len,
+                            "form": "two graphs + eager gradient exchange" if trainer.split else "one graph"}}
+
+    # ---------------------------------------------------------------------------------------------- the line
+    src_note = ("per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region" if a.no_graph
+                else "two instrumented eager steps right after the timed region (timed steps are hipGraph replays)")
+
+    def fwd_roofline(ktimes):
+        fwd = {k: v for k, v in ktimes.items() if k[0] in ("fwd_t1d_d64", "fwd_generic")}
+        dec_key = next((k for k in fwd if k[1] == a.queries and k[2] == B), None)
+        if dec_key is None:
+            return None
+        us, n = fwd[dec_key]
+        nbytes = msda_bytes(B, S, a.queries, value_bytes=vb)
+        achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
+        traffic, traffic_src = traffic_of("k_fwd_t1d_d64_fused_dec")
         roof = {"bound": "hbm", "kernel": f"k_{dec_key[0]} (decoder cross-attention launch, Lq={a.queries})",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK_TBS * 1e3), 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_us": round(us, 2), "launches_timed": n, "algorithmic_bytes": nbytes,
-                "source": roofline_source}
+                "kernel_us": round(us, 2), "launches_timed": n, "algorithmic_bytes": nbytes, "source": src_note}
         enc_key = next((k for k in fwd if k[1] == S and k[2] == B), None)
         if enc_key is not None:
             eus, en = fwd[enc_key]
             eb = msda_bytes(B, S, S, value_bytes=vb)
             roof["encoder_launch"] = {"kernel_us": round(eus, 2), "launches_timed": en, "algorithmic_bytes": eb,
                                       "frac": round(eb / (eus * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
-    other = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in ktimes.items() if k not in fwd}
-    if roof is not None and rank == 0 and a.T != 512 and a.dtype == "f32":
-        roof["cfg_L_launch"] = cfg_l_probe(dev, B)
+        return roof
 
-    line = {
-        "metric": "videos/sec (eval fwd)" if a.mode == "eval" else "train-step ms",
-        "value": round(videos_per_s, 3) if a.mode == "eval" else round(ms_per_step, 3),
-        "unit": "videos/s" if a.mode == "eval" else "ms",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": a.mode == "eval", "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if a.dtype == "f32" else "bf16 storage + bf16 GEMMs, f32 accumulate / locations / captioner",
-        "data": "synthetic",
-        "config": {"workload": f"cfgs/{a.cfg}.yml PDVC {'eval forward' if a.mode == 'eval' else 'train step'}"
-                               f" B={B}/GPU T={a.T} L=4 Q={a.queries}, "
-                               + ("captioner off (diagnostic)" if a.no_captioner else
-                                  f"LSTM-DSA greedy captioning of {opt.max_caption_len} tokens ({opt.max_caption_len} token steps; the "
-                                  f"reference's extra step after the last token is dead code -- never read -- and is "
-                                  f"not evaluated)")
-                               + ", set criterion + Hungarian matcher on 3 GT/video",
-                   "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
-                   "global_batch": world * B, "parallelism": f"dp{world} (videos sharded, no data-path collective)"
-                   if a.mode == "eval" else f"dp{world} (RCCL gradient all-reduce)"},
-        "roofline": roof,
-        "kernels_us": other,
-    }
-    if a.mode == "train":
-        line["videos_per_s"] = round(videos_per_s, 3)
-    if rank == 0 and a.mode == "eval" and not a.no_captioner and a.dtype == "f32":
+    def bwd_roofline(ktimes):
+        bwd = {k: v for k, v in ktimes.items() if k[0] in ("bwd_t1d_d64", "bwd_generic")}
+        part = {k: v for k, v in ktimes.items() if k[0] == "sum_partials"}
+        out = {}
+        for name, Lq in (("decoder", a.queries), ("encoder", S)):
+            key = next((k for k in bwd if k[1] == Lq and k[2] == B), None)
+            if key is None:
+                continue
+            us, n = bwd[key]
+            pk = part.get(("sum_partials", Lq, B))
+            extra = pk[0] * pk[1] / n if pk else 0.0
+            nbytes = msda_bwd_bytes(B, S, Lq, value_bytes=vb)
+            tot = us + extra
+            out[name] = {"kernel_us": round(us, 2), "partial_sum_us_per_launch": round(extra, 2), "launches_timed": n,
+                         "algorithmic_bytes": nbytes, "achieved": round(nbytes / (tot * 1e-6) / 1e9, 1),
+                         "frac": round(nbytes / (tot * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
+        if not out:
+            return None
+        d = out.get("decoder") or out["encoder"]
+        traffic, traffic_src = traffic_of("k_bwd_t1d_d64_fused_dec")
+        return {"bound": "hbm", "kernel": "k_bwd_t1d_d64 (+ k_sum_partials where it still runs), decoder launch",
+                "achieved": d["achieved"], "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": d["frac"],
+                "traffic": traffic, "traffic_source": traffic_src, "launches": out, "source": src_note}
+
+    workload = (f"cfgs/{a.cfg}.yml PDVC B={B}/GPU T={a.T} L=4 Q={a.queries}, "
+                + ("captioner off (diagnostic)" if a.no_captioner else
+                   f"LSTM-DSA greedy captioning of up to {opt.max_caption_len} tokens (the reference's extra LSTM step "
+                   f"after the last token is dead code -- never read -- and is not evaluated)")
+                + ", set criterion + Hungarian matcher; "
+                + ("one fixed batch, 3 events per video" if a.fixed_layout else
+                   f"{len(batches)} rotating batches with 0-10 events per video and 3-20-word captions"))
+    line = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.dtype == "f32" else "bf16 storage + bf16 GEMMs, f32 accumulate / locations / captioner",
+            "data": "synthetic",
+            "config": {"workload": workload,
+                       "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
+                       "global_batch": world * B,
+                       "parallelism": f"dp{world} (videos sharded; eval: no data-path collective, train: RCCL gradient "
+                                      f"all-reduce)"},
+            "rccl_ranks": world if (world > 1 and backend == "nccl") else (0 if world == 1 else f"{world} ({backend})")}
+    kernels_us = {}
+    if "eval" in res:
+        e = res["eval"]
+        ms = e["elapsed"] * 1e3 / a.steps
+        line.update({"metric": "videos/sec (eval fwd)", "value": round(world * B * a.steps / e["elapsed"], 3),
+                     "unit": "videos/s", "ms_per_step": round(ms, 3), "higher_is_better": True,
+                     "roofline": fwd_roofline(e["ktimes"]), "eval_graphs": e["graphs"],
+                     "eval_seconds_per_rank": [round(x, 4) for x in e["per_rank"]]})
+        kernels_us["eval"] = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in e["ktimes"].items()
+                              if not k[0].startswith("fwd_")}
+    if "train" in res:
+        t_ = res["train"]
+        ms = t_["elapsed"] * 1e3 / a.steps
+        line.update({"train_step_ms": round(ms, 3), "train_videos_per_s": round(world * B * a.steps / t_["elapsed"], 3),
+                     "train_roofline": bwd_roofline(t_["ktimes"]), "train_graphs": t_["graphs"],
+                     "train_seconds_per_rank": [round(x, 4) for x in t_["per_rank"]]})
+        kernels_us["train"] = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in t_["ktimes"].items()}
+        if "eval" not in res:
+            line.update({"metric": "train-step ms", "value": round(ms, 3), "unit": "ms", "ms_per_step": round(ms, 3),
+                         "higher_is_better": False, "roofline": line["train_roofline"]})
+    line["kernels_us"] = kernels_us
+    if line.get("roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and "eval" in res:
+        line["roofline"]["cfg_L_launch"] = cfg_l_probe(dev, B)
+    if rank == 0 and "eval" in res and not a.no_captioner and a.dtype == "f32":
         with torch.no_grad():
             line["dominant_library_gemm"] = gemm_probe(model, dev, B * a.queries)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "eval":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and "eval" in res:
         line["cpu_baseline"] = cpu_baseline(model, opt, a.T)
     if rank == 0:
         print(json.dumps(line), flush=True)

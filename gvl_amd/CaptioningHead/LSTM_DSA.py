@@ -444,23 +444,23 @@ class Captioner(nn.Module):
         it = torch.zeros(n, dtype=torch.long, device=hs.device)                       # <bos>
         T = self.max_caption_len
         if sample_max:
-            # greedy: argmax, log-prob and the per-step bookkeeping (unfinished / alive / seq / seq_lp) are one kernel
-            unfinished = torch.empty(n, dtype=torch.uint8, device=hs.device)
-            seq = torch.empty(n, T, dtype=torch.long, device=hs.device)
-            seq_lp = torch.empty(n, T, dtype=torch.float32, device=hs.device)
+            # greedy: argmax, log-prob and the per-step bookkeeping (unfinished / alive / seq / seq_lp) are one kernel.
+            # seq starts as zeros: a loop that is cut short (decode_stop / decode_continue below) leaves exactly what
+            # the full loop would have written after every row has ended (seq = token * unfinished, :183-188)
+            st = {"hs": hs, "ref_in": ref_in, "tshapes": tshapes, "lsi": lsi, "const": const, "emb_gates": emb_gates,
+                  "h": h, "c": c, "it": it, "logits": None,
+                  "unfinished": torch.empty(n, dtype=torch.uint8, device=hs.device),
+                  "seq": torch.zeros(n, T, dtype=torch.long, device=hs.device),
+                  "seq_lp": torch.zeros(n, T, dtype=torch.float32, device=hs.device)}
             # (running the vocabulary GEMM + argmax of token t on a second stream beside the token-independent half of
             #  step t+1 was tried -- fork / join inside the captured graph -- and measured no gain: 742-757 vs 750
             #  videos/s; the GEMMs already occupy every CU)
-            for t in range(T + 1):
-                if t > 0:
-                    it = MSDA.greedy_step(logits, t - 1, unfinished, seq, seq_lp)
-                if t < T:
-                    # (the reference also evaluates the LSTM step + vocabulary logits of the LAST token,
-                    #  LSTM_DSA.py:189-190, and then leaves the loop without reading them)
-                    out, (h, c) = self.core.step((emb_gates, it), (h, c), hs, ref_in, tshapes, lsi, const)
-                    logits = self.logit(self.dropout(getattr(out, "_gvl_lowp", out)))
+            stop = getattr(self, "decode_stop", None)             # iterations [0, stop) now, the rest by decode_continue
+            stop = T + 1 if stop is None else max(1, min(int(stop), T + 1))
+            self._greedy_iterations(st, 0, stop)
+            self._decode_state = st if stop < T + 1 else None
             # a row is unfinished at step t exactly while its tokens are non-zero (seq = token * unfinished, :183-188)
-            return seq, seq_lp, (seq != 0).any(0)
+            return st["seq"], st["seq_lp"], (st["seq"] != 0).any(0)
         unfinished = torch.ones(n, dtype=torch.bool, device=hs.device)
         seq, seq_lp, alive = [], [], []
         for t in range(T + 1):
@@ -479,6 +479,28 @@ class Captioner(nn.Module):
                 seq.append(it * unfinished.type_as(it))
                 seq_lp.append(lp)
         return torch.stack(seq, 1), torch.stack(seq_lp, 1), torch.stack(alive)
+
+    def _greedy_iterations(self, st, t0, t1):
+        """iterations [t0, t1) of the greedy loop (LSTM_DSA.py:162-190) on the state dict of _decode_device: iteration t
+        first books token t - 1 from the logits of the previous iteration, then (t < max_caption_len) runs the LSTM
+        step + vocabulary logits for token t.  (The reference also evaluates that step after the LAST token,
+        :189-190, and then leaves the loop without reading it.)"""
+        T = self.max_caption_len
+        for t in range(t0, t1):
+            if t > 0:
+                st["it"] = MSDA.greedy_step(st["logits"], t - 1, st["unfinished"], st["seq"], st["seq_lp"])
+            if t < T:
+                out, (st["h"], st["c"]) = self.core.step((st["emb_gates"], st["it"]), (st["h"], st["c"]), st["hs"],
+                                                         st["ref_in"], st["tshapes"], st["lsi"], st["const"])
+                st["logits"] = self.logit(self.dropout(getattr(out, "_gvl_lowp", out)))
+
+    def decode_continue(self, t0, t1):
+        """continue a greedy loop that `decode_stop` cut at iteration t0 (gvl_amd.parallel.GraphedEvalForward captures
+        the loop in segments and stops replaying them once every caption has ended) -> alive flags of the tokens this
+        segment booked, i.e. tokens [t0 - 1, t1 - 1)"""
+        st = self._decode_state
+        self._greedy_iterations(st, t0, t1)
+        return (st["seq"][:, t0 - 1:t1 - 1] != 0).any(0)
 
     def _decode_graphed(self, hs, reference, memory, mask, valid_ratios, tshapes, lsi):
         """Greedy decoding replayed from a hipGraph: the 31-step loop is ~800 kernel launches whose host-side issue

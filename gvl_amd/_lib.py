@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 4          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 5          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -44,8 +44,9 @@ SIGNATURES = {
     "gvl_col_sum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "gvl_pos_embed_sine_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P, _P]),
     "gvl_match_cost_f32": (_I, [_P] * 4 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),
-    "gvl_set_criterion_forward_f32": (_I, [_P] * 12 + [_I] * 7 + [ctypes.c_float] * 4 + [_I, _P, _P]),
-    "gvl_set_criterion_backward_f32": (_I, [_P] * 12 + [_I] * 7 + [ctypes.c_float] * 4 + [_I, _P, _P, _P, _P, _P]),
+    "gvl_match_cost_padded_f32": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),
+    "gvl_set_criterion_forward_f32": (_I, [_P] * 12 + [_I] * 7 + [ctypes.c_float] * 4 + [_I, _P, _P, _P, _P]),
+    "gvl_set_criterion_backward_f32": (_I, [_P] * 12 + [_I] * 7 + [ctypes.c_float] * 4 + [_I, _P, _P, _P, _P, _P, _P, _P]),
     "gvl_row_argmax_lse_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "gvl_cap_attend_bf16": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_lstm_cell_bf16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P]),

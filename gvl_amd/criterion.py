@@ -64,27 +64,34 @@ class SetCriterionFunction(torch.autograd.Function):
     The PyTorch formulation below (SetCriterion.loss_*) is ~190 launch-bound kernels per layer and direction."""
 
     @staticmethod
-    def _call(fn, ctx_t, cfg, *outs):
-        logits, counts, boxes, mq, mt, vid, tbase, ent_start, labels, tboxes, gt_counts, ccr = ctx_t
+    def _call(fn, ctx_t, cfg, padded, *outs):
+        logits, counts, boxes, mq, mt, vid, tbase, ent_start, labels, tboxes, gt_counts, ccr = ctx_t[:12]
         nl, B, Q, NC = logits.shape
+        pair_count, nb_dev = (ctx_t[12].data_ptr(), ctx_t[13].data_ptr()) if padded else (None, None)
         with torch.cuda.device(logits.device):
             rc = fn(logits.data_ptr(), counts.data_ptr(), boxes.data_ptr(), mq.data_ptr(), mt.data_ptr(),
                     vid.data_ptr(), tbase.data_ptr(), ent_start.data_ptr(), labels.data_ptr(), tboxes.data_ptr(),
                     gt_counts.data_ptr(), ccr.data_ptr(), nl, B, Q, NC, counts.shape[-1], mq.shape[-1],
-                    labels.shape[0], *cfg, *[o.data_ptr() for o in outs], torch.cuda.current_stream().cuda_stream)
+                    labels.shape[0], *cfg, pair_count, nb_dev, *[o.data_ptr() for o in outs],
+                    torch.cuda.current_stream().cuda_stream)
         return rc
 
     @staticmethod
     def forward(ctx, logits, counts, boxes, mq, mt, vid, tbase, ent_start, labels, tboxes, gt_counts, ccr, num_boxes,
-                alpha, gamma, beta, gau_mask):
+                alpha, gamma, beta, gau_mask, pair_count=None, num_boxes_dev=None):
+        """pair_count (B) / num_boxes_dev (1): the padded, layout-independent form (gvl_amd.targets.PaddedTargets) --
+        match slots beyond a video's count are empty and the normaliser is read from device memory."""
         tensors = (logits.contiguous(), counts.contiguous(), boxes.contiguous(), mq.contiguous(), mt.contiguous(), vid,
                    tbase, ent_start, labels.contiguous(), tboxes.float().contiguous(), gt_counts, ccr)
-        cfg = (float(num_boxes), float(alpha), float(gamma), float(beta), int(bool(gau_mask)))
+        padded = pair_count is not None
+        if padded:
+            tensors = tensors + (pair_count.contiguous(), num_boxes_dev)
+        cfg = (1.0 if padded else float(num_boxes), float(alpha), float(gamma), float(beta), int(bool(gau_mask)))
         losses = torch.empty((logits.shape[0], len(LOSS_KEYS)), dtype=torch.float32, device=logits.device)
-        _lib.check(SetCriterionFunction._call(_lib.lib().gvl_set_criterion_forward_f32, tensors, cfg, losses),
+        _lib.check(SetCriterionFunction._call(_lib.lib().gvl_set_criterion_forward_f32, tensors, cfg, padded, losses),
                    "set_criterion_forward")
         ctx.save_for_backward(*tensors)
-        ctx.cfg = cfg
+        ctx.cfg, ctx.padded = cfg, padded
         return losses
 
     @staticmethod
@@ -92,10 +99,10 @@ class SetCriterionFunction(torch.autograd.Function):
     def backward(ctx, grad_losses):
         tensors = ctx.saved_tensors
         g_logits, g_counts, g_boxes = (torch.empty_like(t_) for t_ in tensors[:3])
-        _lib.check(SetCriterionFunction._call(_lib.lib().gvl_set_criterion_backward_f32, tensors, ctx.cfg,
+        _lib.check(SetCriterionFunction._call(_lib.lib().gvl_set_criterion_backward_f32, tensors, ctx.cfg, ctx.padded,
                                               grad_losses.contiguous(), g_logits, g_counts, g_boxes),
                    "set_criterion_backward")
-        return (g_logits, g_counts, g_boxes) + (None,) * 14
+        return (g_logits, g_counts, g_boxes) + (None,) * 16
 
 
 class SetCriterion(nn.Module):
@@ -212,10 +219,12 @@ class SetCriterion(nn.Module):
         ccr = self._const_cache.get(wkey)
         if ccr is None:
             ccr = self._const_cache[wkey] = self.counter_class_rate[:max_length + 1].to(dev)
+        padded = getattr(plan, "padded", False)
         table = SetCriterionFunction.apply(
             logits, counts, boxes, mq, mt, plan.vid_of_entry, plan.tgt_base, plan.ent_start, self._tgt_cat[0],
             self._tgt_cat[1], self._gt_counts, ccr, num_boxes, self.focal_alpha, self.focal_gamma,
-            getattr(self.opt, "lloss_beta", 1), getattr(self.opt, "lloss_gau_mask", 1))
+            getattr(self.opt, "lloss_beta", 1), getattr(self.opt, "lloss_gau_mask", 1),
+            plan.pair_count if padded else None, num_boxes if padded else None)
         flat = table.flatten().unbind(0)
         losses = {}
         for l in range(nl):
@@ -229,8 +238,37 @@ class SetCriterion(nn.Module):
         assert loss in table, f'do you really want to compute {loss} loss?'
         return table[loss](outputs, targets, indices, num_boxes, **kwargs)
 
+    def padded_eligible(self, outputs, pt):
+        """can this step run in the layout-independent form (PaddedTargets in, everything on the device)?"""
+        lg = outputs['pred_logits']
+        layers = [outputs] + list(outputs.get('aux_outputs', []))
+        return (self.fused and self.device_matching and lg.is_cuda and lg.dtype == torch.float32
+                and set(self.losses) == {'labels', 'boxes', 'cardinality'} and lg.shape[0] * lg.shape[1] <= 24576
+                and hasattr(self.matcher, "match_layers_padded")
+                and self.matcher.padded_eligible(layers, lg.shape[1], pt.slots))
+
+    def _forward_padded(self, outputs, pt):
+        """criterion.py:163-207 on ``PaddedTargets``: padded cost blocks -> on-device Hungarian -> fused losses; the
+        normaliser num_boxes (criterion.py:178-181) is the device scalar pt.num_boxes, which whoever loaded the batch
+        has already averaged over the ranks.  Nothing here depends on the number of events per video."""
+        main = {k: v for k, v in outputs.items() if k not in ('aux_outputs', 'enc_outputs')}
+        layers = [main] + list(outputs.get('aux_outputs', []))
+        self._tgt_cat = (pt.labels.view(-1), pt.boxes.view(-1, 2))
+        self._gt_counts = pt.counts
+        batched = self.matcher.match_layers_padded(layers, pt)
+        outputs['matched_indices'] = batched[0]
+        losses = self._fused_losses(layers, batched, pt.num_boxes)
+        if 'aux_outputs' in outputs:
+            return losses, batched[0], list(batched[1:])
+        return losses, batched[0]
+
     def forward(self, outputs, targets):
-        """criterion.py:163-207 -> (losses, last_indices[, aux_indices])"""
+        """criterion.py:163-207 -> (losses, last_indices[, aux_indices]).  targets: the reference's list of per-video
+        dicts, or a gvl_amd.targets.PaddedTargets (fixed-shape form used by the captured steps)."""
+        if hasattr(targets, "host_counts"):
+            if self.padded_eligible(outputs, targets):
+                return self._forward_padded(outputs, targets)
+            targets = targets.as_list()
         main = {k: v for k, v in outputs.items() if k not in ('aux_outputs', 'enc_outputs')}
         aux_list = outputs.get('aux_outputs', [])
         dev = outputs['pred_logits'].device
@@ -245,7 +283,9 @@ class SetCriterion(nn.Module):
         batched = None
         if hasattr(self.matcher, "match_layers_device") and dev.type == "cuda" and self.device_matching:
             # all layers x videos solved on the device in one launch: no device->host copy at all
+            # (None when a problem exceeds the on-chip solver, e.g. Q = 300 with > 64 events in one video)
             batched = self.matcher.match_layers_device([main] + list(aux_list), targets)
+        if batched is not None:
             last_indices = batched[0]
         elif hasattr(self.matcher, "match_layers"):
             # same matchings as one matcher call per layer, but one device->host copy for all layers

@@ -80,6 +80,46 @@ __global__ void __launch_bounds__(256) k_match_cost(const float *__restrict__ lo
   if (!good) atomicAnd(ok, 0);
 }
 
+// Padded (layout-independent) form: every video owns Gp target slots, of which the first gt_counts[b] are real;
+// cost (nl, B, Q, Gp) holds only the video's own block (the concatenated form above also prices every query against
+// the other videos' targets, which the solver never reads).  Slots beyond the count are written as 0 and are never
+// read (the solver's problem descriptor carries n = gt_counts[b]).  Same arithmetic, same roundings.
+__global__ void __launch_bounds__(256) k_match_cost_padded(const float *__restrict__ logits, const float *__restrict__ boxes,
+                                                           const int64_t *__restrict__ tgt_labels,
+                                                           const float *__restrict__ tgt_boxes,
+                                                           const int64_t *__restrict__ gt_counts, CritDims d,
+                                                           float w_class, float w_bbox, float w_giou, float alpha,
+                                                           float gamma, float *__restrict__ C, int *__restrict__ ok) {
+#pragma clang fp contract(off)
+  const int64_t total = (int64_t)d.nl * d.B * d.Q * d.G;             // d.G = Gp slots per video
+  int good = 1;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % d.G);
+    const int64_t row = idx / d.G;                                   // (l, b, q)
+    const int b = (int)((row / d.Q) % d.B);
+    if (g >= (int)gt_counts[b]) { C[idx] = 0.f; continue; }
+    const int64_t t = (int64_t)b * d.G + g;
+    const float p = sigmoid_(logits[row * d.NC + (int)tgt_labels[t]]);
+    const float neg = ((1.f - alpha) * powg(p, gamma)) * (-logf((1.f - p) + 1e-8f));
+    const float pos = (alpha * powg(1.f - p, gamma)) * (-logf(p + 1e-8f));
+    const float cost_class = pos - neg;
+    const float c = boxes[row * 2], l = boxes[row * 2 + 1];
+    const float tc = tgt_boxes[t * 2], tl = tgt_boxes[t * 2 + 1];
+    const float sx0 = c - 0.5f * l, sx1 = c + 0.5f * l, tx0 = tc - 0.5f * tl, tx1 = tc + 0.5f * tl;
+    if (!(sx1 >= sx0) || !(tx1 >= tx0)) good = 0;                    // box_ops.py:39-40
+    const float inter = fmaxf(fminf(sx1, tx1) - fmaxf(sx0, tx0), 0.f);
+    const float uni = ((sx1 - sx0) + (tx1 - tx0)) - inter;
+    const float iou = inter / (uni + kEps);
+    const float area = fmaxf(fmaxf(sx1, tx1) - fminf(sx0, tx0), 0.f);
+    const float giou = iou - (area - uni) / (area + kEps);
+    float cost = w_class * cost_class;
+    if (w_bbox != 0.f) cost = w_bbox * (fabsf(c - tc) + fabsf(l - tl)) + cost;
+    cost = cost + w_giou * (-giou);
+    C[idx] = cost;
+  }
+  if (!good) atomicAnd(ok, 0);
+}
+
 // ------------------------------------------------------------------------------------------------------
 struct CritArgs {
   const float *logits;        // (nl, B, Q, NC)
@@ -96,7 +136,19 @@ struct CritArgs {
   const float *ccr;           // (Wd) class rate of the counter
   float num_boxes, alpha, gamma, beta;
   int gau_mask;
+  // layout-independent (padded) form: pair slots [ent_start[v], ent_start[v] + pair_count[v]) of video v are real, the
+  // rest of the video's slots carry no match; the normaliser lives on the device.  Both null in the compact form.
+  const int64_t *pair_count;  // (B) or null
+  const float *num_boxes_dev; // (1) or null
 };
+
+__device__ inline float num_boxes_of(const CritArgs &a) { return a.num_boxes_dev ? a.num_boxes_dev[0] : a.num_boxes; }
+__device__ inline int pairs_end(const CritArgs &a, int v) {
+  return a.pair_count ? (int)a.ent_start[v] + (int)a.pair_count[v] : (int)a.ent_start[v + 1];
+}
+__device__ inline bool pair_valid(const CritArgs &a, int e) {
+  return !a.pair_count || e < pairs_end(a, (int)a.vid[e]);
+}
 
 __device__ inline float focal_terms(float x, float t, float alpha, float gamma, float &grad) {
   const float p = sigmoid_(x);
@@ -140,6 +192,7 @@ __device__ inline void build_class_map(int *cls, const CritArgs &a, const CritDi
   for (int i = threadIdx.x; i < d.B * d.Q; i += blockDim.x) cls[i] = d.NC;
   __syncthreads();
   for (int e = threadIdx.x; e < d.T1; e += blockDim.x) {
+    if (!pair_valid(a, e)) continue;
     const int v = (int)a.vid[e];
     cls[v * d.Q + (int)a.mq[(int64_t)l * d.T1 + e]] = (int)a.tgt_labels[a.tbase[e] + a.mt[(int64_t)l * d.T1 + e]];
   }
@@ -170,7 +223,8 @@ __global__ void __launch_bounds__(1024) k_criterion_fwd(CritArgs a, CritDims d, 
     float g;
     s += focal_terms(a.logits[(int64_t)l * nlog + i], t, a.alpha, a.gamma, g);
   }
-  const float loss_ce = block_sum(s, red) / a.num_boxes;
+  const float num_boxes = num_boxes_of(a);
+  const float loss_ce = block_sum(s, red) / num_boxes;
   // ---- counter (criterion.py:77,209-229) --------------------------------------------------------------------------
   s = 0.f;
   for (int i = threadIdx.x; i < d.B * d.Wd; i += blockDim.x) {
@@ -183,6 +237,7 @@ __global__ void __launch_bounds__(1024) k_criterion_fwd(CritArgs a, CritDims d, 
   // ---- matched boxes: L1 and GIoU (criterion.py:103-121) ----------------------------------------------------------
   float s1 = 0.f, s2 = 0.f;
   for (int e = threadIdx.x; e < d.T1; e += blockDim.x) {
+    if (!pair_valid(a, e)) continue;
     const PairBox p = load_pair(a, d, l, e);
     s1 += fabsf(p.c - p.tc) + fabsf(p.l - p.tl);
     const float sx0 = p.c - 0.5f * p.l, sx1 = p.c + 0.5f * p.l, tx0 = p.tc - 0.5f * p.tl, tx1 = p.tc + 0.5f * p.tl;
@@ -191,12 +246,12 @@ __global__ void __launch_bounds__(1024) k_criterion_fwd(CritArgs a, CritDims d, 
     const float area = fmaxf(fmaxf(sx1, tx1) - fminf(sx0, tx0), 0.f);
     s2 += 1.f - (inter / (uni + kEps) - (area - uni) / (area + kEps));
   }
-  const float loss_bbox = block_sum(s1, red) / a.num_boxes;
-  const float loss_giou = block_sum(s2, red) / a.num_boxes;
+  const float loss_bbox = block_sum(s1, red) / num_boxes;
+  const float loss_giou = block_sum(s2, red) / num_boxes;
   // ---- self-IoU of the matched predictions of one video (criterion.py:123-130) ------------------------------------
   s = 0.f;
   for (int v = threadIdx.x; v < d.B; v += blockDim.x) {
-    const int e0 = (int)a.ent_start[v], e1 = (int)a.ent_start[v + 1];
+    const int e0 = (int)a.ent_start[v], e1 = pairs_end(a, v);
     float acc = 0.f;
     for (int i = e0; i < e1; ++i) {
       const PairBox pi = load_pair(a, d, l, i);
@@ -237,7 +292,8 @@ __global__ void __launch_bounds__(1024) k_criterion_bwd(CritArgs a, CritDims d, 
   const float *w = gl + l * kLosses;                                  // upstream gradient of the six loss terms
   build_class_map(cls, a, d, l);
   const int nlog = d.B * d.Q * d.NC;
-  const float k_ce = w[0] / a.num_boxes;
+  const float num_boxes = num_boxes_of(a);
+  const float k_ce = w[0] / num_boxes;
   for (int i = threadIdx.x; i < nlog; i += blockDim.x) {
     const float t = (cls[i / d.NC] == i % d.NC) ? 1.f : 0.f;
     float g;
@@ -255,8 +311,9 @@ __global__ void __launch_bounds__(1024) k_criterion_bwd(CritArgs a, CritDims d, 
   float *gb = g_boxes + (int64_t)l * d.B * d.Q * 2;
   for (int i = threadIdx.x; i < d.B * d.Q * 2; i += blockDim.x) gb[i] = 0.f;
   __syncthreads();
-  const float k_l1 = w[2] / a.num_boxes, k_giou = -w[3] / a.num_boxes;
+  const float k_l1 = w[2] / num_boxes, k_giou = -w[3] / num_boxes;
   for (int e = threadIdx.x; e < d.T1; e += blockDim.x) {
+    if (!pair_valid(a, e)) continue;
     const PairBox p = load_pair(a, d, l, e);
     const float sgc = p.c > p.tc ? 1.f : (p.c < p.tc ? -1.f : 0.f), sgl = p.l > p.tl ? 1.f : (p.l < p.tl ? -1.f : 0.f);
     const float sx0 = p.c - 0.5f * p.l, sx1 = p.c + 0.5f * p.l, tx0 = p.tc - 0.5f * p.tl, tx1 = p.tc + 0.5f * p.tl;
@@ -278,7 +335,7 @@ __global__ void __launch_bounds__(1024) k_criterion_bwd(CritArgs a, CritDims d, 
     g1 *= k_giou; g0 *= k_giou;
     // self-IoU with every other matched prediction of the same video
     const int v = (int)a.vid[e];
-    const int e0 = (int)a.ent_start[v], e1 = (int)a.ent_start[v + 1];
+    const int e0 = (int)a.ent_start[v], e1 = pairs_end(a, v);
     const float cnt = (float)(e1 - e0);
     const float k_self = w[4] / (0.5f * cnt * (cnt - 1.f));
     for (int j = e0; j < e1; ++j) {
@@ -323,12 +380,31 @@ int gvl_match_cost_f32(const float *pred_logits, const float *pred_boxes, const 
                      alpha, gamma, cost, ok);
 }
 
+int gvl_match_cost_padded_f32(const float *pred_logits, const float *pred_boxes, const int64_t *tgt_labels,
+                              const float *tgt_boxes, const int64_t *gt_counts, int n_layers, int B, int Q,
+                              int n_classes, int slots, float w_class, float w_bbox, float w_giou, float alpha,
+                              float gamma, float *cost, int *ok, void *stream) {
+  const CritDims d = {n_layers, B, Q, n_classes, 1, 0, slots};
+  if (n_layers <= 0 || B < 0 || Q < 0 || n_classes <= 0 || slots < 0)
+    return fail(GVL_EINVAL, "gvl_match_cost_padded_f32: bad sizes");
+  const int64_t total = (int64_t)n_layers * B * Q * slots;
+  if (total == 0) return 0;
+  if (!pred_logits || !pred_boxes || !tgt_labels || !tgt_boxes || !gt_counts || !cost || !ok)
+    return fail(GVL_EINVAL, "gvl_match_cost_padded_f32: null pointer");
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  return gvl::launch(GVL_PROF_MATCH_COST, Q, B, "k_match_cost_padded", k_match_cost_padded, dim3((unsigned)blocks),
+                     dim3(256), 0, (hipStream_t)stream, pred_logits, pred_boxes, tgt_labels, tgt_boxes, gt_counts, d,
+                     w_class, w_bbox, w_giou, alpha, gamma, cost, ok);
+}
+
 static CritArgs make_args(const float *logits, const float *counts, const float *boxes, const int64_t *mq,
                           const int64_t *mt, const int64_t *vid, const int64_t *tbase, const int64_t *ent_start,
                           const int64_t *tgt_labels, const float *tgt_boxes, const int64_t *gt_counts,
-                          const float *ccr, float num_boxes, float alpha, float gamma, float beta, int gau_mask) {
+                          const float *ccr, float num_boxes, float alpha, float gamma, float beta, int gau_mask,
+                          const int64_t *pair_count, const float *num_boxes_dev) {
   return {logits, counts, boxes, mq, mt, vid, tbase, ent_start, tgt_labels, tgt_boxes, gt_counts, ccr,
-          num_boxes, alpha, gamma, beta, gau_mask};
+          num_boxes, alpha, gamma, beta, gau_mask, pair_count, num_boxes_dev};
 }
 
 int gvl_set_criterion_forward_f32(const float *pred_logits, const float *pred_count, const float *pred_boxes,
@@ -337,7 +413,8 @@ int gvl_set_criterion_forward_f32(const float *pred_logits, const float *pred_co
                                   const int64_t *tgt_labels, const float *tgt_boxes, const int64_t *gt_counts,
                                   const float *counter_class_rate, int n_layers, int B, int Q, int n_classes,
                                   int count_bins, int n_pairs, int G, float num_boxes, float focal_alpha,
-                                  float focal_gamma, float lloss_beta, int lloss_gau_mask, float *losses,
+                                  float focal_gamma, float lloss_beta, int lloss_gau_mask,
+                                  const int64_t *video_pair_count, const float *num_boxes_dev, float *losses,
                                   void *stream) {
   const CritDims d = {n_layers, B, Q, n_classes, count_bins, n_pairs, G};
   if (int rc = check_args("gvl_set_criterion_forward_f32", d)) return rc;
@@ -347,7 +424,7 @@ int gvl_set_criterion_forward_f32(const float *pred_logits, const float *pred_co
     return fail(GVL_EINVAL, "gvl_set_criterion_forward_f32: null pointer");
   const CritArgs a = make_args(pred_logits, pred_count, pred_boxes, match_q, match_t, pair_video, pair_target_base,
                                video_pair_start, tgt_labels, tgt_boxes, gt_counts, counter_class_rate, num_boxes,
-                               focal_alpha, focal_gamma, lloss_beta, lloss_gau_mask);
+                               focal_alpha, focal_gamma, lloss_beta, lloss_gau_mask, video_pair_count, num_boxes_dev);
   const size_t lds = (size_t)B * Q * sizeof(int);
   if (int rc = gvl::ensure_lds(k_criterion_fwd, lds)) return rc;
   return gvl::launch(GVL_PROF_CRITERION, Q, B, "k_criterion_fwd", k_criterion_fwd, dim3(n_layers), dim3(1024), lds,
@@ -360,8 +437,10 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
                                    const int64_t *tgt_labels, const float *tgt_boxes, const int64_t *gt_counts,
                                    const float *counter_class_rate, int n_layers, int B, int Q, int n_classes,
                                    int count_bins, int n_pairs, int G, float num_boxes, float focal_alpha,
-                                   float focal_gamma, float lloss_beta, int lloss_gau_mask, const float *grad_losses,
-                                   float *grad_logits, float *grad_count, float *grad_boxes, void *stream) {
+                                   float focal_gamma, float lloss_beta, int lloss_gau_mask,
+                                   const int64_t *video_pair_count, const float *num_boxes_dev,
+                                   const float *grad_losses, float *grad_logits, float *grad_count, float *grad_boxes,
+                                   void *stream) {
   const CritDims d = {n_layers, B, Q, n_classes, count_bins, n_pairs, G};
   if (int rc = check_args("gvl_set_criterion_backward_f32", d)) return rc;
   if (!pred_logits || !pred_count || !pred_boxes || !gt_counts || !counter_class_rate || !grad_losses ||
@@ -370,7 +449,7 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
     return fail(GVL_EINVAL, "gvl_set_criterion_backward_f32: null pointer");
   const CritArgs a = make_args(pred_logits, pred_count, pred_boxes, match_q, match_t, pair_video, pair_target_base,
                                video_pair_start, tgt_labels, tgt_boxes, gt_counts, counter_class_rate, num_boxes,
-                               focal_alpha, focal_gamma, lloss_beta, lloss_gau_mask);
+                               focal_alpha, focal_gamma, lloss_beta, lloss_gau_mask, video_pair_count, num_boxes_dev);
   const size_t lds = (size_t)B * Q * sizeof(int);
   if (int rc = gvl::ensure_lds(k_criterion_bwd, lds)) return rc;
   return gvl::launch(GVL_PROF_CRITERION, Q, B, "k_criterion_bwd", k_criterion_bwd, dim3(n_layers), dim3(1024), lds,

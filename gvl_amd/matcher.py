@@ -70,14 +70,18 @@ def hungarian_batch(C, sizes, m2o_rate=4, num_threads=0):
     return indices, rl
 
 
-def lsap_batch_device(C, problems, out_total, max_rows, max_cols):
+def lsap_batch_device(C, problems, out_total, max_rows, max_cols, fill=None):
     """Solve assignment problems on the device (include/gvl_msda.h: gvl_lsap_batch_device_f32).
     C: float32 CUDA tensor (any shape; problems index its storage); problems: int64 CUDA tensor (n, 8) of
     {base, ld, Q, n, tile, out_off, 0, 0}.  -> (rows (out_total,), cols (out_total,), status (1,) int32)"""
     assert C.is_cuda and C.dtype == torch.float32 and C.is_contiguous()
     assert problems.is_cuda and problems.dtype == torch.int64 and problems.is_contiguous() and problems.shape[1] == 8
-    rows = torch.empty(out_total, dtype=torch.int64, device=C.device)
-    cols = torch.empty(out_total, dtype=torch.int64, device=C.device)
+    if fill is None:
+        rows = torch.empty(out_total, dtype=torch.int64, device=C.device)
+        cols = torch.empty(out_total, dtype=torch.int64, device=C.device)
+    else:                          # padded result slots: entries no problem writes keep the fill value
+        rows = torch.full((2, out_total), fill, dtype=torch.int64, device=C.device)
+        rows, cols = rows[0], rows[1]
     status = torch.zeros(1, dtype=torch.int32, device=C.device)
     with torch.cuda.device(C.device):
         rc = _lib.lib().gvl_lsap_batch_device_f32(C.data_ptr(), problems.data_ptr(), problems.shape[0], max_rows,
@@ -129,13 +133,46 @@ class MatchPlan:
         self.ent_start = torch.tensor(starts, dtype=torch.int64, device=device)       # first pair of every video
 
 
+class PaddedMatchPlan:
+    """The same bookkeeping for ``gvl_amd.targets.PaddedTargets``: every video owns `slots` target slots and
+    G1 = min(Q, slots) one-to-one / G4 = min(Q, 4 slots) many-to-one result slots, so nothing here depends on how
+    many events a video really has -- the per-video counts are read on the device (column 3 of the problem
+    descriptors is refreshed from ``targets.counts`` before every solve).  Result slots beyond a video's count hold
+    -1.  This is what a layout-independent hipGraph capture of the step needs."""
+    padded = True
+
+    def __init__(self, nl, B, Q, slots, device, m2o_rate):
+        self.nl, self.B, self.Q, self.slots, self.m2o = nl, B, Q, slots, m2o_rate
+        self.G1, self.G4 = min(Q, slots), min(Q, slots * m2o_rate)
+        self.t1, self.t4 = B * self.G1, B * self.G4
+        desc = []
+        for tile, per, first in ((1, self.G1, 0), (m2o_rate, self.G4, nl * self.t1)):
+            for l in range(nl):
+                for i in range(B):
+                    desc.append([((l * B + i) * Q) * slots, slots, Q, 0, tile, first + (l * B + i) * per, 0, 0])
+        self.problems = torch.tensor(desc, dtype=torch.int64, device=device).reshape(-1, 8)
+        self.out_total = nl * (self.t1 + self.t4)
+        self.max_rows, self.max_cols = min(Q, slots * m2o_rate), max(Q, slots * m2o_rate)
+        ar = torch.arange(B, dtype=torch.int64, device=device)
+        self.vid_of_entry = ar.repeat_interleave(self.G1)
+        self.slot_of_entry = torch.arange(self.G1, dtype=torch.int64, device=device).repeat(B)
+        self.tgt_base = self.vid_of_entry * slots
+        self.ent_start = torch.arange(B + 1, dtype=torch.int64, device=device) * self.G1
+
+    def refresh(self, counts):
+        """write n = counts[video] into every problem descriptor (one small device copy; capturable)"""
+        self.problems.view(2 * self.nl, self.B, 8)[:, :, 3] = counts
+        self.pair_count = counts.clamp(max=self.Q)                      # matches per video, one-to-one
+        self.valid = self.slot_of_entry < self.pair_count[self.vid_of_entry]
+
+
 class LayerMatch:
     """The matching of one decoder layer, resident on the device.  ``q`` / ``t``: matched query id and (video-local)
     target id of every match, videos concatenated; ``t_global`` the target's row in the concatenated targets.
     Indexing ([0] -> indices, [1] -> rl_indices) materialises the reference's host structure (one copy)."""
 
-    def __init__(self, plan, layer, rows, cols, status, ok):
-        self.plan, self.layer = plan, layer
+    def __init__(self, plan, layer, rows, cols, status, ok, targets=None):
+        self.plan, self.layer, self.targets = plan, layer, targets      # targets: PaddedTargets of a padded plan
         a = layer * plan.t1
         self.q, self.t = rows[a:a + plan.t1], cols[a:a + plan.t1]
         b = plan.nl * plan.t1 + layer * plan.t4
@@ -158,6 +195,15 @@ class LayerMatch:
         if self._host is None:
             self.check()
             q, t_, rq, rt = (x.cpu() for x in (self.q, self.t, self.rl_q, self.rl_t))
+            if getattr(self.plan, "padded", False):
+                # padded result slots -> the reference's per-video lists (host-known counts of the loaded batch)
+                p_, ns = self.plan, self.targets.host_counts
+                one = [(q.view(p_.B, p_.G1)[i, :min(p_.Q, n)], t_.view(p_.B, p_.G1)[i, :min(p_.Q, n)])
+                       for i, n in enumerate(ns)]
+                many = [(rq.view(p_.B, p_.G4)[i, :min(p_.Q, n * p_.m2o)], rt.view(p_.B, p_.G4)[i, :min(p_.Q, n * p_.m2o)])
+                        for i, n in enumerate(ns)]
+                self._host = (one, many)
+                return self._host
             self._host = ([(a, b) for a, b in zip(q.split(self.plan.n1), t_.split(self.plan.n1))],
                           [(a, b) for a, b in zip(rq.split(self.plan.n4), rt.split(self.plan.n4))])
         return self._host
@@ -231,8 +277,48 @@ class HungarianMatcher(nn.Module):
         C, ok = self.cost_matrices(outputs_list, targets, tgt_cat)    # (nl, B, Q, G)
         nl, B, Q, G = C.shape
         plan = self._plan(nl, B, Q, sizes, C.device)
+        if plan.max_rows > self.LSAP_DEVICE_MAX_ROWS or plan.max_cols > self.LSAP_DEVICE_MAX_COLS:
+            return None                                   # beyond the on-chip solver: caller takes the host path
         rows, cols, status = lsap_batch_device(C, plan.problems, plan.out_total, plan.max_rows, plan.max_cols)
         return [LayerMatch(plan, l, rows, cols, status, ok) for l in range(nl)]
+
+    LSAP_DEVICE_MAX_ROWS, LSAP_DEVICE_MAX_COLS = 256, 1024        # on-chip limits of k_lsap (gvl_lsap_dev.hip)
+
+    def padded_eligible(self, outputs_list, Q, slots, m2o_rate=4):
+        """domain of the layout-independent path: fused cost kernel (class / box / GIoU terms only, fp32, on the GPU)
+        and assignment problems that fit the on-device solver"""
+        first = outputs_list[0]
+        extra = any(isinstance(o.get('cl_match_mats', 0), torch.Tensor) and self.cost_cl != 0 for o in outputs_list) \
+            or (self.opt is not None and getattr(self.opt, "set_cost_caption", 0) > 0
+                and any('cap_cost_mat' in o for o in outputs_list))
+        return (not extra and first["pred_logits"].is_cuda and first["pred_logits"].dtype == torch.float32
+                and min(Q, slots * m2o_rate) <= self.LSAP_DEVICE_MAX_ROWS
+                and max(Q, slots * m2o_rate) <= self.LSAP_DEVICE_MAX_COLS)
+
+    @torch.no_grad()
+    def match_layers_padded(self, outputs_list, pt, m2o_rate=4):
+        """match_layers_device on ``PaddedTargets``: cost blocks (nl, B, Q, slots) from gvl_match_cost_padded_f32, one
+        solver launch over 2 * nl * B fixed problem slots whose sizes come from ``pt.counts`` on the device.  No
+        tensor shape, launch parameter or host value depends on the number of events per video."""
+        logits = torch.stack([o["pred_logits"] for o in outputs_list]).contiguous()
+        boxes = torch.stack([o["pred_boxes"] for o in outputs_list]).contiguous()
+        nl, B, Q, NC = logits.shape
+        key = ("padded", nl, B, Q, pt.slots, str(logits.device), m2o_rate)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = PaddedMatchPlan(nl, B, Q, pt.slots, logits.device, m2o_rate)
+        plan.refresh(pt.counts)
+        C = torch.empty((nl, B, Q, pt.slots), dtype=torch.float32, device=logits.device)
+        ok = torch.ones(1, dtype=torch.int32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = _lib.lib().gvl_match_cost_padded_f32(
+                logits.data_ptr(), boxes.data_ptr(), pt.labels.data_ptr(), pt.boxes.data_ptr(), pt.counts.data_ptr(),
+                nl, B, Q, NC, pt.slots, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou),
+                float(self.cost_alpha), float(self.cost_gamma), C.data_ptr(), ok.data_ptr(),
+                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "match_cost_padded")
+        rows, cols, status = lsap_batch_device(C, plan.problems, plan.out_total, plan.max_rows, plan.max_cols, fill=-1)
+        return [LayerMatch(plan, l, rows, cols, status, ok, targets=pt) for l in range(nl)]
 
     @torch.no_grad()
     def cost_matrices(self, outputs_list, targets, tgt_cat, fused=None):

@@ -13,8 +13,12 @@ module adds what a data-parallel run of the reference loop (train.py:385-409) ne
     mesh (7 links x ~153 GB/s per GPU) large messages are what the ring/direct algorithms need to reach link rate;
   * after backward: wait, scale by 1/world, clip_grad_norm_, Adam step -- train.py:405-409.
 """
+from collections import OrderedDict
+
 import torch
 import torch.distributed as dist
+
+from .targets import PaddedTargets, needed_capacity, round_up_pow2
 
 
 def shard_batch(dt, rank, world):
@@ -50,6 +54,7 @@ class GradBuckets:
         # per-parameter accumulate kernel into a pre-existing buffer (133 launches per step; the step is launch-bound).
         self.flat = None
         self.buckets, self.bucket_of, self.ready, self.handles = [], {}, [], []
+        self.next_bucket, self.seen = 0, set()
         self.overlap = overlap
         if not (self.world > 1 if flat is None else flat):
             return
@@ -77,12 +82,21 @@ class GradBuckets:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
-    def _hook(self, p):
-        b = self.bucket_of[id(p)]
-        self.ready[b] += 1
-        if self.ready[b] == self.buckets[b][2]:
-            s, e, _ = self.buckets[b]
+    def _launch_ready(self, everything=False):
+        """issue the all-reduces in BUCKET ORDER: bucket b only after buckets 0..b-1.  Ranks whose backward completes the
+        buckets in different orders (or leaves some incomplete: parameters without a gradient this step) still post the
+        same sequence of collectives, so RCCL never pairs buckets of different sizes."""
+        while self.next_bucket < len(self.buckets):
+            s, e, n = self.buckets[self.next_bucket]
+            if not everything and self.ready[self.next_bucket] != n:
+                return
             self.handles.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
+            self.next_bucket += 1
+
+    def _hook(self, p):
+        self.seen.add(id(p))
+        self.ready[self.bucket_of[id(p)]] += 1
+        self._launch_ready()
 
     def zero(self):
         if self.flat is None:
@@ -92,6 +106,7 @@ class GradBuckets:
         self.flat.zero_()
         self.ready = [0] * len(self.buckets)
         self.handles = []
+        self.next_bucket, self.seen = 0, set()
 
     def exchange(self):
         """non-overlapped variant: all-reduce every bucket now (on the current stream's ordering) and average"""
@@ -108,12 +123,18 @@ class GradBuckets:
             return
         if not self.overlap:
             return self.exchange()
-        for b, (s, e, n) in enumerate(self.buckets):
-            if self.ready[b] != n:                       # some parameter unused this step: reduce the bucket now
-                self.handles.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
+        self._launch_ready(everything=True)              # buckets with a parameter unused this step, in index order
         for h in self.handles:
             h.wait()
         self.flat.div_(self.world)
+
+    def unused_params(self):
+        """parameters that received no gradient in the step just finished (overlap mode).  The single-GPU loop leaves
+        their .grad = None and Adam skips them (no weight decay, no moment update); with the flat buffer they hold
+        zeros, so the step hides them from the optimizer.  Parameter usage must be the same on every rank."""
+        if self.flat is None or not self.overlap or self.world == 1:
+            return []
+        return [p for p in self.params if id(p) not in self.seen]
 
 
 class TrainStep:
@@ -150,31 +171,116 @@ class TrainStep:
         final, loss = self._forward_loss(dt)
         final.backward()
         self.buckets.finish()
-        torch.nn.utils.clip_grad_norm_(self.params, self.opt.grad_clip)
+        hidden = [(p, p.grad) for p in self.buckets.unused_params()]
+        for p, _ in hidden:
+            p.grad = None                                   # as train.py's loop sees them: Adam skips these
+        torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], self.opt.grad_clip)
         self.optimizer.step()
+        for p, g in hidden:
+            p.grad = g
         return final.detach(), loss
+
+
+class _LRU(OrderedDict):
+    """captured graphs, least recently used first; each entry pins a private memory pool, so the cache is bounded"""
+
+    def __init__(self, limit):
+        super().__init__()
+        self.limit = max(1, int(limit))
+
+    def lookup(self, key):
+        entry = self.get(key)
+        if entry is not None:
+            self.move_to_end(key)
+        return entry
+
+    def store(self, key, entry):
+        self[key] = entry
+        self.move_to_end(key)
+        while len(self) > self.limit:
+            self.popitem(last=False)
+
+
+_STATIC_KEYS = ("video_tensor", "video_mask", "video_length")
+
+
+def _drop_superseded(graphs, key):
+    """capacities only grow, so a padded graph of the same tensor shapes with a smaller capacity is never replayed again"""
+    for k in [k for k in graphs if k[0] == "padded" and k[1] == key[1]]:
+        del graphs[k]
+
+
+class _PaddedBatch:
+    """static device buffers of one captured step: the three feature tensors of pdvc.py:250-258 + PaddedTargets"""
+
+    def __init__(self, dt, slots, cap_len):
+        dev = dt["video_tensor"].device
+        self.dt = {k: dt[k].clone() for k in _STATIC_KEYS}
+        self.targets = PaddedTargets(dt["video_tensor"].shape[0], slots, cap_len, dev)
+        self.dt["_gvl_targets"] = self.targets
+        # paths that still want the reference's list (LayerMatch.host(), PostProcess) are served from the host counts
+        self.dt["video_target"] = None
+
+    def load(self, dt, num_boxes=None):
+        for k in _STATIC_KEYS:
+            self.dt[k].copy_(dt[k], non_blocking=True)
+        self.targets.load(dt, num_boxes)
+        for k, v in dt.items():                               # non-tensor bookkeeping travels along (video_key, cap_raw ...)
+            if k not in self.dt and not isinstance(v, torch.Tensor):
+                self.dt[k] = v
+        self.dt["video_target"] = dt["video_target"]
+
+
+class _Capacity:
+    """Grow-only capacities of the padded layout: slots per video = next power of two >= the largest event count seen
+    (>= 4), caption width = next multiple of 4 >= the widest caption tensor seen.  A batch that does not fit raises the
+    capacity and the step is captured again; in a steady run that happens a handful of times, then never."""
+
+    def __init__(self, slots=0, cap_len=0):
+        self.slots, self.cap_len = int(slots or 0), int(cap_len or 0)
+
+    def fit(self, dt, with_captions):
+        n_gt, cap_len = needed_capacity(dt)
+        self.slots = max(self.slots, round_up_pow2(n_gt, 4))
+        if with_captions:
+            self.cap_len = max(self.cap_len, 4 * ((max(cap_len, 2) + 3) // 4))
+        return self.slots, (self.cap_len if with_captions else 0)
 
 
 class GraphedTrainStep(TrainStep):
     """The whole train step -- forward, on-device Hungarian matching, losses, backward, gradient exchange, clipping and
-    Adam -- captured ONCE per batch layout in a hipGraph and replayed with a single launch.  The eager step issues
-    ~5 000 kernel launches whose host-side cost (~55 ms) exceeds their GPU time (~30 ms); nothing in the step reads
-    the device back (gvl_amd.matcher.LayerMatch stays on the device), which is what makes the capture possible.
+    Adam -- captured in a hipGraph and replayed with a single launch.  The eager step issues ~5 000 kernel launches
+    whose host-side cost (~55 ms) exceeds their GPU time (~30 ms); nothing in the step reads the device back
+    (gvl_amd.matcher.LayerMatch stays on the device), which is what makes the capture possible.
 
-    Inputs are copied into static buffers before every replay; the batch layout (tensor shapes, number of events per
-    video, teacher-forcing length) is the cache key."""
+    **Layout independence.**  The reference loop (train.py:385-409) feeds batches whose number of events per video,
+    number of captions and caption lengths differ every iteration.  The captured step therefore runs on
+    ``gvl_amd.targets.PaddedTargets``: fixed-shape target / caption buffers with device-side counts, refreshed before
+    every replay, so ONE graph serves every batch that fits its capacity (``_Capacity``: grow-only).  The graph cache
+    is keyed on tensor shapes and capacities only and is LRU-bounded (``max_graphs``).  Models / criteria outside the
+    padded path's domain (``PDVC.supports_padded_targets``, ``'gt_proposals'`` decoder input) fall back to one graph
+    per batch layout -- same cache, same bound.
 
-    def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=3, split_exchange=None,
-                 autocast_dtype=None):
+    **Warm-up is side-effect free.**  A capture needs >= 1 eager run first (autograd's accumulators, hipBLASLt
+    workspaces, lazily built constants); those runs and the capture itself leave parameters, Adam state, buffers and
+    the RNG state exactly as they were (snapshot / restore), so every batch gets ONE update, as in train.py."""
+
+    def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=2, split_exchange=None,
+                 autocast_dtype=None, max_graphs=4, max_gt=0, max_cap_len=0, padded=None):
         """split_exchange (default: exactly when there is more than one process): the step is captured as TWO graphs --
         zero_grad + forward + backward into the flat gradient buffer, then clip + Adam -- with the bucketed RCCL
         all-reduce issued eagerly between the two replays, so no collective is ever inside a hipGraph.  The criterion's
         own ``all_reduce(num_boxes)`` (criterion.py:178-180) is taken before the first graph from the host-known
-        target counts."""
+        target counts and reaches the captured criterion through device memory.
+        max_gt / max_cap_len: initial capacities of the padded layout (0 = grow from the batches seen).
+        padded: None = automatic, False = always one graph per batch layout."""
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
         super().__init__(model, criterion, opt, world_size, process_group, capturable=True,
                          flat=True if self.split else None, overlap=not self.split, autocast_dtype=autocast_dtype)
-        self.graphs = {}
+        self.graphs = _LRU(max_graphs)
+        self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, max_cap_len)
+        self.padded = padded
+        self.captures = self.replays = 0
         # >= 1 real step must run before the capture (on a side stream): autograd's gradient accumulators, hipBLASLt
         # workspaces and the library's lazily built constants have to exist before a stream is capturing
         self.warmup = max(1, int(warmup))
@@ -188,18 +294,28 @@ class GraphedTrainStep(TrainStep):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
 
+    # ---- batch forms -------------------------------------------------------------------------------------------
     @staticmethod
     def _tensor_keys(dt):
         return [k for k, v in dt.items() if isinstance(v, torch.Tensor)]
 
-    def _key(self, dt):
+    def _use_padded(self, dt):
+        if self.padded is False or self.opt.transformer_input_type != "queries":
+            return False
+        ok = self.model.supports_padded_targets(self.criterion, eval_mode=False)
+        if not ok and self.padded:
+            raise RuntimeError("GraphedTrainStep(padded=True): this model / criterion has no padded-target path")
+        return ok and round_up_pow2(needed_capacity(dt)[0], 4) <= min(64, self.opt.num_queries)
+
+    def _layout_key(self, dt):
+        """fallback form: one graph per batch layout (tensor shapes, events per video, teacher-forcing length)"""
         sig = tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in self._tensor_keys(dt))
         n_gt = tuple(len(t_["boxes"]) for t_ in dt["video_target"])
         if "_gvl_cap_steps" not in dt:                      # teacher-forcing length: one host read per NEW batch
             live = (dt["cap_tensor"][:, 1:] != 0).any(0).cpu().tolist()
             dt["_gvl_cap_steps"] = min(1 + (live.index(False) if False in live else len(live)),
                                        dt["cap_tensor"].shape[-1] - 1)
-        return sig, n_gt, dt["_gvl_cap_steps"]
+        return "layout", sig, n_gt, dt["_gvl_cap_steps"]
 
     @staticmethod
     def _static_copy(dt):
@@ -242,85 +358,135 @@ class GraphedTrainStep(TrainStep):
         torch.nn.utils.clip_grad_norm_(self.params, self.opt.grad_clip)
         self.optimizer.step()
 
-    def _call_split(self, dt):
-        nb = self._global_num_boxes(dt)
-        key = self._key(dt) + (nb,)
-        entry = self.graphs.get(key)
-        self.criterion.num_boxes_override = nb                # a kernel argument of the captured criterion
-        try:
-            if entry is None:
-                st = GraphedTrainStep._static_copy(dt)
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(self.warmup):
-                        self._forward_backward(st)
-                        self.buckets.exchange()
-                        self._update()
-                torch.cuda.current_stream().wait_stream(side)
-                g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb, stream=side):
-                    outs = self._forward_backward(st)
-                with torch.cuda.graph(g_up, pool=g_fb.pool(), stream=side):
+    # ---- side-effect-free warm-up --------------------------------------------------------------------------------
+    def _snapshot(self):
+        dev = self.params[0].device
+        opt_state = [{k: v.clone() for k, v in self.optimizer.state[p].items() if isinstance(v, torch.Tensor)}
+                     for p in self.params]
+        return ([p.detach().clone() for p in self.params], [b.detach().clone() for b in self.model.buffers()],
+                opt_state, torch.cuda.get_rng_state(dev), torch.get_rng_state())
+
+    def _restore(self, snap):
+        params, buffers, opt_state, cuda_rng, cpu_rng = snap
+        with torch.no_grad():
+            for p, v in zip(self.params, params):
+                p.copy_(v)                                   # in place: the graphs captured these addresses
+            for b, v in zip(self.model.buffers(), buffers):
+                b.copy_(v)
+            for p, saved in zip(self.params, opt_state):
+                for k, v in saved.items():
+                    self.optimizer.state[p][k].copy_(v)
+        torch.cuda.set_rng_state(cuda_rng, self.params[0].device)
+        torch.set_rng_state(cpu_rng)
+
+    def _capture(self, st):
+        """warm up on `st` (local work only: no collective, so ranks may capture at different times) and capture;
+        -> (graphs, outs).  Parameters / optimizer / RNG are restored afterwards: the capture records, it does not run."""
+        snap = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                if self.split:
+                    self._forward_backward(st)
                     self._update()
-                entry = self.graphs[key] = (g_fb, g_up, st, outs)
-            g_fb, g_up, st, outs = entry
-            self._refresh(st, dt)
-            g_fb.replay()
-            self.buckets.exchange()                           # eager RCCL between the two replays
-            g_up.replay()
-        finally:
-            self.criterion.num_boxes_override = None
-        return outs
+                else:
+                    TrainStep.__call__(self, st)
+        torch.cuda.current_stream().wait_stream(side)
+        # capture ON the warm-up stream: autograd's AccumulateGrad nodes were created there and keep running there;
+        # captured from another stream they become a parallel branch of the graph that the optimizer kernels do not
+        # wait for (seen as NaN parameters after a few replays of the bf16 step)
+        if self.split:
+            g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb, stream=side):
+                outs = self._forward_backward(st)
+            with torch.cuda.graph(g_up, pool=g_fb.pool(), stream=side):
+                self._update()
+            graphs = (g_fb, g_up)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                outs = TrainStep.__call__(self, st)
+            graphs = (graph,)
+        self._restore(snap)
+        self.captures += 1
+        return graphs, outs
 
     def __call__(self, dt):
+        nb = self._global_num_boxes(dt) if self.split else None      # every rank, every step (a collective at N > 1)
+        if self._use_padded(dt):
+            slots, cap_len = self.capacity.fit(dt, with_captions=True)
+            key = ("padded", tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in _STATIC_KEYS), slots, cap_len)
+            entry = self.graphs.lookup(key)
+            if entry is None:
+                _drop_superseded(self.graphs, key)
+                batch = _PaddedBatch(dt, slots, cap_len)
+                batch.load(dt, nb)
+                graphs, outs = self._capture(batch.dt)
+                entry = (graphs, batch, outs)
+                self.graphs.store(key, entry)
+            graphs, batch, outs = entry
+            batch.load(dt, nb)
+        else:
+            key = self._layout_key(dt) + ((nb,) if self.split else ())
+            entry = self.graphs.lookup(key)
+            self.criterion.num_boxes_override = nb              # a kernel argument of the captured criterion
+            try:
+                if entry is None:
+                    st = GraphedTrainStep._static_copy(dt)
+                    graphs, outs = self._capture(st)
+                    entry = (graphs, st, outs)
+                    self.graphs.store(key, entry)
+            finally:
+                self.criterion.num_boxes_override = None
+            graphs, st, outs = entry
+            self._refresh(st, dt)
+        graphs[0].replay()
         if self.split:
-            return self._call_split(dt)
-        key = self._key(dt)
-        entry = self.graphs.get(key)
-        if entry is None:
-            st = GraphedTrainStep._static_copy(dt)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(self.warmup):               # real optimisation steps (Adam state, lazy inits, LDS attrs)
-                    self._eager(st)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            # capture ON the warm-up stream: autograd's AccumulateGrad nodes were created there and keep running there;
-            # captured from another stream they become a parallel branch of the graph that the optimizer kernels do not
-            # wait for (seen as NaN parameters after a few replays of the bf16 step)
-            with torch.cuda.graph(graph, stream=side):
-                outs = self._eager(st)
-            entry = self.graphs[key] = (graph, st, outs)        # capture records, it does not execute: replay below
-        graph, st, outs = entry
-        self._refresh(st, dt)
-        graph.replay()
+            self.buckets.exchange()                               # eager RCCL between the two replays
+            graphs[1].replay()
+        self.replays += 1
         return outs
 
 
 class GraphedEvalForward:
     """The whole evaluation forward -- base encoder, deformable encoder / decoder, heads, greedy captioning loop, on-device
-    matching and the set criterion -- captured once per batch layout in a hipGraph and replayed with one launch.
-    The eager forward is host-bound outside the captioner (≈450 launches, 4.9 ms for 1.5 ms of GPU work at cfg A).
+    matching and the set criterion -- captured in hipGraphs and replayed.  The eager forward is host-bound outside the
+    captioner (≈450 launches, 4.9 ms for 1.5 ms of GPU work at cfg A).
 
-    The one data-dependent host decision of the reference's eval forward -- cutting the caption tensor at the first
-    step where every sequence has ended (LSTM_DSA.py:186-187) -- is taken AFTER the replay from the `alive` flags the
-    graph leaves on the device.  Returned tensors are the graph's static outputs: they are overwritten by the next
-    call (clone what must survive)."""
+    **Layout independence**: as in GraphedTrainStep, the ground truth travels as ``PaddedTargets`` (device-side counts),
+    so batches with different numbers of events per video (eval_utils.py:187-203 feeds them in dataset order) replay the
+    same graph; the cache is keyed on tensor shapes + capacity + parameter version and LRU-bounded.
 
-    def __init__(self, model, criterion, transformer_input_type="queries", warmup=1, autocast_dtype=None):
+    **Finished captions stop costing**: the reference leaves the decoding loop at the first step where every sequence
+    has ended (LSTM_DSA.py:186-187).  The loop is captured in segments of ``decode_chunk`` tokens; after each segment
+    ONE small device->host read of the `alive` flags decides whether the next segment is replayed.  Trained
+    checkpoints (captions of ~10-15 tokens against max_caption_len = 30) therefore pay for the longest caption of the
+    batch, rounded up to the chunk, not for 30 steps.  decode_chunk=0: one graph, flags read once at the end.
+    Returned tensors are the graphs' static outputs: they are overwritten by the next call (clone what must survive)."""
+
+    def __init__(self, model, criterion, transformer_input_type="queries", warmup=1, autocast_dtype=None,
+                 max_graphs=4, max_gt=0, decode_chunk=5, padded=None):
         self.model, self.criterion, self.kind = model, criterion, transformer_input_type
         self.autocast_dtype = autocast_dtype          # e.g. torch.bfloat16: capture the forward under torch.autocast
         self.warmup = max(1, int(warmup))
-        self.graphs = {}
+        self.graphs = _LRU(max_graphs)
+        self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, 0)
+        self.decode_chunk = max(0, int(decode_chunk))
+        self.padded = padded
+        self.captures = self.replays = 0
+        self.segments_replayed = 0                    # decode segments actually run (diagnostic)
 
-    def _key(self, dt):
-        sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in dt.items() if isinstance(v, torch.Tensor))
+    def _epoch(self):
         # operands derived from weights only (concatenated / pre-multiplied matrices of the captioner) are cached per
         # parameter version and are constants of the captured graph: updated parameters => a new capture
-        epoch = sum(p_._version for p_ in self.model.parameters())
-        return sig, tuple(len(t_["boxes"]) for t_ in dt["video_target"]), epoch
+        return sum(p_._version for p_ in self.model.parameters())
+
+    def _use_padded(self, dt):
+        if self.padded is False or self.kind != "queries" or self.criterion is None:
+            return False
+        return (self.model.supports_padded_targets(self.criterion, eval_mode=True)
+                and round_up_pow2(needed_capacity(dt)[0], 4) <= min(64, self.model.opt.num_queries))
 
     def _forward(self, dt):
         with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
@@ -335,41 +501,93 @@ class GraphedEvalForward:
                 found.append(m)
         return found
 
+    def _segments(self, head):
+        """iteration ranges of the greedy loop: [0, b1) inside the main graph, then one graph per further range"""
+        T = head.max_caption_len
+        if (self.decode_chunk <= 0 or self.decode_chunk >= T or self.model.opt.eval_disable_captioning
+                or self.model.opt.caption_decoder_type != "standard"):
+            return [T + 1]
+        bounds = list(range(self.decode_chunk + 1, T + 1, self.decode_chunk))
+        return bounds + [T + 1]
+
+    def _capture(self, st):
+        heads = list(self.model.caption_head)
+        head = heads[-1]
+        bounds = self._segments(head)
+        for h_ in heads:
+            h_.defer_trim = True
+            h_.decode_stop = bounds[0]
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self._forward(st)
+                    for a, b in zip(bounds[:-1], bounds[1:]):
+                        head.decode_continue(a, b)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                out, loss = self._forward(st)
+                alive0 = getattr(head, "last_alive", None)
+            flags = [alive0[:bounds[0] - 1] if alive0 is not None and len(bounds) > 1 else alive0]
+            seg_graphs = []
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=graph.pool(), stream=side):
+                    flags.append(head.decode_continue(a, b))
+                seg_graphs.append(g)
+        finally:
+            for h_ in heads:
+                h_.defer_trim = False
+                h_.decode_stop = None
+                h_._decode_state = None
+        self.captures += 1
+        return graph, seg_graphs, out, loss, flags
+
     @torch.no_grad()
     def __call__(self, dt):
-        key = self._key(dt)
-        if self.graphs and next(iter(self.graphs))[-1] != key[-1]:
+        epoch = self._epoch()
+        if self.graphs and next(iter(self.graphs))[-1] != epoch:
             self.graphs.clear()                              # parameters changed: graphs of the old weights are dead
-        entry = self.graphs.get(key)
-        heads = list(self.model.caption_head)
+        padded = self._use_padded(dt)
+        if padded:
+            slots, _ = self.capacity.fit(dt, with_captions=False)
+            key = ("padded", tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in _STATIC_KEYS), slots, epoch)
+        else:
+            sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in dt.items() if isinstance(v, torch.Tensor))
+            key = ("layout", sig, tuple(len(t_["boxes"]) for t_ in dt["video_target"]), epoch)
+        entry = self.graphs.lookup(key)
         if entry is None:
-            st = GraphedTrainStep._static_copy(dt)
-            for h_ in heads:
-                h_.defer_trim = True
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(self.warmup):
-                        self._forward(st)
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    out, loss = self._forward(st)
-                alive = getattr(heads[-1], "last_alive", None)
-            finally:
-                for h_ in heads:
-                    h_.defer_trim = False
-            entry = self.graphs[key] = (graph, st, out, loss, alive)
-        graph, st, out, loss, alive = entry
-        GraphedTrainStep._refresh(st, dt)
+            if padded:
+                _drop_superseded(self.graphs, key)
+                batch = _PaddedBatch(dt, slots, 0)
+                batch.load(dt)
+                st = batch.dt
+            else:
+                batch, st = None, GraphedTrainStep._static_copy(dt)
+            entry = (batch, st) + self._capture(st)
+            self.graphs.store(key, entry)
+        batch, st, graph, seg_graphs, out, loss, flags = entry
+        if batch is not None:
+            batch.load(dt)
+        else:
+            GraphedTrainStep._refresh(st, dt)
         graph.replay()
+        self.replays += 1
         out = dict(out)
         for m in self._matches(out):
             m._host = None                                   # the device indices changed under the cached host copy
-        if alive is not None and isinstance(out.get("seq"), torch.Tensor) and not self.model.opt.eval_disable_captioning:
-            flags = alive.cpu().tolist()                     # the forward's only host read (LSTM_DSA.py:186-187)
-            keep = flags.index(False) if False in flags else len(flags)
+        if flags[0] is not None and isinstance(out.get("seq"), torch.Tensor) and not self.model.opt.eval_disable_captioning:
+            # the forward's only host reads (LSTM_DSA.py:186-187): one per decode segment that ran
+            alive = flags[0].cpu().tolist()
+            for g, f_ in zip(seg_graphs, flags[1:]):
+                if False in alive:
+                    break
+                g.replay()
+                self.segments_replayed += 1
+                alive += f_.cpu().tolist()
+            keep = alive.index(False) if False in alive else len(alive)
             if keep == 0:
                 out["seq"], out["caption_probs"] = [], {"cap_prob_eval": []}
             else:

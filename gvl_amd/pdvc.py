@@ -135,6 +135,30 @@ class PDVC(nn.Module):
         memory = self.transformer.forward_encoder(src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat)
         return memory, tshapes, lsi, valid_ratios, mask_flat
 
+    def supports_padded_targets(self, criterion, eval_mode):
+        """Can a step on this model run in the layout-independent form (dt['_gvl_targets'] = PaddedTargets; what
+        gvl_amd.parallel's captured steps use)?  Eval: whenever the criterion can.  Train: additionally the caption
+        losses of all decoder layers must come from the one-pass teacher-forced path (caption_prediction_layers)."""
+        if criterion is None or not getattr(criterion, "fused", False) or not getattr(criterion, "device_matching", False):
+            return False
+        if eval_mode or self.opt.caption_loss_coef == 0:
+            return True
+        head = self.caption_head[-1]
+        return (self.training and self.aux_loss and len(self.caption_head) > 1
+                and getattr(self, "one_pass_captioning", True)
+                and all(h_ is head for h_ in self.caption_head)
+                and not vars(self.opt).get('enable_pos_emb_for_captioner', False)
+                and getattr(head, "ss_prob", 0.0) == 0.0 and hasattr(head, "core")
+                and getattr(head.core, "fused_train", True) and head.core.att_feat_size == 512
+                and head.core.att_hid_size == 512 and head.core.n_levels * head.core.n_points == 16
+                and self.opt.set_cost_caption == 0)
+
+    @staticmethod
+    def _targets(dt):
+        """the criterion's targets: the padded fixed-shape form when the caller prepared one, else the reference's list"""
+        pt = dt.get('_gvl_targets')
+        return pt if pt is not None else dt['video_target']
+
     def forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
         N = dt['video_tensor'].shape[0]
         memory, tshapes, lsi, valid_ratios, mask_flat = self.encode(dt)
@@ -231,7 +255,7 @@ class PDVC(nn.Module):
             out['aux_outputs'] = [{k: all_out[k][j] for k in keys} for j in range(num_pred - 1)]
         if criterion is None:                                   # pure-inference use (bench / graph capture)
             return out, {}
-        loss, last_indices, *_ = criterion(out, dt['video_target'])
+        loss, last_indices, *_ = criterion(out, self._targets(dt))
         return out, loss
 
     def caption_prediction_eval(self, cap_head, dt, hs, reference, others, decoder_type, indices=None):
@@ -267,15 +291,25 @@ class PDVC(nn.Module):
         if self.aux_loss:
             keys = list(all_out.keys())
             out['aux_outputs'] = [{k: all_out[k][j] for k in keys} for j in range(num_pred - 1)]
-            loss, last_indices, aux_indices = criterion(out, dt['video_target'])
+            loss, last_indices, aux_indices = criterion(out, self._targets(dt))
             layers = range(num_pred)
         else:
-            loss, last_indices = criterion(out, dt['video_target'])
+            loss, last_indices = criterion(out, self._targets(dt))
             aux_indices = None
             layers = [num_pred - 1]
         layers = list(layers)
         matches = [last_indices if l_id == num_pred - 1 else aux_indices[l_id] for l_id in layers]
         refs = [init_reference if l_id == 0 else inter_references[l_id - 1] for l_id in layers]
+        if getattr(matches[0], "plan", None) is not None and getattr(matches[0].plan, "padded", False):
+            if not self._one_pass_captioning(layers, matches, hs, None):
+                raise RuntimeError("padded targets need the one-pass teacher-forced caption path "
+                                   "(PDVC.supports_padded_targets)")
+            cap_losses, probs, seq = self.caption_prediction_layers_padded(
+                self.caption_head[layers[-1]], dt['_gvl_targets'], [hs_l[l_id] for l_id in layers], refs, others, matches)
+            for l_id, cap_loss in zip(layers, cap_losses):
+                loss['loss_caption' if l_id == num_pred - 1 else f'loss_caption_{l_id}'] = cap_loss
+            out.update({'caption_probs': probs, 'seq': seq})
+            return out, loss
         if self._one_pass_captioning(layers, matches, hs, dt):
             # every decoder layer's caption loss from ONE pass of the shared caption head over all layers' matched
             # queries (the value / ctx2att slab, the token loop and every weight gradient are then computed once)
@@ -306,7 +340,45 @@ class PDVC(nn.Module):
                 and not vars(self.opt).get('enable_pos_emb_for_captioner', False)
                 and getattr(head, "ss_prob", 0.0) == 0.0 and hasattr(head, "core")
                 and head.core.fused_train_eligible(hs[0]) and torch.is_grad_enabled()
-                and all(len(t_['boxes']) <= hs.shape[2] for t_ in dt['video_target']))
+                and (dt is None or all(len(t_['boxes']) <= hs.shape[2] for t_ in dt['video_target'])))
+
+    def caption_prediction_layers_padded(self, cap_head, pt, hs_layers, ref_layers, others, matches):
+        """caption_prediction_layers on PaddedTargets: video v owns rows [k * G1, (k + 1) * G1) for decoder layer k, of
+        which the first pair_count[v] carry a matched (query, caption) pair; the others are fed the <pad> caption with
+        an all-zero mask (loss and gradient contribution exactly 0).  The teacher-forced loop runs the full static
+        cap_len - 1 steps: steps beyond the longest caption of the batch only see masked positions, so the loss equals
+        the reference's, which leaves the loop at the first all-<pad> input column (LSTM_DSA.py:110-112).  The mean
+        over (videos x max pairs) rows of pdvc.py:868 divides by a DEVICE scalar.  No shape depends on the batch."""
+        nl = len(matches)
+        plan = matches[0].plan
+        N_, N_q, C = hs_layers[0].shape
+        G1 = plan.G1
+        if pt.slots > N_q:
+            raise RuntimeError("more target slots than queries")
+        cache = plan.__dict__.setdefault("_cap_rows", {})
+        rows = cache.get(nl)
+        if rows is None:
+            t1 = plan.vid_of_entry.numel()
+            rows = cache[nl] = (plan.vid_of_entry.repeat(nl),
+                                torch.arange(nl, device=plan.vid_of_entry.device).repeat_interleave(t1))
+        vid_all, lay_all = rows
+        valid = plan.valid.repeat(nl)
+        q_all = torch.cat([m.q for m in matches]).clamp(min=0)
+        t_all = torch.cat([m.t for m in matches]).clamp(min=0)
+        hs_stack = torch.stack(hs_layers)
+        ref_stack = torch.stack([r if r.shape[-1] == 2 else torch.cat([r, torch.full_like(r, -1.0)], -1)
+                                 for r in ref_layers])
+
+        def per_video(x):                                  # (nl * N * G1, ...) in (layer, video, slot) order
+            return x.view(nl, N_, G1, *x.shape[1:]).transpose(0, 1).reshape(N_, nl * G1, *x.shape[1:])
+        hs_m = per_video(hs_stack[lay_all, vid_all, q_all])
+        ref_m = per_video(ref_stack[lay_all, vid_all, q_all])
+        seq_flat = per_video(pt.cap_tensor[vid_all, t_all] * valid[:, None]).flatten(0, 1)
+        mask_flat = per_video(pt.cap_mask[vid_all, t_all] * valid[:, None]).flatten(0, 1)
+        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=pt.cap_len - 1)
+        row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
+        per_layer = row_loss.view(N_, nl, G1).sum(dim=(0, 2)) / (N_ * plan.pair_count.max())
+        return per_layer.unbind(0), {}, pt.cap_tensor[plan.vid_of_entry, matches[-1].t.clamp(min=0)]
 
     def caption_prediction_layers(self, cap_head, dt, hs_layers, ref_layers, others, matches):
         """caption_prediction for all decoder layers at once (shared head): the matched queries of layer k of video v

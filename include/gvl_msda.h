@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 4   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32 (earlier entry points unchanged) */
+#define GVL_MSDA_ABI_VERSION 5   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, and gvl_set_criterion_* take video_pair_count / num_boxes_dev */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -76,6 +76,15 @@ int gvl_match_cost_f32(const float *pred_logits, const float *pred_boxes, const 
                        const float *tgt_boxes, int n_layers, int B, int Q, int n_classes, int G, float w_class,
                        float w_bbox, float w_giou, float alpha, float gamma, float *cost, int *ok, void *stream);
 
+/* The same cost in the PADDED target layout (what a captured hipGraph needs: no shape depends on how many events a
+ * video has): every video owns `slots` target rows -- tgt_labels (B*slots), tgt_boxes (B*slots, 2) -- of which the
+ * first gt_counts[b] (DEVICE int64 (B)) are real.  cost (nl,B,Q,slots) holds each video's own block only; columns at
+ * or beyond the count are written as 0 and never read (the LSAP problem descriptor carries n = gt_counts[b]). */
+int gvl_match_cost_padded_f32(const float *pred_logits, const float *pred_boxes, const int64_t *tgt_labels,
+                              const float *tgt_boxes, const int64_t *gt_counts, int n_layers, int B, int Q,
+                              int n_classes, int slots, float w_class, float w_bbox, float w_giou, float alpha,
+                              float gamma, float *cost, int *ok, void *stream);
+
 /* -- set criterion of ALL decoder layers: replaces SetCriterion.loss_labels / loss_boxes / loss_cardinality
  *    (pdvc/criterion.py:48-132) with sigmoid_focal_loss (:232-257) and cross_entropy_with_gaussian_mask (:209-229).
  *      pred_logits (nl,B,Q,NC), pred_count (nl,B,count_bins), pred_boxes (nl,B,Q,2)
@@ -83,6 +92,10 @@ int gvl_match_cost_f32(const float *pred_logits, const float *pred_boxes, const 
  *      pair_video, pair_target_base (n_pairs)  video of the pair, first row of that video in the concatenated targets
  *      video_pair_start (B+1)                  first pair of every video
  *      tgt_labels (G), tgt_boxes (G,2), gt_counts (B) int64, counter_class_rate (count_bins)
+ *      video_pair_count (B) int64 or NULL      padded layout: only pair slots [start[v], start[v] + count[v]) of video v
+ *                                              hold a match (match_q = -1 elsewhere); NULL = every slot is a match
+ *      num_boxes_dev (1) float or NULL         the normaliser of criterion.py:178-181 read from DEVICE memory (a captured
+ *                                              step refreshes it per replay); NULL = the scalar argument num_boxes
  *    forward : losses (nl, 6) = [loss_ce, loss_counter, loss_bbox, loss_giou, loss_self_iou, cardinality_error]
  *    backward: grad_losses (nl, 6) -> grad_logits, grad_count, grad_boxes (same shapes as the predictions, fully
  *              written), with PyTorch's subgradient conventions. */
@@ -92,7 +105,8 @@ int gvl_set_criterion_forward_f32(const float *pred_logits, const float *pred_co
                                   const int64_t *tgt_labels, const float *tgt_boxes, const int64_t *gt_counts,
                                   const float *counter_class_rate, int n_layers, int B, int Q, int n_classes,
                                   int count_bins, int n_pairs, int G, float num_boxes, float focal_alpha,
-                                  float focal_gamma, float lloss_beta, int lloss_gau_mask, float *losses,
+                                  float focal_gamma, float lloss_beta, int lloss_gau_mask,
+                                  const int64_t *video_pair_count, const float *num_boxes_dev, float *losses,
                                   void *stream);
 int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_count, const float *pred_boxes,
                                    const int64_t *match_q, const int64_t *match_t, const int64_t *pair_video,
@@ -100,8 +114,10 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
                                    const int64_t *tgt_labels, const float *tgt_boxes, const int64_t *gt_counts,
                                    const float *counter_class_rate, int n_layers, int B, int Q, int n_classes,
                                    int count_bins, int n_pairs, int G, float num_boxes, float focal_alpha,
-                                   float focal_gamma, float lloss_beta, int lloss_gau_mask, const float *grad_losses,
-                                   float *grad_logits, float *grad_count, float *grad_boxes, void *stream);
+                                   float focal_gamma, float lloss_beta, int lloss_gau_mask,
+                                   const int64_t *video_pair_count, const float *num_boxes_dev,
+                                   const float *grad_losses, float *grad_logits, float *grad_count, float *grad_boxes,
+                                   void *stream);
 
 /* -- PositionEmbeddingSine.forward of one pyramid level (pdvc/position_encoding.py:38-64; the step in front of the
  *    path): normalised cumulative frame index -> interleaved sin / cos over `dim_t`, followed
