@@ -91,7 +91,8 @@ class ShowAttendTellCore(nn.Module):
                 and self.att_feat_size == 512 and self.att_hid_size == 512
                 and self.n_levels * self.n_points == 16)
 
-    def teacher_forced(self, xt_all, query, reference_points, temporal_shapes, level_start_index, const):
+    def teacher_forced(self, xt_all, query, reference_points, temporal_shapes, level_start_index, const,
+                       row_video=None):
         """every teacher-forced token step as one autograd node (TeacherForcedLoop) -> hidden (n, steps, H)"""
         att = self.deformable_att
         H, E, C = self.rnn_size, self.input_encoding_size, self.att_feat_size
@@ -105,7 +106,7 @@ class ShowAttendTellCore(nn.Module):
             slab.view(B, S, -1), reference_points.contiguous(), const["off_hs"].reshape(-1, K), const["gates_hs"],
             xt_all, w_hcat, b_hcat, self.rnn.weight_ih_l0[:, E:E + C].contiguous(), self.alpha_net.weight.reshape(-1),
             self.alpha_net.bias.reshape(1), temporal_shapes_2d(temporal_shapes, level_start_index), level_start_index,
-            self.n_levels, self.n_points)
+            self.n_levels, self.n_points, row_video)
 
     def _inference_weights(self, gemm_dtype=torch.float32):
         """Weight-only operands of the fused token step (re-laid-out / concatenated weights): rebuilt only when a
@@ -238,7 +239,7 @@ class TeacherForcedLoop(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, slab, ref_in, off_hs, gates_hs, xt_all, w_hcat, b_hcat, w_att, alpha_w, alpha_b, shapes2d, lsi,
-                n_levels, n_points):
+                n_levels, n_points, row_video=None):
         n, steps, H4 = xt_all.shape
         H = H4 // 4
         C = w_att.shape[1]
@@ -254,13 +255,15 @@ class TeacherForcedLoop(torch.autograd.Function):
         for i in range(steps):
             torch.addmm(b_hcat, h_all[i], w_hcat_t, out=g_h[i])                   # [h2att(h) | h W_hh^T | offsets(h)]
             MSDA.cap_attend_train_forward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
-                                          alpha_w, alpha_b, n_levels, n_points, att_res=att[i], alpha_out=alpha[i])
+                                          alpha_w, alpha_b, n_levels, n_points, att_res=att[i], alpha_out=alpha[i],
+                                          row_video=row_video)
             torch.addmm(gates_hs, att[i], w_att_t, out=g_x)                       # hs part + attention part of W_ih x
             MSDA.lstm_cell_train_forward(g_x, g_h[i][:, A:A + H4], xt_all[:, i], c_all[i], act[i], h_all[i + 1],
                                          c_all[i + 1])
         ctx.save_for_backward(slab, ref_in, off_hs, w_hcat, w_att, alpha_w, shapes2d, lsi, g_h, h_all, c_all, att,
                               alpha, act)
         ctx.cfg = (n_levels, n_points, A)
+        ctx.row_video = row_video
         return h_all[1:].permute(1, 0, 2).contiguous()
 
     @staticmethod
@@ -286,7 +289,7 @@ class TeacherForcedLoop(torch.autograd.Function):
             torch.mm(dgates, w_att, out=d_att)
             MSDA.cap_attend_train_backward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
                                            alpha_w, alpha[i], d_att, n_levels, n_points, g_slab, dg[i][:, :A],
-                                           dg[i][:, A + H4:], g_ref, g_aw, g_ab)
+                                           dg[i][:, A + H4:], g_ref, g_aw, g_ab, row_video=ctx.row_video)
             if i > 0:                                  # h_{-1} = 0 is a constant
                 dh_carry = torch.mm(dg[i], w_hcat, out=dh_buf[i & 1])
         dgf = dg.view(steps * n, W)
@@ -295,7 +298,7 @@ class TeacherForcedLoop(torch.autograd.Function):
         d_gates = dg[:, :, A:A + H4]
         d_w_att = d_gates.reshape(steps * n, H4).t().mm(att.view(steps * n, C))
         return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates.sum(0), d_gates.permute(1, 0, 2), d_w_hcat, d_b_hcat,
-                d_w_att, g_aw, g_ab, None, None, None, None)
+                d_w_att, g_aw, g_ab, None, None, None, None, None)
 
 
 def _fp32_island(fn):
@@ -372,13 +375,23 @@ class Captioner(nn.Module):
         return F.log_softmax(self.logit(self.dropout(output)), dim=1), state
 
     @_fp32_island
-    def forward(self, hs, reference, others, cap_tensor, steps=None):
-        """Teacher-forced log-probs (LSTM_DSA.py:63-117) -> (B*Q, steps, vocab+1)."""
+    def forward(self, hs, reference, others, cap_tensor, steps=None, row_video=None):
+        """Teacher-forced log-probs (LSTM_DSA.py:63-117) -> (B*Q, steps, vocab+1).
+        row_video (n,) int64: the COMPACT row form of the layout-independent train step -- hs (n, C) and reference (n, RD)
+        are rows of any video (row_video[r], negative = unused row of the fixed-capacity row set) instead of (B, Q, .)."""
         seq = cap_tensor.long()
-        vid_num, query_num, _ = hs.shape
-        ref_in = self._scaled_reference(reference, others)
+        if row_video is not None:
+            if not (torch.is_grad_enabled() and self.core.fused_train_eligible(hs)
+                    and not (self.training and self.ss_prob > 0.0)):
+                raise RuntimeError("compact caption rows need the fused teacher-forced path")
+            vr = others['valid_ratios'][row_video.clamp(min=0)]                      # (n, L)
+            ref_in = reference[:, None, :] * (torch.stack([vr] * 2, -1) if reference.shape[-1] == 2 else vr[..., None])
+            n = hs.shape[0]
+        else:
+            vid_num, query_num, _ = hs.shape
+            ref_in = self._scaled_reference(reference, others)
+            n = vid_num * query_num
         memory, tshapes, lsi, mask, ref_in = self._level_inputs(others, ref_in)
-        n = vid_num * query_num
         const = self.core.prepare(hs, memory, mask)
         h = hs.new_zeros(n, self.rnn_size)
         c = hs.new_zeros(n, self.rnn_size)
@@ -396,9 +409,14 @@ class Captioner(nn.Module):
             # does not depend on it is batched over time -- the embedding part of the LSTM input GEMM before the loop,
             # the vocabulary GEMM + log_softmax after it -- so their weights see ONE forward and ONE gradient GEMM
             # instead of `steps` of each followed by `steps` accumulations of a 17 MB gradient.
-            xt_all = F.linear(self.embed(seq[:, :steps]), w_x)                    # (n, steps, 4H)
+            # embedding rows by index_select: its backward is an atomic index_add.  nn.Embedding's backward switches to
+            # a rocPRIM radix sort above 3072 indices (512 padded rows x 11 steps), and that path faulted when replayed
+            # from a hipGraph on MI355X / ROCm 7.2 (eager was fine)
+            ids = seq[:, :steps]
+            emb = self.embed.weight.index_select(0, ids.reshape(-1)).view(*ids.shape, -1)
+            xt_all = F.linear(emb, w_x)                                           # (n, steps, 4H)
             if torch.is_grad_enabled() and self.core.fused_train_eligible(hs):
-                hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const)
+                hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const, row_video)
                 return F.log_softmax(self.logit(self.dropout(hidden)), dim=2)
             hidden = []
             for i in range(steps):

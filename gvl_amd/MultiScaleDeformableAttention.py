@@ -248,13 +248,24 @@ def _f32_rows(name, t_, cols):
              f"{name} must be an fp32 CUDA matrix with {cols} unit-stride columns")
 
 
+def _cap_rows(ref_in, row_video, B):
+    """(Q argument, number of rows, row_video pointer) of the two row layouts of gvl_cap_attend_train_*"""
+    if row_video is None:
+        _require(ref_in.dim() == 4 and ref_in.shape[0] == B, "cap_attend_train: ref_in must be (B, Q, L, RD)")
+        return ref_in.shape[1], B * ref_in.shape[1], None
+    _require(ref_in.dim() == 3 and row_video.is_cuda and row_video.dtype == torch.int64 and row_video.is_contiguous()
+             and row_video.numel() == ref_in.shape[0],
+             "cap_attend_train: compact form needs ref_in (n, L, RD) and row_video (n,) int64 on the device")
+    return ref_in.shape[0], ref_in.shape[0], row_video.data_ptr()
+
+
 def cap_attend_train_forward(slab, spatial_shapes, level_start_index, ref_in, off_hs, off_h, att_h, alpha_w, alpha_b,
-                             n_levels, n_points, att_res=None, alpha_out=None):
+                             n_levels, n_points, att_res=None, alpha_out=None, row_video=None):
     """include/gvl_msda.h: gvl_cap_attend_train_forward_f32 -> (att_res (n,C), alpha (n,16)); off_h / att_h may be
-    column blocks of one GEMM output (row strides are passed on)."""
+    column blocks of one GEMM output (row strides are passed on).  row_video: the compact row form (ref_in (n,L,RD))."""
     B, S, C2 = slab.shape
-    C, Q, RD, K = C2 // 2, ref_in.shape[1], ref_in.shape[-1], n_levels * n_points
-    n = B * Q
+    C, RD, K = C2 // 2, ref_in.shape[-1], n_levels * n_points
+    Q, n, rv = _cap_rows(ref_in, row_video, B)
     for name, t_ in (("slab", slab), ("ref_in", ref_in), ("off_hs", off_hs), ("alpha_w", alpha_w), ("alpha_b", alpha_b)):
         _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
                  f"cap_attend_train: {name} must be a contiguous fp32 CUDA tensor")
@@ -268,7 +279,7 @@ def cap_attend_train_forward(slab, spatial_shapes, level_start_index, ref_in, of
         rc = _lib.lib().gvl_cap_attend_train_forward_f32(
             slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
             off_hs.data_ptr(), off_h.data_ptr(), off_h.stride(0), att_h.data_ptr(), att_h.stride(0),
-            alpha_w.data_ptr(), alpha_b.data_ptr(), B, S, C, n_levels, Q, n_points, RD, att_res.data_ptr(),
+            alpha_w.data_ptr(), alpha_b.data_ptr(), B, S, C, n_levels, Q, n_points, RD, rv, att_res.data_ptr(),
             alpha_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "cap_attend_train_forward")
     return att_res, alpha_out
@@ -276,11 +287,12 @@ def cap_attend_train_forward(slab, spatial_shapes, level_start_index, ref_in, of
 
 def cap_attend_train_backward(slab, spatial_shapes, level_start_index, ref_in, off_hs, off_h, att_h, alpha_w, alpha,
                               grad_att_res, n_levels, n_points, grad_slab, grad_att_h, grad_off, grad_ref,
-                              grad_alpha_w, grad_alpha_b):
+                              grad_alpha_w, grad_alpha_b, row_video=None):
     """include/gvl_msda.h: gvl_cap_attend_train_backward_f32.  grad_att_h / grad_off are overwritten (may be column
     blocks of one matrix); grad_slab / grad_ref / grad_alpha_w / grad_alpha_b are accumulated into."""
     B, S, C2 = slab.shape
-    C, Q, RD, K = C2 // 2, ref_in.shape[1], ref_in.shape[-1], n_levels * n_points
+    C, RD, K = C2 // 2, ref_in.shape[-1], n_levels * n_points
+    Q, _, rv = _cap_rows(ref_in, row_video, B)
     _f32_rows("cap_attend_train: grad_att_res", grad_att_res, C)
     _f32_rows("cap_attend_train: grad_att_h", grad_att_h, C)
     _f32_rows("cap_attend_train: grad_off", grad_off, 16)
@@ -293,7 +305,7 @@ def cap_attend_train_backward(slab, spatial_shapes, level_start_index, ref_in, o
             slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
             off_hs.data_ptr(), off_h.data_ptr(), off_h.stride(0), att_h.data_ptr(), att_h.stride(0),
             alpha_w.data_ptr(), alpha.data_ptr(), grad_att_res.data_ptr(), grad_att_res.stride(0), B, S, C, n_levels,
-            Q, n_points, RD, grad_slab.data_ptr(), grad_att_h.data_ptr(), grad_att_h.stride(0), grad_off.data_ptr(),
+            Q, n_points, RD, rv, grad_slab.data_ptr(), grad_att_h.data_ptr(), grad_att_h.stride(0), grad_off.data_ptr(),
             grad_off.stride(0), grad_ref.data_ptr(), grad_alpha_w.data_ptr(), grad_alpha_b.data_ptr(),
             torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "cap_attend_train_backward")

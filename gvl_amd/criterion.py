@@ -208,9 +208,10 @@ class SetCriterion(nn.Module):
         """every loss term of every decoder layer from ONE autograd node (SetCriterionFunction)"""
         plan = matches[0].plan
         nl = len(layers)
-        logits = torch.stack([o['pred_logits'] for o in layers])
-        counts = torch.stack([o['pred_count'] for o in layers])
-        boxes = torch.stack([o['pred_boxes'] for o in layers])
+        # (.float(): a no-op in fp32; under autocast the heads emit bf16 and the criterion kernels are an fp32 island)
+        logits = torch.stack([o['pred_logits'] for o in layers]).float()
+        counts = torch.stack([o['pred_count'] for o in layers]).float()
+        boxes = torch.stack([o['pred_boxes'] for o in layers]).float()
         rows, cols = matches[0].rows_all, matches[0].cols_all           # (nl * t1 + ...) laid out layer-major
         mq, mt = rows[:nl * plan.t1].view(nl, plan.t1), cols[:nl * plan.t1].view(nl, plan.t1)
         dev = logits.device
@@ -242,7 +243,7 @@ class SetCriterion(nn.Module):
         """can this step run in the layout-independent form (PaddedTargets in, everything on the device)?"""
         lg = outputs['pred_logits']
         layers = [outputs] + list(outputs.get('aux_outputs', []))
-        return (self.fused and self.device_matching and lg.is_cuda and lg.dtype == torch.float32
+        return (self.fused and self.device_matching and lg.is_cuda
                 and set(self.losses) == {'labels', 'boxes', 'cardinality'} and lg.shape[0] * lg.shape[1] <= 24576
                 and hasattr(self.matcher, "match_layers_padded")
                 and self.matcher.padded_eligible(layers, lg.shape[1], pt.slots))

@@ -148,13 +148,21 @@ __global__ void __launch_bounds__(kRowWaves * 64) k_cap_train_fwd(
     const float *__restrict__ slab, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ ref, const float *__restrict__ off_hs, const float *__restrict__ off_h, int off_h_ld,
     const float *__restrict__ att_h, int att_h_ld, const float *__restrict__ alpha_w,
-    const float *__restrict__ alpha_b, int S, int L, int Q, int P, int RD, float *__restrict__ att_res,
-    float *__restrict__ alpha_out) {
+    const float *__restrict__ alpha_b, int S, int L, int Q, int P, int RD, const int64_t *__restrict__ row_video,
+    float *__restrict__ att_res, float *__restrict__ alpha_out) {
   __shared__ float sh_e[kLP];
   __shared__ float sh_acc[kRowWaves][64][8];
   const int64_t row = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k_own = lane >> 2, LP = L * P;
-  const int b = (int)(row / Q);
+  // rows grouped per video (Q rows each), or -- compact form -- the video of every row given explicitly; a negative
+  // entry marks an unused row of a fixed-capacity (padded) row set: zeros out, no work
+  const int b = row_video ? (int)row_video[row] : (int)(row / Q);
+  if (b < 0) {
+    att_res[row * kC + threadIdx.x] = 0.f;
+    att_res[row * kC + 256 + threadIdx.x] = 0.f;
+    if (threadIdx.x < kLP) alpha_out[row * kLP + threadIdx.x] = 0.f;
+    return;
+  }
   const RowSetup rs = setup_row(shapes, lsi, ref, off_hs, off_h + row * (int64_t)off_h_ld, row, k_own, L, P, RD);
   const float4 *ah4 = reinterpret_cast<const float4 *>(att_h + row * (int64_t)att_h_ld);
   const float4 ta = ah4[lane], tb = ah4[64 + lane];
@@ -247,13 +255,20 @@ __global__ void __launch_bounds__(kRowWaves * 64) k_cap_train_bwd(
     const float *__restrict__ ref, const float *__restrict__ off_hs, const float *__restrict__ off_h, int off_h_ld,
     const float *__restrict__ att_h, int att_h_ld, const float *__restrict__ alpha_w,
     const float *__restrict__ alpha_saved, const float *__restrict__ g_att, int g_att_ld, int S, int L, int Q, int P,
-    int RD, float *__restrict__ g_slab, float *__restrict__ g_att_h, int g_att_h_ld, float *__restrict__ g_off,
-    int g_off_ld, float *__restrict__ g_ref, float *__restrict__ g_alpha_w, float *__restrict__ g_alpha_b) {
+    int RD, const int64_t *__restrict__ row_video, float *__restrict__ g_slab, float *__restrict__ g_att_h,
+    int g_att_h_ld, float *__restrict__ g_off, int g_off_ld, float *__restrict__ g_ref,
+    float *__restrict__ g_alpha_w, float *__restrict__ g_alpha_b) {
   __shared__ float sh_da[kLP], sh_dx[kLP];
   __shared__ float sh_part[kRowWaves][64][16];
   const int64_t row = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k_own = lane >> 2, LP = L * P;
-  const int b = (int)(row / Q);
+  const int b = row_video ? (int)row_video[row] : (int)(row / Q);
+  if (b < 0) {                                       // unused row of a padded row set: its overwritten outputs are zero
+    g_att_h[row * (int64_t)g_att_h_ld + threadIdx.x] = 0.f;
+    g_att_h[row * (int64_t)g_att_h_ld + 256 + threadIdx.x] = 0.f;
+    if (threadIdx.x < kLP) g_off[row * (int64_t)g_off_ld + threadIdx.x] = 0.f;
+    return;
+  }
   const RowSetup rs = setup_row(shapes, lsi, ref, off_hs, off_h + row * (int64_t)off_h_ld, row, k_own, L, P, RD);
   const float alpha = k_own < LP ? alpha_saved[row * kLP + k_own] : 0.f;
   float4 ga, gb;
@@ -420,41 +435,45 @@ extern "C" {
 int gvl_cap_attend_train_forward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                                      const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
                                      int att_h_ld, const float *alpha_w, const float *alpha_b, int B, int S, int C,
-                                     int L, int Q, int P, int RD, float *att_res, float *alpha_out, void *stream) {
-  if (int rc = check_cap("gvl_cap_attend_train_forward_f32", B, S, C, L, Q, P, RD)) return rc;
+                                     int L, int Q, int P, int RD, const int64_t *row_video, float *att_res,
+                                     float *alpha_out, void *stream) {
+  if (int rc = check_cap("gvl_cap_attend_train_forward_f32", row_video ? 1 : B, S, C, L, Q, P, RD)) return rc;
+  const int64_t n_rows = row_video ? (int64_t)Q : (int64_t)B * Q;
   if (att_h_ld < C || (att_h_ld & 3) || off_h_ld < L * P)
     return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: bad leading dimensions");
-  if ((int64_t)B * Q == 0) return 0;
+  if (n_rows == 0) return 0;
   if (!slab || !shapes || !lsi || !ref || !off_hs || !off_h || !att_h || !alpha_w || !alpha_b || !att_res || !alpha_out)
     return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: null pointer");
   if (((uintptr_t)att_h & 15) || ((uintptr_t)att_res & 15))
     return fail(GVL_EINVAL, "gvl_cap_attend_train_forward_f32: att_h / att_res must be 16-byte aligned");
-  return gvl::launch(GVL_PROF_CAP_TRAIN_FWD, B * Q, B, "k_cap_train_fwd", k_cap_train_fwd, dim3(B * Q), dim3(256), 0,
-                     (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld, alpha_w,
-                     alpha_b, S, L, Q, P, RD, att_res, alpha_out);
+  return gvl::launch(GVL_PROF_CAP_TRAIN_FWD, (int)n_rows, B, "k_cap_train_fwd", k_cap_train_fwd, dim3((unsigned)n_rows),
+                     dim3(256), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld,
+                     alpha_w, alpha_b, S, L, Q, P, RD, row_video, att_res, alpha_out);
 }
 
 int gvl_cap_attend_train_backward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                                       const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
                                       int att_h_ld, const float *alpha_w, const float *alpha_saved,
                                       const float *grad_att_res, int grad_att_res_ld, int B, int S, int C, int L, int Q,
-                                      int P, int RD, float *grad_slab, float *grad_att_h, int grad_att_h_ld,
+                                      int P, int RD, const int64_t *row_video, float *grad_slab, float *grad_att_h,
+                                      int grad_att_h_ld,
                                       float *grad_off, int grad_off_ld, float *grad_ref, float *grad_alpha_w,
                                       float *grad_alpha_b, void *stream) {
-  if (int rc = check_cap("gvl_cap_attend_train_backward_f32", B, S, C, L, Q, P, RD)) return rc;
+  if (int rc = check_cap("gvl_cap_attend_train_backward_f32", row_video ? 1 : B, S, C, L, Q, P, RD)) return rc;
+  const int64_t n_rows = row_video ? (int64_t)Q : (int64_t)B * Q;
   if (att_h_ld < C || (att_h_ld & 3) || off_h_ld < L * P || grad_att_res_ld < C || (grad_att_res_ld & 3) ||
       grad_att_h_ld < C || (grad_att_h_ld & 3) || grad_off_ld < kLP)
     return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: bad leading dimensions");
-  if ((int64_t)B * Q == 0) return 0;
+  if (n_rows == 0) return 0;
   if (!slab || !shapes || !lsi || !ref || !off_hs || !off_h || !att_h || !alpha_w || !alpha_saved || !grad_att_res ||
       !grad_slab || !grad_att_h || !grad_off || !grad_ref || !grad_alpha_w || !grad_alpha_b)
     return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: null pointer");
   if (((uintptr_t)att_h & 15) || ((uintptr_t)grad_att_res & 15) || ((uintptr_t)grad_att_h & 15))
     return fail(GVL_EINVAL, "gvl_cap_attend_train_backward_f32: row pointers must be 16-byte aligned");
-  return gvl::launch(GVL_PROF_CAP_TRAIN_BWD, B * Q, B, "k_cap_train_bwd", k_cap_train_bwd, dim3(B * Q), dim3(256), 0,
-                     (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld, alpha_w,
-                     alpha_saved, grad_att_res, grad_att_res_ld, S, L, Q, P, RD, grad_slab, grad_att_h, grad_att_h_ld,
-                     grad_off, grad_off_ld, grad_ref, grad_alpha_w, grad_alpha_b);
+  return gvl::launch(GVL_PROF_CAP_TRAIN_BWD, (int)n_rows, B, "k_cap_train_bwd", k_cap_train_bwd, dim3((unsigned)n_rows),
+                     dim3(256), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, off_h, off_h_ld, att_h, att_h_ld,
+                     alpha_w, alpha_saved, grad_att_res, grad_att_res_ld, S, L, Q, P, RD, row_video, grad_slab,
+                     grad_att_h, grad_att_h_ld, grad_off, grad_off_ld, grad_ref, grad_alpha_w, grad_alpha_b);
 }
 
 int gvl_lstm_cell_train_forward_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *gates_c,

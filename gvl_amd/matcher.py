@@ -70,6 +70,15 @@ def hungarian_batch(C, sizes, m2o_rate=4, num_threads=0):
     return indices, rl
 
 
+def lsap_launch(C, problems, max_rows, max_cols, rows, cols, status):
+    """one solver launch over `problems` (a contiguous row block of a descriptor tensor) into existing result buffers"""
+    with torch.cuda.device(C.device):
+        rc = _lib.lib().gvl_lsap_batch_device_f32(C.data_ptr(), problems.data_ptr(), problems.shape[0], max_rows,
+                                                  max_cols, rows.data_ptr(), cols.data_ptr(), status.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "lsap_batch_device")
+
+
 def lsap_batch_device(C, problems, out_total, max_rows, max_cols, fill=None):
     """Solve assignment problems on the device (include/gvl_msda.h: gvl_lsap_batch_device_f32).
     C: float32 CUDA tensor (any shape; problems index its storage); problems: int64 CUDA tensor (n, 8) of
@@ -83,11 +92,7 @@ def lsap_batch_device(C, problems, out_total, max_rows, max_cols, fill=None):
         rows = torch.full((2, out_total), fill, dtype=torch.int64, device=C.device)
         rows, cols = rows[0], rows[1]
     status = torch.zeros(1, dtype=torch.int32, device=C.device)
-    with torch.cuda.device(C.device):
-        rc = _lib.lib().gvl_lsap_batch_device_f32(C.data_ptr(), problems.data_ptr(), problems.shape[0], max_rows,
-                                                  max_cols, rows.data_ptr(), cols.data_ptr(), status.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "lsap_batch_device")
+    lsap_launch(C, problems, max_rows, max_cols, rows, cols, status)
     return rows, cols, status
 
 
@@ -118,6 +123,7 @@ class MatchPlan:
                 desc.append([((l * B + i) * Q) * G + coff[i], G, Q, n, m2o_rate, o, 0, 0])
                 o += self.n4[i]
         desc = [d for d in desc if d[3] > 0]                       # videos without GT have no problem
+        self.n_one = sum(1 for d in desc if d[4] == 1)             # the one-to-one problems come first
         self.problems = torch.tensor(desc, dtype=torch.int64, device=device).reshape(-1, 8)
         self.out_total = nl * (t1 + t4)
         self.max_rows = max([1] + [min(Q, n * m2o_rate) for n in sizes])
@@ -151,6 +157,7 @@ class PaddedMatchPlan:
                 for i in range(B):
                     desc.append([((l * B + i) * Q) * slots, slots, Q, 0, tile, first + (l * B + i) * per, 0, 0])
         self.problems = torch.tensor(desc, dtype=torch.int64, device=device).reshape(-1, 8)
+        self.n_one = nl * B
         self.out_total = nl * (self.t1 + self.t4)
         self.max_rows, self.max_cols = min(Q, slots * m2o_rate), max(Q, slots * m2o_rate)
         ar = torch.arange(B, dtype=torch.int64, device=device)
@@ -166,20 +173,59 @@ class PaddedMatchPlan:
         self.valid = self.slot_of_entry < self.pair_count[self.vid_of_entry]
 
 
+class ManyToOne:
+    """The 4x-tiled many-to-one assignment (matcher.py:125-128), solved ON DEMAND.  The reference computes it in every
+    matcher call and returns it as the second element of `indices`, but nothing on its path reads it (criterion.py:52,108
+    unpack and drop it; pdvc.py:419,524,617,647 take `[0]`), and its problems are 4x taller -- ~90 % of the solver's time.
+    Here the problems (same cost tensor, same descriptors) are solved the first time someone asks --
+    ``LayerMatch[1]`` / ``.rl_q`` / ``.rl_t`` -- with the same kernel, into the same result buffers, bit-identical."""
+
+    def __init__(self, C, plan, rows, cols, status):
+        self.C, self.plan, self.rows, self.cols, self.status = C, plan, rows, cols, status
+        self.done = False
+
+    @torch.no_grad()
+    def ensure(self):
+        if not self.done:
+            p_ = self.plan
+            if p_.problems.shape[0] > p_.n_one:
+                lsap_launch(self.C, p_.problems[p_.n_one:], p_.max_rows, p_.max_cols, self.rows, self.cols, self.status)
+            self.done = True
+
+
 class LayerMatch:
     """The matching of one decoder layer, resident on the device.  ``q`` / ``t``: matched query id and (video-local)
     target id of every match, videos concatenated; ``t_global`` the target's row in the concatenated targets.
     Indexing ([0] -> indices, [1] -> rl_indices) materialises the reference's host structure (one copy)."""
 
-    def __init__(self, plan, layer, rows, cols, status, ok, targets=None):
+    def __init__(self, plan, layer, rows, cols, status, ok, targets=None, many=None):
         self.plan, self.layer, self.targets = plan, layer, targets      # targets: PaddedTargets of a padded plan
         a = layer * plan.t1
         self.q, self.t = rows[a:a + plan.t1], cols[a:a + plan.t1]
         b = plan.nl * plan.t1 + layer * plan.t4
-        self.rl_q, self.rl_t = rows[b:b + plan.t4], cols[b:b + plan.t4]
+        self._rl = (rows[b:b + plan.t4], cols[b:b + plan.t4])
+        self.many = many                                                # ManyToOne shared by the layers of one step
         self.status, self.ok = status, ok
         self.rows_all, self.cols_all = rows, cols       # all layers, for consumers that process the layers together
         self._host = None
+
+    @property
+    def rl_q(self):
+        if self.many is not None:
+            self.many.ensure()
+        return self._rl[0]
+
+    @property
+    def rl_t(self):
+        if self.many is not None:
+            self.many.ensure()
+        return self._rl[1]
+
+    def invalidate(self):
+        """the device buffers behind this match were rewritten (a hipGraph replay): drop everything derived from them"""
+        self._host = None
+        if self.many is not None:
+            self.many.done = False
 
     @property
     def t_global(self):
@@ -191,25 +237,31 @@ class LayerMatch:
             raise ValueError("cost matrix is infeasible / contains invalid numeric entries")
         assert bool(self.ok.all()), "degenerate boxes (x1 < x0) in the matcher"
 
-    def host(self):
+    def _split(self, q, t_, per, tile):
+        """flat result slots -> the reference's per-video (query ids, target ids) lists"""
+        p_ = self.plan
+        q, t_ = q.cpu(), t_.cpu()
+        if getattr(p_, "padded", False):     # padded result slots; the counts of the loaded batch are known on the host
+            ns = [min(p_.Q, n * tile) for n in self.targets.host_counts]
+            return [(q.view(p_.B, per)[i, :n], t_.view(p_.B, per)[i, :n]) for i, n in enumerate(ns)]
+        sizes = p_.n1 if tile == 1 else p_.n4
+        return [(a, b) for a, b in zip(q.split(sizes), t_.split(sizes))]
+
+    def host(self, kind=None):
+        """the reference's host structure (matcher.py:124-131): kind 0 -> indices, 1 -> rl_indices (solved on demand),
+        None -> both"""
         if self._host is None:
             self.check()
-            q, t_, rq, rt = (x.cpu() for x in (self.q, self.t, self.rl_q, self.rl_t))
-            if getattr(self.plan, "padded", False):
-                # padded result slots -> the reference's per-video lists (host-known counts of the loaded batch)
-                p_, ns = self.plan, self.targets.host_counts
-                one = [(q.view(p_.B, p_.G1)[i, :min(p_.Q, n)], t_.view(p_.B, p_.G1)[i, :min(p_.Q, n)])
-                       for i, n in enumerate(ns)]
-                many = [(rq.view(p_.B, p_.G4)[i, :min(p_.Q, n * p_.m2o)], rt.view(p_.B, p_.G4)[i, :min(p_.Q, n * p_.m2o)])
-                        for i, n in enumerate(ns)]
-                self._host = (one, many)
-                return self._host
-            self._host = ([(a, b) for a, b in zip(q.split(self.plan.n1), t_.split(self.plan.n1))],
-                          [(a, b) for a, b in zip(rq.split(self.plan.n4), rt.split(self.plan.n4))])
+            self._host = [None, None]
+        p_ = self.plan
+        if kind in (0, None) and self._host[0] is None:
+            self._host[0] = self._split(self.q, self.t, getattr(p_, "G1", 0), 1)
+        if kind in (1, None) and self._host[1] is None:
+            self._host[1] = self._split(self.rl_q, self.rl_t, getattr(p_, "G4", 0), p_.m2o)
         return self._host
 
     def __getitem__(self, k):
-        return self.host()[k]
+        return self.host(k)[k]
 
     def __iter__(self):
         return iter(self.host())
@@ -279,8 +331,10 @@ class HungarianMatcher(nn.Module):
         plan = self._plan(nl, B, Q, sizes, C.device)
         if plan.max_rows > self.LSAP_DEVICE_MAX_ROWS or plan.max_cols > self.LSAP_DEVICE_MAX_COLS:
             return None                                   # beyond the on-chip solver: caller takes the host path
-        rows, cols, status = lsap_batch_device(C, plan.problems, plan.out_total, plan.max_rows, plan.max_cols)
-        return [LayerMatch(plan, l, rows, cols, status, ok) for l in range(nl)]
+        rows, cols, status = lsap_batch_device(C, plan.problems[:plan.n_one], plan.out_total, plan.max_rows,
+                                               plan.max_cols)
+        many = ManyToOne(C, plan, rows, cols, status)               # the 4x-tiled problems: solved when first read
+        return [LayerMatch(plan, l, rows, cols, status, ok, many=many) for l in range(nl)]
 
     LSAP_DEVICE_MAX_ROWS, LSAP_DEVICE_MAX_COLS = 256, 1024        # on-chip limits of k_lsap (gvl_lsap_dev.hip)
 
@@ -291,7 +345,7 @@ class HungarianMatcher(nn.Module):
         extra = any(isinstance(o.get('cl_match_mats', 0), torch.Tensor) and self.cost_cl != 0 for o in outputs_list) \
             or (self.opt is not None and getattr(self.opt, "set_cost_caption", 0) > 0
                 and any('cap_cost_mat' in o for o in outputs_list))
-        return (not extra and first["pred_logits"].is_cuda and first["pred_logits"].dtype == torch.float32
+        return (not extra and first["pred_logits"].is_cuda
                 and min(Q, slots * m2o_rate) <= self.LSAP_DEVICE_MAX_ROWS
                 and max(Q, slots * m2o_rate) <= self.LSAP_DEVICE_MAX_COLS)
 
@@ -300,8 +354,8 @@ class HungarianMatcher(nn.Module):
         """match_layers_device on ``PaddedTargets``: cost blocks (nl, B, Q, slots) from gvl_match_cost_padded_f32, one
         solver launch over 2 * nl * B fixed problem slots whose sizes come from ``pt.counts`` on the device.  No
         tensor shape, launch parameter or host value depends on the number of events per video."""
-        logits = torch.stack([o["pred_logits"] for o in outputs_list]).contiguous()
-        boxes = torch.stack([o["pred_boxes"] for o in outputs_list]).contiguous()
+        logits = torch.stack([o["pred_logits"] for o in outputs_list]).float().contiguous()
+        boxes = torch.stack([o["pred_boxes"] for o in outputs_list]).float().contiguous()
         nl, B, Q, NC = logits.shape
         key = ("padded", nl, B, Q, pt.slots, str(logits.device), m2o_rate)
         plan = self._plans.get(key)
@@ -317,8 +371,10 @@ class HungarianMatcher(nn.Module):
                 float(self.cost_alpha), float(self.cost_gamma), C.data_ptr(), ok.data_ptr(),
                 torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "match_cost_padded")
-        rows, cols, status = lsap_batch_device(C, plan.problems, plan.out_total, plan.max_rows, plan.max_cols, fill=-1)
-        return [LayerMatch(plan, l, rows, cols, status, ok, targets=pt) for l in range(nl)]
+        rows, cols, status = lsap_batch_device(C, plan.problems[:plan.n_one], plan.out_total, plan.max_rows,
+                                               plan.max_cols, fill=-1)
+        many = ManyToOne(C, plan, rows, cols, status)               # the 4x-tiled problems: solved when first read
+        return [LayerMatch(plan, l, rows, cols, status, ok, targets=pt, many=many) for l in range(nl)]
 
     @torch.no_grad()
     def cost_matrices(self, outputs_list, targets, tgt_cat, fused=None):

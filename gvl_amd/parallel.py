@@ -18,7 +18,7 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
-from .targets import PaddedTargets, needed_capacity, round_up_pow2
+from .targets import PaddedTargets, needed_capacity, round_up_pow2, total_events
 
 
 def shard_batch(dt, rank, world):
@@ -213,10 +213,10 @@ def _drop_superseded(graphs, key):
 class _PaddedBatch:
     """static device buffers of one captured step: the three feature tensors of pdvc.py:250-258 + PaddedTargets"""
 
-    def __init__(self, dt, slots, cap_len):
+    def __init__(self, dt, slots, cap_len, pair_rows=0):
         dev = dt["video_tensor"].device
         self.dt = {k: dt[k].clone() for k in _STATIC_KEYS}
-        self.targets = PaddedTargets(dt["video_tensor"].shape[0], slots, cap_len, dev)
+        self.targets = PaddedTargets(dt["video_tensor"].shape[0], slots, cap_len, dev, pair_rows)
         self.dt["_gvl_targets"] = self.targets
         # paths that still want the reference's list (LayerMatch.host(), PostProcess) are served from the host counts
         self.dt["video_target"] = None
@@ -233,17 +233,19 @@ class _PaddedBatch:
 
 class _Capacity:
     """Grow-only capacities of the padded layout: slots per video = next power of two >= the largest event count seen
-    (>= 4), caption width = next multiple of 4 >= the widest caption tensor seen.  A batch that does not fit raises the
-    capacity and the step is captured again; in a steady run that happens a handful of times, then never."""
+    (>= 4), caption width = next multiple of 4 >= the widest caption tensor seen, caption rows (matched pairs of a
+    whole batch, train only) = next multiple of 32 >= the largest event total seen.  A batch that does not fit raises
+    the capacity and the step is captured again; in a steady run that happens a handful of times, then never."""
 
-    def __init__(self, slots=0, cap_len=0):
-        self.slots, self.cap_len = int(slots or 0), int(cap_len or 0)
+    def __init__(self, slots=0, cap_len=0, pair_rows=0):
+        self.slots, self.cap_len, self.pair_rows = int(slots or 0), int(cap_len or 0), int(pair_rows or 0)
 
     def fit(self, dt, with_captions):
         n_gt, cap_len = needed_capacity(dt)
         self.slots = max(self.slots, round_up_pow2(n_gt, 4))
         if with_captions:
             self.cap_len = max(self.cap_len, 4 * ((max(cap_len, 2) + 3) // 4))
+            self.pair_rows = max(self.pair_rows, 32 * ((max(total_events(dt), 1) + 31) // 32))
         return self.slots, (self.cap_len if with_captions else 0)
 
 
@@ -266,19 +268,21 @@ class GraphedTrainStep(TrainStep):
     the RNG state exactly as they were (snapshot / restore), so every batch gets ONE update, as in train.py."""
 
     def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=2, split_exchange=None,
-                 autocast_dtype=None, max_graphs=4, max_gt=0, max_cap_len=0, padded=None):
+                 autocast_dtype=None, max_graphs=4, max_gt=0, max_cap_len=0, max_events=0, padded=None):
         """split_exchange (default: exactly when there is more than one process): the step is captured as TWO graphs --
         zero_grad + forward + backward into the flat gradient buffer, then clip + Adam -- with the bucketed RCCL
         all-reduce issued eagerly between the two replays, so no collective is ever inside a hipGraph.  The criterion's
         own ``all_reduce(num_boxes)`` (criterion.py:178-180) is taken before the first graph from the host-known
         target counts and reaches the captured criterion through device memory.
-        max_gt / max_cap_len: initial capacities of the padded layout (0 = grow from the batches seen).
+        max_gt / max_cap_len / max_events: initial capacities of the padded layout -- events per video, caption tensor
+        width, events per batch (0 = grow from the batches seen).
         padded: None = automatic, False = always one graph per batch layout."""
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
         super().__init__(model, criterion, opt, world_size, process_group, capturable=True,
                          flat=True if self.split else None, overlap=not self.split, autocast_dtype=autocast_dtype)
         self.graphs = _LRU(max_graphs)
-        self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, max_cap_len)
+        self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, max_cap_len,
+                                  32 * ((max_events + 31) // 32) if max_events else 0)
         self.padded = padded
         self.captures = self.replays = 0
         # >= 1 real step must run before the capture (on a side stream): autograd's gradient accumulators, hipBLASLt
@@ -416,11 +420,12 @@ class GraphedTrainStep(TrainStep):
         nb = self._global_num_boxes(dt) if self.split else None      # every rank, every step (a collective at N > 1)
         if self._use_padded(dt):
             slots, cap_len = self.capacity.fit(dt, with_captions=True)
-            key = ("padded", tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in _STATIC_KEYS), slots, cap_len)
+            rows = min(self.capacity.pair_rows, dt["video_tensor"].shape[0] * min(slots, self.opt.num_queries))
+            key = ("padded", tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in _STATIC_KEYS), slots, cap_len, rows)
             entry = self.graphs.lookup(key)
             if entry is None:
                 _drop_superseded(self.graphs, key)
-                batch = _PaddedBatch(dt, slots, cap_len)
+                batch = _PaddedBatch(dt, slots, cap_len, rows)
                 batch.load(dt, nb)
                 graphs, outs = self._capture(batch.dt)
                 entry = (graphs, batch, outs)
@@ -488,9 +493,16 @@ class GraphedEvalForward:
         return (self.model.supports_padded_targets(self.criterion, eval_mode=True)
                 and round_up_pow2(needed_capacity(dt)[0], 4) <= min(64, self.model.opt.num_queries))
 
+    def _autocast(self):
+        return torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None)
+
     def _forward(self, dt):
-        with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+        with self._autocast():
             return self.model(dt, self.criterion, None, self.kind, eval_mode=True)
+
+    def _continue(self, head, a, b):
+        with self._autocast():
+            return head.decode_continue(a, b)
 
     @staticmethod
     def _matches(out):
@@ -524,7 +536,7 @@ class GraphedEvalForward:
                 for _ in range(self.warmup):
                     self._forward(st)
                     for a, b in zip(bounds[:-1], bounds[1:]):
-                        head.decode_continue(a, b)
+                        self._continue(head, a, b)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
@@ -535,7 +547,7 @@ class GraphedEvalForward:
             for a, b in zip(bounds[:-1], bounds[1:]):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=graph.pool(), stream=side):
-                    flags.append(head.decode_continue(a, b))
+                    flags.append(self._continue(head, a, b))
                 seg_graphs.append(g)
         finally:
             for h_ in heads:
@@ -577,7 +589,7 @@ class GraphedEvalForward:
         self.replays += 1
         out = dict(out)
         for m in self._matches(out):
-            m._host = None                                   # the device indices changed under the cached host copy
+            m.invalidate()                                   # the device indices changed under the cached host copy
         if flags[0] is not None and isinstance(out.get("seq"), torch.Tensor) and not self.model.opt.eval_disable_captioning:
             # the forward's only host reads (LSTM_DSA.py:186-187): one per decode segment that ran
             alive = flags[0].cpu().tolist()

@@ -343,41 +343,53 @@ class PDVC(nn.Module):
                 and (dt is None or all(len(t_['boxes']) <= hs.shape[2] for t_ in dt['video_target'])))
 
     def caption_prediction_layers_padded(self, cap_head, pt, hs_layers, ref_layers, others, matches):
-        """caption_prediction_layers on PaddedTargets: video v owns rows [k * G1, (k + 1) * G1) for decoder layer k, of
-        which the first pair_count[v] carry a matched (query, caption) pair; the others are fed the <pad> caption with
-        an all-zero mask (loss and gradient contribution exactly 0).  The teacher-forced loop runs the full static
-        cap_len - 1 steps: steps beyond the longest caption of the batch only see masked positions, so the loss equals
-        the reference's, which leaves the loop at the first all-<pad> input column (LSTM_DSA.py:110-112).  The mean
-        over (videos x max pairs) rows of pdvc.py:868 divides by a DEVICE scalar.  No shape depends on the batch."""
+        """caption_prediction_layers on PaddedTargets, with a COMPACT fixed-capacity row set: decoder layer k owns rows
+        [k * R, (k + 1) * R), R = pt.pair_rows (a capacity >= the number of matched pairs of the batch); row r of a layer
+        is the r-th matched (query, caption) pair in (video, slot) order -- found on the device from the per-video pair
+        counts (cumulative sum + searchsorted) -- and rows beyond the batch's pair count are marked unused
+        (row_video = -1: the captioner kernels skip them, their caption is <pad> with an all-zero mask, loss and gradient
+        contribution exactly 0).  The teacher-forced loop runs the static pt.cap_len - 1 steps: steps beyond the longest
+        caption of the batch only see masked positions, so the loss equals the reference's, which leaves the loop at the
+        first all-<pad> input column (LSTM_DSA.py:110-112).  The mean over (videos x max pairs) rows of pdvc.py:868
+        divides by a DEVICE scalar.  No shape depends on the batch."""
         nl = len(matches)
         plan = matches[0].plan
         N_, N_q, C = hs_layers[0].shape
         G1 = plan.G1
         if pt.slots > N_q:
             raise RuntimeError("more target slots than queries")
+        R = pt.pair_rows or N_ * G1
+        dev = hs_layers[0].device
         cache = plan.__dict__.setdefault("_cap_rows", {})
-        rows = cache.get(nl)
-        if rows is None:
-            t1 = plan.vid_of_entry.numel()
-            rows = cache[nl] = (plan.vid_of_entry.repeat(nl),
-                                torch.arange(nl, device=plan.vid_of_entry.device).repeat_interleave(t1))
-        vid_all, lay_all = rows
-        valid = plan.valid.repeat(nl)
-        q_all = torch.cat([m.q for m in matches]).clamp(min=0)
-        t_all = torch.cat([m.t for m in matches]).clamp(min=0)
+        consts = cache.get((nl, R))
+        if consts is None:
+            consts = cache[(nl, R)] = (torch.arange(R, dtype=torch.int64, device=dev),
+                                       torch.arange(nl, dtype=torch.int64, device=dev).repeat_interleave(R))
+        r, lay = consts
+        n1 = plan.pair_count
+        incl = n1.cumsum(0)
+        v = torch.searchsorted(incl, r, right=True)                     # video of the r-th pair
+        used = v < N_
+        v = v.clamp(max=N_ - 1)
+        e = v * G1 + (r - (incl - n1)[v]).clamp(min=0, max=G1 - 1)      # its slot in the padded match layout
+        q_all = torch.cat([m.q[e] for m in matches]).clamp(min=0)
+        t_all = torch.cat([m.t[e] for m in matches]).clamp(min=0)
+        v_all, used_all = v.repeat(nl), used.repeat(nl)
+        row_video = torch.where(used_all, v_all, torch.full_like(v_all, -1))
         hs_stack = torch.stack(hs_layers)
-        ref_stack = torch.stack([r if r.shape[-1] == 2 else torch.cat([r, torch.full_like(r, -1.0)], -1)
-                                 for r in ref_layers])
-
-        def per_video(x):                                  # (nl * N * G1, ...) in (layer, video, slot) order
-            return x.view(nl, N_, G1, *x.shape[1:]).transpose(0, 1).reshape(N_, nl * G1, *x.shape[1:])
-        hs_m = per_video(hs_stack[lay_all, vid_all, q_all])
-        ref_m = per_video(ref_stack[lay_all, vid_all, q_all])
-        seq_flat = per_video(pt.cap_tensor[vid_all, t_all] * valid[:, None]).flatten(0, 1)
-        mask_flat = per_video(pt.cap_mask[vid_all, t_all] * valid[:, None]).flatten(0, 1)
-        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=pt.cap_len - 1)
+        ref_stack = torch.stack([r_ if r_.shape[-1] == 2 else torch.cat([r_, torch.full_like(r_, -1.0)], -1)
+                                 for r_ in ref_layers])
+        # index_select on the flattened (layer, video, query) axis: its backward is an atomic index_add.  Advanced
+        # indexing (hs_stack[lay, vid, q]) differentiates into index_put_(accumulate=True), a rocPRIM radix sort -- the
+        # same sort inside nn.Embedding's backward faulted when replayed from a hipGraph on MI355X / ROCm 7.2
+        flat = (lay * N_ + v_all) * N_q + q_all
+        hs_m = hs_stack.view(-1, C).index_select(0, flat)
+        ref_m = ref_stack.view(-1, 2).index_select(0, flat)
+        seq_flat = pt.cap_tensor[v_all, t_all] * used_all[:, None]
+        mask_flat = pt.cap_mask[v_all, t_all] * used_all[:, None]
+        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=pt.cap_len - 1, row_video=row_video)
         row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
-        per_layer = row_loss.view(N_, nl, G1).sum(dim=(0, 2)) / (N_ * plan.pair_count.max())
+        per_layer = row_loss.view(nl, R).sum(dim=1) / (N_ * n1.max())
         return per_layer.unbind(0), {}, pt.cap_tensor[plan.vid_of_entry, matches[-1].t.clamp(min=0)]
 
     def caption_prediction_layers(self, cap_head, dt, hs_layers, ref_layers, others, matches):

@@ -33,9 +33,16 @@ def needed_capacity(dt):
     return n_gt, cap_len
 
 
+def total_events(dt):
+    return sum(len(t_["boxes"]) for t_ in dt["video_target"])
+
+
 class PaddedTargets:
-    def __init__(self, B, slots, cap_len, device):
+    def __init__(self, B, slots, cap_len, device, pair_rows=0):
+        """pair_rows: capacity of the compact caption-row set of the train step (>= the number of events of a whole
+        batch; 0 = B * slots, i.e. no compaction)"""
         self.B, self.slots, self.cap_len, self.device = B, slots, cap_len, torch.device(device)
+        self.pair_rows = int(pair_rows or 0)
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=self.device)      # noqa: E731
         self.boxes, self.labels = z(B, slots, 2), z(B, slots, dtype=torch.int64)
         self.counts = z(B, dtype=torch.int64)
@@ -64,8 +71,10 @@ class PaddedTargets:
         ns = [len(t_["boxes"]) for t_ in targets]
         if len(ns) != self.B or max(ns + [0]) > self.slots:
             raise ValueError(f"PaddedTargets(B={self.B}, slots={self.slots}) cannot hold a batch with event counts {ns}")
-        self.host_counts = ns
         total = sum(ns)
+        if self.pair_rows and total > self.pair_rows:
+            raise ValueError(f"PaddedTargets(pair_rows={self.pair_rows}) cannot hold a batch with {total} events")
+        self.host_counts = ns
         nb = float(max(total, 1)) if num_boxes is None else float(num_boxes)
         pos = [v * self.slots + k for v, n in enumerate(ns) for k in range(n)]
         st, ev = self._ring[self._turn]

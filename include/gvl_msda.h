@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 5   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, and gvl_set_criterion_* take video_pair_count / num_boxes_dev */
+#define GVL_MSDA_ABI_VERSION 5   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -298,18 +298,24 @@ int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int l
  *    backward <- grad_att_res (B*Q, C; row stride);  grad_att_h / grad_off are OVERWRITTEN (row strides given: they
  *               may be column blocks of one gradient matrix); grad_slab (B,S,2C), grad_ref (B,Q,L,RD), grad_alpha_w
  *               (C), grad_alpha_b (1) are ACCUMULATED INTO (float atomics; the caller zeroes them once per token
- *               loop, so the per-step autograd accumulation of a 12 MB slab gradient disappears). */
+ *               loop, so the per-step autograd accumulation of a 12 MB slab gradient disappears).
+ *    row_video (ABI 5): NULL = rows are grouped per video, row r belongs to video r / Q (as above).  Non-NULL = the
+ *               COMPACT form used by the layout-independent captured train step: Q is the TOTAL number of rows, ref is
+ *               (Q, L, RD), B only sizes the slab, and row_video (Q) int64 DEVICE gives each row's video; a negative
+ *               entry marks an unused row of the fixed-capacity row set: its outputs (att_res, alpha_out; grad_att_h,
+ *               grad_off) are written as zeros and it contributes nothing to the accumulated gradients. */
 int gvl_cap_attend_train_forward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                                      const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
                                      int att_h_ld, const float *alpha_w, const float *alpha_b, int B, int S, int C,
-                                     int L, int Q, int P, int RD, float *att_res, float *alpha_out, void *stream);
+                                     int L, int Q, int P, int RD, const int64_t *row_video, float *att_res,
+                                     float *alpha_out, void *stream);
 int gvl_cap_attend_train_backward_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                                       const float *off_hs, const float *off_h, int off_h_ld, const float *att_h,
                                       int att_h_ld, const float *alpha_w, const float *alpha_saved,
                                       const float *grad_att_res, int grad_att_res_ld, int B, int S, int C, int L, int Q,
-                                      int P, int RD, float *grad_slab, float *grad_att_h, int grad_att_h_ld,
-                                      float *grad_off, int grad_off_ld, float *grad_ref, float *grad_alpha_w,
-                                      float *grad_alpha_b, void *stream);
+                                      int P, int RD, const int64_t *row_video, float *grad_slab, float *grad_att_h,
+                                      int grad_att_h_ld, float *grad_off, int grad_off_ld, float *grad_ref,
+                                      float *grad_alpha_w, float *grad_alpha_b, void *stream);
 /*    LSTM cell (nn.LSTM single layer, bias-free; gate order i,f,g,o): gates = gates_a + gates_b + gates_c (row strides
  *    in floats).  forward keeps the ACTIVATED gates act (n, 4H); backward takes dh = grad_h_a + grad_h_b (either may
  *    be NULL), grad_c (may be NULL) and writes the pre-activation gate gradients (row stride grad_gates_ld) and

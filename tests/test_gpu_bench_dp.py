@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("mode", ["both", "train"])
 def test_two_ranks_on_one_gpu(mode):
     env = dict(os.environ, GVL_DIST_BACKEND="gloo", GVL_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -31,4 +31,7 @@ def test_two_ranks_on_one_gpu(mode):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8
-    assert d["value"] > 0 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["train_step_ms"] > 0
+    assert len(d["train_seconds_per_rank"]) == 2 and d["train_graphs"]["captures_in_timed_region"] == 0
+    if mode == "both":
+        assert d["metric"].startswith("videos/sec") and d["eval_graphs"]["cached"] == 1
