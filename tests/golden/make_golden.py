@@ -475,6 +475,193 @@ def make_collate():
     save("collate", **rec)
 
 
+def make_dataset():
+    """the reference's PropSeqDataset.__getitem__ (video_dataset.py:209-281) + collate_fn on the synthetic on-disk
+    dataset of tests/golden/synth.py:synth_dataset, both feature-type branches of load_feats"""
+    import tempfile
+    from synth import synth_dataset, dataset_opt
+    import video_dataset as VD
+    root = tempfile.mkdtemp(prefix="gvl_ds_")
+    info = synth_dataset(root)
+    rec = {}
+    for kind in ("tsp", "c3d"):
+        opt = dataset_opt(kind, info["vocab_size"])
+        folder = [info["tsp_dir"]] if kind == "tsp" else info["c3d_dir"]
+        ds = VD.PropSeqDataset(info["anno"], folder, info["vocab"], True, "gt", opt)
+        np.random.seed(7)
+        samples = [ds[i] for i in range(len(ds))]
+        rec[f"{kind}.n"] = np.array(len(ds))
+        for i, (feats, featstamps, labels, caps, stamps, dur, raw, key) in enumerate(samples):
+            pre = f"{kind}.{i}."
+            rec[pre + "feats"] = np.asarray(feats)
+            rec[pre + "featstamps"] = np.asarray(featstamps).reshape(-1, 2)
+            rec[pre + "labels"] = np.asarray(labels)
+            rec[pre + "cap_lens"] = np.array([len(c) for c in caps])
+            rec[pre + "caps"] = np.concatenate(caps)
+            rec[pre + "stamps"] = np.asarray(stamps, dtype=np.float64).reshape(-1, 2)
+            rec[pre + "duration"] = np.array(dur)
+            rec[pre + "raw"] = np.array(raw)
+            rec[pre + "key"] = np.array(key)
+        dt = VD.collate_fn(samples[:3])
+        rec[f"{kind}.collate.video_tensor"] = dt["video_tensor"]
+        rec[f"{kind}.collate.cap_tensor"] = dt["cap_tensor"]
+        rec[f"{kind}.collate.video_length"] = dt["video_length"]
+    tr = VD.Translator(info["vocab"], info["vocab_size"])
+    rec["rtranslate"] = np.array([tr.rtranslate([3, 7, 0, 5]), tr.rtranslate([0, 1]), tr.rtranslate([2, 22, 4])])
+    save("dataset", **rec)
+
+
+def make_anet_c3d():
+    """BASELINE.json config 0 -- cfgs/anet_c3d_ssvg.yml (500-d C3D features, the file's own 30 queries) at its real
+    dimensions: evaluation forward of the reference on a padded 2-video batch, CUDA-op semantics."""
+    opt, model, criterion, cc = build_pdvc("cfgs/anet_c3d_ssvg.yml", dict(enable_contrastive=False, device="cpu"))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=500)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 2, 100
+    valid, n_gt = [100, 61], [2, 4]
+    dt = synth_dt(B, T, opt.feature_dim, valid=valid, n_gt=n_gt, seed=8)
+    with cuda_semantics(), torch.no_grad():
+        out, loss = model(dt, criterion, cc, "queries", eval_mode=True)
+    rec = dict(meta_T=np.array(T), valid=np.array(valid), n_gt=np.array(n_gt), feature_dim=np.array(opt.feature_dim),
+               num_queries=np.array(opt.num_queries), vocab_size=np.array(opt.vocab_size),
+               max_caption_len=np.array(opt.max_caption_len),
+               param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]),
+               pred_logits=out["pred_logits"], pred_boxes=out["pred_boxes"], pred_count=out["pred_count"],
+               seq=out["seq"], cap_prob_eval=out["caption_probs"]["cap_prob_eval"],
+               aux_pred_boxes=out["aux_outputs"][0]["pred_boxes"])
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        rec[f"match_{i}"] = torch.stack([a, b])
+    for k, v in loss.items():
+        rec[f"loss.{k}"] = torch.as_tensor(v)
+    save("pdvc_anet_c3d", **rec)
+
+
+def _f64_eval(cfg, overrides, seed_w, B, T, valid, n_gt, seed_dt):
+    """the SAME eval forward in float64 (model.double(), double inputs): the value both fp32 implementations approximate"""
+    opt, model, criterion, cc = build_pdvc(cfg, overrides)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=seed_w)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    dt = synth_dt(B, T, opt.feature_dim, valid=valid, n_gt=n_gt, seed=seed_dt)
+    with cuda_semantics(), torch.no_grad():
+        out32, _ = model(dt, criterion, cc, "queries", eval_mode=True)
+    model = model.double()
+    criterion.counter_class_rate = criterion.counter_class_rate.double() if hasattr(criterion, "counter_class_rate") else None
+    dt64 = dict(dt)
+    dt64["video_tensor"] = dt["video_tensor"].double()
+    dt64["video_length"] = dt["video_length"].double()
+    dt64["video_target"] = [{"boxes": t_["boxes"].double(), "labels": t_["labels"]} for t_ in dt["video_target"]]
+    torch.set_default_dtype(torch.float64)            # the reference creates several tensors with the default type
+    try:
+        with cuda_semantics(), torch.no_grad():
+            out64, _ = model(dt64, criterion, cc, "queries", eval_mode=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    rec = {}
+    for k in ("pred_logits", "pred_boxes", "pred_count"):
+        rec[k + "_f64"] = out64[k].double()
+        rec[k + "_f32_err"] = (out32[k].double() - out64[k].double()).abs().max()      # the REFERENCE's own fp32 error
+    rec["cap_prob_eval_f32_err"] = (out32["caption_probs"]["cap_prob_eval"].double()
+                                    - out64["caption_probs"]["cap_prob_eval"].double())[out32["seq"] == out64["seq"]].abs().max()
+    rec["seq_agree"] = (out32["seq"] == out64["seq"]).double().mean()
+    rec["seq_f64"] = out64["seq"]
+    return rec
+
+
+def make_f64():
+    """fp64 evaluations of the two full-dimension eval fixtures (pdvc_anet_full, pdvc_yc2): the noise floor of an fp32
+    evaluation of these models = the reference's OWN fp32 run against its fp64 run.  The GPU tests bound gvl_amd's error
+    against the fp64 values by a small multiple of that floor instead of an unexplained tolerance."""
+    rec = _f64_eval("cfgs/anet_tsp_ssvg.yml", dict(enable_contrastive=False, device="cpu", num_queries=300,
+                                                   frame_embedding_num=100), 100, 2, 100, [100, 73], [3, 5], 6)
+    save("pdvc_anet_full_f64", **rec)
+
+
+def make_anet_full_train():
+    """BASELINE.json config 2 at the REAL dimensions: one training forward/backward of the reference on
+    cfgs/anet_tsp_ssvg.yml (300 queries, vocabulary 8517, T = 100), B = 2, every dropout 0, captions of up to 12 tokens:
+    every loss term, the matcher indices of both decoder layers, the gradient norm of EVERY parameter and a few
+    gradients element-wise (pdvc.py:540-620, train.py:403-406).  CUDA-op semantics."""
+    opt, model, criterion, cc = build_pdvc("cfgs/anet_tsp_ssvg.yml",
+                                           dict(enable_contrastive=False, device="cpu", num_queries=300,
+                                                frame_embedding_num=100, transformer_dropout_prob=0.0, drop_prob=0.0))
+    model.train()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=100)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 2, 100
+    valid, n_gt = [100, 73], [3, 5]
+    dt = synth_dt(B, T, opt.feature_dim, valid=valid, n_gt=n_gt, seed=6)
+    g = torch.Generator().manual_seed(21)
+    cap_len = 12
+    words = torch.randint(3, cap_len - 1, (sum(n_gt),), generator=g)              # words per caption: 3..10
+    caps = torch.zeros(sum(n_gt), cap_len, dtype=torch.long)
+    cap_mask = torch.zeros(sum(n_gt), cap_len)
+    for i, w in enumerate(words.tolist()):
+        caps[i, 1:1 + w] = torch.randint(1, opt.vocab_size, (w,), generator=g)
+        cap_mask[i, :w + 2] = 1
+    mx = max(n_gt)
+    dt.update(cap_tensor=caps, cap_mask=cap_mask,
+              gt_boxes_mask=torch.tensor([[k < n for k in range(mx)] for n in n_gt]).bool(),
+              gt_gather_idx=torch.tensor([i for i, n in enumerate(n_gt) for _ in range(n)]))
+    with cuda_semantics():
+        out, loss = model(dt, criterion, cc, "queries")
+        wd = criterion.weight_dict
+        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        final.backward()
+    rec = dict(meta_T=np.array(T), valid=np.array(valid), n_gt=np.array(n_gt), cap_tensor=caps, cap_mask=cap_mask,
+               final_loss=final.detach(),
+               param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+    for k, v in loss.items():
+        rec[f"loss.{k}"] = torch.as_tensor(v).detach()
+    names = sorted(n for n, p_ in model.named_parameters() if p_.grad is not None)
+    params = dict(model.named_parameters())
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = torch.stack([params[n].grad.norm() for n in names])
+    for n in ("transformer.encoder.layers.0.self_attn.sampling_offsets.bias",
+              "transformer.decoder.layers.0.cross_attn.sampling_offsets.bias",
+              "transformer.decoder.layers.1.cross_attn.attention_weights.bias",
+              "transformer.decoder.layers.1.cross_attn.sampling_offsets.bias",
+              "transformer.level_embed", "caption_head.0.core.deformable_att.sampling_offsets.bias",
+              "caption_head.0.core.alpha_net.weight", "class_head.1.weight", "count_head.0.bias",
+              "transformer.decoder.bbox_head.0.layers.2.bias", "transformer.reference_points.weight"):
+        rec["grad." + n] = params[n].grad
+    rec["grad_rows.caption_head.0.logit.weight"] = params["caption_head.0.logit.weight"].grad[::97]
+    rec["grad_rows.query_embed.weight"] = params["query_embed.weight"].grad[::13]
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        rec[f"match_{i}"] = torch.stack([a, b])
+    # the same step in float64: the gradient of a sampling location is piecewise constant in the location (difference of
+    # the two neighbouring frames), so an fp32 rounding that moves a sample across a frame boundary changes it by O(1);
+    # the reference's own fp32-vs-fp64 deviation of every gradient norm is the noise floor the GPU tests bound against
+    grads32 = {n: params[n].grad.clone() for n in names}
+    model.zero_grad(set_to_none=True)
+    model.double()
+    dt64 = dict(dt)
+    dt64["video_tensor"], dt64["video_length"] = dt["video_tensor"].double(), dt["video_length"].double()
+    dt64["cap_mask"] = cap_mask.double()
+    dt64["video_target"] = [{"boxes": t_["boxes"].double(), "labels": t_["labels"]} for t_ in dt["video_target"]]
+    torch.set_default_dtype(torch.float64)
+    try:
+        with cuda_semantics():
+            out64, loss64 = model(dt64, criterion, cc, "queries")
+            final64 = sum(loss64[k] * wd[k] for k in loss64.keys() if k in wd)
+            final64.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    rec["final_loss_f64"] = final64.detach()
+    rec["grad_f64.transformer.decoder.layers.1.cross_attn.sampling_offsets.bias"] = \
+        params["transformer.decoder.layers.1.cross_attn.sampling_offsets.bias"].grad
+    rec["grad_norms_f64"] = torch.stack([params[n].grad.norm() for n in names])
+    rec["grad_norm_f32_err"] = torch.stack([(grads32[n].double() - params[n].grad).norm() for n in names])
+    for k, v in loss64.items():
+        rec[f"loss_f64.{k}"] = torch.as_tensor(v).detach()
+    same = all(torch.equal(torch.stack(list(a)), torch.stack(list(b)))
+               for a, b in zip(out["matched_indices"][0], out64["matched_indices"][0]))
+    rec["match_same_in_f64"] = np.array(same)
+    save("pdvc_anet_full_train", **rec)
+
+
 def make_train():
     """One training forward/backward of the reference (pdvc.py parallel_prediction_matched, train.py:403-406) with
     every dropout probability set to 0 so that the step is deterministic; CUDA-op (zero padding) semantics."""
@@ -573,6 +760,11 @@ if __name__ == "__main__":
     if "--only-train" in sys.argv:
         make_train()
         sys.exit(0)
+    for flag, fn in (("--only-dataset", make_dataset), ("--only-anet-c3d", make_anet_c3d), ("--only-f64", make_f64),
+                     ("--only-anet-full-train", make_anet_full_train)):
+        if flag in sys.argv:
+            fn()
+            sys.exit(0)
     make_op()
     make_module()
     make_matcher()
@@ -583,4 +775,8 @@ if __name__ == "__main__":
         make_yc2()
         make_anet_full()
         make_train()
+        make_anet_c3d()
+        make_f64()
+        make_anet_full_train()
+    make_dataset()
     make_init()

@@ -68,3 +68,49 @@ def synth_samples(seed=3):
         raw = ["caption %d %d" % (i, k) for k in range(n)]
         out.append((feats, featstamps, [0] * n, caps, raw_ts, dur, raw, "v_%03d" % i))
     return out
+
+
+def synth_dataset(root, seed=5):
+    """A tiny on-disk dataset in the reference's formats (annotation JSON, vocabulary JSON, one .npy per video) for the
+    PropSeqDataset fixtures: videos whose feature length equals / exceeds / is below the target length, a single-frame
+    video, a video WITHOUT a feature file, and one with more events than gt_proposal_sample_num.
+    -> dict(anno, vocab, tsp_dir, c3d_dir, vocab_size)"""
+    import json
+    import os
+    rs = np.random.RandomState(seed)
+    words = ["a", "man", "woman", "is", "are", "the", "dog", "runs", "jumps", "then", "she", "he", "cooks", "plays",
+             "guitar", "outside", "inside", "while", "people", "watch", ".", ","]
+    vocab = {"word_to_ix": {w: i + 1 for i, w in enumerate(words)}, "ix_to_word": {str(i + 1): w for i, w in enumerate(words)}}
+    os.makedirs(os.path.join(root, "tsp"), exist_ok=True)
+    os.makedirs(os.path.join(root, "c3d"), exist_ok=True)
+    anno = {}
+    for i, (T, n) in enumerate([(20, 2), (33, 5), (1, 1), (None, 3), (11, 4)]):
+        key = "v_%011d" % (i * 7 + 3)                       # 13 characters, as ActivityNet ids
+        dur = 35.0 + 11.25 * i
+        starts = np.sort(rs.uniform(0, dur * 0.8, n))
+        stamps = [[round(float(s_), 2), round(float(min(dur + 3.0, s_ + rs.uniform(1.0, dur * 0.4))), 2)] for s_ in starts]
+        sents = [" ".join(rs.choice(words[:20] + ["unknownword"], size=rs.randint(3, 12))).capitalize() + "." for _ in range(n)]
+        anno[key] = {"duration": dur, "timestamps": stamps, "sentences": sents}
+        if T is not None:
+            np.save(os.path.join(root, "tsp", key + ".npy"), rs.standard_normal((T, 512)).astype(np.float32))
+            np.save(os.path.join(root, "c3d", key + ".npy"), rs.standard_normal((T, 500)).astype(np.float32))
+    with open(os.path.join(root, "anno.json"), "w") as f:
+        json.dump(anno, f)
+    with open(os.path.join(root, "vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    return {"anno": os.path.join(root, "anno.json"), "vocab": os.path.join(root, "vocab.json"),
+            "tsp_dir": os.path.join(root, "tsp"), "c3d_dir": os.path.join(root, "c3d"), "vocab_size": len(words)}
+
+
+def dataset_opt(kind, vocab_size):
+    """options PropSeqDataset reads, for the two feature-type branches of load_feats (list-typed 'tsp' as
+    cfgs/anet_tsp_ssvg.yml, scalar 'c3d' with data_norm as cfgs/anet_c3d_ssvg.yml allows)"""
+    import argparse
+    common = dict(vocab_size=vocab_size, max_caption_len=8, invalid_video_json=[], feature_sample_rate=1,
+                  train_proposal_sample_num=24, gt_proposal_sample_num=3, num_queries=10, data_rescale=1,
+                  frame_embedding_num=20, data_norm=0)
+    if kind == "tsp":
+        common.update(visual_feature_type=["tsp"], feature_dim=512)
+    else:
+        common.update(visual_feature_type="c3d", feature_dim=500, data_norm=1)
+    return argparse.Namespace(**common)

@@ -543,8 +543,11 @@ def test_anet_full_dimension_eval_matches_reference():
         assert maxerr(memory[:, ::4], f["memory_rows"]) <= 2e-4 * max(1.0, ms)
         assert maxerr(out["pred_boxes"], f["pred_boxes"]) <= 2e-4
         assert maxerr(out["aux_outputs"][0]["pred_boxes"], f["aux_pred_boxes"]) <= 2e-4
-        assert maxerr(out["pred_logits"], f["pred_logits"]) <= 1e-3
-        assert maxerr(out["pred_count"], f["pred_count"]) <= 1e-3
+        # (the noise floor of an fp32 evaluation of this model -- the reference's own fp32 run against its fp64 run -- is
+        #  5e-5 / 6e-6 / 3e-5 for logits / boxes / counts: tests/golden/pdvc_anet_full_f64.npz, asserted against in
+        #  tests/test_gpu_full_dims.py; two fp32 runs may differ by the sum of their errors)
+        assert maxerr(out["pred_logits"], f["pred_logits"]) <= 3e-4
+        assert maxerr(out["pred_count"], f["pred_count"]) <= 3e-4
         assert maxerr(out["event_feat"][:, ::8], f["event_feat"]) <= 1e-3 * max(1.0, float(np.abs(f["event_feat"]).max()))
         for i in range(len(out["matched_indices"][0])):
             assert torch.equal(torch.stack(out["matched_indices"][0][i]), t(f[f"match_{i}"]))
