@@ -46,3 +46,32 @@ def save_dvc_json(out_json, path, verbose=False):
             n = [len(v) for v in out_json['results'].values()]
             out_json['avg_proposal_num'] = float(sum(n)) / len(n) if n else float('nan')
         json.dump(out_json, f)
+
+
+def gather_results(local_results, dst=0, group=None):
+    """Evaluation sharded by video over the ranks: every rank holds the result records of
+    ITS videos ({video_key: [prediction dicts]}, as batch_result_json returns them); rank `dst` receives the union and
+    every other rank None.  The reference's helper for this is the pickle all_gather of misc/detr_utils/misc.py:183-223
+    (size exchange + padded byte tensors); torch.distributed's object collectives do exactly that on either backend --
+    RCCL ("nccl" on ROCm) moves the bytes through device memory, gloo through host memory.  One collective per call,
+    after the last batch; the data path of the eval forward itself has none."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dict(local_results)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(dict(local_results), parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = {}
+    for r, part in enumerate(parts):
+        dup = set(part) & set(merged)
+        if dup:
+            raise ValueError(f"video keys evaluated on more than one rank (rank {r}): {sorted(dup)[:3]}")
+        merged.update(part)
+    return merged
+
+
+def shard_indices(n_items, rank, world):
+    """DistributedSampler-style shard without padding: rank r takes items r, r + W, ... (every video exactly once)"""
+    return list(range(rank, n_items, world))

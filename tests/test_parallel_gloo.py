@@ -121,3 +121,70 @@ def test_shard_batch_partitions_videos_and_captions():
         assert len(s["video_target"]) == s["video_tensor"].shape[0] == len(s["cap_raw"])
         assert s["cap_tensor"].shape[0] == sum(len(t_["boxes"]) for t_ in s["video_target"])
     assert sorted(seen_v) == list(range(B)) and sorted(seen_c) == list(range(sum(n_gt)))
+
+
+def _worker_gather(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gvl_amd.eval_utils import gather_results, shard_indices
+        from gvl_amd.parallel import GradBuckets
+        keys = [f"v_{i:03d}" for i in range(7)]
+        mine = {keys[i]: [{"timestamp": [float(i), float(i) + 1.5], "sentence": f"s{i}", "query_id": i % 3}
+                          for _ in range(1 + i % 2)] for i in shard_indices(len(keys), rank, world)}
+        merged = gather_results(mine, dst=0)
+        # ---- bucket launch order: rank 1 completes its buckets in the opposite order and leaves one parameter
+        # without a gradient; both ranks must still post the same sequence of collectives (parallel.py:80)
+        torch.manual_seed(0)
+        layers = [torch.nn.Linear(16, 16) for _ in range(4)]
+        params = [p for l_ in layers for p in l_.parameters()]
+        buckets = GradBuckets(params, bucket_bytes=600, overlap=True)
+        assert len(buckets.buckets) >= 3
+        x = torch.ones(2, 16) * (rank + 1)
+        order = layers if rank == 0 else list(reversed(layers))
+        buckets.zero()
+        used = order[:3]                                     # the 4th layer of each rank's order gets no gradient locally
+        loss = sum(l_(x).sum() for l_ in used)
+        loss.backward()
+        buckets.finish()
+        grads = [p.grad.clone().numpy() for p in params]
+        unused = [i for i, p in enumerate(params) if any(p is u for u in buckets.unused_params())]
+        q.put((rank, merged, grads, unused))
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eval_result_gather_and_fixed_bucket_order():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_gather, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    merged0, merged1 = res[0][1], res[1][1]
+    assert merged1 is None and sorted(merged0) == [f"v_{i:03d}" for i in range(7)]
+    assert [len(merged0[f"v_{i:03d}"]) for i in range(7)] == [1 + i % 2 for i in range(7)]
+    assert merged0["v_003"][0]["sentence"] == "s3"
+    # gradients: mean over the ranks of each rank's local gradient (zeros where a rank had none)
+    torch.manual_seed(0)
+    layers = [torch.nn.Linear(16, 16) for _ in range(4)]
+    want = []
+    for li, l_ in enumerate(layers):
+        gw = sum((r + 1.0) * (1.0 if (li < 3 if r == 0 else li > 0) else 0.0) for r in range(2)) * 2 / 2
+        gb = sum((1.0 if (li < 3 if r == 0 else li > 0) else 0.0) for r in range(2)) * 2 / 2
+        want += [torch.full((16, 16), gw), torch.full((16,), gb)]
+    for r in range(2):
+        for got, w in zip(res[r][2], want):
+            assert torch.allclose(torch.from_numpy(got), w, atol=1e-6)
+    assert res[0][3] == [6, 7] and res[1][3] == [0, 1]          # each rank's locally unused layer (weight, bias)
