@@ -909,6 +909,352 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
   } while (LOOP && (chunk += ngroup) < nchunk);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// t1d_d64 backward, LEVEL-SPLIT form -- for the case where a (b,m) slab is shared by exactly TWO workgroups (B*M = 128
+// at cfg A: 256 workgroups, one per CU) and L = P = 4.  The query-split form above lets each of the two workgroups
+// produce a partial grad_value slab for its half of the queries and needs k_sum_partials afterwards (12 MB written,
+// 12 MB re-read, a second launch: 5 of 28 us and 1.22x the algorithmic HBM traffic, profiles/r01_pmc_traffic.json).
+// Here the two workgroups split the OUTPUT instead: workgroup g owns the grad_value rows of two pyramid levels
+// ({0,3} / {1,2}: 113 / 75 rows, the same number of samples) and writes them once, final, with plain stores.
+// An entry list sorted by row needs EVERY sample that falls into the workgroup's levels, from all Q queries, so
+//   own pass      the workgroup's half of the queries, exactly as above (coefficients, 16 sample steps against the LDS
+//                 slab, reduce-scatter, grad_loc / grad_attn or the fused softmax / location epilogue) -- entries are
+//                 recorded for the samples of the workgroup's levels only;
+//   foreign pass  the OTHER half of the queries: operand fetch + coefficient arithmetic only (no slab reads, no dot
+//                 products: ~100 of the ~430 VALU instructions of a pass), entries for the workgroup's levels, and the
+//                 queries' grad_out rows go to LDS on the way.  It runs BEFORE the value slab is needed, i.e. while the
+//                 slab's global loads are in flight: the staging round trip of the query-split form is hidden.
+// Both workgroups read all of loc / attn (proj / ref) and grad_out of the slab's queries; they sit on the same XCD
+// (workgroup ids B*M apart), so the second read is an L2 hit.  The counting sort keeps the slot each entry drew from
+// the integer histogram in phase 1 (packed beside the row), so the scatter needs no second round of LDS atomics.
+// ------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t bwd_split_lds_bytes(int S, int qper) {
+  return (size_t)(S + 1) * 256 + (size_t)qper * 256 + (size_t)(S + 2) * 2 * sizeof(int) + (size_t)(2 * qper * 8) * 4 * sizeof(int);
+}
+
+template <int PAD, bool FUSED, typename VT>
+__global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restrict__ value,
+                                                               const int64_t *__restrict__ shapes,
+                                                               const int64_t *__restrict__ lsi,
+                                                               const void *__restrict__ loc,
+                                                               const float *__restrict__ attn,
+                                                               const VT *__restrict__ gout, int B, int S, int M, int Q,
+                                                               int RD, int qper, VT *__restrict__ gvalue,
+                                                               void *__restrict__ gloc, float *__restrict__ gattn,
+                                                               unsigned long long *__restrict__ stamps) {
+  constexpr int L = 4, P = 4, LP = 16;
+  extern __shared__ float4 slab4[];
+  __shared__ int next_blk_s;
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
+  const int rowsV = S + 1;
+  float4 *G_oth = slab4 + (size_t)rowsV * 16;                          // grad_out rows of the foreign queries
+  int *cnt = reinterpret_cast<int *>(G_oth + (size_t)qper * 16);       // [S+2] histogram
+  int *off = cnt + (S + 2);                                            // [S+2] exclusive prefix
+  const int nent = 2 * qper * 8;                                       // 8 samples of the owned levels per query
+  int *ent_rp = off + (S + 2);                                         // slab row | slot in the row << 12, or -1
+  float *ent_lo = reinterpret_cast<float *>(ent_rp + nent);
+  float *ent_hi = ent_lo + nent;
+  int *sorted = reinterpret_cast<int *>(ent_hi + nent);
+
+  const int BM = B * M;
+  const int bm = blockIdx.x % BM, g = blockIdx.x / BM;                 // g in {0, 1}
+  const int b = bm / M, m = bm % M;
+  const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lvl = j >> 2;
+  const int Tl = (int)shapes[2 * lvl + 1], st = (int)lsi[lvl];
+  const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
+  // levels {0,3} belong to workgroup 0, {1,2} to workgroup 1; k = the sample's index among the 8 owned samples of a query
+  const bool mine = g == 0 ? (lvl == 0 || lvl == 3) : (lvl == 1 || lvl == 2);
+  const int k_own = g == 0 ? (lvl == 0 ? j : j - 8) : j - 4;
+  const int q0 = g * qper, q1 = max(q0, min(Q, q0 + qper));            // own queries
+  const int f0 = (1 - g) * qper, f1 = max(f0, min(Q, f0 + qper));      // foreign queries
+  const int nq = q1 - q0;
+
+  // ---- set-up: histogram and entry table, slab loads into registers ---------------------------------------
+  for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
+  for (int i = threadIdx.x; i < nent; i += blockDim.x) ent_rp[i] = -1;
+  constexpr int kPre = 3;
+  const int64_t src0 = ((int64_t)b * S * M + m) * 16;
+  const int nstage = S * 16;
+  float4 pre[kPre];
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < nstage) pre[k] = ld4(value, src0 + (int64_t)(i >> 4) * M * 16 + (i & 15));
+  }
+  __syncthreads();
+
+  // entry of sample j of slab query `ql` (0 .. 2 qper): row, coefficients, slot in the row's list
+  auto record = [&](int ql, int roff, float elo, float ehi) {
+    const int e = ql * 8 + k_own;
+    const int pos = atomicAdd(&cnt[roff], 1);
+    ent_rp[e] = roff | (pos << 12);
+    ent_lo[e] = elo;
+    ent_hi[e] = ehi;
+  };
+
+  // ---- foreign pass: coefficients of the other half's samples in the owned levels + their grad_out rows -----------
+  {
+    int qb = f0 + wave * 4;
+    RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
+    float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qb < f1) {
+      const int64_t bqn = (int64_t)b * Q + min(qb + tq, f1 - 1);
+      r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+      if (qb + tq < f1) g_n = ld4(gout, (bqn * M + m) * 16 + j);
+    }
+    for (; qb < f1; qb += nw * 4) {
+      const int q = qb + tq;
+      const bool act = q < f1;
+      const RawOps r = r_n;
+      const float4 gq = g_n;
+      const int qbn = qb + nw * 4;
+      if (qbn < f1) {
+        const int64_t bqn = (int64_t)b * Q + min(qbn + tq, f1 - 1);
+        r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+        g_n = (qbn + tq < f1) ? ld4(gout, (bqn * M + m) * 16 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float2 xy;
+      float w, dloc;
+      resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc);      // (FUSED: the softmax needs all 16 lanes of the row)
+      const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
+      const float elo = c.c_lo * c.wy * w, ehi = c.c_hi * c.wy * w;
+      if (act) {
+        G_oth[(q - f0) * 16 + j] = gq;
+        if (mine && (elo != 0.f || ehi != 0.f)) record(qper + (q - f0), st + c.r, elo, ehi);
+      }
+    }
+  }
+
+  // ---- own pass operands, then the slab goes to LDS ----------------------------------------------------------
+  int qb = q0 + wave * 4;
+  RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
+  float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (qb < q1) {
+    const int64_t bqn = (int64_t)b * Q + min(qb + tq, q1 - 1);
+    r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+    if (qb + tq < q1) g_n = ld4(gout, (bqn * M + m) * 16 + j);
+  }
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < nstage) slab4[i] = pre[k];
+  }
+  for (int i = threadIdx.x + kPre * blockDim.x; i < nstage; i += blockDim.x)
+    slab4[i] = ld4(value, src0 + (int64_t)(i >> 4) * M * 16 + (i & 15));
+  if (threadIdx.x < 16) slab4[nstage + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
+
+  // ---- own pass (phase 1 of the query-split kernel; entries for the owned levels only) -----------------------------
+  for (; qb < q1; qb += nw * 4) {
+    const int q = qb + tq;
+    const bool act = q < q1;
+    const int qq = act ? q : q1 - 1;
+    const int64_t tb = (((int64_t)b * Q + qq) * M + m) * LP;
+    const RawOps r = r_n;
+    const float4 gq = g_n;
+    const int qbn = qb + nw * 4;
+    if (qbn < q1) {
+      const int64_t bqn = (int64_t)b * Q + min(qbn + tq, q1 - 1);
+      r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+      g_n = (qbn + tq < q1) ? ld4(gout, (bqn * M + m) * 16 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float2 xy;
+    float w, dloc;
+    resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc);
+    const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
+    const int roff = st + c.r;
+    const float clo = c.c_lo * c.wy, chi = c.c_hi * c.wy;
+    const float dxlo = c.dx_lo * c.wy * w, dxhi = c.dx_hi * c.wy * w;
+    const float dylo = c.c_lo * c.dy * w, dyhi = c.c_hi * c.dy * w;
+    {
+      const float elo = clo * w, ehi = chi * w;
+      if (act && mine && (elo != 0.f || ehi != 0.f)) record(q - q0, roff, elo, ehi);
+    }
+    float p0[16], p1[16];
+#define GVL_BWD_STEP(SI)                                                      \
+  {                                                                           \
+    const int rr = row_bcast_i<SI>(roff);                                     \
+    const float4 v0 = slab4[rr * 16 + j], v1 = slab4[rr * 16 + 16 + j];       \
+    p0[SI] = dot4(gq, v0);                                                    \
+    p1[SI] = dot4(gq, v1);                                                    \
+  }
+    GVL_BWD_STEP(0) GVL_BWD_STEP(1) GVL_BWD_STEP(2) GVL_BWD_STEP(3)
+    GVL_BWD_STEP(4) GVL_BWD_STEP(5) GVL_BWD_STEP(6) GVL_BWD_STEP(7)
+    GVL_BWD_STEP(8) GVL_BWD_STEP(9) GVL_BWD_STEP(10) GVL_BWD_STEP(11)
+    GVL_BWD_STEP(12) GVL_BWD_STEP(13) GVL_BWD_STEP(14) GVL_BWD_STEP(15)
+#undef GVL_BWD_STEP
+    const float d0 = row_reduce_scatter16(p0, j), d1 = row_reduce_scatter16(p1, j);
+    const float keep_w = fmaf(clo, d0, chi * d1);
+    const float keep_x = fmaf(dxlo, d0, dxhi * d1);
+    const float keep_y = fmaf(dylo, d0, dyhi * d1);
+    if (!FUSED) {
+      if (act) {
+        st_stream(gattn + tb + j, keep_w);                                     // cuh:156-157
+        st_stream(reinterpret_cast<float2 *>(gloc) + tb + j, make_float2(keep_x, keep_y));
+      }
+    } else {
+      const float dsum = row_allsum(w * keep_w);                               // softmax backward (ms_deform_attn.py:100-101)
+      const float glogit = w * (keep_w - dsum);
+      const float goff = keep_x * dloc;
+      float gr0 = keep_x, gr1 = keep_x * r.a * (0.5f * invP);
+      gr0 += dpp_f<0xB1>(gr0); gr0 += dpp_f<0x4E>(gr0);
+      gr1 += dpp_f<0xB1>(gr1); gr1 += dpp_f<0x4E>(gr1);
+      if (act) {
+        VT *grow = reinterpret_cast<VT *>(gloc) + ((int64_t)b * Q + qq) * (int64_t)(2 * M * LP);
+        grow[m * LP + j] = (VT)goff;
+        grow[M * LP + m * LP + j] = (VT)glogit;
+        if (gattn && (j & 3) == 0) {
+          float *gr = gattn + ((((int64_t)b * Q + qq) * M + m) * L + lvl) * RD;
+          gr[0] = gr0;
+          if (RD == 2) gr[1] = gr1;
+        }
+      }
+    }
+  }
+  // grad_out rows of the OWN queries for phase 3: requested now, stored over the value slab once it is dead
+  constexpr int kG = 3;
+  float4 gpre[kG];
+  const int64_t gsrc = (((int64_t)b * Q + q0) * M + m) * 16;
+#pragma unroll
+  for (int k = 0; k < kG; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < nq * 16) gpre[k] = ld4(gout, gsrc + (int64_t)(i >> 4) * M * 16 + (i & 15));
+  }
+  __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
+
+  // ---- phase 2: exclusive scan of the histogram; own grad_out rows over the slab; entry ids into row order ----------
+  float4 *G4 = slab4;
+#pragma unroll
+  for (int k = 0; k < kG; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < nq * 16) G4[i] = gpre[k];
+  }
+  for (int i = threadIdx.x + kG * blockDim.x; i < nq * 16; i += blockDim.x)
+    G4[i] = ld4(gout, gsrc + (int64_t)(i >> 4) * M * 16 + (i & 15));
+  {
+    __shared__ int wave_tot[kBwdThreads / 64];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) { carry_s = 0; next_blk_s = 0; }
+    __syncthreads();
+    for (int base = 0; base < S + 1; base += blockDim.x) {
+      const int i = base + threadIdx.x;
+      const int v = (i < S + 1) ? cnt[i] : 0;
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t_ = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t_;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
+      __syncthreads();
+      int pre_ = carry_s;
+      for (int k = 0; k < wave; ++k) pre_ += wave_tot[k];
+      if (i < S + 1) off[i] = pre_ + incl - v;
+      __syncthreads();
+      if (threadIdx.x == blockDim.x - 1) carry_s = pre_ + incl;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) off[S + 1] = carry_s;
+  }
+  for (int e = threadIdx.x; e < nent; e += blockDim.x) {
+    const int rp = ent_rp[e];
+    if (rp >= 0) sorted[off[rp & 4095] + (rp >> 12)] = e;
+  }
+  __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = wall_clock64();
+
+  // ---- phase 3: gather over the OWNED rows, final stores ------------------------------------------------------------
+  // Own rows = a FINE level (level 0 | 1: many rows, short entry lists) followed by a COARSE one (level 3 | 2: few rows,
+  // the same number of entries -> lists 8x / 2x as long; with ALL queries of the slab in one workgroup they reach
+  // ~250 entries).  Work units, handed out dynamically from an LDS counter, longest first:
+  //   coarse rows  one row per WAVEFRONT: its four DPP rows take interleaved 16-entry batches of the row's list and
+  //                their partial sums meet through two cross-row shuffles (a 250-entry list costs 4 batches, not 16);
+  //   fine rows    four adjacent rows per wavefront in lockstep, as in the query-split kernel.
+  const int T0 = (int)shapes[1], s3 = (int)lsi[3], s2 = (int)lsi[2];
+  const int nF = g == 0 ? T0 : s2 - T0, nC = g == 0 ? S - s3 : s3 - s2;  // fine | coarse rows of this workgroup
+  const int sF = g == 0 ? 0 : T0, sC = g == 0 ? s3 : s2;                 // their first slab rows
+  const int n_units = nC + (nF + 3) / 4;
+  const char *G_b = reinterpret_cast<const char *>(G4);
+  const int lane_off = j * 16;
+  const int oth_rows = rowsV - qper;          // entry query index ql >= qper lives at LDS row ql + oth_rows (G_oth)
+  // (LDS byte offset of the query's grad_out row, coefficient) of list element i of slab row s; past the end: (0, 0)
+  auto fetch_tc = [&](int i, int n_own, int n1, int a1, int a0) {
+    f2v tc = {0.f, 0.f};
+    if (i < n_own) {
+      const bool first = i < n1;
+      const int e = sorted[first ? a1 + i : a0 + (i - n1)];
+      const int ql = e >> 3;
+      tc = (f2v){__builtin_bit_cast(float, (ql < qper ? ql : ql + oth_rows) << 8), first ? ent_lo[e] : ent_hi[e]};
+    }
+    return tc;
+  };
+#define GVL_GATHER_STEP(SI)                                                                            \
+  {                                                                                                    \
+    const f2v t2 = row_bcast_f2<SI>(tc);                                                               \
+    const float4 gq = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t2.x) + lane_off); \
+    const f2v cf = __builtin_shufflevector(t2, t2, 1, 1);                                              \
+    a01 = __builtin_elementwise_fma(cf, (f2v){gq.x, gq.y}, a01);                                       \
+    a23 = __builtin_elementwise_fma(cf, (f2v){gq.z, gq.w}, a23);                                       \
+  }
+#define GVL_GATHER_BATCH(LEFT)                                                                         \
+  GVL_GATHER_STEP(0) GVL_GATHER_STEP(1) GVL_GATHER_STEP(2) GVL_GATHER_STEP(3)                          \
+  if ((LEFT) > 4) { GVL_GATHER_STEP(4) GVL_GATHER_STEP(5) GVL_GATHER_STEP(6) GVL_GATHER_STEP(7) }       \
+  if ((LEFT) > 8) {                                                                                    \
+    GVL_GATHER_STEP(8) GVL_GATHER_STEP(9) GVL_GATHER_STEP(10) GVL_GATHER_STEP(11)                      \
+    GVL_GATHER_STEP(12) GVL_GATHER_STEP(13) GVL_GATHER_STEP(14) GVL_GATHER_STEP(15)                    \
+  }
+  for (;;) {
+    int u = 0;
+    if (lane == 0) u = atomicAdd(&next_blk_s, 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (u >= n_units) break;
+    f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    if (u < nC) {
+      // ---- one coarse row for the whole wavefront -----------------------------------------------------------
+      const int s = sC + nC - 1 - u;
+      const int a1 = off[s], n1 = off[s + 1] - a1;
+      const int a0 = off[s - 1], n0 = a1 - a0;                            // (s >= 1: a coarse level never starts the slab)
+      const int n_own = n1 + n0;
+      f2v tc = fetch_tc(tq * 16 + j, n_own, n1, a1, a0);
+      for (int base = 0; base < n_own; base += 64) {
+        const f2v tc_next = fetch_tc(base + 64 + tq * 16 + j, n_own, n1, a1, a0);
+        const int left = n_own - base - tq * 16;                          // entries left for this DPP row's batch
+        if (left > 0) { GVL_GATHER_BATCH(left) }
+        tc = tc_next;
+      }
+      a01 += (f2v){__shfl_xor(a01.x, 16, 64), __shfl_xor(a01.y, 16, 64)};
+      a23 += (f2v){__shfl_xor(a23.x, 16, 64), __shfl_xor(a23.y, 16, 64)};
+      a01 += (f2v){__shfl_xor(a01.x, 32, 64), __shfl_xor(a01.y, 32, 64)};
+      a23 += (f2v){__shfl_xor(a23.x, 32, 64), __shfl_xor(a23.y, 32, 64)};
+      if (tq == 0)
+        st4_stream(gvalue, ((int64_t)b * S + s) * M * 16 + (int64_t)m * 16 + j, make_float4(a01.x, a01.y, a23.x, a23.y));
+    } else {
+      // ---- four adjacent fine rows in lockstep ------------------------------------------------------------------
+      const int i_row = nF - 1 - ((u - nC) * 4 + tq);
+      const bool live = i_row >= 0;
+      const int s = sF + (live ? i_row : 0);
+      const int a1 = off[s], n1 = live ? off[s + 1] - a1 : 0;
+      const int a0 = s > 0 ? off[s - 1] : 0, n0 = (live && s > 0) ? a1 - a0 : 0;
+      const int n_own = n1 + n0;
+      int n = max(n_own, __shfl_xor(n_own, 16, 64));
+      n = max(n, __shfl_xor(n, 32, 64));
+      f2v tc = fetch_tc(j, n_own, n1, a1, a0);
+      for (int base = 0; base < n; base += 16) {
+        const f2v tc_next = fetch_tc(base + 16 + j, n_own, n1, a1, a0);
+        GVL_GATHER_BATCH(n - base)
+        tc = tc_next;
+      }
+      if (live) st4_stream(gvalue, ((int64_t)b * S + s) * M * 16 + (int64_t)m * 16 + j, make_float4(a01.x, a01.y, a23.x, a23.y));
+    }
+  }
+#undef GVL_GATHER_BATCH
+#undef GVL_GATHER_STEP
+}
+
 // sum `n` fp32 partial slabs (each `count4` float4 long) into dst (storage type VT)
 template <typename VT>
 __global__ void __launch_bounds__(256) k_sum_partials(const float4 *__restrict__ part, int n, int64_t count4,
@@ -1011,10 +1357,19 @@ int bwd_chunks(int B, int M, int Q, int S, int rowsV) {
   return up <= Q ? up : n;
 }
 
+// level-split form (k_bwd_t1d_split): two workgroups per slab, one chunk each, L = P = 4, everything in LDS
+bool bwd_split_ok(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan, int nchunk) {
+  if (!env_int("GVL_MSDA_BWD_SPLIT", 1)) return false;
+  if (L != 4 || P != 4 || plan.l0g || !plan.ok || nchunk != 2 || bwd_groups(B, M, nchunk) != 2 || Q < 2) return false;
+  if (S + 2 > 4095) return false;                                       // row packed into 12 bits beside the slot
+  return bwd_split_lds_bytes(S, (Q + 1) / 2) <= kLdsMax;
+}
+
 // fp32 workspace the t1d_d64 backward needs: one partial slab per workgroup when a (b,m) slab is shared by several
 // workgroups, and always one fp32 slab set for bf16 storage (the gather accumulates and writes fp32; k_sum_partials
 // rounds once)
-size_t bwd_workspace_bytes(int B, int S, int M, int nchunk, bool bf16) {
+size_t bwd_workspace_bytes(int B, int S, int M, int nchunk, bool bf16, bool split = false) {
+  if (split) return 0;                                                  // final rows written directly
   const int ngroup = bwd_groups(B, M, nchunk);
   return (ngroup > 1 || bf16) ? (size_t)ngroup * B * S * M * 64 * sizeof(float) : 0;
 }
@@ -1025,6 +1380,15 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
                 int nchunk, VT *gvalue, void *g0, float *g1, void *ws, size_t ws_bytes, hipStream_t st) {
   constexpr bool kBf16 = !std::is_same<VT, float>::value;
   const int qper = (Q + nchunk - 1) / nchunk;
+  if (bwd_split_ok(B, S, M, L, P, Q, plan, nchunk)) {
+    auto kern = pad == kPadZeros ? k_bwd_t1d_split<kPadZeros, FUSED, VT> : k_bwd_t1d_split<kPadBorder, FUSED, VT>;
+    const size_t lds = bwd_split_lds_bytes(S, qper);
+    if (int rc = ensure_lds(kern, lds)) return rc;
+    g_last_impl = FUSED ? 3 : 2;
+    return gvl::launch(GVL_PROF_BWD_T1D, Q, B, FUSED ? "k_bwd_t1d_split<fused>" : "k_bwd_t1d_split", kern,
+                       dim3(2 * B * M), dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M, Q, RD, qper,
+                       gvalue, g0, g1, g_bwd_stamps);
+  }
   const int ngroup = bwd_groups(B, M, nchunk);
   const size_t lds = bwd_lds_bytes(S, qper, plan.rowsV);
   const size_t need = bwd_workspace_bytes(B, S, M, nchunk, kBf16);
@@ -1254,7 +1618,7 @@ size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int 
   const SlabPlan plan = slab_plan(S, L, P, shapes_host);
   if (!plan.ok) return 0;
   const int n = bwd_chunks(B, M, Q, S, plan.rowsV);
-  return n > 0 ? bwd_workspace_bytes(B, S, M, n, elem_bytes == 2) : 0;
+  return n > 0 ? bwd_workspace_bytes(B, S, M, n, elem_bytes == 2, bwd_split_ok(B, S, M, L, P, Q, plan, n)) : 0;
 }
 
 int gvl_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
