@@ -105,10 +105,12 @@ def kernel_times(entries):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
-def cfg_l_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20):
-    """The same kernel on the long-video launch shape (cfg L: T = 512, S = 960; level 0 read from global memory):
-    `iters` fused decoder-shaped launches on synthetic operands, timed with the library's per-dispatch stamps.  A
-    supplementary data point for DESIGN.md section 4.7 -- not part of the timed region, not part of `value`."""
+def kernel_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20, backward=False):
+    """The same kernels at other launch sizes -- cfg L (T = 512, S = 960; level 0 read from global memory) and the
+    latency-free batch B = 64: `iters` fused decoder-shaped launches on synthetic operands, timed with the library's
+    per-dispatch stamps.  Supplementary data points (DESIGN.md sections 4.1 / 4.2 / 4.7: at cfg A one launch moves
+    23-37 MB, i.e. 3-5 us of HBM time against a ~5 us floor of launch ramp + one staging round trip + the VALU-bound
+    sample loop) -- not part of the timed region, not part of `value`."""
     from gvl_amd import MultiScaleDeformableAttention as MSDA
     from gvl_amd.deformable_transformer import make_level_tensors
     from gvl_amd.ops.modules.ms_deform_attn import temporal_shapes_2d
@@ -122,18 +124,24 @@ def cfg_l_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20):
     value = torch.randn(B, S, M, 64, device=dev, generator=g)
     proj = torch.randn(B, Q, 2 * M * L * P, device=dev, generator=g)
     ref = torch.rand(B, Q, L, 1, device=dev, generator=g)
+    gout = torch.randn(B, Q, M * 64, device=dev, generator=g) if backward else None
+
+    def call():
+        if backward:
+            MSDA.msda1d_fused_backward(value, shapes2d, lsi, proj, ref, gout, L, P)
+        else:
+            MSDA.msda1d_fused_forward(value, shapes2d, lsi, proj, ref, L, P)
     for _ in range(3):
-        MSDA.msda1d_fused_forward(value, shapes2d, lsi, proj, ref, L, P)
+        call()
     torch.cuda.synchronize()
     MSDA.profile_enable(True)
     for _ in range(iters):
-        MSDA.msda1d_fused_forward(value, shapes2d, lsi, proj, ref, L, P)
+        call()
     torch.cuda.synchronize()
     MSDA.profile_enable(False)
-    us = [e[3] for e in MSDA.profile_collect()]
-    us = sum(us) / len(us)
-    nbytes = msda_bytes(B, S, Q)
-    return {"T": T, "S": S, "kernel_us": round(us, 2), "launches_timed": iters, "algorithmic_bytes": nbytes,
+    us = sum(e[3] for e in MSDA.profile_collect()) / iters              # backward: + k_sum_partials where it still runs
+    nbytes = (msda_bwd_bytes if backward else msda_bytes)(B, S, Q)
+    return {"B": B, "T": T, "S": S, "kernel_us": round(us, 2), "launches_timed": iters, "algorithmic_bytes": nbytes,
             "frac": round(nbytes / (us * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4),
             "note": "back-to-back launches on synthetic operands after the timed region"}
 
@@ -490,7 +498,11 @@ def main():
                          "higher_is_better": False, "roofline": line["train_roofline"]})
     line["kernels_us"] = kernels_us
     if line.get("roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and "eval" in res:
-        line["roofline"]["cfg_L_launch"] = cfg_l_probe(dev, B)
+        line["roofline"]["cfg_L_launch"] = kernel_probe(dev, B)
+        line["roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries)
+    if line.get("train_roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32":
+        line["train_roofline"]["cfg_L_launch"] = kernel_probe(dev, B, backward=True)
+        line["train_roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries, backward=True)
     if rank == 0 and "eval" in res and not a.no_captioner and a.dtype == "f32":
         with torch.no_grad():
             line["dominant_library_gemm"] = gemm_probe(model, dev, B * a.queries)

@@ -11,6 +11,9 @@ import re
 import sys
 
 
+variants = set()
+
+
 def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     out = {}
@@ -19,9 +22,17 @@ def per_kernel(d, counter):
             continue
         m = re.search(r"k_(fwd|bwd)_t1d_d64<(\d), (true|false), (true|false), (true|false), (?:(true|false), )?(\w+)>",
                       r["Kernel_Name"])
-        if not m:
-            continue
-        kind, pad, full, fused, l0g, _loop, vt = m.groups()
+        if m:
+            kind, pad, full, fused, l0g, _loop, vt = m.groups()
+        else:
+            # the level-split backward (two workgroups per slab, round 2): k_bwd_t1d_split<PAD, FUSED, VT>; it takes the
+            # role (and the key) of k_bwd_t1d_d64 at the shapes it serves
+            m = re.search(r"k_bwd_t1d_split<(\d), (true|false), (\w+)>", r["Kernel_Name"])
+            if not m:
+                continue
+            kind, l0g = "bwd", "false"
+            pad, fused, vt = m.groups()
+            variants.add("k_bwd_t1d_split")
         if vt != "float" or l0g == "true":
             continue
         key = f"k_{kind}_t1d_d64" + ("_fused" if fused == "true" else "")
@@ -40,5 +51,6 @@ for key in sorted(fetch):
     for tag, pick in (("dec", max), ("enc", min)):
         f_, w_ = pick(fetch[key]), pick(write.get(key, [0.0]))
         res[f"{key}_{tag}"] = {"fetch_bytes_raw": f_, "write_bytes": w_, "hbm_bytes_corrected": 2 * f_ + w_}
+res["backward_kernel_variant"] = sorted(variants) or ["k_bwd_t1d_d64 (+ k_sum_partials, not counted here)"]
 res["algorithmic_bytes"] = {"fwd_dec": 23363584, "fwd_enc": 16941056, "bwd_dec": 36900000, "bwd_enc": 27720000}
 print(json.dumps(res, indent=1))
