@@ -273,6 +273,8 @@ def main():
                     help="bf16 = torch.autocast(bfloat16): bf16 GEMMs + bf16-storage deformable attention, fp32 captioner")
     ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probes", action="store_true", help="skip the supplementary kernel / GEMM probes after the timed "
+                    "regions (for rocprofv3 runs: the probes launch the same kernels at other sizes)")
     ap.add_argument("--no-graph", action="store_true", help="eager steps (no hipGraph replay)")
     ap.add_argument("--decode-chunk", type=int, default=5, help="tokens per captured decode segment (0: one graph)")
     ap.add_argument("--split-exchange", action="store_true",
@@ -497,13 +499,13 @@ def main():
             line.update({"metric": "train-step ms", "value": round(ms, 3), "unit": "ms", "ms_per_step": round(ms, 3),
                          "higher_is_better": False, "roofline": line["train_roofline"]})
     line["kernels_us"] = kernels_us
-    if line.get("roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and "eval" in res:
+    if line.get("roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and "eval" in res and not a.no_probes:
         line["roofline"]["cfg_L_launch"] = kernel_probe(dev, B)
         line["roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries)
-    if line.get("train_roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32":
+    if line.get("train_roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and not a.no_probes:
         line["train_roofline"]["cfg_L_launch"] = kernel_probe(dev, B, backward=True)
         line["train_roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries, backward=True)
-    if rank == 0 and "eval" in res and not a.no_captioner and a.dtype == "f32":
+    if rank == 0 and "eval" in res and not a.no_captioner and a.dtype == "f32" and not a.no_probes:
         with torch.no_grad():
             line["dominant_library_gemm"] = gemm_probe(model, dev, B * a.queries)
     if rank == 0 and world == 1 and not a.no_cpu_baseline and "eval" in res:

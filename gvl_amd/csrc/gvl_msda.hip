@@ -971,9 +971,15 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   const int f0 = (1 - g) * qper, f1 = max(f0, min(Q, f0 + qper));      // foreign queries
   const int nq = q1 - q0;
 
-  // ---- set-up: histogram and entry table, slab loads into registers ---------------------------------------
-  for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
-  for (int i = threadIdx.x; i < nent; i += blockDim.x) ent_rp[i] = -1;
+  // ---- set-up: operands of the first foreign pass and the slab are requested first (one cold round trip for all of
+  // them), then the histogram and the entry table are initialised while those loads are in flight --------------------
+  RawOps rf_n = {0.f, 0.5f, 0.f, 0.f};
+  float4 gf_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (f0 + wave * 4 < f1) {
+    const int64_t bqn = (int64_t)b * Q + min(f0 + wave * 4 + tq, f1 - 1);
+    rf_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+    if (f0 + wave * 4 + tq < f1) gf_n = ld4(gout, (bqn * M + m) * 16 + j);
+  }
   constexpr int kPre = 3;
   const int64_t src0 = ((int64_t)b * S * M + m) * 16;
   const int nstage = S * 16;
@@ -983,6 +989,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
     const int i = threadIdx.x + k * blockDim.x;
     if (i < nstage) pre[k] = ld4(value, src0 + (int64_t)(i >> 4) * M * 16 + (i & 15));
   }
+  for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
+  for (int i = threadIdx.x; i < nent; i += blockDim.x) ent_rp[i] = -1;
   __syncthreads();
 
   // entry of sample j of slab query `ql` (0 .. 2 qper): row, coefficients, slot in the row's list
@@ -997,13 +1005,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   // ---- foreign pass: coefficients of the other half's samples in the owned levels + their grad_out rows -----------
   {
     int qb = f0 + wave * 4;
-    RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
-    float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qb < f1) {
-      const int64_t bqn = (int64_t)b * Q + min(qb + tq, f1 - 1);
-      r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-      if (qb + tq < f1) g_n = ld4(gout, (bqn * M + m) * 16 + j);
-    }
+    RawOps r_n = rf_n;
+    float4 g_n = gf_n;
     for (; qb < f1; qb += nw * 4) {
       const int q = qb + tq;
       const bool act = q < f1;
@@ -1253,6 +1256,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   }
 #undef GVL_GATHER_BATCH
 #undef GVL_GATHER_STEP
+  if (stamps) {                                                          // diagnostics only: gather done (before the store drain)
+    __syncthreads();
+    if (threadIdx.x == 0) stamps[(1024 + blockIdx.x) * 4] = wall_clock64();
+  }
 }
 
 // sum `n` fp32 partial slabs (each `count4` float4 long) into dst (storage type VT)

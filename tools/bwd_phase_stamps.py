@@ -41,6 +41,9 @@ for name, Q, rd in (("dec (Lq=300, ref-dim 2)", 300, 2), ("enc (Lq=188, ref-dim 
           f"start skew max {us[:, 0].max():.2f} | start->own pass mean {np.mean(us[:, 1] - us[:, 0]):.2f} | "
           f"own pass mean {np.mean(us[:, 2] - us[:, 1]):.2f} max {np.max(us[:, 2] - us[:, 1]):.2f} | "
           f"phase 2 mean {np.mean(us[:, 3] - us[:, 2]):.2f} | phase 2 done at mean {np.mean(us[:, 3]):.2f} max {us[:, 3].max():.2f}")
+    e3 = (buf.view(-1, 4)[4096 + 1024:4096 + 1024 + 256, 0].cpu().numpy().astype(np.int64) - s_[:, 0].min()) / 100.0
+    if e3.max() > 0:
+        print(f"    gather (phase 3) done at mean {e3.mean():.2f} max {e3.max():.2f}; per group: {e3[:128].mean():.2f} / {e3[128:].mean():.2f}")
     for g in (0, 1):
         u = us[g * 128:(g + 1) * 128]
         print(f"    workgroups g={g}: own pass begins {np.mean(u[:, 1]):.2f}, phase 1 done {np.mean(u[:, 2]):.2f}, phase 2 done {np.mean(u[:, 3]):.2f}")
