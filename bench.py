@@ -210,10 +210,26 @@ def cpu_baseline(model, opt, T, budget_s=30.0):
     threads = min(probes, key=probes.get)
     torch.set_num_threads(threads)
     probe = run(1, True)                                       # one video with the captioner: sizes the sample
-    nvid = max(1, min(16, int(budget_s * 0.7 / 7.0 / max(probe, 1e-3))))
+    nvid = max(1, min(16, int(budget_s * 0.6 / 7.0 / max(probe, 1e-3))))
     med, ts = median_of(nvid, True)
     nvid_nc = 16
     med_nc, ts_nc = median_of(nvid_nc, False)
+
+    # train step (forward + Hungarian matcher + losses + backward) through the oracle's training
+    # restatement (oracle/torch_ref.py:pdvc_train_forward, pinned to the reference by tests/test_oracle_golden.py)
+    def run_train(nv):
+        dt = synth_batch(nv, T, opt.feature_dim, opt.vocab_size, 3, "cpu", seed=1)
+        leaf = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        t0 = time.perf_counter()
+        _, total = R.pdvc_train_forward(leaf, dt, n_enc=opt.enc_layers, n_dec=opt.dec_layers, pad_mode="border")
+        total.backward()
+        return time.perf_counter() - t0
+    probe_t = run_train(2)
+    nv_t = max(2, min(16, int(2 * budget_s * 0.4 / 7.0 / max(probe_t, 1e-3))))
+    for _ in range(2):
+        run_train(nv_t)
+    tt = [run_train(nv_t) for _ in range(5)]
+    med_t = statistics.median(tt)
     return {"value": nvid / med, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{nvid} synthetic videos per iteration (3 events each), eval forward incl. {opt.max_caption_len + 1} "
                       f"greedy caption steps, oracle/torch_ref.py (grid_sample border = reference CPU fallback), "
@@ -225,8 +241,11 @@ def cpu_baseline(model, opt, T, budget_s=30.0):
             "thread_probe_s": {str(k): round(v, 3) for k, v in probes.items()},
             "thread_probe_note": "seconds for one warmed 2-video forward without captioner at each thread count; the "
                                  "protocol above ran with the faster one (BASELINE.md section 3 names os.cpu_count())",
-            "train_step": None,
-            "train_step_note": "the CPU port covers the eval forward only (no CPU training path is shipped or timed)"}
+            "train_step": {"value": med_t * 1e3, "unit": "ms", "videos_per_step": nv_t,
+                           "videos_per_s": nv_t / med_t,
+                           "sample": f"forward + Hungarian matcher (scipy) + losses + autograd backward on {nv_t} videos "
+                                     f"(3 events, 10-word captions), no optimizer step; 2 warm-ups + median of 5 "
+                                     f"(runs {', '.join(f'{x:.2f}' for x in tt)} s)"}}
 
 
 def timed_loop(step, batches, steps, warmup, world, dev):
@@ -337,9 +356,15 @@ def main():
         if os.path.exists(pmc) and (B, a.T, a.queries, a.dtype) == (16, 100, 300, "f32"):
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same launch shape (FETCH_SIZE and
             # WRITE_SIZE in separate passes, gfx950 2x FETCH correction); counters cannot be read from inside the run
-            rec = json.load(open(pmc)).get(name)
-            if rec:
+            table = json.load(open(pmc))
+            rec = table.get(name)
+            import hashlib
+            src = os.path.join(ROOT, "gvl_amd", "csrc", "gvl_msda.hip")
+            sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+            if rec and table.get("kernel_source_sha16") == sha:
                 return rec["hbm_bytes_corrected"], PMC_FILE
+            if rec:                     # counters were collected on other kernel sources: do not report them as current
+                return None, f"{PMC_FILE} is stale (collected for kernel source {table.get('kernel_source_sha16')}, now {sha})"
         return None, None
 
     def instrumented(fn, n=2):

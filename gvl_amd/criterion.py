@@ -279,6 +279,8 @@ class SetCriterion(nn.Module):
         sizes_key = (tuple(len(t_["boxes"]) for t_ in targets), str(dev))
         cached = self._const_cache.get(sizes_key)
         if cached is None:        # constants of this batch layout live on the device once (no per-step host->device copy)
+            if len(self._const_cache) >= 64:                    # bounded: one entry per batch layout seen
+                self._const_cache.pop(next(iter(self._const_cache)))
             cached = self._const_cache[sizes_key] = torch.tensor(sizes_key[0], dtype=torch.long, device=dev)
         self._gt_counts = cached
         batched = None

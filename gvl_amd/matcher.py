@@ -315,6 +315,8 @@ class HungarianMatcher(nn.Module):
         key = (nl, B, Q, tuple(sizes), str(device), m2o_rate)
         plan = self._plans.get(key)
         if plan is None:
+            if len(self._plans) >= 64:          # one plan per batch LAYOUT: bounded (a real loop rarely repeats a layout)
+                self._plans.pop(next(iter(self._plans)))
             plan = MatchPlan(nl, B, Q, list(sizes), device, m2o_rate)
             self._plans[key] = plan
         return plan

@@ -390,3 +390,151 @@ def hungarian(C, sizes, m2o_rate=4):
         r, k = linear_sum_assignment(torch.cat([c[i]] * m2o_rate, -1))
         rl.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(k % sizes[i], dtype=torch.int64)))
     return indices, rl
+
+
+# --------------------------------------------------------------------------------------------------
+# Training step (test infrastructure, like everything in this file): set criterion + teacher-forced caption loss.
+# Restates pdvc/criterion.py:48-132,163-257 and pdvc/pdvc.py:540-660,743-884 with pdvc/CaptioningHead/LSTM_DSA.py:48-117.
+# Plain differentiable PyTorch on CPU: autograd supplies the backward, as it does in the reference.
+# --------------------------------------------------------------------------------------------------
+# dataset statistic of the reference (criterion.py:39-45): share of videos with k events, k = 0..27
+COUNTER_CLASS_RATE = [
+    0.00000000e+00, 0.00000000e+00, 1.93425917e-01, 4.12129084e-01, 1.88929963e-01, 7.81296833e-02, 5.09541413e-02,
+    3.12718553e-02, 1.84833650e-02, 8.39244680e-03, 6.59406534e-03, 4.49595364e-03, 2.19802178e-03, 1.79838146e-03,
+    5.99460486e-04, 4.99550405e-04, 4.99550405e-04, 1.99820162e-04, 2.99730243e-04, 3.99640324e-04, 2.99730243e-04,
+    0.00000000e+00, 1.99820162e-04, 0.00000000e+00, 0.00000000e+00, 0.00000000e+00, 9.99100809e-05, 9.99100809e-05]
+
+
+def focal_loss(logits, onehot, num_boxes, alpha=0.25, gamma=2.0):
+    """criterion.py:232-257"""
+    p = logits.sigmoid()
+    ce = F.binary_cross_entropy_with_logits(logits, onehot, reduction="none")
+    p_t = p * onehot + (1 - p) * (1 - onehot)
+    loss = ce * (1 - p_t) ** gamma
+    if alpha >= 0:
+        loss = (alpha * onehot + (1 - alpha) * (1 - onehot)) * loss
+    return loss.mean(1).sum() / num_boxes
+
+
+def counter_loss(pred_count, n_events, beta=1, gau_mask=1):
+    """criterion.py:70-77 with cross_entropy_with_gaussian_mask (:209-229)"""
+    width = pred_count.shape[1]
+    tgt = torch.tensor([min(n, width - 1) for n in n_events], dtype=torch.long)
+    onehot = torch.zeros_like(pred_count).scatter_(1, tgt[:, None], 1.0)
+    k = torch.arange(width, dtype=pred_count.dtype)
+    gauss = torch.exp(-(k[:, None] - k[None, :]) ** 2 / (2 * 2 ** 2))[tgt]
+    weight = torch.tensor(COUNTER_CLASS_RATE[:width], dtype=pred_count.dtype)
+    loss = F.binary_cross_entropy_with_logits(pred_count, onehot, reduction="none", weight=1 - weight)
+    coef = onehot + ((1 - gauss) ** beta) * (1 - onehot) if gau_mask else torch.ones_like(onehot)
+    return (loss * coef).mean(1).mean()
+
+
+def iou_1d(a, b):
+    """box_ops.py:19-27 on (x0, x1) segments -> (iou (n, m), union)"""
+    inter = (torch.min(a[:, None, 1], b[:, 1]) - torch.max(a[:, None, 0], b[:, 0])).clamp(min=0)
+    union = (a[:, 1] - a[:, 0])[:, None] + (b[:, 1] - b[:, 0]) - inter
+    return inter / (union + 1e-5), union
+
+
+def set_losses(logits, counts, boxes, targets, indices, num_boxes, num_classes=1):
+    """labels / boxes / cardinality losses of ONE decoder layer (criterion.py:48-132) -> dict"""
+    B, Q, NC = logits.shape
+    bidx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+    qidx = torch.cat([src for src, _ in indices])
+    classes = torch.full((B, Q), num_classes, dtype=torch.long)
+    classes[bidx, qidx] = torch.cat([t_["labels"][j] for t_, (_, j) in zip(targets, indices)])
+    onehot = torch.zeros(B, Q, NC + 1, dtype=logits.dtype).scatter_(2, classes[..., None], 1.0)[..., :-1]
+    n_events = [len(t_["boxes"]) for t_ in targets]
+    out = {"loss_ce": focal_loss(logits, onehot, num_boxes) * Q, "loss_counter": counter_loss(counts, n_events)}
+    src = boxes[bidx, qidx]
+    tgt = torch.cat([t_["boxes"][j] for t_, (_, j) in zip(targets, indices)])
+    out["loss_bbox"] = (src - tgt).abs().sum() / num_boxes
+    out["loss_giou"] = (1 - torch.diag(giou_1d(box_cl_to_xy(src), box_cl_to_xy(tgt)))).sum() / num_boxes
+    self_iou = torch.triu(iou_1d(box_cl_to_xy(src), box_cl_to_xy(src))[0], diagonal=1)
+    sizes = [len(s_) for s_, _ in indices]
+    total = 0
+    for i, c in enumerate(self_iou.split(sizes, -1)):
+        total = total + c.split(sizes, -2)[i].sum() / (0.5 * sizes[i] * (sizes[i] - 1))
+    out["loss_self_iou"] = total
+    with torch.no_grad():
+        card = (logits.argmax(-1) != NC - 1).sum(1).float()
+        out["cardinality_error"] = (card - torch.tensor(n_events, dtype=torch.float32)).abs().mean()
+    return out
+
+
+def caption_loss(sd, pre, dt, hs, reference, memory, tshapes, mask, valid_ratios, indices):
+    """pdvc.py:743-884 ('standard' head, training) + Captioner.forward (LSTM_DSA.py:63-117) + build_loss (:48-52):
+    per video the matched queries packed to the front of (N, max pairs, .), teacher forcing until the first all-<pad>
+    input column, masked NLL per row, mean over all N * max_pairs rows."""
+    N, Q, C = hs.shape
+    n_gt = [len(t_["boxes"]) for t_ in dt["video_target"]]
+    base = [sum(n_gt[:i]) for i in range(N)]
+    mp = max(len(f_) for f_, _ in indices)
+    cap_len = dt["cap_tensor"].shape[-1]
+    hs_m = hs.new_zeros(N, mp, C)
+    ref_m = reference.new_zeros(N, mp, reference.shape[-1])
+    seq = torch.zeros(N, mp, cap_len, dtype=torch.long)
+    msk = torch.zeros(N, mp, cap_len)
+    for i, (feat_ids, cap_ids) in enumerate(indices):
+        k = len(feat_ids)
+        hs_m[i, :k] = hs[i, feat_ids]
+        ref_m[i, :k] = reference[i, feat_ids]
+        seq[i, :k] = dt["cap_tensor"][base[i] + cap_ids]
+        msk[i, :k] = dt["cap_mask"][base[i] + cap_ids].float()
+    seq, msk = seq.flatten(0, 1), msk.flatten(0, 1)
+    ref_in = captioner_ref_in(ref_m, valid_ratios)
+    n = N * mp
+    state = (hs.new_zeros(n, C), hs.new_zeros(n, C))
+    outs = []
+    for i in range(cap_len - 1):
+        if i >= 1 and int(seq[:, i].sum()) == 0:
+            break
+        logp, state = captioner_step(sd, pre, seq[:, i], state, hs_m, ref_in, memory, tshapes, mask)
+        outs.append(logp)
+    logp = torch.stack(outs, 1)                                               # (n, steps, V+1)
+    steps = logp.shape[1]
+    picked = logp.gather(2, seq[:, 1:1 + steps, None]).squeeze(2)
+    row = -(picked * msk[:, 1:1 + steps]).sum(1) / (msk[:, 1:].sum(1) + 1e-6)
+    return row.mean()
+
+
+def pdvc_train_forward(sd, dt, n_enc=2, n_dec=2, n_heads=8, n_levels=4, pad_mode="zeros", weights=None):
+    """PDVC.forward in training ('queries', contrastive off, aux losses, shared caption head): -> (loss dict with the
+    reference's keys, weighted total).  sd must hold tensors with requires_grad=True for a backward pass."""
+    vf = dt["video_tensor"]
+    mask = ~dt["video_mask"]
+    B = vf.shape[0]
+    srcs, masks, poses = base_encoder(sd, vf, mask, dt["video_length"][:, 1], n_levels)
+    src, tshapes, lsi, vr, pos, mflat = prepare_encoder_inputs(sd, srcs, masks, poses)
+    memory = encoder(sd, src, tshapes, lsi, vr, pos, mflat, n_enc, pad_mode=pad_mode, n_heads=n_heads)
+    qe = sd["query_embed.weight"]
+    init_ref, tgt, ref, qpos = prepare_decoder_input_query(sd, qe, B)
+    qmask = torch.ones(B, qe.shape[0], dtype=torch.bool)
+    hs, inter = decoder(sd, tgt, ref, memory, tshapes, lsi, vr, qpos, mflat, qmask, n_dec, n_heads=n_heads,
+                        pad_mode=pad_mode)
+    targets = dt["video_target"]
+    sizes = [len(t_["boxes"]) for t_ in targets]
+    num_boxes = max(float(sum(sizes)), 1.0)
+    tl = torch.cat([t_["labels"] for t_ in targets])
+    tb = torch.cat([t_["boxes"] for t_ in targets])
+    losses = {}
+    for l in range(n_dec):
+        reference = init_ref if l == 0 else inter[l - 1]
+        h = hs[l]
+        logits = _lin(sd, f"class_head.{l}", h)
+        counts = _lin(sd, f"count_head.{l}", h.max(dim=1)[0])
+        tmp = mlp3(sd, f"bbox_head.{l}.", h)
+        r = inverse_sigmoid(reference)
+        tmp = tmp + r if r.shape[-1] == 2 else torch.cat([tmp[..., :1] + r, tmp[..., 1:]], -1)
+        boxes = tmp.sigmoid()
+        with torch.no_grad():
+            indices, _ = hungarian(matcher_cost(logits, boxes, tl, tb), sizes)
+        suffix = "" if l == n_dec - 1 else f"_{l}"
+        for k, v in set_losses(logits, counts, boxes, targets, indices, num_boxes).items():
+            losses[k + suffix] = v
+        losses["loss_caption" + suffix] = caption_loss(sd, f"caption_head.{l}.", dt, h, reference, memory, tshapes, mflat,
+                                                       vr, indices)
+    w = weights or {"loss_ce": 2.0, "loss_bbox": 0.0, "loss_giou": 4.0, "loss_counter": 0.5, "loss_caption": 2.0}
+    total = sum(v * w[k.rsplit("_", 1)[0] if k[-1].isdigit() else k] for k, v in losses.items()
+                if (k.rsplit("_", 1)[0] if k[-1].isdigit() else k) in w)
+    return losses, total

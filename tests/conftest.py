@@ -20,7 +20,7 @@ def pytest_sessionstart(session):
     import subprocess
     from gvl_amd import build as b
     try:
-        if not os.path.exists(b.OUT):
+        if b.needs_build():                                 # missing OR older than its sources
             b.build()
         if not os.path.exists(os.path.join(ROOT, "oracle", "libgvl_oracle.so")):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])

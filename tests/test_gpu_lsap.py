@@ -77,3 +77,26 @@ def test_device_lsap_flags_invalid_costs():
     P = torch.tensor([[0, 2, 2, 2, 1, 0, 0, 0]], dtype=torch.int64, device=dev)
     _, _, status = lsap_batch_device(C.reshape(-1), P, 2, 2, 2)
     assert int(status) == 1
+
+
+def test_more_events_than_the_on_chip_solver_holds_falls_back_to_the_host_solver():
+    """Q = 300 with > 64 events in one video exceeds the device solver's min(Q, 4 n) <= 256 limit; the criterion
+    must then take the host solver (gvl_hungarian_batch_f32) instead of raising -- the reference handles any size."""
+    from scipy.optimize import linear_sum_assignment
+    from gvl_amd.config import make_opt
+    from gvl_amd.pdvc import build
+    dev = torch.device("cuda:0")
+    opt = make_opt(num_queries=300, device="cuda")
+    _, criterion, _, _ = build(opt)
+    g = torch.Generator().manual_seed(9)
+    B, Q, ns = 2, 300, [70, 3]
+    out = {"pred_logits": torch.randn(B, Q, 1, generator=g).to(dev), "pred_count": torch.randn(B, 11, generator=g).to(dev),
+           "pred_boxes": (torch.rand(B, Q, 2, generator=g) * 0.5 + 0.2).to(dev)}
+    targets = [{"boxes": (torch.rand(n, 2, generator=g) * 0.4 + 0.2).to(dev), "labels": torch.zeros(n, dtype=torch.long, device=dev)}
+               for n in ns]
+    losses, idx = criterion(dict(out), targets)
+    C = criterion.matcher.cost_matrix(out, targets).float().cpu()
+    for i, (c, (rows, cols)) in enumerate(zip(C.split(ns, -1), idx[0])):
+        r, k = linear_sum_assignment(c[i].numpy())
+        assert torch.equal(rows.cpu(), torch.as_tensor(r)) and torch.equal(cols.cpu(), torch.as_tensor(k))
+    assert all(torch.isfinite(v) for k, v in losses.items() if "self_iou" not in k)

@@ -294,3 +294,36 @@ def test_collate_fn_matches_reference():
     for i, tg in enumerate(dt["video_target"]):
         assert torch.equal(tg["boxes"], t(f[f"target.{i}.boxes"])) and torch.equal(tg["labels"], t(f[f"target.{i}.labels"]))
         assert tg["masks"] is None and tg["image_id"] == dt["video_key"][i]
+
+
+def test_oracle_train_step_matches_reference_golden():
+    """the oracle's restatement of the TRAINING step (set criterion, Hungarian matching, teacher-forced caption loss,
+    autograd backward) against the reference run recorded in pdvc_train.npz: every loss term, the weighted total and the
+    gradient norm of every parameter."""
+    from oracle import torch_ref as R
+    from helpers import pdvc_state, pdvc_dt
+    f, g = load("pdvc_eval"), load("pdvc_train")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in pdvc_state(f).items()}
+    dt = pdvc_dt(f)
+    dt.update(cap_tensor=t(g["cap_tensor"]), cap_mask=t(g["cap_mask"]))
+    losses, total = R.pdvc_train_forward(sd, dt)
+    for k in [k for k in g if k.startswith("loss.")]:
+        assert abs(float(losses[k[5:]]) - float(g[k])) <= 2e-4 * max(1.0, abs(float(g[k]))), k
+    assert abs(float(total) - float(g["final_loss"])) <= 2e-4 * float(g["final_loss"])
+    total.backward()
+    names = [str(n) for n in g["grad_names"]]
+    # tied parameters (pdvc.py:124-140): the reference accumulates both uses into ONE tensor, the flat state dict of the
+    # oracle keeps them under two names
+    def grad_of(n):
+        tot = None
+        for k in (n, "transformer.decoder." + n if n.startswith("bbox_head.") else None,
+                  "caption_head.0." + n[len("caption_head.1."):] if n.startswith("caption_head.1.") else None,
+                  "caption_head.1." + n[len("caption_head.0."):] if n.startswith("caption_head.0.") else None,
+                  n[len("transformer.decoder."):] if n.startswith("transformer.decoder.bbox_head.") else None):
+            if k is not None and k in sd and sd[k].grad is not None:
+                tot = sd[k].grad if tot is None else tot + sd[k].grad
+        return tot
+    for n, want in zip(names, g["grad_norms"]):
+        got = grad_of(n)
+        assert got is not None, n
+        assert abs(float(got.norm()) - float(want)) <= 2e-3 * max(1.0, float(want)), (n, float(got.norm()), float(want))

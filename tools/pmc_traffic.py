@@ -51,6 +51,10 @@ for key in sorted(fetch):
     for tag, pick in (("dec", max), ("enc", min)):
         f_, w_ = pick(fetch[key]), pick(write.get(key, [0.0]))
         res[f"{key}_{tag}"] = {"fetch_bytes_raw": f_, "write_bytes": w_, "hbm_bytes_corrected": 2 * f_ + w_}
+import hashlib
+import os
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gvl_amd", "csrc", "gvl_msda.hip")
+res["kernel_source_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]    # bench.py flags a stale file
 res["backward_kernel_variant"] = sorted(variants) or ["k_bwd_t1d_d64 (+ k_sum_partials, not counted here)"]
 res["algorithmic_bytes"] = {"fwd_dec": 23363584, "fwd_enc": 16941056, "bwd_dec": 36900000, "bwd_enc": 27720000}
 print(json.dumps(res, indent=1))
