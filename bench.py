@@ -296,6 +296,8 @@ def main():
                     "regions (for rocprofv3 runs: the probes launch the same kernels at other sizes)")
     ap.add_argument("--no-graph", action="store_true", help="eager steps (no hipGraph replay)")
     ap.add_argument("--decode-chunk", type=int, default=5, help="tokens per captured decode segment (0: one graph)")
+    ap.add_argument("--cap-len-policy", default="bucket", choices=["bucket", "grow"],
+                    help="train graphs: one per caption-width bucket of 4 tokens (default) or ONE at the widest width seen")
     ap.add_argument("--split-exchange", action="store_true",
                     help="train on one GPU in the data-parallel form (two graphs + eager exchange point); diagnostic")
     ap.add_argument("--no-tuned-gemm", action="store_true",
@@ -417,7 +419,8 @@ def main():
         # all-reduce of the flat gradient buffer, clip/Adam graph (no collective inside a graph) -- GraphedTrainStep
         if not a.no_graph:
             trainer = GraphedTrainStep(model, criterion, opt, world_size=world,
-                                       split_exchange=True if a.split_exchange else None, autocast_dtype=ac)
+                                       split_exchange=True if a.split_exchange else None, autocast_dtype=ac,
+                                       cap_len_policy=a.cap_len_policy)
         else:
             trainer = TrainStep(model, criterion, opt, world_size=world, autocast_dtype=ac)
         for dt in batches:
@@ -436,6 +439,8 @@ def main():
                             "captures_in_timed_region": trainer.captures - caps0, "replays": trainer.replays,
                             "padded_targets_slots": trainer.capacity.slots,
                             "padded_caption_width": trainer.capacity.cap_len,
+                            "caption_width_policy": trainer.capacity.cap_len_policy,
+                            "device_memory_reserved_GB": round(torch.cuda.memory_reserved() / 2 ** 30, 2),
                             "form": "two graphs + eager gradient exchange" if trainer.split else "one graph"}}
 
     # ---------------------------------------------------------------------------------------------- the line

@@ -204,9 +204,13 @@ class _LRU(OrderedDict):
 _STATIC_KEYS = ("video_tensor", "video_mask", "video_length")
 
 
-def _drop_superseded(graphs, key):
-    """capacities only grow, so a padded graph of the same tensor shapes with a smaller capacity is never replayed again"""
-    for k in [k for k in graphs if k[0] == "padded" and k[1] == key[1]]:
+def _drop_superseded(graphs, key, keep_width_buckets=False):
+    """grow-only capacities never shrink, so a padded graph of the same tensor shapes with a smaller one is never
+    replayed again.  Key layout: ("padded", shapes, slots, cap_len, rows[, epoch]); with cap_len_policy="bucket" the
+    caption width is not a grow-only capacity: graphs that differ only in it stay."""
+    def grow_part(k):
+        return ((k[2],) + tuple(k[4:])) if keep_width_buckets else tuple(k[2:])
+    for k in [k for k in graphs if k[0] == "padded" and k[1] == key[1] and grow_part(k) != grow_part(key)]:
         del graphs[k]
 
 
@@ -237,16 +241,22 @@ class _Capacity:
     whole batch, train only) = next multiple of 32 >= the largest event total seen.  A batch that does not fit raises
     the capacity and the step is captured again; in a steady run that happens a handful of times, then never."""
 
-    def __init__(self, slots=0, cap_len=0, pair_rows=0):
+    def __init__(self, slots=0, cap_len=0, pair_rows=0, cap_len_policy="grow"):
         self.slots, self.cap_len, self.pair_rows = int(slots or 0), int(cap_len or 0), int(pair_rows or 0)
+        self.cap_len_policy = cap_len_policy
 
     def fit(self, dt, with_captions):
         n_gt, cap_len = needed_capacity(dt)
         self.slots = max(self.slots, round_up_pow2(n_gt, 4))
-        if with_captions:
-            self.cap_len = max(self.cap_len, 4 * ((max(cap_len, 2) + 3) // 4))
-            self.pair_rows = max(self.pair_rows, 32 * ((max(total_events(dt), 1) + 31) // 32))
-        return self.slots, (self.cap_len if with_captions else 0)
+        if not with_captions:
+            return self.slots, 0
+        bucket = 4 * ((max(cap_len, 2) + 3) // 4)
+        self.cap_len = max(self.cap_len, bucket)
+        self.pair_rows = max(self.pair_rows, 32 * ((max(total_events(dt), 1) + 31) // 32))
+        # "bucket": the step runs at THIS batch's caption-width bucket (one graph per bucket of 4 tokens, <= 8 for
+        # max_caption_len = 30) instead of at the widest caption tensor seen so far -- the teacher-forced loop is serial in
+        # the caption length, so a batch of 10-word captions then pays 11 steps, not the 23 a 22-word batch once needed
+        return self.slots, (bucket if self.cap_len_policy == "bucket" else self.cap_len)
 
 
 class GraphedTrainStep(TrainStep):
@@ -268,7 +278,8 @@ class GraphedTrainStep(TrainStep):
     the RNG state exactly as they were (snapshot / restore), so every batch gets ONE update, as in train.py."""
 
     def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=2, split_exchange=None,
-                 autocast_dtype=None, max_graphs=4, max_gt=0, max_cap_len=0, max_events=0, padded=None):
+                 autocast_dtype=None, max_graphs=8, max_gt=0, max_cap_len=0, max_events=0, padded=None,
+                 cap_len_policy="bucket"):
         """split_exchange (default: exactly when there is more than one process): the step is captured as TWO graphs --
         zero_grad + forward + backward into the flat gradient buffer, then clip + Adam -- with the bucketed RCCL
         all-reduce issued eagerly between the two replays, so no collective is ever inside a hipGraph.  The criterion's
@@ -276,13 +287,16 @@ class GraphedTrainStep(TrainStep):
         target counts and reaches the captured criterion through device memory.
         max_gt / max_cap_len / max_events: initial capacities of the padded layout -- events per video, caption tensor
         width, events per batch (0 = grow from the batches seen).
-        padded: None = automatic, False = always one graph per batch layout."""
+        padded: None = automatic, False = always one graph per batch layout.
+        cap_len_policy: "bucket" (default) = one graph per caption-width bucket of 4 tokens, each batch replays the graph
+        of its own bucket; "grow" = ONE graph at the widest caption tensor seen (fewer graphs, every batch pays the
+        longest caption's teacher-forced steps)."""
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
         super().__init__(model, criterion, opt, world_size, process_group, capturable=True,
                          flat=True if self.split else None, overlap=not self.split, autocast_dtype=autocast_dtype)
         self.graphs = _LRU(max_graphs)
         self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, max_cap_len,
-                                  32 * ((max_events + 31) // 32) if max_events else 0)
+                                  32 * ((max_events + 31) // 32) if max_events else 0, cap_len_policy)
         self.padded = padded
         self.captures = self.replays = 0
         # >= 1 real step must run before the capture (on a side stream): autograd's gradient accumulators, hipBLASLt
@@ -424,7 +438,7 @@ class GraphedTrainStep(TrainStep):
             key = ("padded", tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in _STATIC_KEYS), slots, cap_len, rows)
             entry = self.graphs.lookup(key)
             if entry is None:
-                _drop_superseded(self.graphs, key)
+                _drop_superseded(self.graphs, key, self.capacity.cap_len_policy == "bucket")
                 batch = _PaddedBatch(dt, slots, cap_len, rows)
                 batch.load(dt, nb)
                 graphs, outs = self._capture(batch.dt)

@@ -89,7 +89,7 @@ def test_graphed_train_step_one_graph_for_all_layouts(split):
     opt, model_a, crit_a, T = toy(True)
     _, model_b, crit_b, _ = toy(True)
     eager = TrainStep(model_a, crit_a, opt, capturable=True)
-    graphed = GraphedTrainStep(model_b, crit_b, opt, split_exchange=split, max_gt=8, max_cap_len=8)
+    graphed = GraphedTrainStep(model_b, crit_b, opt, split_exchange=split, max_gt=8, max_cap_len=8, cap_len_policy="grow")
     bs = batches(T)
     for step in range(12):
         dt = bs[step % len(bs)]
@@ -120,10 +120,16 @@ def test_graphed_train_step_capacity_grows_and_cache_is_bounded():
     from gvl_amd.parallel import GraphedTrainStep
     opt, model, crit, T = toy(True)
     bs = batches(T)
-    g = GraphedTrainStep(model, crit, opt)
+    g = GraphedTrainStep(model, crit, opt, cap_len_policy="grow")
     for dt in bs + bs:
         g(dt)
     assert len(g.graphs) == 1 and g.captures <= 4 and g.capacity.slots == 8
+    # default policy: one graph per caption-width bucket of 4 tokens (widths 3..6 here -> buckets 4 and 8), each batch
+    # replayed at its own bucket; growth of the grow-only capacities (slots, rows) drops the graphs it supersedes
+    gb = GraphedTrainStep(model, crit, opt)
+    for dt in bs + bs:
+        gb(dt)
+    assert len(gb.graphs) == 2 and {k[3] for k in gb.graphs} == {4, 8} and gb.replays == 2 * len(bs)
     g2 = GraphedTrainStep(model, crit, opt, padded=False, max_graphs=3)
     for dt in bs:
         g2(dt)
