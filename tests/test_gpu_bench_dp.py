@@ -24,7 +24,7 @@ def test_two_ranks_on_one_gpu(mode):
     env = dict(os.environ, GVL_DIST_BACKEND="gloo", GVL_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--batch", "4", "--queries", "40", "--no-cpu-baseline"] + (["--mode", "train"] if mode == "train" else [])
+           "--warmup", "1", "--batch", "4", "--queries", "40", "--rotate", "3", "--no-cpu-baseline", "--no-probes"] + (["--mode", "train"] if mode == "train" else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
