@@ -114,7 +114,26 @@ CFG = [
     ("cfgA_enc", 16, 100, 8, 64, 188, 4),          # encoder self-attention (Lq = S)
     ("ragged", 3, 37, 5, 64, 23, 3),               # Q not a multiple of 4, L*P = 12 < 16, odd sizes
     ("one_row_levels", 2, 4, 2, 64, 9, 4),         # levels 4,2,1,1 -> T_l == 1 edge case
+    ("split_odd", 16, 37, 8, 64, 33, 4),           # B*M = 128: the level-split backward with an odd query count (17 + 16)
+    ("split_q3", 16, 20, 8, 64, 3, 4),             # ... and with almost no queries (2 + 1)
 ]
+
+
+def test_level_split_backward_equals_query_split(dev, MSDA):
+    """k_bwd_t1d_split (two workgroups per slab own disjoint pyramid levels) against k_bwd_t1d_d64 + k_sum_partials on the
+    same inputs: grad_loc / grad_attn bit for bit (same arithmetic in the own pass), grad_value to summation order."""
+    value, shapes, lsi, loc, aw, gout = make_inputs(16, 100, 8, 64, 300, 4, seed=77)
+    args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
+    res = {}
+    for split in ("1", "0"):
+        os.environ["GVL_MSDA_BWD_SPLIT"] = split
+        try:
+            res[split] = MSDA.ms_deform_attn_backward(*args, t(gout).to(dev), 64)
+        finally:
+            os.environ.pop("GVL_MSDA_BWD_SPLIT", None)
+    (gv1, gl1, gw1), (gv0, gl0, gw0) = res["1"], res["0"]
+    assert torch.equal(gl1, gl0) and torch.equal(gw1, gw0)
+    assert maxerr(gv1, gv0) <= 1e-5 * scale(gv0.cpu().numpy())
 
 
 @pytest.mark.parametrize("name,B,T,M,D,Q,P", CFG)
