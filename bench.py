@@ -299,7 +299,7 @@ def main():
     ap.add_argument("--cap-len-policy", default="bucket", choices=["bucket", "grow"],
                     help="train graphs: one per caption-width bucket of 4 tokens (default) or ONE at the widest width seen")
     ap.add_argument("--split-exchange", action="store_true",
-                    help="train on one GPU in the data-parallel form (two graphs + eager exchange point); diagnostic")
+                    help="train on one GPU in the data-parallel form (three graphs + eager exchange points); diagnostic")
     ap.add_argument("--no-tuned-gemm", action="store_true",
                     help="keep hipBLASLt's default kernel choice instead of gvl_amd/tunableop_mi355x.csv")
     a = ap.parse_args()
@@ -441,7 +441,9 @@ def main():
                             "padded_caption_width": trainer.capacity.cap_len,
                             "caption_width_policy": trainer.capacity.cap_len_policy,
                             "device_memory_reserved_GB": round(torch.cuda.memory_reserved() / 2 ** 30, 2),
-                            "form": "two graphs + eager gradient exchange" if trainer.split else "one graph"}}
+                            "form": ("three graphs (forward + backward to the encoder output | encoder backward | clip + Adam) with "
+                                     "the bucketed gradient exchange posted eagerly between them") if trainer.split
+                            else "one graph"}}
 
     # ---------------------------------------------------------------------------------------------- the line
     src_note = ("per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region" if a.no_graph

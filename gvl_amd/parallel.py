@@ -43,11 +43,15 @@ def shard_batch(dt, rank, world):
 class GradBuckets:
     """Flat gradient storage + overlapped bucketed all-reduce."""
 
-    def __init__(self, params, bucket_bytes=25 << 20, process_group=None, flat=None, overlap=True):
+    def __init__(self, params, bucket_bytes=25 << 20, process_group=None, flat=None, overlap=True, first=None):
         """flat=None: flat buffer exactly when there is more than one process.  overlap=False: no autograd hooks --
         the buckets are exchanged by an explicit ``exchange()`` after backward (what a captured forward/backward
-        needs: collectives stay outside the hipGraph)."""
+        needs: collectives stay outside the hipGraph).
+        first: parameters whose gradients are complete EARLY (a two-stage backward: everything downstream of a cut);
+        they are laid out first, with a bucket boundary behind them, so that ``exchange_begin(0)`` can put them on the
+        wire while the second stage still runs (``self.n_first`` buckets)."""
         self.params = [p for p in params if p.requires_grad]
+        first_ids = {id(p) for p in (first or [])}
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # One process, nothing to exchange: leave .grad = None so that autograd hands every gradient over without the
@@ -55,6 +59,7 @@ class GradBuckets:
         self.flat = None
         self.buckets, self.bucket_of, self.ready, self.handles = [], {}, [], []
         self.next_bucket, self.seen = 0, set()
+        self.n_first = 0
         self.overlap = overlap
         if not (self.world > 1 if flat is None else flat):
             return
@@ -65,15 +70,21 @@ class GradBuckets:
         self.buckets = []            # (start, end, n_params)
         self.bucket_of = {}
         cur_start, cur_n, off = 0, 0, 0
-        for p in reversed(self.params):
+        rev = list(reversed(self.params))
+        order = [p for p in rev if id(p) in first_ids] + [p for p in rev if id(p) not in first_ids]
+        n_lead = sum(1 for p in rev if id(p) in first_ids)
+        self.n_first = 0
+        for k, p in enumerate(order):
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             self.bucket_of[id(p)] = len(self.buckets)
             off += n
             cur_n += 1
-            if (off - cur_start) * self.flat.element_size() >= bucket_bytes:
+            if (off - cur_start) * self.flat.element_size() >= bucket_bytes or (n_lead and k == n_lead - 1):
                 self.buckets.append((cur_start, off, cur_n))
                 cur_start, cur_n = off, 0
+                if n_lead and k == n_lead - 1:
+                    self.n_first = len(self.buckets)
         if cur_n:
             self.buckets.append((cur_start, off, cur_n))
         self.ready = [0] * len(self.buckets)
@@ -117,6 +128,23 @@ class GradBuckets:
             h.wait()
         self.flat.div_(self.world)
 
+    def exchange_begin(self, stage):
+        """two-stage form: stage 0 = the `first` buckets (complete after the first backward stage), stage 1 = the rest.
+        The all-reduces are posted asynchronously (RCCL's stream waits for the work already queued on the current stream,
+        later work on the current stream overlaps them); ``exchange_end()`` waits for all of them and averages."""
+        if self.world == 1 or self.flat is None:
+            return
+        part = self.buckets[:self.n_first] if stage == 0 else self.buckets[self.n_first:]
+        self.handles += [dist.all_reduce(self.flat[s:e], group=self.group, async_op=True) for s, e, _ in part]
+
+    def exchange_end(self):
+        if self.world == 1 or self.flat is None:
+            return
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.flat.div_(self.world)
+
     def finish(self):
         """wait for the in-flight buckets, reduce the ones whose parameters got no gradient this step, average."""
         if self.world == 1 or self.flat is None:
@@ -141,14 +169,14 @@ class TrainStep:
     """zero_grad -> forward -> weighted loss -> backward (+ overlapped all-reduce) -> clip -> Adam (train.py:385-409)"""
 
     def __init__(self, model, criterion, opt, world_size=1, process_group=None, capturable=False, flat=None,
-                 overlap=True, autocast_dtype=None):
+                 overlap=True, autocast_dtype=None, first=None):
         """autocast_dtype (e.g. torch.bfloat16): forward + losses under torch.autocast -- bf16 GEMMs and bf16-storage
         deformable attention, fp32 master weights / Adam, fp32 islands for the teacher-forced captioner loop and the
         criterion kernels."""
         self.model, self.criterion, self.opt = model, criterion, opt
         self.autocast_dtype = autocast_dtype
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.buckets = GradBuckets(self.params, process_group=process_group, flat=flat, overlap=overlap)
+        self.buckets = GradBuckets(self.params, process_group=process_group, flat=flat, overlap=overlap, first=first)
         # fused=True: one multi-tensor kernel per ~100 parameters instead of ~15 foreach kernels each (321 -> ~10
         # launches per step; the step is launch-bound even inside a hipGraph).  Same update rule (train.py:286).
         fused = self.params[0].is_cuda
@@ -280,9 +308,11 @@ class GraphedTrainStep(TrainStep):
     def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=2, split_exchange=None,
                  autocast_dtype=None, max_graphs=8, max_gt=0, max_cap_len=0, max_events=0, padded=None,
                  cap_len_policy="bucket"):
-        """split_exchange (default: exactly when there is more than one process): the step is captured as TWO graphs --
-        zero_grad + forward + backward into the flat gradient buffer, then clip + Adam -- with the bucketed RCCL
-        all-reduce issued eagerly between the two replays, so no collective is ever inside a hipGraph.  The criterion's
+        """split_exchange (default: exactly when there is more than one process): the step is captured as THREE graphs --
+        (1) zero_grad + forward + losses + backward down to the encoder output, (2) the encoder's backward, (3) clip +
+        Adam -- with the bucketed RCCL all-reduce issued eagerly between the replays, so no collective is ever inside a
+        hipGraph: the buckets of stage 1 (captioner, heads, decoder) are posted before graph 2 is replayed and travel
+        while it runs, the encoder's buckets follow, graph 3 waits for all of them.  The criterion's
         own ``all_reduce(num_boxes)`` (criterion.py:178-180) is taken before the first graph from the host-known
         target counts and reaches the captured criterion through device memory.
         max_gt / max_cap_len / max_events: initial capacities of the padded layout -- events per video, caption tensor
@@ -292,8 +322,17 @@ class GraphedTrainStep(TrainStep):
         of its own bucket; "grow" = ONE graph at the widest caption tensor seen (fewer graphs, every batch pays the
         longest caption's teacher-forced steps)."""
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
+        # data-parallel form: the backward is cut at the encoder output (`memory`).  Stage 1 (captioner, heads, decoder:
+        # ~2/3 of the 100 MB of gradients) completes first; its buckets travel while stage 2 (deformable encoder, base
+        # encoder) still runs -- the exchange is eager RCCL between graph replays, never inside a hipGraph
+        late = None
+        if self.split and hasattr(model, "encoder_decoder_parameters"):
+            late = [p for p in model.encoder_decoder_parameters()[1] if p.requires_grad]
         super().__init__(model, criterion, opt, world_size, process_group, capturable=True,
-                         flat=True if self.split else None, overlap=not self.split, autocast_dtype=autocast_dtype)
+                         flat=True if self.split else None, overlap=not self.split, autocast_dtype=autocast_dtype,
+                         first=late)
+        self.two_stage = bool(self.split and late and self.buckets.n_first)
+        self._cut = None
         self.graphs = _LRU(max_graphs)
         self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, max_cap_len,
                                   32 * ((max_events + 31) // 32) if max_events else 0, cap_len_policy)
@@ -367,10 +406,28 @@ class GraphedTrainStep(TrainStep):
         return max(n, 1.0)
 
     def _forward_backward(self, dt):
+        """stage 1 of the data-parallel step: zero_grad, forward, losses, backward down to the encoder output"""
         self.buckets.zero()
-        final, loss = self._forward_loss(dt)
+        cut = {}
+
+        def memory_cut(memory):
+            cut["src"], cut["leaf"] = memory, memory.detach().requires_grad_()
+            return cut["leaf"]
+        if self.two_stage:
+            self.model.memory_cut = memory_cut
+        try:
+            final, loss = self._forward_loss(dt)
+        finally:
+            self.model.memory_cut = None
         final.backward()
+        self._cut = cut
         return final.detach(), loss
+
+    def _backward_encoder(self):
+        """stage 2: the gradient of the encoder output through the deformable encoder and the base encoder"""
+        if self.two_stage and self._cut:
+            self._cut["src"].backward(self._cut["leaf"].grad)
+        self._cut = None
 
     def _update(self):
         torch.nn.utils.clip_grad_norm_(self.params, self.opt.grad_clip)
@@ -407,6 +464,7 @@ class GraphedTrainStep(TrainStep):
             for _ in range(self.warmup):
                 if self.split:
                     self._forward_backward(st)
+                    self._backward_encoder()
                     self._update()
                 else:
                     TrainStep.__call__(self, st)
@@ -415,12 +473,14 @@ class GraphedTrainStep(TrainStep):
         # captured from another stream they become a parallel branch of the graph that the optimizer kernels do not
         # wait for (seen as NaN parameters after a few replays of the bf16 step)
         if self.split:
-            g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            g_fb, g_enc, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_fb, stream=side):
                 outs = self._forward_backward(st)
+            with torch.cuda.graph(g_enc, pool=g_fb.pool(), stream=side):
+                self._backward_encoder()
             with torch.cuda.graph(g_up, pool=g_fb.pool(), stream=side):
                 self._update()
-            graphs = (g_fb, g_up)
+            graphs = (g_fb, g_enc, g_up)
         else:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
@@ -462,8 +522,12 @@ class GraphedTrainStep(TrainStep):
             self._refresh(st, dt)
         graphs[0].replay()
         if self.split:
-            self.buckets.exchange()                               # eager RCCL between the two replays
+            # eager RCCL between the replays: the first-stage buckets are on the wire while the encoder's backward runs
+            self.buckets.exchange_begin(0)
             graphs[1].replay()
+            self.buckets.exchange_begin(1)
+            self.buckets.exchange_end()
+            graphs[2].replay()
         self.replays += 1
         return outs
 

@@ -162,6 +162,11 @@ class PDVC(nn.Module):
     def forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
         N = dt['video_tensor'].shape[0]
         memory, tshapes, lsi, valid_ratios, mask_flat = self.encode(dt)
+        cut = getattr(self, "memory_cut", None)
+        if cut is not None and torch.is_grad_enabled():
+            # two-stage backward of the data-parallel captured step (gvl_amd.parallel): everything below sees a detached
+            # leaf; the caller later feeds its gradient into the encoder's graph
+            memory = cut(memory)
         if transformer_input_type == 'gt_proposals':                              # misc/utils.py:32-43
             proposals_mask = dt['gt_boxes_mask']
             criterion.matcher.cost_caption = 0

@@ -149,10 +149,28 @@ def _worker_gather(rank, world, port, q):
         buckets.finish()
         grads = [p.grad.clone().numpy() for p in params]
         unused = [i for i, p in enumerate(params) if any(p is u for u in buckets.unused_params())]
-        q.put((rank, merged, grads, unused))
+        # ---- two-stage exchange of the captured data-parallel step: the `first` group (gradients complete after the
+        # first backward stage) occupies the leading buckets and travels while the second stage would still run
+        torch.manual_seed(1)
+        l2 = [torch.nn.Linear(16, 16) for _ in range(4)]
+        p2 = [p for l_ in l2 for p in l_.parameters()]
+        late = [p for l_ in l2[2:] for p in l_.parameters()]
+        b2 = GradBuckets(p2, bucket_bytes=600, flat=True, overlap=False, first=late)
+        assert 0 < b2.n_first < len(b2.buckets)
+        lead = {b2.bucket_of[id(p)] for p in late}
+        assert lead == set(range(b2.n_first)) and all(b2.bucket_of[id(p)] >= b2.n_first for p in p2 if all(p is not q_ for q_ in late))
+        b2.zero()
+        xx = torch.ones(2, 16) * (rank + 1)
+        sum(l_(xx).sum() for l_ in l2[2:]).backward()                  # stage 1: the late layers
+        b2.exchange_begin(0)
+        sum(l_(xx).sum() for l_ in l2[:2]).backward()                  # stage 2 overlaps the first exchange
+        b2.exchange_begin(1)
+        b2.exchange_end()
+        two_stage = [p.grad.clone().numpy() for p in p2]
+        q.put((rank, merged, grads, unused, two_stage))
     except Exception:
         import traceback
-        q.put((rank, "error", traceback.format_exc(), None))
+        q.put((rank, "error", traceback.format_exc(), None, None))
     finally:
         dist.destroy_process_group()
 
@@ -188,3 +206,8 @@ def test_eval_result_gather_and_fixed_bucket_order():
         for got, w in zip(res[r][2], want):
             assert torch.allclose(torch.from_numpy(got), w, atol=1e-6)
     assert res[0][3] == [6, 7] and res[1][3] == [0, 1]          # each rank's locally unused layer (weight, bias)
+    # two-stage exchange: every layer's gradient is the mean over the ranks (x = 1 and 2 -> weight 3, bias 2)
+    for r in range(2):
+        for li in range(4):
+            assert torch.allclose(torch.from_numpy(res[r][4][2 * li]), torch.full((16, 16), 3.0), atol=1e-6)
+            assert torch.allclose(torch.from_numpy(res[r][4][2 * li + 1]), torch.full((16,), 2.0), atol=1e-6)
