@@ -296,8 +296,8 @@ def main():
                     "regions (for rocprofv3 runs: the probes launch the same kernels at other sizes)")
     ap.add_argument("--no-graph", action="store_true", help="eager steps (no hipGraph replay)")
     ap.add_argument("--decode-chunk", type=int, default=5, help="tokens per captured decode segment (0: one graph)")
-    ap.add_argument("--cap-len-policy", default="bucket", choices=["bucket", "grow"],
-                    help="train graphs: one per caption-width bucket of 4 tokens (default) or ONE at the widest width seen")
+    ap.add_argument("--cap-len-policy", default="grow", choices=["bucket", "grow"],
+                    help="train graphs: ONE at the widest caption width seen (default) or one per caption-width bucket of 4 tokens")
     ap.add_argument("--split-exchange", action="store_true",
                     help="train on one GPU in the data-parallel form (three graphs + eager exchange points); diagnostic")
     ap.add_argument("--no-tuned-gemm", action="store_true",

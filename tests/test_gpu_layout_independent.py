@@ -124,9 +124,9 @@ def test_graphed_train_step_capacity_grows_and_cache_is_bounded():
     for dt in bs + bs:
         g(dt)
     assert len(g.graphs) == 1 and g.captures <= 4 and g.capacity.slots == 8
-    # default policy: one graph per caption-width bucket of 4 tokens (widths 3..6 here -> buckets 4 and 8), each batch
+    # bucket policy: one graph per caption-width bucket of 4 tokens (widths 3..6 here -> buckets 4 and 8), each batch
     # replayed at its own bucket; growth of the grow-only capacities (slots, rows) drops the graphs it supersedes
-    gb = GraphedTrainStep(model, crit, opt)
+    gb = GraphedTrainStep(model, crit, opt, cap_len_policy="bucket")
     for dt in bs + bs:
         gb(dt)
     assert len(gb.graphs) == 2 and {k[3] for k in gb.graphs} == {4, 8} and gb.replays == 2 * len(bs)
