@@ -382,7 +382,7 @@ class GraphedTrainStep(TrainStep):
         for k in GraphedTrainStep._tensor_keys(dt):
             st[k] = dt[k].clone()
         st["video_target"] = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in t_.items()}
-                              for t_ in dt["video_target"]]
+                              for t_ in dt.get("video_target") or []]
         return st
 
     @staticmethod
@@ -390,7 +390,7 @@ class GraphedTrainStep(TrainStep):
         for k, v in dt.items():
             if isinstance(v, torch.Tensor):
                 st[k].copy_(v, non_blocking=True)
-        for a, b in zip(st["video_target"], dt["video_target"]):
+        for a, b in zip(st["video_target"], dt.get("video_target") or []):
             for k, v in b.items():
                 if isinstance(v, torch.Tensor):
                     a[k].copy_(v, non_blocking=True)
@@ -648,7 +648,7 @@ class GraphedEvalForward:
             key = ("padded", tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in _STATIC_KEYS), slots, epoch)
         else:
             sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in dt.items() if isinstance(v, torch.Tensor))
-            key = ("layout", sig, tuple(len(t_["boxes"]) for t_ in dt["video_target"]), epoch)
+            key = ("layout", sig, tuple(len(t_["boxes"]) for t_ in dt.get("video_target") or []), epoch)
         entry = self.graphs.lookup(key)
         if entry is None:
             if padded:

@@ -215,3 +215,18 @@ def test_decode_segments_stop_with_the_longest_caption():
         assert ge.segments_replayed == expect, (bias, n_e, ge.segments_replayed)
         lengths.append(n_e)
     assert lengths[0] >= lengths[1] >= lengths[2] and lengths[2] < 12
+
+
+def test_graphed_eval_forward_without_criterion_or_targets():
+    """pure inference (no ground truth in dt, criterion=None): one graph keyed on the tensor shapes alone"""
+    from gvl_amd.parallel import GraphedEvalForward
+    opt, model, crit, T = toy(False)
+    ge = GraphedEvalForward(model, None)
+    for i, dt in enumerate(batches(T, seed=80)[:3]):
+        infer = {k: v for k, v in dt.items() if k in ("video_tensor", "video_mask", "video_length")}
+        with torch.no_grad():
+            out_e, _ = model(infer, None, None, "queries", eval_mode=True)
+        out_g, loss_g = ge(infer)
+        assert loss_g == {} and maxerr(out_g["pred_boxes"], out_e["pred_boxes"]) < 1e-5
+        assert (len(out_g["seq"]) == 0 and len(out_e["seq"]) == 0) or torch.equal(out_g["seq"], out_e["seq"])
+    assert len(ge.graphs) == 1 and ge.captures == 1
