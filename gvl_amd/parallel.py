@@ -492,9 +492,19 @@ class GraphedTrainStep(TrainStep):
         self.captures += 1
         return graphs, outs
 
+    def _mean_num_boxes_on_device(self, pt):
+        """criterion.py:178-181 without a host round trip: load() left this rank's target count in pt.num_boxes; sum over
+        the ranks, divide, clamp -- three tiny stream-ordered operations on the device scalar the captured criterion reads"""
+        if dist.is_available() and dist.is_initialized() and self.world > 1:
+            pt.num_boxes.copy_(pt.counts.sum())                    # un-clamped local count
+            dist.all_reduce(pt.num_boxes)
+            pt.num_boxes.div_(self.world).clamp_(min=1.0)
+
     def __call__(self, dt):
-        nb = self._global_num_boxes(dt) if self.split else None      # every rank, every step (a collective at N > 1)
-        if self._use_padded(dt):
+        padded = self._use_padded(dt)
+        # fallback form only: the cross-rank mean enters the capture as a HOST value (one collective + host read per step)
+        nb = self._global_num_boxes(dt) if (self.split and not padded) else None
+        if padded:
             slots, cap_len = self.capacity.fit(dt, with_captions=True)
             rows = min(self.capacity.pair_rows, dt["video_tensor"].shape[0] * min(slots, self.opt.num_queries))
             key = ("padded", tuple((k, tuple(dt[k].shape), str(dt[k].dtype)) for k in _STATIC_KEYS), slots, cap_len, rows)
@@ -502,12 +512,14 @@ class GraphedTrainStep(TrainStep):
             if entry is None:
                 _drop_superseded(self.graphs, key, self.capacity.cap_len_policy == "bucket")
                 batch = _PaddedBatch(dt, slots, cap_len, rows)
-                batch.load(dt, nb)
+                batch.load(dt)
                 graphs, outs = self._capture(batch.dt)
                 entry = (graphs, batch, outs)
                 self.graphs.store(key, entry)
             graphs, batch, outs = entry
-            batch.load(dt, nb)
+            batch.load(dt)
+            if self.split:
+                self._mean_num_boxes_on_device(batch.targets)       # every rank, every step: one scalar all-reduce
         else:
             key = self._layout_key(dt) + ((nb,) if self.split else ())
             entry = self.graphs.lookup(key)
