@@ -1,11 +1,43 @@
-"""PostProcess -- mirror of pdvc/pdvc.py:932-1089 for the non-contrastive LSTM-DSA path (what eval_utils.py:213-216
-calls on every eval batch): top-N_q events by confidence, boxes clipped to the video and scaled to seconds, captions
-re-ordered accordingly and decoded with the dataset's translator, caption scores = sum of token log-probs.
-Host glue; the only device work is a topk / gather."""
+"""PostProcess -- the result side of the eval loop, mirror of pdvc/pdvc.py:932-1089 for the non-contrastive LSTM-DSA
+path (what eval_utils.py:213-216 calls on every eval batch).  Per video: the N_q most confident (query, class) pairs,
+their segments clipped to the video and scaled to seconds, their captions decoded with the dataset's translator and
+scored by the sum of the token log-probabilities.  Host glue; the only device work is a top-k and a gather.
+The record keys are the reference's wire format (eval_utils.py:216-239 reads them)."""
 import torch
 from torch import nn
 
 from .matcher import box_cl_to_xy
+
+RECORD_KEYS = ('scores', 'labels', 'boxes', 'raw_boxes', 'captions', 'caption_scores', 'cl_scores', 'query_id',
+               'vid_duration', 'pred_seq_len', 'raw_idx')
+
+
+def rank_events(pred_logits):
+    """confidence ranking over all (query, class) pairs of a video (pdvc.py:1019-1023)
+    -> (scores (N, N_q) descending, flat pair index, query id, class id)"""
+    n_vid, n_query, n_class = pred_logits.shape
+    scores, flat = torch.topk(pred_logits.sigmoid().reshape(n_vid, n_query * n_class), n_query, dim=1)
+    return scores, flat, flat // n_class, flat % n_class
+
+
+def segments_in_seconds(pred_boxes, query_id, durations):
+    """(centre, length) in [0, 1] -> [start, end] seconds of the ranked queries, clipped to the video (pdvc.py:1024-1031)"""
+    spans = box_cl_to_xy(pred_boxes).clamp(0, 1)
+    picked = spans.gather(1, query_id[..., None].expand(-1, -1, 2))
+    return picked * durations[:, None, None]
+
+
+def decode_captions(seq, log_probs, query_id, translator):
+    """token ids + per-token log-probs of every query -> (sentences, scores) re-ordered by the ranking (pdvc.py:1046-1066)"""
+    n_vid, n_query = query_id.shape
+    if not len(seq):                                         # captioning disabled / every caption empty
+        return [[''] * n_query] * n_vid, [[-1e5] * n_query] * n_vid
+    total = ((seq > 0).float() * log_probs).sum(2).cpu().numpy().astype('float')
+    tokens = seq.detach().cpu().numpy().astype('int')
+    ranking = query_id.cpu().tolist()
+    sentences = [[translator.rtranslate(tokens[v][q]) for q in ranking[v]] for v in range(n_vid)]
+    scores = [[total[v, q] for q in ranking[v]] for v in range(n_vid)]
+    return sentences, scores
 
 
 class PostProcess(nn.Module):
@@ -15,40 +47,19 @@ class PostProcess(nn.Module):
 
     @torch.no_grad()
     def forward_grounding(self, outputs, target_sizes, targets):
-        """pdvc.py:951-953: grounding needs the contrastive text branch, which this build does not carry."""
+        """pdvc.py:949-951: without the contrastive text branch the reference returns (None, None) here too."""
         return None, None
 
     @torch.no_grad()
     def forward(self, outputs, target_sizes, loader, model=None, tokenizer=None):
-        out_logits, out_bbox = outputs['pred_logits'], outputs['pred_boxes']
-        N, N_q, N_class = out_logits.shape
-        assert len(out_logits) == len(target_sizes)
-        prob = out_logits.sigmoid()
-        scores, topk_indexes = torch.topk(prob.view(N, -1), N_q, dim=1)
-        topk_boxes = topk_indexes // N_class
-        labels = topk_indexes % N_class
-        raw_boxes = box_cl_to_xy(out_bbox)
-        boxes = raw_boxes.clamp(min=0, max=1)
-        boxes = torch.gather(boxes, 1, topk_boxes.unsqueeze(-1).repeat(1, 1, 2))
-        boxes = boxes * torch.stack([target_sizes, target_sizes], dim=1)[:, None, :]
-        seq = outputs['seq']
-        cap_prob = outputs['caption_probs']['cap_prob_eval']
-        eseq_lens = outputs['pred_count'].argmax(dim=-1).clamp(min=1)
-        bs, num_queries = boxes.shape[:2]
-        if len(seq):
-            mask = (seq > 0).float()
-            cap_scores = (mask * cap_prob).sum(2).cpu().numpy().astype('float')
-            order = topk_boxes.cpu().tolist()
-            seq_np = seq.detach().cpu().numpy().astype('int')
-            caps = [[loader.dataset.translator.rtranslate(s) for s in s_vid] for s_vid in seq_np]
-            caps = [[caps[b][idx] for idx in row] for b, row in enumerate(order)]
-            cap_scores = [[cap_scores[b, idx] for idx in row] for b, row in enumerate(order)]
-        else:
-            cap_scores = [[-1e5] * num_queries] * bs
-            caps = [[''] * num_queries] * bs
-        cl_scores = [[0.0] * num_queries] * bs
-        return [{'scores': s, 'labels': l, 'boxes': b, 'raw_boxes': b, 'captions': c, 'caption_scores': cs,
-                 'cl_scores': cls, 'query_id': qid, 'vid_duration': ts, 'pred_seq_len': sl, 'raw_idx': idx}
-                for s, l, b, c, cs, cls, qid, ts, sl, idx in
-                zip(scores, labels, boxes, caps, cap_scores, cl_scores, topk_boxes, target_sizes, eseq_lens,
-                    topk_indexes)]
+        logits = outputs['pred_logits']
+        assert len(logits) == len(target_sizes)
+        scores, flat, query_id, class_id = rank_events(logits)
+        segments = segments_in_seconds(outputs['pred_boxes'], query_id, target_sizes)
+        sentences, sentence_scores = decode_captions(outputs['seq'], outputs['caption_probs']['cap_prob_eval'], query_id,
+                                                     loader.dataset.translator)
+        n_events = outputs['pred_count'].argmax(dim=-1).clamp(min=1)          # predicted number of events, at least one
+        no_cl = [0.0] * query_id.shape[1]                                     # contrastive scores: branch not built
+        columns = (scores, class_id, segments, segments, sentences, sentence_scores, [no_cl] * len(logits), query_id,
+                   target_sizes, n_events, flat)
+        return [dict(zip(RECORD_KEYS, row)) for row in zip(*columns)]
