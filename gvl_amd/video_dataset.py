@@ -5,6 +5,10 @@
 gt_boxes_mask, cap_tensor, cap_length, cap_mask, cap_raw``), and of the dataset that produces those samples
 (``PropSeqDataset``: annotation JSON + one feature file per video, nearest temporal rescale, zeros for missing files).
 Host-side data formats only."""
+import json
+import os
+import pickle
+from collections import defaultdict
 from itertools import chain
 
 import numpy as np
@@ -59,11 +63,6 @@ def collate_fn(batch):
 # (video_dataset.py:264-281) with load_feats (:209-247), get_feats / read_file (:307-384), resizeFeature (:386-397),
 # Translator (:109-137) and process_time_step (:193-200).  Pure host code (numpy / json), no GPU on this side.
 # ---------------------------------------------------------------------------------------------------------------
-import json
-import os
-import pickle
-from collections import defaultdict
-
 # feature type -> (dimension, file name from the video key, normalisation mean, variance)   video_dataset.py:309-357
 _FEATURE_TYPES = {
     "c3d": (500, lambda k: k[0:13] + ".npy", -0.001915027447565527, 1.9239444588254049),
