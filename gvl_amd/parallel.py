@@ -683,14 +683,37 @@ class GraphedEvalForward:
         for m in self._matches(out):
             m.invalidate()                                   # the device indices changed under the cached host copy
         if flags[0] is not None and isinstance(out.get("seq"), torch.Tensor) and not self.model.opt.eval_disable_captioning:
-            # the forward's only host reads (LSTM_DSA.py:186-187): one per decode segment that ran
-            alive = flags[0].cpu().tolist()
-            for g, f_ in zip(seg_graphs, flags[1:]):
-                if False in alive:
+            # The forward's only host reads (LSTM_DSA.py:186-187): the `alive` flags of every decode segment that ran.
+            # They are read ONE SEGMENT BEHIND the GPU: segment k + 1 is already queued when the host waits for the flags
+            # of segment k (a stream-ordered copy into pinned memory + an event), so the device never idles on the read;
+            # the price is at most one speculative segment after the last caption has ended -- it only writes columns
+            # that are trimmed below.
+            def post(f_):
+                host = torch.empty(f_.shape, dtype=f_.dtype, pin_memory=True)
+                host.copy_(f_, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                return host, ev
+
+            def take(p_):
+                p_[1].synchronize()
+                return p_[0].tolist()
+            pending = post(flags[0])
+            alive, nxt = [], 0
+            while True:
+                ahead = None
+                if nxt < len(seg_graphs):                       # keep the GPU one segment ahead of the flags in hand
+                    seg_graphs[nxt].replay()
+                    self.segments_replayed += 1
+                    ahead = post(flags[nxt + 1])
+                    nxt += 1
+                alive += take(pending)
+                if ahead is None:
                     break
-                g.replay()
-                self.segments_replayed += 1
-                alive += f_.cpu().tolist()
+                if False in alive:                              # every caption ended: the segment in flight is the last one
+                    take(ahead)
+                    break
+                pending = ahead
             keep = alive.index(False) if False in alive else len(alive)
             if keep == 0:
                 out["seq"], out["caption_probs"] = [], {"cap_prob_eval": []}
