@@ -110,3 +110,23 @@ def test_unfused_decoder_call_has_no_hidden_host_cost(reference_named_extension)
     torch.cuda.synchronize()
     per_call = (time.perf_counter() - t0) / 100 * 1e6
     assert per_call < 150.0, per_call
+
+
+def test_the_ctypes_binding_printed_in_integration_md_works_as_written():
+    """INTEGRATION.md section 1 prints a ~15-line ctypes binding of gvl_msda_forward_f32; run exactly that text (library
+    path made absolute) against the oracle, so the document cannot drift from the ABI."""
+    import os
+    import re
+    from oracle import msda_oracle as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = next(b for b in blocks if "gvl_msda_forward_f32.argtypes" in b)
+    code = code.replace('"gvl_amd/libgvl_msda.so"', repr(os.path.join(root, "gvl_amd", "libgvl_msda.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    value, shapes, lsi, loc, aw, _ = inputs(2, 19, [12, 6, 3, 2], seed=4)
+    tt = lambda a: torch.from_numpy(a).to(DEV)                                   # noqa: E731
+    out = ns["ms_deform_attn_forward"](tt(value), tt(shapes), tt(lsi), tt(loc), tt(aw), 64)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - O.msda_forward(value, shapes, lsi, loc, aw, "zeros")).max() < 1e-4
