@@ -311,6 +311,28 @@ def cap_attend_train_backward(slab, spatial_shapes, level_start_index, ref_in, o
     _lib.check(rc, "cap_attend_train_backward")
 
 
+def proj_eligible(x, weight, bias):
+    """domain of gvl_proj_f32: fp32, contiguous, K in {256, 512, 1024}, N a multiple of 64"""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous()
+            and weight.is_contiguous() and x.shape[-1] == weight.shape[1] and weight.shape[1] in (256, 512, 1024)
+            and weight.shape[0] % 64 == 0 and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))
+            and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
+
+
+def proj_linear(x, weight, bias=None):
+    """x (..., K) @ weight (N, K)^T + bias -> (..., N) through the hand-written fp32 MFMA kernel (include/gvl_msda.h:
+    gvl_proj_f32): the offset / attention-logit projection of MSDeformAttn (ms_deform_attn.py:99-100)."""
+    _require(proj_eligible(x, weight, bias), "proj_linear: needs contiguous fp32 CUDA operands with K, N multiples of 64")
+    K, N = weight.shape[1], weight.shape[0]
+    R = x.numel() // K
+    out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gvl_proj_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, R, K,
+                                     N, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "proj")
+    return out
+
+
 def col_sum_eligible(x):
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] > 0
 
@@ -423,11 +445,13 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp):
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
              12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train", 15: "match_cost", 16: "criterion",
-             17: "pos_embed", 18: "col_sum"}
+             17: "pos_embed", 18: "col_sum", 19: "proj"}
 
 
 def profile_enable(on=True):
-    _lib.lib().gvl_prof_enable(1 if on else 0)
+    """on: False / 0 = off; True / 1 = per-dispatch stamps of the sampling-path kernels; 2 = additionally the projection
+    kernel in front of them (stamping two consecutive launches inflates the second one's interval, see gvl_common.hpp)"""
+    _lib.lib().gvl_prof_enable(int(on))
 
 
 def profile_collect(capacity=1 << 16):

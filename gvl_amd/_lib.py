@@ -42,6 +42,7 @@ SIGNATURES = {
     "gvl_lstm_cell_train_forward_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
     "gvl_lstm_cell_train_backward_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P]),
     "gvl_col_sum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "gvl_proj_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "gvl_pos_embed_sine_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P, _P]),
     "gvl_match_cost_f32": (_I, [_P] * 4 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),
     "gvl_match_cost_padded_f32": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),

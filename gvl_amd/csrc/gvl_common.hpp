@@ -31,7 +31,7 @@ struct ProfEntry {
 };
 struct Profiler {
   std::mutex mu;
-  bool on = false;
+  int level = 0;      // 0 off | 1 the kernels of the sampling path | 2 additionally the projection GEMM in front of them
   std::vector<ProfEntry> entries;
 };
 inline Profiler &profiler() {
@@ -43,7 +43,11 @@ template <typename K, typename... Args>
 inline int launch(int tag, int meta_a, int meta_b, const char *what, K kernel, dim3 grid, dim3 block, size_t lds,
                   hipStream_t st, Args... args) {
   Profiler &p = profiler();
-  bool stamp = p.on;
+  // Level 1 leaves the projection kernel (the launch directly in front of the sampling kernel) un-stamped: two
+  // event-stamped launches back to back inflate the second one's interval by 2-3 us (measured: 12.2 vs 9.2-9.5 us for
+  // the same dispatch, whose duration in a rocprofv3 trace is identical either way), and the bench's roofline block
+  // reports exactly that second launch.
+  bool stamp = p.level > 0 && (tag != GVL_PROF_PROJ || p.level > 1);
   if (stamp) {   // event-stamped launches cannot be recorded into a hipGraph: inside a capture launch plainly
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) stamp = false;

@@ -1572,7 +1572,7 @@ void gvl_msda_debug_stamps(void *device_buffer) {
 int gvl_prof_enable(int on) {
   gvl::Profiler &p = gvl::profiler();
   std::lock_guard<std::mutex> g(p.mu);
-  p.on = on != 0;
+  p.level = on < 0 ? 0 : on;
   return 0;
 }
 

@@ -5,6 +5,8 @@ axis takes 10-20 us on the (B*Q | B*S, 256...2048) gradients of the path, ~40 ti
 the two GEMMs exactly as autograd issues them (same operand order, so the same tuned library kernels) and replaces
 only that reduction.  Anything it is not built for -- no bias, CPU, non-fp32, autocast -- goes through
 F.linear unchanged."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -33,6 +35,28 @@ class _LinearFunction(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gb = MSDA.col_sum(g2) if MSDA.col_sum_eligible(g2) else g2.sum(0)
         return gx, gw, gb
+
+
+class _ProjFunction(_LinearFunction):
+    """the same linear map with the FORWARD product on the hand-written fp32 MFMA kernel (include/gvl_msda.h:
+    gvl_proj_f32); the two gradient GEMMs stay the library's, the bias gradient is gvl_col_sum_f32"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return MSDA.proj_linear(x, weight, bias)
+
+
+def projection(x, weight, bias):
+    """MSDeformAttn's offset / attention-logit projection (ms_deform_attn.py:99-100 against the concatenated weight):
+    hand-written HIP when the operands are in the kernel's domain (contiguous fp32, K in {256, 512, 1024}, N % 64 == 0,
+    no autocast), the library GEMM otherwise.  GVL_PROJ=library forces the library for A/B runs."""
+    if (torch.is_autocast_enabled() or os.environ.get("GVL_PROJ", "") == "library"
+            or not MSDA.proj_eligible(x, weight, bias)):
+        return linear(x, weight, bias)
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return _ProjFunction.apply(x, weight, bias)
+    return MSDA.proj_linear(x, weight, bias)
 
 
 def linear(x, weight, bias=None):

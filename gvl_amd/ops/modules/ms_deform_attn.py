@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import functions as _fn
 from ... import MultiScaleDeformableAttention as MSDA
-from ...linear import Linear, linear
+from ...linear import Linear, linear, projection
 
 
 def _power_of_two(n):
@@ -119,7 +119,7 @@ class MSDeformAttn(nn.Module):
         # one GEMM for both projections: columns [0,128) raw offsets, [128,256) attention logits
         w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
         b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        proj = linear(query, w_cat, b_cat)
+        proj = projection(query.contiguous(), w_cat, b_cat)
         out = _fn.MSDeformAttnFusedFunction.apply(value, proj, reference_points.contiguous(), shapes2d,
                                                   level_start_index, self.n_levels, self.n_points, self.pad_mode)
         return self.output_proj(out)

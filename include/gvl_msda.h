@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 5   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video */
+#define GVL_MSDA_ABI_VERSION 5   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -119,6 +119,14 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
                                    const float *grad_losses, float *grad_logits, float *grad_count, float *grad_boxes,
                                    void *stream);
 
+/* -- the sampling-offset / attention-weight projections of MSDeformAttn.forward (pdvc/ops/modules/ms_deform_attn.py:99-100:
+ *    `self.sampling_offsets(query)`, `self.attention_weights(query)`) as ONE hand-written fp32 MFMA GEMM against the
+ *    concatenated weight:  out (R, N) = x (R, K) . weight (N, K)^T + bias (N);  row-major, contiguous, fp32; bias may be
+ *    NULL.  K in {256, 512, 1024} and N a multiple of 64 (512 and 256 on the path); x / weight 16-byte aligned.  Exact fp32 arithmetic
+ *    (v_mfma_f32_16x16x4_f32).  Columns [0, N/2) are the raw offsets, [N/2, N) the attention logits that
+ *    gvl_msda1d_fused_forward_f32 consumes as `proj`. */
+int gvl_proj_f32(const float *x, const float *weight, const float *bias, int R, int K, int N, float *out, void *stream);
+
 /* -- PositionEmbeddingSine.forward of one pyramid level (pdvc/position_encoding.py:38-64; the step in front of the
  *    path): normalised cumulative frame index -> interleaved sin / cos over `dim_t`, followed
  *    by the duration embedding broadcast over time.
@@ -157,7 +165,9 @@ int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stre
 #define GVL_PROF_CRITERION 16
 #define GVL_PROF_POS_EMBED 17
 #define GVL_PROF_COL_SUM 18
-int gvl_prof_enable(int on);
+#define GVL_PROF_PROJ 19
+int gvl_prof_enable(int on);   /* 0 off | 1 sampling-path kernels | 2 also GVL_PROF_PROJ (stamping two consecutive launches
+                                  inflates the second one's interval by 2-3 us, so level 1 leaves the projection alone) */
 /* Phase stamps of the temporal kernels (diagnostics): while a DEVICE buffer of 2 x 4096 x 4 uint64 is set, every
  * workgroup of k_fwd_t1d_d64 records the 100 MHz wall clock at {start, slab staged, loop done} in the first half and
  * every workgroup of k_bwd_t1d_d64 {start, staged, phase 1 done, phase 2 done} in the second half.  NULL = off. */

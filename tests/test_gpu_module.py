@@ -66,3 +66,36 @@ def test_msdeformattncap_module_golden():
     with torch.no_grad():
         out = mod(query, ref.to(dev), inp, t(f["tshapes"]).to(dev), t(f["lsi"]).to(dev), t(f["mask"]).to(dev))
     assert maxerr(out, f["out"]) < 1e-4
+
+
+def test_hand_written_projection_kernel_matches_fp64_and_library():
+    """gvl_proj_f32 (MSDeformAttn's offset / attention-logit projection, ms_deform_attn.py:99-100, as a hand-written fp32
+    MFMA GEMM): exact-fp32 arithmetic -- its error against an fp64 product is the library's (a k-ordered fmaf chain) --
+    for the two row counts of cfg A, a ragged row count, the other supported K, without bias; and its autograd wrapper
+    hands back the library's gradients."""
+    import torch.nn.functional as F
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd.linear import projection
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    for R, K, N in ((4800, 512, 256), (3008, 512, 256), (37, 512, 256), (1, 512, 64), (100, 256, 128), (70, 1024, 192)):
+        x = torch.randn(R, K, device=dev, generator=g)
+        w = torch.randn(N, K, device=dev, generator=g) * 0.05
+        b = torch.randn(N, device=dev, generator=g)
+        ref = x.double() @ w.double().t() + b.double()
+        mine, lib = MSDA.proj_linear(x, w, b), F.linear(x, w, b)
+        e_mine, e_lib = float((mine.double() - ref).abs().max()), float((lib.double() - ref).abs().max())
+        # a k-ordered fp32 fmaf chain: error <= ~1.5e-7 * sum |a b| for K <= 1024 (the MFMA's documented numerics); the
+        # library's blocked summation is usually a little tighter, never by an order of magnitude
+        bound = 3e-7 * float((x.abs().double() @ w.abs().double().t()).max()) + 1e-7
+        assert e_mine <= bound and e_mine <= 8.0 * e_lib + 1e-6, (R, K, N, e_mine, e_lib, bound)
+        assert float((MSDA.proj_linear(x, w, None).double() - (ref - b.double())).abs().max()) <= bound
+    x = torch.randn(2, 50, 512, device=dev, generator=g, requires_grad=True)
+    w = (torch.randn(256, 512, device=dev, generator=g) * 0.05).requires_grad_()
+    b = torch.randn(256, device=dev, generator=g, requires_grad=True)
+    go = torch.randn(2, 50, 256, device=dev, generator=g)
+    projection(x, w, b).backward(go)
+    x2, w2, b2 = (t_.detach().clone().requires_grad_() for t_ in (x, w, b))
+    F.linear(x2, w2, b2).backward(go)
+    for a_, b_ in ((x.grad, x2.grad), (w.grad, w2.grad), (b.grad, b2.grad)):
+        assert float((a_ - b_).abs().max()) <= 1e-5 * max(1.0, float(b_.abs().max()))
