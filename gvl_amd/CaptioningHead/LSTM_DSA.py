@@ -29,7 +29,7 @@ from ..ops.functions import MSDASampleFunction
 from ..ops.modules import MSDeformAttnCap
 from ..ops.modules.ms_deform_attn import temporal_shapes_2d
 from .. import MultiScaleDeformableAttention as MSDA
-from ..linear import Linear
+from ..linear import Linear, split_gemm_enabled
 
 
 class ShowAttendTellCore(nn.Module):
@@ -115,7 +115,7 @@ class ShowAttendTellCore(nn.Module):
         every call); the operands of the attention kernel stay fp32."""
         params = (self.deformable_att.sampling_offsets.weight, self.h2att.weight, self.h2att.bias, self.rnn.weight_hh_l0,
                   self.rnn.weight_ih_l0, self.alpha_net.weight)
-        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (gemm_dtype,)
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (split_gemm_enabled(), gemm_dtype)
         cache = self.__dict__.setdefault("_inf_w", {})
         if cache and next(iter(cache))[:-1] != key[:-1]:
             cache.clear()
@@ -129,6 +129,11 @@ class ShowAttendTellCore(nn.Module):
                          w_h_cat=torch.cat([self.h2att.weight, self.rnn.weight_hh_l0], 0).to(gemm_dtype),
                          b_h_cat=torch.cat([self.h2att.bias, self.h2att.bias.new_zeros(4 * self.rnn_size)]).to(gemm_dtype),
                          w_att_t=self.rnn.weight_ih_l0[:, E:E + self.att_feat_size].t().contiguous().to(gemm_dtype))
+                if (gemm_dtype == torch.float32 and split_gemm_enabled() and self.rnn_size % 32 == 0
+                        and self.att_feat_size % 32 == 0):
+                    # fp32 products on the fp16 matrix cores (gvl_gemm_f16x3_f32): the weight side is split once
+                    w["w_h_cat_p"] = MSDA.split_rows(w["w_h_cat"])
+                    w["w_att_p"] = MSDA.split_rows(self.rnn.weight_ih_l0[:, E:E + self.att_feat_size].contiguous())
             cache[key] = w
         return w
 
@@ -140,11 +145,18 @@ class ShowAttendTellCore(nn.Module):
             shapes2d = const["shapes2d"] = temporal_shapes_2d(temporal_shapes, level_start_index)
             const["ref_in"] = reference_points.contiguous()
         A = self.att_hid_size
-        h_gemm = getattr(h, "_gvl_lowp", h)                              # bf16 copy left by the cell kernel (autocast)
-        g_h = F.linear(h_gemm, const["w_h_cat"], const["b_h_cat"])      # (n, A + 4H): [h2att(h) | h W_hh^T]
+        split = "w_h_cat_p" in const and h.dtype == torch.float32
+        if split:
+            hp = getattr(h, "_gvl_planes", None)                         # left by the vocabulary product of the last step
+            g_h = MSDA.gemm_f16x3(hp if hp is not None else MSDA.split_rows(h), const["w_h_cat_p"], const["b_h_cat"])
+        else:
+            h_gemm = getattr(h, "_gvl_lowp", h)                          # bf16 copy left by the cell kernel (autocast)
+            g_h = F.linear(h_gemm, const["w_h_cat"], const["b_h_cat"])  # (n, A + 4H): [h2att(h) | h W_hh^T]
         att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
                                   h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
                                   self.n_levels, self.n_points)
+        if split and att_res.dtype == torch.float32:
+            return MSDA.gemm_f16x3(MSDA.split_rows(att_res), const["w_att_p"]), g_h
         return torch.mm(att_res, const["w_att_t"]), g_h                 # (the hs part, gates_hs, is added in the cell)
 
     def cell_part(self, g_x, g_h, xt_gates, c, const):
@@ -449,6 +461,20 @@ class Captioner(nn.Module):
                 cached = self._emb_gates = (key, F.linear(w_e, w_ih[:, :self.input_encoding_size]).contiguous())
         return cached[1]
 
+    def _logit_planes(self, out):
+        """fp16 planes of the vocabulary layer's weight (gvl_split_rows_f16), rebuilt when the weight changes; None when
+        the split product does not apply (training / dropout active, autocast, GVL_GEMM=f32)"""
+        w = self.logit.weight
+        if (self.training or torch.is_grad_enabled() or torch.is_autocast_enabled() or out.dtype != torch.float32
+                or hasattr(out, "_gvl_lowp") or not split_gemm_enabled() or not MSDA.split_eligible(w)):
+            return None
+        key = (w.data_ptr(), w._version)
+        cached = getattr(self, "_logit_p", None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = self._logit_p = (key, MSDA.split_rows(w.detach()))
+        return cached[1]
+
     def _decode_device(self, hs, reference, memory, mask, valid_ratios, tshapes, lsi, sample_max, temperature):
         """The whole decoding loop on the device, no host interaction: -> (seq (n, T), logprob (n, T), alive (T,))
         with T = max_caption_len.  Capturable in a hipGraph."""
@@ -510,7 +536,12 @@ class Captioner(nn.Module):
             if t < T:
                 out, (st["h"], st["c"]) = self.core.step((st["emb_gates"], st["it"]), (st["h"], st["c"]), st["hs"],
                                                          st["ref_in"], st["tshapes"], st["lsi"], st["const"])
-                st["logits"] = self.logit(self.dropout(getattr(out, "_gvl_lowp", out)))
+                planes = self._logit_planes(out)
+                if planes is not None:                                   # fp32 product on the fp16 matrix cores
+                    out._gvl_planes = MSDA.split_rows(out)               # the next step's h product reads the same planes
+                    st["logits"] = MSDA.gemm_f16x3(out._gvl_planes, planes, self.logit.bias)
+                else:
+                    st["logits"] = self.logit(self.dropout(getattr(out, "_gvl_lowp", out)))
 
     def decode_continue(self, t0, t1):
         """continue a greedy loop that `decode_stop` cut at iteration t0 (gvl_amd.parallel.GraphedEvalForward captures

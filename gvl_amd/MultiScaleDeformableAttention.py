@@ -333,6 +333,57 @@ def proj_linear(x, weight, bias=None):
     return out
 
 
+class SplitPlanes:
+    """an fp32 matrix as two fp16 planes and a row scale: x[r, k] = scale[r] (hi[r, k] + 2^-11 lo[r, k])
+    (include/gvl_msda.h: gvl_split_rows_f16)"""
+    __slots__ = ("hi", "lo", "scale", "rows", "cols")
+
+    def __init__(self, rows, cols, device):
+        self.rows, self.cols = rows, cols
+        self.hi = torch.empty(rows, cols, device=device, dtype=torch.float16)
+        self.lo = torch.empty(rows, cols, device=device, dtype=torch.float16)
+        self.scale = torch.empty(rows, device=device, dtype=torch.float32)
+
+
+def split_eligible(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1 and x.is_contiguous() and x.shape[-1] % 32 == 0
+            and x.data_ptr() % 16 == 0)
+
+
+def split_rows(x, out=None):
+    """x (..., K) contiguous fp32 -> SplitPlanes of its (R, K) view"""
+    _require(split_eligible(x), "split_rows: needs a contiguous fp32 CUDA tensor whose last dimension is a multiple of 32")
+    K = x.shape[-1]
+    R = x.numel() // K
+    if out is None:
+        out = SplitPlanes(R, K, x.device)
+    _require(out.rows == R and out.cols == K, "split_rows: `out` has a different shape")
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gvl_split_rows_f16(x.data_ptr(), R, K, out.hi.data_ptr(), out.lo.data_ptr(), out.scale.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "split_rows")
+    return out
+
+
+def gemm_f16x3(a, b, bias=None, out=None):
+    """a: SplitPlanes (R, K), b: SplitPlanes (N, K) -> a . b^T + bias, (R, N) fp32, at fp32 accuracy on the fp16 matrix
+    cores (include/gvl_msda.h: gvl_gemm_f16x3_f32)"""
+    _require(a.cols == b.cols, "gemm_f16x3: inner dimensions differ")
+    _require(bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == b.rows),
+             "gemm_f16x3: bias must be contiguous fp32 of length N")
+    if out is None:
+        out = torch.empty(a.rows, b.rows, device=a.hi.device, dtype=torch.float32)
+    _require(out.dtype == torch.float32 and out.dim() == 2 and out.stride(1) == 1 and tuple(out.shape) == (a.rows, b.rows),
+             "gemm_f16x3: `out` must be (R, N) fp32 with unit column stride")
+    with torch.cuda.device(out.device):
+        rc = _lib.lib().gvl_gemm_f16x3_f32(a.hi.data_ptr(), a.lo.data_ptr(), a.scale.data_ptr(), a.rows, b.hi.data_ptr(),
+                                           b.lo.data_ptr(), b.scale.data_ptr(), b.rows, a.cols,
+                                           bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
+                                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "gemm_f16x3")
+    return out
+
+
 def col_sum_eligible(x):
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] > 0
 
@@ -445,7 +496,7 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp):
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
              12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train", 15: "match_cost", 16: "criterion",
-             17: "pos_embed", 18: "col_sum", 19: "proj"}
+             17: "pos_embed", 18: "col_sum", 19: "proj", 20: "split_rows", 21: "gemm_f16x3"}
 
 
 def profile_enable(on=True):

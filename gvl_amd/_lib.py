@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 5          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 6          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -43,6 +43,8 @@ SIGNATURES = {
     "gvl_lstm_cell_train_backward_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P]),
     "gvl_col_sum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "gvl_proj_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "gvl_split_rows_f16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "gvl_gemm_f16x3_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, ctypes.c_int64, _P]),
     "gvl_pos_embed_sine_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P, _P]),
     "gvl_match_cost_f32": (_I, [_P] * 4 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),
     "gvl_match_cost_padded_f32": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),

@@ -59,6 +59,12 @@ def projection(x, weight, bias):
     return MSDA.proj_linear(x, weight, bias)
 
 
+def split_gemm_enabled():
+    """the captioner's fp32 token-loop products run on the fp16 matrix cores at fp32 accuracy (include/gvl_msda.h:
+    gvl_gemm_f16x3_f32) unless GVL_GEMM=f32 asks for the fp32 library GEMMs (A/B runs)"""
+    return os.environ.get("GVL_GEMM", "") != "f32"
+
+
 def linear(x, weight, bias=None):
     if (bias is None or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32
             or bias.dtype != torch.float32 or torch.is_autocast_enabled()

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 5   /* 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 6   /* 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -127,6 +127,19 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
  *    gvl_msda1d_fused_forward_f32 consumes as `proj`. */
 int gvl_proj_f32(const float *x, const float *weight, const float *bias, int R, int K, int N, float *out, void *stream);
 
+/* -- fp32 products of the captioner's token loop on the fp16 matrix cores at fp32 accuracy (gvl_gemm16.hip): the
+ *    nn.Linear calls `self.logit(output)` (pdvc/CaptioningHead/LSTM_DSA.py:121,165), `h2att(h)` and the two halves of
+ *    the LSTM's gate pre-activations (:247,267-269).
+ *    gvl_split_rows_f16:  x (R, K) fp32 row-major, K % 4 == 0 -> hi, lo (R, K) IEEE half, scale (R) fp32 with
+ *        x[r][k] = scale[r] (hi[r][k] + 2^-11 lo[r][k])  to 2^-22 |x|;  scale[r] = 2^floor(log2 max_k |x[r][k]|).
+ *    gvl_gemm_f16x3_f32:  out (R, ldo >= N) = A (R, K) . B (N, K)^T + bias (N, may be NULL), both operands as the
+ *        planes + scales of gvl_split_rows_f16, K % 32 == 0, planes 16-byte aligned.  Three fp16 MFMAs per product
+ *        (hi.hi, hi.lo, lo.hi; fp32 accumulation, cross terms in their own accumulator); error against an fp64
+ *        product no larger than an fp32 GEMM's. */
+int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *lo, float *scale, void *stream);
+int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi, const void *b_lo,
+                       const float *b_scale, int N, int K, const float *bias, float *out, int64_t ldo, void *stream);
+
 /* -- PositionEmbeddingSine.forward of one pyramid level (pdvc/position_encoding.py:38-64; the step in front of the
  *    path): normalised cumulative frame index -> interleaved sin / cos over `dim_t`, followed
  *    by the duration embedding broadcast over time.
@@ -166,6 +179,8 @@ int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stre
 #define GVL_PROF_POS_EMBED 17
 #define GVL_PROF_COL_SUM 18
 #define GVL_PROF_PROJ 19
+#define GVL_PROF_SPLIT 20
+#define GVL_PROF_GEMM16 21
 int gvl_prof_enable(int on);   /* 0 off | 1 sampling-path kernels | 2 also GVL_PROF_PROJ (stamping two consecutive launches
                                   inflates the second one's interval by 2-3 us, so level 1 leaves the projection alone) */
 /* Phase stamps of the temporal kernels (diagnostics): while a DEVICE buffer of 2 x 4096 x 4 uint64 is set, every
