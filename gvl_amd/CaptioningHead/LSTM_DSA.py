@@ -539,7 +539,7 @@ class Captioner(nn.Module):
                 planes = self._logit_planes(out)
                 if planes is not None:                                   # fp32 product on the fp16 matrix cores
                     out._gvl_planes = MSDA.split_rows(out)               # the next step's h product reads the same planes
-                    st["logits"] = MSDA.gemm_f16x3(out._gvl_planes, planes, self.logit.bias)
+                    st["logits"] = MSDA.gemm_f16x3_argmax(out._gvl_planes, planes, self.logit.bias)   # never written out
                 else:
                     st["logits"] = self.logit(self.dropout(getattr(out, "_gvl_lowp", out)))
 

@@ -471,10 +471,58 @@ def row_argmax_lse(logits):
     return idx, lp
 
 
+class GreedyPartials:
+    """what gvl_gemm_f16x3_argmax_f32 leaves instead of the (R, V) logits: per row and 64 vocabulary entries
+    {max, sum exp(v - max), index}"""
+    __slots__ = ("part", "rows", "vocab")
+
+    def __init__(self, part, rows, vocab):
+        self.part, self.rows, self.vocab = part, rows, vocab
+
+
+def gemm_f16x3_argmax(x, w, bias=None):
+    """x: SplitPlanes (R, K) hidden states, w: SplitPlanes (V, K) vocabulary weight -> GreedyPartials of x . w^T + bias
+    (include/gvl_msda.h: gvl_gemm_f16x3_argmax_f32); consumed by greedy_step / row_argmax_lse_partials"""
+    _require(x.cols == w.cols, "gemm_f16x3_argmax: inner dimensions differ")
+    _require(bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == w.rows),
+             "gemm_f16x3_argmax: bias must be contiguous fp32 of length V")
+    L = _lib.lib()
+    part = torch.empty(L.gvl_gemm_f16x3_argmax_chunks(w.rows), x.rows, 4, device=x.hi.device, dtype=torch.float32)
+    with torch.cuda.device(part.device):
+        rc = L.gvl_gemm_f16x3_argmax_f32(x.hi.data_ptr(), x.lo.data_ptr(), x.scale.data_ptr(), x.rows, w.hi.data_ptr(),
+                                         w.lo.data_ptr(), w.scale.data_ptr(), w.rows, x.cols,
+                                         bias.data_ptr() if bias is not None else None, part.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "gemm_f16x3_argmax")
+    return GreedyPartials(part, x.rows, w.rows)
+
+
+def _greedy_from_partials(p, first, unfinished, seq_ptr, lp_ptr, T):
+    tok = torch.empty(p.rows, dtype=torch.int64, device=p.part.device)
+    lp = torch.empty(p.rows, dtype=torch.float32, device=p.part.device)
+    with torch.cuda.device(p.part.device):
+        rc = _lib.lib().gvl_greedy_step_partials_f32(p.part.data_ptr(), p.rows, p.vocab, first, tok.data_ptr(),
+                                                     lp.data_ptr(), unfinished, seq_ptr, lp_ptr, T,
+                                                     torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "greedy_step_partials")
+    return tok, lp
+
+
+def row_argmax_lse_partials(p):
+    """GreedyPartials -> (argmax (R,) int64, log-softmax at the argmax (R,) fp32)"""
+    return _greedy_from_partials(p, 0, None, None, None, 0)
+
+
 def greedy_step(logits, t_col, unfinished, seq, seq_lp):
     """argmax + log-softmax-at-argmax of the (R, V) logits AND the greedy bookkeeping of decoding step t_col
     (include/gvl_msda.h: gvl_greedy_step_f32): updates unfinished (R,) uint8 and seq / seq_lp (R, T) in place at
-    column t_col; -> raw argmax tokens (R,) int64"""
+    column t_col; -> raw argmax tokens (R,) int64.  `logits` may be the GreedyPartials of gemm_f16x3_argmax."""
+    if isinstance(logits, GreedyPartials):
+        _require(unfinished.dtype == torch.uint8 and seq.dtype == torch.int64 and seq_lp.dtype == torch.float32
+                 and seq.is_contiguous() and seq_lp.is_contiguous() and seq.shape == seq_lp.shape
+                 and seq.shape[0] == logits.rows, "greedy_step: bad bookkeeping tensors")
+        return _greedy_from_partials(logits, 1 if t_col == 0 else 0, unfinished.data_ptr(), seq.data_ptr() + 8 * t_col,
+                                     seq_lp.data_ptr() + 4 * t_col, seq.shape[1])[0]
     _require(logits.is_cuda and logits.is_contiguous() and logits.dtype in (torch.float32, torch.bfloat16)
              and logits.dim() == 2, "greedy_step: logits must be a contiguous fp32 / bf16 CUDA matrix")
     R, V = logits.shape

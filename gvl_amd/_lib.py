@@ -45,6 +45,9 @@ SIGNATURES = {
     "gvl_proj_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "gvl_split_rows_f16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "gvl_gemm_f16x3_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, ctypes.c_int64, _P]),
+    "gvl_gemm_f16x3_argmax_chunks": (_I, [_I]),
+    "gvl_gemm_f16x3_argmax_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "gvl_greedy_step_partials_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gvl_pos_embed_sine_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P, _P]),
     "gvl_match_cost_f32": (_I, [_P] * 4 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),
     "gvl_match_cost_padded_f32": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float] * 5 + [_P, _P, _P]),

@@ -16,8 +16,8 @@
 // folded in once at the end, so their low bits are not lost against the leading sum.  Measured against an fp64 product
 // on the shapes above (tools/split_gemm_probe2.py, tests/test_gpu_gemm16.py): rms error 1.9e-7 against the fp32 library
 // GEMM's 4.6e-7 (a k-ordered fp32 chain rounds 512 times, this one 32 + 64 times per output) -- the result is MORE
-// accurate than the fp32 path it replaces, also on operands spread over 12 orders of magnitude, at 3/16 of the
-// matrix-core time.  (Three bf16 parts would need six products: bf16 carries 8 bits per part, fp16 11.)
+// accurate than the fp32 path it replaces, at 3/16 of the matrix-core time.  Domain: the scale is per ROW, so an element
+// more than 2^-35 below its row's largest is not represented: |error| <= 2^-21 sum |a||b| + K 2^-33 max|a| max|b|.  (Three bf16 parts would need six products: bf16 carries 8 bits per part, fp16 11.)
 //
 // k_split_rows:  one wavefront per row -> hi / lo planes (fp16, row-major like the input) + the row scale.
 // k_gemm_f16x3:  out (R, N) = A (R, K) . B (N, K)^T [+ bias], both operands as planes.
@@ -85,7 +85,17 @@ constexpr int kBM = 128, kBK = 32, kGroupM = 8;
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
 
-template <int BN>
+// What happens to the 128 x BN tile D = A . B^T once it is complete:
+//   kStore       out[row][col] = D            (A = activations, B = weight; bias per column)
+//   kArgmax      A = the vocabulary layer's weight, B = the hidden states: per (token row = column of D, 64 vocabulary
+//                entries = the wavefront's rows of D) the maximum, its index and sum exp(v - max) -- the logits are never
+//                written.  All 32 vocabulary entries of one MFMA tile column sit in ONE lane's registers (and the lane
+//                32 further): the reduction is register-local plus one cross-lane step.
+enum { kStore = 0, kArgmax = 2 };
+// (a transposed store -- weight on the row side, one 16-byte store per 4 values of a lane -- was measured: 3 us SLOWER
+//  than the 4-byte stores of 128-byte row segments on the 4800 x 2560 / 2048 outputs)
+
+template <int BN, int EPI>
 __global__ void __launch_bounds__(256, 2)
     k_gemm_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                  const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
@@ -191,19 +201,120 @@ __global__ void __launch_bounds__(256, 2)
 #undef GVL_STASH
 
   // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const float *bias_p = bias ? bias : As;                               // branch-free optional bias
+  const float bias_on = bias ? 1.f : 0.f;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int col = n0 + wn + 32 * j + frow;
     const bool col_ok = col < N;
-    const float cs = col_ok ? Bs[col] : 0.f, cb = (col_ok && bias) ? bias[col] : 0.f;
+    const float cs = col_ok ? Bs[col] : 0.f;
+    if constexpr (EPI == kStore) {
+      const float cb = bias_on * bias_p[min(col, N - 1)];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (col_ok && row < R && (!(dbg & 1) || acc_m[i][j][r] == 12345.f)) out[(int64_t)row * ldo + col] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (As[row] * cs) + cb;
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (col_ok && row < R && (!(dbg & 1) || acc_m[i][j][r] == 12345.f))
+            out[(int64_t)row * ldo + col] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (As[row] * cs) + cb;
+        }
+    } else {
+      // two passes over the lane's 32 values of this column (recomputed, not kept: registers): maximum, then the sum
+      float best = -INFINITY, sum = 0.f;
+      int arg = 0x7fffffff;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, rc = min(row, R - 1);
+            const float v = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (As[rc] * cs) + bias_on * bias_p[rc];
+            if (pass == 0) {
+              if (row < R && v > best) { best = v; arg = row; }            // rows ascend: the first maximum is kept
+            } else if (row < R) {
+              sum += __expf(v - best);
+            }
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);           // four values at a time: more in flight spill
+          }
       }
+      // the lane 32 further holds the other half of this column's 64 rows
+      const float b2 = __shfl_xor(best, 32), s2 = __shfl_xor(sum, 32);
+      const int a2 = __shfl_xor(arg, 32);
+      const float bn = fmaxf(best, b2);
+      if (bn > -INFINITY) sum = sum * __expf(best - bn) + s2 * __expf(b2 - bn);        // exp(-inf) = 0 for an empty half
+      arg = (b2 > best || (b2 == best && a2 < arg)) ? a2 : arg;
+      if (fh == 0 && col_ok)
+        reinterpret_cast<float4 *>(out)[(int64_t)((m0 + wm) >> 6) * N + col] = make_float4(bn, sum, __int_as_float(arg), 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);            // one tile column at a time: interleaving them spills
   }
+}
+
+// partials (chunks, R) of {max, sum exp(v - max), index, -} -> per row argmax and log-softmax at the argmax, plus the
+// bookkeeping of one greedy step (gvl_cap.hip: k_row_argmax_lse has the same tail).  Block = 32 rows x 8 chunk groups.
+struct GreedyBook {
+  unsigned char *unfinished;
+  int64_t *seq;
+  float *seq_lp;
+  int seq_ld, first;
+};
+
+__global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__restrict__ part, int R, int chunks,
+                                                              int64_t *__restrict__ idx, float *__restrict__ logp,
+                                                              GreedyBook book) {
+  __shared__ float s_m[8][32], s_s[8][32];
+  __shared__ int s_a[8][32];
+  const int rr = threadIdx.x & 31, g = threadIdx.x >> 5, row = blockIdx.x * 32 + rr;
+  float m = -INFINITY, s = 0.f;
+  int a = 0x7fffffff;
+  if (row < R)
+    for (int c = g; c < chunks; c += 8) {
+      const float4 p = part[(int64_t)c * R + row];
+      const int pa = __float_as_int(p.z);
+      const float mn = fmaxf(m, p.x);
+      if (mn > -INFINITY) s = s * __expf(m - mn) + p.y * __expf(p.x - mn);
+      a = (p.x > m || (p.x == m && pa < a)) ? pa : a;
+      m = mn;
+    }
+  s_m[g][rr] = m; s_s[g][rr] = s; s_a[g][rr] = a;
+  __syncthreads();
+  if (g == 0 && row < R) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float m2 = s_m[k][rr], s2 = s_s[k][rr];
+      const int a2 = s_a[k][rr];
+      const float mn = fmaxf(m, m2);
+      if (mn > -INFINITY) s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+      a = (m2 > m || (m2 == m && a2 < a)) ? a2 : a;
+      m = mn;
+    }
+    const float lp = -logf(s);
+    idx[row] = a;
+    logp[row] = lp;
+    if (book.unfinished) {
+      const bool unf = (book.first || book.unfinished[row]) && a > 0;
+      book.unfinished[row] = unf;
+      book.seq[(int64_t)row * book.seq_ld] = unf ? a : 0;
+      book.seq_lp[(int64_t)row * book.seq_ld] = lp;
+    }
+  }
+}
+
+int check_operands(const char *what, const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi,
+                   const void *b_lo, const float *b_scale, int N, int K) {
+  if (R < 0 || N <= 0 || K <= 0 || (K % kBK))
+    return fail(GVL_EINVAL, "%s: needs K %% 32 == 0 (got R=%d N=%d K=%d)", what, R, N, K);
+  if (R == 0) return 0;
+  if (!a_hi || !a_lo || !a_scale || !b_hi || !b_lo || !b_scale) return fail(GVL_EINVAL, "%s: null pointer", what);
+  if (((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)b_hi | (uintptr_t)b_lo) & 15)
+    return fail(GVL_EINVAL, "%s: operand planes must be 16-byte aligned", what);
+  return 0;
+}
+
+int debug_flags() {
+  const char *e = getenv("GVL_GEMM16_DEBUG");
+  return e ? atoi(e) : 0;
 }
 
 }  // namespace
@@ -221,23 +332,48 @@ extern "C" int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *
 extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi,
                                   const void *b_lo, const float *b_scale, int N, int K, const float *bias, float *out,
                                   int64_t ldo, void *stream) {
-  if (R < 0 || N <= 0 || K <= 0 || (K % kBK) || ldo < N)
-    return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: needs K %% 32 == 0 and ldo >= N (got R=%d N=%d K=%d ldo=%lld)", R, N, K,
-                (long long)ldo);
+  if (int rc = check_operands("gvl_gemm_f16x3_f32", a_hi, a_lo, a_scale, R, b_hi, b_lo, b_scale, N, K)) return rc;
+  if (ldo < N) return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: ldo < N");
   if (R == 0) return 0;
-  if (!a_hi || !a_lo || !a_scale || !b_hi || !b_lo || !b_scale || !out)
-    return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: null pointer");
-  if (((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)b_hi | (uintptr_t)b_lo) & 15)
-    return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: operand planes must be 16-byte aligned");
+  if (!out) return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: null pointer");
+  const _Float16 *ah = (const _Float16 *)a_hi, *al = (const _Float16 *)a_lo, *bh = (const _Float16 *)b_hi,
+                 *bl = (const _Float16 *)b_lo;
+  const int dbg = debug_flags();
+  // wide 128-column tiles when they fill the chip for several rounds, narrow ones otherwise
   const int tiles_m = (R + kBM - 1) / kBM;
-  // wide tiles when they fill the chip for several rounds; narrow ones for the products with few column tiles
   const bool wide = (int64_t)tiles_m * ((N + 127) / 128) >= 1536;
   const int bn = wide ? 128 : 64, tiles_n = (N + bn - 1) / bn;
-  const int total = tiles_m * tiles_n, per = (total + 7) / 8;
-  const dim3 grid(per * 8);
-  auto kern = wide ? k_gemm_f16x3<128> : k_gemm_f16x3<64>;
-  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", kern, grid, dim3(256), 0, (hipStream_t)stream,
-                     (const _Float16 *)a_hi, (const _Float16 *)a_lo, a_scale, (const _Float16 *)b_hi,
-                     (const _Float16 *)b_lo, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n,
-                     getenv("GVL_GEMM16_DEBUG") ? atoi(getenv("GVL_GEMM16_DEBUG")) : 0);
+  const dim3 grid((tiles_m * tiles_n + 7) / 8 * 8);
+  auto kern = wide ? k_gemm_f16x3<128, kStore> : k_gemm_f16x3<64, kStore>;
+  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", kern, grid, dim3(256), 0, (hipStream_t)stream, ah, al,
+                     a_scale, bh, bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, dbg);
+}
+
+extern "C" int gvl_gemm_f16x3_argmax_chunks(int V) { return V > 0 ? (V + kBM - 1) / kBM * 2 : 0; }
+
+extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, const float *x_scale, int R, const void *w_hi,
+                                         const void *w_lo, const float *w_scale, int V, int K, const float *bias,
+                                         float *partials, void *stream) {
+  if (int rc = check_operands("gvl_gemm_f16x3_argmax_f32", x_hi, x_lo, x_scale, R, w_hi, w_lo, w_scale, V, K)) return rc;
+  if (R == 0) return 0;
+  if (!partials || ((uintptr_t)partials & 15)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_argmax_f32: partials null / unaligned");
+  const int tiles_m = (V + kBM - 1) / kBM, tiles_n = (R + 127) / 128;
+  const dim3 grid((tiles_m * tiles_n + 7) / 8 * 8);
+  return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3<argmax>", k_gemm_f16x3<128, kArgmax>, grid, dim3(256), 0,
+                     (hipStream_t)stream, (const _Float16 *)w_hi, (const _Float16 *)w_lo, w_scale, (const _Float16 *)x_hi,
+                     (const _Float16 *)x_lo, x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n,
+                     debug_flags());
+}
+
+extern "C" int gvl_greedy_step_partials_f32(const float *partials, int R, int V, int first_step, int64_t *token,
+                                            float *logp, unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col,
+                                            int seq_ld, void *stream) {
+  if (R < 0 || V <= 0 || (unfinished && seq_ld <= 0)) return fail(GVL_EINVAL, "gvl_greedy_step_partials_f32: bad sizes");
+  if (R == 0) return 0;
+  if (!partials || !token || !logp || (unfinished && (!seq_col || !seq_lp_col)))
+    return fail(GVL_EINVAL, "gvl_greedy_step_partials_f32: null pointer");
+  const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0};
+  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_from_partials", k_greedy_from_partials, dim3((R + 31) / 32),
+                     dim3(256), 0, (hipStream_t)stream, (const float4 *)partials, R, gvl_gemm_f16x3_argmax_chunks(V), token,
+                     logp, book);
 }

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 6   /* 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 6   /* 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -134,11 +134,24 @@ int gvl_proj_f32(const float *x, const float *weight, const float *bias, int R, 
  *        x[r][k] = scale[r] (hi[r][k] + 2^-11 lo[r][k])  to 2^-22 |x|;  scale[r] = 2^floor(log2 max_k |x[r][k]|).
  *    gvl_gemm_f16x3_f32:  out (R, ldo >= N) = A (R, K) . B (N, K)^T + bias (N, may be NULL), both operands as the
  *        planes + scales of gvl_split_rows_f16, K % 32 == 0, planes 16-byte aligned.  Three fp16 MFMAs per product
- *        (hi.hi, hi.lo, lo.hi; fp32 accumulation, cross terms in their own accumulator); error against an fp64
- *        product no larger than an fp32 GEMM's. */
+ *        (hi.hi, hi.lo, lo.hi; fp32 accumulation, cross terms in their own accumulator):
+ *        |error| <= 2^-21 sum_k |a||b| + K 2^-33 max_k|a| max_k|b| per output; at K >= 256 measured BELOW the summation
+ *        error of an fp32 GEMM (whose chain rounds K times). */
 int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *lo, float *scale, void *stream);
 int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi, const void *b_lo,
                        const float *b_scale, int N, int K, const float *bias, float *out, int64_t ldo, void *stream);
+/*    The same product for the vocabulary layer of GREEDY decoding, with the consumer fused (`torch.max(logprobs, 1)` over
+ *    `F.log_softmax(self.logit(output))`, LSTM_DSA.py:121-123,165-167): the logits (R, V) are never written.
+ *    gvl_gemm_f16x3_argmax_f32 leaves, per token row and per 64 vocabulary entries, {max, sum exp(v - max), index of the
+ *    first maximum, -} in partials (gvl_gemm_f16x3_argmax_chunks(V), R, 4) fp32 (16-byte aligned);
+ *    gvl_greedy_step_partials_f32 reduces them to token (R) = argmax, logp (R) = log-softmax at the argmax and applies the
+ *    bookkeeping of gvl_greedy_step_f32 (unfinished NULL = none).  Ties resolve to the lowest index, as torch.max. */
+int gvl_gemm_f16x3_argmax_chunks(int V);
+int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, const float *x_scale, int R, const void *w_hi,
+                              const void *w_lo, const float *w_scale, int V, int K, const float *bias, float *partials,
+                              void *stream);
+int gvl_greedy_step_partials_f32(const float *partials, int R, int V, int first_step, int64_t *token, float *logp,
+                                 unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld, void *stream);
 
 /* -- PositionEmbeddingSine.forward of one pyramid level (pdvc/position_encoding.py:38-64; the step in front of the
  *    path): normalised cumulative frame index -> interleaved sin / cos over `dim_t`, followed

@@ -45,33 +45,44 @@ def test_product_error_is_within_the_fp32_library_gemm_s(R, K, N):
     mine = MSDA.gemm_f16x3(MSDA.split_rows(x), MSDA.split_rows(w), b)
     d_mine, d_lib = (mine.double() - ref), (lib.double() - ref)
     rms_mine, rms_lib = float(d_mine.pow(2).mean().sqrt()), float(d_lib.pow(2).mean().sqrt())
-    ulp = 2.0 ** -23 * float(ref.abs().max())                            # the final rounding to fp32 alone (tiny cases)
-    assert rms_mine <= 1.05 * rms_lib + ulp, (rms_mine, rms_lib)
-    assert float(d_mine.abs().max()) <= 1.5 * float(d_lib.abs().max()) + ulp
+    ulp = 2.0 ** -23 * float(ref.abs().max())                            # the final rounding to fp32
+    # by construction every product carries 22 bits: |error| <= 2^-21 sum |a||b| + the final rounding
+    hard = 2.0 ** -21 * float((x.abs().double() @ w.abs().double().t()).max()) + ulp
+    assert float(d_mine.abs().max()) <= hard
+    if K >= 256 and R * N >= 10000:
+        # ... and at the depths of the path the fp32 GEMM's own summation error (a chain of K roundings) is the larger
+        assert rms_mine <= 1.05 * rms_lib, (rms_mine, rms_lib)
+        assert float(d_mine.abs().max()) <= 1.5 * float(d_lib.abs().max())
     # without bias, into a wider output buffer (ldo > N)
     wide = torch.full((R, N + 5), 7.0, device=dev)
     MSDA.gemm_f16x3(MSDA.split_rows(x), MSDA.split_rows(w), None, out=wide[:, :N])
-    assert float((wide[:, :N].double() - (ref - b.double())).abs().max()) <= 1.5 * float(d_lib.abs().max()) + ulp
+    assert float((wide[:, :N].double() - (ref - b.double())).abs().max()) <= hard
     assert bool((wide[:, N:] == 7.0).all())
 
 
 def test_product_of_operands_spread_over_many_orders_of_magnitude():
+    """rows of any magnitude (the row scale absorbs it), elements spread over 2^+-8 inside a row.  The contract:
+    |error| <= 2^-21 sum_k |a||b|  +  K 2^-33 max_k|a| max_k|b|  (elements more than 2^-35 below their row's maximum are
+    not represented -- no operand of the path comes near that)."""
     MSDA = _ops()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(9)
     R, K, N = 512, 512, 640
-    x = torch.randn(R, K, device=dev, generator=g) * torch.exp2(torch.randint(-20, 20, (R, K), device=dev, generator=g).float())
-    w = torch.randn(N, K, device=dev, generator=g) * torch.exp2(torch.randint(-20, 20, (N, K), device=dev, generator=g).float())
-    x[:, 0] = 1e30                                                        # far beyond fp16's range: the row scale absorbs it
-    w[:, 0] = 1e-30
+    x = torch.randn(R, K, device=dev, generator=g) * torch.exp2(torch.randint(-8, 8, (R, K), device=dev, generator=g).float())
+    w = torch.randn(N, K, device=dev, generator=g) * torch.exp2(torch.randint(-8, 8, (N, K), device=dev, generator=g).float())
+    x *= torch.exp2(torch.randint(-40, 40, (R, 1), device=dev, generator=g).float())      # far beyond fp16's range
+    w *= torch.exp2(torch.randint(-40, 40, (N, 1), device=dev, generator=g).float())
     ref = x.double() @ w.double().t()
     lib = x @ w.t()
     mine = MSDA.gemm_f16x3(MSDA.split_rows(x), MSDA.split_rows(w))
     assert bool(torch.isfinite(mine).all())
-    bound = x.abs().double() @ w.abs().double().t()                      # error relative to sum |a||b|, like any GEMM's
-    r_mine = float(((mine.double() - ref).abs() / bound).max())
-    r_lib = float(((lib.double() - ref).abs() / bound).max())
-    assert r_mine <= 2.0 * r_lib + 1e-9, (r_mine, r_lib)
+    bound = (2.0 ** -21 * (x.abs().double() @ w.abs().double().t())
+             + K * 2.0 ** -33 * x.abs().amax(1).double()[:, None] * w.abs().amax(1).double()[None, :]
+             + 2.0 ** -23 * ref.abs())
+    assert bool(((mine.double() - ref).abs() <= bound).all())
+    rel = x.abs().double() @ w.abs().double().t()
+    r_mine, r_lib = float(((mine.double() - ref).abs() / rel).max()), float(((lib.double() - ref).abs() / rel).max())
+    assert r_mine <= 2.0 * r_lib, (r_mine, r_lib)                        # and in practice like the fp32 GEMM
 
 
 def test_bad_arguments_are_refused():
@@ -82,3 +93,48 @@ def test_bad_arguments_are_refused():
     a, b = MSDA.split_rows(torch.randn(4, 64, device=dev)), MSDA.split_rows(torch.randn(6, 32, device=dev))
     with pytest.raises(RuntimeError):
         MSDA.gemm_f16x3(a, b)
+
+
+@pytest.mark.parametrize("R,V", [(4800, 8518), (100, 8518), (33, 70), (1, 1)])
+def test_fused_argmax_equals_argmax_of_the_written_logits(R, V):
+    """gvl_gemm_f16x3_argmax_f32 + gvl_greedy_step_partials_f32 against the same product written out and reduced by
+    torch: same token, log-probability to fp32 rounding, same bookkeeping as gvl_greedy_step_f32"""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(V)
+    K = 512
+    x = torch.randn(R, K, device=dev, generator=g)
+    w = torch.randn(V, K, device=dev, generator=g) * 0.05
+    b = torch.randn(V, device=dev, generator=g)
+    xp, wp = MSDA.split_rows(x), MSDA.split_rows(w)
+    logits = MSDA.gemm_f16x3(xp, wp, b)
+    lp_ref, tok_ref = torch.log_softmax(logits.double(), 1).max(1)
+    tok, lp = MSDA.row_argmax_lse_partials(MSDA.gemm_f16x3_argmax(xp, wp, b))
+    assert bool((tok == tok_ref).all())
+    assert float((lp.double() - lp_ref).abs().max()) <= 2e-6
+    # bookkeeping: identical to the kernel that reads written logits
+    T = 5
+    books = []
+    for src in (logits, MSDA.gemm_f16x3_argmax(xp, wp, b)):
+        unf = torch.empty(R, dtype=torch.uint8, device=dev)
+        seq = torch.zeros(R, T, dtype=torch.long, device=dev)
+        seq_lp = torch.zeros(R, T, device=dev)
+        t0 = MSDA.greedy_step(src, 0, unf, seq, seq_lp)
+        t1 = MSDA.greedy_step(src, 1, unf, seq, seq_lp)
+        books.append((unf, seq, seq_lp, t0, t1))
+    for a_, b_ in zip(*books):
+        assert bool((a_ == b_).all()) if a_.dtype != torch.float32 else float((a_ - b_).abs().max()) <= 2e-6
+
+
+def test_fused_argmax_ties_resolve_to_the_lowest_index():
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    R, V, K = 70, 300, 64
+    x = torch.zeros(R, K, device=dev)
+    x[:, 0] = 1.0
+    w = torch.zeros(V, K, device=dev)
+    w[[7, 64, 200, 299], 0] = 2.0                                       # four equal maxima, in different 64-entry chunks
+    tok, lp = MSDA.row_argmax_lse_partials(MSDA.gemm_f16x3_argmax(MSDA.split_rows(x), MSDA.split_rows(w)))
+    assert bool((tok == 7).all())
+    ref = torch.log_softmax(x.double() @ w.double().t(), 1)[:, 7]
+    assert float((lp.double() - ref).abs().max()) <= 1e-6
