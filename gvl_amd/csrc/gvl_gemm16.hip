@@ -201,15 +201,17 @@ __global__ void __launch_bounds__(256, 2)
 #undef GVL_STASH
 
   // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  const float *bias_p = bias ? bias : As;                               // branch-free optional bias
+  // branch-free optional bias: without one every read goes to As[0] (a finite power of two) and is multiplied by 0
+  const float *bias_p = bias ? bias : As;
   const float bias_on = bias ? 1.f : 0.f;
+  const int bias_ix = bias ? 0x7fffffff : 0;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int col = n0 + wn + 32 * j + frow;
     const bool col_ok = col < N;
     const float cs = col_ok ? Bs[col] : 0.f;
     if constexpr (EPI == kStore) {
-      const float cb = bias_on * bias_p[min(col, N - 1)];
+      const float cb = bias_on * bias_p[min(min(col, N - 1), bias_ix)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -229,7 +231,7 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, rc = min(row, R - 1);
-            const float v = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (As[rc] * cs) + bias_on * bias_p[rc];
+            const float v = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (As[rc] * cs) + bias_on * bias_p[min(rc, bias_ix)];
             if (pass == 0) {
               if (row < R && v > best) { best = v; arg = row; }            // rows ascend: the first maximum is kept
             } else if (row < R) {
