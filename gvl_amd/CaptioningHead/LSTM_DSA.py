@@ -152,11 +152,12 @@ class ShowAttendTellCore(nn.Module):
         else:
             h_gemm = getattr(h, "_gvl_lowp", h)                          # bf16 copy left by the cell kernel (autocast)
             g_h = F.linear(h_gemm, const["w_h_cat"], const["b_h_cat"])  # (n, A + 4H): [h2att(h) | h W_hh^T]
+        split = split and const["slab3"].dtype == torch.float32
         att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
                                   h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
-                                  self.n_levels, self.n_points)
-        if split and att_res.dtype == torch.float32:
-            return MSDA.gemm_f16x3(MSDA.split_rows(att_res), const["w_att_p"]), g_h
+                                  self.n_levels, self.n_points, planes=split)
+        if split:                                                       # att_res arrives as the planes of the product
+            return MSDA.gemm_f16x3(att_res, const["w_att_p"]), g_h
         return torch.mm(att_res, const["w_att_t"]), g_h                 # (the hs part, gates_hs, is added in the cell)
 
     def cell_part(self, g_x, g_h, xt_gates, c, const):
@@ -164,7 +165,8 @@ class ShowAttendTellCore(nn.Module):
         if not isinstance(xt_gates, tuple):                             # per-row pre-activations given directly
             xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
         emb_gates, it = xt_gates                                        # (table (V+1,4H), token ids)
-        return MSDA.lstm_cell(g_x, g_h[:, self.att_hid_size:], emb_gates, it, c, gates_c=const["gates_hs"])
+        return MSDA.lstm_cell(g_x, g_h[:, self.att_hid_size:], emb_gates, it, c, gates_c=const["gates_hs"],
+                              planes="w_h_cat_p" in const and g_x.dtype == torch.float32)
 
     def step(self, xt_gates, state, query, reference_points, temporal_shapes, level_start_index, const):
         """one token.  xt_gates = embed(it) @ W_ih[:, :E]^T  (B*Q, 4H)"""
@@ -538,7 +540,8 @@ class Captioner(nn.Module):
                                                          st["ref_in"], st["tshapes"], st["lsi"], st["const"])
                 planes = self._logit_planes(out)
                 if planes is not None:                                   # fp32 product on the fp16 matrix cores
-                    out._gvl_planes = MSDA.split_rows(out)               # the next step's h product reads the same planes
+                    if getattr(out, "_gvl_planes", None) is None:        # (the cell kernel normally leaves them)
+                        out._gvl_planes = MSDA.split_rows(out)           # the next step's h product reads the same planes
                     st["logits"] = MSDA.gemm_f16x3_argmax(out._gvl_planes, planes, self.logit.bias)   # never written out
                 else:
                     st["logits"] = self.logit(self.dropout(getattr(out, "_gvl_lowp", out)))

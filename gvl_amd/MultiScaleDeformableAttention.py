@@ -213,10 +213,11 @@ def ms_deform_attn_sample_backward(value, spatial_shapes, level_start_index, sam
 
 
 def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off_h, att_h, alpha_w, alpha_b,
-               n_levels, n_points, debug=False):
+               n_levels, n_points, debug=False, planes=False):
     """Fused deformable soft attention of one captioner token step (include/gvl_msda.h: gvl_cap_attend_f32 / _bf16).
     slab (B,S,2C) | ref_in (B,Q,L,1|2) | off_hs (B,Q,L*P) | h, att_h (B*Q,C) | w_off_h (L*P,C) | alpha_w (C,)
-    slab and att_h: both fp32 or both bf16 (GEMM outputs under autocast); everything else fp32."""
+    slab and att_h: both fp32 or both bf16 (GEMM outputs under autocast); everything else fp32.
+    planes=True (fp32 only): the result as the SplitPlanes operand of gemm_f16x3 (gvl_cap_attend_split_f32)."""
     st = slab.dtype
     _require(st in (torch.float32, torch.bfloat16), "cap_attend: slab must be fp32 or bf16")
     for name, t_ in (("ref_in", ref_in), ("off_hs", off_hs), ("h", h), ("w_off_h", w_off_h), ("alpha_w", alpha_w)):
@@ -229,6 +230,17 @@ def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off
     C = C2 // 2
     Q = ref_in.shape[1]
     RD = ref_in.shape[-1]
+    if planes:
+        _require(st == torch.float32 and not debug, "cap_attend: planes=True needs fp32 operands (and no debug outputs)")
+        out = SplitPlanes(B * Q, C, slab.device)
+        with torch.cuda.device(slab.device):
+            rc = _lib.lib().gvl_cap_attend_split_f32(
+                slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
+                off_hs.data_ptr(), h.data_ptr(), w_off_h.data_ptr(), att_h.data_ptr(), alpha_w.data_ptr(),
+                float(alpha_b), B, S, C, n_levels, Q, n_points, RD, att_h.stride(0), out.hi.data_ptr(),
+                out.lo.data_ptr(), out.scale.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "cap_attend_split")
+        return out
     att_res = torch.empty((B * Q, C), device=slab.device, dtype=st)      # bf16 kernel: bf16 (A operand of a bf16 GEMM)
     dbg_a = torch.empty((B * Q, n_levels * n_points), device=slab.device) if debug else None
     dbg_l = torch.empty((B * Q, n_levels * n_points), device=slab.device) if debug else None
@@ -429,9 +441,10 @@ def lstm_cell_train_backward(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, gra
     _lib.check(rc, "lstm_cell_train_backward")
 
 
-def lstm_cell(gates_a, gates_b, emb_gates, it, c, gates_c=None):
+def lstm_cell(gates_a, gates_b, emb_gates, it, c, gates_c=None, planes=False):
     """fused LSTM cell pointwise step (include/gvl_msda.h: gvl_lstm_cell_f32 / _bf16) -> (h', c').  The gate operands
-    are all fp32 or all bf16; the state c (and the outputs) fp32."""
+    are all fp32 or all bf16; the state c (and the outputs) fp32.  planes=True (fp32 gates): h' additionally as the
+    SplitPlanes operand of gemm_f16x3, left in h'._gvl_planes (gvl_lstm_cell_split_f32)."""
     n, H = c.shape
     gt = gates_a.dtype
     _require(gt in (torch.float32, torch.bfloat16) and c.dtype == torch.float32, "lstm_cell: gates fp32 | bf16, c fp32")
@@ -441,6 +454,18 @@ def lstm_cell(gates_a, gates_b, emb_gates, it, c, gates_c=None):
     _require(emb_gates.is_contiguous() and emb_gates.dtype == gt and c.is_contiguous() and it.is_contiguous()
              and it.dtype == torch.int64, "lstm_cell: emb_gates / c / it must be contiguous (it int64)")
     h_out, c_out = torch.empty_like(c), torch.empty_like(c)
+    if planes:
+        _require(gt == torch.float32 and H % 32 == 0, "lstm_cell: planes=True needs fp32 gates and H % 32 == 0")
+        hp = SplitPlanes(n, H, c.device)
+        with torch.cuda.device(c.device):
+            rc = _lib.lib().gvl_lstm_cell_split_f32(
+                gates_a.data_ptr(), gates_a.stride(0), gates_b.data_ptr(), gates_b.stride(0), emb_gates.data_ptr(),
+                it.data_ptr(), gates_c.data_ptr() if gates_c is not None else None,
+                gates_c.stride(0) if gates_c is not None else 0, c.data_ptr(), n, H, h_out.data_ptr(), c_out.data_ptr(),
+                hp.hi.data_ptr(), hp.lo.data_ptr(), hp.scale.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "lstm_cell_split")
+        h_out._gvl_planes = hp
+        return h_out, c_out
     extra = ()
     if gt == torch.bfloat16:                      # a bf16 copy of h' for the next GEMMs (returned as h_out._gvl_lowp)
         h_lp = torch.empty((n, H), dtype=gt, device=c.device)

@@ -107,6 +107,24 @@ __device__ inline void border_coef(float loc, int T, int &r, float &c_lo, float 
 }
 
 // ST: storage type of the slab and of att_h (fp32, or bf16 as a GEMM under autocast leaves them); arithmetic fp32
+// fp32 -> two fp16 parts with x = s (hi + 2^-11 lo), the operand form of gvl_gemm_f16x3_f32 (gvl_gemm16.hip): `inv` = 1 / s
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ inline void split4_f16(const float4 v, float inv, half4_t &hi, half4_t &lo) {
+  const float a[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    hi[c] = (_Float16)a[c];
+    lo[c] = (_Float16)((a[c] - (float)hi[c]) * 2048.f);
+  }
+}
+// power-of-two scale of a row whose largest magnitude is m: s = 2^floor(log2 m) (exponent field clamped so that 1 / s exists)
+__device__ inline void pow2_scale(float m, float &s, float &inv) {
+  int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  e = min(max(e, 1), 253);
+  s = __uint_as_float((uint32_t)e << 23);
+  inv = __uint_as_float((uint32_t)(254 - e) << 23);
+}
+
 // FULL: L*P == 16 known at compile time -- the sample loops lose their guards and become straight-line code, so the
 // eight loads of a sample pair really are in flight together
 template <typename ST, bool FULL>
@@ -123,7 +141,10 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     float alpha_b, int B, int S, int L, int Q, int P, int RD, int rows_per_xcd_group, int att_h_ld,
     ST *__restrict__ att_res,            // (B*Q, C), in the storage type: it is the A operand of the next GEMM
     float *__restrict__ dbg_alpha,       // optional (B*Q, 16)
-    float *__restrict__ dbg_loc) {       // optional (B*Q, 16)
+    float *__restrict__ dbg_loc,         // optional (B*Q, 16)
+    _Float16 *__restrict__ o_hi,         // optional: the result as the fp16 planes + row scale of gvl_gemm_f16x3_f32
+    _Float16 *__restrict__ o_lo,         //           INSTEAD of att_res (fp32 kernel only)
+    float *__restrict__ o_scale) {
   __shared__ float4 wo4[kLP * kC / 4];   // 32 KiB: the h part of the offsets projection
   for (int i = threadIdx.x; i < kLP * kC / 4; i += blockDim.x) wo4[i] = reinterpret_cast<const float4 *>(w_off_h)[i];
 
@@ -232,6 +253,24 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     __builtin_amdgcn_sched_barrier(0);
     if (k < LP) { coef(k, cl0, ch0); fma8(cl0, ra.l0, ra.l1, acc); fma8(ch0, ra.u0, ra.u1, acc); }
     if (k + 1 < LP) { coef(k + 1, cl1, ch1); fma8(cl1, rb.l0, rb.l1, acc); fma8(ch1, rb.u0, rb.u1, acc); }
+  }
+  if (o_hi) {
+    // the wavefront owns the whole row: its largest magnitude is one reduction away
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(acc[c]));
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sc, inv;
+    pow2_scale(m, sc, inv);
+    if (lane == 0) o_scale[row] = sc;
+    half4_t h0, l0, h1, l1;
+    split4_f16(make_float4(acc[0], acc[1], acc[2], acc[3]), inv, h0, l0);
+    split4_f16(make_float4(acc[4], acc[5], acc[6], acc[7]), inv, h1, l1);
+    half4_t *ph = reinterpret_cast<half4_t *>(o_hi + row * kC), *pl = reinterpret_cast<half4_t *>(o_lo + row * kC);
+    ph[lane] = h0; ph[64 + lane] = h1;
+    pl[lane] = l0; pl[64 + lane] = l1;
+    return;
   }
   ST *o = att_res + row * kC;
   st4(o, lane, make_float4(acc[0], acc[1], acc[2], acc[3]));
@@ -439,7 +478,8 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const GT *__restrict__ ga, in
                                                    int ldb, const GT *__restrict__ emb, const int64_t *__restrict__ it,
                                                    const GT *__restrict__ gc, int ldc, const float *__restrict__ c,
                                                    int n, int H, float *__restrict__ h_out, float *__restrict__ c_out,
-                                                   GT *__restrict__ h_gemm) {
+                                                   GT *__restrict__ h_gemm, _Float16 *__restrict__ h_hi,
+                                                   _Float16 *__restrict__ h_lo, float *__restrict__ h_scale) {
   const int H4 = H >> 2;
   const int64_t total = (int64_t)n * H4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -465,6 +505,15 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const GT *__restrict__ ga, in
     reinterpret_cast<float4 *>(c_out)[idx] = cn;
     reinterpret_cast<float4 *>(h_out)[idx] = hn;
     if (h_gemm) st4(h_gemm, idx, hn);        // h' once more in the gates' storage type: the A operand of the next GEMMs
+    if (h_hi) {
+      // ... or as the fp16 planes of gvl_gemm_f16x3_f32.  |h'| = |sigmoid . tanh| < 1, so the row scale is 1 for every
+      // row (no overflow; an element below 2^-14 sits in fp16's subnormal range, absolute precision 2^-35 with the lo part)
+      half4_t hi, lo;
+      split4_f16(hn, 1.f, hi, lo);
+      reinterpret_cast<half4_t *>(h_hi)[idx] = hi;
+      reinterpret_cast<half4_t *>(h_lo)[idx] = lo;
+      if (j == 0) h_scale[row] = 1.f;
+    }
   }
 }
 
@@ -495,12 +544,14 @@ template <typename ST>
 int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
                     const float *off_hs, const float *h, const float *w_off_h, const ST *att_h, const float *alpha_w,
                     float alpha_b, int B, int S, int C, int L, int Q, int P, int RD, int att_h_ld, ST *att_res,
-                    float *dbg_alpha, float *dbg_loc, void *stream) {
+                    float *dbg_alpha, float *dbg_loc, void *stream, void *o_hi = nullptr, void *o_lo = nullptr,
+                    float *o_scale = nullptr) {
   if (att_h_ld < C || (att_h_ld & 3)) return fail(GVL_EINVAL, "%s: att_h_ld must be >= C and a multiple of 4", what);
   if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
     return fail(GVL_EINVAL, "%s: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", what, C, L, P, RD);
   if ((int64_t)B * Q == 0) return 0;
-  if (!slab || !shapes || !lsi || !ref || !off_hs || !h || !w_off_h || !att_h || !alpha_w || !att_res)
+  if (!slab || !shapes || !lsi || !ref || !off_hs || !h || !w_off_h || !att_h || !alpha_w || (!att_res && !o_hi)
+      || (o_hi && (!o_lo || !o_scale)))
     return fail(GVL_EINVAL, "%s: null pointer", what);
   const int vids_per_group = (B + 7) / 8;
   const int rows_per_group = vids_per_group * Q;
@@ -508,13 +559,16 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
   auto kern = L * P == kLP ? k_cap_attend<ST, true> : k_cap_attend<ST, false>;
   return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", kern, dim3(8 * blocks_per_group),
                      dim3(kWaves * 64), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
-                     alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_h_ld, att_res, dbg_alpha, dbg_loc);
+                     alpha_w, alpha_b, B, S, L, Q, P, RD, rows_per_group, att_h_ld, att_res, dbg_alpha, dbg_loc,
+                     (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale);
 }
 
 template <typename GT>
 int lstm_cell_impl(const char *what, const GT *gates_a, int lda, const GT *gates_b, int ldb, const GT *emb_gates,
                    const int64_t *it, const GT *gates_c, int ldc, const float *c, int n, int H, float *h_out,
-                   float *c_out, GT *h_gemm, void *stream) {
+                   float *c_out, GT *h_gemm, void *stream, void *h_hi = nullptr, void *h_lo = nullptr,
+                   float *h_scale = nullptr) {
+  if (h_hi && (!h_lo || !h_scale)) return fail(GVL_EINVAL, "%s: null pointer", what);
   if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3) ||
       (gates_c && (ldc < 4 * H || (ldc & 3))))
     return fail(GVL_EINVAL, "%s: bad sizes n=%d H=%d lda=%d ldb=%d", what, n, H, lda, ldb);
@@ -524,7 +578,7 @@ int lstm_cell_impl(const char *what, const GT *gates_a, int lda, const GT *gates
   if (blocks > 4096) blocks = 4096;
   return gvl::launch(GVL_PROF_LSTM_CELL, n, H, "k_lstm_cell", k_lstm_cell<GT>, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H, h_out, c_out,
-                     h_gemm);
+                     h_gemm, (_Float16 *)h_hi, (_Float16 *)h_lo, h_scale);
 }
 
 template <typename LT>
@@ -556,6 +610,24 @@ int gvl_cap_attend_bf16(const uint16_t *slab, const int64_t *shapes, const int64
   return cap_attend_impl<bf16_t>("gvl_cap_attend_bf16", (const bf16_t *)slab, shapes, lsi, ref, off_hs, h, w_off_h,
                                  (const bf16_t *)att_h, alpha_w, alpha_b, B, S, C, L, Q, P, RD, att_h_ld,
                                  (bf16_t *)att_res, dbg_alpha, dbg_loc, stream);
+}
+
+int gvl_cap_attend_split_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                             const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
+                             const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
+                             int att_h_ld, void *att_hi, void *att_lo, float *att_scale, void *stream) {
+  if (!att_hi) return fail(GVL_EINVAL, "gvl_cap_attend_split_f32: null pointer");
+  return cap_attend_impl<float>("gvl_cap_attend_split_f32", slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h, alpha_w,
+                                alpha_b, B, S, C, L, Q, P, RD, att_h_ld, (float *)nullptr, nullptr, nullptr, stream, att_hi,
+                                att_lo, att_scale);
+}
+
+int gvl_lstm_cell_split_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
+                            const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
+                            float *c_out, void *h_hi, void *h_lo, float *h_scale, void *stream) {
+  if (!h_hi) return fail(GVL_EINVAL, "gvl_lstm_cell_split_f32: null pointer");
+  return lstm_cell_impl<float>("gvl_lstm_cell_split_f32", gates_a, lda, gates_b, ldb, emb_gates, it, gates_c, ldc, c, n, H,
+                               h_out, c_out, (float *)nullptr, stream, h_hi, h_lo, h_scale);
 }
 
 int gvl_lstm_cell_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,

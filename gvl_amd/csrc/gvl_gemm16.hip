@@ -31,7 +31,6 @@
 //   workgroups resident on one XCD share 2 MB + 2 MB of operand planes in its 4 MB L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "gvl_common.hpp"
 #include "gvl_msda.h"
@@ -85,7 +84,13 @@ constexpr int kBM = 128, kBK = 32, kGroupM = 8;
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
 
-// What happens to the 128 x BN tile D = A . B^T once it is complete:
+// 16 bytes per lane, global -> LDS without a register: the wavefront's 64 lanes land at lds .. lds + 1 KiB, lane-linear
+__device__ __forceinline__ void glds16(const void *g, void *lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+// What happens to a tile of D = A . B^T once it is complete:
 //   kStore       out[row][col] = D            (A = activations, B = weight; bias per column)
 //   kArgmax      A = the vocabulary layer's weight, B = the hidden states: per (token row = column of D, 64 vocabulary
 //                entries = the wavefront's rows of D) the maximum, its index and sum exp(v - max) -- the logits are never
@@ -95,52 +100,180 @@ enum { kStore = 0, kArgmax = 2 };
 // (a transposed store -- weight on the row side, one 16-byte store per 4 values of a lane -- was measured: 3 us SLOWER
 //  than the 4-byte stores of 128-byte row segments on the 4800 x 2560 / 2048 outputs)
 
+// tile (row0, col0) of workgroup `bid`: XCD x (= bid % 8) walks the contiguous range [x per, (x + 1) per) of the tile order
+// "groups of kGroupM row tiles, column-major inside a group"
+__device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int &tm, int &tn) {
+  const int total = tiles_m * tiles_n, per = (total + 7) >> 3;
+  const int t = (bid & 7) * per + (bid >> 3);
+  if ((bid >> 3) >= per || t >= total) return false;
+  const int gsz_full = kGroupM * tiles_n, g = t / gsz_full, first_m = g * kGroupM;
+  const int gm = min(tiles_m - first_m, kGroupM), in_g = t - g * gsz_full;
+  tm = first_m + in_g % gm;
+  tn = in_g / gm;
+  return true;
+}
+
+// the 24 (NJ = 2) MFMAs of one wavefront on one K stage of 32: fragments at slots fa / fb of the stage image `st`
+template <int NJ>
+__device__ __forceinline__ void mfma_stage(const uint4 *st, int a_lo_off, int b_lo_off, const int (&fa)[2][2],
+                                           const int (&fb)[NJ][2], f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ]) {
+  // all fragment reads of the stage first: the second K half lands under the MFMAs of the first
+  h8 f_ah[2][2], f_al[2][2], f_bh[2][NJ], f_bl[2][NJ];
+#ifdef GVL_ABLATE_LDS
+  st = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(st, 16));
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { f_ah[s][i] = __builtin_bit_cast(h8, make_uint4(fa[i][s], 1, 2, 3)); f_al[s][i] = f_ah[s][i]; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { f_bh[s][j] = __builtin_bit_cast(h8, make_uint4(fb[j][s], 5, 6, 7)); f_bl[s][j] = f_bh[s][j]; }
+  }
+  if (false)
+#endif
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f_ah[s][i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);
+      f_al[s][i] = *reinterpret_cast<const h8 *>(&st[a_lo_off + fa[i][s]]);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f_bh[s][j] = *reinterpret_cast<const h8 *>(&st[fb[j][s]]);
+      f_bl[s][j] = *reinterpret_cast<const h8 *>(&st[b_lo_off + fb[j][s]]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bh[s][j], acc_m[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s][j], acc_x[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s][j], acc_x[i][j], 0, 0, 0);
+      }
+}
+
+// epilogue of one wavefront: its 64 x 32 NJ part of D starts at (row0, col0)
+template <int NJ, int EPI>
+__device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ], int row0, int col0, int lane,
+                                         const float *__restrict__ As, const float *__restrict__ Bs,
+                                         const float *__restrict__ bias, int R, int N, float *__restrict__ out,
+                                         int64_t ldo) {
+  // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const int frow = lane & 31, fh = lane >> 5;
+  // branch-free optional bias: without one every read goes to As[0] (a finite power of two) and is multiplied by 0
+  const float *bias_p = bias ? bias : As;
+  const float bias_on = bias ? 1.f : 0.f;
+  const int bias_ix = bias ? 0x7fffffff : 0;
+  // The row scales (and, for kArgmax, the per-row bias) of this lane's 32 rows are read ONCE, before anything is stored:
+  // a load between two stores makes the compiler wait vmcnt(0) for it, i.e. for every store issued so far
+  float rs[2][16], rb[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rc = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
+      rs[i][r] = As[rc];
+      if constexpr (EPI == kArgmax) rb[i][r] = bias_on * bias_p[min(rc, bias_ix)];
+    }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = col0 + 32 * j + frow;
+    const bool col_ok = col < N;
+    const float cs = col_ok ? Bs[col] : 0.f;
+    if constexpr (EPI == kStore) {
+      const float cb = bias_on * bias_p[min(min(col, N - 1), bias_ix)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (col_ok && row < R)
+            out[(int64_t)row * ldo + col] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[i][r] * cs) + cb;
+        }
+    } else {
+      // two passes over the lane's 32 values of this column (recomputed, not kept: registers): maximum, then the sum
+      float best = -INFINITY, sum = 0.f;
+      int arg = 0x7fffffff;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            const float v = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[i][r] * cs) + rb[i][r];
+            if (pass == 0) {
+              if (row < R && v > best) { best = v; arg = row; }            // rows ascend: the first maximum is kept
+            } else if (row < R) {
+              sum += __expf(v - best);
+            }
+          }
+      }
+      // the lane 32 further holds the other half of this column's 64 rows
+      const float b2 = __shfl_xor(best, 32), s2 = __shfl_xor(sum, 32);
+      const int a2 = __shfl_xor(arg, 32);
+      const float bn = fmaxf(best, b2);
+      if (bn > -INFINITY) sum = sum * __expf(best - bn) + s2 * __expf(b2 - bn);        // exp(-inf) = 0 for an empty half
+      arg = (b2 > best || (b2 == best && a2 < arg)) ? a2 : arg;
+      if (fh == 0 && col_ok)
+        reinterpret_cast<float4 *>(out)[(int64_t)(row0 >> 6) * N + col] = make_float4(bn, sum, __int_as_float(arg), 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);            // one tile column at a time: interleaving them spills
+  }
+}
+
+// ---- four wavefronts, 128 x BN tile, two LDS stages: the form for few rows / few tiles (three workgroups per CU at BN = 64)
 template <int BN, int EPI>
 __global__ void __launch_bounds__(256, 2)
     k_gemm_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                  const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
                  const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo, int tiles_m,
-                 int tiles_n, int dbg) {
+                 int tiles_n) {
   constexpr int NJ = BN / 64;                                         // 32-column MFMA tiles per wavefront
-  constexpr int NBR = BN / 64;                                        // B rows staged per thread and plane
-  __shared__ uint4 sA[2][2][kBM * 4];                                 // [stage][plane hi | lo][row * 4 + swizzled chunk]
-  __shared__ uint4 sB[2][2][BN * 4];
+  // ONE LDS object (a second one beside an LDS-DMA target can make hipcc drain the DMA before every ds_read):
+  // [stage][A hi | A lo | B hi | B lo][row * 4 + swizzled chunk], 16-byte slots
+  constexpr int kASlots = kBM * 4, kBSlots = BN * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  __shared__ uint4 smem[2 * kStageSlots];
 
-  // tile of this workgroup: XCD x walks the contiguous range [x per, (x + 1) per) of the grouped tile order
-  const int total = tiles_m * tiles_n, per = (total + 7) >> 3;
-  const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || t >= total) return;
-  const int gsz_full = kGroupM * tiles_n, g = t / gsz_full, first_m = g * kGroupM;
-  const int gm = min(tiles_m - first_m, kGroupM), in_g = t - g * gsz_full;
-  const int m0 = (first_m + in_g % gm) * kBM, n0 = (in_g / gm) * BN;
-
+  int tm, tn;
+  if (!tile_of((int)blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+  const int m0 = tm * kBM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
 
-  // staging map: thread -> 16-byte chunk c of row r (and r + 64) of every plane
-  const int sc = tid & 3, sr = tid >> 2;
-  const int64_t a_off0 = (int64_t)min(m0 + sr, R - 1) * K + sc * 8, a_off1 = (int64_t)min(m0 + sr + 64, R - 1) * K + sc * 8;
-  const int64_t b_off0 = (int64_t)min(n0 + sr, N - 1) * K + sc * 8, b_off1 = (int64_t)min(n0 + sr + 64, N - 1) * K + sc * 8;
-
-  // one K stage's share of a thread, in plain registers (named, not an array: a loop-carried array goes to scratch)
-  uint4 a_h0, a_h1, a_l0, a_l1, b_h0, b_h1 = {}, b_l0, b_l1 = {};
-#define GVL_FETCH(k0)                                                        \
-  a_h0 = *reinterpret_cast<const uint4 *>(Ah + a_off0 + (k0));               \
-  a_h1 = *reinterpret_cast<const uint4 *>(Ah + a_off1 + (k0));               \
-  a_l0 = *reinterpret_cast<const uint4 *>(Al + a_off0 + (k0));               \
-  a_l1 = *reinterpret_cast<const uint4 *>(Al + a_off1 + (k0));               \
-  b_h0 = *reinterpret_cast<const uint4 *>(Bh + b_off0 + (k0));               \
-  b_l0 = *reinterpret_cast<const uint4 *>(Bl + b_off0 + (k0));               \
-  if (NBR == 2) {                                                            \
-    b_h1 = *reinterpret_cast<const uint4 *>(Bh + b_off1 + (k0));             \
-    b_l1 = *reinterpret_cast<const uint4 *>(Bl + b_off1 + (k0));             \
+  // Staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction writes 64 consecutive slots = 16 rows of a plane,
+  // lane l the slot base + l.  The swizzle therefore sits on the SOURCE address: slot (row, position p) holds chunk
+  // p ^ ((row >> 2) & 3) of the row.  Wavefront w fills rows 32 w .. 32 w + 31 of A (two instructions per plane) and the
+  // same rows of B (BN = 128) or rows 16 w .. 16 w + 15 (BN = 64).
+  constexpr int NBU = BN / 64;                                        // B units (16 rows) per wavefront and plane
+  const int srow = lane >> 2, spos = lane & 3;
+  int64_t a_src[2], b_src[NBU];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = (2 * wave + u) * 16 + srow;
+    a_src[u] = (int64_t)min(m0 + row, R - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
   }
-#define GVL_STASH(buf)                                                       \
-  sA[buf][0][slot0] = a_h0; sA[buf][0][slot1] = a_h1;                        \
-  sA[buf][1][slot0] = a_l0; sA[buf][1][slot1] = a_l1;                        \
-  sB[buf][0][slot0] = b_h0; sB[buf][1][slot0] = b_l0;                        \
-  if (NBR == 2) { sB[buf][0][slot1] = b_h1; sB[buf][1][slot1] = b_l1; }
-  const int slot0 = lds_slot(sr, sc), slot1 = lds_slot(sr + 64, sc);
+#pragma unroll
+  for (int u = 0; u < NBU; ++u) {
+    const int row = (NBU * wave + u) * 16 + srow;
+    b_src[u] = (int64_t)min(n0 + row, N - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
+  }
+  auto issue = [&](int k0, int buf) {
+    uint4 *st = smem + buf * kStageSlots;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      glds16(Ah + a_src[u] + k0, st + (2 * wave + u) * 64);
+      glds16(Al + a_src[u] + k0, st + kASlots + (2 * wave + u) * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < NBU; ++u) {
+      glds16(Bh + b_src[u] + k0, st + 2 * kASlots + (NBU * wave + u) * 64);
+      glds16(Bl + b_src[u] + k0, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
+    }
+  };
 
   f16acc acc_m[2][NJ], acc_x[2][NJ];                                  // leading sum | cross terms
 #pragma unroll
@@ -158,103 +291,168 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
     for (int i = 0; i < 2; ++i) fa[i][s] = lds_slot(wm + 32 * i + frow, 2 * s + fh);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) fb[j][s] = lds_slot(wn + 32 * j + frow, 2 * s + fh);
+    for (int j = 0; j < NJ; ++j) fb[j][s] = 2 * kASlots + lds_slot(wn + 32 * j + frow, 2 * s + fh);
   }
-  auto compute = [&](int buf) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      h8 f_ah[2], f_al[2], f_bh[NJ], f_bl[NJ];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f_ah[i] = *reinterpret_cast<const h8 *>(&sA[buf][0][fa[i][s]]);
-        f_al[i] = *reinterpret_cast<const h8 *>(&sA[buf][1][fa[i][s]]);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        f_bh[j] = *reinterpret_cast<const h8 *>(&sB[buf][0][fb[j][s]]);
-        f_bl[j] = *reinterpret_cast<const h8 *>(&sB[buf][1][fb[j][s]]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[i], f_bh[j], acc_m[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[i], f_bl[j], acc_x[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[i], f_bh[j], acc_x[i][j], 0, 0, 0);
-        }
-    }
-  };
 
   const int KT = K / kBK;
-  GVL_FETCH(0)
-  GVL_STASH(0)
-  __syncthreads();
+  issue(0, 0);
+  __syncthreads();                              // (waits for the DMA: vmcnt(0))
   for (int kt = 0; kt + 1 < KT; ++kt) {
     const int buf = kt & 1;
-    if (!(dbg & 2)) { GVL_FETCH((kt + 1) * kBK) }   // in flight under this stage's MFMAs
-    compute(buf);
-    GVL_STASH(buf ^ 1)                          // last read one barrier ago
+    issue((kt + 1) * kBK, buf ^ 1);             // the other buffer was last read one barrier ago
+    mfma_stage<NJ>(smem + buf * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
     __syncthreads();
   }
-  compute((KT - 1) & 1);
-#undef GVL_FETCH
-#undef GVL_STASH
+  mfma_stage<NJ>(smem + ((KT - 1) & 1) * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
+  epilogue<NJ, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
+}
 
-  // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  // branch-free optional bias: without one every read goes to As[0] (a finite power of two) and is multiplied by 0
-  const float *bias_p = bias ? bias : As;
-  const float bias_on = bias ? 1.f : 0.f;
-  const int bias_ix = bias ? 0x7fffffff : 0;
+// ---- eight wavefronts (WM x WN, 64 x 64 each), tile 64 WM x 64 WN, THREE LDS stages with the DMA two stages ahead.
+// The operand traffic of 128 x 128 tiles is 1.3 GB per vocabulary product (8 TB/s out of L2 while it runs) and a stage's
+// DMA, issued when the stage before it starts, does not land within that stage's 1536 MFMA cycles: measured 30 % MFMA
+// utilisation, waves parked at the barrier.  Here a stage has two stages' time to arrive and the tile moves 3/4 of the
+// bytes per FLOP.  One barrier per stage: counted `s_waitcnt vmcnt` (this wavefront's DMA of the stage about to be read
+// is complete, the next stage's stays in flight), raw s_barrier (everybody's is, and everybody has finished reading the
+// buffer that is refilled next), then the DMA of stage kt + 2, then the MFMAs of stage kt.
+template <int WM, int WN, int EPI>
+__global__ void __launch_bounds__(512, 1)
+    k_gemm_f16x3_w8(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
+                    const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
+                    const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo,
+                    int tiles_m, int tiles_n) {
+  static_assert(WM * WN == 8, "eight wavefronts");
+  constexpr int kRowsA = 64 * WM, kRowsB = 64 * WN;
+  constexpr int kASlots = kRowsA * 4, kBSlots = kRowsB * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  constexpr int NG = WM + WN;                                         // DMA instructions per wavefront and stage
+  __shared__ uint4 smem[3 * kStageSlots];
+
+  int tm, tn;
+  if (!tile_of((int)blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+  const int m0 = tm * kRowsA, n0 = tn * kRowsB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave % WM) * 64, wn = (wave / WM) * 64;
+
+  // DMA units of 16 rows: unit q = wave + 8 i; i < WM -> A (plane q / (4 WM), block q % (4 WM)), else B likewise
+  const int srow = lane >> 2, spos = lane & 3;
+  const _Float16 *src[NG];
+  int dst[NG];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int col = n0 + wn + 32 * j + frow;
-    const bool col_ok = col < N;
-    const float cs = col_ok ? Bs[col] : 0.f;
-    if constexpr (EPI == kStore) {
-      const float cb = bias_on * bias_p[min(min(col, N - 1), bias_ix)];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          if (col_ok && row < R && (!(dbg & 1) || acc_m[i][j][r] == 12345.f))
-            out[(int64_t)row * ldo + col] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (As[row] * cs) + cb;
-        }
+  for (int i = 0; i < NG; ++i) {
+    if (i < WM) {
+      const int q = wave + 8 * i, plane = q / (4 * WM), blk = q % (4 * WM), row = blk * 16 + srow;
+      src[i] = (plane ? Al : Ah) + (int64_t)min(m0 + row, R - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
+      dst[i] = plane * kASlots + blk * 64;
     } else {
-      // two passes over the lane's 32 values of this column (recomputed, not kept: registers): maximum, then the sum
-      float best = -INFINITY, sum = 0.f;
-      int arg = 0x7fffffff;
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, rc = min(row, R - 1);
-            const float v = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (As[rc] * cs) + bias_on * bias_p[min(rc, bias_ix)];
-            if (pass == 0) {
-              if (row < R && v > best) { best = v; arg = row; }            // rows ascend: the first maximum is kept
-            } else if (row < R) {
-              sum += __expf(v - best);
-            }
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);           // four values at a time: more in flight spill
-          }
-      }
-      // the lane 32 further holds the other half of this column's 64 rows
-      const float b2 = __shfl_xor(best, 32), s2 = __shfl_xor(sum, 32);
-      const int a2 = __shfl_xor(arg, 32);
-      const float bn = fmaxf(best, b2);
-      if (bn > -INFINITY) sum = sum * __expf(best - bn) + s2 * __expf(b2 - bn);        // exp(-inf) = 0 for an empty half
-      arg = (b2 > best || (b2 == best && a2 < arg)) ? a2 : arg;
-      if (fh == 0 && col_ok)
-        reinterpret_cast<float4 *>(out)[(int64_t)((m0 + wm) >> 6) * N + col] = make_float4(bn, sum, __int_as_float(arg), 0.f);
+      const int q = wave + 8 * (i - WM), plane = q / (4 * WN), blk = q % (4 * WN), row = blk * 16 + srow;
+      src[i] = (plane ? Bl : Bh) + (int64_t)min(n0 + row, N - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
+      dst[i] = 2 * kASlots + plane * kBSlots + blk * 64;
     }
-    __builtin_amdgcn_sched_barrier(0);            // one tile column at a time: interleaving them spills
   }
+  auto issue = [&](int k0, int buf) {
+    uint4 *st = smem + buf * kStageSlots;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) glds16(src[i] + k0, st + dst[i]);
+  };
+
+  f16acc acc_m[2][2], acc_x[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_m[i][j][r] = 0.f; acc_x[i][j][r] = 0.f; }
+
+  const int frow = lane & 31, fh = lane >> 5;
+  int fa[2][2], fb[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i][s] = lds_slot(wm + 32 * i + frow, 2 * s + fh);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j][s] = 2 * kASlots + lds_slot(wn + 32 * j + frow, 2 * s + fh);
+  }
+
+  // fragments of one K half (16) of a stage: 8 ds_read_b128; the 12 MFMAs they feed
+  auto frags = [&](const uint4 *st, int s, h8 (&ah)[2], h8 (&al)[2], h8 (&bh)[2], h8 (&bl)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);
+      al[i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[i][s]]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[j] = *reinterpret_cast<const h8 *>(&st[fb[j][s]]);
+      bl[j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[j][s]]);
+    }
+  };
+  auto mfma12 = [&](const h8 (&ah)[2], const h8 (&al)[2], const h8 (&bh)[2], const h8 (&bl)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+      }
+  };
+
+  // Software pipeline.  The barrier of a stage sits BETWEEN its two K halves: the fragments of a half are requested one
+  // half ahead (under the 12 MFMAs before them), the DMA of stage kt + 3 is issued -- into the buffer of stage kt, which
+  // everybody has finished reading at that barrier -- under the second half's MFMAs.  No wavefront ever waits for LDS
+  // latency, and a stage's DMA has two and a half stages' time to land.
+  // (the loop is branch-free: past the last stage the DMA re-fetches the last stage into a buffer nobody reads any more,
+  //  so that every wait is the same counted `vmcnt(6)`)
+  const int KT = K / kBK, k_last = (KT - 1) * kBK;
+  issue(0, 0);
+  issue(min(kBK, k_last), 1);
+  issue(min(2 * kBK, k_last), 2);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  h8 p_ah[2], p_al[2], p_bh[2], p_bl[2];                              // first K half of the stage at hand
+  frags(smem, 0, p_ah, p_al, p_bh, p_bl);
+  int buf = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const uint4 *st = smem + buf * kStageSlots;
+    const int nbuf = buf == 2 ? 0 : buf + 1;
+    h8 q_ah[2], q_al[2], q_bh[2], q_bl[2];                            // second K half
+    frags(st, 1, q_ah, q_al, q_bh, q_bl);
+    mfma12(p_ah, p_al, p_bh, p_bl);
+#ifndef GVL_NO_SCHED_GROUPS
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
+    // stage kt + 1 has landed (this wavefront's part; the barrier makes it everybody's); stage kt + 2 stays in flight
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my reads of stage kt are complete
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(min((kt + 3) * kBK, k_last), buf);
+    frags(smem + nbuf * kStageSlots, 0, p_ah, p_al, p_bh, p_bl);     // (after the last stage: read, never used)
+    mfma12(q_ah, q_al, q_bh, q_bl);
+#ifndef GVL_NO_SCHED_GROUPS
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#endif
+    buf = nbuf;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  epilogue<2, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
 }
 
 // partials (chunks, R) of {max, sum exp(v - max), index, -} -> per row argmax and log-softmax at the argmax, plus the
-// bookkeeping of one greedy step (gvl_cap.hip: k_row_argmax_lse has the same tail).  Block = 32 rows x 8 chunk groups.
+// bookkeeping of one greedy step (gvl_cap.hip: k_row_argmax_lse has the same tail).  Block = 16 rows x 16 chunk groups:
+// 16 lanes read 256 contiguous bytes of one chunk row; 300 workgroups at R = 4800.
 struct GreedyBook {
   unsigned char *unfinished;
   int64_t *seq;
@@ -262,16 +460,18 @@ struct GreedyBook {
   int seq_ld, first;
 };
 
+constexpr int kRedRows = 16, kRedGroups = 16;
+
 __global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__restrict__ part, int R, int chunks,
                                                               int64_t *__restrict__ idx, float *__restrict__ logp,
                                                               GreedyBook book) {
-  __shared__ float s_m[8][32], s_s[8][32];
-  __shared__ int s_a[8][32];
-  const int rr = threadIdx.x & 31, g = threadIdx.x >> 5, row = blockIdx.x * 32 + rr;
+  __shared__ float s_m[kRedGroups][kRedRows], s_s[kRedGroups][kRedRows];
+  __shared__ int s_a[kRedGroups][kRedRows];
+  const int rr = threadIdx.x % kRedRows, g = threadIdx.x / kRedRows, row = blockIdx.x * kRedRows + rr;
   float m = -INFINITY, s = 0.f;
   int a = 0x7fffffff;
   if (row < R)
-    for (int c = g; c < chunks; c += 8) {
+    for (int c = g; c < chunks; c += kRedGroups) {
       const float4 p = part[(int64_t)c * R + row];
       const int pa = __float_as_int(p.z);
       const float mn = fmaxf(m, p.x);
@@ -283,7 +483,7 @@ __global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__re
   __syncthreads();
   if (g == 0 && row < R) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
+    for (int k = 1; k < kRedGroups; ++k) {
       const float m2 = s_m[k][rr], s2 = s_s[k][rr];
       const int a2 = s_a[k][rr];
       const float mn = fmaxf(m, m2);
@@ -314,11 +514,6 @@ int check_operands(const char *what, const void *a_hi, const void *a_lo, const f
   return 0;
 }
 
-int debug_flags() {
-  const char *e = getenv("GVL_GEMM16_DEBUG");
-  return e ? atoi(e) : 0;
-}
-
 }  // namespace
 
 extern "C" int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *lo, float *scale, void *stream) {
@@ -340,15 +535,18 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
   if (!out) return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: null pointer");
   const _Float16 *ah = (const _Float16 *)a_hi, *al = (const _Float16 *)a_lo, *bh = (const _Float16 *)b_hi,
                  *bl = (const _Float16 *)b_lo;
-  const int dbg = debug_flags();
-  // wide 128-column tiles when they fill the chip for several rounds, narrow ones otherwise
-  const int tiles_m = (R + kBM - 1) / kBM;
-  const bool wide = (int64_t)tiles_m * ((N + 127) / 128) >= 1536;
-  const int bn = wide ? 128 : 64, tiles_n = (N + bn - 1) / bn;
-  const dim3 grid((tiles_m * tiles_n + 7) / 8 * 8);
-  auto kern = wide ? k_gemm_f16x3<128, kStore> : k_gemm_f16x3<64, kStore>;
-  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", kern, grid, dim3(256), 0, (hipStream_t)stream, ah, al,
-                     a_scale, bh, bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, dbg);
+  // eight-wavefront 256 x 128 tiles when they fill the chip for several rounds, 128 x 64 tiles (three workgroups per CU)
+  // for the products with few rows / few tiles
+  if (R >= 1024 && (int64_t)((R + 255) / 256) * ((N + 127) / 128) >= 1024 && K >= 3 * kBK) {
+    const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
+    return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<4, 2, kStore>,
+                       dim3((tiles_m * tiles_n + 7) / 8 * 8), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl,
+                       b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
+  }
+  const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
+  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", k_gemm_f16x3<64, kStore>, dim3((tiles_m * tiles_n + 7) / 8 * 8),
+                     dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, b_scale, bias, R, N, K, out, ldo, tiles_m,
+                     tiles_n);
 }
 
 extern "C" int gvl_gemm_f16x3_argmax_chunks(int V) { return V > 0 ? (V + kBM - 1) / kBM * 2 : 0; }
@@ -359,12 +557,19 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   if (int rc = check_operands("gvl_gemm_f16x3_argmax_f32", x_hi, x_lo, x_scale, R, w_hi, w_lo, w_scale, V, K)) return rc;
   if (R == 0) return 0;
   if (!partials || ((uintptr_t)partials & 15)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_argmax_f32: partials null / unaligned");
-  const int tiles_m = (V + kBM - 1) / kBM, tiles_n = (R + 127) / 128;
-  const dim3 grid((tiles_m * tiles_n + 7) / 8 * 8);
-  return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3<argmax>", k_gemm_f16x3<128, kArgmax>, grid, dim3(256), 0,
-                     (hipStream_t)stream, (const _Float16 *)w_hi, (const _Float16 *)w_lo, w_scale, (const _Float16 *)x_hi,
-                     (const _Float16 *)x_lo, x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n,
-                     debug_flags());
+  const _Float16 *xh = (const _Float16 *)x_hi, *xl = (const _Float16 *)x_lo, *wh = (const _Float16 *)w_hi,
+                 *wl = (const _Float16 *)w_lo;
+  const int tiles_m = (V + kBM - 1) / kBM;                            // 128 vocabulary entries per tile, either form
+  if (R >= 1024 && K >= 3 * kBK) {
+    const int tiles_n = (R + 255) / 256;
+    return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", k_gemm_f16x3_w8<2, 4, kArgmax>,
+                       dim3((tiles_m * tiles_n + 7) / 8 * 8), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
+                       x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
+  }
+  const int tiles_n = (R + 63) / 64;
+  return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3<argmax>", k_gemm_f16x3<64, kArgmax>,
+                     dim3((tiles_m * tiles_n + 7) / 8 * 8), dim3(256), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
+                     x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
 }
 
 extern "C" int gvl_greedy_step_partials_f32(const float *partials, int R, int V, int first_step, int64_t *token,
@@ -375,7 +580,7 @@ extern "C" int gvl_greedy_step_partials_f32(const float *partials, int R, int V,
   if (!partials || !token || !logp || (unfinished && (!seq_col || !seq_lp_col)))
     return fail(GVL_EINVAL, "gvl_greedy_step_partials_f32: null pointer");
   const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0};
-  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_from_partials", k_greedy_from_partials, dim3((R + 31) / 32),
+  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_from_partials", k_greedy_from_partials, dim3((R + kRedRows - 1) / kRedRows),
                      dim3(256), 0, (hipStream_t)stream, (const float4 *)partials, R, gvl_gemm_f16x3_argmax_chunks(V), token,
                      logp, book);
 }

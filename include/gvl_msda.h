@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 6   /* 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 6   /* 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -146,6 +146,16 @@ int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const float *a_scale,
  *    first maximum, -} in partials (gvl_gemm_f16x3_argmax_chunks(V), R, 4) fp32 (16-byte aligned);
  *    gvl_greedy_step_partials_f32 reduces them to token (R) = argmax, logp (R) = log-softmax at the argmax and applies the
  *    bookkeeping of gvl_greedy_step_f32 (unfinished NULL = none).  Ties resolve to the lowest index, as torch.max. */
+/*    Producers that leave their result directly in that operand form (no gvl_split_rows_f16 pass over it):
+ *    gvl_cap_attend_split_f32 = gvl_cap_attend_f32 with att_res as planes + row scale (att_res itself is not written);
+ *    gvl_lstm_cell_split_f32 = gvl_lstm_cell_f32 that ALSO writes h' as planes (row scale 1: |h'| < 1 by construction). */
+int gvl_cap_attend_split_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                             const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
+                             const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
+                             int att_h_ld, void *att_hi, void *att_lo, float *att_scale, void *stream);
+int gvl_lstm_cell_split_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
+                            const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
+                            float *c_out, void *h_hi, void *h_lo, float *h_scale, void *stream);
 int gvl_gemm_f16x3_argmax_chunks(int V);
 int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, const float *x_scale, int R, const void *w_hi,
                               const void *w_lo, const float *w_scale, int V, int K, const float *bias, float *partials,

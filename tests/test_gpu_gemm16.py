@@ -138,3 +138,24 @@ def test_fused_argmax_ties_resolve_to_the_lowest_index():
     assert bool((tok == 7).all())
     ref = torch.log_softmax(x.double() @ w.double().t(), 1)[:, 7]
     assert float((lp.double() - ref).abs().max()) <= 1e-6
+
+
+def test_lstm_cell_leaves_its_hidden_state_as_planes():
+    """gvl_lstm_cell_split_f32: the same h', c' as gvl_lstm_cell_f32, h' additionally as planes with row scale 1"""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(2)
+    n, H, V = 333, 512, 50
+    ga, gb, gc = (torch.randn(n, 4 * H, device=dev, generator=g) for _ in range(3))
+    emb = torch.randn(V, 4 * H, device=dev, generator=g)
+    it = torch.randint(0, V, (n,), device=dev, generator=g)
+    c = torch.randn(n, H, device=dev, generator=g)
+    ga[7] *= 20.0                                                        # a saturated row: |h'| close to 1
+    gb[9] *= 1e-4; ga[9] *= 1e-4; gc[9] *= 1e-4; emb[int(it[9])] *= 1e-4; c[9] *= 1e-5   # a row of tiny values
+    h0, c0 = MSDA.lstm_cell(ga, gb, emb, it, c, gates_c=gc)
+    h1, c1 = MSDA.lstm_cell(ga, gb, emb, it, c, gates_c=gc, planes=True)
+    assert torch.equal(h0, h1) and torch.equal(c0, c1)
+    p = h1._gvl_planes
+    assert bool((p.scale == 1.0).all()) and float(p.hi.abs().max()) <= 1.0
+    back = p.hi.double() + p.lo.double() / 2048.0
+    assert bool(((back - h1.double()).abs() <= 2.0 ** -22 * h1.abs().double() + 2.0 ** -34).all())

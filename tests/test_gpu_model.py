@@ -170,6 +170,13 @@ def test_cap_attend_kernel_matches_unfused_reference_order():
         assert maxerr(gl, x.reshape(B * Q, L * P)) < 1e-4
         assert maxerr(ga, alpha) < 1e-4
         assert maxerr(got, want) < 1e-4
+        # the same result left as the fp16 planes + row scale of gvl_gemm_f16x3_f32 (gvl_cap_attend_split_f32)
+        pl = MSDA.cap_attend(slab, shapes2d, lsi_d, ref.contiguous().to(dev), off_hs, h.to(dev),
+                             Wo[:, :C].contiguous().to(dev), torch.nn.functional.linear(h, Wh, bh).to(dev), aw.to(dev),
+                             ab, L, P, planes=True)
+        back = pl.scale.double()[:, None] * (pl.hi.double() + pl.lo.double() / 2048.0)
+        rowmax = got.abs().amax(1, keepdim=True).double()
+        assert bool(((back - got.double()).abs() <= 2.0 ** -22 * got.abs().double() + 2.0 ** -34 * rowmax).all())
 
 
 def test_row_argmax_lse_matches_torch():
