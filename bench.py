@@ -146,6 +146,7 @@ def kernel_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20, backward=False):
             "note": "back-to-back launches on synthetic operands after the timed region"}
 
 
+F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA peak (no xf32 / TF32 on gfx950)
 
 
@@ -417,6 +418,23 @@ def main():
             graphed_eval.graphs.clear()
         del step, graphed_eval
         torch.cuda.empty_cache()
+        # A/B of the same step with the token loop's three products on the fp32 library GEMMs (GVL_GEMM=f32) instead of
+        # gvl_gemm_f16x3 (fp32 operands split exactly into fp16 pairs, fp16 MFMA, fp32 accumulation): reported beside
+        # `value`, never as `value`
+        from gvl_amd.linear import split_gemm_enabled
+        if (split_gemm_enabled() and a.dtype == "f32" and not a.no_graph and not a.no_captioner and not a.no_probes):
+            os.environ["GVL_GEMM"] = "f32"
+            try:
+                g2 = GraphedEvalForward(model, criterion, autocast_dtype=ac, decode_chunk=a.decode_chunk)
+                for dt in batches:
+                    g2(dt)
+                el2, _ = timed_loop(g2, batches, a.steps, a.warmup, world, dev)
+                res["eval"]["fp32_library_gemms_elapsed"] = el2
+                g2.graphs.clear()
+                del g2
+            finally:
+                del os.environ["GVL_GEMM"]
+            torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------------------------------------- train half
     if a.mode in ("both", "train"):
@@ -507,16 +525,25 @@ def main():
                 + ", set criterion + Hungarian matcher; "
                 + ("one fixed batch, 3 events per video" if a.fixed_layout else
                    f"{len(batches)} rotating batches with 0-10 events per video and 3-20-word captions"))
+    from gvl_amd.linear import split_gemm_enabled as _sge
+    gemm16_on = _sge() and a.dtype == "f32"
     line = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.dtype == "f32" else "bf16 storage + bf16 GEMMs, f32 accumulate / locations / captioner",
             "data": "synthetic",
             "config": {"workload": workload,
                        "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
+                       "token_loop_gemms": ("gvl_gemm_f16x3: fp32 operands split exactly into fp16 (hi, 2^11 residual) "
+                                            "pairs, 3 fp16-MFMA partial products, fp32 accumulation -- error vs fp64 "
+                                            "below the fp32 GEMM's (tests/test_gpu_gemm16.py); vocabulary argmax / "
+                                            "log-sum-exp fused into the GEMM") if gemm16_on else "hipBLASLt fp32",
                        "global_batch": world * B,
                        "parallelism": f"dp{world} (videos sharded; eval: no data-path collective, train: RCCL gradient "
                                       f"all-reduce)"},
             "rccl_ranks": world if (world > 1 and backend == "nccl") else (0 if world == 1 else f"{world} ({backend})")}
     kernels_us = {}
+
+    def ktag(k):                         # (kernel, meta_a, meta_b): the GEMM launches differ in meta_b (N) only
+        return f"{k[0]}[{k[1]}x{k[2]}]" if k[0] == "gemm_f16x3" else f"{k[0]}[{k[1]}]"
     if "eval" in res:
         e = res["eval"]
         ms = e["elapsed"] * 1e3 / a.steps
@@ -524,15 +551,21 @@ def main():
                      "unit": "videos/s", "ms_per_step": round(ms, 3), "higher_is_better": True,
                      "roofline": fwd_roofline(e["ktimes"]), "eval_graphs": e["graphs"],
                      "eval_seconds_per_rank": [round(x, 4) for x in e["per_rank"]]})
-        kernels_us["eval"] = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in e["ktimes"].items()
+        kernels_us["eval"] = {ktag(k): {"us": round(v[0], 2), "n": v[1]} for k, v in e["ktimes"].items()
                               if not k[0].startswith("fwd_")}
+        if "fp32_library_gemms_elapsed" in e:
+            e2 = e["fp32_library_gemms_elapsed"]
+            line["eval_with_fp32_library_gemms"] = {
+                "value": round(world * B * a.steps / e2, 3), "unit": "videos/s", "ms_per_step": round(e2 * 1e3 / a.steps, 3),
+                "note": "the same step with GVL_GEMM=f32: the captioner's three token-loop products on hipBLASLt fp32 "
+                        "GEMMs + gvl_greedy_step_f32 over written logits (round 2's path until gvl_gemm_f16x3)"}
     if "train" in res:
         t_ = res["train"]
         ms = t_["elapsed"] * 1e3 / a.steps
         line.update({"train_step_ms": round(ms, 3), "train_videos_per_s": round(world * B * a.steps / t_["elapsed"], 3),
                      "train_roofline": bwd_roofline(t_["ktimes"]), "train_graphs": t_["graphs"],
                      "train_seconds_per_rank": [round(x, 4) for x in t_["per_rank"]]})
-        kernels_us["train"] = {f"{k[0]}[{k[1]}]": {"us": round(v[0], 2), "n": v[1]} for k, v in t_["ktimes"].items()}
+        kernels_us["train"] = {ktag(k): {"us": round(v[0], 2), "n": v[1]} for k, v in t_["ktimes"].items()}
         if "eval" not in res:
             line.update({"metric": "train-step ms", "value": round(ms, 3), "unit": "ms", "ms_per_step": round(ms, 3),
                          "higher_is_better": False, "roofline": line["train_roofline"]})
@@ -545,7 +578,23 @@ def main():
         line["train_roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries, backward=True)
     if rank == 0 and "eval" in res and not a.no_captioner and a.dtype == "f32" and not a.no_probes:
         with torch.no_grad():
-            line["dominant_library_gemm"] = gemm_probe(model, dev, B * a.queries)
+            lib = gemm_probe(model, dev, B * a.queries)
+        head = model.caption_head[-1]
+        V, Kd, rows = head.logit.weight.shape[0], head.logit.weight.shape[1], B * a.queries
+        mine = [v for k, v in res["eval"]["ktimes"].items() if k[0] == "gemm_f16x3" and k[2] == V]
+        if gemm16_on and mine:
+            us = mine[0][0]
+            tf16 = 3 * 2.0 * rows * V * Kd / (us * 1e-6) / 1e12
+            line["dominant_gemm"] = {
+                "kernel": f"k_gemm_f16x3_w8<argmax> {rows}x{Kd}x{V} (vocabulary product of every token step, argmax / "
+                          f"log-sum-exp fused, logits never written), hand-written",
+                "bound": "mfma", "achieved": round(tf16, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, 3 "
+                "partial products per fp32 product)", "frac": round(tf16 / F16_MFMA_PEAK_TFLOPS, 4),
+                "fp32_equivalent_tflops": round(tf16 / 3, 1), "kernel_us": round(us, 1), "launches_timed": mine[0][1],
+                "source": "in-library stamps of two instrumented eager steps after the timed region",
+                "fp32_library_gemm_same_shape": lib}
+        else:
+            line["dominant_library_gemm"] = lib
     if rank == 0 and world == 1 and not a.no_cpu_baseline and "eval" in res:
         line["cpu_baseline"] = cpu_baseline(model, opt, a.T)
     if rank == 0:
