@@ -31,6 +31,7 @@
 //   workgroups resident on one XCD share 2 MB + 2 MB of operand planes in its 4 MB L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gvl_common.hpp"
 #include "gvl_msda.h"
@@ -167,23 +168,72 @@ __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)
   const float *bias_p = bias ? bias : As;
   const float bias_on = bias ? 1.f : 0.f;
   const int bias_ix = bias ? 0x7fffffff : 0;
-  // The row scales (and, for kArgmax, the per-row bias) of this lane's 32 rows are read ONCE, before anything is stored:
-  // a load between two stores makes the compiler wait vmcnt(0) for it, i.e. for every store issued so far
-  float rs[2][16], rb[2][16];
+  if constexpr (EPI == kArgmax) {
+    // scaled, biased values in place (acc_m), one 32-row block at a time: 32 registers of row scale / bias live, and the
+    // cross-term accumulators are dead afterwards
+    float cs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cs[j] = Bs[min(col0 + 32 * j + frow, N - 1)];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float rs[16], rb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rc = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
+        rs[r] = As[rc];
+        rb[r] = bias_on * bias_p[min(rc, bias_ix)];
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc_m[i][j][r] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[r] * cs[j]) + rb[r];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = col0 + 32 * j + frow;
+      float best = -INFINITY, sum = 0.f;
+      int arg = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (row < R && acc_m[i][j][r] > best) { best = acc_m[i][j][r]; arg = row; }   // rows ascend: first maximum
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (row < R) sum += __expf(acc_m[i][j][r] - best);
+        }
+      // the lane 32 further holds the other half of this column's 64 rows
+      const float b2 = __shfl_xor(best, 32), s2 = __shfl_xor(sum, 32);
+      const int a2 = __shfl_xor(arg, 32);
+      const float bn = fmaxf(best, b2);
+      if (bn > -INFINITY) sum = sum * __expf(best - bn) + s2 * __expf(b2 - bn);        // exp(-inf) = 0 for an empty half
+      arg = (b2 > best || (b2 == best && a2 < arg)) ? a2 : arg;
+      if (fh == 0 && col < N)
+        reinterpret_cast<float4 *>(out)[(int64_t)(row0 >> 6) * N + col] = make_float4(bn, sum, __int_as_float(arg), 0.f);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  // kStore: the row scales of this lane's 32 rows are read ONCE, before anything is stored: a load between two stores
+  // makes the compiler wait vmcnt(0) for it, i.e. for every store issued so far
+  float rs[2][16];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rc = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
-      rs[i][r] = As[rc];
-      if constexpr (EPI == kArgmax) rb[i][r] = bias_on * bias_p[min(rc, bias_ix)];
-    }
+    for (int r = 0; r < 16; ++r) rs[i][r] = As[min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1)];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int col = col0 + 32 * j + frow;
     const bool col_ok = col < N;
     const float cs = col_ok ? Bs[col] : 0.f;
-    if constexpr (EPI == kStore) {
+    {
       const float cb = bias_on * bias_p[min(min(col, N - 1), bias_ix)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -193,35 +243,7 @@ __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)
           if (col_ok && row < R)
             out[(int64_t)row * ldo + col] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[i][r] * cs) + cb;
         }
-    } else {
-      // two passes over the lane's 32 values of this column (recomputed, not kept: registers): maximum, then the sum
-      float best = -INFINITY, sum = 0.f;
-      int arg = 0x7fffffff;
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const float v = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[i][r] * cs) + rb[i][r];
-            if (pass == 0) {
-              if (row < R && v > best) { best = v; arg = row; }            // rows ascend: the first maximum is kept
-            } else if (row < R) {
-              sum += __expf(v - best);
-            }
-          }
-      }
-      // the lane 32 further holds the other half of this column's 64 rows
-      const float b2 = __shfl_xor(best, 32), s2 = __shfl_xor(sum, 32);
-      const int a2 = __shfl_xor(arg, 32);
-      const float bn = fmaxf(best, b2);
-      if (bn > -INFINITY) sum = sum * __expf(best - bn) + s2 * __expf(b2 - bn);        // exp(-inf) = 0 for an empty half
-      arg = (b2 > best || (b2 == best && a2 < arg)) ? a2 : arg;
-      if (fh == 0 && col_ok)
-        reinterpret_cast<float4 *>(out)[(int64_t)(row0 >> 6) * N + col] = make_float4(bn, sum, __int_as_float(arg), 0.f);
     }
-    __builtin_amdgcn_sched_barrier(0);            // one tile column at a time: interleaving them spills
   }
 }
 
@@ -326,32 +348,40 @@ __global__ void __launch_bounds__(512, 1)
   constexpr int NG = WM + WN;                                         // DMA instructions per wavefront and stage
   __shared__ uint4 smem[3 * kStageSlots];
 
-  int tm, tn;
-  if (!tile_of((int)blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
-  const int m0 = tm * kRowsA, n0 = tn * kRowsB;
+  // PERSISTENT workgroups: workgroup b takes the tiles b, b + gridDim, ... of the XCD-grouped order, and the stage
+  // stream runs on across tile boundaries -- the DMA of the next tile's first three stages is issued under the last
+  // MFMAs of the current tile and lands during its epilogue (one workgroup per CU: nobody else would fill that gap).
+  int vb = (int)blockIdx.x, tm, tn;
+  if (!tile_of(vb, tiles_m, tiles_n, tm, tn)) return;
+  int m0 = tm * kRowsA, n0 = tn * kRowsB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave % WM) * 64, wn = (wave / WM) * 64;
 
-  // DMA units of 16 rows: unit q = wave + 8 i; i < WM -> A (plane q / (4 WM), block q % (4 WM)), else B likewise
-  const int srow = lane >> 2, spos = lane & 3;
-  const _Float16 *src[NG];
-  int dst[NG];
+  // DMA units of 16 rows: unit q = wave + 8 i; i < WM -> A (plane q / (4 WM), block q % (4 WM)), else B likewise.  Per
+  // unit everything but the lane's row inside the block is wave-uniform (plane base, LDS slot, first row); the swizzled
+  // chunk depends on the lane only ((row >> 2) & 3 == (srow >> 2) & 3: blocks start at multiples of 16 rows), so a
+  // stage's source addresses are rebuilt from two lane registers whenever it is issued -- nothing per-tile is kept live.
+  const int srow = lane >> 2, schunk = ((lane & 3) ^ ((srow >> 2) & 3)) * 8;
+  const _Float16 *base[NG];
+  int dst[NG], blk16[NG];
 #pragma unroll
   for (int i = 0; i < NG; ++i) {
-    if (i < WM) {
-      const int q = wave + 8 * i, plane = q / (4 * WM), blk = q % (4 * WM), row = blk * 16 + srow;
-      src[i] = (plane ? Al : Ah) + (int64_t)min(m0 + row, R - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
-      dst[i] = plane * kASlots + blk * 64;
-    } else {
-      const int q = wave + 8 * (i - WM), plane = q / (4 * WN), blk = q % (4 * WN), row = blk * 16 + srow;
-      src[i] = (plane ? Bl : Bh) + (int64_t)min(n0 + row, N - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
-      dst[i] = 2 * kASlots + plane * kBSlots + blk * 64;
-    }
+    const int per_plane = 4 * (i < WM ? WM : WN), q = wave + 8 * (i < WM ? i : i - WM);
+    const int plane = __builtin_amdgcn_readfirstlane(q / per_plane), blk = __builtin_amdgcn_readfirstlane(q % per_plane);
+    blk16[i] = blk * 16;
+    base[i] = i < WM ? (plane ? Al : Ah) : (plane ? Bl : Bh);
+    dst[i] = (i < WM ? plane * kASlots : 2 * kASlots + plane * kBSlots) + blk * 64;
   }
-  auto issue = [&](int k0, int buf) {
+  int tm2, tn2;
+  bool has_next = tile_of(vb + (int)gridDim.x, tiles_m, tiles_n, tm2, tn2);
+  if (!has_next) { tm2 = tm; tn2 = tn; }
+  auto issue = [&](int tm_, int tn_, int k0, int buf) {
     uint4 *st = smem + buf * kStageSlots;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) glds16(src[i] + k0, st + dst[i]);
+    for (int i = 0; i < NG; ++i) {
+      const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
+      glds16(base[i] + (row * K + schunk + k0), st + dst[i]);
+    }
   };
 
   f16acc acc_m[2][2], acc_x[2][2];
@@ -363,26 +393,26 @@ __global__ void __launch_bounds__(512, 1)
       for (int r = 0; r < 16; ++r) { acc_m[i][j][r] = 0.f; acc_x[i][j][r] = 0.f; }
 
   const int frow = lane & 31, fh = lane >> 5;
-  int fa[2][2], fb[2][2];
+  // fragment slots: one register per operand and K half; the second 32-row block is 128 slots further (same swizzle
+  // term: (row + 32) >> 2 has the same low bits), an immediate offset of the ds_read
+  int fa[2], fb[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i][s] = lds_slot(wm + 32 * i + frow, 2 * s + fh);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j][s] = 2 * kASlots + lds_slot(wn + 32 * j + frow, 2 * s + fh);
+    fa[s] = lds_slot(wm + frow, 2 * s + fh);
+    fb[s] = 2 * kASlots + lds_slot(wn + frow, 2 * s + fh);
   }
 
   // fragments of one K half (16) of a stage: 8 ds_read_b128; the 12 MFMAs they feed
   auto frags = [&](const uint4 *st, int s, h8 (&ah)[2], h8 (&al)[2], h8 (&bh)[2], h8 (&bl)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ah[i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);
-      al[i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[i][s]]);
+      ah[i] = *reinterpret_cast<const h8 *>(&st[fa[s] + 128 * i]);
+      al[i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[s] + 128 * i]);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bh[j] = *reinterpret_cast<const h8 *>(&st[fb[j][s]]);
-      bl[j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[j][s]]);
+      bh[j] = *reinterpret_cast<const h8 *>(&st[fb[s] + 128 * j]);
+      bl[j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[s] + 128 * j]);
     }
   };
   auto mfma12 = [&](const h8 (&ah)[2], const h8 (&al)[2], const h8 (&bh)[2], const h8 (&bl)[2]) {
@@ -397,22 +427,22 @@ __global__ void __launch_bounds__(512, 1)
   };
 
   // Software pipeline.  The barrier of a stage sits BETWEEN its two K halves: the fragments of a half are requested one
-  // half ahead (under the 12 MFMAs before them), the DMA of stage kt + 3 is issued -- into the buffer of stage kt, which
-  // everybody has finished reading at that barrier -- under the second half's MFMAs.  No wavefront ever waits for LDS
-  // latency, and a stage's DMA has two and a half stages' time to land.
-  // (the loop is branch-free: past the last stage the DMA re-fetches the last stage into a buffer nobody reads any more,
-  //  so that every wait is the same counted `vmcnt(6)`)
-  const int KT = K / kBK, k_last = (KT - 1) * kBK;
-  issue(0, 0);
-  issue(min(kBK, k_last), 1);
-  issue(min(2 * kBK, k_last), 2);
+  // half ahead (under the 12 MFMAs before them), the DMA of the stage three ahead is issued -- into the buffer of the
+  // current stage, which everybody has finished reading at that barrier -- under the second half's MFMAs.  No wavefront
+  // ever waits for LDS latency, and a stage's DMA has two and a half stages' time to land.  Every wait is the same
+  // counted `vmcnt(6)` (stores of an epilogue in between are younger than the stage waited for: the wait only becomes
+  // conservative); past the last tile the DMA re-fetches into buffers nobody reads any more.
+  const int KT = K / kBK;                                             // >= 3 (host)
+  issue(tm, tn, 0, 0);
+  issue(tm, tn, kBK, 1);
+  issue(tm, tn, 2 * kBK, 2);
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   h8 p_ah[2], p_al[2], p_bh[2], p_bl[2];                              // first K half of the stage at hand
   frags(smem, 0, p_ah, p_al, p_bh, p_bl);
-  int buf = 0;
-  for (int kt = 0; kt < KT; ++kt) {
+  int buf = 0, kt = 0;
+  for (;;) {
     const uint4 *st = smem + buf * kStageSlots;
     const int nbuf = buf == 2 ? 0 : buf + 1;
     h8 q_ah[2], q_al[2], q_bh[2], q_bl[2];                            // second K half
@@ -426,13 +456,16 @@ __global__ void __launch_bounds__(512, 1)
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #endif
-    // stage kt + 1 has landed (this wavefront's part; the barrier makes it everybody's); stage kt + 2 stays in flight
+    // the next stage has landed (this wavefront's part; the barrier makes it everybody's); the one after stays in flight
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my reads of stage kt are complete
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my reads of this stage are complete
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(min((kt + 3) * kBK, k_last), buf);
-    frags(smem + nbuf * kStageSlots, 0, p_ah, p_al, p_bh, p_bl);     // (after the last stage: read, never used)
+    {
+      const bool over = kt + 3 >= KT;                                 // the stage three ahead belongs to the next tile
+      issue(over ? tm2 : tm, over ? tn2 : tn, (over ? kt + 3 - KT : kt + 3) * kBK, buf);
+    }
+    frags(smem + nbuf * kStageSlots, 0, p_ah, p_al, p_bh, p_bl);     // (stage 0 of the next tile at a tile's end)
     mfma12(q_ah, q_al, q_bh, q_bl);
 #ifndef GVL_NO_SCHED_GROUPS
 #pragma unroll
@@ -445,9 +478,29 @@ __global__ void __launch_bounds__(512, 1)
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #endif
     buf = nbuf;
+    if (++kt == KT) {
+      epilogue<2, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
+      if (!has_next) break;
+      kt = 0;
+      vb += (int)gridDim.x;
+      tm = tm2;
+      tn = tn2;
+      m0 = tm * kRowsA;
+      n0 = tn * kRowsB;
+      has_next = tile_of(vb + (int)gridDim.x, tiles_m, tiles_n, tm2, tn2);
+      if (!has_next) { tm2 = tm; tn2 = tn; }
+      // the first half of the new tile's stage 0 is read again here rather than kept across the epilogue (32 registers
+      // that the epilogue needs: keeping them spilled fragments inside the MFMA loop)
+      frags(smem + buf * kStageSlots, 0, p_ah, p_al, p_bh, p_bl);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc_m[i][j][r] = 0.f; acc_x[i][j][r] = 0.f; }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  epilogue<2, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
 }
 
 // partials (chunks, R) of {max, sum exp(v - max), index, -} -> per row argmax and log-softmax at the argmax, plus the
@@ -503,6 +556,21 @@ __global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__re
   }
 }
 
+// one persistent workgroup per CU for the eight-wavefront kernel (144 KB of LDS each)
+int persistent_grid(int tiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n / 8 * 8 > 0 ? n / 8 * 8 : 8;
+  }
+  const char *e = getenv("GVL_GEMM16_GRID");                          // (experiments: 0 = one workgroup per tile)
+  const int padded = (tiles + 7) / 8 * 8;
+  if (e && atoi(e) == 0) return padded;
+  return padded < cus ? padded : cus;
+}
+
 int check_operands(const char *what, const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi,
                    const void *b_lo, const float *b_scale, int N, int K) {
   if (R < 0 || N <= 0 || K <= 0 || (K % kBK))
@@ -540,7 +608,7 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
   if (R >= 1024 && (int64_t)((R + 255) / 256) * ((N + 127) / 128) >= 1024 && K >= 3 * kBK) {
     const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
     return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<4, 2, kStore>,
-                       dim3((tiles_m * tiles_n + 7) / 8 * 8), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl,
+                       dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl,
                        b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
   }
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
@@ -563,7 +631,7 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   if (R >= 1024 && K >= 3 * kBK) {
     const int tiles_n = (R + 255) / 256;
     return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", k_gemm_f16x3_w8<2, 4, kArgmax>,
-                       dim3((tiles_m * tiles_n + 7) / 8 * 8), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
+                       dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
                        x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
   }
   const int tiles_n = (R + 63) / 64;
