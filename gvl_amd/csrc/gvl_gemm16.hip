@@ -336,16 +336,17 @@ __global__ void __launch_bounds__(256, 2)
 // bytes per FLOP.  One barrier per stage: counted `s_waitcnt vmcnt` (this wavefront's DMA of the stage about to be read
 // is complete, the next stage's stays in flight), raw s_barrier (everybody's is, and everybody has finished reading the
 // buffer that is refilled next), then the DMA of stage kt + 2, then the MFMAs of stage kt.
-template <int WM, int WN, int EPI>
+template <int WM, int WN, int NJ, int EPI>
 __global__ void __launch_bounds__(512, 1)
     k_gemm_f16x3_w8(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                     const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
                     const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo,
                     int tiles_m, int tiles_n) {
   static_assert(WM * WN == 8, "eight wavefronts");
-  constexpr int kRowsA = 64 * WM, kRowsB = 64 * WN;
+  constexpr int kRowsA = 64 * WM, kRowsB = 32 * NJ * WN;             // wavefront tile 64 x 32 NJ
   constexpr int kASlots = kRowsA * 4, kBSlots = kRowsB * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
-  constexpr int NG = WM + WN;                                         // DMA instructions per wavefront and stage
+  constexpr int NGB = kRowsB / 64, NG = WM + NGB;                     // DMA instructions per wavefront and stage
+  static_assert(NG == 6 || NG == 4, "the counted waits below are written for 6 or 4 DMA instructions per stage");
   __shared__ uint4 smem[3 * kStageSlots];
 
   // PERSISTENT workgroups: workgroup b takes the tiles b, b + gridDim, ... of the XCD-grouped order, and the stage
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(512, 1)
   if (!tile_of(vb, tiles_m, tiles_n, tm, tn)) return;
   int m0 = tm * kRowsA, n0 = tn * kRowsB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave % WM) * 64, wn = (wave / WM) * 64;
+  const int wm = (wave % WM) * 64, wn = (wave / WM) * (32 * NJ);
 
   // DMA units of 16 rows: unit q = wave + 8 i; i < WM -> A (plane q / (4 WM), block q % (4 WM)), else B likewise.  Per
   // unit everything but the lane's row inside the block is wave-uniform (plane base, LDS slot, first row); the swizzled
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(512, 1)
   int dst[NG], blk16[NG];
 #pragma unroll
   for (int i = 0; i < NG; ++i) {
-    const int per_plane = 4 * (i < WM ? WM : WN), q = wave + 8 * (i < WM ? i : i - WM);
+    const int per_plane = i < WM ? 4 * WM : kRowsB / 16, q = wave + 8 * (i < WM ? i : i - WM);
     const int plane = __builtin_amdgcn_readfirstlane(q / per_plane), blk = __builtin_amdgcn_readfirstlane(q % per_plane);
     blk16[i] = blk * 16;
     base[i] = i < WM ? (plane ? Al : Ah) : (plane ? Bl : Bh);
@@ -384,11 +385,11 @@ __global__ void __launch_bounds__(512, 1)
     }
   };
 
-  f16acc acc_m[2][2], acc_x[2][2];
+  f16acc acc_m[2][NJ], acc_x[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc_m[i][j][r] = 0.f; acc_x[i][j][r] = 0.f; }
 
@@ -403,23 +404,23 @@ __global__ void __launch_bounds__(512, 1)
   }
 
   // fragments of one K half (16) of a stage: 8 ds_read_b128; the 12 MFMAs they feed
-  auto frags = [&](const uint4 *st, int s, h8 (&ah)[2], h8 (&al)[2], h8 (&bh)[2], h8 (&bl)[2]) {
+  auto frags = [&](const uint4 *st, int s, h8 (&ah)[2], h8 (&al)[2], h8 (&bh)[NJ], h8 (&bl)[NJ]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const h8 *>(&st[fa[s] + 128 * i]);
       al[i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[s] + 128 * i]);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       bh[j] = *reinterpret_cast<const h8 *>(&st[fb[s] + 128 * j]);
       bl[j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[s] + 128 * j]);
     }
   };
-  auto mfma12 = [&](const h8 (&ah)[2], const h8 (&al)[2], const h8 (&bh)[2], const h8 (&bl)[2]) {
+  auto mfma12 = [&](const h8 (&ah)[2], const h8 (&al)[2], const h8 (&bh)[NJ], const h8 (&bl)[NJ]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
         acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
         acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
@@ -436,28 +437,31 @@ __global__ void __launch_bounds__(512, 1)
   issue(tm, tn, 0, 0);
   issue(tm, tn, kBK, 1);
   issue(tm, tn, 2 * kBK, 2);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  h8 p_ah[2], p_al[2], p_bh[2], p_bl[2];                              // first K half of the stage at hand
+  h8 p_ah[2], p_al[2], p_bh[NJ], p_bl[NJ];                            // first K half of the stage at hand
   frags(smem, 0, p_ah, p_al, p_bh, p_bl);
   int buf = 0, kt = 0;
   for (;;) {
     const uint4 *st = smem + buf * kStageSlots;
     const int nbuf = buf == 2 ? 0 : buf + 1;
-    h8 q_ah[2], q_al[2], q_bh[2], q_bl[2];                            // second K half
+    h8 q_ah[2], q_al[2], q_bh[NJ], q_bl[NJ];                          // second K half
     frags(st, 1, q_ah, q_al, q_bh, q_bl);
     mfma12(p_ah, p_al, p_bh, p_bl);
 #ifndef GVL_NO_SCHED_GROUPS
+    // (4 + 2 NJ) fragment reads of the next half between the 6 NJ MFMAs of this one
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 4 + 2 * NJ; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if constexpr (NJ == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #endif
     // the next stage has landed (this wavefront's part; the barrier makes it everybody's); the one after stays in flight
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my reads of this stage are complete
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -468,18 +472,32 @@ __global__ void __launch_bounds__(512, 1)
     frags(smem + nbuf * kStageSlots, 0, p_ah, p_al, p_bh, p_bl);     // (stage 0 of the next tile at a tile's end)
     mfma12(q_ah, q_al, q_bh, q_bl);
 #ifndef GVL_NO_SCHED_GROUPS
+    if constexpr (NJ == 2) {                                           // 6 DMA, 8 reads, 12 MFMAs
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      for (int g = 0; g < 6; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    } else {                                                           // 4 DMA, 6 reads, 6 MFMAs
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #endif
     buf = nbuf;
     if (++kt == KT) {
-      epilogue<2, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
+      epilogue<NJ, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
       if (!has_next) break;
       kt = 0;
       vb += (int)gridDim.x;
@@ -495,7 +513,7 @@ __global__ void __launch_bounds__(512, 1)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) { acc_m[i][j][r] = 0.f; acc_x[i][j][r] = 0.f; }
     }
@@ -603,13 +621,24 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
   if (!out) return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: null pointer");
   const _Float16 *ah = (const _Float16 *)a_hi, *al = (const _Float16 *)a_lo, *bh = (const _Float16 *)b_hi,
                  *bl = (const _Float16 *)b_lo;
-  // eight-wavefront 256 x 128 tiles when they fill the chip for several rounds, 128 x 64 tiles (three workgroups per CU)
-  // for the products with few rows / few tiles
-  if (R >= 1024 && (int64_t)((R + 255) / 256) * ((N + 127) / 128) >= 1024 && K >= 3 * kBK) {
-    const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
-    return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<4, 2, kStore>,
-                       dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl,
-                       b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
+  // Eight-wavefront persistent kernel: 256 x 128 tiles when they fill the chip for several rounds, 128 x 128 tiles
+  // (wavefront tile 64 x 32) for fewer -- 760 / 608 tiles over 256 CUs are 3 rounds of a half-size tile where the large
+  // tile has 2 rounds of a full one.  128 x 64 tiles on the four-wavefront kernel (three workgroups per CU) for the
+  // products with few rows.
+  if (R >= 1024 && K >= 3 * kBK) {
+    const int t_big = ((R + 255) / 256) * ((N + 127) / 128), t_mid = ((R + 127) / 128) * ((N + 127) / 128);
+    if (t_big >= 1024) {
+      const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<4, 2, 2, kStore>,
+                         dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
+                         bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
+    }
+    if (t_mid >= 384 && !getenv("GVL_GEMM16_NO_MID")) {
+      const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<2, 4, 1, kStore>,
+                         dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
+                         bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
+    }
   }
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
   return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", k_gemm_f16x3<64, kStore>, dim3((tiles_m * tiles_n + 7) / 8 * 8),
@@ -630,7 +659,7 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   const int tiles_m = (V + kBM - 1) / kBM;                            // 128 vocabulary entries per tile, either form
   if (R >= 1024 && K >= 3 * kBK) {
     const int tiles_n = (R + 255) / 256;
-    return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", k_gemm_f16x3_w8<2, 4, kArgmax>,
+    return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", k_gemm_f16x3_w8<2, 4, 2, kArgmax>,
                        dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
                        x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
   }
