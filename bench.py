@@ -98,11 +98,20 @@ def msda_bwd_bytes(B, S, Q, M=8, L=4, P=4, C=512, value_bytes=4):
 
 
 def kernel_times(entries):
-    """group the in-library dispatch timings (gvl_prof_collect) by (kernel, meta_a, meta_b) -> (mean us, count)"""
+    """group the in-library dispatch timings (gvl_prof_collect) by (kernel, meta_a, meta_b) -> (median us, count, mean us).
+    The MEDIAN is what the roofline blocks use: of a dozen event-stamped eager launches of one kernel one or two read
+    1.3-2x the others (tools/fwd_insitu_samples.py: 9.8 10.1 9.7 10.0 19.0 15.4 9.9 ... us) -- an artefact of stamping
+    eager launches (the rocprofv3 trace of the replayed graph, profiles/r02_msda_launches_in_graph.txt, shows a mean within
+    5 % of its minimum) -- and with a handful of samples such a reading moves the mean by 20 %."""
     acc = {}
     for tag, ma, mb, us in entries:
         acc.setdefault((tag, ma, mb), []).append(us)
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    out = {}
+    for k, v in acc.items():
+        w = sorted(v)
+        med = w[len(w) // 2] if len(w) % 2 else 0.5 * (w[len(w) // 2 - 1] + w[len(w) // 2])
+        out[k] = (med, len(v), sum(v) / len(v))
+    return out
 
 
 def kernel_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20, backward=False):
@@ -370,7 +379,7 @@ def main():
                 return None, f"{PMC_FILE} is stale (collected for kernel source {table.get('kernel_source_sha16')}, now {sha})"
         return None, None
 
-    def instrumented(fn, n=2):
+    def instrumented(fn, n=6):
         """kernel stamps of `n` eager steps run right after a timed region whose steps were graph replays (the library
         launches nothing at replay time)"""
         MSDA.profile_enable(True)
@@ -471,24 +480,26 @@ def main():
 
     # ---------------------------------------------------------------------------------------------- the line
     src_note = ("per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region" if a.no_graph
-                else "two instrumented eager steps right after the timed region (timed steps are hipGraph replays)")
+                else "median over six instrumented eager steps right after the timed region (timed steps are hipGraph replays); "
+                     "kernel_us_mean = the plain mean of the same launches")
 
     def fwd_roofline(ktimes):
         fwd = {k: v for k, v in ktimes.items() if k[0] in ("fwd_t1d_d64", "fwd_generic")}
         dec_key = next((k for k in fwd if k[1] == a.queries and k[2] == B), None)
         if dec_key is None:
             return None
-        us, n = fwd[dec_key]
+        us, n, us_mean = fwd[dec_key]
         nbytes = msda_bytes(B, S, a.queries, value_bytes=vb)
         achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
         traffic, traffic_src = traffic_of("k_fwd_t1d_d64_fused_dec")
         roof = {"bound": "hbm", "kernel": f"k_{dec_key[0]} (decoder cross-attention launch, Lq={a.queries})",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK_TBS * 1e3), 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_us": round(us, 2), "launches_timed": n, "algorithmic_bytes": nbytes, "source": src_note}
+                "kernel_us": round(us, 2), "kernel_us_mean": round(us_mean, 2), "launches_timed": n,
+                "algorithmic_bytes": nbytes, "source": src_note}
         enc_key = next((k for k in fwd if k[1] == S and k[2] == B), None)
         if enc_key is not None:
-            eus, en = fwd[enc_key]
+            eus, en = fwd[enc_key][:2]
             eb = msda_bytes(B, S, S, value_bytes=vb)
             roof["encoder_launch"] = {"kernel_us": round(eus, 2), "launches_timed": en, "algorithmic_bytes": eb,
                                       "frac": round(eb / (eus * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
@@ -502,12 +513,13 @@ def main():
             key = next((k for k in bwd if k[1] == Lq and k[2] == B), None)
             if key is None:
                 continue
-            us, n = bwd[key]
+            us, n, us_mean = bwd[key]
             pk = part.get(("sum_partials", Lq, B))
             extra = pk[0] * pk[1] / n if pk else 0.0
             nbytes = msda_bwd_bytes(B, S, Lq, value_bytes=vb)
             tot = us + extra
-            out[name] = {"kernel_us": round(us, 2), "partial_sum_us_per_launch": round(extra, 2), "launches_timed": n,
+            out[name] = {"kernel_us": round(us, 2), "kernel_us_mean": round(us_mean, 2),
+                         "partial_sum_us_per_launch": round(extra, 2), "launches_timed": n,
                          "algorithmic_bytes": nbytes, "achieved": round(nbytes / (tot * 1e-6) / 1e9, 1),
                          "frac": round(nbytes / (tot * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
         if not out:

@@ -29,7 +29,7 @@ from ..ops.functions import MSDASampleFunction
 from ..ops.modules import MSDeformAttnCap
 from ..ops.modules.ms_deform_attn import temporal_shapes_2d
 from .. import MultiScaleDeformableAttention as MSDA
-from ..linear import Linear, split_gemm_enabled
+from ..linear import Linear, split_gemm_enabled, split_linear
 
 
 class ShowAttendTellCore(nn.Module):
@@ -431,13 +431,13 @@ class Captioner(nn.Module):
             xt_all = F.linear(emb, w_x)                                           # (n, steps, 4H)
             if torch.is_grad_enabled() and self.core.fused_train_eligible(hs):
                 hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const, row_video)
-                return F.log_softmax(self.logit(self.dropout(hidden)), dim=2)
+                return F.log_softmax(split_linear(self.dropout(hidden), self.logit.weight, self.logit.bias), dim=2)
             hidden = []
             for i in range(steps):
                 out, (h, c) = self.core.step(xt_all[:, i], (h, c), hs, ref_in, tshapes, lsi, const)
                 hidden.append(out)
             hidden = torch.stack(hidden, 1)                                       # (n, steps, H)
-            return F.log_softmax(self.logit(self.dropout(hidden)), dim=2)
+            return F.log_softmax(split_linear(self.dropout(hidden), self.logit.weight, self.logit.bias), dim=2)
         for i in range(steps):                                                    # scheduled sampling (:92-105)
             it = seq[:, i].clone()
             if i >= 1:

@@ -593,6 +593,8 @@ int check_operands(const char *what, const void *a_hi, const void *a_lo, const f
                    const void *b_lo, const float *b_scale, int N, int K) {
   if (R < 0 || N <= 0 || K <= 0 || (K % kBK))
     return fail(GVL_EINVAL, "%s: needs K %% 32 == 0 (got R=%d N=%d K=%d)", what, R, N, K);
+  if ((int64_t)(R > N ? R : N) * K >= (int64_t)1 << 31)               // element offsets inside a plane are 32-bit
+    return fail(GVL_EINVAL, "%s: an operand plane of more than 2^31 elements (R=%d N=%d K=%d)", what, R, N, K);
   if (R == 0) return 0;
   if (!a_hi || !a_lo || !a_scale || !b_hi || !b_lo || !b_scale) return fail(GVL_EINVAL, "%s: null pointer", what);
   if (((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)b_hi | (uintptr_t)b_lo) & 15)
