@@ -1,0 +1,33 @@
+"""Host-side dispatch of gvl_amd.linear (no GPU): which products go to the hand-written kernels and which to PyTorch."""
+import torch
+import torch.nn.functional as F
+
+
+def test_split_linear_outside_the_kernel_domain_is_plain_linear():
+    from gvl_amd.linear import split_linear, projection, linear
+    g = torch.Generator().manual_seed(0)
+    x, w, b = torch.randn(3, 7, 64, generator=g), torch.randn(10, 64, generator=g), torch.randn(10, generator=g)
+    ref = F.linear(x, w, b)
+    assert torch.equal(split_linear(x, w, b), ref)                       # CPU tensors: never the HIP path
+    assert torch.equal(linear(x, w, b), ref)
+    assert torch.equal(projection(x, w, b), ref)
+    assert torch.equal(split_linear(x, w, None), F.linear(x, w))
+
+
+def test_gemm_switch_follows_the_environment(monkeypatch):
+    from gvl_amd.linear import split_gemm_enabled
+    monkeypatch.delenv("GVL_GEMM", raising=False)
+    assert split_gemm_enabled()
+    monkeypatch.setenv("GVL_GEMM", "f32")
+    assert not split_gemm_enabled()
+
+
+def test_split_gemm_entry_points_are_declared_and_exported():
+    """the ABI-6 symbols of include/gvl_msda.h resolve in the built library (no compute call: there is no GPU here)"""
+    from gvl_amd import _lib
+    L = _lib.lib()
+    for name in ("gvl_split_rows_f16", "gvl_gemm_f16x3_f32", "gvl_gemm_f16x3_argmax_f32", "gvl_gemm_f16x3_argmax_chunks",
+                 "gvl_greedy_step_partials_f32", "gvl_cap_attend_split_f32", "gvl_lstm_cell_split_f32"):
+        assert hasattr(L, name), name
+    assert L.gvl_gemm_f16x3_argmax_chunks(8518) == 134 and L.gvl_gemm_f16x3_argmax_chunks(1) == 2
+    assert L.gvl_msda_abi_version() == _lib.ABI_VERSION == 6
