@@ -76,6 +76,53 @@ int main(void) {
   if (gvl_msda_backward_workspace_bytes(B, S, M, D, L, Q, P, 4, shapes) > 0 &&
       gvl_msda_backward_f32(d_value, d_shapes, d_lsi, d_loc, d_attn, d_gout, B, S, M, D, L, Q, P, 0, shapes, lsi, d_gv, d_gl,
                             d_ga, NULL, 0, st) != GVL_ENOSPC) { fprintf(stderr, "expected GVL_ENOSPC\n"); return 1; }
+  /* the captioner's token-loop products from plain C: split both operands, multiply, argmax + log-sum-exp without logits */
+  {
+    enum { GR = 70, GK = 64, GV = 301 };
+    float *x = malloc(4 * GR * GK), *w = malloc(4 * GV * GK), *bias = malloc(4 * GV);
+    for (int i = 0; i < GR * GK; ++i) x[i] = 2.0f * frand(&seed) - 1.0f;
+    for (int i = 0; i < GV * GK; ++i) w[i] = 0.2f * frand(&seed) - 0.1f;
+    for (int i = 0; i < GV; ++i) bias[i] = frand(&seed) - 0.5f;
+    float *d_x = dev_copy(x, 4 * GR * GK), *d_w = dev_copy(w, 4 * GV * GK), *d_b = dev_copy(bias, 4 * GV);
+    void *xh, *xl, *wh, *wl; float *xs, *ws2, *d_o, *d_part, *d_lp; int64_t *d_tok;
+    CHECK(hipMalloc(&xh, 2 * GR * GK)); CHECK(hipMalloc(&xl, 2 * GR * GK)); CHECK(hipMalloc((void **)&xs, 4 * GR));
+    CHECK(hipMalloc(&wh, 2 * GV * GK)); CHECK(hipMalloc(&wl, 2 * GV * GK)); CHECK(hipMalloc((void **)&ws2, 4 * GV));
+    CHECK(hipMalloc((void **)&d_o, 4 * GR * GV));
+    const int chunks = gvl_gemm_f16x3_argmax_chunks(GV);
+    CHECK(hipMalloc((void **)&d_part, 16 * (size_t)chunks * GR)); CHECK(hipMalloc((void **)&d_lp, 4 * GR));
+    CHECK(hipMalloc((void **)&d_tok, 8 * GR));
+    int rc = gvl_split_rows_f16(d_x, GR, GK, xh, xl, xs, st);
+    if (!rc) rc = gvl_split_rows_f16(d_w, GV, GK, wh, wl, ws2, st);
+    if (!rc) rc = gvl_gemm_f16x3_f32(xh, xl, xs, GR, wh, wl, ws2, GV, GK, d_b, d_o, GV, st);
+    if (!rc) rc = gvl_gemm_f16x3_argmax_f32(xh, xl, xs, GR, wh, wl, ws2, GV, GK, d_b, d_part, st);
+    if (!rc) rc = gvl_greedy_step_partials_f32(d_part, GR, GV, 1, d_tok, d_lp, NULL, NULL, NULL, 0, st);
+    if (rc) { fprintf(stderr, "gemm_f16x3: %d %s\n", rc, gvl_last_error()); return 1; }
+    CHECK(hipStreamSynchronize(st));
+    float *o = malloc(4 * GR * GV), *lp = malloc(4 * GR); int64_t *tok = malloc(8 * GR);
+    CHECK(hipMemcpy(o, d_o, 4 * GR * GV, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(lp, d_lp, 4 * GR, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(tok, d_tok, 8 * GR, hipMemcpyDeviceToHost));
+    double emax = 0, elp = 0; int bad = 0;
+    for (int r = 0; r < GR; ++r) {
+      double best = -1e300, sum = 0; int arg = -1;
+      for (int n = 0; n < GV; ++n) {
+        double acc = bias[n];
+        for (int k = 0; k < GK; ++k) acc += (double)x[r * GK + k] * w[n * GK + k];
+        const double d = fabs(acc - o[r * GV + n]); if (d > emax) emax = d;
+        if (acc > best) { best = acc; arg = n; }
+      }
+      for (int n = 0; n < GV; ++n) {
+        double acc = bias[n];
+        for (int k = 0; k < GK; ++k) acc += (double)x[r * GK + k] * w[n * GK + k];
+        sum += exp(acc - best);
+      }
+      if (tok[r] != arg) ++bad;
+      const double d = fabs(-log(sum) - lp[r]); if (d > elp) elp = d;
+    }
+    printf("gemm_f16x3 max|diff| vs double %.2e, fused argmax: %d wrong tokens, log-prob %.2e\n", emax, bad, elp);
+    if (emax > 2e-6 || bad || elp > 2e-6) { fprintf(stderr, "gemm_f16x3 mismatch\n"); return 1; }
+    if (gvl_gemm_f16x3_f32(xh, xl, xs, GR, wh, wl, ws2, GV, 48, d_b, d_o, GV, st) != GVL_EINVAL) {
+      fprintf(stderr, "expected GVL_EINVAL for K %% 32 != 0\n"); return 1; }
+  }
   printf("C ABI OK\n");
   return 0;
 }
