@@ -17,18 +17,20 @@
 // on the shapes above (tools/split_gemm_probe2.py, tests/test_gpu_gemm16.py): rms error 1.9e-7 against the fp32 library
 // GEMM's 4.6e-7 (a k-ordered fp32 chain rounds 512 times, this one 32 + 64 times per output) -- the result is MORE
 // accurate than the fp32 path it replaces, at 3/16 of the matrix-core time.  Domain: the scale is per ROW, so an element
-// more than 2^-35 below its row's largest is not represented: |error| <= 2^-21 sum |a||b| + K 2^-33 max|a| max|b|.  (Three bf16 parts would need six products: bf16 carries 8 bits per part, fp16 11.)
+// more than 2^-35 below its row's largest is not represented: |error| <= 2^-21 sum |a||b| + K 2^-33 max|a| max|b|.
+// (Three bf16 parts would need six products: bf16 carries 8 bits per part, fp16 11.)
 //
-// k_split_rows:  one wavefront per row -> hi / lo planes (fp16, row-major like the input) + the row scale.
-// k_gemm_f16x3:  out (R, N) = A (R, K) . B (N, K)^T [+ bias], both operands as planes.
-//   workgroup = 4 wavefronts (2 x 2) on a 128 x BN tile (BN = 128 | 64), wavefront tile 64 x BN/2 in 32 x 32 MFMA tiles
-//   (v_mfma_f32_32x32x16_f16); K in stages of 32 through a double-buffered LDS image (64-byte rows per plane, 16-byte
-//   chunks XOR-swizzled by (row >> 2) & 3: the ds_read_b128 of an MFMA operand -- lane l reads row l & 31, chunk
-//   2 s + (l >> 5) -- is then conflict-free); the next stage's global loads are issued before the MFMAs of the current
-//   one and written to the other buffer after them: one barrier per stage, two workgroups per CU cover each other's
-//   barriers.  Per stage and wavefront: 16 ds_read_b128 feed 24 MFMAs (4 operand fragments serve 3 products).
-//   Tiles are walked in groups of 8 row tiles x 8 column tiles per XCD (workgroup id -> XCD is id % 8): the 64
-//   workgroups resident on one XCD share 2 MB + 2 MB of operand planes in its 4 MB L2.
+// k_split_rows        one wavefront per row -> hi / lo planes (fp16, row-major like the input) + the row scale; used
+//                     for the weights (the cell / attention kernels of gvl_cap.hip write their results as planes).
+// k_gemm_f16x3_w8     out (R, N) = A (R, K) . B (N, K)^T [+ bias], both operands as planes: 8 wavefronts, 256 x 128 /
+//                     128 x 256 / 128 x 128 tiles, three-stage LDS ring filled by LDS-DMA, software-pipelined, persistent
+//                     workgroups (comments at the kernel).  Epilogues: store | vocabulary argmax + log-sum-exp partials.
+// k_gemm_f16x3        4 wavefronts, 128 x 64 tiles, two stages, three workgroups per CU: few rows / few tiles.
+//   Common: v_mfma_f32_32x32x16_f16; K in stages of 32; LDS image of a stage = 64-byte rows per plane, 16-byte chunks
+//   XOR-swizzled by (row >> 2) & 3 -- the ds_read_b128 of an MFMA operand (lane l reads row l & 31, chunk 2 s + (l >> 5))
+//   is then conflict-free; 16 ds_read_b128 feed 24 MFMAs per wavefront and stage (4 operand fragments serve 3 products).
+//   Tiles are walked in groups of 8 row tiles per XCD (workgroup id -> XCD is id % 8) so that the workgroups resident on
+//   one XCD share their operand planes in its 4 MB L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
