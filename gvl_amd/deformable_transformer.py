@@ -148,7 +148,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def forward(self, tgt, query_pos, reference_points, src, src_temporal_shapes, level_start_index,
                 src_padding_mask=None, query_mask=None):
         qk = self.with_pos_embed(tgt, query_pos).transpose(0, 1)
-        sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask)[0].transpose(0, 1)
+        # need_weights=False: the reference discards the averaged attention map ([0] at pdvc/deformable_transformer.py:267-268);
+        # not asking for it lets nn.MultiheadAttention skip it (and take its fused attention path)
+        sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask,
+                            need_weights=False)[0].transpose(0, 1)
         tgt = self.norm2(tgt + self.dropout2(sa))
         ca = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_temporal_shapes,
                              level_start_index, src_padding_mask)

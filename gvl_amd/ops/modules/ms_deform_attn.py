@@ -110,6 +110,21 @@ class MSDeformAttn(nn.Module):
                 and self.d_model // self.n_heads == 64 and self.n_levels * self.n_points == 16 and self.n_points == 4
                 and (input_flatten.shape[1] <= 600 or input_flatten.shape[1] - host_lengths[0][0] <= 600))
 
+    def _cat_projection(self):
+        """[sampling_offsets; attention_weights] weight and bias.  With autograd on, a differentiable cat (the gradient
+        splits back onto the two layers); in inference kept per parameter version instead of rebuilt on every call."""
+        ws = (self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
+              self.attention_weights.bias)
+        if torch.is_grad_enabled() and any(p_.requires_grad for p_ in ws):
+            return torch.cat(ws[:2], 0), torch.cat(ws[2:], 0)
+        key = tuple((p_.data_ptr(), p_._version) for p_ in ws)
+        cached = self.__dict__.get("_cat_proj")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = (key, torch.cat(ws[:2], 0), torch.cat(ws[2:], 0))
+            self.__dict__["_cat_proj"] = cached
+        return cached[1], cached[2]
+
     def _forward_fused(self, query, reference_points, input_flatten, shapes2d, level_start_index, padding_mask):
         N, Len_in, _ = input_flatten.shape
         value = self.value_proj(input_flatten)
@@ -117,8 +132,7 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         # one GEMM for both projections: columns [0,128) raw offsets, [128,256) attention logits
-        w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
-        b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        w_cat, b_cat = self._cat_projection()
         proj = projection(query.contiguous(), w_cat, b_cat)
         out = _fn.MSDeformAttnFusedFunction.apply(value, proj, reference_points.contiguous(), shapes2d,
                                                   level_start_index, self.n_levels, self.n_points, self.pad_mode)
