@@ -23,7 +23,7 @@ step = TrainStep(model, criterion, opt, world_size=1)
 for i in range(3):
     step(batches[i])
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for i in range(4):
         step(batches[i])
     torch.cuda.synchronize()
@@ -33,3 +33,9 @@ tot = sum(e.self_device_time_total for e in rows)
 print(f"# per step: {tot / 4 / 1e3:.2f} ms of device time in {sum(e.count for e in rows) / 4:.0f} op calls")
 for e in rows[:40]:
     print(f"{e.key[:60]:60s} {e.count / 4:7.1f} calls {e.self_device_time_total / 4:8.1f} us")
+
+print("# GEMMs by shape")
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::mm", "aten::addmm", "aten::bmm", "aten::baddbmm")]
+rows.sort(key=lambda e: -e.self_device_time_total)
+for e in rows[:24]:
+    print(f"{e.key:12s} {str(e.input_shapes)[:70]:70s} {e.count / 4:6.1f} calls {e.self_device_time_total / 4:8.1f} us  ({e.self_device_time_total / e.count:6.1f} each)")
