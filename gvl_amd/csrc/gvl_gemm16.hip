@@ -407,6 +407,13 @@ __global__ void __launch_bounds__(512, 1)
 
   // fragments of one K half (16) of a stage: 8 ds_read_b128; the 12 MFMAs they feed
   auto frags = [&](const uint4 *st, int s, h8 (&ah)[2], h8 (&al)[2], h8 (&bh)[NJ], h8 (&bl)[NJ]) {
+#ifdef GVL_ABLATE_LDS                                                  // (timing-only build: operands from registers)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ah[i] = __builtin_bit_cast(h8, make_uint4(fa[s], i, 2, 3)); al[i] = ah[i]; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { bh[j] = __builtin_bit_cast(h8, make_uint4(fb[s], j, 6, 7)); bl[j] = bh[j]; }
+    if (true) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const h8 *>(&st[fa[s] + 128 * i]);
@@ -465,12 +472,16 @@ __global__ void __launch_bounds__(512, 1)
     if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my reads of this stage are complete
+#ifndef GVL_ABLATE_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
+#ifndef GVL_ABLATE_DMA                                                 // (tools/gemm16_ablate.sh: timing-only builds)
     {
       const bool over = kt + 3 >= KT;                                 // the stage three ahead belongs to the next tile
       issue(over ? tm2 : tm, over ? tn2 : tn, (over ? kt + 3 - KT : kt + 3) * kBK, buf);
     }
+#endif
     frags(smem + nbuf * kStageSlots, 0, p_ah, p_al, p_bh, p_bl);     // (stage 0 of the next tile at a tile's end)
     mfma12(q_ah, q_al, q_bh, q_bl);
 #ifndef GVL_NO_SCHED_GROUPS
