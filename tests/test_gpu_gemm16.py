@@ -159,3 +159,30 @@ def test_lstm_cell_leaves_its_hidden_state_as_planes():
     assert bool((p.scale == 1.0).all()) and float(p.hi.abs().max()) <= 1.0
     back = p.hi.double() + p.lo.double() / 2048.0
     assert bool(((back - h1.double()).abs() <= 2.0 ** -22 * h1.abs().double() + 2.0 ** -34).all())
+
+
+def test_random_shapes_through_every_kernel_form():
+    """40 random (R, K, N): every dispatch branch of gvl_gemm_f16x3_f32 / _argmax_f32 (four-wavefront kernel, 128 x 128 and
+    256 x 128 persistent tiles, workgroups that take several tiles, ragged last tiles, K = 96 = three stages) against fp64"""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(123)
+    cpu = torch.Generator().manual_seed(123)
+    for case in range(40):
+        R = int(torch.randint(1, 6000, (1,), generator=cpu))
+        N = int(torch.randint(1, 5000, (1,), generator=cpu))
+        K = [32, 64, 96, 128, 256, 512, 1024][int(torch.randint(0, 7, (1,), generator=cpu))]
+        if case % 5 == 0:
+            R, N = max(R, 3000), max(N, 4000)                            # many tiles per persistent workgroup
+        x = torch.randn(R, K, device=dev, generator=g)
+        w = torch.randn(N, K, device=dev, generator=g) * 0.1
+        b = torch.randn(N, device=dev, generator=g)
+        ref = x.double() @ w.double().t() + b.double()
+        xp, wp = MSDA.split_rows(x), MSDA.split_rows(w)
+        out = MSDA.gemm_f16x3(xp, wp, b)
+        bound = 2.0 ** -21 * float((x.abs().double() @ w.abs().double().t()).max()) + 2.0 ** -22 * float(ref.abs().max())
+        assert float((out.double() - ref).abs().max()) <= bound, (R, K, N)
+        tok, lp = MSDA.row_argmax_lse_partials(MSDA.gemm_f16x3_argmax(xp, wp, b))
+        lp_ref, tok_ref = torch.log_softmax(out.double(), 1).max(1)
+        assert bool((tok == tok_ref).all()), (R, K, N)
+        assert float((lp.double() - lp_ref).abs().max()) <= 3e-6, (R, K, N)
