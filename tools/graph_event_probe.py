@@ -1,4 +1,7 @@
-"""Does an external event pair recorded inside a captured graph time the kernel between them?  (ROCm 7.2 / torch 2.10)"""
+"""Does an external event pair recorded inside a captured graph time the kernel between them?  (ROCm 7.2 / torch 2.10)
+Outcome on MI355X: no -- `RuntimeError: External events are disallowed in rocm` at the first record() under capture, so
+bench.py cannot time a kernel INSIDE the replayed graph with events; its roofline blocks stamp eager launches after the
+timed region and the rocprofv3 trace of the replays is committed beside them (profiles/r02_msda_launches_in_graph.txt)."""
 import os
 import sys
 
