@@ -554,15 +554,25 @@ __global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__re
   const int rr = threadIdx.x % kRedRows, g = threadIdx.x / kRedRows, row = blockIdx.x * kRedRows + rr;
   float m = -INFINITY, s = 0.f;
   int a = 0x7fffffff;
-  if (row < R)
-    for (int c = g; c < chunks; c += kRedGroups) {
-      const float4 p = part[(int64_t)c * R + row];
-      const int pa = __float_as_int(p.z);
-      const float mn = fmaxf(m, p.x);
-      if (mn > -INFINITY) s = s * __expf(m - mn) + p.y * __expf(p.x - mn);
-      a = (p.x > m || (p.x == m && pa < a)) ? pa : a;
-      m = mn;
+  if (row < R) {
+    // four partials requested together (the running max / sum chain is serial, the loads need not be)
+    for (int c0 = g; c0 < chunks; c0 += 4 * kRedGroups) {
+      float4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * kRedGroups;
+        p[u] = c < chunks ? part[(int64_t)c * R + row] : make_float4(-INFINITY, 0.f, __int_as_float(0x7fffffff), 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pa = __float_as_int(p[u].z);
+        const float mn = fmaxf(m, p[u].x);
+        if (mn > -INFINITY) s = s * __expf(m - mn) + p[u].y * __expf(p[u].x - mn);
+        a = (p[u].x > m || (p[u].x == m && pa < a)) ? pa : a;
+        m = mn;
+      }
     }
+  }
   s_m[g][rr] = m; s_s[g][rr] = s; s_a[g][rr] = a;
   __syncthreads();
   if (g == 0 && row < R) {
