@@ -258,6 +258,26 @@ def test_pdvc_train_step_matches_reference():
         assert maxerr(params[k[5:]].grad, want) <= 2e-3 * max(1.0, float(abs(want).max())), k
 
 
+def test_token_loop_gemm_paths_agree(built, monkeypatch):
+    """the captioner's token loop on gvl_gemm_f16x3 (default; argmax fused, cell / attention kernels emitting planes) and
+    on the fp32 library GEMMs (GVL_GEMM=f32): the same greedy tokens, log-probabilities within fp32 noise"""
+    f, model, criterion, dev = built
+    dt = to_dev(pdvc_dt(f), dev)
+    cap = model.caption_head[-1]
+    outs = {}
+    with torch.no_grad():
+        cap.graph_decode = False
+        for mode in ("f16x3", "f32"):
+            if mode == "f32":
+                monkeypatch.setenv("GVL_GEMM", "f32")
+            else:
+                monkeypatch.delenv("GVL_GEMM", raising=False)
+            outs[mode], _ = model(dt, None, None, "queries", eval_mode=True)
+    monkeypatch.delenv("GVL_GEMM", raising=False)
+    assert torch.equal(outs["f16x3"]["seq"], outs["f32"]["seq"])
+    assert maxerr(outs["f16x3"]["caption_probs"]["cap_prob_eval"], outs["f32"]["caption_probs"]["cap_prob_eval"]) < 2e-5
+
+
 def test_graph_replayed_decoding_equals_eager(built):
     """The hipGraph replay of the greedy decoding loop returns exactly what the eager loop returns, also when the
     inputs change between replays (static input buffers are refreshed)."""
