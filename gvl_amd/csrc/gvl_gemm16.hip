@@ -534,6 +534,252 @@ __global__ void __launch_bounds__(512, 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the same eight-wavefront persistent kernel on v_mfma_f32_16x16x32_f16.  Why: on random operands the 16 x 16 x 32
+// form sustains 1.2 x the FLOP rate of the 32 x 32 x 16 form (MFMA-only builds of this kernel: 84 against 103 us for the
+// vocabulary product; MI355X_MICROARCH.md notes the same for bf16) -- the chip is clock / power limited under MFMA load and
+// the smaller tile costs less per FLOP.
+//   wavefront tile 64 x 64 = 4 x 4 MFMA tiles; a K stage (32) is ONE MFMA step; operand lane map: row = lane & 15, the 8
+//   halves k = 8 (lane >> 4) ..; LDS chunks swizzled by 2 ((row >> 2) & 1) (conflict-free for this read, on the DMA's
+//   source address as before); C/D: column = lane & 15, row = 4 (lane >> 4) + register.
+//   The 48 MFMAs of a stage run as four quarters of 12 in the order (rows 0-1 | cols 0-1), (0-1 | 2-3), (2-3 | 2-3),
+//   (2-3 | 0-1): consecutive quarters share one operand pair, the other one is read during the quarter before -- three
+//   fragment sets of 16 registers rotate (a01 / a23 and two column sets that swap roles every stage: two stages per loop
+//   iteration), the barrier + DMA issue sit between the second and the third quarter.
+typedef float f4acc4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int lds_slot16(int row, int chunk) { return row * 4 + (chunk ^ (((row >> 2) & 1) << 1)); }
+
+template <int EPI>
+__device__ __forceinline__ void epilogue16(f4acc4 (&acc_m)[4][4], f4acc4 (&acc_x)[4][4], int row0, int col0, int lane,
+                                           const float *__restrict__ As, const float *__restrict__ Bs,
+                                           const float *__restrict__ bias, int R, int N, float *__restrict__ out,
+                                           int64_t ldo) {
+  const int fc = lane & 15, fq = lane >> 4;
+  const float *bias_p = bias ? bias : As;                               // branch-free optional bias (see epilogue())
+  const float bias_on = bias ? 1.f : 0.f;
+  const int bias_ix = bias ? 0x7fffffff : 0;
+  float rs[4][4];                                                       // row scales of this lane's 16 rows, read once
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[i][r] = As[min(row0 + 16 * i + 4 * fq + r, R - 1)];
+  if constexpr (EPI == kArgmax) {
+    float rb[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rb[i][r] = bias_on * bias_p[min(min(row0 + 16 * i + 4 * fq + r, R - 1), bias_ix)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + 16 * j + fc;
+      const float cs = Bs[min(col, N - 1)];
+      float best = -INFINITY, sum = 0.f;
+      int arg = 0x7fffffff;
+      float v[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + 16 * i + 4 * fq + r;
+          v[i][r] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[i][r] * cs) + rb[i][r];
+          if (row < R && v[i][r] > best) { best = v[i][r]; arg = row; }     // rows ascend: the first maximum is kept
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (row0 + 16 * i + 4 * fq + r < R) sum += __expf(v[i][r] - best);
+      // the lanes 16, 32, 48 further hold the other rows of this column
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float b2 = __shfl_xor(best, o), s2 = __shfl_xor(sum, o);
+        const int a2 = __shfl_xor(arg, o);
+        const float bn = fmaxf(best, b2);
+        if (bn > -INFINITY) sum = sum * __expf(best - bn) + s2 * __expf(b2 - bn);
+        arg = (b2 > best || (b2 == best && a2 < arg)) ? a2 : arg;
+        best = bn;
+      }
+      if (fq == 0 && col < N)
+        reinterpret_cast<float4 *>(out)[(int64_t)(row0 >> 6) * N + col] = make_float4(best, sum, __int_as_float(arg), 0.f);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + 16 * j + fc;
+      const bool col_ok = col < N;
+      const float cs = Bs[min(col, N - 1)], cb = bias_on * bias_p[min(min(col, N - 1), bias_ix)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + 16 * i + 4 * fq + r;
+          if (col_ok && row < R)
+            out[(int64_t)row * ldo + col] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[i][r] * cs) + cb;
+        }
+    }
+  }
+}
+
+template <int WM, int WN, int EPI>
+__global__ void __launch_bounds__(512, 1)
+    k_gemm_f16x3_m16(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
+                     const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
+                     const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo,
+                     int tiles_m, int tiles_n) {
+  static_assert(WM * WN == 8 && WM + WN == 6, "eight wavefronts, six DMA instructions per wavefront and stage");
+  constexpr int kRowsA = 64 * WM, kRowsB = 64 * WN;
+  constexpr int kASlots = kRowsA * 4, kBSlots = kRowsB * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  constexpr int NG = WM + WN;
+  __shared__ uint4 smem[3 * kStageSlots];
+
+  int vb = (int)blockIdx.x, tm, tn;
+  if (!tile_of(vb, tiles_m, tiles_n, tm, tn)) return;
+  int m0 = tm * kRowsA, n0 = tn * kRowsB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave % WM) * 64, wn = (wave / WM) * 64;
+
+  // DMA units exactly as in k_gemm_f16x3_w8, with this kernel's swizzle on the source address
+  const int srow = lane >> 2, schunk = ((lane & 3) ^ (((srow >> 2) & 1) << 1)) * 8;
+  const _Float16 *base[NG];
+  int dst[NG], blk16[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int per_plane = 4 * (i < WM ? WM : WN), q = wave + 8 * (i < WM ? i : i - WM);
+    const int plane = __builtin_amdgcn_readfirstlane(q / per_plane), blk = __builtin_amdgcn_readfirstlane(q % per_plane);
+    blk16[i] = blk * 16;
+    base[i] = i < WM ? (plane ? Al : Ah) : (plane ? Bl : Bh);
+    dst[i] = (i < WM ? plane * kASlots : 2 * kASlots + plane * kBSlots) + blk * 64;
+  }
+  int tm2, tn2;
+  bool has_next = tile_of(vb + (int)gridDim.x, tiles_m, tiles_n, tm2, tn2);
+  if (!has_next) { tm2 = tm; tn2 = tn; }
+  auto issue = [&](int tm_, int tn_, int k0, int buf) {
+    uint4 *st = smem + buf * kStageSlots;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
+      glds16(base[i] + (row * K + schunk + k0), st + dst[i]);
+    }
+  };
+
+  f4acc4 acc_m[4][4], acc_x[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc_m[i][j] = f4acc4{0.f, 0.f, 0.f, 0.f}; acc_x[i][j] = f4acc4{0.f, 0.f, 0.f, 0.f}; }
+
+  // fragment slots: block u of 16 rows is 64 slots further (the swizzle term repeats every 8 rows)
+  const int fa = lds_slot16(wm + (lane & 15), lane >> 4), fb = 2 * kASlots + lds_slot16(wn + (lane & 15), lane >> 4);
+  struct Frag { h8 h[2], l[2]; };                                      // two 16-row blocks, hi | lo
+  auto rdA = [&](const uint4 *st, int i0, Frag &f) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f.h[u] = *reinterpret_cast<const h8 *>(&st[fa + 64 * (i0 + u)]);
+      f.l[u] = *reinterpret_cast<const h8 *>(&st[kASlots + fa + 64 * (i0 + u)]);
+    }
+  };
+  auto rdB = [&](const uint4 *st, int j0, Frag &f) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f.h[u] = *reinterpret_cast<const h8 *>(&st[fb + 64 * (j0 + u)]);
+      f.l[u] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb + 64 * (j0 + u)]);
+    }
+  };
+#define GVL_QUARTER(A, B, I0, J0)                                                                                  \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v) {                     \
+    acc_m[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[u], B.h[v], acc_m[I0 + u][J0 + v], 0, 0, 0); \
+    acc_x[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[u], B.l[v], acc_x[I0 + u][J0 + v], 0, 0, 0); \
+    acc_x[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.l[u], B.h[v], acc_x[I0 + u][J0 + v], 0, 0, 0); \
+  }
+#define GVL_GROUPS_READS()  /* 4 fragment reads among 12 MFMAs */                                                   \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+  }
+#define GVL_GROUPS_DMA()    /* 6 DMA + 4 fragment reads among 12 MFMAs */                                           \
+  _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+  }                                                                                                                  \
+  _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+  }                                                                                                                  \
+  _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+  }
+
+  const int KT = K / kBK;                                             // even and >= 4 (host)
+  issue(tm, tn, 0, 0);
+  issue(tm, tn, kBK, 1);
+  issue(tm, tn, 2 * kBK, 2);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frag a01, a23, bX, bY;                                              // bX: columns 0-1 of the stage at hand
+  rdA(smem, 0, a01);
+  rdB(smem, 0, bX);
+  int buf = 0, kt = 0;
+  // one K stage: bA holds its columns 0-1 on entry, bB receives columns 2-3 and then the NEXT stage's columns 0-1
+#define GVL_STAGE(bA, bB)                                                                                           \
+  {                                                                                                                  \
+    const uint4 *st = smem + buf * kStageSlots;                                                                      \
+    const int nbuf = buf == 2 ? 0 : buf + 1;                                                                         \
+    rdB(st, 2, bB);                                                                                                  \
+    GVL_QUARTER(a01, bA, 0, 0)                                                                                       \
+    GVL_GROUPS_READS()                                                                                               \
+    rdA(st, 2, a23);                                                                                                 \
+    GVL_QUARTER(a01, bB, 0, 2)                                                                                       \
+    GVL_GROUPS_READS()                                                                                               \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    asm volatile("" ::: "memory");                                                                                   \
+    {                                                                                                                \
+      const bool over = kt + 3 >= KT;                                                                                \
+      issue(over ? tm2 : tm, over ? tn2 : tn, (over ? kt + 3 - KT : kt + 3) * kBK, buf);                             \
+    }                                                                                                                \
+    rdA(smem + nbuf * kStageSlots, 0, a01);                                                                          \
+    GVL_QUARTER(a23, bB, 2, 2)                                                                                       \
+    GVL_GROUPS_DMA()                                                                                                 \
+    rdB(smem + nbuf * kStageSlots, 0, bB);                                                                           \
+    GVL_QUARTER(a23, bA, 2, 0)                                                                                       \
+    GVL_GROUPS_READS()                                                                                               \
+    buf = nbuf;                                                                                                      \
+    ++kt;                                                                                                            \
+  }
+  for (;;) {
+    GVL_STAGE(bX, bY)
+    GVL_STAGE(bY, bX)
+    if (kt == KT) {
+      epilogue16<EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
+      if (!has_next) break;
+      kt = 0;
+      vb += (int)gridDim.x;
+      tm = tm2;
+      tn = tn2;
+      m0 = tm * kRowsA;
+      n0 = tn * kRowsB;
+      has_next = tile_of(vb + (int)gridDim.x, tiles_m, tiles_n, tm2, tn2);
+      if (!has_next) { tm2 = tm; tn2 = tn; }
+      // (the first fragments of the new tile are read again rather than kept across the epilogue)
+      rdA(smem + buf * kStageSlots, 0, a01);
+      rdB(smem + buf * kStageSlots, 0, bX);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc_m[i][j] = f4acc4{0.f, 0.f, 0.f, 0.f}; acc_x[i][j] = f4acc4{0.f, 0.f, 0.f, 0.f}; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef GVL_STAGE
+#undef GVL_GROUPS_DMA
+#undef GVL_GROUPS_READS
+#undef GVL_QUARTER
+}
+
 // partials (chunks, R) of {max, sum exp(v - max), index, -} -> per row argmax and log-softmax at the argmax, plus the
 // bookkeeping of one greedy step (gvl_cap.hip: k_row_argmax_lse has the same tail).  Block = 16 rows x 16 chunk groups:
 // 16 lanes read 256 contiguous bytes of one chunk row; 300 workgroups at R = 4800.
@@ -612,6 +858,13 @@ int persistent_grid(int tiles) {
   return padded < cus ? padded : cus;
 }
 
+// the 16 x 16 x 32 form (two K stages per loop iteration: K % 64 == 0, at least four stages); GVL_GEMM16_MFMA=32 keeps
+// the 32 x 32 x 16 kernels for A/B runs
+bool use_m16(int K) {
+  const char *e = getenv("GVL_GEMM16_MFMA");
+  return !(e && atoi(e) == 32) && K % 64 == 0 && K >= 128;
+}
+
 int check_operands(const char *what, const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi,
                    const void *b_lo, const float *b_scale, int N, int K) {
   if (R < 0 || N <= 0 || K <= 0 || (K % kBK))
@@ -654,6 +907,10 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
     const int t_big = ((R + 255) / 256) * ((N + 127) / 128), t_mid = ((R + 127) / 128) * ((N + 127) / 128);
     if (t_big >= 1024) {
       const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
+      if (use_m16(K))
+        return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_m16", k_gemm_f16x3_m16<4, 2, kStore>,
+                           dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale,
+                           bh, bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
       return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<4, 2, 2, kStore>,
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
@@ -684,6 +941,10 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   const int tiles_m = (V + kBM - 1) / kBM;                            // 128 vocabulary entries per tile, either form
   if (R >= 1024 && K >= 3 * kBK) {
     const int tiles_n = (R + 255) / 256;
+    if (use_m16(K))
+      return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_m16<argmax>", k_gemm_f16x3_m16<2, 4, kArgmax>,
+                         dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh,
+                         xl, x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
     return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", k_gemm_f16x3_w8<2, 4, 2, kArgmax>,
                        dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
                        x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
