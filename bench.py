@@ -598,7 +598,7 @@ def main():
             us = mine[0][0]
             tf16 = 3 * 2.0 * rows * V * Kd / (us * 1e-6) / 1e12
             line["dominant_gemm"] = {
-                "kernel": f"k_gemm_f16x3_w8<argmax> {rows}x{Kd}x{V} (vocabulary product of every token step, argmax / "
+                "kernel": f"k_gemm_f16x3_m16<argmax> {rows}x{Kd}x{V} (vocabulary product of every token step, argmax / "
                           f"log-sum-exp fused, logits never written), hand-written",
                 "bound": "mfma", "achieved": round(tf16, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, 3 "
                 "partial products per fp32 product)", "frac": round(tf16 / F16_MFMA_PEAK_TFLOPS, 4),
