@@ -67,7 +67,8 @@ class SetCriterionFunction(torch.autograd.Function):
     def _call(fn, ctx_t, cfg, padded, *outs):
         logits, counts, boxes, mq, mt, vid, tbase, ent_start, labels, tboxes, gt_counts, ccr = ctx_t[:12]
         nl, B, Q, NC = logits.shape
-        pair_count, nb_dev = (ctx_t[12].data_ptr(), ctx_t[13].data_ptr()) if padded else (None, None)
+        pair_count = ctx_t[12].data_ptr() if padded else None
+        nb_dev = ctx_t[-1].data_ptr() if len(ctx_t) > (13 if padded else 12) else None
         with torch.cuda.device(logits.device):
             rc = fn(logits.data_ptr(), counts.data_ptr(), boxes.data_ptr(), mq.data_ptr(), mt.data_ptr(),
                     vid.data_ptr(), tbase.data_ptr(), ent_start.data_ptr(), labels.data_ptr(), tboxes.data_ptr(),
@@ -79,14 +80,18 @@ class SetCriterionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, counts, boxes, mq, mt, vid, tbase, ent_start, labels, tboxes, gt_counts, ccr, num_boxes,
                 alpha, gamma, beta, gau_mask, pair_count=None, num_boxes_dev=None):
-        """pair_count (B) / num_boxes_dev (1): the padded, layout-independent form (gvl_amd.targets.PaddedTargets) --
-        match slots beyond a video's count are empty and the normaliser is read from device memory."""
+        """pair_count (B): the padded, layout-independent form (gvl_amd.targets.PaddedTargets) -- match slots beyond a
+        video's count are empty.  num_boxes_dev (1): the normaliser of criterion.py:178-181 read from device memory
+        (padded form; or a captured list-form step whose cross-rank mean changes from batch to batch)."""
         tensors = (logits.contiguous(), counts.contiguous(), boxes.contiguous(), mq.contiguous(), mt.contiguous(), vid,
                    tbase, ent_start, labels.contiguous(), tboxes.float().contiguous(), gt_counts, ccr)
         padded = pair_count is not None
         if padded:
-            tensors = tensors + (pair_count.contiguous(), num_boxes_dev)
-        cfg = (1.0 if padded else float(num_boxes), float(alpha), float(gamma), float(beta), int(bool(gau_mask)))
+            tensors = tensors + (pair_count.contiguous(),)
+        if num_boxes_dev is not None:
+            tensors = tensors + (num_boxes_dev,)
+        cfg = (1.0 if num_boxes_dev is not None else float(num_boxes), float(alpha), float(gamma), float(beta),
+               int(bool(gau_mask)))
         losses = torch.empty((logits.shape[0], len(LOSS_KEYS)), dtype=torch.float32, device=logits.device)
         _lib.check(SetCriterionFunction._call(_lib.lib().gvl_set_criterion_forward_f32, tensors, cfg, padded, losses),
                    "set_criterion_forward")
@@ -118,7 +123,9 @@ class SetCriterion(nn.Module):
         self.counter_class_rate = torch.tensor(COUNTER_CLASS_RATE)
         self.device_matching = True      # solve the Hungarian problems on the GPU (bit-identical to scipy)
         self.fused = True                # all layers' losses in one HIP launch per direction (SetCriterionFunction)
-        self.num_boxes_override = None   # set by a caller that has already taken the cross-rank mean (graph capture)
+        # set by a caller that has already taken the cross-rank mean (graph capture): a float, or a (1,) fp32 DEVICE
+        # tensor the captured kernels read at replay time (so the value is not baked into the graph)
+        self.num_boxes_override = None
         self._const_cache = {}
 
     @staticmethod
@@ -225,7 +232,7 @@ class SetCriterion(nn.Module):
             logits, counts, boxes, mq, mt, plan.vid_of_entry, plan.tgt_base, plan.ent_start, self._tgt_cat[0],
             self._tgt_cat[1], self._gt_counts, ccr, num_boxes, self.focal_alpha, self.focal_gamma,
             getattr(self.opt, "lloss_beta", 1), getattr(self.opt, "lloss_gau_mask", 1),
-            plan.pair_count if padded else None, num_boxes if padded else None)
+            plan.pair_count if padded else None, num_boxes if isinstance(num_boxes, torch.Tensor) else None)
         flat = table.flatten().unbind(0)
         losses = {}
         for l in range(nl):
@@ -239,13 +246,22 @@ class SetCriterion(nn.Module):
         assert loss in table, f'do you really want to compute {loss} loss?'
         return table[loss](outputs, targets, indices, num_boxes, **kwargs)
 
+    def padded_static_ok(self, batch, queries, slots, m2o_rate=4):
+        """the conditions of the layout-independent form that are known BEFORE a forward (what a captured step checks
+        when it decides between one padded graph and one graph per batch layout -- ADVICE r2: the decision and
+        `padded_eligible` below must agree, or a graph bakes one batch's event layout in)"""
+        m = self.matcher
+        return (self.fused and self.device_matching and set(self.losses) == {'labels', 'boxes', 'cardinality'}
+                and batch * queries <= 24576 and hasattr(m, "match_layers_padded")
+                and not (m.opt is not None and getattr(m.opt, "set_cost_caption", 0) > 0)
+                and min(queries, slots * m2o_rate) <= m.LSAP_DEVICE_MAX_ROWS
+                and max(queries, slots * m2o_rate) <= m.LSAP_DEVICE_MAX_COLS)
+
     def padded_eligible(self, outputs, pt):
         """can this step run in the layout-independent form (PaddedTargets in, everything on the device)?"""
         lg = outputs['pred_logits']
         layers = [outputs] + list(outputs.get('aux_outputs', []))
-        return (self.fused and self.device_matching and lg.is_cuda
-                and set(self.losses) == {'labels', 'boxes', 'cardinality'} and lg.shape[0] * lg.shape[1] <= 24576
-                and hasattr(self.matcher, "match_layers_padded")
+        return (lg.is_cuda and self.padded_static_ok(lg.shape[0], lg.shape[1], pt.slots)
                 and self.matcher.padded_eligible(layers, lg.shape[1], pt.slots))
 
     def _forward_padded(self, outputs, pt):
@@ -269,6 +285,11 @@ class SetCriterion(nn.Module):
         if hasattr(targets, "host_counts"):
             if self.padded_eligible(outputs, targets):
                 return self._forward_padded(outputs, targets)
+            if outputs['pred_logits'].is_cuda and torch.cuda.is_current_stream_capturing():
+                # as_list() slices with the HOST counts of the batch at hand: captured, that layout would be replayed
+                # against every later batch without an error
+                raise RuntimeError("SetCriterion: PaddedTargets outside the padded path's domain while a hipGraph is "
+                                   "being captured (the caller's padded_static_ok() check and padded_eligible() disagree)")
             targets = targets.as_list()
         main = {k: v for k, v in outputs.items() if k not in ('aux_outputs', 'enc_outputs')}
         aux_list = outputs.get('aux_outputs', [])
@@ -300,7 +321,9 @@ class SetCriterion(nn.Module):
         num_boxes = sum(len(t_["labels"]) for t_ in targets)
         # criterion.py:178-181.  Only while training: the reference never evaluates under a process group, and an
         # eval forward sharded by video must not synchronise the ranks (its losses are per-rank diagnostics)
-        if self.num_boxes_override is not None:
+        if isinstance(self.num_boxes_override, torch.Tensor):
+            num_boxes = self.num_boxes_override.reshape(())             # device scalar: read by the kernels / ops
+        elif self.num_boxes_override is not None:
             num_boxes = float(self.num_boxes_override)
         elif is_dist_avail_and_initialized() and torch.is_grad_enabled():
             nb = torch.as_tensor([num_boxes], dtype=torch.float, device=outputs['pred_logits'].device)

@@ -929,7 +929,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
 // the integer histogram in phase 1 (packed beside the row), so the scatter needs no second round of LDS atomics.
 // ------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t bwd_split_lds_bytes(int S, int qper) {
-  return (size_t)(S + 1) * 256 + (size_t)qper * 256 + (size_t)(S + 2) * 2 * sizeof(int) + (size_t)(2 * qper * 8) * 4 * sizeof(int);
+  // first region: the value slab (S + 1 rows), later reused for the OWN queries' grad_out rows (qper rows) -- sized for both
+  const int rowsA = S + 1 > qper ? S + 1 : qper;
+  return (size_t)rowsA * 256 + (size_t)qper * 256 + (size_t)(S + 2) * 2 * sizeof(int) + (size_t)(2 * qper * 8) * 4 * sizeof(int);
 }
 
 template <int PAD, bool FUSED, typename VT>
@@ -946,7 +948,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   extern __shared__ float4 slab4[];
   __shared__ int next_blk_s;
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
-  const int rowsV = S + 1;
+  const int rowsV = max(S + 1, qper);                                  // region A: slab, then the own grad_out rows
   float4 *G_oth = slab4 + (size_t)rowsV * 16;                          // grad_out rows of the foreign queries
   int *cnt = reinterpret_cast<int *>(G_oth + (size_t)qper * 16);       // [S+2] histogram
   int *off = cnt + (S + 2);                                            // [S+2] exclusive prefix

@@ -157,12 +157,32 @@ class GradBuckets:
         self.flat.div_(self.world)
 
     def unused_params(self):
-        """parameters that received no gradient in the step just finished (overlap mode).  The single-GPU loop leaves
-        their .grad = None and Adam skips them (no weight decay, no moment update); with the flat buffer they hold
-        zeros, so the step hides them from the optimizer.  Parameter usage must be the same on every rank."""
+        """parameters that received no gradient ON ANY RANK in the step just finished (overlap mode).  The single-GPU
+        loop leaves their .grad = None and Adam skips them (no weight decay, no moment update); with the flat buffer they
+        hold zeros, so the step hides them from the optimizer.  The set is agreed across the ranks with one small MAX
+        all-reduce of a per-parameter flag vector: a parameter some rank did use keeps its (averaged) gradient everywhere,
+        so the replicas cannot drift apart on rank-dependent usage."""
         if self.flat is None or not self.overlap or self.world == 1:
             return []
-        return [p for p in self.params if id(p) not in self.seen]
+        used = torch.tensor([1 if id(p) in self.seen else 0 for p in self.params], dtype=torch.int32,
+                            device=self.flat.device)
+        dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)
+        used = used.tolist()
+        return [p for p, u in zip(self.params, used) if not u]
+
+    def probe_unused(self, run):
+        """no-hook (captured) mode: run one eager step `run()` with temporary post-accumulate hooks and return the
+        parameters autograd never delivered a gradient to.  With the flat buffer installed their .grad is a zero view,
+        not None, so a captured clip + Adam would decay them (weight_decay) and advance their moments where the
+        single-GPU step and the reference (train.py:405-409) skip them."""
+        seen = set()
+        handles = [p.register_post_accumulate_grad_hook(lambda p_: seen.add(id(p_))) for p in self.params]
+        try:
+            run()
+        finally:
+            for h in handles:
+                h.remove()
+        return [p for p in self.params if id(p) not in seen]
 
 
 class TrainStep:
@@ -361,10 +381,12 @@ class GraphedTrainStep(TrainStep):
     def _use_padded(self, dt):
         if self.padded is False or self.opt.transformer_input_type != "queries":
             return False
-        ok = self.model.supports_padded_targets(self.criterion, eval_mode=False)
+        slots = max(self.capacity.slots, round_up_pow2(needed_capacity(dt)[0], 4))
+        ok = self.model.supports_padded_targets(self.criterion, eval_mode=False, batch=dt["video_tensor"].shape[0],
+                                                slots=slots)
         if not ok and self.padded:
             raise RuntimeError("GraphedTrainStep(padded=True): this model / criterion has no padded-target path")
-        return ok and round_up_pow2(needed_capacity(dt)[0], 4) <= min(64, self.opt.num_queries)
+        return ok and slots <= min(64, self.opt.num_queries)
 
     def _layout_key(self, dt):
         """fallback form: one graph per batch layout (tensor shapes, events per video, teacher-forcing length)"""
@@ -399,13 +421,19 @@ class GraphedTrainStep(TrainStep):
         return TrainStep.__call__(self, dt)
 
     def _global_num_boxes(self, dt):
-        """criterion.py:178-181, outside any capture: mean over the ranks of the (host-known) number of targets"""
+        """criterion.py:178-181, outside any capture: mean over the ranks of the (host-known) number of targets, left in
+        a persistent DEVICE scalar that the captured criterion reads at replay time -- no host read, and the value is
+        not part of the graph key (a float argument re-captured the step for every new value)"""
         n = float(sum(len(t_["labels"]) for t_ in dt["video_target"]))
+        nb = self.__dict__.get("_nb_dev")
+        if nb is None:
+            nb = self._nb_dev = torch.zeros(1, dtype=torch.float32, device=self.params[0].device)
+        nb.fill_(n)
         if dist.is_available() and dist.is_initialized() and self.world > 1:
-            nb = torch.tensor([n], dtype=torch.float32, device=self.params[0].device)
             dist.all_reduce(nb)
-            n = float(nb.item()) / self.world
-        return max(n, 1.0)
+            nb.div_(self.world)
+        nb.clamp_(min=1.0)
+        return nb
 
     def _forward_backward(self, dt):
         """stage 1 of the data-parallel step: zero_grad, forward, losses, backward down to the encoder output"""
@@ -431,9 +459,18 @@ class GraphedTrainStep(TrainStep):
             self._cut["src"].backward(self._cut["leaf"].grad)
         self._cut = None
 
-    def _update(self):
-        torch.nn.utils.clip_grad_norm_(self.params, self.opt.grad_clip)
-        self.optimizer.step()
+    def _update(self, unused=()):
+        """clip + Adam over the parameters that take part in this captured step; `unused` (found by the warm-up probe)
+        are hidden exactly as TrainStep.__call__ hides them: grad = None while the optimizer looks"""
+        hidden = [(p, p.grad) for p in unused]
+        for p, _ in hidden:
+            p.grad = None
+        try:
+            torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], self.opt.grad_clip)
+            self.optimizer.step()
+        finally:
+            for p, g in hidden:
+                p.grad = g
 
     # ---- side-effect-free warm-up --------------------------------------------------------------------------------
     def _snapshot(self):
@@ -462,12 +499,20 @@ class GraphedTrainStep(TrainStep):
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        unused = []
         with torch.cuda.stream(side):
-            for _ in range(self.warmup):
+            for it in range(self.warmup):
                 if self.split:
-                    self._forward_backward(st)
-                    self._backward_encoder()
-                    self._update()
+                    def fb():
+                        self._forward_backward(st)
+                        self._backward_encoder()
+                    if it == 0 and self.buckets.flat is not None:
+                        # which parameters does this step's autograd graph reach?  (static per capture: the padded step
+                        # has no data-dependent structure, the layout-keyed step is captured per layout)
+                        unused = self.buckets.probe_unused(fb)
+                    else:
+                        fb()
+                    self._update(unused)
                 else:
                     TrainStep.__call__(self, st)
         torch.cuda.current_stream().wait_stream(side)
@@ -481,7 +526,8 @@ class GraphedTrainStep(TrainStep):
             with torch.cuda.graph(g_enc, pool=g_fb.pool(), stream=side):
                 self._backward_encoder()
             with torch.cuda.graph(g_up, pool=g_fb.pool(), stream=side):
-                self._update()
+                self._update(unused)
+            self.last_unused = unused
             graphs = (g_fb, g_enc, g_up)
         else:
             graph = torch.cuda.CUDAGraph()
@@ -502,7 +548,7 @@ class GraphedTrainStep(TrainStep):
 
     def __call__(self, dt):
         padded = self._use_padded(dt)
-        # fallback form only: the cross-rank mean enters the capture as a HOST value (one collective + host read per step)
+        # fallback form only: the cross-rank mean of the target count, in a device scalar (one small collective per step)
         nb = self._global_num_boxes(dt) if (self.split and not padded) else None
         if padded:
             slots, cap_len = self.capacity.fit(dt, with_captions=True)
@@ -521,9 +567,9 @@ class GraphedTrainStep(TrainStep):
             if self.split:
                 self._mean_num_boxes_on_device(batch.targets)       # every rank, every step: one scalar all-reduce
         else:
-            key = self._layout_key(dt) + ((nb,) if self.split else ())
+            key = self._layout_key(dt)
             entry = self.graphs.lookup(key)
-            self.criterion.num_boxes_override = nb              # a kernel argument of the captured criterion
+            self.criterion.num_boxes_override = nb              # device scalar read by the captured criterion
             try:
                 if entry is None:
                     st = GraphedTrainStep._static_copy(dt)
@@ -577,13 +623,18 @@ class GraphedEvalForward:
     def _epoch(self):
         # operands derived from weights only (concatenated / pre-multiplied matrices of the captioner) are cached per
         # parameter version and are constants of the captured graph: updated parameters => a new capture
-        return sum(p_._version for p_ in self.model.parameters())
+        ps = self.__dict__.get("_param_list")
+        if ps is None:                                        # (module traversal once, not on every call)
+            ps = self._param_list = list(self.model.parameters())
+        return sum(p_._version for p_ in ps)
 
     def _use_padded(self, dt):
         if self.padded is False or self.kind != "queries" or self.criterion is None:
             return False
-        return (self.model.supports_padded_targets(self.criterion, eval_mode=True)
-                and round_up_pow2(needed_capacity(dt)[0], 4) <= min(64, self.model.opt.num_queries))
+        slots = max(self.capacity.slots, round_up_pow2(needed_capacity(dt)[0], 4))
+        return (self.model.supports_padded_targets(self.criterion, eval_mode=True, batch=dt["video_tensor"].shape[0],
+                                                   slots=slots)
+                and slots <= min(64, self.model.opt.num_queries))
 
     def _autocast(self):
         return torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None)

@@ -135,11 +135,16 @@ class PDVC(nn.Module):
         memory = self.transformer.forward_encoder(src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat)
         return memory, tshapes, lsi, valid_ratios, mask_flat
 
-    def supports_padded_targets(self, criterion, eval_mode):
+    def supports_padded_targets(self, criterion, eval_mode, batch=None, slots=None):
         """Can a step on this model run in the layout-independent form (dt['_gvl_targets'] = PaddedTargets; what
         gvl_amd.parallel's captured steps use)?  Eval: whenever the criterion can.  Train: additionally the caption
-        losses of all decoder layers must come from the one-pass teacher-forced path (caption_prediction_layers)."""
+        losses of all decoder layers must come from the one-pass teacher-forced path (caption_prediction_layers).
+        batch / slots (videos per step, target slots per video): when given, the criterion's own static conditions
+        (problem sizes of the on-device solver, B * Q limit, loss set) are evaluated too -- the same ones its forward
+        checks, so a captured step never meets the list-form fallback."""
         if criterion is None or not getattr(criterion, "fused", False) or not getattr(criterion, "device_matching", False):
+            return False
+        if batch is not None and not criterion.padded_static_ok(batch, self.opt.num_queries, slots or 4):
             return False
         if eval_mode or self.opt.caption_loss_coef == 0:
             return True
@@ -394,7 +399,9 @@ class PDVC(nn.Module):
         mask_flat = pt.cap_mask[v_all, t_all] * used_all[:, None]
         cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=pt.cap_len - 1, row_video=row_video)
         row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
-        per_layer = row_loss.view(nl, R).sum(dim=1) / (N_ * n1.max())
+        # (a batch without a single event: every row is masked, the sum is exactly 0 -- 0 / 1, not 0 / 0: a NaN here would
+        #  flow through clip_grad_norm_ into the captured Adam and poison parameters and moments for good)
+        per_layer = row_loss.view(nl, R).sum(dim=1) / (N_ * n1.max().clamp(min=1))
         return per_layer.unbind(0), {}, pt.cap_tensor[plan.vid_of_entry, matches[-1].t.clamp(min=0)]
 
     def caption_prediction_layers(self, cap_head, dt, hs_layers, ref_layers, others, matches):

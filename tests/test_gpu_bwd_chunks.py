@@ -71,6 +71,23 @@ def test_ragged_last_chunk_and_two_workgroups_per_slab(dev, MSDA, monkeypatch):
     _check(MSDA, dev, B=16, T=100, Q=277, pad="border", seed=99)
 
 
+@pytest.mark.parametrize("T,Q", [(50, 300), (100, 400), (24, 512)])
+def test_level_split_with_more_own_queries_than_slab_rows(T, Q, dev, MSDA, monkeypatch):
+    """k_bwd_t1d_split stages the workgroup's own grad_out rows over the dead value slab; with
+    (Q + 1) / 2 > S + 1 (short videos, many queries) those rows used to run into the foreign queries' rows.  The first
+    LDS region is now sized for both uses; checked against the generic kernel / oracle and against the query-split form."""
+    _check(MSDA, dev, B=16, T=T, Q=Q, pad="zeros", seed=300 + T)
+    value, shapes, lsi, loc, aw, gout = make_inputs(16, T, 8, 64, Q, 4, seed=77)
+    args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
+    g = t(gout).to(dev)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GVL_MSDA_BWD_SPLIT", flag)
+        res[flag] = [x.cpu().numpy() for x in MSDA.ms_deform_attn_backward(*args, g, 64)]
+    for a, b in zip(res["1"], res["0"]):
+        assert maxerr(a, b) <= 2e-5 * scale(b)
+
+
 @pytest.mark.parametrize("ref_dim", [1, 2])
 def test_fused_entry_point_with_chunks_matches_autograd_composition(ref_dim, dev, MSDA, monkeypatch):
     from gvl_amd.ops.functions.ms_deform_attn_func import MSDeformAttnFunction

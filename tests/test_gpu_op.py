@@ -207,7 +207,7 @@ def test_full_size_properties(dev, MSDA):
         assert maxerr(x, y) <= 1e-4 * scale(y.cpu().numpy())
     for x, y in zip(gf1[1:], gf2[1:]):
         assert torch.equal(x, y), "grad_loc / grad_attn involve no atomics and must be bitwise reproducible"
-    assert maxerr(gf1[0], gf2[0]) <= 1e-5 * scale(gf1[0].cpu().numpy())     # LDS float adds: order varies
+    assert maxerr(gf1[0], gf2[0]) <= 1e-5 * scale(gf1[0].cpu().numpy())     # no float atomics; equal-row entries are summed in counting-sort slot order, which varies
     assert maxerr(gf1[1][..., 1], -a * gf1[2]) < 1e-4 * scale(gf1[2].cpu().numpy())
 
 

@@ -149,6 +149,16 @@ def _worker_gather(rank, world, port, q):
         buckets.finish()
         grads = [p.grad.clone().numpy() for p in params]
         unused = [i for i, p in enumerate(params) if any(p is u for u in buckets.unused_params())]
+        # a second step in which BOTH ranks leave layer 3 (and each rank one more, different, layer) without a gradient:
+        # only the layer nobody used is hidden from the optimizer, on every rank (the set is agreed)
+        buckets.zero()
+        sum(l_(x).sum() for l_ in (layers[:2] if rank == 0 else layers[1:3])).backward()
+        buckets.finish()
+        unused += [100 + i for i, p in enumerate(params) if any(p is u for u in buckets.unused_params())]
+        # the captured (no-hook) form finds the parameters a step never reaches with a probe run
+        probe = GradBuckets([p for l_ in layers for p in l_.parameters()], flat=True, overlap=False)
+        never = probe.probe_unused(lambda: sum(l_(x).sum() for l_ in layers[:3]).backward())
+        unused += [200 + i for i, p in enumerate(probe.params) if any(p is u for u in never)]
         # ---- two-stage exchange of the captured data-parallel step: the `first` group (gradients complete after the
         # first backward stage) occupies the leading buckets and travels while the second stage would still run
         torch.manual_seed(1)
@@ -205,7 +215,9 @@ def test_eval_result_gather_and_fixed_bucket_order():
     for r in range(2):
         for got, w in zip(res[r][2], want):
             assert torch.allclose(torch.from_numpy(got), w, atol=1e-6)
-    assert res[0][3] == [6, 7] and res[1][3] == [0, 1]          # each rank's locally unused layer (weight, bias)
+    # step 1: every layer is used by some rank -> nothing hidden; step 2: layer 3 unused everywhere -> hidden on both
+    # ranks; the probe of the captured form reports the unreached layer 3
+    assert res[0][3] == [106, 107, 206, 207] and res[1][3] == [106, 107, 206, 207]
     # two-stage exchange: every layer's gradient is the mean over the ranks (x = 1 and 2 -> weight 3, bias 2)
     for r in range(2):
         for li in range(4):
