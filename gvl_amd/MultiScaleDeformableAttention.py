@@ -148,9 +148,11 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return grad_value, grad_loc, grad_attn
 
 
-def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_levels, n_points, pad_mode="zeros"):
+def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_levels, n_points, pad_mode="zeros",
+                         amax_out=None):
     """include/gvl_msda.h: gvl_msda1d_fused_forward_{f32,bf16}.  value (B,S,M,64) | proj (B,Q,2*M*L*P) | ref (B,Q,L,1|2);
-    value / proj fp32 or both bf16, ref always fp32."""
+    value / proj fp32 or both bf16, ref always fp32.  amax_out (B*Q) fp32, zero-initialised: additionally receives
+    max |out| of every output row (gvl_msda1d_fused_forward_amax_f32; fp32 only)."""
     _require(value.dtype in (torch.float32, torch.bfloat16), "msda1d_fused: value must be fp32 or bf16")
     for name, t_, dt_ in (("value", value, value.dtype), ("proj", proj, value.dtype), ("ref", ref, torch.float32)):
         _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == dt_,
@@ -161,6 +163,16 @@ def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_
              "msda1d_fused: proj / ref have wrong shapes")
     sh, ls = host_shapes(spatial_shapes, level_start_index)
     out = value.new_empty((B, Q, M * D))
+    if amax_out is not None:
+        _require(value.dtype == torch.float32 and amax_out.is_cuda and amax_out.dtype == torch.float32
+                 and amax_out.is_contiguous() and amax_out.numel() == B * Q, "msda1d_fused: amax_out must be (B*Q) fp32")
+        with torch.cuda.device(value.device):
+            rc = _lib.lib().gvl_msda1d_fused_forward_amax_f32(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
+                ref.data_ptr(), B, S, M, D, n_levels, Q, n_points, RD, PAD_MODES[pad_mode], _hp(sh), _hp(ls),
+                out.data_ptr(), amax_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "msda1d_fused_forward_amax")
+        return out
     with torch.cuda.device(value.device):
         rc = getattr(_lib.lib(), "gvl_msda1d_fused_forward_" + _SUFFIX[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(), ref.data_ptr(),

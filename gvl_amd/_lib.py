@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 6          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 7          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -62,6 +62,10 @@ SIGNATURES = {
     "gvl_greedy_step_bf16": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gvl_greedy_step_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
+    "gvl_msda1d_fused_forward_amax_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P, _P]),
+    "gvl_linear_f16x3_f32": (_I, [_P, _I64, _P, _I64, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "gvl_layer_norm_rows_f32": (_I, [_P, _I, _I, _P, _P, ctypes.c_float, _P, _I, _P, _P, _P, _P]),
+    "gvl_row_absmax_f32": (_I, [_P, _I64, _I, _I, _P, _I64, _I, _P, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),
     "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_msda1d_fused_forward_bf16": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),

@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", n) for n in ("gvl_msda.hip", "gvl_cap.hip", "gvl_cap_train.hip", "gvl_criterion.hip", "gvl_lsap_dev.hip", "gvl_proj.hip", "gvl_gemm16.hip", "gvl_lsap.cpp")]
+SRC = [os.path.join(HERE, "csrc", n) for n in ("gvl_msda.hip", "gvl_cap.hip", "gvl_cap_train.hip", "gvl_criterion.hip", "gvl_lsap_dev.hip", "gvl_proj.hip", "gvl_gemm16.hip", "gvl_layers.hip", "gvl_lsap.cpp")]
 OUT = os.path.join(HERE, "libgvl_msda.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-pthread",
          "-Wall", "-Wno-unused-function"]
@@ -23,7 +23,8 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     deps = [s for s in SRC if os.path.exists(s)] + [os.path.join(ROOT, "include", "gvl_msda.h"), __file__,
-                                                    os.path.join(HERE, "csrc", "gvl_common.hpp")]
+                                                    os.path.join(HERE, "csrc", "gvl_common.hpp"),
+                                                    os.path.join(HERE, "csrc", "gvl_gemm16_common.hpp")]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 

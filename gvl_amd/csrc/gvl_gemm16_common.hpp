@@ -1,0 +1,92 @@
+// gvl_gemm16_common.hpp -- device helpers shared by the split-fp16 GEMM kernels (gvl_gemm16.hip: token loop of the
+// captioner; gvl_layers.hip: the transformer layers' Linear products).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gvl16 {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16acc __attribute__((ext_vector_type(16)));
+
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kBM = 128, kBK = 32, kGroupM = 8;
+
+__device__ __forceinline__ int lds_slot(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
+
+// 16 bytes per lane, global -> LDS without a register: the wavefront's 64 lanes land at lds .. lds + 1 KiB, lane-linear
+__device__ __forceinline__ void glds16(const void *g, void *lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+// What happens to a tile of D = A . B^T once it is complete:
+//   kStore       out[row][col] = D            (A = activations, B = weight; bias per column)
+//   kArgmax      A = the vocabulary layer's weight, B = the hidden states: per (token row = column of D, 64 vocabulary
+//                entries = the wavefront's rows of D) the maximum, its index and sum exp(v - max) -- the logits are never
+//                written.  All 32 vocabulary entries of one MFMA tile column sit in ONE lane's registers (and the lane
+//                32 further): the reduction is register-local plus one cross-lane step.
+enum { kStore = 0, kArgmax = 2 };
+// (a transposed store -- weight on the row side, one 16-byte store per 4 values of a lane -- was measured: 3 us SLOWER
+//  than the 4-byte stores of 128-byte row segments on the 4800 x 2560 / 2048 outputs)
+
+// tile (row0, col0) of workgroup `bid`: XCD x (= bid % 8) walks the contiguous range [x per, (x + 1) per) of the tile order
+// "groups of kGroupM row tiles, column-major inside a group"
+__device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int &tm, int &tn) {
+  const int total = tiles_m * tiles_n, per = (total + 7) >> 3;
+  const int t = (bid & 7) * per + (bid >> 3);
+  if ((bid >> 3) >= per || t >= total) return false;
+  const int gsz_full = kGroupM * tiles_n, g = t / gsz_full, first_m = g * kGroupM;
+  const int gm = min(tiles_m - first_m, kGroupM), in_g = t - g * gsz_full;
+  tm = first_m + in_g % gm;
+  tn = in_g / gm;
+  return true;
+}
+
+// the 24 (NJ = 2) MFMAs of one wavefront on one K stage of 32: fragments at slots fa / fb of the stage image `st`
+template <int NJ>
+__device__ __forceinline__ void mfma_stage(const uint4 *st, int a_lo_off, int b_lo_off, const int (&fa)[2][2],
+                                           const int (&fb)[NJ][2], f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ]) {
+  // all fragment reads of the stage first: the second K half lands under the MFMAs of the first
+  h8 f_ah[2][2], f_al[2][2], f_bh[2][NJ], f_bl[2][NJ];
+#ifdef GVL_ABLATE_LDS
+  st = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(st, 16));
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { f_ah[s][i] = __builtin_bit_cast(h8, make_uint4(fa[i][s], 1, 2, 3)); f_al[s][i] = f_ah[s][i]; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { f_bh[s][j] = __builtin_bit_cast(h8, make_uint4(fb[j][s], 5, 6, 7)); f_bl[s][j] = f_bh[s][j]; }
+  }
+  if (false)
+#endif
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f_ah[s][i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);
+      f_al[s][i] = *reinterpret_cast<const h8 *>(&st[a_lo_off + fa[i][s]]);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f_bh[s][j] = *reinterpret_cast<const h8 *>(&st[fb[j][s]]);
+      f_bl[s][j] = *reinterpret_cast<const h8 *>(&st[b_lo_off + fb[j][s]]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bh[s][j], acc_m[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s][j], acc_x[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s][j], acc_x[i][j], 0, 0, 0);
+      }
+}
+
+
+}  // namespace gvl16

@@ -1,0 +1,501 @@
+// gvl_layers.hip -- the dense layers AROUND the deformable attention, for inference: every nn.Linear of the
+// encoder / decoder layers (pdvc/ops/modules/ms_deform_attn.py:95,99-100,125: value_proj, sampling_offsets +
+// attention_weights, output_proj; pdvc/deformable_transformer.py:189-199,257-261: linear1 / linear2 of the FFN;
+// :266-270 the in / out projections of nn.MultiheadAttention; pdvc/pdvc.py:1166-1178 the box MLP) and the LayerNorms
+// between them (:193,198,270,277,261), on the fp16 matrix cores at fp32 accuracy.
+//
+// k_lin_f16x3       out = epilogue((A [+ A2]) . W^T + bias): A is the fp32 ACTIVATION as its producer left it; it is
+//                   split into the (hi, 2^11 residual) fp16 planes of gvl_gemm16.hip IN THE LOAD PATH (global -> registers
+//                   -> two v_cvt per element -> LDS), so no plane ever exists in HBM and no separate split pass runs;
+//                   the weight arrives as planes (split once per parameter version) through LDS-DMA.  The row scale of the
+//                   split comes from a per-row maximum `amax` that the PRODUCER of A leaves behind (LayerNorm kernel below:
+//                   register-local; the sampling kernel and this kernel's own epilogue: one atomic max per row and tile).
+//                   One launch serves several column SEGMENTS of a concatenated weight, each with its own output, epilogue
+//                   and A variant (e.g. [value_proj | sampling_offsets ; attention_weights]: the first segment multiplies
+//                   src, the second src + pos).  Epilogue per segment: bias, ReLU, residual add, zeroed rows
+//                   (masked_fill of ms_deform_attn.py:96-97), row maxima of the result.
+// k_ln_rows         LayerNorm of (R, C) rows, one wavefront per row, + the row maxima of the result and of result + pos
+// k_row_absmax      row maxima of a tensor some other kernel produced (attention core of nn.MultiheadAttention)
+//
+// Accuracy: as gvl_gemm16.hip (three fp16 MFMAs per product, fp32 accumulate, lo.lo dropped): |error| <= 2^-21 sum|a||w|
+// + K 2^-33 amax_row max|w|; tests/test_gpu_layers.py holds every product to the fp64 result at the fp32 library GEMM's
+// own error.  A non-finite element of A makes its output row non-finite (hi = inf / NaN, lo = NaN), as in an fp32 GEMM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "gvl_common.hpp"
+#include "gvl_gemm16_common.hpp"
+#include "gvl_msda.h"
+
+namespace {
+
+using gvl::fail;
+using namespace gvl16;
+
+constexpr int kLinBN = 64, kLinThreads = 256, kMaxSeg = 4;
+
+struct LinParams {
+  const float *A;
+  int64_t lda;
+  const float *A2;
+  int64_t lda2;
+  int a2_rows;
+  const _Float16 *Wh, *Wl;
+  const float *Ws, *bias;
+  int R, N, K, tiles_m, tiles_n, nseg, xcd_cols;
+  gvl_lin_seg seg[kMaxSeg];
+};
+
+// s = 2^floor(log2 amax) (exponent clamped to the range whose reciprocal is representable), inv = 1 / s
+__device__ __forceinline__ void scale_of(float amax, float &s, float &inv) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  e = min(max(e, 1), 253);
+  s = __uint_as_float((uint32_t)e << 23);
+  inv = __uint_as_float((uint32_t)(254 - e) << 23);
+}
+
+__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, (h2){a, b});
+}
+
+// 4 consecutive k of one row -> 8 bytes per plane
+__device__ __forceinline__ void split4(const float4 &x, float inv, uint2 &hi, uint2 &lo) {
+  const float a[4] = {x.x * inv, x.y * inv, x.z * inv, x.w * inv};
+  _Float16 hh[4], ll[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    hh[c] = (_Float16)a[c];
+    ll[c] = (_Float16)((a[c] - (float)hh[c]) * kLoScale);
+  }
+  hi = make_uint2(pack2(hh[0], hh[1]), pack2(hh[2], hh[3]));
+  lo = make_uint2(pack2(ll[0], ll[1]), pack2(ll[2], ll[3]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Workgroup = 4 wavefronts on a 128 x 64 tile (wavefront tile 64 x 32: 2 MFMA tiles x {leading, cross} accumulators),
+// K in stages of 32 through two LDS stage images [A hi | A lo | W hi | W lo] of 24 KB.
+//   A path   4 global_load_dwordx4 per thread and stage (+ 4 of the addend), each instruction 8 whole 128-byte lines,
+//            requested TWO stages ahead into one of two register sets, split and written as 8 ds_write_b64 into the
+//            swizzled plane image one stage ahead;
+//   W path   the weight planes travel the same way (one 16-byte chunk per plane and thread).  NOT by LDS-DMA: hipcc marks a
+//            pending global_load_lds as a FLAT access of both memories and then forces EVERY later vmcnt / lgkmcnt wait to
+//            zero -- the wait in front of the split arithmetic would drain the rows requested for two stages ahead once
+//            per stage (seen in the ISA); with ordinary loads the waits are counted (vmcnt(n) = exactly the older set);
+//   barrier  one per stage, raw s_barrier after `s_waitcnt lgkmcnt(0)`: the loads in flight are not waited for.
+// 304 / 192 tiles for the 4800 / 3008 x 512 products of cfg A, up to 1216 for the FFN: two workgroups per CU.
+template <bool HAS_A2>
+__global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p) {
+  constexpr int kASlots = kBM * 4, kBSlots = kLinBN * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  constexpr int nA = HAS_A2 ? 8 : 4;                                   // global loads of one A register set
+  __shared__ uint4 smem[2 * kStageSlots];
+
+  int tm, tn;
+  if (p.xcd_cols) {
+    // column tile = XCD (workgroup id % 8): the (b, m) slabs of `value` are written from the XCD whose L2 the sampling
+    // kernel reads them from (its workgroups of head m sit on XCD m: ids B M apart, M = 8)
+    tn = (int)blockIdx.x & 7;
+    tm = (int)blockIdx.x >> 3;
+    if (tn >= p.tiles_n || tm >= p.tiles_m) return;
+  } else if (!tile_of((int)blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) {
+    return;
+  }
+  const int m0 = tm * kBM, n0 = tn * kLinBN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+  const int R = p.R, N = p.N, K = p.K;
+
+  // the segment of this column tile (workgroup-uniform)
+  int si = 0;
+#pragma unroll
+  for (int s = 1; s < kMaxSeg; ++s)
+    if (s < p.nseg && p.seg[s].n_begin <= n0) si = s;
+  const gvl_lin_seg sg = p.seg[si];
+  const bool addend = HAS_A2 && (sg.flags & GVL_LIN_ADDEND);
+
+  // ---- A path.  One K stage of a row is exactly one 128-byte line (32 floats): wavefront w covers rows 32 w .. 32 w + 31
+  // of the tile with four loads, load i = rows 32 w + 8 i + (lane >> 3), 16-byte piece lane & 7 -- every instruction reads 8
+  // whole lines.  Addresses are (workgroup-uniform base + k offset) + a 32-bit per-thread offset fixed for the whole
+  // kernel, so that no vector register is spent on address arithmetic inside the loop (with 64-bit per-thread pointers the
+  // register allocator recycled the destination of an in-flight load as the next address and serialised the prefetch).
+  const int apiece = lane & 7, arow0 = wave * 32 + (lane >> 3);
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  // buffer loads: the descriptor (uniform base) sits in scalar registers, the per-thread part is a 32-bit offset fixed for
+  // the whole kernel, the K offset of a stage travels in the instruction's scalar offset operand
+  // (the base is passed through readfirstlane: hipcc must be able to PROVE the descriptor wave-uniform, or it wraps every
+  //  buffer load in a waterfall loop)
+  auto rsrc_of = [](const void *ptr) {
+    const uint64_t u = (uint64_t)(uintptr_t)ptr;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  };
+  const auto a_rs = rsrc_of(p.A + (int64_t)m0 * p.lda);
+  const auto a2_rs = rsrc_of(HAS_A2 ? p.A2 : p.A);
+  const auto wh_rs = rsrc_of(p.Wh + (int64_t)n0 * K);
+  const auto wl_rs = rsrc_of(p.Wl + (int64_t)n0 * K);
+  int a_off[4], a2_off[4];
+  uint32_t a_dst[4];
+  float a_inv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = arow0 + 8 * i, grow = min(m0 + row, R - 1);
+    a_off[i] = (int)(((int64_t)(grow - m0) * p.lda + apiece * 4) * 4);
+    a2_off[i] = HAS_A2 ? (int)(((int64_t)(grow % p.a2_rows) * p.lda2 + apiece * 4) * 4) : 0;
+    float s_;
+    scale_of(sg.amax_in[grow], s_, a_inv[i]);
+    a_dst[i] = (uint32_t)lds_slot(row, apiece >> 1) * 16u + (uint32_t)(apiece & 1) * 8u;     // byte offset inside a plane image
+  }
+
+  // ---- W path: thread t carries chunk t & 3 of weight row t >> 2 of the tile, both planes (same swizzled image)
+  const int wrow = tid >> 2, wch = tid & 3;
+  const int w_off = (min(wrow, N - 1 - n0) * K + wch * 8) * 2;
+  const int w_dst = 2 * kASlots + lds_slot(wrow, wch);
+
+  struct ASet { u4v x[4], y[4], wh, wl; };
+  auto load_a = [&](ASet &s, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.x[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_off[i], k0 * 4, 0);
+    if (HAS_A2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off[i], k0 * 4, 0);
+    }
+    s.wh = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_off, k0 * 2, 0);
+    s.wl = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off, k0 * 2, 0);
+  };
+  auto store_a = [&](ASet &s, int buf) {
+    char *st = reinterpret_cast<char *>(smem + buf * kStageSlots);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 x = __builtin_bit_cast(float4, s.x[i]);
+      if (HAS_A2 && addend) {
+        const float4 y = __builtin_bit_cast(float4, s.y[i]);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+      uint2 hi, lo;
+      split4(x, a_inv[i], hi, lo);
+      *reinterpret_cast<uint2 *>(st + a_dst[i]) = hi;
+      *reinterpret_cast<uint2 *>(st + kASlots * 16 + a_dst[i]) = lo;
+    }
+    reinterpret_cast<uint4 *>(st)[w_dst] = __builtin_bit_cast(uint4, s.wh);
+    reinterpret_cast<uint4 *>(st)[kBSlots + w_dst] = __builtin_bit_cast(uint4, s.wl);
+  };
+
+  f16acc acc_m[2], acc_x[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_m[i][r] = 0.f; acc_x[i][r] = 0.f; }
+
+  const int frow = lane & 31, fh = lane >> 5;
+  int fa[2][2], fb[2];                                                 // [i][s] | [s]
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i][s] = lds_slot(wm + 32 * i + frow, 2 * s + fh);
+    fb[s] = 2 * kASlots + lds_slot(wn + frow, 2 * s + fh);
+  }
+
+  const int KT = K / kBK;
+  ASet set0, set1;
+  load_a(set0, 0);
+  load_a(set1, min(1, KT - 1) * kBK);
+  store_a(set0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // one K stage: `cur` holds the A rows of stage kt + 1 (requested one stage ago), `nxt` receives those of stage kt + 2
+#define GVL_LIN_STAGE(cur, nxt)                                                                         \
+  {                                                                                                      \
+    const int buf = kt & 1;                                                                              \
+    const uint4 *st = smem + buf * kStageSlots;                                                          \
+    load_a(nxt, min(kt + 2, KT - 1) * kBK);                                                              \
+    h8 f_ah[2][2], f_al[2][2], f_bh[2], f_bl[2];                                                         \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+        f_ah[s][i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);                                       \
+        f_al[s][i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[i][s]]);                             \
+      }                                                                                                  \
+      f_bh[s] = *reinterpret_cast<const h8 *>(&st[fb[s]]);                                               \
+      f_bl[s] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[s]]);                                     \
+    }                                                                                                    \
+    store_a(cur, buf ^ 1);                                                                               \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 2; ++i) {        \
+      acc_m[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bh[s], acc_m[i], 0, 0, 0);         \
+      acc_x[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s], acc_x[i], 0, 0, 0);         \
+      acc_x[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s], acc_x[i], 0, 0, 0);         \
+    }                                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("" ::: "memory");                                                                       \
+    ++kt;                                                                                                \
+  }
+  int kt = 0;
+  while (kt < KT) {
+    GVL_LIN_STAGE(set1, set0)
+    if (kt < KT) GVL_LIN_STAGE(set0, set1)
+  }
+#undef GVL_LIN_STAGE
+  (void)nA;
+
+  // ---- epilogue.  C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  // Every load (row scales, residual, mask) is issued before the first store: a load between two stores makes the
+  // compiler wait for all stores issued so far.
+  const int row0 = m0 + wm, col = n0 + wn + frow;
+  const bool col_ok = col < N;
+  const int colc = min(col, N - 1), ocol = colc - sg.n_begin;
+  const float cs = p.Ws[colc];
+  const float cb = p.bias ? p.bias[colc] : 0.f;
+  const bool relu = sg.flags & GVL_LIN_RELU;
+  float v[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
+      float s_, inv_;
+      scale_of(sg.amax_in[row], s_, inv_);
+      v[i][r] = s_;
+    }
+  float res[2][16];
+  if (sg.resid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
+        res[i][r] = sg.resid[(int64_t)row * sg.ldr + ocol];
+      }
+  }
+  unsigned keep[2] = {0xffffu, 0xffffu};
+  if (sg.rowmask) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
+        if (sg.rowmask[row]) keep[i] &= ~(1u << r);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float o = (acc_m[i][r] + acc_x[i][r] * kLoInv) * (v[i][r] * cs) + cb;
+      if (relu) o = fmaxf(o, 0.f);
+      if (sg.resid) o = res[i][r] + o;
+      if (!((keep[i] >> r) & 1u)) o = 0.f;
+      v[i][r] = o;
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (col_ok && row < R) sg.out[(int64_t)row * sg.ldo + ocol] = v[i][r];
+    }
+  if (sg.amax_out) {
+    // Row maxima of this wavefront's 64 x 32 part: a butterfly reduce-SCATTER over the 32 lanes that hold one row's
+    // columns -- each exchange halves the registers a lane keeps -- leaves ONE row per lane: block i = lane & 1,
+    // register (lane >> 1) & 15.  31 exchanges instead of 160; then one atomic max per lane (non-negative floats order
+    // like their bit patterns; a NaN is larger than everything and survives).
+    float m[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m[i][r] = col_ok ? fabsf(v[i][r]) : 0.f;
+    float one[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float a8[8], a4[4], a2[2];
+      const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float mine = b4 ? m[i][k + 8] : m[i][k], send = b4 ? m[i][k] : m[i][k + 8];
+        a8[k] = fmaxf(mine, __shfl_xor(send, 16, 64));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float mine = b3 ? a8[k + 4] : a8[k], send = b3 ? a8[k] : a8[k + 4];
+        a4[k] = fmaxf(mine, __shfl_xor(send, 8, 64));
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float mine = b2 ? a4[k + 2] : a4[k], send = b2 ? a4[k] : a4[k + 2];
+        a2[k] = fmaxf(mine, __shfl_xor(send, 4, 64));
+      }
+      const float mine = b1 ? a2[1] : a2[0], send = b1 ? a2[0] : a2[1];
+      one[i] = fmaxf(mine, __shfl_xor(send, 2, 64));
+    }
+    const bool b0 = lane & 1;
+    const float mine = b0 ? one[1] : one[0], send = b0 ? one[0] : one[1];
+    const float rmax = fmaxf(mine, __shfl_xor(send, 1, 64));
+    const int rr = (lane >> 1) & 15;
+    const int row = row0 + 32 * (int)b0 + (rr & 3) + 8 * (rr >> 2) + 4 * fh;
+    if (row < R) atomicMax(reinterpret_cast<unsigned *>(sg.amax_out) + row, __float_as_uint(rmax));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last axis, one wavefront per row (C <= 1024, C % 4 == 0): y = (x - mean) / sqrt(var + eps) * gamma
+// + beta (biased variance, as torch.nn.LayerNorm), two passes over registers.  Also the row maxima the consumers of y
+// need: amax_y[r] = max |y|, amax_yp[r] = max |y + pos[r % pos_rows]| (the query of the next attention is y + pos).
+constexpr int kLnMaxV = 4;                                             // float4 per lane: C <= 1024
+
+__global__ void __launch_bounds__(256) k_ln_rows(const float *__restrict__ x, int R, int C, const float *__restrict__ gamma,
+                                                 const float *__restrict__ beta, float eps, const float *__restrict__ pos,
+                                                 int pos_rows, float *__restrict__ y, float *__restrict__ amax_y,
+                                                 float *__restrict__ amax_yp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const int n4 = C >> 2;
+  const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)row * C);
+  float4 v[kLnMaxV];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < kLnMaxV; ++k) {
+    const int i = lane + 64 * k;
+    v[k] = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < kLnMaxV; ++k) {
+    if (lane + 64 * k < n4) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.f / sqrtf(sq / (float)C + eps);
+  const float4 *g4 = reinterpret_cast<const float4 *>(gamma), *b4 = reinterpret_cast<const float4 *>(beta);
+  const float4 *p4 = pos ? reinterpret_cast<const float4 *>(pos + (int64_t)(row % pos_rows) * C) : nullptr;
+  float4 *yr = reinterpret_cast<float4 *>(y + (int64_t)row * C);
+  float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < kLnMaxV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      const float4 g = g4[i], b = b4[i];
+      float4 o;
+      o.x = (v[k].x - mean) * rstd * g.x + b.x;
+      o.y = (v[k].y - mean) * rstd * g.y + b.y;
+      o.z = (v[k].z - mean) * rstd * g.z + b.z;
+      o.w = (v[k].w - mean) * rstd * g.w + b.w;
+      yr[i] = o;
+      m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      if (p4) {
+        const float4 q = p4[i];
+        m1 = fmaxf(fmaxf(m1, fmaxf(fabsf(o.x + q.x), fabsf(o.y + q.y))), fmaxf(fabsf(o.z + q.z), fabsf(o.w + q.w)));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    m0 = fmaxf(m0, __shfl_xor(m0, o, 64));
+    m1 = fmaxf(m1, __shfl_xor(m1, o, 64));
+  }
+  if (lane == 0) {
+    if (amax_y) amax_y[row] = m0;
+    if (amax_yp) amax_yp[row] = m1;
+  }
+}
+
+// row maxima of x (R, C) [+ pos]: what k_lin_f16x3 needs for an A operand some other kernel produced
+__global__ void __launch_bounds__(256) k_row_absmax(const float *__restrict__ x, int64_t ldx, int R, int C,
+                                                    const float *__restrict__ pos, int64_t ldp, int pos_rows,
+                                                    float *__restrict__ amax_x, float *__restrict__ amax_xp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const int n4 = C >> 2;
+  const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)row * ldx);
+  const float4 *p4 = pos ? reinterpret_cast<const float4 *>(pos + (int64_t)(row % pos_rows) * ldp) : nullptr;
+  float m0 = 0.f, m1 = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    const float4 o = xr[i];
+    m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    if (p4) {
+      const float4 q = p4[i];
+      m1 = fmaxf(fmaxf(m1, fmaxf(fabsf(o.x + q.x), fabsf(o.y + q.y))), fmaxf(fabsf(o.z + q.z), fabsf(o.w + q.w)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    m0 = fmaxf(m0, __shfl_xor(m0, o, 64));
+    m1 = fmaxf(m1, __shfl_xor(m1, o, 64));
+  }
+  if (lane == 0) {
+    if (amax_x) amax_x[row] = m0;
+    if (amax_xp) amax_xp[row] = m1;
+  }
+}
+
+}  // namespace
+
+extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2, int64_t lda2, int a2_rows, int R, int K,
+                                    const void *w_hi, const void *w_lo, const float *w_scale, const float *bias, int N,
+                                    const gvl_lin_seg *segs, int nseg, int flags, void *stream) {
+  if (R < 0 || N <= 0 || K <= 0 || (K % kBK) || (N % kLinBN))
+    return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: needs K %% 32 == 0 and N %% 64 == 0 (got R=%d N=%d K=%d)", R, N, K);
+  if (nseg < 1 || nseg > kMaxSeg || !segs) return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: 1..%d segments", kMaxSeg);
+  if ((int64_t)N * K >= (int64_t)1 << 31) return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: weight plane of more than 2^31 elements");
+  if (R == 0) return 0;
+  if (!a || !w_hi || !w_lo || !w_scale) return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: null pointer");
+  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15))
+    return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: a (lda %% 4 == 0) and the weight planes must be 16-byte aligned");
+  bool any_addend = false;
+  for (int s = 0; s < nseg; ++s) {
+    const gvl_lin_seg &g = segs[s];
+    if (g.n_begin % kLinBN || g.n_begin < 0 || g.n_begin >= N || (s == 0 && g.n_begin != 0) ||
+        (s > 0 && g.n_begin <= segs[s - 1].n_begin))
+      return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: segment %d starts at column %d (ascending multiples of 64 from 0)", s, g.n_begin);
+    const int n_end = s + 1 < nseg ? segs[s + 1].n_begin : N;
+    if (!g.out || !g.amax_in || g.ldo < n_end - g.n_begin || (g.resid && g.ldr < n_end - g.n_begin))
+      return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: segment %d: null output / row maxima or a leading dimension too small", s);
+    any_addend |= (g.flags & GVL_LIN_ADDEND) != 0;
+  }
+  if (any_addend && (!a2 || a2_rows <= 0 || lda2 < K || (lda2 & 3) || ((uintptr_t)a2 & 15)))
+    return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: an ADDEND segment needs a2 (16-byte aligned, lda2 >= K, a2_rows > 0)");
+  LinParams p;
+  p.A = a; p.lda = lda; p.A2 = any_addend ? a2 : nullptr; p.lda2 = lda2; p.a2_rows = any_addend ? a2_rows : 1;
+  p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = bias;
+  p.R = R; p.N = N; p.K = K;
+  p.tiles_m = (R + kBM - 1) / kBM; p.tiles_n = N / kLinBN; p.nseg = nseg;
+  p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n == 8;
+  for (int s = 0; s < kMaxSeg; ++s) p.seg[s] = segs[s < nseg ? s : nseg - 1];
+  const int grid = p.xcd_cols ? p.tiles_m * 8 : (p.tiles_m * p.tiles_n + 7) / 8 * 8;
+  if (any_addend)
+    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<addend>", k_lin_f16x3<true>, dim3(grid), dim3(kLinThreads), 0,
+                       (hipStream_t)stream, p);
+  return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3", k_lin_f16x3<false>, dim3(grid), dim3(kLinThreads), 0,
+                     (hipStream_t)stream, p);
+}
+
+extern "C" int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float *gamma, const float *beta, float eps,
+                                       const float *pos, int pos_rows, float *y, float *amax_y, float *amax_ypos,
+                                       void *stream) {
+  if (R < 0 || C <= 0 || (C & 3) || C > 256 * kLnMaxV)
+    return fail(GVL_EINVAL, "gvl_layer_norm_rows_f32: needs C %% 4 == 0 and C <= %d (got R=%d C=%d)", 256 * kLnMaxV, R, C);
+  if (R == 0) return 0;
+  if (!x || !gamma || !beta || !y || (pos && pos_rows <= 0)) return fail(GVL_EINVAL, "gvl_layer_norm_rows_f32: null pointer");
+  if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)pos) & 15)
+    return fail(GVL_EINVAL, "gvl_layer_norm_rows_f32: operands must be 16-byte aligned");
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_ln_rows", k_ln_rows, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
+                     R, C, gamma, beta, eps, pos, pos ? pos_rows : 1, y, amax_y, amax_ypos);
+}
+
+extern "C" int gvl_row_absmax_f32(const float *x, int64_t ldx, int R, int C, const float *pos, int64_t ldp, int pos_rows,
+                                  float *amax_x, float *amax_xpos, void *stream) {
+  if (R < 0 || C <= 0 || (C & 3) || ldx < C || (ldx & 3)) return fail(GVL_EINVAL, "gvl_row_absmax_f32: needs C %% 4 == 0, ldx %% 4 == 0");
+  if (R == 0) return 0;
+  if (!x || (!amax_x && !amax_xpos) || (pos && (pos_rows <= 0 || ldp < C || (ldp & 3))))
+    return fail(GVL_EINVAL, "gvl_row_absmax_f32: null pointer / bad pos");
+  if (((uintptr_t)x | (uintptr_t)pos) & 15) return fail(GVL_EINVAL, "gvl_row_absmax_f32: operands must be 16-byte aligned");
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_row_absmax", k_row_absmax, dim3((R + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, R, C, pos, ldp, pos ? pos_rows : 1, amax_x, amax_xpos);
+}

@@ -465,13 +465,17 @@ __device__ inline void resolve_ops(const RawOps &r, float invT, float invP, int 
 // ------------------------------------------------------------------------------------------------------
 // t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
 // ------------------------------------------------------------------------------------------------------
-template <int PAD, bool FULL16, bool FUSED, bool L0G, typename VT>
+// AMAX: additionally leave max |out[b, q, :]| per output ROW in amax_out (B*Q floats, zero-initialised by the caller) --
+// the row maximum the split-fp16 output projection behind it (gvl_layers.hip) derives its operand scale from.  A row's
+// 512 channels come from the 8 heads' workgroups: one DPP row reduction + one atomic max per (row, head).
+template <int PAD, bool FULL16, bool FUSED, bool L0G, typename VT, bool AMAX = false>
 __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ value,
                                                      const int64_t *__restrict__ shapes,
                                                      const int64_t *__restrict__ lsi, const void *__restrict__ loc,
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
                                                      int P, int RD, int nchunk, VT *__restrict__ out,
-                                                     unsigned long long *__restrict__ stamps) {
+                                                     unsigned long long *__restrict__ stamps,
+                                                     unsigned *__restrict__ amax_out) {
   extern __shared__ float4 slab4[];
   // diagnostics (gvl_msda_debug_stamps): 100 MHz wall-clock stamps per workgroup {start, slab staged, loop done}
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
@@ -593,6 +597,10 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 #undef GVL_FWD_STEP
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
     if (act) st4_stream(out, (((int64_t)b * Q + q) * M + m) * 16 + j, acc);
+    if (AMAX) {
+      const float mx = row_allmax(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+      if (act && j == 0) atomicMax(amax_out + (int64_t)b * Q + q, __float_as_uint(mx));
+    }
     if (qb + nw * 4 < q1) prep(r_next, roff_c, cc_c);
   }
   if (stamps) {
@@ -1327,7 +1335,8 @@ int pick_chunks(const char *env, int BM, int Q, int target_wgs) {
 // ---- launchers of the t1d_d64 kernels, shared by the fp32 / bf16 and the plain / fused entry points ------------------
 template <typename VT, bool FUSED>
 int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, const void *p0, const float *p1, int B,
-                int S, int M, int L, int Q, int P, int RD, int pad, const SlabPlan &plan, VT *out, hipStream_t st) {
+                int S, int M, int L, int Q, int P, int RD, int pad, const SlabPlan &plan, VT *out, hipStream_t st,
+                float *amax_out = nullptr) {
   // one 1024-thread workgroup per CU (measured best on MI355X: the 47 KB slab is staged once per CU and 16
   // wavefronts hide the LDS latency); GVL_MSDA_FWD_{THREADS,CHUNKS} override for tuning sweeps
   const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
@@ -1343,11 +1352,20 @@ int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
     kern = plan.l0g ? k_fwd_t1d_d64<kPadBorder, true, FUSED, true, VT>
                     : (full || FUSED) ? k_fwd_t1d_d64<kPadBorder, true, FUSED, false, VT>
                                       : k_fwd_t1d_d64<kPadBorder, false, false, false, VT>;
+  if constexpr (FUSED && std::is_same<VT, float>::value) {
+    if (amax_out)                                                     // (fused fp32 form only: what the inference layers use)
+      kern = pad == kPadZeros ? (plan.l0g ? k_fwd_t1d_d64<kPadZeros, true, true, true, VT, true>
+                                          : k_fwd_t1d_d64<kPadZeros, true, true, false, VT, true>)
+                              : (plan.l0g ? k_fwd_t1d_d64<kPadBorder, true, true, true, VT, true>
+                                          : k_fwd_t1d_d64<kPadBorder, true, true, false, VT, true>);
+  } else if (amax_out) {
+    return fail(GVL_EINVAL, "gvl_msda: row maxima are produced by the fused fp32 forward only");
+  }
   if (int rc = ensure_lds(kern, lds)) return rc;
   g_last_impl = FUSED ? 3 : 2;
   return gvl::launch(GVL_PROF_FWD_T1D, Q, B, FUSED ? "k_fwd_t1d_d64<fused>" : "k_fwd_t1d_d64", kern,
                      dim3(nchunk * B * M), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
-                     nchunk, out, g_fwd_stamps);
+                     nchunk, out, g_fwd_stamps, reinterpret_cast<unsigned *>(amax_out));
 }
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
@@ -1528,14 +1546,15 @@ int fused_eligible(int B, int S, int M, int D, int L, int Q, int P, int RD, int 
 template <typename VT>
 int fused_forward(const VT *value, const int64_t *shapes, const int64_t *lsi, const VT *proj, const float *ref,
                          int B, int S, int M, int D, int L, int Q, int P, int RD, int pad_mode,
-                         const int64_t *shapes_host, const int64_t *lsi_host, VT *out, void *stream) {
+                         const int64_t *shapes_host, const int64_t *lsi_host, VT *out, void *stream,
+                         float *amax_out = nullptr) {
   if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
   if ((int64_t)B * Q == 0) return 0;
   if (!value || !shapes || !lsi || !proj || !ref || !out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: null pointer");
   const SlabPlan plan = slab_plan(S, L, P, shapes_host);
   if (!plan.ok) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: slab of %d rows does not fit LDS", S);
   return run_fwd_t1d<VT, true>(value, shapes, lsi, proj, ref, B, S, M, L, Q, P, RD, pad_mode, plan, out,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, amax_out);
 }
 
 template <typename VT>
@@ -1653,6 +1672,14 @@ int gvl_msda1d_fused_forward_f32(const float *value, const int64_t *shapes, cons
                                  void *stream) {
   return fused_forward<float>(value, shapes, lsi, proj, ref, B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host,
                               out, stream);
+}
+int gvl_msda1d_fused_forward_amax_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
+                                      const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
+                                      int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
+                                      float *amax_out, void *stream) {
+  if (!amax_out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward_amax_f32: null pointer");
+  return fused_forward<float>(value, shapes, lsi, proj, ref, B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host,
+                              out, stream, amax_out);
 }
 int gvl_msda1d_fused_forward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                                   const uint16_t *proj, const float *ref, int B, int S, int M, int D, int L, int Q,

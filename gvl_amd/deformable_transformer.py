@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import layers as _layers
 from .ops.modules import MSDeformAttn
 from .linear import Linear
 
@@ -113,6 +114,10 @@ class DeformableTransformerEncoder(nn.Module):
         return (ref[:, :, None] * valid_ratios[:, None])[..., None]
 
     def forward(self, src, temporal_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
+        if _layers.encoder_eligible(self, src, temporal_shapes):
+            # inference: the layers' Linear / LayerNorm chain on the hand-written kernels of gvl_amd/layers.py
+            return _layers.encoder_forward(self, src, temporal_shapes, level_start_index, valid_ratios, pos,
+                                           padding_mask)
         ref = self.get_reference_points(temporal_shapes, valid_ratios, device=src.device)
         out = src
         for layer in self.layers:
@@ -171,6 +176,11 @@ class DeformableTransformerDecoder(nn.Module):
 
     def forward(self, tgt, reference_points, src, src_temporal_shapes, src_level_start_index, src_valid_ratios,
                 query_pos=None, src_padding_mask=None, query_padding_mask=None, disable_iterative_refine=False):
+        self.__dict__["_gvl_deltas"] = None
+        if _layers.decoder_eligible(self, tgt, src, src_temporal_shapes):
+            return _layers.decoder_forward(self, tgt, reference_points, src, src_temporal_shapes,
+                                           src_level_start_index, src_valid_ratios, query_pos, src_padding_mask,
+                                           query_padding_mask, disable_iterative_refine)
         out = tgt
         hs, refs = [], []
         for lid, layer in enumerate(self.layers):

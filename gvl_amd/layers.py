@@ -1,0 +1,371 @@
+"""Inference form of the transformer layers around the deformable attention: every ``nn.Linear`` of the encoder /
+decoder layers (pdvc/deformable_transformer.py:189-199,257-280; pdvc/ops/modules/ms_deform_attn.py:95,99-100,125) and
+the box MLP (pdvc/pdvc.py:1166-1178) on ``gvl_linear_f16x3_f32`` -- fp32 activations split into fp16 planes inside the
+kernel's load path, three fp16 MFMAs per product, fp32 accuracy (include/gvl_msda.h) -- with bias / ReLU / residual /
+masked rows in the GEMM's epilogue and LayerNorm as one kernel that also leaves the row maxima the next product needs.
+
+The modules keep their parameters, names and training path; ``DeformableTransformerEncoder / Decoder.forward`` call
+into this file when ``enabled()`` and the call is inference (no grad, eval mode, fp32, shapes in the kernels' domain).
+``GVL_LAYERS=torch`` keeps the PyTorch formulation for A/B runs.
+
+Row maxima ("amax"): the split needs a power-of-two scale per activation row.  Every producer on the path leaves
+max |row| behind for its consumer -- LayerNorm (register-local), the sampling kernel and the GEMM epilogue (one atomic
+max per row and tile into a zero-initialised vector), ``row_absmax`` for tensors that come from PyTorch ops.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import MultiScaleDeformableAttention as MSDA
+from . import _lib
+
+LIN_ADDEND, LIN_RELU = 1, 2
+LIN_XCD_COLUMNS = 1
+
+
+def enabled():
+    return os.environ.get("GVL_LAYERS", "") != "torch"
+
+
+class _Seg(ctypes.Structure):                      # include/gvl_msda.h: gvl_lin_seg
+    _fields_ = [("n_begin", ctypes.c_int), ("flags", ctypes.c_int), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
+                ("amax_in", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("ldr", ctypes.c_int64),
+                ("amax_out", ctypes.c_void_p), ("rowmask", ctypes.c_void_p)]
+
+
+class Weights:
+    """[W_0; W_1; ...] (each padded to a multiple of 64 rows) as fp16 planes + the concatenated bias; ``starts[i]`` is the
+    first column of block i.  Built once per parameter version (``cached``)."""
+
+    def __init__(self, pairs):
+        ws, bs, self.starts, self.widths = [], [], [], []
+        n = 0
+        for w, b in pairs:
+            w = w.detach()
+            rows = w.shape[0]
+            pad = (-rows) % 64
+            self.starts.append(n)
+            self.widths.append(rows)
+            ws.append(w if not pad else torch.cat([w, w.new_zeros(pad, w.shape[1])], 0))
+            bias = b.detach() if b is not None else w.new_zeros(rows)
+            bs.append(bias if not pad else torch.cat([bias, bias.new_zeros(pad)], 0))
+            n += rows + pad
+        self.N, self.K = n, ws[0].shape[1]
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):
+            self.planes = MSDA.split_rows(torch.cat(ws, 0).float().contiguous())
+            self.bias = torch.cat(bs, 0).float().contiguous()
+
+
+def cached(owner, name, params):
+    """Weights of `params` = [(weight, bias), ...] kept on `owner` until one of the parameters changes"""
+    key = tuple((p_.data_ptr(), p_._version) for pair in params for p_ in pair if p_ is not None)
+    store = owner.__dict__.setdefault("_gvl_lin_w", {})
+    hit = store.get(name)
+    if hit is None or hit[0] != key:
+        hit = store[name] = (key, Weights(params))
+    return hit[1]
+
+
+def seg(n_begin, out, amax_in, resid=None, amax_out=None, rowmask=None, relu=False, addend=False):
+    return dict(n_begin=n_begin, out=out, amax_in=amax_in, resid=resid, amax_out=amax_out, rowmask=rowmask, relu=relu,
+                addend=addend)
+
+
+def linear(a, w, segs, a2=None, flags=0):
+    """gvl_linear_f16x3_f32: a (R, K) fp32 (row stride a.stride(0)); a2 (rows2, K) the addend of ADDEND segments, row
+    r uses a2[r % rows2]; w: Weights; segs: list of seg(...) -- the outputs are written in place."""
+    R, K = a.shape
+    assert a.dtype == torch.float32 and a.stride(1) == 1 and K == w.K, (a.shape, a.stride(), w.K)
+    arr = (_Seg * len(segs))()
+    for i, s in enumerate(segs):
+        o = s["out"]
+        assert o.dtype == torch.float32 and o.stride(1) == 1 and o.shape[0] == R
+        r_ = s["resid"]
+        assert s["amax_in"].numel() == R and s["amax_in"].dtype == torch.float32
+        arr[i] = _Seg(s["n_begin"], (LIN_ADDEND if s["addend"] else 0) | (LIN_RELU if s["relu"] else 0), o.data_ptr(),
+                      o.stride(0), s["amax_in"].data_ptr(), r_.data_ptr() if r_ is not None else None,
+                      r_.stride(0) if r_ is not None else 0,
+                      s["amax_out"].data_ptr() if s["amax_out"] is not None else None,
+                      s["rowmask"].data_ptr() if s["rowmask"] is not None else None)
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().gvl_linear_f16x3_f32(
+            a.data_ptr(), a.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
+            a2.shape[0] if a2 is not None else 0, R, K, w.planes.hi.data_ptr(), w.planes.lo.data_ptr(),
+            w.planes.scale.data_ptr(), w.bias.data_ptr(), w.N, arr, len(segs), flags,
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "linear_f16x3")
+
+
+def layer_norm(x, norm, pos=None, want_amax=True):
+    """LayerNorm of the rows of x (R, C) -> (y, amax_y, amax_{y + pos} or None)   (gvl_layer_norm_rows_f32)"""
+    R, C = x.shape
+    y = torch.empty_like(x)
+    am = torch.empty(R, device=x.device, dtype=torch.float32) if want_amax else None
+    amp = torch.empty(R, device=x.device, dtype=torch.float32) if pos is not None else None
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gvl_layer_norm_rows_f32(
+            x.data_ptr(), R, C, norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
+            pos.data_ptr() if pos is not None else None, pos.shape[0] if pos is not None else 0, y.data_ptr(),
+            am.data_ptr() if am is not None else None, amp.data_ptr() if amp is not None else None,
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "layer_norm_rows")
+    return y, am, amp
+
+
+def row_absmax(x, pos=None, want_x=True):
+    """(max |x[r]|, max |x[r] + pos[r % rows]|) for x (R, C) with unit column stride   (gvl_row_absmax_f32)"""
+    R, C = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    am = torch.empty(R, device=x.device, dtype=torch.float32) if want_x else None
+    amp = torch.empty(R, device=x.device, dtype=torch.float32) if pos is not None else None
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gvl_row_absmax_f32(
+            x.data_ptr(), x.stride(0), R, C, pos.data_ptr() if pos is not None else None,
+            pos.stride(0) if pos is not None else 0, pos.shape[0] if pos is not None else 0,
+            am.data_ptr() if am is not None else None, amp.data_ptr() if amp is not None else None,
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "row_absmax")
+    return am, amp
+
+
+class _Arena:
+    """zero-initialised row-maximum vectors for the producers that use atomic max: ONE fill per forward"""
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n, device=device, dtype=torch.float32)
+        self.used = 0
+
+    def take(self, n):
+        n16 = (n + 3) // 4 * 4
+        assert self.used + n16 <= self.buf.numel()
+        out = self.buf[self.used:self.used + n]
+        self.used += n16
+        return out
+
+
+def _new(rows, cols, like):
+    return torch.empty(rows, cols, device=like.device, dtype=torch.float32)
+
+
+# ---- eligibility ------------------------------------------------------------------------------------------------------
+def _attn_ok(att, host_lengths, S):
+    return (att.fused and att.pad_mode in ("zeros", "border") and host_lengths is not None
+            and att.d_model // att.n_heads == 64 and att.n_levels * att.n_points == 16 and att.n_points == 4
+            and att.d_model % 64 == 0 and (S <= 600 or S - host_lengths[0][0] <= 600))
+
+
+def _plain(x):
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and not torch.is_grad_enabled()
+
+
+def encoder_eligible(enc, src, temporal_shapes):
+    host = getattr(temporal_shapes, "_gvl_host_lengths", None)
+    if not (enabled() and _plain(src) and not enc.training and len(enc.layers) > 0):
+        return False
+    for layer in enc.layers:
+        if not (_attn_ok(layer.self_attn, host, src.shape[1]) and layer.linear1.out_features % 64 == 0
+                and layer.activation is torch.nn.functional.relu and src.shape[-1] <= 1024):
+            return False
+    return True
+
+
+def decoder_eligible(dec, tgt, src, temporal_shapes):
+    host = getattr(temporal_shapes, "_gvl_host_lengths", None)
+    if not (enabled() and _plain(tgt) and _plain(src) and not dec.training and 0 < len(dec.layers) <= 4):
+        return False
+    for layer in dec.layers:
+        sa = layer.self_attn
+        if not (_attn_ok(layer.cross_attn, host, src.shape[1]) and layer.linear1.out_features % 64 == 0
+                and layer.activation is torch.nn.functional.relu and tgt.shape[-1] <= 1024
+                and sa._qkv_same_embed_dim and sa.in_proj_bias is not None and not sa.batch_first
+                and sa.bias_k is None and not sa.add_zero_attn):
+            return False
+    return True
+
+
+# ---- encoder ------------------------------------------------------------------------------------------------------------
+def _msda(att, value, proj, ref, shapes2d, lsi, B, Lq, arena):
+    am_o = arena.take(B * Lq)
+    M = att.n_heads
+    o = MSDA.msda1d_fused_forward(value.view(B, -1, M, att.d_model // M), shapes2d, lsi, proj.view(B, Lq, -1),
+                                  ref.contiguous(), att.n_levels, att.n_points, att.pad_mode, amax_out=am_o)
+    return o.view(B * Lq, -1), am_o
+
+
+def _ffn(layer, x, am_x, norm, arena, pos=None):
+    """x -> norm(x + linear2(relu(linear1(x))))   (deformable_transformer.py:189-191 / :257-261)"""
+    R, C = x.shape
+    h = _new(R, layer.linear1.out_features, x)
+    am_h = arena.take(R)
+    linear(x, cached(layer, "l1", [(layer.linear1.weight, layer.linear1.bias)]),
+           [seg(0, h, am_x, relu=True, amax_out=am_h)])
+    y = _new(R, C, x)
+    linear(h, cached(layer, "l2", [(layer.linear2.weight, layer.linear2.bias)]), [seg(0, y, am_h, resid=x)])
+    return layer_norm(y, norm, pos=pos)
+
+
+def encoder_forward(enc, src, temporal_shapes, level_start_index, valid_ratios, pos, padding_mask):
+    """DeformableTransformerEncoder.forward (deformable_transformer.py:202-226) for inference: 8 launches per layer
+    ([value_proj | offsets ; weights] product, sampling, output_proj + residual, LayerNorm, linear1 + ReLU, linear2 +
+    residual, LayerNorm) -> memory (B, S, C); its row maxima travel along as ``memory._gvl_amax``."""
+    from .ops.modules.ms_deform_attn import temporal_shapes_2d
+    B, S, C = src.shape
+    R = B * S
+    ref = enc.get_reference_points(temporal_shapes, valid_ratios, device=src.device)          # (B, S, L, 1)
+    shapes2d = temporal_shapes_2d(temporal_shapes, level_start_index)
+    x = src.reshape(R, C).contiguous()
+    posf = pos.reshape(R, C).contiguous() if pos is not None else None
+    am_x, am_xp = row_absmax(x, posf)
+    if posf is None:
+        am_xp = am_x
+    mask = padding_mask.reshape(R).contiguous().view(torch.uint8) if padding_mask is not None else None
+    arena = _Arena(2 * len(enc.layers) * (R + 4), src.device)
+    for layer in enc.layers:
+        att = layer.self_attn
+        n_proj = 2 * att.n_heads * att.n_levels * att.n_points
+        w = cached(att, "vp", [(att.value_proj.weight, att.value_proj.bias),
+                               (att.sampling_offsets.weight, att.sampling_offsets.bias),
+                               (att.attention_weights.weight, att.attention_weights.bias)])
+        value, proj = _new(R, C, x), _new(R, n_proj, x)
+        linear(x, w, [seg(0, value, am_x, rowmask=mask), seg(C, proj, am_xp, addend=posf is not None)], a2=posf)
+        o, am_o = _msda(att, value, proj, ref, shapes2d, level_start_index, B, S, arena)
+        y = _new(R, C, x)
+        linear(o, cached(att, "op", [(att.output_proj.weight, att.output_proj.bias)]), [seg(0, y, am_o, resid=x)])
+        x1, am1, _ = layer_norm(y, layer.norm1)
+        x, am_x, am_xp = _ffn(layer, x1, am1, layer.norm2, arena, pos=posf)
+        if posf is None:
+            am_xp = am_x
+    memory = x.view(B, S, C)
+    memory._gvl_amax = am_x
+    return memory
+
+
+# ---- decoder ------------------------------------------------------------------------------------------------------------
+def mlp_forward(mlp, x, am_x, arena, extra=None):
+    """pdvc.py:1166-1178 MLP on rows x (R, C): Linear + ReLU ... Linear -> (R, out_dim).  `extra` = (name, [(w, b)]): a
+    further linear map of x computed by the first launch (the class head shares the box MLP's input) -> (out, extra_out)"""
+    R = x.shape[0]
+    layers = list(mlp.layers)
+    cur, am = x, am_x
+    extra_out = None
+    for i, lin in enumerate(layers):
+        last = i == len(layers) - 1
+        pairs = [(lin.weight, lin.bias)]
+        if i == 0 and extra is not None:
+            pairs += extra[1]
+        w = cached(mlp, f"mlp{i}" + (extra[0] if (i == 0 and extra is not None) else ""), pairs)
+        out = _new(R, w.starts[1] if len(pairs) > 1 else w.N, x)
+        am_o = None if last else arena.take(R)
+        segs = [seg(0, out, am, relu=not last, amax_out=am_o)]
+        if len(pairs) > 1:
+            extra_out = _new(R, w.N - w.starts[1], x)
+            segs.append(seg(w.starts[1], extra_out, am))
+        linear(cur, w, segs)
+        cur, am = out, am_o
+    res = cur[:, :layers[-1].out_features]
+    if extra_out is not None:
+        return res, extra_out
+    return res
+
+
+def _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_mask):
+    """nn.MultiheadAttention of the decoder layer (deformable_transformer.py:266-270): q = k = x + query_pos, v = x ->
+    attention output rows (R, C) BEFORE out_proj.  The in-projection is one launch (q, k columns multiply x + query_pos,
+    the v columns x); the 300 x 300 attention core runs through torch's fused SDPA kernel."""
+    sa = layer.self_attn
+    R, C = x.shape
+    H = sa.num_heads
+    w = cached(sa, "in", [(sa.in_proj_weight, sa.in_proj_bias)])
+    qkv = _new(R, 3 * C, x)
+    linear(x, w, [seg(0, qkv[:, :2 * C], am_xp, addend=True), seg(2 * C, qkv[:, 2 * C:], am_x)], a2=qpos)
+    t = qkv.view(B, Q, 3, H, C // H).permute(2, 0, 3, 1, 4)                      # (3, B, H, Q, D)
+    mask = query_mask[:, None, None, :] if query_mask is not None else None       # True = attend (key_padding_mask = ~)
+    o = torch.nn.functional.scaled_dot_product_attention(t[0], t[1], t[2], attn_mask=mask)
+    return o.transpose(1, 2).reshape(R, C)
+
+
+def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_level_start_index, src_valid_ratios,
+                    query_pos, src_padding_mask, query_padding_mask, disable_iterative_refine):
+    """DeformableTransformerDecoder.forward (deformable_transformer.py:283-335) for inference.  value_proj(memory) of ALL
+    layers is one launch up front; per layer: in-projection, attention core, out_proj + residual, LayerNorm, offset /
+    weight projection of tgt + query_pos, sampling, output_proj + residual, LayerNorm, FFN (3 launches), box MLP."""
+    from .deformable_transformer import inverse_sigmoid
+    from .ops.modules.ms_deform_attn import temporal_shapes_2d
+    B, Q, C = tgt.shape
+    S = src.shape[1]
+    R, Rs = B * Q, B * S
+    shapes2d = temporal_shapes_2d(src_temporal_shapes, src_level_start_index)
+    mem = src.reshape(Rs, C)
+    if not mem.is_contiguous():
+        mem = mem.contiguous()
+    am_mem = getattr(src, "_gvl_amax", None)
+    if am_mem is None or am_mem.numel() != Rs:
+        am_mem, _ = row_absmax(mem)
+    mask = src_padding_mask.reshape(Rs).contiguous().view(torch.uint8) if src_padding_mask is not None else None
+    nl = len(dec.layers)
+    arena = _Arena((4 * nl + 2) * (R + 4), tgt.device)
+    # value_proj(memory) of every layer: one product against the concatenated weights
+    wv = cached(dec, "values", [(l_.cross_attn.value_proj.weight, l_.cross_attn.value_proj.bias) for l_ in dec.layers])
+    values = [_new(Rs, C, mem) for _ in dec.layers]
+    linear(mem, wv, [seg(wv.starts[i], values[i], am_mem, rowmask=mask) for i in range(nl)])
+    x = tgt.reshape(R, C).contiguous()
+    if query_pos is None:
+        qpos = None
+    elif query_pos.stride(0) == 0:                    # 'queries' input: the same embedding for every video (:130-133)
+        qpos = query_pos[0].contiguous()
+    else:
+        qpos = query_pos.reshape(R, C).contiguous()
+    am_x, am_xp = row_absmax(x, qpos)
+    if qpos is None:
+        am_xp = am_x
+    hs, refs, deltas = [], [], []
+    for lid, layer in enumerate(dec.layers):
+        if reference_points.shape[-1] == 2:                                       # :302-304
+            ref_in = reference_points[:, :, None] * torch.stack([src_valid_ratios] * 2, -1)[:, None]
+        else:
+            assert reference_points.shape[-1] == 1
+            ref_in = reference_points[:, :, None] * src_valid_ratios[:, None, :, None]
+        # -- self attention over the queries
+        a = _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_padding_mask)
+        am_a, _ = row_absmax(a)
+        sa = layer.self_attn
+        y = _new(R, C, x)
+        linear(a, cached(sa, "out", [(sa.out_proj.weight, sa.out_proj.bias)]), [seg(0, y, am_a, resid=x)])
+        x2, am2, am2p = layer_norm(y, layer.norm2, pos=qpos)
+        if qpos is None:
+            am2p = am2
+        # -- deformable cross attention into the memory
+        att = layer.cross_attn
+        proj = _new(R, 2 * att.n_heads * att.n_levels * att.n_points, x)
+        linear(x2, cached(att, "proj", [(att.sampling_offsets.weight, att.sampling_offsets.bias),
+                                        (att.attention_weights.weight, att.attention_weights.bias)]),
+               [seg(0, proj, am2p, addend=qpos is not None)], a2=qpos)
+        o, am_o = _msda(att, values[lid], proj, ref_in, shapes2d, src_level_start_index, B, Q, arena)
+        y = _new(R, C, x)
+        linear(o, cached(att, "op", [(att.output_proj.weight, att.output_proj.bias)]), [seg(0, y, am_o, resid=x2)])
+        x3, am3, _ = layer_norm(y, layer.norm1)
+        # -- FFN
+        x, am_x, am_xp = _ffn(layer, x3, am3, layer.norm3, arena, pos=qpos)
+        if qpos is None:
+            am_xp = am_x
+        out = x.view(B, Q, C)
+        if not disable_iterative_refine and dec.bbox_head is not None:           # :314-324
+            delta = mlp_forward(dec.bbox_head[lid], x, am_x, arena).reshape(B, Q, -1)
+            deltas.append(delta)
+            prior = inverse_sigmoid(reference_points)
+            if reference_points.shape[-1] == 2:
+                new_ref = (delta + prior).sigmoid()
+            else:
+                new_ref = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
+            reference_points = new_ref.detach()
+        if dec.return_intermediate:
+            hs.append(out)
+            refs.append(reference_points)
+    # the heads of pdvc.py:452-474 apply the same box MLP to the same rows: hand the result over (taken once)
+    dec.__dict__["_gvl_deltas"] = deltas if len(deltas) == nl else None
+    if dec.return_intermediate:
+        hs_t = torch.stack(hs)
+        hs_t._gvl_amax = am_x
+        return hs_t, torch.stack(refs)
+    return out, reference_points

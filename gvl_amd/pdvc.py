@@ -214,7 +214,13 @@ class PDVC(nn.Module):
         """class / count / box heads of one decoder layer (pdvc.py:452-474)."""
         cls = self.class_head[l_id](hs_lid)
         cnt = self.predict_event_num(self.count_head[l_id], hs_lid)
-        delta = self.bbox_head[l_id](hs_lid)
+        # inference with box refinement: the decoder has just applied this very MLP to these very rows
+        # (deformable_transformer.py:314-316 and pdvc.py:455 share `bbox_head[l_id]`) -- its result is taken over
+        shared = self.transformer.decoder.__dict__.get("_gvl_deltas") if self.with_box_refine else None
+        if shared is not None and not disable_refine and not torch.is_grad_enabled() and shared[l_id].shape[:2] == hs_lid.shape[:2]:
+            delta = shared[l_id]
+        else:
+            delta = self.bbox_head[l_id](hs_lid)
         if disable_refine:
             coord = reference
         else:

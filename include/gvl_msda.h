@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 6   /* 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 7   /* 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -127,6 +127,53 @@ int gvl_set_criterion_backward_f32(const float *pred_logits, const float *pred_c
  *    gvl_msda1d_fused_forward_f32 consumes as `proj`. */
 int gvl_proj_f32(const float *x, const float *weight, const float *bias, int R, int K, int N, float *out, void *stream);
 
+/* -- the dense layers around the deformable attention, for inference (gvl_layers.hip): every nn.Linear of the encoder /
+ *    decoder layers -- value_proj, sampling_offsets + attention_weights, output_proj (pdvc/ops/modules/ms_deform_attn.py:
+ *    95,99-100,125), linear1 / linear2 (pdvc/deformable_transformer.py:189-199,257-261), the in / out projections of
+ *    nn.MultiheadAttention (:266-270), the box MLP (pdvc/pdvc.py:1166-1178) -- as ONE kernel on the fp16 matrix cores at
+ *    fp32 accuracy:
+ *        out_s[r][n - n_begin_s] = epilogue_s( sum_k (a[r][k] [+ a2[r % a2_rows][k]]) w[n][k] + bias[n] )
+ *    a (R, K) fp32, row stride lda: the activation as its producer left it.  It is split into the (hi, 2^11 residual) fp16
+ *    planes of gvl_split_rows_f16 INSIDE the kernel's load path; the row scale comes from amax_in (R): any upper bound of
+ *    max_k |a[r][k] (+ a2)| that is at most ~2^10 above it (the producers on the path leave the exact row maximum:
+ *    gvl_layer_norm_rows_f32, gvl_msda1d_fused_forward_amax_f32, this function's own amax_out, gvl_row_absmax_f32).
+ *    w: planes + scales of the (N, K) weight from gvl_split_rows_f16, N % 64 == 0, K % 32 == 0; bias (N) or NULL.
+ *    The N columns are cut into 1..4 SEGMENTS (ascending n_begin, multiples of 64, the first one 0), each with its own
+ *    output matrix, epilogue and A variant, so that one launch serves e.g. [value_proj ; sampling_offsets ;
+ *    attention_weights] where value_proj multiplies src and the other two src + pos (ms_deform_attn.py:95,99-100).
+ *    Epilogue order: + bias, ReLU (GVL_LIN_RELU), resid[r][.] + (.), rows with rowmask[r] != 0 written as zeros (the
+ *    masked_fill of ms_deform_attn.py:96-97); amax_out (R floats, ZERO-INITIALISED by the caller, or NULL) receives
+ *    max_n |out_s[r][n]| through one atomic max per row and tile.
+ *    flags: GVL_LIN_XCD_COLUMNS (only with N == 512) = column tile c is computed on XCD c (workgroup id % 8).
+ *    Accuracy: |error| <= 2^-21 sum|a||w| + K 2^-33 amax_in[r] max|w| (three fp16 MFMAs, fp32 accumulation, lo.lo dropped);
+ *    a non-finite a[r][k] makes row r of the outputs non-finite. */
+#define GVL_LIN_ADDEND 1       /* segment flag: the A operand of this segment is a + a2 */
+#define GVL_LIN_RELU 2         /* segment flag */
+#define GVL_LIN_XCD_COLUMNS 1  /* launch flag */
+typedef struct gvl_lin_seg {
+  int n_begin;                  /* first column of the segment in the concatenated weight */
+  int flags;                    /* GVL_LIN_ADDEND | GVL_LIN_RELU */
+  float *out;                   /* (R, n_end - n_begin), row stride ldo */
+  int64_t ldo;
+  const float *amax_in;         /* (R) row maxima of the A operand this segment multiplies */
+  const float *resid;           /* (R, n_end - n_begin), row stride ldr, or NULL */
+  int64_t ldr;
+  float *amax_out;              /* (R) or NULL */
+  const unsigned char *rowmask; /* (R) or NULL */
+} gvl_lin_seg;
+int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2, int64_t lda2, int a2_rows, int R, int K,
+                         const void *w_hi, const void *w_lo, const float *w_scale, const float *bias, int N,
+                         const gvl_lin_seg *segs_host, int nseg, int flags, void *stream);
+/*    gvl_layer_norm_rows_f32: torch.nn.LayerNorm over the last axis of x (R, C) (deformable_transformer.py:193,198,261,
+ *        270,277; biased variance, eps inside the square root), C % 4 == 0, C <= 1024, one wavefront per row; also writes
+ *        amax_y[r] = max |y[r][.]| and amax_ypos[r] = max |y[r][.] + pos[r % pos_rows][.]| (either may be NULL; pos (pos_rows,
+ *        C) may be NULL): the row maxima gvl_linear_f16x3_f32 needs for `y` and for the attention query `y + pos`.
+ *    gvl_row_absmax_f32: the same two row maxima for a tensor some other kernel produced. */
+int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float *gamma, const float *beta, float eps,
+                            const float *pos, int pos_rows, float *y, float *amax_y, float *amax_ypos, void *stream);
+int gvl_row_absmax_f32(const float *x, int64_t ldx, int R, int C, const float *pos, int64_t ldp, int pos_rows,
+                       float *amax_x, float *amax_xpos, void *stream);
+
 /* -- fp32 products of the captioner's token loop on the fp16 matrix cores at fp32 accuracy (gvl_gemm16.hip): the
  *    nn.Linear calls `self.logit(output)` (pdvc/CaptioningHead/LSTM_DSA.py:121,165), `h2att(h)` and the two halves of
  *    the LSTM's gate pre-activations (:247,267-269).
@@ -204,6 +251,8 @@ int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stre
 #define GVL_PROF_PROJ 19
 #define GVL_PROF_SPLIT 20
 #define GVL_PROF_GEMM16 21
+#define GVL_PROF_LINEAR 22
+#define GVL_PROF_LAYER_NORM 23
 int gvl_prof_enable(int on);   /* 0 off | 1 sampling-path kernels | 2 also GVL_PROF_PROJ (stamping two consecutive launches
                                   inflates the second one's interval by 2-3 us, so level 1 leaves the projection alone) */
 /* Phase stamps of the temporal kernels (diagnostics): while a DEVICE buffer of 2 x 4096 x 4 uint64 is set, every
@@ -276,6 +325,13 @@ int gvl_msda1d_fused_forward_f32(const float *value, const int64_t *shapes, cons
                                  const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
                                  int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
                                  void *stream);
+/*    ..._amax_f32: the same forward, additionally leaving amax_out[b*Q + q] = max_c |out[b][q][c]| (B*Q floats,
+ *    ZERO-INITIALISED by the caller; one atomic max per (row, head)): the row maxima from which gvl_linear_f16x3_f32
+ *    derives the operand scale of `output_proj` (ms_deform_attn.py:125) behind it. */
+int gvl_msda1d_fused_forward_amax_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
+                                      const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
+                                      int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
+                                      float *amax_out, void *stream);
 size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P,
                                                  const int64_t *shapes_host);
 int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,
