@@ -60,9 +60,61 @@ class ShowAttendTellCore(nn.Module):
                              "(every reference config)")
 
     # -- per-forward constants ---------------------------------------------------------------------------------
+    def _prepare_inference(self, query, input_flatten, input_padding_mask):
+        """prepare() for inference on the split-fp16 layer kernel (gvl_amd/layers.py): value_proj(memory) with masked rows
+        straight into the left half of the [value | ctx2att(value)] slab, ctx2att of it into the right half, and the two
+        token-independent products of the event features (gate part, offset part) as one launch: 3 launches, no cat."""
+        from .. import layers as L
+        att = self.deformable_att
+        B, S, C = input_flatten.shape
+        A, H, E, Cf = self.att_hid_size, self.rnn_size, self.input_encoding_size, self.att_feat_size
+        Rs = B * S
+        mem = input_flatten.reshape(Rs, C)
+        am_mem = getattr(input_flatten, "_gvl_amax", None)
+        if am_mem is None or am_mem.numel() != Rs:
+            am_mem, _ = L.row_absmax(mem)
+        slab = torch.empty(B, S, Cf + A, device=mem.device, dtype=torch.float32)
+        slab2 = slab.view(Rs, Cf + A)
+        am_v = torch.zeros(Rs, device=mem.device, dtype=torch.float32)
+        mask = input_padding_mask.reshape(Rs).contiguous().view(torch.uint8) if input_padding_mask is not None else None
+        L.linear(mem, L.cached(att, "capv", [(att.value_proj.weight, att.value_proj.bias)]),
+                 [L.seg(0, slab2[:, :Cf], am_mem, rowmask=mask, amax_out=am_v)])
+        L.linear(slab2[:, :Cf], L.cached(self, "ctx", [(self.ctx2att.weight, self.ctx2att.bias)]),
+                 [L.seg(0, slab2[:, Cf:], am_v)])
+        q = query.reshape(-1, query.shape[-1])
+        am_q = getattr(query, "_gvl_amax", None)
+        if am_q is None or am_q.numel() != q.shape[0]:
+            am_q, _ = L.row_absmax(q)
+        K = self.n_levels * self.n_points
+        ow = att.sampling_offsets.weight
+        w = L.cached(self, "hs", [(self.rnn.weight_ih_l0[:, E + Cf:], None), (ow[:, H:], att.sampling_offsets.bias)])
+        gates_hs = torch.empty(q.shape[0], 4 * H, device=q.device, dtype=torch.float32)
+        off_hs = torch.empty(q.shape[0], K, device=q.device, dtype=torch.float32)
+        L.linear(q, w, [L.seg(0, gates_hs, am_q), L.seg(w.starts[1], off_hs, am_q, width=K)])
+        return slab.view(B, S, 1, Cf + A), gates_hs, off_hs.view(*query.shape[:-1], K)
+
+    def _inference_layers_ok(self, query, input_flatten):
+        from .. import layers as L
+        return (L.enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and query.is_cuda
+                and query.dtype == torch.float32 and input_flatten.dtype == torch.float32 and self.att_hid_size % 64 == 0
+                and self.att_feat_size % 64 == 0 and query.shape[-1] % 32 == 0 and (4 * self.rnn_size) % 64 == 0
+                and self.att_feat_size == input_flatten.shape[-1] and query.is_contiguous()
+                and self.rnn.weight_ih_l0.shape[1] == self.input_encoding_size + self.att_feat_size + query.shape[-1]
+                and self.deformable_att.sampling_offsets.weight.shape[1] == self.rnn_size + query.shape[-1])
+
     def prepare(self, query, input_flatten, input_padding_mask):
         """Everything that does not depend on the token index."""
         att = self.deformable_att
+        if self._inference_layers_ok(query, input_flatten):
+            slab, gates_hs, off_hs = self._prepare_inference(query, input_flatten, input_padding_mask)
+            B, S = slab.shape[:2]
+            bias = self.alpha_net.bias
+            if getattr(self, "_alpha_b_version", None) != bias._version:
+                self._alpha_b = float(bias.detach().cpu())
+                self._alpha_b_version = bias._version
+            const = {"slab": slab, "gates_hs": gates_hs, "off_hs": off_hs}
+            const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **self._inference_weights(slab.dtype))
+            return const
         value = att.project_value(input_flatten, input_padding_mask)              # (B,S,1,C)
         B, S = value.shape[:2]
         v2 = value.reshape(B, S, -1)

@@ -211,6 +211,8 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
     const int buf = kt & 1;                                                                              \
     const uint4 *st = smem + buf * kStageSlots;                                                          \
     load_a(nxt, min(kt + 2, KT - 1) * kBK);                                                              \
+    __builtin_amdgcn_sched_barrier(0);       /* the requests leave FIRST: left alone, the scheduler sinks them below */ \
+                                             /* the split arithmetic and the rows arrive a stage late               */ \
     h8 f_ah[2][2], f_al[2][2], f_bh[2], f_bl[2];                                                         \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
@@ -231,11 +233,15 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
     asm volatile("" ::: "memory");                                                                       \
     ++kt;                                                                                                \
   }
+  // Two stages per iteration and NO exit between them: with a conditional exit after the first stage the loop header has
+  // a predecessor on which that stage's own loads are still pending, and hipcc's wait-count pass then drains the prefetch
+  // at the top of every iteration (the temporaries there reuse the registers of the set loaded later in the stage).
   int kt = 0;
-  while (kt < KT) {
+  for (int it = KT >> 1; it > 0; --it) {
     GVL_LIN_STAGE(set1, set0)
-    if (kt < KT) GVL_LIN_STAGE(set0, set1)
+    GVL_LIN_STAGE(set0, set1)
   }
+  if (KT & 1) GVL_LIN_STAGE(set1, set0)
 #undef GVL_LIN_STAGE
   (void)nA;
 
@@ -245,6 +251,7 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
   const int row0 = m0 + wm, col = n0 + wn + frow;
   const bool col_ok = col < N;
   const int colc = min(col, N - 1), ocol = colc - sg.n_begin;
+  const bool st_ok = col_ok && (sg.width <= 0 || ocol < sg.width);
   const float cs = p.Ws[colc];
   const float cb = p.bias ? p.bias[colc] : 0.f;
   const bool relu = sg.flags & GVL_LIN_RELU;
@@ -265,7 +272,7 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
-        res[i][r] = sg.resid[(int64_t)row * sg.ldr + ocol];
+        res[i][r] = st_ok ? sg.resid[(int64_t)row * sg.ldr + ocol] : 0.f;
       }
   }
   unsigned keep[2] = {0xffffu, 0xffffu};
@@ -293,7 +300,7 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (col_ok && row < R) sg.out[(int64_t)row * sg.ldo + ocol] = v[i][r];
+      if (st_ok && row < R) sg.out[(int64_t)row * sg.ldo + ocol] = v[i][r];
     }
   if (sg.amax_out) {
     // Row maxima of this wavefront's 64 x 32 part: a butterfly reduce-SCATTER over the 32 lanes that hold one row's
@@ -304,7 +311,7 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m[i][r] = col_ok ? fabsf(v[i][r]) : 0.f;
+      for (int r = 0; r < 16; ++r) m[i][r] = st_ok ? fabsf(v[i][r]) : 0.f;
     float one[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -435,7 +442,248 @@ __global__ void __launch_bounds__(256) k_row_absmax(const float *__restrict__ x,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention core of the decoder's nn.MultiheadAttention (deformable_transformer.py:266-270; head dimension 64, <= 320
+// queries): softmax(q k^T / 8 + key mask) v for one (video, head, block of 64 queries) per workgroup, in exact fp32 on
+// v_mfma_f32_16x16x4_f32.  A wavefront owns 16 queries and keeps its whole score strip (16 x Q) in registers:
+//   scores   S^T = K Q^T, one 16-key tile at a time: the C/D layout leaves key 16 kt + 4 (lane >> 4) + r, query lane & 15 in
+//            register r -- exactly the B-operand layout of the second product when its MFMA steps walk the keys in the order
+//            (4 g + j), so P never moves between lanes or through LDS;
+//   output   O^T = V^T P^T with the channel order inside an MFMA tile chosen as 4 (lane & 15) + tile, so that a lane reads
+//            four consecutive channels of a V row as ONE 16-byte load and stores four consecutive output channels as one.
+// K and V pass through LDS one 16-key tile at a time (4 KB, double-buffered, the next tile requested before the current
+// one is multiplied), laid out so that the operand reads are conflict-free 16-byte reads.
+// Also leaves max |out row| per (row, head) in amax (atomic max; zero-initialised by the caller) for out_proj's split.
+typedef float f4acc __attribute__((ext_vector_type(4)));
+constexpr int kMhaMaxTiles = 20;
+
+__global__ void __launch_bounds__(256) k_mha_core(const float *__restrict__ qkv, int64_t ld, const unsigned char *__restrict__ keep,
+                                                  int B, int Q, int H, float *__restrict__ out, float *__restrict__ amax) {
+  // one 16-key tile of K (then of V) at a time through LDS, shared by the workgroup's four wavefronts (each reading all of
+  // K and V for itself cost 394 MB of L2 reads per launch: 70 us); two buffers, one barrier per tile
+  __shared__ float4 tile[2][256];
+  const int nqb = (Q + 63) >> 6;
+  const int qb = blockIdx.x % nqb, h = (blockIdx.x / nqb) % H, b = blockIdx.x / (nqb * H);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qi = lane & 15, g = lane >> 4;
+  const int q0 = qb * 64 + wave * 16;
+  const bool active = q0 < Q;                                          // (wavefront-uniform; idle wavefronts still stage)
+  const int C = H * 64, KT = (Q + 15) >> 4;
+  const float *base = qkv + (int64_t)b * Q * ld + h * 64;
+  // staging: thread t carries the 16-byte piece t & 15 of key row t >> 4 of the tile (a wavefront = 4 whole 256-byte rows)
+  const int srow = tid >> 4, spc = tid & 15;
+  const float *kstage = base + C + 4 * spc, *vstage = base + 2 * C + 4 * spc;
+  const int k_slot = srow * 16 + (spc ^ srow);                         // K: 16-byte units XOR-swizzled by the key
+  float4 qreg[4];
+  {
+    const float *qp = base + (int64_t)min(q0 + qi, Q - 1) * ld + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      qreg[t] = *reinterpret_cast<const float4 *>(qp + 16 * t);
+      qreg[t].x *= 0.125f; qreg[t].y *= 0.125f; qreg[t].z *= 0.125f; qreg[t].w *= 0.125f;
+    }
+  }
+  f4acc s[kMhaMaxTiles];
+  float4 st = *reinterpret_cast<const float4 *>(kstage + (int64_t)min(srow, Q - 1) * ld);
+#pragma unroll
+  for (int kt = 0; kt < kMhaMaxTiles; ++kt) {
+    if (kt < KT) {
+      tile[kt & 1][k_slot] = st;
+      if (kt + 1 < KT) st = *reinterpret_cast<const float4 *>(kstage + (int64_t)min(16 * (kt + 1) + srow, Q - 1) * ld);
+      __syncthreads();
+      f4acc acc = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 kc = tile[kt & 1][qi * 16 + ((4 * t + g) ^ qi)];   // K[key qi of the tile][16 t + 4 g ..]
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.x, qreg[t].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.y, qreg[t].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.z, qreg[t].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kc.w, qreg[t].w, acc, 0, 0, 0);
+        }
+      }
+      // key mask: padded keys (beyond Q) and keys the caller excludes (key_padding_mask) get -inf
+      const int key0 = 16 * kt + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + r;
+        const bool ok = key < Q && (!keep || keep[(int64_t)b * Q + min(key, Q - 1)]);
+        acc[r] = ok ? acc[r] : -INFINITY;
+      }
+      s[kt] = acc;
+    }
+  }
+  // first V tile on its way while the softmax runs
+  st = *reinterpret_cast<const float4 *>(vstage + (int64_t)min(srow, Q - 1) * ld);
+  // softmax over the keys of query lane & 15: registers, then the four lane groups
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < kMhaMaxTiles; ++kt)
+    if (kt < KT) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < kMhaMaxTiles; ++kt)
+    if (kt < KT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[kt][r] - m);
+        s[kt][r] = e;
+        sum += e;
+      }
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  // O^T = V^T P^T
+  f4acc o[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) o[ct] = f4acc{0.f, 0.f, 0.f, 0.f};
+  // (KT and KT + 1 have different parity bookkeeping: the V tiles simply continue the buffer alternation after a barrier)
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < kMhaMaxTiles; ++kt) {
+    if (kt < KT) {
+      tile[kt & 1][tid] = st;                                          // V: linear image, row = key of the tile
+      if (kt + 1 < KT) st = *reinterpret_cast<const float4 *>(vstage + (int64_t)min(16 * (kt + 1) + srow, Q - 1) * ld);
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 vc = tile[kt & 1][(4 * g + j) * 16 + qi];       // V[key 4 g + j of the tile][4 qi ..]
+          o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc.x, s[kt][j], o[0], 0, 0, 0);
+          o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc.y, s[kt][j], o[1], 0, 0, 0);
+          o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc.z, s[kt][j], o[2], 0, 0, 0);
+          o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc.w, s[kt][j], o[3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float inv = 1.f / sum;
+  float mx = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[ct][r] *= inv;
+      mx = fmaxf(mx, fabsf(o[ct][r]));
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const int q = q0 + qi;
+  if (active && q < Q) {
+    float *op = out + ((int64_t)b * Q + q) * C + h * 64 + 16 * g;       // register r: channels 16 g + 4 r .. + 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<float4 *>(op + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+    if (amax && g == 0) atomicMax(reinterpret_cast<unsigned *>(amax) + (int64_t)b * Q + q, __float_as_uint(mx));
+  }
+}
+
+// sigmoid(delta + inverse_sigmoid(ref)) and the next layer's scaled reference points (deformable_transformer.py:301-324)
+__global__ void __launch_bounds__(256) k_box_refine(const float *__restrict__ delta, int64_t ldd, const float *__restrict__ ref,
+                                                    int RD, const float *__restrict__ vr, int R, int Q, int L,
+                                                    float *__restrict__ new_ref, float *__restrict__ ref_in) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  constexpr float eps = 1e-5f;
+  float o[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float v = delta[(int64_t)r * ldd + c];
+    if (c < RD) {
+      const float x = fminf(fmaxf(ref[(int64_t)r * RD + c], 0.f), 1.f);
+      v += logf(fmaxf(x, eps) / fmaxf(1.f - x, eps));
+    }
+    o[c] = 1.f / (1.f + expf(-v));
+  }
+  new_ref[2 * (int64_t)r] = o[0];
+  new_ref[2 * (int64_t)r + 1] = o[1];
+  if (ref_in) {
+    const int b = r / Q;
+    for (int l = 0; l < L; ++l) {
+      const float s = vr[b * L + l];
+      ref_in[((int64_t)r * L + l) * 2] = o[0] * s;
+      ref_in[((int64_t)r * L + l) * 2 + 1] = o[1] * s;
+    }
+  }
+}
+
+// out[b] = W . max_q hs[b][q][:] + bias: one workgroup (16 wavefronts) per video.  Wavefront w pools rows w, w + 16, ...
+// (four rows' loads in flight at a time: the pooling is a chain of load latencies, not of bytes), lane = float4 columns
+// lane, lane + 64, ...; the wavefronts' partial maxima meet in LDS.
+constexpr int kCountWaves = 16;
+__global__ void __launch_bounds__(64 * kCountWaves) k_count_head(const float *__restrict__ hs, int Q, int C,
+                                                                 const float *__restrict__ W, const float *__restrict__ bias,
+                                                                 int n_out, float *__restrict__ out) {
+  extern __shared__ float pooled[];                                    // [kCountWaves][C], then row 0 = the pooled vector
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n4 = C >> 2;
+  const float4 *base = reinterpret_cast<const float4 *>(hs + (int64_t)b * Q * C);
+  for (int i = lane; i < n4; i += 64) {
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int q = wave; q < Q; q += 4 * kCountWaves) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qq = q + u * kCountWaves;
+        v[u] = qq < Q ? base[(int64_t)qq * n4 + i] : m;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+      }
+    }
+    reinterpret_cast<float4 *>(pooled + (int64_t)wave * C)[i] = m;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float m = pooled[c];
+    for (int w = 1; w < kCountWaves; ++w) m = fmaxf(m, pooled[w * C + c]);
+    pooled[c] = m;                                                     // (row 0: each column is touched by one thread only)
+  }
+  __syncthreads();
+  for (int n = wave; n < n_out; n += kCountWaves) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(pooled[c], W[(int64_t)n * C + c], acc);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[(int64_t)b * n_out + n] = acc + (bias ? bias[n] : 0.f);
+  }
+}
+
 }  // namespace
+
+extern "C" int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, int B, int Q, int H, float *out,
+                                float *amax_out, void *stream) {
+  if (B < 0 || Q <= 0 || H <= 0 || ld < (int64_t)3 * H * 64 || (ld & 3) || Q > 16 * kMhaMaxTiles)
+    return fail(GVL_EINVAL, "gvl_mha_core_f32: needs head dimension 64, ld %% 4 == 0, Q <= %d (got B=%d Q=%d H=%d)",
+                16 * kMhaMaxTiles, B, Q, H);
+  if (B == 0) return 0;
+  if (!qkv || !out || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return fail(GVL_EINVAL, "gvl_mha_core_f32: null / unaligned pointer");
+  const int nqb = (Q + 63) / 64;
+  return gvl::launch(GVL_PROF_LINEAR, Q, B, "k_mha_core", k_mha_core, dim3(nqb * H * B), dim3(256), 0, (hipStream_t)stream, qkv,
+                     ld, key_keep, B, Q, H, out, amax_out);
+}
+
+extern "C" int gvl_box_refine_f32(const float *delta, int64_t ldd, const float *ref, int RD, const float *valid_ratios, int B,
+                                  int Q, int L, float *new_ref, float *ref_in, void *stream) {
+  if (B < 0 || Q < 0 || L <= 0 || ldd < 2 || (RD != 1 && RD != 2)) return fail(GVL_EINVAL, "gvl_box_refine_f32: bad sizes");
+  if ((int64_t)B * Q == 0) return 0;
+  if (!delta || !ref || !new_ref || (ref_in && !valid_ratios)) return fail(GVL_EINVAL, "gvl_box_refine_f32: null pointer");
+  const int R = B * Q;
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, L, "k_box_refine", k_box_refine, dim3((R + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, delta, ldd, ref, RD, valid_ratios, R, Q, L, new_ref, ref_in);
+}
+
+extern "C" int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight, const float *bias, int n_out,
+                                  float *out, void *stream) {
+  if (B < 0 || Q <= 0 || C <= 0 || (C & 3) || n_out <= 0 || C > 2048)
+    return fail(GVL_EINVAL, "gvl_count_head_f32: bad sizes (C %% 4 == 0, C <= 2048)");
+  if (B == 0) return 0;
+  if (!hs || !weight || !out) return fail(GVL_EINVAL, "gvl_count_head_f32: null pointer");
+  const size_t lds = (size_t)kCountWaves * C * sizeof(float);
+  if (int rc = gvl::ensure_lds(k_count_head, lds)) return rc;
+  return gvl::launch(GVL_PROF_LAYER_NORM, B, Q, "k_count_head", k_count_head, dim3(B), dim3(64 * kCountWaves), lds,
+                     (hipStream_t)stream, hs, Q, C, weight, bias, n_out, out);
+}
 
 extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2, int64_t lda2, int a2_rows, int R, int K,
                                     const void *w_hi, const void *w_lo, const float *w_scale, const float *bias, int N,
@@ -455,7 +703,9 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
         (s > 0 && g.n_begin <= segs[s - 1].n_begin))
       return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: segment %d starts at column %d (ascending multiples of 64 from 0)", s, g.n_begin);
     const int n_end = s + 1 < nseg ? segs[s + 1].n_begin : N;
-    if (!g.out || !g.amax_in || g.ldo < n_end - g.n_begin || (g.resid && g.ldr < n_end - g.n_begin))
+    const int w_ = g.width > 0 ? g.width : n_end - g.n_begin;
+    if (g.width < 0 || g.width > n_end - g.n_begin) return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: segment %d: bad width", s);
+    if (!g.out || !g.amax_in || g.ldo < w_ || (g.resid && g.ldr < w_))
       return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: segment %d: null output / row maxima or a leading dimension too small", s);
     any_addend |= (g.flags & GVL_LIN_ADDEND) != 0;
   }

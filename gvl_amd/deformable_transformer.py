@@ -176,7 +176,8 @@ class DeformableTransformerDecoder(nn.Module):
 
     def forward(self, tgt, reference_points, src, src_temporal_shapes, src_level_start_index, src_valid_ratios,
                 query_pos=None, src_padding_mask=None, query_padding_mask=None, disable_iterative_refine=False):
-        self.__dict__["_gvl_deltas"] = None
+        for k in ("_gvl_deltas", "_gvl_coords", "_gvl_cls"):
+            self.__dict__[k] = None
         if _layers.decoder_eligible(self, tgt, src, src_temporal_shapes):
             return _layers.decoder_forward(self, tgt, reference_points, src, src_temporal_shapes,
                                            src_level_start_index, src_valid_ratios, query_pos, src_padding_mask,

@@ -31,7 +31,7 @@ def enabled():
 class _Seg(ctypes.Structure):                      # include/gvl_msda.h: gvl_lin_seg
     _fields_ = [("n_begin", ctypes.c_int), ("flags", ctypes.c_int), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
                 ("amax_in", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("ldr", ctypes.c_int64),
-                ("amax_out", ctypes.c_void_p), ("rowmask", ctypes.c_void_p)]
+                ("amax_out", ctypes.c_void_p), ("rowmask", ctypes.c_void_p), ("width", ctypes.c_int)]
 
 
 class Weights:
@@ -67,9 +67,11 @@ def cached(owner, name, params):
     return hit[1]
 
 
-def seg(n_begin, out, amax_in, resid=None, amax_out=None, rowmask=None, relu=False, addend=False):
+def seg(n_begin, out, amax_in, resid=None, amax_out=None, rowmask=None, relu=False, addend=False, width=0):
+    """one column segment of a linear() launch; width > 0: only the first `width` columns of the segment are stored (a
+    weight block padded to a multiple of 64 rows)"""
     return dict(n_begin=n_begin, out=out, amax_in=amax_in, resid=resid, amax_out=amax_out, rowmask=rowmask, relu=relu,
-                addend=addend)
+                addend=addend, width=width)
 
 
 def linear(a, w, segs, a2=None, flags=0):
@@ -87,7 +89,7 @@ def linear(a, w, segs, a2=None, flags=0):
                       o.stride(0), s["amax_in"].data_ptr(), r_.data_ptr() if r_ is not None else None,
                       r_.stride(0) if r_ is not None else 0,
                       s["amax_out"].data_ptr() if s["amax_out"] is not None else None,
-                      s["rowmask"].data_ptr() if s["rowmask"] is not None else None)
+                      s["rowmask"].data_ptr() if s["rowmask"] is not None else None, s["width"])
     with torch.cuda.device(a.device):
         rc = _lib.lib().gvl_linear_f16x3_f32(
             a.data_ptr(), a.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
@@ -243,7 +245,7 @@ def encoder_forward(enc, src, temporal_shapes, level_start_index, valid_ratios, 
 
 # ---- decoder ------------------------------------------------------------------------------------------------------------
 def mlp_forward(mlp, x, am_x, arena, extra=None):
-    """pdvc.py:1166-1178 MLP on rows x (R, C): Linear + ReLU ... Linear -> (R, out_dim).  `extra` = (name, [(w, b)]): a
+    """pdvc.py:1166-1178 MLP on rows x (R, C): Linear + ReLU ... Linear -> (R, out_dim).  `extra` = (name, weight, bias): a
     further linear map of x computed by the first launch (the class head shares the box MLP's input) -> (out, extra_out)"""
     R = x.shape[0]
     layers = list(mlp.layers)
@@ -252,37 +254,90 @@ def mlp_forward(mlp, x, am_x, arena, extra=None):
     for i, lin in enumerate(layers):
         last = i == len(layers) - 1
         pairs = [(lin.weight, lin.bias)]
-        if i == 0 and extra is not None:
-            pairs += extra[1]
-        w = cached(mlp, f"mlp{i}" + (extra[0] if (i == 0 and extra is not None) else ""), pairs)
-        out = _new(R, w.starts[1] if len(pairs) > 1 else w.N, x)
+        with_extra = i == 0 and extra is not None
+        if with_extra:
+            pairs.append((extra[1], extra[2]))
+        w = cached(mlp, f"mlp{i}" + (extra[0] if with_extra else ""), pairs)
+        out = _new(R, lin.out_features, x)
         am_o = None if last else arena.take(R)
-        segs = [seg(0, out, am, relu=not last, amax_out=am_o)]
-        if len(pairs) > 1:
-            extra_out = _new(R, w.N - w.starts[1], x)
-            segs.append(seg(w.starts[1], extra_out, am))
+        segs = [seg(0, out, am, relu=not last, amax_out=am_o, width=lin.out_features)]
+        if with_extra:
+            extra_out = _new(R, extra[1].shape[0], x)
+            segs.append(seg(w.starts[1], extra_out, am, width=extra[1].shape[0]))
         linear(cur, w, segs)
         cur, am = out, am_o
-    res = cur[:, :layers[-1].out_features]
     if extra_out is not None:
-        return res, extra_out
-    return res
+        return cur, extra_out
+    return cur
 
 
-def _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_mask):
+def box_refine(delta, ref, valid_ratios, B, Q, want_ref_in=True):
+    """gvl_box_refine_f32: delta (R, >= 2), ref (B, Q, RD) -> (sigmoid(delta + inverse_sigmoid(ref)) (B, Q, 2),
+    that times the valid ratios (B, Q, L, 2): the reference points of the next layer)"""
+    R, L = B * Q, valid_ratios.shape[1]
+    ref = ref.contiguous()
+    vr = valid_ratios.contiguous()
+    new_ref = torch.empty(B, Q, 2, device=delta.device, dtype=torch.float32)
+    ref_in = torch.empty(B, Q, L, 2, device=delta.device, dtype=torch.float32) if want_ref_in else None
+    with torch.cuda.device(delta.device):
+        rc = _lib.lib().gvl_box_refine_f32(delta.data_ptr(), delta.stride(0), ref.data_ptr(), ref.shape[-1], vr.data_ptr(),
+                                           B, Q, L, new_ref.data_ptr(), ref_in.data_ptr() if want_ref_in else None,
+                                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "box_refine")
+    return new_ref, ref_in
+
+
+def count_head_eligible(counter, hs):
+    return (enabled() and _plain(hs) and hs.dim() == 3 and hs.is_contiguous() and isinstance(counter, torch.nn.Linear)
+            and counter.weight.dtype == torch.float32 and hs.shape[-1] % 4 == 0 and hs.shape[-1] <= 2048)
+
+
+def count_head(counter, hs):
+    """predict_event_num (pdvc.py:316-319): counter(max over the queries of hs (B, Q, C)) in one launch"""
+    B, Q, C = hs.shape
+    out = torch.empty(B, counter.out_features, device=hs.device, dtype=torch.float32)
+    with torch.cuda.device(hs.device):
+        rc = _lib.lib().gvl_count_head_f32(hs.data_ptr(), B, Q, C, counter.weight.data_ptr(),
+                                           counter.bias.data_ptr() if counter.bias is not None else None,
+                                           counter.out_features, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "count_head")
+    return out
+
+
+def mha_core(qkv, B, Q, H, key_keep=None, amax_out=None):
+    """gvl_mha_core_f32: qkv (B*Q, 3*H*64) rows [q | k | v] -> softmax(q k^T / 8) v per head, (B*Q, H*64); key_keep (B, Q)
+    bool, True = the key takes part (the complement of nn.MultiheadAttention's key_padding_mask)"""
+    R = B * Q
+    assert qkv.shape == (R, 3 * H * 64) and qkv.dtype == torch.float32 and qkv.stride(1) == 1 and Q <= 320
+    out = torch.empty(R, H * 64, device=qkv.device, dtype=torch.float32)
+    keep = key_keep.contiguous().view(torch.uint8) if key_keep is not None else None
+    with torch.cuda.device(qkv.device):
+        rc = _lib.lib().gvl_mha_core_f32(qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if keep is not None else None, B, Q, H,
+                                         out.data_ptr(), amax_out.data_ptr() if amax_out is not None else None,
+                                         torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "mha_core")
+    return out
+
+
+def _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_mask, arena):
     """nn.MultiheadAttention of the decoder layer (deformable_transformer.py:266-270): q = k = x + query_pos, v = x ->
-    attention output rows (R, C) BEFORE out_proj.  The in-projection is one launch (q, k columns multiply x + query_pos,
-    the v columns x); the 300 x 300 attention core runs through torch's fused SDPA kernel."""
+    (attention output rows (R, C) BEFORE out_proj, their row maxima).  The in-projection is one launch (q, k columns
+    multiply x + query_pos, the v columns x); the attention core is gvl_mha_core_f32 (head dimension 64, <= 320 queries)
+    or torch's fused SDPA kernel."""
     sa = layer.self_attn
     R, C = x.shape
     H = sa.num_heads
     w = cached(sa, "in", [(sa.in_proj_weight, sa.in_proj_bias)])
     qkv = _new(R, 3 * C, x)
-    linear(x, w, [seg(0, qkv[:, :2 * C], am_xp, addend=True), seg(2 * C, qkv[:, 2 * C:], am_x)], a2=qpos)
+    linear(x, w, [seg(0, qkv[:, :2 * C], am_xp, addend=qpos is not None), seg(2 * C, qkv[:, 2 * C:], am_x)], a2=qpos)
+    if C == 64 * H and Q <= 320 and os.environ.get("GVL_MHA", "") != "torch":
+        am_a = arena.take(R)
+        return mha_core(qkv, B, Q, H, query_mask, am_a), am_a
     t = qkv.view(B, Q, 3, H, C // H).permute(2, 0, 3, 1, 4)                      # (3, B, H, Q, D)
     mask = query_mask[:, None, None, :] if query_mask is not None else None       # True = attend (key_padding_mask = ~)
     o = torch.nn.functional.scaled_dot_product_attention(t[0], t[1], t[2], attn_mask=mask)
-    return o.transpose(1, 2).reshape(R, C)
+    a = o.transpose(1, 2).reshape(R, C)
+    return a, row_absmax(a)[0]
 
 
 def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_level_start_index, src_valid_ratios,
@@ -304,7 +359,7 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
         am_mem, _ = row_absmax(mem)
     mask = src_padding_mask.reshape(Rs).contiguous().view(torch.uint8) if src_padding_mask is not None else None
     nl = len(dec.layers)
-    arena = _Arena((4 * nl + 2) * (R + 4), tgt.device)
+    arena = _Arena((5 * nl + 2) * (R + 4), tgt.device)
     # value_proj(memory) of every layer: one product against the concatenated weights
     wv = cached(dec, "values", [(l_.cross_attn.value_proj.weight, l_.cross_attn.value_proj.bias) for l_ in dec.layers])
     values = [_new(Rs, C, mem) for _ in dec.layers]
@@ -319,16 +374,18 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
     am_x, am_xp = row_absmax(x, qpos)
     if qpos is None:
         am_xp = am_x
-    hs, refs, deltas = [], [], []
+    hs, refs, deltas, coords, clss = [], [], [], [], []
+    next_ref_in = None
     for lid, layer in enumerate(dec.layers):
-        if reference_points.shape[-1] == 2:                                       # :302-304
+        if next_ref_in is not None:                                               # left by the previous layer's refinement
+            ref_in = next_ref_in
+        elif reference_points.shape[-1] == 2:                                     # :302-304
             ref_in = reference_points[:, :, None] * torch.stack([src_valid_ratios] * 2, -1)[:, None]
         else:
             assert reference_points.shape[-1] == 1
             ref_in = reference_points[:, :, None] * src_valid_ratios[:, None, :, None]
         # -- self attention over the queries
-        a = _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_padding_mask)
-        am_a, _ = row_absmax(a)
+        a, am_a = _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_padding_mask, arena)
         sa = layer.self_attn
         y = _new(R, C, x)
         linear(a, cached(sa, "out", [(sa.out_proj.weight, sa.out_proj.bias)]), [seg(0, y, am_a, resid=x)])
@@ -351,19 +408,26 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
             am_xp = am_x
         out = x.view(B, Q, C)
         if not disable_iterative_refine and dec.bbox_head is not None:           # :314-324
-            delta = mlp_forward(dec.bbox_head[lid], x, am_x, arena).reshape(B, Q, -1)
-            deltas.append(delta)
-            prior = inverse_sigmoid(reference_points)
-            if reference_points.shape[-1] == 2:
-                new_ref = (delta + prior).sigmoid()
+            cls_heads = dec.__dict__.get("_gvl_class_head")
+            ch = cls_heads[lid] if cls_heads is not None and isinstance(cls_heads[lid], torch.nn.Linear) else None
+            if ch is not None:                                                    # pdvc.py:452: same input rows
+                delta, cls = mlp_forward(dec.bbox_head[lid], x, am_x, arena, extra=("cls", ch.weight, ch.bias))
+                clss.append(cls.view(B, Q, -1))
             else:
-                new_ref = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
-            reference_points = new_ref.detach()
+                delta = mlp_forward(dec.bbox_head[lid], x, am_x, arena)
+            deltas.append(delta.view(B, Q, -1))
+            # sigmoid(delta + inverse_sigmoid(ref)) and the next layer's scaled reference points in one launch
+            new_ref, next_ref_in = box_refine(delta, reference_points, src_valid_ratios, B, Q, lid + 1 < nl)
+            coords.append(new_ref)
+            reference_points = new_ref
         if dec.return_intermediate:
             hs.append(out)
             refs.append(reference_points)
-    # the heads of pdvc.py:452-474 apply the same box MLP to the same rows: hand the result over (taken once)
-    dec.__dict__["_gvl_deltas"] = deltas if len(deltas) == nl else None
+    # the heads of pdvc.py:452-474 apply the same box MLP / refinement arithmetic to the same rows: handed over (taken once)
+    ok = len(deltas) == nl
+    dec.__dict__["_gvl_deltas"] = deltas if ok else None
+    dec.__dict__["_gvl_coords"] = coords if ok else None
+    dec.__dict__["_gvl_cls"] = clss if ok and len(clss) == nl else None
     if dec.return_intermediate:
         hs_t = torch.stack(hs)
         hs_t._gvl_amax = am_x

@@ -90,6 +90,9 @@ class PDVC(nn.Module):
             self.bbox_head = _clones(self.bbox_head, num_pred)
             nn.init.constant_(self.bbox_head[0].layers[-1].bias.data[1:], init_bias)
             self.transformer.decoder.bbox_head = self.bbox_head          # iterative refinement shares these heads
+            # (a plain attribute, not a registered sub-module: the inference decoder computes the class logits beside the
+            #  box MLP, whose input rows they share)
+            self.transformer.decoder.__dict__["_gvl_class_head"] = self.class_head
         else:
             nn.init.constant_(self.bbox_head.layers[-1].bias.data[1:], init_bias)
             self.class_head = nn.ModuleList([self.class_head for _ in range(num_pred)])
@@ -208,19 +211,25 @@ class PDVC(nn.Module):
 
     def predict_event_num(self, counter, hs_lid):
         # max over the queries (pdvc.py:316-319); amax = the same values without the argmax bookkeeping of torch.max
+        from . import layers as _layers
+        if _layers.count_head_eligible(counter, hs_lid):
+            return _layers.count_head(counter, hs_lid)                  # pooling + Linear in one launch (inference)
         return counter(torch.amax(hs_lid, dim=1))
 
     def _layer_heads(self, l_id, hs_lid, reference, disable_refine):
         """class / count / box heads of one decoder layer (pdvc.py:452-474)."""
-        cls = self.class_head[l_id](hs_lid)
+        # inference with box refinement: the decoder (gvl_amd/layers.py) has just applied this very box MLP, the class head
+        # and the refinement arithmetic to these very rows (deformable_transformer.py:314-324 and pdvc.py:452-474 share
+        # `bbox_head[l_id]`): its results are taken over
+        dec = self.transformer.decoder.__dict__
+        take = self.with_box_refine and not disable_refine and not torch.is_grad_enabled()
+        shared = {k: (dec.get("_gvl_" + k) if take else None) for k in ("cls", "coords", "deltas")}
+        same = lambda t_: t_ is not None and t_[l_id].shape[:2] == hs_lid.shape[:2]          # noqa: E731
+        cls = shared["cls"][l_id] if same(shared["cls"]) else self.class_head[l_id](hs_lid)
         cnt = self.predict_event_num(self.count_head[l_id], hs_lid)
-        # inference with box refinement: the decoder has just applied this very MLP to these very rows
-        # (deformable_transformer.py:314-316 and pdvc.py:455 share `bbox_head[l_id]`) -- its result is taken over
-        shared = self.transformer.decoder.__dict__.get("_gvl_deltas") if self.with_box_refine else None
-        if shared is not None and not disable_refine and not torch.is_grad_enabled() and shared[l_id].shape[:2] == hs_lid.shape[:2]:
-            delta = shared[l_id]
-        else:
-            delta = self.bbox_head[l_id](hs_lid)
+        if same(shared["coords"]):
+            return cls, cnt, shared["coords"][l_id]
+        delta = shared["deltas"][l_id] if same(shared["deltas"]) else self.bbox_head[l_id](hs_lid)
         if disable_refine:
             coord = reference
         else:
@@ -253,6 +262,8 @@ class PDVC(nn.Module):
         for l_id in range(num_pred):
             reference = init_reference if l_id == 0 else inter_references[l_id - 1]
             hs_lid = hs[l_id]
+            if l_id == num_pred - 1 and getattr(hs, "_gvl_amax", None) is not None:
+                hs_lid._gvl_amax = hs._gvl_amax          # row maxima of the last layer's rows (gvl_amd/layers.py)
             cls, cnt, coord = self._layer_heads(l_id, hs_lid, reference, disable_iterative_refine)
             hs_cap = torch.cat([hs_lid, query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
                                                                                     False) else hs_lid

@@ -160,6 +160,8 @@ typedef struct gvl_lin_seg {
   int64_t ldr;
   float *amax_out;              /* (R) or NULL */
   const unsigned char *rowmask; /* (R) or NULL */
+  int width;                    /* columns [width, n_end - n_begin) of the segment are not stored (a weight block padded
+                                   to a multiple of 64 rows); 0 = all */
 } gvl_lin_seg;
 int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2, int64_t lda2, int a2_rows, int R, int K,
                          const void *w_hi, const void *w_lo, const float *w_scale, const float *bias, int N,
@@ -173,6 +175,24 @@ int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float *gamma, co
                             const float *pos, int pos_rows, float *y, float *amax_y, float *amax_ypos, void *stream);
 int gvl_row_absmax_f32(const float *x, int64_t ldx, int R, int C, const float *pos, int64_t ldp, int pos_rows,
                        float *amax_x, float *amax_xpos, void *stream);
+/*    gvl_box_refine_f32: the iterative box refinement of one decoder layer (pdvc/deformable_transformer.py:314-324, the
+ *        same arithmetic again at pdvc/pdvc.py:465-474) and the reference points of the NEXT layer (:301-306) in one
+ *        launch:  new_ref[r] = sigmoid(delta[r] + inverse_sigmoid(ref[r]))  (RD = 2; RD = 1: only the centre gets the prior),
+ *        inverse_sigmoid as misc/detr_utils/misc.py:582-586 (eps = 1e-5);  ref_in[r][l] = new_ref[r] * valid_ratios[b(r)][l].
+ *        delta (R, ldd >= 2), ref (R, RD), valid_ratios (B, L), R = B * Q -> new_ref (R, 2), ref_in (R, L, 2) (may be NULL).
+ *    gvl_count_head_f32: predict_event_num (pdvc/pdvc.py:316-319): out[b] = W . max_q hs[b][q][:] + bias for hs (B, Q, C),
+ *        W (n_out, C) -> (B, n_out); one workgroup per video. */
+/*    gvl_mha_core_f32: the attention core of nn.MultiheadAttention in the decoder layer (deformable_transformer.py:266-270):
+ *        out[b][q][h*64 ..] = softmax_k(q_h . k_h / 8, keys with key_keep[b][k] == 0 excluded) v_h, for qkv (B*Q, ld) rows
+ *        [q | k | v] (each H*64 wide, the in-projection's output), head dimension 64, Q <= 320, exact fp32 arithmetic
+ *        (v_mfma_f32_16x16x4_f32); key_keep (B, Q) bytes or NULL (all keys); out (B*Q, H*64); amax_out (B*Q) zero-initialised
+ *        or NULL receives max |out row|. */
+int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, int B, int Q, int H, float *out,
+                     float *amax_out, void *stream);
+int gvl_box_refine_f32(const float *delta, int64_t ldd, const float *ref, int RD, const float *valid_ratios, int B, int Q,
+                       int L, float *new_ref, float *ref_in, void *stream);
+int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight, const float *bias, int n_out, float *out,
+                       void *stream);
 
 /* -- fp32 products of the captioner's token loop on the fp16 matrix cores at fp32 accuracy (gvl_gemm16.hip): the
  *    nn.Linear calls `self.logit(output)` (pdvc/CaptioningHead/LSTM_DSA.py:121,165), `h2att(h)` and the two halves of

@@ -136,6 +136,31 @@ def test_sampling_kernel_leaves_exact_row_maxima():
     assert torch.equal(am, out.abs().amax(-1).reshape(-1))
 
 
+@pytest.mark.parametrize("B,Q,H,masked", [(16, 300, 8, False), (3, 300, 8, True), (2, 37, 4, True), (1, 320, 2, False)])
+def test_attention_core_matches_fp64(B, Q, H, masked):
+    """gvl_mha_core_f32 vs softmax(q k^T / sqrt(64)) v in fp64 (nn.MultiheadAttention's core, deformable_transformer.py:266-270)"""
+    from gvl_amd import layers as L
+    C = 64 * H
+    qkv = _rand(B * Q, 3 * C, seed=60, scale=1.5)
+    keep = None
+    if masked:
+        keep = torch.ones(B, Q, dtype=torch.bool, device=DEV)
+        for b in range(B):
+            keep[b, Q - 1 - 7 * b:] = False
+            keep[b, 3 + b] = False
+    am = torch.zeros(B * Q, device=DEV)
+    out = L.mha_core(qkv, B, Q, H, keep, am)
+    t = qkv.double().view(B, Q, 3, H, 64).permute(2, 0, 3, 1, 4)
+    sc = t[0] @ t[1].transpose(-1, -2) / 8.0
+    if keep is not None:
+        sc = sc.masked_fill(~keep[:, None, None, :], float("-inf"))
+    want = (torch.softmax(sc, -1) @ t[2]).transpose(1, 2).reshape(B * Q, C)
+    lib = torch.nn.functional.scaled_dot_product_attention(
+        *(x.float() for x in t), attn_mask=keep[:, None, None, :] if keep is not None else None).transpose(1, 2).reshape(B * Q, C)
+    assert maxerr(out, want) <= 2.0 * maxerr(lib, want) + 2e-6
+    assert torch.equal(am, out.abs().amax(1))
+
+
 def _transformer(seed=0):
     from gvl_amd.deformable_transformer import DeformableTransformer
     torch.manual_seed(seed)

@@ -30,4 +30,19 @@ def test_split_gemm_entry_points_are_declared_and_exported():
                  "gvl_greedy_step_partials_f32", "gvl_cap_attend_split_f32", "gvl_lstm_cell_split_f32"):
         assert hasattr(L, name), name
     assert L.gvl_gemm_f16x3_argmax_chunks(8518) == 134 and L.gvl_gemm_f16x3_argmax_chunks(1) == 2
-    assert L.gvl_msda_abi_version() == _lib.ABI_VERSION == 6
+    assert L.gvl_msda_abi_version() == _lib.ABI_VERSION >= 6
+
+
+def test_inference_layer_entry_points_are_declared_and_exported():
+    """the ABI-7 symbols (gvl_layers.hip) resolve; argument checking runs without a GPU (no launch is reached)"""
+    from gvl_amd import _lib
+    L = _lib.lib()
+    for name in ("gvl_linear_f16x3_f32", "gvl_layer_norm_rows_f32", "gvl_row_absmax_f32", "gvl_box_refine_f32",
+                 "gvl_count_head_f32", "gvl_msda1d_fused_forward_amax_f32"):
+        assert hasattr(L, name), name
+    assert L.gvl_msda_abi_version() == _lib.ABI_VERSION == 7
+    # K not a multiple of 32 / N not a multiple of 64 are refused before anything is launched
+    assert L.gvl_linear_f16x3_f32(None, 0, None, 0, 0, 4, 48, None, None, None, None, 64, None, 1, 0, None) == -1
+    assert b"K % 32" in L.gvl_last_error()
+    assert L.gvl_layer_norm_rows_f32(None, 4, 6, None, None, 1e-5, None, 0, None, None, None, None) == -1
+    assert L.gvl_box_refine_f32(None, 1, None, 2, None, 1, 1, 1, None, None, None) == -1

@@ -19,5 +19,5 @@ for r in csv.DictReader(open(f)):
     cnt[name] += 1
 rest = sum(tot.values())
 print(f"# per step: token loop {loop_us / steps / 1e3:.2f} ms, everything else {rest / steps / 1e3:.2f} ms in {sum(cnt.values()) / steps:.0f} launches")
-for name, us in tot.most_common(28):
+for name, us in tot.most_common(60):
     print(f"{name[:110]:110s} {cnt[name] / steps:7.1f} launches {us / steps:8.1f} us")

@@ -72,5 +72,19 @@ def main():
               f"torch add {timeit(lambda: x + pos):.2f} us")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--mha" not in sys.argv:
     main()
+
+
+def mha():
+    B, Q, H = 16, 300, 8
+    qkv = torch.randn(B * Q, 3 * H * 64, device=dev)
+    am = torch.zeros(B * Q, device=dev)
+    t = qkv.view(B, Q, 3, H, 64).permute(2, 0, 3, 1, 4)
+    keep = torch.ones(B, Q, dtype=torch.bool, device=dev)
+    print(f"mha_core B=16 Q=300 H=8: own {timeit(lambda: L.mha_core(qkv, B, Q, H, keep, am)):.2f} us, "
+          f"torch SDPA (+ mask) {timeit(lambda: torch.nn.functional.scaled_dot_product_attention(t[0], t[1], t[2], attn_mask=keep[:, None, None, :])):.2f} us")
+
+
+if __name__ == "__main__" and "--mha" in sys.argv:
+    mha()
