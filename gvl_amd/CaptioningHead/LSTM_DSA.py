@@ -549,7 +549,9 @@ class Captioner(nn.Module):
                   "h": h, "c": c, "it": it, "logits": None,
                   "unfinished": torch.empty(n, dtype=torch.uint8, device=hs.device),
                   "seq": torch.zeros(n, T, dtype=torch.long, device=hs.device),
-                  "seq_lp": torch.zeros(n, T, dtype=torch.float32, device=hs.device)}
+                  "seq_lp": torch.zeros(n, T, dtype=torch.float32, device=hs.device),
+                  # alive[t]: some row is still unfinished after token t -- set by the greedy kernel itself
+                  "alive": torch.zeros(T, dtype=torch.uint8, device=hs.device)}
             # (running the vocabulary GEMM + argmax of token t on a second stream beside the token-independent half of
             #  step t+1 was tried -- fork / join inside the captured graph -- and measured no gain: 742-757 vs 750
             #  videos/s; the GEMMs already occupy every CU)
@@ -558,7 +560,7 @@ class Captioner(nn.Module):
             self._greedy_iterations(st, 0, stop)
             self._decode_state = st if stop < T + 1 else None
             # a row is unfinished at step t exactly while its tokens are non-zero (seq = token * unfinished, :183-188)
-            return st["seq"], st["seq_lp"], (st["seq"] != 0).any(0)
+            return st["seq"], st["seq_lp"], st["alive"].view(torch.bool)
         unfinished = torch.ones(n, dtype=torch.bool, device=hs.device)
         seq, seq_lp, alive = [], [], []
         for t in range(T + 1):
@@ -586,7 +588,7 @@ class Captioner(nn.Module):
         T = self.max_caption_len
         for t in range(t0, t1):
             if t > 0:
-                st["it"] = MSDA.greedy_step(st["logits"], t - 1, st["unfinished"], st["seq"], st["seq_lp"])
+                st["it"] = MSDA.greedy_step(st["logits"], t - 1, st["unfinished"], st["seq"], st["seq_lp"], st["alive"])
             if t < T:
                 out, (st["h"], st["c"]) = self.core.step((st["emb_gates"], st["it"]), (st["h"], st["c"]), st["hs"],
                                                          st["ref_in"], st["tshapes"], st["lsi"], st["const"])
@@ -604,7 +606,7 @@ class Captioner(nn.Module):
         segment booked, i.e. tokens [t0 - 1, t1 - 1)"""
         st = self._decode_state
         self._greedy_iterations(st, t0, t1)
-        return (st["seq"][:, t0 - 1:t1 - 1] != 0).any(0)
+        return st["alive"][t0 - 1:t1 - 1].view(torch.bool)
 
     def _decode_graphed(self, hs, reference, memory, mask, valid_ratios, tshapes, lsi):
         """Greedy decoding replayed from a hipGraph: the 31-step loop is ~800 kernel launches whose host-side issue

@@ -534,13 +534,13 @@ def gemm_f16x3_argmax(x, w, bias=None):
     return GreedyPartials(part, x.rows, w.rows)
 
 
-def _greedy_from_partials(p, first, unfinished, seq_ptr, lp_ptr, T):
+def _greedy_from_partials(p, first, unfinished, seq_ptr, lp_ptr, T, alive_ptr=None):
     tok = torch.empty(p.rows, dtype=torch.int64, device=p.part.device)
     lp = torch.empty(p.rows, dtype=torch.float32, device=p.part.device)
     with torch.cuda.device(p.part.device):
-        rc = _lib.lib().gvl_greedy_step_partials_f32(p.part.data_ptr(), p.rows, p.vocab, first, tok.data_ptr(),
-                                                     lp.data_ptr(), unfinished, seq_ptr, lp_ptr, T,
-                                                     torch.cuda.current_stream().cuda_stream)
+        rc = _lib.lib().gvl_greedy_step_partials_alive_f32(p.part.data_ptr(), p.rows, p.vocab, first, tok.data_ptr(),
+                                                           lp.data_ptr(), unfinished, seq_ptr, lp_ptr, T, alive_ptr,
+                                                           torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "greedy_step_partials")
     return tok, lp
 
@@ -550,16 +550,21 @@ def row_argmax_lse_partials(p):
     return _greedy_from_partials(p, 0, None, None, None, 0)
 
 
-def greedy_step(logits, t_col, unfinished, seq, seq_lp):
+def greedy_step(logits, t_col, unfinished, seq, seq_lp, alive=None):
     """argmax + log-softmax-at-argmax of the (R, V) logits AND the greedy bookkeeping of decoding step t_col
     (include/gvl_msda.h: gvl_greedy_step_f32): updates unfinished (R,) uint8 and seq / seq_lp (R, T) in place at
-    column t_col; -> raw argmax tokens (R,) int64.  `logits` may be the GreedyPartials of gemm_f16x3_argmax."""
+    column t_col; -> raw argmax tokens (R,) int64.  `logits` may be the GreedyPartials of gemm_f16x3_argmax.
+    alive (T,) uint8, zero-initialised: alive[t_col] is set when any row is still unfinished after the step (the loop-exit
+    test of LSTM_DSA.py:186-187) -- by the kernel itself on the partials path, by two small ops otherwise."""
     if isinstance(logits, GreedyPartials):
         _require(unfinished.dtype == torch.uint8 and seq.dtype == torch.int64 and seq_lp.dtype == torch.float32
                  and seq.is_contiguous() and seq_lp.is_contiguous() and seq.shape == seq_lp.shape
                  and seq.shape[0] == logits.rows, "greedy_step: bad bookkeeping tensors")
+        _require(alive is None or (alive.dtype == torch.uint8 and alive.is_contiguous() and alive.numel() > t_col),
+                 "greedy_step: alive must be a (T,) uint8 tensor")
         return _greedy_from_partials(logits, 1 if t_col == 0 else 0, unfinished.data_ptr(), seq.data_ptr() + 8 * t_col,
-                                     seq_lp.data_ptr() + 4 * t_col, seq.shape[1])[0]
+                                     seq_lp.data_ptr() + 4 * t_col, seq.shape[1],
+                                     alive.data_ptr() + t_col if alive is not None else None)[0]
     _require(logits.is_cuda and logits.is_contiguous() and logits.dtype in (torch.float32, torch.bfloat16)
              and logits.dim() == 2, "greedy_step: logits must be a contiguous fp32 / bf16 CUDA matrix")
     R, V = logits.shape
@@ -575,6 +580,8 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp):
             seq.data_ptr() + 8 * t_col, seq_lp.data_ptr() + 4 * t_col, T,
             torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "greedy_step")
+    if alive is not None:
+        alive[t_col] = (seq[:, t_col] != 0).any()
     return tok
 
 

@@ -695,6 +695,7 @@ struct GreedyBook {
   int64_t *seq;
   float *seq_lp;
   int seq_ld, first;
+  unsigned char *alive;      // (1) or null: set to 1 when any row is still unfinished after this step (LSTM_DSA.py:186-187)
 };
 
 constexpr int kRedRows = 16, kRedGroups = 16;
@@ -746,6 +747,7 @@ __global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__re
       book.unfinished[row] = unf;
       book.seq[(int64_t)row * book.seq_ld] = unf ? a : 0;
       book.seq_lp[(int64_t)row * book.seq_ld] = lp;
+      if (unf && book.alive) *book.alive = 1;                           // (every writer stores the same value)
     }
   }
 }
@@ -863,11 +865,18 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
 extern "C" int gvl_greedy_step_partials_f32(const float *partials, int R, int V, int first_step, int64_t *token,
                                             float *logp, unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col,
                                             int seq_ld, void *stream) {
+  return gvl_greedy_step_partials_alive_f32(partials, R, V, first_step, token, logp, unfinished, seq_col, seq_lp_col, seq_ld,
+                                            nullptr, stream);
+}
+
+extern "C" int gvl_greedy_step_partials_alive_f32(const float *partials, int R, int V, int first_step, int64_t *token,
+                                                  float *logp, unsigned char *unfinished, int64_t *seq_col,
+                                                  float *seq_lp_col, int seq_ld, unsigned char *alive, void *stream) {
   if (R < 0 || V <= 0 || (unfinished && seq_ld <= 0)) return fail(GVL_EINVAL, "gvl_greedy_step_partials_f32: bad sizes");
   if (R == 0) return 0;
   if (!partials || !token || !logp || (unfinished && (!seq_col || !seq_lp_col)))
     return fail(GVL_EINVAL, "gvl_greedy_step_partials_f32: null pointer");
-  const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0};
+  const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0, unfinished ? alive : nullptr};
   return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_from_partials", k_greedy_from_partials, dim3((R + kRedRows - 1) / kRedRows),
                      dim3(256), 0, (hipStream_t)stream, (const float4 *)partials, R, gvl_gemm_f16x3_argmax_chunks(V), token,
                      logp, book);

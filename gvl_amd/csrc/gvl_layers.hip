@@ -33,7 +33,7 @@ namespace {
 using gvl::fail;
 using namespace gvl16;
 
-constexpr int kLinBN = 64, kLinThreads = 256, kMaxSeg = 4;
+constexpr int kLinBN = 64, kMaxSeg = 4;
 
 struct LinParams {
   const float *A;
@@ -85,25 +85,34 @@ __device__ __forceinline__ void split4(const float4 &x, float inv, uint2 &hi, ui
 //            per stage (seen in the ISA); with ordinary loads the waits are counted (vmcnt(n) = exactly the older set);
 //   barrier  one per stage, raw s_barrier after `s_waitcnt lgkmcnt(0)`: the loads in flight are not waited for.
 // 304 / 192 tiles for the 4800 / 3008 x 512 products of cfg A, up to 1216 for the FFN: two workgroups per CU.
-template <bool HAS_A2>
-__global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p) {
-  constexpr int kASlots = kBM * 4, kBSlots = kLinBN * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
-  constexpr int nA = HAS_A2 ? 8 : 4;                                   // global loads of one A register set
+// Two shapes of the same kernel (WM x WN wavefronts, wavefront tile 32 NI x 32 NJ):
+//   <2, 2, 2, 1>  128 x 64 tile, 4 wavefronts: narrow outputs (N < 256), segment boundaries at multiples of 64;
+//   <4, 2, 1, 2>  128 x 128 tile, 8 wavefronts: each A element is split once per 128 output columns instead of once per 64
+//                 and a stage carries twice the MFMA work per barrier (the split arithmetic, not the matrix cores, bounds
+//                 the narrow shape: tools/lin_ksweep.py).
+template <bool HAS_A2, int WM, int WN, int NI, int NJ>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f16x3(const LinParams p) {
+  constexpr int kThreads = 64 * WM * WN, kNW = WM * WN, kBN = 32 * NJ * WN;
+  static_assert(32 * NI * WM == kBM, "128 rows per tile");
+  static_assert(kThreads == 4 * kBN, "one 16-byte weight chunk per plane and thread");
+  constexpr int kASlots = kBM * 4, kBSlots = kBN * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  constexpr int NA = 1024 / kThreads;                                  // A loads (16 bytes) per thread and stage
   __shared__ uint4 smem[2 * kStageSlots];
 
   int tm, tn;
   if (p.xcd_cols) {
-    // column tile = XCD (workgroup id % 8): the (b, m) slabs of `value` are written from the XCD whose L2 the sampling
-    // kernel reads them from (its workgroups of head m sit on XCD m: ids B M apart, M = 8)
-    tn = (int)blockIdx.x & 7;
-    tm = (int)blockIdx.x >> 3;
-    if (tn >= p.tiles_n || tm >= p.tiles_m) return;
+    // column tile c on XCD c % 8 (workgroup id % 8): with 64-wide tiles the (b, m) slabs of `value` are written from the
+    // XCD whose L2 the sampling kernel reads them from (its workgroups of head m sit on XCD m: ids B M apart, M = 8)
+    const int per = p.tiles_n >> 3, bid = (int)blockIdx.x;
+    tn = (bid & 7) + 8 * ((bid >> 3) % per);
+    tm = (bid >> 3) / per;
+    if (tm >= p.tiles_m) return;
   } else if (!tile_of((int)blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) {
     return;
   }
-  const int m0 = tm * kBM, n0 = tn * kLinBN;
+  const int m0 = tm * kBM, n0 = tn * kBN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+  const int wm = (wave % WM) * (32 * NI), wn = (wave / WM) * (32 * NJ);
   const int R = p.R, N = p.N, K = p.K;
 
   // the segment of this column tile (workgroup-uniform)
@@ -114,15 +123,14 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
   const gvl_lin_seg sg = p.seg[si];
   const bool addend = HAS_A2 && (sg.flags & GVL_LIN_ADDEND);
 
-  // ---- A path.  One K stage of a row is exactly one 128-byte line (32 floats): wavefront w covers rows 32 w .. 32 w + 31
-  // of the tile with four loads, load i = rows 32 w + 8 i + (lane >> 3), 16-byte piece lane & 7 -- every instruction reads 8
-  // whole lines.  Addresses are (workgroup-uniform base + k offset) + a 32-bit per-thread offset fixed for the whole
-  // kernel, so that no vector register is spent on address arithmetic inside the loop (with 64-bit per-thread pointers the
-  // register allocator recycled the destination of an in-flight load as the next address and serialised the prefetch).
-  const int apiece = lane & 7, arow0 = wave * 32 + (lane >> 3);
+  // ---- A path.  One K stage of a row is exactly one 128-byte line (32 floats): wavefront w covers rows 8 NA w .. of the
+  // tile with NA loads, load i = rows 8 NA w + 8 i + (lane >> 3), 16-byte piece lane & 7 -- every instruction reads 8 whole
+  // lines.  Buffer loads: the descriptor (workgroup-uniform base) sits in scalar registers, the per-thread part is a 32-bit
+  // offset fixed for the whole kernel, the K offset of a stage travels in the instruction's scalar offset operand -- no
+  // vector register is spent on address arithmetic inside the loop (with 64-bit per-thread pointers the register allocator
+  // recycled the destination of an in-flight load as the next address and serialised the prefetch).
+  const int apiece = lane & 7, arow0 = wave * (8 * NA) + (lane >> 3);
   typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-  // buffer loads: the descriptor (uniform base) sits in scalar registers, the per-thread part is a 32-bit offset fixed for
-  // the whole kernel, the K offset of a stage travels in the instruction's scalar offset operand
   // (the base is passed through readfirstlane: hipcc must be able to PROVE the descriptor wave-uniform, or it wraps every
   //  buffer load in a waterfall loop)
   auto rsrc_of = [](const void *ptr) {
@@ -134,11 +142,11 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
   const auto a2_rs = rsrc_of(HAS_A2 ? p.A2 : p.A);
   const auto wh_rs = rsrc_of(p.Wh + (int64_t)n0 * K);
   const auto wl_rs = rsrc_of(p.Wl + (int64_t)n0 * K);
-  int a_off[4], a2_off[4];
-  uint32_t a_dst[4];
-  float a_inv[4];
+  int a_off[NA], a2_off[NA];
+  uint32_t a_dst[NA];
+  float a_inv[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NA; ++i) {
     const int row = arow0 + 8 * i, grow = min(m0 + row, R - 1);
     a_off[i] = (int)(((int64_t)(grow - m0) * p.lda + apiece * 4) * 4);
     a2_off[i] = HAS_A2 ? (int)(((int64_t)(grow % p.a2_rows) * p.lda2 + apiece * 4) * 4) : 0;
@@ -152,13 +160,13 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
   const int w_off = (min(wrow, N - 1 - n0) * K + wch * 8) * 2;
   const int w_dst = 2 * kASlots + lds_slot(wrow, wch);
 
-  struct ASet { u4v x[4], y[4], wh, wl; };
+  struct ASet { u4v x[NA], y[NA], wh, wl; };
   auto load_a = [&](ASet &s, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s.x[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_off[i], k0 * 4, 0);
+    for (int i = 0; i < NA; ++i) s.x[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_off[i], k0 * 4, 0);
     if (HAS_A2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off[i], k0 * 4, 0);
+      for (int i = 0; i < NA; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off[i], k0 * 4, 0);
     }
     s.wh = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_off, k0 * 2, 0);
     s.wl = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off, k0 * 2, 0);
@@ -166,7 +174,7 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
   auto store_a = [&](ASet &s, int buf) {
     char *st = reinterpret_cast<char *>(smem + buf * kStageSlots);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       float4 x = __builtin_bit_cast(float4, s.x[i]);
       if (HAS_A2 && addend) {
         const float4 y = __builtin_bit_cast(float4, s.y[i]);
@@ -181,19 +189,22 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
     reinterpret_cast<uint4 *>(st)[kBSlots + w_dst] = __builtin_bit_cast(uint4, s.wl);
   };
 
-  f16acc acc_m[2], acc_x[2];
+  f16acc acc_m[NI][NJ], acc_x[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_m[i][r] = 0.f; acc_x[i][r] = 0.f; }
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_m[i][j][r] = 0.f; acc_x[i][j][r] = 0.f; }
 
   const int frow = lane & 31, fh = lane >> 5;
-  int fa[2][2], fb[2];                                                 // [i][s] | [s]
+  int fa[NI][2], fb[NJ][2];                                            // [tile][s]
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i][s] = lds_slot(wm + 32 * i + frow, 2 * s + fh);
-    fb[s] = 2 * kASlots + lds_slot(wn + frow, 2 * s + fh);
+    for (int i = 0; i < NI; ++i) fa[i][s] = lds_slot(wm + 32 * i + frow, 2 * s + fh);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[j][s] = 2 * kASlots + lds_slot(wn + 32 * j + frow, 2 * s + fh);
   }
 
   const int KT = K / kBK;
@@ -213,20 +224,23 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
     load_a(nxt, min(kt + 2, KT - 1) * kBK);                                                              \
     __builtin_amdgcn_sched_barrier(0);       /* the requests leave FIRST: left alone, the scheduler sinks them below */ \
                                              /* the split arithmetic and the rows arrive a stage late               */ \
-    h8 f_ah[2][2], f_al[2][2], f_bh[2], f_bl[2];                                                         \
+    h8 f_ah[2][NI], f_al[2][NI], f_bh[2][NJ], f_bl[2][NJ];                                               \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                   \
         f_ah[s][i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);                                       \
         f_al[s][i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[i][s]]);                             \
       }                                                                                                  \
-      f_bh[s] = *reinterpret_cast<const h8 *>(&st[fb[s]]);                                               \
-      f_bl[s] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[s]]);                                     \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
+        f_bh[s][j] = *reinterpret_cast<const h8 *>(&st[fb[j][s]]);                                       \
+        f_bl[s][j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[j][s]]);                             \
+      }                                                                                                  \
     }                                                                                                    \
     store_a(cur, buf ^ 1);                                                                               \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 2; ++i) {        \
-      acc_m[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bh[s], acc_m[i], 0, 0, 0);         \
-      acc_x[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s], acc_x[i], 0, 0, 0);         \
-      acc_x[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s], acc_x[i], 0, 0, 0);         \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < NI; ++i)         \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
+      acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bh[s][j], acc_m[i][j], 0, 0, 0); \
+      acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s][j], acc_x[i][j], 0, 0, 0); \
+      acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s][j], acc_x[i][j], 0, 0, 0); \
     }                                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
     __builtin_amdgcn_s_barrier();                                                                        \
@@ -243,42 +257,50 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
   }
   if (KT & 1) GVL_LIN_STAGE(set1, set0)
 #undef GVL_LIN_STAGE
-  (void)nA;
 
   // ---- epilogue.  C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
   // Every load (row scales, residual, mask) is issued before the first store: a load between two stores makes the
   // compiler wait for all stores issued so far.
-  const int row0 = m0 + wm, col = n0 + wn + frow;
-  const bool col_ok = col < N;
-  const int colc = min(col, N - 1), ocol = colc - sg.n_begin;
-  const bool st_ok = col_ok && (sg.width <= 0 || ocol < sg.width);
-  const float cs = p.Ws[colc];
-  const float cb = p.bias ? p.bias[colc] : 0.f;
+  const int row0 = m0 + wm;
   const bool relu = sg.flags & GVL_LIN_RELU;
-  float v[2][16];
+  int ocol[NJ];
+  bool st_ok[NJ];
+  float cs[NJ], cb[NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < NJ; ++j) {
+    const int col = n0 + wn + 32 * j + frow, colc = min(col, N - 1);
+    ocol[j] = colc - sg.n_begin;
+    st_ok[j] = col < N && (sg.width <= 0 || ocol[j] < sg.width);
+    cs[j] = p.Ws[colc];
+    cb[j] = p.bias ? p.bias[colc] : 0.f;
+  }
+  float rsc[NI][16];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
-      float s_, inv_;
-      scale_of(sg.amax_in[row], s_, inv_);
-      v[i][r] = s_;
+      float inv_;
+      scale_of(sg.amax_in[row], rsc[i][r], inv_);
     }
-  float res[2][16];
+  float v[NI][NJ][16];
   if (sg.resid) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
-        res[i][r] = st_ok ? sg.resid[(int64_t)row * sg.ldr + ocol] : 0.f;
-      }
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
+          v[i][j][r] = st_ok[j] ? sg.resid[(int64_t)row * sg.ldr + ocol[j]] : 0.f;
+        }
   }
-  unsigned keep[2] = {0xffffu, 0xffffu};
+  unsigned keep[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) keep[i] = 0xffffu;
   if (sg.rowmask) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh, R - 1);
@@ -286,40 +308,45 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
       }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float o = (acc_m[i][r] + acc_x[i][r] * kLoInv) * (v[i][r] * cs) + cb;
-      if (relu) o = fmaxf(o, 0.f);
-      if (sg.resid) o = res[i][r] + o;
-      if (!((keep[i] >> r) & 1u)) o = 0.f;
-      v[i][r] = o;
-    }
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int r = 0; r < 16; ++r) {
+        float o = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rsc[i][r] * cs[j]) + cb[j];
+        if (relu) o = fmaxf(o, 0.f);
+        if (sg.resid) o = v[i][j][r] + o;
+        if (!((keep[i] >> r) & 1u)) o = 0.f;
+        v[i][j][r] = o;
+      }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (st_ok && row < R) sg.out[(int64_t)row * sg.ldo + ocol] = v[i][r];
-    }
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (st_ok[j] && row < R) sg.out[(int64_t)row * sg.ldo + ocol[j]] = v[i][j][r];
+      }
   if (sg.amax_out) {
-    // Row maxima of this wavefront's 64 x 32 part: a butterfly reduce-SCATTER over the 32 lanes that hold one row's
-    // columns -- each exchange halves the registers a lane keeps -- leaves ONE row per lane: block i = lane & 1,
-    // register (lane >> 1) & 15.  31 exchanges instead of 160; then one atomic max per lane (non-negative floats order
-    // like their bit patterns; a NaN is larger than everything and survives).
-    float m[2][16];
+    // Row maxima of this wavefront's part: a butterfly reduce-SCATTER over the 32 lanes that hold one row's columns --
+    // each exchange halves the registers a lane keeps -- leaves ONE row per lane pair: register (lane >> 1) & 15 (and, with
+    // two 32-row blocks, block lane & 1).  16 exchanges per block instead of 80; then one atomic max per row (non-negative
+    // floats order like their bit patterns; a NaN is larger than everything and survives).
+    float one[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i) {
+      float m[16], a8[8], a4[4], a2[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m[i][r] = st_ok ? fabsf(v[i][r]) : 0.f;
-    float one[2];
+      for (int r = 0; r < 16; ++r) {
+        m[r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float a8[8], a4[4], a2[2];
+        for (int j = 0; j < NJ; ++j) m[r] = fmaxf(m[r], st_ok[j] ? fabsf(v[i][j][r]) : 0.f);
+      }
       const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float mine = b4 ? m[i][k + 8] : m[i][k], send = b4 ? m[i][k] : m[i][k + 8];
+        const float mine = b4 ? m[k + 8] : m[k], send = b4 ? m[k] : m[k + 8];
         a8[k] = fmaxf(mine, __shfl_xor(send, 16, 64));
       }
 #pragma unroll
@@ -336,11 +363,17 @@ __global__ void __launch_bounds__(kLinThreads, 2) k_lin_f16x3(const LinParams p)
       one[i] = fmaxf(mine, __shfl_xor(send, 2, 64));
     }
     const bool b0 = lane & 1;
-    const float mine = b0 ? one[1] : one[0], send = b0 ? one[0] : one[1];
-    const float rmax = fmaxf(mine, __shfl_xor(send, 1, 64));
     const int rr = (lane >> 1) & 15;
-    const int row = row0 + 32 * (int)b0 + (rr & 3) + 8 * (rr >> 2) + 4 * fh;
-    if (row < R) atomicMax(reinterpret_cast<unsigned *>(sg.amax_out) + row, __float_as_uint(rmax));
+    if constexpr (NI == 2) {
+      const float mine = b0 ? one[1] : one[0], send = b0 ? one[0] : one[1];
+      const float rmax = fmaxf(mine, __shfl_xor(send, 1, 64));
+      const int row = row0 + 32 * (int)b0 + (rr & 3) + 8 * (rr >> 2) + 4 * fh;
+      if (row < R) atomicMax(reinterpret_cast<unsigned *>(sg.amax_out) + row, __float_as_uint(rmax));
+    } else {
+      const float rmax = fmaxf(one[0], __shfl_xor(one[0], 1, 64));
+      const int row = row0 + (rr & 3) + 8 * (rr >> 2) + 4 * fh;
+      if (!b0 && row < R) atomicMax(reinterpret_cast<unsigned *>(sg.amax_out) + row, __float_as_uint(rmax));
+    }
   }
 }
 
@@ -578,6 +611,41 @@ __global__ void __launch_bounds__(256) k_mha_core(const float *__restrict__ qkv,
   }
 }
 
+// valid ratios + encoder reference points of one video per workgroup (deformable_transformer.py:81-83, 209-218)
+struct LevelDims { int len[8], start[8]; };
+__global__ void __launch_bounds__(256) k_encoder_geometry(const unsigned char *__restrict__ mask, int S, int L, LevelDims d,
+                                                          float *__restrict__ vr_out, float *__restrict__ ref) {
+  __shared__ int cnt[8];
+  __shared__ float vr[8];
+  const int b = blockIdx.x;
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    int c = 0;
+    for (int t = threadIdx.x; t < d.len[l]; t += blockDim.x) c += mask[(int64_t)b * S + d.start[l] + t] ? 0 : 1;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[l], c);
+  }
+  __syncthreads();
+  if (threadIdx.x < L) {
+    // (count * (1 / T), not count / T: PyTorch divides a tensor by a scalar through the reciprocal -- same bits as :81-83)
+    const float v = (float)cnt[threadIdx.x] * (1.0f / (float)d.len[threadIdx.x]);
+    vr[threadIdx.x] = v;
+    vr_out[b * L + threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (!ref) return;
+  for (int l = 0; l < L; ++l) {
+    const float den = vr[l] * (float)d.len[l];
+    for (int t = threadIdx.x; t < d.len[l]; t += blockDim.x) {
+      const float c = ((float)t + 0.5f) / den;
+      float *o = ref + ((int64_t)b * S + d.start[l] + t) * L;
+      for (int l2 = 0; l2 < L; ++l2) o[l2] = c * vr[l2];
+    }
+  }
+}
+
 // sigmoid(delta + inverse_sigmoid(ref)) and the next layer's scaled reference points (deformable_transformer.py:301-324)
 __global__ void __launch_bounds__(256) k_box_refine(const float *__restrict__ delta, int64_t ldd, const float *__restrict__ ref,
                                                     int RD, const float *__restrict__ vr, int R, int Q, int L,
@@ -663,6 +731,21 @@ extern "C" int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned cha
                      ld, key_keep, B, Q, H, out, amax_out);
 }
 
+extern "C" int gvl_encoder_geometry_f32(const unsigned char *mask, int B, int S, int L, const int64_t *lengths_host,
+                                        const int64_t *starts_host, float *valid_ratios, float *ref, void *stream) {
+  if (B < 0 || S <= 0 || L <= 0 || L > 8 || !lengths_host || !starts_host) return fail(GVL_EINVAL, "gvl_encoder_geometry_f32: bad sizes (L <= 8)");
+  if (B == 0) return 0;
+  if (!mask || !valid_ratios) return fail(GVL_EINVAL, "gvl_encoder_geometry_f32: null pointer");
+  LevelDims d = {};
+  for (int l = 0; l < L; ++l) {
+    d.len[l] = (int)lengths_host[l];
+    d.start[l] = (int)starts_host[l];
+    if (d.len[l] <= 0 || d.start[l] < 0 || d.start[l] + d.len[l] > S) return fail(GVL_EINVAL, "gvl_encoder_geometry_f32: level %d outside S", l);
+  }
+  return gvl::launch(GVL_PROF_LAYER_NORM, B, S, "k_encoder_geometry", k_encoder_geometry, dim3(B), dim3(256), 0, (hipStream_t)stream,
+                     mask, S, L, d, valid_ratios, ref);
+}
+
 extern "C" int gvl_box_refine_f32(const float *delta, int64_t ldd, const float *ref, int RD, const float *valid_ratios, int B,
                                   int Q, int L, float *new_ref, float *ref_in, void *stream) {
   if (B < 0 || Q < 0 || L <= 0 || ldd < 2 || (RD != 1 && RD != 2)) return fail(GVL_EINVAL, "gvl_box_refine_f32: bad sizes");
@@ -715,15 +798,28 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   p.A = a; p.lda = lda; p.A2 = any_addend ? a2 : nullptr; p.lda2 = lda2; p.a2_rows = any_addend ? a2_rows : 1;
   p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = bias;
   p.R = R; p.N = N; p.K = K;
-  p.tiles_m = (R + kBM - 1) / kBM; p.tiles_n = N / kLinBN; p.nseg = nseg;
-  p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n == 8;
+  p.nseg = nseg;
   for (int s = 0; s < kMaxSeg; ++s) p.seg[s] = segs[s < nseg ? s : nseg - 1];
-  const int grid = p.xcd_cols ? p.tiles_m * 8 : (p.tiles_m * p.tiles_n + 7) / 8 * 8;
+  // wide tile when every segment starts at a multiple of 128 columns and the output is wide enough to fill the chip with
+  // 128 x 128 tiles (GVL_LIN_TILE=64 keeps the narrow tile for A/B runs)
+  bool wide = N % 128 == 0 && N >= 256;
+  for (int s = 0; s < nseg; ++s) wide = wide && segs[s].n_begin % 128 == 0;
+  if (const char *e = getenv("GVL_LIN_TILE")) wide = wide && atoi(e) != 64;
+  const int bn = wide ? 128 : kLinBN;
+  p.tiles_m = (R + kBM - 1) / kBM; p.tiles_n = N / bn;
+  p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n % 8 == 0;
+  const int grid = p.xcd_cols ? p.tiles_m * p.tiles_n : (p.tiles_m * p.tiles_n + 7) / 8 * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (wide) {
+    if (any_addend)
+      return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128,addend>", k_lin_f16x3<true, 4, 2, 1, 2>, dim3(grid), dim3(512),
+                         0, st, p);
+    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128>", k_lin_f16x3<false, 4, 2, 1, 2>, dim3(grid), dim3(512), 0, st, p);
+  }
   if (any_addend)
-    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<addend>", k_lin_f16x3<true>, dim3(grid), dim3(kLinThreads), 0,
-                       (hipStream_t)stream, p);
-  return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3", k_lin_f16x3<false>, dim3(grid), dim3(kLinThreads), 0,
-                     (hipStream_t)stream, p);
+    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64,addend>", k_lin_f16x3<true, 2, 2, 2, 1>, dim3(grid), dim3(256), 0,
+                       st, p);
+  return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64>", k_lin_f16x3<false, 2, 2, 2, 1>, dim3(grid), dim3(256), 0, st, p);
 }
 
 extern "C" int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float *gamma, const float *beta, float eps,

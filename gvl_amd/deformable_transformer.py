@@ -260,7 +260,14 @@ class DeformableTransformer(nn.Module):
         lvl_pos = torch.cat([p.transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)],
                             1)
         temporal_shapes, level_start_index = make_level_tensors(lengths, src_flatten.device)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        if (_layers.enabled() and mask_flatten.is_cuda and not torch.is_grad_enabled() and not self.no_encoder
+                and len(lengths) <= 8):
+            # inference: valid ratios and the encoder's reference points (:209-218) from the flat mask in ONE launch
+            starts = temporal_shapes._gvl_host_lengths[1]
+            valid_ratios, ref = _layers.encoder_geometry(mask_flatten, lengths, starts)
+            valid_ratios._gvl_enc_ref = ref
+        else:
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         return src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos, mask_flatten
 
     def forward_encoder(self, src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,

@@ -38,13 +38,14 @@ class Weights:
     """[W_0; W_1; ...] (each padded to a multiple of 64 rows) as fp16 planes + the concatenated bias; ``starts[i]`` is the
     first column of block i.  Built once per parameter version (``cached``)."""
 
-    def __init__(self, pairs):
+    def __init__(self, pairs, pad_to=64):
+        """pad_to=128: every block starts at a multiple of 128 columns, which lets the kernel use its 128 x 128 tile"""
         ws, bs, self.starts, self.widths = [], [], [], []
         n = 0
         for w, b in pairs:
             w = w.detach()
             rows = w.shape[0]
-            pad = (-rows) % 64
+            pad = (-rows) % pad_to
             self.starts.append(n)
             self.widths.append(rows)
             ws.append(w if not pad else torch.cat([w, w.new_zeros(pad, w.shape[1])], 0))
@@ -57,13 +58,16 @@ class Weights:
             self.bias = torch.cat(bs, 0).float().contiguous()
 
 
-def cached(owner, name, params):
-    """Weights of `params` = [(weight, bias), ...] kept on `owner` until one of the parameters changes"""
+def cached(owner, name, params, pad_to=None):
+    """Weights of `params` = [(weight, bias), ...] kept on `owner` until one of the parameters changes.  Several blocks
+    are padded to multiples of 128 columns when that keeps the launch on the wide tile (total >= 256 columns)."""
     key = tuple((p_.data_ptr(), p_._version) for pair in params for p_ in pair if p_ is not None)
     store = owner.__dict__.setdefault("_gvl_lin_w", {})
     hit = store.get(name)
     if hit is None or hit[0] != key:
-        hit = store[name] = (key, Weights(params))
+        if pad_to is None:
+            pad_to = 128 if len(params) > 1 and sum(w_.shape[0] for w_, _ in params) >= 256 else 64
+        hit = store[name] = (key, Weights(params, pad_to))
     return hit[1]
 
 
@@ -186,6 +190,23 @@ def decoder_eligible(dec, tgt, src, temporal_shapes):
     return True
 
 
+def encoder_geometry(mask_flatten, lengths, starts, want_ref=True):
+    """gvl_encoder_geometry_f32: flattened padding mask (B, S) -> (valid_ratios (B, L), encoder reference points
+    (B, S, L, 1) or None)   (deformable_transformer.py:81-83, 209-218)"""
+    B, S = mask_flatten.shape
+    L = len(lengths)
+    m8 = mask_flatten.contiguous().view(torch.uint8)
+    vr = torch.empty(B, L, device=m8.device, dtype=torch.float32)
+    ref = torch.empty(B, S, L, 1, device=m8.device, dtype=torch.float32) if want_ref else None
+    arr = (ctypes.c_int64 * L)
+    with torch.cuda.device(m8.device):
+        rc = _lib.lib().gvl_encoder_geometry_f32(m8.data_ptr(), B, S, L, arr(*lengths), arr(*starts), vr.data_ptr(),
+                                                 ref.data_ptr() if want_ref else None,
+                                                 torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "encoder_geometry")
+    return vr, ref
+
+
 # ---- encoder ------------------------------------------------------------------------------------------------------------
 def _msda(att, value, proj, ref, shapes2d, lsi, B, Lq, arena):
     am_o = arena.take(B * Lq)
@@ -214,7 +235,9 @@ def encoder_forward(enc, src, temporal_shapes, level_start_index, valid_ratios, 
     from .ops.modules.ms_deform_attn import temporal_shapes_2d
     B, S, C = src.shape
     R = B * S
-    ref = enc.get_reference_points(temporal_shapes, valid_ratios, device=src.device)          # (B, S, L, 1)
+    ref = getattr(valid_ratios, "_gvl_enc_ref", None)                        # left by prepare_encoder_inputs
+    if ref is None or ref.shape[:2] != src.shape[:2]:
+        ref = enc.get_reference_points(temporal_shapes, valid_ratios, device=src.device)      # (B, S, L, 1)
     shapes2d = temporal_shapes_2d(temporal_shapes, level_start_index)
     x = src.reshape(R, C).contiguous()
     posf = pos.reshape(R, C).contiguous() if pos is not None else None

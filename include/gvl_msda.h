@@ -189,6 +189,12 @@ int gvl_row_absmax_f32(const float *x, int64_t ldx, int R, int C, const float *p
  *        or NULL receives max |out row|. */
 int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, int B, int Q, int H, float *out,
                      float *amax_out, void *stream);
+/*    gvl_encoder_geometry_f32: valid ratios (pdvc/deformable_transformer.py:81-83,113: share of un-padded frames per level)
+ *        and the encoder's reference points (:209-218) from the flattened padding mask in one launch:
+ *        valid_ratios[b][l] = #{t < T_l : !mask[b][s_l + t]} / T_l;   ref[b][s_l + t][l'] = (t + 0.5) / (vr[b][l] T_l) * vr[b][l'].
+ *        mask (B, S) bytes (non-zero = padded), level lengths / starts as host arrays of L <= 8 entries. */
+int gvl_encoder_geometry_f32(const unsigned char *mask, int B, int S, int L, const int64_t *lengths_host,
+                             const int64_t *starts_host, float *valid_ratios, float *ref, void *stream);
 int gvl_box_refine_f32(const float *delta, int64_t ldd, const float *ref, int RD, const float *valid_ratios, int B, int Q,
                        int L, float *new_ref, float *ref_in, void *stream);
 int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight, const float *bias, int n_out, float *out,
@@ -229,6 +235,12 @@ int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, const float *x
                               void *stream);
 int gvl_greedy_step_partials_f32(const float *partials, int R, int V, int first_step, int64_t *token, float *logp,
                                  unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld, void *stream);
+/*    ..._alive_f32: additionally sets *alive = 1 (device byte, zero-initialised by the caller, may be NULL) when any row is
+ *    still unfinished after this step -- the loop-exit test `unfinished.sum() == 0` of LSTM_DSA.py:186-187 without a
+ *    reduction kernel per step. */
+int gvl_greedy_step_partials_alive_f32(const float *partials, int R, int V, int first_step, int64_t *token, float *logp,
+                                       unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld,
+                                       unsigned char *alive, void *stream);
 
 /* -- PositionEmbeddingSine.forward of one pyramid level (pdvc/position_encoding.py:38-64; the step in front of the
  *    path): normalised cumulative frame index -> interleaved sin / cos over `dim_t`, followed

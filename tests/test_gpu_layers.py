@@ -161,6 +161,28 @@ def test_attention_core_matches_fp64(B, Q, H, masked):
     assert torch.equal(am, out.abs().amax(1))
 
 
+def test_encoder_geometry_equals_the_pytorch_formulation():
+    """valid ratios and encoder reference points from the flat mask in one launch == deformable_transformer.py:81-83,209-218"""
+    from gvl_amd import layers as L
+    from gvl_amd.deformable_transformer import DeformableTransformerEncoder, make_level_tensors
+    from helpers import level_lengths
+    B, T = 5, 100
+    lens = level_lengths(T)
+    starts = [int(v) for v in np.concatenate([[0], np.cumsum(lens)[:-1]])]
+    masks = []
+    for l_, n in enumerate(lens):
+        m = torch.zeros(B, n, dtype=torch.bool, device=DEV)
+        for b in range(B):
+            m[b, max(1, n - (b * n) // 6):] = True
+        masks.append(m)
+    vr, ref = L.encoder_geometry(torch.cat(masks, 1), lens, starts)
+    want_vr = torch.stack([torch.sum(~m, 1).float() / m.shape[1] for m in masks], 1)
+    assert torch.equal(vr, want_vr)
+    ts, _ = make_level_tensors(lens, torch.device(DEV))
+    want_ref = DeformableTransformerEncoder.get_reference_points(ts, want_vr, torch.device(DEV))
+    assert ref.shape == want_ref.shape and maxerr(ref, want_ref) <= 1e-7
+
+
 def _transformer(seed=0):
     from gvl_amd.deformable_transformer import DeformableTransformer
     torch.manual_seed(seed)
