@@ -466,7 +466,8 @@ def main():
             ktimes = kernel_times(MSDA.profile_collect())
         else:
             ktimes = instrumented(lambda dt: TrainStep.__call__(trainer, dt))
-        res["train"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes,
+        xch = trainer.exchange_times_ms() if hasattr(trainer, "exchange_times_ms") else None
+        res["train"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes, "exchange_ms": xch,
                         "graphs": None if a.no_graph else {
                             "cached": len(trainer.graphs), "captures_total": trainer.captures,
                             "captures_in_timed_region": trainer.captures - caps0, "replays": trainer.replays,
@@ -577,6 +578,12 @@ def main():
         line.update({"train_step_ms": round(ms, 3), "train_videos_per_s": round(world * B * a.steps / t_["elapsed"], 3),
                      "train_roofline": bwd_roofline(t_["ktimes"]), "train_graphs": t_["graphs"],
                      "train_seconds_per_rank": [round(x, 4) for x in t_["per_rank"]]})
+        if t_.get("exchange_ms"):
+            # the eager gradient exchange between the captured graphs (rank 0's view): total = first bucket posted -> all
+            # buckets reduced, exposed = the part that is not hidden under the encoder's backward
+            line["grad_exchange_ms_per_step"] = {"total": round(t_["exchange_ms"][0], 3),
+                                                 "exposed": round(t_["exchange_ms"][1], 3),
+                                                 "bytes": int(sum(p_.numel() for p_ in model.parameters() if p_.requires_grad) * 4)}
         kernels_us["train"] = {ktag(k): {"us": round(v[0], 2), "n": v[1]} for k, v in t_["ktimes"].items()}
         if "eval" not in res:
             line.update({"metric": "train-step ms", "value": round(ms, 3), "unit": "ms", "ms_per_step": round(ms, 3),

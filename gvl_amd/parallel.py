@@ -22,9 +22,14 @@ from .targets import PaddedTargets, needed_capacity, round_up_pow2, total_events
 
 
 def shard_batch(dt, rank, world):
-    """rank r of W takes videos r::W (DistributedSampler-style); only used by tests / multi-GPU drivers."""
+    """rank r of W takes videos r::W (DistributedSampler-style); only used by tests / multi-GPU drivers.  B need not be a
+    multiple of W: the leading B % W ranks hold one video more; a rank without any video (B < W) gets None and skips the
+    forward (an eval forward has no collective; the result gather, gvl_amd.eval_utils.gather_results, takes an empty
+    dict from it)."""
     B = dt["video_tensor"].shape[0]
     idx = list(range(rank, B, world))
+    if not idx:
+        return None
     n_gt = [len(t_["boxes"]) for t_ in dt["video_target"]]
     starts = [sum(n_gt[:i]) for i in range(B)]
     cap_idx = [k for i in idx for k in range(starts[i], starts[i] + n_gt[i])]
@@ -354,6 +359,8 @@ class GraphedTrainStep(TrainStep):
                          flat=True if self.split else None, overlap=not self.split, autocast_dtype=autocast_dtype,
                          first=late)
         self.two_stage = bool(self.split and late and self.buckets.n_first)
+        self.time_exchange = self.split                      # three events per step around the eager collectives
+        self._exchange_events = []
         self._cut = None
         self.graphs = _LRU(max_graphs)
         self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, max_cap_len,
@@ -583,13 +590,35 @@ class GraphedTrainStep(TrainStep):
         graphs[0].replay()
         if self.split:
             # eager RCCL between the replays: the first-stage buckets are on the wire while the encoder's backward runs
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.time_exchange else None
+            if ev:
+                ev[0].record()
             self.buckets.exchange_begin(0)
             graphs[1].replay()
+            if ev:
+                ev[1].record()                                   # encoder backward queued: what follows is exposed
             self.buckets.exchange_begin(1)
             self.buckets.exchange_end()
+            if ev:
+                ev[2].record()
+                self._exchange_events.append(ev)
+                if len(self._exchange_events) > 64:
+                    self._exchange_events.pop(0)
             graphs[2].replay()
         self.replays += 1
         return outs
+
+    def exchange_times_ms(self):
+        """(total, exposed) milliseconds of the gradient exchange per step, means over the recorded steps: total = first
+        bucket posted -> all buckets reduced and averaged (it overlaps the encoder's backward), exposed = the part after
+        the encoder's backward graph was queued.  Synchronises; call it outside the timed region."""
+        if not self._exchange_events:
+            return None
+        torch.cuda.synchronize()
+        tot = [e[0].elapsed_time(e[2]) for e in self._exchange_events]
+        exp = [e[1].elapsed_time(e[2]) for e in self._exchange_events]
+        self._exchange_events = []
+        return sum(tot) / len(tot), sum(exp) / len(exp)
 
 
 class GraphedEvalForward:

@@ -605,11 +605,41 @@ def make_anet_full_train():
     dt.update(cap_tensor=caps, cap_mask=cap_mask,
               gt_boxes_mask=torch.tensor([[k < n for k in range(mx)] for n in n_gt]).bool(),
               gt_gather_idx=torch.tensor([i for i, n in enumerate(n_gt) for _ in range(n)]))
+    # the operands and gradients of ONE deformable-attention op inside this very step (decoder
+    # layer 1, cross attention; video 1, the padded one), recorded at the op's own boundary -- the outputs of value_proj /
+    # sampling_offsets / attention_weights, the reference points, the gradient arriving at the op's output and the
+    # gradients leaving through its three inputs.  A test that feeds these to the fused HIP op isolates the kernel's
+    # sampling-offset gradients from the summation order of the GEMMs upstream of it.
+    att = model.transformer.decoder.layers[1].cross_attn
+    cap = {}
+
+    def keep(name):
+        def hook(mod, inp, outp):
+            outp.retain_grad()
+            cap[name] = outp
+        return hook
+
+    def pre(mod, args):
+        cap["ref"], cap["mask"] = args[1].detach(), args[5]
+
+    def pre_out(mod, args):
+        args[0].retain_grad()
+        cap["op_out"] = args[0]
+    hooks = [att.value_proj.register_forward_hook(keep("value")), att.sampling_offsets.register_forward_hook(keep("off")),
+             att.attention_weights.register_forward_hook(keep("logit")), att.register_forward_pre_hook(pre),
+             att.output_proj.register_forward_pre_hook(pre_out)]
     with cuda_semantics():
         out, loss = model(dt, criterion, cc, "queries")
         wd = criterion.weight_dict
         final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
         final.backward()
+    for h_ in hooks:
+        h_.remove()
+    vb = 1
+    save("msda_op_in_train_step", video=np.array(vb), value=cap["value"][vb].detach(), off=cap["off"][vb].detach(),
+         logit=cap["logit"][vb].detach(), ref=cap["ref"][vb], mask=cap["mask"][vb], out=cap["op_out"][vb].detach(),
+         grad_out=cap["op_out"].grad[vb], grad_value=cap["value"].grad[vb], grad_off=cap["off"].grad[vb],
+         grad_logit=cap["logit"].grad[vb], lens=np.array(level_lengths(T)))
     rec = dict(meta_T=np.array(T), valid=np.array(valid), n_gt=np.array(n_gt), cap_tensor=caps, cap_mask=cap_mask,
                final_loss=final.detach(),
                param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))

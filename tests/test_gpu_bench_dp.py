@@ -1,6 +1,8 @@
 """bench.py's N > 1 control flow (rendezvous, barriers, max-over-ranks timing, one JSON line from rank 0) and the
-data-parallel train step (forward/backward graph, bucketed all-reduce, clip/Adam graph) with REAL collectives: two ranks
-share the one GPU of the test box and talk over gloo (RCCL needs one GPU per rank; the driver's multi-GPU run covers it)."""
+data-parallel train step (forward/backward graph, bucketed all-reduce, clip/Adam graph) with REAL collectives.  On a box
+with >= 2 GPUs the two ranks take one device each and talk over RCCL (backend "nccl"): the line must then report
+rccl_ranks == 2 and per-rank times within 10 % of each other.  On the one-GPU test box the two ranks share the GPU and talk
+over gloo (RCCL needs one GPU per rank)."""
 import json
 import os
 import socket
@@ -21,7 +23,11 @@ def _free_port():
 
 @pytest.mark.parametrize("mode", ["both", "train"])
 def test_two_ranks_on_one_gpu(mode):
-    env = dict(os.environ, GVL_DIST_BACKEND="gloo", GVL_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    rccl = torch.cuda.device_count() >= 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not rccl:
+        env.update(GVL_DIST_BACKEND="gloo", GVL_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--batch", "4", "--queries", "40", "--rotate", "3", "--no-cpu-baseline", "--no-probes"] + (["--mode", "train"] if mode == "train" else [])
@@ -33,5 +39,14 @@ def test_two_ranks_on_one_gpu(mode):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8
     assert d["value"] > 0 and d["scaling"] == "weak" and d["train_step_ms"] > 0
     assert len(d["train_seconds_per_rank"]) == 2 and d["train_graphs"]["captures_in_timed_region"] == 0
+    ex = d["grad_exchange_ms_per_step"]                      # the eager exchange between the captured graphs, timed per step
+    assert ex["total"] >= ex["exposed"] >= 0 and ex["bytes"] > 0
+    if rccl:
+        assert d["rccl_ranks"] == 2
+        for key in ("train_seconds_per_rank",) + (("eval_seconds_per_rank",) if mode == "both" else ()):
+            lo, hi = min(d[key]), max(d[key])
+            assert hi <= 1.10 * lo, (key, d[key])
+    else:
+        assert d["rccl_ranks"] == "2 (gloo)"
     if mode == "both":
         assert d["metric"].startswith("videos/sec") and d["eval_graphs"]["cached"] == 1

@@ -158,7 +158,8 @@ def test_anet_full_dimension_graphed_train_step_equals_eager():
 def test_anet_full_eval_error_is_at_the_fp32_noise_floor():
     """|gvl_amd fp32 - reference fp64| <= 4 x |reference fp32 - reference fp64| (+ 2e-6): gvl_amd's model-level outputs
     are as close to the exact values as the reference's own fp32 run is.  Greedy tokens: the reference's fp32 and fp64
-    runs agree on every token; gvl_amd may flip near-ties (different summation order), >= 95 % of the tokens agree."""
+    runs agree on every token; gvl_amd may flip a near-tie (different summation order; measured: 1 of 18 000 tokens):
+    at least 99.95 % of the tokens agree."""
     h = load("pdvc_anet_full_f64")
     f, opt, model, criterion = build_anet(False)
     dt = to_dev(pdvc_dt(f, feat=int(f["feature_dim"]), seed=6))
@@ -173,7 +174,7 @@ def test_anet_full_eval_error_is_at_the_fp32_noise_floor():
     seq = out["seq"].cpu()
     agree = float((seq == t(h["seq_f64"])).float().mean())
     report["tokens"] = agree
-    assert agree >= 0.95
+    assert agree >= 0.9995
     print("error vs fp64 (gvl_amd, reference fp32 floor):", report)
 
 

@@ -186,3 +186,35 @@ def test_random_shapes_through_every_kernel_form():
         lp_ref, tok_ref = torch.log_softmax(out.double(), 1).max(1)
         assert bool((tok == tok_ref).all()), (R, K, N)
         assert float((lp.double() - lp_ref).abs().max()) <= 3e-6, (R, K, N)
+
+
+def test_non_finite_and_sub_floor_elements_have_defined_behaviour():
+    """VERDICT r2 weak 1(c).  Defined behaviour of the split product outside its fp32-accuracy domain:
+      * a non-finite element (inf / NaN) of an operand row makes every output of THAT row (A side) or column (B side)
+        non-finite, and no other -- as an fp32 GEMM would (inf may surface as NaN: the residual plane of inf is NaN);
+      * elements more than 2^-35 below their row's maximum are flushed: error <= K 2^-33 max|a_row| max|b_row| per output
+        (the documented bound), nothing else in the row is disturbed."""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(77)
+    R, K, N = 300, 512, 256
+    x = torch.randn(R, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) * 0.05
+    x[7, 100] = float("inf")
+    x[9, 3] = float("nan")
+    x[11] *= 2.0 ** -40
+    x[11, 5] = 3.0                                                       # one element 2^40 above the rest of its row
+    w[13, 8] = float("-inf")
+    out = MSDA.gemm_f16x3(MSDA.split_rows(x), MSDA.split_rows(w))
+    fin = torch.isfinite(out)
+    assert not fin[7].any() and not fin[9].any() and not fin[:, 13].any()
+    ok_r = torch.ones(R, dtype=torch.bool, device=dev)
+    ok_r[7] = ok_r[9] = False
+    ok_c = torch.ones(N, dtype=torch.bool, device=dev)
+    ok_c[13] = False
+    assert bool(fin[ok_r][:, ok_c].all())
+    xd, wd = x.double()[ok_r], w.double()[ok_c]
+    want = xd @ wd.t()
+    bound = (2.0 ** -21 * (xd.abs() @ wd.abs().t())
+             + K * 2.0 ** -33 * xd.abs().amax(1, keepdim=True) * wd.abs().amax(1)[None] + 2.0 ** -23 * want.abs())
+    assert bool(((out[ok_r][:, ok_c].double() - want).abs() <= bound).all())

@@ -584,7 +584,9 @@ def test_anet_full_dimension_eval_matches_reference():
         assert seq.shape == ref_seq.shape == (2, 300, int(f["max_caption_len"]))
         seq, ref_seq = seq.reshape(-1, seq.shape[-1]), ref_seq.reshape(-1, ref_seq.shape[-1])
         row_same = (seq == ref_seq).all(1)
-        assert float((seq == ref_seq).float().mean()) >= 0.95 and float(row_same.float().mean()) >= 0.85
+        # greedy tokens: equal to the reference's except where two logits tie to within the fp32 noise of the products in
+        # front of them (a flipped tie changes that token and the rest of its caption): at most 3 of the 600 captions
+        assert float((seq == ref_seq).float().mean()) >= 0.999 and int((~row_same).sum()) <= 3
         lp = out["caption_probs"]["cap_prob_eval"].float().cpu().reshape(-1, seq.shape[-1])
         assert maxerr(lp[row_same], t(f["cap_prob_eval"]).reshape(-1, seq.shape[-1])[row_same]) <= 2e-3
 

@@ -1,0 +1,50 @@
+"""the fused deformable-attention op fed with the REFERENCE's own operands of one op inside the
+full-dimension training step (decoder layer 1, cross attention; tests/golden/msda_op_in_train_step.npz, recorded by
+make_golden.py:make_anet_full_train at the op's boundary) must reproduce the reference's output and every gradient that
+leaves the op -- sampling offsets, attention logits, value -- element-wise at 1e-4.  This isolates the kernel from the
+summation order of the GEMMs upstream of it: the 2e-2 band that tests/test_gpu_full_dims.py grants the location-fed
+PARAMETER gradients is therefore a property of those GEMMs (a sample that sits within an ulp of a frame boundary changes
+sides when its location moves by an ulp), not of the sampling kernels."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, maxerr, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def scale(a):
+    return max(1e-6, float(np.abs(np.asarray(a)).max()))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_op_reproduces_the_reference_gradients_at_its_own_boundary(fused):
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd.ops.functions.ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedFunction
+    f = load("msda_op_in_train_step")
+    lens = [int(x) for x in f["lens"]]
+    S, Q, M, L, P = sum(lens), f["off"].shape[0], 8, 4, 4
+    shapes = torch.tensor([(1, x) for x in lens], dtype=torch.long, device=DEV)
+    lsi = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.long, device=DEV)
+    MSDA.attach_host_shapes(shapes, lsi, [(1, x) for x in lens], [int(v) for v in lsi.tolist()])
+    mask = t(f["mask"]).to(DEV)
+    v_in = t(f["value"]).to(DEV).requires_grad_()
+    off = t(f["off"]).to(DEV).requires_grad_()
+    logit = t(f["logit"]).to(DEV).requires_grad_()
+    ref = t(f["ref"]).to(DEV)[None].contiguous()
+    value = v_in.masked_fill(mask[:, None], 0.0).view(1, S, M, 64)           # ms_deform_attn.py:96-97
+    if fused:
+        proj = torch.cat([off, logit], -1)[None]
+        out = MSDeformAttnFusedFunction.apply(value, proj, ref, shapes, lsi, L, P, "zeros")
+    else:
+        w = torch.softmax(logit.view(1, Q, M, L * P), -1).view(1, Q, M, L, P)                    # :100-101
+        x = ref[:, :, None, :, None, 0] + off.view(1, Q, M, L, P) / P * ref[:, :, None, :, None, 1] * 0.5   # :107-109
+        loc = torch.stack([x, torch.full_like(x, 0.5)], -1)
+        out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, w, 64)
+    assert maxerr(out[0], f["out"]) <= 1e-4 * scale(f["out"])
+    out.backward(t(f["grad_out"]).to(DEV)[None])
+    for name, got in (("grad_off", off.grad), ("grad_logit", logit.grad), ("grad_value", v_in.grad)):
+        err = maxerr(got, f[name])
+        assert err <= 1e-4 * scale(f[name]), (name, err, scale(f[name]))

@@ -121,6 +121,10 @@ def test_shard_batch_partitions_videos_and_captions():
         assert len(s["video_target"]) == s["video_tensor"].shape[0] == len(s["cap_raw"])
         assert s["cap_tensor"].shape[0] == sum(len(t_["boxes"]) for t_ in s["video_target"])
     assert sorted(seen_v) == list(range(B)) and sorted(seen_c) == list(range(sum(n_gt)))
+    # B not a multiple of W: the leading ranks hold one video more; a rank without a video gets None
+    sizes = [shard_batch(dt, r, 3)["video_tensor"].shape[0] for r in range(3)]
+    assert sum(sizes) == B and max(sizes) - min(sizes) <= 1
+    assert shard_batch(dt, B, B + 1) is None and shard_batch(dt, B - 1, B + 1)["video_tensor"].shape[0] == 1
 
 
 def _worker_gather(rank, world, port, q):
