@@ -537,8 +537,11 @@ class Captioner(nn.Module):
         const = self.core.prepare(hs, memory, mask)
         # embedding rows pre-multiplied by their slice of W_ih: one gather per step instead of a GEMM
         emb_gates = self._embedding_gates()
-        h = torch.zeros(n, self.rnn_size, dtype=torch.float32, device=hs.device)      # the recurrent state is fp32, also
-        c = torch.zeros(n, self.rnn_size, dtype=torch.float32, device=hs.device)      # under autocast
+        # the recurrent state is fp32, also under autocast; h, c (and the greedy loop's log-prob table) share ONE zero fill
+        T_ = self.max_caption_len
+        zbuf = torch.zeros(2 * n * self.rnn_size + n * T_, dtype=torch.float32, device=hs.device)
+        h = zbuf[:n * self.rnn_size].view(n, self.rnn_size)
+        c = zbuf[n * self.rnn_size:2 * n * self.rnn_size].view(n, self.rnn_size)
         it = torch.zeros(n, dtype=torch.long, device=hs.device)                       # <bos>
         T = self.max_caption_len
         if sample_max:
@@ -549,7 +552,7 @@ class Captioner(nn.Module):
                   "h": h, "c": c, "it": it, "logits": None,
                   "unfinished": torch.empty(n, dtype=torch.uint8, device=hs.device),
                   "seq": torch.zeros(n, T, dtype=torch.long, device=hs.device),
-                  "seq_lp": torch.zeros(n, T, dtype=torch.float32, device=hs.device),
+                  "seq_lp": zbuf[2 * n * self.rnn_size:].view(n, T),
                   # alive[t]: some row is still unfinished after token t -- set by the greedy kernel itself
                   "alive": torch.zeros(T, dtype=torch.uint8, device=hs.device)}
             # (running the vocabulary GEMM + argmax of token t on a second stream beside the token-independent half of

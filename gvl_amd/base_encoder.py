@@ -2,6 +2,7 @@
 pdvc/position_encoding.py:38-64.  Plain PyTorch-ROCm ops (conv1d / GroupNorm): SURVEY.md section 8 keeps these out
 of hand-kernel scope (row f2 "next").  Parameter names: ``input_proj.{l}.{0,1}``, ``pos_embed.duration_embed_layer``.
 """
+import ctypes
 import math
 
 import torch
@@ -115,6 +116,101 @@ class BaseEncoder(nn.Module):
             cols = torch.cat([xp[:, :, k:k + 2 * t_out:2] for k in range(3)], dim=1)      # (N, 3*C_in, T_out)
             y = torch.matmul(w.permute(0, 2, 1).reshape(w.shape[0], -1), cols)
         return norm(y + conv.bias[None, :, None])
+
+    # -- inference: the whole pyramid flattened, on the hand-written kernels ------------------------------------------
+    def flat_eligible(self, vf, mask):
+        from . import layers as L
+        c0 = self.input_proj[0][0]
+        return (L.enabled() and not torch.is_grad_enabled() and not self.training and not torch.is_autocast_enabled()
+                and vf.is_cuda and vf.dtype == torch.float32 and 1 < self.num_feature_levels <= 8
+                and isinstance(c0, nn.Conv1d) and vf.shape[-1] % 32 == 0 and self.hidden_dim % 64 == 0
+                and self.pos_embed.normalize and self.pos_embed.num_pos_feats + self.pos_embed.max_duration == self.hidden_dim
+                and all(64 % (self.hidden_dim // p_[1].num_groups) == 0 for p_ in self.input_proj)
+                and vf.shape[1] >= 2 ** (self.num_feature_levels - 1))
+
+    def _conv_weights(self, l):
+        """the level's convolution as the (C_out, k * C_in) matrix of a product over rows of taps, as split planes"""
+        from . import layers as L
+        conv = self.input_proj[l][0]
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version)
+        hit = conv.__dict__.get("_gvl_conv_w")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = conv.weight.detach()
+                w2 = w[:, :, 0] if conv.kernel_size[0] == 1 else w.permute(0, 2, 1).reshape(w.shape[0], -1)
+                hit = conv.__dict__["_gvl_conv_w"] = (key, L.Weights([(w2.contiguous(), conv.bias.detach())]))
+        return hit[1]
+
+    def forward_flat(self, vf, mask, duration, level_embed):
+        """Inference form of forward() + DeformableTransformer.prepare_encoder_inputs (deformable_transformer.py:85-115):
+        -> (src_flatten (N, S, C), mask_flatten (N, S) bool, lvl_pos_embed_flatten (N, S, C), level lengths).
+        Every conv1d is one gvl_linear_f16x3_f32 product -- the k = 3, stride 2 levels read their three taps as ONE row of
+        a strided view of the zero-padded input ((N, 2 (T' + 1), C_in) rows: tap row 2 t' - 1 .. 2 t' + 1 of frame t' are
+        contiguous) --, GroupNorm writes each level straight into its rows of the flattened tensor (and into the next
+        level's padded input), one launch produces all masks / position / level embeddings (gvl_pyramid_geometry_f32)."""
+        from . import _lib
+        from . import layers as L
+        N, T, Cin = vf.shape
+        C, nl = self.hidden_dim, self.num_feature_levels
+        lengths = [T]
+        for _ in range(nl - 1):
+            lengths.append((lengths[-1] - 1) // 2 + 1)
+        starts = [sum(lengths[:i]) for i in range(nl)]
+        S = sum(lengths)
+        dev = vf.device
+        src = torch.empty(N, S, C, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def group_norm(y, rows_per_video, l, dst2=None, dst2_vs=0):
+            norm = self.input_proj[l][1]
+            with torch.cuda.device(dev):
+                rc = _lib.lib().gvl_group_norm_rows_f32(
+                    y.data_ptr(), y.stride(0), rows_per_video, N, lengths[l], C, norm.num_groups, norm.weight.data_ptr(),
+                    norm.bias.data_ptr(), float(norm.eps), src.data_ptr() + 4 * starts[l] * C, S * C,
+                    dst2.data_ptr() + 4 * C if dst2 is not None else None, dst2_vs, stream)
+            _lib.check(rc, "group_norm_rows")
+
+        def padded(t_in, ch):
+            """zeroed (N + 1, 2 (T' + 1), ch) buffer: row 0 and the rows behind the t_in frames are the convolution's padding
+            (and slack for the last, unused tap row of every video); the extra video keeps the strided view in bounds"""
+            t_out = (t_in - 1) // 2 + 1
+            return torch.zeros(N + 1, 2 * (t_out + 1), ch, device=dev, dtype=torch.float32), t_out
+
+        def conv_s2(xp, t_out, ch, l):
+            a = xp.as_strided((N * (t_out + 1), 3 * ch), (2 * ch, 1))           # row (n, t'): taps 2 t' - 1 .. 2 t' + 1
+            am, _ = L.row_absmax(a)
+            y = torch.empty(N * (t_out + 1), C, device=dev, dtype=torch.float32)
+            L.linear(a, self._conv_weights(l), [L.seg(0, y, am)])
+            return y
+
+        x = vf.reshape(N * T, Cin)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        am, _ = L.row_absmax(x)
+        y0 = torch.empty(N * T, C, device=dev, dtype=torch.float32)
+        L.linear(x, self._conv_weights(0), [L.seg(0, y0, am)])
+        group_norm(y0, T, 0)
+        xp, t_out = padded(T, Cin)                                             # level 1 convolves the RAW features
+        xp[:N, 1:T + 1] = vf
+        ch = Cin
+        for l in range(1, nl):
+            y = conv_s2(xp, t_out, ch, l)
+            nxt = padded(lengths[l], C) if l + 1 < nl else (None, 0)
+            group_norm(y, t_out + 1, l, nxt[0], nxt[0].shape[1] * C if nxt[0] is not None else 0)
+            xp, t_out, ch = nxt[0], nxt[1], C
+        dur = self.pos_embed.duration_embedding(duration).contiguous()
+        mask_u8 = mask.contiguous().view(torch.uint8)
+        mask_flat = torch.empty(N, S, device=dev, dtype=torch.uint8)
+        lvl_pos = torch.empty(N, S, C, device=dev, dtype=torch.float32)
+        arr = (ctypes.c_int64 * nl)
+        pe = self.pos_embed
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gvl_pyramid_geometry_f32(
+                mask_u8.data_ptr(), N, T, S, nl, arr(*lengths), arr(*starts), pe._dim_t(dev).data_ptr(), dur.data_ptr(),
+                level_embed.contiguous().data_ptr(), pe.num_pos_feats, pe.max_duration, float(pe.scale),
+                mask_flat.data_ptr(), lvl_pos.data_ptr(), stream)
+        _lib.check(rc, "pyramid_geometry")
+        return src, mask_flat.view(torch.bool), lvl_pos, lengths
 
     def forward(self, vf, mask, duration):
         """vf (N,T,C_in), mask (N,T) True=pad, duration (N,) -> lists over levels of (N,C,T_l), (N,T_l), (N,C,T_l)"""

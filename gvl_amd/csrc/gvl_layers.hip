@@ -101,12 +101,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
 
   int tm, tn;
   if (p.xcd_cols) {
-    // column tile c on XCD c % 8 (workgroup id % 8): with 64-wide tiles the (b, m) slabs of `value` are written from the
-    // XCD whose L2 the sampling kernel reads them from (its workgroups of head m sit on XCD m: ids B M apart, M = 8)
-    const int per = p.tiles_n >> 3, bid = (int)blockIdx.x;
-    tn = (bid & 7) + 8 * ((bid >> 3) % per);
-    tm = (bid >> 3) / per;
-    if (tm >= p.tiles_m) return;
+    // column tile c (< 8 floor(tiles_n / 8)) on XCD c % 8 (= workgroup id % 8): with 64-wide tiles the (b, m) slabs of
+    // `value` are written from the XCD whose L2 the sampling kernel reads them from (its workgroups of head m sit on XCD
+    // m: ids B M apart, M = 8).  The remaining tiles_n % 8 column tiles follow behind, in any order.
+    const int per = p.tiles_n >> 3, rem = p.tiles_n & 7, bid = (int)blockIdx.x, na = 8 * per * p.tiles_m;
+    if (bid < na) {
+      tn = (bid & 7) + 8 * ((bid >> 3) % per);
+      tm = (bid >> 3) / per;
+    } else {
+      const int t = bid - na;
+      if (t >= rem * p.tiles_m) return;
+      tn = 8 * per + t % rem;
+      tm = t / rem;
+    }
   } else if (!tile_of((int)blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) {
     return;
   }
@@ -646,6 +653,107 @@ __global__ void __launch_bounds__(256) k_encoder_geometry(const unsigned char *_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Feature pyramid of the base encoder, inference (pdvc/base_encoder.py:55-82, pdvc/position_encoding.py:38-64,
+// pdvc/deformable_transformer.py:85-115): the conv1d of every level is a gvl_linear_f16x3_f32 product (k = 3, stride 2
+// reads its three taps as ONE row of a strided view of the zero-padded input); what remains around it is
+//   k_group_norm_rows    GroupNorm of a level's conv output, written straight into the level's rows of the flattened
+//                        (B, S, C) encoder input -- and, zero-padded, into the next level's conv input;
+//   k_pyramid_geometry   every level's padding mask (nearest-neighbour resampling of the frame mask), sine position
+//                        embedding + duration embedding + level embedding, flattened: mask (B, S), lvl_pos (B, S, C).
+// ~60 PyTorch launches per forward otherwise (transposes, cats, interpolate, cumsum, sin / cos, group-norm passes).
+
+// one wavefront per (video, group): rows y[(n rows_per_video + t) ldy + c], t < T, c in the group's cg channels
+__global__ void __launch_bounds__(256) k_group_norm_rows(const float *__restrict__ y, int64_t ldy, int rows_per_video, int T,
+                                                         int C, int G, int N, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float eps, float *__restrict__ dst,
+                                                         int64_t dst_vs, float *__restrict__ dst2, int64_t dst2_vs) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= N * G) return;
+  const int n = unit / G, g = unit % G, cg = C / G;
+  const int c = g * cg + lane % cg, tr = lane / cg, tstep = 64 / cg;
+  const float *src = y + (int64_t)n * rows_per_video * ldy + c;
+  float sum = 0.f;
+  for (int t = tr; t < T; t += tstep) sum += src[(int64_t)t * ldy];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float cnt = (float)T * (float)cg, mean = sum / cnt;
+  float sq = 0.f;
+  for (int t = tr; t < T; t += tstep) {
+    const float d = src[(int64_t)t * ldy] - mean;
+    sq = fmaf(d, d, sq);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.f / sqrtf(sq / cnt + eps);
+  const float a = rstd * gamma[c], b2 = beta[c] - mean * rstd * gamma[c];
+  float *d1 = dst + (int64_t)n * dst_vs + c;
+  float *d2 = dst2 ? dst2 + (int64_t)n * dst2_vs + c : nullptr;
+  for (int t = tr; t < T; t += tstep) {
+    const float v = fmaf(src[(int64_t)t * ldy], a, b2);
+    d1[(int64_t)t * C] = v;
+    if (d2) d2[(int64_t)t * C] = v;
+  }
+}
+
+struct PyramidDims { int len[8], start[8]; };
+
+// grid (videos, levels, slices): mask_flat (N, S) bytes, lvl_pos (N, S, F + Cd)
+__global__ void __launch_bounds__(256) k_pyramid_geometry(const unsigned char *__restrict__ mask0, int T0, int S, int L,
+                                                          PyramidDims d, const float *__restrict__ dim_t,
+                                                          const float *__restrict__ dur, const float *__restrict__ level_embed,
+                                                          int F, int Cd, float scale, unsigned char *__restrict__ mask_flat,
+                                                          float *__restrict__ lvl_pos) {
+  extern __shared__ float xs[];                     // normalised position of every frame of this level
+  __shared__ int wave_tot[4];
+  __shared__ int carry;
+  const int n = blockIdx.x, l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = d.len[l], s0 = d.start[l], C = F + Cd;
+  // nearest-neighbour resampling of the frame mask (F.interpolate(mask.float(), size=T), base_encoder.py:75)
+  const float rs = (float)T0 / (float)T;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < T; base += blockDim.x) {
+    const int t = base + threadIdx.x;
+    int v = 0;
+    if (t < T) {
+      const int src = l == 0 ? t : min((int)floorf((float)t * rs), T0 - 1);
+      const unsigned char m = mask0[(int64_t)n * T0 + src];
+      if (blockIdx.z == 0) mask_flat[(int64_t)n * S + s0 + t] = m ? 1 : 0;
+      v = m ? 0 : 1;
+    }
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int k = 0; k < wave; ++k) pre += wave_tot[k];
+    if (t < T) xs[t] = (float)(pre + incl);
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry = pre + incl;
+    __syncthreads();
+  }
+  const float denom = xs[T - 1] + 1e-6f;
+  float *o = lvl_pos + ((int64_t)n * S + s0) * C;
+  const float *le = level_embed + (int64_t)l * C;
+  const int stride = blockDim.x * gridDim.z, first = blockIdx.z * blockDim.x + threadIdx.x;
+  for (int idx = first; idx < T * C; idx += stride) {
+    const int t = idx / C, c = idx % C;
+    float v;
+    if (c < F) {
+      const float p = (xs[t] - 0.5f) / denom * scale / dim_t[c];
+      v = (c & 1) ? cosf(p) : sinf(p);
+    } else {
+      v = dur[(int64_t)n * Cd + (c - F)];
+    }
+    o[idx] = v + le[c];
+  }
+}
+
 // sigmoid(delta + inverse_sigmoid(ref)) and the next layer's scaled reference points (deformable_transformer.py:301-324)
 __global__ void __launch_bounds__(256) k_box_refine(const float *__restrict__ delta, int64_t ldd, const float *__restrict__ ref,
                                                     int RD, const float *__restrict__ vr, int R, int Q, int L,
@@ -731,6 +839,45 @@ extern "C" int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned cha
                      ld, key_keep, B, Q, H, out, amax_out);
 }
 
+extern "C" int gvl_group_norm_rows_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G,
+                                       const float *gamma, const float *beta, float eps, float *dst, int64_t dst_video_stride,
+                                       float *dst2, int64_t dst2_video_stride, void *stream) {
+  if (N < 0 || T <= 0 || C <= 0 || G <= 0 || C % G || 64 % (C / G) || ldy < C || rows_per_video < T)
+    return fail(GVL_EINVAL, "gvl_group_norm_rows_f32: needs C / G in {1, 2, 4, ..., 64} (got N=%d T=%d C=%d G=%d)", N, T, C, G);
+  if (N == 0) return 0;
+  if (!y || !gamma || !beta || !dst) return fail(GVL_EINVAL, "gvl_group_norm_rows_f32: null pointer");
+  return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows", k_group_norm_rows, dim3((N * G + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, y, ldy, rows_per_video, T, C, G, N, gamma, beta, eps, dst, dst_video_stride, dst2,
+                     dst2_video_stride);
+}
+
+extern "C" int gvl_pyramid_geometry_f32(const unsigned char *mask, int N, int T0, int S, int L, const int64_t *lengths_host,
+                                        const int64_t *starts_host, const float *dim_t, const float *dur_embed,
+                                        const float *level_embed, int n_sine, int n_dur, float scale,
+                                        unsigned char *mask_flat, float *lvl_pos, void *stream) {
+  if (N < 0 || T0 <= 0 || S <= 0 || L <= 0 || L > 8 || n_sine <= 0 || (n_sine & 1) || n_dur < 0 || !lengths_host || !starts_host)
+    return fail(GVL_EINVAL, "gvl_pyramid_geometry_f32: bad sizes");
+  if (N == 0) return 0;
+  if (!mask || !dim_t || !level_embed || !mask_flat || !lvl_pos || (n_dur > 0 && !dur_embed))
+    return fail(GVL_EINVAL, "gvl_pyramid_geometry_f32: null pointer");
+  PyramidDims d = {};
+  int tmax = 0;
+  for (int l = 0; l < L; ++l) {
+    d.len[l] = (int)lengths_host[l];
+    d.start[l] = (int)starts_host[l];
+    if (d.len[l] <= 0 || d.start[l] < 0 || d.start[l] + d.len[l] > S || (l == 0 && d.len[0] != T0))
+      return fail(GVL_EINVAL, "gvl_pyramid_geometry_f32: level %d outside S (level 0 must have T0 frames)", l);
+    tmax = d.len[l] > tmax ? d.len[l] : tmax;
+  }
+  const size_t lds = (size_t)tmax * sizeof(float);
+  if (int rc = gvl::ensure_lds(k_pyramid_geometry, lds)) return rc;
+  int slices = (int)(((int64_t)(n_sine + n_dur) * d.len[0] + 4095) / 4096);
+  slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
+  return gvl::launch(GVL_PROF_POS_EMBED, T0, N, "k_pyramid_geometry", k_pyramid_geometry, dim3(N, L, slices), dim3(256), lds,
+                     (hipStream_t)stream, mask, T0, S, L, d, dim_t, dur_embed, level_embed, n_sine, n_dur, scale, mask_flat,
+                     lvl_pos);
+}
+
 extern "C" int gvl_encoder_geometry_f32(const unsigned char *mask, int B, int S, int L, const int64_t *lengths_host,
                                         const int64_t *starts_host, float *valid_ratios, float *ref, void *stream) {
   if (B < 0 || S <= 0 || L <= 0 || L > 8 || !lengths_host || !starts_host) return fail(GVL_EINVAL, "gvl_encoder_geometry_f32: bad sizes (L <= 8)");
@@ -777,7 +924,8 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   if ((int64_t)N * K >= (int64_t)1 << 31) return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: weight plane of more than 2^31 elements");
   if (R == 0) return 0;
   if (!a || !w_hi || !w_lo || !w_scale) return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: null pointer");
-  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15))
+  // (lda < K is allowed: overlapping rows -- the tap rows of a strided convolution over a padded input)
+  if (lda <= 0 || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15))
     return fail(GVL_EINVAL, "gvl_linear_f16x3_f32: a (lda %% 4 == 0) and the weight planes must be 16-byte aligned");
   bool any_addend = false;
   for (int s = 0; s < nseg; ++s) {
@@ -802,13 +950,13 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   for (int s = 0; s < kMaxSeg; ++s) p.seg[s] = segs[s < nseg ? s : nseg - 1];
   // wide tile when every segment starts at a multiple of 128 columns and the output is wide enough to fill the chip with
   // 128 x 128 tiles (GVL_LIN_TILE=64 keeps the narrow tile for A/B runs)
-  bool wide = N % 128 == 0 && N >= 256;
+  bool wide = N % 128 == 0 && N >= 256 && !(flags & GVL_LIN_XCD_COLUMNS);      // (XCD placement is per 64-column head)
   for (int s = 0; s < nseg; ++s) wide = wide && segs[s].n_begin % 128 == 0;
   if (const char *e = getenv("GVL_LIN_TILE")) wide = wide && atoi(e) != 64;
   const int bn = wide ? 128 : kLinBN;
   p.tiles_m = (R + kBM - 1) / kBM; p.tiles_n = N / bn;
-  p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n % 8 == 0;
-  const int grid = p.xcd_cols ? p.tiles_m * p.tiles_n : (p.tiles_m * p.tiles_n + 7) / 8 * 8;
+  p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n >= 8;
+  const int grid = (p.tiles_m * p.tiles_n + 7) / 8 * 8;
   hipStream_t st = (hipStream_t)stream;
   if (wide) {
     if (any_addend)
@@ -837,7 +985,8 @@ extern "C" int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float
 
 extern "C" int gvl_row_absmax_f32(const float *x, int64_t ldx, int R, int C, const float *pos, int64_t ldp, int pos_rows,
                                   float *amax_x, float *amax_xpos, void *stream) {
-  if (R < 0 || C <= 0 || (C & 3) || ldx < C || (ldx & 3)) return fail(GVL_EINVAL, "gvl_row_absmax_f32: needs C %% 4 == 0, ldx %% 4 == 0");
+  // (ldx < C is allowed: overlapping rows -- the tap rows of a strided convolution over a padded input)
+  if (R < 0 || C <= 0 || (C & 3) || ldx <= 0 || (ldx & 3)) return fail(GVL_EINVAL, "gvl_row_absmax_f32: needs C %% 4 == 0, ldx %% 4 == 0");
   if (R == 0) return 0;
   if (!x || (!amax_x && !amax_xpos) || (pos && (pos_rows <= 0 || ldp < C || (ldp & 3))))
     return fail(GVL_EINVAL, "gvl_row_absmax_f32: null pointer / bad pos");

@@ -270,6 +270,15 @@ class DeformableTransformer(nn.Module):
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         return src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos, mask_flatten
 
+    def flat_geometry(self, mask_flatten, lengths):
+        """level tensors + valid ratios (+ the encoder's reference points, stashed on them) for inputs that arrive already
+        flattened (BaseEncoder.forward_flat): the tail of prepare_encoder_inputs (:100-115)"""
+        temporal_shapes, level_start_index = make_level_tensors(lengths, mask_flatten.device)
+        starts = temporal_shapes._gvl_host_lengths[1]
+        valid_ratios, ref = _layers.encoder_geometry(mask_flatten, lengths, starts)
+        valid_ratios._gvl_enc_ref = ref
+        return temporal_shapes, level_start_index, valid_ratios
+
     def forward_encoder(self, src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,
                         mask_flatten):
         if self.no_encoder:

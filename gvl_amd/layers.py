@@ -150,6 +150,11 @@ class _Arena:
         return out
 
 
+def _value_flags():
+    """launch flags of the products that write `value` slabs: head m's columns on XCD m (GVL_VALUE_XCD=1; off by default: measured no effect on the sampling launch)"""
+    return LIN_XCD_COLUMNS if os.environ.get("GVL_VALUE_XCD", "0") == "1" else 0
+
+
 def _new(rows, cols, like):
     return torch.empty(rows, cols, device=like.device, dtype=torch.float32)
 
@@ -253,7 +258,8 @@ def encoder_forward(enc, src, temporal_shapes, level_start_index, valid_ratios, 
                                (att.sampling_offsets.weight, att.sampling_offsets.bias),
                                (att.attention_weights.weight, att.attention_weights.bias)])
         value, proj = _new(R, C, x), _new(R, n_proj, x)
-        linear(x, w, [seg(0, value, am_x, rowmask=mask), seg(C, proj, am_xp, addend=posf is not None)], a2=posf)
+        linear(x, w, [seg(0, value, am_x, rowmask=mask), seg(C, proj, am_xp, addend=posf is not None)], a2=posf,
+               flags=_value_flags())
         o, am_o = _msda(att, value, proj, ref, shapes2d, level_start_index, B, S, arena)
         y = _new(R, C, x)
         linear(o, cached(att, "op", [(att.output_proj.weight, att.output_proj.bias)]), [seg(0, y, am_o, resid=x)])
@@ -386,7 +392,7 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
     # value_proj(memory) of every layer: one product against the concatenated weights
     wv = cached(dec, "values", [(l_.cross_attn.value_proj.weight, l_.cross_attn.value_proj.bias) for l_ in dec.layers])
     values = [_new(Rs, C, mem) for _ in dec.layers]
-    linear(mem, wv, [seg(wv.starts[i], values[i], am_mem, rowmask=mask) for i in range(nl)])
+    linear(mem, wv, [seg(wv.starts[i], values[i], am_mem, rowmask=mask) for i in range(nl)], flags=_value_flags())
     x = tgt.reshape(R, C).contiguous()
     if query_pos is None:
         qpos = None

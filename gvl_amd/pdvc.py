@@ -133,8 +133,14 @@ class PDVC(nn.Module):
         vf = dt['video_tensor']
         mask = ~dt['video_mask']
         duration = dt['video_length'][:, 1]
-        srcs, masks, pos = self.base_encoder(vf, mask, duration)
-        src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat = self.transformer.prepare_encoder_inputs(srcs, masks, pos)
+        if self.base_encoder.flat_eligible(vf, mask) and not self.transformer.no_encoder:
+            # inference: pyramid, masks, position / level embeddings produced flattened by the hand-written kernels
+            src, mask_flat, lvl_pos, lengths = self.base_encoder.forward_flat(vf, mask, duration,
+                                                                              self.transformer.level_embed)
+            tshapes, lsi, valid_ratios = self.transformer.flat_geometry(mask_flat, lengths)
+        else:
+            srcs, masks, pos = self.base_encoder(vf, mask, duration)
+            src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat = self.transformer.prepare_encoder_inputs(srcs, masks, pos)
         memory = self.transformer.forward_encoder(src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat)
         return memory, tshapes, lsi, valid_ratios, mask_flat
 
@@ -241,9 +247,26 @@ class PDVC(nn.Module):
                 coord = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
         return cls, cnt, coord
 
+    _NO_CAPTION = {}
+
     @staticmethod
     def _no_caption(hs):
+        """the placeholders of a layer without captioning (pdvc.py:476-479).  Inference: constants, built once per shape
+        (nobody writes them) instead of three zero fills per layer and forward."""
         N_, N_q = hs.shape[:2]
+        if not torch.is_grad_enabled() and hs.is_cuda and not torch.cuda.is_current_stream_capturing():
+            key = (N_, N_q, str(hs.device))
+            hit = PDVC._NO_CAPTION.get(key)
+            if hit is None:
+                if len(PDVC._NO_CAPTION) > 16:
+                    PDVC._NO_CAPTION.clear()
+                hit = PDVC._NO_CAPTION[key] = (torch.zeros(1, device=hs.device), torch.zeros(N_, N_q, 3, device=hs.device),
+                                               torch.zeros(N_, N_q, 3, device=hs.device))
+            return {'cap_prob_train': hit[0], 'cap_prob_eval': hit[1]}, hit[2]
+        if not torch.is_grad_enabled() and hs.is_cuda:
+            hit = PDVC._NO_CAPTION.get((N_, N_q, str(hs.device)))
+            if hit is not None:                       # (capturing: constants created by the warm-up run are reused)
+                return {'cap_prob_train': hit[0], 'cap_prob_eval': hit[1]}, hit[2]
         probs = {'cap_prob_train': torch.zeros(1, device=hs.device),
                  'cap_prob_eval': torch.zeros(N_, N_q, 3, device=hs.device)}
         return probs, torch.zeros(N_, N_q, 3, device=hs.device)

@@ -133,7 +133,9 @@ int gvl_proj_f32(const float *x, const float *weight, const float *bias, int R, 
  *    nn.MultiheadAttention (:266-270), the box MLP (pdvc/pdvc.py:1166-1178) -- as ONE kernel on the fp16 matrix cores at
  *    fp32 accuracy:
  *        out_s[r][n - n_begin_s] = epilogue_s( sum_k (a[r][k] [+ a2[r % a2_rows][k]]) w[n][k] + bias[n] )
- *    a (R, K) fp32, row stride lda: the activation as its producer left it.  It is split into the (hi, 2^11 residual) fp16
+ *    a (R, K) fp32, row stride lda (a multiple of 4; lda < K = overlapping rows is allowed: the three taps of a k = 3,
+ *    stride 2 conv1d over a zero-padded (frames, channels) input are ONE row of length 3 C at stride 2 C): the activation as
+ *    its producer left it.  It is split into the (hi, 2^11 residual) fp16
  *    planes of gvl_split_rows_f16 INSIDE the kernel's load path; the row scale comes from amax_in (R): any upper bound of
  *    max_k |a[r][k] (+ a2)| that is at most ~2^10 above it (the producers on the path leave the exact row maximum:
  *    gvl_layer_norm_rows_f32, gvl_msda1d_fused_forward_amax_f32, this function's own amax_out, gvl_row_absmax_f32).
@@ -144,7 +146,8 @@ int gvl_proj_f32(const float *x, const float *weight, const float *bias, int R, 
  *    Epilogue order: + bias, ReLU (GVL_LIN_RELU), resid[r][.] + (.), rows with rowmask[r] != 0 written as zeros (the
  *    masked_fill of ms_deform_attn.py:96-97); amax_out (R floats, ZERO-INITIALISED by the caller, or NULL) receives
  *    max_n |out_s[r][n]| through one atomic max per row and tile.
- *    flags: GVL_LIN_XCD_COLUMNS (only with N == 512) = column tile c is computed on XCD c (workgroup id % 8).
+ *    flags: GVL_LIN_XCD_COLUMNS = 64-wide column tile c is computed on XCD c % 8 (workgroup id % 8): the head slabs of a
+ *    `value` tensor are then written from the XCD whose L2 gvl_msda1d_fused_forward_* reads them from.
  *    Accuracy: |error| <= 2^-21 sum|a||w| + K 2^-33 amax_in[r] max|w| (three fp16 MFMAs, fp32 accumulation, lo.lo dropped);
  *    a non-finite a[r][k] makes row r of the outputs non-finite. */
 #define GVL_LIN_ADDEND 1       /* segment flag: the A operand of this segment is a + a2 */
@@ -193,6 +196,22 @@ int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned char *key_keep
  *        and the encoder's reference points (:209-218) from the flattened padding mask in one launch:
  *        valid_ratios[b][l] = #{t < T_l : !mask[b][s_l + t]} / T_l;   ref[b][s_l + t][l'] = (t + 0.5) / (vr[b][l] T_l) * vr[b][l'].
  *        mask (B, S) bytes (non-zero = padded), level lengths / starts as host arrays of L <= 8 entries. */
+/*    gvl_group_norm_rows_f32 / gvl_pyramid_geometry_f32: what surrounds the conv1d products of the base encoder's feature
+ *    pyramid in inference (pdvc/base_encoder.py:55-82, pdvc/position_encoding.py:38-64, deformable_transformer.py:85-115).
+ *      group norm: nn.GroupNorm(G, C) of a level's conv output given as ROWS y[(n rows_per_video + t) ldy + c] (t < T; the
+ *        layout gvl_linear_f16x3_f32 leaves), written as rows dst[n dst_video_stride + t C + c] (the level's slice of the
+ *        flattened (B, S, C) encoder input) and, when dst2 != NULL, to dst2[n dst2_video_stride + t C + c] (the zero-padded
+ *        input of the next level's stride-2 convolution).  C / G must divide 64.
+ *      geometry: mask_flat (N, S) = every level's padding mask (level 0: mask itself; level l: nearest-neighbour resampling,
+ *        F.interpolate(mask.float(), size=T_l)); lvl_pos (N, S, n_sine + n_dur) = PositionEmbeddingSine of that mask (see
+ *        gvl_pos_embed_sine_f32) transposed, + level_embed[l] (deformable_transformer.py:105). */
+int gvl_group_norm_rows_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G, const float *gamma,
+                            const float *beta, float eps, float *dst, int64_t dst_video_stride, float *dst2,
+                            int64_t dst2_video_stride, void *stream);
+int gvl_pyramid_geometry_f32(const unsigned char *mask, int N, int T0, int S, int L, const int64_t *lengths_host,
+                             const int64_t *starts_host, const float *dim_t, const float *dur_embed,
+                             const float *level_embed, int n_sine, int n_dur, float scale, unsigned char *mask_flat,
+                             float *lvl_pos, void *stream);
 int gvl_encoder_geometry_f32(const unsigned char *mask, int B, int S, int L, const int64_t *lengths_host,
                              const int64_t *starts_host, float *valid_ratios, float *ref, void *stream);
 int gvl_box_refine_f32(const float *delta, int64_t ldd, const float *ref, int RD, const float *valid_ratios, int B, int Q,

@@ -183,6 +183,38 @@ def test_encoder_geometry_equals_the_pytorch_formulation():
     assert ref.shape == want_ref.shape and maxerr(ref, want_ref) <= 1e-7
 
 
+@pytest.mark.parametrize("N,T,Cin", [(16, 100, 512), (3, 61, 96)])
+def test_flat_base_encoder_equals_the_pytorch_formulation(N, T, Cin, monkeypatch):
+    """BaseEncoder.forward_flat (conv1d levels as strided-view products, GroupNorm into the flattened layout, one geometry
+    launch) == BaseEncoder.forward + DeformableTransformer.prepare_encoder_inputs (base_encoder.py:55-82,
+    position_encoding.py:38-64, deformable_transformer.py:85-115)"""
+    from gvl_amd.base_encoder import BaseEncoder
+    torch.manual_seed(5)
+    enc = BaseEncoder(4, Cin, 512).to(DEV).eval()
+    with torch.no_grad():
+        for seq in enc.input_proj:
+            seq[0].bias.normal_(0, 0.1)
+            seq[1].weight.normal_(1.0, 0.2)
+            seq[1].bias.normal_(0, 0.2)
+    tr = _transformer()
+    vf = _rand(N, T, Cin, seed=70)
+    mask = torch.zeros(N, T, dtype=torch.bool, device=DEV)
+    for b in range(N):
+        mask[b, T - (b * T) // (2 * N):] = True
+    dur = torch.tensor([30.0 + 13.7 * b for b in range(N)], device=DEV)
+    with torch.no_grad():
+        assert enc.flat_eligible(vf, mask)
+        src, mflat, pos, lengths = enc.forward_flat(vf, mask, dur, tr.level_embed)
+        tsh, lsi, vr = tr.flat_geometry(mflat, lengths)
+        srcs, masks, poses = enc(vf, mask, dur)
+        monkeypatch.setenv("GVL_LAYERS", "torch")
+        w_src, w_tsh, w_lsi, w_vr, w_pos, w_mask = tr.prepare_encoder_inputs(srcs, masks, poses)
+    assert lengths == [int(x) for x in w_tsh.tolist()] and torch.equal(lsi, w_lsi)
+    assert torch.equal(mflat, w_mask) and torch.equal(vr, w_vr)
+    assert maxerr(src, w_src) <= 2e-5 * float(w_src.abs().max())
+    assert maxerr(pos, w_pos) <= 1e-6 * max(1.0, float(w_pos.abs().max()))
+
+
 def _transformer(seed=0):
     from gvl_amd.deformable_transformer import DeformableTransformer
     torch.manual_seed(seed)
