@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_TBS = 8.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def synth_batch(B, T, feat, vocab, n_gt, device, seed=1, cap_words=10):
@@ -363,13 +363,13 @@ def main():
     vb = 2 if a.dtype == "bf16" else 4
     res = {}
 
-    def traffic_of(name):
+    def traffic_of(cfg_key, launch):
+        """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_run.sh: FETCH_SIZE and WRITE_SIZE in
+        separate passes, gfx950 2x FETCH correction) of this same launch shape; counters cannot be read from inside the run"""
         pmc = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc) and (B, a.T, a.queries, a.dtype) == (16, 100, 300, "f32"):
-            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same launch shape (FETCH_SIZE and
-            # WRITE_SIZE in separate passes, gfx950 2x FETCH correction); counters cannot be read from inside the run
             table = json.load(open(pmc))
-            rec = table.get(name)
+            rec = table.get(cfg_key, {}).get(launch) if isinstance(table.get(cfg_key), dict) else None
             import hashlib
             src = os.path.join(ROOT, "gvl_amd", "csrc", "gvl_msda.hip")
             sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
@@ -444,6 +444,22 @@ def main():
             finally:
                 del os.environ["GVL_GEMM"]
             torch.cuda.empty_cache()
+        # A/B of the same step with the transformer layers / base encoder / heads in their PyTorch formulation (library
+        # fp32 GEMMs, ATen elementwise) instead of the hand-written inference layers of gvl_amd/layers.py
+        from gvl_amd import layers as _layers
+        if (_layers.enabled() and a.dtype == "f32" and not a.no_graph and not a.no_probes):
+            os.environ["GVL_LAYERS"] = "torch"
+            try:
+                g3 = GraphedEvalForward(model, criterion, autocast_dtype=ac, decode_chunk=a.decode_chunk)
+                for dt in batches:
+                    g3(dt)
+                el3, _ = timed_loop(g3, batches, a.steps, a.warmup, world, dev)
+                res["eval"]["pytorch_layers_elapsed"] = el3
+                g3.graphs.clear()
+                del g3
+            finally:
+                del os.environ["GVL_LAYERS"]
+            torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------------------------------------- train half
     if a.mode in ("both", "train"):
@@ -492,7 +508,8 @@ def main():
         us, n, us_mean = fwd[dec_key]
         nbytes = msda_bytes(B, S, a.queries, value_bytes=vb)
         achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
-        traffic, traffic_src = traffic_of("k_fwd_t1d_d64_fused_dec")
+        # (the eval forward's launches are the row-maxima variant the inference layers use: "100_f32_amax")
+        traffic, traffic_src = traffic_of("100_f32_amax" if "eval" in res else "100_f32", "fwd_dec")
         roof = {"bound": "hbm", "kernel": f"k_{dec_key[0]} (decoder cross-attention launch, Lq={a.queries})",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK_TBS * 1e3), 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -526,7 +543,7 @@ def main():
         if not out:
             return None
         d = out.get("decoder") or out["encoder"]
-        traffic, traffic_src = traffic_of("k_bwd_t1d_d64_fused_dec")
+        traffic, traffic_src = traffic_of("100_f32", "bwd_dec")
         return {"bound": "hbm", "kernel": "k_bwd_t1d_d64 (+ k_sum_partials where it still runs), decoder launch",
                 "achieved": d["achieved"], "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": d["frac"],
                 "traffic": traffic, "traffic_source": traffic_src, "launches": out, "source": src_note}
@@ -540,6 +557,8 @@ def main():
                    f"{len(batches)} rotating batches with 0-10 events per video and 3-20-word captions"))
     from gvl_amd.linear import split_gemm_enabled as _sge
     gemm16_on = _sge() and a.dtype == "f32"
+    from gvl_amd import layers as _lay
+    _lay_on = _lay.enabled() and a.dtype == "f32"
     line = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.dtype == "f32" else "bf16 storage + bf16 GEMMs, f32 accumulate / locations / captioner",
             "data": "synthetic",
@@ -549,6 +568,11 @@ def main():
                                             "pairs, 3 fp16-MFMA partial products, fp32 accumulation -- error vs fp64 "
                                             "below the fp32 GEMM's (tests/test_gpu_gemm16.py); vocabulary argmax / "
                                             "log-sum-exp fused into the GEMM") if gemm16_on else "hipBLASLt fp32",
+                       "inference_layers": ("gvl_amd/layers.py: every Linear of the encoder / decoder layers, the box MLP, the "
+                                            "captioner's per-forward constants and the base encoder's conv1d levels on "
+                                            "gvl_linear_f16x3_f32 (fp32 A split in the load path, fused bias / ReLU / residual / "
+                                            "mask / row-maxima epilogues), LayerNorm / GroupNorm / attention core / refinement "
+                                            "as hand-written kernels") if _lay_on else "PyTorch (GVL_LAYERS=torch)",
                        "global_batch": world * B,
                        "parallelism": f"dp{world} (videos sharded; eval: no data-path collective, train: RCCL gradient "
                                       f"all-reduce)"},
@@ -566,6 +590,13 @@ def main():
                      "eval_seconds_per_rank": [round(x, 4) for x in e["per_rank"]]})
         kernels_us["eval"] = {ktag(k): {"us": round(v[0], 2), "n": v[1]} for k, v in e["ktimes"].items()
                               if not k[0].startswith("fwd_")}
+        if "pytorch_layers_elapsed" in e:
+            e3 = e["pytorch_layers_elapsed"]
+            line["eval_with_pytorch_layers"] = {
+                "value": round(world * B * a.steps / e3, 3), "ms_per_step": round(e3 / a.steps * 1e3, 3),
+                "note": "same run, GVL_LAYERS=torch: encoder / decoder layers, base encoder and heads through PyTorch "
+                        "(library fp32 GEMMs + ATen kernels) instead of gvl_amd/layers.py (gvl_linear_f16x3_f32 with fused "
+                        "epilogues, gvl_layer_norm_rows_f32, gvl_mha_core_f32, ...); token loop unchanged"}
         if "fp32_library_gemms_elapsed" in e:
             e2 = e["fp32_library_gemms_elapsed"]
             line["eval_with_fp32_library_gemms"] = {

@@ -588,7 +588,8 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp, alive=None):
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
              12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train", 15: "match_cost", 16: "criterion",
-             17: "pos_embed", 18: "col_sum", 19: "proj", 20: "split_rows", 21: "gemm_f16x3"}
+             17: "pos_embed", 18: "col_sum", 19: "proj", 20: "split_rows", 21: "gemm_f16x3", 22: "layer_gemm",
+             23: "layer_norm_etc"}
 
 
 def profile_enable(on=True):
