@@ -952,6 +952,9 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   // 128 x 128 tiles (GVL_LIN_TILE=64 keeps the narrow tile for A/B runs)
   bool wide = N % 128 == 0 && N >= 256 && !(flags & GVL_LIN_XCD_COLUMNS);      // (XCD placement is per 64-column head)
   for (int s = 0; s < nseg; ++s) wide = wide && segs[s].n_begin % 128 == 0;
+  // ... and only when the wide tiles still cover at least half of the CUs (3008 x 512: 96 wide tiles take 19 / 49 us at
+  // K = 512 / 2048, 192 narrow ones 17 / 42 us; 4800 x 512: 152 wide 20 / 50 us against 304 narrow 24 / 67 us)
+  wide = wide && ((R + kBM - 1) / kBM) * (N / 128) >= 128;
   if (const char *e = getenv("GVL_LIN_TILE")) wide = wide && atoi(e) != 64;
   const int bn = wide ? 128 : kLinBN;
   p.tiles_m = (R + kBM - 1) / kBM; p.tiles_n = N / bn;
