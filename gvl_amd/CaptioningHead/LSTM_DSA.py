@@ -428,7 +428,11 @@ class Captioner(nn.Module):
     def _level_inputs(self, others, reference_points):
         n_levels = self.core.n_levels
         if n_levels < self.core.opt.num_feature_levels:
-            raise NotImplementedError("cap_num_feature_levels < num_feature_levels is not used by any reference config")
+            # (the reference's own branch cannot run on temporal features: LSTM_DSA.py:151 takes torch.prod(dim=1) of the
+            #  1-D (L,) tensor of level lengths and raises IndexError -- verified by running the reference with
+            #  cap_num_feature_levels = 2; there is no behaviour to mirror)
+            raise NotImplementedError("cap_num_feature_levels < num_feature_levels: the reference itself raises on this "
+                                      "branch for temporal features (LSTM_DSA.py:151) and no config uses it")
         return (others['memory'], others['spatial_shapes'], others['level_start_index'], others['mask_flatten'],
                 reference_points)
 
