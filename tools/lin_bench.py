@@ -72,7 +72,7 @@ def main():
               f"torch add {timeit(lambda: x + pos):.2f} us")
 
 
-if __name__ == "__main__" and "--mha" not in sys.argv:
+if __name__ == "__main__" and "--mha" not in sys.argv and "--skinny" not in sys.argv:
     main()
 
 
@@ -88,3 +88,20 @@ def mha():
 
 if __name__ == "__main__" and "--mha" in sys.argv:
     mha()
+
+
+def skinny():
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    for M, K, N in ((192, 512, 2576), (192, 512, 2048), (192, 2048, 512), (192, 2576, 512), (96, 512, 2576)):
+        x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.05
+        p = MSDA.skinny_pack(w)
+        out = torch.empty(M, N, device=dev)
+        wt = w.t()
+        # a dependent chain (each product waits for the previous one), as in the token loop: latency, not throughput
+        t_own = timeit(lambda: MSDA.skinny_gemm(x, p, out))
+        t_lib = timeit(lambda: torch.mm(x, wt, out=out))
+        print(f"skinny M={M} K={K} N={N}: own {t_own:.2f} us, library {t_lib:.2f} us")
+
+
+if __name__ == "__main__" and "--skinny" in sys.argv:
+    skinny()
