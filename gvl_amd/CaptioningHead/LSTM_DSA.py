@@ -62,7 +62,7 @@ class ShowAttendTellCore(nn.Module):
                              "(every reference config)")
 
     # -- per-forward constants ---------------------------------------------------------------------------------
-    def _prepare_inference(self, query, input_flatten, input_padding_mask):
+    def _prepare_inference(self, query, input_flatten, input_padding_mask, perm=None):
         """prepare() for inference on the split-fp16 layer kernel (gvl_amd/layers.py): value_proj(memory) with masked rows
         straight into the left half of the [value | ctx2att(value)] slab, ctx2att of it into the right half, and the two
         token-independent products of the event features (gate part, offset part) as one launch: 3 launches, no cat."""
@@ -89,7 +89,11 @@ class ShowAttendTellCore(nn.Module):
             am_q, _ = L.row_absmax(q)
         K = self.n_levels * self.n_points
         ow = att.sampling_offsets.weight
-        w = L.cached(self, "hs", [(self.rnn.weight_ih_l0[:, E + Cf:], None), (ow[:, H:], att.sampling_offsets.bias)])
+        if perm is None:
+            w = L.cached(self, "hs", [(self.rnn.weight_ih_l0[:, E + Cf:], None), (ow[:, H:], att.sampling_offsets.bias)])
+        else:                                                           # gate rows in the order 4 unit + gate
+            w = L.cached(self, "hs_perm", [(self.rnn.weight_ih_l0[:, E + Cf:][perm], None),
+                                           (ow[:, H:], att.sampling_offsets.bias)])
         gates_hs = torch.empty(q.shape[0], 4 * H, device=q.device, dtype=torch.float32)
         off_hs = torch.empty(q.shape[0], K, device=q.device, dtype=torch.float32)
         L.linear(q, w, [L.seg(0, gates_hs, am_q), L.seg(w.starts[1], off_hs, am_q, width=K)])
@@ -108,14 +112,16 @@ class ShowAttendTellCore(nn.Module):
         """Everything that does not depend on the token index."""
         att = self.deformable_att
         if self._inference_layers_ok(query, input_flatten):
-            slab, gates_hs, off_hs = self._prepare_inference(query, input_flatten, input_padding_mask)
+            weights = self._inference_weights(torch.float32)
+            slab, gates_hs, off_hs = self._prepare_inference(query, input_flatten, input_padding_mask,
+                                                             weights.get("gate_perm"))
             B, S = slab.shape[:2]
             bias = self.alpha_net.bias
             if getattr(self, "_alpha_b_version", None) != bias._version:
                 self._alpha_b = float(bias.detach().cpu())
                 self._alpha_b_version = bias._version
             const = {"slab": slab, "gates_hs": gates_hs, "off_hs": off_hs}
-            const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **self._inference_weights(slab.dtype))
+            const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **weights)
             return const
         value = att.project_value(input_flatten, input_padding_mask)              # (B,S,1,C)
         B, S = value.shape[:2]
@@ -125,7 +131,11 @@ class ShowAttendTellCore(nn.Module):
         C = query.shape[-1]
         w_ih = self.rnn.weight_ih_l0
         E = self.input_encoding_size
-        gates_hs = F.linear(query.reshape(-1, C), w_ih[:, E + self.att_feat_size:])     # hs part of the LSTM input
+        weights = self._inference_weights(slab.dtype) if not torch.is_grad_enabled() else {}
+        w_hs = w_ih[:, E + self.att_feat_size:]
+        if weights.get("gate_perm") is not None:                                  # fused cell: gates as 4 unit + gate
+            w_hs = w_hs[weights["gate_perm"]]
+        gates_hs = F.linear(query.reshape(-1, C), w_hs)                           # hs part of the LSTM input
         # the offsets projection splits into an h part (per step) and an hs part (constant)
         ow = att.sampling_offsets.weight
         off_hs = F.linear(query, ow[:, self.rnn_size:], att.sampling_offsets.bias)     # (B,Q,16)
@@ -136,7 +146,7 @@ class ShowAttendTellCore(nn.Module):
             if getattr(self, "_alpha_b_version", None) != bias._version:
                 self._alpha_b = float(bias.detach().cpu())        # one host read per weight update, not per step
                 self._alpha_b_version = bias._version
-            const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **self._inference_weights(slab.dtype))
+            const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **weights)
         return const
 
     def fused_train_eligible(self, query):
@@ -169,7 +179,8 @@ class ShowAttendTellCore(nn.Module):
         every call); the operands of the attention kernel stay fp32."""
         params = (self.deformable_att.sampling_offsets.weight, self.h2att.weight, self.h2att.bias, self.rnn.weight_hh_l0,
                   self.rnn.weight_ih_l0, self.alpha_net.weight)
-        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (split_gemm_enabled(), gemm_dtype)
+        cell_fused = os.environ.get("GVL_CELL_FUSED", "1") != "0"
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (split_gemm_enabled(), cell_fused, gemm_dtype)
         cache = self.__dict__.setdefault("_inf_w", {})
         if cache and next(iter(cache))[:-1] != key[:-1]:
             cache.clear()
@@ -186,8 +197,14 @@ class ShowAttendTellCore(nn.Module):
                 if (gemm_dtype == torch.float32 and split_gemm_enabled() and self.rnn_size % 32 == 0
                         and self.att_feat_size % 32 == 0):
                     # fp32 products on the fp16 matrix cores (gvl_gemm_f16x3_f32): the weight side is split once
-                    w["w_h_cat_p"] = MSDA.split_rows(w["w_h_cat"])
-                    w["w_att_p"] = MSDA.split_rows(self.rnn.weight_ih_l0[:, E:E + self.att_feat_size].contiguous())
+                    w_hh, w_att = self.rnn.weight_hh_l0, self.rnn.weight_ih_l0[:, E:E + self.att_feat_size]
+                    if cell_fused and self.rnn_size % 8 == 0:
+                        # the LSTM cell runs in the epilogue of the attention product (gvl_gemm_f16x3_lstm_f32): every
+                        # gate operand of the step is laid out as 4 unit + gate (GVL_CELL_FUSED=0: separate cell kernel)
+                        perm = w["gate_perm"] = MSDA.gate_permutation(self.rnn_size, w_hh.device)
+                        w_hh, w_att = w_hh[perm], w_att[perm]
+                    w["w_h_cat_p"] = MSDA.split_rows(torch.cat([self.h2att.weight, w_hh], 0))
+                    w["w_att_p"] = MSDA.split_rows(w_att.contiguous())
             cache[key] = w
         return w
 
@@ -210,6 +227,8 @@ class ShowAttendTellCore(nn.Module):
         att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
                                   h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
                                   self.n_levels, self.n_points, planes=split)
+        if split and const.get("gate_perm") is not None:                # ... whose epilogue is the cell (step)
+            return att_res, g_h
         if split:                                                       # att_res arrives as the planes of the product
             return MSDA.gemm_f16x3(att_res, const["w_att_p"]), g_h
         return torch.mm(att_res, const["w_att_t"]), g_h                 # (the hs part, gates_hs, is added in the cell)
@@ -217,8 +236,13 @@ class ShowAttendTellCore(nn.Module):
     def cell_part(self, g_x, g_h, xt_gates, c, const):
         """(gate parts, input token) -> (h', c')"""
         if not isinstance(xt_gates, tuple):                             # per-row pre-activations given directly
+            if const.get("gate_perm") is not None:
+                xt_gates = xt_gates[:, const["gate_perm"]]
             xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
         emb_gates, it = xt_gates                                        # (table (V+1,4H), token ids)
+        if const.get("gate_perm") is not None:                          # g_x: planes of the attended feature (attend_part)
+            return MSDA.gemm_f16x3_lstm(g_x, const["w_att_p"], g_h[:, self.att_hid_size:], const["gates_hs"], emb_gates,
+                                        it, c)
         return MSDA.lstm_cell(g_x, g_h[:, self.att_hid_size:], emb_gates, it, c, gates_c=const["gates_hs"],
                               planes="w_h_cat_p" in const and g_x.dtype == torch.float32)
 
@@ -534,16 +558,18 @@ class Captioner(nn.Module):
             outputs.append(F.log_softmax(self.logit(self.dropout(out)), dim=1))
         return torch.stack(outputs, 1)
 
-    def _embedding_gates(self):
+    def _embedding_gates(self, perm=None):
         """embedding table pre-multiplied by its slice of W_ih ((V+1, 4H); a 17.9 GFLOP GEMM at vocabulary 8517):
-        depends on weights only -> rebuilt when they change (or the autocast type does), not per forward"""
+        depends on weights only -> rebuilt when they change (or the autocast type does), not per forward.  perm: gate
+        columns in the order 4 unit + gate (the fused cell of ShowAttendTellCore._inference_weights)"""
         w_e, w_ih = self.embed.weight, self.core.rnn.weight_ih_l0
         ac = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else torch.float32
-        key = (w_e.data_ptr(), w_e._version, w_ih.data_ptr(), w_ih._version, ac)
+        key = (w_e.data_ptr(), w_e._version, w_ih.data_ptr(), w_ih._version, ac, perm is not None)
         cached = getattr(self, "_emb_gates", None)
         if cached is None or cached[0] != key:
             with torch.no_grad():
-                cached = self._emb_gates = (key, F.linear(w_e, w_ih[:, :self.input_encoding_size]).contiguous())
+                w_x = w_ih[:, :self.input_encoding_size]
+                cached = self._emb_gates = (key, F.linear(w_e, w_x if perm is None else w_x[perm]).contiguous())
         return cached[1]
 
     def _logit_planes(self, out):
@@ -567,7 +593,7 @@ class Captioner(nn.Module):
         ref_in = self._scaled_reference(reference, {'valid_ratios': valid_ratios})
         const = self.core.prepare(hs, memory, mask)
         # embedding rows pre-multiplied by their slice of W_ih: one gather per step instead of a GEMM
-        emb_gates = self._embedding_gates()
+        emb_gates = self._embedding_gates(const.get("gate_perm"))
         # the recurrent state is fp32, also under autocast; h, c (and the greedy loop's log-prob table) share ONE zero fill
         T_ = self.max_caption_len
         zbuf = torch.zeros(2 * n * self.rnn_size + n * T_, dtype=torch.float32, device=hs.device)

@@ -550,6 +550,37 @@ def lstm_cell(gates_a, gates_b, emb_gates, it, c, gates_c=None, planes=False):
     return h_out, c_out
 
 
+def gate_permutation(H, device=None):
+    """row index of nn.LSTM's (4H, .) gate-major weights in the order 4 * unit + gate (gvl_gemm_f16x3_lstm_f32)"""
+    return torch.arange(4 * H, device=device).view(4, H).t().reshape(-1)
+
+
+def gemm_f16x3_lstm(a, w, gates_h, gates_c, emb_gates, it, c):
+    """(h', c') = LSTM cell of a . w^T + gates_c + gates_h + emb_gates[it] (include/gvl_msda.h: gvl_gemm_f16x3_lstm_f32):
+    a SplitPlanes (n, K), w SplitPlanes (4H, K) with rows in gate_permutation order, gates_h / gates_c (n, 4H) fp32 (unit
+    column stride) and emb_gates (V + 1, 4H) with columns in the same order; h' carries its planes (h'._gvl_planes)."""
+    n, H = c.shape
+    _require(a.rows == n and w.rows == 4 * H and a.cols == w.cols, "gemm_f16x3_lstm: operand shapes")
+    for name, t_ in (("gates_h", gates_h),) + ((("gates_c", gates_c),) if gates_c is not None else ()):
+        _require(t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1
+                 and tuple(t_.shape) == (n, 4 * H), f"gemm_f16x3_lstm: {name} must be an (n, 4H) fp32 CUDA matrix")
+    _require(emb_gates.is_contiguous() and emb_gates.dtype == torch.float32 and emb_gates.shape[1] == 4 * H
+             and c.is_contiguous() and c.dtype == torch.float32 and it.is_contiguous() and it.dtype == torch.int64
+             and it.numel() == n, "gemm_f16x3_lstm: emb_gates (V+1, 4H) / c fp32 contiguous, it int64 (n)")
+    h_out, c_out = torch.empty_like(c), torch.empty_like(c)
+    hp = SplitPlanes(n, H, c.device)
+    with torch.cuda.device(c.device):
+        rc = _lib.lib().gvl_gemm_f16x3_lstm_f32(
+            a.hi.data_ptr(), a.lo.data_ptr(), a.scale.data_ptr(), n, w.hi.data_ptr(), w.lo.data_ptr(), w.scale.data_ptr(),
+            H, a.cols, gates_h.data_ptr(), gates_h.stride(0), gates_c.data_ptr() if gates_c is not None else None,
+            gates_c.stride(0) if gates_c is not None else 0, emb_gates.data_ptr(), it.data_ptr(), c.data_ptr(),
+            h_out.data_ptr(), c_out.data_ptr(), hp.hi.data_ptr(), hp.lo.data_ptr(), hp.scale.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "gemm_f16x3_lstm")
+    h_out._gvl_planes = hp
+    return h_out, c_out
+
+
 def row_argmax_lse(logits):
     """(R, V) fp32 | bf16 -> (argmax int64 (R,), log_softmax value at the argmax (R,)); first maximal index on ties."""
     _require(logits.is_cuda and logits.is_contiguous() and logits.dtype in (torch.float32, torch.bfloat16)

@@ -497,9 +497,7 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const GT *__restrict__ ga, in
     }
     const float4 cp = reinterpret_cast<const float4 *>(c)[idx];
     float4 cn, hn;
-#define GVL_CELL(X)                                                         \
-    cn.X = sigmoidf_(g4[1].X) * cp.X + sigmoidf_(g4[0].X) * tanhf_(g4[2].X); \
-    hn.X = sigmoidf_(g4[3].X) * tanhf_(cn.X);
+#define GVL_CELL(X) gvl_lstm_point(g4[0].X, g4[1].X, g4[2].X, g4[3].X, cp.X, cn.X, hn.X);
     GVL_CELL(x) GVL_CELL(y) GVL_CELL(z) GVL_CELL(w)
 #undef GVL_CELL
     reinterpret_cast<float4 *>(c_out)[idx] = cn;

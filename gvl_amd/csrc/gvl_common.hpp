@@ -115,6 +115,16 @@ inline int ensure_lds(K kernel, size_t bytes) {
 
 }  // namespace gvl
 
+// ---- LSTM cell of one hidden unit (nn.LSTM, gate order i f g o; LSTM_DSA.py:216-217,269): shared by the pointwise kernel
+// (gvl_cap.hip: k_lstm_cell) and the GEMM epilogue that absorbs it (gvl_gemm16.hip: kLstm) -- ONE expression, contraction
+// written out, so that the two paths produce the same bits
+__device__ __forceinline__ float gvl_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float gvl_tanh(float x) { return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)), 1.f); }
+__device__ __forceinline__ void gvl_lstm_point(float gi, float gf, float gg, float go, float cp, float &cn, float &hn) {
+  cn = fmaf(gvl_sigmoid(gf), cp, gvl_sigmoid(gi) * gvl_tanh(gg));
+  hn = gvl_sigmoid(go) * gvl_tanh(cn);
+}
+
 // ---- storage types: fp32 or bf16 in HBM, fp32 in registers / LDS.  `i4` indexes groups of 4 consecutive elements.
 using bf16_t = __bf16;
 struct alignas(8) bf16x4 { bf16_t a, b, c, d; };

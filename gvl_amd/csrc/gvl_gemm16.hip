@@ -79,14 +79,142 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ x,
   }
 }
 
+// quad_perm DPP move
+template <int CTRL>
+__device__ __forceinline__ float quad_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// 4 x 4 transpose inside every quad: lane q of the quad ends up with a[g] = what lane g held in a[q]
+__device__ __forceinline__ void quad_transpose(float (&a)[4], int q) {
+  const bool odd = q & 1, hi = q & 2;
+#pragma unroll
+  for (int p = 0; p < 4; p += 2) {                                    // pairs (0,1) (2,3) across lanes q ^ 1
+    const float recv = quad_mov<0xB1>(odd ? a[p] : a[p + 1]);
+    if (odd) a[p] = recv; else a[p + 1] = recv;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {                                       // pairs (0,2) (1,3) across lanes q ^ 2
+    const float recv = quad_mov<0x4E>(hi ? a[p] : a[p + 2]);
+    if (hi) a[p] = recv; else a[p + 2] = recv;
+  }
+}
+
+// kLstm epilogue of one wavefront (its 64 x 32 NJ part of D at (row0, col0), columns = 4 unit + gate), in three steps per
+// 32 x 32 block so that the loads can be requested early: lstm_rows (this lane's 4 rows after the transposes, their input
+// tokens and row scales), lstm_loads (the other gate parts, the token's embedding row -- a dependent load -- and the
+// state), lstm_finish (transposes, cell, stores).  A first version that walked the row groups one by one (load, wait,
+// compute, store) spent 12 us per tile in exposed latency.
+struct LstmPre {
+  int rowc[4], tok[4];
+  float rs[4], cp[4];
+  float4 gh[4], gc[4], ge[4], cs;
+};
+
+__device__ __forceinline__ void lstm_rows(LstmPre &p, int rbase, int lane, const float *__restrict__ As, int R,
+                                          const LstmEpi &le) {
+  const int fh = lane >> 5, q = lane & 3;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    p.rowc[k] = min(rbase + 8 * k + 4 * fh + q, R - 1);
+    p.tok[k] = (int)le.it[p.rowc[k]];
+    p.rs[k] = As[p.rowc[k]];
+  }
+}
+
+__device__ __forceinline__ void lstm_loads(LstmPre &p, int cbase, int lane, const float *__restrict__ Bs, int N,
+                                           const LstmEpi &le) {
+  const int u = (lane & 31) >> 2;
+  const int gcol = cbase + 4 * u < N ? cbase + 4 * u : 0;              // first of this lane's unit's four gate columns
+  const int H = le.H;
+  p.cs = *reinterpret_cast<const float4 *>(Bs + gcol);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    p.gh[k] = *reinterpret_cast<const float4 *>(le.gates_h + (int64_t)p.rowc[k] * le.ld_h + gcol);
+    p.gc[k] = le.gates_c ? *reinterpret_cast<const float4 *>(le.gates_c + (int64_t)p.rowc[k] * le.ld_c + gcol)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    p.cp[k] = le.c[(int64_t)p.rowc[k] * H + (gcol >> 2)];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) p.ge[k] = *reinterpret_cast<const float4 *>(le.emb + (int64_t)p.tok[k] * (4 * H) + gcol);
+}
+
+__device__ __forceinline__ void lstm_finish(const LstmPre &p, const f16acc &am, const f16acc &ax, int rbase, int cbase,
+                                            int lane, int R, int N, const LstmEpi &le) {
+  const int fh = lane >> 5, q = lane & 3, u = (lane & 31) >> 2;
+  const bool unit_ok = cbase + 4 * u < N;
+  const int unit = unit_ok ? (cbase + 4 * u) >> 2 : 0, H = le.H;
+  const float cs[4] = {p.cs.x, p.cs.y, p.cs.z, p.cs.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = am[4 * k + t] + ax[4 * k + t] * kLoInv;
+    quad_transpose(a, q);                                              // a[gate] of row rbase + 8 k + 4 fh + q, this lane's unit
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = a[t] * (p.rs[k] * cs[t]) + 0.f;  // (the value kStore would have written)
+    if (le.gates_c) {                                                  // same association as k_lstm_cell: (c + a) + b + e
+      a[0] = p.gc[k].x + a[0]; a[1] = p.gc[k].y + a[1]; a[2] = p.gc[k].z + a[2]; a[3] = p.gc[k].w + a[3];
+    }
+    const float gi = a[0] + p.gh[k].x + p.ge[k].x, gf = a[1] + p.gh[k].y + p.ge[k].y, gg = a[2] + p.gh[k].z + p.ge[k].z,
+                go = a[3] + p.gh[k].w + p.ge[k].w;
+    float cn, hn;
+    gvl_lstm_point(gi, gf, gg, go, p.cp[k], cn, hn);
+    // (h' as the fp32 number it is stored as: left to itself the compiler folds the last product of the cell into the
+    //  fp16 conversions below -- v_fma_mixlo_f16 of the exact product -- and the planes no longer split h' itself)
+    asm volatile("" : "+v"(hn));
+    const int row = rbase + 8 * k + 4 * fh + q;
+    if (row < R && unit_ok) {
+      const int64_t at = (int64_t)row * H + unit;
+      le.c_out[at] = cn;
+      le.h_out[at] = hn;
+      const _Float16 hi = (_Float16)hn;                                // planes at row scale 1 (|h'| < 1), as split4_f16
+      le.h_hi[at] = hi;
+      le.h_lo[at] = (_Float16)((hn - (float)hi) * 2048.f);
+      if (unit == 0) le.h_scale[row] = 1.f;
+    }
+  }
+}
+
+template <int NJ>
+__device__ __forceinline__ void lstm_epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ], int row0, int col0, int lane,
+                                              const float *__restrict__ As, const float *__restrict__ Bs, int R, int N,
+                                              const LstmEpi &le) {
+  if constexpr (NJ == 1) {
+    LstmPre p[2];
+    lstm_rows(p[0], row0, lane, As, R, le);
+    lstm_rows(p[1], row0 + 32, lane, As, R, le);
+    lstm_loads(p[0], col0, lane, Bs, N, le);
+    lstm_loads(p[1], col0, lane, Bs, N, le);
+    lstm_finish(p[0], acc_m[0][0], acc_x[0][0], row0, col0, lane, R, N, le);
+    lstm_finish(p[1], acc_m[1][0], acc_x[1][0], row0 + 32, col0, lane, R, N, le);
+  } else {                                                             // 128 accumulator registers live: one block at a time
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      LstmPre p;
+      lstm_rows(p, row0 + 32 * i, lane, As, R, le);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        lstm_loads(p, col0 + 32 * j, lane, Bs, N, le);
+        lstm_finish(p, acc_m[i][j], acc_x[i][j], row0 + 32 * i, col0 + 32 * j, lane, R, N, le);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 // epilogue of one wavefront: its 64 x 32 NJ part of D starts at (row0, col0)
 template <int NJ, int EPI>
 __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ], int row0, int col0, int lane,
                                          const float *__restrict__ As, const float *__restrict__ Bs,
                                          const float *__restrict__ bias, int R, int N, float *__restrict__ out,
-                                         int64_t ldo) {
+                                         int64_t ldo, const LstmEpi &le) {
   // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   const int frow = lane & 31, fh = lane >> 5;
+  if constexpr (EPI == kLstm) {
+    lstm_epilogue<NJ>(acc_m, acc_x, row0, col0, lane, As, Bs, R, N, le);
+    return;
+  }
   // branch-free optional bias: without one every read goes to As[0] (a finite power of two) and is multiplied by 0
   const float *bias_p = bias ? bias : As;
   const float bias_on = bias ? 1.f : 0.f;
@@ -176,7 +304,7 @@ __global__ void __launch_bounds__(256, 2)
     k_gemm_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                  const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
                  const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo, int tiles_m,
-                 int tiles_n) {
+                 int tiles_n, const LstmEpi le) {
   constexpr int NJ = BN / 64;                                         // 32-column MFMA tiles per wavefront
   // ONE LDS object (a second one beside an LDS-DMA target can make hipcc drain the DMA before every ds_read):
   // [stage][A hi | A lo | B hi | B lo][row * 4 + swizzled chunk], 16-byte slots
@@ -249,7 +377,7 @@ __global__ void __launch_bounds__(256, 2)
     __syncthreads();
   }
   mfma_stage<NJ>(smem + ((KT - 1) & 1) * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
-  epilogue<NJ, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
+  epilogue<NJ, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo, le);
 }
 
 // ---- eight wavefronts (WM x WN, 64 x 64 each), tile 64 WM x 64 WN, THREE LDS stages with the DMA two stages ahead.
@@ -264,7 +392,7 @@ __global__ void __launch_bounds__(512, 1)
     k_gemm_f16x3_w8(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                     const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
                     const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo,
-                    int tiles_m, int tiles_n) {
+                    int tiles_m, int tiles_n, const LstmEpi le) {
   static_assert(WM * WN == 8, "eight wavefronts");
   constexpr int kRowsA = 64 * WM, kRowsB = 32 * NJ * WN;             // wavefront tile 64 x 32 NJ
   constexpr int kASlots = kRowsA * 4, kBSlots = kRowsB * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
@@ -364,6 +492,9 @@ __global__ void __launch_bounds__(512, 1)
   // counted `vmcnt(6)` (stores of an epilogue in between are younger than the stage waited for: the wait only becomes
   // conservative); past the last tile the DMA re-fetches into buffers nobody reads any more.
   const int KT = K / kBK;                                             // >= 3 (host)
+  constexpr bool kPrefetch = EPI == kLstm && NJ == 1;
+  LstmPre pre[2];
+  const int pre_rows_at = max(KT - 5, 0), pre_loads_at = max(KT - 3, 1);        // (kt counts finished stages: 0 .. KT - 1)
   issue(tm, tn, 0, 0);
   issue(tm, tn, kBK, 1);
   issue(tm, tn, 2 * kBK, 2);
@@ -430,8 +561,24 @@ __global__ void __launch_bounds__(512, 1)
     }
 #endif
     buf = nbuf;
+    if constexpr (kPrefetch) {
+      // the cell's operands are requested while the tile's last stages run: tokens and row scales four stages before
+      // its end, the first 32-row block's gate parts two stages before it (the loads are older than the DMA issued after
+      // them, so the counted waits above also cover them)
+      if (kt == pre_rows_at) {
+        lstm_rows(pre[0], m0 + wm, lane, As, R, le);
+        lstm_rows(pre[1], m0 + wm + 32, lane, As, R, le);
+      }
+      if (kt == pre_loads_at) lstm_loads(pre[0], n0 + wn, lane, Bs, N, le);
+    }
     if (++kt == KT) {
-      epilogue<NJ, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo);
+      if constexpr (kPrefetch) {
+        lstm_loads(pre[1], n0 + wn, lane, Bs, N, le);
+        lstm_finish(pre[0], acc_m[0][0], acc_x[0][0], m0 + wm, n0 + wn, lane, R, N, le);
+        lstm_finish(pre[1], acc_m[1][0], acc_x[1][0], m0 + wm + 32, n0 + wn, lane, R, N, le);
+      } else {
+        epilogue<NJ, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo, le);
+      }
       if (!has_next) break;
       kt = 0;
       vb += (int)gridDim.x;
@@ -820,19 +967,60 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
       //  it is used where nothing is stored, the argmax form)
       return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<4, 2, 2, kStore>,
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
-                         bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
+                         bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, LstmEpi{});
     }
     if (t_mid >= 384 && !getenv("GVL_GEMM16_NO_MID")) {
       const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
       return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<2, 4, 1, kStore>,
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
-                         bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n);
+                         bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, LstmEpi{});
     }
   }
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
   return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", k_gemm_f16x3<64, kStore>, dim3((tiles_m * tiles_n + 7) / 8 * 8),
                      dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, b_scale, bias, R, N, K, out, ldo, tiles_m,
-                     tiles_n);
+                     tiles_n, LstmEpi{});
+}
+
+extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *w_hi,
+                                       const void *w_lo, const float *w_scale, int H, int K, const float *gates_h,
+                                       int64_t ld_h, const float *gates_c, int64_t ld_c, const float *emb_gates,
+                                       const int64_t *it, const float *c, float *h_out, float *c_out, void *h_hi,
+                                       void *h_lo, float *h_scale, void *stream) {
+  const int N = 4 * H;
+  if (H <= 0 || (H & 7)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: H must be a positive multiple of 8 (got %d)", H);
+  if (int rc = check_operands("gvl_gemm_f16x3_lstm_f32", a_hi, a_lo, a_scale, R, w_hi, w_lo, w_scale, N, K)) return rc;
+  if (ld_h < N || (ld_h & 3) || (gates_c && (ld_c < N || (ld_c & 3))))
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: gate operands need a row stride >= 4H, a multiple of 4");
+  if (R == 0) return 0;
+  if (!gates_h || !emb_gates || !it || !c || !h_out || !c_out || !h_hi || !h_lo || !h_scale)
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: null pointer");
+  if (((uintptr_t)gates_h | (uintptr_t)gates_c | (uintptr_t)emb_gates) & 15)
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: gate operands must be 16-byte aligned");
+  const _Float16 *ah = (const _Float16 *)a_hi, *al = (const _Float16 *)a_lo, *bh = (const _Float16 *)w_hi,
+                 *bl = (const _Float16 *)w_lo;
+  const LstmEpi le = {gates_h, ld_h, gates_c, ld_c, emb_gates, it, c, h_out, c_out, (_Float16 *)h_hi, (_Float16 *)h_lo,
+                      h_scale, H};
+  // same tile choice as gvl_gemm_f16x3_f32 (the product is the same; only what happens to a finished tile differs)
+  if (R >= 1024 && K >= 3 * kBK) {
+    const int t_big = ((R + 255) / 256) * ((N + 127) / 128), t_mid = ((R + 127) / 128) * ((N + 127) / 128);
+    if (t_big >= 1024) {
+      const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8<lstm>", k_gemm_f16x3_w8<4, 2, 2, kLstm>,
+                         dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
+                         bl, w_scale, (const float *)nullptr, R, N, K, (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
+    }
+    if (t_mid >= 384 && !getenv("GVL_GEMM16_NO_MID")) {
+      const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8<lstm>", k_gemm_f16x3_w8<2, 4, 1, kLstm>,
+                         dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
+                         bl, w_scale, (const float *)nullptr, R, N, K, (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
+    }
+  }
+  const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
+  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3<lstm>", k_gemm_f16x3<64, kLstm>, dim3((tiles_m * tiles_n + 7) / 8 * 8),
+                     dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, w_scale, (const float *)nullptr, R, N, K,
+                     (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
 }
 
 extern "C" int gvl_gemm_f16x3_argmax_chunks(int V) { return V > 0 ? (V + kBM - 1) / kBM * 2 : 0; }
@@ -854,12 +1042,12 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
                          xl, x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
     return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", k_gemm_f16x3_w8<2, 4, 2, kArgmax>,
                        dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
-                       x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
+                       x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n, LstmEpi{});
   }
   const int tiles_n = (R + 63) / 64;
   return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3<argmax>", k_gemm_f16x3<64, kArgmax>,
                      dim3((tiles_m * tiles_n + 7) / 8 * 8), dim3(256), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
-                     x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
+                     x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n, LstmEpi{});
 }
 
 extern "C" int gvl_greedy_step_partials_f32(const float *partials, int R, int V, int first_step, int64_t *token,

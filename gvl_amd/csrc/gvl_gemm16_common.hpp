@@ -29,7 +29,28 @@ __device__ __forceinline__ void glds16(const void *g, void *lds) {
 //                entries = the wavefront's rows of D) the maximum, its index and sum exp(v - max) -- the logits are never
 //                written.  All 32 vocabulary entries of one MFMA tile column sit in ONE lane's registers (and the lane
 //                32 further): the reduction is register-local plus one cross-lane step.
-enum { kStore = 0, kArgmax = 2 };
+//   kLstm        D = the attention part of the LSTM gate pre-activations, never written: the weight rows arrive in the
+//                order 4 unit + gate (i f g o), so the four gates of a hidden unit are four neighbouring columns = the
+//                four lanes of a quad; a 4 x 4 transpose inside the quad (rows of D <-> gates) leaves every lane with
+//                the four gates of ONE (row, unit), the other gate parts are added and the cell is applied in place
+//                (LstmEpi below) -- the pointwise kernel and the (n, 4H) tensor between the two disappear.
+enum { kStore = 0, kArgmax = 2, kLstm = 3 };
+
+// operands of the kLstm epilogue: the other parts of the gate pre-activations in the SAME permuted column order
+// (4 unit + gate), the input token's row of the pre-multiplied embedding table, the state
+struct LstmEpi {
+  const float *gates_h;      // (R, >= 4H) h W_hh^T part
+  int64_t ld_h;
+  const float *gates_c;      // (R, >= 4H) token-independent part (event features), may be null
+  int64_t ld_c;
+  const float *emb;          // (V + 1, 4H) embedding table x W_ih[:, :E]^T
+  const int64_t *it;         // (R) input token
+  const float *c;            // (R, H)
+  float *h_out, *c_out;      // (R, H)
+  _Float16 *h_hi, *h_lo;     // (R, H) planes of h' at row scale 1
+  float *h_scale;            // (R)
+  int H;
+};
 // (a transposed store -- weight on the row side, one 16-byte store per 4 values of a lane -- was measured: 3 us SLOWER
 //  than the 4-byte stores of 128-byte row segments on the 4800 x 2560 / 2048 outputs)
 

@@ -262,6 +262,17 @@ int gvl_cap_attend_split_f32(const float *slab, const int64_t *shapes, const int
 int gvl_lstm_cell_split_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
                             const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
                             float *c_out, void *h_hi, void *h_lo, float *h_scale, void *stream);
+/*    gvl_gemm_f16x3_lstm_f32: the attention half of the LSTM input product WITH the cell applied to the finished tile
+ *        (LSTM_DSA.py:267-269 + nn.LSTM's pointwise part, :216-217): gates = A (R, K) . W (4H, K)^T + gates_c + gates_h +
+ *        emb_gates[it], (h', c') = cell(gates, c); the (R, 4H) product is never written and gvl_lstm_cell_split_f32 does not
+ *        run.  Every gate operand -- the ROWS of W and the columns of gates_h (row stride ld_h), gates_c (ld_c, may be NULL)
+ *        and emb_gates (V + 1, 4H) -- is in the order 4 * unit + gate (gate = i, f, g, o), i.e. row g * H + u of nn.LSTM's
+ *        weight_ih at row 4 * u + g.  Outputs as gvl_lstm_cell_split_f32; same bits as that path (shared cell expression,
+ *        same product).  H % 8 == 0, K % 32 == 0. */
+int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *w_hi,
+                            const void *w_lo, const float *w_scale, int H, int K, const float *gates_h, int64_t ld_h,
+                            const float *gates_c, int64_t ld_c, const float *emb_gates, const int64_t *it, const float *c,
+                            float *h_out, float *c_out, void *h_hi, void *h_lo, float *h_scale, void *stream);
 int gvl_gemm_f16x3_argmax_chunks(int V);
 int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, const float *x_scale, int R, const void *w_hi,
                               const void *w_lo, const float *w_scale, int V, int K, const float *bias, float *partials,

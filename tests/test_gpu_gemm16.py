@@ -218,3 +218,45 @@ def test_non_finite_and_sub_floor_elements_have_defined_behaviour():
     bound = (2.0 ** -21 * (xd.abs() @ wd.abs().t())
              + K * 2.0 ** -33 * xd.abs().amax(1, keepdim=True) * wd.abs().amax(1)[None] + 2.0 ** -23 * want.abs())
     assert bool(((out[ok_r][:, ok_c].double() - want).abs() <= bound).all())
+
+
+@pytest.mark.parametrize("n,K,H,with_c", [(4800, 512, 512, True), (16384, 512, 512, True), (300, 512, 512, True),
+                                          (157, 64, 96, False), (1, 32, 32, True), (1100, 96, 64, True)])
+def test_cell_in_the_product_s_epilogue_equals_product_then_cell_kernel(n, K, H, with_c):
+    """gvl_gemm_f16x3_lstm_f32 (attention half of the gate pre-activations with the LSTM cell applied to the finished tile,
+    gate operands in the order 4 unit + gate; LSTM_DSA.py:216-217,267-269) against gvl_gemm_f16x3_f32 followed by
+    gvl_lstm_cell_split_f32 in nn.LSTM's gate-major order: h', c' and the planes of h' bit for bit -- through every kernel
+    form (persistent 256 x 128 / 128 x 128 tiles, four-wavefront tiles), ragged rows and unit counts."""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(n + H)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)                         # noqa: E731
+    att, w = rnd(n, K) * 1.5, rnd(4 * H, K) * K ** -0.5
+    ld = 4 * H + 64                                                                   # g_h is a column slice of a wider product
+    gh_full = rnd(n, ld)
+    gates_h = gh_full[:, 64:]
+    gates_c = rnd(n, 4 * H) if with_c else None
+    V = 50
+    emb = rnd(V, 4 * H)
+    it = torch.randint(0, V, (n,), device=dev, generator=g)
+    c = rnd(n, H)
+    # reference order: product, then the pointwise kernel
+    ap = MSDA.split_rows(att)
+    g_x = MSDA.gemm_f16x3(ap, MSDA.split_rows(w))
+    h0, c0 = MSDA.lstm_cell(g_x, gates_h, emb, it, c, gates_c=gates_c, planes=True)
+    # fused: every gate operand permuted to 4 unit + gate
+    perm = MSDA.gate_permutation(H, dev)
+    assert perm[:8].tolist() == [0, H, 2 * H, 3 * H, 1, H + 1, 2 * H + 1, 3 * H + 1]
+    ghp_full = torch.cat([gh_full[:, :64], gates_h[:, perm]], 1).contiguous()
+    h1, c1 = MSDA.gemm_f16x3_lstm(ap, MSDA.split_rows(w[perm].contiguous()), ghp_full[:, 64:],
+                                  gates_c[:, perm].contiguous() if with_c else None, emb[:, perm].contiguous(), it, c)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c0) and torch.equal(h1, h0)
+    p0, p1 = h0._gvl_planes, h1._gvl_planes
+    assert torch.equal(p1.hi, p0.hi) and torch.equal(p1.lo, p0.lo) and torch.equal(p1.scale, p0.scale)
+    # and the cell itself against torch in fp64
+    gates = (att.double() @ w.double().t() + (gates_c.double() if with_c else 0) + gates_h.double() + emb.double()[it])
+    i_, f_, g_, o_ = gates.chunk(4, 1)
+    c_ref = torch.sigmoid(f_) * c.double() + torch.sigmoid(i_) * torch.tanh(g_)
+    h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
+    assert float((c1.double() - c_ref).abs().max()) < 2e-5 and float((h1.double() - h_ref).abs().max()) < 2e-5
