@@ -87,7 +87,7 @@ __device__ inline void fma8(float a, const float4 &x0, const float4 &x1, float (
 
 constexpr int kC = 512;      // channels of the value half and of the ctx2att half (hidden_dim = att_hid_size = 512)
 constexpr int kLP = 16;      // samples per query (cap_num_feature_levels * cap_dec_n_points)
-constexpr int kWaves = 8;    // rows (wavefronts) per workgroup
+constexpr int kWaves = 4;    // rows (wavefronts) in flight per workgroup; three workgroups per CU (152 VGPRs)
 
 // border-mode coefficients of one temporal sample (grid_sampler border, align_corners=False), row pair (r, r+1)
 __device__ inline void border_coef(float loc, int T, int &r, float &c_lo, float &c_hi) {
@@ -128,7 +128,7 @@ __device__ inline void pow2_scale(float m, float &s, float &inv) {
 // FULL: L*P == 16 known at compile time -- the sample loops lose their guards and become straight-line code, so the
 // eight loads of a sample pair really are in flight together
 template <typename ST, bool FULL>
-__global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
+__global__ void __launch_bounds__(kWaves * 64, (FULL && sizeof(ST) == 4) ? 3 : 2) k_cap_attend(
     const ST *__restrict__ slab,         // (B, S, 2C)  [value_proj(memory) | ctx2att(value_proj(memory))]
     const int64_t *__restrict__ shapes,  // (L, 2)
     const int64_t *__restrict__ lsi,     // (L)
@@ -152,11 +152,14 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
   // contiguous group of videos; its L2 then holds only those videos' slabs.
   const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = jblk * kWaves + wave;
-  const int64_t row = (int64_t)xcd * rows_per_xcd_group + lr;
-  const bool active = lr < rows_per_xcd_group && row < (int64_t)B * Q;
   __syncthreads();
-  if (!active) return;
+  // PERSISTENT: the XCD's workgroups (gridDim / 8 of them, all resident) walk its rows with a stride of one row per
+  // wavefront slot -- the 32 KB above are staged once per workgroup, and 4800 rows over 3072 slots are 1.6 rounds of a
+  // latency-bound row instead of the 3 rounds of 600 one-shot workgroups of 8 rows at two wavefronts per SIMD
+  const int slots = (int)(gridDim.x >> 3) * kWaves;
+  for (int lr = jblk * kWaves + wave; lr < rows_per_xcd_group; lr += slots) {
+  const int64_t row = (int64_t)xcd * rows_per_xcd_group + lr;
+  if (row >= (int64_t)B * Q) break;
   const int b = (int)(row / Q);
 
   // own channels: [4*lane, 4*lane+4) and [256 + 4*lane, 256 + 4*lane + 4)
@@ -219,16 +222,20 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     return s;
   };
   float e[16];
+  constexpr int kBatch = 2;                                          // samples whose 4 kBatch loads are in flight together (4: measured the same)
 #pragma unroll
-  for (int k = 0; k < 16; k += 2) {
-    e[k] = 0.f; e[k + 1] = 0.f;
-    float cl0, ch0, cl1, ch1;
-    Rows ra, rb;
-    if (k < LP) ra = load_rows(k, kC / 4, cl0, ch0);                 // ctx2att half of the slab rows
-    if (k + 1 < LP) rb = load_rows(k + 1, kC / 4, cl1, ch1);
-    __builtin_amdgcn_sched_barrier(0);                               // keep the eight loads ahead of the arithmetic
-    if (k < LP) e[k] = logit_part(ra, cl0, ch0);
-    if (k + 1 < LP) e[k + 1] = logit_part(rb, cl1, ch1);
+  for (int k = 0; k < 16; k += kBatch) {
+    float cl[kBatch], ch[kBatch];
+    Rows rr[kBatch];
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t) {
+      e[k + t] = 0.f;
+      if (k + t < LP) rr[t] = load_rows(k + t, kC / 4, cl[t], ch[t]);  // ctx2att half of the slab rows
+    }
+    __builtin_amdgcn_sched_barrier(0);                               // keep the loads ahead of the arithmetic
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t)
+      if (k + t < LP) e[k + t] = logit_part(rr[t], cl[t], ch[t]);
   }
   float ek = butterfly16(e, lane) + alpha_b;
   if (k_own >= LP) ek = -INFINITY;
@@ -245,14 +252,21 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_hi), 4 * k));
   };
 #pragma unroll
-  for (int k = 0; k < 16; k += 2) {
-    float d0, d1, cl0, ch0, cl1, ch1;
-    Rows ra, rb;
-    if (k < LP) ra = load_rows(k, 0, d0, d1);                        // value half of the slab rows
-    if (k + 1 < LP) rb = load_rows(k + 1, 0, d0, d1);
+  for (int k = 0; k < 16; k += kBatch) {
+    float d0, d1;
+    Rows rr[kBatch];
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t)
+      if (k + t < LP) rr[t] = load_rows(k + t, 0, d0, d1);           // value half of the slab rows
     __builtin_amdgcn_sched_barrier(0);
-    if (k < LP) { coef(k, cl0, ch0); fma8(cl0, ra.l0, ra.l1, acc); fma8(ch0, ra.u0, ra.u1, acc); }
-    if (k + 1 < LP) { coef(k + 1, cl1, ch1); fma8(cl1, rb.l0, rb.l1, acc); fma8(ch1, rb.u0, rb.u1, acc); }
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t)
+      if (k + t < LP) {
+        float cl, ch;
+        coef(k + t, cl, ch);
+        fma8(cl, rr[t].l0, rr[t].l1, acc);
+        fma8(ch, rr[t].u0, rr[t].u1, acc);
+      }
   }
   if (o_hi) {
     // the wavefront owns the whole row: its largest magnitude is one reduction away
@@ -270,11 +284,12 @@ __global__ void __launch_bounds__(kWaves * 64) k_cap_attend(
     half4_t *ph = reinterpret_cast<half4_t *>(o_hi + row * kC), *pl = reinterpret_cast<half4_t *>(o_lo + row * kC);
     ph[lane] = h0; ph[64 + lane] = h1;
     pl[lane] = l0; pl[64 + lane] = l1;
-    return;
+  } else {
+    ST *o = att_res + row * kC;
+    st4(o, lane, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    st4(o, 64 + lane, make_float4(acc[4], acc[5], acc[6], acc[7]));
   }
-  ST *o = att_res + row * kC;
-  st4(o, lane, make_float4(acc[0], acc[1], acc[2], acc[3]));
-  st4(o, 64 + lane, make_float4(acc[4], acc[5], acc[6], acc[7]));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -553,7 +568,8 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
     return fail(GVL_EINVAL, "%s: null pointer", what);
   const int vids_per_group = (B + 7) / 8;
   const int rows_per_group = vids_per_group * Q;
-  const int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
+  int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
+  if (blocks_per_group > 96) blocks_per_group = 96;                    // 3 resident workgroups on each of an XCD's 32 CUs
   auto kern = L * P == kLP ? k_cap_attend<ST, true> : k_cap_attend<ST, false>;
   return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend", kern, dim3(8 * blocks_per_group),
                      dim3(kWaves * 64), 0, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
