@@ -31,7 +31,7 @@ from ..ops.functions import MSDASampleFunction
 from ..ops.modules import MSDeformAttnCap
 from ..ops.modules.ms_deform_attn import temporal_shapes_2d
 from .. import MultiScaleDeformableAttention as MSDA
-from ..linear import Linear, split_gemm_enabled, split_linear
+from ..linear import Linear, split_gemm_enabled, split_linear, vocab_nll, vocab_nll_eligible
 
 
 class ShowAttendTellCore(nn.Module):
@@ -437,6 +437,14 @@ def _fp32_island(fn):
     return wrapped
 
 
+class RowLoss:
+    """what Captioner.forward(..., nll=(target, mask)) returns instead of log-probs when the loss never needs them"""
+    __slots__ = ("row_loss",)
+
+    def __init__(self, row_loss):
+        self.row_loss = row_loss
+
+
 class Captioner(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -466,6 +474,8 @@ class Captioner(nn.Module):
     def build_loss(self, input, target, mask):
         """LSTM_DSA.py:48-52.  The reference multiplies by a materialised one-hot (n, len, vocab+1) tensor and sums the
         vocabulary axis: a sum of one term and zeros, i.e. exactly the gathered log-prob -- taken directly here."""
+        if isinstance(input, RowLoss):                                  # forward(..., nll=(target, mask)) already did it
+            return input.row_loss
         max_len = input.shape[1]
         picked = input.gather(2, target[:, :max_len, None]).squeeze(2)
         return -(picked * mask[:, :max_len]).sum(1) / (mask.sum(1) + 1e-6)
@@ -496,8 +506,11 @@ class Captioner(nn.Module):
         return F.log_softmax(self.logit(self.dropout(output)), dim=1), state
 
     @_fp32_island
-    def forward(self, hs, reference, others, cap_tensor, steps=None, row_video=None):
+    def forward(self, hs, reference, others, cap_tensor, steps=None, row_video=None, nll=None):
         """Teacher-forced log-probs (LSTM_DSA.py:63-117) -> (B*Q, steps, vocab+1).
+        nll = (target, mask): the caller only wants build_loss(log-probs, target, mask) -- on the fused teacher-forced path
+        that loss is returned directly as RowLoss (gvl_amd.linear.vocab_nll: the (n, steps, vocab+1) log-prob tensor, its
+        gather and their backward chain never exist); otherwise the log-probs as always.
         row_video (n,) int64: the COMPACT row form of the layout-independent train step -- hs (n, C) and reference (n, RD)
         are rows of any video (row_video[r], negative = unused row of the fixed-capacity row set) instead of (B, Q, .)."""
         seq = cap_tensor.long()
@@ -538,6 +551,11 @@ class Captioner(nn.Module):
             xt_all = F.linear(emb, w_x)                                           # (n, steps, 4H)
             if torch.is_grad_enabled() and self.core.fused_train_eligible(hs):
                 hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const, row_video)
+                if nll is not None and vocab_nll_eligible(hidden, self.logit.weight, self.logit.bias):
+                    target, tmask = nll
+                    picked = vocab_nll(self.dropout(hidden), self.logit.weight, self.logit.bias, target[:, :steps],
+                                       tmask[:, :steps]).view(n, steps)
+                    return RowLoss(-picked.sum(1) / (tmask.sum(1) + 1e-6))               # build_loss (:48-52)
                 return F.log_softmax(split_linear(self.dropout(hidden), self.logit.weight, self.logit.bias), dim=2)
             hidden = []
             for i in range(steps):

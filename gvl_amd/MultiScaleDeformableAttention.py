@@ -464,6 +464,37 @@ def skinny_gemm_eligible(x, n_out):
             and x.stride(0) % 4 == 0 and n_out % 4 == 0 and x.data_ptr() % 16 == 0 and 0 < x.shape[0] <= 1024)
 
 
+def ce_rows_forward(logits, target, weight):
+    """(R, V) fp32 logits -> (out (R) = weight * (logits[r, target[r]] - logsumexp(logits[r])), lse (R)): the masked
+    log-probability of the target word without the log-prob tensor (include/gvl_msda.h: gvl_ce_rows_forward_f32)"""
+    _require(logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1,
+             "ce_rows: logits must be an (R, V) fp32 CUDA matrix with unit column stride")
+    R, V = logits.shape
+    _require(target.dtype == torch.int64 and target.is_contiguous() and target.numel() == R and weight.dtype == torch.float32
+             and weight.is_contiguous() and weight.numel() == R, "ce_rows: target int64 (R), weight fp32 (R)")
+    out = torch.empty(R, device=logits.device, dtype=torch.float32)
+    lse = torch.empty(R, device=logits.device, dtype=torch.float32)
+    with torch.cuda.device(logits.device):
+        rc = _lib.lib().gvl_ce_rows_forward_f32(logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(),
+                                                weight.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "ce_rows_forward")
+    return out, lse
+
+
+def ce_rows_backward_(logits, target, weight, grad_out, lse):
+    """overwrites `logits` with d sum(grad_out * out) / d logits (include/gvl_msda.h: gvl_ce_rows_backward_f32)"""
+    R, V = logits.shape
+    _require(grad_out.dtype == torch.float32 and grad_out.is_contiguous() and grad_out.numel() == R,
+             "ce_rows: grad_out fp32 (R)")
+    with torch.cuda.device(logits.device):
+        rc = _lib.lib().gvl_ce_rows_backward_f32(logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(),
+                                                 weight.data_ptr(), grad_out.data_ptr(), lse.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "ce_rows_backward")
+    return logits
+
+
 def col_sum_eligible(x):
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] > 0
 

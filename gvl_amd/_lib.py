@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 7          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 8          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -44,6 +44,8 @@ SIGNATURES = {
     "gvl_lstm_cell_train_forward_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
     "gvl_lstm_cell_train_backward_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P]),
     "gvl_col_sum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "gvl_ce_rows_forward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P]),
+    "gvl_ce_rows_backward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P]),
     "gvl_proj_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "gvl_split_rows_f16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "gvl_gemm_f16x3_lstm_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

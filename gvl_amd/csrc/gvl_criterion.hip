@@ -572,6 +572,84 @@ __global__ void __launch_bounds__(256) k_col_sum_scalar(const float *__restrict_
   atomicAdd(out + c, acc);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Caption loss over the vocabulary (LSTM_DSA.py:48-52 applied to :121-123): per (caption row, token step) r the masked
+// log-probability of the target word, out[r] = w[r] (x[r][t_r] - logsumexp_v x[r][v]) -- what
+// `(F.log_softmax(logits, 2).gather(2, target) * mask)` leaves -- WITHOUT the (R, V) log-prob tensor: one read of the
+// logits forward; backward the logits are overwritten by their own gradient g[r] w[r] (onehot - softmax), one read and
+// one write (autograd's chain: log_softmax (read + write 150 MB at cfg A), gather, its zero-filled scatter backward,
+// log_softmax backward: 0.33 ms of the train step).  Rows with w = 0 (padding, steps past the caption's end: about half
+// of the padded layout) are not read at all.  One workgroup per row.
+constexpr int kCeThreads = 256;
+
+__device__ inline void ce_block_max_sum(float &m, float &s) {          // (m, s): running maximum and sum exp(x - m)
+  __shared__ float sm[kCeThreads / 64], ss[kCeThreads / 64];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sm[wave] = m; ss[wave] = s; }
+  __syncthreads();
+  float mm = sm[0], sum = ss[0];
+#pragma unroll
+  for (int k = 1; k < kCeThreads / 64; ++k) {
+    const float mn = fmaxf(mm, sm[k]);
+    sum = (mn == -INFINITY) ? 0.f : sum * __expf(mm - mn) + ss[k] * __expf(sm[k] - mn);
+    mm = mn;
+  }
+  m = mm;
+  s = sum;
+}
+
+__global__ void __launch_bounds__(kCeThreads) k_ce_rows_fwd(const float *__restrict__ logits, int64_t ld, int V,
+                                                            const int64_t *__restrict__ target,
+                                                            const float *__restrict__ w, float *__restrict__ out,
+                                                            float *__restrict__ lse) {
+  const int row = blockIdx.x;
+  const float wr = w[row];
+  if (wr == 0.f) {                                                     // (uniform for the workgroup)
+    if (threadIdx.x == 0) { out[row] = 0.f; lse[row] = 0.f; }
+    return;
+  }
+  const float *x = logits + (int64_t)row * ld;
+  float m = -INFINITY, s = 0.f;
+  for (int v = threadIdx.x; v < V; v += kCeThreads) {
+    const float xv = x[v];
+    if (xv > m) { s = s * __expf(m - xv) + 1.f; m = xv; }              // (exp(-inf - xv) = 0 on the first element)
+    else s += __expf(xv - m);
+  }
+  ce_block_max_sum(m, s);
+  if (threadIdx.x == 0) {
+    const float l = m + __logf(s);
+    lse[row] = l;
+    out[row] = wr * (x[target[row]] - l);
+  }
+}
+
+__global__ void __launch_bounds__(kCeThreads) k_ce_rows_bwd(float *__restrict__ logits, int64_t ld, int V,
+                                                            const int64_t *__restrict__ target,
+                                                            const float *__restrict__ w, const float *__restrict__ g,
+                                                            const float *__restrict__ lse) {
+  const int row = blockIdx.x;
+  const float coef = g[row] * w[row];
+  float *x = logits + (int64_t)row * ld;
+  if (coef == 0.f) {
+    for (int v = threadIdx.x; v < V; v += kCeThreads) x[v] = 0.f;
+    return;
+  }
+  const float l = lse[row];
+  const int t = (int)target[row];
+  for (int v = threadIdx.x; v < V; v += kCeThreads) {
+    const float p = __expf(x[v] - l);
+    x[v] = coef * ((v == t ? 1.f : 0.f) - p);
+  }
+}
+
 }  // namespace
 
 extern "C" int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stream) {
@@ -586,4 +664,22 @@ extern "C" int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out,
     return gvl::launch(GVL_PROF_COL_SUM, R, C, "k_col_sum", k_col_sum, grid, dim3(256), 0, st, x, (int64_t)ld, R, C, out);
   return gvl::launch(GVL_PROF_COL_SUM, R, C, "k_col_sum_scalar", k_col_sum_scalar, grid, dim3(256), 0, st, x,
                      (int64_t)ld, R, C, out);
+}
+
+extern "C" int gvl_ce_rows_forward_f32(const float *logits, int64_t ld, int R, int V, const int64_t *target,
+                                       const float *weight, float *out, float *lse, void *stream) {
+  if (R < 0 || V <= 0 || ld < V) return fail(GVL_EINVAL, "gvl_ce_rows_forward_f32: bad sizes R=%d V=%d", R, V);
+  if (R == 0) return 0;
+  if (!logits || !target || !weight || !out || !lse) return fail(GVL_EINVAL, "gvl_ce_rows_forward_f32: null pointer");
+  return gvl::launch(GVL_PROF_CRITERION, R, V, "k_ce_rows_fwd", k_ce_rows_fwd, dim3(R), dim3(kCeThreads), 0,
+                     (hipStream_t)stream, logits, ld, V, target, weight, out, lse);
+}
+
+extern "C" int gvl_ce_rows_backward_f32(float *logits, int64_t ld, int R, int V, const int64_t *target,
+                                        const float *weight, const float *grad_out, const float *lse, void *stream) {
+  if (R < 0 || V <= 0 || ld < V) return fail(GVL_EINVAL, "gvl_ce_rows_backward_f32: bad sizes R=%d V=%d", R, V);
+  if (R == 0) return 0;
+  if (!logits || !target || !weight || !grad_out || !lse) return fail(GVL_EINVAL, "gvl_ce_rows_backward_f32: null pointer");
+  return gvl::launch(GVL_PROF_CRITERION, R, V, "k_ce_rows_bwd", k_ce_rows_bwd, dim3(R), dim3(kCeThreads), 0,
+                     (hipStream_t)stream, logits, ld, V, target, weight, grad_out, lse);
 }

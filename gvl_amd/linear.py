@@ -91,6 +91,48 @@ def split_linear(x, weight, bias):
     return _SplitLinearFunction.forward(_NoCtx(), x, weight, bias)
 
 
+class _VocabNLLFunction(torch.autograd.Function):
+    """weight[r] * log_softmax(x W^T + b)[r, target[r]] for every (caption row, token step) r, without the (R, V)
+    log-prob tensor: product (fp16 matrix cores at fp32 accuracy when in the kernel's domain), one pass for log-sum-exp
+    and the picked logit; backward the logits buffer is overwritten by its own gradient and feeds the three gradient
+    products of the layer (include/gvl_msda.h: gvl_ce_rows_*_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target, row_weight):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        if split_gemm_enabled() and x2.shape[1] % 32 == 0 and weight.is_contiguous():
+            logits = MSDA.gemm_f16x3(MSDA.split_rows(x2), MSDA.split_rows(weight.detach()), bias.detach())
+        else:
+            logits = torch.addmm(bias.detach(), x2, weight.detach().t())
+        out, lse = MSDA.ce_rows_forward(logits, target, row_weight)
+        ctx.save_for_backward(x2, weight, logits, lse, target, row_weight)
+        ctx.x_shape = x.shape
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        x2, weight, logits, lse, target, row_weight = ctx.saved_tensors
+        g = MSDA.ce_rows_backward_(logits, target, row_weight, grad_out.contiguous(), lse)     # (R, V), in place
+        gx = g.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        gw = g.t().mm(x2) if ctx.needs_input_grad[1] else None
+        gb = MSDA.col_sum(g) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None
+
+
+def vocab_nll_eligible(x, weight, bias):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and bias is not None
+            and bias.dtype == torch.float32 and not torch.is_autocast_enabled() and bias.is_contiguous()
+            and os.environ.get("GVL_VOCAB_NLL", "") != "torch")
+
+
+def vocab_nll(x, weight, bias, target, row_weight):
+    """(..., H) hidden states -> (R,) row_weight * log_softmax(linear(x))[target] (R = product of the leading dimensions);
+    callers check vocab_nll_eligible first"""
+    return _VocabNLLFunction.apply(x, weight, bias, target.reshape(-1).contiguous(),
+                                   row_weight.reshape(-1).to(torch.float32).contiguous())
+
+
 class _NoCtx:
     def save_for_backward(self, *a):
         pass

@@ -437,7 +437,8 @@ class PDVC(nn.Module):
         ref_m = ref_stack.view(-1, 2).index_select(0, flat)
         seq_flat = pt.cap_tensor[v_all, t_all] * used_all[:, None]
         mask_flat = pt.cap_mask[v_all, t_all] * used_all[:, None]
-        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=pt.cap_len - 1, row_video=row_video)
+        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=pt.cap_len - 1, row_video=row_video,
+                            nll=(seq_flat[:, 1:], mask_flat[:, 1:]))
         row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
         # (a batch without a single event: every row is masked, the sum is exactly 0 -- 0 / 1, not 0 / 0: a NaN here would
         #  flow through clip_grad_norm_ into the captured Adam and poison parameters and moments for good)
@@ -481,7 +482,7 @@ class PDVC(nn.Module):
             live = (dt['cap_tensor'][:, 1:] != 0).any(0).cpu().tolist()
             steps = min(1 + (live.index(False) if False in live else len(live)), cap_len - 1)
             dt['_gvl_cap_steps'] = steps
-        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=steps)
+        cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=steps, nll=(seq_flat[:, 1:], mask_flat[:, 1:]))
         row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
         per_layer = row_loss.view(N_, nl, mp).mean(dim=(0, 2))
         return per_layer.unbind(0), {}, dt['cap_tensor'][matches[-1].t_global]

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 7   /* 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 8   /* 8: + gvl_gemm_f16x3_lstm_f32, gvl_skinny_gemm_f16x3_f32, gvl_skinny_pack_f16, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -299,6 +299,20 @@ int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const 
  *    are multiples of 4 and x is 16-byte aligned); out is overwritten.  Summation order across row chunks is not
  *    fixed (float atomics). */
 int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stream);
+
+/* -- caption loss over the vocabulary without the (R, V) log-prob tensor (pdvc/CaptioningHead/LSTM_DSA.py:48-52 applied
+ *    to the log_softmax of :121-123; R = caption rows x token steps):
+ *      gvl_ce_rows_forward_f32:   out[r] = weight[r] (logits[r][target[r]] - lse[r]),  lse[r] = logsumexp_v logits[r][v]
+ *                                 (= `F.log_softmax(logits, -1).gather(-1, target) * mask`); rows with weight 0 are not read
+ *                                 (out = lse = 0);
+ *      gvl_ce_rows_backward_f32:  logits[r][v] <- grad_out[r] weight[r] ((v == target[r]) - exp(logits[r][v] - lse[r])), IN
+ *                                 PLACE: the gradient with respect to the logits, from which the caller takes the three
+ *                                 gradients of the vocabulary layer.
+ *    logits (R, ld >= V) fp32, target (R) int64 in [0, V), weight / out / lse / grad_out (R) fp32. */
+int gvl_ce_rows_forward_f32(const float *logits, int64_t ld, int R, int V, const int64_t *target, const float *weight,
+                            float *out, float *lse, void *stream);
+int gvl_ce_rows_backward_f32(float *logits, int64_t ld, int R, int V, const int64_t *target, const float *weight,
+                             const float *grad_out, const float *lse, void *stream);
 
 /* -- kernel timing inside the library (measurement only; no reference equivalent).  While enabled, every kernel the
  *    library launches is dispatched with hipExtLaunchKernel start/stop events on the launch stream, i.e. the

@@ -128,3 +128,37 @@ def test_linear_gradients_equal_autograd_of_f_linear():
     assert type(linear(x, lin.weight, None).grad_fn).__name__ != "_LinearFunctionBackward"
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert type(lin(x).grad_fn).__name__ != "_LinearFunctionBackward"
+
+
+@pytest.mark.parametrize("n,steps,H,V", [(192, 23, 512, 8518), (5, 3, 64, 37), (40, 7, 96, 1000)])
+def test_vocab_nll_equals_log_softmax_gather_and_its_autograd(n, steps, H, V):
+    """gvl_amd.linear.vocab_nll (gvl_ce_rows_*_f32: the masked target log-prob without the log-prob tensor) against the
+    reference formulation -- build_loss over F.log_softmax(logit(x)) (LSTM_DSA.py:48-52, 121-123) -- and its autograd:
+    values and the gradients of the hidden states, the vocabulary weight and bias; masked rows (padding, steps past the
+    caption's end) contribute exactly zero."""
+    import torch.nn.functional as F
+    from gvl_amd.linear import vocab_nll, vocab_nll_eligible
+    g = torch.Generator().manual_seed(n + V)
+    x = (torch.randn(n, steps, H, generator=g) * 0.5).cuda().requires_grad_()
+    w = (torch.rand(V, H, generator=g) * 0.2 - 0.1).cuda().requires_grad_()
+    b = (torch.randn(V, generator=g) * 0.1).cuda().requires_grad_()
+    target = torch.randint(0, V, (n, steps), generator=g).cuda()
+    lens = torch.randint(0, steps + 1, (n,), generator=g)
+    mask = (torch.arange(steps)[None, :] < lens[:, None]).cuda()
+    gout = torch.randn(n, generator=g).cuda()
+    assert vocab_nll_eligible(x, w, b)
+    picked = vocab_nll(x, w, b, target, mask).view(n, steps)
+    loss = -picked.sum(1) / (mask.sum(1) + 1e-6)
+    (loss * gout).sum().backward()
+    got = (loss.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    logp = F.log_softmax(F.linear(x.double(), w.double(), b.double()), dim=2)
+    ref = -(logp.gather(2, target[:, :, None]).squeeze(2) * mask).sum(1) / (mask.sum(1) + 1e-6)
+    (ref * gout.double()).sum().backward()
+    want = (ref.detach(), x.grad, w.grad, b.grad)
+    for name, a, r in zip(("loss", "d hidden", "d weight", "d bias"), got, want):
+        err = float((a.double() - r.double()).abs().max())
+        assert err <= 2e-5 * max(1.0, float(r.abs().max())), (name, err, float(r.abs().max()))
+    dead = ~mask.any(1)
+    if bool(dead.any()):
+        assert float(got[0][dead].abs().max()) == 0.0 and float(got[1][dead].abs().max()) == 0.0

@@ -40,7 +40,7 @@ def test_inference_layer_entry_points_are_declared_and_exported():
     for name in ("gvl_linear_f16x3_f32", "gvl_layer_norm_rows_f32", "gvl_row_absmax_f32", "gvl_box_refine_f32",
                  "gvl_count_head_f32", "gvl_msda1d_fused_forward_amax_f32"):
         assert hasattr(L, name), name
-    assert L.gvl_msda_abi_version() == _lib.ABI_VERSION == 7
+    assert L.gvl_msda_abi_version() == _lib.ABI_VERSION >= 7
     # K not a multiple of 32 / N not a multiple of 64 are refused before anything is launched
     assert L.gvl_linear_f16x3_f32(None, 0, None, 0, 0, 4, 48, None, None, None, None, 64, None, 1, 0, None) == -1
     assert b"K % 32" in L.gvl_last_error()
