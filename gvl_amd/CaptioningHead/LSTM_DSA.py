@@ -215,6 +215,8 @@ class ShowAttendTellCore(nn.Module):
         if shapes2d is None:
             shapes2d = const["shapes2d"] = temporal_shapes_2d(temporal_shapes, level_start_index)
             const["ref_in"] = reference_points.contiguous()
+            host = getattr(temporal_shapes, "_gvl_host_lengths", None)          # (lengths, starts) known without a read-back
+            const["host_starts"] = tuple(host[1]) if host is not None else None
         A = self.att_hid_size
         split = "w_h_cat_p" in const and h.dtype == torch.float32
         if split:
@@ -226,7 +228,7 @@ class ShowAttendTellCore(nn.Module):
         split = split and const["slab3"].dtype == torch.float32
         att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
                                   h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
-                                  self.n_levels, self.n_points, planes=split)
+                                  self.n_levels, self.n_points, planes=split, host_starts=const.get("host_starts"))
         if split and const.get("gate_perm") is not None:                # ... whose epilogue is the cell (step)
             return att_res, g_h
         if split:                                                       # att_res arrives as the planes of the product

@@ -225,11 +225,13 @@ def ms_deform_attn_sample_backward(value, spatial_shapes, level_start_index, sam
 
 
 def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off_h, att_h, alpha_w, alpha_b,
-               n_levels, n_points, debug=False, planes=False):
+               n_levels, n_points, debug=False, planes=False, host_starts=None):
     """Fused deformable soft attention of one captioner token step (include/gvl_msda.h: gvl_cap_attend_f32 / _bf16).
     slab (B,S,2C) | ref_in (B,Q,L,1|2) | off_hs (B,Q,L*P) | h, att_h (B*Q,C) | w_off_h (L*P,C) | alpha_w (C,)
     slab and att_h: both fp32 or both bf16 (GEMM outputs under autocast); everything else fp32.
-    planes=True (fp32 only): the result as the SplitPlanes operand of gemm_f16x3 (gvl_cap_attend_split_f32)."""
+    planes=True (fp32 only): the result as the SplitPlanes operand of gemm_f16x3 (gvl_cap_attend_split_f32);
+    host_starts: the level starts as host integers when the caller has them (gvl_cap_attend_split_levels_f32: the coarse
+    levels' rows then stay in LDS)."""
     st = slab.dtype
     _require(st in (torch.float32, torch.bfloat16), "cap_attend: slab must be fp32 or bf16")
     for name, t_ in (("ref_in", ref_in), ("off_hs", off_hs), ("h", h), ("w_off_h", w_off_h), ("alpha_w", alpha_w)):
@@ -245,11 +247,15 @@ def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off
     if planes:
         _require(st == torch.float32 and not debug, "cap_attend: planes=True needs fp32 operands (and no debug outputs)")
         out = SplitPlanes(B * Q, C, slab.device)
+        hs_arr = None
+        if host_starts is not None and len(host_starts) == n_levels:
+            hs_arr = (ctypes.c_int64 * n_levels)(*[int(v) for v in host_starts])
         with torch.cuda.device(slab.device):
-            rc = _lib.lib().gvl_cap_attend_split_f32(
+            rc = _lib.lib().gvl_cap_attend_split_levels_f32(
                 slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(),
                 off_hs.data_ptr(), h.data_ptr(), w_off_h.data_ptr(), att_h.data_ptr(), alpha_w.data_ptr(),
-                float(alpha_b), B, S, C, n_levels, Q, n_points, RD, att_h.stride(0), out.hi.data_ptr(),
+                float(alpha_b), B, S, C, n_levels, Q, n_points, RD, att_h.stride(0),
+                ctypes.cast(hs_arr, ctypes.c_void_p) if hs_arr is not None else None, out.hi.data_ptr(),
                 out.lo.data_ptr(), out.scale.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "cap_attend_split")
         return out

@@ -38,6 +38,7 @@ SIGNATURES = {
     "gvl_lstm_cell_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "gvl_lstm_cell_split_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "gvl_cap_attend_split_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P]),
+    "gvl_cap_attend_split_levels_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P, _P]),
     "gvl_cap_attend_train_forward_f32": (_I, [_P] * 6 + [_I, _P, _I, _P, _P] + [_I] * 7 + [_P, _P, _P, _P]),
     "gvl_cap_attend_train_backward_f32": (_I, [_P] * 6 + [_I, _P, _I, _P, _P, _P, _I] + [_I] * 7
                                           + [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P]),

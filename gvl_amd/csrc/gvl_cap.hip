@@ -20,6 +20,8 @@
 //                     func.py:44-68, used by the teacher-forced captioner in training).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "gvl_common.hpp"
 #include "gvl_msda.h"
@@ -292,6 +294,191 @@ __global__ void __launch_bounds__(kWaves * 64, (FULL && sizeof(ST) == 4) ? 3 : 2
   }
 }
 
+// k_cap_attend_lds -- the same token step with the COARSE end of the video's slab resident in LDS.  k_cap_attend is bound
+// by the CU's vector-memory path: 630 MB of slab rows per token through 256 texture-address units at ~70 GB/s each are
+// 35 us, whatever the rows' cache level (measured: every sample redirected to two L1-resident rows: -1.6 us; tanh removed:
+// no change; twice the loads in flight: no change).  The samples of a query are spread evenly over the pyramid levels
+// while the levels' rows are not (100 / 50 / 25 / 13 at cfg A): the last 32 rows of a slab receive 44 % of all reads.
+// Here a workgroup serves ONE video (a contiguous share of its queries), stages the ctx2att half of the slab's last
+// n_ctx rows and the value half of its last n_val rows in LDS once (as many as fit beside the offsets weight) and every
+// sample whose rows lie there reads LDS (ds_read_b128, 4-8 x the rate) -- the test is wavefront-uniform (the row index
+// is a scalar).  fp32, L * P == 16, result as planes (the inference token loop).
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) k_cap_attend_lds(
+    const float *__restrict__ slab,         // (B, S, 2C)  [value_proj(memory) | ctx2att(value_proj(memory))]
+    const int64_t *__restrict__ shapes,  // (L, 2)
+    const int64_t *__restrict__ lsi,     // (L)
+    const float *__restrict__ ref,       // (B, Q, L, RD) reference points scaled by the valid ratios
+    const float *__restrict__ off_hs,    // (B*Q, 16)   sampling_offsets bias + hs part
+    const float *__restrict__ h,         // (B*Q, C)    previous hidden state
+    const float *__restrict__ w_off_h,   // (16, C)     sampling_offsets.weight[:, :C]
+    const float *__restrict__ att_h,        // (B*Q, C)    h2att(h), row stride att_h_ld elements
+    const float *__restrict__ alpha_w,   // (C)
+    float alpha_b, int B, int S, int L, int Q, int P, int RD, int vids_per_xcd, int parts, int n_ctx, int n_val,
+    int att_h_ld,
+    _Float16 *__restrict__ o_hi,         // the result as the fp16 planes + row scale of gvl_gemm_f16x3_f32
+    _Float16 *__restrict__ o_lo, float *__restrict__ o_scale) {
+  constexpr bool FULL = true;
+  extern __shared__ float4 cap_lds[];    // [offsets weight 32 KiB | ctx2att half of rows S - n_ctx .. | value half of rows S - n_val ..]
+  float4 *wo4 = cap_lds, *lds_ctx = cap_lds + kLP * kC / 4, *lds_val = lds_ctx + n_ctx * (kC / 4);
+  for (int i = threadIdx.x; i < kLP * kC / 4; i += blockDim.x) wo4[i] = reinterpret_cast<const float4 *>(w_off_h)[i];
+
+  // workgroup -> (video, share of its queries): XCD x (= workgroup id % 8) serves videos [x vids_per_xcd, (x + 1)
+  // vids_per_xcd), `parts` workgroups per video
+  const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = xcd * vids_per_xcd + jblk / parts, part_id = jblk % parts;
+  if (b >= B || jblk / parts >= vids_per_xcd) return;                  // (uniform for the workgroup)
+  const float *slab_b = slab + (int64_t)b * S * (2 * kC);             // this video's slab; ld4 indexes groups of 4 elements
+  const int c0 = S - n_ctx, v0 = S - n_val;                           // first slab row resident in LDS, per half
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(slab_b);
+    for (int i = threadIdx.x; i < n_ctx * (kC / 4); i += blockDim.x)
+      lds_ctx[i] = src[(int64_t)(c0 + i / (kC / 4)) * (2 * kC / 4) + kC / 4 + i % (kC / 4)];
+    for (int i = threadIdx.x; i < n_val * (kC / 4); i += blockDim.x)
+      lds_val[i] = src[(int64_t)(v0 + i / (kC / 4)) * (2 * kC / 4) + i % (kC / 4)];
+  }
+  __syncthreads();
+  const int per = (Q + parts - 1) / parts, q_begin = part_id * per, q_end = min(Q, q_begin + per);
+  for (int q = q_begin + wave; q < q_end; q += WAVES) {
+  const int64_t row = (int64_t)b * Q + q;
+
+  // own channels: [4*lane, 4*lane+4) and [256 + 4*lane, 256 + 4*lane + 4)
+  const float4 *h4 = reinterpret_cast<const float4 *>(h + row * kC);
+  const float4 ha = h4[lane], hb = h4[64 + lane];
+  float part[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float4 wa = wo4[k * (kC / 4) + lane], wb = wo4[k * (kC / 4) + 64 + lane];
+    part[k] = wa.x * ha.x + wa.y * ha.y + wa.z * ha.z + wa.w * ha.w + wb.x * hb.x + wb.y * hb.y + wb.z * hb.z +
+              wb.w * hb.w;
+  }
+  const int k_own = lane >> 2;                       // the sample this lane group owns after the butterfly
+  float off = butterfly16(part, lane);
+  int roff = 0;
+  float c_lo = 0.f, c_hi = 0.f, locx = 0.f;
+  const int LP = FULL ? kLP : L * P;
+  if (k_own < LP) {
+    off += off_hs[row * LP + k_own];
+    const int l = k_own / P;
+    const int T = (int)shapes[2 * l + 1];
+    const float *rp = ref + (row * L + l) * RD;
+    if (RD == 1) locx = rp[0] + off / (float)T;                              // ms_deform_attn_for_caption.py:108-109
+    else locx = rp[0] + off / (float)P * rp[1] * 0.5f;                       // :110-112
+    int r;
+    border_coef(locx, T, r, c_lo, c_hi);
+    roff = (int)lsi[l] + r;
+  }
+
+  // ---- pass 1: attention logits from the ctx2att half ------------------------------------------------------
+  const float *ah = att_h + row * (int64_t)att_h_ld;
+  const float4 ta = ld4(ah, lane), tb = ld4(ah, 64 + lane);
+  const float4 qa = reinterpret_cast<const float4 *>(alpha_w)[lane], qb = reinterpret_cast<const float4 *>(alpha_w)[64 + lane];
+  // Samples are taken two at a time with all eight 16-byte loads requested before any arithmetic: a wavefront walks a
+  // chain of 32 dependent L2 round trips otherwise (4 loads in flight), and the kernel is bound by that latency
+  struct Rows { float4 l0, l1, u0, u1; };
+  auto load_rows = [&](int k, int half4, float &cl, float &ch) {
+    const int rr = __builtin_amdgcn_readlane(roff, 4 * k);
+    cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_lo), 4 * k));
+    ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_hi), 4 * k));
+    const int rr1 = min(rr + 1, S - 1);             // c_hi == 0 whenever rr + 1 leaves the level (T_l == 1)
+    Rows r;
+    // WHERE a sample's rows live is static: the ctx2att half of levels 2, 3 (samples 8 .. 15) and the value half of level
+    // 3 (samples 12 .. 15) are resident (the host launches this kernel only when they fit)
+    if (half4 ? k >= 8 : k >= 12) {
+      const float4 *img = half4 ? lds_ctx : lds_val;
+      const int first = half4 ? c0 : v0;
+      const int i0 = (rr - first) * (kC / 4), i1 = (rr1 - first) * (kC / 4);
+      r.l0 = img[i0 + lane]; r.l1 = img[i0 + 64 + lane];
+      r.u0 = img[i1 + lane]; r.u1 = img[i1 + 64 + lane];
+    } else {
+      const int64_t r0 = (int64_t)rr * (2 * kC / 4) + half4, r1 = (int64_t)rr1 * (2 * kC / 4) + half4;
+      r.l0 = ld4(slab_b, r0 + lane); r.l1 = ld4(slab_b, r0 + 64 + lane);
+      r.u0 = ld4(slab_b, r1 + lane); r.u1 = ld4(slab_b, r1 + 64 + lane);
+    }
+    return r;
+  };
+  auto logit_part = [&](const Rows &r, float cl, float ch) {
+    float s = 0.f;
+    s = fmaf(qa.x, fast_tanh(fmaf(cl, r.l0.x, fmaf(ch, r.u0.x, ta.x))), s);
+    s = fmaf(qa.y, fast_tanh(fmaf(cl, r.l0.y, fmaf(ch, r.u0.y, ta.y))), s);
+    s = fmaf(qa.z, fast_tanh(fmaf(cl, r.l0.z, fmaf(ch, r.u0.z, ta.z))), s);
+    s = fmaf(qa.w, fast_tanh(fmaf(cl, r.l0.w, fmaf(ch, r.u0.w, ta.w))), s);
+    s = fmaf(qb.x, fast_tanh(fmaf(cl, r.l1.x, fmaf(ch, r.u1.x, tb.x))), s);
+    s = fmaf(qb.y, fast_tanh(fmaf(cl, r.l1.y, fmaf(ch, r.u1.y, tb.y))), s);
+    s = fmaf(qb.z, fast_tanh(fmaf(cl, r.l1.z, fmaf(ch, r.u1.z, tb.z))), s);
+    s = fmaf(qb.w, fast_tanh(fmaf(cl, r.l1.w, fmaf(ch, r.u1.w, tb.w))), s);
+    return s;
+  };
+  float e[16];
+  constexpr int kBatch = 2;                                          // samples whose 4 kBatch loads are in flight together (4: measured the same)
+#pragma unroll
+  for (int k = 0; k < 16; k += kBatch) {
+    float cl[kBatch], ch[kBatch];
+    Rows rr[kBatch];
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t) {
+      e[k + t] = 0.f;
+      if (k + t < LP) rr[t] = load_rows(k + t, kC / 4, cl[t], ch[t]);  // ctx2att half of the slab rows
+    }
+    __builtin_amdgcn_sched_barrier(0);                               // keep the loads ahead of the arithmetic
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t)
+      if (k + t < LP) e[k + t] = logit_part(rr[t], cl[t], ch[t]);
+    __builtin_amdgcn_sched_barrier(0);                               // (no hoisting of the next pair's two-way loads)
+  }
+  float ek = butterfly16(e, lane) + alpha_b;
+  if (k_own >= LP) ek = -INFINITY;
+  const float m = groups_max(ek);
+  const float pexp = (k_own < LP) ? __expf(ek - m) : 0.f;
+  const float alpha = pexp / groups_sum(pexp);
+  const float a_lo = alpha * c_lo, a_hi = alpha * c_hi;
+
+  // ---- pass 2: weighted sum of the value half --------------------------------------------------------------
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto coef = [&](int k, float &cl, float &ch) {
+    cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_lo), 4 * k));
+    ch = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_hi), 4 * k));
+  };
+#pragma unroll
+  for (int k = 0; k < 16; k += kBatch) {
+    float d0, d1;
+    Rows rr[kBatch];
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t)
+      if (k + t < LP) rr[t] = load_rows(k + t, 0, d0, d1);           // value half of the slab rows
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t)
+      if (k + t < LP) {
+        float cl, ch;
+        coef(k + t, cl, ch);
+        fma8(cl, rr[t].l0, rr[t].l1, acc);
+        fma8(ch, rr[t].u0, rr[t].u1, acc);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    // the wavefront owns the whole row: its largest magnitude is one reduction away
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m = fmaxf(m, fabsf(acc[c]));
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sc, inv;
+    pow2_scale(m, sc, inv);
+    if (lane == 0) o_scale[row] = sc;
+    half4_t h0, l0, h1, l1;
+    split4_f16(make_float4(acc[0], acc[1], acc[2], acc[3]), inv, h0, l0);
+    split4_f16(make_float4(acc[4], acc[5], acc[6], acc[7]), inv, h1, l1);
+    half4_t *ph = reinterpret_cast<half4_t *>(o_hi + row * kC), *pl = reinterpret_cast<half4_t *>(o_lo + row * kC);
+    ph[lane] = h0; ph[64 + lane] = h1;
+    pl[lane] = l0; pl[64 + lane] = l1;
+  }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------------
 // greedy-decoding epilogue: one workgroup per row: argmax (first maximal index) and log_softmax at the argmax
 // ------------------------------------------------------------------------------------------------------
@@ -558,7 +745,7 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
                     const float *off_hs, const float *h, const float *w_off_h, const ST *att_h, const float *alpha_w,
                     float alpha_b, int B, int S, int C, int L, int Q, int P, int RD, int att_h_ld, ST *att_res,
                     float *dbg_alpha, float *dbg_loc, void *stream, void *o_hi = nullptr, void *o_lo = nullptr,
-                    float *o_scale = nullptr) {
+                    float *o_scale = nullptr, const int64_t *lsi_host = nullptr) {
   if (att_h_ld < C || (att_h_ld & 3)) return fail(GVL_EINVAL, "%s: att_h_ld must be >= C and a multiple of 4", what);
   if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
     return fail(GVL_EINVAL, "%s: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", what, C, L, P, RD);
@@ -567,6 +754,30 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
       || (o_hi && (!o_lo || !o_scale)))
     return fail(GVL_EINVAL, "%s: null pointer", what);
   const int vids_per_group = (B + 7) / 8;
+  if constexpr (std::is_same<ST, float>::value) {
+    const char *e = getenv("GVL_CAP_LDS");
+    // rows of levels 2, 3 (ctx2att half) and of level 3 (value half): known to the caller that passes host level starts
+    const int n_ctx = lsi_host ? S - (int)lsi_host[2] : 0, n_val = lsi_host ? S - (int)lsi_host[3] : 0;
+    if (o_hi && L == 4 && P == 4 && lsi_host && n_val >= 1 && n_ctx >= n_val && n_ctx + n_val <= 63 &&
+        !(e && atoi(e) == 0)) {
+      // the coarse end of each video's slab in LDS (k_cap_attend_lds): 64 half rows of 2 KB beside the 32 KB offsets weight
+      int parts = 32 / vids_per_group;                                 // workgroups per video: one per CU of the video's XCD
+      parts = parts < 1 ? 1 : (parts > Q ? Q : parts);
+      const size_t lds = (size_t)kLP * kC * sizeof(float) + (size_t)(n_ctx + n_val) * kC * sizeof(float);
+      const char *w = getenv("GVL_CAP_LDS_WAVES");
+      const dim3 grid(8 * vids_per_group * parts);
+      if (w && atoi(w) == 8) {
+        if (int rc = gvl::ensure_lds(k_cap_attend_lds<8>, lds)) return rc;
+        return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend_lds", k_cap_attend_lds<8>, grid, dim3(8 * 64), lds,
+                           (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h, alpha_w, alpha_b, B, S, L,
+                           Q, P, RD, vids_per_group, parts, n_ctx, n_val, att_h_ld, (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale);
+      }
+      if (int rc = gvl::ensure_lds(k_cap_attend_lds<12>, lds)) return rc;
+      return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend_lds", k_cap_attend_lds<12>, grid, dim3(12 * 64), lds,
+                         (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h, alpha_w, alpha_b, B, S, L, Q,
+                         P, RD, vids_per_group, parts, n_ctx, n_val, att_h_ld, (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale);
+    }
+  }
   const int rows_per_group = vids_per_group * Q;
   int blocks_per_group = (rows_per_group + kWaves - 1) / kWaves;
   if (blocks_per_group > 96) blocks_per_group = 96;                    // 3 resident workgroups on each of an XCD's 32 CUs
@@ -634,6 +845,17 @@ int gvl_cap_attend_split_f32(const float *slab, const int64_t *shapes, const int
   return cap_attend_impl<float>("gvl_cap_attend_split_f32", slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h, alpha_w,
                                 alpha_b, B, S, C, L, Q, P, RD, att_h_ld, (float *)nullptr, nullptr, nullptr, stream, att_hi,
                                 att_lo, att_scale);
+}
+
+int gvl_cap_attend_split_levels_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                                    const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
+                                    const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
+                                    int att_h_ld, const int64_t *lsi_host, void *att_hi, void *att_lo, float *att_scale,
+                                    void *stream) {
+  if (!att_hi) return fail(GVL_EINVAL, "gvl_cap_attend_split_levels_f32: null pointer");
+  return cap_attend_impl<float>("gvl_cap_attend_split_levels_f32", slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
+                                alpha_w, alpha_b, B, S, C, L, Q, P, RD, att_h_ld, (float *)nullptr, nullptr, nullptr, stream,
+                                att_hi, att_lo, att_scale, lsi_host);
 }
 
 int gvl_lstm_cell_split_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 8   /* 8: + gvl_gemm_f16x3_lstm_f32, gvl_skinny_gemm_f16x3_f32, gvl_skinny_pack_f16, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 8   /* 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_skinny_gemm_f16x3_f32, gvl_skinny_pack_f16, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -262,6 +262,17 @@ int gvl_cap_attend_split_f32(const float *slab, const int64_t *shapes, const int
 int gvl_lstm_cell_split_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,
                             const int64_t *it, const float *gates_c, int ldc, const float *c, int n, int H, float *h_out,
                             float *c_out, void *h_hi, void *h_lo, float *h_scale, void *stream);
+/*    gvl_cap_attend_split_levels_f32 = gvl_cap_attend_split_f32 for a caller that also knows the level starts on the
+ *        HOST (lsi_host (L), the values of `lsi`; NULL = unknown): with L = P = 4 and few enough rows in the two coarsest
+ *        levels (all of levels 2, 3 plus level 3 again <= 63 rows: T <= 100 at the pyramid of the path) the kernel keeps
+ *        those rows of each video's slab in LDS -- the ctx2att half of levels 2 and 3, the value half of level 3 -- and
+ *        serves 3 / 8 of all sample reads from there instead of the CU's vector-memory path, which bounds the plain
+ *        kernel.  Same results (the same arithmetic on the same numbers). */
+int gvl_cap_attend_split_levels_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref,
+                                    const float *off_hs, const float *h, const float *w_off_h, const float *att_h,
+                                    const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
+                                    int att_h_ld, const int64_t *lsi_host, void *att_hi, void *att_lo, float *att_scale,
+                                    void *stream);
 /*    gvl_gemm_f16x3_lstm_f32: the attention half of the LSTM input product WITH the cell applied to the finished tile
  *        (LSTM_DSA.py:267-269 + nn.LSTM's pointwise part, :216-217): gates = A (R, K) . W (4H, K)^T + gates_c + gates_h +
  *        emb_gates[it], (h', c') = cell(gates, c); the (R, 4H) product is never written and gvl_lstm_cell_split_f32 does not

@@ -177,6 +177,13 @@ def test_cap_attend_kernel_matches_unfused_reference_order():
         back = pl.scale.double()[:, None] * (pl.hi.double() + pl.lo.double() / 2048.0)
         rowmax = got.abs().amax(1, keepdim=True).double()
         assert bool(((back - got.double()).abs() <= 2.0 ** -22 * got.abs().double() + 2.0 ** -34 * rowmax).all())
+        # ... and from the kernel that keeps the coarse levels' rows in LDS (gvl_cap_attend_split_levels_f32, taken when the
+        # caller knows the level starts on the host, L = P = 4 and the rows fit): the same bits
+        pl2 = MSDA.cap_attend(slab, shapes2d, lsi_d, ref.contiguous().to(dev), off_hs, h.to(dev),
+                              Wo[:, :C].contiguous().to(dev), torch.nn.functional.linear(h, Wh, bh).to(dev), aw.to(dev),
+                              ab, L, P, planes=True, host_starts=[int(v) for v in lsi])
+        torch.cuda.synchronize()
+        assert torch.equal(pl2.hi, pl.hi) and torch.equal(pl2.lo, pl.lo) and torch.equal(pl2.scale, pl.scale)
 
 
 def test_row_argmax_lse_matches_torch():
