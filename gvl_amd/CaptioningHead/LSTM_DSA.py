@@ -92,8 +92,9 @@ class ShowAttendTellCore(nn.Module):
         if perm is None:
             w = L.cached(self, "hs", [(self.rnn.weight_ih_l0[:, E + Cf:], None), (ow[:, H:], att.sampling_offsets.bias)])
         else:                                                           # gate rows in the order 4 unit + gate
-            w = L.cached(self, "hs_perm", [(self.rnn.weight_ih_l0[:, E + Cf:][perm], None),
-                                           (ow[:, H:], att.sampling_offsets.bias)])
+            w = L.cached(self, "hs_perm", lambda: [(self.rnn.weight_ih_l0[:, E + Cf:][perm], None),
+                                                   (ow[:, H:], att.sampling_offsets.bias)],
+                         key_of=(self.rnn.weight_ih_l0, ow, att.sampling_offsets.bias))
         gates_hs = torch.empty(q.shape[0], 4 * H, device=q.device, dtype=torch.float32)
         off_hs = torch.empty(q.shape[0], K, device=q.device, dtype=torch.float32)
         L.linear(q, w, [L.seg(0, gates_hs, am_q), L.seg(w.starts[1], off_hs, am_q, width=K)])

@@ -58,13 +58,20 @@ class Weights:
             self.bias = torch.cat(bs, 0).float().contiguous()
 
 
-def cached(owner, name, params, pad_to=None):
+def cached(owner, name, params, pad_to=None, key_of=None):
     """Weights of `params` = [(weight, bias), ...] kept on `owner` until one of the parameters changes.  Several blocks
-    are padded to multiples of 128 columns when that keeps the launch on the wide tile (total >= 256 columns)."""
-    key = tuple((p_.data_ptr(), p_._version) for pair in params for p_ in pair if p_ is not None)
+    are padded to multiples of 128 columns when that keeps the launch on the wide tile (total >= 256 columns).
+    key_of: the PARAMETERS the blocks derive from, with `params` a callable that builds the blocks on a miss -- for blocks
+    that are not views of a parameter (a row permutation: a new tensor, and a new address, on every evaluation)."""
+    if key_of is not None:
+        key = tuple((p_.data_ptr(), p_._version) for p_ in key_of)
+    else:
+        key = tuple((p_.data_ptr(), p_._version) for pair in params for p_ in pair if p_ is not None)
     store = owner.__dict__.setdefault("_gvl_lin_w", {})
     hit = store.get(name)
     if hit is None or hit[0] != key:
+        if callable(params):
+            params = params()
         if pad_to is None:
             pad_to = 128 if len(params) > 1 and sum(w_.shape[0] for w_, _ in params) >= 256 else 64
         hit = store[name] = (key, Weights(params, pad_to))
