@@ -46,3 +46,25 @@ def test_inference_layer_entry_points_are_declared_and_exported():
     assert b"K % 32" in L.gvl_last_error()
     assert L.gvl_layer_norm_rows_f32(None, 4, 6, None, None, 1e-5, None, 0, None, None, None, None) == -1
     assert L.gvl_box_refine_f32(None, 1, None, 2, None, 1, 1, 1, None, None, None) == -1
+
+
+def test_round3_token_loop_entry_points_are_declared_and_exported():
+    """the ABI-8 symbols (cell in the gate product's epilogue, attention kernel with host level starts, caption loss rows,
+    few-row product) resolve; argument checking runs without a GPU; the gate permutation is what the header states"""
+    import torch
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd import _lib
+    L = _lib.lib()
+    for name in ("gvl_gemm_f16x3_lstm_f32", "gvl_cap_attend_split_levels_f32", "gvl_ce_rows_forward_f32",
+                 "gvl_ce_rows_backward_f32", "gvl_skinny_gemm_f16x3_f32", "gvl_skinny_pack_f16"):
+        assert hasattr(L, name), name
+    assert L.gvl_msda_abi_version() == _lib.ABI_VERSION >= 8
+    assert L.gvl_ce_rows_forward_f32(None, 4, 2, 8, None, None, None, None, None) == -1        # ld < V
+    assert b"bad sizes" in L.gvl_last_error()
+    assert L.gvl_gemm_f16x3_lstm_f32(None, None, None, 4, None, None, None, 6, 32, None, 24, None, 0, None, None, None, None,
+                                     None, None, None, None, None) == -1                       # H not a multiple of 8
+    assert b"multiple of 8" in L.gvl_last_error()
+    perm = MSDA.gate_permutation(3)
+    assert perm.tolist() == [0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8, 11]                             # row g * H + u at 4 * u + g
+    w = torch.arange(12.0)[:, None]
+    assert torch.equal(w[perm].view(3, 4), torch.tensor([[0.0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]]))
