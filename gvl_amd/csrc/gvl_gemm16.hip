@@ -176,11 +176,11 @@ __device__ __forceinline__ void lstm_finish(const LstmPre &p, const f16acc &am, 
   }
 }
 
-template <int NJ>
+template <int NJ, bool SEQ>
 __device__ __forceinline__ void lstm_epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ], int row0, int col0, int lane,
                                               const float *__restrict__ As, const float *__restrict__ Bs, int R, int N,
                                               const LstmEpi &le) {
-  if constexpr (NJ == 1) {
+  if constexpr (NJ == 1 && !SEQ) {
     LstmPre p[2];
     lstm_rows(p[0], row0, lane, As, R, le);
     lstm_rows(p[1], row0 + 32, lane, As, R, le);
@@ -204,7 +204,7 @@ __device__ __forceinline__ void lstm_epilogue(f16acc (&acc_m)[2][NJ], f16acc (&a
 }
 
 // epilogue of one wavefront: its 64 x 32 NJ part of D starts at (row0, col0)
-template <int NJ, int EPI>
+template <int NJ, int EPI, bool SEQ = false>
 __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ], int row0, int col0, int lane,
                                          const float *__restrict__ As, const float *__restrict__ Bs,
                                          const float *__restrict__ bias, int R, int N, float *__restrict__ out,
@@ -212,7 +212,7 @@ __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)
   // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   const int frow = lane & 31, fh = lane >> 5;
   if constexpr (EPI == kLstm) {
-    lstm_epilogue<NJ>(acc_m, acc_x, row0, col0, lane, As, Bs, R, N, le);
+    lstm_epilogue<NJ, SEQ>(acc_m, acc_x, row0, col0, lane, As, Bs, R, N, le);
     return;
   }
   // branch-free optional bias: without one every read goes to As[0] (a finite power of two) and is multiplied by 0
@@ -377,7 +377,9 @@ __global__ void __launch_bounds__(256, 2)
     __syncthreads();
   }
   mfma_stage<NJ>(smem + ((KT - 1) & 1) * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
-  epilogue<NJ, EPI>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo, le);
+  // (kLstm: one 32-row block at a time -- 64 registers fewer than both in flight, which keeps three workgroups on a CU; the
+  //  other workgroups' products cover the block's load latency)
+  epilogue<NJ, EPI, true>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo, le);
 }
 
 // ---- eight wavefronts (WM x WN, 64 x 64 each), tile 64 WM x 64 WN, THREE LDS stages with the DMA two stages ahead.
@@ -1001,8 +1003,12 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
                  *bl = (const _Float16 *)w_lo;
   const LstmEpi le = {gates_h, ld_h, gates_c, ld_c, emb_gates, it, c, h_out, c_out, (_Float16 *)h_hi, (_Float16 *)h_lo,
                       h_scale, H};
-  // same tile choice as gvl_gemm_f16x3_f32 (the product is the same; only what happens to a finished tile differs)
-  if (R >= 1024 && K >= 3 * kBK) {
+  // The four-wavefront kernel by default (128 x 64 tiles, three workgroups per CU at 142 VGPRs): a tile's cell epilogue --
+  // a third of its time -- runs under the other two workgroups' products, where the persistent eight-wavefront kernel
+  // (one workgroup per CU, GVL_LSTM_GEMM_FORM=8) leaves the matrix cores idle for it: 60.9 against 65.6 us at 4800 x 512 x
+  // 2048 although the plain product is faster on the eight-wavefront kernel
+  const char *form = getenv("GVL_LSTM_GEMM_FORM");
+  if (R >= 1024 && K >= 3 * kBK && form && atoi(form) == 8) {
     const int t_big = ((R + 255) / 256) * ((N + 127) / 128), t_mid = ((R + 127) / 128) * ((N + 127) / 128);
     if (t_big >= 1024) {
       const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
@@ -1017,6 +1023,7 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
                          bl, w_scale, (const float *)nullptr, R, N, K, (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
     }
   }
+  // (128 x 128 tiles on this kernel, two workgroups per CU: 10.44 against 10.17 ms per eval step)
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
   return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3<lstm>", k_gemm_f16x3<64, kLstm>, dim3((tiles_m * tiles_n + 7) / 8 * 8),
                      dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, w_scale, (const float *)nullptr, R, N, K,
@@ -1034,7 +1041,8 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   const _Float16 *xh = (const _Float16 *)x_hi, *xl = (const _Float16 *)x_lo, *wh = (const _Float16 *)w_hi,
                  *wl = (const _Float16 *)w_lo;
   const int tiles_m = (V + kBM - 1) / kBM;                            // 128 vocabulary entries per tile, either form
-  if (R >= 1024 && K >= 3 * kBK) {
+  const char *aform = getenv("GVL_ARGMAX_FORM");                      // (4: the four-wavefront kernel, A/B runs)
+  if (R >= 1024 && K >= 3 * kBK && !(aform && atoi(aform) == 4)) {
     const int tiles_n = (R + 255) / 256;
     if (use_m16(K))
       return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_m16<argmax>", k_gemm_f16x3_m16<2, 4, kArgmax>,
