@@ -220,13 +220,15 @@ def test_non_finite_and_sub_floor_elements_have_defined_behaviour():
     assert bool(((out[ok_r][:, ok_c].double() - want).abs() <= bound).all())
 
 
+@pytest.mark.parametrize("form", ["", "8"])
 @pytest.mark.parametrize("n,K,H,with_c", [(4800, 512, 512, True), (16384, 512, 512, True), (300, 512, 512, True),
                                           (157, 64, 96, False), (1, 32, 32, True), (1100, 96, 64, True)])
-def test_cell_in_the_product_s_epilogue_equals_product_then_cell_kernel(n, K, H, with_c):
+def test_cell_in_the_product_s_epilogue_equals_product_then_cell_kernel(n, K, H, with_c, form, monkeypatch):
     """gvl_gemm_f16x3_lstm_f32 (attention half of the gate pre-activations with the LSTM cell applied to the finished tile,
     gate operands in the order 4 unit + gate; LSTM_DSA.py:216-217,267-269) against gvl_gemm_f16x3_f32 followed by
     gvl_lstm_cell_split_f32 in nn.LSTM's gate-major order: h', c' and the planes of h' bit for bit -- through every kernel
     form (persistent 256 x 128 / 128 x 128 tiles, four-wavefront tiles), ragged rows and unit counts."""
+    monkeypatch.setenv("GVL_LSTM_GEMM_FORM", form)          # "": four-wavefront kernel (default); "8": persistent eight-wavefront
     MSDA = _ops()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(n + H)
