@@ -349,7 +349,7 @@ class TeacherForcedLoop(torch.autograd.Function):
         w_hcat_t, w_att_t = w_hcat.t(), w_att.t()
         # GVL_SKINNY=own: the two products of a token through the latency-cut split-fp16 kernel
         # (gvl_skinny_gemm_f16x3_f32).  Off by default: measured 9.1 / 8.8 / 14.7 / 23.2 us per product in a dependent chain
-        # against 8.2 / 7.7 / 8.5 / 13.3 us of the tuned library kernels (train step 11.14 against 10.89 ms; DESIGN.md 4.19)
+        # against 8.2 / 7.7 / 8.5 / 13.3 us of the tuned library kernels (train step 11.14 against 10.89 ms; DESIGN.md 4.22)
         skinny = (split_gemm_enabled() and os.environ.get("GVL_SKINNY", "") == "own" and not torch.is_autocast_enabled()
                   and MSDA.skinny_gemm_eligible(h_all[0], W) and MSDA.skinny_gemm_eligible(att[0], H4)
                   and w_hcat.dtype == torch.float32 and gates_hs.stride(1) == 1)

@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
 //     (16 lanes per row), the weight planes from the TILED layout of k_skinny_pack (1 KB per 32 columns x 16 k, in MFMA
 //     operand order: the operand goes from global memory straight into the register the matrix core reads).  (A first
 //     version that loaded the activation in operand order -- 64 pieces of 16 bytes from 64 lines per instruction -- ran
-//     11 us where this one runs [see DESIGN.md 4.19]: the lines were evicted from the 32 KB L1 between the 8
+//     11 us where this one runs 9 us: the lines were evicted from the 32 KB L1 between the 8
 //     instructions that each used 1/8 of them.)  All loads of a wavefront are requested before the first one is used;
 //   * the activation is split in registers and transposed through a wavefront-private LDS image (64 rows x 64 k, two
 //     planes, 144-byte rows) into operand order;
