@@ -232,3 +232,29 @@ def test_graphed_eval_forward_without_criterion_or_targets():
         assert loss_g == {} and maxerr(out_g["pred_boxes"], out_e["pred_boxes"]) < 1e-5
         assert (len(out_g["seq"]) == 0 and len(out_e["seq"]) == 0) or torch.equal(out_g["seq"], out_e["seq"])
     assert len(ge.graphs) == 1 and ge.captures == 1
+
+
+def test_graphed_eval_forward_beyond_the_padded_capacity_falls_back_and_returns():
+    """a video with more events than queries (or more than 64) cannot use the padded layout
+    (GraphedEvalForward._use_padded); such a batch gets a layout-keyed graph, results still equal the eager forward, and
+    the next ordinary batch is served by the one padded graph again (no re-capture)."""
+    from gvl_amd.parallel import GraphedEvalForward
+    opt, model, crit, T = toy(False)                        # 8 queries
+    ge = GraphedEvalForward(model, crit, max_gt=8, decode_chunk=0)    # (capacity preset: no growth captures in between)
+    small = batches(T, seed=70)[:2]
+    big = synth_batch(2, T, 64, 40, [11, 2], DEV, seed=75, cap_words=(3, 5))          # 11 events > 8 queries
+    seen = []
+    for dt in (small[0], big, small[1], big):
+        with torch.no_grad():
+            out_e, loss_e = model(dt, crit, None, "queries", eval_mode=True)
+        out_g, loss_g = ge(dt)
+        for k in ("pred_logits", "pred_boxes", "pred_count"):
+            assert maxerr(out_g[k], out_e[k]) < 1e-5, k
+        assert torch.equal(out_g["seq"], out_e["seq"])
+        for k in loss_e:
+            a, b = float(loss_e[k]), float(loss_g[k])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) < 1e-5 * max(1.0, abs(a)), k
+        seen.append((ge.captures, sorted(k[0] for k in ge.graphs)))
+    # capture 1: padded graph; capture 2: the layout-keyed graph of the big batch; then both are replayed
+    assert [c for c, _ in seen] == [1, 2, 2, 2], seen
+    assert seen[-1][1] == ["layout", "padded"], seen
