@@ -113,7 +113,10 @@ class BaseEncoder(nn.Module):
             T = x.shape[-1]
             t_out = (T - 1) // 2 + 1
             xp = F.pad(x, (1, 1))
-            cols = torch.cat([xp[:, :, k:k + 2 * t_out:2] for k in range(3)], dim=1)      # (N, 3*C_in, T_out)
+            # taps k = 0, 1, 2 of every output frame as one strided view (unfold) and one copy: (N, 3*C_in, T_out) with
+            # row k * C_in + c -- what cat([xp[:, :, k::2]]) builds from three slices, whose backward is three zero-filled
+            # strided SliceBackward + two accumulations per level instead of one UnfoldBackward
+            cols = xp.unfold(2, 3, 2)[:, :, :t_out].permute(0, 3, 1, 2).reshape(x.shape[0], -1, t_out)
             y = torch.matmul(w.permute(0, 2, 1).reshape(w.shape[0], -1), cols)
         return norm(y + conv.bias[None, :, None])
 

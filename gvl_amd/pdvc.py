@@ -272,10 +272,12 @@ class PDVC(nn.Module):
         return probs, torch.zeros(N_, N_q, 3, device=hs.device)
 
     def _pack(self, hs, classes, counts, coords, cap_probs, seqs):
+        """the per-layer outputs under the reference's keys (pdvc.py:283-290 stacks the three prediction tensors and then
+        only ever indexes the stack by layer: the per-layer tensors themselves are kept instead -- no stack launch, and no
+        zero-filled SelectBackward + accumulation per layer and key in the train step)"""
         num_pred = hs.shape[0]
-        all_out = {'pred_logits': torch.stack(classes), 'pred_count': torch.stack(counts),
-                   'pred_boxes': torch.stack(coords), 'caption_probs': cap_probs, 'seq': seqs,
-                   'cl_match_mats': [0] * num_pred}
+        all_out = {'pred_logits': classes, 'pred_count': counts, 'pred_boxes': coords, 'caption_probs': cap_probs,
+                   'seq': seqs, 'cl_match_mats': [0] * num_pred}
         return all_out
 
     def parallel_prediction_full(self, dt, criterion, contrastive_criterion, hs, query_embed, init_reference,
