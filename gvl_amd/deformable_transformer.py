@@ -183,7 +183,7 @@ class DeformableTransformerDecoder(nn.Module):
                                            src_level_start_index, src_valid_ratios, query_pos, src_padding_mask,
                                            query_padding_mask, disable_iterative_refine)
         out = tgt
-        hs, refs = [], []
+        hs, refs, coords = [], [], []
         for lid, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 2:                                       # (centre, length): :302-304
                 ref_in = reference_points[:, :, None] * torch.stack([src_valid_ratios] * 2, -1)[:, None]
@@ -200,9 +200,13 @@ class DeformableTransformerDecoder(nn.Module):
                 else:
                     new_ref = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
                 reference_points = new_ref.detach()
+                coords.append(new_ref)
             if self.return_intermediate:
                 hs.append(out)
                 refs.append(reference_points)
+        # pdvc.py:452-474 applies the SAME box MLP to the same rows and adds the same inverse_sigmoid(reference): PDVC's
+        # heads take these (attached) results instead of repeating ~23 launches per layer (as the inference path does)
+        self.__dict__["_gvl_coords"] = coords if len(coords) == len(self.layers) else None
         if self.return_intermediate:
             return torch.stack(hs), torch.stack(refs)
         return out, reference_points

@@ -13,6 +13,8 @@ class_head.N, count_head.N, bbox_head.N.layers.K``) so reference checkpoints loa
 import copy
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -228,7 +230,10 @@ class PDVC(nn.Module):
         # and the refinement arithmetic to these very rows (deformable_transformer.py:314-324 and pdvc.py:452-474 share
         # `bbox_head[l_id]`): its results are taken over
         dec = self.transformer.decoder.__dict__
-        take = self.with_box_refine and not disable_refine and not torch.is_grad_enabled()
+        # (training: the decoder leaves the refined boxes of every layer WITH their autograd history; class head and deltas
+        #  are shared by the inference path only)
+        take = self.with_box_refine and not disable_refine and (
+            not torch.is_grad_enabled() or os.environ.get("GVL_SHARE_COORDS", "1") != "0")
         shared = {k: (dec.get("_gvl_" + k) if take else None) for k in ("cls", "coords", "deltas")}
         same = lambda t_: t_ is not None and t_[l_id].shape[:2] == hs_lid.shape[:2]          # noqa: E731
         cls = shared["cls"][l_id] if same(shared["cls"]) else self.class_head[l_id](hs_lid)
