@@ -157,8 +157,9 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # The reference discards the averaged attention map ([0] at pdvc/deformable_transformer.py:267-268).  Not asking for
         # it lets nn.MultiheadAttention take its fused attention path: measured 0.4 % of the eval step; in training the
         # fused forward + backward kernels are slower than bmm / softmax / bmm at this size (300 queries): +0.9 % of the step
-        sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask,
-                            need_weights=self.training)[0].transpose(0, 1)
+        # (average_attn_weights=False: the unfused path without the mean over the heads of a (B, 8, Q, Q) map nobody reads)
+        sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask, need_weights=self.training,
+                            average_attn_weights=False)[0].transpose(0, 1)
         tgt = self.norm2(tgt + self.dropout2(sa))
         ca = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_temporal_shapes,
                              level_start_index, src_padding_mask)
