@@ -231,7 +231,14 @@ class TrainStep:
         self.optimizer.step()
         for p, g in hidden:
             p.grad = g
-        return final.detach(), loss
+        return final.detach(), _detached(loss)
+
+
+def _detached(loss):
+    """the loss dict without its autograd history: the caller logs these values, and a captured step keeps them for its
+    whole life -- attached, they hold the step's graph nodes (the parameters' AccumulateGrad nodes among them) alive, and
+    the next capture, on another stream, records waits on those nodes' stream into its graph"""
+    return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in loss.items()}
 
 
 class _LRU(OrderedDict):
@@ -458,7 +465,7 @@ class GraphedTrainStep(TrainStep):
             self.model.memory_cut = None
         final.backward()
         self._cut = cut
-        return final.detach(), loss
+        return final.detach(), _detached(loss)
 
     def _backward_encoder(self):
         """stage 2: the gradient of the encoder output through the deformable encoder and the base encoder"""
