@@ -306,8 +306,9 @@ def main():
                     "regions (for rocprofv3 runs: the probes launch the same kernels at other sizes)")
     ap.add_argument("--no-graph", action="store_true", help="eager steps (no hipGraph replay)")
     ap.add_argument("--decode-chunk", type=int, default=5, help="tokens per captured decode segment (0: one graph)")
-    ap.add_argument("--cap-len-policy", default="grow", choices=["bucket", "grow"],
-                    help="train graphs: ONE at the widest caption width seen (default) or one per caption-width bucket of 4 tokens")
+    ap.add_argument("--cap-len-policy", default="bucket", choices=["bucket", "grow"],
+                    help="train graphs: one per caption-width bucket of 4 tokens (default: a batch pays the steps of its own "
+                         "longest caption) or ONE at the widest caption width seen")
     ap.add_argument("--split-exchange", action="store_true",
                     help="train on one GPU in the data-parallel form (three graphs + eager exchange points); diagnostic")
     ap.add_argument("--no-tuned-gemm", action="store_true",
@@ -493,7 +494,7 @@ def main():
                             "device_memory_reserved_GB": round(torch.cuda.memory_reserved() / 2 ** 30, 2),
                             "form": ("three graphs (forward + backward to the encoder output | encoder backward | clip + Adam) with "
                                      "the bucketed gradient exchange posted eagerly between them") if trainer.split
-                            else "one graph"}}
+                            else ("one graph per caption-width bucket" if trainer.capacity.cap_len_policy == "bucket" else "one graph")}}
 
     # ---------------------------------------------------------------------------------------------- the line
     src_note = ("per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region" if a.no_graph

@@ -339,7 +339,7 @@ class GraphedTrainStep(TrainStep):
 
     def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=2, split_exchange=None,
                  autocast_dtype=None, max_graphs=8, max_gt=0, max_cap_len=0, max_events=0, padded=None,
-                 cap_len_policy="grow"):
+                 cap_len_policy="bucket"):
         """split_exchange (default: exactly when there is more than one process): the step is captured as THREE graphs --
         (1) zero_grad + forward + losses + backward down to the encoder output, (2) the encoder's backward, (3) clip +
         Adam -- with the bucketed RCCL all-reduce issued eagerly between the replays, so no collective is ever inside a
@@ -350,11 +350,13 @@ class GraphedTrainStep(TrainStep):
         max_gt / max_cap_len / max_events: initial capacities of the padded layout -- events per video, caption tensor
         width, events per batch (0 = grow from the batches seen).
         padded: None = automatic, False = always one graph per batch layout.
-        cap_len_policy: "grow" (default) = ONE graph at the widest caption tensor seen (every batch pays the longest
-        caption's teacher-forced steps, but replays the same buffers every step); "bucket" = one graph per
-        caption-width bucket of 4 tokens, each batch replays the graph of its own bucket (fewer steps for short
-        captions, but the step alternates between several multi-GB memory pools: measured 11.8 vs 11.0 ms on one box
-        and 11.9 vs 12.8 ms on another at cfg A -- no clear winner, so the simpler form is the default)."""
+        cap_len_policy: "bucket" (default) = one graph per caption-width bucket of 4 tokens (<= 8 graphs at
+        max_caption_len = 30), each batch replays the graph of its own bucket and pays the teacher-forced steps of ITS longest
+        caption, as the reference loop does (LSTM_DSA.py:110-112); "grow" = ONE graph at the widest caption tensor seen
+        (every batch pays the longest caption's steps; 5.2 instead of 8.5 GB of graph pools at cfg A).  9.67 against 10.46
+        ms per step on the rotating workload.  (Rounds 2-3 measured the opposite, 11.8 against 11.0 ms: the captures after
+        the first recorded waits on the previous capture's still-alive autograd nodes -- TrainStep returned its loss values
+        attached -- and "bucket" replays exactly those later captures.)"""
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
         # data-parallel form: the backward is cut at the encoder output (`memory`).  Stage 1 (captioner, heads, decoder:
         # ~2/3 of the 100 MB of gradients) completes first; its buckets travel while stage 2 (deformable encoder, base
