@@ -15,6 +15,8 @@ module adds what a data-parallel run of the reference loop (train.py:385-409) ne
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -301,20 +303,21 @@ class _Capacity:
     whole batch, train only) = next multiple of 32 >= the largest event total seen.  A batch that does not fit raises
     the capacity and the step is captured again; in a steady run that happens a handful of times, then never."""
 
-    def __init__(self, slots=0, cap_len=0, pair_rows=0, cap_len_policy="grow"):
+    def __init__(self, slots=0, cap_len=0, pair_rows=0, cap_len_policy="grow", cap_len_step=4):
         self.slots, self.cap_len, self.pair_rows = int(slots or 0), int(cap_len or 0), int(pair_rows or 0)
-        self.cap_len_policy = cap_len_policy
+        self.cap_len_policy, self.cap_len_step = cap_len_policy, max(1, int(cap_len_step))
 
     def fit(self, dt, with_captions):
         n_gt, cap_len = needed_capacity(dt)
         self.slots = max(self.slots, round_up_pow2(n_gt, 4))
         if not with_captions:
             return self.slots, 0
-        bucket = 4 * ((max(cap_len, 2) + 3) // 4)
+        step = self.cap_len_step
+        bucket = step * ((max(cap_len, 2) + step - 1) // step)
         self.cap_len = max(self.cap_len, bucket)
         self.pair_rows = max(self.pair_rows, 32 * ((max(total_events(dt), 1) + 31) // 32))
-        # "bucket": the step runs at THIS batch's caption-width bucket (one graph per bucket of 4 tokens, <= 8 for
-        # max_caption_len = 30) instead of at the widest caption tensor seen so far -- the teacher-forced loop is serial in
+        # "bucket": the step runs at THIS batch's caption-width bucket (one graph per bucket of cap_len_step tokens)
+        # instead of at the widest caption tensor seen so far -- the teacher-forced loop is serial in
         # the caption length, so a batch of 10-word captions then pays 11 steps, not the 23 a 22-word batch once needed
         return self.slots, (bucket if self.cap_len_policy == "bucket" else self.cap_len)
 
@@ -338,8 +341,8 @@ class GraphedTrainStep(TrainStep):
     the RNG state exactly as they were (snapshot / restore), so every batch gets ONE update, as in train.py."""
 
     def __init__(self, model, criterion, opt, world_size=1, process_group=None, warmup=2, split_exchange=None,
-                 autocast_dtype=None, max_graphs=8, max_gt=0, max_cap_len=0, max_events=0, padded=None,
-                 cap_len_policy="bucket"):
+                 autocast_dtype=None, max_graphs=16, max_gt=0, max_cap_len=0, max_events=0, padded=None,
+                 cap_len_policy="bucket", cap_len_step=2):
         """split_exchange (default: exactly when there is more than one process): the step is captured as THREE graphs --
         (1) zero_grad + forward + losses + backward down to the encoder output, (2) the encoder's backward, (3) clip +
         Adam -- with the bucketed RCCL all-reduce issued eagerly between the replays, so no collective is ever inside a
@@ -350,11 +353,12 @@ class GraphedTrainStep(TrainStep):
         max_gt / max_cap_len / max_events: initial capacities of the padded layout -- events per video, caption tensor
         width, events per batch (0 = grow from the batches seen).
         padded: None = automatic, False = always one graph per batch layout.
-        cap_len_policy: "bucket" (default) = one graph per caption-width bucket of 4 tokens (<= 8 graphs at
-        max_caption_len = 30), each batch replays the graph of its own bucket and pays the teacher-forced steps of ITS longest
-        caption, as the reference loop does (LSTM_DSA.py:110-112); "grow" = ONE graph at the widest caption tensor seen
-        (every batch pays the longest caption's steps; 5.2 instead of 8.5 GB of graph pools at cfg A).  9.67 against 10.46
-        ms per step on the rotating workload.  (Rounds 2-3 measured the opposite, 11.8 against 11.0 ms: the captures after
+        cap_len_policy: "bucket" (default) = one graph per caption-width bucket of `cap_len_step` (2) tokens (<= 15 graphs at
+        max_caption_len = 30, hence max_graphs = 16: ~1.5 GB of pool each, spent from 288 GB to save serial token steps), each
+        batch replays the graph of its own bucket and pays the teacher-forced steps of ITS longest caption, as the reference
+        loop does (LSTM_DSA.py:110-112); "grow" = ONE graph at the widest caption tensor seen (every batch pays the longest
+        caption's steps; 5.2 GB of graph pool at cfg A).  Rotating workload: 10.46 ms per step with "grow", 9.67 with buckets
+        of 4, 9.50 of 2, 9.46 of 1.  (Rounds 2-3 measured the opposite, 11.8 against 11.0 ms: the captures after
         the first recorded waits on the previous capture's still-alive autograd nodes -- TrainStep returned its loss values
         attached -- and "bucket" replays exactly those later captures.)"""
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
@@ -373,7 +377,7 @@ class GraphedTrainStep(TrainStep):
         self._cut = None
         self.graphs = _LRU(max_graphs)
         self.capacity = _Capacity(round_up_pow2(max_gt, 4) if max_gt else 0, max_cap_len,
-                                  32 * ((max_events + 31) // 32) if max_events else 0, cap_len_policy)
+                                  32 * ((max_events + 31) // 32) if max_events else 0, cap_len_policy, cap_len_step)
         self.padded = padded
         self.captures = self.replays = 0
         # >= 1 real step must run before the capture (on a side stream): autograd's gradient accumulators, hipBLASLt

@@ -126,10 +126,15 @@ def test_graphed_train_step_capacity_grows_and_cache_is_bounded():
     assert len(g.graphs) == 1 and g.captures <= 4 and g.capacity.slots == 8
     # bucket policy: one graph per caption-width bucket of 4 tokens (widths 3..6 here -> buckets 4 and 8), each batch
     # replayed at its own bucket; growth of the grow-only capacities (slots, rows) drops the graphs it supersedes
-    gb = GraphedTrainStep(model, crit, opt, cap_len_policy="bucket")
+    gb = GraphedTrainStep(model, crit, opt, cap_len_policy="bucket", cap_len_step=4)
     for dt in bs + bs:
         gb(dt)
     assert len(gb.graphs) == 2 and {k[3] for k in gb.graphs} == {4, 8} and gb.replays == 2 * len(bs)
+    # the default: buckets of 2 tokens
+    gd = GraphedTrainStep(model, crit, opt)
+    for dt in bs + bs:
+        gd(dt)
+    assert gd.capacity.cap_len_policy == "bucket" and {k[3] for k in gd.graphs} <= {4, 6, 8} and len(gd.graphs) >= 2
     g2 = GraphedTrainStep(model, crit, opt, padded=False, max_graphs=3)
     for dt in bs:
         g2(dt)
