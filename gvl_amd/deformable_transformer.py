@@ -118,7 +118,9 @@ class DeformableTransformerEncoder(nn.Module):
             # inference: the layers' Linear / LayerNorm chain on the hand-written kernels of gvl_amd/layers.py
             return _layers.encoder_forward(self, src, temporal_shapes, level_start_index, valid_ratios, pos,
                                            padding_mask)
-        ref = self.get_reference_points(temporal_shapes, valid_ratios, device=src.device)
+        ref = getattr(valid_ratios, "_gvl_enc_ref", None)          # left by prepare_encoder_inputs (one launch, same bits)
+        if ref is None or ref.shape[:2] != src.shape[:2]:
+            ref = self.get_reference_points(temporal_shapes, valid_ratios, device=src.device)
         out = src
         for layer in self.layers:
             out = layer(out, pos, ref, temporal_shapes, level_start_index, padding_mask)
@@ -265,9 +267,10 @@ class DeformableTransformer(nn.Module):
         lvl_embed = self.level_embed.unbind(0)        # (one UnbindBackward instead of a zero-filled SelectBackward per level)
         lvl_pos = torch.cat([p.transpose(1, 2) + lvl_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
         temporal_shapes, level_start_index = make_level_tensors(lengths, src_flatten.device)
-        if (_layers.enabled() and mask_flatten.is_cuda and not torch.is_grad_enabled() and not self.no_encoder
-                and len(lengths) <= 8):
-            # inference: valid ratios and the encoder's reference points (:209-218) from the flat mask in ONE launch
+        if (_layers.enabled() and mask_flatten.is_cuda and not self.no_encoder and len(lengths) <= 8
+                and mask_flatten.dtype == torch.bool):
+            # valid ratios and the encoder's reference points (:209-218) from the flat mask in ONE launch (masks carry no
+            # gradient: the training forward takes the same kernel)
             starts = temporal_shapes._gvl_host_lengths[1]
             valid_ratios, ref = _layers.encoder_geometry(mask_flatten, lengths, starts)
             valid_ratios._gvl_enc_ref = ref
