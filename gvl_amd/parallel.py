@@ -219,7 +219,16 @@ class TrainStep:
                             cache_enabled=False):
             out, loss = self.model(dt, self.criterion, None, self.opt.transformer_input_type)
         wd = self.criterion.weight_dict
-        return sum(loss[k].float() * wd[k] for k in loss.keys() if k in wd), loss
+        keys = tuple(k for k in loss.keys() if k in wd)
+        if len(keys) > 2 and all(isinstance(loss[k], torch.Tensor) and loss[k].dim() == 0 and loss[k].is_cuda for k in keys):
+            # the weighted sum of train.py:403 (`sum(loss[k] * weight_dict[k] ...)`) as stack + dot: 2 launches forward and 1
+            # backward instead of a mul + add per loss term and their backward (30 launches for the 10 terms of cfg A)
+            cache = self.__dict__.setdefault("_loss_weights", {})
+            w = cache.get(keys)
+            if w is None or w.device != loss[keys[0]].device:
+                w = cache[keys] = torch.tensor([float(wd[k]) for k in keys], dtype=torch.float32, device=loss[keys[0]].device)
+            return torch.dot(torch.stack([loss[k].float() for k in keys]), w), loss
+        return sum(loss[k].float() * wd[k] for k in keys), loss
 
     def __call__(self, dt):
         self.buckets.zero()                                                    # optimizer.zero_grad(), flat
