@@ -113,6 +113,10 @@ class _VocabNLLFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         x2, weight, logits, lse, target, row_weight = ctx.saved_tensors
+        if getattr(ctx, "consumed", False):                 # the logits buffer now holds their gradient
+            raise RuntimeError("vocab_nll: backward runs once (the logits are overwritten by their gradient); "
+                               "GVL_VOCAB_NLL=torch keeps the log-prob formulation for retain_graph use")
+        ctx.consumed = True
         g = MSDA.ce_rows_backward_(logits, target, row_weight, grad_out.contiguous(), lse)     # (R, V), in place
         gx = g.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = g.t().mm(x2) if ctx.needs_input_grad[1] else None
