@@ -285,6 +285,57 @@ def timed_loop(step, batches, steps, warmup, world, dev):
     return elapsed, per_rank
 
 
+def self_launch(n, argv, timeout_s):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks the way the driver does --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the
+    same arguments>` -- as a CHILD job in its own process group, relay its stdout (rank 0's one JSON line) and return its
+    exit code.  The caller has not initialised the GPU and nothing here does (no exec of a process that has: the ranks
+    are fresh interpreters); a rank that fails makes the launcher exit non-zero, which is returned; a job that outlives
+    `timeout_s` is killed as a group and reported as 124; exit 0 without a JSON line is reported as 1."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    lines = []
+
+    def relay():
+        for ln in proc.stdout:
+            if ln.startswith("{"):
+                lines.append(ln)
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        print(f"bench.py: the {n} self-launched ranks did not finish within {timeout_s:.0f} s; killed", file=sys.stderr)
+        return 124
+    except KeyboardInterrupt:
+        os.killpg(proc.pid, signal.SIGTERM)
+        proc.wait()
+        return 130
+    t.join(timeout=10)
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: the self-launched job printed {len(lines)} JSON lines, expected 1", file=sys.stderr)
+        return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,8 +364,14 @@ def main():
                     help="train on one GPU in the data-parallel form (three graphs + eager exchange points); diagnostic")
     ap.add_argument("--no-tuned-gemm", action="store_true",
                     help="keep hipBLASLt's default kernel choice instead of gvl_amd/tunableop_mi355x.csv")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="seconds the self-launched ranks of `python bench.py --gpus N` (N > 1, no launcher) may take")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (no HIP call so far, and
+        # none below) -- it starts the ranks as a fresh child job and relays rank 0's line
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:], a.launch_timeout))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

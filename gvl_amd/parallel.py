@@ -522,9 +522,16 @@ class GraphedTrainStep(TrainStep):
         torch.cuda.set_rng_state(cuda_rng, self.params[0].device)
         torch.set_rng_state(cpu_rng)
 
-    def _capture(self, st):
+    def _capture(self, st, static_structure=True):
         """warm up on `st` (local work only: no collective, so ranks may capture at different times) and capture;
-        -> (graphs, outs).  Parameters / optimizer / RNG are restored afterwards: the capture records, it does not run."""
+        -> (graphs, outs).  Parameters / optimizer / RNG are restored afterwards: the capture records, it does not run.
+        static_structure: the step's autograd graph does not depend on the batch (the padded form: fixed-capacity target
+        and caption rows, masked where empty), so the set of parameters it never reaches is the same on every rank and
+        may be hidden from the captured clip + Adam.  A layout-keyed capture is made from THIS rank's batch -- a rank
+        whose batch has no events would hide the captioner's parameters while the others apply the averaged gradient --
+        so there every parameter stays visible: all ranks update all parameters from the all-reduced buffer and the
+        replicas stay identical (the set cannot be agreed inside _capture: captures happen at rank-dependent
+        times and must not contain a collective)."""
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -535,7 +542,7 @@ class GraphedTrainStep(TrainStep):
                     def fb():
                         self._forward_backward(st)
                         self._backward_encoder()
-                    if it == 0 and self.buckets.flat is not None:
+                    if it == 0 and self.buckets.flat is not None and static_structure:
                         # which parameters does this step's autograd graph reach?  (static per capture: the padded step
                         # has no data-dependent structure, the layout-keyed step is captured per layout)
                         unused = self.buckets.probe_unused(fb)
@@ -602,7 +609,7 @@ class GraphedTrainStep(TrainStep):
             try:
                 if entry is None:
                     st = GraphedTrainStep._static_copy(dt)
-                    graphs, outs = self._capture(st)
+                    graphs, outs = self._capture(st, static_structure=False)
                     entry = (graphs, st, outs)
                     self.graphs.store(key, entry)
             finally:

@@ -114,6 +114,29 @@ def test_graphed_train_step_one_graph_for_all_layouts(split):
         assert maxerr(sa[pa]["exp_avg"], sb[pb]["exp_avg"]) <= 1e-4 * max(1.0, float(sa[pa]["exp_avg"].abs().max()))
 
 
+def test_layout_keyed_capture_hides_no_parameter_from_the_update():
+    """a layout-keyed (padded=False) capture is made from THIS rank's batch; a batch without events never
+    reaches the captioner, and hiding "its" unused parameters from the captured clip + Adam would let the ranks of a
+    data-parallel job apply different updates.  In the data-parallel (split) form such a capture therefore hides nothing:
+    every parameter takes the step from the (all-reduced) flat gradient buffer, whatever the local batch looked like.  The
+    padded capture -- static structure, the same on every rank -- may hide what its autograd graph never reaches."""
+    from gvl_amd.parallel import GraphedTrainStep
+    opt, model, crit, T = toy(True)
+    bs = batches(T)
+    g = GraphedTrainStep(model, crit, opt, split_exchange=True, padded=False, max_graphs=4)
+    for dt in bs[:3]:                                       # incl. a batch with an event-less video
+        g(dt)
+        assert g.last_unused == [], [n for n, p in model.named_parameters() if any(p is u for u in g.last_unused)]
+    # every trainable parameter was stepped by the captured update (Adam's step counter advanced for all of them)
+    steps = {float(g.optimizer.state[p]["step"]) for p in g.params}
+    assert len(steps) == 1 and steps.pop() == 3.0
+    _, model2, crit2, _ = toy(True)
+    g2 = GraphedTrainStep(model2, crit2, opt, split_exchange=True, max_gt=8, max_cap_len=8, cap_len_policy="grow")
+    g2(bs[0])
+    g2(bs[1])
+    assert isinstance(g2.last_unused, list)                 # probed (possibly non-empty: rank-independent by construction)
+
+
 def test_graphed_train_step_capacity_grows_and_cache_is_bounded():
     """Without a preset capacity the padded layout grows with the batches seen (each growth = one new capture, the
     superseded graph is dropped); the fallback form (padded=False: one graph per layout) is LRU-bounded."""
