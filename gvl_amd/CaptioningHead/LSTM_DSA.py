@@ -72,8 +72,8 @@ class ShowAttendTellCore(nn.Module):
         A, H, E, Cf = self.att_hid_size, self.rnn_size, self.input_encoding_size, self.att_feat_size
         Rs = B * S
         mem = input_flatten.reshape(Rs, C)
-        am_mem = getattr(input_flatten, "_gvl_amax", None)
-        if am_mem is None or am_mem.numel() != Rs:
+        am_mem = L.amax_of(input_flatten, Rs)
+        if am_mem is None:
             am_mem, _ = L.row_absmax(mem)
         slab = torch.empty(B, S, Cf + A, device=mem.device, dtype=torch.float32)
         slab2 = slab.view(Rs, Cf + A)
@@ -84,8 +84,8 @@ class ShowAttendTellCore(nn.Module):
         L.linear(slab2[:, :Cf], L.cached(self, "ctx", [(self.ctx2att.weight, self.ctx2att.bias)]),
                  [L.seg(0, slab2[:, Cf:], am_v)])
         q = query.reshape(-1, query.shape[-1])
-        am_q = getattr(query, "_gvl_amax", None)
-        if am_q is None or am_q.numel() != q.shape[0]:
+        am_q = L.amax_of(query, q.shape[0])
+        if am_q is None:
             am_q, _ = L.row_absmax(q)
         K = self.n_levels * self.n_points
         ow = att.sampling_offsets.weight

@@ -118,7 +118,7 @@ class DeformableTransformerEncoder(nn.Module):
             # inference: the layers' Linear / LayerNorm chain on the hand-written kernels of gvl_amd/layers.py
             return _layers.encoder_forward(self, src, temporal_shapes, level_start_index, valid_ratios, pos,
                                            padding_mask)
-        ref = getattr(valid_ratios, "_gvl_enc_ref", None)          # left by prepare_encoder_inputs (one launch, same bits)
+        ref = _layers.enc_ref_of(valid_ratios)          # left by prepare_encoder_inputs (one launch, same bits)
         if ref is None or ref.shape[:2] != src.shape[:2]:
             ref = self.get_reference_points(temporal_shapes, valid_ratios, device=src.device)
         out = src
@@ -273,7 +273,7 @@ class DeformableTransformer(nn.Module):
             # gradient: the training forward takes the same kernel)
             starts = temporal_shapes._gvl_host_lengths[1]
             valid_ratios, ref = _layers.encoder_geometry(mask_flatten, lengths, starts)
-            valid_ratios._gvl_enc_ref = ref
+            valid_ratios._gvl_enc_ref = (ref, valid_ratios._version)
         else:
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         return src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos, mask_flatten
@@ -284,7 +284,7 @@ class DeformableTransformer(nn.Module):
         temporal_shapes, level_start_index = make_level_tensors(lengths, mask_flatten.device)
         starts = temporal_shapes._gvl_host_lengths[1]
         valid_ratios, ref = _layers.encoder_geometry(mask_flatten, lengths, starts)
-        valid_ratios._gvl_enc_ref = ref
+        valid_ratios._gvl_enc_ref = (ref, valid_ratios._version)
         return temporal_shapes, level_start_index, valid_ratios
 
     def forward_encoder(self, src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,

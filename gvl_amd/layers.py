@@ -142,6 +142,34 @@ def row_absmax(x, pos=None, want_x=True):
     return am, amp
 
 
+def tag_amax(t, am):
+    """leave the row maxima `am` of tensor `t` on it for the next consumer, valid for THIS version of the data: an
+    in-place edit of `t` (a mask, a scale, a user hook) bumps `t._version` and the consumer recomputes (a
+    stale, too-small maximum would scale a row's fp16 split out of range, silently)"""
+    t._gvl_amax = (am, t._version)
+    return t
+
+
+def amax_of(t, rows):
+    """the row maxima left by tag_amax, or None when absent / of another shape / `t` was written since"""
+    hit = getattr(t, "_gvl_amax", None)
+    if hit is None:
+        return None
+    am, version = hit
+    if am is None or am.numel() != rows or version != t._version:
+        return None
+    return am
+
+
+def enc_ref_of(valid_ratios):
+    """the encoder's reference points left on `valid_ratios` by prepare_encoder_inputs (one launch produces both), or
+    None when absent or `valid_ratios` was written since"""
+    hit = getattr(valid_ratios, "_gvl_enc_ref", None)
+    if hit is None or hit[1] != valid_ratios._version:
+        return None
+    return hit[0]
+
+
 class _Arena:
     """zero-initialised row-maximum vectors for the producers that use atomic max: ONE fill per forward"""
 
@@ -170,7 +198,11 @@ def _new(rows, cols, like):
 def _attn_ok(att, host_lengths, S):
     return (att.fused and att.pad_mode in ("zeros", "border") and host_lengths is not None
             and att.d_model // att.n_heads == 64 and att.n_levels * att.n_points == 16 and att.n_points == 4
-            and att.d_model % 64 == 0 and (S <= 600 or S - host_lengths[0][0] <= 600))
+            and att.d_model % 64 == 0 and (S <= 600 or S - host_lengths[0][0] <= 600)
+            # [sampling_offsets | attention_weights] must stay adjacent columns of the concatenated products after
+            # Weights' 128-row block padding (encoder: behind value_proj; decoder: the "proj" pair): other head counts
+            # take the PyTorch layers
+            and (att.n_heads * att.n_levels * att.n_points) % 128 == 0 and att.d_model % 128 == 0)
 
 
 def _plain(x):
@@ -247,7 +279,7 @@ def encoder_forward(enc, src, temporal_shapes, level_start_index, valid_ratios, 
     from .ops.modules.ms_deform_attn import temporal_shapes_2d
     B, S, C = src.shape
     R = B * S
-    ref = getattr(valid_ratios, "_gvl_enc_ref", None)                        # left by prepare_encoder_inputs
+    ref = enc_ref_of(valid_ratios)                        # left by prepare_encoder_inputs
     if ref is None or ref.shape[:2] != src.shape[:2]:
         ref = enc.get_reference_points(temporal_shapes, valid_ratios, device=src.device)      # (B, S, L, 1)
     shapes2d = temporal_shapes_2d(temporal_shapes, level_start_index)
@@ -265,7 +297,7 @@ def encoder_forward(enc, src, temporal_shapes, level_start_index, valid_ratios, 
                                (att.sampling_offsets.weight, att.sampling_offsets.bias),
                                (att.attention_weights.weight, att.attention_weights.bias)])
         value, proj = _new(R, C, x), _new(R, n_proj, x)
-        linear(x, w, [seg(0, value, am_x, rowmask=mask), seg(C, proj, am_xp, addend=posf is not None)], a2=posf,
+        linear(x, w, [seg(0, value, am_x, rowmask=mask), seg(w.starts[1], proj, am_xp, addend=posf is not None)], a2=posf,
                flags=_value_flags())
         o, am_o = _msda(att, value, proj, ref, shapes2d, level_start_index, B, S, arena)
         y = _new(R, C, x)
@@ -275,8 +307,7 @@ def encoder_forward(enc, src, temporal_shapes, level_start_index, valid_ratios, 
         if posf is None:
             am_xp = am_x
     memory = x.view(B, S, C)
-    memory._gvl_amax = am_x
-    return memory
+    return tag_amax(memory, am_x)
 
 
 # ---- decoder ------------------------------------------------------------------------------------------------------------
@@ -390,8 +421,8 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
     mem = src.reshape(Rs, C)
     if not mem.is_contiguous():
         mem = mem.contiguous()
-    am_mem = getattr(src, "_gvl_amax", None)
-    if am_mem is None or am_mem.numel() != Rs:
+    am_mem = amax_of(src, Rs)
+    if am_mem is None:
         am_mem, _ = row_absmax(mem)
     mask = src_padding_mask.reshape(Rs).contiguous().view(torch.uint8) if src_padding_mask is not None else None
     nl = len(dec.layers)
@@ -466,6 +497,6 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
     dec.__dict__["_gvl_cls"] = clss if ok and len(clss) == nl else None
     if dec.return_intermediate:
         hs_t = torch.stack(hs)
-        hs_t._gvl_amax = am_x
+        tag_amax(hs_t, am_x)
         return hs_t, torch.stack(refs)
     return out, reference_points

@@ -252,24 +252,18 @@ class PDVC(nn.Module):
                 coord = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
         return cls, cnt, coord
 
-    _NO_CAPTION = {}
-
-    @staticmethod
-    def _no_caption(hs):
+    def _no_caption(self, hs):
         """the placeholders of a layer without captioning (pdvc.py:476-479).  Inference: constants, built once per shape
-        (nobody writes them) instead of three zero fills per layer and forward."""
+        instead of three zero fills per layer and forward.  They belong to THIS model (captured eval graphs and earlier
+        output dicts alias them) and are never evicted; the set of (batch, queries) shapes a model sees is small."""
         N_, N_q = hs.shape[:2]
-        if not torch.is_grad_enabled() and hs.is_cuda and not torch.cuda.is_current_stream_capturing():
-            key = (N_, N_q, str(hs.device))
-            hit = PDVC._NO_CAPTION.get(key)
-            if hit is None:
-                if len(PDVC._NO_CAPTION) > 16:
-                    PDVC._NO_CAPTION.clear()
-                hit = PDVC._NO_CAPTION[key] = (torch.zeros(1, device=hs.device), torch.zeros(N_, N_q, 3, device=hs.device),
-                                               torch.zeros(N_, N_q, 3, device=hs.device))
-            return {'cap_prob_train': hit[0], 'cap_prob_eval': hit[1]}, hit[2]
         if not torch.is_grad_enabled() and hs.is_cuda:
-            hit = PDVC._NO_CAPTION.get((N_, N_q, str(hs.device)))
+            cache = self.__dict__.setdefault("_no_caption_consts", {})
+            key = (N_, N_q, str(hs.device))
+            hit = cache.get(key)
+            if hit is None and not torch.cuda.is_current_stream_capturing():
+                hit = cache[key] = (torch.zeros(1, device=hs.device), torch.zeros(N_, N_q, 3, device=hs.device),
+                                    torch.zeros(N_, N_q, 3, device=hs.device))
             if hit is not None:                       # (capturing: constants created by the warm-up run are reused)
                 return {'cap_prob_train': hit[0], 'cap_prob_eval': hit[1]}, hit[2]
         probs = {'cap_prob_train': torch.zeros(1, device=hs.device),
@@ -293,7 +287,8 @@ class PDVC(nn.Module):
             reference = init_reference if l_id == 0 else inter_references[l_id - 1]
             hs_lid = hs[l_id]
             if l_id == num_pred - 1 and getattr(hs, "_gvl_amax", None) is not None:
-                hs_lid._gvl_amax = hs._gvl_amax          # row maxima of the last layer's rows (gvl_amd/layers.py)
+                hs_lid._gvl_amax = hs._gvl_amax          # row maxima of the last layer's rows (gvl_amd/layers.py); a view
+                #                                          shares its base's version counter, so the tag stays checkable
             cls, cnt, coord = self._layer_heads(l_id, hs_lid, reference, disable_iterative_refine)
             hs_cap = torch.cat([hs_lid, query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
                                                                                     False) else hs_lid

@@ -68,3 +68,23 @@ def test_round3_token_loop_entry_points_are_declared_and_exported():
     assert perm.tolist() == [0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8, 11]                             # row g * H + u at 4 * u + g
     w = torch.arange(12.0)[:, None]
     assert torch.equal(w[perm].view(3, 4), torch.tensor([[0.0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]]))
+
+
+def test_row_maxima_tag_is_dropped_after_an_in_place_write():
+    """row maxima ride on the producing tensor only for the version of the data they were computed from"""
+    import torch
+    from gvl_amd.layers import tag_amax, amax_of, enc_ref_of
+    x = torch.randn(6, 8)
+    am = x.abs().amax(1)
+    tag_amax(x, am)
+    assert amax_of(x, 6) is am and amax_of(x, 5) is None
+    view = x[:]                                   # a view shares the version counter: the tag can be handed over
+    view._gvl_amax = x._gvl_amax
+    assert amax_of(view, 6) is am
+    x.mul_(4.0)                                   # a mask / scale / hook between producer and consumer
+    assert amax_of(x, 6) is None and amax_of(view, 6) is None
+    vr = torch.ones(2, 4)
+    vr._gvl_enc_ref = (torch.zeros(2, 3, 4, 1), vr._version)
+    assert enc_ref_of(vr) is not None
+    vr[0, 0] = 0.5
+    assert enc_ref_of(vr) is None and enc_ref_of(torch.ones(2, 4)) is None
