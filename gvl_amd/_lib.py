@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 8          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 9          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -20,6 +20,7 @@ SIGNATURES = {
     "gvl_last_error": (ctypes.c_char_p, []),
     "gvl_msda_set_impl": (None, [_I]),
     "gvl_msda_last_impl": (_I, []),
+    "gvl_msda_last_kernel": (ctypes.c_char_p, []),
     "gvl_msda_forward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_msda_forward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_msda_sample_f32": (_I, [_P] * 4 + [_I] * 8 + [_P, _P]),

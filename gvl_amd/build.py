@@ -28,17 +28,42 @@ def needs_build():
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 
+def _deps(src):
+    return [src, os.path.join(ROOT, "include", "gvl_msda.h"), __file__, os.path.join(HERE, "csrc", "gvl_common.hpp"),
+            os.path.join(HERE, "csrc", "gvl_gemm16_common.hpp")]
+
+
 def build(force=False, verbose=False, save_temps=None):
+    """one object per source file under build/obj (only the stale ones are recompiled, up to 8 at a time), then one link"""
     if not force and not needs_build():
         return OUT
     srcs = [s for s in SRC if os.path.exists(s)]
-    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", OUT] + srcs
+    cc = hipcc()
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
     if save_temps:
         os.makedirs(save_temps, exist_ok=True)
-        cmd += [f"-save-temps={save_temps}", "-Rpass-analysis=kernel-resource-usage"]
+    cflags = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if (not force and os.path.exists(obj)
+                and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src) if os.path.exists(d))):
+            return obj
+        cmd = [cc] + cflags + ["-o", obj, src]
+        if save_temps:
+            cmd += [f"-save-temps={save_temps}", "-Rpass-analysis=kernel-resource-usage"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=save_temps or ROOT)
+        return obj
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=save_temps or ROOT)
+    subprocess.check_call(cmd, cwd=ROOT)
     return OUT
 
 

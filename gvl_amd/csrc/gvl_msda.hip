@@ -36,6 +36,7 @@ using gvl::fail;
 using gvl::ensure_lds;
 
 thread_local int g_last_impl = 0;
+thread_local const char *g_last_kernel = "";     // kernel form of the most recent launch (gvl_msda_last_kernel)
 unsigned long long *g_fwd_stamps = nullptr, *g_bwd_stamps = nullptr;   // diagnostics, see gvl_msda_debug_stamps
 int g_impl = -1;  // -1 = read the environment on first use
 
@@ -462,6 +463,17 @@ __device__ inline void resolve_ops(const RawOps &r, float invT, float invP, int 
   }
 }
 
+// (b,m) slab of a workgroup.  Workgroups go to the 8 XCDs round-robin (id % 8), each XCD with its own L2.  The per-head
+// pieces of the fused operands -- proj (B*Q, 2*M*16): 64 B of offsets and 64 B of logits per (query, head) -- are HALF a
+// 128-byte line, the other half belonging to the next head: with heads on different XCDs every line is fetched by two L2s
+// and half of each fetch is unused (PMC: proj traffic = 2x its bytes).  The map below puts the heads (2k, 2k + 1) of a video
+// on the same XCD; both workgroups of a slab (ids B*M apart) stay together as before.  Identity when B*M % 16 != 0.
+__device__ inline int slab_of_block(int idx, int BM) {
+  if (BM & 15) return idx;
+  const int xcd = idx & 7, slot = idx >> 3;
+  return 2 * ((slot >> 1) * 8 + xcd) + (slot & 1);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
 // ------------------------------------------------------------------------------------------------------
@@ -480,7 +492,9 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   // diagnostics (gvl_msda_debug_stamps): 100 MHz wall-clock stamps per workgroup {start, slab staged, loop done}
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
   const int BM = B * M;
-  const int bm = blockIdx.x % BM, chunk = blockIdx.x / BM;
+  // (nchunk < 0: diagnostic A/B switch GVL_MSDA_XCD_PAIRS=0 -- the plain id -> slab map)
+  const int bm = nchunk < 0 ? (int)(blockIdx.x % BM) : slab_of_block(blockIdx.x % BM, BM), chunk = blockIdx.x / BM;
+  nchunk = nchunk < 0 ? -nchunk : nchunk;
   const int b = bm / M, m = bm % M;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -626,6 +640,44 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 // left (the row is private to the workgroup); only when a (b,m) slab is shared by several workgroups (B*M < 256) do
 // partial slabs + k_sum_partials remain, one per workgroup.
 // ------------------------------------------------------------------------------------------------------
+// Gather steps of the backward's phase 3: list elements S0.. of a 16-entry batch `tc` = (LDS byte offset of the query's
+// grad_out row, coefficient) per lane; each step broadcasts one element over the DPP row, reads the row (one conflict-free
+// ds_read_b128 per lane) and accumulates.  The reads of a group are requested TOGETHER and consumed afterwards: written
+// step by step the compiler waits for every read before it issues the next (one LDS round trip per step).
+template <int S0>
+__device__ inline void gather4(const f2v tc, const char *G_b, int lane_off, f2v &a01, f2v &a23) {
+  const f2v t0 = row_bcast_f2<S0>(tc), t1 = row_bcast_f2<S0 + 1>(tc), t2 = row_bcast_f2<S0 + 2>(tc),
+            t3 = row_bcast_f2<S0 + 3>(tc);
+  const float4 g0 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t0.x) + lane_off);
+  const float4 g1 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t1.x) + lane_off);
+  const float4 g2 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t2.x) + lane_off);
+  const float4 g3 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t3.x) + lane_off);
+#define GVL_ACC(T, G)                                                           \
+  {                                                                             \
+    const f2v cf = __builtin_shufflevector(T, T, 1, 1);                         \
+    a01 = __builtin_elementwise_fma(cf, (f2v){G.x, G.y}, a01);                  \
+    a23 = __builtin_elementwise_fma(cf, (f2v){G.z, G.w}, a23);                  \
+  }
+  GVL_ACC(t0, g0) GVL_ACC(t1, g1) GVL_ACC(t2, g2) GVL_ACC(t3, g3)
+}
+template <int S0>
+__device__ inline void gather8(const f2v tc, const char *G_b, int lane_off, f2v &a01, f2v &a23) {
+  const f2v t0 = row_bcast_f2<S0>(tc), t1 = row_bcast_f2<S0 + 1>(tc), t2 = row_bcast_f2<S0 + 2>(tc),
+            t3 = row_bcast_f2<S0 + 3>(tc), t4 = row_bcast_f2<S0 + 4>(tc), t5 = row_bcast_f2<S0 + 5>(tc),
+            t6 = row_bcast_f2<S0 + 6>(tc), t7 = row_bcast_f2<S0 + 7>(tc);
+  const float4 g0 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t0.x) + lane_off);
+  const float4 g1 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t1.x) + lane_off);
+  const float4 g2 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t2.x) + lane_off);
+  const float4 g3 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t3.x) + lane_off);
+  const float4 g4 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t4.x) + lane_off);
+  const float4 g5 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t5.x) + lane_off);
+  const float4 g6 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t6.x) + lane_off);
+  const float4 g7 = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t7.x) + lane_off);
+  GVL_ACC(t0, g0) GVL_ACC(t1, g1) GVL_ACC(t2, g2) GVL_ACC(t3, g3)
+  GVL_ACC(t4, g4) GVL_ACC(t5, g5) GVL_ACC(t6, g6) GVL_ACC(t7, g7)
+#undef GVL_ACC
+}
+
 constexpr int kBwdThreads = 1024;
 constexpr int kEntStride = 16;       // entry slot = q_local * 16 + sample
 
@@ -668,7 +720,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
   int *sorted = reinterpret_cast<int *>(ent_hi + qper * kEntStride);
 
   const int BM = B * M;
-  const int bm = blockIdx.x % BM, wgc = blockIdx.x / BM;
+  const int bm = slab_of_block(blockIdx.x % BM, BM), wgc = blockIdx.x / BM;
   const int b = bm / M, m = bm % M;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -890,23 +942,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
         const int e = sorted[first ? a1 + i : a0 + (i - n1)];
         tc = (f2v){__builtin_bit_cast(float, (e & ~15) << 4), first ? ent_lo[e] : ent_hi[e]};
       }
-#define GVL_GATHER_STEP(SI)                                                                            \
-  {                                                                                                    \
-    const f2v t2 = row_bcast_f2<SI>(tc);                                                               \
-    const float4 gq = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t2.x) + lane_off); \
-    const f2v cf = __builtin_shufflevector(t2, t2, 1, 1);                                              \
-    a01 = __builtin_elementwise_fma(cf, (f2v){gq.x, gq.y}, a01);                                       \
-    a23 = __builtin_elementwise_fma(cf, (f2v){gq.z, gq.w}, a23);                                       \
-  }
-      GVL_GATHER_STEP(0) GVL_GATHER_STEP(1) GVL_GATHER_STEP(2) GVL_GATHER_STEP(3)
-      if (n - base > 4) {
-        GVL_GATHER_STEP(4) GVL_GATHER_STEP(5) GVL_GATHER_STEP(6) GVL_GATHER_STEP(7)
-      }
-      if (n - base > 8) {
-        GVL_GATHER_STEP(8) GVL_GATHER_STEP(9) GVL_GATHER_STEP(10) GVL_GATHER_STEP(11)
-        GVL_GATHER_STEP(12) GVL_GATHER_STEP(13) GVL_GATHER_STEP(14) GVL_GATHER_STEP(15)
-      }
-#undef GVL_GATHER_STEP
+gather4<0>(tc, G_b, lane_off, a01, a23);
+      if (n - base > 4) gather4<4>(tc, G_b, lane_off, a01, a23);
+      if (n - base > 8) gather8<8>(tc, G_b, lane_off, a01, a23);
     }
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
     if (touch) {
@@ -967,7 +1005,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   int *sorted = reinterpret_cast<int *>(ent_hi + nent);
 
   const int BM = B * M;
-  const int bm = blockIdx.x % BM, g = blockIdx.x / BM;                 // g in {0, 1}
+  const int bm = slab_of_block(blockIdx.x % BM, BM), g = blockIdx.x / BM;   // g in {0, 1}
   const int b = bm / M, m = bm % M;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1205,21 +1243,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
     }
     return tc;
   };
-#define GVL_GATHER_STEP(SI)                                                                            \
-  {                                                                                                    \
-    const f2v t2 = row_bcast_f2<SI>(tc);                                                               \
-    const float4 gq = *reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, t2.x) + lane_off); \
-    const f2v cf = __builtin_shufflevector(t2, t2, 1, 1);                                              \
-    a01 = __builtin_elementwise_fma(cf, (f2v){gq.x, gq.y}, a01);                                       \
-    a23 = __builtin_elementwise_fma(cf, (f2v){gq.z, gq.w}, a23);                                       \
-  }
 #define GVL_GATHER_BATCH(LEFT)                                                                         \
-  GVL_GATHER_STEP(0) GVL_GATHER_STEP(1) GVL_GATHER_STEP(2) GVL_GATHER_STEP(3)                          \
-  if ((LEFT) > 4) { GVL_GATHER_STEP(4) GVL_GATHER_STEP(5) GVL_GATHER_STEP(6) GVL_GATHER_STEP(7) }       \
-  if ((LEFT) > 8) {                                                                                    \
-    GVL_GATHER_STEP(8) GVL_GATHER_STEP(9) GVL_GATHER_STEP(10) GVL_GATHER_STEP(11)                      \
-    GVL_GATHER_STEP(12) GVL_GATHER_STEP(13) GVL_GATHER_STEP(14) GVL_GATHER_STEP(15)                    \
-  }
+  gather4<0>(tc, G_b, lane_off, a01, a23);                                                             \
+  if ((LEFT) > 4) gather4<4>(tc, G_b, lane_off, a01, a23);                                             \
+  if ((LEFT) > 8) gather8<8>(tc, G_b, lane_off, a01, a23);
   for (;;) {
     int u = 0;
     if (lane == 0) u = atomicAdd(&next_blk_s, 1);
@@ -1265,10 +1292,403 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
     }
   }
 #undef GVL_GATHER_BATCH
-#undef GVL_GATHER_STEP
   if (stamps) {                                                          // diagnostics only: gather done (before the store drain)
     __syncthreads();
     if (threadIdx.x == 0) stamps[(1024 + blockIdx.x) * 4] = wall_clock64();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// t1d_d64 backward, ROW-OWNERSHIP form -- the level-split idea for slabs whose queries do NOT fit one LDS carve-up (long
+// videos: T = 512 gives S = 960 rows and, in the encoder, 960 queries per slab).  The query-chunked form above keeps a
+// workgroup-private fp32 partial slab in HBM and read-modify-writes it once per query chunk, then k_sum_partials adds the
+// two workgroups' slabs: 4.0x (fp32) / 4.9x (bf16) the algorithmic bytes at T = 512 (profiles/r03_pmc_traffic.json).
+// Here the two workgroups of a (b,m) slab split the OUTPUT as in k_bwd_t1d_split -- workgroup g owns the grad_value rows
+// of two pyramid levels ({0,3} / {1,2}: the same number of samples) -- and a wavefront keeps the fp32 accumulators of ITS
+// rows in registers for the whole kernel: every row is written once, final, in the storage type; no workspace, no second
+// kernel.  Two phases:
+//   A  the workgroup's half of the queries: coefficients, the 16 sample steps against the LDS slab (L0G: level 0 read
+//      from global memory / L2, its eight row loads requested before the twelve LDS steps run), reduce-scatter,
+//      grad_loc / grad_attn or the fused softmax / location epilogue.  No entries are kept.
+//   B  ALL queries of the slab, in chunks of `qc`: the chunk's grad_out rows go to LDS (over the dead slab), operand
+//      fetch + coefficient arithmetic only (the "foreign pass" of the level-split kernel) yield the entries of the owned
+//      levels, counting sort by owned row, then the gather.  Rows are assigned STATICALLY: unit u = four adjacent owned
+//      rows (one per DPP row, in lockstep) belongs to wavefront u % 16, which visits its units in a fully unrolled loop so
+//      that unit i's accumulator is a fixed register quadruple across all chunks.  Fine and coarse units interleave over
+//      the wavefronts, so a window of rows that one chunk of neighbouring queries reaches is spread over all of them.
+// LDS: max(slab rows * 256, qc * (256 + 8 * 24) + histogram).  Eligibility: L = P = 4, two workgroups per slab, owned
+// rows <= 64 * kOwnNU per workgroup; the single-chunk cfg A case stays on k_bwd_t1d_split (dynamic units, one pass).
+// Semantics: /root/reference/pdvc/ops/src/cuda/ms_deform_im2col_cuda.cuh:407-511 (col2im: grad_value scatter, grad of
+// sampling locations and attention weights), arithmetic shared with the kernels above (coef_1d, resolve_ops).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kOwnNU = 10;           // units (4 rows) per wavefront: up to 640 owned rows per workgroup
+
+__host__ __device__ inline size_t bwd_own_lds_bytes(int rowsV, int n_own_max, int qc) {
+  const size_t a = (size_t)rowsV * 256;
+  const size_t b = (size_t)qc * 256 + (size_t)(n_own_max + 2) * 2 * sizeof(int) + (size_t)qc * 8 * 6 * sizeof(int);
+  return a > b ? a : b;
+}
+
+template <int PAD, bool FUSED, bool L0G, typename VT>
+__global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restrict__ value,
+                                                             const int64_t *__restrict__ shapes,
+                                                             const int64_t *__restrict__ lsi,
+                                                             const void *__restrict__ loc,
+                                                             const float *__restrict__ attn,
+                                                             const VT *__restrict__ gout, int B, int S, int M, int Q,
+                                                             int RD, int qc, VT *__restrict__ gvalue,
+                                                             void *__restrict__ gloc, float *__restrict__ gattn,
+                                                             unsigned long long *__restrict__ stamps, int dbg) {
+  constexpr int L = 4, P = 4, LP = 16;
+  extern __shared__ float4 slab4[];
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
+  const int BM = B * M;
+  const int g = blockIdx.x / BM;                                       // g in {0, 1}
+  const int bm = (dbg & 4) ? (int)(blockIdx.x % BM) : slab_of_block(blockIdx.x % BM, BM);
+  const int b = bm / M, m = bm % M;
+  const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lvl = j >> 2;
+  const int Tl = (int)shapes[2 * lvl + 1], st = (int)lsi[lvl];
+  const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
+  const int T0 = (int)shapes[1], s1 = (int)lsi[1], s2 = (int)lsi[2], s3 = (int)lsi[3];
+  const int row0 = L0G ? __builtin_amdgcn_readfirstlane(T0) : 0;
+  // ownership: levels {0,3} -> workgroup 0, {1,2} -> workgroup 1; owned index o: the fine level's rows, then the coarse one's
+  const int nF = g == 0 ? T0 : s2 - s1, nC = g == 0 ? S - s3 : s3 - s2;
+  const int sF = g == 0 ? 0 : s1, sC = g == 0 ? s3 : s2;
+  const int nOwn = nF + nC;
+  const bool mine = g == 0 ? (lvl == 0 || lvl == 3) : (lvl == 1 || lvl == 2);
+  const int k_own = g == 0 ? (lvl == 0 ? j : j - 8) : j - 4;
+  const int o_base = (g == 0 ? lvl == 0 : lvl == 1) ? 0 : nF;
+  const int qh = (Q + 1) / 2;
+  const int q0 = g * qh, q1 = max(q0, min(Q, q0 + qh));                 // phase A: own half of the queries
+  const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;                // this lane's channels of slab row 0 (global)
+
+  // ================================ phase A =====================================================================
+  {
+    int qb = q0 + wave * 4;
+    RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
+    float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qb < q1) {
+      const int64_t bqn = (int64_t)b * Q + min(qb + tq, q1 - 1);
+      r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+      if (qb + tq < q1) g_n = ld4(gout, (bqn * M + m) * 16 + j);
+    }
+    // slab rows [row0, S) -> LDS, four float4 per thread in flight
+    {
+      const int64_t src0 = ((int64_t)b * S * M + m) * 16;
+      const int nstage = (S - row0) * 16;
+      for (int base = threadIdx.x; base < nstage; base += 4 * blockDim.x) {
+        float4 pre[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = base + k * blockDim.x;
+          if (i < nstage) pre[k] = ld4(value, src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = base + k * blockDim.x;
+          if (i < nstage) slab4[i] = pre[k];
+        }
+      }
+      if (threadIdx.x < 16) slab4[nstage + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
+    if (dbg & 1) qb = q1;                                                  // diagnostics (GVL_MSDA_OWN_DEBUG): traffic of one phase alone
+    for (; qb < q1; qb += nw * 4) {
+      const int q = qb + tq;
+      const bool act = q < q1;
+      const int qq = act ? q : q1 - 1;
+      const int64_t tb = (((int64_t)b * Q + qq) * M + m) * LP;
+      const RawOps r = r_n;
+      const float4 gq = g_n;
+      const int qbn = qb + nw * 4;
+      if (qbn < q1) {
+        const int64_t bqn = (int64_t)b * Q + min(qbn + tq, q1 - 1);
+        r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+        g_n = (qbn + tq < q1) ? ld4(gout, (bqn * M + m) * 16 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float2 xy;
+      float w, dloc;
+      resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc);
+      const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
+      const int roff = st + c.r;
+      const float clo = c.c_lo * c.wy, chi = c.c_hi * c.wy;
+      const float dxlo = c.dx_lo * c.wy * w, dxhi = c.dx_hi * c.wy * w;
+      const float dylo = c.c_lo * c.dy * w, dyhi = c.c_hi * c.dy * w;
+      float p0[16], p1[16];
+      // L0G: the eight level-0 rows of this pass are requested first and consumed last -- the twelve LDS steps run
+      // while they travel
+      float4 v0g[4], v1g[4];
+      if (L0G) {
+#define GVL_OWN_G(SI)                                                         \
+  {                                                                           \
+    const int rr = row_bcast_i<SI>(roff);                                     \
+    v0g[SI] = ld4(value, vg + (int64_t)rr * (M * 16));                        \
+    v1g[SI] = ld4(value, vg + (int64_t)min(rr + 1, S - 1) * (M * 16));        \
+  }
+        GVL_OWN_G(0) GVL_OWN_G(1) GVL_OWN_G(2) GVL_OWN_G(3)
+#undef GVL_OWN_G
+      }
+      // the LDS steps in groups: the row reads of a group are requested together, then consumed (written step by step the
+      // compiler keeps one or two reads in flight and every sample pays most of an LDS round trip)
+#define GVL_OWN_PAIR(SI)                                                      \
+  {                                                                           \
+    const int ra = row_bcast_i<SI>(roff) - row0, rb = row_bcast_i<SI + 1>(roff) - row0; \
+    const float4 va0 = slab4[ra * 16 + j], va1 = slab4[ra * 16 + 16 + j];     \
+    const float4 vb0 = slab4[rb * 16 + j], vb1 = slab4[rb * 16 + 16 + j];     \
+    p0[SI] = dot4(gq, va0);                                                   \
+    p1[SI] = dot4(gq, va1);                                                   \
+    p0[SI + 1] = dot4(gq, vb0);                                               \
+    p1[SI + 1] = dot4(gq, vb1);                                               \
+  }
+#define GVL_OWN_QUAD(SI)                                                      \
+  {                                                                           \
+    const int ra = row_bcast_i<SI>(roff) - row0, rb = row_bcast_i<SI + 1>(roff) - row0; \
+    const int rc = row_bcast_i<SI + 2>(roff) - row0, rd = row_bcast_i<SI + 3>(roff) - row0; \
+    const float4 va0 = slab4[ra * 16 + j], va1 = slab4[ra * 16 + 16 + j];     \
+    const float4 vb0 = slab4[rb * 16 + j], vb1 = slab4[rb * 16 + 16 + j];     \
+    const float4 vc0 = slab4[rc * 16 + j], vc1 = slab4[rc * 16 + 16 + j];     \
+    const float4 vd0 = slab4[rd * 16 + j], vd1 = slab4[rd * 16 + 16 + j];     \
+    p0[SI] = dot4(gq, va0);                                                   \
+    p1[SI] = dot4(gq, va1);                                                   \
+    p0[SI + 1] = dot4(gq, vb0);                                               \
+    p1[SI + 1] = dot4(gq, vb1);                                               \
+    p0[SI + 2] = dot4(gq, vc0);                                               \
+    p1[SI + 2] = dot4(gq, vc1);                                               \
+    p0[SI + 3] = dot4(gq, vd0);                                               \
+    p1[SI + 3] = dot4(gq, vd1);                                               \
+  }
+      if (L0G) {                                                              // (32 registers hold the level-0 rows in flight)
+        GVL_OWN_PAIR(4) GVL_OWN_PAIR(6) GVL_OWN_PAIR(8) GVL_OWN_PAIR(10) GVL_OWN_PAIR(12) GVL_OWN_PAIR(14)
+      } else {
+        GVL_OWN_QUAD(0) GVL_OWN_QUAD(4) GVL_OWN_QUAD(8) GVL_OWN_QUAD(12)
+      }
+#undef GVL_OWN_PAIR
+#undef GVL_OWN_QUAD
+      if (L0G) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          p0[k] = dot4(gq, v0g[k]);
+          p1[k] = dot4(gq, v1g[k]);
+        }
+      }
+      const float d0 = row_reduce_scatter16(p0, j), d1 = row_reduce_scatter16(p1, j);
+      const float keep_w = fmaf(clo, d0, chi * d1);
+      const float keep_x = fmaf(dxlo, d0, dxhi * d1);
+      const float keep_y = fmaf(dylo, d0, dyhi * d1);
+      if (!FUSED) {
+        if (act) {
+          st_stream(gattn + tb + j, keep_w);                                     // cuh:156-157
+          st_stream(reinterpret_cast<float2 *>(gloc) + tb + j, make_float2(keep_x, keep_y));
+        }
+      } else {
+        const float dsum = row_allsum(w * keep_w);                               // softmax backward (ms_deform_attn.py:100-101)
+        const float glogit = w * (keep_w - dsum);
+        const float goff = keep_x * dloc;
+        float gr0 = keep_x, gr1 = keep_x * r.a * (0.5f * invP);
+        gr0 += dpp_f<0xB1>(gr0); gr0 += dpp_f<0x4E>(gr0);
+        gr1 += dpp_f<0xB1>(gr1); gr1 += dpp_f<0x4E>(gr1);
+        if (act) {
+          VT *grow = reinterpret_cast<VT *>(gloc) + ((int64_t)b * Q + qq) * (int64_t)(2 * M * LP);
+          grow[m * LP + j] = (VT)goff;
+          grow[M * LP + m * LP + j] = (VT)glogit;
+          if (gattn && (j & 3) == 0) {
+            float *gr = gattn + ((((int64_t)b * Q + qq) * M + m) * L + lvl) * RD;
+            gr[0] = gr0;
+            if (RD == 2) gr[1] = gr1;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();                                                       // the slab is dead from here on
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
+
+  // ================================ phase B =====================================================================
+  float4 *G4 = slab4;                                                    // [qc] grad_out rows of the chunk
+  int *cnt = reinterpret_cast<int *>(G4 + (size_t)qc * 16);              // [nOwn + 2] histogram over owned rows
+  int *off = cnt + (nOwn + 2);                                           // [nOwn + 2] exclusive prefix
+  int *ent_rp = off + (nOwn + 2);                                        // [qc * 8] owned row | slot << 12, or -1
+  float *ent_lo = reinterpret_cast<float *>(ent_rp + qc * 8);
+  float *ent_hi = ent_lo + qc * 8;
+  // the entries in row order, as the gather wants them: (LDS byte offset of the query's grad_out row, w c_lo, w c_hi) --
+  // one LDS round trip per list element instead of the id -> entry indirection
+  int *srt_q = reinterpret_cast<int *>(ent_hi + qc * 8);
+  float *srt_lo = reinterpret_cast<float *>(srt_q + qc * 8);
+  float *srt_hi = srt_lo + qc * 8;
+  __shared__ int wave_tot[kBwdThreads / 64];
+  __shared__ int carry_s;
+  f2v acc01[kOwnNU], acc23[kOwnNU];
+#pragma unroll
+  for (int i = 0; i < kOwnNU; ++i) acc01[i] = acc23[i] = (f2v){0.f, 0.f};
+  const char *G_b = reinterpret_cast<const char *>(G4);
+  const int lane_off = j * 16;
+
+  for (int c0 = (dbg & 2) ? Q : 0; c0 < Q; c0 += qc) {
+    const int c1 = min(Q, c0 + qc);
+    const int nq = c1 - c0;
+    // operands of the first pass are requested before the barrier that frees the LDS
+    int qb = c0 + wave * 4;
+    RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
+    float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qb < c1) {
+      const int64_t bqn = (int64_t)b * Q + min(qb + tq, c1 - 1);
+      r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+      if (qb + tq < c1) g_n = ld4(gout, (bqn * M + m) * 16 + j);
+    }
+    for (int i = threadIdx.x; i < nOwn + 2; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[(1024 + blockIdx.x) * 4 + 0] = wall_clock64();   // (the LAST chunk's phases)
+    // ---- coefficient pass: entries of the owned levels + the chunk's grad_out rows ---------------------------
+    for (; qb < c1; qb += nw * 4) {
+      const int q = qb + tq;
+      const bool act = q < c1;
+      const RawOps r = r_n;
+      const float4 gq = g_n;
+      const int qbn = qb + nw * 4;
+      if (qbn < c1) {
+        const int64_t bqn = (int64_t)b * Q + min(qbn + tq, c1 - 1);
+        r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+        g_n = (qbn + tq < c1) ? ld4(gout, (bqn * M + m) * 16 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float2 xy;
+      float w, dloc;
+      resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc);        // (FUSED: the softmax needs all 16 lanes of the row)
+      const Coef1D c = coef_1d<PAD>(xy.x, xy.y, Tl);
+      const float elo = c.c_lo * c.wy * w, ehi = c.c_hi * c.wy * w;
+      if (act) {
+        G4[(q - c0) * 16 + j] = gq;
+        if (mine) {
+          const int e = (q - c0) * 8 + k_own;
+          int rp = -1;
+          if (elo != 0.f || ehi != 0.f) {
+            const int o = o_base + c.r;
+            rp = o | (atomicAdd(&cnt[o], 1) << 12);
+            ent_lo[e] = elo;
+            ent_hi[e] = ehi;
+          }
+          ent_rp[e] = rp;
+        }
+      }
+    }
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[(1024 + blockIdx.x) * 4 + 1] = wall_clock64();
+    // ---- exclusive scan of the histogram, entry ids into row order ---------------------------------------------
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nOwn + 1; base += blockDim.x) {
+      const int i = base + threadIdx.x;
+      const int v = (i < nOwn + 1) ? cnt[i] : 0;
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t_ = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t_;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
+      __syncthreads();
+      int pre_ = carry_s;
+      for (int k = 0; k < wave; ++k) pre_ += wave_tot[k];
+      if (i < nOwn + 1) off[i] = pre_ + incl - v;
+      __syncthreads();
+      if (threadIdx.x == blockDim.x - 1) carry_s = pre_ + incl;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nOwn + 1] = carry_s;
+    for (int e = threadIdx.x; e < nq * 8; e += blockDim.x) {
+      const int rp = ent_rp[e];
+      if (rp >= 0) {
+        const int pos = off[rp & 4095] + (rp >> 12);
+        srt_q[pos] = (e >> 3) << 8;
+        srt_lo[pos] = ent_lo[e];
+        srt_hi[pos] = ent_hi[e];
+      }
+    }
+    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[(1024 + blockIdx.x) * 4 + 2] = wall_clock64();
+    // ---- gather: this wavefront's units, accumulators in registers ---------------------------------------------
+    // Units are static, so the chain  list bounds -> list elements -> grad_out rows  is software-pipelined ACROSS units:
+    // at the top of unit i the bounds of unit i + 2 are requested and, from the bounds requested one unit earlier, the
+    // first batch of unit i + 1; unit i's batches then run on operands that are already in registers.
+    struct Raw { int lo, mid, hi; };                                       // off[o - 1], off[o], off[o + 1]
+    struct Unit { int a1, n1, a0, n_own, n; };
+    // (all three loaders are branch-free -- clamped addresses, selects -- so that the compiler's wait counters stay exact
+    // across them: behind a conditional block it waits for EVERY outstanding LDS read, prefetches included)
+    auto raw_of = [&](int i) {
+      Raw r = {0, 0, 0};
+      if (i < kOwnNU) {                                                    // (compile-time after unrolling)
+        const int o = (wave + nw * i) * 4 + tq;
+        const bool live = o < nOwn;
+        const int oc = live ? o : 0;
+        const int lo = off[oc > 0 ? oc - 1 : 0], mid = off[oc], hi = off[oc + 1];
+        r.mid = mid;
+        r.hi = live ? hi : mid;
+        r.lo = (live && oc > 0) ? lo : mid;
+      }
+      return r;
+    };
+    auto unit_of = [&](const Raw &r) {
+      Unit u;
+      u.a1 = r.mid; u.n1 = r.hi - r.mid; u.a0 = r.lo;
+      u.n_own = r.hi - r.lo;                                               // entries with row == o (c_lo), then row == o - 1 (c_hi)
+      // longest list of the four rows: they run in lockstep (wave-uniform trip count, in a scalar register)
+      u.n = max(max(__builtin_amdgcn_readlane(u.n_own, 0), __builtin_amdgcn_readlane(u.n_own, 16)),
+                max(__builtin_amdgcn_readlane(u.n_own, 32), __builtin_amdgcn_readlane(u.n_own, 48)));
+      return u;
+    };
+    auto fetch_tc = [&](int i, const Unit &u) {
+      const bool valid = i < u.n_own, first = i < u.n1;
+      int pos = first ? u.a1 + i : u.a0 + (i - u.n1);
+      pos = valid ? pos : 0;
+      const float *cs = first ? srt_lo : srt_hi;
+      const int qo = srt_q[pos];
+      const float cf = cs[pos];
+      return (f2v){__builtin_bit_cast(float, valid ? qo : 0), valid ? cf : 0.f};
+    };
+#define GVL_GATHER_BATCH(LEFT)                                                                         \
+  gather4<0>(tc, G_b, lane_off, a01, a23);                                                             \
+  if ((LEFT) > 4) gather4<4>(tc, G_b, lane_off, a01, a23);                                             \
+  if ((LEFT) > 8) {                                                                                    \
+    gather4<8>(tc, G_b, lane_off, a01, a23);                                                           \
+    gather4<12>(tc, G_b, lane_off, a01, a23);                                                          \
+  }
+    Raw raw_n = raw_of(1);
+    Unit un = unit_of(raw_of(0));
+    f2v tcn = fetch_tc(j, un);
+#pragma unroll
+    for (int i = 0; i < kOwnNU; ++i) {
+      const Unit u = un;
+      f2v tc = tcn;
+      const Raw raw_nn = raw_of(i + 2);
+      un = unit_of(raw_n);
+      raw_n = raw_nn;
+      tcn = fetch_tc(j, un);
+      if (u.n > 0) {
+        f2v a01 = acc01[i], a23 = acc23[i];
+        for (int base = 0; base < u.n; base += 16) {
+          const f2v tc_next = fetch_tc(base + 16 + j, u);
+          GVL_GATHER_BATCH(u.n - base)
+          tc = tc_next;
+        }
+        acc01[i] = a01;
+        acc23[i] = a23;
+      }
+    }
+#undef GVL_GATHER_BATCH
+    __syncthreads();                                                      // the next chunk rewrites the LDS
+  }
+  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = wall_clock64();
+  // ---- every owned row leaves once, final, in the storage type -----------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < kOwnNU; ++i) {
+    const int o = (wave + nw * i) * 4 + tq;
+    if (o < nOwn) {
+      const int s = o < nF ? sF + o : sC + (o - nF);
+      st4_stream(gvalue, ((int64_t)b * S + s) * M * 16 + (int64_t)m * 16 + j,
+                 make_float4(acc01[i].x, acc01[i].y, acc23[i].x, acc23[i].y));
+    }
   }
 }
 
@@ -1363,9 +1783,11 @@ int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
   }
   if (int rc = ensure_lds(kern, lds)) return rc;
   g_last_impl = FUSED ? 3 : 2;
+  g_last_kernel = "k_fwd_t1d_d64";
   return gvl::launch(GVL_PROF_FWD_T1D, Q, B, FUSED ? "k_fwd_t1d_d64<fused>" : "k_fwd_t1d_d64", kern,
                      dim3(nchunk * B * M), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
-                     nchunk, out, g_fwd_stamps, reinterpret_cast<unsigned *>(amax_out));
+                     env_int("GVL_MSDA_XCD_PAIRS", 1) ? nchunk : -nchunk, out, g_fwd_stamps,
+                     reinterpret_cast<unsigned *>(amax_out));
 }
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
@@ -1392,6 +1814,27 @@ bool bwd_split_ok(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan
   return bwd_split_lds_bytes(S, (Q + 1) / 2) <= kLdsMax;
 }
 
+// row-ownership form (k_bwd_t1d_own): two workgroups per slab, L = P = 4, any number of query chunks, level 0 in LDS or
+// in global memory; -> queries per phase-B chunk, 0 = not eligible
+int bwd_own_chunk(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan, const int64_t *shapes_host) {
+  if (!env_int("GVL_MSDA_BWD_OWN", 1)) return 0;
+  if (L != 4 || P != 4 || !plan.ok || !shapes_host || Q < 2 || (256 + B * M - 1) / (B * M) != 2) return 0;
+  const int n0 = (int)(shapes_host[1] + shapes_host[7]), n1 = (int)(shapes_host[3] + shapes_host[5]);   // {0,3} | {1,2}
+  const int n_own = n0 > n1 ? n0 : n1;
+  if (n_own > 64 * kOwnNU) return 0;
+  const size_t budget = kLdsMax - 512;                                  // the kernel's static LDS (scan scratch) sits beside
+  if ((size_t)plan.rowsV * 256 > budget) return 0;
+  const size_t fixed = (size_t)(n_own + 2) * 2 * sizeof(int);
+  const int qc_max = (int)((budget - fixed) / (256 + 8 * 24));          // grad_out row + 8 entries x (record + sorted record)
+  if (qc_max < 64) return 0;
+  const int forced = env_int("GVL_MSDA_BWD_OWN_QC", 0);                   // tuning sweeps
+  if (forced > 0) return forced <= qc_max ? forced : qc_max;
+  const int nchunk = (Q + qc_max - 1) / qc_max;
+  int qc = ((Q + nchunk - 1) / nchunk + 63) / 64 * 64;                    // whole rounds of 16 wavefronts x 4 queries
+  if (qc > qc_max) qc = qc_max;
+  return qc;
+}
+
 // fp32 workspace the t1d_d64 backward needs: one partial slab per workgroup when a (b,m) slab is shared by several
 // workgroups, and always one fp32 slab set for bf16 storage (the gather accumulates and writes fp32; k_sum_partials
 // rounds once)
@@ -1404,7 +1847,8 @@ size_t bwd_workspace_bytes(int B, int S, int M, int nchunk, bool bf16, bool spli
 template <typename VT, bool FUSED>
 int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, const void *p0, const float *p1,
                 const VT *gout, int B, int S, int M, int L, int Q, int P, int RD, int pad, const SlabPlan &plan,
-                int nchunk, VT *gvalue, void *g0, float *g1, void *ws, size_t ws_bytes, hipStream_t st) {
+                int nchunk, const int64_t *shapes_host, VT *gvalue, void *g0, float *g1, void *ws, size_t ws_bytes,
+                hipStream_t st) {
   constexpr bool kBf16 = !std::is_same<VT, float>::value;
   const int qper = (Q + nchunk - 1) / nchunk;
   if (bwd_split_ok(B, S, M, L, P, Q, plan, nchunk)) {
@@ -1412,9 +1856,25 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
     const size_t lds = bwd_split_lds_bytes(S, qper);
     if (int rc = ensure_lds(kern, lds)) return rc;
     g_last_impl = FUSED ? 3 : 2;
+    g_last_kernel = "k_bwd_t1d_split";
     return gvl::launch(GVL_PROF_BWD_T1D, Q, B, FUSED ? "k_bwd_t1d_split<fused>" : "k_bwd_t1d_split", kern,
                        dim3(2 * B * M), dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M, Q, RD, qper,
                        gvalue, g0, g1, g_bwd_stamps);
+  }
+  if (const int qc = bwd_own_chunk(B, S, M, L, P, Q, plan, shapes_host)) {
+    decltype(&k_bwd_t1d_own<kPadZeros, FUSED, false, VT>) kern;
+    if (pad == kPadZeros)
+      kern = plan.l0g ? k_bwd_t1d_own<kPadZeros, FUSED, true, VT> : k_bwd_t1d_own<kPadZeros, FUSED, false, VT>;
+    else
+      kern = plan.l0g ? k_bwd_t1d_own<kPadBorder, FUSED, true, VT> : k_bwd_t1d_own<kPadBorder, FUSED, false, VT>;
+    const int n0 = (int)(shapes_host[1] + shapes_host[7]), n1 = (int)(shapes_host[3] + shapes_host[5]);
+    const size_t lds = bwd_own_lds_bytes(plan.rowsV, n0 > n1 ? n0 : n1, qc);
+    if (int rc = ensure_lds(kern, lds)) return rc;
+    g_last_impl = FUSED ? 3 : 2;
+    g_last_kernel = "k_bwd_t1d_own";
+    return gvl::launch(GVL_PROF_BWD_T1D, Q, B, FUSED ? "k_bwd_t1d_own<fused>" : "k_bwd_t1d_own", kern, dim3(2 * B * M),
+                       dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M, Q, RD, qc, gvalue, g0, g1,
+                       g_bwd_stamps, env_int("GVL_MSDA_OWN_DEBUG", 0));
   }
   const int ngroup = bwd_groups(B, M, nchunk);
   const size_t lds = bwd_lds_bytes(S, qper, plan.rowsV);
@@ -1451,6 +1911,7 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
       return rc;
   }
   g_last_impl = FUSED ? 3 : 2;
+  g_last_kernel = loop ? "k_bwd_t1d_d64<loop>" : "k_bwd_t1d_d64";
   return 0;
 }
 
@@ -1475,6 +1936,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   g_last_impl = 1;
+  g_last_kernel = "k_fwd_generic";
   return gvl::launch(GVL_PROF_FWD_GENERIC, Q, B, "k_fwd_generic", k_fwd_generic<T, false>, dim3((unsigned)blocks),
                      dim3(256), 0, st, value, shapes, lsi, loc, attn, B, S, M, D, L, Q, P, pad, out);
 }
@@ -1520,13 +1982,14 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   if (fast_ok && mode != 1) {
     if constexpr (sizeof(T) == 4)
       return run_bwd_t1d<float, false>((const float *)value, shapes, lsi, loc, (const float *)attn, (const float *)gout,
-                                       B, S, M, L, Q, P, 0, pad, plan, nchunk_f, (float *)gvalue, gloc, (float *)gattn,
-                                       ws, ws_bytes, st);
+                                       B, S, M, L, Q, P, 0, pad, plan, nchunk_f, shapes_host, (float *)gvalue, gloc,
+                                       (float *)gattn, ws, ws_bytes, st);
   }
   if (int rc = gvl::zero_fill(gvalue, gv_bytes, st)) return rc;
   int64_t blocks = (ntup + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;
   g_last_impl = 1;
+  g_last_kernel = "k_bwd_generic";
   return gvl::launch(GVL_PROF_BWD_GENERIC, Q, B, "k_bwd_generic", k_bwd_generic<T>, dim3((unsigned)blocks), dim3(256),
                      0, st, value, shapes, lsi, loc, attn, gout, B, S, M, D, L, Q, P, pad, gvalue, gloc, gattn);
 }
@@ -1573,7 +2036,7 @@ int fused_backward(const VT *value, const int64_t *shapes, const int64_t *lsi, c
   const int nchunk = plan.ok ? bwd_chunks(B, M, Q, S, plan.rowsV) : 0;
   if (nchunk <= 0) return fail(GVL_EINVAL, "gvl_msda1d_fused_backward: problem does not fit LDS");
   return run_bwd_t1d<VT, true>(value, shapes, lsi, proj, ref, grad_out, B, S, M, L, Q, P, RD, pad_mode, plan, nchunk,
-                               grad_value, grad_proj, grad_ref, workspace, workspace_bytes, st);
+                               shapes_host, grad_value, grad_proj, grad_ref, workspace, workspace_bytes, st);
 }
 
 }  // namespace
@@ -1584,6 +2047,7 @@ int gvl_msda_abi_version(void) { return GVL_MSDA_ABI_VERSION; }
 const char *gvl_last_error(void) { return gvl::g_err; }
 void gvl_msda_set_impl(int impl) { g_impl = (impl >= 0 && impl <= 2) ? impl : 0; }
 int gvl_msda_last_impl(void) { return g_last_impl; }
+const char *gvl_msda_last_kernel(void) { return g_last_kernel; }
 
 void gvl_msda_debug_stamps(void *device_buffer) {
   g_fwd_stamps = (unsigned long long *)device_buffer;
@@ -1646,7 +2110,9 @@ size_t gvl_msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int 
   const SlabPlan plan = slab_plan(S, L, P, shapes_host);
   if (!plan.ok) return 0;
   const int n = bwd_chunks(B, M, Q, S, plan.rowsV);
-  return n > 0 ? bwd_workspace_bytes(B, S, M, n, elem_bytes == 2, bwd_split_ok(B, S, M, L, P, Q, plan, n)) : 0;
+  if (n <= 0) return 0;
+  const bool direct = bwd_split_ok(B, S, M, L, P, Q, plan, n) || bwd_own_chunk(B, S, M, L, P, Q, plan, shapes_host) > 0;
+  return bwd_workspace_bytes(B, S, M, n, elem_bytes == 2, direct);
 }
 
 int gvl_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
@@ -1752,8 +2218,8 @@ int gvl_msda_backward_bf16(const uint16_t *value, const int64_t *shapes, const i
   const int nchunk = bwd_chunks(B, M, Q, S, plan.rowsV);
   if (nchunk <= 0) return fail(GVL_EINVAL, "gvl_msda_backward_bf16: problem does not fit LDS");
   return run_bwd_t1d<bf16_t, false>((const bf16_t *)value, shapes, lsi, loc, attn, (const bf16_t *)grad_out, B, S, M, L,
-                                    Q, P, 0, pad_mode, plan, nchunk, (bf16_t *)grad_value, grad_loc, grad_attn,
-                                    workspace, workspace_bytes, st);
+                                    Q, P, 0, pad_mode, plan, nchunk, shapes_host, (bf16_t *)grad_value, grad_loc,
+                                    grad_attn, workspace, workspace_bytes, st);
 }
 
 }  // extern "C"

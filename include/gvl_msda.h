@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 8   /* 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_skinny_gemm_f16x3_f32, gvl_skinny_pack_f16, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 9   /* 9: + gvl_msda_last_kernel (diagnostic); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_skinny_gemm_f16x3_f32, gvl_skinny_pack_f16, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -64,6 +64,10 @@ const char *gvl_last_error(void);
 void gvl_msda_set_impl(int impl);
 /* Which family the most recent forward/backward call on this thread used: 1 generic, 2 fast, 3 fused. */
 int gvl_msda_last_impl(void);
+/* Name of the kernel form the most recent forward/backward call on this thread launched ("k_fwd_t1d_d64",
+ * "k_bwd_t1d_split", "k_bwd_t1d_own", "k_bwd_t1d_d64", "k_bwd_t1d_d64<loop>", "k_fwd_generic", "k_bwd_generic"): lets a
+ * test assert WHICH backward form served a shape.  Static storage; no reference equivalent. */
+const char *gvl_msda_last_kernel(void);
 
 /* -- matcher cost matrix for ALL decoder layers in one launch: replaces the tensor-op sequence of
  *    HungarianMatcher.forward (pdvc/matcher.py:74-105 with misc/detr_utils/box_ops.py:8-47):

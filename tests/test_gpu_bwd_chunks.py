@@ -28,7 +28,7 @@ def MSDA():
     return m
 
 
-def _check(MSDA, dev, B, T, Q, pad, seed, oracle_rows=4):
+def _check(MSDA, dev, B, T, Q, pad, seed, oracle_rows=4, expect_kernel=None):
     from oracle import msda_oracle as O
     value, shapes, lsi, loc, aw, gout = make_inputs(B, T, 8, 64, Q, 4, seed=seed)
     args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
@@ -37,6 +37,9 @@ def _check(MSDA, dev, B, T, Q, pad, seed, oracle_rows=4):
         set_impl("fast")
         gv, gl, gw = MSDA.ms_deform_attn_backward(*args, g, 64, pad_mode=pad)
         assert last_impl() == "fast"
+        if expect_kernel:
+            from gvl_amd import _lib
+            assert _lib.lib().gvl_msda_last_kernel().decode() == expect_kernel
         set_impl("generic")
         rv, rl, rw = MSDA.ms_deform_attn_backward(*args, g, 64, pad_mode=pad)
     finally:
@@ -120,3 +123,103 @@ def test_fused_entry_point_with_chunks_matches_autograd_composition(ref_dim, dev
     assert maxerr(gv, v2.grad.cpu().numpy()) <= 1e-4 * scale(v2.grad.cpu().numpy())
     assert maxerr(gp, p2.grad.cpu().numpy()) <= 1e-4 * scale(p2.grad.cpu().numpy())
     assert maxerr(gr, r2.grad.cpu().numpy()) <= 1e-4 * scale(r2.grad.cpu().numpy())
+
+
+# ---- row-ownership form (k_bwd_t1d_own, round 4): two workgroups per slab, rows owned across query chunks -------------
+def last_kernel():
+    from gvl_amd import _lib
+    return _lib.lib().gvl_msda_last_kernel().decode()
+
+
+@pytest.mark.parametrize("T,Q", [(512, 300), (512, 960), (512, 777), (200, 375), (300, 450)])
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_row_ownership_backward_matches_generic_and_oracle(T, Q, pad, dev, MSDA):
+    """B*M = 128 (two workgroups per slab) with more queries than one LDS carve-up holds: every grad_value row is owned
+    by one wavefront across all query chunks and written once (no workspace, no k_sum_partials).  T = 512: level 0 read
+    from global memory, 1-3 chunks; T = 200 / 300: whole slab in LDS, 1-2 chunks, ragged last chunk / odd halves."""
+    from gvl_amd import _lib
+    _check(MSDA, dev, B=16, T=T, Q=Q, pad=pad, seed=1000 + T + Q, oracle_rows=2, expect_kernel="k_bwd_t1d_own")
+    from helpers import level_lengths
+    lens = level_lengths(T)
+    arr = (__import__("ctypes").c_int64 * 8)(*[v for x in lens for v in (1, x)])
+    assert _lib.lib().gvl_msda_backward_workspace_bytes(16, sum(lens), 8, 64, 4, Q, 4, 4, arr) == 0
+    assert _lib.lib().gvl_msda_backward_workspace_bytes(16, sum(lens), 8, 64, 4, Q, 4, 2, arr) == 0
+
+
+def test_row_ownership_forced_small_chunks(dev, MSDA, monkeypatch):
+    # 64 queries per chunk: 15 chunks over Q = 960, and a video count that gives B*M = 136 (not a multiple of 128)
+    monkeypatch.setenv("GVL_MSDA_BWD_OWN_QC", "64")
+    _check(MSDA, dev, B=17, T=512, Q=960, pad="zeros", seed=4242, oracle_rows=1, expect_kernel="k_bwd_t1d_own")
+
+
+def test_row_ownership_equals_the_chunked_form(dev, MSDA, monkeypatch):
+    """same inputs through k_bwd_t1d_own and through the query-chunked k_bwd_t1d_d64<loop> + k_sum_partials it replaces:
+    grad_loc / grad_attn bit-equal (same arithmetic), grad_value equal up to the summation order of a row's entries"""
+    value, shapes, lsi, loc, aw, gout = make_inputs(16, 512, 8, 64, 400, 4, seed=31)
+    args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
+    g = t(gout).to(dev)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GVL_MSDA_BWD_OWN", flag)
+        res[flag] = [x.cpu().numpy() for x in MSDA.ms_deform_attn_backward(*args, g, 64)]
+        assert last_kernel() == ("k_bwd_t1d_own" if flag == "1" else "k_bwd_t1d_d64<loop>")
+    assert maxerr(res["1"][0], res["0"][0]) <= 2e-5 * scale(res["0"][0])
+    assert np.array_equal(res["1"][1], res["0"][1]) and np.array_equal(res["1"][2], res["0"][2])
+
+
+@pytest.mark.parametrize("ref_dim", [1, 2])
+@pytest.mark.parametrize("T,Q", [(512, 300), (512, 960)])
+def test_row_ownership_fused_matches_autograd_composition(T, Q, ref_dim, dev, MSDA):
+    from gvl_amd.ops.functions.ms_deform_attn_func import MSDeformAttnFunction
+    from helpers import level_lengths
+    B, M, D, L, P = 16, 8, 64, 4, 4
+    lens = level_lengths(T)
+    S = sum(lens)
+    gen = torch.Generator(device="cpu").manual_seed(50 + ref_dim + Q)
+    value = torch.randn(B, S, M, D, generator=gen).to(dev)
+    proj = (torch.randn(B, Q, 2 * M * L * P, generator=gen) * 0.7).to(dev)
+    ref = torch.rand(B, Q, L, ref_dim, generator=gen).to(dev)
+    if ref_dim == 2:
+        ref[..., 1] = ref[..., 1] * 0.3 + 0.05
+    gout = torch.randn(B, Q, M * D, generator=gen).to(dev)
+    shapes = torch.tensor([(1, x) for x in lens], dtype=torch.long, device=dev)
+    lsi = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.long, device=dev)
+    gv, gp, gr = MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref, gout, L, P, need_ref_grad=True)
+    assert last_kernel() == "k_bwd_t1d_own"
+    v2, p2, r2 = value.clone().requires_grad_(), proj.clone().requires_grad_(), ref.clone().requires_grad_()
+    off = p2[..., :M * L * P].view(B, Q, M, L, P)
+    w = torch.softmax(p2[..., M * L * P:].view(B, Q, M, L * P), -1).view(B, Q, M, L, P)
+    T_l = torch.tensor(lens, dtype=torch.float32, device=dev)
+    if ref_dim == 1:                                     # ms_deform_attn.py:103-106
+        x = r2[:, :, None, :, None, 0] + off / T_l[None, None, None, :, None]
+    else:                                                # :107-109
+        x = r2[:, :, None, :, None, 0] + off / P * r2[:, :, None, :, None, 1] * 0.5
+    loc = torch.stack([x, torch.full_like(x, 0.5)], -1)
+    try:
+        set_impl("generic")                              # the reference side: generic kernels (pinned to the oracle)
+        out = MSDeformAttnFunction.apply(v2, shapes, lsi, loc, w, 64)
+        out.backward(gout)
+    finally:
+        set_impl("auto")
+    assert maxerr(gv, v2.grad.cpu().numpy()) <= 1e-4 * scale(v2.grad.cpu().numpy())
+    assert maxerr(gp, p2.grad.cpu().numpy()) <= 1e-4 * scale(p2.grad.cpu().numpy())
+    assert maxerr(gr, r2.grad.cpu().numpy()) <= 1e-4 * scale(r2.grad.cpu().numpy())
+
+
+@pytest.mark.parametrize("T,Q", [(512, 300), (512, 960)])
+def test_row_ownership_bf16_storage_equals_rounded_fp32(T, Q, dev, MSDA):
+    """bf16 storage through the same kernel: rows leave in bf16 directly (no fp32 partial slabs, no rounding pass);
+    grad_loc / grad_attn bit-equal to the fp32 kernel's, grad_value = round(fp32 result) up to entry order"""
+    BF = torch.bfloat16
+    value, shapes, lsi, loc, aw, gout = make_inputs(16, T, 8, 64, Q, 4, seed=T + Q + 5)
+    v_bf, g_bf = t(value).to(dev).to(BF), t(gout).to(dev).to(BF)
+    sh, ls, lc, w = (t(x).to(dev) for x in (shapes, lsi, loc, aw))
+    gv, gl, gw = MSDA.ms_deform_attn_backward(v_bf, sh, ls, lc, w, g_bf, 64)
+    assert last_kernel() == "k_bwd_t1d_own" and gv.dtype == BF
+    gv32, gl32, gw32 = MSDA.ms_deform_attn_backward(v_bf.float(), sh, ls, lc, w, g_bf.float(), 64)
+    assert last_kernel() == "k_bwd_t1d_own"
+    # grad_value: the same fp32 gather, but the order of one row's entries follows the integer LDS atomics (DESIGN 4.2):
+    # equal before rounding up to fp32 summation order, i.e. within one bf16 ulp, on a tiny fraction of the elements
+    assert maxerr(gv.float(), gv32) <= 2.0 ** -8 * scale(gv32.cpu().numpy())
+    assert float((gv != gv32.to(BF)).float().mean()) < 2e-3
+    assert torch.equal(gl, gl32) and torch.equal(gw, gw32)
