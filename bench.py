@@ -219,8 +219,12 @@ def cpu_baseline(model, opt, T, budget_s=30.0):
         probes[n] = run(2, False)
     threads = min(probes, key=probes.get)
     torch.set_num_threads(threads)
-    probe = run(1, True)                                       # one video with the captioner: sizes the sample
-    nvid = max(1, min(16, int(budget_s * 0.6 / 7.0 / max(probe, 1e-3))))
+    # BASELINE.md section 3 times 16 videos per iteration; the sample is only cut below that if 7 iterations of 16 videos
+    # would not fit the budget.  Sized from a WARMED 2-video run (the first call builds constants and is several times slower;
+    # sizing from it used to cut the sample to 10 videos on hosts that run 16 in a second)
+    run(2, True)
+    probe = run(2, True) / 2.0
+    nvid = max(1, min(16, int(budget_s / 7.0 / max(probe, 1e-3))))
     med, ts = median_of(nvid, True)
     nvid_nc = 16
     med_nc, ts_nc = median_of(nvid_nc, False)
@@ -440,7 +444,7 @@ def main():
     def instrumented(fn, n=6):
         """kernel stamps of `n` eager steps run right after a timed region whose steps were graph replays (the library
         launches nothing at replay time)"""
-        MSDA.profile_enable(True)
+        MSDA.profile_enable(not os.environ.get("GVL_BENCH_NO_STAMPS"))     # (dev switch: the same eager steps, launched plainly)
         for i in range(n):
             fn(batches[i % len(batches)])
         torch.cuda.synchronize()
@@ -517,6 +521,25 @@ def main():
                 del g3
             finally:
                 del os.environ["GVL_LAYERS"]
+            torch.cuda.empty_cache()
+
+        # ... and with BOTH switches off: every Linear on the fp32 library GEMMs (exact fp32 products, no split-fp16 operands
+        # anywhere) -- the number for a reader who does not accept 22-bit operands as fp32
+        if (_layers.enabled() and split_gemm_enabled() and a.dtype == "f32" and not a.no_graph and not a.no_captioner
+                and not a.no_probes):
+            os.environ["GVL_LAYERS"] = "torch"
+            os.environ["GVL_GEMM"] = "f32"
+            try:
+                g4 = GraphedEvalForward(model, criterion, autocast_dtype=ac, decode_chunk=a.decode_chunk)
+                for dt in batches:
+                    g4(dt)
+                el4, _ = timed_loop(g4, batches, a.steps, a.warmup, world, dev)
+                res["eval"]["strict_fp32_elapsed"] = el4
+                g4.graphs.clear()
+                del g4
+            finally:
+                del os.environ["GVL_LAYERS"]
+                del os.environ["GVL_GEMM"]
             torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------------------------------------- train half
@@ -655,6 +678,13 @@ def main():
                 "note": "same run, GVL_LAYERS=torch: encoder / decoder layers, base encoder and heads through PyTorch "
                         "(library fp32 GEMMs + ATen kernels) instead of gvl_amd/layers.py (gvl_linear_f16x3_f32 with fused "
                         "epilogues, gvl_layer_norm_rows_f32, gvl_mha_core_f32, ...); token loop unchanged"}
+        if "strict_fp32_elapsed" in e:
+            e4 = e["strict_fp32_elapsed"]
+            line["eval_strict_fp32"] = {
+                "value": round(world * B * a.steps / e4, 3), "unit": "videos/s", "ms_per_step": round(e4 * 1e3 / a.steps, 3),
+                "note": "same run, GVL_LAYERS=torch AND GVL_GEMM=f32: every Linear of the step an exact-fp32 library GEMM "
+                        "(hipBLASLt), no split-fp16 operands anywhere; the hand-written sampling / attention / criterion / "
+                        "matcher kernels (exact fp32 arithmetic) stay"}
         if "fp32_library_gemms_elapsed" in e:
             e2 = e["fp32_library_gemms_elapsed"]
             line["eval_with_fp32_library_gemms"] = {

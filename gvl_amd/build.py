@@ -43,7 +43,9 @@ def build(force=False, verbose=False, save_temps=None):
     os.makedirs(objdir, exist_ok=True)
     if save_temps:
         os.makedirs(save_temps, exist_ok=True)
-    cflags = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"]
+    # GVL_BUILD_DEFS="-DGVL_PHASE_TIMING": dev-only timing / ablation builds of single kernels (never the shipped library)
+    cflags = ([f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"]
+              + os.environ.get("GVL_BUILD_DEFS", "").split())
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

@@ -1396,7 +1396,16 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
     __syncthreads();
     if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
     if (dbg & 1) qb = q1;                                                  // diagnostics (GVL_MSDA_OWN_DEBUG): traffic of one phase alone
+#ifdef GVL_PHASE_TIMING   // dev build: cycles of the blocks of a pass (wave 0), summed over its passes
+    long long tacc[5] = {0, 0, 0, 0, 0};
+#define GVL_T(K) { const long long t_ = __builtin_amdgcn_s_memtime(); tacc[K] += t_ - tprev; tprev = t_; }
+#else
+#define GVL_T(K)
+#endif
     for (; qb < q1; qb += nw * 4) {
+#ifdef GVL_PHASE_TIMING
+      long long tprev = __builtin_amdgcn_s_memtime();
+#endif
       const int q = qb + tq;
       const bool act = q < q1;
       const int qq = act ? q : q1 - 1;
@@ -1417,6 +1426,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
       const float clo = c.c_lo * c.wy, chi = c.c_hi * c.wy;
       const float dxlo = c.dx_lo * c.wy * w, dxhi = c.dx_hi * c.wy * w;
       const float dylo = c.c_lo * c.dy * w, dyhi = c.c_hi * c.dy * w;
+      GVL_T(0)                                                               // operand hand-over + coefficients
       float p0[16], p1[16];
       // L0G: the eight level-0 rows of this pass are requested first and consumed last -- the twelve LDS steps run
       // while they travel
@@ -1474,7 +1484,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
           p1[k] = dot4(gq, v1g[k]);
         }
       }
+      GVL_T(1)                                                               // 16 sample steps: 32 row reads + 32 dot products
       const float d0 = row_reduce_scatter16(p0, j), d1 = row_reduce_scatter16(p1, j);
+      GVL_T(2)                                                               // two reduce-scatters
       const float keep_w = fmaf(clo, d0, chi * d1);
       const float keep_x = fmaf(dxlo, d0, dxhi * d1);
       const float keep_y = fmaf(dylo, d0, dyhi * d1);
@@ -1501,7 +1513,13 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
           }
         }
       }
+      GVL_T(3)                                                               // epilogue + stores
     }
+#ifdef GVL_PHASE_TIMING
+    if (stamps && threadIdx.x == 0)
+      for (int k_ = 0; k_ < 4; ++k_) stamps[(2048 + blockIdx.x) * 4 + k_] = tacc[k_];
+#endif
+#undef GVL_T
   }
   __syncthreads();                                                       // the slab is dead from here on
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
