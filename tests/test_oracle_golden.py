@@ -138,6 +138,29 @@ def test_torch_oracle_full_dimension_configs(name, seed, dt_seed, cap_len):
         assert torch.equal(torch.stack(idx[i]), t(f[f"match_{i}"]))
 
 
+def test_torch_oracle_headline_batch_of_16():
+    """the CPU restatement on the HEADLINE batch (B = 16 videos of cfgs/anet_tsp_ssvg.yml, different valid lengths, 0..10
+    events per video) against the reference's run (tests/golden/pdvc_anet_full_b16.npz).  The captioner is cut to its first
+    8 token steps here to keep the CPU suite short (all 30 are compared on the GPU path, tests/test_gpu_model.py)."""
+    f = load("pdvc_anet_full_b16")
+    sd = pdvc_state(f, seed=100)
+    dt = pdvc_dt(f, feat=int(f["feature_dim"]), seed=16)
+    with torch.no_grad():
+        out = R.pdvc_eval_forward(sd, dt, pad_mode="zeros", max_caption_len=8)
+    assert maxerr(out["pred_boxes"], f["pred_boxes"]) < 5e-4
+    assert maxerr(out["pred_logits"], f["pred_logits"]) < 5e-3
+    assert maxerr(out["pred_count"], f["pred_count"]) < 5e-3
+    seq, ref_seq = out["seq"].reshape(-1, out["seq"].shape[-1]), t(f["seq"].astype(np.int64)).reshape(-1, f["seq"].shape[-1])
+    n = min(seq.shape[1], ref_seq.shape[1])
+    assert n >= 8 and float((seq[:, :n] == ref_seq[:, :n]).float().mean()) >= 0.95
+    tg = dt["video_target"]
+    C = R.matcher_cost(out["pred_logits"], out["pred_boxes"], torch.cat([x["labels"] for x in tg]),
+                       torch.cat([x["boxes"] for x in tg]))
+    idx, _ = R.hungarian(C, [len(x["boxes"]) for x in tg])
+    for i in range(len(tg)):
+        assert torch.equal(torch.stack(idx[i]), t(f[f"match_{i}"]))
+
+
 def test_torch_oracle_captioner_step():
     f = load("captioner_step")
     sd = pdvc_state(load("pdvc_eval"))

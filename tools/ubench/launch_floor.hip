@@ -48,5 +48,22 @@ int main() {
     std::sort(us.begin(), us.end());
     printf("%-48s dispatch median %6.2f us (min %6.2f)\n", names[m], us[us.size() / 2], us[0]);
   }
+  // the empty kernel at other geometries: (workgroups, threads, dynamic LDS bytes)
+  const int geo[][3] = {{256, 1024, 0}, {256, 1024, 49408}, {256, 512, 49408}, {512, 512, 49408}, {256, 256, 49408}, {1024, 256, 0},
+                        {256, 64, 0}, {1, 64, 0}, {256, 1024, 150000}};
+  for (auto &g_ : geo) {
+    hipFuncSetAttribute((const void *)ks[0], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    std::vector<float> us;
+    for (int it = 0; it < 30; ++it) {
+      hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+      hipExtLaunchKernelGGL(ks[0], dim3(g_[0]), dim3(g_[1]), g_[2], 0, a, b, 0, (const float4 *)v, o, S);
+      hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b);
+      if (it >= 5) us.push_back(ms * 1e3f);
+    }
+    std::sort(us.begin(), us.end());
+    printf("empty kernel, %4d workgroups x %4d threads, %6d B LDS: dispatch median %6.2f us (min %6.2f)\n", g_[0], g_[1], g_[2],
+           us[us.size() / 2], us[0]);
+  }
   return 0;
 }
