@@ -347,33 +347,18 @@ class TeacherForcedLoop(torch.autograd.Function):
         h_all[0].zero_()
         c_all[0].zero_()
         w_hcat_t, w_att_t = w_hcat.t(), w_att.t()
-        # GVL_SKINNY=own: the two products of a token through the latency-cut split-fp16 kernel
-        # (gvl_skinny_gemm_f16x3_f32).  Off by default: measured 9.1 / 8.8 / 14.7 / 23.2 us per product in a dependent chain
-        # against 8.2 / 7.7 / 8.5 / 13.3 us of the tuned library kernels (train step 11.14 against 10.89 ms)
-        skinny = (split_gemm_enabled() and os.environ.get("GVL_SKINNY", "") == "own" and not torch.is_autocast_enabled()
-                  and MSDA.skinny_gemm_eligible(h_all[0], W) and MSDA.skinny_gemm_eligible(att[0], H4)
-                  and w_hcat.dtype == torch.float32 and gates_hs.stride(1) == 1)
-        if skinny:
-            p_hcat, p_att = MSDA.skinny_pack(w_hcat.detach()), MSDA.skinny_pack(w_att.detach())
         for i in range(steps):
-            if skinny:
-                MSDA.skinny_gemm(h_all[i], p_hcat, g_h[i], bias=b_hcat)
-            else:
-                torch.addmm(b_hcat, h_all[i], w_hcat_t, out=g_h[i])               # [h2att(h) | h W_hh^T | offsets(h)]
+            torch.addmm(b_hcat, h_all[i], w_hcat_t, out=g_h[i])                   # [h2att(h) | h W_hh^T | offsets(h)]
             MSDA.cap_attend_train_forward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
                                           alpha_w, alpha_b, n_levels, n_points, att_res=att[i], alpha_out=alpha[i],
                                           row_video=row_video)
-            if skinny:
-                MSDA.skinny_gemm(att[i], p_att, g_x, addend=gates_hs)
-            else:
-                torch.addmm(gates_hs, att[i], w_att_t, out=g_x)                   # hs part + attention part of W_ih x
+            torch.addmm(gates_hs, att[i], w_att_t, out=g_x)                       # hs part + attention part of W_ih x
             MSDA.lstm_cell_train_forward(g_x, g_h[i][:, A:A + H4], xt_all[:, i], c_all[i], act[i], h_all[i + 1],
                                          c_all[i + 1])
         ctx.save_for_backward(slab, ref_in, off_hs, w_hcat, w_att, alpha_w, shapes2d, lsi, g_h, h_all, c_all, att,
                               alpha, act)
         ctx.cfg = (n_levels, n_points, A)
         ctx.row_video = row_video
-        ctx.skinny = skinny
         return h_all[1:].permute(1, 0, 2).contiguous()
 
     @staticmethod
@@ -392,26 +377,16 @@ class TeacherForcedLoop(torch.autograd.Function):
         g_aw, g_ab = torch.zeros_like(alpha_w), slab.new_zeros(1)
         d_att, dh_carry, dc = new(n, C), None, None
         dh_buf, dc_buf = (new(n, H), new(n, H)), (new(n, H), new(n, H))
-        skinny = ctx.skinny and MSDA.skinny_gemm_eligible(dg[0], H) and H4 % 16 == 0 and W % 16 == 0
-        if skinny:                                        # the transposed weights as the (N, K) operand of the kernel
-            p_att_t = MSDA.skinny_pack(w_att.detach().t().contiguous())                      # (C, 4H)
-            p_hcat_t = MSDA.skinny_pack(w_hcat.detach().t().contiguous())                    # (H, A + 4H + 16)
         for i in range(steps - 1, -1, -1):
             dgates = dg[i][:, A:A + H4]
             MSDA.lstm_cell_train_backward(d_h[i], dh_carry, dc, act[i], c_all[i], c_all[i + 1], dgates, dc_buf[i & 1])
             dc = dc_buf[i & 1]
-            if skinny:
-                MSDA.skinny_gemm(dgates, p_att_t, d_att)
-            else:
-                torch.mm(dgates, w_att, out=d_att)
+            torch.mm(dgates, w_att, out=d_att)
             MSDA.cap_attend_train_backward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
                                            alpha_w, alpha[i], d_att, n_levels, n_points, g_slab, dg[i][:, :A],
                                            dg[i][:, A + H4:], g_ref, g_aw, g_ab, row_video=ctx.row_video)
             if i > 0:                                  # h_{-1} = 0 is a constant
-                if skinny:
-                    dh_carry = MSDA.skinny_gemm(dg[i], p_hcat_t, dh_buf[i & 1])
-                else:
-                    dh_carry = torch.mm(dg[i], w_hcat, out=dh_buf[i & 1])
+                dh_carry = torch.mm(dg[i], w_hcat, out=dh_buf[i & 1])
         dgf = dg.view(steps * n, W)
         d_w_hcat = dgf.t().mm(h_all[:steps].reshape(steps * n, H))
         d_b_hcat = MSDA.col_sum(dgf)

@@ -381,7 +381,7 @@ def split_eligible(x, k_multiple=32):
 
 
 def split_rows(x, out=None, k_multiple=32):
-    """x (..., K) contiguous fp32 -> SplitPlanes of its (R, K) view (k_multiple = 16: operands of skinny_gemm)"""
+    """x (..., K) contiguous fp32 -> SplitPlanes of its (R, K) view """
     _require(split_eligible(x, k_multiple), "split_rows: needs a contiguous fp32 CUDA tensor whose last dimension is a "
                                            f"multiple of {k_multiple}")
     K = x.shape[-1]
@@ -413,61 +413,6 @@ def gemm_f16x3(a, b, bias=None, out=None):
                                            torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "gemm_f16x3")
     return out
-
-
-class TiledPlanes:
-    """an fp32 weight (N, K) as the tiled fp16 planes of the few-row product kernel (include/gvl_msda.h:
-    gvl_skinny_pack_f16)"""
-    __slots__ = ("hi", "lo", "scale", "rows", "cols")
-
-    def __init__(self, rows, cols, device):
-        self.rows, self.cols = rows, cols
-        padded = (rows + 31) // 32 * 32
-        self.hi = torch.empty(padded * cols, device=device, dtype=torch.float16)
-        self.lo = torch.empty(padded * cols, device=device, dtype=torch.float16)
-        self.scale = torch.empty(rows, device=device, dtype=torch.float32)
-
-
-def skinny_pack(w):
-    """w (N, K) fp32 with unit column stride, K % 16 == 0 -> TiledPlanes (once per weight and optimisation step)"""
-    _require(w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1 and w.shape[1] % 16 == 0
-             and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0, "skinny_pack: w must be (N, K) fp32, K % 16 == 0")
-    N, K = w.shape
-    out = TiledPlanes(N, K, w.device)
-    with torch.cuda.device(w.device):
-        rc = _lib.lib().gvl_skinny_pack_f16(w.data_ptr(), w.stride(0), N, K, out.hi.data_ptr(), out.lo.data_ptr(),
-                                            out.scale.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "skinny_pack")
-    return out
-
-
-def skinny_gemm(x, w, out, bias=None, addend=None):
-    """out (M, N) = x (M, K) @ w^T [+ bias] [+ addend]: the few-row products of the teacher-forced loop on the fp16 matrix
-    cores at fp32 accuracy, cut for latency (include/gvl_msda.h: gvl_skinny_gemm_f16x3_f32).  x fp32 with unit column
-    stride, w: TiledPlanes (N, K), K % 16 == 0; K > 512 needs a contiguous `out`."""
-    M, K = x.shape
-    N = w.rows
-    _require(isinstance(w, TiledPlanes), "skinny_gemm: w must come from skinny_pack")
-    _require(x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and K == w.cols and K % 16 == 0,
-             "skinny_gemm: x must be (M, K) fp32 with unit column stride, K % 16 == 0")
-    _require(out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.stride(1) == 1, "skinny_gemm: bad out")
-    _require(addend is None or (addend.dtype == torch.float32 and tuple(addend.shape) == (M, N) and addend.stride(1) == 1),
-             "skinny_gemm: addend must be (M, N) fp32")
-    _require(bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N),
-             "skinny_gemm: bias must be (N,) fp32")
-    with torch.cuda.device(x.device):
-        rc = _lib.lib().gvl_skinny_gemm_f16x3_f32(
-            x.data_ptr(), x.stride(0), M, K, w.hi.data_ptr(), w.lo.data_ptr(), w.scale.data_ptr(), N,
-            bias.data_ptr() if bias is not None else None, addend.data_ptr() if addend is not None else None,
-            addend.stride(0) if addend is not None else 0, out.data_ptr(), out.stride(0),
-            torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "skinny_gemm")
-    return out
-
-
-def skinny_gemm_eligible(x, n_out):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 16 == 0
-            and x.stride(0) % 4 == 0 and n_out % 4 == 0 and x.data_ptr() % 16 == 0 and 0 < x.shape[0] <= 1024)
 
 
 def ce_rows_forward(logits, target, weight):

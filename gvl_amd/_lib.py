@@ -69,8 +69,6 @@ SIGNATURES = {
     "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_forward_amax_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P, _P]),
     "gvl_linear_f16x3_f32": (_I, [_P, _I64, _P, _I64, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
-    "gvl_skinny_pack_f16": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P]),
-    "gvl_skinny_gemm_f16x3_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _I, _P, _P, _I64, _P, _I64, _P]),
     "gvl_layer_norm_rows_f32": (_I, [_P, _I, _I, _P, _P, ctypes.c_float, _P, _I, _P, _P, _P, _P]),
     "gvl_row_absmax_f32": (_I, [_P, _I64, _I, _I, _P, _I64, _I, _P, _P, _P]),
     "gvl_mha_core_f32": (_I, [_P, _I64, _P, _I, _I, _I, _P, _P, _P]),

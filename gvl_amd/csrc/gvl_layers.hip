@@ -385,194 +385,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_skinny_f16x3 -- the FEW-ROW products of the teacher-forced training loop (LSTM_DSA.py:63-117 over :241-271: per token
-// h W_hcat^T, att W_att^T forward and dgates W_att, dg W_hcat backward; 96-320 rows x 512-2576 x 512-2576).  The library
-// kernels for these shapes are latency chains (96-486 tiles, each walking its whole K serially: 14-29 us per product in
-// the captured step); the matrix-core work is 0.5 GFLOP.  Here the product is cut for LATENCY:
-//   * workgroup = 64 rows x 32 columns x a K range of <= 512; its 8 wavefronts take 64 of K each and meet once, in LDS,
-//     at the end -- no barrier and no dependence between wavefronts before that;
-//   * every global load instruction reads WHOLE cache lines: the fp32 activation as 4 rows x 256 bytes per instruction
-//     (16 lanes per row), the weight planes from the TILED layout of k_skinny_pack (1 KB per 32 columns x 16 k, in MFMA
-//     operand order: the operand goes from global memory straight into the register the matrix core reads).  (A first
-//     version that loaded the activation in operand order -- 64 pieces of 16 bytes from 64 lines per instruction -- ran
-//     11 us where this one runs 9 us: the lines were evicted from the 32 KB L1 between the 8
-//     instructions that each used 1/8 of them.)  All loads of a wavefront are requested before the first one is used;
-//   * the activation is split in registers and transposed through a wavefront-private LDS image (64 rows x 64 k, two
-//     planes, 144-byte rows) into operand order;
-//   * the power-of-two scale of the split is per (row, wavefront K range) -- the maximum over the 64 k the wavefront
-//     holds, a 16-lane DPP reduction -- and is divided out before the partial sums meet, so no row maximum has to exist
-//     beforehand;
-//   * K > 512: further workgroups along K, partial sums added by float atomics into the zero-filled output (only the
-//     backward products, whose outputs are n x 512).
-constexpr int kSkPitch = 72;                                           // halves per LDS row: 64 k + 8 (144 bytes)
-constexpr int kSkPlane = 64 * kSkPitch;                                // halves per plane
-constexpr int kSkWaveBytes = 2 * kSkPlane * 2;                         // 18432: [hi | lo], later the wavefront's partials
-constexpr int kSkLds = 8 * kSkWaveBytes + 8 * 64 * 4;                  // + row scales
-static_assert(64 * 33 * 4 <= kSkWaveBytes, "partial sums alias the wavefront's own operand image");
-
-struct SkinnyParams {
-  const float *X;
-  int64_t ldx;
-  const uint4 *Wh, *Wl;                                                // tiled planes [column tile][step][lane]
-  const float *Ws, *bias, *addend;
-  int64_t lda;
-  float *out;
-  int64_t ldo;
-  int M, N, K, chunks_wg, ksplit;
-};
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_max(float v) {
-  const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-  return fmaxf(v, o);
-}
-
-__global__ void __launch_bounds__(512, 1) k_skinny_f16x3(const SkinnyParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sk_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 32;
-  const int lr = lane & 31, kg = lane >> 5;
-  unsigned char *mine = sk_lds + wave * kSkWaveBytes;
-  float *rscale = reinterpret_cast<float *>(sk_lds + 8 * kSkWaveBytes) + wave * 64;
-  // this wavefront's 64 of K
-  const int total_steps = p.K >> 4;
-  const int chunk = blockIdx.z * p.chunks_wg + wave;
-  const bool active = wave < p.chunks_wg && chunk * 64 < p.K;
-  f16acc acc_m[2], acc_x[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_m[i][r] = 0.f; acc_x[i][r] = 0.f; }
-  if (active) {
-    // loads: activation rows 4 j + (lane >> 4), k = 64 chunk + 4 (lane & 15); weight planes of steps 4 chunk .. + 3
-    const int kx = chunk * 64 + 4 * (lane & 15);
-    const bool kvalid = kx < p.K;
-    const int kxc = min(kx, p.K - 4);
-    float4 xr[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = min(m0 + 4 * j + (lane >> 4), p.M - 1);
-      xr[j] = *reinterpret_cast<const float4 *>(p.X + (int64_t)row * p.ldx + kxc);
-    }
-    uint4 wh[4], wl[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int64_t at = ((int64_t)blockIdx.y * total_steps + min(chunk * 4 + s, total_steps - 1)) * 64 + lane;
-      wh[s] = p.Wh[at];
-      wl[s] = p.Wl[at];
-    }
-    // split per row: scale from the 16 lanes that hold the row's 64 k
-    _Float16 *img = reinterpret_cast<_Float16 *>(mine);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float4 v = xr[j];
-      if (!kvalid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-      m = dpp_max<0xB1>(m);                                            // quad_perm [1 0 3 2]
-      m = dpp_max<0x4E>(m);                                            // quad_perm [2 3 0 1]
-      m = dpp_max<0x141>(m);                                           // row_half_mirror
-      m = dpp_max<0x140>(m);                                           // row_mirror
-      float sc, inv;
-      scale_of(m, sc, inv);
-      const int row = 4 * j + (lane >> 4);
-      if ((lane & 15) == 0) rscale[row] = sc;
-      uint2 hi, lo;
-      split4(v, inv, hi, lo);
-      *reinterpret_cast<uint2 *>(img + row * kSkPitch + 4 * (lane & 15)) = hi;
-      *reinterpret_cast<uint2 *>(img + kSkPlane + row * kSkPitch + 4 * (lane & 15)) = lo;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the image is this wavefront's own: no barrier
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const h8 bh = __builtin_bit_cast(h8, wh[s]), bl = __builtin_bit_cast(h8, wl[s]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const _Float16 *src = img + (32 * i + lr) * kSkPitch + 16 * s + 8 * kg;
-        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(src));
-        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(src + kSkPlane));
-        acc_m[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m[i], 0, 0, 0);
-        acc_x[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_x[i], 0, 0, 0);
-        acc_x[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_x[i], 0, 0, 0);
-      }
-    }
-  }
-  // partial sums, descaled by the wavefront's own row scales, over the wavefront's operand image (C/D: column lane & 31,
-  // row (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  float *part = reinterpret_cast<float *>(mine);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      part[row * 33 + lr] = active ? (acc_m[i][r] + acc_x[i][r] * kLoInv) * rscale[row] : 0.f;
-    }
-  __syncthreads();
-  // 512 threads x 4 consecutive columns: sum of the 8 wavefronts' partials, weight scale, bias / addend, store | atomic add
-  const int row = tid >> 3, c0 = (tid & 7) * 4;
-  const int gr = m0 + row, gc = n0 + c0;
-  if (gr < p.M && gc < p.N) {
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      const float *pw = reinterpret_cast<const float *>(sk_lds + w * kSkWaveBytes) + row * 33 + c0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] += pw[c];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int col = min(gc + c, p.N - 1);
-      v[c] *= p.Ws[col];
-      if (blockIdx.z == 0) {
-        if (p.bias) v[c] += p.bias[col];
-        if (p.addend) v[c] += p.addend[(int64_t)gr * p.lda + col];
-      }
-    }
-    float *o = p.out + (int64_t)gr * p.ldo + gc;
-    if (p.ksplit == 1) {
-      if (gc + 3 < p.N) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-      else
-        for (int c = 0; c < 4 && gc + c < p.N; ++c) o[c] = v[c];
-    } else {
-      for (int c = 0; c < 4 && gc + c < p.N; ++c) atomicAdd(o + c, v[c]);
-    }
-  }
-}
-
-// k_skinny_pack -- an fp32 weight (N, K) as the tiled fp16 planes k_skinny_f16x3 reads: one wavefront per weight row:
-// row maximum -> power-of-two scale, split, and element (n, k) stored at [(n / 32) (K / 16) + k / 16][(n & 31) + 32 ((k &
-// 15) >> 3)][k & 7] of each plane (rows of the last column tile beyond N are left as the caller zero-filled them).
-__global__ void __launch_bounds__(256) k_skinny_pack(const float *__restrict__ w, int64_t ldw, int N, int K,
-                                                     _Float16 *__restrict__ hi, _Float16 *__restrict__ lo,
-                                                     float *__restrict__ scale) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const float4 *src = reinterpret_cast<const float4 *>(w + (int64_t)n * ldw);
-  const int n4 = K >> 2;
-  float m = 0.f;
-  for (int i = lane; i < n4; i += 64) {
-    const float4 v = src[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-  }
-#pragma unroll
-  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  float sc, inv;
-  scale_of(m, sc, inv);
-  if (lane == 0) scale[n] = sc;
-  const int64_t tile0 = (int64_t)(n >> 5) * (K >> 4);
-  for (int i = lane; i < n4; i += 64) {
-    uint2 h, l;
-    split4(src[i], inv, h, l);
-    const int k = 4 * i;
-    const int64_t at = ((tile0 + (k >> 4)) * 64 + (n & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7);
-    *reinterpret_cast<uint2 *>(hi + at) = h;
-    *reinterpret_cast<uint2 *>(lo + at) = l;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last axis, one wavefront per row (C <= 1024, C % 4 == 0): y = (x - mean) / sqrt(var + eps) * gamma
 // + beta (biased variance, as torch.nn.LayerNorm), two passes over registers.  Also the row maxima the consumers of y
 // need: amax_y[r] = max |y|, amax_yp[r] = max |y + pos[r % pos_rows]| (the query of the next attention is y + pos).
@@ -1159,46 +971,6 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
     return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64,addend>", k_lin_f16x3<true, 2, 2, 2, 1>, dim3(grid), dim3(256), 0,
                        st, p);
   return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64>", k_lin_f16x3<false, 2, 2, 2, 1>, dim3(grid), dim3(256), 0, st, p);
-}
-
-extern "C" int gvl_skinny_pack_f16(const float *w, int64_t ldw, int N, int K, void *hi, void *lo, float *scale, void *stream) {
-  if (N <= 0 || K <= 0 || (K & 15) || (ldw & 3) || ldw < K)
-    return fail(GVL_EINVAL, "gvl_skinny_pack_f16: needs K %% 16 == 0, ldw %% 4 == 0, ldw >= K (got N=%d K=%d)", N, K);
-  if (!w || !hi || !lo || !scale) return fail(GVL_EINVAL, "gvl_skinny_pack_f16: null pointer");
-  if (((uintptr_t)w | (uintptr_t)hi | (uintptr_t)lo) & 15) return fail(GVL_EINVAL, "gvl_skinny_pack_f16: operands must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  if (N & 31) {                                                        // the unused rows of the last column tile: finite
-    const size_t bytes = (size_t)((N + 31) / 32) * 32 * K * sizeof(_Float16);
-    if (int rc = gvl::zero_fill(hi, bytes, st)) return rc;
-    if (int rc = gvl::zero_fill(lo, bytes, st)) return rc;
-  }
-  return gvl::launch(GVL_PROF_LINEAR, N, K, "k_skinny_pack", k_skinny_pack, dim3((N + 3) / 4), dim3(256), 0, st, w, ldw, N, K,
-                     (_Float16 *)hi, (_Float16 *)lo, scale);
-}
-
-extern "C" int gvl_skinny_gemm_f16x3_f32(const float *x, int64_t ldx, int M, int K, const void *w_hi, const void *w_lo,
-                                         const float *w_scale, int N, const float *bias, const float *addend, int64_t lda,
-                                         float *out, int64_t ldo, void *stream) {
-  if (M < 0 || N <= 0 || K <= 0 || (K & 15) || (ldx & 3) || ldx < K || (ldo & 3) || ldo < N || (addend && lda < N))
-    return fail(GVL_EINVAL, "gvl_skinny_gemm_f16x3_f32: needs K %% 16 == 0, ldx / ldo %% 4 == 0 (got M=%d N=%d K=%d)", M, N, K);
-  if (M == 0) return 0;
-  if (!x || !w_hi || !w_lo || !w_scale || !out) return fail(GVL_EINVAL, "gvl_skinny_gemm_f16x3_f32: null pointer");
-  if (((uintptr_t)x | (uintptr_t)w_hi | (uintptr_t)w_lo | (uintptr_t)out) & 15)
-    return fail(GVL_EINVAL, "gvl_skinny_gemm_f16x3_f32: operands must be 16-byte aligned");
-  SkinnyParams p;
-  p.X = x; p.ldx = ldx; p.Wh = (const uint4 *)w_hi; p.Wl = (const uint4 *)w_lo; p.Ws = w_scale; p.bias = bias;
-  p.addend = addend; p.lda = lda; p.out = out; p.ldo = ldo; p.M = M; p.N = N; p.K = K;
-  const int chunks = (K + 63) / 64;                                    // 64 of K per wavefront, <= 8 wavefronts per workgroup
-  p.ksplit = (chunks + 7) / 8;
-  p.chunks_wg = (chunks + p.ksplit - 1) / p.ksplit;
-  hipStream_t st = (hipStream_t)stream;
-  if (p.ksplit > 1) {                                                  // partial sums are added into a zero-filled output
-    if (ldo != N) return fail(GVL_EINVAL, "gvl_skinny_gemm_f16x3_f32: K > 512 needs a contiguous output (ldo == N)");
-    if (int rc = gvl::zero_fill(out, (size_t)M * N * sizeof(float), st)) return rc;
-  }
-  if (int rc = gvl::ensure_lds(k_skinny_f16x3, kSkLds)) return rc;
-  return gvl::launch(GVL_PROF_LINEAR, M, N, "k_skinny_f16x3", k_skinny_f16x3, dim3((M + 63) / 64, (N + 31) / 32, p.ksplit),
-                     dim3(512), kSkLds, st, p);
 }
 
 extern "C" int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float *gamma, const float *beta, float eps,

@@ -48,10 +48,13 @@ class _ProjFunction(_LinearFunction):
 
 
 def projection(x, weight, bias):
-    """MSDeformAttn's offset / attention-logit projection (ms_deform_attn.py:99-100 against the concatenated weight):
-    hand-written HIP when the operands are in the kernel's domain (contiguous fp32, K in {256, 512, 1024}, N % 64 == 0,
-    no autocast), the library GEMM otherwise.  GVL_PROJ=library forces the library for A/B runs."""
-    if (torch.is_autocast_enabled() or os.environ.get("GVL_PROJ", "") == "library"
+    """MSDeformAttn's offset / attention-logit projection (ms_deform_attn.py:99-100 against the concatenated weight) in
+    TRAINING (inference runs it as a column segment of gvl_linear_f16x3_f32, gvl_amd/layers.py).  Default: the tuned library
+    GEMM through linear() -- the hand-written exact-fp32 MFMA kernel gvl_proj_f32 measures 17.2 us against the library's
+    16.7 us at R = 4800 in the same trace (profiles/r03_train_kernel_stats.txt, profiles/r02_proj_gemm.txt), so it is no
+    longer the default; GVL_PROJ=own selects it (contiguous fp32, K in {256, 512, 1024}, N % 64 == 0,
+    no autocast) and tests/test_gpu_criterion.py keeps it pinned."""
+    if (os.environ.get("GVL_PROJ", "") != "own" or torch.is_autocast_enabled()
             or not MSDA.proj_eligible(x, weight, bias)):
         return linear(x, weight, bias)
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):

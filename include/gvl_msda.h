@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 9   /* 9: + gvl_msda_last_kernel (diagnostic); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_skinny_gemm_f16x3_f32, gvl_skinny_pack_f16, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 9   /* 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -173,20 +173,6 @@ typedef struct gvl_lin_seg {
 int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2, int64_t lda2, int a2_rows, int R, int K,
                          const void *w_hi, const void *w_lo, const float *w_scale, const float *bias, int N,
                          const gvl_lin_seg *segs_host, int nseg, int flags, void *stream);
-/*    gvl_skinny_gemm_f16x3_f32: the FEW-ROW products of the teacher-forced training loop (pdvc/CaptioningHead/LSTM_DSA.py:
- *        63-117 over :241-271, and their autograd): out (M, N) = x (M, K) . w (N, K)^T [+ bias (N)] [+ addend (M, N)], x fp32
- *        (split in registers, the scale per row and 64-wide K range found by the kernel itself -- no row maxima needed),
- *        w as the TILED planes of gvl_skinny_pack_f16; K % 16 == 0; M of a few hundred rows, cut for latency (64 x 32
- *        outputs per workgroup, K split over its wavefronts; K > 512: further workgroups along K whose partial sums are
- *        added with float atomics into the output, which the call zero-fills first and which must then be contiguous).
- *        Same accuracy statement as gvl_gemm_f16x3_f32.
- *    gvl_skinny_pack_f16: w (N, K) fp32 (row stride ldw) -> its two fp16 planes (hi, lo: ceil(N / 32) * 32 * K halves each)
- *        and row scales (N), w[n, k] = scale[n] (hi + 2^-11 lo), stored in the operand order of the kernel: element (n, k)
- *        at half index (((n / 32) (K / 16) + k / 16) 64 + (n % 32) + 32 ((k % 16) / 8)) 8 + k % 8.  Once per weight. */
-int gvl_skinny_pack_f16(const float *w, int64_t ldw, int N, int K, void *hi, void *lo, float *scale, void *stream);
-int gvl_skinny_gemm_f16x3_f32(const float *x, int64_t ldx, int M, int K, const void *w_hi, const void *w_lo,
-                              const float *w_scale, int N, const float *bias, const float *addend, int64_t lda, float *out,
-                              int64_t ldo, void *stream);
 /*    gvl_layer_norm_rows_f32: torch.nn.LayerNorm over the last axis of x (R, C) (deformable_transformer.py:193,198,261,
  *        270,277; biased variance, eps inside the square root), C % 4 == 0, C <= 1024, one wavefront per row; also writes
  *        amax_y[r] = max |y[r][.]| and amax_ypos[r] = max |y[r][.] + pos[r % pos_rows][.]| (either may be NULL; pos (pos_rows,

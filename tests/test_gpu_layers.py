@@ -161,33 +161,6 @@ def test_attention_core_matches_fp64(B, Q, H, masked):
     assert torch.equal(am, out.abs().amax(1))
 
 
-@pytest.mark.parametrize("M,K,N,extra", [(192, 512, 2576, "bias"), (192, 512, 2048, "addend"), (192, 2048, 512, None),
-                                          (192, 2576, 512, None), (96, 512, 2576, "bias"), (37, 64, 36, "addend"),
-                                          (320, 1040, 100, None)])
-def test_skinny_gemm_matches_fp64_at_fp32_gemm_accuracy(M, K, N, extra):
-    """gvl_skinny_gemm_f16x3_f32 at the four product shapes of a teacher-forced token step (LSTM_DSA.py:241-271 and their
-    autograd) and ragged ones: error vs fp64 within the fp32 library GEMM's; rows of gradients-like magnitudes (1e-6) too"""
-    from gvl_amd import MultiScaleDeformableAttention as MSDA
-    x = _rand(M, K, seed=80) * torch.exp2(_rand(M, 1, seed=81, scale=6.0))          # rows from ~1e-6 to ~1e+5
-    w = _rand(N, K, seed=82, scale=K ** -0.5)
-    bias = _rand(N, seed=83) if extra == "bias" else None
-    add = _rand(M, N, seed=84) if extra == "addend" else None
-    out = torch.full((M, N), float("nan"), device=DEV)
-    MSDA.skinny_gemm(x, MSDA.skinny_pack(w), out, bias=bias, addend=add)
-    want = x.double() @ w.double().t()
-    lib = x @ w.t()
-    if bias is not None:
-        want, lib = want + bias.double(), lib + bias
-    if add is not None:
-        want, lib = want + add.double(), lib + add
-    rms, mx = _errs(out, want)
-    rms32, mx32 = _errs(lib, want)
-    assert rms <= 1.05 * rms32 + 1e-12 and mx <= 1.5 * mx32 + 1e-9, (rms, rms32, mx, mx32)
-    # per-row relative accuracy (tiny rows are not drowned by large ones: the scale is per row and K range)
-    rel = (out.double() - want).abs().amax(1) / want.abs().amax(1).clamp_min(1e-30)
-    assert float(rel.max()) <= 2e-5
-
-
 def test_encoder_geometry_equals_the_pytorch_formulation():
     """valid ratios and encoder reference points from the flat mask in one launch == deformable_transformer.py:81-83,209-218"""
     from gvl_amd import layers as L

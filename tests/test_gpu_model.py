@@ -472,14 +472,12 @@ def test_yc2_long_video_eval_under_bf16_autocast(built_yc2):
     assert all(torch.isfinite(v.float()).all() for v in loss.values())
 
 
-@pytest.mark.parametrize("ref_dim,skinny", [(2, ""), (1, ""), (2, "own")])
-def test_teacher_forced_loop_fused_equals_step_by_step(built, ref_dim, skinny, monkeypatch):
+@pytest.mark.parametrize("ref_dim", [2, 1])
+def test_teacher_forced_loop_fused_equals_step_by_step(built, ref_dim, monkeypatch):
     """TeacherForcedLoop (k_cap_train_* / k_lstm_train_* + deferred weight-gradient GEMMs) against the step-by-step
     formulation built from the sampler op + PyTorch autograd (itself pinned to the reference by the train golden):
-    log-probs and the gradients of every captioner parameter and of hs / reference / memory.  skinny = "own": the per-token
-    products through gvl_skinny_gemm_f16x3_f32 (opt-in, GVL_SKINNY=own) instead of the library's kernels."""
+    log-probs and the gradients of every captioner parameter and of hs / reference / memory."""
     from gvl_amd import MultiScaleDeformableAttention as MSDA
-    monkeypatch.setenv("GVL_SKINNY", skinny)
     f, model, criterion, dev = built
     cap = model.caption_head[-1]
     torch.manual_seed(5)

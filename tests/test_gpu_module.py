@@ -68,7 +68,7 @@ def test_msdeformattncap_module_golden():
     assert maxerr(out, f["out"]) < 1e-4
 
 
-def test_hand_written_projection_kernel_matches_fp64_and_library():
+def test_hand_written_projection_kernel_matches_fp64_and_library(monkeypatch):
     """gvl_proj_f32 (MSDeformAttn's offset / attention-logit projection, ms_deform_attn.py:99-100, as a hand-written fp32
     MFMA GEMM): exact-fp32 arithmetic -- its error against an fp64 product is the library's (a k-ordered fmaf chain) --
     for the two row counts of cfg A, a ragged row count, the other supported K, without bias; and its autograd wrapper
@@ -96,6 +96,8 @@ def test_hand_written_projection_kernel_matches_fp64_and_library():
     w = (torch.randn(256, 512, device=dev, generator=g) * 0.05).requires_grad_()
     b = torch.randn(256, device=dev, generator=g, requires_grad=True)
     go = torch.randn(2, 50, 256, device=dev, generator=g)
+    monkeypatch.setenv("GVL_PROJ", "own")                 # (the training default is the tuned library GEMM since round 4)
+    from gvl_amd import _lib
     projection(x, w, b).backward(go)
     x2, w2, b2 = (t_.detach().clone().requires_grad_() for t_ in (x, w, b))
     F.linear(x2, w2, b2).backward(go)

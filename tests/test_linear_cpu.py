@@ -56,7 +56,7 @@ def test_round3_token_loop_entry_points_are_declared_and_exported():
     from gvl_amd import _lib
     L = _lib.lib()
     for name in ("gvl_gemm_f16x3_lstm_f32", "gvl_cap_attend_split_levels_f32", "gvl_ce_rows_forward_f32",
-                 "gvl_ce_rows_backward_f32", "gvl_skinny_gemm_f16x3_f32", "gvl_skinny_pack_f16"):
+                 "gvl_ce_rows_backward_f32"):
         assert hasattr(L, name), name
     assert L.gvl_msda_abi_version() == _lib.ABI_VERSION >= 8
     assert L.gvl_ce_rows_forward_f32(None, 4, 2, 8, None, None, None, None, None) == -1        # ld < V
