@@ -212,8 +212,13 @@ class PDVC(nn.Module):
                                                  init_reference, inter_references, others, disable_refine,
                                                  self.opt.eval_disable_captioning)
         if self.opt.set_cost_caption > 0:
-            raise NotImplementedError("set_cost_caption > 0 (caption cost inside the matcher) is not used by any "
-                                      "reference config and is not built")
+            # pdvc.py:305-309 -> parallel_prediction_full_train (:322-432) -> caption_prediction(..., indices=None) (:355,
+            # :672): for the LSTM-DSA captioner (caption_decoder_type 'standard', the only one of this path) the reference
+            # itself fails there -- `max([len(feat_ids) for feat_ids, _ in indices])` at pdvc.py:743 iterates None:
+            # "TypeError: 'NoneType' object is not iterable" (reproduced by tests/golden/make_golden.py:make_full_train_probe,
+            # recorded in tests/golden/full_train_probe.npz).  No reference config sets set_cost_caption > 0; the branch has
+            # no behaviour to mirror other than this error, which is raised with the reference's own type and message.
+            raise TypeError("'NoneType' object is not iterable")
         return self.parallel_prediction_matched(dt, criterion, contrastive_criterion, hs, query_embed,
                                                 init_reference, inter_references, others, disable_refine)
 

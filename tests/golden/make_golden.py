@@ -491,6 +491,39 @@ def make_anet_full_b16():
     save("pdvc_anet_full_b16", **rec)
 
 
+def make_full_train_probe():
+    """VERDICT r3 missing 3: what does the reference do for set_cost_caption > 0 (pdvc.py:305-309 ->
+    parallel_prediction_full_train, :322-432)?  With the LSTM-DSA captioner ('standard', every cfg of the path) its
+    caption_prediction is called with indices=None and fails at pdvc.py:743; the exception type, message and the raising
+    line are recorded (there is no output to pin)."""
+    import traceback
+    opt, model, criterion, cc = build_pdvc("cfgs/anet_tsp_ssvg.yml",
+                                           dict(enable_contrastive=False, device="cpu", num_queries=20,
+                                                frame_embedding_num=40, set_cost_caption=1.0,
+                                                transformer_dropout_prob=0.0, drop_prob=0.0))
+    model.train()
+    n_gt = [2, 3]
+    dt = synth_dt(2, 40, opt.feature_dim, valid=[40, 31], n_gt=n_gt, seed=6)
+    g = torch.Generator().manual_seed(21)
+    caps = torch.zeros(sum(n_gt), 8, dtype=torch.long)
+    cap_mask = torch.zeros(sum(n_gt), 8)
+    for i in range(sum(n_gt)):
+        caps[i, 1:5] = torch.randint(1, opt.vocab_size, (4,), generator=g)
+        cap_mask[i, :6] = 1
+    dt.update(cap_tensor=caps, cap_mask=cap_mask,
+              gt_boxes_mask=torch.tensor([[k < n for k in range(max(n_gt))] for n in n_gt]).bool(),
+              gt_gather_idx=torch.tensor([i for i, n in enumerate(n_gt) for _ in range(n)]))
+    rec = dict(raised=np.array(False), exc_type=np.array(""), exc_message=np.array(""), where=np.array(""))
+    try:
+        with cuda_semantics():
+            model(dt, criterion, cc, "queries")
+    except Exception as e:                                   # noqa: BLE001
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        rec = dict(raised=np.array(True), exc_type=np.array(type(e).__name__), exc_message=np.array(str(e)),
+                   where=np.array(f"{os.path.basename(tb.filename)}:{tb.lineno} in {tb.name}"))
+    save("full_train_probe", **rec)
+
+
 def make_collate():
     """the reference's collate_fn (video_dataset.py:16-106) on synthetic samples (tests/golden/synth.py:synth_samples)"""
     from itertools import chain as chain_
@@ -823,7 +856,8 @@ if __name__ == "__main__":
         make_train()
         sys.exit(0)
     for flag, fn in (("--only-dataset", make_dataset), ("--only-anet-c3d", make_anet_c3d), ("--only-f64", make_f64),
-                     ("--only-anet-full-train", make_anet_full_train), ("--only-anet-full-b16", make_anet_full_b16)):
+                     ("--only-anet-full-train", make_anet_full_train), ("--only-anet-full-b16", make_anet_full_b16),
+                     ("--only-full-train-probe", make_full_train_probe)):
         if flag in sys.argv:
             fn()
             sys.exit(0)
@@ -841,5 +875,6 @@ if __name__ == "__main__":
         make_f64()
         make_anet_full_train()
         make_anet_full_b16()
+        make_full_train_probe()
     make_dataset()
     make_init()

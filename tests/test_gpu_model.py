@@ -265,6 +265,36 @@ def test_pdvc_train_step_matches_reference():
         assert maxerr(params[k[5:]].grad, want) <= 2e-3 * max(1.0, float(abs(want).max())), k
 
 
+def test_caption_cost_in_the_matcher_fails_as_the_reference_does():
+    """set_cost_caption > 0 routes training through parallel_prediction_full_train (pdvc.py:305-309, :322-432).  With the
+    LSTM-DSA captioner the REFERENCE fails inside it (caption_prediction iterates indices=None, pdvc.py:743): the probe
+    tests/golden/make_golden.py:make_full_train_probe ran the reference and recorded the exception
+    (tests/golden/full_train_probe.npz).  There is no output to mirror; gvl_amd raises the same exception type and message
+    at the same point of the forward (after the decoder), and the evaluation forward -- which never takes that branch in
+    the reference either (pdvc.py:301-304) -- is unaffected by the option."""
+    from gvl_amd.config import make_opt
+    from gvl_amd.pdvc import build
+    probe = load("full_train_probe")
+    assert bool(probe["raised"]) and str(probe["exc_type"]) == "TypeError" and "pdvc.py:743" in str(probe["where"])
+    dev = torch.device("cuda:0")
+    f, g = load("pdvc_eval"), load("pdvc_train")
+    opt = make_opt(num_queries=8, feature_dim=64, vocab_size=40, max_caption_len=6, device="cuda", set_cost_caption=1.0)
+    model, criterion, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f), strict=True)
+    model = model.to(dev).train()
+    dt = to_dev(pdvc_dt(f), dev)
+    dt.update(cap_tensor=t(g["cap_tensor"]).to(dev), cap_mask=t(g["cap_mask"]).to(dev),
+              gt_boxes_mask=torch.tensor([[1, 1, 1], [1, 1, 0]], dtype=torch.bool, device=dev))
+    with pytest.raises(TypeError) as e:
+        model(dt, criterion, None, "queries")
+    assert str(e.value) == str(probe["exc_message"])
+    model.eval()
+    with torch.no_grad():
+        out, loss = model(dt, criterion, None, "queries", eval_mode=True)
+    assert maxerr(out["pred_boxes"], f["cuda.pred_boxes"]) <= 2e-4
+
+
+
 def test_token_loop_gemm_paths_agree(built, monkeypatch):
     """the captioner's token loop on gvl_gemm_f16x3 (default; argmax fused, cell / attention kernels emitting planes) and
     on the fp32 library GEMMs (GVL_GEMM=f32): the same greedy tokens, log-probabilities within fp32 noise"""
