@@ -637,11 +637,16 @@ def main():
                 + ("one fixed batch, 3 events per video" if a.fixed_layout else
                    f"{len(batches)} rotating batches with 0-10 events per video and 3-20-word captions"))
     from gvl_amd.linear import split_gemm_enabled as _sge
-    gemm16_on = _sge() and a.dtype == "f32"
+    from gvl_amd.pdvc import autocast_inference_policy
+    island = a.dtype == "bf16" and autocast_inference_policy() == "fp32"      # eval forward under autocast = the fp32 path
+    gemm16_on = _sge() and (a.dtype == "f32" or island)
     from gvl_amd import layers as _lay
-    _lay_on = _lay.enabled() and a.dtype == "f32"
+    _lay_on = _lay.enabled() and (a.dtype == "f32" or island)
     line = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.dtype == "f32" else "bf16 storage + bf16 GEMMs, f32 accumulate / locations / captioner",
+            "dtype": "f32" if a.dtype == "f32" else (
+                "torch.autocast(bfloat16): train step on bf16 storage + bf16 GEMMs (f32 accumulate / locations / captioner); "
+                + ("eval forward as an fp32 island on the hand-written inference path (faster than the bf16 library route; "
+                   "GVL_AUTOCAST_INFERENCE=bf16 for bf16 storage)" if island else "eval forward on bf16 storage + bf16 GEMMs")),
             "data": "synthetic",
             "config": {"workload": workload,
                        "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",

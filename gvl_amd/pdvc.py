@@ -49,6 +49,13 @@ class MLP(nn.Module):
         return x
 
 
+def autocast_inference_policy():
+    """"fp32" (default): an inference forward under torch.autocast runs the hand-written fp32-accurate path; "bf16": the
+    bf16-storage path (library bf16 GEMMs + the _bf16 kernel twins)"""
+    import os
+    return "bf16" if os.environ.get("GVL_AUTOCAST_INFERENCE", "") == "bf16" else "fp32"
+
+
 class PDVC(nn.Module):
     def __init__(self, base_encoder, text_encoder, transformer, captioner, num_classes, num_queries,
                  num_feature_levels, aux_loss=True, with_box_refine=False, opt=None, translator=None):
@@ -176,6 +183,16 @@ class PDVC(nn.Module):
         return pt if pt is not None else dt['video_target']
 
     def forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
+        if (torch.is_autocast_enabled() and not torch.is_grad_enabled() and not self.training
+                and dt['video_tensor'].is_cuda and autocast_inference_policy() == "fp32"):
+            # INFERENCE under torch.autocast (BASELINE config 5 is named "bf16"): the hand-written inference path -- split-fp16
+            # products at fp32 accuracy with fused epilogues, the fused token loop -- is FASTER than the bf16 library GEMMs +
+            # ATen casts autocast would route the layers through (profiles/r03_other_configs.json: yc2 T = 512, 3121 against
+            # 2936 videos/s) and more accurate, so the forward runs as an fp32 island: autocast may lower precision, it need
+            # not.  GVL_AUTOCAST_INFERENCE=bf16 restores the bf16-storage path (bf16 GEMMs, the _bf16 kernel twins); training
+            # under autocast is unaffected.
+            with torch.autocast("cuda", enabled=False):
+                return self.forward(dt, criterion, contrastive_criterion, transformer_input_type, eval_mode)
         N = dt['video_tensor'].shape[0]
         memory, tshapes, lsi, valid_ratios, mask_flat = self.encode(dt)
         cut = getattr(self, "memory_cut", None)
