@@ -29,6 +29,10 @@ import statistics
 import sys
 import time
 
+# before the first HIP call of the process (see gvl_amd/__init__.py): hipGraph replays without the runtime's packet-capture
+# fast path, which mis-orders the non-kernel nodes of a captured step after a host synchronisation on ROCm 7.2
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import torch
 import torch.distributed as dist
 
@@ -36,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_TBS = 8.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 def synth_batch(B, T, feat, vocab, n_gt, device, seed=1, cap_words=10):
@@ -266,19 +270,55 @@ def timed_loop(step, batches, steps, warmup, world, dev):
     """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize; -> elapsed seconds (max over
     ranks), per-rank seconds"""
     for i in range(warmup):
-        step(batches[i % len(batches)])
+        o_ = step(batches[i % len(batches)])
+        if os.environ.get("GVL_BENCH_TRACE_LOSS") and isinstance(o_, tuple) and isinstance(o_[0], torch.Tensor) and o_[0].numel() == 1:
+            print(f"[trace] warm-up step {i}: loss {float(o_[0]):.4f}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    out = None
+    trace = bool(os.environ.get("GVL_BENCH_TRACE_LOSS"))       # dev: print every timed step's loss (synchronises: not a timing run)
     for i in range(steps):
-        step(batches[i % len(batches)])
+        if trace and os.environ.get("GVL_BENCH_TRACE_GRADS") == str(i) and hasattr(step, "_forward_loss"):
+            # dev: the gradients of THIS step's batch from an eager forward / backward on the current parameters (no update)
+            mdl = step.model
+            for p_ in mdl.parameters():
+                p_.grad = None
+            final, _l = step._forward_loss(batches[i % len(batches)])
+            final.backward()
+            gb = [(n, int((~torch.isfinite(p_.grad)).sum())) for n, p_ in mdl.named_parameters()
+                  if p_.grad is not None and not bool(torch.isfinite(p_.grad).all())]
+            gn = sorted(((float(p_.grad.float().norm()), n) for n, p_ in mdl.named_parameters() if p_.grad is not None), reverse=True)[:5]
+            print(f"[trace] eager gradients before timed step {i}: loss {float(final):.4f}; non-finite: {gb[:10]}; largest norms {gn}",
+                  file=sys.stderr, flush=True)
+            for p_ in mdl.parameters():
+                p_.grad = None
+        out = step(batches[i % len(batches)])
+        if trace and isinstance(out, tuple) and isinstance(out[0], torch.Tensor) and out[0].numel() == 1:
+            print(f"[trace] timed step {i}: loss {float(out[0]):.4f}", file=sys.stderr, flush=True)
+            if not bool(torch.isfinite(out[0])) and not getattr(timed_loop, "reported", False):
+                timed_loop.reported = True
+                bad = {k: float(v) for k, v in out[1].items() if isinstance(v, torch.Tensor) and v.numel() == 1
+                       and not bool(torch.isfinite(v).all()) and "self_iou" not in k}
+                print(f"[trace]   non-finite loss terms (besides self_iou): {bad}", file=sys.stderr, flush=True)
+                mdl = getattr(step, "model", None)
+                if mdl is not None:
+                    gb = [n for n, p_ in mdl.named_parameters() if p_.grad is not None and not bool(torch.isfinite(p_.grad).all())]
+                    pb = [n for n, p_ in mdl.named_parameters() if not bool(torch.isfinite(p_).all())]
+                    print(f"[trace]   non-finite grads {len(gb)} {gb[:8]}; params {len(pb)} {pb[:3]}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
+    timed_loop.last_out = out                     # (read by the caller after the region: is the last step's loss finite?)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    try:                                   # the shader clock right behind the timed steps (diagnostic; outside the timing)
+        from gvl_amd import MultiScaleDeformableAttention as _M
+        timed_loop.last_clock_mhz = round(_M.clock_probe_mhz(dev, 4000), 0)
+    except Exception:                      # noqa: BLE001
+        timed_loop.last_clock_mhz = None
     per_rank = [elapsed]
     if world > 1:
         mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -423,6 +463,8 @@ def main():
         lens.append((lens[-1] - 1) // 2 + 1)
     S = sum(lens)
     vb = 2 if a.dtype == "bf16" else 4
+    from gvl_amd.pdvc import autocast_inference_policy as _aip
+    vb_eval = 4 if (a.dtype == "f32" or _aip() == "fp32") else 2      # (autocast inference as an fp32 island: fp32 kernels)
     res = {}
 
     def traffic_of(cfg_key, launch):
@@ -470,6 +512,7 @@ def main():
         caps0 = graphed_eval.captures if graphed_eval else 0
         MSDA.profile_enable(a.no_graph)
         elapsed, per_rank = timed_loop(step, batches, a.steps, a.warmup, world, dev)
+        eval_clock = getattr(timed_loop, "last_clock_mhz", None)
         MSDA.profile_enable(False)
         ktimes = kernel_times(MSDA.profile_collect()) if a.no_graph else instrumented(eager_eval)
         # the hand-written projection GEMM in front of every sampling launch: stamped in a pass of its own (level 2)
@@ -478,7 +521,7 @@ def main():
         torch.cuda.synchronize()
         MSDA.profile_enable(False)
         ktimes.update({k: v for k, v in kernel_times(MSDA.profile_collect()).items() if k[0] == "proj"})
-        res["eval"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes,
+        res["eval"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes, "clock_mhz": eval_clock,
                        "graphs": None if graphed_eval is None else {
                            "cached": len(graphed_eval.graphs), "captures_total": graphed_eval.captures,
                            "captures_in_timed_region": graphed_eval.captures - caps0,
@@ -553,18 +596,27 @@ def main():
                                        cap_len_policy=a.cap_len_policy)
         else:
             trainer = TrainStep(model, criterion, opt, world_size=world, autocast_dtype=ac)
-        for dt in batches:
-            trainer(dt)
+        for i_, dt in enumerate(batches):
+            o_ = trainer(dt)
+            if os.environ.get("GVL_BENCH_TRACE_LOSS"):
+                print(f"[trace] set-up call {i_}: loss {float(o_[0]):.4f}", file=sys.stderr, flush=True)
         caps0 = getattr(trainer, "captures", 0)
         MSDA.profile_enable(a.no_graph)
         elapsed, per_rank = timed_loop(trainer, batches, a.steps, a.warmup, world, dev)
+        train_clock = [getattr(timed_loop, "last_clock_mhz", None)]
+        last = getattr(timed_loop, "last_out", None)
+        try:
+            last_loss = float(last[0]) if last is not None else None
+        except Exception:                      # noqa: BLE001
+            last_loss = None
         MSDA.profile_enable(False)
         if a.no_graph:
             ktimes = kernel_times(MSDA.profile_collect())
         else:
             ktimes = instrumented(lambda dt: TrainStep.__call__(trainer, dt))
+            train_clock.append(round(MSDA.clock_probe_mhz(dev, 4000), 0))      # ... and behind the instrumented eager steps
         xch = trainer.exchange_times_ms() if hasattr(trainer, "exchange_times_ms") else None
-        res["train"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes, "exchange_ms": xch,
+        res["train"] = {"elapsed": elapsed, "per_rank": per_rank, "ktimes": ktimes, "exchange_ms": xch, "clock_mhz": train_clock, "last_loss": last_loss,
                         "graphs": None if a.no_graph else {
                             "cached": len(trainer.graphs), "captures_total": trainer.captures,
                             "captures_in_timed_region": trainer.captures - caps0, "replays": trainer.replays,
@@ -587,7 +639,7 @@ def main():
         if dec_key is None:
             return None
         us, n, us_mean = fwd[dec_key]
-        nbytes = msda_bytes(B, S, a.queries, value_bytes=vb)
+        nbytes = msda_bytes(B, S, a.queries, value_bytes=vb_eval)
         achieved = nbytes / (us * 1e-6) / 1e9              # GB/s
         # (the eval forward's launches are the row-maxima variant the inference layers use: "100_f32_amax")
         traffic, traffic_src = traffic_of("100_f32_amax" if "eval" in res else "100_f32", "fwd_dec")
@@ -599,7 +651,7 @@ def main():
         enc_key = next((k for k in fwd if k[1] == S and k[2] == B), None)
         if enc_key is not None:
             eus, en = fwd[enc_key][:2]
-            eb = msda_bytes(B, S, S, value_bytes=vb)
+            eb = msda_bytes(B, S, S, value_bytes=vb_eval)
             roof["encoder_launch"] = {"kernel_us": round(eus, 2), "launches_timed": en, "algorithmic_bytes": eb,
                                       "frac": round(eb / (eus * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1e3), 4)}
         return roof
@@ -700,6 +752,7 @@ def main():
         t_ = res["train"]
         ms = t_["elapsed"] * 1e3 / a.steps
         line.update({"train_step_ms": round(ms, 3), "train_videos_per_s": round(world * B * a.steps / t_["elapsed"], 3),
+                     "train_last_timed_step_loss": t_.get("last_loss"),
                      "train_roofline": bwd_roofline(t_["ktimes"]), "train_graphs": t_["graphs"],
                      "train_seconds_per_rank": [round(x, 4) for x in t_["per_rank"]]})
         if t_.get("exchange_ms"):
@@ -713,6 +766,10 @@ def main():
             line.update({"metric": "train-step ms", "value": round(ms, 3), "unit": "ms", "ms_per_step": round(ms, 3),
                          "higher_is_better": False, "roofline": line["train_roofline"]})
     line["kernels_us"] = kernels_us
+    line["shader_clock_mhz"] = {"after_eval_timed_region": (res.get("eval") or {}).get("clock_mhz"),
+                                "after_train_timed_region_and_instrumented_steps": (res.get("train") or {}).get("clock_mhz"),
+                                "note": "gvl_clock_probe: cycle counter against the 100 MHz wall clock over a chain of dependent "
+                                        "FMAs queued right behind the region (MI355X max 2400)"}
     if line.get("roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and "eval" in res and not a.no_probes:
         line["roofline"]["cfg_L_launch"] = kernel_probe(dev, B)
         line["roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries)

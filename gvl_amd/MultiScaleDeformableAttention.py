@@ -661,6 +661,18 @@ PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_gener
              23: "layer_norm_etc"}
 
 
+def clock_probe_mhz(device=None, n_fma=20000):
+    """the shader clock the chip holds right now on the current stream (include/gvl_msda.h: gvl_clock_probe): a short chain
+    of dependent FMAs timed with the cycle counter against the 100 MHz wall clock; synchronises"""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    out = torch.zeros(2, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        rc = _lib.lib().gvl_clock_probe(out.data_ptr(), int(n_fma), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "clock_probe")
+    cyc, ref = out.tolist()
+    return 100.0 * cyc / max(ref, 1)
+
+
 def profile_enable(on=True):
     """on: False / 0 = off; True / 1 = per-dispatch stamps of the sampling-path kernels; 2 = additionally the projection
     kernel in front of them (stamping two consecutive launches inflates the second one's interval, see gvl_common.hpp)"""

@@ -32,6 +32,7 @@ SIGNATURES = {
     "gvl_msda_backward_bf16": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_prof_enable": (_I, [_I]),
     "gvl_msda_debug_stamps": (None, [_P]),
+    "gvl_clock_probe": (_I, [_P, _I, _P]),
     "gvl_prof_collect": (_I, [_P, _P, _P, _P, _I]),
     "gvl_msda_sample_backward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),
     "gvl_msda_sample_backward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),

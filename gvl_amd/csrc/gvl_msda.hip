@@ -2072,6 +2072,29 @@ void gvl_msda_debug_stamps(void *device_buffer) {
   g_bwd_stamps = g_fwd_stamps ? g_fwd_stamps + 4 * 4096 : nullptr;        // backward: second half of the buffer
 }
 
+static __global__ void __launch_bounds__(64) k_clock_probe(long long *out, int n, float seed) {
+  float a = seed + threadIdx.x * 1e-3f;
+  const float b = 1.0001f;
+  const long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < n; i += 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[0] = t1 - t0;
+    out[1] = r1 - r0;
+  }
+  if (a == 12345.678f) out[1] = 0;                                       // keep the chain alive
+}
+
+int gvl_clock_probe(long long *device_out2, int n_fma, void *stream) {
+  if (!device_out2 || n_fma <= 0) return fail(GVL_EINVAL, "gvl_clock_probe: null pointer / n_fma <= 0");
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, device_out2, n_fma, 0.5f);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? 0 : fail((int)err, "gvl_clock_probe: launch failed: %s", hipGetErrorString(err));
+}
+
 int gvl_prof_enable(int on) {
   gvl::Profiler &p = gvl::profiler();
   std::lock_guard<std::mutex> g(p.mu);

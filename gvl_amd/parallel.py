@@ -695,7 +695,11 @@ class GraphedEvalForward:
                 and slots <= min(64, self.model.opt.num_queries))
 
     def _autocast(self):
-        return torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None)
+        # inference under autocast runs as an fp32 island unless GVL_AUTOCAST_INFERENCE=bf16 (gvl_amd/pdvc.py): the decode
+        # segments captured after the main forward follow the same policy as PDVC.forward itself
+        from .pdvc import autocast_inference_policy
+        on = self.autocast_dtype is not None and autocast_inference_policy() == "bf16"
+        return torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=on)
 
     def _forward(self, dt):
         with self._autocast():

@@ -350,6 +350,11 @@ int gvl_prof_enable(int on);   /* 0 off | 1 sampling-path kernels | 2 also GVL_P
  * workgroup of k_fwd_t1d_d64 records the 100 MHz wall clock at {start, slab staged, loop done} in the first half and
  * every workgroup of k_bwd_t1d_d64 {start, staged, phase 1 done, phase 2 done} in the second half.  NULL = off. */
 void gvl_msda_debug_stamps(void *device_buffer);
+/* Shader-clock probe (diagnostics, no reference equivalent): one wavefront runs a chain of `n_fma` dependent v_fma_f32 and
+ * writes {s_memtime ticks (shader cycles), s_memrealtime ticks (100 MHz)} of the chain to device_out2 (2 x int64): the clock the
+ * chip holds at this point of the stream = 100 MHz x out[0] / out[1].  bench.py reports it next to its timed regions (a
+ * kernel-time comparison between two runs means little when one of them ran at half the clock). */
+int gvl_clock_probe(long long *device_out2, int n_fma, void *stream);
 int gvl_prof_collect(float *us, int *tag, int *meta_a, int *meta_b, int capacity);
 
 /* -- forward: replaces ms_deform_attn_forward (pdvc/ops/src/ms_deform_attn.h:20-39 ->

@@ -777,3 +777,39 @@ def test_graphed_bf16_train_step_stays_finite():
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0]
     assert all(torch.isfinite(p_).all() for p_ in model.parameters())
+
+
+def test_graphed_bf16_train_step_survives_a_device_synchronisation():
+    """Round-4 regression: in bench.py's bf16 train half (cfg A, caption-width buckets: 7 graphs over 8 rotating batches) the
+    parameters went NaN two replays after the torch.cuda.synchronize() between warm-up and timed region -- every run, while
+    the same sequence without the synchronisation, and the eager step, stayed finite.  Cause: ROCm 7.2's graph "packet
+    capture" replay path mis-orders non-kernel nodes (hipMemsetAsync of PyTorch's reduction semaphores, D2D copies) against the
+    kernel packets once the queue has gone idle; gvl_amd / bench.py set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first HIP
+    call.  This test replays that exact sequence and asserts finiteness, and that the switch is in the environment."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import rotating_batches
+    from gvl_amd.config import make_opt
+    from gvl_amd.parallel import GraphedTrainStep
+    from gvl_amd.pdvc import build
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"          # set by `import gvl_amd` (conftest, before CUDA init)
+    dev = torch.device("cuda:0")
+    opt = make_opt("anet_tsp_ssvg", num_queries=300, frame_embedding_num=100, device="cuda")
+    torch.manual_seed(0)
+    model, criterion, _, _ = build(opt)
+    model = model.to(dev).train()
+    batches = rotating_batches(8, 16, 100, opt.feature_dim, opt.vocab_size, dev, seed=1)
+    step = GraphedTrainStep(model, criterion, opt, autocast_dtype=torch.bfloat16, cap_len_policy="bucket")
+    losses = []
+    for i in list(range(8)) + [0, 1, 2]:
+        losses.append(step(batches[i])[0].clone())
+    torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for i in (0, 1, 2, 3, 4, 5):
+        losses.append(step(batches[i])[0].clone())
+    torch.cuda.synchronize()
+    for i in (6, 7, 0):
+        losses.append(step(batches[i])[0].clone())
+    losses = [float(x) for x in torch.stack(losses)]
+    assert all(np.isfinite(losses)), losses
+    assert all(torch.isfinite(p_).all() for p_ in model.parameters())
