@@ -1343,8 +1343,20 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
   extern __shared__ float4 slab4[];
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
   const int BM = B * M;
-  const int g = blockIdx.x / BM;                                       // g in {0, 1}
-  const int bm = (dbg & 4) ? (int)(blockIdx.x % BM) : slab_of_block(blockIdx.x % BM, BM);
+  // workgroup id -> (slab, level pair g).  B*M = 128: the two workgroups of a slab are ids B*M apart, both in the first (only)
+  // round of 256 and on one XCD.  B*M > 128 (dbg & 8, B*M % 8 == 0): 2 B*M workgroups run in several rounds, so the PAIR gets
+  // consecutive positions on its XCD -- ids (x, k) and (x, k + 1) with x = id % 8, k = id / 8 -- and is dispatched together:
+  // the second reader of every grad_out / proj row still finds it in the XCD's L2
+  int g, sidx;
+  if (dbg & 8) {
+    const int k = (int)blockIdx.x >> 3;
+    g = k & 1;
+    sidx = (k >> 1) * 8 + ((int)blockIdx.x & 7);
+  } else {
+    g = blockIdx.x / BM;                                                  // g in {0, 1}
+    sidx = blockIdx.x % BM;
+  }
+  const int bm = (dbg & 4) ? sidx : slab_of_block(sidx, BM);
   const int b = bm / M, m = bm % M;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1836,7 +1848,14 @@ bool bwd_split_ok(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan
 // in global memory; -> queries per phase-B chunk, 0 = not eligible
 int bwd_own_chunk(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan, const int64_t *shapes_host) {
   if (!env_int("GVL_MSDA_BWD_OWN", 1)) return 0;
-  if (L != 4 || P != 4 || !plan.ok || !shapes_host || Q < 2 || (256 + B * M - 1) / (B * M) != 2) return 0;
+  // B*M >= 256: one workgroup per slab already covers the chip; the pair form only pays where that workgroup would have to
+  // walk several query chunks (read-modify-write of its slab per chunk)
+  // (measured at T = 512, B = 32 / 64: 960 queries = 8 chunks: 230 -> 174 us / 468 -> 392 us; 300 queries = 3 chunks: 70 vs 76
+  // us / 139 vs 137 us -- the pair form repeats the coefficient arithmetic in both workgroups and wins from 4 chunks on)
+  if (B * M >= 256 && plan.ok && bwd_chunks(B, M, Q, S, plan.rowsV) < 4) return 0;
+  // two workgroups per slab: B*M = 128 ... 255 fills the chip in one round (what bwd_groups gives the chunked form too);
+  // larger batches run 2 B*M workgroups in rounds (pairs adjacent on their XCD: needs B*M % 8 == 0)
+  if (L != 4 || P != 4 || !plan.ok || !shapes_host || Q < 2 || B * M < 128 || (B * M >= 256 && (B * M) % 8)) return 0;
   const int n0 = (int)(shapes_host[1] + shapes_host[7]), n1 = (int)(shapes_host[3] + shapes_host[5]);   // {0,3} | {1,2}
   const int n_own = n0 > n1 ? n0 : n1;
   if (n_own > 64 * kOwnNU) return 0;
@@ -1892,7 +1911,7 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
     g_last_kernel = "k_bwd_t1d_own";
     return gvl::launch(GVL_PROF_BWD_T1D, Q, B, FUSED ? "k_bwd_t1d_own<fused>" : "k_bwd_t1d_own", kern, dim3(2 * B * M),
                        dim3(kBwdThreads), lds, st, value, shapes, lsi, p0, p1, gout, B, S, M, Q, RD, qc, gvalue, g0, g1,
-                       g_bwd_stamps, env_int("GVL_MSDA_OWN_DEBUG", 0));
+                       g_bwd_stamps, env_int("GVL_MSDA_OWN_DEBUG", 0) | ((B * M > 128 && (B * M) % 8 == 0) ? 8 : 0));
   }
   const int ngroup = bwd_groups(B, M, nchunk);
   const size_t lds = bwd_lds_bytes(S, qper, plan.rowsV);

@@ -58,13 +58,15 @@ def _check(MSDA, dev, B, T, Q, pad, seed, oracle_rows=4, expect_kernel=None):
 
 
 @pytest.mark.parametrize("pad", ["zeros", "border"])
-def test_long_video_chunks_accumulate_in_place(pad, dev, MSDA):
+def test_long_video_chunks_accumulate_in_place(pad, dev, MSDA, monkeypatch):
     # B*M = 256 slabs -> one workgroup each; 400 queries beside a 449-row slab need >= 3 chunks
-    _check(MSDA, dev, B=32, T=512, Q=400, pad=pad, seed=41)
+    monkeypatch.setenv("GVL_MSDA_BWD_OWN", "0")
+    _check(MSDA, dev, B=32, T=512, Q=400, pad=pad, seed=41, expect_kernel="k_bwd_t1d_d64<loop>")
 
 
 @pytest.mark.parametrize("chunks", [2, 3, 5])
 def test_forced_chunk_counts_at_the_training_shape(chunks, dev, MSDA, monkeypatch):
+    monkeypatch.setenv("GVL_MSDA_BWD_OWN", "0")
     monkeypatch.setenv("GVL_MSDA_BWD_CHUNKS", str(chunks))
     _check(MSDA, dev, B=32, T=100, Q=300, pad="zeros", seed=7 + chunks)
 
@@ -95,6 +97,7 @@ def test_level_split_with_more_own_queries_than_slab_rows(T, Q, dev, MSDA, monke
 @pytest.mark.parametrize("ref_dim", [1, 2])
 def test_fused_entry_point_with_chunks_matches_autograd_composition(ref_dim, dev, MSDA, monkeypatch):
     from gvl_amd.ops.functions.ms_deform_attn_func import MSDeformAttnFunction
+    monkeypatch.setenv("GVL_MSDA_BWD_OWN", "0")                 # keep this test on the chunked form it was written for
     monkeypatch.setenv("GVL_MSDA_BWD_CHUNKS", "4")
     B, M, D, L, P, Q = 32, 8, 64, 4, 4, 120
     lens = [100, 50, 25, 13]
@@ -240,3 +243,15 @@ def test_row_ownership_odd_shapes(T, Q, pad, dev, MSDA):
            expect_kernel=("k_bwd_t1d_own", "k_bwd_t1d_split") if own else None)      # (split: the queries fit one carve-up)
     if not own:
         assert _lib.lib().gvl_msda_last_kernel().decode() != "k_bwd_t1d_own"
+
+
+@pytest.mark.parametrize("B,T,Q", [(32, 512, 700), (40, 512, 960), (24, 512, 300)])
+def test_row_ownership_beyond_one_round_of_workgroups(B, T, Q, dev, MSDA):
+    """B*M > 128: 2 B*M workgroups run in rounds; the two workgroups of a slab take adjacent positions on their XCD.  B = 32
+    with few chunks stays on the chunked form (test_long_video_chunks_accumulate_in_place: 3 chunks)."""
+    _check(MSDA, dev, B=B, T=T, Q=Q, pad="zeros", seed=9000 + B + Q, oracle_rows=1, expect_kernel="k_bwd_t1d_own")
+
+
+def test_one_workgroup_per_slab_single_chunk_keeps_the_plain_form(dev, MSDA):
+    # B*M = 256 at cfg A: everything fits one carve-up -> k_bwd_t1d_d64 (no chunks, no pair form)
+    _check(MSDA, dev, B=32, T=100, Q=300, pad="zeros", seed=123, oracle_rows=1, expect_kernel="k_bwd_t1d_d64")

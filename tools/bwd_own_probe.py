@@ -83,3 +83,8 @@ for dt in (torch.float32, torch.bfloat16):
 if os.environ.get("SWEEP"):
     for qc in (128, 192, 256, 320, 384):
         run(512, 960, 1, torch.float32, f"qc={qc}", {"GVL_MSDA_BWD_OWN_QC": str(qc)})
+if os.environ.get("BIGB"):
+    B = int(os.environ["BIGB"])
+    for T, Q, rd in ((512, 960, 1), (512, 300, 2)):
+        run(T, Q, rd, torch.float32, "default", {})
+        run(T, Q, rd, torch.float32, "OWN=0", {"GVL_MSDA_BWD_OWN": "0"})
