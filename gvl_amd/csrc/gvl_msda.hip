@@ -1854,8 +1854,13 @@ int bwd_own_chunk(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan
   // us / 139 vs 137 us -- the pair form repeats the coefficient arithmetic in both workgroups and wins from 4 chunks on)
   if (B * M >= 256 && plan.ok && bwd_chunks(B, M, Q, S, plan.rowsV) < 4) return 0;
   // two workgroups per slab: B*M = 128 ... 255 fills the chip in one round (what bwd_groups gives the chunked form too);
-  // larger batches run 2 B*M workgroups in rounds (pairs adjacent on their XCD: needs B*M % 8 == 0)
-  if (L != 4 || P != 4 || !plan.ok || !shapes_host || Q < 2 || B * M < 128 || (B * M >= 256 && (B * M) % 8)) return 0;
+  // larger batches run 2 B*M workgroups in rounds (pairs adjacent on their XCD: needs B*M % 8 == 0); smaller ones leave CUs
+  // idle but still beat the chunked form's 3-4 partial slabs per (b,m) down to B*M = 64 (T = 512, encoder / decoder shape:
+  // B = 12 81 vs 137 / 35 vs 60 us, B = 8 77 vs 73 / 33 vs 36 us; B = 4: 75 vs 41 us -- the chunked form spreads a slab over 8
+  // workgroups there)
+  if (L != 4 || P != 4 || !plan.ok || !shapes_host || Q < 2 || B * M < env_int("GVL_MSDA_BWD_OWN_MINBM", 64) ||
+      (B * M >= 256 && (B * M) % 8))
+    return 0;
   const int n0 = (int)(shapes_host[1] + shapes_host[7]), n1 = (int)(shapes_host[3] + shapes_host[5]);   // {0,3} | {1,2}
   const int n_own = n0 > n1 ? n0 : n1;
   if (n_own > 64 * kOwnNU) return 0;

@@ -245,9 +245,10 @@ def test_row_ownership_odd_shapes(T, Q, pad, dev, MSDA):
         assert _lib.lib().gvl_msda_last_kernel().decode() != "k_bwd_t1d_own"
 
 
-@pytest.mark.parametrize("B,T,Q", [(32, 512, 700), (40, 512, 960), (24, 512, 300)])
+@pytest.mark.parametrize("B,T,Q", [(32, 512, 700), (40, 512, 960), (24, 512, 300), (8, 512, 500), (12, 512, 960)])
 def test_row_ownership_beyond_one_round_of_workgroups(B, T, Q, dev, MSDA):
-    """B*M > 128: 2 B*M workgroups run in rounds; the two workgroups of a slab take adjacent positions on their XCD.  B = 32
+    """B*M > 128: 2 B*M workgroups run in rounds; the two workgroups of a slab take adjacent positions on their XCD; B*M = 64,
+    96: fewer workgroups than CUs (still ahead of the chunked form's partial slabs).  B = 32
     with few chunks stays on the chunked form (test_long_video_chunks_accumulate_in_place: 3 chunks)."""
     _check(MSDA, dev, B=B, T=T, Q=Q, pad="zeros", seed=9000 + B + Q, oracle_rows=1, expect_kernel="k_bwd_t1d_own")
 
