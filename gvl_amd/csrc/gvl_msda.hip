@@ -1347,15 +1347,11 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
   // round of 256 and on one XCD.  B*M > 128 (dbg & 8, B*M % 8 == 0): 2 B*M workgroups run in several rounds, so the PAIR gets
   // consecutive positions on its XCD -- ids (x, k) and (x, k + 1) with x = id % 8, k = id / 8 -- and is dispatched together:
   // the second reader of every grad_out / proj row still finds it in the XCD's L2
-  int g, sidx;
-  if (dbg & 8) {
-    const int k = (int)blockIdx.x >> 3;
-    g = k & 1;
-    sidx = (k >> 1) * 8 + ((int)blockIdx.x & 7);
-  } else {
-    g = blockIdx.x / BM;                                                  // g in {0, 1}
-    sidx = blockIdx.x % BM;
-  }
+  const int id = (int)blockIdx.x, kk = id >> 3;
+  // (selects on scalars, forced back into scalar registers: as a branch the compiler treated g as a vector value and the
+  // kernel went from 5 to 37 spilled vector registers -- 77 -> 84 us)
+  const int g = __builtin_amdgcn_readfirstlane((dbg & 8) ? (kk & 1) : id / BM);                  // g in {0, 1}
+  const int sidx = __builtin_amdgcn_readfirstlane((dbg & 8) ? (kk >> 1) * 8 + (id & 7) : id % BM);
   const int bm = (dbg & 4) ? sidx : slab_of_block(sidx, BM);
   const int b = bm / M, m = bm % M;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
@@ -1848,19 +1844,24 @@ bool bwd_split_ok(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan
 // in global memory; -> queries per phase-B chunk, 0 = not eligible
 int bwd_own_chunk(int B, int S, int M, int L, int P, int Q, const SlabPlan &plan, const int64_t *shapes_host) {
   if (!env_int("GVL_MSDA_BWD_OWN", 1)) return 0;
-  // B*M >= 256: one workgroup per slab already covers the chip; the pair form only pays where that workgroup would have to
-  // walk several query chunks (read-modify-write of its slab per chunk)
-  // (measured at T = 512, B = 32 / 64: 960 queries = 8 chunks: 230 -> 174 us / 468 -> 392 us; 300 queries = 3 chunks: 70 vs 76
-  // us / 139 vs 137 us -- the pair form repeats the coefficient arithmetic in both workgroups and wins from 4 chunks on)
-  if (B * M >= 256 && plan.ok && bwd_chunks(B, M, Q, S, plan.rowsV) < 4) return 0;
-  // two workgroups per slab: B*M = 128 ... 255 fills the chip in one round (what bwd_groups gives the chunked form too);
-  // larger batches run 2 B*M workgroups in rounds (pairs adjacent on their XCD: needs B*M % 8 == 0); smaller ones leave CUs
-  // idle but still beat the chunked form's 3-4 partial slabs per (b,m) down to B*M = 64 (T = 512, encoder / decoder shape:
-  // B = 12 81 vs 137 / 35 vs 60 us, B = 8 77 vs 73 / 33 vs 36 us; B = 4: 75 vs 41 us -- the chunked form spreads a slab over 8
-  // workgroups there)
   if (L != 4 || P != 4 || !plan.ok || !shapes_host || Q < 2 || B * M < env_int("GVL_MSDA_BWD_OWN_MINBM", 64) ||
       (B * M >= 256 && (B * M) % 8))
     return 0;
+  // WHERE the pair form pays (round 4, T = 100 ... 512, B = 4 ... 64, fused entry points, back to back): it removes the
+  // chunked form's read-modify-write of a partial slab per query chunk and k_sum_partials, at the price of the coefficient
+  // arithmetic done in both workgroups of a slab -- a win for LONG slabs (level 0 in global memory: B = 16, T = 512: 128 -> 77
+  // us encoder / 50 -> 32 us decoder shape; B = 12: 137 -> 81 / 60 -> 35; B = 8: 73 vs 77 / 36 -> 33) and wherever a workgroup
+  // of the chunked form would walk two or more chunks; a loss for short slabs that fit one carve-up (B = 8, T = 100: 21 vs 35
+  // us; B = 24, T = 200: 53 vs 64) -- those stay on the chunked / level-split forms.  B*M >= 256 (one workgroup per slab
+  // already covers the chip, 2 B*M workgroups run in rounds): from four chunks on (B = 32, T = 512: 960 queries 230 -> 174 us,
+  // 300 queries 70 vs 76).
+  {
+    const int n_old = bwd_chunks(B, M, Q, S, plan.rowsV);
+    if (n_old <= 0) return 0;
+    const int g_old = bwd_groups(B, M, n_old);
+    const bool pays = B * M >= 256 ? n_old >= 4 : (plan.l0g || (n_old + g_old - 1) / g_old >= 2);
+    if (!pays && !env_int("GVL_MSDA_BWD_OWN_ALWAYS", 0)) return 0;
+  }
   const int n0 = (int)(shapes_host[1] + shapes_host[7]), n1 = (int)(shapes_host[3] + shapes_host[5]);   // {0,3} | {1,2}
   const int n_own = n0 > n1 ? n0 : n1;
   if (n_own > 64 * kOwnNU) return 0;

@@ -137,11 +137,13 @@ def last_kernel():
 
 @pytest.mark.parametrize("T,Q", [(512, 300), (512, 960), (512, 777), (200, 375), (300, 450)])
 @pytest.mark.parametrize("pad", ["zeros", "border"])
-def test_row_ownership_backward_matches_generic_and_oracle(T, Q, pad, dev, MSDA):
-    """B*M = 128 (two workgroups per slab) with more queries than one LDS carve-up holds: every grad_value row is owned
+def test_row_ownership_backward_matches_generic_and_oracle(T, Q, pad, dev, MSDA, monkeypatch):
+    """(GVL_MSDA_BWD_OWN_ALWAYS: the form is selected wherever it is ELIGIBLE -- by default short slabs that fit one carve-up stay
+    on the chunked form, which is faster there; the kernel must be right on them all the same.)  B*M = 128 (two workgroups per slab) with more queries than one LDS carve-up holds: every grad_value row is owned
     by one wavefront across all query chunks and written once (no workspace, no k_sum_partials).  T = 512: level 0 read
     from global memory, 1-3 chunks; T = 200 / 300: whole slab in LDS, 1-2 chunks, ragged last chunk / odd halves."""
     from gvl_amd import _lib
+    monkeypatch.setenv("GVL_MSDA_BWD_OWN_ALWAYS", "1")
     _check(MSDA, dev, B=16, T=T, Q=Q, pad=pad, seed=1000 + T + Q, oracle_rows=2, expect_kernel="k_bwd_t1d_own")
     from helpers import level_lengths
     lens = level_lengths(T)
@@ -231,12 +233,13 @@ def test_row_ownership_bf16_storage_equals_rounded_fp32(T, Q, dev, MSDA):
 
 @pytest.mark.parametrize("T,Q,pad", [(24, 1500, "zeros"), (131, 333, "border"), (257, 64, "zeros"), (600, 130, "zeros"),
                                      (411, 901, "border"), (512, 2, "zeros")])
-def test_row_ownership_odd_shapes(T, Q, pad, dev, MSDA):
+def test_row_ownership_odd_shapes(T, Q, pad, dev, MSDA, monkeypatch):
     """short videos with very many queries (tiny levels, many chunks), odd level lengths, a level length just past a power
     of two, the longest video the register accumulators hold (T = 600 -> 675 owned rows... of which {0,3} = 600 + 75 > 640
     falls back to the chunked kernel: asserted), two queries"""
     from gvl_amd import _lib
     from helpers import level_lengths
+    monkeypatch.setenv("GVL_MSDA_BWD_OWN_ALWAYS", "1")
     lens = level_lengths(T)
     own = max(lens[0] + lens[3], lens[1] + lens[2]) <= 640
     _check(MSDA, dev, B=16, T=T, Q=Q, pad=pad, seed=7000 + T + Q, oracle_rows=1,
@@ -256,3 +259,11 @@ def test_row_ownership_beyond_one_round_of_workgroups(B, T, Q, dev, MSDA):
 def test_one_workgroup_per_slab_single_chunk_keeps_the_plain_form(dev, MSDA):
     # B*M = 256 at cfg A: everything fits one carve-up -> k_bwd_t1d_d64 (no chunks, no pair form)
     _check(MSDA, dev, B=32, T=100, Q=300, pad="zeros", seed=123, oracle_rows=1, expect_kernel="k_bwd_t1d_d64")
+
+
+def test_short_slabs_stay_on_the_faster_forms(dev, MSDA):
+    """the default selection: a slab that fits one LDS carve-up per workgroup is not handed to the pair form (B = 8, T = 100:
+    21 us chunked + partial sum against 35 us; B = 24, T = 200: 53 against 64 us), long slabs are"""
+    for B, T, Q, want in ((8, 100, 300, "k_bwd_t1d_d64"), (24, 200, 300, "k_bwd_t1d_d64"), (16, 100, 300, "k_bwd_t1d_split"),
+                          (16, 512, 300, "k_bwd_t1d_own"), (12, 512, 960, "k_bwd_t1d_own")):
+        _check(MSDA, dev, B=B, T=T, Q=Q, pad="zeros", seed=B + T + Q, oracle_rows=1, expect_kernel=want)

@@ -85,6 +85,6 @@ if os.environ.get("SWEEP"):
         run(512, 960, 1, torch.float32, f"qc={qc}", {"GVL_MSDA_BWD_OWN_QC": str(qc)})
 if os.environ.get("BIGB"):
     B = int(os.environ["BIGB"])
-    for T, Q, rd in ((512, 960, 1), (512, 300, 2)):
+    for T, Q, rd in ((512, 960, 1), (512, 300, 2), (100, 300, 2), (100, 188, 1), (200, 300, 2)):
         run(T, Q, rd, torch.float32, "default", {})
         run(T, Q, rd, torch.float32, "OWN=0", {"GVL_MSDA_BWD_OWN": "0"})
