@@ -464,7 +464,7 @@ def main():
     S = sum(lens)
     vb = 2 if a.dtype == "bf16" else 4
     from gvl_amd.pdvc import autocast_inference_policy as _aip
-    vb_eval = 4 if (a.dtype == "f32" or _aip() == "fp32") else 2      # (autocast inference as an fp32 island: fp32 kernels)
+    vb_eval = 4 if (a.dtype == "f32" or _aip() != "bf16") else 2      # (autocast inference on the fp32-storage kernels)
     res = {}
 
     def traffic_of(cfg_key, launch):
@@ -585,6 +585,20 @@ def main():
                 del os.environ["GVL_GEMM"]
             torch.cuda.empty_cache()
 
+        # ... and the same step under torch.autocast(bfloat16) with the default autocast inference policy ("f16": the same
+        # fp32-storage path with ONE fp16 product per fp32 product -- 11-bit operands where bf16 keeps 8; gvl_amd/pdvc.py):
+        # a reduced-precision number, reported beside `value`, never as `value`
+        if (_layers.enabled() and split_gemm_enabled() and a.dtype == "f32" and not a.no_graph and not a.no_captioner
+                and not a.no_probes and _aip() == "f16"):
+            g5 = GraphedEvalForward(model, criterion, autocast_dtype=torch.bfloat16, decode_chunk=a.decode_chunk)
+            for dt in batches:
+                g5(dt)
+            el5, _ = timed_loop(g5, batches, a.steps, a.warmup, world, dev)
+            res["eval"]["autocast_f16_elapsed"] = el5
+            g5.graphs.clear()
+            del g5
+            torch.cuda.empty_cache()
+
     # ---------------------------------------------------------------------------------------------- train half
     if a.mode in ("both", "train"):
         model.train()
@@ -690,15 +704,19 @@ def main():
                    f"{len(batches)} rotating batches with 0-10 events per video and 3-20-word captions"))
     from gvl_amd.linear import split_gemm_enabled as _sge
     from gvl_amd.pdvc import autocast_inference_policy
-    island = a.dtype == "bf16" and autocast_inference_policy() == "fp32"      # eval forward under autocast = the fp32 path
+    _pol = autocast_inference_policy()
+    island = a.dtype == "bf16" and _pol != "bf16"                # eval forward under autocast = the fp32-storage path
     gemm16_on = _sge() and (a.dtype == "f32" or island)
     from gvl_amd import layers as _lay
     _lay_on = _lay.enabled() and (a.dtype == "f32" or island)
     line = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.dtype == "f32" else (
                 "torch.autocast(bfloat16): train step on bf16 storage + bf16 GEMMs (f32 accumulate / locations / captioner); "
-                + ("eval forward as an fp32 island on the hand-written inference path (faster than the bf16 library route; "
-                   "GVL_AUTOCAST_INFERENCE=bf16 for bf16 storage)" if island else "eval forward on bf16 storage + bf16 GEMMs")),
+                + (("eval forward on the hand-written fp32-storage inference path with ONE fp16 product per fp32 product "
+                    "(11-bit operands, fp32 accumulate; GVL_AUTOCAST_INFERENCE=fp32 for the exact products, =bf16 for bf16 "
+                    "storage)" if _pol == "f16" else
+                    "eval forward as an fp32 island on the hand-written inference path (GVL_AUTOCAST_INFERENCE=fp32)")
+                   if island else "eval forward on bf16 storage + bf16 GEMMs")),
             "data": "synthetic",
             "config": {"workload": workload,
                        "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
@@ -742,6 +760,16 @@ def main():
                 "note": "same run, GVL_LAYERS=torch AND GVL_GEMM=f32: every Linear of the step an exact-fp32 library GEMM "
                         "(hipBLASLt), no split-fp16 operands anywhere; the hand-written sampling / attention / criterion / "
                         "matcher kernels (exact fp32 arithmetic) stay"}
+        if "autocast_f16_elapsed" in e:
+            e5 = e["autocast_f16_elapsed"]
+            line["eval_under_autocast"] = {
+                "value": round(world * B * a.steps / e5, 3), "unit": "videos/s", "ms_per_step": round(e5 * 1e3 / a.steps, 3),
+                "policy": "f16",
+                "note": "REDUCED PRECISION, not comparable with `value`: the same step under torch.autocast(bfloat16) with the "
+                        "default policy of gvl_amd.pdvc.autocast_inference_policy -- the fp32-storage path with one fp16 "
+                        "matrix-core product per fp32 product instead of three (operands rounded to 11 bits at their row scale, "
+                        "bf16 keeps 8; fp32 accumulation, fp32 activations).  Logits within 1.4e-3 of the fp32 forward where "
+                        "the bf16 library route sits 1.1e-1 away (tools/f16_policy_probe.py)"}
         if "fp32_library_gemms_elapsed" in e:
             e2 = e["fp32_library_gemms_elapsed"]
             line["eval_with_fp32_library_gemms"] = {

@@ -673,6 +673,26 @@ def clock_probe_mhz(device=None, n_fma=20000):
     return 100.0 * cyc / max(ref, 1)
 
 
+class f16_products:
+    """``with f16_products(1):`` -- every split-fp16 product launched inside (token-loop GEMMs, the inference layers' Linear
+    kernel) spends ONE fp16 product per fp32 product instead of three: operands rounded to fp16 at their row scale (11
+    significant bits against bf16's 8), fp32 accumulation (include/gvl_msda.h: gvl_f16_products).  What inference under
+    torch.autocast runs on (gvl_amd/pdvc.py: autocast_inference_policy).  Thread-local, restored on exit; a hipGraph captured
+    inside keeps the kernels that were selected at capture."""
+
+    def __init__(self, n):
+        self.n, self.prev = int(n), None
+
+    def __enter__(self):
+        self.prev = _lib.lib().gvl_f16_products(self.n)
+        _lib.check(min(self.prev, 0), "f16_products")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().gvl_f16_products(self.prev)
+        return False
+
+
 def profile_enable(on=True):
     """on: False / 0 = off; True / 1 = per-dispatch stamps of the sampling-path kernels; 2 = additionally the projection
     kernel in front of them (stamping two consecutive launches inflates the second one's interval, see gvl_common.hpp)"""

@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 9          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 10          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -33,6 +33,7 @@ SIGNATURES = {
     "gvl_prof_enable": (_I, [_I]),
     "gvl_msda_debug_stamps": (None, [_P]),
     "gvl_clock_probe": (_I, [_P, _I, _P]),
+    "gvl_f16_products": (_I, [_I]),
     "gvl_prof_collect": (_I, [_P, _P, _P, _P, _I]),
     "gvl_msda_sample_backward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),
     "gvl_msda_sample_backward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),

@@ -299,7 +299,7 @@ __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)
 }
 
 // ---- four wavefronts, 128 x BN tile, two LDS stages: the form for few rows / few tiles (three workgroups per CU at BN = 64)
-template <int BN, int EPI>
+template <int BN, int EPI, bool X1 = false>
 __global__ void __launch_bounds__(256, 2)
     k_gemm_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                  const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
@@ -339,12 +339,12 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       glds16(Ah + a_src[u] + k0, st + (2 * wave + u) * 64);
-      glds16(Al + a_src[u] + k0, st + kASlots + (2 * wave + u) * 64);
+      if constexpr (!X1) glds16(Al + a_src[u] + k0, st + kASlots + (2 * wave + u) * 64);
     }
 #pragma unroll
     for (int u = 0; u < NBU; ++u) {
       glds16(Bh + b_src[u] + k0, st + 2 * kASlots + (NBU * wave + u) * 64);
-      glds16(Bl + b_src[u] + k0, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
+      if constexpr (!X1) glds16(Bl + b_src[u] + k0, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
     }
   };
 
@@ -373,10 +373,10 @@ __global__ void __launch_bounds__(256, 2)
   for (int kt = 0; kt + 1 < KT; ++kt) {
     const int buf = kt & 1;
     issue((kt + 1) * kBK, buf ^ 1);             // the other buffer was last read one barrier ago
-    mfma_stage<NJ>(smem + buf * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
+    mfma_stage<NJ, X1>(smem + buf * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
     __syncthreads();
   }
-  mfma_stage<NJ>(smem + ((KT - 1) & 1) * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
+  mfma_stage<NJ, X1>(smem + ((KT - 1) & 1) * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
   // (kLstm: one 32-row block at a time -- 64 registers fewer than both in flight, which keeps three workgroups on a CU; the
   //  other workgroups' products cover the block's load latency)
   epilogue<NJ, EPI, true>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo, le);
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256, 2)
 // bytes per FLOP.  One barrier per stage: counted `s_waitcnt vmcnt` (this wavefront's DMA of the stage about to be read
 // is complete, the next stage's stays in flight), raw s_barrier (everybody's is, and everybody has finished reading the
 // buffer that is refilled next), then the DMA of stage kt + 2, then the MFMAs of stage kt.
-template <int WM, int WN, int NJ, int EPI>
+template <int WM, int WN, int NJ, int EPI, bool X1 = false>
 __global__ void __launch_bounds__(512, 1)
     k_gemm_f16x3_w8(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                     const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
@@ -433,10 +433,13 @@ __global__ void __launch_bounds__(512, 1)
     uint4 *st = smem + buf * kStageSlots;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
+      // (which plane a unit belongs to is a compile-time fact: 8 wavefronts' units of one i lie inside one plane)
+      if (X1 && (i < WM ? 8 * i / (4 * WM) : 8 * (i - WM) / (kRowsB / 16))) continue;
       const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
       glds16(base[i] + (row * K + schunk + k0), st + dst[i]);
     }
   };
+  constexpr int kDma = X1 ? NG / 2 : NG;                              // DMA instructions per wavefront and stage
 
   f16acc acc_m[2][NJ], acc_x[2][NJ];
 #pragma unroll
@@ -468,12 +471,12 @@ __global__ void __launch_bounds__(512, 1)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       ah[i] = *reinterpret_cast<const h8 *>(&st[fa[s] + 128 * i]);
-      al[i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[s] + 128 * i]);
+      if constexpr (!X1) al[i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[s] + 128 * i]);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       bh[j] = *reinterpret_cast<const h8 *>(&st[fb[s] + 128 * j]);
-      bl[j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[s] + 128 * j]);
+      if constexpr (!X1) bl[j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[s] + 128 * j]);
     }
   };
   auto mfma12 = [&](const h8 (&ah)[2], const h8 (&al)[2], const h8 (&bh)[NJ], const h8 (&bl)[NJ]) {
@@ -482,8 +485,10 @@ __global__ void __launch_bounds__(512, 1)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
-        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
-        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        if constexpr (!X1) {
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        }
       }
   };
 
@@ -500,8 +505,7 @@ __global__ void __launch_bounds__(512, 1)
   issue(tm, tn, 0, 0);
   issue(tm, tn, kBK, 1);
   issue(tm, tn, 2 * kBK, 2);
-  if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  wait_vmcnt<2 * kDma>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   h8 p_ah[2], p_al[2], p_bh[NJ], p_bl[NJ];                            // first K half of the stage at hand
@@ -515,16 +519,24 @@ __global__ void __launch_bounds__(512, 1)
     mfma12(p_ah, p_al, p_bh, p_bl);
 #ifndef GVL_NO_SCHED_GROUPS
     // (4 + 2 NJ) fragment reads of the next half between the 6 NJ MFMAs of this one
+    if constexpr (!X1) {
 #pragma unroll
-    for (int g = 0; g < 4 + 2 * NJ; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      for (int g = 0; g < 4 + 2 * NJ; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      if constexpr (NJ == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    } else {                                                           // (2 + NJ) reads, 2 NJ MFMAs
+#pragma unroll
+      for (int g = 0; g < 2 * NJ; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 - NJ, 0);
     }
-    if constexpr (NJ == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #endif
     // the next stage has landed (this wavefront's part; the barrier makes it everybody's); the one after stays in flight
-    if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    wait_vmcnt<kDma>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my reads of this stage are complete
 #ifndef GVL_ABLATE_BARRIER
     __builtin_amdgcn_s_barrier();
@@ -539,7 +551,14 @@ __global__ void __launch_bounds__(512, 1)
     frags(smem + nbuf * kStageSlots, 0, p_ah, p_al, p_bh, p_bl);     // (stage 0 of the next tile at a tile's end)
     mfma12(q_ah, q_al, q_bh, q_bl);
 #ifndef GVL_NO_SCHED_GROUPS
-    if constexpr (NJ == 2) {                                           // 6 DMA, 8 reads, 12 MFMAs
+    if constexpr (X1) {                                                // kDma DMA, 2 + NJ reads, 2 NJ MFMAs
+#pragma unroll
+      for (int g = 0; g < 2 * NJ; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    } else if constexpr (NJ == 2) {                                    // 6 DMA, 8 reads, 12 MFMAs
 #pragma unroll
       for (int g = 0; g < 6; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -677,7 +696,7 @@ __device__ __forceinline__ void epilogue16(f4acc4 (&acc_m)[4][4], f4acc4 (&acc_x
   }
 }
 
-template <int WM, int WN, int EPI>
+template <int WM, int WN, int EPI, bool X1 = false>
 __global__ void __launch_bounds__(512, 1)
     k_gemm_f16x3_m16(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                      const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
@@ -714,10 +733,12 @@ __global__ void __launch_bounds__(512, 1)
     uint4 *st = smem + buf * kStageSlots;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
+      if (X1 && (i < WM ? 8 * i / (4 * WM) : 8 * (i - WM) / (4 * WN))) continue;       // lo-plane units (see k_gemm_f16x3_w8)
       const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
       glds16(base[i] + (row * K + schunk + k0), st + dst[i]);
     }
   };
+  constexpr int kDma = X1 ? NG / 2 : NG;
 
   f4acc4 acc_m[4][4], acc_x[4][4];
 #pragma unroll
@@ -732,28 +753,44 @@ __global__ void __launch_bounds__(512, 1)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f.h[u] = *reinterpret_cast<const h8 *>(&st[fa + 64 * (i0 + u)]);
-      f.l[u] = *reinterpret_cast<const h8 *>(&st[kASlots + fa + 64 * (i0 + u)]);
+      if constexpr (!X1) f.l[u] = *reinterpret_cast<const h8 *>(&st[kASlots + fa + 64 * (i0 + u)]);
     }
   };
   auto rdB = [&](const uint4 *st, int j0, Frag &f) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f.h[u] = *reinterpret_cast<const h8 *>(&st[fb + 64 * (j0 + u)]);
-      f.l[u] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb + 64 * (j0 + u)]);
+      if constexpr (!X1) f.l[u] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb + 64 * (j0 + u)]);
     }
   };
 #define GVL_QUARTER(A, B, I0, J0)                                                                                  \
   _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v) {                     \
     acc_m[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[u], B.h[v], acc_m[I0 + u][J0 + v], 0, 0, 0); \
-    acc_x[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[u], B.l[v], acc_x[I0 + u][J0 + v], 0, 0, 0); \
-    acc_x[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.l[u], B.h[v], acc_x[I0 + u][J0 + v], 0, 0, 0); \
+    if constexpr (!X1) {                                                                                             \
+      acc_x[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[u], B.l[v], acc_x[I0 + u][J0 + v], 0, 0, 0); \
+      acc_x[I0 + u][J0 + v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.l[u], B.h[v], acc_x[I0 + u][J0 + v], 0, 0, 0); \
+    }                                                                                                                \
   }
-#define GVL_GROUPS_READS()  /* 4 fragment reads among 12 MFMAs */                                                   \
+#define GVL_GROUPS_READS()  /* 4 fragment reads among 12 MFMAs (X1: 2 among 4) */                                  \
+  if constexpr (X1) {                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+    }                                                                                                                \
+  } else                                                                                                             \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                   \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
   }
-#define GVL_GROUPS_DMA()    /* 6 DMA + 4 fragment reads among 12 MFMAs */                                           \
+#define GVL_GROUPS_DMA()    /* 6 DMA + 4 fragment reads among 12 MFMAs (X1: 3 + 2 among 4) */                       \
+  if constexpr (X1) {                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+  } else {                                                                                                           \
   _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                                   \
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
@@ -765,13 +802,14 @@ __global__ void __launch_bounds__(512, 1)
   _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                   \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+  }                                                                                                                  \
   }
 
   const int KT = K / kBK;                                             // even and >= 4 (host)
   issue(tm, tn, 0, 0);
   issue(tm, tn, kBK, 1);
   issue(tm, tn, 2 * kBK, 2);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  wait_vmcnt<2 * kDma>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   Frag a01, a23, bX, bY;                                              // bX: columns 0-1 of the stage at hand
@@ -789,7 +827,7 @@ __global__ void __launch_bounds__(512, 1)
     rdA(st, 2, a23);                                                                                                 \
     GVL_QUARTER(a01, bB, 0, 2)                                                                                       \
     GVL_GROUPS_READS()                                                                                               \
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                 \
+    wait_vmcnt<kDma>();                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
     __builtin_amdgcn_s_barrier();                                                                                    \
     asm volatile("" ::: "memory");                                                                                   \
@@ -938,6 +976,15 @@ int check_operands(const char *what, const void *a_hi, const void *a_lo, const f
 
 }  // namespace
 
+thread_local int gvl16::g_f16_products = 3;
+
+extern "C" int gvl_f16_products(int n) {
+  const int prev = gvl16::g_f16_products;
+  if (n == 1 || n == 3) gvl16::g_f16_products = n;
+  else if (n != 0) return fail(GVL_EINVAL, "gvl_f16_products: 3 (exact split), 1 (leading product only) or 0 (query), got %d", n);
+  return prev;
+}
+
 extern "C" int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *lo, float *scale, void *stream) {
   if (R < 0 || K <= 0 || (K & 3)) return fail(GVL_EINVAL, "gvl_split_rows_f16: needs K %% 4 == 0 (got R=%d K=%d)", R, K);
   if (R == 0) return 0;
@@ -951,6 +998,7 @@ extern "C" int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *
 extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi,
                                   const void *b_lo, const float *b_scale, int N, int K, const float *bias, float *out,
                                   int64_t ldo, void *stream) {
+  const bool x1 = gvl16::g_f16_products == 1;
   if (int rc = check_operands("gvl_gemm_f16x3_f32", a_hi, a_lo, a_scale, R, b_hi, b_lo, b_scale, N, K)) return rc;
   if (ldo < N) return fail(GVL_EINVAL, "gvl_gemm_f16x3_f32: ldo < N");
   if (R == 0) return 0;
@@ -967,19 +1015,19 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
       const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
       // (the 16 x 16 x 32 form stores 64-byte row segments: 190 against 180 us back to back for 4800 x 512 x 8518 --
       //  it is used where nothing is stored, the argmax form)
-      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<4, 2, 2, kStore>,
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", (x1 ? k_gemm_f16x3_w8<4, 2, 2, kStore, true> : k_gemm_f16x3_w8<4, 2, 2, kStore, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, LstmEpi{});
     }
     if (t_mid >= 384 && !getenv("GVL_GEMM16_NO_MID")) {
       const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
-      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", k_gemm_f16x3_w8<2, 4, 1, kStore>,
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", (x1 ? k_gemm_f16x3_w8<2, 4, 1, kStore, true> : k_gemm_f16x3_w8<2, 4, 1, kStore, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, LstmEpi{});
     }
   }
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
-  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", k_gemm_f16x3<64, kStore>, dim3((tiles_m * tiles_n + 7) / 8 * 8),
+  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", (x1 ? k_gemm_f16x3<64, kStore, true> : k_gemm_f16x3<64, kStore, false>), dim3((tiles_m * tiles_n + 7) / 8 * 8),
                      dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, b_scale, bias, R, N, K, out, ldo, tiles_m,
                      tiles_n, LstmEpi{});
 }
@@ -989,6 +1037,7 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
                                        int64_t ld_h, const float *gates_c, int64_t ld_c, const float *emb_gates,
                                        const int64_t *it, const float *c, float *h_out, float *c_out, void *h_hi,
                                        void *h_lo, float *h_scale, void *stream) {
+  const bool x1 = gvl16::g_f16_products == 1;
   const int N = 4 * H;
   if (H <= 0 || (H & 7)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: H must be a positive multiple of 8 (got %d)", H);
   if (int rc = check_operands("gvl_gemm_f16x3_lstm_f32", a_hi, a_lo, a_scale, R, w_hi, w_lo, w_scale, N, K)) return rc;
@@ -1012,20 +1061,20 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
     const int t_big = ((R + 255) / 256) * ((N + 127) / 128), t_mid = ((R + 127) / 128) * ((N + 127) / 128);
     if (t_big >= 1024) {
       const int tiles_m = (R + 255) / 256, tiles_n = (N + 127) / 128;
-      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8<lstm>", k_gemm_f16x3_w8<4, 2, 2, kLstm>,
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8<lstm>", (x1 ? k_gemm_f16x3_w8<4, 2, 2, kLstm, true> : k_gemm_f16x3_w8<4, 2, 2, kLstm, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, w_scale, (const float *)nullptr, R, N, K, (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
     }
     if (t_mid >= 384 && !getenv("GVL_GEMM16_NO_MID")) {
       const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
-      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8<lstm>", k_gemm_f16x3_w8<2, 4, 1, kLstm>,
+      return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8<lstm>", (x1 ? k_gemm_f16x3_w8<2, 4, 1, kLstm, true> : k_gemm_f16x3_w8<2, 4, 1, kLstm, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, w_scale, (const float *)nullptr, R, N, K, (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
     }
   }
   // (128 x 128 tiles on this kernel, two workgroups per CU: 10.44 against 10.17 ms per eval step)
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
-  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3<lstm>", k_gemm_f16x3<64, kLstm>, dim3((tiles_m * tiles_n + 7) / 8 * 8),
+  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3<lstm>", (x1 ? k_gemm_f16x3<64, kLstm, true> : k_gemm_f16x3<64, kLstm, false>), dim3((tiles_m * tiles_n + 7) / 8 * 8),
                      dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, w_scale, (const float *)nullptr, R, N, K,
                      (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
 }
@@ -1035,6 +1084,7 @@ extern "C" int gvl_gemm_f16x3_argmax_chunks(int V) { return V > 0 ? (V + kBM - 1
 extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, const float *x_scale, int R, const void *w_hi,
                                          const void *w_lo, const float *w_scale, int V, int K, const float *bias,
                                          float *partials, void *stream) {
+  const bool x1 = gvl16::g_f16_products == 1;
   if (int rc = check_operands("gvl_gemm_f16x3_argmax_f32", x_hi, x_lo, x_scale, R, w_hi, w_lo, w_scale, V, K)) return rc;
   if (R == 0) return 0;
   if (!partials || ((uintptr_t)partials & 15)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_argmax_f32: partials null / unaligned");
@@ -1045,15 +1095,15 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   if (R >= 1024 && K >= 3 * kBK && !(aform && atoi(aform) == 4)) {
     const int tiles_n = (R + 255) / 256;
     if (use_m16(K))
-      return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_m16<argmax>", k_gemm_f16x3_m16<2, 4, kArgmax>,
+      return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_m16<argmax>", (x1 ? k_gemm_f16x3_m16<2, 4, kArgmax, true> : k_gemm_f16x3_m16<2, 4, kArgmax, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh,
                          xl, x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n);
-    return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", k_gemm_f16x3_w8<2, 4, 2, kArgmax>,
+    return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_w8<argmax>", (x1 ? k_gemm_f16x3_w8<2, 4, 2, kArgmax, true> : k_gemm_f16x3_w8<2, 4, 2, kArgmax, false>),
                        dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
                        x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n, LstmEpi{});
   }
   const int tiles_n = (R + 63) / 64;
-  return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3<argmax>", k_gemm_f16x3<64, kArgmax>,
+  return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3<argmax>", (x1 ? k_gemm_f16x3<64, kArgmax, true> : k_gemm_f16x3<64, kArgmax, false>),
                      dim3((tiles_m * tiles_n + 7) / 8 * 8), dim3(256), 0, (hipStream_t)stream, wh, wl, w_scale, xh, xl,
                      x_scale, bias, V, R, K, partials, (int64_t)0, tiles_m, tiles_n, LstmEpi{});
 }

@@ -12,6 +12,8 @@ typedef float f16acc __attribute__((ext_vector_type(16)));
 
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
+extern thread_local int g_f16_products;      // 3 | 1 (gvl_f16_products; defined in gvl_gemm16.hip)
+
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kBM = 128, kBK = 32, kGroupM = 8;
 
@@ -67,8 +69,11 @@ __device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int &
   return true;
 }
 
+// Number of fp16 products per fp32 product (gvl_f16_products): 3 = the exact split (hi.hi, hi.lo, lo.hi), 1 = the leading
+// product only -- operands rounded to fp16 at their row scale (11 significant bits; bf16 keeps 8), fp32 accumulation: what
+// inference under torch.autocast runs on.  X1 kernels neither fetch nor read the lo planes.
 // the 24 (NJ = 2) MFMAs of one wavefront on one K stage of 32: fragments at slots fa / fb of the stage image `st`
-template <int NJ>
+template <int NJ, bool X1 = false>
 __device__ __forceinline__ void mfma_stage(const uint4 *st, int a_lo_off, int b_lo_off, const int (&fa)[2][2],
                                            const int (&fb)[NJ][2], f16acc (&acc_m)[2][NJ], f16acc (&acc_x)[2][NJ]) {
   // all fragment reads of the stage first: the second K half lands under the MFMAs of the first
@@ -89,12 +94,12 @@ __device__ __forceinline__ void mfma_stage(const uint4 *st, int a_lo_off, int b_
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       f_ah[s][i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);
-      f_al[s][i] = *reinterpret_cast<const h8 *>(&st[a_lo_off + fa[i][s]]);
+      if constexpr (!X1) f_al[s][i] = *reinterpret_cast<const h8 *>(&st[a_lo_off + fa[i][s]]);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       f_bh[s][j] = *reinterpret_cast<const h8 *>(&st[fb[j][s]]);
-      f_bl[s][j] = *reinterpret_cast<const h8 *>(&st[b_lo_off + fb[j][s]]);
+      if constexpr (!X1) f_bl[s][j] = *reinterpret_cast<const h8 *>(&st[b_lo_off + fb[j][s]]);
     }
   }
 #pragma unroll
@@ -104,10 +109,16 @@ __device__ __forceinline__ void mfma_stage(const uint4 *st, int a_lo_off, int b_
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bh[s][j], acc_m[i][j], 0, 0, 0);
-        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s][j], acc_x[i][j], 0, 0, 0);
-        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s][j], acc_x[i][j], 0, 0, 0);
+        if constexpr (!X1) {
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s][j], acc_x[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s][j], acc_x[i][j], 0, 0, 0);
+        }
       }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 }  // namespace gvl16

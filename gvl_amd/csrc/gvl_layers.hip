@@ -90,7 +90,8 @@ __device__ __forceinline__ void split4(const float4 &x, float inv, uint2 &hi, ui
 //   <4, 2, 1, 2>  128 x 128 tile, 8 wavefronts: each A element is split once per 128 output columns instead of once per 64
 //                 and a stage carries twice the MFMA work per barrier (the split arithmetic, not the matrix cores, bounds
 //                 the narrow shape: tools/lin_ksweep.py).
-template <bool HAS_A2, int WM, int WN, int NI, int NJ>
+// X1: the leading fp16 product only (gvl_f16_products(1): inference under autocast) -- no lo planes are formed, fetched or read.
+template <bool HAS_A2, int WM, int WN, int NI, int NJ, bool X1 = false>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f16x3(const LinParams p) {
   constexpr int kThreads = 64 * WM * WN, kNW = WM * WN, kBN = 32 * NJ * WN;
   static_assert(32 * NI * WM == kBM, "128 rows per tile");
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
       for (int i = 0; i < NA; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off[i], k0 * 4, 0);
     }
     s.wh = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_off, k0 * 2, 0);
-    s.wl = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off, k0 * 2, 0);
+    if constexpr (!X1) s.wl = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off, k0 * 2, 0);
   };
   auto store_a = [&](ASet &s, int buf) {
     char *st = reinterpret_cast<char *>(smem + buf * kStageSlots);
@@ -188,12 +189,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
         x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
       }
       uint2 hi, lo;
-      split4(x, a_inv[i], hi, lo);
+      if constexpr (X1) {
+        hi = make_uint2(pack2((_Float16)(x.x * a_inv[i]), (_Float16)(x.y * a_inv[i])),
+                        pack2((_Float16)(x.z * a_inv[i]), (_Float16)(x.w * a_inv[i])));
+      } else {
+        split4(x, a_inv[i], hi, lo);
+        *reinterpret_cast<uint2 *>(st + kASlots * 16 + a_dst[i]) = lo;
+      }
       *reinterpret_cast<uint2 *>(st + a_dst[i]) = hi;
-      *reinterpret_cast<uint2 *>(st + kASlots * 16 + a_dst[i]) = lo;
     }
     reinterpret_cast<uint4 *>(st)[w_dst] = __builtin_bit_cast(uint4, s.wh);
-    reinterpret_cast<uint4 *>(st)[kBSlots + w_dst] = __builtin_bit_cast(uint4, s.wl);
+    if constexpr (!X1) reinterpret_cast<uint4 *>(st)[kBSlots + w_dst] = __builtin_bit_cast(uint4, s.wl);
   };
 
   f16acc acc_m[NI][NJ], acc_x[NI][NJ];
@@ -235,19 +241,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
     _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
       _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                   \
         f_ah[s][i] = *reinterpret_cast<const h8 *>(&st[fa[i][s]]);                                       \
-        f_al[s][i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[i][s]]);                             \
+        if constexpr (!X1) f_al[s][i] = *reinterpret_cast<const h8 *>(&st[kASlots + fa[i][s]]);          \
       }                                                                                                  \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
         f_bh[s][j] = *reinterpret_cast<const h8 *>(&st[fb[j][s]]);                                       \
-        f_bl[s][j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[j][s]]);                             \
+        if constexpr (!X1) f_bl[s][j] = *reinterpret_cast<const h8 *>(&st[kBSlots + fb[j][s]]);          \
       }                                                                                                  \
     }                                                                                                    \
     store_a(cur, buf ^ 1);                                                                               \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < NI; ++i)         \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                     \
       acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bh[s][j], acc_m[i][j], 0, 0, 0); \
-      acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s][j], acc_x[i][j], 0, 0, 0); \
-      acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s][j], acc_x[i][j], 0, 0, 0); \
+      if constexpr (!X1) {                                                                               \
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_ah[s][i], f_bl[s][j], acc_x[i][j], 0, 0, 0); \
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_al[s][i], f_bh[s][j], acc_x[i][j], 0, 0, 0); \
+      }                                                                                                  \
     }                                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
     __builtin_amdgcn_s_barrier();                                                                        \
@@ -961,16 +969,23 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n >= 8;
   const int grid = (p.tiles_m * p.tiles_n + 7) / 8 * 8;
   hipStream_t st = (hipStream_t)stream;
+  const bool x1 = gvl16::g_f16_products == 1;
   if (wide) {
     if (any_addend)
-      return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128,addend>", k_lin_f16x3<true, 4, 2, 1, 2>, dim3(grid), dim3(512),
+      return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128,addend>",
+                         x1 ? k_lin_f16x3<true, 4, 2, 1, 2, true> : k_lin_f16x3<true, 4, 2, 1, 2, false>, dim3(grid), dim3(512),
                          0, st, p);
-    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128>", k_lin_f16x3<false, 4, 2, 1, 2>, dim3(grid), dim3(512), 0, st, p);
+    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128>",
+                       x1 ? k_lin_f16x3<false, 4, 2, 1, 2, true> : k_lin_f16x3<false, 4, 2, 1, 2, false>, dim3(grid), dim3(512), 0,
+                       st, p);
   }
   if (any_addend)
-    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64,addend>", k_lin_f16x3<true, 2, 2, 2, 1>, dim3(grid), dim3(256), 0,
+    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64,addend>",
+                       x1 ? k_lin_f16x3<true, 2, 2, 2, 1, true> : k_lin_f16x3<true, 2, 2, 2, 1, false>, dim3(grid), dim3(256), 0,
                        st, p);
-  return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64>", k_lin_f16x3<false, 2, 2, 2, 1>, dim3(grid), dim3(256), 0, st, p);
+  return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64>",
+                     x1 ? k_lin_f16x3<false, 2, 2, 2, 1, true> : k_lin_f16x3<false, 2, 2, 2, 1, false>, dim3(grid), dim3(256), 0, st,
+                     p);
 }
 
 extern "C" int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float *gamma, const float *beta, float eps,

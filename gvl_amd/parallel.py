@@ -695,11 +695,18 @@ class GraphedEvalForward:
                 and slots <= min(64, self.model.opt.num_queries))
 
     def _autocast(self):
-        # inference under autocast runs as an fp32 island unless GVL_AUTOCAST_INFERENCE=bf16 (gvl_amd/pdvc.py): the decode
-        # segments captured after the main forward follow the same policy as PDVC.forward itself
-        from .pdvc import autocast_inference_policy
+        # inference under autocast follows GVL_AUTOCAST_INFERENCE (gvl_amd/pdvc.py): the fp32-storage path with one ("f16",
+        # default) or three ("fp32") fp16 products per fp32 product, or the bf16-storage path ("bf16"); the decode segments
+        # captured after the main forward follow the same policy as PDVC.forward itself
+        import contextlib
+        from . import MultiScaleDeformableAttention as MSDA
+        from .pdvc import autocast_inference_policy, autocast_products
         on = self.autocast_dtype is not None and autocast_inference_policy() == "bf16"
-        return torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=on)
+        ctx = contextlib.ExitStack()
+        ctx.enter_context(torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=on))
+        if self.autocast_dtype is not None and not on:
+            ctx.enter_context(MSDA.f16_products(autocast_products()))
+        return ctx
 
     def _forward(self, dt):
         with self._autocast():

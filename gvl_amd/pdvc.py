@@ -50,10 +50,20 @@ class MLP(nn.Module):
 
 
 def autocast_inference_policy():
-    """"fp32" (default): an inference forward under torch.autocast runs the hand-written fp32-accurate path; "bf16": the
-    bf16-storage path (library bf16 GEMMs + the _bf16 kernel twins)"""
+    """What an INFERENCE forward under torch.autocast runs on (GVL_AUTOCAST_INFERENCE):
+    "f16"  (default) the hand-written fp32-storage path with ONE fp16 matrix-core product per fp32 product instead of three
+           (MSDA.f16_products(1)): operands rounded to fp16 at their row scale -- 11 significant bits where autocast's
+           bfloat16 keeps 8 -- fp32 accumulation, fp32 activations, every fused epilogue of the fp32 path;
+    "fp32" the same path at full fp32 accuracy (three products): autocast may lower precision, it need not;
+    "bf16" the bf16-storage path (library bf16 GEMMs + the _bf16 kernel twins)."""
     import os
-    return "bf16" if os.environ.get("GVL_AUTOCAST_INFERENCE", "") == "bf16" else "fp32"
+    v = os.environ.get("GVL_AUTOCAST_INFERENCE", "")
+    return v if v in ("bf16", "fp32") else "f16"
+
+
+def autocast_products():
+    """fp16 products per fp32 product of the split-fp16 kernels under the current autocast inference policy"""
+    return 1 if autocast_inference_policy() == "f16" else 3
 
 
 class PDVC(nn.Module):
@@ -184,14 +194,16 @@ class PDVC(nn.Module):
 
     def forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
         if (torch.is_autocast_enabled() and not torch.is_grad_enabled() and not self.training
-                and dt['video_tensor'].is_cuda and autocast_inference_policy() == "fp32"):
-            # INFERENCE under torch.autocast (BASELINE config 5 is named "bf16"): the hand-written inference path -- split-fp16
-            # products at fp32 accuracy with fused epilogues, the fused token loop -- is FASTER than the bf16 library GEMMs +
-            # ATen casts autocast would route the layers through (profiles/r03_other_configs.json: yc2 T = 512, 3121 against
-            # 2936 videos/s) and more accurate, so the forward runs as an fp32 island: autocast may lower precision, it need
-            # not.  GVL_AUTOCAST_INFERENCE=bf16 restores the bf16-storage path (bf16 GEMMs, the _bf16 kernel twins); training
-            # under autocast is unaffected.
-            with torch.autocast("cuda", enabled=False):
+                and dt['video_tensor'].is_cuda and autocast_inference_policy() != "bf16"):
+            # INFERENCE under torch.autocast (BASELINE config 5 is named "bf16"): the forward stays on the hand-written
+            # fp32-storage path (fused epilogues, fused token loop) and lowers precision where autocast would -- in the Linear
+            # products -- by spending one fp16 matrix-core product per fp32 product instead of three (policy "f16", the
+            # default: 11-bit operands against bf16's 8, 1.4x the fp32 path's throughput; tools/x1_probe.py).  The bf16
+            # library GEMMs + ATen casts autocast would route the layers through are SLOWER than even the exact fp32 path
+            # (profiles/r03_other_configs.json: yc2 T = 512, 2936 against 3121 videos/s).  GVL_AUTOCAST_INFERENCE=fp32 keeps
+            # the exact products, =bf16 restores the bf16-storage path; training under autocast is unaffected.
+            from . import MultiScaleDeformableAttention as MSDA
+            with torch.autocast("cuda", enabled=False), MSDA.f16_products(autocast_products()):
                 return self.forward(dt, criterion, contrastive_criterion, transformer_input_type, eval_mode)
         N = dt['video_tensor'].shape[0]
         memory, tshapes, lsi, valid_ratios, mask_flat = self.encode(dt)

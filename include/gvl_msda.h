@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 9   /* 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 10  /* 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -234,6 +234,13 @@ int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight
  *        |error| <= 2^-21 sum_k |a||b| + K 2^-33 max_k|a| max_k|b| per output; at K >= 256 measured BELOW the summation
  *        error of an fp32 GEMM (whose chain rounds K times). */
 int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *lo, float *scale, void *stream);
+/*    gvl_f16_products(n): how many fp16 products EVERY split-fp16 entry point of this library (gvl_gemm_f16x3_*,
+ *        gvl_linear_f16x3_f32) spends per fp32 product from now on, for the calling thread: 3 = the exact split above
+ *        (default), 1 = hi.hi only -- both operands rounded to fp16 at their row scale (11 significant bits, bf16 keeps 8;
+ *        no overflow whatever the magnitude), fp32 accumulation; the lo planes are then neither fetched nor read.  This is
+ *        what the host runs the Linear layers on under `torch.autocast` (the reference's autocast runs them in bf16;
+ *        results agree with either to bf16 rounding).  n = 0 queries.  Returns the previous value, or GVL_EINVAL (< 0). */
+int gvl_f16_products(int n);
 int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi, const void *b_lo,
                        const float *b_scale, int N, int K, const float *bias, float *out, int64_t ldo, void *stream);
 /*    The same product for the vocabulary layer of GREEDY decoding, with the consumer fused (`torch.max(logprobs, 1)` over
