@@ -365,14 +365,21 @@ def proj_linear(x, weight, bias=None):
 
 class SplitPlanes:
     """an fp32 matrix as two fp16 planes and a row scale: x[r, k] = scale[r] (hi[r, k] + 2^-11 lo[r, k])
-    (include/gvl_msda.h: gvl_split_rows_f16)"""
+    (include/gvl_msda.h: gvl_split_rows_f16).  The planes are stored K-STAGE-MAJOR, (K / 32, rows, 32): the 64 bytes one K
+    stage of the GEMM kernels takes from a row lie beside the next row's, so a staging instruction reads one contiguous
+    1 KiB run; ``dense()`` gives the (rows, K) view for inspection."""
     __slots__ = ("hi", "lo", "scale", "rows", "cols")
 
     def __init__(self, rows, cols, device):
+        assert cols % 32 == 0, "operand planes need K % 32 == 0"
         self.rows, self.cols = rows, cols
-        self.hi = torch.empty(rows, cols, device=device, dtype=torch.float16)
-        self.lo = torch.empty(rows, cols, device=device, dtype=torch.float16)
+        self.hi = torch.empty(cols // 32, rows, 32, device=device, dtype=torch.float16)
+        self.lo = torch.empty(cols // 32, rows, 32, device=device, dtype=torch.float16)
         self.scale = torch.empty(rows, device=device, dtype=torch.float32)
+
+    def dense(self):
+        """-> (hi, lo) as (rows, K) tensors (copies)"""
+        return tuple(p_.permute(1, 0, 2).reshape(self.rows, self.cols) for p_ in (self.hi, self.lo))
 
 
 def split_eligible(x, k_multiple=32):

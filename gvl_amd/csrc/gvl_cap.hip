@@ -283,9 +283,10 @@ __global__ void __launch_bounds__(kWaves * 64, (FULL && sizeof(ST) == 4) ? 3 : 2
     half4_t h0, l0, h1, l1;
     split4_f16(make_float4(acc[0], acc[1], acc[2], acc[3]), inv, h0, l0);
     split4_f16(make_float4(acc[4], acc[5], acc[6], acc[7]), inv, h1, l1);
-    half4_t *ph = reinterpret_cast<half4_t *>(o_hi + row * kC), *pl = reinterpret_cast<half4_t *>(o_lo + row * kC);
-    ph[lane] = h0; ph[64 + lane] = h1;
-    pl[lane] = l0; pl[64 + lane] = l1;
+    // K-stage-major planes (gvl_gemm16_common.hpp: plane_off): channel k of row r at ((k >> 5) n + r) 32 + (k & 31)
+    const int64_t at0 = ((int64_t)(lane >> 3) * ((int64_t)B * Q) + row) * 32 + 4 * (lane & 7), at1 = at0 + (int64_t)B * Q * 256;
+    *reinterpret_cast<half4_t *>(o_hi + at0) = h0; *reinterpret_cast<half4_t *>(o_hi + at1) = h1;
+    *reinterpret_cast<half4_t *>(o_lo + at0) = l0; *reinterpret_cast<half4_t *>(o_lo + at1) = l1;
   } else {
     ST *o = att_res + row * kC;
     st4(o, lane, make_float4(acc[0], acc[1], acc[2], acc[3]));
@@ -471,9 +472,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) k_cap_attend_
     half4_t h0, l0, h1, l1;
     split4_f16(make_float4(acc[0], acc[1], acc[2], acc[3]), inv, h0, l0);
     split4_f16(make_float4(acc[4], acc[5], acc[6], acc[7]), inv, h1, l1);
-    half4_t *ph = reinterpret_cast<half4_t *>(o_hi + row * kC), *pl = reinterpret_cast<half4_t *>(o_lo + row * kC);
-    ph[lane] = h0; ph[64 + lane] = h1;
-    pl[lane] = l0; pl[64 + lane] = l1;
+    // K-stage-major planes (gvl_gemm16_common.hpp: plane_off): channel k of row r at ((k >> 5) n + r) 32 + (k & 31)
+    const int64_t at0 = ((int64_t)(lane >> 3) * ((int64_t)B * Q) + row) * 32 + 4 * (lane & 7), at1 = at0 + (int64_t)B * Q * 256;
+    *reinterpret_cast<half4_t *>(o_hi + at0) = h0; *reinterpret_cast<half4_t *>(o_hi + at1) = h1;
+    *reinterpret_cast<half4_t *>(o_lo + at0) = l0; *reinterpret_cast<half4_t *>(o_lo + at1) = l1;
   }
   }
 }
@@ -710,8 +712,9 @@ __global__ void __launch_bounds__(256) k_lstm_cell(const GT *__restrict__ ga, in
       // row (no overflow; an element below 2^-14 sits in fp16's subnormal range, absolute precision 2^-35 with the lo part)
       half4_t hi, lo;
       split4_f16(hn, 1.f, hi, lo);
-      reinterpret_cast<half4_t *>(h_hi)[idx] = hi;
-      reinterpret_cast<half4_t *>(h_lo)[idx] = lo;
+      const int64_t at = ((int64_t)(j >> 3) * n + row) * 32 + 4 * (j & 7);       // K-stage-major planes (plane_off)
+      *reinterpret_cast<half4_t *>(h_hi + at) = hi;
+      *reinterpret_cast<half4_t *>(h_lo + at) = lo;
       if (j == 0) h_scale[row] = 1.f;
     }
   }
@@ -794,6 +797,7 @@ int lstm_cell_impl(const char *what, const GT *gates_a, int lda, const GT *gates
                    float *c_out, GT *h_gemm, void *stream, void *h_hi = nullptr, void *h_lo = nullptr,
                    float *h_scale = nullptr) {
   if (h_hi && (!h_lo || !h_scale)) return fail(GVL_EINVAL, "%s: null pointer", what);
+  if (h_hi && (H & 31)) return fail(GVL_EINVAL, "%s: operand planes need H %% 32 == 0 (got %d)", what, H);
   if (n < 0 || H <= 0 || (H & 3) || lda < 4 * H || ldb < 4 * H || (lda & 3) || (ldb & 3) ||
       (gates_c && (ldc < 4 * H || (ldc & 3))))
     return fail(GVL_EINVAL, "%s: bad sizes n=%d H=%d lda=%d ldb=%d", what, n, H, lda, ldb);

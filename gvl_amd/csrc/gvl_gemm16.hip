@@ -20,7 +20,7 @@
 // more than 2^-35 below its row's largest is not represented: |error| <= 2^-21 sum |a||b| + K 2^-33 max|a| max|b|.
 // (Three bf16 parts would need six products: bf16 carries 8 bits per part, fp16 11.)
 //
-// k_split_rows        one wavefront per row -> hi / lo planes (fp16, row-major like the input) + the row scale; used
+// k_split_rows        one wavefront per row -> hi / lo planes (fp16, K-stage-major: gvl_gemm16_common.hpp) + the row scale; used
 //                     for the weights (the cell / attention kernels of gvl_cap.hip write their results as planes).
 // k_gemm_f16x3_w8     out (R, N) = A (R, K) . B (N, K)^T [+ bias], both operands as planes: 8 wavefronts, 256 x 128 /
 //                     128 x 256 / 128 x 128 tiles, three-stage LDS ring filled by LDS-DMA, software-pipelined, persistent
@@ -64,7 +64,6 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ x,
   e = min(max(e, 1), 253);
   const float s = __uint_as_float((uint32_t)e << 23), inv = __uint_as_float((uint32_t)(254 - e) << 23);
   if (lane == 0) scale[row] = s;
-  h4 *hr = reinterpret_cast<h4 *>(hi + (int64_t)row * K), *lr = reinterpret_cast<h4 *>(lo + (int64_t)row * K);
   for (int i = lane; i < n4; i += 64) {
     const float4 v = xr[i];                                            // second read: L1 / L2
     const float a[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
@@ -74,8 +73,9 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ x,
       h[c] = (_Float16)a[c];
       l[c] = (_Float16)((a[c] - (float)h[c]) * kLoScale);
     }
-    hr[i] = h;
-    lr[i] = l;
+    const int64_t at = plane_off(row, 4 * i, R);
+    *reinterpret_cast<h4 *>(hi + at) = h;
+    *reinterpret_cast<h4 *>(lo + at) = l;
   }
 }
 
@@ -169,8 +169,9 @@ __device__ __forceinline__ void lstm_finish(const LstmPre &p, const f16acc &am, 
       le.c_out[at] = cn;
       le.h_out[at] = hn;
       const _Float16 hi = (_Float16)hn;                                // planes at row scale 1 (|h'| < 1), as split4_f16
-      le.h_hi[at] = hi;
-      le.h_lo[at] = (_Float16)((hn - (float)hi) * 2048.f);
+      const int64_t pat = plane_off(row, unit, R);
+      le.h_hi[pat] = hi;
+      le.h_lo[pat] = (_Float16)((hn - (float)hi) * 2048.f);
       if (unit == 0) le.h_scale[row] = 1.f;
     }
   }
@@ -327,24 +328,24 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int row = (2 * wave + u) * 16 + srow;
-    a_src[u] = (int64_t)min(m0 + row, R - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
+    a_src[u] = (int64_t)min(m0 + row, R - 1) * 32 + (spos ^ ((row >> 2) & 3)) * 8;      // (plane_off: stage k0 / 32 adds k0 R)
   }
 #pragma unroll
   for (int u = 0; u < NBU; ++u) {
     const int row = (NBU * wave + u) * 16 + srow;
-    b_src[u] = (int64_t)min(n0 + row, N - 1) * K + (spos ^ ((row >> 2) & 3)) * 8;
+    b_src[u] = (int64_t)min(n0 + row, N - 1) * 32 + (spos ^ ((row >> 2) & 3)) * 8;
   }
   auto issue = [&](int k0, int buf) {
     uint4 *st = smem + buf * kStageSlots;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      glds16(Ah + a_src[u] + k0, st + (2 * wave + u) * 64);
-      if constexpr (!X1) glds16(Al + a_src[u] + k0, st + kASlots + (2 * wave + u) * 64);
+      glds16(Ah + a_src[u] + (int64_t)k0 * R, st + (2 * wave + u) * 64);
+      if constexpr (!X1) glds16(Al + a_src[u] + (int64_t)k0 * R, st + kASlots + (2 * wave + u) * 64);
     }
 #pragma unroll
     for (int u = 0; u < NBU; ++u) {
-      glds16(Bh + b_src[u] + k0, st + 2 * kASlots + (NBU * wave + u) * 64);
-      if constexpr (!X1) glds16(Bl + b_src[u] + k0, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
+      glds16(Bh + b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + (NBU * wave + u) * 64);
+      if constexpr (!X1) glds16(Bl + b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
     }
   };
 
@@ -436,7 +437,7 @@ __global__ void __launch_bounds__(512, 1)
       // (which plane a unit belongs to is a compile-time fact: 8 wavefronts' units of one i lie inside one plane)
       if (X1 && (i < WM ? 8 * i / (4 * WM) : 8 * (i - WM) / (kRowsB / 16))) continue;
       const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
-      glds16(base[i] + (row * K + schunk + k0), st + dst[i]);
+      glds16(base[i] + (row * 32 + schunk + k0 * (i < WM ? R : N)), st + dst[i]);       // plane_off(row, k0 + chunk, rows)
     }
   };
   constexpr int kDma = X1 ? NG / 2 : NG;                              // DMA instructions per wavefront and stage
@@ -735,7 +736,7 @@ __global__ void __launch_bounds__(512, 1)
     for (int i = 0; i < NG; ++i) {
       if (X1 && (i < WM ? 8 * i / (4 * WM) : 8 * (i - WM) / (4 * WN))) continue;       // lo-plane units (see k_gemm_f16x3_w8)
       const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
-      glds16(base[i] + (row * K + schunk + k0), st + dst[i]);
+      glds16(base[i] + (row * 32 + schunk + k0 * (i < WM ? R : N)), st + dst[i]);
     }
   };
   constexpr int kDma = X1 ? NG / 2 : NG;
@@ -986,7 +987,7 @@ extern "C" int gvl_f16_products(int n) {
 }
 
 extern "C" int gvl_split_rows_f16(const float *x, int R, int K, void *hi, void *lo, float *scale, void *stream) {
-  if (R < 0 || K <= 0 || (K & 3)) return fail(GVL_EINVAL, "gvl_split_rows_f16: needs K %% 4 == 0 (got R=%d K=%d)", R, K);
+  if (R < 0 || K <= 0 || (K & 31)) return fail(GVL_EINVAL, "gvl_split_rows_f16: needs K %% 32 == 0 (got R=%d K=%d)", R, K);
   if (R == 0) return 0;
   if (!x || !hi || !lo || !scale) return fail(GVL_EINVAL, "gvl_split_rows_f16: null pointer");
   if (((uintptr_t)x & 15) || ((uintptr_t)hi & 7) || ((uintptr_t)lo & 7))
@@ -1039,7 +1040,7 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
                                        void *h_lo, float *h_scale, void *stream) {
   const bool x1 = gvl16::g_f16_products == 1;
   const int N = 4 * H;
-  if (H <= 0 || (H & 7)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: H must be a positive multiple of 8 (got %d)", H);
+  if (H <= 0 || (H & 31)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: H must be a positive multiple of 32 (got %d)", H);
   if (int rc = check_operands("gvl_gemm_f16x3_lstm_f32", a_hi, a_lo, a_scale, R, w_hi, w_lo, w_scale, N, K)) return rc;
   if (ld_h < N || (ld_h & 3) || (gates_c && (ld_c < N || (ld_c & 3))))
     return fail(GVL_EINVAL, "gvl_gemm_f16x3_lstm_f32: gate operands need a row stride >= 4H, a multiple of 4");

@@ -12,6 +12,15 @@ typedef float f16acc __attribute__((ext_vector_type(16)));
 
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
+// PLANE LAYOUT (round 4): an (R, K) operand plane is stored K-STAGE-MAJOR, [K / 32][R][32]: the 32 halves (64 bytes) that one K
+// stage takes from a row lie beside those of the next ROW, so the 16 rows x 64 bytes one staging instruction moves are ONE
+// contiguous 1 KiB run (8 whole 128-byte lines) -- row-major planes made it 16 half lines at a 2 K-byte stride, twice the
+// requests into the L2 (vocabulary product 151 -> 133 us, single-product form 76 -> 69 us, same run; tools/kmaj_probe.py).
+// Element (row, k) of a plane of `rows` rows:
+__host__ __device__ __forceinline__ int64_t plane_off(int row, int k, int rows) {
+  return ((int64_t)(k >> 5) * rows + row) * 32 + (k & 31);
+}
+
 extern thread_local int g_f16_products;      // 3 | 1 (gvl_f16_products; defined in gvl_gemm16.hip)
 
 // ---------------------------------------------------------------------------------------------------------------------

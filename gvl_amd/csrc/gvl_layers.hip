@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
   };
   const auto a_rs = rsrc_of(p.A + (int64_t)m0 * p.lda);
   const auto a2_rs = rsrc_of(HAS_A2 ? p.A2 : p.A);
-  const auto wh_rs = rsrc_of(p.Wh + (int64_t)n0 * K);
-  const auto wl_rs = rsrc_of(p.Wl + (int64_t)n0 * K);
+  const auto wh_rs = rsrc_of(p.Wh + (int64_t)n0 * 32);                  // planes are K-stage-major (plane_off): stage s of the
+  const auto wl_rs = rsrc_of(p.Wl + (int64_t)n0 * 32);                  // tile's rows starts s N 32 halves further
   int a_off[NA], a2_off[NA];
   uint32_t a_dst[NA];
   float a_inv[NA];
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
 
   // ---- W path: thread t carries chunk t & 3 of weight row t >> 2 of the tile, both planes (same swizzled image)
   const int wrow = tid >> 2, wch = tid & 3;
-  const int w_off = (min(wrow, N - 1 - n0) * K + wch * 8) * 2;
+  const int w_off = (min(wrow, N - 1 - n0) * 32 + wch * 8) * 2;
   const int w_dst = 2 * kASlots + lds_slot(wrow, wch);
 
   struct ASet { u4v x[NA], y[NA], wh, wl; };
@@ -176,8 +176,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
 #pragma unroll
       for (int i = 0; i < NA; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off[i], k0 * 4, 0);
     }
-    s.wh = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_off, k0 * 2, 0);
-    if constexpr (!X1) s.wl = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off, k0 * 2, 0);
+    s.wh = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_off, k0 * N * 2, 0);
+    if constexpr (!X1) s.wl = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off, k0 * N * 2, 0);
   };
   auto store_a = [&](ASet &s, int buf) {
     char *st = reinterpret_cast<char *>(smem + buf * kStageSlots);

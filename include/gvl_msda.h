@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 10  /* 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 10  /* 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major; 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -226,8 +226,12 @@ int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight
 /* -- fp32 products of the captioner's token loop on the fp16 matrix cores at fp32 accuracy (gvl_gemm16.hip): the
  *    nn.Linear calls `self.logit(output)` (pdvc/CaptioningHead/LSTM_DSA.py:121,165), `h2att(h)` and the two halves of
  *    the LSTM's gate pre-activations (:247,267-269).
- *    gvl_split_rows_f16:  x (R, K) fp32 row-major, K % 4 == 0 -> hi, lo (R, K) IEEE half, scale (R) fp32 with
+ *    gvl_split_rows_f16:  x (R, K) fp32 row-major, K % 32 == 0 -> hi, lo: R K IEEE halves each, scale (R) fp32 with
  *        x[r][k] = scale[r] (hi[r][k] + 2^-11 lo[r][k])  to 2^-22 |x|;  scale[r] = 2^floor(log2 max_k |x[r][k]|).
+ *        PLANE LAYOUT (every entry point that takes or leaves planes; ABI 10): K-stage-major, element (r, k) at
+ *        ((k / 32) R + r) 32 + k % 32 -- the 64 bytes one K stage takes from a row lie beside the next row's, so a staging
+ *        instruction of the GEMM kernels reads ONE contiguous 1 KiB run instead of 16 half lines (-12 % on the vocabulary
+ *        product).  R is the row count of the WHOLE plane: operands are passed whole, not as row slices.
  *    gvl_gemm_f16x3_f32:  out (R, ldo >= N) = A (R, K) . B (N, K)^T + bias (N, may be NULL), both operands as the
  *        planes + scales of gvl_split_rows_f16, K % 32 == 0, planes 16-byte aligned.  Three fp16 MFMAs per product
  *        (hi.hi, hi.lo, lo.hi; fp32 accumulation, cross terms in their own accumulator):
@@ -276,7 +280,7 @@ int gvl_cap_attend_split_levels_f32(const float *slab, const int64_t *shapes, co
  *        run.  Every gate operand -- the ROWS of W and the columns of gates_h (row stride ld_h), gates_c (ld_c, may be NULL)
  *        and emb_gates (V + 1, 4H) -- is in the order 4 * unit + gate (gate = i, f, g, o), i.e. row g * H + u of nn.LSTM's
  *        weight_ih at row 4 * u + g.  Outputs as gvl_lstm_cell_split_f32; same bits as that path (shared cell expression,
- *        same product).  H % 8 == 0, K % 32 == 0. */
+ *        same product).  H % 32 == 0, K % 32 == 0. */
 int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *w_hi,
                             const void *w_lo, const float *w_scale, int H, int K, const float *gates_h, int64_t ld_h,
                             const float *gates_c, int64_t ld_c, const float *emb_gates, const int64_t *it, const float *c,

@@ -103,7 +103,8 @@ def test_lstm_cell_epilogue_single_product(n, form, monkeypatch):
     assert float((h1.double() - h_ref).abs().max()) <= 5e-3
     # h' leaves as planes for the next products of the step: they reconstruct h' itself
     p = h1._gvl_planes
-    back = p.scale[:, None] * (p.hi.float() + p.lo.float() / 2048.0)
+    hi, lo = p.dense()
+    back = p.scale[:, None] * (hi.float() + lo.float() / 2048.0)
     assert float((back - h1).abs().max()) <= 2.0 ** -20
 
 

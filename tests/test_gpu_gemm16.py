@@ -21,12 +21,13 @@ def test_split_planes_reconstruct_the_input_to_22_bits():
     x[3] = 0.0                                                           # an all-zero row
     x[5, ::2] *= 1e-6                                                    # elements far below the row's maximum
     p = MSDA.split_rows(x)
-    back = p.scale.double()[:, None] * (p.hi.double() + p.lo.double() / 2048.0)
+    hi, lo = p.dense()
+    back = p.scale.double()[:, None] * (hi.double() + lo.double() / 2048.0)
     rowmax = x.abs().amax(1, keepdim=True).double()
     # per element: 2^-22 relative, or 2^-35 of the row maximum for elements that sit in fp16's subnormal range
     err = (back - x.double()).abs()
     assert bool((err <= 2.0 ** -22 * x.abs().double() + 2.0 ** -34 * rowmax).all())
-    assert float(p.hi.abs().max()) <= 2.0 and bool(torch.isfinite(p.lo.float()).all())
+    assert float(hi.abs().max()) <= 2.0 and bool(torch.isfinite(lo.float()).all())
     e = torch.log2(p.scale)
     assert bool((e == e.round()).all())                                  # scales are powers of two
 
@@ -156,8 +157,9 @@ def test_lstm_cell_leaves_its_hidden_state_as_planes():
     h1, c1 = MSDA.lstm_cell(ga, gb, emb, it, c, gates_c=gc, planes=True)
     assert torch.equal(h0, h1) and torch.equal(c0, c1)
     p = h1._gvl_planes
-    assert bool((p.scale == 1.0).all()) and float(p.hi.abs().max()) <= 1.0
-    back = p.hi.double() + p.lo.double() / 2048.0
+    hi, lo = p.dense()
+    assert bool((p.scale == 1.0).all()) and float(hi.abs().max()) <= 1.0
+    back = hi.double() + lo.double() / 2048.0
     assert bool(((back - h1.double()).abs() <= 2.0 ** -22 * h1.abs().double() + 2.0 ** -34).all())
 
 

@@ -174,7 +174,8 @@ def test_cap_attend_kernel_matches_unfused_reference_order():
         pl = MSDA.cap_attend(slab, shapes2d, lsi_d, ref.contiguous().to(dev), off_hs, h.to(dev),
                              Wo[:, :C].contiguous().to(dev), torch.nn.functional.linear(h, Wh, bh).to(dev), aw.to(dev),
                              ab, L, P, planes=True)
-        back = pl.scale.double()[:, None] * (pl.hi.double() + pl.lo.double() / 2048.0)
+        hi_, lo_ = pl.dense()
+        back = pl.scale.double()[:, None] * (hi_.double() + lo_.double() / 2048.0)
         rowmax = got.abs().amax(1, keepdim=True).double()
         assert bool(((back - got.double()).abs() <= 2.0 ** -22 * got.abs().double() + 2.0 ** -34 * rowmax).all())
         # ... and from the kernel that keeps the coarse levels' rows in LDS (gvl_cap_attend_split_levels_f32, taken when the

@@ -62,8 +62,8 @@ def test_round3_token_loop_entry_points_are_declared_and_exported():
     assert L.gvl_ce_rows_forward_f32(None, 4, 2, 8, None, None, None, None, None) == -1        # ld < V
     assert b"bad sizes" in L.gvl_last_error()
     assert L.gvl_gemm_f16x3_lstm_f32(None, None, None, 4, None, None, None, 6, 32, None, 24, None, 0, None, None, None, None,
-                                     None, None, None, None, None) == -1                       # H not a multiple of 8
-    assert b"multiple of 8" in L.gvl_last_error()
+                                     None, None, None, None, None) == -1                       # H not a multiple of 32
+    assert b"multiple of 32" in L.gvl_last_error()
     perm = MSDA.gate_permutation(3)
     assert perm.tolist() == [0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8, 11]                             # row g * H + u at 4 * u + g
     w = torch.arange(12.0)[:, None]

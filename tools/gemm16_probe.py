@@ -34,8 +34,9 @@ for R, K, N in ((4800, 512, 8518), (4800, 512, 2560), (4800, 512, 2048), (2208, 
     out = torch.empty(R, N, device=dev)
     mine = MSDA.gemm_f16x3(xp, wp, b, out=out)
     lib = torch.nn.functional.linear(x, w, b)
-    xa = torch.cat([xp.hi * 2048.0, xp.hi, xp.lo], 1).contiguous()
-    wa = torch.cat([wp.hi, wp.lo, wp.hi], 1).contiguous()
+    (xh, xl), (wh, wl) = xp.dense(), wp.dense()
+    xa = torch.cat([xh * 2048.0, xh, xl], 1).contiguous()
+    wa = torch.cat([wh, wl, wh], 1).contiguous()
     t_mine = timeit(lambda: MSDA.gemm_f16x3(xp, wp, b, out=out))
     t_split = timeit(lambda: MSDA.split_rows(x, out=xp))
     t_lib = timeit(lambda: torch.nn.functional.linear(x, w, b))
