@@ -34,6 +34,14 @@ SIGNATURES = {
     "gvl_msda_debug_stamps": (None, [_P]),
     "gvl_clock_probe": (_I, [_P, _I, _P]),
     "gvl_f16_products": (_I, [_I]),
+    "gvl_residual_dropout_layer_norm_forward_f32": (_I, [_P, _I64, _I64, _P, _I64, _I64, _I, _I, _I, _P, _P, ctypes.c_float, ctypes.c_float,
+                                                         ctypes.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "gvl_residual_dropout_layer_norm_backward_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, ctypes.c_float, ctypes.c_uint32, _P, _P, _P,
+                                                          _P, _P, _P]),
+    "gvl_rdln_backward_blocks": (_I, [_I]),
+    "gvl_advance_step": (_I, [_P, _P]),
+    "gvl_relu_dropout_forward_f32": (_I, [_P, _I64, ctypes.c_float, ctypes.c_uint32, _P, _P, _P]),
+    "gvl_relu_dropout_backward_f32": (_I, [_P, _P, _I64, ctypes.c_float, _P, _P]),
     "gvl_prof_collect": (_I, [_P, _P, _P, _P, _I]),
     "gvl_msda_sample_backward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),
     "gvl_msda_sample_backward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P]),

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import layers as _layers
+from . import train_layers as _tl
 from .ops.modules import MSDeformAttn
 from .linear import Linear
 
@@ -86,12 +87,14 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        return self.norm2(src + self.dropout3(self.linear2(self.dropout2(self.activation(self.linear1(src))))))
+        # (norm(x + dropout(sub)): one hand-written forward / backward kernel in training, gvl_amd/train_layers.py)
+        return _tl.residual_dropout_norm(src, self.linear2(_tl.relu_dropout(self.linear1(src), self.activation, self.dropout2)),
+                                         self.dropout3, self.norm2)
 
     def forward(self, src, pos, reference_points, temporal_shapes, level_start_index, padding_mask=None):
         attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, temporal_shapes,
                               level_start_index, padding_mask)
-        return self.forward_ffn(self.norm1(src + self.dropout1(attn)))
+        return self.forward_ffn(_tl.residual_dropout_norm(src, attn, self.dropout1, self.norm1))
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -151,7 +154,8 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        return self.norm3(tgt + self.dropout4(self.linear2(self.dropout3(self.activation(self.linear1(tgt))))))
+        return _tl.residual_dropout_norm(tgt, self.linear2(_tl.relu_dropout(self.linear1(tgt), self.activation, self.dropout3)),
+                                         self.dropout4, self.norm3)
 
     def forward(self, tgt, query_pos, reference_points, src, src_temporal_shapes, level_start_index,
                 src_padding_mask=None, query_mask=None):
@@ -162,10 +166,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # (average_attn_weights=False: the unfused path without the mean over the heads of a (B, 8, Q, Q) map nobody reads)
         sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask, need_weights=self.training,
                             average_attn_weights=False)[0].transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(sa))
+        tgt = _tl.residual_dropout_norm(tgt, sa, self.dropout2, self.norm2)       # (sa: a transposed view, read in place)
         ca = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_temporal_shapes,
                              level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(ca))
+        tgt = _tl.residual_dropout_norm(tgt, ca, self.dropout1, self.norm1)
         return self.forward_ffn(tgt)
 
 
@@ -289,6 +293,8 @@ class DeformableTransformer(nn.Module):
 
     def forward_encoder(self, src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,
                         mask_flatten):
+        if self.training and torch.is_grad_enabled():
+            _tl.advance(src_flatten.device)           # new dropout masks for this forward's residual chains (train_layers.py)
         if self.no_encoder:
             return src_flatten
         return self.encoder(src_flatten, temporal_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,

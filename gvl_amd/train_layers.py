@@ -1,0 +1,151 @@
+"""The residual chains of the encoder / decoder layers in TRAINING -- ``norm(x + dropout(sub))`` of
+pdvc/deformable_transformer.py:189-199 (encoder norm1 / norm2) and :266-280 (decoder norm2 / norm1 / norm3) -- as one
+hand-written forward and one backward kernel (gvl_train_layers.hip: gvl_residual_dropout_layer_norm_{forward,backward}_f32)
+instead of PyTorch's fused_dropout + add + layer_norm and their five backward launches.
+
+Dropout masks come from a counter-based hash of (seed, step, element index): ``seed`` is derived on the host from
+``torch.initial_seed()`` and the Dropout module's site number, ``step`` is a DEVICE counter that
+``DeformableTransformer.forward_encoder`` advances once per training forward (one tiny kernel), so a step replayed from a hipGraph
+draws new masks every replay and the backward regenerates the mask instead of storing it.  They are not torch's Philox stream.
+With p = 0 (every golden of tests/golden is generated that way) the result is exactly LayerNorm(x + sub).
+
+``GVL_TRAIN_LAYERS=torch`` keeps the PyTorch formulation (A/B switch)."""
+import itertools
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+_STEP = {}                       # device -> int64 counter tensor
+_SITES = itertools.count(1)
+
+
+def enabled():
+    return os.environ.get("GVL_TRAIN_LAYERS", "") != "torch"
+
+
+def step_counter(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = _STEP.get(device)
+    if t is None:
+        t = _STEP[device] = torch.zeros(1, dtype=torch.int64, device=device)
+    return t
+
+
+def advance(device):
+    """one training forward begins: the dropout masks of its residual chains change (graph-capturable)"""
+    if torch.device(device).type != "cuda" or not enabled():
+        return
+    t = step_counter(device)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.lib().gvl_advance_step(t.data_ptr(), torch.cuda.current_stream().cuda_stream), "advance_step")
+
+
+def _site_seed(drop):
+    site = drop.__dict__.get("_gvl_site")
+    if site is None:
+        site = drop.__dict__["_gvl_site"] = next(_SITES)
+    return (torch.initial_seed() * 0x9E3779B1 + site * 0x85EBCA77) & 0xFFFFFFFF
+
+
+def eligible(x, sub, norm, drop):
+    return (enabled() and x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and x.dtype == torch.float32 and sub.dtype == torch.float32 and x.dim() == 3 and x.shape == sub.shape
+            and all(t_.stride(2) == 1 and t_.stride(0) % 4 == 0 and t_.stride(1) % 4 == 0 for t_ in (x, sub))
+            and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and tuple(norm.normalized_shape) == (x.shape[-1],)
+            and norm.elementwise_affine and norm.bias is not None and norm.weight.dtype == torch.float32
+            and x.data_ptr() % 16 == 0 and sub.data_ptr() % 16 == 0 and x.numel() < 2 ** 32)
+
+
+class ResidualDropoutLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sub, weight, bias, eps, p, seed, step):
+        B, Q, C = x.shape
+        R = B * Q
+        y = torch.empty(B, Q, C, device=x.device, dtype=torch.float32)
+        z = torch.empty_like(y)
+        stats = torch.empty(2, R, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().gvl_residual_dropout_layer_norm_forward_f32(
+                x.data_ptr(), x.stride(0), x.stride(1), sub.data_ptr(), sub.stride(0), sub.stride(1), Q, R, C,
+                weight.data_ptr(), bias.data_ptr(),
+                float(eps), float(p), int(seed), step.data_ptr() if step is not None else None, y.data_ptr(), z.data_ptr(),
+                stats[0].data_ptr(), stats[1].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "residual_dropout_layer_norm_forward")
+        ctx.save_for_backward(z, stats, weight, step if step is not None else x.new_empty(0))
+        ctx.p, ctx.seed, ctx.has_step = float(p), int(seed), step is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, stats, weight, step = ctx.saved_tensors
+        B, Q, C = z.shape
+        R = B * Q
+        dy = dy.contiguous()
+        L = _lib.lib()
+        dz = torch.empty_like(z)
+        dsub = torch.empty_like(z) if ctx.p > 0 else None
+        part = torch.empty(L.gvl_rdln_backward_blocks(R), 2 * C, device=z.device, dtype=torch.float32)
+        dgb = torch.empty(2, C, device=z.device, dtype=torch.float32)
+        with torch.cuda.device(z.device):
+            rc = L.gvl_residual_dropout_layer_norm_backward_f32(
+                dy.data_ptr(), z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), R, C, weight.data_ptr(), ctx.p,
+                ctx.seed, step.data_ptr() if ctx.has_step else None, dz.data_ptr(),
+                dsub.data_ptr() if dsub is not None else None, part.data_ptr(), dgb.data_ptr(),
+                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "residual_dropout_layer_norm_backward")
+        return dz, (dsub if dsub is not None else dz), dgb[0], dgb[1], None, None, None, None
+
+
+def residual_dropout_norm(x, sub, drop, norm):
+    """norm(x + drop(sub)) -- the fused kernels when they apply, PyTorch's formulation otherwise"""
+    if not eligible(x, sub, norm, drop):
+        return norm(x + drop(sub))
+    p = drop.p if drop.training else 0.0
+    if p >= 1.0:
+        return norm(x + drop(sub))
+    return ResidualDropoutLayerNorm.apply(x, sub, norm.weight, norm.bias, norm.eps, p, _site_seed(drop),
+                                          step_counter(x.device) if p > 0 else None)
+
+
+class ReluDropout(torch.autograd.Function):
+    """dropout(relu(x)) in ONE kernel; backward from the OUTPUT alone (y > 0 exactly where the element was kept and positive):
+    no mask tensor, and x -- the output of linear1, which no backward reads -- is free as soon as y exists"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, step):
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().gvl_relu_dropout_forward_f32(x.data_ptr(), x.numel(), float(p), int(seed),
+                                                         step.data_ptr() if step is not None else None, y.data_ptr(),
+                                                         torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "relu_dropout_forward")
+        ctx.save_for_backward(y)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            rc = _lib.lib().gvl_relu_dropout_backward_f32(dy.data_ptr(), y.data_ptr(), y.numel(), ctx.p, dx.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "relu_dropout_backward")
+        return dx, None, None, None
+
+
+def relu_dropout(x, activation, drop):
+    """drop(activation(x)) -- one kernel for ReLU on fp32 activations in training"""
+    if not (enabled() and x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and x.requires_grad
+            and x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0 and x.numel() < 2 ** 32
+            and x.data_ptr() % 16 == 0 and activation in (F.relu, torch.relu)
+            and 0.0 <= (drop.p if drop.training else 0.0) < 1.0):
+        return drop(activation(x))
+    p = drop.p if drop.training else 0.0
+    return ReluDropout.apply(x, p, _site_seed(drop), step_counter(x.device) if p > 0 else None)

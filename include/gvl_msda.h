@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 10  /* 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major; 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 10  /* 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -305,6 +305,34 @@ int gvl_greedy_step_partials_alive_f32(const float *partials, int R, int V, int 
  *      dur_embed (N, n_dur) = duration_embed_layer(step one-hot);  scale = 2 pi;  out (N, n_sine + n_dur, T). */
 int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const float *dur_embed, int N, int T,
                            int n_sine, int n_dur, float scale, float *out, void *stream);
+
+/* -- the residual chains of the encoder / decoder layers in TRAINING (gvl_train_layers.hip; ABI 10):
+ *        y = LayerNorm(x + dropout(sub))     pdvc/deformable_transformer.py:189-199 (norm1, norm2), :266-280 (norm2, norm1, norm3)
+ *    one forward and one backward kernel instead of PyTorch's dropout + add + layer_norm (3 launches) and their 5 backward
+ *    launches.  y, z, dy, dz, dsub: (R, C) fp32 row-major, C % 4 == 0, C <= 1024; x and sub: row r = (b, q), b = r / Q, at element
+ *    offset b sb + q sq (strides multiples of 4: a transposed (Q, B, C) tensor or a batch-expanded one is read in place);
+ *    gamma, beta (C).
+ *    forward leaves z = x + keep sub / (1 - p), mean (R), rstd (R) (biased variance + eps, as torch.nn.LayerNorm) for the
+ *    backward.  backward: dz = gradient w.r.t. x, dsub = keep dz / (1 - p) (NULL allowed when p == 0: it equals dz),
+ *    dgamma_dbeta (2 C) = [sum_r dy xhat | sum_r dy]; part: workspace of gvl_rdln_backward_blocks(R) x 2 C floats.
+ *    Dropout: element i kept iff hash32(i ^ hash32(seed + *step 0x9E3779B9)) >= p 2^32 -- `step` lives in DEVICE memory
+ *    (gvl_advance_step: *step += 1, one tiny kernel per training forward; NULL = 0), so a step replayed from a hipGraph draws
+ *    new masks; the backward regenerates the mask from the same (seed, *step).  Not torch's Philox stream; p == 0 is exactly
+ *    LayerNorm(x + sub). */
+int gvl_residual_dropout_layer_norm_forward_f32(const float *x, int64_t x_sb, int64_t x_sq, const float *sub, int64_t sub_sb,
+                                                int64_t sub_sq, int Q, int R, int C, const float *gamma, const float *beta,
+                                                float eps, float p, uint32_t seed, const int64_t *step, float *y, float *z,
+                                                float *mean, float *rstd, void *stream);
+int gvl_residual_dropout_layer_norm_backward_f32(const float *dy, const float *z, const float *mean, const float *rstd, int R,
+                                                 int C, const float *gamma, float p, uint32_t seed, const int64_t *step,
+                                                 float *dz, float *dsub, float *part, float *dgamma_dbeta, void *stream);
+int gvl_rdln_backward_blocks(int R);
+/*    y = dropout(relu(x)) of the FFNs (deformable_transformer.py:189-191, 257-259), n elements (n % 4 == 0, < 2^32), y == x
+ *    allowed; same mask rule as above.  backward: dx = y > 0 ? dy / (1 - p) : 0 -- no mask tensor (y > 0 exactly
+ *    where the element was kept and positive). */
+int gvl_relu_dropout_forward_f32(const float *x, int64_t n, float p, uint32_t seed, const int64_t *step, float *y, void *stream);
+int gvl_relu_dropout_backward_f32(const float *dy, const float *y, int64_t n, float p, float *dx, void *stream);
+int gvl_advance_step(int64_t *step, void *stream);
 
 /* -- column sums of a row-major fp32 matrix: out[c] = sum_r x[r * ld + c] -- the bias gradient of the nn.Linear layers on
  *    the path (autograd's AddmmBackward: grad_bias = grad_output.sum(0)).  Any C and ld >= C (16-byte loads when C, ld

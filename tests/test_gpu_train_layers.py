@@ -1,0 +1,160 @@
+"""gvl_amd/train_layers.py (gvl_train_layers.hip): norm(x + dropout(sub)) of the encoder / decoder layers in training
+(pdvc/deformable_transformer.py:189-199, 266-280) as one forward and one backward kernel, against the PyTorch formulation in
+fp64.  p = 0: exact LayerNorm(x + sub) and its gradients.  p > 0: the mask the kernel drew is recovered from its own output
+(z = x + keep sub / (1 - p)), must have the right keep rate, differ between sites and steps, and the gradients must be those of
+the PyTorch formulation UNDER THAT MASK."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _ref(x, sub, keep, p, w, b, eps):
+    z = x.double() + keep.double() * sub.double() / (1.0 - p)
+    return torch.nn.functional.layer_norm(z, (x.shape[-1],), w.double(), b.double(), eps)
+
+
+@pytest.mark.parametrize("B,Q,C", [(16, 300, 512), (16, 188, 512), (3, 7, 64), (2, 129, 1024), (1, 1, 4)])
+@pytest.mark.parametrize("layout", ["contiguous", "transposed_sub", "expanded_x"])
+def test_no_dropout_is_layer_norm_of_the_sum(B, Q, C, layout):
+    from gvl_amd import train_layers as TL
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(_rand(C, seed=1) * 0.5 + 1.0)
+        norm.bias.copy_(_rand(C, seed=2))
+    drop = torch.nn.Dropout(0.1).eval()                      # eval: p = 0
+    x0, s0 = _rand(B, Q, C, seed=3), _rand(B, Q, C, seed=4, scale=2.0)
+    if layout == "expanded_x":
+        x0 = _rand(Q, C, seed=3)
+    x0.requires_grad_(True)
+    s0.requires_grad_(True)
+    x = x0.unsqueeze(0).expand(B, -1, -1) if layout == "expanded_x" else x0
+    sub = s0.transpose(0, 1).contiguous().transpose(0, 1) if layout == "transposed_sub" else s0
+    assert TL.eligible(x, sub, norm, drop)
+    y = TL.residual_dropout_norm(x, sub, drop, norm)
+    gy = _rand(B, Q, C, seed=5)
+    y.backward(gy)
+    got = [t_.grad.clone() for t_ in (x0, s0, norm.weight, norm.bias)]
+    for t_ in (x0, s0, norm.weight, norm.bias):
+        t_.grad = None
+    x64, s64 = x0.detach().double().requires_grad_(True), s0.detach().double().requires_grad_(True)
+    w64, b64 = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    xx = x64.unsqueeze(0).expand(B, -1, -1) if layout == "expanded_x" else x64
+    ref = torch.nn.functional.layer_norm(xx + s64, (C,), w64, b64, norm.eps)
+    ref.backward(gy.double())
+    assert float((y.detach().double() - ref.detach()).abs().max()) <= 5e-6
+    for g_, r_ in zip(got, (x64.grad, s64.grad, w64.grad, b64.grad)):
+        assert float((g_.double() - r_).abs().max()) <= 2e-5 * max(1.0, float(r_.abs().max()))
+
+
+def test_dropout_mask_rate_sites_steps_and_gradients():
+    from gvl_amd import train_layers as TL
+    B, Q, C, p = 16, 300, 512, 0.1
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(_rand(C, seed=1) * 0.5 + 1.0)
+        norm.bias.copy_(_rand(C, seed=2))
+    drop_a, drop_b = torch.nn.Dropout(p).train(), torch.nn.Dropout(p).train()
+    x = _rand(B, Q, C, seed=3).requires_grad_(True)
+    sub = (_rand(B, Q, C, seed=4).abs() + 0.5).requires_grad_(True)          # no zeros: the mask is readable from z
+
+    def run(drop):
+        """-> (y, keep mask recovered through the autograd graph's saved z)"""
+        y = TL.residual_dropout_norm(x, sub, drop, norm)
+        z = y.grad_fn.saved_tensors[0]
+        return y, ((z - x.detach()).abs() > 1e-6)
+    torch.manual_seed(11)
+    TL.advance(DEV)
+    y1, k1 = run(drop_a)
+    rate = float(k1.float().mean())
+    assert abs(rate - (1 - p)) < 2e-3                                        # 2.4 M draws: sigma = 2e-4
+    assert abs(float(k1.float().mean(dim=(0, 1)).min()) - (1 - p)) < 0.03    # ... per column
+    assert abs(float(k1.float().mean(dim=2).min()) - (1 - p)) < 0.08         # ... per row
+    # forward and backward under THAT mask
+    gy = _rand(B, Q, C, seed=5)
+    y1.backward(gy)
+    got = [t_.grad.clone() for t_ in (x, sub, norm.weight, norm.bias)]
+    x64, s64 = x.detach().double().requires_grad_(True), sub.detach().double().requires_grad_(True)
+    w64, b64 = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x64 + k1.double() * s64 / (1 - p), (C,), w64, b64, norm.eps)
+    ref.backward(gy.double())
+    assert float((y1.detach().double() - ref.detach()).abs().max()) <= 5e-6
+    for g_, r_ in zip(got, (x64.grad, s64.grad, w64.grad, b64.grad)):
+        assert float((g_.double() - r_).abs().max()) <= 2e-5 * max(1.0, float(r_.abs().max()))
+    # same site, same step: the same mask (the backward relies on it); another site: another mask; next step: another mask
+    _, k1b = run(drop_a)
+    assert torch.equal(k1, k1b)
+    _, k2 = run(drop_b)
+    assert 0.15 < float((k1 != k2).float().mean()) < 0.21                    # independent masks differ on 2 p (1 - p) = 0.18
+    TL.advance(DEV)
+    _, k3 = run(drop_a)
+    assert 0.15 < float((k1 != k3).float().mean()) < 0.21
+    # the generator seed matters
+    torch.manual_seed(12)
+    _, k4 = run(drop_a)
+    assert 0.15 < float((k3 != k4).float().mean()) < 0.21
+
+
+def test_fallbacks_and_switch(monkeypatch):
+    from gvl_amd import train_layers as TL
+    norm, drop = torch.nn.LayerNorm(64).to(DEV), torch.nn.Dropout(0.0)
+    x, sub = _rand(2, 5, 64, seed=1).requires_grad_(True), _rand(2, 5, 64, seed=2)
+    assert TL.eligible(x, sub, norm, drop)
+    with torch.no_grad():
+        assert not TL.eligible(x, sub, norm, drop)                           # inference: gvl_amd/layers.py serves it
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not TL.eligible(x, sub, norm, drop)
+    assert not TL.eligible(x, sub.half(), norm, drop)
+    monkeypatch.setenv("GVL_TRAIN_LAYERS", "torch")
+    assert not TL.eligible(x, sub, norm, drop)
+    y = TL.residual_dropout_norm(x, sub, drop, norm)
+    assert float((y - norm(x + sub)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("p,train", [(0.1, True), (0.1, False), (0.0, True)])
+def test_relu_dropout_forward_and_maskless_backward(p, train):
+    from gvl_amd import train_layers as TL
+    from gvl_amd.linear import Linear
+    lin = Linear(512, 2048).to(DEV)
+    drop = torch.nn.Dropout(p).train(train)
+    x = _rand(16, 300, 512, seed=1).requires_grad_(True)
+    torch.manual_seed(5)
+    TL.advance(DEV)
+    h = lin(x)
+    pre = h.detach().clone()
+    y = TL.relu_dropout(h, torch.nn.functional.relu, drop)
+    assert type(y.grad_fn).__name__ == "ReluDropoutBackward"
+    pe = p if train else 0.0
+    keep = (y.detach() != 0) | (pre <= 0)                                     # where relu passed, the mask is readable
+    want = torch.relu(pre) * keep / (1 - pe)
+    assert float((y.detach() - want).abs().max()) <= 1e-6
+    if pe > 0:
+        kept = float(((y.detach() != 0) & (pre > 0)).sum()) / float((pre > 0).sum())
+        assert abs(kept - (1 - pe)) < 2e-3
+    else:
+        assert torch.equal(y.detach(), torch.relu(pre))
+    gy = _rand(16, 300, 2048, seed=2)
+    y.backward(gy)
+    gx, gw, gb = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    dh = (gy * ((pre > 0) & keep) / (1 - pe))
+    ref_h = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    ref_h.backward(dh)
+    for a_, b_ in ((gx, x.grad), (gw, lin.weight.grad), (gb, lin.bias.grad)):
+        assert float((a_ - b_).abs().max()) <= 1e-4 * max(1.0, float(b_.abs().max()))
+
+
+def test_relu_dropout_falls_back_for_other_activations():
+    from gvl_amd import train_layers as TL
+    drop = torch.nn.Dropout(0.0)
+    x = _rand(4, 8, 64, seed=1).requires_grad_(True)
+    y = TL.relu_dropout(x * 2.0, torch.nn.functional.gelu, drop)
+    assert type(y.grad_fn).__name__ != "ReluDropoutBackward" and torch.equal(y, torch.nn.functional.gelu(x * 2.0))
+    with torch.no_grad():
+        assert TL.relu_dropout(x, torch.nn.functional.relu, drop).grad_fn is None
