@@ -341,7 +341,9 @@ class TeacherForcedLoop(torch.autograd.Function):
         W = w_hcat.shape[0]
         A = W - H4 - 16
         new = lambda *shape: torch.empty(shape, device=slab.device, dtype=torch.float32)      # noqa: E731
-        xt_all = xt_all.contiguous()
+        # the token-independent gate part joins the per-token embedding part ONCE (one pass over (n, steps, 4H)); as the
+        # matrix addend of the attention product below it cost a (n, 4H) copy into `out` per token (addmm with beta = 1)
+        xt_all = xt_all + gates_hs[:, None, :]
         g_h, h_all, c_all = new(steps, n, W), new(steps + 1, n, H), new(steps + 1, n, H)
         att, alpha, act, g_x = new(steps, n, C), new(steps, n, 16), new(steps, n, H4), new(n, H4)
         h_all[0].zero_()
@@ -352,7 +354,7 @@ class TeacherForcedLoop(torch.autograd.Function):
             MSDA.cap_attend_train_forward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
                                           alpha_w, alpha_b, n_levels, n_points, att_res=att[i], alpha_out=alpha[i],
                                           row_video=row_video)
-            torch.addmm(gates_hs, att[i], w_att_t, out=g_x)                       # hs part + attention part of W_ih x
+            torch.mm(att[i], w_att_t, out=g_x)                                    # attention part of W_ih x
             MSDA.lstm_cell_train_forward(g_x, g_h[i][:, A:A + H4], xt_all[:, i], c_all[i], act[i], h_all[i + 1],
                                          c_all[i + 1])
         ctx.save_for_backward(slab, ref_in, off_hs, w_hcat, w_att, alpha_w, shapes2d, lsi, g_h, h_all, c_all, att,
