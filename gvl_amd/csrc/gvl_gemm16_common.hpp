@@ -24,7 +24,10 @@ __host__ __device__ __forceinline__ int64_t plane_off(int row, int k, int rows) 
 extern thread_local int g_f16_products;      // 3 | 1 (gvl_f16_products; defined in gvl_gemm16.hip)
 
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBM = 128, kBK = 32, kGroupM = 8;
+#ifndef GVL_GROUPM
+#define GVL_GROUPM 8
+#endif
+constexpr int kBM = 128, kBK = 32, kGroupM = GVL_GROUPM;
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
 
