@@ -801,9 +801,11 @@ def main():
     if line.get("roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and "eval" in res and not a.no_probes:
         line["roofline"]["cfg_L_launch"] = kernel_probe(dev, B)
         line["roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries)
+        line["roofline"]["B256_launch"] = kernel_probe(dev, 256, T=a.T, Q=a.queries)      # latency-free sweep 16 / 64 / 256
     if line.get("train_roofline") is not None and rank == 0 and a.T != 512 and a.dtype == "f32" and not a.no_probes:
         line["train_roofline"]["cfg_L_launch"] = kernel_probe(dev, B, backward=True)
         line["train_roofline"]["B64_launch"] = kernel_probe(dev, 64, T=a.T, Q=a.queries, backward=True)
+        line["train_roofline"]["B256_launch"] = kernel_probe(dev, 256, T=a.T, Q=a.queries, backward=True)
     if rank == 0 and "eval" in res and not a.no_captioner and a.dtype == "f32" and not a.no_probes:
         with torch.no_grad():
             lib = gemm_probe(model, dev, B * a.queries)
