@@ -654,7 +654,14 @@ __device__ __forceinline__ void epilogue16(f4acc4 (&acc_m)[4][4], f4acc4 (&acc_x
 #pragma unroll
     for (int r = 0; r < 4; ++r) rs[i][r] = As[min(row0 + 16 * i + 4 * fq + r, R - 1)];
   static_assert(EPI == kArgmax, "the 16 x 16 x 32 form serves the argmax epilogue (its stores would be 64-byte segments)");
+  // The arithmetic below is NOT hidden behind the matrix cores -- all eight wavefronts reach it together -- and cost 15 us of
+  // the 120-130 us vocabulary product when written value by value as (compare + two selects, subtract + exp, guarded add;
+  // timing-only build GVL_ABLATE_EPI).  Per value now: 2 FMAs (logit), 1/2 v_max3 (column maximum FIRST, across the four
+  // lanes of the column too, so that no partial sum is ever rescaled), 1 FMA + v_exp (2^(v log2e - max log2e)), 1 add, and
+  // compare + select for the index of the first maximum; the row < R guards only in the last row tile (wavefront-uniform).
   {
+    constexpr float kLog2e = 1.4426950408889634f;
+    const bool full = row0 + 64 <= R;                                   // every row of this wavefront exists
     float rb[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -667,28 +674,43 @@ __device__ __forceinline__ void epilogue16(f4acc4 (&acc_m)[4][4], f4acc4 (&acc_x
       float best = -INFINITY, sum = 0.f;
       int arg = 0x7fffffff;
       float v[4][4];
+#ifdef GVL_ABLATE_EPI                                                  /* timing-only build: what the epilogue's arithmetic costs */
+      best = cs;                                                       /* (every accumulator stays live: 32 adds) */
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) best += acc_m[i][j][r] + acc_x[i][j][r];
+      sum = rs[0][0] + rb[1][1];
+      arg = row0;
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = row0 + 16 * i + 4 * fq + r;
           v[i][r] = (acc_m[i][j][r] + acc_x[i][j][r] * kLoInv) * (rs[i][r] * cs) + rb[i][r];
-          if (row < R && v[i][r] > best) { best = v[i][r]; arg = row; }     // rows ascend: the first maximum is kept
+          if (!full && row0 + 16 * i + 4 * fq + r >= R) v[i][r] = -INFINITY;           // (exp2(-inf) = 0: adds nothing)
         }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (row0 + 16 * i + 4 * fq + r < R) sum += __expf(v[i][r] - best);
+        best = fmaxf(best, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
       // the lanes 16, 32, 48 further hold the other rows of this column
+      best = fmaxf(best, __shfl_xor(best, 16));
+      best = fmaxf(best, __shfl_xor(best, 32));
+      if (best > -INFINITY) {                                           // (a column tile without a single existing row: sum 0)
+        const float nb = -best * kLog2e;
+#pragma unroll
+        for (int i = 3; i >= 0; --i)
+#pragma unroll
+          for (int r = 3; r >= 0; --r) {                                // descending: the FIRST maximum's row is what remains
+            sum += __builtin_amdgcn_exp2f(__builtin_fmaf(v[i][r], kLog2e, nb));
+            arg = v[i][r] == best ? row0 + 16 * i + 4 * fq + r : arg;
+          }
+      }
+#endif
 #pragma unroll
       for (int o = 16; o <= 32; o <<= 1) {
-        const float b2 = __shfl_xor(best, o), s2 = __shfl_xor(sum, o);
-        const int a2 = __shfl_xor(arg, o);
-        const float bn = fmaxf(best, b2);
-        if (bn > -INFINITY) sum = sum * __expf(best - bn) + s2 * __expf(b2 - bn);
-        arg = (b2 > best || (b2 == best && a2 < arg)) ? a2 : arg;
-        best = bn;
+        sum += __shfl_xor(sum, o);
+        arg = min(arg, __shfl_xor(arg, o));
       }
       if (fq == 0 && col < N)
         reinterpret_cast<float4 *>(out)[(int64_t)(row0 >> 6) * N + col] = make_float4(best, sum, __int_as_float(arg), 0.f);
