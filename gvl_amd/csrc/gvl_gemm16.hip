@@ -839,6 +839,21 @@ __global__ void __launch_bounds__(512, 1)
   rdA(smem, 0, a01);
   rdB(smem, 0, bX);
   int buf = 0, kt = 0;
+  // (timing-only builds, tools/m16_ablate.sh: GVL_ABLATE_BARRIER / GVL_ABLATE_DMA drop the stage barrier / the operand DMA)
+#ifdef GVL_ABLATE_BARRIER
+#define GVL_M16_BARRIER()
+#else
+#define GVL_M16_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef GVL_ABLATE_DMA
+#define GVL_M16_ISSUE()
+#else
+#define GVL_M16_ISSUE()                                                                                              \
+  {                                                                                                                  \
+    const bool over = kt + 3 >= KT;                                                                                  \
+    issue(over ? tm2 : tm, over ? tn2 : tn, (over ? kt + 3 - KT : kt + 3) * kBK, buf);                               \
+  }
+#endif
   // one K stage: bA holds its columns 0-1 on entry, bB receives columns 2-3 and then the NEXT stage's columns 0-1
 #define GVL_STAGE(bA, bB)                                                                                           \
   {                                                                                                                  \
@@ -852,12 +867,9 @@ __global__ void __launch_bounds__(512, 1)
     GVL_GROUPS_READS()                                                                                               \
     wait_vmcnt<kDma>();                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-    __builtin_amdgcn_s_barrier();                                                                                    \
+    GVL_M16_BARRIER();                                                                                               \
     asm volatile("" ::: "memory");                                                                                   \
-    {                                                                                                                \
-      const bool over = kt + 3 >= KT;                                                                                \
-      issue(over ? tm2 : tm, over ? tn2 : tn, (over ? kt + 3 - KT : kt + 3) * kBK, buf);                             \
-    }                                                                                                                \
+    GVL_M16_ISSUE();                                                                                                 \
     rdA(smem + nbuf * kStageSlots, 0, a01);                                                                          \
     GVL_QUARTER(a23, bB, 2, 2)                                                                                       \
     GVL_GROUPS_DMA()                                                                                                 \
@@ -892,6 +904,8 @@ __global__ void __launch_bounds__(512, 1)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef GVL_STAGE
+#undef GVL_M16_ISSUE
+#undef GVL_M16_BARRIER
 #undef GVL_GROUPS_DMA
 #undef GVL_GROUPS_READS
 #undef GVL_QUARTER
