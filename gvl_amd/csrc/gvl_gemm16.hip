@@ -128,6 +128,11 @@ __device__ __forceinline__ void lstm_loads(LstmPre &p, int cbase, int lane, cons
   const int gcol = cbase + 4 * u < N ? cbase + 4 * u : 0;              // first of this lane's unit's four gate columns
   const int H = le.H;
   p.cs = *reinterpret_cast<const float4 *>(Bs + gcol);
+#ifdef GVL_ABLATE_CELL_LOADS                                           /* timing-only build (tools/cell_ablate.sh) */
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { p.gh[k] = p.cs; p.gc[k] = p.cs; p.ge[k] = p.cs; p.cp[k] = p.cs.x; }
+  if (true) return;
+#endif
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     p.gh[k] = *reinterpret_cast<const float4 *>(le.gates_h + (int64_t)p.rowc[k] * le.ld_h + gcol);
@@ -159,7 +164,12 @@ __device__ __forceinline__ void lstm_finish(const LstmPre &p, const f16acc &am, 
     const float gi = a[0] + p.gh[k].x + p.ge[k].x, gf = a[1] + p.gh[k].y + p.ge[k].y, gg = a[2] + p.gh[k].z + p.ge[k].z,
                 go = a[3] + p.gh[k].w + p.ge[k].w;
     float cn, hn;
+#ifdef GVL_ABLATE_CELL_MATH                                            /* timing-only build */
+    cn = gi + gf + p.cp[k];
+    hn = gg + go;
+#else
     gvl_lstm_point(gi, gf, gg, go, p.cp[k], cn, hn);
+#endif
     // (h' as the fp32 number it is stored as: left to itself the compiler folds the last product of the cell into the
     //  fp16 conversions below -- v_fma_mixlo_f16 of the exact product -- and the planes no longer split h' itself)
     asm volatile("" : "+v"(hn));
