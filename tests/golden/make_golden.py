@@ -757,6 +757,57 @@ def make_anet_full_train():
     save("pdvc_anet_full_train", **rec)
 
 
+def make_anet_full_train_b16():
+    """The train step of make_anet_full_train at the HEADLINE batch: B = 16 videos of different valid lengths with 0..10 events
+    each (the batch of make_anet_full_b16), captions of 3..10 words, every dropout 0, CUDA-op semantics: every loss term, the
+    matcher indices of both decoder layers, the gradient norm of EVERY parameter (pdvc.py:540-620, train.py:403-406)."""
+    opt, model, criterion, cc = build_pdvc("cfgs/anet_tsp_ssvg.yml",
+                                           dict(enable_contrastive=False, device="cpu", num_queries=300,
+                                                frame_embedding_num=100, transformer_dropout_prob=0.0, drop_prob=0.0))
+    model.train()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=100)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 16, 100
+    valid = [100, 73, 100, 41, 88, 100, 57, 96, 100, 100, 64, 29, 100, 81, 100, 50]
+    n_gt = [3, 5, 0, 1, 10, 2, 4, 7, 1, 6, 3, 2, 8, 0, 5, 4]
+    dt = synth_dt(B, T, opt.feature_dim, valid=valid, n_gt=n_gt, seed=16)
+    g = torch.Generator().manual_seed(22)
+    cap_len = 12
+    words = torch.randint(3, cap_len - 1, (sum(n_gt),), generator=g)              # words per caption: 3..10
+    caps = torch.zeros(sum(n_gt), cap_len, dtype=torch.long)
+    cap_mask = torch.zeros(sum(n_gt), cap_len)
+    for i, w in enumerate(words.tolist()):
+        caps[i, 1:1 + w] = torch.randint(1, opt.vocab_size, (w,), generator=g)
+        cap_mask[i, :w + 2] = 1
+    mx = max(n_gt)
+    dt.update(cap_tensor=caps, cap_mask=cap_mask,
+              gt_boxes_mask=torch.tensor([[k < n for k in range(mx)] for n in n_gt]).bool(),
+              gt_gather_idx=torch.tensor([i for i, n in enumerate(n_gt) for _ in range(n)]))
+    with cuda_semantics():
+        out, loss = model(dt, criterion, cc, "queries")
+        wd = criterion.weight_dict
+        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        final.backward()
+    rec = dict(meta_T=np.array(T), valid=np.array(valid), n_gt=np.array(n_gt), feature_dim=np.array(opt.feature_dim),
+               cap_tensor=caps, cap_mask=cap_mask, final_loss=final.detach(),
+               param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+    for k, v in loss.items():
+        rec[f"loss.{k}"] = torch.as_tensor(v).detach()
+    names = sorted(n for n, p_ in model.named_parameters() if p_.grad is not None)
+    params = dict(model.named_parameters())
+    rec["grad_names"] = np.array(names)
+    # norms accumulated in float64 (an fp32 accumulation over the 4.4 M elements of logit.weight is itself off by 1.5e-3)
+    rec["grad_norms"] = torch.stack([params[n].grad.double().norm() for n in names])
+    rec["grad_rows.caption_head.0.logit.weight"] = params["caption_head.0.logit.weight"].grad[::97]
+    rec["grad.class_head.1.weight"] = params["class_head.1.weight"].grad
+    rec["grad.count_head.0.bias"] = params["count_head.0.bias"].grad
+    rec["grad.transformer.level_embed"] = params["transformer.level_embed"].grad
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        rec[f"match_{i}"] = torch.stack([a, b])
+    save("pdvc_anet_full_train_b16", **rec)
+
+
 def make_train():
     """One training forward/backward of the reference (pdvc.py parallel_prediction_matched, train.py:403-406) with
     every dropout probability set to 0 so that the step is deterministic; CUDA-op (zero padding) semantics."""
@@ -857,6 +908,7 @@ if __name__ == "__main__":
         sys.exit(0)
     for flag, fn in (("--only-dataset", make_dataset), ("--only-anet-c3d", make_anet_c3d), ("--only-f64", make_f64),
                      ("--only-anet-full-train", make_anet_full_train), ("--only-anet-full-b16", make_anet_full_b16),
+                     ("--only-anet-full-train-b16", make_anet_full_train_b16),
                      ("--only-full-train-probe", make_full_train_probe)):
         if flag in sys.argv:
             fn()
@@ -875,6 +927,7 @@ if __name__ == "__main__":
         make_f64()
         make_anet_full_train()
         make_anet_full_b16()
+        make_anet_full_train_b16()
         make_full_train_probe()
     make_dataset()
     make_init()

@@ -127,6 +127,56 @@ def test_anet_full_dimension_train_step_matches_reference():
     print(f"worst relative gradient-norm error of the smooth parameters {worst:.2e}; boundary-sensitive: {sensitive}")
 
 
+def test_anet_full_dimension_train_step_at_the_headline_batch_matches_reference():
+    """The same comparison at B = 16 (the benchmark's batch: 16 videos of different valid lengths, 0..10 events each, 61 caption
+    rows; tests/golden/pdvc_anet_full_train_b16.npz, generated by importing the reference): every loss term, the matcher indices
+    of every video, the gradient norm of EVERY parameter.  Boundary-sensitive (sampling-location-fed) parameters as above; with
+    eight times the samples more of them see a boundary sample, so their band is checked, not their count."""
+    g = load("pdvc_anet_full_train_b16")
+    f, opt, model, criterion = build_anet(True, transformer_dropout_prob=0.0, drop_prob=0.0)
+    runs = []
+    for scale in PERTURB:
+        dt = to_dev(pdvc_dt(g, feat=int(g["feature_dim"]), seed=16))
+        n_gt = [int(n) for n in g["n_gt"]]
+        mx = max(n_gt)
+        dt.update(cap_tensor=t(g["cap_tensor"]).to(DEV), cap_mask=t(g["cap_mask"]).to(DEV),
+                  gt_boxes_mask=torch.tensor([[k < n for k in range(mx)] for n in n_gt], dtype=torch.bool, device=DEV))
+        dt["video_tensor"] = dt["video_tensor"] * scale
+        runs.append(train_grads(model, criterion, dt))
+    out, loss, final, grads = runs[0]
+    for k in [k for k in g if k.startswith("loss.")]:
+        want = float(g[k])
+        if np.isnan(want):          # (loss_self_iou: the reference's mean over the pairs of a video WITHOUT events is NaN; unweighted)
+            assert np.isnan(loss[k[5:]]) and k[5:] not in criterion.weight_dict, k
+            continue
+        assert abs(loss[k[5:]] - want) <= 2e-4 * max(1.0, abs(want)), (k, loss[k[5:]], want)
+    assert abs(final - float(g["final_loss"])) <= 2e-4 * float(g["final_loss"])
+    assert len(out["matched_indices"][0]) == 16
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        assert torch.equal(torch.stack([a, b]), t(g[f"match_{i}"])), i
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(n for n, v in grads.items() if float(v.abs().max()) > 0) == \
+        [n for n, w in zip(names, g["grad_norms"]) if float(w) > 0]
+    sensitive, worst = [], 0.0
+    for n, want in zip(names, g["grad_norms"]):            # (this fixture's norms are accumulated in float64; so are ours)
+        want = float(want)
+        errs = [abs(float(r[3][n].double().norm()) - want) / max(1e-3, want) for r in runs]
+        if errs[0] > SMOOTH_TOL:
+            norms = [float(r[3][n].double().norm()) for r in runs]
+            spread = (max(norms) - min(norms)) / max(1e-3, want)
+            sensitive.append((n, errs[0], spread))
+            assert location_fed(n) and min(errs) <= max(2e-2, 1.5 * spread), (n, errs, spread)
+        else:
+            worst = max(worst, errs[0])
+    assert all(location_fed(s_[0]) for s_ in sensitive), sensitive
+    for k, step in (("grad_rows.caption_head.0.logit.weight", 97), ("grad.class_head.1.weight", None),
+                    ("grad.count_head.0.bias", None), ("grad.transformer.level_embed", None)):
+        n = k.split(".", 1)[1]
+        got = grads[n][::step] if step else grads[n]
+        assert maxerr(got, g[k]) <= 5e-3 * max(1e-3, float(np.abs(g[k]).max())), k
+    print(f"B = 16: worst relative gradient-norm error of the smooth parameters {worst:.2e}; boundary-sensitive: {sensitive}")
+
+
 def test_anet_full_dimension_graphed_train_step_equals_eager():
     """the captured, layout-independent step (padded targets with capacities larger than the batch) computes what the
     eager step computes at the real dimensions: losses and smooth gradients agree to rounding.  The captioner's GEMMs run
