@@ -425,6 +425,79 @@ def make_yc2():
     save("pdvc_yc2", **rec)
 
 
+def make_yc2_train():
+    """One TRAINING forward / backward of the reference on the long-video configuration of make_yc2 (cfgs/yc2_tsn_dvc.yml, T = 512
+    -> S = 960, 100 queries, vocabulary 1607), B = 8 (B x heads = 64: the smallest batch the row-ownership backward serves),
+    every dropout 0, captions of 3..6 words, CUDA-op semantics: every loss term,
+    the matcher indices, the float64-accumulated gradient norm of EVERY parameter.  Pins the long-video BACKWARD kernels (level 0
+    in global memory, rows owned across query chunks) inside the real model."""
+    opt, model, criterion, cc = build_pdvc("cfgs/yc2_tsn_dvc.yml",
+                                           dict(enable_contrastive=False, device="cpu", max_caption_len=8,
+                                                frame_embedding_num=512, transformer_dropout_prob=0.0, drop_prob=0.0))
+    model.train()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed=512)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    B, T = 8, 512
+    valid, n_gt = [512, 389, 512, 277, 450, 512, 130, 498], [4, 3, 0, 2, 6, 1, 2, 5]
+    dt = synth_dt(B, T, opt.feature_dim, valid=valid, n_gt=n_gt, seed=4)
+    g = torch.Generator().manual_seed(23)
+    cap_len = 8
+    words = torch.randint(3, cap_len - 1, (sum(n_gt),), generator=g)              # words per caption: 3..6
+    caps = torch.zeros(sum(n_gt), cap_len, dtype=torch.long)
+    cap_mask = torch.zeros(sum(n_gt), cap_len)
+    for i, w in enumerate(words.tolist()):
+        caps[i, 1:1 + w] = torch.randint(1, opt.vocab_size, (w,), generator=g)
+        cap_mask[i, :w + 2] = 1
+    mx = max(n_gt)
+    dt.update(cap_tensor=caps, cap_mask=cap_mask,
+              gt_boxes_mask=torch.tensor([[k < n for k in range(mx)] for n in n_gt]).bool(),
+              gt_gather_idx=torch.tensor([i for i, n in enumerate(n_gt) for _ in range(n)]))
+    with cuda_semantics():
+        out, loss = model(dt, criterion, cc, "queries")
+        wd = criterion.weight_dict
+        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        final.backward()
+    rec = dict(meta_T=np.array(T), valid=np.array(valid), n_gt=np.array(n_gt), feature_dim=np.array(opt.feature_dim),
+               num_queries=np.array(opt.num_queries), vocab_size=np.array(opt.vocab_size),
+               cap_tensor=caps, cap_mask=cap_mask, final_loss=final.detach(),
+               param_names=np.array(sorted(shapes)), param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+    for k, v in loss.items():
+        rec[f"loss.{k}"] = torch.as_tensor(v).detach()
+    names = sorted(n for n, p_ in model.named_parameters() if p_.grad is not None)
+    params = dict(model.named_parameters())
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = torch.stack([params[n].grad.double().norm() for n in names])
+    for n in ("transformer.encoder.layers.0.self_attn.value_proj.weight", "transformer.decoder.layers.1.cross_attn.value_proj.bias",
+              "transformer.level_embed", "class_head.1.weight", "count_head.0.bias"):
+        rec["grad." + n] = params[n].grad if params[n].grad.numel() <= 4096 else params[n].grad[::16, ::8]
+    for i, (a, b) in enumerate(out["matched_indices"][0]):
+        rec[f"match_{i}"] = torch.stack([a, b])
+    # the same step in float64: the reference's OWN fp32 error of every gradient (at T = 512 the sampling-location gradients --
+    # differences of neighbouring frames times T_l -- make every parameter upstream of an offsets projection noisy)
+    grads32 = {n: params[n].grad.clone() for n in names}
+    model.zero_grad(set_to_none=True)
+    model.double()
+    dt64 = dict(dt)
+    dt64["video_tensor"], dt64["video_length"] = dt["video_tensor"].double(), dt["video_length"].double()
+    dt64["cap_mask"] = cap_mask.double()
+    dt64["video_target"] = [{"boxes": t_["boxes"].double(), "labels": t_["labels"]} for t_ in dt["video_target"]]
+    torch.set_default_dtype(torch.float64)
+    try:
+        with cuda_semantics():
+            out64, loss64 = model(dt64, criterion, cc, "queries")
+            final64 = sum(loss64[k] * wd[k] for k in loss64.keys() if k in wd)
+            final64.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    rec["final_loss_f64"] = final64.detach()
+    rec["grad_norms_f64"] = torch.stack([params[n].grad.norm() for n in names])
+    rec["grad_norm_f32_err"] = torch.stack([(grads32[n].double() - params[n].grad).norm() for n in names])
+    rec["match_same_in_f64"] = np.array(all(torch.equal(torch.stack(list(a)), torch.stack(list(b)))
+                                            for a, b in zip(out["matched_indices"][0], out64["matched_indices"][0])))
+    save("pdvc_yc2_train", **rec)
+
+
 def make_anet_full():
     """BASELINE.json configs 1-2 at the REAL model dimensions (cfgs/anet_tsp_ssvg.yml: 512-d TSP features, T = 100,
     300 queries, vocabulary 8517, 30 caption tokens) on a padded 2-video batch: evaluation forward of the reference,
@@ -908,7 +981,7 @@ if __name__ == "__main__":
         sys.exit(0)
     for flag, fn in (("--only-dataset", make_dataset), ("--only-anet-c3d", make_anet_c3d), ("--only-f64", make_f64),
                      ("--only-anet-full-train", make_anet_full_train), ("--only-anet-full-b16", make_anet_full_b16),
-                     ("--only-anet-full-train-b16", make_anet_full_train_b16),
+                     ("--only-anet-full-train-b16", make_anet_full_train_b16), ("--only-yc2-train", make_yc2_train),
                      ("--only-full-train-probe", make_full_train_probe)):
         if flag in sys.argv:
             fn()
@@ -928,6 +1001,7 @@ if __name__ == "__main__":
         make_anet_full_train()
         make_anet_full_b16()
         make_anet_full_train_b16()
+        make_yc2_train()
         make_full_train_probe()
     make_dataset()
     make_init()
