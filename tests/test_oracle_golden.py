@@ -350,3 +350,44 @@ def test_oracle_train_step_matches_reference_golden():
         got = grad_of(n)
         assert got is not None, n
         assert abs(float(got.norm()) - float(want)) <= 2e-3 * max(1.0, float(want)), (n, float(got.norm()), float(want))
+
+
+@pytest.mark.parametrize("name,seed_w,seed_dt", [("pdvc_anet_full_train_b16", 100, 16), ("pdvc_yc2_train", 512, 4)])
+def test_oracle_train_step_at_real_dimensions(name, seed_w, seed_dt):
+    """the oracle's training step on the round-4 fixtures at the real model dimensions -- the headline batch of 16 (anet) and the
+    long-video configuration (yc2, T = 512, B = 8): every loss term (NaN where the reference's unweighted self-IoU term of a video
+    without events is NaN), the weighted total, the matcher's cost through the total, and the float64-accumulated gradient norm of
+    every parameter.  Where the fixture carries the reference's own fp32-vs-fp64 error (yc2) it is the yardstick, as on the GPU."""
+    from oracle import torch_ref as R
+    from helpers import pdvc_state, pdvc_dt
+    g = load(name)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in pdvc_state(g, seed=seed_w).items()}
+    dt = pdvc_dt(g, feat=int(g["feature_dim"]), seed=seed_dt)
+    dt.update(cap_tensor=t(g["cap_tensor"]), cap_mask=t(g["cap_mask"]))
+    losses, total = R.pdvc_train_forward(sd, dt)
+    for k in [k for k in g if k.startswith("loss.")]:
+        want = float(g[k])
+        if np.isnan(want):
+            assert np.isnan(float(losses[k[5:]])), k
+            continue
+        assert abs(float(losses[k[5:]]) - want) <= 2e-4 * max(1.0, abs(want)), k
+    assert abs(float(total) - float(g["final_loss"])) <= 2e-4 * float(g["final_loss"])
+    total.backward()
+    names = [str(n) for n in g["grad_names"]]
+
+    def grad_of(n):                                   # tied parameters: see test_oracle_train_step_matches_reference_golden
+        tot = None
+        for k in (n, "transformer.decoder." + n if n.startswith("bbox_head.") else None,
+                  "caption_head.0." + n[len("caption_head.1."):] if n.startswith("caption_head.1.") else None,
+                  "caption_head.1." + n[len("caption_head.0."):] if n.startswith("caption_head.0.") else None,
+                  n[len("transformer.decoder."):] if n.startswith("transformer.decoder.bbox_head.") else None):
+            if k is not None and k in sd and sd[k].grad is not None:
+                tot = sd[k].grad if tot is None else tot + sd[k].grad
+        return tot
+    ref_err = ({n: float(e) / max(1e-3, float(w)) for n, e, w in zip(names, g["grad_norm_f32_err"], g["grad_norms_f64"])}
+               if "grad_norm_f32_err" in g else {})
+    for n, want in zip(names, g["grad_norms"]):
+        got = grad_of(n)
+        assert got is not None, n
+        tol = max(2e-3, 3.0 * ref_err.get(n, 0.0))
+        assert abs(float(got.double().norm()) - float(want)) <= tol * max(1.0, float(want)), (n, float(got.double().norm()), float(want))
