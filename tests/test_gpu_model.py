@@ -710,6 +710,54 @@ def test_headline_batch_of_16_eval_matches_reference():
         assert maxerr(lp[keep], t(f["cap_prob_eval"])[keep]) <= 2e-3
 
 
+def test_headline_batch_of_16_eval_under_autocast_against_the_fp32_reference(monkeypatch):
+    """The same batch under torch.autocast(bfloat16) against the reference's FP32 run: how far reduced-precision inference is from
+    the reference at the benchmark's batch, for the default policy (one fp16 matrix-core product per fp32 product,
+    gvl_amd/pdvc.py) -- eager and through GraphedEvalForward -- and, beside it, for the bf16-storage policy.  Measured (max / mean
+    where two): boxes 5.3e-3, logits 4.4e-2, 91 % of the 144 000 greedy tokens; the mean errors must be at least 3x below the
+    bf16-storage policy's."""
+    from gvl_amd.config import make_opt
+    from gvl_amd.parallel import GraphedEvalForward
+    from gvl_amd.pdvc import build
+    monkeypatch.delenv("GVL_AUTOCAST_INFERENCE", raising=False)
+    dev = torch.device("cuda:0")
+    f = load("pdvc_anet_full_b16")
+    opt = make_opt("anet_tsp_ssvg", num_queries=300, frame_embedding_num=100, device="cuda")
+    model, criterion, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f, seed=100), strict=True)
+    model = model.to(dev).eval()
+    dt = to_dev(pdvc_dt(f, feat=int(f["feature_dim"]), seed=16), dev)
+
+    def errors(out):
+        e = {}
+        for k, name in (("pred_boxes", "boxes"), ("pred_logits", "logits"), ("pred_count", "count")):
+            d = (out[k].float().cpu() - t(f[k])).abs()
+            e[name], e[name + "_mean"] = float(d.max()), float(d.mean())
+        e["tokens"] = float((out["seq"].cpu() == t(f["seq"].astype(np.int64))).float().mean())
+        return e
+    graphed = GraphedEvalForward(model, criterion, autocast_dtype=torch.bfloat16)
+    stats = {}
+    for mode in ("eager", "graph"):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "eager"):
+            out, loss = model(dt, criterion, None, "queries", eval_mode=True) if mode == "eager" else graphed(dt)
+        assert out["pred_logits"].dtype == torch.float32
+        e = stats[mode] = errors(out)
+        assert e["boxes"] <= 2e-2 and e["logits"] <= 1.5e-1 and e["count"] <= 6e-2 and e["tokens"] >= 0.85, e
+        for k in ("loss_ce", "loss_giou", "loss_counter"):             # (loss_ce is a sum over 4800 queries x the focal weight: ~60)
+            assert maxerr(loss[k].reshape(()), f[f"loss.{k}"].reshape(())) <= 2e-2 * max(1.0, abs(float(f[f"loss.{k}"]))), k     # (a matched pair may differ on a cost near-tie)
+    assert stats["eager"] == stats["graph"]                 # the captured step runs the same single-product kernels
+    with torch.no_grad():
+        exact, _ = model(dt, criterion, None, "queries", eval_mode=True)
+    assert errors(exact)["logits"] < stats["eager"]["logits"]                # ... and they ARE the reduced product
+    monkeypatch.setenv("GVL_AUTOCAST_INFERENCE", "bf16")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        lowp, _ = model(dt, criterion, None, "queries", eval_mode=True)
+    bf = errors(lowp)
+    print("autocast vs the fp32 reference at B = 16 -- single-product:", stats["eager"], "| bf16 storage:", bf)
+    for k in ("boxes_mean", "logits_mean", "count_mean"):
+        assert stats["eager"][k] * 3 <= bf[k], (k, stats["eager"][k], bf[k])
+
+
 def test_graphed_eval_forward_follows_parameter_updates(built):
     """operands derived from weights are cached by parameter version and captured as graph constants: after an
     in-place parameter update the graphed forward must agree with the eager one again (new capture)."""
