@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(512, 1)
       // (which plane a unit belongs to is a compile-time fact: 8 wavefronts' units of one i lie inside one plane)
       if (X1 && (i < WM ? 8 * i / (4 * WM) : 8 * (i - WM) / (kRowsB / 16))) continue;
       const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
-      glds16(base[i] + (row * 32 + schunk + k0 * (i < WM ? R : N)), st + dst[i]);       // plane_off(row, k0 + chunk, rows)
+      glds16_at(base[i], 2u * (uint32_t)(row * 32 + schunk + k0 * (i < WM ? R : N)), st + dst[i]);   // plane_off(row, k0 + chunk, rows)
     }
   };
   constexpr int kDma = X1 ? NG / 2 : NG;                              // DMA instructions per wavefront and stage
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(512, 1)
     for (int i = 0; i < NG; ++i) {
       if (X1 && (i < WM ? 8 * i / (4 * WM) : 8 * (i - WM) / (4 * WN))) continue;       // lo-plane units (see k_gemm_f16x3_w8)
       const int row = i < WM ? min(tm_ * kRowsA + blk16[i] + srow, R - 1) : min(tn_ * kRowsB + blk16[i] + srow, N - 1);
-      glds16(base[i] + (row * 32 + schunk + k0 * (i < WM ? R : N)), st + dst[i]);
+      glds16_at(base[i], 2u * (uint32_t)(row * 32 + schunk + k0 * (i < WM ? R : N)), st + dst[i]);
     }
   };
   constexpr int kDma = X1 ? NG / 2 : NG;

@@ -37,6 +37,13 @@ __device__ __forceinline__ void glds16(const void *g, void *lds) {
                                    (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
 }
 
+// the same with the source given as a wave-uniform base + an UNSIGNED 32-bit byte offset per lane: the instruction then takes
+// the base from scalar registers and the offset from one vector register (global_load_lds_dwordx4 v_off, s[base:base+1]) -- a signed
+// element index costs three more vector instructions per DMA (sign extension, 64-bit shift, 64-bit add)
+__device__ __forceinline__ void glds16_at(const _Float16 *base, uint32_t byte_off, void *lds) {
+  glds16(reinterpret_cast<const char *>(base) + (size_t)byte_off, lds);
+}
+
 // What happens to a tile of D = A . B^T once it is complete:
 //   kStore       out[row][col] = D            (A = activations, B = weight; bias per column)
 //   kArgmax      A = the vocabulary layer's weight, B = the hidden states: per (token row = column of D, 64 vocabulary
