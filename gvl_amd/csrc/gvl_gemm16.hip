@@ -783,6 +783,11 @@ __global__ void __launch_bounds__(512, 1)
   const int fa = lds_slot16(wm + (lane & 15), lane >> 4), fb = 2 * kASlots + lds_slot16(wn + (lane & 15), lane >> 4);
   struct Frag { h8 h[2], l[2]; };                                      // two 16-row blocks, hi | lo
   auto rdA = [&](const uint4 *st, int i0, Frag &f) {
+#ifdef GVL_ABLATE_LDS                                                  /* timing-only build: operand fragments from registers */
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { f.h[u] = __builtin_bit_cast(h8, make_uint4(fa, i0 + u, 2, 3)); f.l[u] = f.h[u]; }
+    if (true) return;
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f.h[u] = *reinterpret_cast<const h8 *>(&st[fa + 64 * (i0 + u)]);
@@ -790,6 +795,11 @@ __global__ void __launch_bounds__(512, 1)
     }
   };
   auto rdB = [&](const uint4 *st, int j0, Frag &f) {
+#ifdef GVL_ABLATE_LDS
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { f.h[u] = __builtin_bit_cast(h8, make_uint4(fb, j0 + u, 6, 7)); f.l[u] = f.h[u]; }
+    if (true) return;
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f.h[u] = *reinterpret_cast<const h8 *>(&st[fb + 64 * (j0 + u)]);

@@ -2,7 +2,7 @@
 # dev experiment: what the stage barrier, the operand DMA and the epilogue arithmetic cost the vocabulary product (k_gemm_f16x3_m16);
 # timing-only builds (results wrong), rebuilt and run alternately on one box
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for d in "" "-DGVL_ABLATE_EPI" "-DGVL_ABLATE_EPI -DGVL_ABLATE_DMA" "-DGVL_ABLATE_EPI -DGVL_ABLATE_BARRIER" "-DGVL_ABLATE_EPI -DGVL_ABLATE_DMA -DGVL_ABLATE_BARRIER" ""; do
+for d in "" "-DGVL_ABLATE_EPI" "-DGVL_ABLATE_EPI -DGVL_ABLATE_DMA" "-DGVL_ABLATE_EPI -DGVL_ABLATE_BARRIER" "-DGVL_ABLATE_EPI -DGVL_ABLATE_DMA -DGVL_ABLATE_BARRIER" "-DGVL_ABLATE_EPI -DGVL_ABLATE_LDS" "-DGVL_ABLATE_EPI -DGVL_ABLATE_LDS -DGVL_ABLATE_DMA -DGVL_ABLATE_BARRIER" ""; do
   GVL_BUILD_DEFS="$d" python -c "from gvl_amd import build; build.build(force=True)" > /dev/null 2>&1
   echo "== defs '$d'"
   python tools/x1_probe.py 2>&1 | grep "argmax form" | cut -c1-30
