@@ -468,6 +468,43 @@ def col_sum(x):
     return out
 
 
+def wgrad_eligible(dy, x):
+    return (dy.is_cuda and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.dim() == 2 and x.dim() == 2
+            and dy.shape[0] == x.shape[0] and dy.shape[0] > 0 and dy.stride(1) == 1 and x.stride(1) == 1
+            and dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def wgrad(dy, x, amax_dy, amax_x, grad_w=None, grad_b=None, want_bias=True, accumulate=False):
+    """dy (R, N), x (R, K) fp32 -> (grad_w (N, K) = dy^T x, grad_b (N) = column sums of dy) on the fp16 matrix cores at fp32
+    accuracy (include/gvl_msda.h: gvl_wgrad_f16x3_f32).  amax_*: fp32 vectors (or one number) whose maximum bounds |dy| / |x|.
+    grad_w / grad_b given: written in place, with accumulate=True ON TOP of their contents."""
+    _require(wgrad_eligible(dy, x), "wgrad: dy (R, N), x (R, K) fp32 CUDA matrices, unit column stride, N, K, strides % 4 == 0")
+    R, N = dy.shape
+    K = x.shape[1]
+    for a_ in (amax_dy, amax_x):
+        _require(a_.dtype == torch.float32 and a_.is_contiguous() and a_.numel() >= 1, "wgrad: amax must be contiguous fp32")
+    if grad_w is None:
+        _require(not accumulate, "wgrad: accumulate needs grad_w")
+        grad_w = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+    if grad_b is None and want_bias:
+        _require(not accumulate, "wgrad: accumulate needs grad_b")
+        grad_b = torch.empty(N, device=dy.device, dtype=torch.float32)
+    _require(grad_w.dtype == torch.float32 and grad_w.is_contiguous() and tuple(grad_w.shape) == (N, K)
+             and (grad_b is None or (grad_b.dtype == torch.float32 and grad_b.is_contiguous() and grad_b.numel() == N)),
+             "wgrad: grad_w (N, K) / grad_b (N) must be contiguous fp32")
+    L = _lib.lib()
+    nbytes = L.gvl_wgrad_workspace_bytes(R, N, K)
+    ws = torch.empty(max(nbytes, 16) // 4, device=dy.device, dtype=torch.float32)
+    with torch.cuda.device(dy.device):
+        rc = L.gvl_wgrad_f16x3_f32(dy.data_ptr(), dy.stride(0), amax_dy.data_ptr(), amax_dy.numel(), x.data_ptr(), x.stride(0),
+                                   amax_x.data_ptr(), amax_x.numel(), R, N, K, grad_w.data_ptr(),
+                                   grad_b.data_ptr() if grad_b is not None else None, 1 if accumulate else 0,
+                                   ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "wgrad_f16x3")
+    return grad_w, grad_b
+
+
 def lstm_cell_train_forward(gates_a, gates_b, gates_c, c_prev, act, h_out, c_out):
     n, H = c_prev.shape
     for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b), ("gates_c", gates_c)):
@@ -665,7 +702,7 @@ PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_gener
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
              12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train", 15: "match_cost", 16: "criterion",
              17: "pos_embed", 18: "col_sum", 19: "proj", 20: "split_rows", 21: "gemm_f16x3", 22: "layer_gemm",
-             23: "layer_norm_etc"}
+             23: "layer_norm_etc", 24: "wgrad_f16x3", 25: "mha_train"}
 
 
 def clock_probe_mhz(device=None, n_fma=20000):

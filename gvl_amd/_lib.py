@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 10          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 11          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -35,9 +35,11 @@ SIGNATURES = {
     "gvl_clock_probe": (_I, [_P, _I, _P]),
     "gvl_f16_products": (_I, [_I]),
     "gvl_residual_dropout_layer_norm_forward_f32": (_I, [_P, _I64, _I64, _P, _I64, _I64, _I, _I, _I, _P, _P, ctypes.c_float, ctypes.c_float,
-                                                         ctypes.c_uint32, _P, _P, _P, _P, _P, _P]),
+                                                         ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "gvl_residual_dropout_layer_norm_backward_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, ctypes.c_float, ctypes.c_uint32, _P, _P, _P,
-                                                          _P, _P, _P]),
+                                                          _P, _P, _P, _P]),
+    "gvl_relu_dropout_rows_forward_f32": (_I, [_P, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P, _P]),
+    "gvl_relu_dropout_rows_backward_f32": (_I, [_P, _P, _I, _I, ctypes.c_float, _P, _P, _P]),
     "gvl_rdln_backward_blocks": (_I, [_I]),
     "gvl_advance_step": (_I, [_P, _P]),
     "gvl_relu_dropout_forward_f32": (_I, [_P, _I64, ctypes.c_float, ctypes.c_uint32, _P, _P, _P]),
@@ -92,6 +94,10 @@ SIGNATURES = {
     "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_msda1d_fused_forward_bf16": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_bf16": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gvl_wgrad_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "gvl_wgrad_f16x3_f32": (_I, [_P, _I64, _P, _I, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _I, _P, _SZ, _P]),
+    "gvl_planes_chunk_elems": (_I, []),
+    "gvl_planes_refresh_f16": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_batch_device_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),

@@ -77,9 +77,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_fwd(
     const float *__restrict__ x, int64_t x_sb, int64_t x_sq, const float *__restrict__ sub, int64_t sub_sb, int64_t sub_sq,
     int Q, int R, int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float p, uint32_t seed,
     const int64_t *__restrict__ step, float *__restrict__ y, float *__restrict__ z, float *__restrict__ mean_out,
-    float *__restrict__ rstd_out) {
+    float *__restrict__ rstd_out, int64_t *__restrict__ step_used, const float *__restrict__ pos, int64_t pos_sb, int64_t pos_sq,
+    float *__restrict__ amax_y, float *__restrict__ amax_ypos) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = C >> 2;
   const Drop d = make_drop(p, seed, step);
+  // the step this forward drew its masks for, kept with the saved tensors: the backward regenerates the masks from THIS number,
+  // not from the live counter, which a second forward may have advanced in between
+  if (step_used && blockIdx.x == 0 && threadIdx.x == 0) *step_used = step ? *step : 0;
   const float4 *g4 = reinterpret_cast<const float4 *>(gamma), *b4 = reinterpret_cast<const float4 *>(beta);
   for (int row = blockIdx.x * kWavesPerBlock + wave; row < R; row += gridDim.x * kWavesPerBlock) {
     const int rb = row / Q, rq = row % Q;
@@ -113,8 +117,36 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_fwd(
       if (i < n4) {
         const float4 g = g4[i], b = b4[i];
         zr[i] = v[k];
-        yr[i] = make_float4((v[k].x - mean) * rstd * g.x + b.x, (v[k].y - mean) * rstd * g.y + b.y,
-                            (v[k].z - mean) * rstd * g.z + b.z, (v[k].w - mean) * rstd * g.w + b.w);
+        const float4 o = make_float4((v[k].x - mean) * rstd * g.x + b.x, (v[k].y - mean) * rstd * g.y + b.y,
+                                     (v[k].z - mean) * rstd * g.z + b.z, (v[k].w - mean) * rstd * g.w + b.w);
+        yr[i] = o;
+        v[k] = o;
+      }
+    }
+    if (amax_y || amax_ypos) {
+      // row maxima of y (and of y + pos, the query of the attention behind this norm): what the split of the next Linear
+      // product's activation operand needs (gvl_linear_f16x3_f32), left here instead of a pass of its own
+      const float4 *pr = pos ? reinterpret_cast<const float4 *>(pos + (int64_t)rb * pos_sb + (int64_t)rq * pos_sq) : nullptr;
+      float m = 0.f, mp = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n4) {
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+          if (pr) {
+            const float4 q = pr[i];
+            mp = fmaxf(fmaxf(mp, fmaxf(fabsf(v[k].x + q.x), fabsf(v[k].y + q.y))), fmaxf(fabsf(v[k].z + q.z), fabsf(v[k].w + q.w)));
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+        mp = fmaxf(mp, __shfl_xor(mp, o, 64));
+      }
+      if (lane == 0) {
+        if (amax_y) amax_y[row] = m;
+        if (amax_ypos) amax_ypos[row] = pr ? mp : m;
       }
     }
     if (lane == 0) {
@@ -128,7 +160,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_fwd(
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_bwd(
     const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, int R, int C, const float *__restrict__ gamma, float p, uint32_t seed,
-    const int64_t *__restrict__ step, float *__restrict__ dz, float *__restrict__ dsub, float *__restrict__ part) {
+    const int64_t *__restrict__ step, float *__restrict__ dz, float *__restrict__ dsub, float *__restrict__ part,
+    float *__restrict__ amax_dz) {
   __shared__ float4 red[kWavesPerBlock - 1][2][kMaxV * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = C >> 2;
   const Drop d = make_drop(p, seed, step);
@@ -164,6 +197,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_bwd(
     const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
     float4 *or_ = reinterpret_cast<float4 *>(dz + (int64_t)row * C);
     float4 *os = dsub ? reinterpret_cast<float4 *>(dsub + (int64_t)row * C) : nullptr;
+    float am = 0.f;
 #pragma unroll
     for (int k = 0; k < kMaxV; ++k) {
       const int i = lane + 64 * k;
@@ -172,7 +206,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_bwd(
                                      rstd * (g[k].z - m1 - xh[k].z * m2), rstd * (g[k].w - m1 - xh[k].w * m2));
         or_[i] = o;
         if (os) os[i] = drop4(d, o, (uint32_t)row * (uint32_t)C + 4u * (uint32_t)i);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
       }
+    }
+    if (amax_dz) {
+      // max |dz row| (x 1 / (1 - p): a bound of the dropped row dsub too) for the Linear products of the sublayer's backward
+#pragma unroll
+      for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+      if (lane == 0) amax_dz[row] = am * d.scale;
     }
   }
   // the workgroup's column sums: wavefronts 1.. hand theirs to wavefront 0 through LDS
@@ -265,6 +306,50 @@ __global__ void __launch_bounds__(256) k_relu_dropout_bwd(const float4 *__restri
   }
 }
 
+// row forms: one wavefront per row, the row's maximum of the result left for the next Linear product's split
+__global__ void __launch_bounds__(256) k_relu_dropout_rows_fwd(const float *__restrict__ x, int R, int C, float p, uint32_t seed,
+                                                               const int64_t *__restrict__ step, float *__restrict__ y,
+                                                               float *__restrict__ amax, int64_t *__restrict__ step_used) {
+  const Drop d = make_drop(p, seed, step);
+  if (step_used && blockIdx.x == 0 && threadIdx.x == 0) *step_used = step ? *step : 0;
+  const int lane = threadIdx.x & 63, n4 = C >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += gridDim.x * 4) {
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)row * C);
+    float4 *yr = reinterpret_cast<float4 *>(y + (int64_t)row * C);
+    float m = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+      float4 v = xr[i];
+      v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      v = drop4(d, v, (uint32_t)row * (uint32_t)C + 4u * (uint32_t)i);       // (the element index of the flat form)
+      yr[i] = v;
+      m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) amax[row] = m;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_relu_dropout_rows_bwd(const float *__restrict__ dy, const float *__restrict__ y, int R, int C,
+                                                               float scale, float *__restrict__ dx, float *__restrict__ amax) {
+  const int lane = threadIdx.x & 63, n4 = C >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += gridDim.x * 4) {
+    const float4 *gr = reinterpret_cast<const float4 *>(dy + (int64_t)row * C), *yr = reinterpret_cast<const float4 *>(y + (int64_t)row * C);
+    float4 *xr = reinterpret_cast<float4 *>(dx + (int64_t)row * C);
+    float m = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+      const float4 g = gr[i], v = yr[i];
+      const float4 o = make_float4(v.x > 0.f ? g.x * scale : 0.f, v.y > 0.f ? g.y * scale : 0.f, v.z > 0.f ? g.z * scale : 0.f,
+                                   v.w > 0.f ? g.w * scale : 0.f);
+      xr[i] = o;
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) amax[row] = m;
+  }
+}
+
 __global__ void k_advance_step(int64_t *step) { *step += 1; }
 
 int blocks_for(int R) {
@@ -295,7 +380,9 @@ extern "C" int gvl_residual_dropout_layer_norm_forward_f32(const float *x, int64
                                                            int64_t sub_sb, int64_t sub_sq, int Q, int R, int C,
                                                            const float *gamma, const float *beta, float eps, float p,
                                                            uint32_t seed, const int64_t *step, float *y, float *z,
-                                                           float *mean, float *rstd, void *stream) {
+                                                           float *mean, float *rstd, int64_t *step_used, const float *pos,
+                                                           int64_t pos_sb, int64_t pos_sq, float *amax_y, float *amax_ypos,
+                                                           void *stream) {
   const char *what = "gvl_residual_dropout_layer_norm_forward_f32";
   if (int rc = check_shape(what, R, C, p)) return rc;
   if (R == 0) return 0;
@@ -303,15 +390,17 @@ extern "C" int gvl_residual_dropout_layer_norm_forward_f32(const float *x, int64
   if (Q <= 0 || ((sub_sb | sub_sq | x_sb | x_sq) & 3) || (((uintptr_t)x | (uintptr_t)sub | (uintptr_t)gamma | (uintptr_t)beta |
                                                     (uintptr_t)y | (uintptr_t)z) & 15))
     return fail(GVL_EINVAL, "%s: Q > 0, row strides of x / sub multiples of 4, every tensor 16-byte aligned", what);
+  if (pos && (((pos_sb | pos_sq) & 3) || ((uintptr_t)pos & 15)))
+    return fail(GVL_EINVAL, "%s: pos must be 16-byte aligned with row strides that are multiples of 4", what);
   return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_rdln_fwd", k_rdln_fwd, dim3(blocks_for(R)), dim3(64 * kWavesPerBlock), 0,
                      (hipStream_t)stream, x, x_sb, x_sq, sub, sub_sb, sub_sq, Q, R, C, gamma, beta, eps, p, seed, step, y, z, mean,
-                     rstd);
+                     rstd, step_used, pos, pos_sb, pos_sq, amax_y, amax_ypos);
 }
 
 extern "C" int gvl_residual_dropout_layer_norm_backward_f32(const float *dy, const float *z, const float *mean,
                                                             const float *rstd, int R, int C, const float *gamma, float p,
                                                             uint32_t seed, const int64_t *step, float *dz, float *dsub,
-                                                            float *part, float *dgamma_dbeta, void *stream) {
+                                                            float *part, float *dgamma_dbeta, float *amax_dz, void *stream) {
   const char *what = "gvl_residual_dropout_layer_norm_backward_f32";
   if (int rc = check_shape(what, R, C, p)) return rc;
   if (!dgamma_dbeta) return fail(GVL_EINVAL, "%s: null pointer", what);
@@ -323,7 +412,7 @@ extern "C" int gvl_residual_dropout_layer_norm_backward_f32(const float *dy, con
   const int nb = blocks_for(R);
   if (int rc = gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_rdln_bwd", k_rdln_bwd, dim3(nb), dim3(64 * kWavesPerBlock), 0,
                            (hipStream_t)stream, dy, z, mean, rstd, R, C, gamma, p, seed, step, dz, p > 0.f ? dsub : nullptr,
-                           part))
+                           part, amax_dz))
     return rc;
   return gvl::launch(GVL_PROF_LAYER_NORM, nb, 2 * C, "k_rdln_finish", k_rdln_finish, dim3((2 * C / 4 + 15) / 16), dim3(16 * kFinGroups), 0,
                      (hipStream_t)stream, part, nb, 2 * C, dgamma_dbeta);
@@ -352,4 +441,30 @@ extern "C" int gvl_relu_dropout_backward_f32(const float *dy, const float *y, in
   const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
   return gvl::launch(GVL_PROF_LAYER_NORM, (int)(n >> 10), 0, "k_relu_dropout_bwd", k_relu_dropout_bwd, dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (const float4 *)dy, (const float4 *)y, n4, p > 0.f ? 1.f / (1.f - p) : 1.f, (float4 *)dx);
+}
+
+extern "C" int gvl_relu_dropout_rows_forward_f32(const float *x, int R, int C, float p, uint32_t seed, const int64_t *step, float *y,
+                                                 float *amax, int64_t *step_used, void *stream) {
+  const char *what = "gvl_relu_dropout_rows_forward_f32";
+  if (R < 0 || C <= 0 || (C & 3) || (int64_t)R * C >= ((int64_t)1 << 32))
+    return fail(GVL_EINVAL, "%s: needs C %% 4 == 0 and fewer than 2^32 elements (got R=%d C=%d)", what, R, C);
+  if (!(p >= 0.f && p < 1.f)) return fail(GVL_EINVAL, "%s: dropout probability must be in [0, 1) (got %g)", what, (double)p);
+  if (R == 0) return 0;
+  if (!x || !y || !amax || (((uintptr_t)x | (uintptr_t)y) & 15)) return fail(GVL_EINVAL, "%s: null / unaligned pointer", what);
+  const int blocks = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_relu_dropout_rows_fwd", k_relu_dropout_rows_fwd, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, x, R, C, p, seed, step, y, amax, step_used);
+}
+
+extern "C" int gvl_relu_dropout_rows_backward_f32(const float *dy, const float *y, int R, int C, float p, float *dx, float *amax,
+                                                  void *stream) {
+  const char *what = "gvl_relu_dropout_rows_backward_f32";
+  if (R < 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "%s: needs C %% 4 == 0 (got R=%d C=%d)", what, R, C);
+  if (!(p >= 0.f && p < 1.f)) return fail(GVL_EINVAL, "%s: dropout probability must be in [0, 1) (got %g)", what, (double)p);
+  if (R == 0) return 0;
+  if (!dy || !y || !dx || !amax || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15))
+    return fail(GVL_EINVAL, "%s: null / unaligned pointer", what);
+  const int blocks = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_relu_dropout_rows_bwd", k_relu_dropout_rows_bwd, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, dy, y, R, C, p > 0.f ? 1.f / (1.f - p) : 1.f, dx, amax);
 }

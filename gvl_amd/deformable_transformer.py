@@ -86,15 +86,16 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_ffn(self, src):
-        # (norm(x + dropout(sub)): one hand-written forward / backward kernel in training, gvl_amd/train_layers.py)
+    def forward_ffn(self, src, pos=None):
+        # (norm(x + dropout(sub)): one hand-written forward / backward kernel in training, gvl_amd/train_layers.py; `pos`: the
+        #  result also carries the row maxima of result + pos for the next layer's attention query)
         return _tl.residual_dropout_norm(src, self.linear2(_tl.relu_dropout(self.linear1(src), self.activation, self.dropout2)),
-                                         self.dropout3, self.norm2)
+                                         self.dropout3, self.norm2, pos)
 
     def forward(self, src, pos, reference_points, temporal_shapes, level_start_index, padding_mask=None):
-        attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, temporal_shapes,
+        attn = self.self_attn(_tl.add_pos(src, pos), reference_points, src, temporal_shapes,
                               level_start_index, padding_mask)
-        return self.forward_ffn(_tl.residual_dropout_norm(src, attn, self.dropout1, self.norm1))
+        return self.forward_ffn(_tl.residual_dropout_norm(src, attn, self.dropout1, self.norm1), pos)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -153,24 +154,24 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_ffn(self, tgt):
+    def forward_ffn(self, tgt, pos=None):
         return _tl.residual_dropout_norm(tgt, self.linear2(_tl.relu_dropout(self.linear1(tgt), self.activation, self.dropout3)),
-                                         self.dropout4, self.norm3)
+                                         self.dropout4, self.norm3, pos)
 
     def forward(self, tgt, query_pos, reference_points, src, src_temporal_shapes, level_start_index,
                 src_padding_mask=None, query_mask=None):
-        qk = self.with_pos_embed(tgt, query_pos).transpose(0, 1)
+        qk = _tl.add_pos(tgt, query_pos).transpose(0, 1)
         # The reference discards the averaged attention map ([0] at pdvc/deformable_transformer.py:267-268).  Not asking for
         # it lets nn.MultiheadAttention take its fused attention path: measured 0.4 % of the eval step; in training the
         # fused forward + backward kernels are slower than bmm / softmax / bmm at this size (300 queries): +0.9 % of the step
         # (average_attn_weights=False: the unfused path without the mean over the heads of a (B, 8, Q, Q) map nobody reads)
         sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask, need_weights=self.training,
                             average_attn_weights=False)[0].transpose(0, 1)
-        tgt = _tl.residual_dropout_norm(tgt, sa, self.dropout2, self.norm2)       # (sa: a transposed view, read in place)
-        ca = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_temporal_shapes,
+        tgt = _tl.residual_dropout_norm(tgt, sa, self.dropout2, self.norm2, query_pos)   # (sa: a transposed view, read in place)
+        ca = self.cross_attn(_tl.add_pos(tgt, query_pos), reference_points, src, src_temporal_shapes,
                              level_start_index, src_padding_mask)
         tgt = _tl.residual_dropout_norm(tgt, ca, self.dropout1, self.norm1)
-        return self.forward_ffn(tgt)
+        return self.forward_ffn(tgt, query_pos)
 
 
 class DeformableTransformerDecoder(nn.Module):

@@ -105,7 +105,7 @@ def linear(a, w, segs, a2=None, flags=0):
         rc = _lib.lib().gvl_linear_f16x3_f32(
             a.data_ptr(), a.stride(0), a2.data_ptr() if a2 is not None else None, a2.stride(0) if a2 is not None else 0,
             a2.shape[0] if a2 is not None else 0, R, K, w.planes.hi.data_ptr(), w.planes.lo.data_ptr(),
-            w.planes.scale.data_ptr(), w.bias.data_ptr(), w.N, arr, len(segs), flags,
+            w.planes.scale.data_ptr(), w.bias.data_ptr() if w.bias is not None else None, w.N, arr, len(segs), flags,
             torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "linear_f16x3")
 

@@ -145,7 +145,151 @@ class _NoCtx:
         pass
 
 
+# ---- the TRAINING form on the hand-written kernels -------------------------------------------------------------------------
+# forward  y = x [W_0; W_1; ..]^T + [b_0; b_1; ..]   gvl_linear_f16x3_f32 on the planes of the stacked weight
+# backward dx = dy W                                  the same kernel on the planes of the TRANSPOSED stacked weight
+#          dW = dy^T x,  db = sum_r dy                gvl_wgrad_f16x3_f32 (one pass over dy for both)
+# The planes come from the model's TrainPlanes (gvl_amd/train_planes.py: all weights of the step in two launches per forward);
+# a weight that is not registered there is split on demand, per parameter version.  The row maxima the activation splits need
+# ride on the tensors (gvl_amd.layers.tag_amax) when the producer is one of the path's own kernels; otherwise one
+# gvl_row_absmax_f32 launch computes them.
+_TRAIN_LINEAR = os.environ.get("GVL_TRAIN_LINEAR", "") != "torch"
+_ACTIVE_PLANES = None
+MIN_TRAIN_ROWS = 512
+
+
+def train_linear_enabled(on=None):
+    """query / set the switch (GVL_TRAIN_LINEAR=torch at import: the library GEMMs of round 4, for A/B runs)"""
+    global _TRAIN_LINEAR
+    if on is not None:
+        _TRAIN_LINEAR = bool(on)
+    return _TRAIN_LINEAR
+
+
+def set_active_planes(planes):
+    """the TrainPlanes the current training forward refreshed (gvl_amd.pdvc.PDVC.forward), or None"""
+    global _ACTIVE_PLANES
+    prev, _ACTIVE_PLANES = _ACTIVE_PLANES, planes
+    return prev
+
+
+def _operands(weights, biases):
+    """(forward operand, transposed operand) of the stacked weight"""
+    from .train_planes import Operand
+    tp = _ACTIVE_PLANES
+    n_total, K = sum(w.shape[0] for w in weights), weights[0].shape[1]
+    if tp is not None:
+        hit = tp.lookup(weights)
+        if hit is not None and tp.is_fresh():
+            return Operand(hit[0], n_total, K, hit[2]), Operand(hit[1], K, n_total, None)
+    owner = weights[0]
+    key = tuple((t.data_ptr(), t._version) for t in list(weights) + [b for b in biases if b is not None])
+    cached = owner.__dict__.get("_gvl_train_planes")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            w = weights[0].detach() if len(weights) == 1 else torch.cat([w_.detach() for w_ in weights], 0)
+            if all(b is None for b in biases):
+                b = None
+            elif len(biases) == 1:
+                b = biases[0].detach()
+            else:
+                b = torch.cat([b_.detach() if b_ is not None else w.new_zeros(w_.shape[0]) for w_, b_ in zip(weights, biases)], 0)
+            cached = (key, Operand(MSDA.split_rows(w.contiguous()), n_total, K, b),
+                      Operand(MSDA.split_rows(w.t().contiguous()), K, n_total, None))
+        owner.__dict__["_gvl_train_planes"] = cached
+    return cached[1], cached[2]
+
+
+def _row_amax(t2, src=None):
+    """row maxima of the (R, C) matrix t2: the tag its producer left (on t2 itself or on the tensor `src` it is a view of), or one
+    gvl_row_absmax_f32 launch"""
+    from . import layers as L
+    for cand in (t2, src):
+        if cand is not None:
+            am = L.amax_of(cand, t2.shape[0])
+            if am is not None:
+                return am
+    return L.row_absmax(t2)[0]
+
+
+class _TrainLinearFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nblk, *params):
+        from . import layers as L
+        weights, biases = params[:nblk], params[nblk:]
+        K = weights[0].shape[1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        am = _row_amax(x2, x)
+        op, op_t = _operands(weights, biases)
+        out = torch.empty(x2.shape[0], op.N, device=x.device, dtype=torch.float32)
+        L.linear(x2, op, [L.seg(0, out, am)])
+        ctx.save_for_backward(x2, am, *weights)
+        ctx.op_t, ctx.nblk, ctx.x_shape = op_t, nblk, x.shape
+        ctx.has_bias = [b is not None for b in biases]
+        return out.view(*x.shape[:-1], op.N)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        from . import layers as L
+        x2, am_x = ctx.saved_tensors[:2]
+        weights = ctx.saved_tensors[2:]
+        nblk, op_t = ctx.nblk, ctx.op_t
+        n_total = op_t.K
+        g2 = grad_out.reshape(-1, n_total)
+        if g2.stride(1) != 1 or g2.stride(0) % 4 or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        am_g = _row_amax(g2, grad_out)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(x2.shape[0], op_t.N, device=g2.device, dtype=torch.float32)
+            L.linear(g2, op_t, [L.seg(0, gx, am_g)])
+            gx = gx.view(ctx.x_shape)
+        need_w = any(ctx.needs_input_grad[2:2 + nblk])
+        need_b = any(n and h for n, h in zip(ctx.needs_input_grad[2 + nblk:], ctx.has_bias))
+        gws, gbs = [None] * nblk, [None] * nblk
+        if need_w or need_b:
+            gw, gb = MSDA.wgrad(g2, x2, am_g, am_x, want_bias=need_b)
+            off = 0
+            for i, w in enumerate(weights):
+                n = w.shape[0]
+                if ctx.needs_input_grad[2 + i]:
+                    gws[i] = gw[off:off + n]
+                if ctx.has_bias[i] and ctx.needs_input_grad[2 + nblk + i]:
+                    gbs[i] = gb[off:off + n]
+                off += n
+        return (gx, None, *gws, *gbs)
+
+
+def train_linear_eligible(x, weights, biases):
+    if not (_TRAIN_LINEAR and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and x.dim() >= 2):
+        return False
+    K = x.shape[-1]
+    if K % 64 or x.numel() // K < MIN_TRAIN_ROWS or x.numel() >= 2 ** 31:
+        return False
+    n_total = 0
+    for w, b in zip(weights, biases):
+        if not (w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == K and w.shape[0] % 32 == 0 and w.is_contiguous()
+                and w.is_cuda and (b is None or (b.dtype == torch.float32 and b.is_contiguous() and b.numel() == w.shape[0]))):
+            return False
+        n_total += w.shape[0]
+    if n_total % 64:
+        return False
+    return x.requires_grad or any(w.requires_grad for w in weights) or any(b is not None and b.requires_grad for b in biases)
+
+
+def train_linear(x, weights, biases):
+    """x (..., K) -> x [W_0; W_1; ..]^T + [b_0; ..]  (..., sum N_i) through the hand-written kernels, differentiable in x, every
+    W_i and every b_i; callers check train_linear_eligible first"""
+    return _TrainLinearFunction.apply(x, len(weights), *weights, *biases)
+
+
 def linear(x, weight, bias=None):
+    if train_linear_eligible(x, (weight,), (bias,)):
+        return train_linear(x, (weight,), (bias,))
     if (bias is None or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32
             or bias.dtype != torch.float32 or torch.is_autocast_enabled()
             or not torch.is_grad_enabled() or not bias.requires_grad):

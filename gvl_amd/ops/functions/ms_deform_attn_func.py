@@ -119,14 +119,21 @@ class MSDeformAttnFusedFunction(Function):
         ctx.in_dtypes = (proj.dtype, reference_points.dtype)
         proj = _like(proj, value.dtype)                              # bf16 value <-> bf16 projection rows
         reference_points = _like(reference_points, torch.float32)    # positions are never rounded to bf16
+        # fp32: the kernel also leaves max |out row| (one atomic max per row and head) -- the row scale output_proj's split needs
+        amax = None
+        if value.dtype == torch.float32 and torch.is_grad_enabled():
+            amax = torch.zeros(proj.shape[0] * proj.shape[1], device=value.device, dtype=torch.float32)
         out = MSDA.msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, reference_points, n_levels,
-                                        n_points, pad_mode)
+                                        n_points, pad_mode, amax_out=amax)
         ctx.save_for_backward(value, proj, reference_points, spatial_shapes, level_start_index)
-        return out
+        if amax is not None:
+            ctx.mark_non_differentiable(amax)
+            return out, amax
+        return out, None
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, _damax=None):
         value, proj, ref, shapes, lsi = ctx.saved_tensors
         if getattr(shapes, "_gvl_host", None) is None:
             shapes._gvl_host = ctx.host

@@ -14,7 +14,7 @@ from torch import nn
 
 from .. import functions as _fn
 from ... import MultiScaleDeformableAttention as MSDA
-from ...linear import Linear, linear, projection
+from ...linear import Linear, linear, projection, train_linear, train_linear_eligible
 
 
 def _power_of_two(n):
@@ -132,10 +132,21 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         # one GEMM for both projections: columns [0,128) raw offsets, [128,256) attention logits
-        w_cat, b_cat = self._cat_projection()
-        proj = projection(query.contiguous(), w_cat, b_cat)
-        out = _fn.MSDeformAttnFusedFunction.apply(value, proj, reference_points.contiguous(), shapes2d,
-                                                  level_start_index, self.n_levels, self.n_points, self.pad_mode)
+        q = query.contiguous()
+        ws = (self.sampling_offsets.weight, self.attention_weights.weight)
+        bs = (self.sampling_offsets.bias, self.attention_weights.bias)
+        if train_linear_eligible(q, ws, bs):
+            # training: both projections as ONE hand-written product over the stacked weight (no torch.cat of the parameters:
+            # the planes of the stack come from the model's TrainPlanes), dx / dW / db from the hand-written backward kernels
+            proj = train_linear(q, ws, bs)
+        else:
+            w_cat, b_cat = self._cat_projection()
+            proj = projection(q, w_cat, b_cat)
+        out, amax = _fn.MSDeformAttnFusedFunction.apply(value, proj, reference_points.contiguous(), shapes2d,
+                                                        level_start_index, self.n_levels, self.n_points, self.pad_mode)
+        if amax is not None:
+            from ... import layers as _layers
+            _layers.tag_amax(out, amax)
         return self.output_proj(out)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,

@@ -192,7 +192,31 @@ class PDVC(nn.Module):
         pt = dt.get('_gvl_targets')
         return pt if pt is not None else dt['video_target']
 
+    def train_planes(self):
+        """operand planes of the weights the hand-written training products read (gvl_amd/train_planes.py), built on first use"""
+        tp = self.__dict__.get("_gvl_train_planes")
+        dev = self.query_embed.weight.device
+        if tp is None or tp.device != dev:
+            from .train_planes import build_train_planes
+            tp = self.__dict__["_gvl_train_planes"] = build_train_planes(self, dev)
+        return tp
+
     def forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
+        from . import linear as _linear
+        if (self.training and torch.is_grad_enabled() and not torch.is_autocast_enabled() and dt['video_tensor'].is_cuda
+                and _linear.train_linear_enabled()):
+            # TRAINING: the planes of every weight the hand-written Linear products read, for this forward's parameter values
+            # (two launches); the products' autograd nodes keep what their backward needs
+            tp = self.train_planes()
+            tp.refresh()
+            prev = _linear.set_active_planes(tp)
+            try:
+                return self._forward(dt, criterion, contrastive_criterion, transformer_input_type, eval_mode)
+            finally:
+                _linear.set_active_planes(prev)
+        return self._forward(dt, criterion, contrastive_criterion, transformer_input_type, eval_mode)
+
+    def _forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
         if (torch.is_autocast_enabled() and not torch.is_grad_enabled() and not self.training
                 and dt['video_tensor'].is_cuda and autocast_inference_policy() != "bf16"):
             # INFERENCE under torch.autocast (BASELINE config 5 is named "bf16"): the forward stays on the hand-written
@@ -247,7 +271,8 @@ class PDVC(nn.Module):
             # "TypeError: 'NoneType' object is not iterable" (reproduced by tests/golden/make_golden.py:make_full_train_probe,
             # recorded in tests/golden/full_train_probe.npz).  No reference config sets set_cost_caption > 0; the branch has
             # no behaviour to mirror other than this error, which is raised with the reference's own type and message.
-            raise TypeError("'NoneType' object is not iterable")
+            raise TypeError("'NoneType' object is not iterable (set_cost_caption > 0 is not supported: the reference itself "
+                            "fails here, pdvc.py:743, with the LSTM-DSA captioner)")
         return self.parallel_prediction_matched(dt, criterion, contrastive_criterion, hs, query_embed,
                                                 init_reference, inter_references, others, disable_refine)
 

@@ -61,91 +61,144 @@ def eligible(x, sub, norm, drop):
             and x.data_ptr() % 16 == 0 and sub.data_ptr() % 16 == 0 and x.numel() < 2 ** 32)
 
 
+def _pos_strides(pos, B, Q, C):
+    """(pointer, batch stride, query stride) of the positional addend of the NEXT attention query for k_rdln_fwd, or None when
+    its layout is not addressable that way"""
+    if pos is None or pos.dtype != torch.float32 or not pos.is_cuda or pos.dim() != 3 or tuple(pos.shape) != (B, Q, C) \
+            or pos.stride(2) != 1 or pos.stride(0) % 4 or pos.stride(1) % 4 or pos.data_ptr() % 16:
+        return None
+    return pos.data_ptr(), pos.stride(0), pos.stride(1)
+
+
 class ResidualDropoutLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, sub, weight, bias, eps, p, seed, step):
+    def forward(ctx, x, sub, weight, bias, eps, p, seed, step, pos):
+        from . import layers as L
         B, Q, C = x.shape
         R = B * Q
         y = torch.empty(B, Q, C, device=x.device, dtype=torch.float32)
         z = torch.empty_like(y)
-        stats = torch.empty(2, R, device=x.device, dtype=torch.float32)
+        stats = torch.empty(4, R, device=x.device, dtype=torch.float32)        # mean | rstd | max |y| | max |y + pos|
+        # the step whose masks this forward drew, kept for the backward (the live counter may move before it runs: ADVICE r4)
+        used = torch.empty(1, device=x.device, dtype=torch.int64) if step is not None else None
+        ps = _pos_strides(pos, B, Q, C)
         with torch.cuda.device(x.device):
             rc = _lib.lib().gvl_residual_dropout_layer_norm_forward_f32(
                 x.data_ptr(), x.stride(0), x.stride(1), sub.data_ptr(), sub.stride(0), sub.stride(1), Q, R, C,
                 weight.data_ptr(), bias.data_ptr(),
                 float(eps), float(p), int(seed), step.data_ptr() if step is not None else None, y.data_ptr(), z.data_ptr(),
-                stats[0].data_ptr(), stats[1].data_ptr(), torch.cuda.current_stream().cuda_stream)
+                stats[0].data_ptr(), stats[1].data_ptr(), used.data_ptr() if used is not None else None,
+                ps[0] if ps else None, ps[1] if ps else 0, ps[2] if ps else 0, stats[2].data_ptr(),
+                stats[3].data_ptr() if ps else None, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "residual_dropout_layer_norm_forward")
-        ctx.save_for_backward(z, stats, weight, step if step is not None else x.new_empty(0))
+        ctx.save_for_backward(z, stats, weight, used if used is not None else x.new_empty(0))
         ctx.p, ctx.seed, ctx.has_step = float(p), int(seed), step is not None
-        return y
+        ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats):
+        from . import layers as L
         z, stats, weight, step = ctx.saved_tensors
         B, Q, C = z.shape
         R = B * Q
         dy = dy.contiguous()
-        L = _lib.lib()
+        lib = _lib.lib()
         dz = torch.empty_like(z)
         dsub = torch.empty_like(z) if ctx.p > 0 else None
-        part = torch.empty(L.gvl_rdln_backward_blocks(R), 2 * C, device=z.device, dtype=torch.float32)
+        part = torch.empty(lib.gvl_rdln_backward_blocks(R), 2 * C, device=z.device, dtype=torch.float32)
         dgb = torch.empty(2, C, device=z.device, dtype=torch.float32)
+        am = torch.empty(R, device=z.device, dtype=torch.float32)
         with torch.cuda.device(z.device):
-            rc = L.gvl_residual_dropout_layer_norm_backward_f32(
+            rc = lib.gvl_residual_dropout_layer_norm_backward_f32(
                 dy.data_ptr(), z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), R, C, weight.data_ptr(), ctx.p,
                 ctx.seed, step.data_ptr() if ctx.has_step else None, dz.data_ptr(),
-                dsub.data_ptr() if dsub is not None else None, part.data_ptr(), dgb.data_ptr(),
+                dsub.data_ptr() if dsub is not None else None, part.data_ptr(), dgb.data_ptr(), am.data_ptr(),
                 torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "residual_dropout_layer_norm_backward")
-        return dz, (dsub if dsub is not None else dz), dgb[0], dgb[1], None, None, None, None
+        # (one bound serves both: |dsub| <= |dz| / (1 - p))
+        L.tag_amax(dz, am)
+        if dsub is not None:
+            L.tag_amax(dsub, am)
+        return dz, (dsub if dsub is not None else dz), dgb[0], dgb[1], None, None, None, None, None
 
 
-def residual_dropout_norm(x, sub, drop, norm):
-    """norm(x + drop(sub)) -- the fused kernels when they apply, PyTorch's formulation otherwise"""
+def residual_dropout_norm(x, sub, drop, norm, pos=None):
+    """norm(x + drop(sub)) -- the fused kernels when they apply, PyTorch's formulation otherwise.  pos: the positional addend
+    of the attention that consumes the result next; the result then also carries the row maxima of `result + pos`
+    (add_pos below hands them to the sum), so the attention's projection needs no pass of its own over its query"""
     if not eligible(x, sub, norm, drop):
         return norm(x + drop(sub))
     p = drop.p if drop.training else 0.0
     if p >= 1.0:
         return norm(x + drop(sub))
-    return ResidualDropoutLayerNorm.apply(x, sub, norm.weight, norm.bias, norm.eps, p, _site_seed(drop),
-                                          step_counter(x.device) if p > 0 else None)
+    from . import layers as L
+    y, stats = ResidualDropoutLayerNorm.apply(x, sub, norm.weight, norm.bias, norm.eps, p, _site_seed(drop),
+                                              step_counter(x.device) if p > 0 else None, pos)
+    L.tag_amax(y, stats[2])
+    if _pos_strides(pos, *x.shape) is not None:
+        y._gvl_amax_pos = (stats[3], y._version, pos.data_ptr(), pos._version)
+    return y
+
+
+def add_pos(t, pos):
+    """t + pos (with_pos_embed of pdvc/deformable_transformer.py:185,253) -- carrying the row maxima of the sum when t's producer
+    left them (residual_dropout_norm(..., pos=pos))"""
+    if pos is None:
+        return t
+    q = t + pos
+    hit = getattr(t, "_gvl_amax_pos", None)
+    if hit is not None and hit[1] == t._version and hit[2] == pos.data_ptr() and hit[3] == pos._version:
+        from . import layers as L
+        L.tag_amax(q, hit[0])
+    return q
 
 
 class ReluDropout(torch.autograd.Function):
     """dropout(relu(x)) in ONE kernel; backward from the OUTPUT alone (y > 0 exactly where the element was kept and positive):
-    no mask tensor, and x -- the output of linear1, which no backward reads -- is free as soon as y exists"""
+    no mask tensor, and x -- the output of linear1, which no backward reads -- is free as soon as y exists.  Row forms of the
+    kernels: the row maxima of y / of dx are left for the Linear products on either side."""
 
     @staticmethod
     def forward(ctx, x, p, seed, step):
+        C = x.shape[-1]
+        R = x.numel() // C
         y = torch.empty_like(x)
+        am = torch.empty(R, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            rc = _lib.lib().gvl_relu_dropout_forward_f32(x.data_ptr(), x.numel(), float(p), int(seed),
-                                                         step.data_ptr() if step is not None else None, y.data_ptr(),
-                                                         torch.cuda.current_stream().cuda_stream)
+            rc = _lib.lib().gvl_relu_dropout_rows_forward_f32(x.data_ptr(), R, C, float(p), int(seed),
+                                                              step.data_ptr() if step is not None else None, y.data_ptr(),
+                                                              am.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "relu_dropout_forward")
         ctx.save_for_backward(y)
         ctx.p = float(p)
-        return y
+        ctx.mark_non_differentiable(am)
+        return y, am
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dam):
+        from . import layers as L
         y, = ctx.saved_tensors
         dy = dy.contiguous()
+        C = y.shape[-1]
+        R = y.numel() // C
         dx = torch.empty_like(y)
+        am = torch.empty(R, device=y.device, dtype=torch.float32)
         with torch.cuda.device(y.device):
-            rc = _lib.lib().gvl_relu_dropout_backward_f32(dy.data_ptr(), y.data_ptr(), y.numel(), ctx.p, dx.data_ptr(),
-                                                          torch.cuda.current_stream().cuda_stream)
+            rc = _lib.lib().gvl_relu_dropout_rows_backward_f32(dy.data_ptr(), y.data_ptr(), R, C, ctx.p, dx.data_ptr(),
+                                                               am.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "relu_dropout_backward")
-        return dx, None, None, None
+        return L.tag_amax(dx, am), None, None, None
 
 
 def relu_dropout(x, activation, drop):
     """drop(activation(x)) -- one kernel for ReLU on fp32 activations in training"""
     if not (enabled() and x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and x.requires_grad
-            and x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0 and x.numel() < 2 ** 32
+            and x.dtype == torch.float32 and x.is_contiguous() and x.dim() >= 2 and x.shape[-1] % 4 == 0 and x.numel() < 2 ** 32
             and x.data_ptr() % 16 == 0 and activation in (F.relu, torch.relu)
             and 0.0 <= (drop.p if drop.training else 0.0) < 1.0):
         return drop(activation(x))
     p = drop.p if drop.training else 0.0
-    return ReluDropout.apply(x, p, _site_seed(drop), step_counter(x.device) if p > 0 else None)
+    from . import layers as L
+    y, am = ReluDropout.apply(x, p, _site_seed(drop), step_counter(x.device) if p > 0 else None)
+    return L.tag_amax(y, am)

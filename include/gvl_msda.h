@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 10  /* 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 11  /* 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step); 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -322,16 +322,28 @@ int gvl_pos_embed_sine_f32(const unsigned char *mask, const float *dim_t, const 
 int gvl_residual_dropout_layer_norm_forward_f32(const float *x, int64_t x_sb, int64_t x_sq, const float *sub, int64_t sub_sb,
                                                 int64_t sub_sq, int Q, int R, int C, const float *gamma, const float *beta,
                                                 float eps, float p, uint32_t seed, const int64_t *step, float *y, float *z,
-                                                float *mean, float *rstd, void *stream);
+                                                float *mean, float *rstd, int64_t *step_used, const float *pos, int64_t pos_sb,
+                                                int64_t pos_sq, float *amax_y, float *amax_ypos, void *stream);
 int gvl_residual_dropout_layer_norm_backward_f32(const float *dy, const float *z, const float *mean, const float *rstd, int R,
                                                  int C, const float *gamma, float p, uint32_t seed, const int64_t *step,
-                                                 float *dz, float *dsub, float *part, float *dgamma_dbeta, void *stream);
+                                                 float *dz, float *dsub, float *part, float *dgamma_dbeta, float *amax_dz,
+                                                 void *stream);
+/*    ABI 11 additions (all optional, NULL = absent): step_used receives the value of *step this forward drew its masks for -- the
+ *    backward is given THAT pointer as `step`, so a forward that ran in between (and advanced the live counter) cannot change the
+ *    masks the backward regenerates; amax_y[r] = max |y[r][.]| and amax_ypos[r] = max |y[r][.] + pos[row r][.]| (pos addressed
+ *    like x: b * pos_sb + q * pos_sq) -- the row maxima the next Linear product's split needs for `y` and for the attention query
+ *    `y + pos` (gvl_linear_f16x3_f32); amax_dz[r] = max |dz[r][.]| / (1 - p), a bound of row r of dz AND of dsub. */
 int gvl_rdln_backward_blocks(int R);
 /*    y = dropout(relu(x)) of the FFNs (deformable_transformer.py:189-191, 257-259), n elements (n % 4 == 0, < 2^32), y == x
  *    allowed; same mask rule as above.  backward: dx = y > 0 ? dy / (1 - p) : 0 -- no mask tensor (y > 0 exactly
  *    where the element was kept and positive). */
 int gvl_relu_dropout_forward_f32(const float *x, int64_t n, float p, uint32_t seed, const int64_t *step, float *y, void *stream);
 int gvl_relu_dropout_backward_f32(const float *dy, const float *y, int64_t n, float p, float *dx, void *stream);
+/*    the same two kernels over ROWS of C elements (C % 4 == 0, C <= 4096; one wavefront per row), leaving max |row| of the result
+ *    in amax (R): the row maxima of the FFN's hidden activation / of its gradient for the Linear products around it. */
+int gvl_relu_dropout_rows_forward_f32(const float *x, int R, int C, float p, uint32_t seed, const int64_t *step, float *y,
+                                      float *amax, int64_t *step_used, void *stream);
+int gvl_relu_dropout_rows_backward_f32(const float *dy, const float *y, int R, int C, float p, float *dx, float *amax, void *stream);
 int gvl_advance_step(int64_t *step, void *stream);
 
 /* -- column sums of a row-major fp32 matrix: out[c] = sum_r x[r * ld + c] -- the bias gradient of the nn.Linear layers on
@@ -383,6 +395,8 @@ int gvl_ce_rows_backward_f32(float *logits, int64_t ld, int R, int V, const int6
 #define GVL_PROF_GEMM16 21
 #define GVL_PROF_LINEAR 22
 #define GVL_PROF_LAYER_NORM 23
+#define GVL_PROF_WGRAD 24
+#define GVL_PROF_MHA_TRAIN 25
 int gvl_prof_enable(int on);   /* 0 off | 1 sampling-path kernels | 2 also GVL_PROF_PROJ (stamping two consecutive launches
                                   inflates the second one's interval by 2-3 us, so level 1 leaves the projection alone) */
 /* Phase stamps of the temporal kernels (diagnostics): while a DEVICE buffer of 2 x 4096 x 4 uint64 is set, every
@@ -623,6 +637,49 @@ int gvl_hungarian_batch_f32(const float *C, int B, int Q, int G, const int *size
  *   max_rows / max_cols: the largest min(Q, n*tile) and max(Q, n*tile) over the problems (<= 256 / <= 1024). */
 int gvl_lsap_batch_device_f32(const float *C, const int64_t *problems, int n_problems, int max_rows, int max_cols,
                               int64_t *rows_out, int64_t *cols_out, int *status, void *stream);
+
+/* -- TRAINING: the weight / bias gradient of an nn.Linear -- what autograd's AddmmBackward computes as `grad_output.t().mm(input)`
+ *    and `grad_output.sum(0)` for every Linear of the encoder / decoder layers (pdvc/deformable_transformer.py:189-199,257-280),
+ *    of MSDeformAttn (pdvc/ops/modules/ms_deform_attn.py:95,99-100,125) and of the captioner's vocabulary layer
+ *    (pdvc/CaptioningHead/LSTM_DSA.py:121) -- on the fp16 matrix cores at fp32 accuracy, one pass over dy for both:
+ *        grad_w[n][k] (+)= sum_r dy[r][n] x[r][k]      grad_b[n] (+)= sum_r dy[r][n]
+ *    dy (R, N) row stride ld_dy, x (R, K) row stride ld_x, fp32, N, K and both strides multiples of 4, 16-byte aligned.
+ *    amax_dy / amax_x: n_amax_* >= 1 fp32 upper bounds of |dy| / |x| whose maximum bounds the whole tensor (the row maxima the
+ *    producers of the path leave behind, or one number); the split scale is ONE power of two per tensor (the contraction runs
+ *    over the rows).  accumulate != 0 adds to the existing grad_w / grad_b (AccumulateGrad folded in).  grad_b may be NULL.
+ *    workspace: gvl_wgrad_workspace_bytes(R, N, K) bytes (split-K partial tiles, summed in a fixed order: deterministic).
+ *    |error| <= 2^-22 sum_r |dy||x| + R 2^-36 max|dy| max|x|. */
+size_t gvl_wgrad_workspace_bytes(int R, int N, int K);
+int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *amax_dy, int n_amax_dy, const float *x, int64_t ld_x,
+                        const float *amax_x, int n_amax_x, int R, int N, int K, float *grad_w, float *grad_b, int accumulate,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* -- TRAINING: operand planes of all weights of the step in two launches.  The forward product of an nn.Linear needs the planes
+ *    of W (N, K), its input gradient `grad_output.mm(weight)` (AddmmBackward) those of W^T; the weights change with every
+ *    optimizer step (train.py:405-409), so both are rebuilt once per training forward -- for ALL matrices at once.
+ *    Each descriptor (DEVICE array) names one fp32 matrix w (N, K), N % 32 == 0, K % 32 == 0, contiguous, and where its planes go:
+ *      hi / lo / scale      planes of the concatenated operand [.. ; W ; ..] of n_total rows: this matrix fills rows n_off ..
+ *                           n_off + N (n_off % 32 == 0), K-stage-major as gvl_split_rows_f16 writes them; scale[n] per row
+ *      t_hi / t_lo / t_scale  planes of the TRANSPOSED operand (K rows, contraction over the n_total rows); NULL = not wanted
+ *      group_chunk_begin / group_chunks   the chunk maxima (see below) of ALL matrices of this matrix's group: one scale per group
+ *    chunk_map (n_chunks x {descriptor, chunk}) / wg_map (n_workgroups x {descriptor, first 32 x 32 tile}): the launch geometry,
+ *    built once by the caller: a matrix has ceil(N K / gvl_planes_chunk_elems()) chunks and ceil(N K / 4096) workgroups of four
+ *    tiles.  chunk_amax: n_chunks floats of scratch. */
+typedef struct gvl_plane_desc {
+  const float *w;
+  int N, K;
+  void *hi, *lo;
+  float *scale;
+  int n_total, n_off;
+  void *t_hi, *t_lo;
+  float *t_scale;
+  int group_chunk_begin, group_chunks;
+  const float *bias;   /* (N) or NULL: copied to bias_dst[n_off ..] (the concatenated bias of the operand) */
+  float *bias_dst;
+} gvl_plane_desc;
+int gvl_planes_chunk_elems(void);
+int gvl_planes_refresh_f16(const gvl_plane_desc *descs_device, const int *chunk_map_device, int n_chunks, const int *wg_map_device,
+                           int n_workgroups, float *chunk_amax_device, void *stream);
 
 #ifdef __cplusplus
 }

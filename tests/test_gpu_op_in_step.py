@@ -37,7 +37,7 @@ def test_op_reproduces_the_reference_gradients_at_its_own_boundary(fused):
     value = v_in.masked_fill(mask[:, None], 0.0).view(1, S, M, 64)           # ms_deform_attn.py:96-97
     if fused:
         proj = torch.cat([off, logit], -1)[None]
-        out = MSDeformAttnFusedFunction.apply(value, proj, ref, shapes, lsi, L, P, "zeros")
+        out = MSDeformAttnFusedFunction.apply(value, proj, ref, shapes, lsi, L, P, "zeros")[0]
     else:
         w = torch.softmax(logit.view(1, Q, M, L * P), -1).view(1, Q, M, L, P)                    # :100-101
         x = ref[:, :, None, :, None, 0] + off.view(1, Q, M, L, P) / P * ref[:, :, None, :, None, 1] * 0.5   # :107-109

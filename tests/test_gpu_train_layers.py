@@ -158,3 +158,55 @@ def test_relu_dropout_falls_back_for_other_activations():
     assert type(y.grad_fn).__name__ != "ReluDropoutBackward" and torch.equal(y, torch.nn.functional.gelu(x * 2.0))
     with torch.no_grad():
         assert TL.relu_dropout(x, torch.nn.functional.relu, drop).grad_fn is None
+
+
+def test_backward_redraws_the_masks_of_its_own_forward_after_a_later_forward():
+    """the backward regenerated its mask from the LIVE step counter; a second training forward between a forward and
+    its backward (two micro-batches summed before .backward(), a checkpoint recompute) then masked dsub with another keep set"""
+    from gvl_amd import train_layers as TL
+    B, Q, C, p = 4, 300, 512, 0.3
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    drop = torch.nn.Dropout(p).train()
+    x = _rand(B, Q, C, seed=3).requires_grad_(True)
+    sub = (_rand(B, Q, C, seed=4).abs() + 0.5).requires_grad_(True)
+    TL.advance(DEV)
+    y1 = TL.residual_dropout_norm(x, sub, drop, norm)
+    keep1 = (y1.grad_fn.saved_tensors[0] - x.detach()).abs() > 1e-6
+    TL.advance(DEV)                                                          # the next forward begins ...
+    y2 = TL.residual_dropout_norm(x.detach(), sub.detach(), drop, norm)      # ... and draws other masks
+    keep2 = (y2 - torch.nn.functional.layer_norm(x.detach() + 0, (C,), norm.weight, norm.bias, norm.eps)).abs() > 0
+    assert keep2.any()
+    y1.backward(_rand(B, Q, C, seed=5))
+    passed = sub.grad != 0
+    assert torch.equal(passed | ~keep1, torch.ones_like(keep1)) or float((passed ^ keep1).float().mean()) < 1e-4
+    assert float((passed & ~keep1).float().sum()) == 0                       # nothing flows through an element forward dropped
+
+
+def test_row_maxima_ride_on_the_results_forward_and_backward():
+    """the kernels leave max |row| of their results for the next Linear product's split (gvl_amd.layers.tag_amax): exact for
+    y, y + pos, relu-dropout's output; an upper bound within 1 / (1 - p) for dz / dsub -- and the tags survive autograd's hand-over"""
+    from gvl_amd import layers as L
+    from gvl_amd import train_layers as TL
+    B, Q, C, p = 16, 188, 512, 0.1
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    drop = torch.nn.Dropout(p).train()
+    x, sub = _rand(B, Q, C, seed=3).requires_grad_(True), _rand(B, Q, C, seed=4).requires_grad_(True)
+    pos = _rand(Q, C, seed=6).unsqueeze(0).expand(B, -1, -1)
+    TL.advance(DEV)
+    y = TL.residual_dropout_norm(x, sub, drop, norm, pos)
+    assert torch.equal(L.amax_of(y, B * Q), y.detach().abs().amax(-1).reshape(-1))
+    q = TL.add_pos(y, pos)
+    assert torch.allclose(L.amax_of(q, B * Q), q.detach().abs().amax(-1).reshape(-1), rtol=1e-6, atol=0)
+    h = TL.relu_dropout(y, torch.relu, drop)
+    assert torch.equal(L.amax_of(h, B * Q), h.detach().abs().amax(-1).reshape(-1))
+    seen = {}
+    sub.register_hook(lambda g: seen.__setitem__("dsub", (g, L.amax_of(g, B * Q))))
+    y.register_hook(lambda g: seen.__setitem__("dy", (g, L.amax_of(g, B * Q))))
+    h.backward(_rand(B, Q, C, seed=7))
+    for k in ("dsub", "dy"):
+        g, am = seen[k]
+        assert am is not None, k + ": the tag did not survive"
+        true = g.abs().amax(-1).reshape(-1)
+        assert bool((am >= true * (1 - 1e-6)).all()) and bool((am <= true / (1 - p) * (1 + 1e-6) + 1e-30).all() or k == "dy")
+    y.add_(1.0)                                                              # an in-place edit invalidates the tag
+    assert L.amax_of(y, B * Q) is None
