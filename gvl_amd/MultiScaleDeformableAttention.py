@@ -440,14 +440,16 @@ def ce_rows_forward(logits, target, weight):
     return out, lse
 
 
-def ce_rows_backward_(logits, target, weight, grad_out, lse):
-    """overwrites `logits` with d sum(grad_out * out) / d logits (include/gvl_msda.h: gvl_ce_rows_backward_f32)"""
+def ce_rows_backward_(logits, target, weight, grad_out, lse, amax=None):
+    """overwrites `logits` with d sum(grad_out * out) / d logits (include/gvl_msda.h: gvl_ce_rows_backward_f32); amax (R) fp32
+    receives an upper bound of every gradient row"""
     R, V = logits.shape
     _require(grad_out.dtype == torch.float32 and grad_out.is_contiguous() and grad_out.numel() == R,
              "ce_rows: grad_out fp32 (R)")
     with torch.cuda.device(logits.device):
         rc = _lib.lib().gvl_ce_rows_backward_f32(logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(),
                                                  weight.data_ptr(), grad_out.data_ptr(), lse.data_ptr(),
+                                                 amax.data_ptr() if amax is not None else None,
                                                  torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "ce_rows_backward")
     return logits
@@ -471,7 +473,8 @@ def col_sum(x):
 def wgrad_eligible(dy, x):
     return (dy.is_cuda and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.dim() == 2 and x.dim() == 2
             and dy.shape[0] == x.shape[0] and dy.shape[0] > 0 and dy.stride(1) == 1 and x.stride(1) == 1
-            and dy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0
+            and x.shape[1] % 4 == 0 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0
+            and dy.stride(0) >= (dy.shape[1] + 3) // 4 * 4
             and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 

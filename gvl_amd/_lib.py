@@ -59,7 +59,7 @@ SIGNATURES = {
     "gvl_lstm_cell_train_backward_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P]),
     "gvl_col_sum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "gvl_ce_rows_forward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P]),
-    "gvl_ce_rows_backward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P]),
+    "gvl_ce_rows_backward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P]),
     "gvl_proj_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "gvl_split_rows_f16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "gvl_gemm_f16x3_lstm_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -98,6 +98,8 @@ SIGNATURES = {
     "gvl_wgrad_f16x3_f32": (_I, [_P, _I64, _P, _I, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _I, _P, _SZ, _P]),
     "gvl_planes_chunk_elems": (_I, []),
     "gvl_planes_refresh_f16": (_I, [_P, _P, _I, _P, _I, _P, _P]),
+    "gvl_mha_train_forward_f32": (_I, [_P, _I64, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P]),
+    "gvl_mha_train_backward_f32": (_I, [_P, _I64, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_batch_device_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),

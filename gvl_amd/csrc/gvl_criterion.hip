@@ -634,10 +634,14 @@ __global__ void __launch_bounds__(kCeThreads) k_ce_rows_fwd(const float *__restr
 __global__ void __launch_bounds__(kCeThreads) k_ce_rows_bwd(float *__restrict__ logits, int64_t ld, int V,
                                                             const int64_t *__restrict__ target,
                                                             const float *__restrict__ w, const float *__restrict__ g,
-                                                            const float *__restrict__ lse) {
+                                                            const float *__restrict__ lse, float *__restrict__ amax) {
   const int row = blockIdx.x;
   const float coef = g[row] * w[row];
   float *x = logits + (int64_t)row * ld;
+  // |gradient row| <= |coef| (one-hot minus a probability): the row bound the split-fp16 products behind this kernel scale by;
+  // the padding columns [V, ld) become zeros (those products read whole 16-byte pieces / K stages of a row)
+  if (threadIdx.x == 0 && amax) amax[row] = fabsf(coef);
+  if ((int)threadIdx.x < (int)ld - V) x[V + threadIdx.x] = 0.f;
   if (coef == 0.f) {
     for (int v = threadIdx.x; v < V; v += kCeThreads) x[v] = 0.f;
     return;
@@ -676,10 +680,10 @@ extern "C" int gvl_ce_rows_forward_f32(const float *logits, int64_t ld, int R, i
 }
 
 extern "C" int gvl_ce_rows_backward_f32(float *logits, int64_t ld, int R, int V, const int64_t *target,
-                                        const float *weight, const float *grad_out, const float *lse, void *stream) {
-  if (R < 0 || V <= 0 || ld < V) return fail(GVL_EINVAL, "gvl_ce_rows_backward_f32: bad sizes R=%d V=%d", R, V);
+                                        const float *weight, const float *grad_out, const float *lse, float *amax, void *stream) {
+  if (R < 0 || V <= 0 || ld < V || ld - V > kCeThreads) return fail(GVL_EINVAL, "gvl_ce_rows_backward_f32: bad sizes R=%d V=%d", R, V);
   if (R == 0) return 0;
   if (!logits || !target || !weight || !grad_out || !lse) return fail(GVL_EINVAL, "gvl_ce_rows_backward_f32: null pointer");
   return gvl::launch(GVL_PROF_CRITERION, R, V, "k_ce_rows_bwd", k_ce_rows_bwd, dim3(R), dim3(kCeThreads), 0,
-                     (hipStream_t)stream, logits, ld, V, target, weight, grad_out, lse);
+                     (hipStream_t)stream, logits, ld, V, target, weight, grad_out, lse, amax);
 }

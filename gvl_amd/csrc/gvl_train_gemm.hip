@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
   const uint32_t a_col = n0 + 4 * c4 < p.N ? (uint32_t)(n0 + 4 * c4) * 4u : kOob;
   const uint32_t b_col = k0 + 4 * c4 < p.K ? (uint32_t)(k0 + 4 * c4) * 4u : kOob;
   const uint32_t a_ld = (uint32_t)p.ld_dy * 4u, b_ld = (uint32_t)p.ld_x * 4u;
+  const int a_tail = p.N - (n0 + 4 * c4);            // valid columns of this thread's 16-byte piece of dy (>= 4: all)
   const uint32_t st_off = (uint32_t)(lr * kWgRowB + c4 * 8);
   struct Set { float4 a[2], b[2]; };
   auto load = [&](Set &s, int stage) {
@@ -160,6 +161,11 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
       s.a[i] = make_float4((float)r, 1.f, 2.f, 3.f); s.b[i] = make_float4(1.f, (float)r, 2.f, 3.f);
 #else
       s.a[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, min(r * a_ld + a_col, kOob), 0, 0));
+      if (a_tail < 4) {                              // the piece that straddles column N (N % 4 != 0: the vocabulary layer)
+        if (a_tail < 2) s.a[i].y = 0.f;
+        if (a_tail < 3) s.a[i].z = 0.f;
+        s.a[i].w = 0.f;
+      }
       s.b[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, min(r * b_ld + b_col, kOob), 0, 0));
 #endif
     }
@@ -310,12 +316,12 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
         const float4 u = red[i * 32 + tid];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      float4 *o = reinterpret_cast<float4 *>(p.part_b + (int64_t)sk * p.N + n0 + 4 * tid);
-      if (p.SK == 1 && p.accumulate) {
-        const float4 e = *o;
-        t.x += e.x; t.y += e.y; t.z += e.z; t.w += e.w;
-      }
-      *o = t;
+      float *o = p.part_b + (int64_t)sk * ((p.N + 3) & ~3) + n0 + 4 * tid;      // (partial bias rows: stride N rounded up to 4)
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+      const bool add = p.SK == 1 && p.accumulate;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (n0 + 4 * tid + c < p.N) o[c] = add ? o[c] + tv[c] : tv[c];
     }
   }
   GVL_WG_STAMP(3)
@@ -323,7 +329,7 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
 
 // grad (+)= sum over the SK partial slabs, in slab order; the same for the bias row
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float4 *__restrict__ part, int64_t n4, int SK, float4 *__restrict__ grad,
-                                                      const float4 *__restrict__ part_b, int nb4, float4 *__restrict__ grad_b,
+                                                      const float *__restrict__ part_b, int N, float *__restrict__ grad_b,
                                                       int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n4) {
@@ -333,16 +339,15 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float4 *__restrict__
       t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
     }
     grad[i] = t;
-  } else if (grad_b && i - n4 < nb4) {
+  } else if (grad_b && i - n4 < N) {
     const int64_t b = i - n4;
-    float4 t = accumulate ? grad_b[b] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < SK; ++s) {
-      const float4 u = part_b[(int64_t)s * nb4 + b];
-      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-    }
+    const int stride = (N + 3) & ~3;
+    float t = accumulate ? grad_b[b] : 0.f;
+    for (int s = 0; s < SK; ++s) t += part_b[(int64_t)s * stride + b];
     grad_b[b] = t;
   }
 }
+
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -492,20 +497,22 @@ extern "C" int gvl_planes_refresh_f16(const gvl_plane_desc *descs_device, const 
 extern "C" size_t gvl_wgrad_workspace_bytes(int R, int N, int K) {
   if (R <= 0 || N <= 0 || K <= 0) return 0;
   const WgPlan pl = wgrad_plan(R, N, K);
-  return pl.SK == 1 ? 0 : (size_t)pl.SK * ((size_t)N * K + N) * sizeof(float);
+  return pl.SK == 1 ? 0 : (size_t)pl.SK * ((size_t)N * K + ((N + 3) & ~3)) * sizeof(float);
 }
 
 extern "C" int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *amax_dy, int n_amax_dy, const float *x, int64_t ld_x,
                                    const float *amax_x, int n_amax_x, int R, int N, int K, float *grad_w, float *grad_b,
                                    int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
   if (!dy || !x || !amax_dy || !amax_x || !grad_w) return fail(GVL_EINVAL, "gvl_wgrad_f16x3_f32: null pointer");
-  if (R <= 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || (ld_dy & 3) || (ld_x & 3) || ld_dy < N || ld_x < K || n_amax_dy < 1 ||
+  if (R <= 0 || N <= 0 || K <= 0 || (K & 3) || (ld_dy & 3) || (ld_x & 3) || ld_dy < ((N + 3) & ~3) || ld_x < K || n_amax_dy < 1 ||
       n_amax_x < 1)
-    return fail(GVL_EINVAL, "gvl_wgrad_f16x3_f32: R, N, K > 0, N, K and both row strides multiples of 4 (got R=%d N=%d K=%d)", R, N, K);
+    return fail(GVL_EINVAL, "gvl_wgrad_f16x3_f32: R, N, K > 0, K and both row strides multiples of 4, ld_dy >= N rounded up to 4 (got R=%d N=%d K=%d)", R, N, K);
+  if ((int64_t)R * ld_dy >= ((int64_t)1 << 29) || (int64_t)R * ld_x >= ((int64_t)1 << 29))
+    return fail(GVL_EINVAL, "gvl_wgrad_f16x3_f32: operands of 2 GB or more are not addressed (32-bit buffer offsets)");
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)grad_w | (uintptr_t)grad_b | (uintptr_t)workspace) & 15)
     return fail(GVL_EINVAL, "gvl_wgrad_f16x3_f32: pointers must be 16-byte aligned");
   const WgPlan pl = wgrad_plan(R, N, K);
-  const size_t need = pl.SK == 1 ? 0 : (size_t)pl.SK * ((size_t)N * K + N) * sizeof(float);
+  const size_t need = pl.SK == 1 ? 0 : (size_t)pl.SK * ((size_t)N * K + ((N + 3) & ~3)) * sizeof(float);
   if (need > workspace_bytes || (need && !workspace)) return fail(GVL_ENOSPC, "gvl_wgrad_f16x3_f32: workspace of %zu bytes needed", need);
   hipStream_t st = (hipStream_t)stream;
   WgParams p;
@@ -529,11 +536,10 @@ extern "C" int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *
     return rc;
   if (pl.SK > 1) {
     const int64_t n4 = (int64_t)N * K / 4;
-    const int nb4 = grad_b ? N / 4 : 0;
-    const int64_t total = n4 + nb4;
+    const int64_t total = n4 + (grad_b ? N : 0);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        reinterpret_cast<const float4 *>(p.part), n4, pl.SK, reinterpret_cast<float4 *>(grad_w),
-                       reinterpret_cast<const float4 *>(p.part_b), nb4, reinterpret_cast<float4 *>(grad_b), accumulate);
+                       p.part_b, N, grad_b, accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, "gvl_wgrad_f16x3_f32: reduce launch failed: %s", hipGetErrorString(e));
   }

@@ -21,6 +21,7 @@ from torch import nn
 
 from . import layers as _layers
 from . import train_layers as _tl
+from . import train_mha as _mha
 from .ops.modules import MSDeformAttn
 from .linear import Linear
 
@@ -160,13 +161,18 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, src_temporal_shapes, level_start_index,
                 src_padding_mask=None, query_mask=None):
-        qk = _tl.add_pos(tgt, query_pos).transpose(0, 1)
-        # The reference discards the averaged attention map ([0] at pdvc/deformable_transformer.py:267-268).  Not asking for
-        # it lets nn.MultiheadAttention take its fused attention path: measured 0.4 % of the eval step; in training the
-        # fused forward + backward kernels are slower than bmm / softmax / bmm at this size (300 queries): +0.9 % of the step
-        # (average_attn_weights=False: the unfused path without the mean over the heads of a (B, 8, Q, Q) map nobody reads)
-        sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask, need_weights=self.training,
-                            average_attn_weights=False)[0].transpose(0, 1)
+        if _mha.eligible(self.self_attn, tgt, query_pos):
+            # training: in-projection (one launch, the positional addend applied in its load path), attention core and
+            # out-projection on the hand-written kernels (gvl_amd/train_mha.py); same parameters, same result
+            sa = _mha.self_attention(self.self_attn, tgt, query_pos, query_mask)
+        else:
+            qk = _tl.add_pos(tgt, query_pos).transpose(0, 1)
+            # The reference discards the averaged attention map ([0] at pdvc/deformable_transformer.py:267-268).  Not asking for
+            # it lets nn.MultiheadAttention take its fused attention path: measured 0.4 % of the eval step; in training the
+            # fused forward + backward kernels are slower than bmm / softmax / bmm at this size (300 queries): +0.9 % of the step
+            # (average_attn_weights=False: the unfused path without the mean over the heads of a (B, 8, Q, Q) map nobody reads)
+            sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask, need_weights=self.training,
+                                average_attn_weights=False)[0].transpose(0, 1)
         tgt = _tl.residual_dropout_norm(tgt, sa, self.dropout2, self.norm2, query_pos)   # (sa: a transposed view, read in place)
         ca = self.cross_attn(_tl.add_pos(tgt, query_pos), reference_points, src, src_temporal_shapes,
                              level_start_index, src_padding_mask)

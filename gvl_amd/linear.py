@@ -103,10 +103,15 @@ class _VocabNLLFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, target, row_weight):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        R, V = x2.shape[0], weight.shape[0]
+        # rows of the logits padded to a multiple of 4 columns (+ one spare row): the hand-written gradient products read whole
+        # 16-byte pieces of a row
+        ld = (V + 3) // 4 * 4
+        logits = torch.empty(R + 1, ld, device=x.device, dtype=torch.float32)[:R, :V]
         if split_gemm_enabled() and x2.shape[1] % 32 == 0 and weight.is_contiguous():
-            logits = MSDA.gemm_f16x3(MSDA.split_rows(x2), MSDA.split_rows(weight.detach()), bias.detach())
+            MSDA.gemm_f16x3(MSDA.split_rows(x2), MSDA.split_rows(weight.detach()), bias.detach(), out=logits)
         else:
-            logits = torch.addmm(bias.detach(), x2, weight.detach().t())
+            torch.addmm(bias.detach(), x2, weight.detach().t(), out=logits)
         out, lse = MSDA.ce_rows_forward(logits, target, row_weight)
         ctx.save_for_backward(x2, weight, logits, lse, target, row_weight)
         ctx.x_shape = x.shape
@@ -120,8 +125,16 @@ class _VocabNLLFunction(torch.autograd.Function):
             raise RuntimeError("vocab_nll: backward runs once (the logits are overwritten by their gradient); "
                                "GVL_VOCAB_NLL=torch keeps the log-prob formulation for retain_graph use")
         ctx.consumed = True
-        g = MSDA.ce_rows_backward_(logits, target, row_weight, grad_out.contiguous(), lse)     # (R, V), in place
+        own = _TRAIN_LINEAR and MSDA.wgrad_eligible(logits, x2) and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        am_g = torch.empty(logits.shape[0], device=logits.device, dtype=torch.float32) if own else None
+        g = MSDA.ce_rows_backward_(logits, target, row_weight, grad_out.contiguous(), lse, amax=am_g)     # (R, V), in place
         gx = g.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        if own:
+            # dW = g^T x and db = sum_r g in ONE pass over g on the fp16 matrix cores (gvl_wgrad_f16x3_f32): 135 us against the
+            # library's 241 us + the column sum's 17 us at (2208, 8518, 512)
+            from . import layers as L
+            gw, gb = MSDA.wgrad(g, x2, am_g, L.row_absmax(x2)[0])
+            return gx, gw, gb, None, None
         gw = g.t().mm(x2) if ctx.needs_input_grad[1] else None
         gb = MSDA.col_sum(g) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None

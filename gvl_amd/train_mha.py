@@ -1,0 +1,156 @@
+"""The decoder layer's self-attention in TRAINING (pdvc/deformable_transformer.py:263-270:
+``self.self_attn(q, k, tgt, key_padding_mask=~query_mask)`` with q = k = tgt + query_pos, an nn.MultiheadAttention with dropout on
+the attention weights) on the hand-written kernels:
+
+    in-projection   ONE gvl_linear_f16x3_f32 launch over in_proj_weight: columns [0, 2C) multiply tgt + query_pos (the addend is
+                    applied in the kernel's load path), columns [2C, 3C) multiply tgt; the epilogue leaves the row maxima of the
+                    q | k and of the v columns
+    attention core  gvl_mha_train_forward_f32 / _backward_f32 (scores, softmax, dropout stay in registers)
+    out-projection  gvl_amd.linear.train_linear
+
+PyTorch runs this as 3 projection GEMMs + 6 elementwise launches + bmm / softmax / dropout / bmm (~250 us forward, ~420 us
+backward per layer at B = 16, Q = 300: profiles/r05_train_timeline_before.txt).  The module keeps its parameters and state-dict
+keys (``in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias``); this file only replaces what its forward launches.
+``GVL_TRAIN_MHA=torch`` keeps nn.MultiheadAttention's own forward (A/B switch)."""
+import os
+
+import torch
+
+from . import _lib
+from . import layers as L
+from . import linear as GL
+from . import train_layers as TL
+from . import MultiScaleDeformableAttention as MSDA
+from .train_planes import Operand
+
+_ENABLED = os.environ.get("GVL_TRAIN_MHA", "") != "torch"
+
+
+def enabled(on=None):
+    global _ENABLED
+    if on is not None:
+        _ENABLED = bool(on)
+    return _ENABLED
+
+
+class _Sub:
+    """a K-stage range of operand planes (planes are K-stage-major, so a range of the contraction is a contiguous piece)"""
+    __slots__ = ("hi", "lo", "scale")
+
+    def __init__(self, planes, stage0, stage1):
+        self.hi, self.lo, self.scale = planes.hi[stage0:stage1], planes.lo[stage0:stage1], planes.scale
+
+
+class _InProj(torch.autograd.Function):
+    """qkv = [ (x + pos) W_qk^T | x W_v^T ] + b   ->  (qkv (R, 3C), row maxima of the q | k columns, of the v columns)"""
+
+    @staticmethod
+    def forward(ctx, x, pos, xq, weight, bias):
+        # x (B, Q, C) contiguous; pos (Q, C) (row stride arbitrary); xq = x + pos as a tensor (the weight gradient's operand)
+        B, Q, C = x.shape
+        R = B * Q
+        x2 = x.reshape(R, C)
+        op, op_t = GL._operands((weight,), (bias,))
+        am_v = GL._row_amax(x2, x)
+        am_qk = GL._row_amax(xq.reshape(R, C), xq)
+        qkv = torch.empty(R, 3 * C, device=x.device, dtype=torch.float32)
+        am_out = torch.zeros(2, R, device=x.device, dtype=torch.float32)
+        L.linear(x2, op, [L.seg(0, qkv[:, :2 * C], am_qk, amax_out=am_out[0], addend=True),
+                          L.seg(2 * C, qkv[:, 2 * C:], am_v, amax_out=am_out[1])], a2=pos)
+        ctx.save_for_backward(x2, xq.reshape(R, C), am_v, am_qk, weight)
+        ctx.op_t, ctx.shape = op_t, (B, Q, C)
+        ctx.mark_non_differentiable(am_out)
+        return qkv, am_out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dqkv, _dam):
+        x2, xq2, am_v, am_qk, weight = ctx.saved_tensors
+        B, Q, C = ctx.shape
+        R = B * Q
+        op_t = ctx.op_t
+        dqkv = dqkv.contiguous()
+        g_qk, g_v = dqkv[:, :2 * C], dqkv[:, 2 * C:]
+        am_gqk, am_gv = L.row_absmax(g_qk)[0], L.row_absmax(g_v)[0]
+        # dx of the two operand groups: the transposed planes cut at contraction stage 2C / 32
+        cut = 2 * C // 32
+        dxq = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
+        dxv = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
+        L.linear(g_qk, Operand(_Sub(op_t.planes, 0, cut), C, 2 * C, None), [L.seg(0, dxq, am_gqk)])
+        L.linear(g_v, Operand(_Sub(op_t.planes, cut, 3 * C // 32), C, C, None), [L.seg(0, dxv, am_gv)])
+        gw = torch.empty(3 * C, C, device=dqkv.device, dtype=torch.float32)
+        gb = torch.empty(3 * C, device=dqkv.device, dtype=torch.float32)
+        MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gw[:2 * C], grad_b=gb[:2 * C])
+        MSDA.wgrad(g_v, x2, am_gv, am_v, grad_w=gw[2 * C:], grad_b=gb[2 * C:])
+        return dxv.view(B, Q, C), None, dxq.view(B, Q, C), gw, gb
+
+
+class _Core(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, am, keep, B, Q, H, p, seed, step):
+        R = B * Q
+        out = torch.empty(R, H * 64, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(B, H, Q, device=qkv.device, dtype=torch.float32)
+        used = step.clone() if step is not None else None        # the step whose masks this forward drew (as train_layers.py)
+        with torch.cuda.device(qkv.device):
+            rc = _lib.lib().gvl_mha_train_forward_f32(
+                qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if keep is not None else None, am[0].data_ptr(), am[1].data_ptr(),
+                B, Q, H, float(p), int(seed), used.data_ptr() if used is not None else None, out.data_ptr(), lse.data_ptr(),
+                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mha_train_forward")
+        ctx.save_for_backward(qkv, am, keep if keep is not None else qkv.new_empty(0), out, lse,
+                              used if used is not None else qkv.new_empty(0))
+        ctx.cfg = (B, Q, H, float(p), int(seed), keep is not None, used is not None)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        qkv, am, keep, out, lse, used = ctx.saved_tensors
+        B, Q, H, p, seed, has_keep, has_step = ctx.cfg
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, H, Q, device=qkv.device, dtype=torch.float32)
+        am_g = torch.empty(B * Q, device=qkv.device, dtype=torch.float32)
+        with torch.cuda.device(qkv.device):
+            rc = _lib.lib().gvl_mha_train_backward_f32(
+                qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if has_keep else None, am[0].data_ptr(), am[1].data_ptr(), B, Q, H,
+                p, seed, used.data_ptr() if has_step else None, out.data_ptr(), lse.data_ptr(), dout.data_ptr(), delta.data_ptr(),
+                am_g.data_ptr(), dqkv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mha_train_backward")
+        return dqkv, None, None, None, None, None, None, None, None
+
+
+def eligible(mha, tgt, query_pos):
+    C = tgt.shape[-1]
+    return (_ENABLED and GL.train_linear_enabled() and isinstance(mha, torch.nn.MultiheadAttention) and mha._qkv_same_embed_dim
+            and mha.in_proj_bias is not None and mha.bias_k is None and not mha.add_zero_attn and not mha.batch_first
+            and tgt.is_cuda and tgt.dtype == torch.float32 and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and tgt.dim() == 3 and C == mha.embed_dim and C // mha.num_heads == 64 and C % 64 == 0
+            and tgt.shape[0] * tgt.shape[1] >= GL.MIN_TRAIN_ROWS and tgt.shape[1] <= 4096
+            and tgt.shape[0] * mha.num_heads * tgt.shape[1] * tgt.shape[1] < 2 ** 32
+            and query_pos is not None and query_pos.dim() == 3 and query_pos.shape == tgt.shape and query_pos.stride(0) == 0
+            and query_pos.stride(2) == 1 and query_pos.stride(1) % 4 == 0 and query_pos.data_ptr() % 16 == 0
+            and query_pos.dtype == torch.float32)
+
+
+def self_attention(mha, tgt, query_pos, query_mask):
+    """nn.MultiheadAttention(q = k = tgt + query_pos, v = tgt, key_padding_mask = ~query_mask)[0] for batch-major tgt (B, Q, C)
+    -> (B, Q, C); callers check `eligible` first.  query_pos: the batch-expanded (stride 0) query embedding."""
+    B, Q, C = tgt.shape
+    x = tgt.contiguous()
+    xq = TL.add_pos(x if x is tgt else tgt, query_pos)                  # (carries the row maxima of the sum when norm3 left them)
+    L_ = L
+    if L_.amax_of(x, B * Q) is None and L_.amax_of(tgt, B * Q) is not None:
+        L_.tag_amax(x, L_.amax_of(tgt, B * Q))
+    qkv, am = _InProj.apply(x, query_pos[0], xq, mha.in_proj_weight, mha.in_proj_bias)
+    keep = query_mask.to(torch.uint8).contiguous() if query_mask is not None else None
+    p = mha.dropout if mha.training else 0.0
+    site = mha.__dict__.get("_gvl_site_drop")
+    if site is None:
+        site = mha.__dict__["_gvl_site_drop"] = torch.nn.Dropout(mha.dropout)
+    o = _Core.apply(qkv, am, keep, B, Q, mha.num_heads, p, TL._site_seed(site), TL.step_counter(tgt.device) if p > 0 else None)
+    ob = mha.out_proj.bias
+    if GL.train_linear_eligible(o, (mha.out_proj.weight,), (ob,)):
+        return GL.train_linear(o, (mha.out_proj.weight,), (ob,)).view(B, Q, C)
+    return torch.nn.functional.linear(o, mha.out_proj.weight, ob).view(B, Q, C)

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 11  /* 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step); 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 11  /* 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -364,7 +364,9 @@ int gvl_col_sum_f32(const float *x, int ld, int R, int C, float *out, void *stre
 int gvl_ce_rows_forward_f32(const float *logits, int64_t ld, int R, int V, const int64_t *target, const float *weight,
                             float *out, float *lse, void *stream);
 int gvl_ce_rows_backward_f32(float *logits, int64_t ld, int R, int V, const int64_t *target, const float *weight,
-                             const float *grad_out, const float *lse, void *stream);
+                             const float *grad_out, const float *lse, float *amax, void *stream);
+/*    (ABI 11: amax (R) or NULL receives |grad_out[r] weight[r]|, an upper bound of row r of the gradient -- the row scale of the
+ *     split-fp16 products that consume it; the padding columns [V, ld) of every row are set to zero, ld - V <= 256) */
 
 /* -- kernel timing inside the library (measurement only; no reference equivalent).  While enabled, every kernel the
  *    library launches is dispatched with hipExtLaunchKernel start/stop events on the launch stream, i.e. the
@@ -680,6 +682,22 @@ typedef struct gvl_plane_desc {
 int gvl_planes_chunk_elems(void);
 int gvl_planes_refresh_f16(const gvl_plane_desc *descs_device, const int *chunk_map_device, int n_chunks, const int *wg_map_device,
                            int n_workgroups, float *chunk_amax_device, void *stream);
+
+/* -- TRAINING: the attention core of the decoder layer's nn.MultiheadAttention (pdvc/deformable_transformer.py:266-270: self_attn
+ *    over the queries with key_padding_mask and dropout on the attention weights), forward and backward, head dimension 64:
+ *        out[b][q][h 64 ..] = sum_k dropout(softmax_k(q_h . k_h / 8, keys with key_keep[b][k] == 0 excluded))[k] v_h[k]
+ *    qkv (B Q, ld) rows [q | k | v] (each H 64 wide: the in-projection's output, batch-major rows), out / dout (B Q, H 64),
+ *    lse (B, H, Q) = log sum_k exp(score) (kept for the backward), dqkv laid out like qkv.  amax_qk / amax_v (B Q): upper bounds of
+ *    |row| of the q and k columns / of the v columns (the in-projection's epilogue leaves them).  Dropout: weight (b, h, q, k) is
+ *    kept iff hash32(((b H + h) Q + q) Q + k ^ hash32(seed + *step 0x9E3779B9)) >= p 2^32 (the rule of gvl_residual_dropout_*;
+ *    the backward is given the step value the forward used); p == 0: plain softmax attention.  A query whose keys are all
+ *    excluded yields NaN, as torch.softmax of a fully masked row.  delta_ws (B H Q) and amax_dout_ws (B Q): scratch.
+ *    Products: three fp16 MFMAs per fp32 product in one fp32 accumulator (22-bit operands); scores never leave registers. */
+int gvl_mha_train_forward_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk, const float *amax_v,
+                              int B, int Q, int H, float p, uint32_t seed, const int64_t *step, float *out, float *lse, void *stream);
+int gvl_mha_train_backward_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk, const float *amax_v,
+                               int B, int Q, int H, float p, uint32_t seed, const int64_t *step, const float *out, const float *lse,
+                               const float *dout, float *delta_ws, float *amax_dout_ws, float *dqkv, void *stream);
 
 #ifdef __cplusplus
 }
