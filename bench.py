@@ -250,7 +250,9 @@ def cpu_baseline(model, opt, T, budget_s=30.0):
     med_t = statistics.median(tt)
     return {"value": nvid / med, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{nvid} synthetic videos per iteration (3 events each), eval forward incl. {opt.max_caption_len + 1} "
-                      f"greedy caption steps, oracle/torch_ref.py (grid_sample border = reference CPU fallback), "
+                      f"greedy caption steps (the reference's own count: its dead extra LSTM step after the last token is evaluated "
+                      f"here and skipped by the GPU path -- about 3 % of this leg's time), oracle/torch_ref.py (grid_sample border = "
+                      f"reference CPU fallback), "
                       f"2 warm-ups + median of 5: {med:.2f} s (runs {', '.join(f'{x:.2f}' for x in ts)})",
             "without_captioner": {"value": nvid_nc / med_nc, "unit": "videos/s",
                                   "sample": f"{nvid_nc} videos per iteration, eval_disable_captioning, 2 warm-ups + "
@@ -533,7 +535,7 @@ def main():
         del step, graphed_eval
         torch.cuda.empty_cache()
         # A/B of the same step with the token loop's three products on the fp32 library GEMMs (GVL_GEMM=f32) instead of
-        # gvl_gemm_f16x3 (fp32 operands split exactly into fp16 pairs, fp16 MFMA, fp32 accumulation): reported beside
+        # gvl_gemm_f16x3 (fp32 operands split into fp16 (hi, residual) pairs that keep 22 significant bits, fp16 MFMA, fp32 accumulation): reported beside
         # `value`, never as `value`
         from gvl_amd.linear import split_gemm_enabled
         if (split_gemm_enabled() and a.dtype == "f32" and not a.no_graph and not a.no_captioner and not a.no_probes):
@@ -720,8 +722,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload,
                        "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
-                       "token_loop_gemms": ("gvl_gemm_f16x3: fp32 operands split exactly into fp16 (hi, 2^11 residual) "
-                                            "pairs, 3 fp16-MFMA partial products, fp32 accumulation -- error vs fp64 "
+                       "token_loop_gemms": ("gvl_gemm_f16x3: fp32 operands split into fp16 (hi, 2^11 residual) pairs that keep 22 of fp32's 24 significant bits (operand_bits = 22), "
+                                            "3 fp16-MFMA partial products, fp32 accumulation -- error vs fp64 "
                                             "below the fp32 GEMM's (tests/test_gpu_gemm16.py); vocabulary argmax / "
                                             "log-sum-exp fused into the GEMM") if gemm16_on else "hipBLASLt fp32",
                        "inference_layers": ("gvl_amd/layers.py: every Linear of the encoder / decoder layers, the box MLP, the "

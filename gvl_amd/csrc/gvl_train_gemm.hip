@@ -351,6 +351,251 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float4 *__restrict__
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_nt_f16x3        out[r][n] = epilogue(sum_k (A [+ A2])[r][k] W[n][k] + bias[n])   -- the forward product and the input gradient
+//                   (dx = dy W = dy (W^T)^T on the planes of W^T) of every nn.Linear of the training step.
+//   A    fp32 activations.  A wavefront owns 32 rows for the whole kernel and takes them STRAIGHT INTO REGISTERS: lane (row r =
+//        l & 31, half h = l >> 5) loads the 64 contiguous bytes k0 + 16 h .. + 15 of its row per K stage of 32 and splits them
+//        there -- the activation never passes through LDS (in gvl_linear_f16x3_f32 its LDS writes, at 80 B / clk, and fragment
+//        reads were half of a stage).  The contraction order inside a stage is permuted accordingly (k-step s of the MFMA takes
+//        elements 16 h + 8 s ..: any order works as long as both operands agree), which for W means reading chunk 2 h + s
+//        instead of 2 s + h of its 64-byte stage row.
+//   W    fp16 planes in the SAME-SCALE form (hi, lo = residual at hi's scale; gvl_planes_refresh_f16 format 1), staged through
+//        LDS for the workgroup's wavefronts (each multiplies all 128 columns of the tile): hi.hi + hi.lo + lo.hi in ONE accumulator.
+//   Tile = 32 NW rows x 128 columns, NW = 2, 3 or 4 wavefronts (chosen so that the grid covers the chip: 4800 rows -> NW = 2 or 3);
+//   64 accumulator registers per wavefront, two workgroups per CU.
+//   Epilogue: bias, ReLU, residual add, row maxima of the result (atomic max into a zeroed vector).
+//   `addend_cols`: tiles left of that column multiply A + A2[r % a2_rows] (nn.MultiheadAttention's in-projection: q and k take
+//   tgt + query_pos, v takes tgt) and scale by amax_in2 / report to amax_out2.
+struct NtParams {
+  const float *A, *A2;
+  int64_t lda, lda2;
+  int a2_rows, addend_cols;
+  const float *amax_in, *amax_in2;     // (R) row bounds of A / of A + A2
+  const _Float16 *Wh, *Wl;             // planes (K / 32, N, 32)
+  const float *Ws, *bias;              // (N) row scales of W, bias or NULL
+  int R, N, K, tiles_n, tiles_m;
+  float *out;
+  int64_t ldo;
+  const float *resid;
+  int64_t ldr;
+  float *amax_out, *amax_out2;
+  int relu;
+#ifdef GVL_WG_STAMPS
+  unsigned long long *stamps;
+#endif
+};
+
+// 2^11 / s, s = 2^floor(log2 amax): the row's largest element lands in [2^11, 2^12)
+__device__ __forceinline__ void row_scale(float amax, float &mul, float &back) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  e = min(max(e, 13), 240);
+  mul = __uint_as_float((uint32_t)(254 - e + 11) << 23);
+  back = __uint_as_float((uint32_t)(e - 11) << 23);
+}
+
+template <int NW, bool ADD>
+__global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
+  constexpr int kT = 64 * NW, kCh = 512 / kT + (512 % kT ? 1 : 0);      // 16-byte chunks per plane, thread and stage
+  __shared__ uint4 wlds[2][2][512];                                      // [buffer][hi | lo][128 rows x 4 chunks, swizzled]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  // the column tiles of ONE row tile on one XCD (workgroup id % 8; speed only): they read the same rows of A, which that XCD's L2
+  // then fetches once -- dealt round-robin they sit on tiles_n different XCDs and A crosses the fabric tiles_n times
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int tm = xcd + 8 * (slot / p.tiles_n), tn = slot % p.tiles_n;
+  if (tm >= p.tiles_m) return;
+  GVL_WG_STAMP(0)
+  const int m0 = tm * 32 * NW + 32 * wave, n0 = tn * 128;
+  const bool addend = ADD && n0 < p.addend_cols;
+  const int row = min(m0 + (lane & 31), p.R - 1);
+  float mul_a, back_a;
+  row_scale((addend ? p.amax_in2 : p.amax_in)[row], mul_a, back_a);
+
+  // ---- A: 64 bytes per lane and stage (four 16-byte loads), three stages in flight
+  const auto a_rs = rsrc_of(p.A, (uint32_t)min((int64_t)p.R * p.lda * 4, (int64_t)0x7ffffff0));
+  const auto a2_rs = rsrc_of(ADD ? p.A2 : p.A, (uint32_t)min((int64_t)(ADD ? p.a2_rows : 1) * (ADD ? p.lda2 : 1) * 4, (int64_t)0x7ffffff0));
+  const uint32_t a_off = (uint32_t)row * (uint32_t)p.lda * 4u + 64u * half;
+  const uint32_t a2_off = ADD ? (uint32_t)(row % p.a2_rows) * (uint32_t)p.lda2 * 4u + 64u * half : 0u;
+  struct ASet { u4v x[4], y[4]; };
+  auto load_a = [&](ASet &s, int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.x[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_off + 128u * stage + 16u * i, 0, 0);
+    if (ADD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off + 128u * stage + 16u * i, 0, 0);
+    }
+  };
+  // ---- W: chunk c (16 bytes) of tile row w of the stage -> swizzled slot; through registers, one stage ahead
+  const auto wh_rs = rsrc_of(p.Wh, (uint32_t)min((int64_t)p.N * p.K * 2, (int64_t)0x7ffffff0));
+  const auto wl_rs = rsrc_of(p.Wl, (uint32_t)min((int64_t)p.N * p.K * 2, (int64_t)0x7ffffff0));
+  uint32_t w_src[kCh];
+  int w_dst[kCh];
+#pragma unroll
+  for (int i = 0; i < kCh; ++i) {
+    const int id = tid + i * kT, wr = (id >> 2) & 127, ch = id & 3;
+    w_src[i] = ((uint32_t)min(n0 + wr, p.N - 1) * 32u + 8u * ch) * 2u;
+    w_dst[i] = id < 512 ? lds_slot(wr, ch) : -1;
+  }
+  const uint32_t w_stage = (uint32_t)p.N * 64u;                         // bytes between two K stages of a plane
+  struct WSet { u4v h[kCh], l[kCh]; };
+  auto load_w = [&](WSet &s, int stage) {
+#pragma unroll
+    for (int i = 0; i < kCh; ++i) {
+      s.h[i] = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_src[i] + w_stage * stage, 0, 0);
+      s.l[i] = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_src[i] + w_stage * stage, 0, 0);
+    }
+  };
+  auto store_w = [&](const WSet &s, int buf) {
+#pragma unroll
+    for (int i = 0; i < kCh; ++i)
+      if (512 % kT == 0 || w_dst[i] >= 0) {
+        wlds[buf][0][w_dst[i]] = __builtin_bit_cast(uint4, s.h[i]);
+        wlds[buf][1][w_dst[i]] = __builtin_bit_cast(uint4, s.l[i]);
+      }
+  };
+
+  f16acc acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  int fb[4][2];                                                         // B fragment slots: tile column block j, k-step s
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) fb[j][s2] = lds_slot(32 * j + (lane & 31), 2 * half + s2);
+
+  // ---- pipeline.  A(S) sits in register set S % NA from NA stages before its stage; W(S + 1) sits in set (S + 1) % NWS from NWS
+  // stages before stage S stores it into the other LDS buffer.  Fewer sets where the registers are needed elsewhere (the addend
+  // doubles an A set, a narrow workgroup carries more W chunks per thread): 256 registers = two workgroups per CU.
+  constexpr int NA = ADD ? 2 : 3, NWS = NW == 4 ? 2 : 1;
+  const int KT = p.K >> 5;
+  ASet aset[NA];
+  WSet wset[NWS];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) load_a(aset[i], i);
+  load_w(wset[0], 0);
+#pragma unroll
+  for (int i = 1; i < NWS; ++i) load_w(wset[i], i);
+  store_w(wset[0], 0);
+  load_w(wset[0], NWS);
+  __syncthreads();
+  // the fragments of stage S are split during stage S - 1, BETWEEN that stage's MFMAs (same basic block, no dependence): with one
+  // workgroup per CU a wavefront has its SIMD to itself, and split-then-multiply in sequence left the matrix pipe idle during
+  // every split (13.4 us of loop for 7.4 us of MFMAs at 4800 x 512 x 512; tools/ubench/run_nt.sh)
+  h8 ah[2], al[2];
+  auto split_a = [&](const ASet &as, h8 (&oh)[2], h8 (&ol)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float t[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = __uint_as_float(as.x[2 * s2 + (c >> 2)][c & 3]);
+        if (ADD && addend) v += __uint_as_float(as.y[2 * s2 + (c >> 2)][c & 3]);
+        t[c] = v * mul_a;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        oh[s2][c] = (_Float16)t[c];
+        ol[s2][c] = (_Float16)(t[c] - (float)oh[s2][c]);
+      }
+    }
+  };
+  split_a(aset[0], ah, al);
+  load_a(aset[0], NA);
+  // stage S: `as_next` holds A(S + 1) (split now for the next stage, then re-requested for S + 1 + NA)
+  auto stage = [&](ASet &as_next, WSet &ws, int S) __attribute__((always_inline)) {
+    const int buf = S & 1;
+#ifndef GVL_NT_NO_W
+    store_w(ws, buf ^ 1);
+    load_w(ws, S + 1 + NWS);
+#endif
+    h8 nh[2], nl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      h8 bh[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#ifdef GVL_NT_NO_FRAG
+        bh[j] = __builtin_bit_cast(h8, make_uint4(fb[j][s2], 1u, 2u, 3u));
+        bl[j] = bh[j];
+#else
+        bh[j] = __builtin_bit_cast(h8, wlds[buf][0][fb[j][s2]]);
+        bl[j] = __builtin_bit_cast(h8, wlds[buf][1][fb[j][s2]]);
+#endif
+      }
+      if (s2 == 0) split_a(as_next, nh, nl);
+#ifdef GVL_NT_NO_MFMA
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(ah[s2]), "v"(al[s2]), "v"(bh[j]), "v"(bl[j]));
+      if (false)
+#endif
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bh[j], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bl[j], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s2], bh[j], acc[j], 0, 0, 0);
+      }
+    }
+#ifndef GVL_NT_NO_ALOAD
+    load_a(as_next, S + 1 + NA);
+#endif
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) { ah[s2] = nh[s2]; al[s2] = nl[s2]; }
+    __syncthreads();
+  };
+  GVL_WG_STAMP(1)
+  int s = 0;
+  for (; s + 6 <= KT; s += 6) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) stage(aset[(u + 1) % NA], wset[(u + 1) % NWS], s + u);
+  }
+#pragma unroll
+  for (int u = 0; u < 5; ++u)
+    if (s + u < KT) stage(aset[(u + 1) % NA], wset[(u + 1) % NWS], s + u);
+  GVL_WG_STAMP(2)
+
+  // ---- epilogue.  C/D map: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float rs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rr = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * half, p.R - 1);
+    float mul_;
+    row_scale((addend ? p.amax_in2 : p.amax_in)[rr], mul_, rs[r]);
+  }
+  float rowmax[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowmax[r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + 32 * j + (lane & 31), nc = min(n, p.N - 1);
+    const float cs = p.Ws[nc] * (1.f / 2048.f), cb = p.bias ? p.bias[nc] : 0.f;         // (rs carries the activation's 2^-11)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float o = fmaf(acc[j][r], rs[r] * cs, cb);
+      if (p.relu) o = fmaxf(o, 0.f);
+      if (rr < p.R && n < p.N) {
+        if (p.resid) o += p.resid[(int64_t)rr * p.ldr + n];
+        p.out[(int64_t)rr * p.ldo + n] = o;
+        rowmax[r] = fmaxf(rowmax[r], fabsf(o));
+      }
+    }
+  }
+  float *am = addend ? p.amax_out2 : p.amax_out;
+  if (am) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float m = rowmax[r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      const int rr = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if ((lane & 31) == 0 && rr < p.R) atomicMax(reinterpret_cast<unsigned *>(am) + rr, __float_as_uint(m));
+    }
+  }
+  GVL_WG_STAMP(3)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Operand planes of EVERY weight of the training step, refreshed by two launches per step (the weights change with every
 // optimizer update; one gvl_split_rows_f16 per matrix and orientation would be ~150 launches).  For each matrix W (N, K):
 //   planes of W     rows n, contraction k   -- the forward product  y = x W^T            (gvl_linear_f16x3_f32)
@@ -416,8 +661,11 @@ __global__ void __launch_bounds__(256) k_planes_split(const gvl_plane_desc *__re
     _Float16 h[4], l[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      h[c] = (_Float16)a[c];
-      l[c] = (_Float16)((a[c] - (float)h[c]) * kLoScale);
+      // format 0: x = s (hi + 2^-11 lo), |hi| < 2 (gvl_gemm16 / gvl_linear_f16x3_f32);  format 1: x = s 2^-11 (hi + lo), the residual at
+      // hi's own scale, |hi| < 2^12 (k_nt_f16x3: one accumulator for the three partial products)
+      const float t_ = d.format ? a[c] * kLoScale : a[c];
+      h[c] = (_Float16)t_;
+      l[c] = (_Float16)(d.format ? t_ - (float)h[c] : (t_ - (float)h[c]) * kLoScale);
     }
     const uint2 ph = make_uint2(__builtin_bit_cast(uint32_t, (h2v){h[0], h[1]}), __builtin_bit_cast(uint32_t, (h2v){h[2], h[3]}));
     const uint2 pl = make_uint2(__builtin_bit_cast(uint32_t, (h2v){l[0], l[1]}), __builtin_bit_cast(uint32_t, (h2v){l[2], l[3]}));
@@ -478,6 +726,48 @@ WgPlan wgrad_plan(int R, int N, int K) {
 
 }  // namespace
 
+
+extern "C" int gvl_linear_nt_f16x3_f32(const float *a, int64_t lda, const float *amax_a, const float *a2, int64_t lda2, int a2_rows,
+                                       int addend_cols, const float *amax_a2, int R, int K, const void *w_hi, const void *w_lo,
+                                       const float *w_scale, const float *bias, int N, float *out, int64_t ldo, const float *resid,
+                                       int64_t ldr, float *amax_out, float *amax_out2, int relu, void *stream) {
+  const char *what = "gvl_linear_nt_f16x3_f32";
+  if (R < 0 || N <= 0 || K <= 0 || (K & 31)) return fail(GVL_EINVAL, "%s: needs K %% 32 == 0 (got R=%d N=%d K=%d)", what, R, N, K);
+  if (R == 0) return 0;
+  if (!a || !amax_a || !w_hi || !w_lo || !w_scale || !out) return fail(GVL_EINVAL, "%s: null pointer", what);
+  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15) || ldo < N || (resid && ldr < N))
+    return fail(GVL_EINVAL, "%s: lda >= K, lda %% 4 == 0, 16-byte aligned operands, ldo / ldr >= N", what);
+  if ((int64_t)R * lda >= ((int64_t)1 << 29) || (int64_t)N * K >= ((int64_t)1 << 30))
+    return fail(GVL_EINVAL, "%s: operands of 2 GB or more are not addressed (32-bit buffer offsets)", what);
+  const bool add = addend_cols > 0;
+  if (add && (!a2 || !amax_a2 || a2_rows <= 0 || lda2 < K || (lda2 & 3) || ((uintptr_t)a2 & 15) || (addend_cols & 127)))
+    return fail(GVL_EINVAL, "%s: an addend needs a2 (16-byte aligned, lda2 >= K), its row maxima and addend_cols %% 128 == 0", what);
+  NtParams p;
+  p.A = a; p.A2 = a2; p.lda = lda; p.lda2 = lda2; p.a2_rows = a2_rows; p.addend_cols = addend_cols;
+  p.amax_in = amax_a; p.amax_in2 = amax_a2;
+  p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = bias;
+  p.R = R; p.N = N; p.K = K; p.tiles_n = (N + 127) / 128;
+  p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.amax_out = amax_out; p.amax_out2 = amax_out2; p.relu = relu;
+  // rows per tile: the largest of 128 / 96 / 64 that still gives every CU a tile (two tiles per CU are resident)
+  int nw = 4;
+  while (nw > (add ? 3 : 2) && ((R + 32 * nw - 1) / (32 * nw)) * p.tiles_n < 256) --nw;     // (addend + 2 wavefronts would spill)
+#ifdef GVL_WG_STAMPS
+  if (const char *e = getenv("GVL_NT_NW")) nw = atoi(e);      // (timing builds only)
+#endif
+  p.tiles_m = (R + 32 * nw - 1) / (32 * nw);
+  const dim3 grid(8 * ((p.tiles_m + 7) / 8) * p.tiles_n);
+  hipStream_t st = (hipStream_t)stream;
+#ifdef GVL_WG_STAMPS
+  p.stamps = g_wg_stamps;
+#endif
+#define GVL_NT_LAUNCH(NW)                                                                                                    \
+  return add ? gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, true>, grid, dim3(64 * NW), 0, st, p)         \
+             : gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, false>, grid, dim3(64 * NW), 0, st, p);
+  if (nw == 4) { GVL_NT_LAUNCH(4) }
+  if (nw == 3) { GVL_NT_LAUNCH(3) }
+  GVL_NT_LAUNCH(2)
+#undef GVL_NT_LAUNCH
+}
 
 extern "C" int gvl_planes_chunk_elems(void) { return kPlChunk; }
 

@@ -159,7 +159,7 @@ class _NoCtx:
 
 
 # ---- the TRAINING form on the hand-written kernels -------------------------------------------------------------------------
-# forward  y = x [W_0; W_1; ..]^T + [b_0; b_1; ..]   gvl_linear_f16x3_f32 on the planes of the stacked weight
+# forward  y = x [W_0; W_1; ..]^T + [b_0; b_1; ..]   gvl_linear_nt_f16x3_f32 on the planes of the stacked weight
 # backward dx = dy W                                  the same kernel on the planes of the TRANSPOSED stacked weight
 #          dW = dy^T x,  db = sum_r dy                gvl_wgrad_f16x3_f32 (one pass over dy for both)
 # The planes come from the model's TrainPlanes (gvl_amd/train_planes.py: all weights of the step in two launches per forward);
@@ -195,22 +195,19 @@ def _operands(weights, biases):
         hit = tp.lookup(weights)
         if hit is not None and tp.is_fresh():
             return Operand(hit[0], n_total, K, hit[2]), Operand(hit[1], K, n_total, None)
+    # not registered with the active planes (a module used on its own): a private TrainPlanes for this operand, refreshed when one
+    # of its parameters changes
     owner = weights[0]
-    key = tuple((t.data_ptr(), t._version) for t in list(weights) + [b for b in biases if b is not None])
     cached = owner.__dict__.get("_gvl_train_planes")
-    if cached is None or cached[0] != key:
+    if cached is None or cached.key_of(weights) not in cached.by_key or cached.device != owner.device:
+        from .train_planes import TrainPlanes
+        cached = owner.__dict__["_gvl_train_planes"] = TrainPlanes(owner.device)
+        cached.register([w for w in weights], [b for b in biases])
+    if not cached.is_fresh():
         with torch.no_grad():
-            w = weights[0].detach() if len(weights) == 1 else torch.cat([w_.detach() for w_ in weights], 0)
-            if all(b is None for b in biases):
-                b = None
-            elif len(biases) == 1:
-                b = biases[0].detach()
-            else:
-                b = torch.cat([b_.detach() if b_ is not None else w.new_zeros(w_.shape[0]) for w_, b_ in zip(weights, biases)], 0)
-            cached = (key, Operand(MSDA.split_rows(w.contiguous()), n_total, K, b),
-                      Operand(MSDA.split_rows(w.t().contiguous()), K, n_total, None))
-        owner.__dict__["_gvl_train_planes"] = cached
-    return cached[1], cached[2]
+            cached.refresh()
+    hit = cached.lookup(weights)
+    return Operand(hit[0], n_total, K, hit[2]), Operand(hit[1], K, n_total, None)
 
 
 def _row_amax(t2, src=None):
@@ -237,7 +234,7 @@ class _TrainLinearFunction(torch.autograd.Function):
         am = _row_amax(x2, x)
         op, op_t = _operands(weights, biases)
         out = torch.empty(x2.shape[0], op.N, device=x.device, dtype=torch.float32)
-        L.linear(x2, op, [L.seg(0, out, am)])
+        L.linear_nt(x2, am, op, out)
         ctx.save_for_backward(x2, am, *weights)
         ctx.op_t, ctx.nblk, ctx.x_shape = op_t, nblk, x.shape
         ctx.has_bias = [b is not None for b in biases]
@@ -258,7 +255,7 @@ class _TrainLinearFunction(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(x2.shape[0], op_t.N, device=g2.device, dtype=torch.float32)
-            L.linear(g2, op_t, [L.seg(0, gx, am_g)])
+            L.linear_nt(g2, am_g, op_t, gx)
             gx = gx.view(ctx.x_shape)
         need_w = any(ctx.needs_input_grad[2:2 + nblk])
         need_b = any(n and h for n, h in zip(ctx.needs_input_grad[2 + nblk:], ctx.has_bias))

@@ -370,6 +370,8 @@ class GraphedTrainStep(TrainStep):
         of 4, 9.50 of 2, 9.46 of 1.  (Rounds 2-3 measured the opposite, 11.8 against 11.0 ms: the captures after
         the first recorded waits on the previous capture's still-alive autograd nodes -- TrainStep returned its loss values
         attached -- and "bucket" replays exactly those later captures.)"""
+        from . import graph_replay_guard
+        graph_replay_guard("GraphedTrainStep")
         self.split = (world_size > 1) if split_exchange is None else bool(split_exchange)
         # data-parallel form: the backward is cut at the encoder output (`memory`).  Stage 1 (captioner, heads, decoder:
         # ~2/3 of the 100 MB of gradients) completes first; its buckets travel while stage 2 (deformable encoder, base
@@ -668,6 +670,8 @@ class GraphedEvalForward:
 
     def __init__(self, model, criterion, transformer_input_type="queries", warmup=1, autocast_dtype=None,
                  max_graphs=4, max_gt=0, decode_chunk=5, padded=None):
+        from . import graph_replay_guard
+        graph_replay_guard("GraphedEvalForward")
         self.model, self.criterion, self.kind = model, criterion, transformer_input_type
         self.autocast_dtype = autocast_dtype          # e.g. torch.bfloat16: capture the forward under torch.autocast
         self.warmup = max(1, int(warmup))

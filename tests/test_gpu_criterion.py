@@ -108,9 +108,13 @@ def test_col_sum_matches_float64(R, C, pad):
     assert (got.double() - want).abs().max().item() <= 1e-5 * max(1.0, R ** 0.5) * 4
 
 
-def test_linear_gradients_equal_autograd_of_f_linear():
+def test_linear_gradients_equal_autograd_of_f_linear(monkeypatch):
+    """the library-GEMM form of gvl_amd.linear.Linear (GVL_TRAIN_LINEAR=torch: the A/B switch of the hand-written training
+    products, tests/test_gpu_train_linear.py): autograd's own two GEMMs + the column-sum kernel for the bias"""
     import torch.nn.functional as F
+    from gvl_amd import linear as GL
     from gvl_amd.linear import Linear, linear
+    monkeypatch.setattr(GL, "_TRAIN_LINEAR", False)
     torch.manual_seed(3)
     lin = Linear(512, 2048).cuda()
     x = torch.randn(16, 300, 512, device="cuda", requires_grad=True)

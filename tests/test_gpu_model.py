@@ -288,7 +288,8 @@ def test_caption_cost_in_the_matcher_fails_as_the_reference_does():
               gt_boxes_mask=torch.tensor([[1, 1, 1], [1, 1, 0]], dtype=torch.bool, device=dev))
     with pytest.raises(TypeError) as e:
         model(dt, criterion, None, "queries")
-    assert str(e.value) == str(probe["exc_message"])
+    # the reference's own exception type and message, followed by the explanation a user needs
+    assert str(e.value).startswith(str(probe["exc_message"])) and "set_cost_caption" in str(e.value)
     model.eval()
     with torch.no_grad():
         out, loss = model(dt, criterion, None, "queries", eval_mode=True)

@@ -73,3 +73,29 @@ def test_capacity_policies_and_graph_cache():
     assert ("padded", sig, 8, 8, 32) in graphs
     _drop_superseded(graphs, ("padded", sig, 8, 12, 32), keep_width_buckets=False)    # grow policy: it is superseded
     assert ("padded", sig, 8, 8, 32) not in graphs
+
+
+def test_graph_replay_guard_detects_a_late_environment_setting():
+    """DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in place before the HIP runtime initialises; gvl_amd records when it
+    was not and the captured steps refuse to capture (a fresh interpreter per case: the flag is computed at import)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "import gvl_amd\n"
+            "print(int(gvl_amd.GRAPH_REPLAY_UNSAFE), os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'))\n"
+            "try:\n    gvl_amd.graph_replay_guard('x'); print('ok')\nexcept RuntimeError as e:\n    print('raised')\n") % root
+
+    def run(env_value, extra=None):
+        env = dict(os.environ)
+        env.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
+        env.pop("GVL_ALLOW_GRAPH_PACKET_CAPTURE", None)
+        if env_value is not None:
+            env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = env_value
+        env.update(extra or {})
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.split()
+    assert run(None) == ["0", "0", "ok"]                      # unset, runtime not up: gvl_amd sets it in time
+    assert run("0") == ["0", "0", "ok"]
+    assert run("1") == ["1", "1", "raised"]                   # an explicit non-zero setting is respected -- and refused for captures
+    assert run("1", {"GVL_ALLOW_GRAPH_PACKET_CAPTURE": "1"}) == ["1", "1", "ok"]
