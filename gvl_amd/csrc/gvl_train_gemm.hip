@@ -393,6 +393,25 @@ __device__ __forceinline__ void row_scale(float amax, float &mul, float &back) {
   back = __uint_as_float((uint32_t)(e - 11) << 23);
 }
 
+// quad_perm DPP move and the 4 x 4 transpose inside every lane quad: lane q of the quad ends up with a[g] = what lane g held in a[q]
+template <int CTRL>
+__device__ __forceinline__ float quad_mov4(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], int q) {
+  const bool odd = q & 1, hi = q & 2;
+#pragma unroll
+  for (int p_ = 0; p_ < 4; p_ += 2) {                                  // pairs (0,1) (2,3) across lanes q ^ 1
+    const float recv = quad_mov4<0xB1>(odd ? a[p_] : a[p_ + 1]);
+    if (odd) a[p_] = recv; else a[p_ + 1] = recv;
+  }
+#pragma unroll
+  for (int p_ = 0; p_ < 2; ++p_) {                                     // pairs (0,2) (1,3) across lanes q ^ 2
+    const float recv = quad_mov4<0x4E>(hi ? a[p_] : a[p_ + 2]);
+    if (hi) a[p_] = recv; else a[p_ + 2] = recv;
+  }
+}
+
 template <int NW, bool ADD>
 __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
   constexpr int kT = 64 * NW, kCh = 512 / kT + (512 % kT ? 1 : 0);      // 16-byte chunks per plane, thread and stage
@@ -523,10 +542,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
         bl[j] = __builtin_bit_cast(h8, wlds[buf][1][fb[j][s2]]);
 #endif
       }
-      if (s2 == 0) split_a(as_next, nh, nl);
 #ifdef GVL_NT_NO_MFMA
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(ah[s2]), "v"(al[s2]), "v"(bh[j]), "v"(bl[j]));
+      if (s2 == 1) split_a(as_next, nh, nl);
       if (false)
 #endif
 #pragma unroll
@@ -534,6 +553,16 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bh[j], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bl[j], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s2], bh[j], acc[j], 0, 0, 0);
+#ifndef GVL_NT_NO_MFMA
+        if (s2 == 1 && j == 1) {
+          // the NEXT stage's rows are waited for and split HERE, behind 18 of the stage's 24 MFMAs: an in-order wavefront that waits
+          // for memory earlier in the stage holds back every MFMA behind the wait (the wait, not the split arithmetic, was what
+          // did not overlap: 14.1 us of loop against 9.4 without / 8.1 with only the MFMAs)
+          __builtin_amdgcn_sched_barrier(0);
+          split_a(as_next, nh, nl);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
     }
 #ifndef GVL_NT_NO_ALOAD
@@ -562,34 +591,45 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
     float mul_;
     row_scale((addend ? p.amax_in2 : p.amax_in)[rr], mul_, rs[r]);
   }
-  float rowmax[16];
+  // 4 x 4 transposes inside the lane quads: registers 4 g .. 4 g + 3 of a lane are four consecutive ROWS of its column; afterwards
+  // lane 4 q + i of a quad holds row i, columns 4 q .. 4 q + 3 -- one 16-byte store per lane instead of four 4-byte ones (the
+  // 64 scalar stores per lane were 4.3 of the kernel's 19.9 us)
+  float *am = addend ? p.amax_out2 : p.amax_out;
+  const int qi = lane & 3, cq = 4 * ((lane & 31) >> 2);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) rowmax[r] = 0.f;
+  for (int g = 0; g < 4; ++g) {
+    const int rr = m0 + 8 * g + 4 * half + qi;
+    float rmax = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + 32 * j + (lane & 31), nc = min(n, p.N - 1);
-    const float cs = p.Ws[nc] * (1.f / 2048.f), cb = p.bias ? p.bias[nc] : 0.f;         // (rs carries the activation's 2^-11)
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 32 * j + (lane & 31), nc = min(n, p.N - 1);
+      const float cs = p.Ws[nc] * (1.f / 2048.f), cb = p.bias ? p.bias[nc] : 0.f;       // (rs carries the activation's 2^-11)
+      float v[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float o = fmaf(acc[j][r], rs[r] * cs, cb);
-      if (p.relu) o = fmaxf(o, 0.f);
-      if (rr < p.R && n < p.N) {
-        if (p.resid) o += p.resid[(int64_t)rr * p.ldr + n];
-        p.out[(int64_t)rr * p.ldo + n] = o;
-        rowmax[r] = fmaxf(rowmax[r], fabsf(o));
+      for (int i = 0; i < 4; ++i) {
+        v[i] = fmaf(acc[j][4 * g + i], rs[4 * g + i] * cs, cb);
+        if (p.relu) v[i] = fmaxf(v[i], 0.f);
+      }
+      quad_transpose4(v, qi);
+      const int col = n0 + 32 * j + cq;
+      if (rr < p.R && col < p.N) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.resid) {
+          const float4 e = *reinterpret_cast<const float4 *>(p.resid + (int64_t)rr * p.ldr + col);
+          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
+        // (streaming store: written through instead of parked dirty in the XCD's L2 for the end-of-kernel release)
+        typedef float f4n __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((f4n){o.x, o.y, o.z, o.w}, reinterpret_cast<f4n *>(p.out + (int64_t)rr * p.ldo + col));
+        rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
       }
     }
-  }
-  float *am = addend ? p.amax_out2 : p.amax_out;
-  if (am) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float m = rowmax[r];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      const int rr = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if ((lane & 31) == 0 && rr < p.R) atomicMax(reinterpret_cast<unsigned *>(am) + rr, __float_as_uint(m));
+    if (am) {
+      // a row's 128 columns sit in the 8 lanes with the same (lane & 3) of this half
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64));
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 8, 64));
+      rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
+      if ((lane & 28) == 0 && rr < p.R) atomicMax(reinterpret_cast<unsigned *>(am) + rr, __float_as_uint(rmax));
     }
   }
   GVL_WG_STAMP(3)
@@ -735,8 +775,9 @@ extern "C" int gvl_linear_nt_f16x3_f32(const float *a, int64_t lda, const float 
   if (R < 0 || N <= 0 || K <= 0 || (K & 31)) return fail(GVL_EINVAL, "%s: needs K %% 32 == 0 (got R=%d N=%d K=%d)", what, R, N, K);
   if (R == 0) return 0;
   if (!a || !amax_a || !w_hi || !w_lo || !w_scale || !out) return fail(GVL_EINVAL, "%s: null pointer", what);
-  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15) || ldo < N || (resid && ldr < N))
-    return fail(GVL_EINVAL, "%s: lda >= K, lda %% 4 == 0, 16-byte aligned operands, ldo / ldr >= N", what);
+  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15) || ldo < N || (resid && ldr < N) ||
+      (N & 3) || (ldo & 3) || ((uintptr_t)out & 15) || (resid && ((ldr & 3) || ((uintptr_t)resid & 15))))
+    return fail(GVL_EINVAL, "%s: lda >= K, N, lda, ldo, ldr multiples of 4, 16-byte aligned operands, ldo / ldr >= N", what);
   if ((int64_t)R * lda >= ((int64_t)1 << 29) || (int64_t)N * K >= ((int64_t)1 << 30))
     return fail(GVL_EINVAL, "%s: operands of 2 GB or more are not addressed (32-bit buffer offsets)", what);
   const bool add = addend_cols > 0;

@@ -227,3 +227,83 @@ def test_eval_result_gather_and_fixed_bucket_order():
         for li in range(4):
             assert torch.allclose(torch.from_numpy(res[r][4][2 * li]), torch.full((16, 16), 3.0), atol=1e-6)
             assert torch.allclose(torch.from_numpy(res[r][4][2 * li + 1]), torch.full((16,), 2.0), atol=1e-6)
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gvl_amd.parallel import GradBuckets, shard_batch
+        # ---- an uneven batch: 13 videos over 8 ranks, two of them without any event ---------------------------------
+        B = 13
+        n_gt = [2, 0, 3, 1, 0, 2, 1, 4, 1, 2, 3, 1, 2]          # videos 1 and 4 (ranks 1 and 4) have no event
+        dt = {"video_tensor": torch.arange(B)[:, None, None].float().expand(B, 4, 2), "video_mask": torch.ones(B, 4, dtype=torch.bool),
+              "video_length": torch.zeros(B, 3), "gt_boxes_mask": torch.ones(B, 3, dtype=torch.bool),
+              "video_target": [{"boxes": torch.zeros(n, 2), "labels": torch.zeros(n)} for n in n_gt],
+              "cap_raw": [["c"] * n for n in n_gt], "cap_tensor": torch.arange(sum(n_gt))[:, None].expand(-1, 6),
+              "cap_mask": torch.ones(sum(n_gt), 6)}
+        mine = shard_batch(dt, rank, world)
+        vids = mine["video_tensor"][:, 0, 0].long().tolist()
+        assert vids == list(range(rank, B, world)) and mine["cap_tensor"].shape[0] == sum(n_gt[v] for v in vids)
+        # num_boxes: the mean over the ranks of the local target count (criterion.py:178-181), >= 1
+        nb = torch.tensor([float(sum(n_gt[v] for v in vids))])
+        dist.all_reduce(nb)
+        nb = (nb / world).clamp(min=1.0)
+        # ---- gradient buckets at their real size: 25 MB buckets over a 34 MB parameter set, three steps ------------
+        torch.manual_seed(0)
+        layers = [torch.nn.Linear(1024, 1024) for _ in range(8)] + [torch.nn.Linear(1024, 520)]
+        params = [p for l_ in layers for p in l_.parameters()]
+        buckets = GradBuckets(params)                             # default bucket_bytes = 25 MB, overlap hooks
+        sizes = [(e - s_) * 4 for s_, e, _ in buckets.buckets]
+        assert len(sizes) == 2 and sizes[0] >= 25 << 20 and sum(sizes) == 4 * sum(p.numel() for p in params)
+        x = torch.full((1, 1024), float(rank + 1))
+        seq = []
+        orig = dist.all_reduce
+
+        def spy(t, *a, **k):
+            seq.append(t.numel())
+            return orig(t, *a, **k)
+        dist.all_reduce = spy
+        try:
+            for step in range(3):
+                buckets.zero()
+                # every rank walks the layers in its own order and skips one (rank-dependent) layer: completion order of
+                # the buckets differs between ranks, the posted order must not
+                order = layers[rank % 9:] + layers[:rank % 9]
+                used = [l_ for i, l_ in enumerate(order) if i != (rank + step) % 9]
+                sum(l_(x).sum() for l_ in used).backward()
+                buckets.finish()
+        finally:
+            dist.all_reduce = orig
+        assert seq == [sizes[0] // 4, sizes[1] // 4] * 3, seq      # bucket 0 then bucket 1, every step, on every rank
+        q.put((rank, float(nb), [float(p.grad.double().sum()) for p in params[:4]], len(buckets.unused_params())))
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_batch_empty_ranks_and_bucket_order():
+    """the data-parallel machinery at W = 8 (the node's GPU count) -- B not a multiple of W, ranks whose videos
+    carry no event, 25 MB bucket boundaries, the same all-reduce sequence on every rank although their backward orders differ"""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    n_gt = [2, 0, 3, 1, 0, 2, 1, 4, 1, 2, 3, 1, 2]
+    assert all(abs(r[1] - sum(n_gt) / 8) < 1e-6 for r in res)       # 22 targets / 8 ranks = 2.75 on every rank
+    # the gradients every rank holds after the exchange are identical (the mean over the ranks)
+    for r in res[1:]:
+        assert r[2] == res[0][2] and r[3] == res[0][3]
