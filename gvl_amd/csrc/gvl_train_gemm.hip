@@ -413,23 +413,27 @@ __device__ __forceinline__ void quad_transpose4(float (&a)[4], int q) {
 }
 
 template <int NW, bool ADD>
-__global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
-  constexpr int kT = 64 * NW, kCh = 512 / kT + (512 % kT ? 1 : 0);      // 16-byte chunks per plane, thread and stage
-  __shared__ uint4 wlds[2][2][512];                                      // [buffer][hi | lo][128 rows x 4 chunks, swizzled]
+__global__ void __launch_bounds__(128 * NW, 2) k_nt_f16x3(const NtParams p) {
+  // 2 NW wavefronts: row group g = wave % NW (32 rows), K parity kp = wave / NW.  The two wavefronts of a row group sit on one
+  // SIMD and take ALTERNATE K stages of the same 32 x 128 tile (partial sums exchanged once, at the end): neither waits for
+  // the other inside an iteration, so while one waits for its rows the other's MFMAs run -- with ONE wavefront per SIMD (and
+  // the grids of this path give a CU one workgroup) every wait idled the matrix pipe (tools/ubench/run_nt.sh).
+  constexpr int kT = 128 * NW, kCh = (2048 + kT - 1) / kT;               // W chunks (16 B) per thread and iteration (= 2 stages)
+  __shared__ uint4 wlds[2][2][2][512];                                   // [iteration parity][stage of the pair][hi | lo][slot]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  // the column tiles of ONE row tile on one XCD (workgroup id % 8; speed only): they read the same rows of A, which that XCD's L2
-  // then fetches once -- dealt round-robin they sit on tiles_n different XCDs and A crosses the fabric tiles_n times
+  const int grp = wave % NW, kp = wave / NW;
+  // the column tiles of ONE row tile on one XCD (workgroup id % 8; speed only): they read the same rows of A
   const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
   const int tm = xcd + 8 * (slot / p.tiles_n), tn = slot % p.tiles_n;
   if (tm >= p.tiles_m) return;
   GVL_WG_STAMP(0)
-  const int m0 = tm * 32 * NW + 32 * wave, n0 = tn * 128;
+  const int m0 = tm * 32 * NW + 32 * grp, n0 = tn * 128;
   const bool addend = ADD && n0 < p.addend_cols;
   const int row = min(m0 + (lane & 31), p.R - 1);
   float mul_a, back_a;
   row_scale((addend ? p.amax_in2 : p.amax_in)[row], mul_a, back_a);
 
-  // ---- A: 64 bytes per lane and stage (four 16-byte loads), three stages in flight
+  // ---- A: 64 bytes per lane and stage (four 16-byte loads) straight into registers
   const auto a_rs = rsrc_of(p.A, (uint32_t)min((int64_t)p.R * p.lda * 4, (int64_t)0x7ffffff0));
   const auto a2_rs = rsrc_of(ADD ? p.A2 : p.A, (uint32_t)min((int64_t)(ADD ? p.a2_rows : 1) * (ADD ? p.lda2 : 1) * 4, (int64_t)0x7ffffff0));
   const uint32_t a_off = (uint32_t)row * (uint32_t)p.lda * 4u + 64u * half;
@@ -443,33 +447,33 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
       for (int i = 0; i < 4; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off + 128u * stage + 16u * i, 0, 0);
     }
   };
-  // ---- W: chunk c (16 bytes) of tile row w of the stage -> swizzled slot; through registers, one stage ahead
+  // ---- W: the workgroup stages the planes of TWO K stages per iteration through registers: chunk id = ((stage of the pair * 2
+  // + plane) * 512 + row * 4 + 16-byte piece)
   const auto wh_rs = rsrc_of(p.Wh, (uint32_t)min((int64_t)p.N * p.K * 2, (int64_t)0x7ffffff0));
   const auto wl_rs = rsrc_of(p.Wl, (uint32_t)min((int64_t)p.N * p.K * 2, (int64_t)0x7ffffff0));
+  const uint32_t w_stage = (uint32_t)p.N * 64u;                         // bytes between two K stages of a plane
   uint32_t w_src[kCh];
   int w_dst[kCh];
+  bool w_lo[kCh];
 #pragma unroll
   for (int i = 0; i < kCh; ++i) {
-    const int id = tid + i * kT, wr = (id >> 2) & 127, ch = id & 3;
-    w_src[i] = ((uint32_t)min(n0 + wr, p.N - 1) * 32u + 8u * ch) * 2u;
-    w_dst[i] = id < 512 ? lds_slot(wr, ch) : -1;
+    const int id = tid + i * kT, st2 = (id >> 10) & 1, pl = (id >> 9) & 1, wr = (id >> 2) & 127, ch = id & 3;
+    w_src[i] = ((uint32_t)min(n0 + wr, p.N - 1) * 32u + 8u * ch) * 2u + w_stage * st2;
+    w_dst[i] = id < 2048 ? (st2 * 2 + pl) * 512 + lds_slot(wr, ch) : -1;
+    w_lo[i] = pl;
   }
-  const uint32_t w_stage = (uint32_t)p.N * 64u;                         // bytes between two K stages of a plane
-  struct WSet { u4v h[kCh], l[kCh]; };
-  auto load_w = [&](WSet &s, int stage) {
-#pragma unroll
-    for (int i = 0; i < kCh; ++i) {
-      s.h[i] = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_src[i] + w_stage * stage, 0, 0);
-      s.l[i] = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_src[i] + w_stage * stage, 0, 0);
-    }
-  };
-  auto store_w = [&](const WSet &s, int buf) {
+  struct WSet { u4v c[kCh]; };
+  auto load_w = [&](WSet &s, int it) {                                  // the chunks of stages 2 it, 2 it + 1
 #pragma unroll
     for (int i = 0; i < kCh; ++i)
-      if (512 % kT == 0 || w_dst[i] >= 0) {
-        wlds[buf][0][w_dst[i]] = __builtin_bit_cast(uint4, s.h[i]);
-        wlds[buf][1][w_dst[i]] = __builtin_bit_cast(uint4, s.l[i]);
-      }
+      s.c[i] = w_lo[i] ? __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_src[i] + 2u * w_stage * it, 0, 0)
+                       : __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_src[i] + 2u * w_stage * it, 0, 0);
+  };
+  auto store_w = [&](const WSet &s, int par) {
+    uint4 *dst = &wlds[par][0][0][0];
+#pragma unroll
+    for (int i = 0; i < kCh; ++i)
+      if (2048 % kT == 0 || w_dst[i] >= 0) dst[w_dst[i]] = __builtin_bit_cast(uint4, s.c[i]);
   };
 
   f16acc acc[4];
@@ -483,24 +487,18 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) fb[j][s2] = lds_slot(32 * j + (lane & 31), 2 * half + s2);
 
-  // ---- pipeline.  A(S) sits in register set S % NA from NA stages before its stage; W(S + 1) sits in set (S + 1) % NWS from NWS
-  // stages before stage S stores it into the other LDS buffer.  Fewer sets where the registers are needed elsewhere (the addend
-  // doubles an A set, a narrow workgroup carries more W chunks per thread): 256 registers = two workgroups per CU.
-  constexpr int NA = ADD ? 2 : 3, NWS = NW == 4 ? 2 : 1;
-  const int KT = p.K >> 5;
+  // ---- pipeline.  Iteration `it` covers K stages 2 it and 2 it + 1; this wavefront multiplies stage S = 2 it + kp.  Its rows of
+  // stage S sit in register set it % NA from NA iterations before; W of iteration it + 1 sits in registers from one iteration
+  // before it is stored into the other LDS half.
+  constexpr int NA = ADD ? 2 : 3;
+  const int KT = p.K >> 5, IT = (KT + 1) >> 1;
   ASet aset[NA];
-  WSet wset[NWS];
+  WSet wset;
 #pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(aset[i], i);
-  load_w(wset[0], 0);
-#pragma unroll
-  for (int i = 1; i < NWS; ++i) load_w(wset[i], i);
-  store_w(wset[0], 0);
-  load_w(wset[0], NWS);
-  __syncthreads();
-  // the fragments of stage S are split during stage S - 1, BETWEEN that stage's MFMAs (same basic block, no dependence): with one
-  // workgroup per CU a wavefront has its SIMD to itself, and split-then-multiply in sequence left the matrix pipe idle during
-  // every split (13.4 us of loop for 7.4 us of MFMAs at 4800 x 512 x 512; tools/ubench/run_nt.sh)
+  for (int i = 0; i < NA; ++i) load_a(aset[i], 2 * i + kp);
+  load_w(wset, 0);
+  store_w(wset, 0);
+  load_w(wset, 1);
   h8 ah[2], al[2];
   auto split_a = [&](const ASet &as, h8 (&oh)[2], h8 (&ol)[2]) __attribute__((always_inline)) {
 #pragma unroll
@@ -520,13 +518,15 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
     }
   };
   split_a(aset[0], ah, al);
-  load_a(aset[0], NA);
-  // stage S: `as_next` holds A(S + 1) (split now for the next stage, then re-requested for S + 1 + NA)
-  auto stage = [&](ASet &as_next, WSet &ws, int S) __attribute__((always_inline)) {
-    const int buf = S & 1;
+  load_a(aset[0], 2 * NA + kp);
+  __syncthreads();
+  // iteration it: `as_next` holds the rows of this wavefront's stage of iteration it + 1
+  auto iter = [&](ASet &as_next, int it) __attribute__((always_inline)) {
+    const int par = it & 1;
+    const bool live = 2 * it + kp < KT;                                 // (K / 32 odd: the last iteration has one stage)
 #ifndef GVL_NT_NO_W
-    store_w(ws, buf ^ 1);
-    load_w(ws, S + 1 + NWS);
+    store_w(wset, par ^ 1);
+    load_w(wset, it + 2);
 #endif
     h8 nh[2], nl[2];
 #pragma unroll
@@ -538,8 +538,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
         bh[j] = __builtin_bit_cast(h8, make_uint4(fb[j][s2], 1u, 2u, 3u));
         bl[j] = bh[j];
 #else
-        bh[j] = __builtin_bit_cast(h8, wlds[buf][0][fb[j][s2]]);
-        bl[j] = __builtin_bit_cast(h8, wlds[buf][1][fb[j][s2]]);
+        bh[j] = __builtin_bit_cast(h8, wlds[par][kp][0][fb[j][s2]]);
+        bl[j] = __builtin_bit_cast(h8, wlds[par][kp][1][fb[j][s2]]);
 #endif
       }
 #ifdef GVL_NT_NO_MFMA
@@ -550,14 +550,15 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
 #endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bh[j], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bl[j], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s2], bh[j], acc[j], 0, 0, 0);
+        if (live) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bh[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bl[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s2], bh[j], acc[j], 0, 0, 0);
+        }
 #ifndef GVL_NT_NO_MFMA
         if (s2 == 1 && j == 1) {
           // the NEXT stage's rows are waited for and split HERE, behind 18 of the stage's 24 MFMAs: an in-order wavefront that waits
-          // for memory earlier in the stage holds back every MFMA behind the wait (the wait, not the split arithmetic, was what
-          // did not overlap: 14.1 us of loop against 9.4 without / 8.1 with only the MFMAs)
+          // for memory earlier holds back every MFMA behind the wait
           __builtin_amdgcn_sched_barrier(0);
           split_a(as_next, nh, nl);
           __builtin_amdgcn_sched_barrier(0);
@@ -566,22 +567,37 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
       }
     }
 #ifndef GVL_NT_NO_ALOAD
-    load_a(as_next, S + 1 + NA);
+    load_a(as_next, 2 * (it + 1 + NA) + kp);
 #endif
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) { ah[s2] = nh[s2]; al[s2] = nl[s2]; }
     __syncthreads();
   };
   GVL_WG_STAMP(1)
-  int s = 0;
-  for (; s + 6 <= KT; s += 6) {
+  int it = 0;
+  for (; it + NA <= IT; it += NA) {
 #pragma unroll
-    for (int u = 0; u < 6; ++u) stage(aset[(u + 1) % NA], wset[(u + 1) % NWS], s + u);
+    for (int u = 0; u < NA; ++u) iter(aset[(u + 1) % NA], it + u);
   }
 #pragma unroll
-  for (int u = 0; u < 5; ++u)
-    if (s + u < KT) stage(aset[(u + 1) % NA], wset[(u + 1) % NWS], s + u);
+  for (int u = 0; u < NA - 1; ++u)
+    if (it + u < IT) iter(aset[(u + 1) % NA], it + u);
   GVL_WG_STAMP(2)
+  // ---- the two K parities of a row group exchange halves of their partial sums through LDS: parity 0 keeps column blocks 0, 1,
+  // parity 1 keeps 2, 3 -- all 2 NW wavefronts run the epilogue, 64 columns each
+  {
+    float *xl = reinterpret_cast<float *>(&wlds[0][0][0][0]) + (size_t)grp * (2 * 2 * 16 * 64);       // [parity][block][reg][lane]
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xl[((kp * 2 + jj) * 16 + r) * 64 + lane] = acc[kp ? jj : 2 + jj][r];   // the blocks the PARTNER keeps
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kp ? 2 + jj : jj][r] += xl[(((kp ^ 1) * 2 + jj) * 16 + r) * 64 + lane];
+  }
+  const int jlo = kp ? 2 : 0;                                           // this wavefront's column blocks jlo, jlo + 1
 
   // ---- epilogue.  C/D map: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float rs[16];
@@ -601,13 +617,14 @@ __global__ void __launch_bounds__(64 * NW, 2) k_nt_f16x3(const NtParams p) {
     const int rr = m0 + 8 * g + 4 * half + qi;
     float rmax = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = jlo + jj;
       const int n = n0 + 32 * j + (lane & 31), nc = min(n, p.N - 1);
       const float cs = p.Ws[nc] * (1.f / 2048.f), cb = p.bias ? p.bias[nc] : 0.f;       // (rs carries the activation's 2^-11)
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        v[i] = fmaf(acc[j][4 * g + i], rs[4 * g + i] * cs, cb);
+        v[i] = fmaf((kp ? acc[2 + jj] : acc[jj])[4 * g + i], rs[4 * g + i] * cs, cb);
         if (p.relu) v[i] = fmaxf(v[i], 0.f);
       }
       quad_transpose4(v, qi);
@@ -802,8 +819,8 @@ extern "C" int gvl_linear_nt_f16x3_f32(const float *a, int64_t lda, const float 
   p.stamps = g_wg_stamps;
 #endif
 #define GVL_NT_LAUNCH(NW)                                                                                                    \
-  return add ? gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, true>, grid, dim3(64 * NW), 0, st, p)         \
-             : gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, false>, grid, dim3(64 * NW), 0, st, p);
+  return add ? gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, true>, grid, dim3(128 * NW), 0, st, p)        \
+             : gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, false>, grid, dim3(128 * NW), 0, st, p);
   if (nw == 4) { GVL_NT_LAUNCH(4) }
   if (nw == 3) { GVL_NT_LAUNCH(3) }
   GVL_NT_LAUNCH(2)
