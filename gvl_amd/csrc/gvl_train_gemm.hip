@@ -351,308 +351,6 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float4 *__restrict__
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_nt_f16x3        out[r][n] = epilogue(sum_k (A [+ A2])[r][k] W[n][k] + bias[n])   -- the forward product and the input gradient
-//                   (dx = dy W = dy (W^T)^T on the planes of W^T) of every nn.Linear of the training step.
-//   A    fp32 activations.  A wavefront owns 32 rows for the whole kernel and takes them STRAIGHT INTO REGISTERS: lane (row r =
-//        l & 31, half h = l >> 5) loads the 64 contiguous bytes k0 + 16 h .. + 15 of its row per K stage of 32 and splits them
-//        there -- the activation never passes through LDS (in gvl_linear_f16x3_f32 its LDS writes, at 80 B / clk, and fragment
-//        reads were half of a stage).  The contraction order inside a stage is permuted accordingly (k-step s of the MFMA takes
-//        elements 16 h + 8 s ..: any order works as long as both operands agree), which for W means reading chunk 2 h + s
-//        instead of 2 s + h of its 64-byte stage row.
-//   W    fp16 planes in the SAME-SCALE form (hi, lo = residual at hi's scale; gvl_planes_refresh_f16 format 1), staged through
-//        LDS for the workgroup's wavefronts (each multiplies all 128 columns of the tile): hi.hi + hi.lo + lo.hi in ONE accumulator.
-//   Tile = 32 NW rows x 128 columns, NW = 2, 3 or 4 wavefronts (chosen so that the grid covers the chip: 4800 rows -> NW = 2 or 3);
-//   64 accumulator registers per wavefront, two workgroups per CU.
-//   Epilogue: bias, ReLU, residual add, row maxima of the result (atomic max into a zeroed vector).
-//   `addend_cols`: tiles left of that column multiply A + A2[r % a2_rows] (nn.MultiheadAttention's in-projection: q and k take
-//   tgt + query_pos, v takes tgt) and scale by amax_in2 / report to amax_out2.
-struct NtParams {
-  const float *A, *A2;
-  int64_t lda, lda2;
-  int a2_rows, addend_cols;
-  const float *amax_in, *amax_in2;     // (R) row bounds of A / of A + A2
-  const _Float16 *Wh, *Wl;             // planes (K / 32, N, 32)
-  const float *Ws, *bias;              // (N) row scales of W, bias or NULL
-  int R, N, K, tiles_n, tiles_m;
-  float *out;
-  int64_t ldo;
-  const float *resid;
-  int64_t ldr;
-  float *amax_out, *amax_out2;
-  int relu;
-#ifdef GVL_WG_STAMPS
-  unsigned long long *stamps;
-#endif
-};
-
-// 2^11 / s, s = 2^floor(log2 amax): the row's largest element lands in [2^11, 2^12)
-__device__ __forceinline__ void row_scale(float amax, float &mul, float &back) {
-  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-  e = min(max(e, 13), 240);
-  mul = __uint_as_float((uint32_t)(254 - e + 11) << 23);
-  back = __uint_as_float((uint32_t)(e - 11) << 23);
-}
-
-// quad_perm DPP move and the 4 x 4 transpose inside every lane quad: lane q of the quad ends up with a[g] = what lane g held in a[q]
-template <int CTRL>
-__device__ __forceinline__ float quad_mov4(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ void quad_transpose4(float (&a)[4], int q) {
-  const bool odd = q & 1, hi = q & 2;
-#pragma unroll
-  for (int p_ = 0; p_ < 4; p_ += 2) {                                  // pairs (0,1) (2,3) across lanes q ^ 1
-    const float recv = quad_mov4<0xB1>(odd ? a[p_] : a[p_ + 1]);
-    if (odd) a[p_] = recv; else a[p_ + 1] = recv;
-  }
-#pragma unroll
-  for (int p_ = 0; p_ < 2; ++p_) {                                     // pairs (0,2) (1,3) across lanes q ^ 2
-    const float recv = quad_mov4<0x4E>(hi ? a[p_] : a[p_ + 2]);
-    if (hi) a[p_] = recv; else a[p_ + 2] = recv;
-  }
-}
-
-template <int NW, bool ADD>
-__global__ void __launch_bounds__(128 * NW, 2) k_nt_f16x3(const NtParams p) {
-  // 2 NW wavefronts: row group g = wave % NW (32 rows), K parity kp = wave / NW.  The two wavefronts of a row group sit on one
-  // SIMD and take ALTERNATE K stages of the same 32 x 128 tile (partial sums exchanged once, at the end): neither waits for
-  // the other inside an iteration, so while one waits for its rows the other's MFMAs run -- with ONE wavefront per SIMD (and
-  // the grids of this path give a CU one workgroup) every wait idled the matrix pipe (tools/ubench/run_nt.sh).
-  constexpr int kT = 128 * NW, kCh = (2048 + kT - 1) / kT;               // W chunks (16 B) per thread and iteration (= 2 stages)
-  __shared__ uint4 wlds[2][2][2][512];                                   // [iteration parity][stage of the pair][hi | lo][slot]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  const int grp = wave % NW, kp = wave / NW;
-  // the column tiles of ONE row tile on one XCD (workgroup id % 8; speed only): they read the same rows of A
-  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-  const int tm = xcd + 8 * (slot / p.tiles_n), tn = slot % p.tiles_n;
-  if (tm >= p.tiles_m) return;
-  GVL_WG_STAMP(0)
-  const int m0 = tm * 32 * NW + 32 * grp, n0 = tn * 128;
-  const bool addend = ADD && n0 < p.addend_cols;
-  const int row = min(m0 + (lane & 31), p.R - 1);
-  float mul_a, back_a;
-  row_scale((addend ? p.amax_in2 : p.amax_in)[row], mul_a, back_a);
-
-  // ---- A: 64 bytes per lane and stage (four 16-byte loads) straight into registers
-  const auto a_rs = rsrc_of(p.A, (uint32_t)min((int64_t)p.R * p.lda * 4, (int64_t)0x7ffffff0));
-  const auto a2_rs = rsrc_of(ADD ? p.A2 : p.A, (uint32_t)min((int64_t)(ADD ? p.a2_rows : 1) * (ADD ? p.lda2 : 1) * 4, (int64_t)0x7ffffff0));
-  const uint32_t a_off = (uint32_t)row * (uint32_t)p.lda * 4u + 64u * half;
-  const uint32_t a2_off = ADD ? (uint32_t)(row % p.a2_rows) * (uint32_t)p.lda2 * 4u + 64u * half : 0u;
-  struct ASet { u4v x[4], y[4]; };
-  auto load_a = [&](ASet &s, int stage) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s.x[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_off + 128u * stage + 16u * i, 0, 0);
-    if (ADD) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off + 128u * stage + 16u * i, 0, 0);
-    }
-  };
-  // ---- W: the workgroup stages the planes of TWO K stages per iteration through registers: chunk id = ((stage of the pair * 2
-  // + plane) * 512 + row * 4 + 16-byte piece)
-  const auto wh_rs = rsrc_of(p.Wh, (uint32_t)min((int64_t)p.N * p.K * 2, (int64_t)0x7ffffff0));
-  const auto wl_rs = rsrc_of(p.Wl, (uint32_t)min((int64_t)p.N * p.K * 2, (int64_t)0x7ffffff0));
-  const uint32_t w_stage = (uint32_t)p.N * 64u;                         // bytes between two K stages of a plane
-  uint32_t w_src[kCh];
-  int w_dst[kCh];
-  bool w_lo[kCh];
-#pragma unroll
-  for (int i = 0; i < kCh; ++i) {
-    const int id = tid + i * kT, st2 = (id >> 10) & 1, pl = (id >> 9) & 1, wr = (id >> 2) & 127, ch = id & 3;
-    w_src[i] = ((uint32_t)min(n0 + wr, p.N - 1) * 32u + 8u * ch) * 2u + w_stage * st2;
-    w_dst[i] = id < 2048 ? (st2 * 2 + pl) * 512 + lds_slot(wr, ch) : -1;
-    w_lo[i] = pl;
-  }
-  struct WSet { u4v c[kCh]; };
-  auto load_w = [&](WSet &s, int it) {                                  // the chunks of stages 2 it, 2 it + 1
-#pragma unroll
-    for (int i = 0; i < kCh; ++i)
-      s.c[i] = w_lo[i] ? __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_src[i] + 2u * w_stage * it, 0, 0)
-                       : __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_src[i] + 2u * w_stage * it, 0, 0);
-  };
-  auto store_w = [&](const WSet &s, int par) {
-    uint4 *dst = &wlds[par][0][0][0];
-#pragma unroll
-    for (int i = 0; i < kCh; ++i)
-      if (2048 % kT == 0 || w_dst[i] >= 0) dst[w_dst[i]] = __builtin_bit_cast(uint4, s.c[i]);
-  };
-
-  f16acc acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  int fb[4][2];                                                         // B fragment slots: tile column block j, k-step s
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) fb[j][s2] = lds_slot(32 * j + (lane & 31), 2 * half + s2);
-
-  // ---- pipeline.  Iteration `it` covers K stages 2 it and 2 it + 1; this wavefront multiplies stage S = 2 it + kp.  Its rows of
-  // stage S sit in register set it % NA from NA iterations before; W of iteration it + 1 sits in registers from one iteration
-  // before it is stored into the other LDS half.
-  constexpr int NA = ADD ? 2 : 3;
-  const int KT = p.K >> 5, IT = (KT + 1) >> 1;
-  ASet aset[NA];
-  WSet wset;
-#pragma unroll
-  for (int i = 0; i < NA; ++i) load_a(aset[i], 2 * i + kp);
-  load_w(wset, 0);
-  store_w(wset, 0);
-  load_w(wset, 1);
-  h8 ah[2], al[2];
-  auto split_a = [&](const ASet &as, h8 (&oh)[2], h8 (&ol)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      float t[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float v = __uint_as_float(as.x[2 * s2 + (c >> 2)][c & 3]);
-        if (ADD && addend) v += __uint_as_float(as.y[2 * s2 + (c >> 2)][c & 3]);
-        t[c] = v * mul_a;
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        oh[s2][c] = (_Float16)t[c];
-        ol[s2][c] = (_Float16)(t[c] - (float)oh[s2][c]);
-      }
-    }
-  };
-  split_a(aset[0], ah, al);
-  load_a(aset[0], 2 * NA + kp);
-  __syncthreads();
-  // iteration it: `as_next` holds the rows of this wavefront's stage of iteration it + 1
-  auto iter = [&](ASet &as_next, int it) __attribute__((always_inline)) {
-    const int par = it & 1;
-    const bool live = 2 * it + kp < KT;                                 // (K / 32 odd: the last iteration has one stage)
-#ifndef GVL_NT_NO_W
-    store_w(wset, par ^ 1);
-    load_w(wset, it + 2);
-#endif
-    h8 nh[2], nl[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      h8 bh[4], bl[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#ifdef GVL_NT_NO_FRAG
-        bh[j] = __builtin_bit_cast(h8, make_uint4(fb[j][s2], 1u, 2u, 3u));
-        bl[j] = bh[j];
-#else
-        bh[j] = __builtin_bit_cast(h8, wlds[par][kp][0][fb[j][s2]]);
-        bl[j] = __builtin_bit_cast(h8, wlds[par][kp][1][fb[j][s2]]);
-#endif
-      }
-#ifdef GVL_NT_NO_MFMA
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(ah[s2]), "v"(al[s2]), "v"(bh[j]), "v"(bl[j]));
-      if (s2 == 1) split_a(as_next, nh, nl);
-      if (false)
-#endif
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (live) {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bh[j], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s2], bl[j], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s2], bh[j], acc[j], 0, 0, 0);
-        }
-#ifndef GVL_NT_NO_MFMA
-        if (s2 == 1 && j == 1) {
-          // the NEXT stage's rows are waited for and split HERE, behind 18 of the stage's 24 MFMAs: an in-order wavefront that waits
-          // for memory earlier holds back every MFMA behind the wait
-          __builtin_amdgcn_sched_barrier(0);
-          split_a(as_next, nh, nl);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-      }
-    }
-#ifndef GVL_NT_NO_ALOAD
-    load_a(as_next, 2 * (it + 1 + NA) + kp);
-#endif
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) { ah[s2] = nh[s2]; al[s2] = nl[s2]; }
-    __syncthreads();
-  };
-  GVL_WG_STAMP(1)
-  int it = 0;
-  for (; it + NA <= IT; it += NA) {
-#pragma unroll
-    for (int u = 0; u < NA; ++u) iter(aset[(u + 1) % NA], it + u);
-  }
-#pragma unroll
-  for (int u = 0; u < NA - 1; ++u)
-    if (it + u < IT) iter(aset[(u + 1) % NA], it + u);
-  GVL_WG_STAMP(2)
-  // ---- the two K parities of a row group exchange halves of their partial sums through LDS: parity 0 keeps column blocks 0, 1,
-  // parity 1 keeps 2, 3 -- all 2 NW wavefronts run the epilogue, 64 columns each
-  {
-    float *xl = reinterpret_cast<float *>(&wlds[0][0][0][0]) + (size_t)grp * (2 * 2 * 16 * 64);       // [parity][block][reg][lane]
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xl[((kp * 2 + jj) * 16 + r) * 64 + lane] = acc[kp ? jj : 2 + jj][r];   // the blocks the PARTNER keeps
-    __syncthreads();
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[kp ? 2 + jj : jj][r] += xl[(((kp ^ 1) * 2 + jj) * 16 + r) * 64 + lane];
-  }
-  const int jlo = kp ? 2 : 0;                                           // this wavefront's column blocks jlo, jlo + 1
-
-  // ---- epilogue.  C/D map: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  float rs[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rr = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * half, p.R - 1);
-    float mul_;
-    row_scale((addend ? p.amax_in2 : p.amax_in)[rr], mul_, rs[r]);
-  }
-  // 4 x 4 transposes inside the lane quads: registers 4 g .. 4 g + 3 of a lane are four consecutive ROWS of its column; afterwards
-  // lane 4 q + i of a quad holds row i, columns 4 q .. 4 q + 3 -- one 16-byte store per lane instead of four 4-byte ones (the
-  // 64 scalar stores per lane were 4.3 of the kernel's 19.9 us)
-  float *am = addend ? p.amax_out2 : p.amax_out;
-  const int qi = lane & 3, cq = 4 * ((lane & 31) >> 2);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int rr = m0 + 8 * g + 4 * half + qi;
-    float rmax = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int j = jlo + jj;
-      const int n = n0 + 32 * j + (lane & 31), nc = min(n, p.N - 1);
-      const float cs = p.Ws[nc] * (1.f / 2048.f), cb = p.bias ? p.bias[nc] : 0.f;       // (rs carries the activation's 2^-11)
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = fmaf((kp ? acc[2 + jj] : acc[jj])[4 * g + i], rs[4 * g + i] * cs, cb);
-        if (p.relu) v[i] = fmaxf(v[i], 0.f);
-      }
-      quad_transpose4(v, qi);
-      const int col = n0 + 32 * j + cq;
-      if (rr < p.R && col < p.N) {
-        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        if (p.resid) {
-          const float4 e = *reinterpret_cast<const float4 *>(p.resid + (int64_t)rr * p.ldr + col);
-          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
-        }
-        // (streaming store: written through instead of parked dirty in the XCD's L2 for the end-of-kernel release)
-        typedef float f4n __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store((f4n){o.x, o.y, o.z, o.w}, reinterpret_cast<f4n *>(p.out + (int64_t)rr * p.ldo + col));
-        rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
-      }
-    }
-    if (am) {
-      // a row's 128 columns sit in the 8 lanes with the same (lane & 3) of this half
-      rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64));
-      rmax = fmaxf(rmax, __shfl_xor(rmax, 8, 64));
-      rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64));
-      if ((lane & 28) == 0 && rr < p.R) atomicMax(reinterpret_cast<unsigned *>(am) + rr, __float_as_uint(rmax));
-    }
-  }
-  GVL_WG_STAMP(3)
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Operand planes of EVERY weight of the training step, refreshed by two launches per step (the weights change with every
 // optimizer update; one gvl_split_rows_f16 per matrix and orientation would be ~150 launches).  For each matrix W (N, K):
 //   planes of W     rows n, contraction k   -- the forward product  y = x W^T            (gvl_linear_f16x3_f32)
@@ -718,11 +416,8 @@ __global__ void __launch_bounds__(256) k_planes_split(const gvl_plane_desc *__re
     _Float16 h[4], l[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      // format 0: x = s (hi + 2^-11 lo), |hi| < 2 (gvl_gemm16 / gvl_linear_f16x3_f32);  format 1: x = s 2^-11 (hi + lo), the residual at
-      // hi's own scale, |hi| < 2^12 (k_nt_f16x3: one accumulator for the three partial products)
-      const float t_ = d.format ? a[c] * kLoScale : a[c];
-      h[c] = (_Float16)t_;
-      l[c] = (_Float16)(d.format ? t_ - (float)h[c] : (t_ - (float)h[c]) * kLoScale);
+      h[c] = (_Float16)a[c];
+      l[c] = (_Float16)((a[c] - (float)h[c]) * kLoScale);
     }
     const uint2 ph = make_uint2(__builtin_bit_cast(uint32_t, (h2v){h[0], h[1]}), __builtin_bit_cast(uint32_t, (h2v){h[2], h[3]}));
     const uint2 pl = make_uint2(__builtin_bit_cast(uint32_t, (h2v){l[0], l[1]}), __builtin_bit_cast(uint32_t, (h2v){l[2], l[3]}));
@@ -783,49 +478,6 @@ WgPlan wgrad_plan(int R, int N, int K) {
 
 }  // namespace
 
-
-extern "C" int gvl_linear_nt_f16x3_f32(const float *a, int64_t lda, const float *amax_a, const float *a2, int64_t lda2, int a2_rows,
-                                       int addend_cols, const float *amax_a2, int R, int K, const void *w_hi, const void *w_lo,
-                                       const float *w_scale, const float *bias, int N, float *out, int64_t ldo, const float *resid,
-                                       int64_t ldr, float *amax_out, float *amax_out2, int relu, void *stream) {
-  const char *what = "gvl_linear_nt_f16x3_f32";
-  if (R < 0 || N <= 0 || K <= 0 || (K & 31)) return fail(GVL_EINVAL, "%s: needs K %% 32 == 0 (got R=%d N=%d K=%d)", what, R, N, K);
-  if (R == 0) return 0;
-  if (!a || !amax_a || !w_hi || !w_lo || !w_scale || !out) return fail(GVL_EINVAL, "%s: null pointer", what);
-  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15) || ldo < N || (resid && ldr < N) ||
-      (N & 3) || (ldo & 3) || ((uintptr_t)out & 15) || (resid && ((ldr & 3) || ((uintptr_t)resid & 15))))
-    return fail(GVL_EINVAL, "%s: lda >= K, N, lda, ldo, ldr multiples of 4, 16-byte aligned operands, ldo / ldr >= N", what);
-  if ((int64_t)R * lda >= ((int64_t)1 << 29) || (int64_t)N * K >= ((int64_t)1 << 30))
-    return fail(GVL_EINVAL, "%s: operands of 2 GB or more are not addressed (32-bit buffer offsets)", what);
-  const bool add = addend_cols > 0;
-  if (add && (!a2 || !amax_a2 || a2_rows <= 0 || lda2 < K || (lda2 & 3) || ((uintptr_t)a2 & 15) || (addend_cols & 127)))
-    return fail(GVL_EINVAL, "%s: an addend needs a2 (16-byte aligned, lda2 >= K), its row maxima and addend_cols %% 128 == 0", what);
-  NtParams p;
-  p.A = a; p.A2 = a2; p.lda = lda; p.lda2 = lda2; p.a2_rows = a2_rows; p.addend_cols = addend_cols;
-  p.amax_in = amax_a; p.amax_in2 = amax_a2;
-  p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = bias;
-  p.R = R; p.N = N; p.K = K; p.tiles_n = (N + 127) / 128;
-  p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.amax_out = amax_out; p.amax_out2 = amax_out2; p.relu = relu;
-  // rows per tile: the largest of 128 / 96 / 64 that still gives every CU a tile (two tiles per CU are resident)
-  int nw = 4;
-  while (nw > (add ? 3 : 2) && ((R + 32 * nw - 1) / (32 * nw)) * p.tiles_n < 256) --nw;     // (addend + 2 wavefronts would spill)
-#ifdef GVL_WG_STAMPS
-  if (const char *e = getenv("GVL_NT_NW")) nw = atoi(e);      // (timing builds only)
-#endif
-  p.tiles_m = (R + 32 * nw - 1) / (32 * nw);
-  const dim3 grid(8 * ((p.tiles_m + 7) / 8) * p.tiles_n);
-  hipStream_t st = (hipStream_t)stream;
-#ifdef GVL_WG_STAMPS
-  p.stamps = g_wg_stamps;
-#endif
-#define GVL_NT_LAUNCH(NW)                                                                                                    \
-  return add ? gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, true>, grid, dim3(128 * NW), 0, st, p)        \
-             : gvl::launch(GVL_PROF_LINEAR, R, N, "k_nt_f16x3", k_nt_f16x3<NW, false>, grid, dim3(128 * NW), 0, st, p);
-  if (nw == 4) { GVL_NT_LAUNCH(4) }
-  if (nw == 3) { GVL_NT_LAUNCH(3) }
-  GVL_NT_LAUNCH(2)
-#undef GVL_NT_LAUNCH
-}
 
 extern "C" int gvl_planes_chunk_elems(void) { return kPlChunk; }
 

@@ -110,25 +110,6 @@ def linear(a, w, segs, a2=None, flags=0):
     _lib.check(rc, "linear_f16x3")
 
 
-def linear_nt(a, amax_a, w, out, a2=None, addend_cols=0, amax_a2=None, resid=None, amax_out=None, amax_out2=None, relu=False):
-    """gvl_linear_nt_f16x3_f32 (the training products): out (R, N) = epilogue((a [+ a2]) w^T + bias) for a (R, K) fp32 with row
-    bounds amax_a and w an operand in FORMAT-1 planes (gvl_amd/train_planes.py); `out` is written in place"""
-    R, K = a.shape
-    assert a.dtype == torch.float32 and a.stride(1) == 1 and K == w.K and out.shape == (R, w.N) and out.stride(1) == 1
-    assert amax_a.numel() == R and amax_a.dtype == torch.float32 and amax_a.is_contiguous()
-    with torch.cuda.device(a.device):
-        rc = _lib.lib().gvl_linear_nt_f16x3_f32(
-            a.data_ptr(), a.stride(0), amax_a.data_ptr(), a2.data_ptr() if a2 is not None else None,
-            a2.stride(0) if a2 is not None else 0, a2.shape[0] if a2 is not None else 0, int(addend_cols),
-            amax_a2.data_ptr() if amax_a2 is not None else None, R, K, w.planes.hi.data_ptr(), w.planes.lo.data_ptr(),
-            w.planes.scale.data_ptr(), w.bias.data_ptr() if w.bias is not None else None, w.N, out.data_ptr(), out.stride(0),
-            resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
-            amax_out.data_ptr() if amax_out is not None else None, amax_out2.data_ptr() if amax_out2 is not None else None,
-            1 if relu else 0, torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "linear_nt_f16x3")
-    return out
-
-
 def layer_norm(x, norm, pos=None, want_amax=True):
     """LayerNorm of the rows of x (R, C) -> (y, amax_y, amax_{y + pos} or None)   (gvl_layer_norm_rows_f32)"""
     R, C = x.shape

@@ -159,7 +159,7 @@ class _NoCtx:
 
 
 # ---- the TRAINING form on the hand-written kernels -------------------------------------------------------------------------
-# forward  y = x [W_0; W_1; ..]^T + [b_0; b_1; ..]   gvl_linear_nt_f16x3_f32 on the planes of the stacked weight
+# forward  y = x [W_0; W_1; ..]^T + [b_0; b_1; ..]   gvl_linear_f16x3_f32 on the planes of the stacked weight
 # backward dx = dy W                                  the same kernel on the planes of the TRANSPOSED stacked weight
 #          dW = dy^T x,  db = sum_r dy                gvl_wgrad_f16x3_f32 (one pass over dy for both)
 # The planes come from the model's TrainPlanes (gvl_amd/train_planes.py: all weights of the step in two launches per forward);
@@ -234,7 +234,7 @@ class _TrainLinearFunction(torch.autograd.Function):
         am = _row_amax(x2, x)
         op, op_t = _operands(weights, biases)
         out = torch.empty(x2.shape[0], op.N, device=x.device, dtype=torch.float32)
-        L.linear_nt(x2, am, op, out)
+        L.linear(x2, op, [L.seg(0, out, am)])
         ctx.save_for_backward(x2, am, *weights)
         ctx.op_t, ctx.nblk, ctx.x_shape = op_t, nblk, x.shape
         ctx.has_bias = [b is not None for b in biases]
@@ -255,7 +255,7 @@ class _TrainLinearFunction(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(x2.shape[0], op_t.N, device=g2.device, dtype=torch.float32)
-            L.linear_nt(g2, am_g, op_t, gx)
+            L.linear(g2, op_t, [L.seg(0, gx, am_g)])
             gx = gx.view(ctx.x_shape)
         need_w = any(ctx.needs_input_grad[2:2 + nblk])
         need_b = any(n and h for n, h in zip(ctx.needs_input_grad[2 + nblk:], ctx.has_bias))

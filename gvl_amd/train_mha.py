@@ -2,7 +2,7 @@
 ``self.self_attn(q, k, tgt, key_padding_mask=~query_mask)`` with q = k = tgt + query_pos, an nn.MultiheadAttention with dropout on
 the attention weights) on the hand-written kernels:
 
-    in-projection   ONE gvl_linear_nt_f16x3_f32 launch over in_proj_weight: columns [0, 2C) multiply tgt + query_pos (the addend is
+    in-projection   ONE gvl_linear_f16x3_f32 launch over in_proj_weight: columns [0, 2C) multiply tgt + query_pos (the addend is
                     applied in the kernel's load path), columns [2C, 3C) multiply tgt; the epilogue leaves the row maxima of the
                     q | k and of the v columns
     attention core  gvl_mha_train_forward_f32 / _backward_f32 (scores, softmax, dropout stay in registers)
@@ -55,7 +55,8 @@ class _InProj(torch.autograd.Function):
         am_qk = GL._row_amax(xq.reshape(R, C), xq)
         qkv = torch.empty(R, 3 * C, device=x.device, dtype=torch.float32)
         am_out = torch.zeros(2, R, device=x.device, dtype=torch.float32)
-        L.linear_nt(x2, am_v, op, qkv, a2=pos, addend_cols=2 * C, amax_a2=am_qk, amax_out=am_out[1], amax_out2=am_out[0])
+        L.linear(x2, op, [L.seg(0, qkv[:, :2 * C], am_qk, amax_out=am_out[0], addend=True),
+                          L.seg(2 * C, qkv[:, 2 * C:], am_v, amax_out=am_out[1])], a2=pos)
         ctx.save_for_backward(x2, xq.reshape(R, C), am_v, am_qk, weight)
         ctx.op_t, ctx.shape = op_t, (B, Q, C)
         ctx.mark_non_differentiable(am_out)
@@ -75,8 +76,8 @@ class _InProj(torch.autograd.Function):
         cut = 2 * C // 32
         dxq = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
         dxv = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
-        L.linear_nt(g_qk, am_gqk, Operand(_Sub(op_t.planes, 0, cut), C, 2 * C, None), dxq)
-        L.linear_nt(g_v, am_gv, Operand(_Sub(op_t.planes, cut, 3 * C // 32), C, C, None), dxv)
+        L.linear(g_qk, Operand(_Sub(op_t.planes, 0, cut), C, 2 * C, None), [L.seg(0, dxq, am_gqk)])
+        L.linear(g_v, Operand(_Sub(op_t.planes, cut, 3 * C // 32), C, C, None), [L.seg(0, dxv, am_gv)])
         gw = torch.empty(3 * C, C, device=dqkv.device, dtype=torch.float32)
         gb = torch.empty(3 * C, device=dqkv.device, dtype=torch.float32)
         MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gw[:2 * C], grad_b=gb[:2 * C])

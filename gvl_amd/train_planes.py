@@ -23,8 +23,7 @@ class _Desc(ctypes.Structure):                      # include/gvl_msda.h: gvl_pl
     _fields_ = [("w", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int), ("hi", ctypes.c_void_p), ("lo", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("n_total", ctypes.c_int), ("n_off", ctypes.c_int), ("t_hi", ctypes.c_void_p),
                 ("t_lo", ctypes.c_void_p), ("t_scale", ctypes.c_void_p), ("group_chunk_begin", ctypes.c_int),
-                ("group_chunks", ctypes.c_int), ("bias", ctypes.c_void_p), ("bias_dst", ctypes.c_void_p), ("format", ctypes.c_int),
-                ("reserved", ctypes.c_int)]
+                ("group_chunks", ctypes.c_int), ("bias", ctypes.c_void_p), ("bias_dst", ctypes.c_void_p)]
 
 
 class Operand:
@@ -42,11 +41,8 @@ def eligible_matrix(w):
 class TrainPlanes:
     """planes of registered operands, both orientations; ``refresh()`` = two launches for all of them"""
 
-    def __init__(self, device, fmt=1):
-        """fmt: plane format (include/gvl_msda.h: gvl_plane_desc.format) -- 1 for gvl_linear_nt_f16x3_f32 (the training
-        products), 0 for gvl_linear_f16x3_f32 / gvl_gemm_f16x3_f32"""
+    def __init__(self, device):
         self.device = torch.device(device)
-        self.format = int(fmt)
         self.operands = []                 # [(key, [weights], fwd Operand planes, transposed Operand planes)]
         self.by_key = {}
         self._built = None
@@ -98,8 +94,7 @@ class TrainPlanes:
                 di = len(descs)
                 descs.append(_Desc(w.data_ptr(), N, K, fwd.hi.data_ptr(), fwd.lo.data_ptr(), fwd.scale.data_ptr(), n_total, n_off,
                                    tr.hi.data_ptr(), tr.lo.data_ptr(), tr.scale.data_ptr(), 0, 0,
-                                   b.data_ptr() if b is not None else None, bias.data_ptr() if bias is not None else None,
-                                   self.format, 0))
+                                   b.data_ptr() if b is not None else None, bias.data_ptr() if bias is not None else None))
                 for c in range((N * K + chunk - 1) // chunk):
                     chunk_map.append((di, c))
                 tiles = (N // 32) * (K // 32)

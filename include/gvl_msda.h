@@ -678,9 +678,6 @@ typedef struct gvl_plane_desc {
   int group_chunk_begin, group_chunks;
   const float *bias;   /* (N) or NULL: copied to bias_dst[n_off ..] (the concatenated bias of the operand) */
   float *bias_dst;
-  int format;          /* 0: x = scale (hi + 2^-11 lo) as gvl_split_rows_f16 (operands of gvl_linear_f16x3_f32 / gvl_gemm_f16x3_f32);
-                          1: x = scale 2^-11 (hi + lo), the residual at hi's own scale (operands of gvl_linear_nt_f16x3_f32) */
-  int reserved;
 } gvl_plane_desc;
 int gvl_planes_chunk_elems(void);
 int gvl_planes_refresh_f16(const gvl_plane_desc *descs_device, const int *chunk_map_device, int n_chunks, const int *wg_map_device,
@@ -701,21 +698,6 @@ int gvl_mha_train_forward_f32(const float *qkv, int64_t ld, const unsigned char 
 int gvl_mha_train_backward_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk, const float *amax_v,
                                int B, int Q, int H, float p, uint32_t seed, const int64_t *step, const float *out, const float *lse,
                                const float *dout, float *delta_ws, float *amax_dout_ws, float *dqkv, void *stream);
-
-/* -- TRAINING: the forward product  y = x W^T + b  and the input gradient  dx = dy W  (= dy (W^T)^T, on the planes of W^T) of an
- *    nn.Linear (pdvc/deformable_transformer.py:189-199,257-280; pdvc/ops/modules/ms_deform_attn.py:95,99-100,125) on the fp16 matrix
- *    cores at fp32 accuracy:   out[r][n] = epilogue(sum_k (a [+ a2])[r][k] w[n][k] + bias[n]).
- *    a (R, K) fp32, row stride lda, amax_a (R) upper bounds of its rows; w as FORMAT-1 planes (gvl_planes_refresh_f16) of an (N, K)
- *    operand, K % 32 == 0; bias (N) or NULL; out (R, N) row stride ldo.  Epilogue: relu != 0; resid (R, N) added after it; amax_out (R)
- *    zero-initialised receives max |out row| (NULL = not wanted).  addend_cols > 0 (a multiple of 128): columns [0, addend_cols)
- *    multiply a + a2[r % a2_rows] (row bounds amax_a2, row maxima of the result to amax_out2), the rest multiply a -- the q | k | v
- *    in-projection of nn.MultiheadAttention with q = k = tgt + query_pos, v = tgt (deformable_transformer.py:263-268) in one launch.
- *    The activation goes from memory straight into MFMA operand registers (split there); only the weight passes through LDS.
- *    |error| <= 2^-21 sum |a||w| + K 2^-33 amax_row max|w|. */
-int gvl_linear_nt_f16x3_f32(const float *a, int64_t lda, const float *amax_a, const float *a2, int64_t lda2, int a2_rows,
-                            int addend_cols, const float *amax_a2, int R, int K, const void *w_hi, const void *w_lo,
-                            const float *w_scale, const float *bias, int N, float *out, int64_t ldo, const float *resid, int64_t ldr,
-                            float *amax_out, float *amax_out2, int relu, void *stream);
 
 #ifdef __cplusplus
 }

@@ -61,15 +61,14 @@ def test_wgrad_bound_instead_of_maximum_and_tiny_values():
     assert torch.count_nonzero(z) == 0 and torch.isfinite(z).all()
 
 
-@pytest.mark.parametrize("fmt", [0, 1])
-def test_planes_refresh_equals_per_matrix_split(fmt):
-    """gvl_planes_refresh_f16: the planes of [W0; W1] and of its transpose reproduce the matrices to 22 bits (both plane formats),
-    the bias is the concatenation, and a second refresh follows the parameters"""
+def test_planes_refresh_equals_per_matrix_split():
+    """gvl_planes_refresh_f16: the planes of [W0; W1] and of its transpose reproduce the matrices to 22 bits, the bias is the
+    concatenation, and a second refresh follows the parameters"""
     torch.manual_seed(1)
     w0, w1 = torch.randn(128, 512, device=DEV) * 0.05, torch.randn(128, 512, device=DEV) * 3e-4
     w2 = torch.randn(1536, 512, device=DEV)
     b0, b1 = torch.randn(128, device=DEV), torch.randn(128, device=DEV)
-    tp = TrainPlanes(DEV, fmt=fmt)
+    tp = TrainPlanes(DEV)
     tp.register([w0, w1], [b0, b1])
     tp.register([w2], [None])
     for rnd in range(2):
@@ -79,8 +78,7 @@ def test_planes_refresh_equals_per_matrix_split(fmt):
             W = torch.cat(ws, 0)
             for planes, M in ((fwd, W), (tr, W.t())):
                 hi, lo = planes.dense()
-                rec = planes.scale[:, None].double() * ((hi.double() + lo.double()) / 2048 if fmt else hi.double() + lo.double() / 2048)
-                assert float(hi.abs().max()) < (4096 if fmt else 2)
+                rec = planes.scale[:, None].double() * (hi.double() + lo.double() / 2048)
                 assert (rec - M.double()).abs().max().item() <= W.abs().max().item() * 2.0 ** -21
             if bs is not None:
                 assert torch.equal(bias, torch.cat(bs))
@@ -150,43 +148,3 @@ def test_linear_module_routes_training_products_to_the_hand_written_kernels():
         assert not GL.train_linear_eligible(x, (lin.weight,), (lin.bias,))
     finally:
         GL.train_linear_enabled(True)
-
-
-def test_linear_nt_epilogues_and_addend():
-    """gvl_linear_nt_f16x3_f32: bias / ReLU / residual / row maxima of the result, and the two-operand form of the attention
-    in-projection (columns [0, 1024) multiply a + a2[r % rows], the rest a) against float64"""
-    torch.manual_seed(5)
-    R, K, N, Q = 4800, 512, 1536, 300
-    a = torch.randn(R, K, device=DEV) * torch.exp(torch.randn(R, 1, device=DEV))
-    a2 = torch.randn(Q, 2 * K, device=DEV)[:, :K]                      # a strided view, as the query embedding's half
-    w, b = torch.randn(N, K, device=DEV) * 0.05, torch.randn(N, device=DEV)
-    tp = TrainPlanes(DEV)
-    tp.register([w], [b])
-    tp.refresh()
-    from gvl_amd.train_planes import Operand
-    fwd, _, bias = tp.lookup([w])
-    op = Operand(fwd, N, K, bias)
-    am = L.row_absmax(a)[0]
-    am2 = L.row_absmax(a, a2.contiguous())[1]
-    out = torch.empty(R, N, device=DEV)
-    mo = torch.zeros(2, R, device=DEV)
-    L.linear_nt(a, am, op, out, a2=a2, addend_cols=1024, amax_a2=am2, amax_out=mo[1], amax_out2=mo[0])
-    a64, w64 = a.double(), w.double()
-    aq = a64 + a2.double().repeat(R // Q, 1)
-    ref = torch.cat([aq @ w64[:1024].t(), a64 @ w64[1024:].t()], 1) + b.double()
-    assert _err(out, ref) < 2e-6
-    assert torch.allclose(mo[0], out[:, :1024].abs().amax(1)) and torch.allclose(mo[1], out[:, 1024:].abs().amax(1))
-    res = torch.randn(R, N, device=DEV)
-    out2 = torch.empty(R, N, device=DEV)
-    L.linear_nt(a, am, op, out2, resid=res, relu=True)
-    ref2 = torch.relu(a64 @ w64.t() + b.double()) + res.double()
-    assert _err(out2, ref2) < 2e-6
-    # rows that are not a multiple of the tile, a narrow operand, a loose row bound
-    for R2, N2 in ((37, 64), (3008, 256), (1000, 512)):
-        w_ = torch.randn(N2, K, device=DEV)
-        tp2 = TrainPlanes(DEV)
-        tp2.register([w_], [None])
-        tp2.refresh()
-        o = torch.empty(R2, N2, device=DEV)
-        L.linear_nt(a[:R2], am[:R2] * 1.7, Operand(tp2.lookup([w_])[0], N2, K, None), o)
-        assert _err(o, a64[:R2] @ w_.double().t()) < 2e-6

@@ -9,10 +9,5 @@ build nofrag "-DGVL_WG_STAMPS -DGVL_WG_NO_MFMA -DGVL_WG_NO_FRAG" &
 build nostore "-DGVL_WG_STAMPS -DGVL_WG_NO_MFMA -DGVL_WG_NO_FRAG -DGVL_WG_NO_STORE" &
 build noload "-DGVL_WG_STAMPS -DGVL_WG_NO_LOAD" &
 build mfmaonly "-DGVL_WG_STAMPS -DGVL_WG_NO_LOAD -DGVL_WG_NO_STORE -DGVL_WG_NO_FRAG" &
-build nt_nomfma "-DGVL_WG_STAMPS -DGVL_NT_NO_MFMA" &
-build nt_nofrag "-DGVL_WG_STAMPS -DGVL_NT_NO_MFMA -DGVL_NT_NO_FRAG" &
-build nt_now "-DGVL_WG_STAMPS -DGVL_NT_NO_MFMA -DGVL_NT_NO_FRAG -DGVL_NT_NO_W" &
-build nt_noa "-DGVL_WG_STAMPS -DGVL_NT_NO_ALOAD" &
-build nt_mfmaonly "-DGVL_WG_STAMPS -DGVL_NT_NO_ALOAD -DGVL_NT_NO_W -DGVL_NT_NO_FRAG" &
 wait
 ls -la $root/tools/_bin/tgemm_*

@@ -18,75 +18,8 @@ static float *dev_rand(size_t n, float scale) {
   return d;
 }
 
-#ifdef GVL_WG_STAMPS
-static void report_stamps() {
-  std::vector<unsigned long long> h(4096 * 8);
-  hipMemcpy(h.data(), g_wg_stamps, h.size() * 8, hipMemcpyDeviceToHost);
-  std::vector<double> cyc[3], us3[3], begin;
-  unsigned long long t0 = ~0ull, t1 = 0;
-  for (int b = 0; b < 4096; ++b) {
-    if (!h[b * 8 + 7]) continue;
-    for (int i = 0; i < 3; ++i) {
-      cyc[i].push_back((double)(h[b * 8 + 2 * (i + 1)] - h[b * 8 + 2 * i]));
-      us3[i].push_back((double)(h[b * 8 + 2 * (i + 1) + 1] - h[b * 8 + 2 * i + 1]) * 0.01);
-    }
-    t0 = std::min(t0, h[b * 8 + 1]); t1 = std::max(t1, h[b * 8 + 7]);
-    begin.push_back((double)h[b * 8 + 1]);
-  }
-  if (begin.empty()) return;
-  const char *nm[3] = {"prologue", "stage loop", "epilogue"};
-  for (int i = 0; i < 3; ++i) {
-    std::sort(cyc[i].begin(), cyc[i].end()); std::sort(us3[i].begin(), us3[i].end());
-    printf("   %-12s median %8.0f cycles %6.2f us   max %6.2f us\n", nm[i], cyc[i][cyc[i].size() / 2], us3[i][us3[i].size() / 2], us3[i].back());
-  }
-  std::sort(begin.begin(), begin.end());
-  printf("   %zu workgroups; first start -> last end %.2f us; start skew %.2f us; loop clock %.0f MHz\n", begin.size(), (double)(t1 - t0) * 0.01,
-         (begin.back() - begin.front()) * 0.01, cyc[1][cyc[1].size() / 2] / us3[1][us3[1].size() / 2]);
-  hipMemset(g_wg_stamps, 0, 4096 * 8 * 8);
-}
-#endif
-
-static int run_nt(int R, int N, int K, int iters) {
-#ifdef GVL_WG_STAMPS
-  hipMalloc(&g_wg_stamps, 4096 * 8 * 8);
-  hipMemset(g_wg_stamps, 0, 4096 * 8 * 8);
-#endif
-  // planes of zeros-free random weights in format 1 are not needed for TIMING: any fp16 bit patterns do
-  float *a = dev_rand((size_t)R * K, 1.f), *am, *out, *ws_, *bias;
-  std::vector<float> one(R > N ? R : N, 1.f);
-  hipMalloc(&am, R * 4); hipMemcpy(am, one.data(), R * 4, hipMemcpyHostToDevice);
-  hipMalloc(&ws_, N * 4); hipMemcpy(ws_, one.data(), N * 4, hipMemcpyHostToDevice);
-  hipMalloc(&bias, N * 4); hipMemcpy(bias, one.data(), N * 4, hipMemcpyHostToDevice);
-  hipMalloc(&out, (size_t)R * N * 4);
-  std::vector<_Float16> hw((size_t)N * K);
-  for (auto &v : hw) v = (_Float16)(((float)rand() / RAND_MAX - 0.5f) * 4096.f);
-  _Float16 *wh, *wl;
-  hipMalloc(&wh, hw.size() * 2); hipMalloc(&wl, hw.size() * 2);
-  hipMemcpy(wh, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-  hipMemcpy(wl, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-  hipStream_t st; hipStreamCreate(&st);
-  std::vector<float> us;
-  for (int it = 0; it < iters + 5; ++it) {
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, st);
-    int rc = gvl_linear_nt_f16x3_f32(a, K, am, nullptr, 0, 0, 0, nullptr, R, K, wh, wl, ws_, bias, N, out, N, nullptr, 0, nullptr, nullptr, 0, st);
-    hipEventRecord(e1, st);
-    hipEventSynchronize(e1);
-    if (rc) { printf("rc %d %s\n", rc, gvl::g_err); return 2; }
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    if (it >= 5) us.push_back(ms * 1e3f);
-  }
-  std::sort(us.begin(), us.end());
-  printf("nt    R=%d N=%d K=%d  median %7.2f us  min %7.2f us (event-to-event)\n", R, N, K, us[us.size() / 2], us[0]);
-#ifdef GVL_WG_STAMPS
-  report_stamps();
-#endif
-  return 0;
-}
-
 int main(int argc, char **argv) {
   if (argc < 5) return 1;
-  if (!strcmp(argv[1], "nt")) return run_nt(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 30);
   const int R = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]), iters = argc > 5 ? atoi(argv[5]) : 30;
   float *dy = dev_rand((size_t)R * N, 1e-3f), *x = dev_rand((size_t)R * K, 1.f);
   std::vector<float> one(R, 1.f);
@@ -119,8 +52,29 @@ int main(int argc, char **argv) {
   printf("wgrad R=%d N=%d K=%d  SK=%d rows/split=%d  median %7.2f us  min %7.2f us (event-to-event, incl. reduce launch)\n", R, N, K, pl.SK,
          pl.rows_per_split, us[us.size() / 2], us[0]);
 #ifdef GVL_WG_STAMPS
-  report_stamps();
+  {
+    std::vector<unsigned long long> h(4096 * 8);
+    hipMemcpy(h.data(), g_wg_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> cyc[3], us3[3], begin;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int b = 0; b < 4096; ++b) {
+      if (!h[b * 8 + 7]) continue;
+      for (int i = 0; i < 3; ++i) {
+        cyc[i].push_back((double)(h[b * 8 + 2 * (i + 1)] - h[b * 8 + 2 * i]));
+        us3[i].push_back((double)(h[b * 8 + 2 * (i + 1) + 1] - h[b * 8 + 2 * i + 1]) * 0.01);
+      }
+      t0 = std::min(t0, h[b * 8 + 1]); t1 = std::max(t1, h[b * 8 + 7]);
+      begin.push_back((double)h[b * 8 + 1]);
+    }
+    const char *nm[3] = {"prologue (amax, first loads, stage 0)", "stage loop", "epilogue (partial tile store)"};
+    for (int i = 0; i < 3; ++i) {
+      std::sort(cyc[i].begin(), cyc[i].end()); std::sort(us3[i].begin(), us3[i].end());
+      printf("   %-40s median %8.0f cycles %6.2f us   max %6.2f us\n", nm[i], cyc[i][cyc[i].size() / 2], us3[i][us3[i].size() / 2], us3[i].back());
+    }
+    std::sort(begin.begin(), begin.end());
+    printf("   %zu workgroups stamped; first start -> last end %.2f us; start skew (last start - first start) %.2f us; loop clock %.0f MHz\n",
+           begin.size(), (double)(t1 - t0) * 0.01, (begin.back() - begin.front()) * 0.01, cyc[1][cyc[1].size() / 2] / us3[1][us3[1].size() / 2]);
+  }
 #endif
   return 0;
 }
-
