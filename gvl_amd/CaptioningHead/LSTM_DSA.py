@@ -390,10 +390,20 @@ class TeacherForcedLoop(torch.autograd.Function):
             if i > 0:                                  # h_{-1} = 0 is a constant
                 dh_carry = torch.mm(dg[i], w_hcat, out=dh_buf[i & 1])
         dgf = dg.view(steps * n, W)
-        d_w_hcat = dgf.t().mm(h_all[:steps].reshape(steps * n, H))
-        d_b_hcat = MSDA.col_sum(dgf)
         d_gates = dg[:, :, A:A + H4]
-        d_w_att = d_gates.reshape(steps * n, H4).t().mm(att.view(steps * n, C))
+        h_prev, att2 = h_all[:steps].reshape(steps * n, H), att.view(steps * n, C)
+        from ..linear import train_linear_enabled
+        if train_linear_enabled() and steps * n >= 512 and MSDA.wgrad_eligible(dgf, h_prev) and C % 4 == 0:
+            # the two weight gradients over ALL steps on the fp16 matrix cores (gvl_wgrad_f16x3_f32; the bias gradient comes
+            # out of the same pass over dg): 84 + 6 + 50 us as fp32 library GEMMs + column sum at (4416, 2576 | 2048, 512)
+            from .. import layers as L
+            am_dg = L.row_absmax(dgf)[0]
+            d_w_hcat, d_b_hcat = MSDA.wgrad(dgf, h_prev, am_dg, L.row_absmax(h_prev)[0])
+            d_w_att, _ = MSDA.wgrad(dgf[:, A:A + H4], att2, am_dg, L.row_absmax(att2)[0], want_bias=False)
+        else:
+            d_w_hcat = dgf.t().mm(h_prev)
+            d_b_hcat = MSDA.col_sum(dgf)
+            d_w_att = d_gates.reshape(steps * n, H4).t().mm(att2)
         return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates.sum(0), d_gates.permute(1, 0, 2), d_w_hcat, d_b_hcat,
                 d_w_att, g_aw, g_ab, None, None, None, None, None)
 

@@ -44,6 +44,8 @@ struct LinParams {
   const _Float16 *Wh, *Wl;
   const float *Ws, *bias;
   int R, N, K, tiles_m, tiles_n, nseg, xcd_cols;
+  int split_stages;            // > 0: split-K -- workgroup row blockIdx.y multiplies K stages [y split_stages, (y + 1) split_stages)
+  int64_t split_stride;        //      and stores its partial tile (no epilogue) at out + y split_stride (floats)
   gvl_lin_seg seg[kMaxSeg];
 };
 
@@ -146,10 +148,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
   };
-  const auto a_rs = rsrc_of(p.A + (int64_t)m0 * p.lda);
-  const auto a2_rs = rsrc_of(HAS_A2 ? p.A2 : p.A);
-  const auto wh_rs = rsrc_of(p.Wh + (int64_t)n0 * 32);                  // planes are K-stage-major (plane_off): stage s of the
-  const auto wl_rs = rsrc_of(p.Wl + (int64_t)n0 * 32);                  // tile's rows starts s N 32 halves further
+  // split-K (the vocabulary layer's input gradient: 2208 x 512 outputs, contraction 8518): this workgroup's stage range
+  const int kbeg = p.split_stages ? (int)blockIdx.y * p.split_stages : 0;
+  const auto a_rs = rsrc_of(p.A + (int64_t)m0 * p.lda + (int64_t)kbeg * kBK);
+  const auto a2_rs = rsrc_of((HAS_A2 ? p.A2 : p.A) + (int64_t)kbeg * kBK);
+  const auto wh_rs = rsrc_of(p.Wh + (int64_t)n0 * 32 + (int64_t)kbeg * N * 32);   // planes are K-stage-major (plane_off): stage s of
+  const auto wl_rs = rsrc_of(p.Wl + (int64_t)n0 * 32 + (int64_t)kbeg * N * 32);   // the tile's rows starts s N 32 halves further
   int a_off[NA], a2_off[NA];
   uint32_t a_dst[NA];
   float a_inv[NA];
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
     for (int j = 0; j < NJ; ++j) fb[j][s] = 2 * kASlots + lds_slot(wn + 32 * j + frow, 2 * s + fh);
   }
 
-  const int KT = K / kBK;
+  const int KT = p.split_stages ? min(K / kBK - kbeg, p.split_stages) : K / kBK;
   ASet set0, set1;
   load_a(set0, 0);
   load_a(set1, min(1, KT - 1) * kBK);
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (st_ok[j] && row < R) sg.out[(int64_t)row * sg.ldo + ocol[j]] = v[i][j][r];
+        if (st_ok[j] && row < R) (sg.out + (int64_t)blockIdx.y * p.split_stride)[(int64_t)row * sg.ldo + ocol[j]] = v[i][j][r];
       }
   if (sg.amax_out) {
     // Row maxima of this wavefront's part: a butterfly reduce-SCATTER over the 32 lanes that hold one row's columns --
@@ -954,6 +958,7 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   p.A = a; p.lda = lda; p.A2 = any_addend ? a2 : nullptr; p.lda2 = lda2; p.a2_rows = any_addend ? a2_rows : 1;
   p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = bias;
   p.R = R; p.N = N; p.K = K;
+  p.split_stages = 0; p.split_stride = 0;
   p.nseg = nseg;
   for (int s = 0; s < kMaxSeg; ++s) p.seg[s] = segs[s < nseg ? s : nseg - 1];
   // wide tile when every segment starts at a multiple of 128 columns and the output is wide enough to fill the chip with
@@ -986,6 +991,63 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64>",
                      x1 ? k_lin_f16x3<false, 2, 2, 2, 1, true> : k_lin_f16x3<false, 2, 2, 2, 1, false>, dim3(grid), dim3(256), 0, st,
                      p);
+}
+
+// partial slabs of a split-K product summed in slab order (deterministic)
+static __global__ void __launch_bounds__(256) k_lin_splitk_reduce(const float4 *__restrict__ part, int64_t n4, int SK, float4 *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 t = part[i];
+  for (int s = 1; s < SK; ++s) {
+    const float4 u = part[(int64_t)s * n4 + i];
+    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+  }
+  out[i] = t;
+}
+
+extern "C" size_t gvl_linear_f16x3_splitk_workspace_bytes(int R, int N, int K) {
+  if (R <= 0 || N <= 0 || K <= 0) return 0;
+  const int tiles = ((R + kBM - 1) / kBM) * ((N + 127) / 128), stages = K / kBK;
+  int sk = max(1, min(512 / max(tiles, 1), stages / 8));
+  return sk <= 1 ? 0 : (size_t)sk * R * N * sizeof(float);
+}
+
+extern "C" int gvl_linear_f16x3_splitk_f32(const float *a, int64_t lda, const float *amax_a, int R, int K, const void *w_hi,
+                                           const void *w_lo, const float *w_scale, int N, float *out, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+  const char *what = "gvl_linear_f16x3_splitk_f32";
+  if (R <= 0 || N <= 0 || K <= 0 || (K % kBK) || (N % 128)) return fail(GVL_EINVAL, "%s: needs K %% 32 == 0 and N %% 128 == 0 (got R=%d N=%d K=%d)", what, R, N, K);
+  if (!a || !amax_a || !w_hi || !w_lo || !w_scale || !out) return fail(GVL_EINVAL, "%s: null pointer", what);
+  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15) || ((uintptr_t)out & 15))
+    return fail(GVL_EINVAL, "%s: a (lda >= K, lda %% 4 == 0), the weight planes and out must be 16-byte aligned", what);
+  const int tiles_m = (R + kBM - 1) / kBM, tiles_n = N / 128, stages = K / kBK;
+  int sk = max(1, min(512 / (tiles_m * tiles_n), stages / 8));
+  const int per = (stages + sk - 1) / sk;
+  sk = (stages + per - 1) / per;
+  const size_t need = sk <= 1 ? 0 : (size_t)sk * R * N * sizeof(float);
+  if (need > workspace_bytes || (need && (!workspace || ((uintptr_t)workspace & 15)))) return fail(GVL_ENOSPC, "%s: workspace of %zu bytes needed", what, need);
+  LinParams p;
+  p.A = a; p.lda = lda; p.A2 = nullptr; p.lda2 = 0; p.a2_rows = 1;
+  p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = nullptr;
+  p.R = R; p.N = N; p.K = K; p.nseg = 1;
+  gvl_lin_seg sg = {};
+  sg.n_begin = 0; sg.flags = 0; sg.out = sk > 1 ? reinterpret_cast<float *>(workspace) : out; sg.ldo = N; sg.amax_in = amax_a;
+  for (int s = 0; s < kMaxSeg; ++s) p.seg[s] = sg;
+  p.tiles_m = tiles_m; p.tiles_n = tiles_n; p.xcd_cols = 0;
+  p.split_stages = sk > 1 ? per : 0; p.split_stride = (int64_t)R * N;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (tiles_m * tiles_n + 7) / 8 * 8;
+  if (int rc = gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128,split-K>", k_lin_f16x3<false, 4, 2, 1, 2, false>, dim3(grid, sk),
+                           dim3(512), 0, st, p))
+    return rc;
+  if (sk > 1) {
+    const int64_t n4 = (int64_t)R * N / 4;
+    hipLaunchKernelGGL(k_lin_splitk_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(workspace), n4, sk, reinterpret_cast<float4 *>(out));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: reduce launch failed: %s", what, hipGetErrorString(e));
+  }
+  return 0;
 }
 
 extern "C" int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float *gamma, const float *beta, float eps,

@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256) k_planes_split(const gvl_plane_desc *__re
   int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
   e = min(max(e, 1), 253);
   const float s = __uint_as_float((uint32_t)e << 23), inv = __uint_as_float((uint32_t)(254 - e) << 23);
-  const bool live = tile < (d.N >> 5) * tiles_k;             // (wavefront-uniform; a matrix's tile count is padded to 4)
+  const bool live = tile < ((d.N + 31) >> 5) * tiles_k;      // (wavefront-uniform; a matrix's tile count is padded to 4)
   const int tn = live ? tile / tiles_k : 0, tk = live ? tile % tiles_k : 0;
   const int n0 = 32 * tn, k0 = 32 * tk, r8 = lane >> 3, c4 = lane & 7;
   typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -411,7 +411,9 @@ __global__ void __launch_bounds__(256) k_planes_split(const gvl_plane_desc *__re
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = r8 + 8 * j;
-    const float4 v = *reinterpret_cast<const float4 *>(d.w + (int64_t)(n0 + row) * d.K + k0 + 4 * c4);
+    const bool in = n0 + row < d.N;                           // (N % 32 != 0, the vocabulary layer: rows beyond N are zeros)
+    float4 v = *reinterpret_cast<const float4 *>(d.w + (int64_t)min(n0 + row, d.N - 1) * d.K + k0 + 4 * c4);
+    if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
     const float a[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
     _Float16 h[4], l[4];
 #pragma unroll
@@ -421,14 +423,14 @@ __global__ void __launch_bounds__(256) k_planes_split(const gvl_plane_desc *__re
     }
     const uint2 ph = make_uint2(__builtin_bit_cast(uint32_t, (h2v){h[0], h[1]}), __builtin_bit_cast(uint32_t, (h2v){h[2], h[3]}));
     const uint2 pl = make_uint2(__builtin_bit_cast(uint32_t, (h2v){l[0], l[1]}), __builtin_bit_cast(uint32_t, (h2v){l[2], l[3]}));
-    if (live) {
+    if (live && in) {
       *reinterpret_cast<uint2 *>(hi + run + row * 32 + 4 * c4) = ph;
       *reinterpret_cast<uint2 *>(lo + run + row * 32 + 4 * c4) = pl;
     }
     *reinterpret_cast<uint2 *>(th + row * 64 + c4 * 8) = ph;
     *reinterpret_cast<uint2 *>(tl + row * 64 + c4 * 8) = pl;
   }
-  if (live && tk == 0 && lane < 32) {
+  if (live && tk == 0 && lane < 32 && n0 + lane < d.N) {
     d.scale[d.n_off + n0 + lane] = s;
     if (d.bias_dst) d.bias_dst[d.n_off + n0 + lane] = d.bias ? d.bias[n0 + lane] : 0.f;
   }

@@ -104,40 +104,63 @@ class _VocabNLLFunction(torch.autograd.Function):
     def forward(ctx, x, weight, bias, target, row_weight):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         R, V = x2.shape[0], weight.shape[0]
-        # rows of the logits padded to a multiple of 4 columns (+ one spare row): the hand-written gradient products read whole
-        # 16-byte pieces of a row
-        ld = (V + 3) // 4 * 4
-        logits = torch.empty(R + 1, ld, device=x.device, dtype=torch.float32)[:R, :V]
+        # rows of the logits padded to a whole K stage of 32 columns: the hand-written gradient products read whole stages of a row
+        # (the padding is zeroed by gvl_ce_rows_backward_f32)
+        ld = (V + 31) // 32 * 32
+        logits = torch.empty(R, ld, device=x.device, dtype=torch.float32)[:, :V]
+        planes = _vocab_planes(weight, bias)
         if split_gemm_enabled() and x2.shape[1] % 32 == 0 and weight.is_contiguous():
-            MSDA.gemm_f16x3(MSDA.split_rows(x2), MSDA.split_rows(weight.detach()), bias.detach(), out=logits)
+            MSDA.gemm_f16x3(MSDA.split_rows(x2), planes[0] if planes is not None else MSDA.split_rows(weight.detach()),
+                            bias.detach(), out=logits)
         else:
             torch.addmm(bias.detach(), x2, weight.detach().t(), out=logits)
         out, lse = MSDA.ce_rows_forward(logits, target, row_weight)
         ctx.save_for_backward(x2, weight, logits, lse, target, row_weight)
-        ctx.x_shape = x.shape
+        ctx.x_shape, ctx.planes_t = x.shape, planes[1] if planes is not None else None
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
+        from . import layers as L
+        from .train_planes import Operand
         x2, weight, logits, lse, target, row_weight = ctx.saved_tensors
         if getattr(ctx, "consumed", False):                 # the logits buffer now holds their gradient
             raise RuntimeError("vocab_nll: backward runs once (the logits are overwritten by their gradient); "
                                "GVL_VOCAB_NLL=torch keeps the log-prob formulation for retain_graph use")
         ctx.consumed = True
-        own = _TRAIN_LINEAR and MSDA.wgrad_eligible(logits, x2) and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        own = _TRAIN_LINEAR and MSDA.wgrad_eligible(logits, x2)
         am_g = torch.empty(logits.shape[0], device=logits.device, dtype=torch.float32) if own else None
         g = MSDA.ce_rows_backward_(logits, target, row_weight, grad_out.contiguous(), lse, amax=am_g)     # (R, V), in place
-        gx = g.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
-        if own:
+        gx = None
+        if ctx.needs_input_grad[0]:
+            K = x2.shape[1]
+            if own and ctx.planes_t is not None and K % 128 == 0:
+                # dx = g W on the planes of W^T, the contraction over the 8518 vocabulary entries cut into K-stage ranges
+                # (gvl_linear_f16x3_splitk_f32): 72 output tiles alone would leave three quarters of the chip idle
+                g_pad = g.as_strided((g.shape[0], g.stride(0)), (g.stride(0), 1))        # the rows with their zeroed padding
+                gx = L.linear_splitk(g_pad, am_g, Operand(ctx.planes_t, K, g.stride(0), None)).view(ctx.x_shape)
+            else:
+                gx = g.mm(weight).view(ctx.x_shape)
+        if own and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             # dW = g^T x and db = sum_r g in ONE pass over g on the fp16 matrix cores (gvl_wgrad_f16x3_f32): 135 us against the
             # library's 241 us + the column sum's 17 us at (2208, 8518, 512)
-            from . import layers as L
             gw, gb = MSDA.wgrad(g, x2, am_g, L.row_absmax(x2)[0])
             return gx, gw, gb, None, None
         gw = g.t().mm(x2) if ctx.needs_input_grad[1] else None
         gb = MSDA.col_sum(g) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None
+
+
+def _vocab_planes(weight, bias):
+    """(planes of W, planes of W^T) of the vocabulary layer from the active TrainPlanes (refreshed for this forward), or None"""
+    tp = _ACTIVE_PLANES
+    if tp is None or not _TRAIN_LINEAR:
+        return None
+    hit = tp.lookup((weight,))
+    if hit is None or not tp.is_fresh():
+        return None
+    return hit[0], hit[1]
 
 
 def vocab_nll_eligible(x, weight, bias):

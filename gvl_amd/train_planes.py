@@ -33,9 +33,9 @@ class Operand:
         self.planes, self.N, self.K, self.bias = planes, N, K, bias
 
 
-def eligible_matrix(w):
+def eligible_matrix(w, any_rows=False):
     return (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
-            and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 and w.data_ptr() % 16 == 0)
+            and (any_rows or w.shape[0] % 32 == 0) and w.shape[1] % 32 == 0 and w.data_ptr() % 16 == 0)
 
 
 class TrainPlanes:
@@ -59,12 +59,13 @@ class TrainPlanes:
         key = self.key_of(weights)
         if key in self.by_key:
             return self.by_key[key]
-        if not all(eligible_matrix(w) for w in weights) or len({w.shape[1] for w in weights}) != 1:
-            raise ValueError("TrainPlanes.register: fp32 CUDA matrices (N_i, K) with N_i, K multiples of 32")
+        if not all(eligible_matrix(w, any_rows=(i == len(weights) - 1)) for i, w in enumerate(weights)) \
+                or len({w.shape[1] for w in weights}) != 1:
+            raise ValueError("TrainPlanes.register: fp32 CUDA matrices (N_i, K) with K and every N_i but the last multiples of 32")
         K = weights[0].shape[1]
         n_total = sum(w.shape[0] for w in weights)
         fwd = MSDA.SplitPlanes(n_total, K, self.device)
-        tr = MSDA.SplitPlanes(K, n_total, self.device)
+        tr = MSDA.SplitPlanes(K, (n_total + 31) // 32 * 32, self.device)       # (contraction padded with zeros to a K stage)
         bias = torch.zeros(n_total, device=self.device, dtype=torch.float32) if any(b is not None for b in biases) else None
         self.operands.append((key, weights, fwd, tr, biases, bias))
         self.by_key[key] = len(self.operands) - 1
@@ -97,7 +98,7 @@ class TrainPlanes:
                                    b.data_ptr() if b is not None else None, bias.data_ptr() if bias is not None else None))
                 for c in range((N * K + chunk - 1) // chunk):
                     chunk_map.append((di, c))
-                tiles = (N // 32) * (K // 32)
+                tiles = ((N + 31) // 32) * (K // 32)
                 for t in range(0, tiles, 4):
                     wg_map.append((di, t))
                 n_off += N
@@ -149,6 +150,11 @@ def build_train_planes(model, device):
             tp.register(ws, bs)
     for m in model.modules():
         if isinstance(m, Linear):
+            if m.weight.shape[0] % 32 and eligible_matrix(m.weight, any_rows=True) and TrainPlanes.key_of([m.weight]) not in seen:
+                # the vocabulary layer (8518 rows): its products are gvl_gemm_f16x3_f32 (forward) and the split-K input gradient
+                seen.add(TrainPlanes.key_of([m.weight]))
+                tp.register([m.weight], [m.bias])
+                continue
             add([m.weight], [m.bias])
         elif isinstance(m, MSDeformAttn):
             add([m.sampling_offsets.weight, m.attention_weights.weight], [m.sampling_offsets.bias, m.attention_weights.bias])

@@ -659,7 +659,9 @@ int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *amax_dy, in
 /* -- TRAINING: operand planes of all weights of the step in two launches.  The forward product of an nn.Linear needs the planes
  *    of W (N, K), its input gradient `grad_output.mm(weight)` (AddmmBackward) those of W^T; the weights change with every
  *    optimizer step (train.py:405-409), so both are rebuilt once per training forward -- for ALL matrices at once.
- *    Each descriptor (DEVICE array) names one fp32 matrix w (N, K), N % 32 == 0, K % 32 == 0, contiguous, and where its planes go:
+ *    Each descriptor (DEVICE array) names one fp32 matrix w (N, K), K % 32 == 0, contiguous (N % 32 == 0 unless it is the only or
+ *    the last block of its operand: the transposed planes then carry zeros for the contraction entries N .. round_up(N, 32)), and
+ *    where its planes go:
  *      hi / lo / scale      planes of the concatenated operand [.. ; W ; ..] of n_total rows: this matrix fills rows n_off ..
  *                           n_off + N (n_off % 32 == 0), K-stage-major as gvl_split_rows_f16 writes them; scale[n] per row
  *      t_hi / t_lo / t_scale  planes of the TRANSPOSED operand (K rows, contraction over the n_total rows); NULL = not wanted
@@ -698,6 +700,15 @@ int gvl_mha_train_forward_f32(const float *qkv, int64_t ld, const unsigned char 
 int gvl_mha_train_backward_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk, const float *amax_v,
                                int B, int Q, int H, float p, uint32_t seed, const int64_t *step, const float *out, const float *lse,
                                const float *dout, float *delta_ws, float *amax_dout_ws, float *dqkv, void *stream);
+
+/* -- the same product as gvl_linear_f16x3_f32 for FEW outputs and a LONG contraction, split over the K stages: the vocabulary layer's
+ *    input gradient `grad_logits.mm(logit.weight)` (AddmmBackward of pdvc/CaptioningHead/LSTM_DSA.py:121: 2208 x 512 outputs,
+ *    contraction 8518 -- 72 tiles would occupy a quarter of the chip for 267 serial K stages).  out (R, N) = a (R, K) . w^T with w
+ *    as planes of an (N, K) operand, N % 128 == 0, K % 32 == 0, amax_a (R) row bounds of a; no bias / epilogue.  workspace:
+ *    gvl_linear_f16x3_splitk_workspace_bytes(R, N, K) bytes (partial slabs, summed in a fixed order). */
+size_t gvl_linear_f16x3_splitk_workspace_bytes(int R, int N, int K);
+int gvl_linear_f16x3_splitk_f32(const float *a, int64_t lda, const float *amax_a, int R, int K, const void *w_hi, const void *w_lo,
+                                const float *w_scale, int N, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -148,3 +148,29 @@ def test_linear_module_routes_training_products_to_the_hand_written_kernels():
         assert not GL.train_linear_eligible(x, (lin.weight,), (lin.bias,))
     finally:
         GL.train_linear_enabled(True)
+
+
+def test_split_k_product_for_a_long_contraction_and_the_vocabulary_planes():
+    """gvl_linear_f16x3_splitk_f32 on the planes of W^T for W (8518, 512) -- N % 32 != 0: the transposed planes carry zeros for the
+    contraction entries 8518 .. 8543 -- against float64; the forward planes of the same registration reproduce W"""
+    torch.manual_seed(11)
+    R, V, K = 2208, 8518, 512
+    w = (torch.rand(V, K, device=DEV) - 0.5) * 0.2
+    ld = (V + 31) // 32 * 32
+    buf = torch.full((R, ld), float("nan"), device=DEV)
+    g = buf[:, :V]
+    g.copy_(torch.randn(R, V, device=DEV) * torch.exp(2 * torch.randn(R, 1, device=DEV)) * 1e-4)
+    g[5] = 0                                                   # a masked-out caption row: bound 0
+    buf[:, V:] = 0                                             # (what gvl_ce_rows_backward_f32 leaves in the padding)
+    tp = TrainPlanes(DEV)
+    tp.register([w], [None])
+    tp.refresh()
+    fwd, tr, _ = tp.lookup([w])
+    hi, lo = fwd.dense()
+    assert ((fwd.scale[:, None].double() * (hi.double() + lo.double() / 2048)) - w.double()).abs().max().item() <= 0.1 * 2.0 ** -21
+    from gvl_amd.train_planes import Operand
+    am = g.abs().amax(1)
+    out = L.linear_splitk(buf, am, Operand(tr, K, ld, None))
+    ref = g.double() @ w.double()
+    assert _err(out, ref) <= max(1.5 * _err(g @ w, ref), 5e-7)
+    assert torch.equal(out, L.linear_splitk(buf, am, Operand(tr, K, ld, None)))          # fixed summation order
