@@ -70,3 +70,20 @@ def maxerr(a, b):
     b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b)).double()
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def path_census(fn):
+    """run fn() with the library's per-dispatch stamps on (eager launches only) -> (fn's result, Counter of the kernel tags that
+    ran): lets a model-level test assert that the hand-written layers served the call, not a silent PyTorch formulation
+    """
+    import collections
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    MSDA.profile_enable(2)
+    try:
+        MSDA.profile_collect()
+        res = fn()
+        torch.cuda.synchronize()
+        tags = collections.Counter(e[0] for e in MSDA.profile_collect())
+    finally:
+        MSDA.profile_enable(0)
+    return res, tags

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load, pdvc_state, pdvc_dt, maxerr, t
+from helpers import load, path_census, pdvc_state, pdvc_dt, maxerr, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -142,7 +142,16 @@ def test_anet_full_dimension_train_step_at_the_headline_batch_matches_reference(
         dt.update(cap_tensor=t(g["cap_tensor"]).to(DEV), cap_mask=t(g["cap_mask"]).to(DEV),
                   gt_boxes_mask=torch.tensor([[k < n for k in range(mx)] for n in n_gt], dtype=torch.bool, device=DEV))
         dt["video_tensor"] = dt["video_tensor"] * scale
-        runs.append(train_grads(model, criterion, dt))
+        if scale == 1.0:
+            res, ran = path_census(lambda: train_grads(model, criterion, dt))
+            runs.append(res)
+            # what served the step: every Linear of the 2 + 2 layers forward and input gradient on
+            # gvl_linear_f16x3_f32, its weight + bias gradient on gvl_wgrad_f16x3_f32, both decoder self-attentions on the
+            # attention-core kernels (forward, dk / dv, dq each), four deformable-attention launches each way
+            assert ran["layer_gemm"] >= 2 * 24 and ran["wgrad_f16x3"] >= 24 and ran["mha_train"] == 6, ran
+            assert ran["fwd_t1d_d64"] == 4 and ran["bwd_t1d_d64"] == 4 and ran["layer_norm_etc"] >= 3 * 10, ran
+        else:
+            runs.append(train_grads(model, criterion, dt))
     out, loss, final, grads = runs[0]
     for k in [k for k in g if k.startswith("loss.")]:
         want = float(g[k])
