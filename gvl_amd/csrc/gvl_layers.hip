@@ -95,11 +95,12 @@ __device__ __forceinline__ void split4(const float4 &x, float inv, uint2 &hi, ui
 // X1: the leading fp16 product only (gvl_f16_products(1): inference under autocast) -- no lo planes are formed, fetched or read.
 template <bool HAS_A2, int WM, int WN, int NI, int NJ, bool X1 = false>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f16x3(const LinParams p) {
-  constexpr int kThreads = 64 * WM * WN, kNW = WM * WN, kBN = 32 * NJ * WN;
-  static_assert(32 * NI * WM == kBM, "128 rows per tile");
-  static_assert(kThreads == 4 * kBN, "one 16-byte weight chunk per plane and thread");
-  constexpr int kASlots = kBM * 4, kBSlots = kBN * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
-  constexpr int NA = 1024 / kThreads;                                  // A loads (16 bytes) per thread and stage
+  constexpr int kThreads = 64 * WM * WN, kBN = 32 * NJ * WN, TBM = 32 * NI * WM;   // tile = TBM rows x kBN columns
+  static_assert((TBM * 8) % kThreads == 0, "whole 16-byte A pieces per thread");
+  constexpr int WCH = (4 * kBN + kThreads - 1) / kThreads;             // 16-byte weight chunks per plane and thread (the last
+                                                                       // round is partial when 4 kBN % kThreads != 0: 96 x 128)
+  constexpr int kASlots = TBM * 4, kBSlots = kBN * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  constexpr int NA = TBM * 8 / kThreads;                               // A loads (16 bytes) per thread and stage
   __shared__ uint4 smem[2 * kStageSlots];
 
   int tm, tn;
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
   } else if (!tile_of((int)blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) {
     return;
   }
-  const int m0 = tm * kBM, n0 = tn * kBN;
+  const int m0 = tm * TBM, n0 = tn * kBN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave % WM) * (32 * NI), wn = (wave / WM) * (32 * NJ);
   const int R = p.R, N = p.N, K = p.K;
@@ -167,12 +168,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
     a_dst[i] = (uint32_t)lds_slot(row, apiece >> 1) * 16u + (uint32_t)(apiece & 1) * 8u;     // byte offset inside a plane image
   }
 
-  // ---- W path: thread t carries chunk t & 3 of weight row t >> 2 of the tile, both planes (same swizzled image)
-  const int wrow = tid >> 2, wch = tid & 3;
-  const int w_off = (min(wrow, N - 1 - n0) * 32 + wch * 8) * 2;
-  const int w_dst = 2 * kASlots + lds_slot(wrow, wch);
+  // ---- W path: chunk id (= thread + round x threads) is piece id & 3 of weight row id >> 2 of the tile, both planes (same
+  // swizzled image); ids beyond the tile's 4 kBN chunks (a partial last round) load a valid address and store nothing
+  int w_off[WCH], w_dst[WCH];
+#pragma unroll
+  for (int c = 0; c < WCH; ++c) {
+    const int id = tid + c * kThreads, wrow = (id >> 2) % kBN, wch = id & 3;
+    w_off[c] = (min(wrow, N - 1 - n0) * 32 + wch * 8) * 2;
+    w_dst[c] = id < 4 * kBN ? 2 * kASlots + lds_slot(wrow, wch) : -1;
+  }
 
-  struct ASet { u4v x[NA], y[NA], wh, wl; };
+  struct ASet { u4v x[NA], y[NA], wh[WCH], wl[WCH]; };
   auto load_a = [&](ASet &s, int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) s.x[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_off[i], k0 * 4, 0);
@@ -180,8 +186,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
 #pragma unroll
       for (int i = 0; i < NA; ++i) s.y[i] = __builtin_amdgcn_raw_buffer_load_b128(a2_rs, a2_off[i], k0 * 4, 0);
     }
-    s.wh = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_off, k0 * N * 2, 0);
-    if constexpr (!X1) s.wl = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off, k0 * N * 2, 0);
+#pragma unroll
+    for (int c = 0; c < WCH; ++c) {
+      s.wh[c] = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, w_off[c], k0 * N * 2, 0);
+      if constexpr (!X1) s.wl[c] = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, w_off[c], k0 * N * 2, 0);
+    }
   };
   auto store_a = [&](ASet &s, int buf) {
     char *st = reinterpret_cast<char *>(smem + buf * kStageSlots);
@@ -202,8 +211,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
       }
       *reinterpret_cast<uint2 *>(st + a_dst[i]) = hi;
     }
-    reinterpret_cast<uint4 *>(st)[w_dst] = __builtin_bit_cast(uint4, s.wh);
-    if constexpr (!X1) reinterpret_cast<uint4 *>(st)[kBSlots + w_dst] = __builtin_bit_cast(uint4, s.wl);
+#pragma unroll
+    for (int c = 0; c < WCH; ++c)
+      if ((4 * kBN) % kThreads == 0 || w_dst[c] >= 0) {
+        reinterpret_cast<uint4 *>(st)[w_dst[c]] = __builtin_bit_cast(uint4, s.wh[c]);
+        if constexpr (!X1) reinterpret_cast<uint4 *>(st)[kBSlots + w_dst[c]] = __builtin_bit_cast(uint4, s.wl[c]);
+      }
   };
 
   f16acc acc_m[NI][NJ], acc_x[NI][NJ];
@@ -961,36 +974,45 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
   p.split_stages = 0; p.split_stride = 0;
   p.nseg = nseg;
   for (int s = 0; s < kMaxSeg; ++s) p.seg[s] = segs[s < nseg ? s : nseg - 1];
-  // wide tile when every segment starts at a multiple of 128 columns and the output is wide enough to fill the chip with
-  // 128 x 128 tiles (GVL_LIN_TILE=64 keeps the narrow tile for A/B runs)
-  bool wide = N % 128 == 0 && N >= 256 && !(flags & GVL_LIN_XCD_COLUMNS);      // (XCD placement is per 64-column head)
+  // Tile shape.  128-column tiles when every segment starts at a multiple of 128 columns; their ROW count is the largest of
+  // 128 / 96 / 64 that still gives (nearly) every CU a tile: these products are bound by what ONE CU can pull through its
+  // memory path and push out through its store path (tools/ubench: ~70 GB/s in, ~20 GB/s out per CU), so a grid that covers
+  // 152 of the 256 CUs (4800 x 512 at 128 rows) leaves 40 % of the chip's bandwidth unused; 96 rows -> 200 tiles, 3008 x 512 at
+  // 64 rows -> 188 instead of 96.  Narrow outputs and segment boundaries at odd multiples of 64 keep the 128 x 64 tile.
+  bool wide = N % 128 == 0 && N >= 128 && !(flags & GVL_LIN_XCD_COLUMNS);      // (XCD placement is per 64-column head)
   for (int s = 0; s < nseg; ++s) wide = wide && segs[s].n_begin % 128 == 0;
-  // ... and only when the wide tiles still cover at least half of the CUs (3008 x 512: 96 wide tiles take 19 / 49 us at
-  // K = 512 / 2048, 192 narrow ones 17 / 42 us; 4800 x 512: 152 wide 20 / 50 us against 304 narrow 24 / 67 us)
-  wide = wide && ((R + kBM - 1) / kBM) * (N / 128) >= 128;
-  if (const char *e = getenv("GVL_LIN_TILE")) wide = wide && atoi(e) != 64;
+  int bm = kBM;
+  if (wide) {
+    const int tn = N / 128;
+    int best = ((R + 127) / 128) * tn;
+    if (best < 256)
+      for (int cand : {96, 64}) {
+        const int t_ = ((R + cand - 1) / cand) * tn;
+        if (t_ <= 256 && t_ > best) { best = t_; bm = cand; }
+      }
+  }
+  if (const char *e = getenv("GVL_LIN_TILE")) { if (atoi(e) == 64) wide = false; }
   const int bn = wide ? 128 : kLinBN;
-  p.tiles_m = (R + kBM - 1) / kBM; p.tiles_n = N / bn;
+  p.tiles_m = (R + bm - 1) / bm; p.tiles_n = N / bn;
   p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n >= 8;
   const int grid = (p.tiles_m * p.tiles_n + 7) / 8 * 8;
   hipStream_t st = (hipStream_t)stream;
   const bool x1 = gvl16::g_f16_products == 1;
-  if (wide) {
-    if (any_addend)
-      return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128,addend>",
-                         x1 ? k_lin_f16x3<true, 4, 2, 1, 2, true> : k_lin_f16x3<true, 4, 2, 1, 2, false>, dim3(grid), dim3(512),
-                         0, st, p);
-    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<128>",
-                       x1 ? k_lin_f16x3<false, 4, 2, 1, 2, true> : k_lin_f16x3<false, 4, 2, 1, 2, false>, dim3(grid), dim3(512), 0,
-                       st, p);
+#define GVL_LIN_LAUNCH(WM, WN, NI, NJ, NAME)                                                                              \
+  {                                                                                                                        \
+    if (any_addend)                                                                                                        \
+      return gvl::launch(GVL_PROF_LINEAR, R, N, NAME ",addend", x1 ? k_lin_f16x3<true, WM, WN, NI, NJ, true>                \
+                                                                  : k_lin_f16x3<true, WM, WN, NI, NJ, false>,               \
+                         dim3(grid), dim3(64 * WM * WN), 0, st, p);                                                       \
+    return gvl::launch(GVL_PROF_LINEAR, R, N, NAME, x1 ? k_lin_f16x3<false, WM, WN, NI, NJ, true>                           \
+                                                       : k_lin_f16x3<false, WM, WN, NI, NJ, false>,                         \
+                       dim3(grid), dim3(64 * WM * WN), 0, st, p);                                                         \
   }
-  if (any_addend)
-    return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64,addend>",
-                       x1 ? k_lin_f16x3<true, 2, 2, 2, 1, true> : k_lin_f16x3<true, 2, 2, 2, 1, false>, dim3(grid), dim3(256), 0,
-                       st, p);
-  return gvl::launch(GVL_PROF_LINEAR, R, N, "k_lin_f16x3<64>",
-                     x1 ? k_lin_f16x3<false, 2, 2, 2, 1, true> : k_lin_f16x3<false, 2, 2, 2, 1, false>, dim3(grid), dim3(256), 0, st,
-                     p);
+  if (wide && bm == 128) GVL_LIN_LAUNCH(4, 2, 1, 2, "k_lin_f16x3<128x128>")
+  if (wide && bm == 96) GVL_LIN_LAUNCH(3, 2, 1, 2, "k_lin_f16x3<96x128>")
+  if (wide) GVL_LIN_LAUNCH(2, 2, 1, 2, "k_lin_f16x3<64x128>")
+  GVL_LIN_LAUNCH(2, 2, 2, 1, "k_lin_f16x3<128x64>")
+#undef GVL_LIN_LAUNCH
 }
 
 // partial slabs of a split-K product summed in slab order (deterministic)

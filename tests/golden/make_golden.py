@@ -931,6 +931,72 @@ def make_train():
     save("pdvc_train", **rec)
 
 
+def make_switches():
+    """The reference's configuration switches on the path that no other fixture exercises: the eval forward
+    with eval_disable_captioning, with_box_refine = 0, share_caption_head = 0, and a TRAINING forward / backward with
+    caption_loss_coef = 0 (pdvc.py:262-275 then routes training through parallel_prediction_full).  Small dimensions, CUDA-op
+    semantics, the loaded state dict is what load_state_dict leaves (tied parameters: the later key wins)."""
+    global PDVC_OVERRIDES
+    B, T = 2, 24
+    cases = {"nocap": dict(eval_disable_captioning=True), "norefine": dict(with_box_refine=0), "unshared": dict(share_caption_head=0),
+             "nocaploss": dict(caption_loss_coef=0, transformer_dropout_prob=0.0, drop_prob=0.0)}
+    for name, over in cases.items():
+        saved = dict(PDVC_OVERRIDES)
+        PDVC_OVERRIDES.update(over)
+        try:
+            opt, model, criterion, cc = build_pdvc()
+        finally:
+            PDVC_OVERRIDES = saved
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(shapes, seed=310).items()}, strict=True)
+        loaded = model.state_dict()                                   # (tied parameters share their storage)
+        dt = synth_dt(B, T, opt.feature_dim, valid=[24, 17], n_gt=[3, 2])
+        rec = dict(meta_T=np.array(T), valid=np.array([24, 17]), n_gt=np.array([3, 2]), param_names=np.array(sorted(shapes)),
+                   param_shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+        # which names ended up tied to which (the test rebuilds the loaded state from the synthetic one)
+        ties = []
+        names = sorted(shapes)
+        for i, a in enumerate(names):
+            for b in names[i + 1:]:
+                if loaded[a].data_ptr() == loaded[b].data_ptr() and a != b:
+                    ties.append(f"{a}={b}")
+        rec["ties"] = np.array(ties if ties else ["-"])
+        with cuda_semantics():
+            if name == "nocaploss":
+                model.train()
+                g = torch.Generator().manual_seed(11)
+                caps = torch.randint(1, opt.vocab_size, (5, 7), generator=g)
+                caps[:, 0] = 0
+                caps[:, -1] = 0
+                cap_mask = (torch.arange(7)[None] <= (caps != 0).sum(1)[:, None]).float()
+                dt.update(cap_tensor=caps, cap_mask=cap_mask, gt_boxes_mask=torch.tensor([[1, 1, 1], [1, 1, 0]]).bool(),
+                          gt_gather_idx=torch.tensor([0, 0, 0, 1, 1]))
+                out, loss = model(dt, criterion, cc, "queries")
+                wd = criterion.weight_dict
+                final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+                final.backward()
+                gn = sorted(n for n, p_ in model.named_parameters() if p_.grad is not None)
+                params = dict(model.named_parameters())
+                rec.update(cap_tensor=caps, cap_mask=cap_mask, final_loss=final.detach(), grad_names=np.array(gn),
+                           grad_norms=torch.stack([params[n].grad.double().norm() for n in gn]))
+            else:
+                with torch.no_grad():
+                    out, loss = model(dt, criterion, cc, "queries", eval_mode=True)
+        rec.update(pred_logits=out["pred_logits"].detach(), pred_boxes=out["pred_boxes"].detach(), pred_count=out["pred_count"].detach())
+        if "aux_outputs" in out and out["aux_outputs"]:
+            rec.update(aux_pred_logits=out["aux_outputs"][0]["pred_logits"].detach(), aux_pred_boxes=out["aux_outputs"][0]["pred_boxes"].detach())
+        if "seq" in out and isinstance(out["seq"], torch.Tensor):
+            rec.update(seq=out["seq"], cap_prob_eval=out["caption_probs"]["cap_prob_eval"].detach())
+            rec["has_seq"] = np.array(1)
+        else:
+            rec["has_seq"] = np.array(0)
+        for i, (a, b) in enumerate(out["matched_indices"][0]):
+            rec[f"match_{i}"] = torch.stack([a, b])
+        for k, v in loss.items():
+            rec[f"loss.{k}"] = torch.as_tensor(v).detach()
+        save("pdvc_switch_" + name, **rec)
+
+
 def make_init():
     """Seeded initialisation of the reference modules (MSDeformAttn._reset_parameters ms_deform_attn.py:62-77, the
     captioner variant :72, DeformableTransformer._reset_parameters deformable_transformer.py:54-63, PDVC.__init__
@@ -982,7 +1048,7 @@ if __name__ == "__main__":
     for flag, fn in (("--only-dataset", make_dataset), ("--only-anet-c3d", make_anet_c3d), ("--only-f64", make_f64),
                      ("--only-anet-full-train", make_anet_full_train), ("--only-anet-full-b16", make_anet_full_b16),
                      ("--only-anet-full-train-b16", make_anet_full_train_b16), ("--only-yc2-train", make_yc2_train),
-                     ("--only-full-train-probe", make_full_train_probe)):
+                     ("--only-full-train-probe", make_full_train_probe), ("--only-switches", make_switches)):
         if flag in sys.argv:
             fn()
             sys.exit(0)
@@ -1003,5 +1069,6 @@ if __name__ == "__main__":
         make_anet_full_train_b16()
         make_yc2_train()
         make_full_train_probe()
+        make_switches()
     make_dataset()
     make_init()
