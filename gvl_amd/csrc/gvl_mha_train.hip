@@ -163,6 +163,7 @@ struct MhaParams {
   const int64_t *step;            // device step counter (gvl_advance_step) or NULL
   float *out;                     // (B Q, H 64)
   float *lse;                     // (B, H, Q)
+  float *amax_out;                // (B Q) zero-initialised: max |out row| over the heads (atomic max), or NULL
   // backward
   const float *dout, *amax_dout;  // (B Q, H 64), (B Q)
   const float *delta;             // (B, H, Q): dO . out per row
@@ -287,6 +288,16 @@ __global__ void __launch_bounds__(kThreads) k_mha_fwd(const MhaParams p) {
         *reinterpret_cast<float4 *>(op + 32 * t + 8 * g + 4 * half) =
             make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
     if (half == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Q + q] = (m + log2f(l)) * 0.69314718055994531f;
+  }
+  if (p.amax_out) {
+    // max |out| of this query's 64 channels (two lanes hold 32 each): the row scale out_proj's split needs (inference path)
+    float mx = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(o[t][r] * inv));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (half == 0 && q < p.Q) atomicMax(reinterpret_cast<unsigned *>(p.amax_out) + (int64_t)b * p.Q + q, __float_as_uint(mx));
   }
 }
 
@@ -530,13 +541,13 @@ int check(const char *what, const float *qkv, int64_t ld, int B, int Q, int H, f
 
 extern "C" int gvl_mha_train_forward_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk,
                                          const float *amax_v, int B, int Q, int H, float p, uint32_t seed, const int64_t *step,
-                                         float *out, float *lse, void *stream) {
+                                         float *out, float *lse, float *amax_out, void *stream) {
   const char *what = "gvl_mha_train_forward_f32";
   if (int rc = check(what, qkv, ld, B, Q, H, p)) return rc;
-  if (!qkv || !amax_qk || !amax_v || !out || !lse || ((uintptr_t)out & 15)) return fail(GVL_EINVAL, "%s: null / unaligned pointer", what);
+  if (!qkv || !amax_qk || !amax_v || !out || ((uintptr_t)out & 15)) return fail(GVL_EINVAL, "%s: null / unaligned pointer", what);
   MhaParams a = {};
   a.qkv = qkv; a.ld = ld; a.keep = key_keep; a.amax_qk = amax_qk; a.amax_v = amax_v; a.B = B; a.Q = Q; a.H = H; a.p = p; a.seed = seed;
-  a.step = step; a.out = out; a.lse = lse;
+  a.step = step; a.out = out; a.lse = lse; a.amax_out = amax_out;
   const int nqb = (Q + 32 * kWaves - 1) / (32 * kWaves);
   return gvl::launch(GVL_PROF_MHA_TRAIN, B, Q, "k_mha_fwd", k_mha_fwd, dim3(B * H * nqb), dim3(kThreads), 0, (hipStream_t)stream, a);
 }

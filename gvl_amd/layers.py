@@ -415,10 +415,22 @@ def _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_mask, arena):
     H = sa.num_heads
     w = cached(sa, "in", [(sa.in_proj_weight, sa.in_proj_bias)])
     qkv = _new(R, 3 * C, x)
-    linear(x, w, [seg(0, qkv[:, :2 * C], am_xp, addend=qpos is not None), seg(2 * C, qkv[:, 2 * C:], am_x)], a2=qpos)
-    if C == 64 * H and Q <= 320 and os.environ.get("GVL_MHA", "") != "torch":
+    own = C == 64 * H and B * H * Q * Q < 2 ** 32 and os.environ.get("GVL_MHA", "") != "torch"
+    am_qk, am_v = (arena.take(R), arena.take(R)) if own else (None, None)
+    linear(x, w, [seg(0, qkv[:, :2 * C], am_xp, addend=qpos is not None, amax_out=am_qk),
+                  seg(2 * C, qkv[:, 2 * C:], am_x, amax_out=am_v)], a2=qpos)
+    if own:
+        # the attention core: the forward kernel of gvl_mha_train.hip at p = 0 (split-fp16 products, scores in registers; it
+        # replaced the exact-fp32 MFMA kernel gvl_mha_core_f32 here: 35 against 55 us per layer at B = 16, Q = 300)
         am_a = arena.take(R)
-        return mha_core(qkv, B, Q, H, query_mask, am_a), am_a
+        a = _new(R, C, x)
+        keep = query_mask.contiguous().view(torch.uint8) if query_mask is not None else None
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().gvl_mha_train_forward_f32(qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if keep is not None else None,
+                                                      am_qk.data_ptr(), am_v.data_ptr(), B, Q, H, 0.0, 0, None, a.data_ptr(), None,
+                                                      am_a.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mha_forward")
+        return a, am_a
     t = qkv.view(B, Q, 3, H, C // H).permute(2, 0, 3, 1, 4)                      # (3, B, H, Q, D)
     mask = query_mask[:, None, None, :] if query_mask is not None else None       # True = attend (key_padding_mask = ~)
     o = torch.nn.functional.scaled_dot_product_attention(t[0], t[1], t[2], attn_mask=mask)
@@ -445,7 +457,7 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
         am_mem, _ = row_absmax(mem)
     mask = src_padding_mask.reshape(Rs).contiguous().view(torch.uint8) if src_padding_mask is not None else None
     nl = len(dec.layers)
-    arena = _Arena((5 * nl + 2) * (R + 4), tgt.device)
+    arena = _Arena((7 * nl + 2) * (R + 4), tgt.device)          # (+ the row maxima of the q | k and v columns per layer)
     # value_proj(memory) of every layer: one product against the concatenated weights
     wv = cached(dec, "values", [(l_.cross_attn.value_proj.weight, l_.cross_attn.value_proj.bias) for l_ in dec.layers])
     values = [_new(Rs, C, mem) for _ in dec.layers]

@@ -96,7 +96,7 @@ class _Core(torch.autograd.Function):
             rc = _lib.lib().gvl_mha_train_forward_f32(
                 qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if keep is not None else None, am[0].data_ptr(), am[1].data_ptr(),
                 B, Q, H, float(p), int(seed), used.data_ptr() if used is not None else None, out.data_ptr(), lse.data_ptr(),
-                torch.cuda.current_stream().cuda_stream)
+                None, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mha_train_forward")
         ctx.save_for_backward(qkv, am, keep if keep is not None else qkv.new_empty(0), out, lse,
                               used if used is not None else qkv.new_empty(0))
