@@ -931,6 +931,311 @@ __global__ void __launch_bounds__(512, 1)
 #undef GVL_QUARTER
 }
 
+// ---- the vocabulary product on 256 x 320 tiles, ONE accumulator per output (round 5).
+// Why: the 128 x 256 tiles of k_gemm_f16x3_m16 keep the CU's LDS pipe 89 % occupied (83 B/clk of fragment reads + 31 B/clk of
+// DMA writes against 128 B/clk) and ask the vector-memory path for 48 KB per 1536 MFMA cycles, close to the ~ 39 B/clk a CU
+// sustains (the kernel ran 74 instead of 104 us without the fragment reads).  Both shrink with the tile:
+//   workgroup tile   256 vocabulary rows (A) x 320 hidden rows (B): 34 x 15 = 510 tiles at (8518, 4800) = 1.99 rounds of 256 CUs;
+//                    a K stage is 72 KB, TWO stage buffers (the three-stage ring of the smaller tile does not fit)
+//   wavefront tile   64 (A) x 160 (B) = 4 x 10 tiles of v_mfma_f32_16x16x32_f16: 28 ds_read_b128 per 120 MFMAs (m16: 16 per 48),
+//                    i.e. 58 B/clk of reads + 19 B/clk of DMA writes per CU
+//   one accumulator  with hi' = 2^11 hi the product 2^22 a b = hi'a hi'b + hi'a lo_b + lo_a hi'b: the three MFMAs add into the same
+//                    fp32 accumulator (the cross terms are 2^11 smaller and lose what an fp32 running sum loses anyway); the
+//                    fragments arrive in the planes' (hi, 2^11 lo) format and hi is scaled after the read (four v_pk_mul_f16 per
+//                    fragment) -- 160 accumulator registers, where two accumulators per output would need 320
+//   schedule         the B fragments rotate through four register sets, requested two blocks (24 MFMAs) ahead; the stage's ONE
+//                    barrier sits before its last two B blocks, when every read of the stage's buffer has been issued: after it the
+//                    DMA of the stage after next goes into that buffer, and the next stage's first fragments (A in place, block
+//                    by block as the last MFMAs release them) come from the other buffer -- whose DMA was issued a stage ago.
+template <int NJ>
+__device__ __forceinline__ void epilogue_v(f4acc4 (&acc)[4][NJ], int row0, int col0, int lane, const float *__restrict__ As,
+                                           const float *__restrict__ Bs, const float *__restrict__ bias, int R, int N,
+                                           float *__restrict__ out) {
+  const int fc = lane & 15, fq = lane >> 4;
+  const float *bias_p = bias ? bias : As;
+  const float bias_on = bias ? 1.f : 0.f;
+  const int bias_ix = bias ? 0x7fffffff : 0;
+  constexpr float kLog2e = 1.4426950408889634f, kInv22 = 1.f / 4194304.f;
+  const bool full = row0 + 64 <= R;
+  float rs[4][4], rb[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(row0 + 16 * i + 4 * fq + r, R - 1);
+      rs[i][r] = As[row] * kInv22;
+      rb[i][r] = bias_on * bias_p[min(row, bias_ix)];
+    }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = col0 + 16 * j + fc;
+    const float cs = Bs[min(col, N - 1)];
+    float best = -INFINITY, sum = 0.f;
+    int arg = 0x7fffffff;
+    float v[4][4];
+#ifdef GVL_V_NO_EPI                                                    /* timing-only build: every accumulator stays live, 16 adds */
+    best = cs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) best += acc[i][j][r];
+    sum = rs[0][0] + rb[1][1];
+    arg = row0;
+    (void)v; (void)full; (void)kLog2e;
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[i][r] = __builtin_fmaf(acc[i][j][r], rs[i][r] * cs, rb[i][r]);
+        if (!full && row0 + 16 * i + 4 * fq + r >= R) v[i][r] = -INFINITY;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) best = fmaxf(best, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+    best = fmaxf(best, __shfl_xor(best, 16));
+    best = fmaxf(best, __shfl_xor(best, 32));
+    if (best > -INFINITY) {
+      const float nb = -best * kLog2e;
+#pragma unroll
+      for (int i = 3; i >= 0; --i)
+#pragma unroll
+        for (int r = 3; r >= 0; --r) {                                  // descending: the FIRST maximum's row is what remains
+          sum += __builtin_amdgcn_exp2f(__builtin_fmaf(v[i][r], kLog2e, nb));
+          arg = v[i][r] == best ? row0 + 16 * i + 4 * fq + r : arg;
+        }
+    }
+#endif
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      sum += __shfl_xor(sum, o);
+      arg = min(arg, __shfl_xor(arg, o));
+    }
+    if (fq == 0 && col < N)
+      reinterpret_cast<float4 *>(out)[(int64_t)(row0 >> 6) * N + col] = make_float4(best, sum, __int_as_float(arg), 0.f);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ void __launch_bounds__(512, 1)
+    k_vocab_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
+                  const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
+                  const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int tiles_m, int tiles_n,
+                  int chunks) {
+  constexpr int kRowsA = 256, kRowsB = 320, NJ = 10;
+  constexpr int kASlots = kRowsA * 4, kBSlots = kRowsB * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  __shared__ uint4 smem[2 * kStageSlots];
+
+  int vb = (int)blockIdx.x, tm, tn;
+  if (!tile_of(vb, tiles_m, tiles_n, tm, tn)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = (wave & 3) * 64, wb = (wave >> 2) * 160;
+
+  // DMA units of 16 rows x 64 bytes (one buffer_load_dwordx4 ... lds): unit i of wavefront w is
+  //   i = 0, 1: A hi block w + 8 i        i = 2, 3: A lo block w + 8 (i - 2)       i = 4, 5: B hi block w + 8 (i - 4)
+  //   i = 6:    B hi block 16 + w (w < 4) | B lo block 12 + w (w >= 4)             i = 7, 8: B lo block w + 8 (i - 7)
+  // The lane's part of the address (row inside the unit, swizzled 16-byte chunk) is ONE register; everything else is scalar, and
+  // the planes are read through buffer descriptors: rows past the end of a plane (ragged last tiles) come back as zeros.
+  const int srow = lane >> 2, schunk = ((lane & 3) ^ (((srow >> 2) & 1) << 1)) * 8;
+  const uint32_t lane_off = 2u * (uint32_t)(srow * 32 + schunk);
+  const __amdgpu_buffer_rsrc_t rs_ah = __builtin_amdgcn_make_buffer_rsrc((void *)Ah, 0, R * K * 2, 0x00020000),
+                               rs_al = __builtin_amdgcn_make_buffer_rsrc((void *)Al, 0, R * K * 2, 0x00020000),
+                               rs_bh = __builtin_amdgcn_make_buffer_rsrc((void *)Bh, 0, N * K * 2, 0x00020000),
+                               rs_bl = __builtin_amdgcn_make_buffer_rsrc((void *)Bl, 0, N * K * 2, 0x00020000);
+  int tm2, tn2;
+  bool has_next = tile_of(vb + (int)gridDim.x, tiles_m, tiles_n, tm2, tn2);
+  if (!has_next) { tm2 = tm; tn2 = tn; }
+#ifdef GVL_V_SAME_SRC                                                   /* timing-only: every unit re-fetches the plane's first KiB */
+#define GVL_V_SRC(X) (lane_off + 0u * (X))
+#else
+#define GVL_V_SRC(X) (X)
+#endif
+  // unit I of the K stage at k0 of tile (tm_, tn_) -> stage buffer st
+#define GVL_V_DMA(I, TM, TN, K0, ST)                                                                                 \
+  {                                                                                                                  \
+    constexpr bool isA = (I) < 4;                                                                                    \
+    const bool lo = (I) == 6 ? wave >= 4 : ((I) == 2 || (I) == 3 || (I) >= 7);                                       \
+    const int blk = (I) == 6 ? (wave >= 4 ? 12 + wave : 16 + wave) : wave + (((I) == 1 || (I) == 3 || (I) == 5 || (I) == 8) ? 8 : 0);  \
+    const int rows = isA ? R : N, row0 = isA ? (TM) * kRowsA : (TN) * kRowsB;                                        \
+    const uint32_t soff = 2u * (uint32_t)((K0) * rows + (row0 + blk * 16) * 32);                                     \
+    const int dst = (isA ? (lo ? kASlots : 0) : 2 * kASlots + (lo ? kBSlots : 0)) + blk * 64;                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? (lo ? rs_al : rs_ah) : (lo ? rs_bl : rs_bh),                      \
+                                             (__attribute__((address_space(3))) void *)((ST) + dst), 16,             \
+                                             GVL_V_SRC(lane_off + soff), 0, 0, 0);                                   \
+  }
+
+  f4acc4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f4acc4{0.f, 0.f, 0.f, 0.f};
+
+  const int fa = lds_slot16(wa + (lane & 15), lane >> 4), fb = 2 * kASlots + lds_slot16(wb + (lane & 15), lane >> 4);
+  h8 ah[4], al[4], bh[4], bl[4];
+  const _Float16 k2048 = (_Float16)2048.f;
+  // (timing-only builds, tools/vocab_ablate.sh: GVL_V_NO_DMA / GVL_V_NO_BARRIER / GVL_V_NO_EPI drop the operand DMA / the stage
+  //  barrier / the epilogue's arithmetic)
+#define GVL_V_RDA(ST, I)                                                                                             \
+  {                                                                                                                  \
+    ah[I] = *reinterpret_cast<const h8 *>(&(ST)[fa + 64 * (I)]);                                                     \
+    al[I] = *reinterpret_cast<const h8 *>(&(ST)[kASlots + fa + 64 * (I)]);                                           \
+  }
+#define GVL_V_RDB(ST, J, S)                                                                                          \
+  {                                                                                                                  \
+    bh[S] = *reinterpret_cast<const h8 *>(&(ST)[fb + 64 * (J)]);                                                     \
+    bl[S] = *reinterpret_cast<const h8 *>(&(ST)[kBSlots + fb + 64 * (J)]);                                           \
+  }
+#ifdef GVL_V_NO_VMWAIT
+#define GVL_V_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define GVL_V_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
+#ifdef GVL_V_NO_BARRIER
+#define GVL_V_BARRIER()
+#else
+#define GVL_V_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+  // the units of a stage's DMA are issued over seven B blocks: units 0-3 under blocks 8, 9 of the stage BEFORE the one that runs
+  // while they land (AHEAD = 2: into the buffer the barrier has just freed), units 4-8 under blocks 0-2 of that stage (AHEAD = 1)
+#if defined(GVL_V_NO_DMA) || defined(GVL_V_DMA_ONCE)                    /* ONCE: both buffers filled before the loop, then none */
+#define GVL_V_ISSUE(P, I, AHEAD, ST)
+#else
+#define GVL_V_ISSUE(P, I, AHEAD, ST)                                                                                 \
+  {                                                                                                                  \
+    const int kn = kt + (P) + (AHEAD);                                                                               \
+    const bool over = kn >= KT;                                                                                      \
+    GVL_V_DMA(I, over ? tm2 : tm, over ? tn2 : tn, (over ? kn - KT : kn) * kBK, ST)                                  \
+  }
+#endif
+#define GVL_V_MFMA3(I, J, BS, S)                                                                                     \
+  {                                                                                                                  \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], BS, acc[I][J], 0, 0, 0);                               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], bl[S], acc[I][J], 0, 0, 0);                            \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[I], BS, acc[I][J], 0, 0, 0);                               \
+  }
+  // B block J of stage parity P: its fragments sit in register set (2 P + J) & 3; the block two further is requested first.
+  // HALVES: the A blocks 0-1 and 2-3 as two scheduling regions -- the stage's first block scales the A fragments that arrived
+  // last (2, 3) only after the MFMAs of blocks 0, 1; its last block reloads A blocks 0, 1 from the next stage's buffer as soon
+  // as their MFMAs have been issued.
+#define GVL_V_BLOCK(P, J, ST, NST, PRE0, MID, POST)                                                                  \
+  {                                                                                                                  \
+    constexpr int cur = (2 * (P) + (J)) & 3, nx = (2 * (P) + (J) + 2) & 3;                                           \
+    if constexpr ((J) + 2 < NJ) GVL_V_RDB(ST, (J) + 2, nx)                                                           \
+    else GVL_V_RDB(NST, (J) + 2 - NJ, nx)                                                                            \
+    PRE0                                                                                                             \
+    const h8 bs = bh[cur] * k2048;                                                                                   \
+    GVL_V_MFMA3(0, J, bs, cur)                                                                                       \
+    GVL_V_MFMA3(1, J, bs, cur)                                                                                       \
+    MID                                                                                                              \
+    GVL_V_MFMA3(2, J, bs, cur)                                                                                       \
+    GVL_V_MFMA3(3, J, bs, cur)                                                                                       \
+    POST                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+#define GVL_V_NONE
+#define GVL_V_STAGE(P)                                                                                               \
+  {                                                                                                                  \
+    uint4 *st = smem + (P) * kStageSlots;                                                                            \
+    uint4 *nst = smem + (1 - (P)) * kStageSlots;                                                                     \
+    GVL_V_BLOCK(P, 0, st, nst,                                                                                       \
+                ah[0] = ah[0] * k2048; ah[1] = ah[1] * k2048; GVL_V_ISSUE(P, 4, 1, nst) GVL_V_ISSUE(P, 5, 1, nst),   \
+                __builtin_amdgcn_sched_barrier(0); ah[2] = ah[2] * k2048; ah[3] = ah[3] * k2048;, GVL_V_NONE)        \
+    GVL_V_BLOCK(P, 1, st, nst, GVL_V_ISSUE(P, 6, 1, nst) GVL_V_ISSUE(P, 7, 1, nst), GVL_V_NONE, GVL_V_NONE)          \
+    GVL_V_BLOCK(P, 2, st, nst, GVL_V_ISSUE(P, 8, 1, nst), GVL_V_NONE, GVL_V_NONE)                                    \
+    GVL_V_BLOCK(P, 3, st, nst, GVL_V_NONE, GVL_V_NONE, GVL_V_NONE)                                                   \
+    GVL_V_BLOCK(P, 4, st, nst, GVL_V_NONE, GVL_V_NONE, GVL_V_NONE)                                                   \
+    GVL_V_BLOCK(P, 5, st, nst, GVL_V_NONE, GVL_V_NONE, GVL_V_NONE)                                                   \
+    GVL_V_BLOCK(P, 6, st, nst, GVL_V_NONE, GVL_V_NONE, GVL_V_NONE)                                                   \
+    GVL_V_BLOCK(P, 7, st, nst, GVL_V_NONE, GVL_V_NONE, GVL_V_NONE)                                                   \
+    /* every read of this stage's buffer has been issued: once they are complete (and my units of the next stage     \
+       have landed) the barrier makes both true for everybody */                                                     \
+    GVL_V_WAIT();                                                                                                    \
+    GVL_V_BARRIER();                                                                                                 \
+    asm volatile("" ::: "memory");                                                                                   \
+    GVL_V_BLOCK(P, 8, st, nst, GVL_V_ISSUE(P, 0, 2, st) GVL_V_ISSUE(P, 1, 2, st), GVL_V_NONE, GVL_V_NONE)            \
+    GVL_V_BLOCK(P, 9, st, nst, GVL_V_ISSUE(P, 2, 2, st) GVL_V_ISSUE(P, 3, 2, st),                                    \
+                __builtin_amdgcn_sched_barrier(0); GVL_V_RDA(nst, 0) GVL_V_RDA(nst, 1),                              \
+                __builtin_amdgcn_sched_barrier(0); GVL_V_RDA(nst, 2) GVL_V_RDA(nst, 3))                              \
+  }
+
+  const int KT = K / kBK;                                              // even, >= 4 (host)
+  int kt = 0;
+#ifdef GVL_V_CLOCKS                                                    /* dev: shader clocks and 100 MHz ticks of workgroup 0 */
+  const uint64_t c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  {                                                                    // stage 0 whole, units 0-3 of stage 1
+    constexpr int P = 0;
+    kt = -2;                                                           // (GVL_V_ISSUE adds P + AHEAD)
+#ifdef GVL_V_DMA_ONCE
+#define GVL_V_ISSUE0(I, ST) GVL_V_DMA(I, tm, tn, (kt + 2) * kBK, ST)
+#else
+#define GVL_V_ISSUE0(I, ST) GVL_V_ISSUE(P, I, 2, ST)
+#endif
+    GVL_V_ISSUE0(0, smem) GVL_V_ISSUE0(1, smem) GVL_V_ISSUE0(2, smem) GVL_V_ISSUE0(3, smem) GVL_V_ISSUE0(4, smem)
+    GVL_V_ISSUE0(5, smem) GVL_V_ISSUE0(6, smem) GVL_V_ISSUE0(7, smem) GVL_V_ISSUE0(8, smem)
+    kt = -1;
+    GVL_V_ISSUE0(0, smem + kStageSlots) GVL_V_ISSUE0(1, smem + kStageSlots) GVL_V_ISSUE0(2, smem + kStageSlots)
+    GVL_V_ISSUE0(3, smem + kStageSlots)
+#ifdef GVL_V_DMA_ONCE
+    GVL_V_ISSUE0(4, smem + kStageSlots) GVL_V_ISSUE0(5, smem + kStageSlots) GVL_V_ISSUE0(6, smem + kStageSlots)
+    GVL_V_ISSUE0(7, smem + kStageSlots) GVL_V_ISSUE0(8, smem + kStageSlots)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#undef GVL_V_ISSUE0
+    kt = 0;
+  }
+  wait_vmcnt<4>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) GVL_V_RDA(smem, i)
+  GVL_V_RDB(smem, 0, 0)
+  GVL_V_RDB(smem, 1, 1)
+  for (;;) {
+    GVL_V_STAGE(0)
+    GVL_V_STAGE(1)
+    kt += 2;
+    if (kt == KT) {
+      if (((tm * kRowsA + wa) >> 6) < chunks)
+        epilogue_v<NJ>(acc, tm * kRowsA + wa, tn * kRowsB + wb, lane, As, Bs, bias, R, N, out);
+      if (!has_next) break;
+      kt = 0;
+      vb += (int)gridDim.x;
+      tm = tm2;
+      tn = tn2;
+      has_next = tile_of(vb + (int)gridDim.x, tiles_m, tiles_n, tm2, tn2);
+      if (!has_next) { tm2 = tm; tn2 = tn; }
+      // (the first fragments of the new tile are read again rather than kept across the epilogue)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) GVL_V_RDA(smem, i)
+      GVL_V_RDB(smem, 0, 0)
+      GVL_V_RDB(smem, 1, 1)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f4acc4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GVL_V_CLOCKS
+  if (blockIdx.x == 0 && tid == 0) {
+    const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    printf("k_vocab clocks: %llu cycles in %llu ticks of 10 ns = %.3f GHz\n", (unsigned long long)(c1 - c0),
+           (unsigned long long)(r1 - r0), (double)(c1 - c0) / (10.0 * (double)(r1 - r0)));
+  }
+#endif
+#undef GVL_V_STAGE
+#undef GVL_V_NONE
+#undef GVL_V_ISSUE
+#undef GVL_V_BARRIER
+#undef GVL_V_WAIT
+#undef GVL_V_BLOCK
+#undef GVL_V_MFMA3
+#undef GVL_V_RDB
+#undef GVL_V_RDA
+#undef GVL_V_DMA
+#undef GVL_V_SRC
+}
+
 // partials (chunks, R) of {max, sum exp(v - max), index, -} -> per row argmax and log-softmax at the argmax, plus the
 // bookkeeping of one greedy step (gvl_cap.hip: k_row_argmax_lse has the same tail).  Block = 16 rows x 16 chunk groups:
 // 16 lanes read 256 contiguous bytes of one chunk row; 300 workgroups at R = 4800.
@@ -1016,6 +1321,16 @@ int persistent_grid(int tiles) {
 bool use_m16(int K) {
   const char *e = getenv("GVL_GEMM16_MFMA");
   return !(e && atoi(e) == 32) && K % 64 == 0 && K >= 128;
+}
+
+// GVL_VOCAB_FORM: "m16" keeps k_gemm_f16x3_m16 for the vocabulary product, "v" takes k_vocab_f16x3 wherever it applies (A/B
+// runs, tests); read once
+int vocab_form() {
+  static const int form = [] {
+    const char *e = getenv("GVL_VOCAB_FORM");
+    return !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'v' ? 2 : 0));
+  }();
+  return form;
 }
 
 int check_operands(const char *what, const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi,
@@ -1151,6 +1466,16 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   const char *aform = getenv("GVL_ARGMAX_FORM");                      // (4: the four-wavefront kernel, A/B runs)
   if (R >= 1024 && K >= 3 * kBK && !(aform && atoi(aform) == 4)) {
     const int tiles_n = (R + 255) / 256;
+    if (use_m16(K) && !x1) {
+      // 256 x 320 tiles with one accumulator (k_vocab_f16x3) when their rounds over the chip cost less than the 128 x 256
+      // tiles': a round of the large tile takes 2.3 x a round of the small one (49 against 21 us at K = 512, one box)
+      const int vm = (V + 255) / 256, vn = (R + 319) / 320, cus = persistent_grid(1 << 20);
+      const int64_t cost_v = (int64_t)((vm * vn + cus - 1) / cus) * 23, cost_m = (int64_t)((tiles_m * tiles_n + cus - 1) / cus) * 10;
+      if (vocab_form() == 2 || (vocab_form() == 0 && cost_v < cost_m))
+        return gvl::launch(GVL_PROF_GEMM16, R, V, "k_vocab_f16x3<argmax>", k_vocab_f16x3, dim3(persistent_grid(vm * vn)), dim3(512),
+                           0, (hipStream_t)stream, wh, wl, w_scale, xh, xl, x_scale, bias, V, R, K, partials, vm, vn,
+                           gvl_gemm_f16x3_argmax_chunks(V));
+    }
     if (use_m16(K))
       return gvl::launch(GVL_PROF_GEMM16, R, V, "k_gemm_f16x3_m16<argmax>", (x1 ? k_gemm_f16x3_m16<2, 4, kArgmax, true> : k_gemm_f16x3_m16<2, 4, kArgmax, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, wh, wl, w_scale, xh,

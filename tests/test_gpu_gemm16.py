@@ -112,7 +112,10 @@ def test_fused_argmax_equals_argmax_of_the_written_logits(R, V):
     lp_ref, tok_ref = torch.log_softmax(logits.double(), 1).max(1)
     tok, lp = MSDA.row_argmax_lse_partials(MSDA.gemm_f16x3_argmax(xp, wp, b))
     assert bool((tok == tok_ref).all())
-    assert float((lp.double() - lp_ref).abs().max()) <= 2e-6
+    # the fused form (k_vocab_f16x3 at the large shapes) adds the three fp16 products into ONE fp32 accumulator: fp32 accumulation
+    # error, 2^-21 of sum |x| |w| at most (the two-accumulator kernels stay within 2e-6 here; the fp32 library GEMM within 7e-6)
+    tol = max(2e-6, 2.0 ** -21 * float((x.abs() @ w.abs().t()).max()))
+    assert float((lp.double() - lp_ref).abs().max()) <= tol
     # bookkeeping: identical to the kernel that reads written logits
     T = 5
     books = []
@@ -187,7 +190,8 @@ def test_random_shapes_through_every_kernel_form():
         tok, lp = MSDA.row_argmax_lse_partials(MSDA.gemm_f16x3_argmax(xp, wp, b))
         lp_ref, tok_ref = torch.log_softmax(out.double(), 1).max(1)
         assert bool((tok == tok_ref).all()), (R, K, N)
-        assert float((lp.double() - lp_ref).abs().max()) <= 3e-6, (R, K, N)
+        tol = max(3e-6, 2.0 ** -21 * float((x.abs() @ w.abs().t()).max()))      # (one fp32 accumulator: see above)
+        assert float((lp.double() - lp_ref).abs().max()) <= tol, (R, K, N)
 
 
 def test_non_finite_and_sub_floor_elements_have_defined_behaviour():
