@@ -5,7 +5,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 11          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 12          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -21,6 +21,7 @@ SIGNATURES = {
     "gvl_msda_set_impl": (None, [_I]),
     "gvl_msda_last_impl": (_I, []),
     "gvl_msda_last_kernel": (ctypes.c_char_p, []),
+    "gvl_reload_env": (None, []),
     "gvl_msda_forward_f32": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_msda_forward_f64": (_I, [_P] * 5 + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_msda_sample_f32": (_I, [_P] * 4 + [_I] * 8 + [_P, _P]),
@@ -139,6 +140,12 @@ def lib():
                     raise GvlLibraryError("libgvl_msda.so ABI version mismatch; rebuild")
                 _lib = handle
     return _lib
+
+
+def reload_env():
+    """the library re-reads its GVL_* switches on their next use (they are cached per process); a no-op before it is loaded"""
+    if _lib is not None:
+        _lib.gvl_reload_env()
 
 
 def check(rc, what):

@@ -758,7 +758,7 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
     return fail(GVL_EINVAL, "%s: null pointer", what);
   const int vids_per_group = (B + 7) / 8;
   if constexpr (std::is_same<ST, float>::value) {
-    const char *e = getenv("GVL_CAP_LDS");
+    const char *e = gvl::env_str("GVL_CAP_LDS");
     // rows of levels 2, 3 (ctx2att half) and of level 3 (value half): known to the caller that passes host level starts
     const int n_ctx = lsi_host ? S - (int)lsi_host[2] : 0, n_val = lsi_host ? S - (int)lsi_host[3] : 0;
     if (o_hi && L == 4 && P == 4 && lsi_host && n_val >= 1 && n_ctx >= n_val && n_ctx + n_val <= 63 &&
@@ -767,7 +767,7 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
       int parts = 32 / vids_per_group;                                 // workgroups per video: one per CU of the video's XCD
       parts = parts < 1 ? 1 : (parts > Q ? Q : parts);
       const size_t lds = (size_t)kLP * kC * sizeof(float) + (size_t)(n_ctx + n_val) * kC * sizeof(float);
-      const char *w = getenv("GVL_CAP_LDS_WAVES");
+      const char *w = gvl::env_str("GVL_CAP_LDS_WAVES");
       const dim3 grid(8 * vids_per_group * parts);
       if (w && atoi(w) == 8) {
         if (int rc = gvl::ensure_lds(k_cap_attend_lds<8>, lds)) return rc;

@@ -6,7 +6,10 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <stdlib.h>
+
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -22,6 +25,39 @@ inline int fail(int code, const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// ---- experiment / A-B switches (GVL_* environment variables): read ONCE per process and name -- keyed by the address of the
+// string literal -- so that no launch path calls getenv(); gvl_reload_env() drops the cache (tests that flip a switch between calls)
+struct EnvCache {
+  struct Entry { const char *name; bool set; std::string value; };
+  std::mutex mu;
+  std::vector<Entry *> seen;                 // (entries are never freed while a caller may hold their value)
+  std::vector<Entry *> retired;
+};
+inline EnvCache &env_cache() {
+  static EnvCache c;
+  return c;
+}
+inline const char *env_str(const char *name) {               // nullptr when unset or empty
+  EnvCache &c = env_cache();
+  std::lock_guard<std::mutex> g(c.mu);
+  for (EnvCache::Entry *e : c.seen)
+    if (e->name == name) return e->set ? e->value.c_str() : nullptr;
+  const char *v = getenv(name);
+  EnvCache::Entry *e = new EnvCache::Entry{name, v && *v, v ? v : ""};
+  c.seen.push_back(e);
+  return e->set ? e->value.c_str() : nullptr;
+}
+inline int env_int(const char *name, int dflt) {
+  const char *v = env_str(name);
+  return v ? atoi(v) : dflt;
+}
+inline void env_reload() {
+  EnvCache &c = env_cache();
+  std::lock_guard<std::mutex> g(c.mu);
+  c.retired.insert(c.retired.end(), c.seen.begin(), c.seen.end());
+  c.seen.clear();
 }
 
 // ---- in-library kernel timing: exact begin/end stamps of individual dispatches (hipExtLaunchKernel events) ----

@@ -1310,7 +1310,7 @@ int persistent_grid(int tiles) {
       n = 256;
     cus = n / 8 * 8 > 0 ? n / 8 * 8 : 8;
   }
-  const char *e = getenv("GVL_GEMM16_GRID");                          // (experiments: 0 = one workgroup per tile)
+  const char *e = gvl::env_str("GVL_GEMM16_GRID");                    // (experiments: 0 = one workgroup per tile)
   const int padded = (tiles + 7) / 8 * 8;
   if (e && atoi(e) == 0) return padded;
   return padded < cus ? padded : cus;
@@ -1319,18 +1319,15 @@ int persistent_grid(int tiles) {
 // the 16 x 16 x 32 form (two K stages per loop iteration: K % 64 == 0, at least four stages); GVL_GEMM16_MFMA=32 keeps
 // the 32 x 32 x 16 kernels for A/B runs
 bool use_m16(int K) {
-  const char *e = getenv("GVL_GEMM16_MFMA");
+  const char *e = gvl::env_str("GVL_GEMM16_MFMA");
   return !(e && atoi(e) == 32) && K % 64 == 0 && K >= 128;
 }
 
 // GVL_VOCAB_FORM: "m16" keeps k_gemm_f16x3_m16 for the vocabulary product, "v" takes k_vocab_f16x3 wherever it applies (A/B
-// runs, tests); read once
+// runs, tests)
 int vocab_form() {
-  static const int form = [] {
-    const char *e = getenv("GVL_VOCAB_FORM");
-    return !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'v' ? 2 : 0));
-  }();
-  return form;
+  const char *e = gvl::env_str("GVL_VOCAB_FORM");
+  return !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 'v' ? 2 : 0));
 }
 
 int check_operands(const char *what, const void *a_hi, const void *a_lo, const float *a_scale, int R, const void *b_hi,
@@ -1391,7 +1388,7 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, LstmEpi{});
     }
-    if (t_mid >= 384 && !getenv("GVL_GEMM16_NO_MID")) {
+    if (t_mid >= 384 && !gvl::env_str("GVL_GEMM16_NO_MID")) {
       const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
       return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", (x1 ? k_gemm_f16x3_w8<2, 4, 1, kStore, true> : k_gemm_f16x3_w8<2, 4, 1, kStore, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
@@ -1428,7 +1425,7 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
   // a third of its time -- runs under the other two workgroups' products, where the persistent eight-wavefront kernel
   // (one workgroup per CU, GVL_LSTM_GEMM_FORM=8) leaves the matrix cores idle for it: 60.9 against 65.6 us at 4800 x 512 x
   // 2048 although the plain product is faster on the eight-wavefront kernel
-  const char *form = getenv("GVL_LSTM_GEMM_FORM");
+  const char *form = gvl::env_str("GVL_LSTM_GEMM_FORM");
   if (R >= 1024 && K >= 3 * kBK && form && atoi(form) == 8) {
     const int t_big = ((R + 255) / 256) * ((N + 127) / 128), t_mid = ((R + 127) / 128) * ((N + 127) / 128);
     if (t_big >= 1024) {
@@ -1437,7 +1434,7 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, w_scale, (const float *)nullptr, R, N, K, (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
     }
-    if (t_mid >= 384 && !getenv("GVL_GEMM16_NO_MID")) {
+    if (t_mid >= 384 && !gvl::env_str("GVL_GEMM16_NO_MID")) {
       const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
       return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8<lstm>", (x1 ? k_gemm_f16x3_w8<2, 4, 1, kLstm, true> : k_gemm_f16x3_w8<2, 4, 1, kLstm, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
@@ -1463,7 +1460,7 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   const _Float16 *xh = (const _Float16 *)x_hi, *xl = (const _Float16 *)x_lo, *wh = (const _Float16 *)w_hi,
                  *wl = (const _Float16 *)w_lo;
   const int tiles_m = (V + kBM - 1) / kBM;                            // 128 vocabulary entries per tile, either form
-  const char *aform = getenv("GVL_ARGMAX_FORM");                      // (4: the four-wavefront kernel, A/B runs)
+  const char *aform = gvl::env_str("GVL_ARGMAX_FORM");                // (4: the four-wavefront kernel, A/B runs)
   if (R >= 1024 && K >= 3 * kBK && !(aform && atoi(aform) == 4)) {
     const int tiles_n = (R + 255) / 256;
     if (use_m16(K) && !x1) {

@@ -991,7 +991,7 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
         if (t_ <= 256 && t_ > best) { best = t_; bm = cand; }
       }
   }
-  if (const char *e = getenv("GVL_LIN_TILE")) { if (atoi(e) == 64) wide = false; }
+  if (gvl::env_int("GVL_LIN_TILE", 0) == 64) wide = false;
   const int bn = wide ? 128 : kLinBN;
   p.tiles_m = (R + bm - 1) / bm; p.tiles_n = N / bn;
   p.xcd_cols = (flags & GVL_LIN_XCD_COLUMNS) && p.tiles_n >= 8;

@@ -42,7 +42,7 @@ int g_impl = -1;  // -1 = read the environment on first use
 
 int impl_mode() {
   if (g_impl < 0) {
-    const char *e = getenv("GVL_MSDA_IMPL");
+    const char *e = gvl::env_str("GVL_MSDA_IMPL");
     g_impl = 0;
     if (e && !strcmp(e, "generic")) g_impl = 1;
     if (e && !strcmp(e, "fast")) g_impl = 2;
@@ -50,10 +50,7 @@ int impl_mode() {
   return g_impl;
 }
 
-int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
+using gvl::env_int;                                  // (cached: gvl_common.hpp)
 
 constexpr int kPadZeros = GVL_PAD_ZEROS;
 constexpr int kPadBorder = GVL_PAD_BORDER;
@@ -2091,6 +2088,10 @@ const char *gvl_last_error(void) { return gvl::g_err; }
 void gvl_msda_set_impl(int impl) { g_impl = (impl >= 0 && impl <= 2) ? impl : 0; }
 int gvl_msda_last_impl(void) { return g_last_impl; }
 const char *gvl_msda_last_kernel(void) { return g_last_kernel; }
+void gvl_reload_env(void) {
+  gvl::env_reload();
+  g_impl = -1;
+}
 
 void gvl_msda_debug_stamps(void *device_buffer) {
   g_fwd_stamps = (unsigned long long *)device_buffer;

@@ -28,6 +28,35 @@ def pytest_sessionstart(session):
         print(f"[conftest] could not build the native pieces: {e}", file=sys.stderr)
 
 
+class _EnvMonkeyPatch(pytest.MonkeyPatch):
+    """libgvl_msda.so caches its GVL_* switches per process (no getenv() on a launch path): a test that flips one through
+    monkeypatch must make the library read it again -- on the change and when it is undone"""
+
+    @staticmethod
+    def _reload():
+        from gvl_amd import _lib
+        _lib.reload_env()
+
+    def setenv(self, *a, **k):
+        super().setenv(*a, **k)
+        self._reload()
+
+    def delenv(self, *a, **k):
+        super().delenv(*a, **k)
+        self._reload()
+
+    def undo(self):
+        super().undo()
+        self._reload()
+
+
+@pytest.fixture
+def monkeypatch():
+    mp = _EnvMonkeyPatch()
+    yield mp
+    mp.undo()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

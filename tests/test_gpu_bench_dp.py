@@ -65,6 +65,9 @@ def test_two_ranks_on_one_gpu(mode, launcher):
     assert ex["total"] >= ex["exposed"] >= 0 and ex["bytes"] > 0
     if rccl:
         assert d["rccl_ranks"] == 2
+        # two GPUs, RCCL: the buckets' all-reduces are launched from the backward's hooks / between the two captured halves, so
+        # part of the exchange must run UNDER the backward -- the time the step waits for it is less than the exchange takes
+        assert ex["exposed"] < ex["total"], ex
         for key in ("train_seconds_per_rank",) + (("eval_seconds_per_rank",) if mode == "both" else ()):
             assert len(d[key]) == 2 and min(d[key]) > 0, (key, d[key])     # (no timing band: 3 steps on a shared box)
     else:

@@ -125,12 +125,15 @@ def test_level_split_backward_equals_query_split(dev, MSDA):
     value, shapes, lsi, loc, aw, gout = make_inputs(16, 100, 8, 64, 300, 4, seed=77)
     args = [t(x).to(dev) for x in (value, shapes, lsi, loc, aw)]
     res = {}
+    from gvl_amd import _lib
     for split in ("1", "0"):
         os.environ["GVL_MSDA_BWD_SPLIT"] = split
+        _lib.reload_env()                                    # (the library caches its switches)
         try:
             res[split] = MSDA.ms_deform_attn_backward(*args, t(gout).to(dev), 64)
         finally:
             os.environ.pop("GVL_MSDA_BWD_SPLIT", None)
+            _lib.reload_env()
     (gv1, gl1, gw1), (gv0, gl0, gw0) = res["1"], res["0"]
     assert torch.equal(gl1, gl0) and torch.equal(gw1, gw0)
     assert maxerr(gv1, gv0) <= 1e-5 * scale(gv0.cpu().numpy())

@@ -38,6 +38,7 @@ def run(T, Q, rd, dt, tag, env):
     gout = torch.randn(B, Q, 512, device=dev, generator=g).to(dt)
     for k, v in env.items():
         os.environ[k] = v
+    lib.gvl_reload_env()                                     # (the library caches its switches)
     try:
         for _ in range(3):
             MSDA.msda1d_fused_backward(value, sh2, lsi, proj, ref, gout, 4, 4, need_ref_grad=True)
@@ -54,6 +55,7 @@ def run(T, Q, rd, dt, tag, env):
     finally:
         for k in env:
             del os.environ[k]
+        lib.gvl_reload_env()
     per = {}
     for tg, ma, mb, us in MSDA.profile_collect():
         per.setdefault(tg, []).append(us)

@@ -45,6 +45,7 @@ for dt in (torch.float32, torch.bfloat16) if os.environ.get("BF16") else (torch.
         for r in range(R):
             for name, env in variants:
                 os.environ.update(env)
+                _lib.reload_env()                            # (the library caches its switches)
                 try:
                     for _ in range(3):
                         call()
@@ -57,6 +58,7 @@ for dt in (torch.float32, torch.bfloat16) if os.environ.get("BF16") else (torch.
                 finally:
                     for k_ in env:
                         del os.environ[k_]
+                    _lib.reload_env()
                 per = {}
                 for tg, ma, mb, us in MSDA.profile_collect():
                     per.setdefault(tg, []).append(us)
