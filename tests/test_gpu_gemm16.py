@@ -188,9 +188,13 @@ def test_random_shapes_through_every_kernel_form():
         bound = 2.0 ** -21 * float((x.abs().double() @ w.abs().double().t()).max()) + 2.0 ** -22 * float(ref.abs().max())
         assert float((out.double() - ref).abs().max()) <= bound, (R, K, N)
         tok, lp = MSDA.row_argmax_lse_partials(MSDA.gemm_f16x3_argmax(xp, wp, b))
-        lp_ref, tok_ref = torch.log_softmax(out.double(), 1).max(1)
-        assert bool((tok == tok_ref).all()), (R, K, N)
+        lsm = torch.log_softmax(out.double(), 1)
+        lp_ref, tok_ref = lsm.max(1)
         tol = max(3e-6, 2.0 ** -21 * float((x.abs() @ w.abs().t()).max()))      # (one fp32 accumulator: see above)
+        # the same token as the written logits' argmax -- or, where the two kernels round a near-tie differently (they add the
+        # products in different orders), a token whose written logit is within that rounding of the maximum
+        assert float((lp_ref - lsm.gather(1, tok[:, None])[:, 0]).max()) <= tol, (R, K, N)
+        assert int((tok != tok_ref).sum()) <= 1 + R // 1000, (R, K, N)
         assert float((lp.double() - lp_ref).abs().max()) <= tol, (R, K, N)
 
 

@@ -37,7 +37,7 @@ def main():
     print("GVL_VOCAB_FORM =", os.environ.get("GVL_VOCAB_FORM"))
     ok = True
     for R, V, K, seed in [] if a.time_only else [(4800, 8518, 512, 1), (1600, 8518, 512, 2), (1030, 300, 128, 3), (2000, 70, 64 * 3, 4),
-                          (3333, 5000, 1024, 5), (4801, 8519, 512, 6)]:
+                          (3333, 5000, 1024, 5), (4801, 8519, 512, 6), (3613, 1657, 256, 7)]:
         ok &= check(R, V, K, dev, seed)
     R, V, K = 4800, 8518, 512
     g = torch.Generator(device=dev).manual_seed(0)
