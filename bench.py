@@ -817,9 +817,19 @@ def main():
         if gemm16_on and mine:
             us = mine[0][0]
             tf16 = 3 * 2.0 * rows * V * Kd / (us * 1e-6) / 1e12
+            # which kernel form serves it: the dispatch rule of gvl_gemm_f16x3_argmax_f32 (gvl_gemm16.hip), GVL_VOCAB_FORM overrides
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count // 8 * 8 or 8
+            cost_v = -(-(-(-V // 256) * -(-rows // 320)) // cus) * 23
+            cost_m = -(-(-(-V // 128) * -(-rows // 256)) // cus) * 10
+            form = os.environ.get("GVL_VOCAB_FORM", "")[:1]
+            big = Kd % 64 == 0 and Kd >= 128 and rows >= 1024 and (form == "v" or (form != "m" and cost_v < cost_m))
+            kname = "k_vocab_f16x3 (256x320 tiles, one accumulator)" if big else "k_gemm_f16x3_m16<argmax>"
             line["dominant_gemm"] = {
-                "kernel": f"k_gemm_f16x3_m16<argmax> {rows}x{Kd}x{V} (vocabulary product of every token step, argmax / "
+                "kernel": f"{kname} {rows}x{Kd}x{V} (vocabulary product of every token step, argmax / "
                           f"log-sum-exp fused, logits never written), hand-written",
+                "note": "the matrix pipe is power-limited under this load (clock 1.87 GHz, issue throttled by the operands' "
+                        "switching activity): with real operands and NO data movement the same MFMA stream reaches 0.63 of "
+                        "the nominal peak (DESIGN.md 4.4, tools/vocab_clocks.sh)",
                 "bound": "mfma", "achieved": round(tf16, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, 3 "
                 "partial products per fp32 product)", "frac": round(tf16 / F16_MFMA_PEAK_TFLOPS, 4),
                 "fp32_equivalent_tflops": round(tf16 / 3, 1), "kernel_us": round(us, 1), "launches_timed": mine[0][1],

@@ -238,6 +238,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
   }
 
   const int KT = p.split_stages ? min(K / kBK - kbeg, p.split_stages) : K / kBK;
+#ifdef GVL_LIN_STAMPS                                                  /* dev: 10 ns ticks of workgroup 0's phases */
+  const uint64_t ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
   ASet set0, set1;
   load_a(set0, 0);
   load_a(set1, min(1, KT - 1) * kBK);
@@ -283,12 +286,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
   // a predecessor on which that stage's own loads are still pending, and hipcc's wait-count pass then drains the prefetch
   // at the top of every iteration (the temporaries there reuse the registers of the set loaded later in the stage).
   int kt = 0;
+#ifdef GVL_LIN_STAMPS
+  const uint64_t ts1 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int it = KT >> 1; it > 0; --it) {
     GVL_LIN_STAGE(set1, set0)
     GVL_LIN_STAGE(set0, set1)
   }
   if (KT & 1) GVL_LIN_STAGE(set1, set0)
 #undef GVL_LIN_STAGE
+#ifdef GVL_LIN_STAMPS
+  const uint64_t ts2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- epilogue.  C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
   // Every load (row scales, residual, mask) is issued before the first store: a load between two stores makes the
@@ -407,6 +416,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) k_lin_f1
       if (!b0 && row < R) atomicMax(reinterpret_cast<unsigned *>(sg.amax_out) + row, __float_as_uint(rmax));
     }
   }
+#ifdef GVL_LIN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (blockIdx.x == 8 && tid == 0)
+    printf("k_lin %dx%dx%d tile %dx%d: prologue %d, loop %d (%d stages), epilogue %d ticks of 10 ns\n", R, K, N, TBM, kBN,
+           (int)(ts1 - ts0), (int)(ts2 - ts1), KT, (int)(__builtin_amdgcn_s_memrealtime() - ts2));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
