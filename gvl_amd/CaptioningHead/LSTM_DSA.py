@@ -181,7 +181,8 @@ class ShowAttendTellCore(nn.Module):
         params = (self.deformable_att.sampling_offsets.weight, self.h2att.weight, self.h2att.bias, self.rnn.weight_hh_l0,
                   self.rnn.weight_ih_l0, self.alpha_net.weight)
         cell_fused = os.environ.get("GVL_CELL_FUSED", "1") != "0"
-        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (split_gemm_enabled(), cell_fused, gemm_dtype)
+        gates_fused = cell_fused and os.environ.get("GVL_GATES_FUSED", "1") != "0"
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params) + (split_gemm_enabled(), cell_fused, gates_fused, gemm_dtype)
         cache = self.__dict__.setdefault("_inf_w", {})
         if cache and next(iter(cache))[:-1] != key[:-1]:
             cache.clear()
@@ -206,6 +207,13 @@ class ShowAttendTellCore(nn.Module):
                         w_hh, w_att = w_hh[perm], w_att[perm]
                     w["w_h_cat_p"] = MSDA.split_rows(torch.cat([self.h2att.weight, w_hh], 0))
                     w["w_att_p"] = MSDA.split_rows(w_att.contiguous())
+                    if gates_fused and w.get("gate_perm") is not None:
+                        # BOTH halves of the gate product + the cell in one launch (gvl_gemm_f16x3_gates_f32: contraction
+                        # [h | att]); the product over h in front of the attention then only yields h2att(h).
+                        # GVL_GATES_FUSED=0: the (n, A + 4H) product + gates_h operand of round 4.
+                        w["w_gate_cat_p"] = MSDA.split_rows(torch.cat([w_hh, w_att], 1).contiguous())
+                        w["w_h2att_p"] = MSDA.split_rows(self.h2att.weight.contiguous())
+                        w["b_h2att"] = self.h2att.bias.detach().contiguous()
             cache[key] = w
         return w
 
@@ -220,9 +228,15 @@ class ShowAttendTellCore(nn.Module):
             const["host_starts"] = tuple(host[1]) if host is not None else None
         A = self.att_hid_size
         split = "w_h_cat_p" in const and h.dtype == torch.float32
+        gates_one = (split and "w_gate_cat_p" in const and const["slab3"].dtype == torch.float32
+                     and MSDA.f16_products_now() == 3 and MSDA.gates_applicable(h.shape[0], self.rnn_size))
         if split:
             hp = getattr(h, "_gvl_planes", None)                         # left by the vocabulary product of the last step
-            g_h = MSDA.gemm_f16x3(hp if hp is not None else MSDA.split_rows(h), const["w_h_cat_p"], const["b_h_cat"])
+            hp = hp if hp is not None else MSDA.split_rows(h)
+            if gates_one:
+                g_h = MSDA.gemm_f16x3(hp, const["w_h2att_p"], const["b_h2att"])            # (n, A): h2att(h) only
+            else:
+                g_h = MSDA.gemm_f16x3(hp, const["w_h_cat_p"], const["b_h_cat"])
         else:
             h_gemm = getattr(h, "_gvl_lowp", h)                          # bf16 copy left by the cell kernel (autocast)
             g_h = F.linear(h_gemm, const["w_h_cat"], const["b_h_cat"])  # (n, A + 4H): [h2att(h) | h W_hh^T]
@@ -230,6 +244,8 @@ class ShowAttendTellCore(nn.Module):
         att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
                                   h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
                                   self.n_levels, self.n_points, planes=split, host_starts=const.get("host_starts"))
+        if gates_one:                                                   # the recurrent operand travels as planes
+            return att_res, (hp,)
         if split and const.get("gate_perm") is not None:                # ... whose epilogue is the cell (step)
             return att_res, g_h
         if split:                                                       # att_res arrives as the planes of the product
@@ -243,6 +259,8 @@ class ShowAttendTellCore(nn.Module):
                 xt_gates = xt_gates[:, const["gate_perm"]]
             xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
         emb_gates, it = xt_gates                                        # (table (V+1,4H), token ids)
+        if isinstance(g_h, tuple):                                      # (attend_part: the planes of h)
+            return MSDA.gemm_f16x3_gates(g_x, g_h[0], const["w_gate_cat_p"], const["gates_hs"], emb_gates, it, c)
         if const.get("gate_perm") is not None:                          # g_x: planes of the attended feature (attend_part)
             return MSDA.gemm_f16x3_lstm(g_x, const["w_att_p"], g_h[:, self.att_hid_size:], const["gates_hs"], emb_gates,
                                         it, c)

@@ -610,6 +610,44 @@ def gemm_f16x3_lstm(a, w, gates_h, gates_c, emb_gates, it, c):
     return h_out, c_out
 
 
+def f16_products_now():
+    """3 | 1: the number of fp16 products per fp32 product the library currently runs (gvl_f16_products(0))"""
+    return int(_lib.lib().gvl_f16_products(0))
+
+
+def gates_applicable(n, H):
+    """whether gvl_gemm_f16x3_gates_f32's tiles fill the chip at (n, 4H) (else the two-launch form is the faster one)"""
+    return bool(_lib.lib().gvl_gemm_f16x3_gates_applicable(n, H))
+
+
+def gemm_f16x3_gates(a, h_prev, w, gates_c, emb_gates, it, c):
+    """(h', c') = LSTM cell of [h_prev | a] . w^T + gates_c + emb_gates[it] (include/gvl_msda.h: gvl_gemm_f16x3_gates_f32):
+    a SplitPlanes (n, K_a), h_prev SplitPlanes (n, K_h) -- the planes of the step's incoming hidden state --, w SplitPlanes
+    (4H, K_h + K_a) = [W_hh | W_ih[:, attention columns]] with rows in gate_permutation order; gates_c (n, 4H) / emb_gates
+    (V + 1, 4H) with columns in that order.  h' carries its planes."""
+    n, H = c.shape
+    _require(a.rows == n and h_prev.rows == n and w.rows == 4 * H and a.cols + h_prev.cols == w.cols,
+             "gemm_f16x3_gates: operand shapes")
+    if gates_c is not None:
+        _require(gates_c.is_cuda and gates_c.dtype == torch.float32 and gates_c.dim() == 2 and gates_c.stride(1) == 1
+                 and tuple(gates_c.shape) == (n, 4 * H), "gemm_f16x3_gates: gates_c must be an (n, 4H) fp32 CUDA matrix")
+    _require(emb_gates.is_contiguous() and emb_gates.dtype == torch.float32 and emb_gates.shape[1] == 4 * H
+             and c.is_contiguous() and c.dtype == torch.float32 and it.is_contiguous() and it.dtype == torch.int64
+             and it.numel() == n, "gemm_f16x3_gates: emb_gates (V+1, 4H) / c fp32 contiguous, it int64 (n)")
+    h_out, c_out = torch.empty_like(c), torch.empty_like(c)
+    hp = SplitPlanes(n, H, c.device)
+    with torch.cuda.device(c.device):
+        rc = _lib.lib().gvl_gemm_f16x3_gates_f32(
+            a.hi.data_ptr(), a.lo.data_ptr(), a.scale.data_ptr(), h_prev.hi.data_ptr(), h_prev.lo.data_ptr(),
+            h_prev.scale.data_ptr(), n, w.hi.data_ptr(), w.lo.data_ptr(), w.scale.data_ptr(), H, h_prev.cols, a.cols,
+            gates_c.data_ptr() if gates_c is not None else None, gates_c.stride(0) if gates_c is not None else 0,
+            emb_gates.data_ptr(), it.data_ptr(), c.data_ptr(), h_out.data_ptr(), c_out.data_ptr(), hp.hi.data_ptr(),
+            hp.lo.data_ptr(), hp.scale.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "gemm_f16x3_gates")
+    h_out._gvl_planes = hp
+    return h_out, c_out
+
+
 def row_argmax_lse(logits):
     """(R, V) fp32 | bf16 -> (argmax int64 (R,), log_softmax value at the argmax (R,)); first maximal index on ties."""
     _require(logits.is_cuda and logits.is_contiguous() and logits.dtype in (torch.float32, torch.bfloat16)

@@ -63,6 +63,8 @@ SIGNATURES = {
     "gvl_ce_rows_backward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P]),
     "gvl_proj_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "gvl_split_rows_f16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "gvl_gemm_f16x3_gates_applicable": (_I, [_I, _I]),
+    "gvl_gemm_f16x3_gates_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gvl_gemm_f16x3_lstm_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gvl_gemm_f16x3_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, ctypes.c_int64, _P]),
     "gvl_gemm_f16x3_argmax_chunks": (_I, [_I]),

@@ -35,6 +35,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gvl_common.hpp"
 #include "gvl_gemm16_common.hpp"
 #include "gvl_msda.h"
@@ -647,6 +649,11 @@ __global__ void __launch_bounds__(512, 1)
 //   iteration), the barrier + DMA issue sit between the second and the third quarter.
 typedef float f4acc4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ uint32_t pack2h(_Float16 a, _Float16 b) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, (h2v){a, b});
+}
+
 __device__ __forceinline__ int lds_slot16(int row, int chunk) { return row * 4 + (chunk ^ (((row >> 2) & 1) << 1)); }
 
 template <int EPI>
@@ -1236,6 +1243,306 @@ __global__ void __launch_bounds__(512, 1)
 #undef GVL_V_SRC
 }
 
+// ---- k_gates_f16x3: BOTH halves of the LSTM gate product of a token step in one launch, the cell applied (round 5).
+//   gates (n, 4H) = h W_hh^T + att W_ih[att]^T + gates_c + emb_gates[it]   (LSTM_DSA.py:267-269, nn.LSTM's pointwise part :216-217)
+// Round 4 ran the recurrent half inside the (n, A + 4H) product over h in front of the attention (45.9 us, 49 MB written) and the
+// attention half + cell as a second product (58.8 us, reading that part back): 104.6 us per token for 68 GFLOP of fp16 MFMA.  Here
+// A = the planes of [W_hh | W_ih[att]] (4H gate rows in the order 4 unit + gate, contraction K1 + K2) and B = the planes of h for
+// the first K1 / 32 stages, of att for the rest; between the two the accumulators move from h's row scale to att's (powers of two:
+// exact).  The k_vocab_f16x3 recipe on a 256 x 160 tile (8 x 30 = 240 tiles at (2048, 4800): one per CU, one round): eight
+// wavefronts of 64 x 80 (4 x 5 tiles of v_mfma_f32_16x16x32_f16, ONE accumulator per output: 80 registers), a K stage is 52 KB and
+// -- a stage being only 960 MFMA cycles per wavefront -- the ring has THREE stage buffers with the DMA two to three stages ahead
+// (every wavefront issues exactly seven units per stage, so the stage barrier's wait is the counted `vmcnt(7)`).  In the
+// accumulator map of the 16 x 16 x 32 MFMA the four registers of a lane are the four gates of ONE (row, unit): the cell needs no
+// transposes; its operands (gate addends, embedding rows, state) are requested in two batches with every load of a batch in
+// flight, and h', c' and the planes of h' leave through an LDS transpose as whole 256-byte row segments (written straight from
+// the accumulator layout -- 16 rows x 16 bytes per store instruction -- the stores alone took 40 us).
+struct GatesEpi {
+  const float *gates_c;                // (n, >= 4H) token-independent gate part, may be null
+  int64_t ld_c;
+  const float *emb;                    // (V + 1, 4H)
+  const int64_t *it;                   // (n)
+  const float *c;                      // (n, H)
+  float *h_out, *c_out;                // (n, H)
+  _Float16 *h_hi, *h_lo;               // planes of h' at row scale 1
+  float *h_scale;
+  int H;
+};
+
+__global__ void __launch_bounds__(512, 1)
+    k_gates_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
+                  const _Float16 *__restrict__ B1h, const _Float16 *__restrict__ B1l, const float *__restrict__ B1s,
+                  const _Float16 *__restrict__ B2h, const _Float16 *__restrict__ B2l, const float *__restrict__ B2s, int R,
+                  int N, int K1, int K2, int tiles_m, int tiles_n, const GatesEpi ge) {
+  constexpr int kRowsA = 256, kRowsB = 160, NJ = 5;
+  constexpr int kASlots = kRowsA * 4, kBSlots = kRowsB * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
+  constexpr int kLdT = 68;                                             // floats per row of the epilogue's transpose image
+  __shared__ uint4 smem[3 * kStageSlots];
+  static_assert(2 * kRowsB * kLdT * 4 <= 3 * kStageSlots * 16, "two transpose images fit the stage ring");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = (wave & 3) * 64, wb = (wave >> 2) * 80;
+  const int KT1 = K1 / kBK, KT = (K1 + K2) / kBK;
+
+  // DMA units of 16 rows x 64 bytes: unit u = wave + 8 i, i = 0 .. 6: [0, 16) A hi, [16, 32) A lo, [32, 42) B hi, [42, 52) B lo,
+  // [52, 56) B lo blocks 6-9 once more (identical bytes to the same place: every wavefront issues seven units per stage)
+  const int srow = lane >> 2, schunk = ((lane & 3) ^ (((srow >> 2) & 1) << 1)) * 8;
+  const uint32_t lane_off = 2u * (uint32_t)(srow * 32 + schunk);
+  const __amdgpu_buffer_rsrc_t rs_ah = __builtin_amdgcn_make_buffer_rsrc((void *)Ah, 0, R * (K1 + K2) * 2, 0x00020000),
+                               rs_al = __builtin_amdgcn_make_buffer_rsrc((void *)Al, 0, R * (K1 + K2) * 2, 0x00020000),
+                               rs_1h = __builtin_amdgcn_make_buffer_rsrc((void *)B1h, 0, N * K1 * 2, 0x00020000),
+                               rs_1l = __builtin_amdgcn_make_buffer_rsrc((void *)B1l, 0, N * K1 * 2, 0x00020000),
+                               rs_2h = __builtin_amdgcn_make_buffer_rsrc((void *)B2h, 0, N * K2 * 2, 0x00020000),
+                               rs_2l = __builtin_amdgcn_make_buffer_rsrc((void *)B2l, 0, N * K2 * 2, 0x00020000);
+  int b_lo[3], b_blk[3];                                               // the B units i = 4, 5, 6 of this wavefront
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int ub = wave + 8 * i;
+    b_lo[i] = ub >= 10;
+    b_blk[i] = ub < 10 ? ub : (ub < 20 ? ub - 10 : ub - 14);
+  }
+  // unit I of stage KN (0 .. KT - 1) of tile (TM, TN) -> stage buffer ST
+#define GVL_G_DMA(I, TM, TN, KN, ST)                                                                                 \
+  {                                                                                                                  \
+    if constexpr ((I) < 4) {                                                                                         \
+      const bool lo = (I) >= 2;                                                                                      \
+      const int blk = wave + 8 * ((I) & 1);                                                                          \
+      const uint32_t soff = 2u * (uint32_t)((KN) * kBK * R + ((TM) * kRowsA + blk * 16) * 32);                       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(lo ? rs_al : rs_ah,                                                   \
+                                               (__attribute__((address_space(3))) void *)((ST) + (lo ? kASlots : 0) + blk * 64), \
+                                               16, lane_off + soff, 0, 0, 0);                                        \
+    } else {                                                                                                         \
+      const bool lo = b_lo[(I) - 4], second = (KN) >= KT1;                                                           \
+      const int blk = b_blk[(I) - 4], ks = second ? (KN) - KT1 : (KN);                                               \
+      const uint32_t soff = 2u * (uint32_t)(ks * kBK * N + ((TN) * kRowsB + blk * 16) * 32);                         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? (lo ? rs_2l : rs_2h) : (lo ? rs_1l : rs_1h),                 \
+                                               (__attribute__((address_space(3))) void *)((ST) + 2 * kASlots + (lo ? kBSlots : 0) + blk * 64), \
+                                               16, lane_off + soff, 0, 0, 0);                                        \
+    }                                                                                                                \
+  }
+
+  const int fa0 = lds_slot16(wa + (lane & 15), lane >> 4), fb0 = 2 * kASlots + lds_slot16(wb + (lane & 15), lane >> 4);
+  const _Float16 k2048 = (_Float16)2048.f;
+  for (int vb = (int)blockIdx.x;; vb += (int)gridDim.x) {
+    int tm, tn;
+    if (!tile_of(vb, tiles_m, tiles_n, tm, tn)) break;
+    f4acc4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f4acc4{0.f, 0.f, 0.f, 0.f};
+    h8 ah[4], al[4], bh[NJ], bl[NJ], nh[2], nl[2];
+    // the three stage buffers rotate: cur is read, nxt holds the next stage, nn receives the one after
+    uint4 *cur = smem, *nxt = smem + kStageSlots, *nn = smem + 2 * kStageSlots;
+    int kt = 0;
+    // stage KN beyond the tile's last one: the same units of stage KN - KT again (nobody reads them; the counts stay uniform)
+#define GVL_G_ISSUE(I, AHEAD, ST)                                                                                    \
+  {                                                                                                                  \
+    const int kn = kt + (AHEAD) >= KT ? kt + (AHEAD) - KT : kt + (AHEAD);                                            \
+    GVL_G_DMA(I, tm, tn, kn, ST)                                                                                     \
+  }
+#define GVL_G_RDA(ST, I)                                                                                             \
+  {                                                                                                                  \
+    ah[I] = *reinterpret_cast<const h8 *>(&(ST)[fa0 + 64 * (I)]);                                                    \
+    al[I] = *reinterpret_cast<const h8 *>(&(ST)[kASlots + fa0 + 64 * (I)]);                                          \
+  }
+#define GVL_G_RDB(ST, J, H_, L_)                                                                                     \
+  {                                                                                                                  \
+    H_ = *reinterpret_cast<const h8 *>(&(ST)[fb0 + 64 * (J)]);                                                       \
+    L_ = *reinterpret_cast<const h8 *>(&(ST)[kBSlots + fb0 + 64 * (J)]);                                             \
+  }
+#define GVL_G_MFMA3(I, J, BS)                                                                                        \
+  {                                                                                                                  \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], BS, acc[I][J], 0, 0, 0);                               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], bl[J], acc[I][J], 0, 0, 0);                            \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[I], BS, acc[I][J], 0, 0, 0);                               \
+  }
+#define GVL_G_BLOCK(J, PRE, MID, POST)                                                                               \
+  {                                                                                                                  \
+    PRE                                                                                                              \
+    const h8 bs = bh[J] * k2048;                                                                                     \
+    GVL_G_MFMA3(0, J, bs)                                                                                            \
+    GVL_G_MFMA3(1, J, bs)                                                                                            \
+    MID                                                                                                              \
+    GVL_G_MFMA3(2, J, bs)                                                                                            \
+    GVL_G_MFMA3(3, J, bs)                                                                                            \
+    POST                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+    // one K stage.  On entry: the A fragments (ah not yet scaled) and the B blocks 0, 1 of the stage are in registers.
+    // Blocks 0-2 request B blocks 2-4 and issue units 4-6 of the stage after next (its buffer was freed by the last barrier);
+    // then every read of `cur` has been issued: barrier; blocks 3, 4 read the next stage's first fragments from `nxt` (A in
+    // place, pair by pair) and issue units 0-3 of the stage three ahead into `cur`.
+#define GVL_G_STAGE()                                                                                                \
+  {                                                                                                                  \
+    GVL_G_BLOCK(0, GVL_G_RDB(cur, 2, bh[2], bl[2]) GVL_G_ISSUE(4, 2, nn) ah[0] = ah[0] * k2048; ah[1] = ah[1] * k2048;, \
+                __builtin_amdgcn_sched_barrier(0); ah[2] = ah[2] * k2048; ah[3] = ah[3] * k2048;, )                  \
+    GVL_G_BLOCK(1, GVL_G_RDB(cur, 3, bh[3], bl[3]) GVL_G_ISSUE(5, 2, nn), , )                                        \
+    GVL_G_BLOCK(2, GVL_G_RDB(cur, 4, bh[4], bl[4]) GVL_G_ISSUE(6, 2, nn), , )                                        \
+    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    asm volatile("" ::: "memory");                                                                                   \
+    GVL_G_BLOCK(3, GVL_G_RDB(nxt, 0, nh[0], nl[0]) GVL_G_ISSUE(0, 3, cur) GVL_G_ISSUE(1, 3, cur), , )                \
+    GVL_G_BLOCK(4, GVL_G_RDB(nxt, 1, nh[1], nl[1]) GVL_G_ISSUE(2, 3, cur) GVL_G_ISSUE(3, 3, cur),                    \
+                __builtin_amdgcn_sched_barrier(0); GVL_G_RDA(nxt, 0) GVL_G_RDA(nxt, 1),                              \
+                __builtin_amdgcn_sched_barrier(0); GVL_G_RDA(nxt, 2) GVL_G_RDA(nxt, 3))                              \
+    bh[0] = nh[0]; bl[0] = nl[0]; bh[1] = nh[1]; bl[1] = nl[1];                                                      \
+    {                                                                                                                \
+      uint4 *t_ = cur;                                                                                               \
+      cur = nxt;                                                                                                     \
+      nxt = nn;                                                                                                      \
+      nn = t_;                                                                                                       \
+    }                                                                                                                \
+    ++kt;                                                                                                            \
+  }
+
+#ifdef GVL_G_STAMPS                                                    /* dev: 10 ns ticks of workgroup 0's phases */
+    const uint64_t ts0 = __builtin_amdgcn_s_memrealtime();
+#define GVL_G_T(X) const uint64_t X = __builtin_amdgcn_s_memrealtime();
+#else
+#define GVL_G_T(X)
+#endif
+    // prologue: stages 0 and 1 whole, units 0-3 of stage 2 (what stage "-1" would have issued under its blocks 3, 4)
+    kt = -2;
+    GVL_G_ISSUE(0, 2, cur) GVL_G_ISSUE(1, 2, cur) GVL_G_ISSUE(2, 2, cur) GVL_G_ISSUE(3, 2, cur) GVL_G_ISSUE(4, 2, cur)
+    GVL_G_ISSUE(5, 2, cur) GVL_G_ISSUE(6, 2, cur)
+    kt = -1;
+    GVL_G_ISSUE(0, 2, nxt) GVL_G_ISSUE(1, 2, nxt) GVL_G_ISSUE(2, 2, nxt) GVL_G_ISSUE(3, 2, nxt) GVL_G_ISSUE(4, 2, nxt)
+    GVL_G_ISSUE(5, 2, nxt) GVL_G_ISSUE(6, 2, nxt)
+    kt = 0;
+    GVL_G_ISSUE(0, 2, nn) GVL_G_ISSUE(1, 2, nn) GVL_G_ISSUE(2, 2, nn) GVL_G_ISSUE(3, 2, nn)
+    float ratio[NJ];                                                   // h's row scale over att's, per column of this lane
+    {
+      float s1[NJ], s2[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = min(tn * kRowsB + wb + 16 * j + (lane & 15), N - 1);
+        s1[j] = B1s[col];
+        s2[j] = B2s[col];
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) ratio[j] = s1[j] / s2[j];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (false)
+    wait_vmcnt<11>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GVL_G_RDA(cur, i)
+    GVL_G_RDB(cur, 0, bh[0], bl[0])
+    GVL_G_RDB(cur, 1, bh[1], bl[1])
+    // the recurrent half (h at its own row scale), then the accumulators move to att's scale, then the attention half: two
+    // loops, no branch inside a K loop
+    GVL_G_T(ts1)
+    for (; kt < KT1;) GVL_G_STAGE()
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = acc[i][j] * ratio[j];
+    for (; kt < KT;) GVL_G_STAGE()
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (the re-fetched stages) -- the ring becomes scratch
+    GVL_G_T(ts2)
+    __syncthreads();
+
+    // ---- the cell.  Lane (fc, fq): hidden row col0 + 16 j + fc, gates 0-3 of unit (row0 >> 2) + 4 i + fq
+    {
+      const int fc = lane & 15, fq = lane >> 4, H = ge.H;
+      const int row0 = tm * kRowsA + wa, col0 = tn * kRowsB + wb;
+      constexpr float kInv22 = 1.f / 4194304.f;
+      float *img_c = reinterpret_cast<float *>(smem), *img_h = img_c + kRowsB * kLdT;
+      float rs[4][4];
+      int g0[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g0[i] = min(row0 + 16 * i + 4 * fq, R - 4);                    // (4H % 4 == 0: a lane's four gate rows exist or none does)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[i][r] = As[g0[i] + r] * kInv22;
+      }
+      int colv[NJ], tokv[NJ];
+      float csv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        colv[j] = min(col0 + 16 * j + fc, N - 1);
+        tokv[j] = (int)ge.it[colv[j]];
+        csv[j] = B2s[colv[j]];
+      }
+      auto batch = [&](auto j_begin, auto j_count) {
+        constexpr int J0 = decltype(j_begin)::value, JC = decltype(j_count)::value;
+        float4 gc[JC][4], em[JC][4];
+        float cp[JC][4];
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            gc[jj][i] = ge.gates_c ? *reinterpret_cast<const float4 *>(ge.gates_c + (int64_t)colv[J0 + jj] * ge.ld_c + g0[i])
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            em[jj][i] = *reinterpret_cast<const float4 *>(ge.emb + (int64_t)tokv[J0 + jj] * R + g0[i]);
+            cp[jj][i] = ge.c[(int64_t)colv[J0 + jj] * H + (g0[i] >> 2)];
+          }
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int j = J0 + jj;
+            const float s0 = rs[i][0] * csv[j], s1 = rs[i][1] * csv[j], s2 = rs[i][2] * csv[j], s3 = rs[i][3] * csv[j];
+            const float gi = (gc[jj][i].x + acc[i][j][0] * s0) + em[jj][i].x, gf = (gc[jj][i].y + acc[i][j][1] * s1) + em[jj][i].y,
+                        gg = (gc[jj][i].z + acc[i][j][2] * s2) + em[jj][i].z, go = (gc[jj][i].w + acc[i][j][3] * s3) + em[jj][i].w;
+            float cn, hn;
+            gvl_lstm_point(gi, gf, gg, go, cp[jj][i], cn, hn);
+            const int at = (wb + 16 * j + fc) * kLdT + (wa >> 2) + 4 * i + fq;
+            img_c[at] = cn;
+            img_h[at] = hn;
+          }
+      };
+      batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+      batch(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+      GVL_G_T(ts3)
+      __syncthreads();
+      // whole row segments out: thread (r, u4) takes units 4 u4 .. 4 u4 + 3 of rows r, r + 32, ...
+      const int u4 = tid & 15, unit = tm * (kRowsA >> 2) + 4 * u4;
+      if (unit < H) {
+#pragma unroll
+        for (int r = tid >> 4; r < kRowsB; r += 32) {
+          const int row = tn * kRowsB + r;
+          if (row >= N) break;
+          const float4 cv = *reinterpret_cast<const float4 *>(img_c + r * kLdT + 4 * u4);
+          float4 hv = *reinterpret_cast<const float4 *>(img_h + r * kLdT + 4 * u4);
+          asm volatile("" : "+v"(hv.x), "+v"(hv.y), "+v"(hv.z), "+v"(hv.w));   // (h' as the fp32 numbers stored: see lstm_finish)
+          *reinterpret_cast<float4 *>(ge.c_out + (int64_t)row * H + unit) = cv;
+          *reinterpret_cast<float4 *>(ge.h_out + (int64_t)row * H + unit) = hv;
+          const float hx[4] = {hv.x, hv.y, hv.z, hv.w};
+          _Float16 hh[4], hl[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            hh[q] = (_Float16)hx[q];
+            hl[q] = (_Float16)((hx[q] - (float)hh[q]) * 2048.f);
+          }
+          const int64_t pat = plane_off(row, unit, N);
+          *reinterpret_cast<uint2 *>(ge.h_hi + pat) = make_uint2(pack2h(hh[0], hh[1]), pack2h(hh[2], hh[3]));
+          *reinterpret_cast<uint2 *>(ge.h_lo + pat) = make_uint2(pack2h(hl[0], hl[1]), pack2h(hl[2], hl[3]));
+          if (unit == 0) ge.h_scale[row] = 1.f;
+        }
+      }
+      __syncthreads();                                                 // the images are free before the next tile's DMA
+#ifdef GVL_G_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (blockIdx.x == 8 && tid == 0)
+        printf("k_gates: prologue %d, K loop %d, cell %d, stores %d ticks of 10 ns\n", (int)(ts1 - ts0), (int)(ts2 - ts1),
+               (int)(ts3 - ts2), (int)(__builtin_amdgcn_s_memrealtime() - ts3));
+#endif
+    }
+#undef GVL_G_T
+#undef GVL_G_STAGE
+#undef GVL_G_BLOCK
+#undef GVL_G_MFMA3
+#undef GVL_G_RDB
+#undef GVL_G_RDA
+#undef GVL_G_ISSUE
+  }
+#undef GVL_G_DMA
+}
+
 // partials (chunks, R) of {max, sum exp(v - max), index, -} -> per row argmax and log-softmax at the argmax, plus the
 // bookkeeping of one greedy step (gvl_cap.hip: k_row_argmax_lse has the same tail).  Block = 16 rows x 16 chunk groups:
 // 16 lanes read 256 contiguous bytes of one chunk row; 300 workgroups at R = 4800.
@@ -1446,6 +1753,43 @@ extern "C" int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const
   return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3<lstm>", (x1 ? k_gemm_f16x3<64, kLstm, true> : k_gemm_f16x3<64, kLstm, false>), dim3((tiles_m * tiles_n + 7) / 8 * 8),
                      dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, w_scale, (const float *)nullptr, R, N, K,
                      (float *)nullptr, (int64_t)0, tiles_m, tiles_n, le);
+}
+
+// k_gates_f16x3 serves a token step when its 256 x 160 tiles fill most of the chip in whole rounds (cfg A: 8 x 30 = 240 tiles)
+extern "C" int gvl_gemm_f16x3_gates_applicable(int n, int H) {
+  if (n <= 0 || H <= 0 || (H & 31)) return 0;
+  const int tiles = ((4 * H + 255) / 256) * ((n + 159) / 160), cus = persistent_grid(1 << 20);
+  const int rounds = (tiles + cus - 1) / cus;
+  return 10 * tiles >= 7 * rounds * cus;
+}
+
+extern "C" int gvl_gemm_f16x3_gates_f32(const void *a_hi, const void *a_lo, const float *a_scale, const void *hp_hi,
+                                        const void *hp_lo, const float *hp_scale, int n, const void *w_hi, const void *w_lo,
+                                        const float *w_scale, int H, int K_h, int K_a, const float *gates_c, int64_t ld_c,
+                                        const float *emb_gates, const int64_t *it, const float *c, float *h_out, float *c_out,
+                                        void *h_hi, void *h_lo, float *h_scale, void *stream) {
+  const int N4 = 4 * H, K = K_h + K_a;
+  if (H <= 0 || (H & 31)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: H must be a positive multiple of 32 (got %d)", H);
+  if (K_h < kBK || K_a < kBK || (K_h % kBK) || (K_a % kBK) || K < 3 * kBK)
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: K_h and K_a must be positive multiples of 32, three stages in all (got %d, %d)", K_h, K_a);
+  if (gvl16::g_f16_products != 3) return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: the exact (three-product) form only");
+  if (int rc = check_operands("gvl_gemm_f16x3_gates_f32", w_hi, w_lo, w_scale, N4, a_hi, a_lo, a_scale, n, K)) return rc;
+  if (gates_c && (ld_c < N4 || (ld_c & 3)))
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: gates_c needs a row stride >= 4H, a multiple of 4");
+  if (n == 0) return 0;
+  if (!hp_hi || !hp_lo || !hp_scale || !emb_gates || !it || !c || !h_out || !c_out || !h_hi || !h_lo || !h_scale)
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: null pointer");
+  if (hp_hi == h_hi || hp_lo == h_lo || c == c_out)
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: the new state must not overwrite the one the step reads");
+  if ((((uintptr_t)hp_hi | (uintptr_t)hp_lo | (uintptr_t)gates_c | (uintptr_t)emb_gates | (uintptr_t)h_out | (uintptr_t)c_out
+        | (uintptr_t)h_hi | (uintptr_t)h_lo) & 15))
+    return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: planes, gate operands and outputs must be 16-byte aligned");
+  const GatesEpi ge = {gates_c, ld_c, emb_gates, it, c, h_out, c_out, (_Float16 *)h_hi, (_Float16 *)h_lo, h_scale, H};
+  const int tiles_m = (N4 + 255) / 256, tiles_n = (n + 159) / 160;
+  return gvl::launch(GVL_PROF_GEMM16, n, N4, "k_gates_f16x3", k_gates_f16x3, dim3(persistent_grid(tiles_m * tiles_n)), dim3(512),
+                     0, (hipStream_t)stream, (const _Float16 *)w_hi, (const _Float16 *)w_lo, w_scale, (const _Float16 *)hp_hi,
+                     (const _Float16 *)hp_lo, hp_scale, (const _Float16 *)a_hi, (const _Float16 *)a_lo, a_scale, N4, n, K_h, K_a,
+                     tiles_m, tiles_n, ge);
 }
 
 extern "C" int gvl_gemm_f16x3_argmax_chunks(int V) { return V > 0 ? (V + kBM - 1) / kBM * 2 : 0; }

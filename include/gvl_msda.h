@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 12  /* 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch); 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 12  /* 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch), gvl_gemm_f16x3_gates_f32 / _applicable (both halves of the LSTM gate product + cell in one launch); 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -288,6 +288,19 @@ int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const float *a_s
                             const void *w_lo, const float *w_scale, int H, int K, const float *gates_h, int64_t ld_h,
                             const float *gates_c, int64_t ld_c, const float *emb_gates, const int64_t *it, const float *c,
                             float *h_out, float *c_out, void *h_hi, void *h_lo, float *h_scale, void *stream);
+/*    gvl_gemm_f16x3_gates_f32 (ABI 12): BOTH halves of the LSTM gate product of a token step in one launch, the cell applied:
+ *        gates = [h | A] (n, K_h + K_a) . W (4H, K_h + K_a)^T + gates_c + emb_gates[it], (h', c') = cell(gates, c)
+ *        (LSTM_DSA.py:267-269 + nn.LSTM's pointwise part) -- the first K_h contraction columns of W (nn.LSTM's weight_hh) multiply
+ *        the planes (hp_*) of the step's incoming hidden state, the other K_a (weight_ih's attention columns) the planes of A;
+ *        rows of W, columns of gates_c / emb_gates in the order 4 * unit + gate as for gvl_gemm_f16x3_lstm_f32.  The (n, 4H)
+ *        recurrent part is neither written by a product in front nor read here.  The new state (h_out, c_out, planes) must be
+ *        other buffers than the incoming one; outputs 16-byte aligned.  gvl_gemm_f16x3_gates_applicable(n, H): 1 when the
+ *        kernel's 256 x 160 tiles fill the chip in whole rounds (cfg A: 240 tiles), else the two-launch form is the faster one. */
+int gvl_gemm_f16x3_gates_applicable(int n, int H);
+int gvl_gemm_f16x3_gates_f32(const void *a_hi, const void *a_lo, const float *a_scale, const void *hp_hi, const void *hp_lo,
+                             const float *hp_scale, int n, const void *w_hi, const void *w_lo, const float *w_scale, int H,
+                             int K_h, int K_a, const float *gates_c, int64_t ld_c, const float *emb_gates, const int64_t *it,
+                             const float *c, float *h_out, float *c_out, void *h_hi, void *h_lo, float *h_scale, void *stream);
 int gvl_gemm_f16x3_argmax_chunks(int V);
 int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, const float *x_scale, int R, const void *w_hi,
                               const void *w_lo, const float *w_scale, int V, int K, const float *bias, float *partials,

@@ -272,3 +272,51 @@ def test_cell_in_the_product_s_epilogue_equals_product_then_cell_kernel(n, K, H,
     c_ref = torch.sigmoid(f_) * c.double() + torch.sigmoid(i_) * torch.tanh(g_)
     h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
     assert float((c1.double() - c_ref).abs().max()) < 2e-5 and float((h1.double() - h_ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("n,Ka,H,with_c", [(4800, 512, 512, True), (300, 512, 512, True), (157, 192, 128, False), (1, 128, 128, True),
+                                           (1100, 96, 160, True), (5200, 512, 512, True), (333, 64, 32, True)])
+def test_both_halves_of_the_gate_product_in_one_launch(n, Ka, H, with_c):
+    """gvl_gemm_f16x3_gates_f32 -- contraction [h | att] against [W_hh | W_ih[att]] in one launch, the accumulators re-scaled from
+    h's row scale to att's between the halves, the cell applied -- against the two-launch form of round 4 (gvl_gemm_f16x3_f32 over
+    h, its output as the gates_h operand of gvl_gemm_f16x3_lstm_f32): same cell, same operands, one fp32 accumulator per output
+    instead of two and another order of the final additions -> fp32 rounding; and against the cell in fp64.  Ragged tiles in both
+    directions, several tiles per workgroup (5200 rows), att rows over several orders of magnitude."""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(n + H + Ka)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)                         # noqa: E731
+    att = rnd(n, Ka) * torch.exp2(torch.randint(-6, 7, (n, 1), device=dev, generator=g).float())
+    h_prev = torch.tanh(rnd(n, H))
+    w_att, w_hh = rnd(4 * H, Ka) * Ka ** -0.5, rnd(4 * H, H) * H ** -0.5
+    gates_c = rnd(n, 4 * H) if with_c else None
+    V = 50
+    emb = rnd(V, 4 * H)
+    it = torch.randint(0, V, (n,), device=dev, generator=g)
+    c = rnd(n, H)
+    perm = MSDA.gate_permutation(H, dev)
+    ap, hp = MSDA.split_rows(att), MSDA.split_rows(h_prev)
+    gc_p = gates_c[:, perm].contiguous() if with_c else None
+    emb_p = emb[:, perm].contiguous()
+    assert MSDA.gates_applicable(4800, 512) and not MSDA.gates_applicable(300, 512)
+    gates_h = MSDA.gemm_f16x3(hp, MSDA.split_rows(w_hh[perm].contiguous()))
+    h0, c0 = MSDA.gemm_f16x3_lstm(ap, MSDA.split_rows(w_att[perm].contiguous()), gates_h, gc_p, emb_p, it, c)
+    w_cat = MSDA.split_rows(torch.cat([w_hh[perm], w_att[perm]], 1).contiguous())
+    for _ in range(2):
+        h1, c1 = MSDA.gemm_f16x3_gates(ap, hp, w_cat, gc_p, emb_p, it, c)
+        torch.cuda.synchronize()
+        gmax = float((att.abs() @ w_att.abs().t() + h_prev.abs() @ w_hh.abs().t()).max()) + 8.0     # magnitude of the gate sums
+        ab = 2.0 ** -20 * gmax                                         # (a few fp32 roundings at that magnitude; |c'| <= |c| + 1)
+        assert float((c1 - c0).abs().max()) < ab * max(1.0, float(c0.abs().max()))
+        assert float((h1 - h0).abs().max()) < ab
+    p1 = h1._gvl_planes
+    hi, lo = p1.dense()
+    assert bool((p1.scale == 1.0).all())
+    assert bool(((hi.double() + lo.double() / 2048.0 - h1.double()).abs() <= 2.0 ** -22 * h1.abs().double() + 2.0 ** -34).all())
+    gates = (att.double() @ w_att.double().t() + h_prev.double() @ w_hh.double().t() + (gates_c.double() if with_c else 0)
+             + emb.double()[it])
+    i_, f_, g_, o_ = gates.chunk(4, 1)
+    c_ref = torch.sigmoid(f_) * c.double() + torch.sigmoid(i_) * torch.tanh(g_)
+    h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
+    tol = 2e-5 * max(1.0, float(gates.abs().max()))
+    assert float((c1.double() - c_ref).abs().max()) < tol and float((h1.double() - h_ref).abs().max()) < tol
