@@ -34,6 +34,8 @@ from .. import MultiScaleDeformableAttention as MSDA
 from ..linear import Linear, split_gemm_enabled, split_linear, vocab_nll, vocab_nll_eligible
 
 
+_GREEDY_MERGED = os.environ.get("GVL_GREEDY_MERGED", "1") != "0"      # (A/B: h2att(h) as a launch of its own)
+
 class ShowAttendTellCore(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -228,13 +230,14 @@ class ShowAttendTellCore(nn.Module):
             const["host_starts"] = tuple(host[1]) if host is not None else None
         A = self.att_hid_size
         split = "w_h_cat_p" in const and h.dtype == torch.float32
-        gates_one = (split and "w_gate_cat_p" in const and const["slab3"].dtype == torch.float32
-                     and MSDA.f16_products_now() == 3 and MSDA.gates_applicable(h.shape[0], self.rnn_size))
+        gates_one = split and self.gates_in_one_launch(h, const)
         if split:
             hp = getattr(h, "_gvl_planes", None)                         # left by the vocabulary product of the last step
             hp = hp if hp is not None else MSDA.split_rows(h)
             if gates_one:
-                g_h = MSDA.gemm_f16x3(hp, const["w_h2att_p"], const["b_h2att"])            # (n, A): h2att(h) only
+                g_h = getattr(h, "_gvl_h2att", None)                     # left by the greedy step's launch (_greedy_iterations)
+                if g_h is None:
+                    g_h = MSDA.gemm_f16x3(hp, const["w_h2att_p"], const["b_h2att"])        # (n, A): h2att(h) only
             else:
                 g_h = MSDA.gemm_f16x3(hp, const["w_h_cat_p"], const["b_h_cat"])
         else:
@@ -251,6 +254,12 @@ class ShowAttendTellCore(nn.Module):
         if split:                                                       # att_res arrives as the planes of the product
             return MSDA.gemm_f16x3(att_res, const["w_att_p"]), g_h
         return torch.mm(att_res, const["w_att_t"]), g_h                 # (the hs part, gates_hs, is added in the cell)
+
+    def gates_in_one_launch(self, h, const):
+        """whether this step's gate product runs as gvl_gemm_f16x3_gates_f32 (the product over h in front of the attention is
+        then h2att(h) alone)"""
+        return ("w_gate_cat_p" in const and h.dtype == torch.float32 and const["slab3"].dtype == torch.float32
+                and MSDA.f16_products_now() == 3 and MSDA.gates_applicable(h.shape[0], self.rnn_size))
 
     def cell_part(self, g_x, g_h, xt_gates, c, const):
         """(gate parts, input token) -> (h', c')"""
@@ -674,7 +683,15 @@ class Captioner(nn.Module):
         T = self.max_caption_len
         for t in range(t0, t1):
             if t > 0:
-                st["it"] = MSDA.greedy_step(st["logits"], t - 1, st["unfinished"], st["seq"], st["seq_lp"], st["alive"])
+                hp = getattr(st["h"], "_gvl_planes", None)
+                if (t < T and hp is not None and _GREEDY_MERGED and isinstance(st["logits"], MSDA.GreedyPartials)
+                        and "w_off_h" in st["const"] and self.core.gates_in_one_launch(st["h"], st["const"])):
+                    # the reduction of token t - 1 and h2att(h) of token t depend on different results of the last step: one launch
+                    st["it"], st["h"]._gvl_h2att = MSDA.greedy_step_and_gemm(
+                        st["logits"], t - 1, st["unfinished"], st["seq"], st["seq_lp"], st["alive"], hp,
+                        st["const"]["w_h2att_p"], st["const"]["b_h2att"])
+                else:
+                    st["it"] = MSDA.greedy_step(st["logits"], t - 1, st["unfinished"], st["seq"], st["seq_lp"], st["alive"])
             if t < T:
                 out, (st["h"], st["c"]) = self.core.step((st["emb_gates"], st["it"]), (st["h"], st["c"]), st["hs"],
                                                          st["ref_in"], st["tshapes"], st["lsi"], st["const"])

@@ -739,6 +739,33 @@ def greedy_step(logits, t_col, unfinished, seq, seq_lp, alive=None):
     return tok
 
 
+def greedy_step_and_gemm(logits, t_col, unfinished, seq, seq_lp, alive, a, b, bias=None):
+    """greedy_step on GreedyPartials AND, in the same launch, gemm_f16x3(a, b, bias) (include/gvl_msda.h:
+    gvl_greedy_step_partials_gemm_f32) -> (raw argmax tokens (R,) int64, a . b^T + bias (Ra, Nb) fp32)"""
+    _require(isinstance(logits, GreedyPartials), "greedy_step_and_gemm: logits must be the GreedyPartials of gemm_f16x3_argmax")
+    _require(unfinished.dtype == torch.uint8 and seq.dtype == torch.int64 and seq_lp.dtype == torch.float32
+             and seq.is_contiguous() and seq_lp.is_contiguous() and seq.shape == seq_lp.shape
+             and seq.shape[0] == logits.rows, "greedy_step_and_gemm: bad bookkeeping tensors")
+    _require(alive is None or (alive.dtype == torch.uint8 and alive.is_contiguous() and alive.numel() > t_col),
+             "greedy_step_and_gemm: alive must be a (T,) uint8 tensor")
+    _require(a.cols == b.cols, "greedy_step_and_gemm: inner dimensions differ")
+    _require(bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == b.rows),
+             "greedy_step_and_gemm: bias must be contiguous fp32 of length N")
+    p = logits
+    tok = torch.empty(p.rows, dtype=torch.int64, device=p.part.device)
+    lp = torch.empty(p.rows, dtype=torch.float32, device=p.part.device)
+    out = torch.empty(a.rows, b.rows, device=a.hi.device, dtype=torch.float32)
+    with torch.cuda.device(p.part.device):
+        rc = _lib.lib().gvl_greedy_step_partials_gemm_f32(
+            p.part.data_ptr(), p.rows, p.vocab, 1 if t_col == 0 else 0, tok.data_ptr(), lp.data_ptr(), unfinished.data_ptr(),
+            seq.data_ptr() + 8 * t_col, seq_lp.data_ptr() + 4 * t_col, seq.shape[1],
+            alive.data_ptr() + t_col if alive is not None else None, a.hi.data_ptr(), a.lo.data_ptr(), a.scale.data_ptr(), a.rows,
+            b.hi.data_ptr(), b.lo.data_ptr(), b.scale.data_ptr(), b.rows, a.cols, bias.data_ptr() if bias is not None else None,
+            out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "greedy_step_partials_gemm")
+    return tok, out
+
+
 PROF_TAGS = {1: "fwd_t1d_d64", 2: "fwd_generic", 3: "bwd_t1d_d64", 4: "bwd_generic", 5: "sample", 6: "sum_partials",
              7: "sample_bwd", 8: "cap_attend", 9: "row_argmax_lse", 10: "lstm_cell", 11: "lsap",
              12: "cap_train_fwd", 13: "cap_train_bwd", 14: "lstm_train", 15: "match_cost", 16: "criterion",

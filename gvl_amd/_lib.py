@@ -91,6 +91,7 @@ SIGNATURES = {
     "gvl_pyramid_geometry_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _P, _P]),
     "gvl_encoder_geometry_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "gvl_greedy_step_partials_alive_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "gvl_greedy_step_partials_gemm_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _I64, _P]),
     "gvl_box_refine_f32": (_I, [_P, _I64, _P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "gvl_count_head_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),

@@ -313,11 +313,11 @@ __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)
 
 // ---- four wavefronts, 128 x BN tile, two LDS stages: the form for few rows / few tiles (three workgroups per CU at BN = 64)
 template <int BN, int EPI, bool X1 = false>
-__global__ void __launch_bounds__(256, 2)
-    k_gemm_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
-                 const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
-                 const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo, int tiles_m,
-                 int tiles_n, const LstmEpi le) {
+__device__ __forceinline__ void gemm4_body(int bid, const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al,
+                                           const float *__restrict__ As, const _Float16 *__restrict__ Bh,
+                                           const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
+                                           const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out,
+                                           int64_t ldo, int tiles_m, int tiles_n, const LstmEpi &le) {
   constexpr int NJ = BN / 64;                                         // 32-column MFMA tiles per wavefront
   // ONE LDS object (a second one beside an LDS-DMA target can make hipcc drain the DMA before every ds_read):
   // [stage][A hi | A lo | B hi | B lo][row * 4 + swizzled chunk], 16-byte slots
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256, 2)
   __shared__ uint4 smem[2 * kStageSlots];
 
   int tm, tn;
-  if (!tile_of((int)blockIdx.x, tiles_m, tiles_n, tm, tn)) return;
+  if (!tile_of(bid, tiles_m, tiles_n, tm, tn)) return;
   const int m0 = tm * kBM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
@@ -393,6 +393,15 @@ __global__ void __launch_bounds__(256, 2)
   // (kLstm: one 32-row block at a time -- 64 registers fewer than both in flight, which keeps three workgroups on a CU; the
   //  other workgroups' products cover the block's load latency)
   epilogue<NJ, EPI, true>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo, le);
+}
+
+template <int BN, int EPI, bool X1 = false>
+__global__ void __launch_bounds__(256, 2)
+    k_gemm_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
+                 const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
+                 const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo, int tiles_m,
+                 int tiles_n, const LstmEpi le) {
+  gemm4_body<BN, EPI, X1>((int)blockIdx.x, Ah, Al, As, Bh, Bl, Bs, bias, R, N, K, out, ldo, tiles_m, tiles_n, le);
 }
 
 // ---- eight wavefronts (WM x WN, 64 x 64 each), tile 64 WM x 64 WN, THREE LDS stages with the DMA two stages ahead.
@@ -1564,12 +1573,11 @@ struct GreedyBook {
 
 constexpr int kRedRows = 16, kRedGroups = 16;
 
-__global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__restrict__ part, int R, int chunks,
-                                                              int64_t *__restrict__ idx, float *__restrict__ logp,
-                                                              GreedyBook book) {
+__device__ __forceinline__ void greedy_body(int bid, const float4 *__restrict__ part, int R, int chunks,
+                                            int64_t *__restrict__ idx, float *__restrict__ logp, const GreedyBook &book) {
   __shared__ float s_m[kRedGroups][kRedRows], s_s[kRedGroups][kRedRows];
   __shared__ int s_a[kRedGroups][kRedRows];
-  const int rr = threadIdx.x % kRedRows, g = threadIdx.x / kRedRows, row = blockIdx.x * kRedRows + rr;
+  const int rr = threadIdx.x % kRedRows, g = threadIdx.x / kRedRows, row = bid * kRedRows + rr;
   float m = -INFINITY, s = 0.f;
   int a = 0x7fffffff;
   if (row < R) {
@@ -1613,6 +1621,39 @@ __global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__re
       book.seq_lp[(int64_t)row * book.seq_ld] = lp;
       if (unf && book.alive) *book.alive = 1;                           // (every writer stores the same value)
     }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_greedy_from_partials(const float4 *__restrict__ part, int R, int chunks,
+                                                              int64_t *__restrict__ idx, float *__restrict__ logp,
+                                                              GreedyBook book) {
+  greedy_body((int)blockIdx.x, part, R, chunks, idx, logp, book);
+}
+
+// ONE launch for two independent pieces of a token step: the greedy bookkeeping of token t (from the vocabulary product's
+// partials) and a plain product over the hidden state for token t + 1 (h2att(h): gvl_gemm_f16x3_f32's four-wavefront form).  The
+// product's workgroups come first (they run 16 us, the 300 reduction workgroups 6 us beside them); saves a launch and the
+// reduction's time per token.
+struct GemmArgs {
+  const _Float16 *Ah, *Al;
+  const float *As;
+  const _Float16 *Bh, *Bl;
+  const float *Bs, *bias;
+  int R, N, K;
+  float *out;
+  int64_t ldo;
+  int tiles_m, tiles_n, blocks;
+};
+
+__global__ void __launch_bounds__(256, 2) k_greedy_and_gemm(const GemmArgs ga, const float4 *__restrict__ part, int R, int chunks,
+                                                            int64_t *__restrict__ idx, float *__restrict__ logp,
+                                                            GreedyBook book) {
+  if ((int)blockIdx.x < ga.blocks) {
+    const LstmEpi none = {};
+    gemm4_body<64, kStore, false>((int)blockIdx.x, ga.Ah, ga.Al, ga.As, ga.Bh, ga.Bl, ga.Bs, ga.bias, ga.R, ga.N, ga.K, ga.out,
+                                  ga.ldo, ga.tiles_m, ga.tiles_n, none);
+  } else {
+    greedy_body((int)blockIdx.x - ga.blocks, part, R, chunks, idx, logp, book);
   }
 }
 
@@ -1857,4 +1898,27 @@ extern "C" int gvl_greedy_step_partials_alive_f32(const float *partials, int R, 
   return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_from_partials", k_greedy_from_partials, dim3((R + kRedRows - 1) / kRedRows),
                      dim3(256), 0, (hipStream_t)stream, (const float4 *)partials, R, gvl_gemm_f16x3_argmax_chunks(V), token,
                      logp, book);
+}
+
+extern "C" int gvl_greedy_step_partials_gemm_f32(const float *partials, int R, int V, int first_step, int64_t *token, float *logp,
+                                                 unsigned char *unfinished, int64_t *seq_col, float *seq_lp_col, int seq_ld,
+                                                 unsigned char *alive, const void *a_hi, const void *a_lo, const float *a_scale,
+                                                 int Ra, const void *b_hi, const void *b_lo, const float *b_scale, int Nb, int K,
+                                                 const float *bias, float *out, int64_t ldo, void *stream) {
+  if (R <= 0 || V <= 0 || (unfinished && seq_ld <= 0)) return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: bad sizes");
+  if (!partials || !token || !logp || (unfinished && (!seq_col || !seq_lp_col)))
+    return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: null pointer");
+  if (gvl16::g_f16_products != 3) return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: the exact (three-product) form only");
+  if (int rc = check_operands("gvl_greedy_step_partials_gemm_f32", a_hi, a_lo, a_scale, Ra, b_hi, b_lo, b_scale, Nb, K)) return rc;
+  if (Ra <= 0 || !out || ldo < Nb) return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: product output missing / ldo < N");
+  const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0, unfinished ? alive : nullptr};
+  GemmArgs ga;
+  ga.Ah = (const _Float16 *)a_hi; ga.Al = (const _Float16 *)a_lo; ga.As = a_scale;
+  ga.Bh = (const _Float16 *)b_hi; ga.Bl = (const _Float16 *)b_lo; ga.Bs = b_scale; ga.bias = bias;
+  ga.R = Ra; ga.N = Nb; ga.K = K; ga.out = out; ga.ldo = ldo;
+  ga.tiles_m = (Ra + kBM - 1) / kBM; ga.tiles_n = (Nb + 63) / 64;
+  ga.blocks = (ga.tiles_m * ga.tiles_n + 7) / 8 * 8;
+  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_and_gemm", k_greedy_and_gemm,
+                     dim3(ga.blocks + (R + kRedRows - 1) / kRedRows), dim3(256), 0, (hipStream_t)stream, ga,
+                     (const float4 *)partials, R, gvl_gemm_f16x3_argmax_chunks(V), token, logp, book);
 }

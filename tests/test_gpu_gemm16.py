@@ -320,3 +320,40 @@ def test_both_halves_of_the_gate_product_in_one_launch(n, Ka, H, with_c):
     h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
     tol = 2e-5 * max(1.0, float(gates.abs().max()))
     assert float((c1.double() - c_ref).abs().max()) < tol and float((h1.double() - h_ref).abs().max()) < tol
+
+
+@pytest.mark.parametrize("R,V,Ra,Nb", [(4800, 8518, 4800, 512), (100, 300, 77, 64), (33, 70, 1100, 200)])
+def test_greedy_reduction_and_an_independent_product_in_one_launch(R, V, Ra, Nb):
+    """gvl_greedy_step_partials_gemm_f32 = gvl_greedy_step_partials_alive_f32 + gvl_gemm_f16x3_f32 (its four-wavefront form) as ONE
+    launch: the same bits as the two launches -- tokens, log-probabilities, bookkeeping, product"""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(R + Nb)
+    K = 512
+    x = torch.randn(R, K, device=dev, generator=g)
+    w = torch.randn(V, K, device=dev, generator=g) * 0.05
+    xp, wp = MSDA.split_rows(x), MSDA.split_rows(w)
+    a, b = MSDA.split_rows(torch.randn(Ra, K, device=dev, generator=g)), MSDA.split_rows(torch.randn(Nb, K, device=dev, generator=g))
+    bias = torch.randn(Nb, device=dev, generator=g)
+    T = 4
+    res = []
+    for fused in (False, True):
+        unf = torch.empty(R, dtype=torch.uint8, device=dev)
+        seq = torch.zeros(R, T, dtype=torch.long, device=dev)
+        seq_lp = torch.zeros(R, T, device=dev)
+        alive = torch.zeros(T, dtype=torch.uint8, device=dev)
+        toks, outs = [], []
+        for t in range(2):
+            part = MSDA.gemm_f16x3_argmax(xp, wp)
+            if fused:
+                tok, out = MSDA.greedy_step_and_gemm(part, t, unf, seq, seq_lp, alive, a, b, bias)
+            else:
+                tok = MSDA.greedy_step(part, t, unf, seq, seq_lp, alive)
+                out = MSDA.gemm_f16x3(a, b, bias)
+                assert MSDA.last_gemm_form() if hasattr(MSDA, "last_gemm_form") else True
+            toks.append(tok)
+            outs.append(out)
+        res.append((unf, seq, seq_lp, alive, toks[0], toks[1], outs[0], outs[1]))
+    torch.cuda.synchronize()
+    for x0, x1 in zip(*res):
+        assert torch.equal(x0, x1)

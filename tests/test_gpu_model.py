@@ -696,7 +696,9 @@ def test_headline_batch_of_16_eval_matches_reference():
                 # base encoder + 2 encoder + 2 decoder layers + heads on gvl_linear_f16x3_f32 / the LayerNorm / attention-core /
                 # geometry kernels, four fused deformable-attention launches, the token loop's split-fp16 products
                 assert ran["layer_gemm"] >= 30 and ran["layer_norm_etc"] >= 10 and ran["fwd_t1d_d64"] == 4, ran
-                assert ran["gemm_f16x3"] >= 3 * 30 and ran["cap_attend"] >= 30, ran
+                # (per token: the gate product + cell and the vocabulary product under the gemm_f16x3 tag; h2att(h) rides in the
+                #  greedy reduction's launch, tagged row_argmax_lse)
+                assert ran["gemm_f16x3"] >= 2 * 30 and ran["cap_attend"] >= 30 and ran["row_argmax_lse"] >= 30, ran
             else:
                 out, loss = graphed(dt)
         assert maxerr(out["pred_boxes"], f["pred_boxes"]) <= 2e-4
