@@ -9,7 +9,7 @@ import sys
 d = sys.argv[1]
 steps = sys.argv[2] if len(sys.argv) > 2 else "auto"
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
-loop = ("k_gemm_f16x3", "k_cap_attend", "k_lstm_cell", "k_greedy_from_partials")
+loop = ("k_gemm_f16x3", "k_vocab_f16x3", "k_gates_f16x3", "k_cap_attend", "k_lstm_cell", "k_greedy_from_partials", "k_greedy_and_gemm")
 tot, cnt, loop_us = collections.Counter(), collections.Counter(), 0.0
 for r in csv.DictReader(open(f)):
     name, us = r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
