@@ -724,8 +724,10 @@ def main():
                        "library_gemm_selection": "gvl_amd/tunableop_mi355x.csv" if tuned else "hipBLASLt default",
                        "token_loop_gemms": ("gvl_gemm_f16x3: fp32 operands split into fp16 (hi, 2^11 residual) pairs that keep 22 of fp32's 24 significant bits (operand_bits = 22), "
                                             "3 fp16-MFMA partial products, fp32 accumulation -- error vs fp64 "
-                                            "below the fp32 GEMM's (tests/test_gpu_gemm16.py); vocabulary argmax / "
-                                            "log-sum-exp fused into the GEMM") if gemm16_on else "hipBLASLt fp32",
+                                            "below the fp32 GEMM's (tests/test_gpu_gemm16.py); per token: h2att(h) in the greedy "
+                                            "reduction's launch, both halves of the LSTM gate product + cell in one launch "
+                                            "(k_gates_f16x3), vocabulary product with argmax / log-sum-exp fused (k_vocab_f16x3)")
+                       if gemm16_on else "hipBLASLt fp32",
                        "inference_layers": ("gvl_amd/layers.py: every Linear of the encoder / decoder layers, the box MLP, the "
                                             "captioner's per-forward constants and the base encoder's conv1d levels on "
                                             "gvl_linear_f16x3_f32 (fp32 A split in the load path, fused bias / ReLU / residual / "
