@@ -4,7 +4,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgvl_msda.so")
+# GVL_LIB_PATH: a dev build (gvl_amd.build.build_dev: timing / ablation variants of single kernels) instead of the shipped library
+LIB_PATH = os.environ.get("GVL_LIB_PATH") or os.path.join(_HERE, "libgvl_msda.so")
 ABI_VERSION = 12          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None

@@ -43,9 +43,7 @@ def build(force=False, verbose=False, save_temps=None):
     os.makedirs(objdir, exist_ok=True)
     if save_temps:
         os.makedirs(save_temps, exist_ok=True)
-    # GVL_BUILD_DEFS="-DGVL_PHASE_TIMING": dev-only timing / ablation builds of single kernels (never the shipped library)
-    cflags = ([f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"]
-              + os.environ.get("GVL_BUILD_DEFS", "").split())
+    cflags = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"]
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -69,6 +67,43 @@ def build(force=False, verbose=False, save_temps=None):
     return OUT
 
 
+OUT_DEV = os.path.join(HERE, "libgvl_msda_dev.so")
+
+
+def build_dev(sources, defs, verbose=False):
+    """Timing / ablation builds of single kernels (`tools/*_ablate.sh`, `*_stamps.sh`): the named source files compiled with `defs`
+    (-DGVL_...) into build/obj_dev, linked with the SHIPPED library's other objects into gvl_amd/libgvl_msda_dev.so -- the shipped
+    library and its objects are never touched.  A process uses it through GVL_LIB_PATH (gvl_amd/_lib.py)."""
+    objdir, devdir = os.path.join(ROOT, "build", "obj"), os.path.join(ROOT, "build", "obj_dev")
+    have_all = all(os.path.exists(os.path.join(objdir, os.path.basename(s_) + ".o")) for s_ in SRC if os.path.exists(s_))
+    build(force=not have_all)                # (a checkout that carries the library but not its objects: compile them once)
+    cc = hipcc()
+    os.makedirs(devdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"] + list(defs)
+    names = {os.path.basename(n) for n in sources}
+    unknown = names - {os.path.basename(s) for s in SRC}
+    if unknown:
+        raise ValueError(f"build_dev: not a source of the library: {sorted(unknown)}")
+    objs = []
+    for src in [s for s in SRC if os.path.exists(s)]:
+        base = os.path.basename(src)
+        if base in names:
+            obj = os.path.join(devdir, base + ".o")
+            cmd = [cc] + cflags + ["-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=ROOT)
+        else:
+            obj = os.path.join(objdir, base + ".o")
+        objs.append(obj)
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT_DEV] + objs, cwd=ROOT)
+    return OUT_DEV
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True,
-                save_temps=os.path.join(ROOT, "build", "temps") if "--save-temps" in sys.argv else None))
+    if "--dev" in sys.argv:                  # python -m gvl_amd.build --dev gvl_gemm16.hip -DGVL_V_NO_EPI ...
+        rest = sys.argv[sys.argv.index("--dev") + 1:]
+        print(build_dev([a for a in rest if not a.startswith("-")], [a for a in rest if a.startswith("-")], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True,
+                    save_temps=os.path.join(ROOT, "build", "temps") if "--save-temps" in sys.argv else None))
