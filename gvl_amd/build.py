@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", n) for n in ("gvl_msda.hip", "gvl_cap.hip", "gvl_cap_train.hip", "gvl_criterion.hip", "gvl_lsap_dev.hip", "gvl_proj.hip", "gvl_gemm16.hip", "gvl_layers.hip", "gvl_train_layers.hip", "gvl_train_gemm.hip", "gvl_mha_train.hip", "gvl_lsap.cpp")]
+SRC = [os.path.join(HERE, "csrc", n) for n in ("gvl_msda.hip", "gvl_cap.hip", "gvl_cap_train.hip", "gvl_criterion.hip", "gvl_lsap_dev.hip", "gvl_proj.hip", "gvl_gemm16.hip", "gvl_layers.hip", "gvl_train_layers.hip", "gvl_train_gemm.hip", "gvl_mha_train.hip", "gvl_optim.hip", "gvl_lsap.cpp")]
 OUT = os.path.join(HERE, "libgvl_msda.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-pthread",
          "-Wall", "-Wno-unused-function"]

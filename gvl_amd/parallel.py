@@ -209,7 +209,16 @@ class TrainStep:
         fused = self.params[0].is_cuda
         self.optimizer = torch.optim.Adam(self.params, lr=opt.lr, weight_decay=opt.weight_decay,
                                           capturable=capturable, fused=fused)
+        # clip + step as three launches over a tensor table (gvl_amd/optim.py); torch's own launches wherever that does not apply
+        from .optim import ClipAdam
+        self.clip_adam = ClipAdam(self.optimizer, opt.grad_clip)
         self.world = world_size
+
+    def _clip_and_step(self):
+        active = [p for p in self.params if p.grad is not None]
+        if not self.clip_adam.step(active):
+            torch.nn.utils.clip_grad_norm_(active, self.opt.grad_clip)
+            self.optimizer.step()
 
     def _forward_loss(self, dt):
         # cache_enabled=False: autocast's weight-cast cache must not live across a hipGraph capture (the cached bf16
@@ -238,8 +247,7 @@ class TrainStep:
         hidden = [(p, p.grad) for p in self.buckets.unused_params()]
         for p, _ in hidden:
             p.grad = None                                   # as train.py's loop sees them: Adam skips these
-        torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], self.opt.grad_clip)
-        self.optimizer.step()
+        self._clip_and_step()
         for p, g in hidden:
             p.grad = g
         return final.detach(), _detached(loss)
@@ -497,8 +505,7 @@ class GraphedTrainStep(TrainStep):
         for p, _ in hidden:
             p.grad = None
         try:
-            torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], self.opt.grad_clip)
-            self.optimizer.step()
+            self._clip_and_step()
         finally:
             for p, g in hidden:
                 p.grad = g
