@@ -312,7 +312,10 @@ __device__ __forceinline__ void epilogue(f16acc (&acc_m)[2][NJ], f16acc (&acc_x)
 }
 
 // ---- four wavefronts, 128 x BN tile, two LDS stages: the form for few rows / few tiles (three workgroups per CU at BN = 64)
-template <int BN, int EPI, bool X1 = false>
+// DEEP: THREE stage buffers, the DMA two stages ahead and a counted wait at the stage barrier (as the eight-wavefront kernels):
+// with two buffers the barrier's vmcnt(0) waits for the DMA issued at the start of the same stage, i.e. every stage costs one
+// L2 round trip (0.9 us at 4800 x 512 x 512, whose MFMA work is 0.4 us per stage); 74 KB of LDS = two workgroups per CU.
+template <int BN, int EPI, bool X1 = false, bool DEEP = false>
 __device__ __forceinline__ void gemm4_body(int bid, const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al,
                                            const float *__restrict__ As, const _Float16 *__restrict__ Bh,
                                            const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
@@ -322,7 +325,7 @@ __device__ __forceinline__ void gemm4_body(int bid, const _Float16 *__restrict__
   // ONE LDS object (a second one beside an LDS-DMA target can make hipcc drain the DMA before every ds_read):
   // [stage][A hi | A lo | B hi | B lo][row * 4 + swizzled chunk], 16-byte slots
   constexpr int kASlots = kBM * 4, kBSlots = BN * 4, kStageSlots = 2 * kASlots + 2 * kBSlots;
-  __shared__ uint4 smem[2 * kStageSlots];
+  __shared__ uint4 smem[(DEEP ? 3 : 2) * kStageSlots];
 
   int tm, tn;
   if (!tile_of(bid, tiles_m, tiles_n, tm, tn)) return;
@@ -347,17 +350,43 @@ __device__ __forceinline__ void gemm4_body(int bid, const _Float16 *__restrict__
     const int row = (NBU * wave + u) * 16 + srow;
     b_src[u] = (int64_t)min(n0 + row, N - 1) * 32 + (spos ^ ((row >> 2) & 3)) * 8;
   }
+  // (DEEP: the buffer form of the DMA -- hipcc treats a pending global_load_lds as aliasing every LDS read and drains it,
+  //  vmcnt(0), in front of the next ds_read: the prefetch two stages ahead would be waited for at once)
+  // ... and even the buffer builtin is waited for (vmcnt(0)) in front of the stage's first ds_read here, so the instruction is
+  // written out: the compiler then neither knows the LDS write nor counts the load -- its own vmcnt waits only become more
+  // conservative (an uncounted younger load makes `vmcnt(n)` wait for more, never for less), the stage waits below are explicit
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  auto rsrc_of = [](const void *ptr) {
+    const uint64_t u = (uint64_t)(uintptr_t)ptr;
+    return v4i_{(int)__builtin_amdgcn_readfirstlane((uint32_t)u), (int)(__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)) & 0xffffu),
+                0x7fffffff, 0x00020000};
+  };
+  const v4i_ rs_ah = rsrc_of(Ah), rs_al = rsrc_of(Al), rs_bh = rsrc_of(Bh), rs_bl = rsrc_of(Bl);
+  auto bdma = [&](const v4i_ &rs, int64_t elem, uint4 *dst) {
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)dst);
+    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(2u * (uint32_t)elem), "s"(rs), "s"(lds) : "memory");   // (m0: hipcc writes it in front of each of its own uses and rejects it as a clobber)
+  };
   auto issue = [&](int k0, int buf) {
     uint4 *st = smem + buf * kStageSlots;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      glds16(Ah + a_src[u] + (int64_t)k0 * R, st + (2 * wave + u) * 64);
-      if constexpr (!X1) glds16(Al + a_src[u] + (int64_t)k0 * R, st + kASlots + (2 * wave + u) * 64);
+      if constexpr (DEEP) {
+        bdma(rs_ah, a_src[u] + (int64_t)k0 * R, st + (2 * wave + u) * 64);
+        if constexpr (!X1) bdma(rs_al, a_src[u] + (int64_t)k0 * R, st + kASlots + (2 * wave + u) * 64);
+      } else {
+        glds16(Ah + a_src[u] + (int64_t)k0 * R, st + (2 * wave + u) * 64);
+        if constexpr (!X1) glds16(Al + a_src[u] + (int64_t)k0 * R, st + kASlots + (2 * wave + u) * 64);
+      }
     }
 #pragma unroll
     for (int u = 0; u < NBU; ++u) {
-      glds16(Bh + b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + (NBU * wave + u) * 64);
-      if constexpr (!X1) glds16(Bl + b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
+      if constexpr (DEEP) {
+        bdma(rs_bh, b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + (NBU * wave + u) * 64);
+        if constexpr (!X1) bdma(rs_bl, b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
+      } else {
+        glds16(Bh + b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + (NBU * wave + u) * 64);
+        if constexpr (!X1) glds16(Bl + b_src[u] + (int64_t)k0 * N, st + 2 * kASlots + kBSlots + (NBU * wave + u) * 64);
+      }
     }
   };
 
@@ -381,6 +410,26 @@ __device__ __forceinline__ void gemm4_body(int bid, const _Float16 *__restrict__
   }
 
   const int KT = K / kBK;
+  if constexpr (DEEP) {
+    constexpr int kDma = (X1 ? 1 : 2) * (2 + NBU);                     // DMA instructions per wavefront and stage
+    issue(0, 0);
+    issue(min(1, KT - 1) * kBK, 1);                                    // (a one-stage product fetches stage 0 twice)
+    wait_vmcnt<kDma>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int buf = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      const int nb2 = buf == 0 ? 2 : buf - 1;                          // (buf + 2) % 3: last read one barrier ago
+      issue(min(kt + 2, KT - 1) * kBK, nb2);                           // (past the end: the last stage again, into a buffer nobody reads)
+      mfma_stage<NJ, X1>(smem + buf * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
+      wait_vmcnt<kDma>();                                              // stage kt + 1 has landed, kt + 2 stays in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
   issue(0, 0);
   __syncthreads();                              // (waits for the DMA: vmcnt(0))
   for (int kt = 0; kt + 1 < KT; ++kt) {
@@ -390,18 +439,19 @@ __device__ __forceinline__ void gemm4_body(int bid, const _Float16 *__restrict__
     __syncthreads();
   }
   mfma_stage<NJ, X1>(smem + ((KT - 1) & 1) * kStageSlots, kASlots, kBSlots, fa, fb, acc_m, acc_x);
+  }
   // (kLstm: one 32-row block at a time -- 64 registers fewer than both in flight, which keeps three workgroups on a CU; the
   //  other workgroups' products cover the block's load latency)
   epilogue<NJ, EPI, true>(acc_m, acc_x, m0 + wm, n0 + wn, lane, As, Bs, bias, R, N, out, ldo, le);
 }
 
-template <int BN, int EPI, bool X1 = false>
+template <int BN, int EPI, bool X1 = false, bool DEEP = false>
 __global__ void __launch_bounds__(256, 2)
     k_gemm_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                  const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
                  const float *__restrict__ bias, int R, int N, int K, float *__restrict__ out, int64_t ldo, int tiles_m,
                  int tiles_n, const LstmEpi le) {
-  gemm4_body<BN, EPI, X1>((int)blockIdx.x, Ah, Al, As, Bh, Bl, Bs, bias, R, N, K, out, ldo, tiles_m, tiles_n, le);
+  gemm4_body<BN, EPI, X1, DEEP>((int)blockIdx.x, Ah, Al, As, Bh, Bl, Bs, bias, R, N, K, out, ldo, tiles_m, tiles_n, le);
 }
 
 // ---- eight wavefronts (WM x WN, 64 x 64 each), tile 64 WM x 64 WN, THREE LDS stages with the DMA two stages ahead.
@@ -1650,7 +1700,7 @@ __global__ void __launch_bounds__(256, 2) k_greedy_and_gemm(const GemmArgs ga, c
                                                             GreedyBook book) {
   if ((int)blockIdx.x < ga.blocks) {
     const LstmEpi none = {};
-    gemm4_body<64, kStore, false>((int)blockIdx.x, ga.Ah, ga.Al, ga.As, ga.Bh, ga.Bl, ga.Bs, ga.bias, ga.R, ga.N, ga.K, ga.out,
+    gemm4_body<64, kStore, false, true>((int)blockIdx.x, ga.Ah, ga.Al, ga.As, ga.Bh, ga.Bl, ga.Bs, ga.bias, ga.R, ga.N, ga.K, ga.out,
                                   ga.ldo, ga.tiles_m, ga.tiles_n, none);
   } else {
     greedy_body((int)blockIdx.x - ga.blocks, part, R, chunks, idx, logp, book);
@@ -1752,7 +1802,7 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
     }
   }
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = (N + 63) / 64;
-  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", (x1 ? k_gemm_f16x3<64, kStore, true> : k_gemm_f16x3<64, kStore, false>), dim3((tiles_m * tiles_n + 7) / 8 * 8),
+  return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3", (x1 ? k_gemm_f16x3<64, kStore, true, true> : k_gemm_f16x3<64, kStore, false, true>), dim3((tiles_m * tiles_n + 7) / 8 * 8),
                      dim3(256), 0, (hipStream_t)stream, ah, al, a_scale, bh, bl, b_scale, bias, R, N, K, out, ldo, tiles_m,
                      tiles_n, LstmEpi{});
 }
