@@ -371,10 +371,10 @@ class TeacherForcedLoop(torch.autograd.Function):
         # the token-independent gate part joins the per-token embedding part ONCE (one pass over (n, steps, 4H)); as the
         # matrix addend of the attention product below it cost a (n, 4H) copy into `out` per token (addmm with beta = 1)
         xt_all = xt_all + gates_hs[:, None, :]
-        g_h, h_all, c_all = new(steps, n, W), new(steps + 1, n, H), new(steps + 1, n, H)
+        g_h, hc_all = new(steps, n, W), new(2, steps + 1, n, H)
+        h_all, c_all = hc_all[0], hc_all[1]
         att, alpha, act, g_x = new(steps, n, C), new(steps, n, 16), new(steps, n, H4), new(n, H4)
-        h_all[0].zero_()
-        c_all[0].zero_()
+        hc_all[:, 0].zero_()                                           # (h_0 = c_0 = 0: one fill for both)
         w_hcat_t, w_att_t = w_hcat.t(), w_att.t()
         for i in range(steps):
             torch.addmm(b_hcat, h_all[i], w_hcat_t, out=g_h[i])                   # [h2att(h) | h W_hh^T | offsets(h)]
@@ -402,8 +402,12 @@ class TeacherForcedLoop(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, device=slab.device, dtype=torch.float32)      # noqa: E731
         d_h = d_hidden.permute(1, 0, 2).contiguous()
         dg = new(steps, n, W)                          # per step [d h2att(h) | d gates | d offsets]: fully overwritten
-        g_slab, g_ref = torch.zeros_like(slab), torch.zeros_like(ref_in)
-        g_aw, g_ab = torch.zeros_like(alpha_w), slab.new_zeros(1)
+        g_slab = torch.zeros_like(slab)
+        n_r, n_a = (ref_in.numel() + 3) // 4 * 4, (alpha_w.numel() + 3) // 4 * 4      # (16-byte aligned pieces)
+        small = slab.new_zeros(n_r + n_a + 4)                          # the three small accumulators: one fill
+        g_ref = small[:ref_in.numel()].view(ref_in.shape)
+        g_aw = small[n_r:n_r + alpha_w.numel()].view(alpha_w.shape)
+        g_ab = small[n_r + n_a:n_r + n_a + 1]
         d_att, dh_carry, dc = new(n, C), None, None
         dh_buf, dc_buf = (new(n, H), new(n, H)), (new(n, H), new(n, H))
         for i in range(steps - 1, -1, -1):

@@ -122,7 +122,8 @@ class MSDeformAttnFusedFunction(Function):
         # fp32: the kernel also leaves max |out row| (one atomic max per row and head) -- the row scale output_proj's split needs
         amax = None
         if value.dtype == torch.float32 and torch.is_grad_enabled():
-            amax = torch.zeros(proj.shape[0] * proj.shape[1], device=value.device, dtype=torch.float32)
+            from ... import train_layers as _tl
+            amax = _tl.step_zeros(proj.shape[0] * proj.shape[1], value.device)
         out = MSDA.msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, reference_points, n_levels,
                                         n_points, pad_mode, amax_out=amax)
         ctx.save_for_backward(value, proj, reference_points, spatial_shapes, level_start_index)

@@ -209,6 +209,8 @@ class PDVC(nn.Module):
             # (two launches); the products' autograd nodes keep what their backward needs
             tp = self.train_planes()
             tp.refresh()
+            from . import train_layers as _tl
+            _tl.arena_reset(dt['video_tensor'].device)                    # one fill for the step's row-maxima vectors
             prev = _linear.set_active_planes(tp)
             try:
                 return self._forward(dt, criterion, contrastive_criterion, transformer_input_type, eval_mode)
@@ -316,7 +318,7 @@ class PDVC(nn.Module):
         instead of three zero fills per layer and forward.  They belong to THIS model (captured eval graphs and earlier
         output dicts alias them) and are never evicted; the set of (batch, queries) shapes a model sees is small."""
         N_, N_q = hs.shape[:2]
-        if not torch.is_grad_enabled() and hs.is_cuda:
+        if hs.is_cuda:                          # (training too: nothing writes into the placeholders, they carry no gradient)
             cache = self.__dict__.setdefault("_no_caption_consts", {})
             key = (N_, N_q, str(hs.device))
             hit = cache.get(key)

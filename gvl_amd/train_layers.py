@@ -36,6 +36,59 @@ def step_counter(device):
     return t
 
 
+class _ZeroArena:
+    """zero-initialised scratch of ONE training step (row-maxima vectors that kernels fill with atomic max): one fill per step for
+    all of them instead of one per vector.  `reset` opens a step (PDVC.forward, training) with a FRESH zero tensor as large as the
+    last step asked for -- vectors an earlier step's autograd nodes still hold keep their storage --; without an open step, or past
+    the capacity, `zeros` returns a torch.zeros of its own.  Graph-capturable (the allocation comes from the graph's pool)."""
+
+    def __init__(self):
+        self.buf, self.off, self.want, self.cap = None, 0, 0, 0
+
+    def reset(self, device):
+        self.cap = max(self.cap, self.want)
+        self.buf = torch.zeros(self.cap, dtype=torch.float32, device=device) if self.cap else None
+        self.off, self.want = 0, 0
+
+    def zeros(self, n, device):
+        need = (n + 63) // 64 * 64
+        self.want += need
+        if self.buf is None or self.buf.device != torch.device(device) or self.off + need > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        v = self.buf[self.off:self.off + n]
+        self.off += need
+        return v
+
+
+_ARENA = {}
+
+
+def _norm_device(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def arena(device):
+    device = _norm_device(device)
+    a = _ARENA.get(device)
+    if a is None:
+        a = _ARENA[device] = _ZeroArena()
+    return a
+
+
+def arena_reset(device):
+    device = _norm_device(device)
+    arena(device).reset(device)
+
+
+def step_zeros(n, device):
+    """n fp32 zeros from the training step's arena (see _ZeroArena)"""
+    device = _norm_device(device)
+    return arena(device).zeros(n, device)
+
+
 def advance(device):
     """one training forward begins: the dropout masks of its residual chains change (graph-capturable)"""
     if torch.device(device).type != "cuda" or not enabled():

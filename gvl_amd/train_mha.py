@@ -54,7 +54,7 @@ class _InProj(torch.autograd.Function):
         am_v = GL._row_amax(x2, x)
         am_qk = GL._row_amax(xq.reshape(R, C), xq)
         qkv = torch.empty(R, 3 * C, device=x.device, dtype=torch.float32)
-        am_out = torch.zeros(2, R, device=x.device, dtype=torch.float32)
+        am_out = TL.step_zeros(2 * R, x.device).view(2, R)
         L.linear(x2, op, [L.seg(0, qkv[:, :2 * C], am_qk, amax_out=am_out[0], addend=True),
                           L.seg(2 * C, qkv[:, 2 * C:], am_v, amax_out=am_out[1])], a2=pos)
         ctx.save_for_backward(x2, xq.reshape(R, C), am_v, am_qk, weight)
