@@ -79,6 +79,117 @@ class PositionEmbeddingSine(nn.Module):
         return torch.cat((pos_x, dur), dim=2).permute(0, 2, 1)
 
 
+class _PyramidTrainFunction(torch.autograd.Function):
+    """TRAINING form of the feature pyramid (base_encoder.py:60-80): Conv1d(k = 1) / Conv1d(k = 3, stride 2, padding 1) + GroupNorm of
+    every level -> the levels' rows of the flattened (N, S, C) encoder input, on the kernels of the inference form (forward_flat)
+    plus their gradients:
+        conv          gvl_linear_f16x3_f32 over rows of taps (one copy gathers the three taps of a frame: the weight gradient's operand)
+        GroupNorm     gvl_group_norm_rows_f32 / gvl_group_norm_rows_backward_f32 (the backward also takes the next level's input
+                      gradient, in its padded layout)
+        dW, db        gvl_wgrad_f16x3_f32;   dx (levels >= 2)  gvl_linear_f16x3_f32 on the transposed planes + gvl_conv_taps_to_rows_f32
+    ~60 launches forward + backward where the PyTorch formulation (pad, unfold copy, matmul, bias add, native group norm and their
+    autograd) takes ~140.  params: (conv.weight, conv.bias, norm.weight, norm.bias) per level."""
+
+    @staticmethod
+    def forward(ctx, enc, vf, *params):
+        from . import _lib
+        from . import layers as L
+        from . import linear as GL
+        from .train_planes import Operand
+        N, T, Cin = vf.shape
+        C, nl = enc.hidden_dim, enc.num_feature_levels
+        lengths = enc.level_lengths(T)
+        starts = [sum(lengths[:i]) for i in range(nl)]
+        S = sum(lengths)
+        dev = vf.device
+        stream = torch.cuda.current_stream().cuda_stream
+        tp, mats = enc._train_conv_operands(params)
+        src = torch.empty(N, S, C, device=dev, dtype=torch.float32)
+        saved, shapes = [], []
+        x = vf.reshape(N * T, Cin)
+        x = x if x.is_contiguous() else x.contiguous()
+        xp = None
+        for l in range(nl):
+            if l == 0:
+                a, rows = x, T
+            else:
+                t_out = lengths[l]
+                rows = t_out + 1
+                a = xp.as_strided((N * rows, 3 * xp.shape[2]), (2 * xp.shape[2], 1)).contiguous()     # rows of taps
+            am = L.row_absmax(a)[0]
+            fwd, _, bias = tp.lookup((mats[l],))
+            y = torch.empty(a.shape[0], C, device=dev, dtype=torch.float32)
+            L.linear(a, Operand(fwd, C, a.shape[1], bias), [L.seg(0, y, am)])
+            norm_w, norm_b = params[4 * l + 2], params[4 * l + 3]
+            nxt = None
+            if l + 1 < nl:                                             # next level's zero-padded input: (N + 1, 2 (T'' + 1), C)
+                t_nxt = lengths[l + 1]
+                nxt = torch.zeros(N + 1, 2 * (t_nxt + 1), C if l > 0 else Cin, device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().gvl_group_norm_rows_f32(
+                    y.data_ptr(), y.stride(0), rows, N, lengths[l], C, enc.input_proj[l][1].num_groups, norm_w.data_ptr(),
+                    norm_b.data_ptr(), float(enc.input_proj[l][1].eps), src.data_ptr() + 4 * starts[l] * C, S * C,
+                    nxt.data_ptr() + 4 * C if (nxt is not None and l > 0) else None,
+                    nxt.shape[1] * C if (nxt is not None and l > 0) else 0, stream)
+            _lib.check(rc, "group_norm_rows")
+            if l == 0 and nxt is not None:
+                nxt[:N, 1:T + 1] = vf                                  # level 1 convolves the RAW features
+            saved += [a, am, y]
+            shapes.append(rows)
+            xp = nxt
+        ctx.save_for_backward(*saved, *params)
+        ctx.enc, ctx.geom, ctx.tp, ctx.mats = enc, (N, T, Cin, C, nl, lengths, starts, S, shapes), tp, mats
+        return src
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dsrc):
+        from . import _lib
+        from . import layers as L
+        from . import MultiScaleDeformableAttention as MSDA
+        from .train_planes import Operand
+        enc, tp, mats = ctx.enc, ctx.tp, ctx.mats
+        N, T, Cin, C, nl, lengths, starts, S, shapes = ctx.geom
+        t_ = ctx.saved_tensors
+        saved, params = t_[:3 * nl], t_[3 * nl:]
+        dev = dsrc.device
+        stream = torch.cuda.current_stream().cuda_stream
+        dsrc = dsrc.contiguous()
+        grads = [None] * (4 * nl)
+        dnext = None                                                   # input gradient of level l + 1, padded layout (N, 2 T1, C)
+        for l in range(nl - 1, -1, -1):
+            a, am, y = saved[3 * l], saved[3 * l + 1], saved[3 * l + 2]
+            rows = shapes[l]
+            norm = enc.input_proj[l][1]
+            dy = torch.empty(N * rows, C, device=dev, dtype=torch.float32)
+            part = torch.empty(2, N, C, device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().gvl_group_norm_rows_backward_f32(
+                    y.data_ptr(), y.stride(0), rows, N, lengths[l], C, norm.num_groups, params[4 * l + 2].data_ptr(), float(norm.eps),
+                    dsrc.data_ptr() + 4 * starts[l] * C, S * C,
+                    dnext.data_ptr() + 4 * C if dnext is not None else None, dnext.shape[1] * C if dnext is not None else 0,
+                    dy.data_ptr(), C, part[0].data_ptr(), part[1].data_ptr(), stream)
+            _lib.check(rc, "group_norm_rows_backward")
+            gb = part.sum(1)                                           # (2, C): d gamma, d beta -- the videos in index order
+            grads[4 * l + 2], grads[4 * l + 3] = gb[0], gb[1]
+            am_dy = L.row_absmax(dy)[0]
+            gw, gbias = MSDA.wgrad(dy, a, am_dy, am)
+            w = params[4 * l]
+            grads[4 * l] = gw.view(C, 1, a.shape[1]).permute(0, 2, 1) if l == 0 else gw.view(C, 3, a.shape[1] // 3).permute(0, 2, 1)
+            grads[4 * l + 1] = gbias
+            dnext = None
+            if l >= 2:                                                 # (level 1 reads the raw features: no input gradient)
+                _, tr, _ = tp.lookup((mats[l],))
+                dcols = torch.empty(N * rows, a.shape[1], device=dev, dtype=torch.float32)
+                L.linear(dy, Operand(tr, a.shape[1], C, None), [L.seg(0, dcols, am_dy)])
+                dnext = torch.empty(N, 2 * rows, C, device=dev, dtype=torch.float32)
+                with torch.cuda.device(dev):
+                    rc = _lib.lib().gvl_conv_taps_to_rows_f32(dcols.data_ptr(), N, rows, C, dnext.data_ptr(), stream)
+                _lib.check(rc, "conv_taps_to_rows")
+            assert w.shape[0] == C
+        return (None, None, *grads)
+
+
 class BaseEncoder(nn.Module):
     def __init__(self, num_feature_levels, vf_dim, hidden_dim):
         super().__init__()
@@ -130,6 +241,69 @@ class BaseEncoder(nn.Module):
                 and self.pos_embed.normalize and self.pos_embed.num_pos_feats + self.pos_embed.max_duration == self.hidden_dim
                 and all(64 % (self.hidden_dim // p_[1].num_groups) == 0 for p_ in self.input_proj)
                 and vf.shape[1] >= 2 ** (self.num_feature_levels - 1))
+
+    def level_lengths(self, T):
+        lengths = [T]
+        for _ in range(self.num_feature_levels - 1):
+            lengths.append((lengths[-1] - 1) // 2 + 1)
+        return lengths
+
+    def flat_train_eligible(self, vf, mask):
+        """the TRAINING forward of the pyramid on the hand-written kernels (_PyramidTrainFunction); GVL_TRAIN_PYRAMID=torch keeps
+        the PyTorch formulation (A/B switch)"""
+        import os
+        from . import layers as L
+        from . import linear as GL
+        c0 = self.input_proj[0][0]
+        return (os.environ.get("GVL_TRAIN_PYRAMID", "") != "torch" and L.enabled() and GL.train_linear_enabled()
+                and torch.is_grad_enabled() and self.training and not torch.is_autocast_enabled()
+                and vf.is_cuda and vf.dtype == torch.float32 and 1 < self.num_feature_levels <= 8
+                and isinstance(c0, nn.Conv1d) and vf.shape[-1] % 64 == 0 and self.hidden_dim % 64 == 0
+                and all(64 % (self.hidden_dim // p_[1].num_groups) == 0 for p_ in self.input_proj)
+                and all(p_[0].weight.dtype == torch.float32 for p_ in self.input_proj)
+                and vf.shape[1] >= 2 ** (self.num_feature_levels - 1) and vf.shape[0] * vf.shape[1] >= 64)
+
+    def _train_conv_operands(self, params):
+        """the levels' convolutions as (C_out, k C_in) matrices in persistent buffers (row c_out: tap-major, as the rows of taps),
+        refreshed from the parameters' current values, and their operand planes in both orientations (a private TrainPlanes:
+        two launches for all levels)"""
+        from .train_planes import TrainPlanes
+        st = self.__dict__.get("_gvl_train_conv")
+        dev = params[0].device
+        if st is None or st[0].device != torch.device(dev):
+            mats = []
+            for l in range(self.num_feature_levels):
+                w = params[4 * l]
+                mats.append(torch.empty(w.shape[0], w.shape[1] * w.shape[2], device=dev, dtype=torch.float32))
+            tp = TrainPlanes(dev)
+            for l, m in enumerate(mats):
+                tp.register([m], [params[4 * l + 1]])
+            st = self.__dict__["_gvl_train_conv"] = (tp, mats)
+        tp, mats = st
+        with torch.no_grad():
+            for l, m in enumerate(mats):
+                w = params[4 * l]
+                m.view(w.shape[0], w.shape[2], w.shape[1]).copy_(w.permute(0, 2, 1))
+            tp.refresh()
+        return tp, mats
+
+    def forward_flat_train(self, vf):
+        """-> the flattened (N, S, C) encoder input with gradients to the levels' conv / norm parameters"""
+        params = []
+        for seq in self.input_proj:
+            params += [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias]
+        return _PyramidTrainFunction.apply(self, vf, *params)
+
+    def train_geometry(self, vf, mask, duration):
+        """the levels' padding masks and position embeddings of forward() without the pyramid itself -> (masks, poses)"""
+        lengths = self.level_lengths(vf.shape[1])
+        dur = self.pos_embed.duration_embedding(duration)
+        masks, poses = [mask], [self.pos_embed(None, mask, duration, dur_embed=dur)]
+        for l in range(1, self.num_feature_levels):
+            m = F.interpolate(mask[None].float(), size=(lengths[l],)).to(torch.bool)[0]
+            masks.append(m)
+            poses.append(self.pos_embed(None, m, duration, dur_embed=dur))
+        return masks, poses
 
     def _conv_weights(self, l):
         """the level's convolution as the (C_out, k * C_in) matrix of a product over rows of taps, as split planes"""

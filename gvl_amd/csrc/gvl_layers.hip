@@ -736,6 +736,90 @@ __global__ void __launch_bounds__(256) k_group_norm_rows(const float *__restrict
   }
 }
 
+// backward of k_group_norm_rows (TRAINING: base_encoder.py:60-80's GroupNorm of a level, rows layout), one wavefront per
+// (video, group): x^ = (y - mean) rstd, g = dout gamma (dout = the gradient of the level's rows of the flattened encoder input, plus
+// the next level's input gradient where there is one), dy = rstd (g - (sum g + x^ sum g x^) / count); per-video partial sums of the
+// affine parameters' gradients (dgamma_part, dbeta_part: (N, C), summed over the videos by the caller: fixed order).  dy covers the
+// level's rows_per_video rows per video: the rows behind its T frames (the next convolution's padding rows) are zero.
+__global__ void __launch_bounds__(256) k_group_norm_rows_bwd(const float *__restrict__ y, int64_t ldy, int rows_per_video, int T,
+                                                             int C, int G, int N, const float *__restrict__ gamma, float eps,
+                                                             const float *__restrict__ dout, int64_t dout_vs,
+                                                             const float *__restrict__ dout2, int64_t dout2_vs,
+                                                             float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dgamma_part,
+                                                             float *__restrict__ dbeta_part) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= N * G) return;
+  const int n = unit / G, g = unit % G, cg = C / G;
+  const int c = g * cg + lane % cg, tr = lane / cg, tstep = 64 / cg;
+  const float *src = y + (int64_t)n * rows_per_video * ldy + c;
+  const float *d1 = dout + (int64_t)n * dout_vs + c;
+  const float *d2 = dout2 ? dout2 + (int64_t)n * dout2_vs + c : nullptr;
+  float sum = 0.f;
+  for (int t = tr; t < T; t += tstep) sum += src[(int64_t)t * ldy];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float cnt = (float)T * (float)cg, mean = sum / cnt;
+  float sq = 0.f;
+  for (int t = tr; t < T; t += tstep) {
+    const float d = src[(int64_t)t * ldy] - mean;
+    sq = fmaf(d, d, sq);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.f / sqrtf(sq / cnt + eps), gm = gamma[c];
+  float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f;
+  for (int t = tr; t < T; t += tstep) {
+    const float xh = (src[(int64_t)t * ldy] - mean) * rstd;
+    const float go = d1[(int64_t)t * C] + (d2 ? d2[(int64_t)t * C] : 0.f);
+    s1 = fmaf(go, gm, s1);
+    s2 = fmaf(go * gm, xh, s2);
+    dg = fmaf(go, xh, dg);
+    db += go;
+  }
+  for (int o = cg; o < 64; o <<= 1) {                                  // the channel's rows sit in the lanes cg apart
+    dg += __shfl_xor(dg, o, 64);
+    db += __shfl_xor(db, o, 64);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (tr == 0) {
+    dgamma_part[(int64_t)n * C + c] = dg;
+    dbeta_part[(int64_t)n * C + c] = db;
+  }
+  const float k1 = s1 / cnt, k2 = s2 / cnt;
+  float *dst = dy + (int64_t)n * rows_per_video * ld_dy + c;
+  for (int t = tr; t < rows_per_video; t += tstep) {
+    float v = 0.f;
+    if (t < T) {
+      const float xh = (src[(int64_t)t * ldy] - mean) * rstd;
+      const float go = d1[(int64_t)t * C] + (d2 ? d2[(int64_t)t * C] : 0.f);
+      v = rstd * (go * gm - k1 - xh * k2);
+    }
+    dst[(int64_t)t * ld_dy] = v;
+  }
+}
+
+// the input gradient of a Conv1d(k = 3, stride 2, padding 1) from the gradient of its rows of taps: dcols (N, T' + 1, 3, C) --
+// row (n, t') = d[x_{2t'-1} | x_{2t'} | x_{2t'+1}] -- summed into dx (N, 2 (T' + 1), C), padded frame index 2 t' + k (frame t of the
+// input is row t + 1).  One thread per 4 channels of a padded row; an even row has one contributor, an odd row two.
+__global__ void __launch_bounds__(256) k_taps_to_rows(const float4 *__restrict__ dcols, int N, int T1, int C4,
+                                                      float4 *__restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)N * 2 * T1 * C4;
+  if (i >= total) return;
+  const int c = (int)(i % C4), r = (int)((i / C4) % (2 * T1)), n = (int)(i / ((int64_t)C4 * 2 * T1));
+  // padded row r = 2 t' + k: (t', k) = (r / 2, r % 2) and, for even r >= 2, also (r / 2 - 1, 2)
+  const float4 *row = dcols + (int64_t)n * T1 * 3 * C4;
+  float4 v = row[((int64_t)(r >> 1) * 3 + (r & 1)) * C4 + c];
+  if (!(r & 1) && r >= 2) {
+    const float4 u = row[((int64_t)((r >> 1) - 1) * 3 + 2) * C4 + c];
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  dx[i] = v;
+}
+
 struct PyramidDims { int len[8], start[8]; };
 
 // grid (videos, levels, slices): mask_flat (N, S) bytes, lvl_pos (N, S, F + Cd)
@@ -889,6 +973,28 @@ extern "C" int gvl_group_norm_rows_f32(const float *y, int64_t ldy, int rows_per
   return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows", k_group_norm_rows, dim3((N * G + 3) / 4), dim3(256), 0,
                      (hipStream_t)stream, y, ldy, rows_per_video, T, C, G, N, gamma, beta, eps, dst, dst_video_stride, dst2,
                      dst2_video_stride);
+}
+
+extern "C" int gvl_group_norm_rows_backward_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G,
+                                                const float *gamma, float eps, const float *dout, int64_t dout_video_stride,
+                                                const float *dout2, int64_t dout2_video_stride, float *dy, int64_t ld_dy,
+                                                float *dgamma_part, float *dbeta_part, void *stream) {
+  if (N < 0 || T <= 0 || C <= 0 || G <= 0 || C % G || 64 % (C / G) || ldy < C || ld_dy < C || rows_per_video < T)
+    return fail(GVL_EINVAL, "gvl_group_norm_rows_backward_f32: needs C / G in {1, 2, 4, ..., 64} (got N=%d T=%d C=%d G=%d)", N, T, C, G);
+  if (N == 0) return 0;
+  if (!y || !gamma || !dout || !dy || !dgamma_part || !dbeta_part) return fail(GVL_EINVAL, "gvl_group_norm_rows_backward_f32: null pointer");
+  return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows_bwd", k_group_norm_rows_bwd, dim3((N * G + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, y, ldy, rows_per_video, T, C, G, N, gamma, eps, dout, dout_video_stride, dout2,
+                     dout2_video_stride, dy, ld_dy, dgamma_part, dbeta_part);
+}
+
+extern "C" int gvl_conv_taps_to_rows_f32(const float *dcols, int N, int T1, int C, float *dx, void *stream) {
+  if (N < 0 || T1 <= 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "gvl_conv_taps_to_rows_f32: needs C %% 4 == 0 (got N=%d T1=%d C=%d)", N, T1, C);
+  if (N == 0) return 0;
+  if (!dcols || !dx || (((uintptr_t)dcols | (uintptr_t)dx) & 15)) return fail(GVL_EINVAL, "gvl_conv_taps_to_rows_f32: null / unaligned pointer");
+  const int64_t total = (int64_t)N * 2 * T1 * (C / 4);
+  return gvl::launch(GVL_PROF_LAYER_NORM, T1, N, "k_taps_to_rows", k_taps_to_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4 *)dcols, N, T1, C / 4, (float4 *)dx);
 }
 
 extern "C" int gvl_pyramid_geometry_f32(const unsigned char *mask, int N, int T0, int S, int L, const int64_t *lengths_host,

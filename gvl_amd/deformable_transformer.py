@@ -270,10 +270,12 @@ class DeformableTransformer(nn.Module):
     def get_valid_ratio(self, mask):
         return torch.sum(~mask, 1).float() / mask.shape[1]
 
-    def prepare_encoder_inputs(self, srcs, masks, pos_embeds):
-        """:85-115.  srcs[l] (B,C,T_l), masks[l] (B,T_l) True=pad, pos_embeds[l] (B,C,T_l)."""
-        lengths = [int(s.shape[-1]) for s in srcs]
-        src_flatten = torch.cat([s.transpose(1, 2) for s in srcs], 1)
+    def prepare_encoder_inputs(self, srcs, masks, pos_embeds, src_flatten=None):
+        """:85-115.  srcs[l] (B,C,T_l), masks[l] (B,T_l) True=pad, pos_embeds[l] (B,C,T_l).  src_flatten given (the training pyramid
+        of BaseEncoder.forward_flat_train): the levels arrive flattened already, srcs is None."""
+        lengths = [int(m.shape[-1]) for m in masks]
+        if src_flatten is None:
+            src_flatten = torch.cat([s.transpose(1, 2) for s in srcs], 1)
         mask_flatten = torch.cat(masks, 1)
         lvl_embed = self.level_embed.unbind(0)        # (one UnbindBackward instead of a zero-filled SelectBackward per level)
         lvl_pos = torch.cat([p.transpose(1, 2) + lvl_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)

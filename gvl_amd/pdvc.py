@@ -157,6 +157,12 @@ class PDVC(nn.Module):
             src, mask_flat, lvl_pos, lengths = self.base_encoder.forward_flat(vf, mask, duration,
                                                                               self.transformer.level_embed)
             tshapes, lsi, valid_ratios = self.transformer.flat_geometry(mask_flat, lengths)
+        elif self.base_encoder.flat_train_eligible(vf, mask) and not self.transformer.no_encoder:
+            # training: the pyramid (conv + GroupNorm of every level) as one autograd node on the hand-written kernels
+            src_flat = self.base_encoder.forward_flat_train(vf)
+            masks, pos = self.base_encoder.train_geometry(vf, mask, duration)
+            src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat = self.transformer.prepare_encoder_inputs(
+                None, masks, pos, src_flatten=src_flat)
         else:
             srcs, masks, pos = self.base_encoder(vf, mask, duration)
             src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat = self.transformer.prepare_encoder_inputs(srcs, masks, pos)

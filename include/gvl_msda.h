@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 12  /* 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch), gvl_gemm_f16x3_gates_f32 / _applicable (both halves of the LSTM gate product + cell in one launch), gvl_greedy_step_partials_gemm_f32 (greedy reduction + an independent product in one launch), gvl_clip_adam_step_f32 (gradient clipping + Adam over a tensor table); 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 12  /* 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch), gvl_gemm_f16x3_gates_f32 / _applicable (both halves of the LSTM gate product + cell in one launch), gvl_greedy_step_partials_gemm_f32 (greedy reduction + an independent product in one launch), gvl_clip_adam_step_f32 (gradient clipping + Adam over a tensor table), gvl_group_norm_rows_backward_f32 / gvl_conv_taps_to_rows_f32 (training form of the base encoder's levels); 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -212,6 +212,16 @@ int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned char *key_keep
  *      geometry: mask_flat (N, S) = every level's padding mask (level 0: mask itself; level l: nearest-neighbour resampling,
  *        F.interpolate(mask.float(), size=T_l)); lvl_pos (N, S, n_sine + n_dur) = PositionEmbeddingSine of that mask (see
  *        gvl_pos_embed_sine_f32) transposed, + level_embed[l] (deformable_transformer.py:105). */
+/*    TRAINING (ABI 12): gvl_group_norm_rows_backward_f32 -- the backward of gvl_group_norm_rows_f32: dy for the level's
+ *    rows_per_video rows per video (the padding rows behind the T frames are zero), per-video partial sums of the affine
+ *    gradients (N, C); `dout2` (may be NULL) is a second gradient of the same rows, the next level's input gradient in ITS
+ *    padded layout.  gvl_conv_taps_to_rows_f32 -- the input gradient of Conv1d(k = 3, stride 2, padding 1) from the gradient of
+ *    its rows of taps: dcols (N, T1, 3, C) -> dx (N, 2 T1, C), row 2 t' + k of a video = tap k of output frame t'. */
+int gvl_group_norm_rows_backward_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G, const float *gamma,
+                                     float eps, const float *dout, int64_t dout_video_stride, const float *dout2,
+                                     int64_t dout2_video_stride, float *dy, int64_t ld_dy, float *dgamma_part, float *dbeta_part,
+                                     void *stream);
+int gvl_conv_taps_to_rows_f32(const float *dcols, int N, int T1, int C, float *dx, void *stream);
 int gvl_group_norm_rows_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G, const float *gamma,
                             const float *beta, float eps, float *dst, int64_t dst_video_stride, float *dst2,
                             int64_t dst2_video_stride, void *stream);
