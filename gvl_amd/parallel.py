@@ -177,6 +177,24 @@ class GradBuckets:
         used = used.tolist()
         return [p for p, u in zip(self.params, used) if not u]
 
+    def agree_unused(self, unused_local, has_events):
+        """ONE agreement, outside any capture, on the parameters the step's autograd graph can never reach: a
+        parameter belongs to the set when every rank whose batch HAD events found it unused (`unused_local`: what
+        probe_unused returned on this rank's batch); a rank without events abstains -- its probe also misses the captioner,
+        which the other ranks do reach.  -> the list (identical on every rank), or None when no rank had events (nothing can be
+        concluded from this step: ask again on a later one)."""
+        ids = {id(p) for p in unused_local}
+        if self.world == 1 or not dist.is_initialized():
+            return [p for p in self.params if id(p) in ids] if has_events else None
+        dev = self.flat.device if self.flat is not None else torch.device("cpu")
+        member = torch.tensor([1 if (not has_events or id(p) in ids) else 0 for p in self.params], dtype=torch.int32, device=dev)
+        voters = torch.tensor([1 if has_events else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(member, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(voters, op=dist.ReduceOp.MAX, group=self.group)
+        if int(voters.item()) == 0:
+            return None
+        return [p for p, m in zip(self.params, member.tolist()) if m]
+
     def probe_unused(self, run):
         """no-hook (captured) mode: run one eager step `run()` with temporary post-accumulate hooks and return the
         parameters autograd never delivered a gradient to.  With the flat buffer installed their .grad is a zero view,
@@ -531,7 +549,24 @@ class GraphedTrainStep(TrainStep):
         torch.cuda.set_rng_state(cuda_rng, self.params[0].device)
         torch.set_rng_state(cpu_rng)
 
-    def _capture(self, st, static_structure=True):
+    def _agree_structural(self, st, dt):
+        """layout-keyed data-parallel captures (every rank captures from ITS batch): which parameters may be hidden from the
+        captured clip + Adam is agreed ONCE across the ranks from an eager probe step (side-effect free), not per capture --
+        GradBuckets.agree_unused.  Until a step where some rank has events, nothing is hidden."""
+        snap = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            def fb():
+                self._forward_backward(st)
+                self._backward_encoder()
+            unused = self.buckets.probe_unused(fb)
+        torch.cuda.current_stream().wait_stream(side)
+        self._restore(snap)
+        has_events = sum(len(t_["labels"]) for t_ in dt["video_target"]) > 0
+        return self.buckets.agree_unused(unused, has_events)
+
+    def _capture(self, st, static_structure=True, hidden=None):
         """warm up on `st` (local work only: no collective, so ranks may capture at different times) and capture;
         -> (graphs, outs).  Parameters / optimizer / RNG are restored afterwards: the capture records, it does not run.
         static_structure: the step's autograd graph does not depend on the batch (the padded form: fixed-capacity target
@@ -544,7 +579,7 @@ class GraphedTrainStep(TrainStep):
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        unused = []
+        unused = list(hidden) if (hidden and not static_structure) else []     # (agreed across the ranks: _agree_structural)
         with torch.cuda.stream(side):
             for it in range(self.warmup):
                 if self.split:
@@ -616,9 +651,17 @@ class GraphedTrainStep(TrainStep):
             entry = self.graphs.lookup(key)
             self.criterion.num_boxes_override = nb              # device scalar read by the captured criterion
             try:
+                if (self.split and self.world > 1 and self.buckets.flat is not None
+                        and self.__dict__.get("_structural") is None):
+                    # a collective, so NOT tied to this rank's cache miss: every rank runs it on every layout-keyed step until
+                    # the set is agreed (the outcome -- agreed / no rank had events yet -- is the same on all of them)
+                    self._structural = self._agree_structural(GraphedTrainStep._static_copy(dt), dt)
+                    if self._structural is not None:
+                        self.graphs.clear()                      # (captured while nothing was hidden: capture again)
+                        entry = None
                 if entry is None:
                     st = GraphedTrainStep._static_copy(dt)
-                    graphs, outs = self._capture(st, static_structure=False)
+                    graphs, outs = self._capture(st, static_structure=False, hidden=self.__dict__.get("_structural"))
                     entry = (graphs, st, outs)
                     self.graphs.store(key, entry)
             finally:

@@ -307,3 +307,45 @@ def test_eight_ranks_uneven_batch_empty_ranks_and_bucket_order():
     # the gradients every rank holds after the exchange are identical (the mean over the ranks)
     for r in res[1:]:
         assert r[2] == res[0][2] and r[3] == res[0][3]
+
+
+def _worker_agree(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gvl_amd.parallel import GradBuckets
+        model = _make_model()
+        params = list(model.parameters())                    # 6 tensors
+        b = GradBuckets(params, bucket_bytes=1024, flat=True, overlap=False)
+        # what each rank's probe found unused on ITS batch: parameter 0 everywhere; parameter 1 on the ranks with events except
+        # rank 2 (which reaches it); parameters 4, 5 only on the ranks WITHOUT events (a batch without events skips the captioner)
+        has_events = rank not in (1, 3)
+        local = [params[0]] + ([params[1]] if rank != 2 else []) + ([] if has_events else [params[4], params[5]])
+        got = b.agree_unused(local, has_events)
+        res = None if got is None else [i for i, p in enumerate(params) if any(p is g for g in got)]
+        # nobody has events: nothing can be concluded
+        none = b.agree_unused(params, False)
+        q.put((rank, "ok", (res, none)))
+    except Exception as e:                                   # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_structurally_unused_parameters_are_agreed_across_the_ranks():
+    """the set of parameters a layout-keyed data-parallel capture hides from clip + Adam is agreed ONCE --
+    unused on EVERY rank whose batch had events; ranks without events abstain; no rank with events -> no conclusion"""
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_agree, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[2]
+        assert r[2] == ([0], None), r                        # parameter 0 only; the same list on every rank
