@@ -433,9 +433,13 @@ constexpr int kLnMaxV = 4;                                             // float4
 __global__ void __launch_bounds__(256) k_ln_rows(const float *__restrict__ x, int R, int C, const float *__restrict__ gamma,
                                                  const float *__restrict__ beta, float eps, const float *__restrict__ pos,
                                                  int pos_rows, float *__restrict__ y, float *__restrict__ amax_y,
-                                                 float *__restrict__ amax_yp) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= R) return;
+                                                 float *__restrict__ amax_yp, int xcd_rows) {
+  // xcd_rows: workgroup b serves the row group (b % 8) (groups / 8) + b / 8 -- XCD x (= b % 8) writes the x-th contiguous eighth of
+  // the rows, the rows the product that reads y next stages from the SAME XCD (tile_of: XCD x walks a contiguous tile range)
+  const int nb = (R + 3) >> 2, per = (nb + 7) >> 3;
+  const int vb = xcd_rows ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int row = vb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (vb >= nb || row >= R) return;
   const int n4 = C >> 2;
   const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)row * C);
   float4 v[kLnMaxV];
@@ -1202,8 +1206,10 @@ extern "C" int gvl_layer_norm_rows_f32(const float *x, int R, int C, const float
   if (!x || !gamma || !beta || !y || (pos && pos_rows <= 0)) return fail(GVL_EINVAL, "gvl_layer_norm_rows_f32: null pointer");
   if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)pos) & 15)
     return fail(GVL_EINVAL, "gvl_layer_norm_rows_f32: operands must be 16-byte aligned");
-  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_ln_rows", k_ln_rows, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
-                     R, C, gamma, beta, eps, pos, pos ? pos_rows : 1, y, amax_y, amax_ypos);
+  const int xcd_rows = gvl::env_int("GVL_ROWS_XCD", 1);   // (0: workgroup b = rows 4 b ..: A/B runs; tools/xcd_rows_probe.py: 28.8 -> 26.9 us for LN + 4800 x 512 x 512 product)
+  const int nb = (R + 3) / 4, grid = xcd_rows ? 8 * ((nb + 7) / 8) : nb;
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_ln_rows", k_ln_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                     R, C, gamma, beta, eps, pos, pos ? pos_rows : 1, y, amax_y, amax_ypos, xcd_rows);
 }
 
 extern "C" int gvl_row_absmax_f32(const float *x, int64_t ldx, int R, int C, const float *pos, int64_t ldp, int pos_rows,
