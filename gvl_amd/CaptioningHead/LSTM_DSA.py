@@ -34,6 +34,7 @@ from .. import MultiScaleDeformableAttention as MSDA
 from ..linear import Linear, split_gemm_enabled, split_linear, vocab_nll, vocab_nll_eligible
 
 
+_ATTEND_PRE = os.environ.get("GVL_ATTEND_PRE", "1") != "0"            # (A/B: the offsets' hidden-state product inside the attention kernel)
 _GREEDY_MERGED = os.environ.get("GVL_GREEDY_MERGED", "1") != "0"      # (A/B: h2att(h) as a launch of its own)
 
 class ShowAttendTellCore(nn.Module):
@@ -214,8 +215,15 @@ class ShowAttendTellCore(nn.Module):
                         # [h | att]); the product over h in front of the attention then only yields h2att(h).
                         # GVL_GATES_FUSED=0: the (n, A + 4H) product + gates_h operand of round 4.
                         w["w_gate_cat_p"] = MSDA.split_rows(torch.cat([w_hh, w_att], 1).contiguous())
-                        w["w_h2att_p"] = MSDA.split_rows(self.h2att.weight.contiguous())
-                        w["b_h2att"] = self.h2att.bias.detach().contiguous()
+                        # ... and, as 16 more output columns, the hidden-state part of the sampling offsets
+                        # (gvl_cap_attend_pre_f32 then reads neither h nor that weight; GVL_ATTEND_PRE=0: the kernel's own product)
+                        if _ATTEND_PRE:
+                            w["w_h2att_p"] = MSDA.split_rows(torch.cat([self.h2att.weight, ow[:, :self.rnn_size]], 0).contiguous())
+                            w["b_h2att"] = torch.cat([self.h2att.bias.detach(), self.h2att.bias.new_zeros(ow.shape[0])])
+                            w["off_pre"] = True
+                        else:
+                            w["w_h2att_p"] = MSDA.split_rows(self.h2att.weight.contiguous())
+                            w["b_h2att"] = self.h2att.bias.detach().contiguous()
             cache[key] = w
         return w
 
@@ -244,9 +252,18 @@ class ShowAttendTellCore(nn.Module):
             h_gemm = getattr(h, "_gvl_lowp", h)                          # bf16 copy left by the cell kernel (autocast)
             g_h = F.linear(h_gemm, const["w_h_cat"], const["b_h_cat"])  # (n, A + 4H): [h2att(h) | h W_hh^T]
         split = split and const["slab3"].dtype == torch.float32
-        att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
-                                  h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
-                                  self.n_levels, self.n_points, planes=split, host_starts=const.get("host_starts"))
+        pre = (gates_one and g_h.shape[1] == A + self.n_levels * self.n_points and self.attend_pre_ok(const, temporal_shapes))
+        if pre:
+            att_res = MSDA.cap_attend_pre(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
+                                          g_h[:, A:], g_h[:, :A], const["alpha_w"], const["alpha_b"], self.n_levels,
+                                          self.n_points, const["host_starts"])
+        else:
+            if getattr(h, "_gvl_planes_only", False):
+                raise RuntimeError("gvl_amd: the hidden state of this step exists as operand planes only (cell_part under "
+                                   "const['h_planes_only']) but the attention kernel that reads it as fp32 was chosen")
+            att_res = MSDA.cap_attend(const["slab3"], shapes2d, level_start_index, const["ref_in"], const["off_hs"],
+                                      h, const["w_off_h"], g_h[:, :A], const["alpha_w"], const["alpha_b"],
+                                      self.n_levels, self.n_points, planes=split, host_starts=const.get("host_starts"))
         if gates_one:                                                   # the recurrent operand travels as planes
             return att_res, (hp,)
         if split and const.get("gate_perm") is not None:                # ... whose epilogue is the cell (step)
@@ -254,6 +271,17 @@ class ShowAttendTellCore(nn.Module):
         if split:                                                       # att_res arrives as the planes of the product
             return MSDA.gemm_f16x3(att_res, const["w_att_p"]), g_h
         return torch.mm(att_res, const["w_att_t"]), g_h                 # (the hs part, gates_hs, is added in the cell)
+
+    def attend_pre_ok(self, const, temporal_shapes):
+        """whether this decode's attention runs as gvl_cap_attend_pre_f32 (the offsets' hidden-state product rides in the h2att(h)
+        launch); decided once per set of step constants"""
+        ok = const.get("pre_ok")
+        if ok is None:
+            host = getattr(temporal_shapes, "_gvl_host_lengths", None)
+            ok = const["pre_ok"] = bool(const.get("off_pre") and host is not None and const["slab3"].dtype == torch.float32
+                                        and MSDA.cap_attend_pre_applicable(const["slab3"].shape[1], self.n_levels, self.n_points,
+                                                                           tuple(host[1])))
+        return ok
 
     def gates_in_one_launch(self, h, const):
         """whether this step's gate product runs as gvl_gemm_f16x3_gates_f32 (the product over h in front of the attention is
@@ -269,7 +297,8 @@ class ShowAttendTellCore(nn.Module):
             xt_gates = (xt_gates.contiguous(), torch.arange(xt_gates.shape[0], device=xt_gates.device))
         emb_gates, it = xt_gates                                        # (table (V+1,4H), token ids)
         if isinstance(g_h, tuple):                                      # (attend_part: the planes of h)
-            return MSDA.gemm_f16x3_gates(g_x, g_h[0], const["w_gate_cat_p"], const["gates_hs"], emb_gates, it, c)
+            return MSDA.gemm_f16x3_gates(g_x, g_h[0], const["w_gate_cat_p"], const["gates_hs"], emb_gates, it, c,
+                                         need_h=not const.get("h_planes_only", False))
         if const.get("gate_perm") is not None:                          # g_x: planes of the attended feature (attend_part)
             return MSDA.gemm_f16x3_lstm(g_x, const["w_att_p"], g_h[:, self.att_hid_size:], const["gates_hs"], emb_gates,
                                         it, c)
@@ -685,6 +714,13 @@ class Captioner(nn.Module):
         step + vocabulary logits for token t.  (The reference also evaluates that step after the LAST token,
         :189-190, and then leaves the loop without reading it.)"""
         T = self.max_caption_len
+        const = st["const"]
+        if "h_planes_only" not in const:
+            # every reader of h' in this loop takes its operand planes (the vocabulary product, h2att(h) + offsets, the next gate
+            # product): the fp32 copy (a third of the gate kernel's stores) is then not written
+            const["h_planes_only"] = bool("w_off_h" in const and _GREEDY_MERGED and self.core.attend_pre_ok(const, st["tshapes"])
+                                          and self.core.gates_in_one_launch(st["h"], const)
+                                          and self._logit_planes(st["h"]) is not None)
         for t in range(t0, t1):
             if t > 0:
                 hp = getattr(st["h"], "_gvl_planes", None)

@@ -224,6 +224,40 @@ def ms_deform_attn_sample_backward(value, spatial_shapes, level_start_index, sam
     return grad_value, grad_loc
 
 
+def cap_attend_pre_applicable(S, n_levels, n_points, host_starts):
+    """does the precomputed-offsets form of the token step's attention exist for this pyramid (gvl_cap_attend_pre_applicable)"""
+    if host_starts is None or len(host_starts) != n_levels:
+        return False
+    arr = (ctypes.c_int64 * n_levels)(*[int(v) for v in host_starts])
+    return bool(_lib.lib().gvl_cap_attend_pre_applicable(int(S), int(n_levels), int(n_points), ctypes.cast(arr, ctypes.c_void_p)))
+
+
+def cap_attend_pre(slab, spatial_shapes, level_start_index, ref_in, off_hs, off_pre, att_h, alpha_w, alpha_b, n_levels, n_points,
+                   host_starts):
+    """cap_attend(planes=True) with the hidden-state part of the offsets precomputed: off_pre (B*Q, >= L*P) fp32, unit column
+    stride (gvl_cap_attend_pre_f32; callers check cap_attend_pre_applicable first)"""
+    for name, t_ in (("ref_in", ref_in), ("off_hs", off_hs), ("alpha_w", alpha_w)):
+        _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32,
+                 f"cap_attend_pre: {name} must be a contiguous fp32 CUDA tensor")
+    _require(slab.is_cuda and slab.is_contiguous() and slab.dtype == torch.float32, "cap_attend_pre: slab must be contiguous fp32")
+    for name, t_ in (("att_h", att_h), ("off_pre", off_pre)):
+        _require(t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1,
+                 f"cap_attend_pre: {name} must be an fp32 CUDA matrix with unit column stride")
+    B, S, C2 = slab.shape
+    C, Q, RD = C2 // 2, ref_in.shape[1], ref_in.shape[-1]
+    _require(off_pre.shape[0] == B * Q and off_pre.shape[1] >= n_levels * n_points, "cap_attend_pre: off_pre must be (B*Q, >= L*P)")
+    out = SplitPlanes(B * Q, C, slab.device)
+    hs_arr = (ctypes.c_int64 * n_levels)(*[int(v) for v in host_starts])
+    with torch.cuda.device(slab.device):
+        rc = _lib.lib().gvl_cap_attend_pre_f32(
+            slab.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref_in.data_ptr(), off_hs.data_ptr(),
+            off_pre.data_ptr(), off_pre.stride(0), att_h.data_ptr(), alpha_w.data_ptr(), float(alpha_b), B, S, C, n_levels, Q,
+            n_points, RD, att_h.stride(0), ctypes.cast(hs_arr, ctypes.c_void_p), out.hi.data_ptr(), out.lo.data_ptr(),
+            out.scale.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "cap_attend_pre")
+    return out
+
+
 def cap_attend(slab, spatial_shapes, level_start_index, ref_in, off_hs, h, w_off_h, att_h, alpha_w, alpha_b,
                n_levels, n_points, debug=False, planes=False, host_starts=None):
     """Fused deformable soft attention of one captioner token step (include/gvl_msda.h: gvl_cap_attend_f32 / _bf16).
@@ -620,11 +654,12 @@ def gates_applicable(n, H):
     return bool(_lib.lib().gvl_gemm_f16x3_gates_applicable(n, H))
 
 
-def gemm_f16x3_gates(a, h_prev, w, gates_c, emb_gates, it, c):
+def gemm_f16x3_gates(a, h_prev, w, gates_c, emb_gates, it, c, need_h=True):
     """(h', c') = LSTM cell of [h_prev | a] . w^T + gates_c + emb_gates[it] (include/gvl_msda.h: gvl_gemm_f16x3_gates_f32):
     a SplitPlanes (n, K_a), h_prev SplitPlanes (n, K_h) -- the planes of the step's incoming hidden state --, w SplitPlanes
     (4H, K_h + K_a) = [W_hh | W_ih[:, attention columns]] with rows in gate_permutation order; gates_c (n, 4H) / emb_gates
-    (V + 1, 4H) with columns in that order.  h' carries its planes."""
+    (V + 1, 4H) with columns in that order.  h' carries its planes; need_h=False: ONLY its planes are written (the returned h'
+    is an unwritten buffer marked ``_gvl_planes_only``)."""
     n, H = c.shape
     _require(a.rows == n and h_prev.rows == n and w.rows == 4 * H and a.cols + h_prev.cols == w.cols,
              "gemm_f16x3_gates: operand shapes")
@@ -641,10 +676,12 @@ def gemm_f16x3_gates(a, h_prev, w, gates_c, emb_gates, it, c):
             a.hi.data_ptr(), a.lo.data_ptr(), a.scale.data_ptr(), h_prev.hi.data_ptr(), h_prev.lo.data_ptr(),
             h_prev.scale.data_ptr(), n, w.hi.data_ptr(), w.lo.data_ptr(), w.scale.data_ptr(), H, h_prev.cols, a.cols,
             gates_c.data_ptr() if gates_c is not None else None, gates_c.stride(0) if gates_c is not None else 0,
-            emb_gates.data_ptr(), it.data_ptr(), c.data_ptr(), h_out.data_ptr(), c_out.data_ptr(), hp.hi.data_ptr(),
+            emb_gates.data_ptr(), it.data_ptr(), c.data_ptr(), h_out.data_ptr() if need_h else None, c_out.data_ptr(), hp.hi.data_ptr(),
             hp.lo.data_ptr(), hp.scale.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "gemm_f16x3_gates")
     h_out._gvl_planes = hp
+    if not need_h:
+        h_out._gvl_planes_only = True
     return h_out, c_out
 
 

@@ -6,7 +6,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GVL_LIB_PATH: a dev build (gvl_amd.build.build_dev: timing / ablation variants of single kernels) instead of the shipped library
 LIB_PATH = os.environ.get("GVL_LIB_PATH") or os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 12          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 13          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -54,6 +54,8 @@ SIGNATURES = {
     "gvl_lstm_cell_split_f32": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "gvl_cap_attend_split_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P]),
     "gvl_cap_attend_split_levels_f32": (_I, [_P] * 9 + [ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P, _P]),
+    "gvl_cap_attend_pre_applicable": (_I, [_I, _I, _I, _P]),
+    "gvl_cap_attend_pre_f32": (_I, [_P] * 6 + [_I] + [_P, _P, ctypes.c_float] + [_I] * 8 + [_P, _P, _P, _P, _P]),
     "gvl_cap_attend_train_forward_f32": (_I, [_P] * 6 + [_I, _P, _I, _P, _P] + [_I] * 7 + [_P, _P, _P, _P]),
     "gvl_cap_attend_train_backward_f32": (_I, [_P] * 6 + [_I, _P, _I, _P, _P, _P, _I] + [_I] * 7
                                           + [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P]),

@@ -304,7 +304,11 @@ __global__ void __launch_bounds__(kWaves * 64, (FULL && sizeof(ST) == 4) ? 3 : 2
 // n_ctx rows and the value half of its last n_val rows in LDS once (as many as fit beside the offsets weight) and every
 // sample whose rows lie there reads LDS (ds_read_b128, 4-8 x the rate) -- the test is wavefront-uniform (the row index
 // is a scalar).  fp32, L * P == 16, result as planes (the inference token loop).
-template <int WAVES>
+// PRE (round 5): the offsets' hidden-state part `h W_off^T` arrives precomputed (off_pre: it rides as 16 more columns in the
+// h2att(h) product in front of this kernel), so neither h nor the 32 KB weight is read, and the freed LDS takes the VALUE half of
+// level 2 as well (VAL_FROM = 8: samples 8 .. 15 of both halves are resident; 16 instead of 20 of a row's 32 sample reads go
+// through the CU's vector-memory path, which bounds the kernel).
+template <int WAVES, bool PRE = false, int VAL_FROM = 12>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) k_cap_attend_lds(
     const float *__restrict__ slab,         // (B, S, 2C)  [value_proj(memory) | ctx2att(value_proj(memory))]
     const int64_t *__restrict__ shapes,  // (L, 2)
@@ -318,11 +322,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) k_cap_attend_
     float alpha_b, int B, int S, int L, int Q, int P, int RD, int vids_per_xcd, int parts, int n_ctx, int n_val,
     int att_h_ld,
     _Float16 *__restrict__ o_hi,         // the result as the fp16 planes + row scale of gvl_gemm_f16x3_f32
-    _Float16 *__restrict__ o_lo, float *__restrict__ o_scale) {
+    _Float16 *__restrict__ o_lo, float *__restrict__ o_scale,
+    const float *__restrict__ off_pre = nullptr, int off_pre_ld = 0) {
   constexpr bool FULL = true;
-  extern __shared__ float4 cap_lds[];    // [offsets weight 32 KiB | ctx2att half of rows S - n_ctx .. | value half of rows S - n_val ..]
-  float4 *wo4 = cap_lds, *lds_ctx = cap_lds + kLP * kC / 4, *lds_val = lds_ctx + n_ctx * (kC / 4);
-  for (int i = threadIdx.x; i < kLP * kC / 4; i += blockDim.x) wo4[i] = reinterpret_cast<const float4 *>(w_off_h)[i];
+  extern __shared__ float4 cap_lds[];    // [offsets weight 32 KiB (not PRE) | ctx2att half of rows S - n_ctx .. | value half of rows S - n_val ..]
+  float4 *wo4 = cap_lds, *lds_ctx = cap_lds + (PRE ? 0 : kLP * kC / 4), *lds_val = lds_ctx + n_ctx * (kC / 4);
+  if constexpr (!PRE)
+    for (int i = threadIdx.x; i < kLP * kC / 4; i += blockDim.x) wo4[i] = reinterpret_cast<const float4 *>(w_off_h)[i];
 
   // workgroup -> (video, share of its queries): XCD x (= workgroup id % 8) serves videos [x vids_per_xcd, (x + 1)
   // vids_per_xcd), `parts` workgroups per video
@@ -344,18 +350,23 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) k_cap_attend_
   for (int q = q_begin + wave; q < q_end; q += WAVES) {
   const int64_t row = (int64_t)b * Q + q;
 
-  // own channels: [4*lane, 4*lane+4) and [256 + 4*lane, 256 + 4*lane + 4)
-  const float4 *h4 = reinterpret_cast<const float4 *>(h + row * kC);
-  const float4 ha = h4[lane], hb = h4[64 + lane];
-  float part[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const float4 wa = wo4[k * (kC / 4) + lane], wb = wo4[k * (kC / 4) + 64 + lane];
-    part[k] = wa.x * ha.x + wa.y * ha.y + wa.z * ha.z + wa.w * ha.w + wb.x * hb.x + wb.y * hb.y + wb.z * hb.z +
-              wb.w * hb.w;
-  }
   const int k_own = lane >> 2;                       // the sample this lane group owns after the butterfly
-  float off = butterfly16(part, lane);
+  float off;
+  if constexpr (PRE) {
+    off = off_pre[row * off_pre_ld + min(k_own, kLP - 1)];
+  } else {
+    // own channels: [4*lane, 4*lane+4) and [256 + 4*lane, 256 + 4*lane + 4)
+    const float4 *h4 = reinterpret_cast<const float4 *>(h + row * kC);
+    const float4 ha = h4[lane], hb = h4[64 + lane];
+    float part[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 wa = wo4[k * (kC / 4) + lane], wb = wo4[k * (kC / 4) + 64 + lane];
+      part[k] = wa.x * ha.x + wa.y * ha.y + wa.z * ha.z + wa.w * ha.w + wb.x * hb.x + wb.y * hb.y + wb.z * hb.z +
+                wb.w * hb.w;
+    }
+    off = butterfly16(part, lane);
+  }
   int roff = 0;
   float c_lo = 0.f, c_hi = 0.f, locx = 0.f;
   const int LP = FULL ? kLP : L * P;
@@ -386,7 +397,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) k_cap_attend_
     Rows r;
     // WHERE a sample's rows live is static: the ctx2att half of levels 2, 3 (samples 8 .. 15) and the value half of level
     // 3 (samples 12 .. 15) are resident (the host launches this kernel only when they fit)
-    if (half4 ? k >= 8 : k >= 12) {
+    if (half4 ? k >= 8 : k >= VAL_FROM) {
       const float4 *img = half4 ? lds_ctx : lds_val;
       const int first = half4 ? c0 : v0;
       const int i0 = (rr - first) * (kC / 4), i1 = (rr1 - first) * (kC / 4);
@@ -748,16 +759,36 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
                     const float *off_hs, const float *h, const float *w_off_h, const ST *att_h, const float *alpha_w,
                     float alpha_b, int B, int S, int C, int L, int Q, int P, int RD, int att_h_ld, ST *att_res,
                     float *dbg_alpha, float *dbg_loc, void *stream, void *o_hi = nullptr, void *o_lo = nullptr,
-                    float *o_scale = nullptr, const int64_t *lsi_host = nullptr) {
+                    float *o_scale = nullptr, const int64_t *lsi_host = nullptr, const float *off_pre = nullptr,
+                    int off_pre_ld = 0) {
   if (att_h_ld < C || (att_h_ld & 3)) return fail(GVL_EINVAL, "%s: att_h_ld must be >= C and a multiple of 4", what);
   if (C != kC || L * P > kLP || L <= 0 || P <= 0 || (RD != 1 && RD != 2) || B < 0 || Q < 0 || S <= 0)
     return fail(GVL_EINVAL, "%s: unsupported shape C=%d L=%d P=%d RD=%d (need C=512, L*P<=16)", what, C, L, P, RD);
   if ((int64_t)B * Q == 0) return 0;
-  if (!slab || !shapes || !lsi || !ref || !off_hs || !h || !w_off_h || !att_h || !alpha_w || (!att_res && !o_hi)
+  if (!slab || !shapes || !lsi || !ref || !off_hs || (!off_pre && (!h || !w_off_h)) || !att_h || !alpha_w || (!att_res && !o_hi)
       || (o_hi && (!o_lo || !o_scale)))
     return fail(GVL_EINVAL, "%s: null pointer", what);
   const int vids_per_group = (B + 7) / 8;
   if constexpr (std::is_same<ST, float>::value) {
+    if (off_pre) {
+      // precomputed offsets: the LDS form only (its conditions are what gvl_cap_attend_pre_applicable reports)
+      const int n_ctx = lsi_host ? S - (int)lsi_host[2] : 0, n_v3 = lsi_host ? S - (int)lsi_host[3] : 0;
+      if (!(o_hi && L == 4 && P == 4 && lsi_host && n_v3 >= 1 && n_ctx >= n_v3 && n_ctx + n_v3 <= 79) || off_pre_ld < kLP)
+        return fail(GVL_EINVAL, "%s: the precomputed-offsets form needs L = P = 4, host level starts and a coarse end that fits the LDS", what);
+      const bool val2 = 2 * n_ctx <= 79;                               // the value half of level 2 fits as well
+      const int n_val = val2 ? n_ctx : n_v3;
+      int parts = 32 / vids_per_group;
+      parts = parts < 1 ? 1 : (parts > Q ? Q : parts);
+      const size_t lds = (size_t)(n_ctx + n_val) * kC * sizeof(float);
+      auto go = [&](auto kernel) -> int {
+        if (int rc = gvl::ensure_lds(kernel, lds)) return rc;
+        return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend_lds<pre>", kernel, dim3(8 * vids_per_group * parts),
+                           dim3(12 * 64), lds, (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, (const float *)nullptr,
+                           (const float *)nullptr, att_h, alpha_w, alpha_b, B, S, L, Q, P, RD, vids_per_group, parts, n_ctx, n_val,
+                           att_h_ld, (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale, off_pre, off_pre_ld);
+      };
+      return val2 ? go(k_cap_attend_lds<12, true, 8>) : go(k_cap_attend_lds<12, true, 12>);
+    }
     const char *e = gvl::env_str("GVL_CAP_LDS");
     // rows of levels 2, 3 (ctx2att half) and of level 3 (value half): known to the caller that passes host level starts
     const int n_ctx = lsi_host ? S - (int)lsi_host[2] : 0, n_val = lsi_host ? S - (int)lsi_host[3] : 0;
@@ -773,12 +804,14 @@ int cap_attend_impl(const char *what, const ST *slab, const int64_t *shapes, con
         if (int rc = gvl::ensure_lds(k_cap_attend_lds<8>, lds)) return rc;
         return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend_lds", k_cap_attend_lds<8>, grid, dim3(8 * 64), lds,
                            (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h, alpha_w, alpha_b, B, S, L,
-                           Q, P, RD, vids_per_group, parts, n_ctx, n_val, att_h_ld, (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale);
+                           Q, P, RD, vids_per_group, parts, n_ctx, n_val, att_h_ld, (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale,
+                           (const float *)nullptr, 0);
       }
       if (int rc = gvl::ensure_lds(k_cap_attend_lds<12>, lds)) return rc;
       return gvl::launch(GVL_PROF_CAP_ATTEND, B * Q, B, "k_cap_attend_lds", k_cap_attend_lds<12>, grid, dim3(12 * 64), lds,
                          (hipStream_t)stream, slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h, alpha_w, alpha_b, B, S, L, Q,
-                         P, RD, vids_per_group, parts, n_ctx, n_val, att_h_ld, (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale);
+                         P, RD, vids_per_group, parts, n_ctx, n_val, att_h_ld, (_Float16 *)o_hi, (_Float16 *)o_lo, o_scale,
+                           (const float *)nullptr, 0);
     }
   }
   const int rows_per_group = vids_per_group * Q;
@@ -860,6 +893,22 @@ int gvl_cap_attend_split_levels_f32(const float *slab, const int64_t *shapes, co
   return cap_attend_impl<float>("gvl_cap_attend_split_levels_f32", slab, shapes, lsi, ref, off_hs, h, w_off_h, att_h,
                                 alpha_w, alpha_b, B, S, C, L, Q, P, RD, att_h_ld, (float *)nullptr, nullptr, nullptr, stream,
                                 att_hi, att_lo, att_scale, lsi_host);
+}
+
+int gvl_cap_attend_pre_applicable(int S, int L, int P, const int64_t *lsi_host) {
+  if (!lsi_host || L != 4 || P != 4 || S <= 0) return 0;
+  const int n_ctx = S - (int)lsi_host[2], n_v3 = S - (int)lsi_host[3];
+  return n_v3 >= 1 && n_ctx >= n_v3 && n_ctx + n_v3 <= 79;
+}
+
+int gvl_cap_attend_pre_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref, const float *off_hs,
+                           const float *off_pre, int off_pre_ld, const float *att_h, const float *alpha_w, float alpha_b, int B,
+                           int S, int C, int L, int Q, int P, int RD, int att_h_ld, const int64_t *lsi_host, void *att_hi,
+                           void *att_lo, float *att_scale, void *stream) {
+  if (!att_hi || !off_pre) return fail(GVL_EINVAL, "gvl_cap_attend_pre_f32: null pointer");
+  return cap_attend_impl<float>("gvl_cap_attend_pre_f32", slab, shapes, lsi, ref, off_hs, nullptr, nullptr, att_h, alpha_w,
+                                alpha_b, B, S, C, L, Q, P, RD, att_h_ld, (float *)nullptr, nullptr, nullptr, stream, att_hi, att_lo,
+                                att_scale, lsi_host, off_pre, off_pre_ld);
 }
 
 int gvl_lstm_cell_split_f32(const float *gates_a, int lda, const float *gates_b, int ldb, const float *emb_gates,

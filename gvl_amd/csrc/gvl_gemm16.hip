@@ -1565,7 +1565,7 @@ __global__ void __launch_bounds__(512, 1)
           float4 hv = *reinterpret_cast<const float4 *>(img_h + r * kLdT + 4 * u4);
           asm volatile("" : "+v"(hv.x), "+v"(hv.y), "+v"(hv.z), "+v"(hv.w));   // (h' as the fp32 numbers stored: see lstm_finish)
           *reinterpret_cast<float4 *>(ge.c_out + (int64_t)row * H + unit) = cv;
-          *reinterpret_cast<float4 *>(ge.h_out + (int64_t)row * H + unit) = hv;
+          if (ge.h_out) *reinterpret_cast<float4 *>(ge.h_out + (int64_t)row * H + unit) = hv;
           const float hx[4] = {hv.x, hv.y, hv.z, hv.w};
           _Float16 hh[4], hl[4];
 #pragma unroll
@@ -1876,7 +1876,7 @@ extern "C" int gvl_gemm_f16x3_gates_f32(const void *a_hi, const void *a_lo, cons
   if (gates_c && (ld_c < N4 || (ld_c & 3)))
     return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: gates_c needs a row stride >= 4H, a multiple of 4");
   if (n == 0) return 0;
-  if (!hp_hi || !hp_lo || !hp_scale || !emb_gates || !it || !c || !h_out || !c_out || !h_hi || !h_lo || !h_scale)
+  if (!hp_hi || !hp_lo || !hp_scale || !emb_gates || !it || !c || !c_out || !h_hi || !h_lo || !h_scale)   // (h_out: optional)
     return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: null pointer");
   if (hp_hi == h_hi || hp_lo == h_lo || c == c_out)
     return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: the new state must not overwrite the one the step reads");

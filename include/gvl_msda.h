@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 12  /* 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch), gvl_gemm_f16x3_gates_f32 / _applicable (both halves of the LSTM gate product + cell in one launch), gvl_greedy_step_partials_gemm_f32 (greedy reduction + an independent product in one launch), gvl_clip_adam_step_f32 (gradient clipping + Adam over a tensor table), gvl_group_norm_rows_backward_f32 / gvl_conv_taps_to_rows_f32 (training form of the base encoder's levels); 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 13  /* 13: + gvl_cap_attend_pre_f32 / _applicable (the offsets' hidden-state product arrives precomputed; half of the sample reads from LDS); 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch), gvl_gemm_f16x3_gates_f32 / _applicable (both halves of the LSTM gate product + cell in one launch), gvl_greedy_step_partials_gemm_f32 (greedy reduction + an independent product in one launch), gvl_clip_adam_step_f32 (gradient clipping + Adam over a tensor table), gvl_group_norm_rows_backward_f32 / gvl_conv_taps_to_rows_f32 (training form of the base encoder's levels); 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -287,6 +287,19 @@ int gvl_cap_attend_split_levels_f32(const float *slab, const int64_t *shapes, co
                                     const float *alpha_w, float alpha_b, int B, int S, int C, int L, int Q, int P, int RD,
                                     int att_h_ld, const int64_t *lsi_host, void *att_hi, void *att_lo, float *att_scale,
                                     void *stream);
+/*    gvl_cap_attend_pre_f32 = gvl_cap_attend_split_levels_f32 whose caller has ALREADY multiplied the hidden state into the
+ *        offsets (off_pre (B*Q, >= L*P) row stride off_pre_ld = h . sampling_offsets.weight[:, :C]^T,
+ *        ms_deform_attn_for_caption.py:100-103 -- in the token loop these are 16 more output columns of the h2att(h) product
+ *        that runs in front of this kernel).  Neither h nor the 32 KB weight is read; the LDS the weight occupied holds the
+ *        value half of level 2 too, so HALF of all sample reads are served from LDS.  The sum h W^T is then rounded as the
+ *        fp16x3 product rounds it (2^-21 relative of sum |h||w|) instead of as this kernel's fp32 butterfly does.
+ *        gvl_cap_attend_pre_applicable: 1 when the LDS form exists for this pyramid (L = P = 4, level starts known on the
+ *        host, levels 2 + 3 + 3 <= 79 rows); the entry fails with GVL_EINVAL otherwise. */
+int gvl_cap_attend_pre_applicable(int S, int L, int P, const int64_t *lsi_host);
+int gvl_cap_attend_pre_f32(const float *slab, const int64_t *shapes, const int64_t *lsi, const float *ref, const float *off_hs,
+                           const float *off_pre, int off_pre_ld, const float *att_h, const float *alpha_w, float alpha_b, int B,
+                           int S, int C, int L, int Q, int P, int RD, int att_h_ld, const int64_t *lsi_host, void *att_hi,
+                           void *att_lo, float *att_scale, void *stream);
 /*    gvl_gemm_f16x3_lstm_f32: the attention half of the LSTM input product WITH the cell applied to the finished tile
  *        (LSTM_DSA.py:267-269 + nn.LSTM's pointwise part, :216-217): gates = A (R, K) . W (4H, K)^T + gates_c + gates_h +
  *        emb_gates[it], (h', c') = cell(gates, c); the (R, 4H) product is never written and gvl_lstm_cell_split_f32 does not
@@ -304,7 +317,8 @@ int gvl_gemm_f16x3_lstm_f32(const void *a_hi, const void *a_lo, const float *a_s
  *        the planes (hp_*) of the step's incoming hidden state, the other K_a (weight_ih's attention columns) the planes of A;
  *        rows of W, columns of gates_c / emb_gates in the order 4 * unit + gate as for gvl_gemm_f16x3_lstm_f32.  The (n, 4H)
  *        recurrent part is neither written by a product in front nor read here.  The new state (h_out, c_out, planes) must be
- *        other buffers than the incoming one; outputs 16-byte aligned.  gvl_gemm_f16x3_gates_applicable(n, H): 1 when the
+ *        other buffers than the incoming one; outputs 16-byte aligned; h_out may be NULL (ABI 13: a caller whose readers of h'
+ *        all take the planes saves a third of the kernel's stores).  gvl_gemm_f16x3_gates_applicable(n, H): 1 when the
  *        kernel's 256 x 160 tiles fill the chip in whole rounds (cfg A: 240 tiles), else the two-launch form is the faster one. */
 int gvl_gemm_f16x3_gates_applicable(int n, int H);
 int gvl_gemm_f16x3_gates_f32(const void *a_hi, const void *a_lo, const float *a_scale, const void *hp_hi, const void *hp_lo,

@@ -320,9 +320,15 @@ def test_both_halves_of_the_gate_product_in_one_launch(n, Ka, H, with_c):
     h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
     tol = 2e-5 * max(1.0, float(gates.abs().max()))
     assert float((c1.double() - c_ref).abs().max()) < tol and float((h1.double() - h_ref).abs().max()) < tol
+    # h' as planes only (h_out = NULL: what the greedy loop asks for when every reader of h' takes the planes): the same bits
+    h2, c2 = MSDA.gemm_f16x3_gates(ap, hp, w_cat, gc_p, emb_p, it, c, need_h=False)
+    torch.cuda.synchronize()
+    p2 = h2._gvl_planes
+    assert h2._gvl_planes_only and torch.equal(c2, c1)
+    assert torch.equal(p2.hi, p1.hi) and torch.equal(p2.lo, p1.lo) and torch.equal(p2.scale, p1.scale)
 
 
-@pytest.mark.parametrize("R,V,Ra,Nb", [(4800, 8518, 4800, 512), (100, 300, 77, 64), (33, 70, 1100, 200)])
+@pytest.mark.parametrize("R,V,Ra,Nb", [(4800, 8518, 4800, 512), (4800, 8518, 4800, 528), (100, 300, 77, 64), (33, 70, 1100, 200)])
 def test_greedy_reduction_and_an_independent_product_in_one_launch(R, V, Ra, Nb):
     """gvl_greedy_step_partials_gemm_f32 = gvl_greedy_step_partials_alive_f32 + gvl_gemm_f16x3_f32 (its four-wavefront form) as ONE
     launch: the same bits as the two launches -- tokens, log-probabilities, bookkeeping, product"""

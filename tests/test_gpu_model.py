@@ -187,6 +187,46 @@ def test_cap_attend_kernel_matches_unfused_reference_order():
         assert torch.equal(pl2.hi, pl.hi) and torch.equal(pl2.lo, pl.lo) and torch.equal(pl2.scale, pl.scale)
 
 
+def test_cap_attend_with_precomputed_offsets_matches_the_kernel_that_multiplies_them():
+    """gvl_cap_attend_pre_f32 (h . W_off^T handed in; both halves of levels 2 and 3 -- or, for a longer pyramid, only the ctx2att
+    half of level 2 -- in LDS) against gvl_cap_attend_split_f32 on the same inputs: the two differ only in how the 512-term
+    offset sum is rounded, which moves a sampling location by ~1e-6 of a row."""
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd.deformable_transformer import make_level_tensors
+    from gvl_amd.ops.modules.ms_deform_attn import temporal_shapes_2d
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    C, L, P = 512, 4, 4
+    for B, Q, lens, RD in ((3, 37, [50, 25, 13, 1], 1), (2, 50, [120, 60, 30, 15], 2), (9, 20, [100, 50, 25, 13], 1)):
+        S = sum(lens)
+        lsi = [0] + list(np.cumsum(lens)[:-1])
+        assert MSDA.cap_attend_pre_applicable(S, L, P, lsi)
+        slab = torch.randn(B, S, 2 * C, generator=g).to(dev)
+        Wo = (torch.randn(L * P, C, generator=g) / 16).to(dev)
+        h = (torch.randn(B * Q, C, generator=g) * 0.5).to(dev)
+        off_hs = torch.randn(B, Q, L * P, generator=g).to(dev)
+        ref = torch.rand(B, Q, L, RD, generator=g) * 1.2 - 0.1
+        if RD == 2:
+            ref[..., 1] = ref[..., 1] * 0.4
+        ref = ref.contiguous().to(dev)
+        att_h = torch.randn(B * Q, C, generator=g).to(dev)
+        aw, ab = (torch.randn(C, generator=g) / 10).to(dev), 0.3
+        tsh, lsi_d = make_level_tensors(lens, dev)
+        shapes2d = temporal_shapes_2d(tsh, lsi_d)
+        want = MSDA.cap_attend(slab, shapes2d, lsi_d, ref, off_hs, h, Wo, att_h, aw, ab, L, P, planes=True)
+        # the operands as the token loop hands them over: columns of ONE wider matrix [h2att(h) | h W_off^T]
+        wide = torch.cat([att_h, (h.double() @ Wo.double().t()).float()], 1).contiguous()
+        got = MSDA.cap_attend_pre(slab, shapes2d, lsi_d, ref, off_hs, wide[:, C:], wide[:, :C], aw, ab, L, P, lsi)
+        torch.cuda.synchronize()
+
+        def dense(pl):
+            hi_, lo_ = pl.dense()
+            return pl.scale.double()[:, None] * (hi_.double() + lo_.double() / 2048.0)
+        assert maxerr(dense(got), dense(want)) < 2e-5
+    assert not MSDA.cap_attend_pre_applicable(375, L, P, [0, 200, 300, 350])       # levels 2 + 3 + 3 = 100 rows: no LDS form
+    assert not MSDA.cap_attend_pre_applicable(S, L, P, None)
+
+
 def test_row_argmax_lse_matches_torch():
     from gvl_amd import MultiScaleDeformableAttention as MSDA
     dev = torch.device("cuda:0")
