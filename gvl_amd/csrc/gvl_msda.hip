@@ -251,8 +251,12 @@ __device__ inline float row_bcast_f(float v) { return dpp_f<0x150 + SRC>(v); }
 typedef float f2v __attribute__((ext_vector_type(2)));
 template <int SRC>
 __device__ inline f2v row_bcast_f2(f2v v) {
+#ifdef GVL_BCAST_2X32   // timing build: two 32-bit broadcasts instead of one 64-bit
+  return (f2v){row_bcast_f<SRC>(v.x), row_bcast_f<SRC>(v.y)};
+#else
   const long long r = __builtin_amdgcn_update_dpp((long long)0, __builtin_bit_cast(long long, v), 0x150 + SRC, 0xF, 0xF, true);
   return __builtin_bit_cast(f2v, r);
+#endif
 }
 // lane SRC's v broadcast over its row and added to this lane's `addend`, in ONE VALU instruction (v_add_u32_dpp).  The
 // compiler's DPP combiner does not fold the v_mov_dpp + v_add pair of the forward sample step (the broadcast is
@@ -340,19 +344,20 @@ __device__ inline Coef1D coef_1d(float lx, float ly, int T) {
   const float xf = floorf(x);
   const int x0 = (int)xf;
   const float a = x - xf;
-  const float t0 = (x0 >= 0 && x0 <= T - 1) ? (1.f - a) : 0.f;      // weight of tap x0      (cuh:57-61)
-  const float t1 = (x0 + 1 >= 0 && x0 + 1 <= T - 1) ? a : 0.f;      // weight of tap x0 + 1  (cuh:62-67)
-  const float s0 = (x0 >= 0 && x0 <= T - 1) ? -1.f : 0.f;           // d/dx of the two taps  (cuh:125,134)
-  const float s1 = (x0 + 1 >= 0 && x0 + 1 <= T - 1) ? 1.f : 0.f;
-  int r = x0;
+  // Taps x0 (weight 1 - a, d/dx = -1) and x0 + 1 (weight a, d/dx = +1), each counted only inside [0, T - 1] (cuh:57-67,
+  // 125,134), laid on the row pair (r, r + 1) with r = x0 clamped to [0, max(T - 2, 0)].  x0 is in [-1, T - 1] here, so
+  // there are three cases: x0 = -1 (`below`: only tap x0 + 1 = row r counts), x0 = T - 1 > r (`above`: only tap x0 = row r + 1),
+  // else tap x0 = row r and tap x0 + 1 = row r + 1 (which does not exist when T = 1).  Two compares + selects: the sample loops
+  // are VALU-issue bound and the tap-by-tap form (four range tests, four equality tests, eight selects) was 16 instructions
+  // more per pass; same numbers (each coefficient was one term + 0).
   const int rmax = T >= 2 ? T - 2 : 0;
-  r = r < 0 ? 0 : (r > rmax ? rmax : r);
-  c.r = r;
-  const bool lo0 = (x0 == r), lo1 = (x0 + 1 == r), hi0 = (x0 == r + 1), hi1 = (x0 + 1 == r + 1);
-  c.c_lo = (lo0 ? t0 : 0.f) + (lo1 ? t1 : 0.f);
-  c.c_hi = (hi0 ? t0 : 0.f) + (hi1 ? t1 : 0.f);
-  c.dx_lo = dmx * ((lo0 ? s0 : 0.f) + (lo1 ? s1 : 0.f));
-  c.dx_hi = dmx * ((hi0 ? s0 : 0.f) + (hi1 ? s1 : 0.f));
+  const bool below = x0 < 0, above = x0 > rmax, two = T >= 2;
+  c.r = below ? 0 : (above ? rmax : x0);
+  const float b = 1.f - a;
+  c.c_lo = below ? a : (above ? 0.f : b);
+  c.c_hi = below ? 0.f : (above ? b : (two ? a : 0.f));
+  c.dx_lo = below ? dmx : (above ? 0.f : -dmx);
+  c.dx_hi = below ? 0.f : (above ? -dmx : (two ? dmx : 0.f));
   return c;
 }
 
@@ -408,7 +413,7 @@ __device__ inline RawOps fetch_ops(const void *__restrict__ p0, const float *__r
     r.b = (float)row[M * LP + m * LP + j];
     const float *rp = p1 + (bq * L + l) * RD;
     r.c = rp[0];
-    r.d = RD == 2 ? rp[1] : 0.f;
+    r.d = rp[RD == 2 ? 1 : 0];                                         // (branch-free, see fetch_at; RD == 1: not used)
   }
   return r;
 }
@@ -427,17 +432,23 @@ __device__ inline RawOps fetch_at(const void *__restrict__ p0, const float *__re
     const VT *row = reinterpret_cast<const VT *>(p0) + o0;
     r.a = (float)row[0];
     r.b = (float)row[MLP];
+    // (branch-free: behind a conditional load the compiler waits for EVERY outstanding load -- vmcnt(0) -- which put the
+    // operand fetches of consecutive passes and the slab staging in series)
     r.c = p1[o1];
-    r.d = RD == 2 ? p1[o1 + 1] : 0.f;
+    r.d = p1[o1 + (RD == 2 ? 1 : 0)];                                 // (RD == 1: not used by resolve_ops)
   }
   return r;
 }
 
+// (v_max_f32 with the DPP control on its own operand: written as fmaxf(v, dpp(v)) the compiler emits v_mov_dpp + a
+// canonicalising v_max of the moved value + the v_max -- 12 VALU instructions per reduction instead of 4 in loops that are
+// VALU-issue bound.  `s_nop 1`: the two wait states between a VALU write and a DPP read of the same register.)
 __device__ inline float row_allmax(float v) {
-  v = fmaxf(v, dpp_f<0xB1>(v));
-  v = fmaxf(v, dpp_f<0x4E>(v));
-  v = fmaxf(v, dpp_f<0x124>(v));
-  v = fmaxf(v, dpp_f<0x128>(v));
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(v));
   return v;
 }
 
@@ -472,7 +483,7 @@ __device__ inline int slab_of_block(int idx, int BM) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// t1d_d64 forward.  grid = nchunk * B*M workgroups; workgroups of one (b,m) are B*M apart => same XCD L2.
+// t1d_d64 forward.  grid = (B*M, nchunk) workgroups; workgroups of one (b,m) are B*M apart in dispatch order => same XCD L2.
 // ------------------------------------------------------------------------------------------------------
 // AMAX: additionally leave max |out[b, q, :]| per output ROW in amax_out (B*Q floats, zero-initialised by the caller) --
 // the row maximum the split-fp16 output projection behind it (gvl_layers.hip) derives its operand scale from.  A row's
@@ -484,30 +495,39 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
                                                      int P, int RD, int nchunk, VT *__restrict__ out,
                                                      unsigned long long *__restrict__ stamps,
-                                                     unsigned *__restrict__ amax_out) {
+                                                     unsigned *__restrict__ amax_out, int qper, int m_shift) {
   extern __shared__ float4 slab4[];
-  // diagnostics (gvl_msda_debug_stamps): 100 MHz wall-clock stamps per workgroup {start, slab staged, loop done}
-  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
+  // grid = (B*M, nchunk): workgroups are dispatched x first, so the linear id (what the XCD round-robin sees) is
+  // chunk * B*M + slab as before -- but neither a modulo nor a division by B*M is computed here, the chunk length comes from
+  // the host and b, m come from a shift when M is a power of two (m_shift >= 0): four runtime integer divisions were ~80
+  // instructions in front of the kernel's first memory request.
   const int BM = B * M;
+  const int wg_id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  // diagnostics (gvl_msda_debug_stamps): 100 MHz wall-clock stamps per workgroup {start, slab staged, loop done}
+  if (stamps && threadIdx.x == 0) stamps[wg_id * 4 + 0] = wall_clock64();
   // (nchunk < 0: diagnostic A/B switch GVL_MSDA_XCD_PAIRS=0 -- the plain id -> slab map)
-  const int bm = nchunk < 0 ? (int)(blockIdx.x % BM) : slab_of_block(blockIdx.x % BM, BM), chunk = blockIdx.x / BM;
-  nchunk = nchunk < 0 ? -nchunk : nchunk;
-  const int b = bm / M, m = bm % M;
+  const int bm = nchunk < 0 ? (int)blockIdx.x : slab_of_block((int)blockIdx.x, BM), chunk = (int)blockIdx.y;
+  int b, m;
+  if (m_shift >= 0) { b = bm >> m_shift; m = bm & (M - 1); }
+  else { b = bm / M; m = bm % M; }
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // FULL16: L*P == 16 is a compile-time fact, the 16 sample steps below have no branches between them and the
   // scheduler can put all 32 ds_read_b128 of a pass in flight at once instead of one LDS round trip per step
   const int LP = FULL16 ? 16 : L * P;
-  const int qper = (Q + nchunk - 1) / nchunk;
   const int q0 = chunk * qper;
   const int q1 = min(Q, q0 + qper);
   // The kernel is a latency chain (launch -> slab -> LDS reads), so every global load that does not depend on LDS
   // is issued before the slab staging, and each pass prefetches the sampling operands of the next one.
   int Tl = 1, st = 0;
-  const int lvl = j < LP ? j / P : 0;
+  // (FULL16: L * P = 16, so j / P = j * L / 16 -- a runtime division is ~20 vector instructions, and everything in front of
+  // the barrier is on the critical path of a kernel whose set-up is bound by VALU issue)
+  const int lvl = FULL16 ? (j * L) >> 4 : (j < LP ? j / P : 0);
   if (j < LP) {
-    Tl = (int)shapes[2 * lvl + 1];
-    st = (int)lsi[lvl];
+    // the LOW dwords of the int64 entries: loaded as 64-bit values their unused high halves are registers the compiler
+    // re-uses at once -- and it then waits for the load (vmcnt(0)) in front of every request that should have followed it
+    Tl = reinterpret_cast<const int *>(shapes)[2 * (2 * lvl + 1)];
+    st = reinterpret_cast<const int *>(lsi)[2 * lvl];
   }
   int qb = q0 + wave * 4;
   // operand cursor: query index of the next fetch and the lane's element offsets for it, advanced by a constant per pass
@@ -516,22 +536,37 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   int64_t o0 = FUSED ? ((int64_t)b * Q + qf) * (2 * MLP) + m * LP + j : (((int64_t)b * Q + qf) * M + m) * LP + j;
   int64_t o1 = FUSED ? (((int64_t)b * Q + qf) * L + lvl) * RD : 0;
   const int64_t step0 = (int64_t)nw * 4 * (FUSED ? 2 * MLP : MLP), step1 = FUSED ? (int64_t)nw * 4 * L * RD : 0;
+  // FULL16: no branch around the loads -- lanes past the end of the list re-read the list's last query (their results are
+  // never stored).  Behind a guarded load the compiler cannot count the requests in flight and waits for ALL of them
+  // (vmcnt(0)) before the first use of any operand, the slab transfer included.
+  const int64_t o0_last = o0 + (int64_t)(q1 - 1 - qf) * (FUSED ? 2 * MLP : MLP), o1_last = o1 + (int64_t)(q1 - 1 - qf) * (FUSED ? L * RD : 0);
   auto fetch_next = [&]() {
     RawOps r = {0.f, 0.5f, 0.f, 0.f};
-    if (qf < q1 && j < LP) r = fetch_at<FUSED, VT>(loc, attn, o0, o1, MLP, RD);
+    if constexpr (FULL16) {
+      const bool in = qf < q1;
+      r = fetch_at<FUSED, VT>(loc, attn, in ? o0 : o0_last, in ? o1 : o1_last, MLP, RD);
+    } else {
+      if (qf < q1 && j < LP) r = fetch_at<FUSED, VT>(loc, attn, o0, o1, MLP, RD);
+    }
     qf += nw * 4;
     o0 += step0;
     o1 += step1;
     return r;
   };
   RawOps r_n = fetch_next();
+  int64_t o_out = (((int64_t)b * Q + qb + tq) * M + m) * 16 + j;       // this lane's output quad, advanced per pass
+  const int64_t step_out = (int64_t)nw * 4 * M * 16;
   // L0G: level 0 (rows [0, T_0)) stays in global memory, LDS holds rows [T_0, S); needs FULL16 and P == 4 so that
   // "sample step SI belongs to level 0" is the compile-time test SI < 4
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;
   const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;               // this lane's channels of row 0 of the slab
   const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
   // sampling operands -> (slab row as LDS byte offset | global row index for L0G level 0, coefficient pair)
-  auto prep = [&](const RawOps &r, int &roff, f2v &cc) {
+  auto prep = [&](const RawOps &r_in, int &roff, f2v &cc) {
+    // (the operands as opaque values from here on: otherwise the first instructions of resolve_ops are hoisted into the
+    // guarded fetch that requested them -- where they wait for the loads, in front of every later request)
+    RawOps r = r_in;
+    asm("" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d));
     float2 xy;
     float w, dloc_;
     resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc_);
@@ -544,79 +579,164 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
       cc = (f2v){c.c_lo * ww, c.c_hi * ww};
     }
   };
-  // Slab staging, software-pipelined against the first pass's coefficient arithmetic: the first (up to) four float4
-  // per thread are requested, the ~100 VALU instructions of prep() run while they are in flight (its own operands
-  // were requested earlier and return first), then the registers go to LDS.  Larger slabs finish with a plain loop.
-  constexpr int kPre = 4;
+  // Slab staging, software-pipelined against the coefficient arithmetic of the first kAhead passes.  The sample loop is
+  // bound by VALU issue (round 5: 168 vector instructions per wavefront pass, ~100 of them prep()), while between the kernel's
+  // start and the barrier behind the staging the vector ALUs have nothing to do for 2.3-2.8 us (cfg A: one cold round trip
+  // for 48 KB per CU).  So the operands of the first kAhead passes are requested up front, the slab's float4 are requested, and
+  // prep() of all kAhead passes runs while they travel; those passes then consist of the 16 sample steps alone.  cfg A has
+  // 2.3 passes per wavefront (150 queries per workgroup, 64 per pass): every pass's coefficients are ready at the barrier.
+  // Later passes (longer query lists) run as before: operands two passes ahead, coefficients one pass ahead, inside the loop.
+  constexpr int kPre = 4, kAhead = 3;
   const int64_t src0 = ((int64_t)b * S * M + m) * 16;
   const int nstage = (S - row0) * 16;
+  const int pstep = nw * 4;
+  RawOps r_a[kAhead];
+  r_a[0] = r_n;
+#pragma unroll
+  for (int k = 1; k < kAhead; ++k) r_a[k] = fetch_next();
+  r_n = fetch_next();                                                  // operands of pass kAhead (requested BEFORE the slab:
+                                                                       // requests retire in order, the operands must not queue behind it)
+  // fp32 slabs go to LDS by LDS-DMA (global_load_lds_dwordx4: lane l of a wavefront writes 16 bytes at M0 + 16 l -- exactly
+  // slab4[i] for i = thread + k * blockDim): no data registers, so nothing the compiler could copy or wait for between the
+  // request and the barrier (staged through registers it placed a vmcnt(0) in the middle of the coefficient arithmetic that
+  // should run under the transfer).  Inline assembly, because the compiler cannot count the requests of a loop whose trip
+  // count it does not know and then waits for ALL outstanding loads before the first use of an operand requested earlier;
+  // unseen requests only make its counted waits stricter (they retire in order, the operands first).  The wait for the
+  // transfers themselves is the explicit vmcnt(0) in front of the barrier.  bf16 slabs are widened on the way and keep the
+  // register path.
+  constexpr bool kDma = std::is_same<VT, float>::value;
   float4 pre[kPre];
+  if constexpr (kDma) {
+    for (int i = threadIdx.x; i < nstage; i += blockDim.x) {
+      const float *src = reinterpret_cast<const float *>(value) + (src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15)) * 4;
+      const int dst = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(lds_cbyte *)reinterpret_cast<const char *>(slab4 + (i - lane)));
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory");
+    }
+  } else {
 #pragma unroll
-  for (int k = 0; k < kPre; ++k) {
-    const int i = threadIdx.x + k * blockDim.x;
-    if (i < nstage) pre[k] = ld4(value, src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15));
+    for (int k = 0; k < kPre; ++k) {
+      const int i = min((int)(threadIdx.x + k * blockDim.x), nstage - 1);
+      pre[k] = ld4(value, src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15));
+    }
   }
-  int roff_c;
-  f2v cc_c;
-  prep(r_n, roff_c, cc_c);
-  r_n = fetch_next();                                                  // operands of the second pass
+  int roff_a[kAhead];
+  f2v cc_a[kAhead];
 #pragma unroll
-  for (int k = 0; k < kPre; ++k) {
-    const int i = threadIdx.x + k * blockDim.x;
-    if (i < nstage) slab4[i] = pre[k];
+  for (int k = 0; k < kAhead; ++k) {
+    roff_a[k] = 0;
+    cc_a[k] = (f2v){0.f, 0.f};
+    if (qb + k * pstep < q1) prep(r_a[k], roff_a[k], cc_a[k]);         // (wave-uniform)
   }
-  for (int i = threadIdx.x + kPre * blockDim.x; i < nstage; i += blockDim.x)
-    slab4[i] = ld4(value, src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15));
+  int roff_c = 0;
+  f2v cc_c = {0.f, 0.f};
+  if (qb + kAhead * pstep < q1) {                                      // a longer list: the generic loop's pipeline, primed
+    prep(r_n, roff_c, cc_c);
+    r_n = fetch_next();
+  }
+  if constexpr (!kDma) {
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      if (i < nstage) slab4[i] = pre[k];
+    }
+    for (int i = threadIdx.x + kPre * blockDim.x; i < nstage; i += blockDim.x)
+      slab4[i] = ld4(value, src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15));
+  }
   if (threadIdx.x < 16) slab4[nstage + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
   __syncthreads();
-  if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
+  if (stamps && threadIdx.x == 0) stamps[wg_id * 4 + 1] = wall_clock64();
   const char *slab_b = reinterpret_cast<const char *>(slab4);
   const int lane_off = j * 16;
   const int lane_lds = (int)(uintptr_t)(lds_cbyte *)slab_b + lane_off;          // this lane's 16-byte column, LDS address
 
-  for (; qb < q1; qb += nw * 4) {
+  // one pass = the 16 sample steps of the wavefront's four queries + the store.  Per sample step: v_add_u32_dpp (row
+  // broadcast + lane offset = LDS address), v_mov_b64_dpp (both coefficients), 2 ds_read_b128, 4 v_pk_fma_f32.
+  // (Round 5, with prep() still inside the loop: requesting the reads of four steps together, two groups in flight, changed
+  // nothing -- 4.52 -> 4.75 us in situ at 118 registers -- and neither did 35 fewer VALU instructions per pass; what did was
+  // moving prep() under the slab transfer.)
+#ifdef GVL_FWD_ABL_NO_LDS      // timing build (tools/fwd_ablate.sh): the sample steps without their LDS reads
+#define GVL_FWD_ROWS(ROW, V0, V1) { const float t_ = __builtin_bit_cast(float, (int)(uintptr_t)(ROW)); V0 = make_float4(t_, cc.x, t_, cc.y); V1 = V0; }
+#else
+#define GVL_FWD_ROWS(ROW, V0, V1) { V0 = lds_ld4(ROW); V1 = lds_ld4((ROW) + 256); }
+#endif
+  auto run_pass = [&](const int roff, const f2v cc) {
     const int q = qb + tq;
     const bool act = q < q1;
-    const int roff = roff_c;
-    const f2v cc = cc_c;
-    // operands two passes ahead are requested now; the coefficients of the NEXT pass are computed at the end of this
-    // one, from operands requested one pass ago
-    const RawOps r_next = r_n;
-    r_n = fetch_next();
     f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-    // per sample step: v_add_u32_dpp (row broadcast + lane offset = LDS address), v_mov_b64_dpp (both coefficients),
-    // 2 ds_read_b128, 4 v_pk_fma_f32 -- the loop is VALU-issue bound (tools/fwd_phase_stamps.py), every instruction counts
 #define GVL_FWD_STEP(SI)                                                        \
   if (FULL16 || SI < LP) {                                                      \
     const f2v c2 = row_bcast_f2<SI>(cc);                                        \
     float4 v0, v1;                                                              \
-    if (L0G && SI < 4) {                                                        \
-      const int ro = row_bcast_i<SI>(roff);                                     \
-      v0 = ld4(value, vg + (int64_t)ro * (M * 16));                             \
-      v1 = ld4(value, vg + (int64_t)min(ro + 1, S - 1) * (M * 16));             \
-    } else {                                                                    \
-      lds_cbyte *row = (lds_cbyte *)(uintptr_t)(unsigned)row_bcast_add<SI>(roff, lane_lds, SI == (L0G ? 4 : 0)); \
-      v0 = lds_ld4(row);                                                        \
-      v1 = lds_ld4(row + 256);                                                  \
-    }                                                                           \
+    lds_cbyte *row = (lds_cbyte *)(uintptr_t)(unsigned)row_bcast_add<SI>(roff, lane_lds, SI == (L0G ? 4 : 0)); \
+    GVL_FWD_ROWS(row, v0, v1)                                                   \
     fma4x2(c2, v0, v1, a01, a23);                                               \
   }
-    GVL_FWD_STEP(0) GVL_FWD_STEP(1) GVL_FWD_STEP(2) GVL_FWD_STEP(3)
-    GVL_FWD_STEP(4) GVL_FWD_STEP(5) GVL_FWD_STEP(6) GVL_FWD_STEP(7)
-    GVL_FWD_STEP(8) GVL_FWD_STEP(9) GVL_FWD_STEP(10) GVL_FWD_STEP(11)
-    GVL_FWD_STEP(12) GVL_FWD_STEP(13) GVL_FWD_STEP(14) GVL_FWD_STEP(15)
+    // The fences after every four steps bound the reads in flight (left alone the scheduler requests all 32 rows of a pass up
+    // front and, with the coefficients of kAhead passes live, spills) and pin the accumulators: without AMAX their only use
+    // is the guarded store, and the optimiser sinks the whole FMA chain of a pass into that guard -- behind all 32 reads.
+    // Inside a group the compiler keeps two reads in flight.  Requesting a group's eight reads together was measured again
+    // with prep() out of the loop (tools/fwd_ab.sh): loop 3.27 -> 3.41 us in situ.  Neither the LDS round trips nor the LDS
+    // bandwidth set the pass time: with the reads REMOVED (-DGVL_FWD_ABL_NO_LDS) the loop still takes 2.99 us -- it is the
+    // issue of the 64 v_pk_fma_f32 per wavefront pass (8 clocks each: 2.0 us per workgroup) plus 56 other vector instructions.
+#define GVL_FWD_FENCE asm volatile("" : "+v"(a01), "+v"(a23) : : "memory"); __builtin_amdgcn_sched_barrier(0);
+#define GVL_FWD_QUAD(S0) GVL_FWD_STEP(S0) GVL_FWD_STEP(S0 + 1) GVL_FWD_STEP(S0 + 2) GVL_FWD_STEP(S0 + 3) GVL_FWD_FENCE
+    if constexpr (L0G) {
+      // level 0 from global memory / L2: its eight rows are requested first and consumed last, the twelve LDS steps run
+      // while they travel
+      float4 g0[4], g1[4];
+#define GVL_FWD_G(SI)                                                           \
+  {                                                                             \
+    const int ro = row_bcast_i<SI>(roff);                                       \
+    g0[SI] = ld4(value, vg + (int64_t)ro * (M * 16));                           \
+    g1[SI] = ld4(value, vg + (int64_t)min(ro + 1, S - 1) * (M * 16));           \
+  }
+      GVL_FWD_G(0) GVL_FWD_G(1) GVL_FWD_G(2) GVL_FWD_G(3)
+#undef GVL_FWD_G
+      GVL_FWD_FENCE
+      GVL_FWD_QUAD(4) GVL_FWD_QUAD(8) GVL_FWD_QUAD(12)
+      fma4x2(row_bcast_f2<0>(cc), g0[0], g1[0], a01, a23);
+      fma4x2(row_bcast_f2<1>(cc), g0[1], g1[1], a01, a23);
+      fma4x2(row_bcast_f2<2>(cc), g0[2], g1[2], a01, a23);
+      fma4x2(row_bcast_f2<3>(cc), g0[3], g1[3], a01, a23);
+    } else if constexpr (FULL16) {
+      GVL_FWD_QUAD(0) GVL_FWD_QUAD(4) GVL_FWD_QUAD(8) GVL_FWD_QUAD(12)
+    } else {
+      GVL_FWD_STEP(0) GVL_FWD_STEP(1) GVL_FWD_STEP(2) GVL_FWD_STEP(3)
+      GVL_FWD_STEP(4) GVL_FWD_STEP(5) GVL_FWD_STEP(6) GVL_FWD_STEP(7)
+      GVL_FWD_STEP(8) GVL_FWD_STEP(9) GVL_FWD_STEP(10) GVL_FWD_STEP(11)
+      GVL_FWD_STEP(12) GVL_FWD_STEP(13) GVL_FWD_STEP(14) GVL_FWD_STEP(15)
+    }
+    GVL_FWD_FENCE
+#undef GVL_FWD_QUAD
+#undef GVL_FWD_FENCE
 #undef GVL_FWD_STEP
+#undef GVL_FWD_ROWS
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
-    if (act) st4_stream(out, (((int64_t)b * Q + q) * M + m) * 16 + j, acc);
+    if (act) st4_stream(out, o_out, acc);
+    o_out += step_out;
     if (AMAX) {
       const float mx = row_allmax(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
       if (act && j == 0) atomicMax(amax_out + (int64_t)b * Q + q, __float_as_uint(mx));
     }
-    if (qb + nw * 4 < q1) prep(r_next, roff_c, cc_c);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll
+  for (int k = 0; k < kAhead; ++k) {
+    if (qb < q1) run_pass(roff_a[k], cc_a[k]);
+    qb += pstep;
+  }
+  for (; qb < q1; qb += pstep) {
+    // operands two passes ahead are requested now; the coefficients of the NEXT pass are computed at the end of this
+    // one, from operands requested one pass ago
+    const RawOps r_next = r_n;
+    r_n = fetch_next();
+    run_pass(roff_c, cc_c);
+    if (qb + pstep < q1) prep(r_next, roff_c, cc_c);
   }
   if (stamps) {
     __syncthreads();
-    if (threadIdx.x == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
+    if (threadIdx.x == 0) stamps[wg_id * 4 + 2] = wall_clock64();
   }
 }
 
@@ -1808,9 +1928,10 @@ int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
   g_last_impl = FUSED ? 3 : 2;
   g_last_kernel = "k_fwd_t1d_d64";
   return gvl::launch(GVL_PROF_FWD_T1D, Q, B, FUSED ? "k_fwd_t1d_d64<fused>" : "k_fwd_t1d_d64", kern,
-                     dim3(nchunk * B * M), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
+                     dim3(B * M, nchunk), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
                      env_int("GVL_MSDA_XCD_PAIRS", 1) ? nchunk : -nchunk, out, g_fwd_stamps,
-                     reinterpret_cast<unsigned *>(amax_out));
+                     reinterpret_cast<unsigned *>(amax_out), (Q + nchunk - 1) / nchunk,
+                     (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1);
 }
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
