@@ -512,8 +512,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   else { b = bm / M; m = bm % M; }
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  // FULL16: L*P == 16 is a compile-time fact, the 16 sample steps below have no branches between them and the
-  // scheduler can put all 32 ds_read_b128 of a pass in flight at once instead of one LDS round trip per step
+  // FULL16: L*P == 16 is a compile-time fact: no branches between the 16 sample steps, none around the operand fetches
   const int LP = FULL16 ? 16 : L * P;
   const int q0 = chunk * qper;
   const int q1 = min(Q, q0 + qper);
