@@ -663,12 +663,17 @@ class Captioner(nn.Module):
         # embedding rows pre-multiplied by their slice of W_ih: one gather per step instead of a GEMM
         emb_gates = self._embedding_gates(const.get("gate_perm"))
         # the recurrent state is fp32, also under autocast; h, c (and the greedy loop's log-prob table) share ONE zero fill
-        T_ = self.max_caption_len
-        zbuf = torch.zeros(2 * n * self.rnn_size + n * T_, dtype=torch.float32, device=hs.device)
+        # ... and so do the greedy loop's integer state (<bos> tokens, the token table) and its `alive` flags: byte ranges of it
+        T_ = T = self.max_caption_len
+        n_f = 2 * n * self.rnn_size + n * T_
+        b_f = (4 * n_f + 15) // 16 * 16
+        b_l = (8 * (n + n * T) + 15) // 16 * 16
+        raw = torch.zeros(b_f + b_l + T, dtype=torch.uint8, device=hs.device)
+        zbuf = raw[:4 * n_f].view(torch.float32)
+        longs = raw[b_f:b_f + 8 * (n + n * T)].view(torch.long)
         h = zbuf[:n * self.rnn_size].view(n, self.rnn_size)
         c = zbuf[n * self.rnn_size:2 * n * self.rnn_size].view(n, self.rnn_size)
-        it = torch.zeros(n, dtype=torch.long, device=hs.device)                       # <bos>
-        T = self.max_caption_len
+        it = longs[:n]                                                                # <bos>
         if sample_max:
             # greedy: argmax, log-prob and the per-step bookkeeping (unfinished / alive / seq / seq_lp) are one kernel.
             # seq starts as zeros: a loop that is cut short (decode_stop / decode_continue below) leaves exactly what
@@ -676,10 +681,10 @@ class Captioner(nn.Module):
             st = {"hs": hs, "ref_in": ref_in, "tshapes": tshapes, "lsi": lsi, "const": const, "emb_gates": emb_gates,
                   "h": h, "c": c, "it": it, "logits": None,
                   "unfinished": torch.empty(n, dtype=torch.uint8, device=hs.device),
-                  "seq": torch.zeros(n, T, dtype=torch.long, device=hs.device),
+                  "seq": longs[n:].view(n, T),
                   "seq_lp": zbuf[2 * n * self.rnn_size:].view(n, T),
                   # alive[t]: some row is still unfinished after token t -- set by the greedy kernel itself
-                  "alive": torch.zeros(T, dtype=torch.uint8, device=hs.device)}
+                  "alive": raw[b_f + b_l:]}
             # (running the vocabulary GEMM + argmax of token t on a second stream beside the token-independent half of
             #  step t+1 was tried -- fork / join inside the captured graph -- and measured no gain: 742-757 vs 750
             #  videos/s; the GEMMs already occupy every CU)

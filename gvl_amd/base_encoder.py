@@ -347,11 +347,21 @@ class BaseEncoder(nn.Module):
                     dst2.data_ptr() + 4 * C if dst2 is not None else None, dst2_vs, stream)
             _lib.check(rc, "group_norm_rows")
 
+        # the zero-padded inputs of the strided levels: ONE fill for all of them
+        pad_in = [T] + [lengths[l] for l in range(1, nl - 1)]                  # frames going into the convolution of level 1, 2, ..
+        pad_ch = [Cin] + [C] * (nl - 2)
+        pad_n = [(N + 1) * 2 * ((t_ - 1) // 2 + 2) * c_ for t_, c_ in zip(pad_in, pad_ch)]
+        pad_pool = torch.zeros(sum(pad_n), device=dev, dtype=torch.float32) if nl > 1 else None
+        pad_next = [0, 0]                                                      # (buffers handed out, elements handed out)
+
         def padded(t_in, ch):
             """zeroed (N + 1, 2 (T' + 1), ch) buffer: row 0 and the rows behind the t_in frames are the convolution's padding
             (and slack for the last, unused tap row of every video); the extra video keeps the strided view in bounds"""
             t_out = (t_in - 1) // 2 + 1
-            return torch.zeros(N + 1, 2 * (t_out + 1), ch, device=dev, dtype=torch.float32), t_out
+            k, at = pad_next
+            assert (t_in, ch) == (pad_in[k], pad_ch[k])
+            pad_next[0], pad_next[1] = k + 1, at + pad_n[k]
+            return pad_pool[at:at + pad_n[k]].view(N + 1, 2 * (t_out + 1), ch), t_out
 
         def conv_s2(xp, t_out, ch, l):
             a = xp.as_strided((N * (t_out + 1), 3 * ch), (2 * ch, 1))           # row (n, t'): taps 2 t' - 1 .. 2 t' + 1

@@ -315,7 +315,18 @@ class DeformableTransformer(nn.Module):
         query_pos, tgt = torch.chunk(query_embed, 2, dim=1)
         query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
         tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
-        reference_points = self.reference_points(query_pos).sigmoid()
+        if not torch.is_grad_enabled() and query_embed.is_cuda and isinstance(self.reference_points, nn.Linear):
+            # inference: sigmoid(reference_points(query_pos)) depends on parameters only -- kept until one of them changes (the
+            # reference evaluates the Linear on the batch-expanded rows: the same arithmetic per row)
+            lin = self.reference_points
+            ps = [query_embed, lin.weight] + ([lin.bias] if lin.bias is not None else [])
+            key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (bs,)
+            hit = self.__dict__.get("_gvl_query_ref")
+            if hit is None or hit[0] != key:
+                hit = self.__dict__["_gvl_query_ref"] = (key, lin(query_pos).sigmoid())
+            reference_points = hit[1]
+        else:
+            reference_points = self.reference_points(query_pos).sigmoid()
         return reference_points, tgt, reference_points, query_pos
 
     def prepare_decoder_input_proposal(self, gt_reference_points, inversed_input=False):

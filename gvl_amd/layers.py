@@ -438,6 +438,27 @@ def _self_attention(layer, x, am_x, am_xp, qpos, B, Q, query_mask, arena):
     return a, row_absmax(a)[0]
 
 
+def _query_rows(dec, tgt, query_pos, B, Q, C):
+    """'queries' input (deformable_transformer.py:128-135): tgt and query_pos are the two halves of the query embedding, expanded
+    over the batch -- the decoder's first residual rows, the positional rows and the row maxima of both depend on PARAMETERS
+    only.  Kept on the decoder until the embedding changes (its address or its version counter): three launches (two copies of
+    9.8 MB / 0.6 MB and the maxima) leave every inference forward.  None when the inputs are not of that form.  Nothing
+    downstream writes these rows (every layer output is a new tensor)."""
+    if (torch.is_grad_enabled() or query_pos is None or tgt.dim() != 3 or query_pos.dim() != 3 or B < 1
+            or tgt.stride(0) != 0 or query_pos.stride(0) != 0 or tgt.dtype != torch.float32 or query_pos.dtype != torch.float32
+            or tgt.stride(2) != 1 or query_pos.stride(2) != 1):
+        return None
+    key = (tgt.data_ptr(), tgt._version, tgt.stride(1), query_pos.data_ptr(), query_pos._version, query_pos.stride(1),
+           B, Q, C, str(tgt.device))
+    hit = dec.__dict__.get("_gvl_query_rows")
+    if hit is None or hit[0] != key:
+        x = tgt.reshape(B * Q, C).contiguous()
+        qpos = query_pos[0].contiguous()
+        am_x, am_xp = row_absmax(x, qpos)
+        hit = dec.__dict__["_gvl_query_rows"] = (key, (x, qpos, am_x, am_xp))
+    return hit[1]
+
+
 def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_level_start_index, src_valid_ratios,
                     query_pos, src_padding_mask, query_padding_mask, disable_iterative_refine):
     """DeformableTransformerDecoder.forward (deformable_transformer.py:283-335) for inference.  value_proj(memory) of ALL
@@ -462,16 +483,20 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
     wv = cached(dec, "values", [(l_.cross_attn.value_proj.weight, l_.cross_attn.value_proj.bias) for l_ in dec.layers])
     values = [_new(Rs, C, mem) for _ in dec.layers]
     linear(mem, wv, [seg(wv.starts[i], values[i], am_mem, rowmask=mask) for i in range(nl)], flags=_value_flags())
-    x = tgt.reshape(R, C).contiguous()
-    if query_pos is None:
-        qpos = None
-    elif query_pos.stride(0) == 0:                    # 'queries' input: the same embedding for every video (:130-133)
-        qpos = query_pos[0].contiguous()
+    rows = _query_rows(dec, tgt, query_pos, B, Q, C)
+    if rows is not None:
+        x, qpos, am_x, am_xp = rows
     else:
-        qpos = query_pos.reshape(R, C).contiguous()
-    am_x, am_xp = row_absmax(x, qpos)
-    if qpos is None:
-        am_xp = am_x
+        x = tgt.reshape(R, C).contiguous()
+        if query_pos is None:
+            qpos = None
+        elif query_pos.stride(0) == 0:                # 'queries' input: the same embedding for every video (:130-133)
+            qpos = query_pos[0].contiguous()
+        else:
+            qpos = query_pos.reshape(R, C).contiguous()
+        am_x, am_xp = row_absmax(x, qpos)
+        if qpos is None:
+            am_xp = am_x
     hs, refs, deltas, coords, clss = [], [], [], [], []
     next_ref_in = None
     for lid, layer in enumerate(dec.layers):
