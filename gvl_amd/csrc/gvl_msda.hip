@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
                                                      int P, int RD, int nchunk, VT *__restrict__ out,
                                                      unsigned long long *__restrict__ stamps,
-                                                     unsigned *__restrict__ amax_out, int qper, int m_shift) {
+                                                     unsigned *__restrict__ amax_out, int qper, int m_shift, float invP) {
   extern __shared__ float4 slab4[];
   // grid = (B*M, nchunk): workgroups are dispatched x first, so the linear id (what the XCD round-robin sees) is
   // chunk * B*M + slab as before -- but neither a modulo nor a division by B*M is computed here, the chunk length comes from
@@ -511,7 +511,9 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   if (m_shift >= 0) { b = bm >> m_shift; m = bm & (M - 1); }
   else { b = bm / M; m = bm % M; }
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // (the wavefront index as a SCALAR: everything derived from it -- the wavefront's first query, the base addresses of its
+  // operand rows and output rows -- is then computed on the scalar unit and the loads / stores take it as their scalar base)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   // FULL16: L*P == 16 is a compile-time fact: no branches between the 16 sample steps, none around the operand fetches
   const int LP = FULL16 ? 16 : L * P;
   const int q0 = chunk * qper;
@@ -525,8 +527,8 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   if (j < LP) {
     // the LOW dwords of the int64 entries: loaded as 64-bit values their unused high halves are registers the compiler
     // re-uses at once -- and it then waits for the load (vmcnt(0)) in front of every request that should have followed it
-    Tl = reinterpret_cast<const int *>(shapes)[2 * (2 * lvl + 1)];
-    st = reinterpret_cast<const int *>(lsi)[2 * lvl];
+    Tl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(shapes) + (unsigned)(16 * lvl + 8));
+    st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(lsi) + (unsigned)(8 * lvl));
   }
   int qb = q0 + wave * 4;
   // operand cursor: query index of the next fetch and the lane's element offsets for it, advanced by a constant per pass
@@ -537,29 +539,50 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   const int64_t step0 = (int64_t)nw * 4 * (FUSED ? 2 * MLP : MLP), step1 = FUSED ? (int64_t)nw * 4 * L * RD : 0;
   // FULL16: no branch around the loads -- lanes past the end of the list re-read the list's last query (their results are
   // never stored).  Behind a guarded load the compiler cannot count the requests in flight and waits for ALL of them
-  // (vmcnt(0)) before the first use of any operand, the slab transfer included.
-  const int64_t o0_last = o0 + (int64_t)(q1 - 1 - qf) * (FUSED ? 2 * MLP : MLP), o1_last = o1 + (int64_t)(q1 - 1 - qf) * (FUSED ? L * RD : 0);
+  // (vmcnt(0)) before the first use of any operand, the slab transfer included.  Addresses = a 64-bit base that is the same
+  // for the whole wavefront (scalar unit) + a 32-bit lane offset: the set-up is bound by VALU issue (four wavefronts per SIMD
+  // run it), and per-lane 64-bit index arithmetic was a third of its vector instructions.
+  int qf_u = qb;                                                       // (uniform) first query of the wavefront's next fetch
   auto fetch_next = [&]() {
     RawOps r = {0.f, 0.5f, 0.f, 0.f};
     if constexpr (FULL16) {
-      const bool in = qf < q1;
-      r = fetch_at<FUSED, VT>(loc, attn, in ? o0 : o0_last, in ? o1 : o1_last, MLP, RD);
+      const int qc = min(qf_u, q1 - 1);                                // (uniform) clamped into the list
+      const int dq = min(tq, q1 - 1 - qc);                             // this lane's query relative to qc, clamped likewise
+      const int64_t bq = (int64_t)b * Q + qc;
+      // (byte offsets in 32-bit arithmetic: scalar base + zero-extended 32-bit offset is an addressing mode of the load)
+      if constexpr (FUSED) {
+        const char *u0 = reinterpret_cast<const char *>(reinterpret_cast<const VT *>(loc) + bq * (2 * MLP) + m * LP);
+        const unsigned e0 = (unsigned)(dq * (2 * MLP) + j) * (unsigned)sizeof(VT);
+        r.a = (float)*reinterpret_cast<const VT *>(u0 + e0);
+        r.b = (float)*reinterpret_cast<const VT *>(u0 + (e0 + (unsigned)MLP * (unsigned)sizeof(VT)));
+        const char *u1 = reinterpret_cast<const char *>(attn + bq * (L * RD));
+        const unsigned e1 = (unsigned)((dq * L + lvl) * RD) * 4u;
+        r.c = *reinterpret_cast<const float *>(u1 + e1);
+        r.d = *reinterpret_cast<const float *>(u1 + (e1 + (RD == 2 ? 4u : 0u)));   // (RD == 1: not used by resolve_ops)
+      } else {
+        const unsigned e0 = (unsigned)(dq * MLP + j);
+        const float2 xy = *reinterpret_cast<const float2 *>(
+            reinterpret_cast<const char *>(reinterpret_cast<const float2 *>(loc) + (bq * M + m) * LP) + e0 * 8u);
+        r.a = xy.x; r.b = xy.y;
+        r.c = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(attn + (bq * M + m) * LP) + e0 * 4u);
+        r.d = 0.f;
+      }
     } else {
       if (qf < q1 && j < LP) r = fetch_at<FUSED, VT>(loc, attn, o0, o1, MLP, RD);
     }
     qf += nw * 4;
+    qf_u += nw * 4;
     o0 += step0;
     o1 += step1;
     return r;
   };
   RawOps r_n = fetch_next();
-  int64_t o_out = (((int64_t)b * Q + qb + tq) * M + m) * 16 + j;       // this lane's output quad, advanced per pass
-  const int64_t step_out = (int64_t)nw * 4 * M * 16;
+  const unsigned e_out = (unsigned)(tq * M * 16 + j);                  // this lane's output quad relative to the wavefront's query
   // L0G: level 0 (rows [0, T_0)) stays in global memory, LDS holds rows [T_0, S); needs FULL16 and P == 4 so that
   // "sample step SI belongs to level 0" is the compile-time test SI < 4
   const int row0 = L0G ? __builtin_amdgcn_readfirstlane((int)shapes[1]) : 0;
   const int64_t vg = ((int64_t)b * S * M + m) * 16 + j;               // this lane's channels of row 0 of the slab
-  const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
+  const float invT = 1.f / (float)Tl;                                 // (invP = 1.f / (float)P: the same division, done by the host)
   // sampling operands -> (slab row as LDS byte offset | global row index for L0G level 0, coefficient pair)
   auto prep = [&](const RawOps &r_in, int &roff, f2v &cc) {
     // (the operands as opaque values from here on: otherwise the first instructions of resolve_ops are hoisted into the
@@ -606,10 +629,11 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   constexpr bool kDma = std::is_same<VT, float>::value;
   float4 pre[kPre];
   if constexpr (kDma) {
+    const char *vsrc = reinterpret_cast<const char *>(value) + (src0 + (int64_t)row0 * M * 16) * 16;     // (uniform)
     for (int i = threadIdx.x; i < nstage; i += blockDim.x) {
-      const float *src = reinterpret_cast<const float *>(value) + (src0 + (int64_t)(row0 + (i >> 4)) * M * 16 + (i & 15)) * 4;
+      const unsigned voff = (unsigned)(((i >> 4) * M * 16 + (i & 15)) * 16);
       const int dst = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(lds_cbyte *)reinterpret_cast<const char *>(slab4 + (i - lane)));
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(voff), "s"(vsrc) : "memory");
     }
   } else {
 #pragma unroll
@@ -712,11 +736,11 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 #undef GVL_FWD_STEP
 #undef GVL_FWD_ROWS
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
-    if (act) st4_stream(out, o_out, acc);
-    o_out += step_out;
+    const int64_t bq_u = (int64_t)b * Q + qb;                          // (uniform) the wavefront's first query of this pass
+    if (act) st4_stream(out + (bq_u * M + m) * 64, (int64_t)e_out, acc);
     if (AMAX) {
       const float mx = row_allmax(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
-      if (act && j == 0) atomicMax(amax_out + (int64_t)b * Q + q, __float_as_uint(mx));
+      if (act && j == 0) atomicMax(amax_out + bq_u + tq, __float_as_uint(mx));
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1930,7 +1954,7 @@ int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
                      dim3(B * M, nchunk), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
                      env_int("GVL_MSDA_XCD_PAIRS", 1) ? nchunk : -nchunk, out, g_fwd_stamps,
                      reinterpret_cast<unsigned *>(amax_out), (Q + nchunk - 1) / nchunk,
-                     (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1);
+                     (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1, 1.f / (float)P);
 }
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
