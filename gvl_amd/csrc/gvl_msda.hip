@@ -397,6 +397,14 @@ __device__ inline void stage_slab(float4 *slab4, const VT *value, int b, int m, 
 struct RawOps {
   float a, b, c, d;   // !FUSED: (x, y, w, -)     FUSED: (offset, logit, ref0, ref1)
 };
+// The backward's query loops request the operands of pass k + 1 at the top of pass k and store pass k's results at its
+// bottom.  gfx9 has ONE counter for vector loads and stores, and they retire out of order with respect to each other: the wait
+// for the prefetched operands at the top of pass k + 1 therefore became vmcnt(0) -- a wait for the STORES issued a few
+// instructions earlier, i.e. a write round trip per pass on the critical path.  This makes the prefetched registers opaque
+// values in front of the stores: the compiler's wait lands here, where the loads (issued a whole pass ago) have long
+// returned, and the stores drain behind the next pass's arithmetic.
+#define GVL_TOUCH_PREFETCH(R, G) \
+  asm volatile("" : "+v"((R).a), "+v"((R).b), "+v"((R).c), "+v"((R).d), "+v"((G).x), "+v"((G).y), "+v"((G).z), "+v"((G).w));
 
 // p0 = loc (fp32) | proj (storage type VT);  p1 = attn | ref (always fp32: positions must not be rounded to bf16)
 template <bool FUSED, typename VT>
@@ -904,6 +912,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
 
   // ---- phase 1 ---------------------------------------------------------------------------------------------
+  GVL_TOUCH_PREFETCH(r_n, g_n)                           // (the first pass: its operands were requested before the staging)
   for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
     const bool act = q < q1;
@@ -969,6 +978,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     const float keep_w = fmaf(clo, d0, chi * d1);
     const float keep_x = fmaf(dxlo, d0, dxhi * d1);
     const float keep_y = fmaf(dylo, d0, dyhi * d1);
+    GVL_TOUCH_PREFETCH(r_n, g_n)
     if (!FUSED) {
       if (act && j < LP) {
         st_stream(gattn + tb + j, keep_w);                                     // cuh:156-157
@@ -1150,8 +1160,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int lvl = j >> 2;
-  const int Tl = (int)shapes[2 * lvl + 1], st = (int)lsi[lvl];
-  const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
+  // (the low dwords of the int64 entries, see k_fwd_t1d_d64: as 64-bit loads the compiler waited for them at once)
+  const int Tl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(shapes) + (unsigned)(16 * lvl + 8));
+  const int st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(lsi) + (unsigned)(8 * lvl));
   // levels {0,3} belong to workgroup 0, {1,2} to workgroup 1; k = the sample's index among the 8 owned samples of a query
   const bool mine = g == 0 ? (lvl == 0 || lvl == 3) : (lvl == 1 || lvl == 2);
   const int k_own = g == 0 ? (lvl == 0 ? j : j - 8) : j - 4;
@@ -1161,12 +1172,20 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
 
   // ---- set-up: operands of the first foreign pass and the slab are requested first (one cold round trip for all of
   // them), then the histogram and the entry table are initialised while those loads are in flight --------------------
-  RawOps rf_n = {0.f, 0.5f, 0.f, 0.f};
-  float4 gf_n = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (f0 + wave * 4 < f1) {
-    const int64_t bqn = (int64_t)b * Q + min(f0 + wave * 4 + tq, f1 - 1);
+  // (no guards around these requests -- indices clamped into the lists instead; rows past a list's end are never stored.
+  // Behind a guard the compiler cannot count the loads in flight and puts a vmcnt(0) in front of the next request.)
+  RawOps rf_n, r_n;
+  float4 gf_n, g_n;
+  {
+    const int64_t bqn = (int64_t)b * Q + max(f0, min(f0 + wave * 4 + tq, f1 - 1));
     rf_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-    if (f0 + wave * 4 + tq < f1) gf_n = ld4(gout, (bqn * M + m) * 16 + j);
+    gf_n = ld4(gout, (bqn * M + m) * 16 + j);
+  }
+  int qb = q0 + wave * 4;
+  {                                                                    // operands of the first OWN pass
+    const int64_t bqn = (int64_t)b * Q + max(q0, min(qb + tq, q1 - 1));
+    r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
+    g_n = ld4(gout, (bqn * M + m) * 16 + j);
   }
   constexpr int kPre = 3;
   const int64_t src0 = ((int64_t)b * S * M + m) * 16;
@@ -1174,9 +1193,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   float4 pre[kPre];
 #pragma unroll
   for (int k = 0; k < kPre; ++k) {
-    const int i = threadIdx.x + k * blockDim.x;
-    if (i < nstage) pre[k] = ld4(value, src0 + (int64_t)(i >> 4) * M * 16 + (i & 15));
+    const int i = min((int)(threadIdx.x + k * blockDim.x), nstage - 1);
+    pre[k] = ld4(value, src0 + (int64_t)(i >> 4) * M * 16 + (i & 15));
   }
+  const float invT = 1.f / (float)Tl, invP = 1.f / (float)P;
   for (int i = threadIdx.x; i < S + 2; i += blockDim.x) cnt[i] = 0;
   for (int i = threadIdx.x; i < nent; i += blockDim.x) ent_rp[i] = -1;
   __syncthreads();
@@ -1218,15 +1238,8 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
     }
   }
 
-  // ---- own pass operands, then the slab goes to LDS ----------------------------------------------------------
-  int qb = q0 + wave * 4;
-  RawOps r_n = {0.f, 0.5f, 0.f, 0.f};
-  float4 g_n = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (qb < q1) {
-    const int64_t bqn = (int64_t)b * Q + min(qb + tq, q1 - 1);
-    r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-    if (qb + tq < q1) g_n = ld4(gout, (bqn * M + m) * 16 + j);
-  }
+  // ---- the slab goes to LDS (the own pass's first operands were requested with the set-up's other loads: requested here,
+  // behind a guard, they made the wait for the slab registers a wait for themselves -- a round trip in front of the barrier)
 #pragma unroll
   for (int k = 0; k < kPre; ++k) {
     const int i = threadIdx.x + k * blockDim.x;
@@ -1239,6 +1252,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
 
   // ---- own pass (phase 1 of the query-split kernel; entries for the owned levels only) -----------------------------
+  GVL_TOUCH_PREFETCH(r_n, g_n)                           // (the first pass: its operands were requested before the staging)
   for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
     const bool act = q < q1;
@@ -1281,6 +1295,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
     const float keep_w = fmaf(clo, d0, chi * d1);
     const float keep_x = fmaf(dxlo, d0, dxhi * d1);
     const float keep_y = fmaf(dylo, d0, dyhi * d1);
+    GVL_TOUCH_PREFETCH(r_n, g_n)
     if (!FUSED) {
       if (act) {
         st_stream(gattn + tb + j, keep_w);                                     // cuh:156-157
@@ -1550,6 +1565,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
 #else
 #define GVL_T(K)
 #endif
+    GVL_TOUCH_PREFETCH(r_n, g_n)
     for (; qb < q1; qb += nw * 4) {
 #ifdef GVL_PHASE_TIMING
       long long tprev = __builtin_amdgcn_s_memtime();
@@ -1638,6 +1654,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
       const float keep_w = fmaf(clo, d0, chi * d1);
       const float keep_x = fmaf(dxlo, d0, dxhi * d1);
       const float keep_y = fmaf(dylo, d0, dyhi * d1);
+      GVL_TOUCH_PREFETCH(r_n, g_n)
       if (!FUSED) {
         if (act) {
           st_stream(gattn + tb + j, keep_w);                                     // cuh:156-157
