@@ -320,7 +320,8 @@ class DeformableTransformer(nn.Module):
             # reference evaluates the Linear on the batch-expanded rows: the same arithmetic per row)
             lin = self.reference_points
             ps = [query_embed, lin.weight] + ([lin.bias] if lin.bias is not None else [])
-            key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (bs,)
+            key = tuple((p_.data_ptr(), p_._version) for p_ in ps) + (
+                bs, torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
             hit = self.__dict__.get("_gvl_query_ref")
             if hit is None or hit[0] != key:
                 hit = self.__dict__["_gvl_query_ref"] = (key, lin(query_pos).sigmoid())

@@ -271,3 +271,40 @@ def test_fused_inference_layers_equal_the_pytorch_formulation(B, T, masked, monk
     for name, a, b in zip(("memory", "hs", "refs"), got, want):
         tol = 2e-4 if name != "refs" else 2e-5
         assert maxerr(a, b) <= tol * max(1.0, float(b.abs().max())), (name, maxerr(a, b))
+
+
+def test_query_constants_kept_for_inference_follow_their_parameters():
+    """'queries' input (deformable_transformer.py:128-135): the decoder's first residual rows, the positional rows, their row
+    maxima and sigmoid(reference_points(query_pos)) depend on parameters only and are kept across inference forwards
+    (gvl_amd.layers._query_rows, DeformableTransformer.prepare_decoder_input_query) -- until a parameter is written."""
+    from gvl_amd import layers as L
+    from gvl_amd.deformable_transformer import DeformableTransformer
+    B, Q, C = 3, 70, 512
+    emb = _rand(Q, 2 * C, seed=5)
+    lin = torch.nn.Linear(C, 1).to(DEV)
+
+    class Shell(torch.nn.Module):                    # the method only touches self.reference_points / self.__dict__
+        prepare_decoder_input_query = DeformableTransformer.prepare_decoder_input_query
+    sh = Shell().to(DEV)
+    sh.reference_points = lin
+    mem = torch.empty(B, 1, C, device=DEV)
+    with torch.no_grad():
+        ref1, tgt, _, qpos = sh.prepare_decoder_input_query(mem, emb)
+        ref2 = sh.prepare_decoder_input_query(mem, emb)[0]
+        assert ref2 is ref1                                            # kept
+        want = torch.sigmoid(torch.nn.functional.linear(emb[:, :C], lin.weight, lin.bias))[None].expand(B, -1, -1)
+        assert maxerr(ref1, want) < 1e-6
+        lin.bias.add_(0.5)                                             # a parameter is written: recomputed
+        ref3 = sh.prepare_decoder_input_query(mem, emb)[0]
+        assert ref3 is not ref1 and maxerr(ref3, torch.sigmoid(torch.logit(want) + 0.5)) < 1e-5
+        dec = torch.nn.Module()
+        rows = L._query_rows(dec, tgt, qpos, B, Q, C)
+        assert rows is not None and L._query_rows(dec, tgt, qpos, B, Q, C) is rows
+        x, qp, am_x, am_xp = rows
+        assert torch.equal(x.view(B, Q, C), tgt) and torch.equal(qp, qpos[0])
+        assert torch.equal(am_x, x.abs().amax(1)) and torch.equal(am_xp.view(B, Q), (tgt + qpos).abs().amax(2))
+        emb.mul_(2.0)                                                  # the embedding is written: new rows
+        rows2 = L._query_rows(dec, tgt, qpos, B, Q, C)
+        assert rows2 is not rows and torch.equal(rows2[0].view(B, Q, C), tgt)
+    with torch.enable_grad():                                          # training keeps the reference's own evaluation
+        assert L._query_rows(dec, tgt, qpos, B, Q, C) is None
