@@ -289,6 +289,23 @@ __device__ inline void fma4x2(f2v c, const float4 &v0, const float4 &v1, f2v &a0
   a01 = __builtin_elementwise_fma(hi, (f2v){v1.x, v1.y}, a01);
   a23 = __builtin_elementwise_fma(hi, (f2v){v1.z, v1.w}, a23);
 }
+// TIMING BUILDS ONLY (-DGVL_FWD_FMAC_DPP; measured in round 5 and not shipped): acc (4 channels) += c.x * v0 + c.y * v1 with
+// the coefficient taken from lane SRC of the DPP row INSIDE the multiply-add (v_fmac_f32_dpp: the VOP2 form carries a DPP
+// control on its first operand) -- 8 instructions per sample step instead of a 64-bit broadcast + 4 v_pk_fma_f32, the same
+// products in the same order.  The forward's sample loop went from 3.33 to 3.94 us in situ (tools/fwd_ab.sh): a DPP operand
+// costs the FMA more than the separate broadcast does.
+template <int SRC>
+__device__ inline void fma4x2_bcast(f2v c, const float4 &v0, const float4 &v1, f2v &a01, f2v &a23) {
+  float ax = a01.x, ay = a01.y, az = a23.x, aw = a23.y;
+  const float cl = c.x, ch = c.y;
+#define GVL_FMAC_DPP(ACC, COEF, VAL) \
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(ACC) : "v"(COEF), "v"(VAL), "n"(SRC));
+  GVL_FMAC_DPP(ax, cl, v0.x) GVL_FMAC_DPP(ay, cl, v0.y) GVL_FMAC_DPP(az, cl, v0.z) GVL_FMAC_DPP(aw, cl, v0.w)
+  GVL_FMAC_DPP(ax, ch, v1.x) GVL_FMAC_DPP(ay, ch, v1.y) GVL_FMAC_DPP(az, ch, v1.z) GVL_FMAC_DPP(aw, ch, v1.w)
+#undef GVL_FMAC_DPP
+  a01 = (f2v){ax, ay};
+  a23 = (f2v){az, aw};
+}
 // all-reduce (sum) inside every 16-lane row
 __device__ inline float row_allsum(float v) {
   v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -695,13 +712,17 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
     const int q = qb + tq;
     const bool act = q < q1;
     f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#ifdef GVL_FWD_FMAC_DPP         // timing build, see fma4x2_bcast
+#define GVL_FWD_ACC(SI, V0, V1) fma4x2_bcast<SI>(cc, V0, V1, a01, a23);
+#else
+#define GVL_FWD_ACC(SI, V0, V1) fma4x2(row_bcast_f2<SI>(cc), V0, V1, a01, a23);
+#endif
 #define GVL_FWD_STEP(SI)                                                        \
   if (FULL16 || SI < LP) {                                                      \
-    const f2v c2 = row_bcast_f2<SI>(cc);                                        \
     float4 v0, v1;                                                              \
     lds_cbyte *row = (lds_cbyte *)(uintptr_t)(unsigned)row_bcast_add<SI>(roff, lane_lds, SI == (L0G ? 4 : 0)); \
     GVL_FWD_ROWS(row, v0, v1)                                                   \
-    fma4x2(c2, v0, v1, a01, a23);                                               \
+    GVL_FWD_ACC(SI, v0, v1)                                                     \
   }
     // The fences after every four steps bound the reads in flight (left alone the scheduler requests all 32 rows of a pass up
     // front and, with the coefficients of kAhead passes live, spills) and pin the accumulators: without AMAX their only use
@@ -709,7 +730,8 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
     // Inside a group the compiler keeps two reads in flight.  Requesting a group's eight reads together was measured again
     // with prep() out of the loop (tools/fwd_ab.sh): loop 3.27 -> 3.41 us in situ.  Neither the LDS round trips nor the LDS
     // bandwidth set the pass time: with the reads REMOVED (-DGVL_FWD_ABL_NO_LDS) the loop still takes 2.99 us -- it is the
-    // issue of the 64 v_pk_fma_f32 per wavefront pass (8 clocks each: 2.0 us per workgroup) plus 56 other vector instructions.
+    // issue of the 64 v_pk_fma_f32 per wavefront pass plus 56 other vector instructions (two 32-bit broadcasts instead of
+    // v_mov_b64_dpp: 3.21 -> 3.24 us; the broadcast folded into 128 v_fmac_f32_dpp: 3.33 -> 3.94 us).
 #define GVL_FWD_FENCE asm volatile("" : "+v"(a01), "+v"(a23) : : "memory"); __builtin_amdgcn_sched_barrier(0);
 #define GVL_FWD_QUAD(S0) GVL_FWD_STEP(S0) GVL_FWD_STEP(S0 + 1) GVL_FWD_STEP(S0 + 2) GVL_FWD_STEP(S0 + 3) GVL_FWD_FENCE
     if constexpr (L0G) {
@@ -726,10 +748,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 #undef GVL_FWD_G
       GVL_FWD_FENCE
       GVL_FWD_QUAD(4) GVL_FWD_QUAD(8) GVL_FWD_QUAD(12)
-      fma4x2(row_bcast_f2<0>(cc), g0[0], g1[0], a01, a23);
-      fma4x2(row_bcast_f2<1>(cc), g0[1], g1[1], a01, a23);
-      fma4x2(row_bcast_f2<2>(cc), g0[2], g1[2], a01, a23);
-      fma4x2(row_bcast_f2<3>(cc), g0[3], g1[3], a01, a23);
+      GVL_FWD_ACC(0, g0[0], g1[0]) GVL_FWD_ACC(1, g0[1], g1[1]) GVL_FWD_ACC(2, g0[2], g1[2]) GVL_FWD_ACC(3, g0[3], g1[3])
     } else if constexpr (FULL16) {
       GVL_FWD_QUAD(0) GVL_FWD_QUAD(4) GVL_FWD_QUAD(8) GVL_FWD_QUAD(12)
     } else {
@@ -742,6 +761,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 #undef GVL_FWD_QUAD
 #undef GVL_FWD_FENCE
 #undef GVL_FWD_STEP
+#undef GVL_FWD_ACC
 #undef GVL_FWD_ROWS
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
     const int64_t bq_u = (int64_t)b * Q + qb;                          // (uniform) the wavefront's first query of this pass
