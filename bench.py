@@ -485,7 +485,7 @@ def main():
                 return None, f"{PMC_FILE} is stale (collected for kernel source {table.get('kernel_source_sha16')}, now {sha})"
         return None, None
 
-    def instrumented(fn, n=6):
+    def instrumented(fn, n=12):
         """kernel stamps of `n` eager steps run right after a timed region whose steps were graph replays (the library
         launches nothing at replay time)"""
         MSDA.profile_enable(not os.environ.get("GVL_BENCH_NO_STAMPS"))     # (dev switch: the same eager steps, launched plainly)
@@ -646,7 +646,7 @@ def main():
 
     # ---------------------------------------------------------------------------------------------- the line
     src_note = ("per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region" if a.no_graph
-                else "median over six instrumented eager steps right after the timed region (timed steps are hipGraph replays); "
+                else "median over twelve instrumented eager steps right after the timed region (timed steps are hipGraph replays); "
                      "kernel_us_mean = the plain mean of the same launches")
 
     def fwd_roofline(ktimes):
