@@ -321,11 +321,38 @@ __device__ inline float row_allsum(float v) {
 // where 16 separate row all-reduces cost 64 DPP adds (and leave every sum on every lane, which nobody needs).
 __device__ inline float row_reduce_scatter16(const float (&v)[16], int j) {
   float a8[8], a4[4], a2[2];
-  const bool b3 = j & 8, b2 = j & 4, b1 = j & 2, b0 = j & 1;
+  const bool b1 = j & 2, b0 = j & 1;
+#ifdef GVL_RS16_SELECTS    // timing build: the select form of rounds 2-5 for all four levels
+  const bool b3 = j & 8, b2 = j & 4;
 #pragma unroll
   for (int i = 0; i < 8; ++i) a8[i] = (b3 ? v[8 + i] : v[i]) + dpp_f<0x140>(b3 ? v[i] : v[8 + i]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) a4[i] = (b2 ? a8[4 + i] : a8[i]) + dpp_f<0x141>(b2 ? a8[i] : a8[4 + i]);
+#else
+  // Levels 1 and 2 without selects: which half of the row keeps element i and which keeps element 8 + i (4 + i) is a matter of
+  // WHOLE DPP banks (lanes 0-7 | 8-15, then banks {0, 2} | {1, 3}), so each output is two v_add_f32_dpp with complementary
+  // bank masks -- the partner's copy of the same element added to the own one -- instead of two selects + move + add.
+  // The same sums of the same operands.  (`s_nop 1`: a VALU write needs two wait states before a DPP read of the register; the
+  // assembler text is opaque to the compiler's hazard recogniser, on the way in and on the way out.)
+#define GVL_RS_PAIR(D, LO, HI, CTRL, M0, M1)                                                            \
+  "v_add_f32_dpp " D ", " LO ", " LO " " CTRL " row_mask:0xf bank_mask:" M0 "\n\t"                       \
+  "v_add_f32_dpp " D ", " HI ", " HI " " CTRL " row_mask:0xf bank_mask:" M1 "\n\t"
+  asm("s_nop 1\n\t"
+      GVL_RS_PAIR("%0", "%8", "%16", "row_mirror", "0x3", "0xc") GVL_RS_PAIR("%1", "%9", "%17", "row_mirror", "0x3", "0xc")
+      GVL_RS_PAIR("%2", "%10", "%18", "row_mirror", "0x3", "0xc") GVL_RS_PAIR("%3", "%11", "%19", "row_mirror", "0x3", "0xc")
+      GVL_RS_PAIR("%4", "%12", "%20", "row_mirror", "0x3", "0xc") GVL_RS_PAIR("%5", "%13", "%21", "row_mirror", "0x3", "0xc")
+      GVL_RS_PAIR("%6", "%14", "%22", "row_mirror", "0x3", "0xc") GVL_RS_PAIR("%7", "%15", "%23", "row_mirror", "0x3", "0xc")
+      : "=&v"(a8[0]), "=&v"(a8[1]), "=&v"(a8[2]), "=&v"(a8[3]), "=&v"(a8[4]), "=&v"(a8[5]), "=&v"(a8[6]), "=&v"(a8[7])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+        "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+  asm("s_nop 1\n\t"
+      GVL_RS_PAIR("%0", "%4", "%8", "row_half_mirror", "0x5", "0xa") GVL_RS_PAIR("%1", "%5", "%9", "row_half_mirror", "0x5", "0xa")
+      GVL_RS_PAIR("%2", "%6", "%10", "row_half_mirror", "0x5", "0xa") GVL_RS_PAIR("%3", "%7", "%11", "row_half_mirror", "0x5", "0xa")
+      "s_nop 1"
+      : "=&v"(a4[0]), "=&v"(a4[1]), "=&v"(a4[2]), "=&v"(a4[3])
+      : "v"(a8[0]), "v"(a8[1]), "v"(a8[2]), "v"(a8[3]), "v"(a8[4]), "v"(a8[5]), "v"(a8[6]), "v"(a8[7]));
+#undef GVL_RS_PAIR
+#endif
 #pragma unroll
   for (int i = 0; i < 2; ++i) a2[i] = (b1 ? a4[2 + i] : a4[i]) + dpp_f<0x1B>(b1 ? a4[i] : a4[2 + i]);
   return (b0 ? a2[1] : a2[0]) + dpp_f<0xB1>(b0 ? a2[0] : a2[1]);
