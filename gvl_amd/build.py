@@ -80,7 +80,8 @@ def build_dev(sources, defs, verbose=False):
     cc = hipcc()
     os.makedirs(devdir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"] + list(defs)
-    names = {os.path.basename(n) for n in sources}
+    given = {os.path.basename(n): os.path.abspath(n) for n in sources}       # (a copy elsewhere, e.g. an older revision of the
+    names = set(given)                                                       #  file, replaces the library's source of that name)
     unknown = names - {os.path.basename(s) for s in SRC}
     if unknown:
         raise ValueError(f"build_dev: not a source of the library: {sorted(unknown)}")
@@ -89,7 +90,8 @@ def build_dev(sources, defs, verbose=False):
         base = os.path.basename(src)
         if base in names:
             obj = os.path.join(devdir, base + ".o")
-            cmd = [cc] + cflags + ["-o", obj, src]
+            use = given[base] if os.path.exists(given[base]) else src
+            cmd = [cc] + cflags + ["-I", os.path.dirname(src), "-o", obj, use]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=ROOT)

@@ -495,6 +495,42 @@ __device__ inline RawOps fetch_at(const void *__restrict__ p0, const float *__re
 // (v_max_f32 with the DPP control on its own operand: written as fmaxf(v, dpp(v)) the compiler emits v_mov_dpp + a
 // canonicalising v_max of the moved value + the v_max -- 12 VALU instructions per reduction instead of 4 in loops that are
 // VALU-issue bound.  `s_nop 1`: the two wait states between a VALU write and a DPP read of the same register.)
+// fetch_ops for a query given as (bq_u: a row index that is the same for the whole wavefront, dq: this lane's offset from it):
+// the 64-bit part of every address is then wavefront-uniform -- computed on the scalar unit -- and the lane part a 32-bit byte
+// offset, which is an addressing mode of the load (scalar base + vector offset).  Per-lane 64-bit index arithmetic (quarter-rate
+// multiplies) was a fifth of the issue time of the backward's query passes.
+template <bool FUSED, typename VT>
+__device__ inline RawOps fetch_ops_u(const void *__restrict__ p0, const float *__restrict__ p1, int64_t bq_u, int dq, int m, int M,
+                                     int LP, int L, int RD, int j, int l) {
+  RawOps r;
+  if (!FUSED) {
+    const unsigned e = (unsigned)((dq * M + m) * LP + j);
+    const float2 xy = *reinterpret_cast<const float2 *>(
+        reinterpret_cast<const char *>(reinterpret_cast<const float2 *>(p0) + bq_u * (M * LP)) + e * 8u);
+    r.a = xy.x; r.b = xy.y;
+    r.c = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(p1 + bq_u * (M * LP)) + e * 4u);
+    r.d = 0.f;
+  } else {
+    const char *u0 = reinterpret_cast<const char *>(reinterpret_cast<const VT *>(p0) + bq_u * (2 * M * LP));
+    const unsigned e0 = (unsigned)(dq * (2 * M * LP) + m * LP + j) * (unsigned)sizeof(VT);
+    r.a = (float)*reinterpret_cast<const VT *>(u0 + e0);
+    r.b = (float)*reinterpret_cast<const VT *>(u0 + (e0 + (unsigned)(M * LP) * (unsigned)sizeof(VT)));
+    const char *u1 = reinterpret_cast<const char *>(p1 + bq_u * (L * RD));
+    const unsigned e1 = (unsigned)((dq * L + l) * RD) * 4u;
+    r.c = *reinterpret_cast<const float *>(u1 + e1);
+    r.d = *reinterpret_cast<const float *>(u1 + (e1 + (RD == 2 ? 4u : 0u)));
+  }
+  return r;
+}
+// four channels at quad index i4 (a 32-bit lane offset) behind a wavefront-uniform base
+__device__ inline float4 ld4_u(const float *base_u, unsigned i4) {
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base_u) + i4 * 16u);
+}
+__device__ inline float4 ld4_u(const bf16_t *base_u, unsigned i4) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const char *>(base_u) + i4 * 8u);
+  return make_float4((float)v.a, (float)v.b, (float)v.c, (float)v.d);
+}
+
 __device__ inline float row_allmax(float v) {
   asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -727,9 +763,9 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
 
   // one pass = the 16 sample steps of the wavefront's four queries + the store.  Per sample step: v_add_u32_dpp (row
   // broadcast + lane offset = LDS address), v_mov_b64_dpp (both coefficients), 2 ds_read_b128, 4 v_pk_fma_f32.
-  // (Round 5, with prep() still inside the loop: requesting the reads of four steps together, two groups in flight, changed
-  // nothing -- 4.52 -> 4.75 us in situ at 118 registers -- and neither did 35 fewer VALU instructions per pass; what did was
-  // moving prep() under the slab transfer.)
+  // (Round 5, with prep() still inside the loop: requesting the reads of four steps together, two groups in flight, did not
+  // help -- 4.52 -> 4.75 us in situ at 118 registers; 35 fewer VALU instructions per pass bought ~0.3 us; moving prep() under
+  // the slab transfer 1.0 us.)
 #ifdef GVL_FWD_ABL_NO_LDS      // timing build (tools/fwd_ablate.sh): the sample steps without their LDS reads
 #define GVL_FWD_ROWS(ROW, V0, V1) { const float t_ = __builtin_bit_cast(float, (int)(uintptr_t)(ROW)); V0 = make_float4(t_, cc.x, t_, cc.y); V1 = V0; }
 #else
@@ -1205,7 +1241,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   const int bm = slab_of_block(blockIdx.x % BM, BM), g = blockIdx.x / BM;   // g in {0, 1}
   const int b = bm / M, m = bm % M;
   const int lane = threadIdx.x & 63, j = lane & 15, tq = lane >> 4;
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // (the wavefront index as a scalar: the first query of a pass, and with it the 64-bit part of every operand / result address,
+  // is then wavefront-uniform -- see fetch_ops_u)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   const int lvl = j >> 2;
   // (the low dwords of the int64 entries, see k_fwd_t1d_d64: as 64-bit loads the compiler waited for them at once)
   const int Tl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(shapes) + (unsigned)(16 * lvl + 8));
@@ -1223,17 +1261,17 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   // Behind a guard the compiler cannot count the loads in flight and puts a vmcnt(0) in front of the next request.)
   RawOps rf_n, r_n;
   float4 gf_n, g_n;
-  {
-    const int64_t bqn = (int64_t)b * Q + max(f0, min(f0 + wave * 4 + tq, f1 - 1));
-    rf_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-    gf_n = ld4(gout, (bqn * M + m) * 16 + j);
-  }
+  // (qc: the pass's first query clamped into its list, wavefront-uniform; dq: the lane's query relative to it, clamped likewise)
+  auto fetch_pass = [&](int qfirst, int lo, int hi, RawOps &r_out, float4 &g_out) {
+    const int qc = max(lo, min(qfirst, hi - 1));
+    const int dq = max(0, min(tq, hi - 1 - qc));
+    const int64_t bq_u = (int64_t)b * Q + qc;
+    r_out = fetch_ops_u<FUSED, VT>(loc, attn, bq_u, dq, m, M, LP, L, RD, j, lvl);
+    g_out = ld4_u(gout + (bq_u * M + m) * 64, (unsigned)(dq * M * 16 + j));
+  };
+  fetch_pass(f0 + wave * 4, f0, f1, rf_n, gf_n);
   int qb = q0 + wave * 4;
-  {                                                                    // operands of the first OWN pass
-    const int64_t bqn = (int64_t)b * Q + max(q0, min(qb + tq, q1 - 1));
-    r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-    g_n = ld4(gout, (bqn * M + m) * 16 + j);
-  }
+  fetch_pass(qb, q0, q1, r_n, g_n);                                    // operands of the first OWN pass
   constexpr int kPre = 3;
   const int64_t src0 = ((int64_t)b * S * M + m) * 16;
   const int nstage = S * 16;
@@ -1268,11 +1306,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
       const RawOps r = r_n;
       const float4 gq = g_n;
       const int qbn = qb + nw * 4;
-      if (qbn < f1) {
-        const int64_t bqn = (int64_t)b * Q + min(qbn + tq, f1 - 1);
-        r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-        g_n = (qbn + tq < f1) ? ld4(gout, (bqn * M + m) * 16 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      if (qbn < f1) fetch_pass(qbn, f0, f1, r_n, g_n);
       float2 xy;
       float w, dloc;
       resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc);      // (FUSED: the softmax needs all 16 lanes of the row)
@@ -1303,16 +1337,11 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   for (; qb < q1; qb += nw * 4) {
     const int q = qb + tq;
     const bool act = q < q1;
-    const int qq = act ? q : q1 - 1;
-    const int64_t tb = (((int64_t)b * Q + qq) * M + m) * LP;
+    const int64_t bq_u = (int64_t)b * Q + qb;                           // (uniform) the wavefront's first query of this pass
     const RawOps r = r_n;
     const float4 gq = g_n;
     const int qbn = qb + nw * 4;
-    if (qbn < q1) {
-      const int64_t bqn = (int64_t)b * Q + min(qbn + tq, q1 - 1);
-      r_n = fetch_ops<FUSED, VT>(loc, attn, bqn, m, M, LP, L, RD, j, lvl);
-      g_n = (qbn + tq < q1) ? ld4(gout, (bqn * M + m) * 16 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (qbn < q1) fetch_pass(qbn, q0, q1, r_n, g_n);
     float2 xy;
     float w, dloc;
     resolve_ops<FUSED>(r, invT, invP, RD, xy.x, xy.y, w, dloc);
@@ -1345,8 +1374,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
     GVL_TOUCH_PREFETCH(r_n, g_n)
     if (!FUSED) {
       if (act) {
-        st_stream(gattn + tb + j, keep_w);                                     // cuh:156-157
-        st_stream(reinterpret_cast<float2 *>(gloc) + tb + j, make_float2(keep_x, keep_y));
+        const unsigned e = (unsigned)((tq * M + m) * LP + j);
+        st_stream(reinterpret_cast<float *>(reinterpret_cast<char *>(gattn + bq_u * (M * LP)) + e * 4u), keep_w);   // cuh:156-157
+        st_stream(reinterpret_cast<float2 *>(reinterpret_cast<char *>(reinterpret_cast<float2 *>(gloc) + bq_u * (M * LP)) + e * 8u),
+                  make_float2(keep_x, keep_y));
       }
     } else {
       const float dsum = row_allsum(w * keep_w);                               // softmax backward (ms_deform_attn.py:100-101)
@@ -1356,13 +1387,15 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
       gr0 += dpp_f<0xB1>(gr0); gr0 += dpp_f<0x4E>(gr0);
       gr1 += dpp_f<0xB1>(gr1); gr1 += dpp_f<0x4E>(gr1);
       if (act) {
-        VT *grow = reinterpret_cast<VT *>(gloc) + ((int64_t)b * Q + qq) * (int64_t)(2 * M * LP);
-        grow[m * LP + j] = (VT)goff;
-        grow[M * LP + m * LP + j] = (VT)glogit;
+        char *grow = reinterpret_cast<char *>(reinterpret_cast<VT *>(gloc) + bq_u * (2 * M * LP));
+        const unsigned e = (unsigned)(tq * (2 * M * LP) + m * LP + j) * (unsigned)sizeof(VT);
+        *reinterpret_cast<VT *>(grow + e) = (VT)goff;
+        *reinterpret_cast<VT *>(grow + (e + (unsigned)(M * LP) * (unsigned)sizeof(VT))) = (VT)glogit;
         if (gattn && (j & 3) == 0) {
-          float *gr = gattn + ((((int64_t)b * Q + qq) * M + m) * L + lvl) * RD;
-          gr[0] = gr0;
-          if (RD == 2) gr[1] = gr1;
+          char *gr = reinterpret_cast<char *>(gattn + bq_u * (M * L * RD));
+          const unsigned eg = (unsigned)(((tq * M + m) * L + lvl) * RD) * 4u;
+          *reinterpret_cast<float *>(gr + eg) = gr0;
+          if (RD == 2) *reinterpret_cast<float *>(gr + (eg + 4u)) = gr1;
         }
       }
     }
