@@ -6,7 +6,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GVL_LIB_PATH: a dev build (gvl_amd.build.build_dev: timing / ablation variants of single kernels) instead of the shipped library
 LIB_PATH = os.environ.get("GVL_LIB_PATH") or os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 13          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 14          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -113,7 +113,7 @@ SIGNATURES = {
     "gvl_linear_f16x3_splitk_f32": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "gvl_adam_chunk_elems": (_I, []),
     "gvl_adam_set_grads": (_I, [_P, _I, _P, _P]),
-    "gvl_clip_adam_step_f32": (_I, [_P, _P, _I, _P, _P, _P] + [ctypes.c_double] * 6 + [_P]),
+    "gvl_clip_adam_step_f32": (_I, [_P, _I, _P, _I, _P, _P, _P] + [ctypes.c_double] * 6 + [_P]),
     "gvl_lsap_solve_f64": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_solve_f32": (_I, [_P, _I64, _I64, _P, _P]),
     "gvl_lsap_batch_device_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),

@@ -75,8 +75,6 @@ def build_dev(sources, defs, verbose=False):
     (-DGVL_...) into build/obj_dev, linked with the SHIPPED library's other objects into gvl_amd/libgvl_msda_dev.so -- the shipped
     library and its objects are never touched.  A process uses it through GVL_LIB_PATH (gvl_amd/_lib.py)."""
     objdir, devdir = os.path.join(ROOT, "build", "obj"), os.path.join(ROOT, "build", "obj_dev")
-    have_all = all(os.path.exists(os.path.join(objdir, os.path.basename(s_) + ".o")) for s_ in SRC if os.path.exists(s_))
-    build(force=not have_all)                # (a checkout that carries the library but not its objects: compile them once)
     cc = hipcc()
     os.makedirs(devdir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"] + list(defs)
@@ -97,6 +95,14 @@ def build_dev(sources, defs, verbose=False):
             subprocess.check_call(cmd, cwd=ROOT)
         else:
             obj = os.path.join(objdir, base + ".o")
+            fresh = os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src) if os.path.exists(d))
+            if not fresh:
+                # a checkout that carries the library but not (or no longer) its objects: this file's plain object goes to
+                # build/obj_dev as well -- neither build/obj nor the shipped library is written from here
+                obj = os.path.join(devdir, base + ".plain.o")
+                plain = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-c"]
+                if not (os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src) if os.path.exists(d))):
+                    subprocess.check_call([cc] + plain + ["-o", obj, src], cwd=ROOT)
         objs.append(obj)
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT_DEV] + objs, cwd=ROOT)
     return OUT_DEV

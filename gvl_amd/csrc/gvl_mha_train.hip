@@ -246,14 +246,17 @@ __global__ void __launch_bounds__(kThreads) k_mha_fwd(const MhaParams p) {
       tmax = fmaxf(tmax, s[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax), corr = exp2f(m - m_new);
-    // (a column with no valid key so far: m_new = -inf, every weight exp2(-inf - -inf) = NaN -- as torch's softmax of a fully
-    //  masked row; the decoder never masks every key of a video)
+    // a query with no valid key SO FAR (a leading tile of 32 padded keys): m_new = -inf, and exp2(-inf - -inf) would
+    // be NaN for good -- nothing has been accumulated yet, so the rescale is 1 and this tile's weights are 0.  A row whose EVERY
+    // key is masked still ends as 0 / 0 = NaN, as torch's softmax of a fully masked row does.
+    const float m_new = fmaxf(m, tmax);
+    const bool none = m_new == -INFINITY;
+    const float corr = none ? 1.f : exp2f(m - m_new);
     float psum = 0.f;
     float pd[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pr = exp2f(s[r] - m_new);
+      const float pr = none ? 0.f : exp2f(s[r] - m_new);
       psum += pr;
       pd[r] = p.p > 0.f ? pr * drop_factor(dk, bh, p.Q, min(q, p.Q - 1), 32 * kt + acc_row(r, half)) : pr;
     }

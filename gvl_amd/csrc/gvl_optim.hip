@@ -48,11 +48,21 @@ __global__ void __launch_bounds__(kOptThreads) k_grad_sqnorm(const gvl_adam_desc
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-// scal: [0] total norm, [1] clip coefficient, [2] lr / (1 - beta1^t), [3] sqrt(1 - beta2^t)
+// scal: [0] total norm, [1] clip coefficient, [2] / [3] the bias corrections of tensor 0 (diagnostic);
+// corr[2 i], corr[2 i + 1]: lr / (1 - beta1^t_i), sqrt(1 - beta2^t_i) from tensor i's OWN step count -- torch.optim.Adam keeps a
+// step per parameter, and they differ as soon as a parameter sat out a step (no gradient on that batch) or got its state later
 __global__ void __launch_bounds__(kOptThreads) k_adam_prep(const float *__restrict__ partial, int n_chunks, float max_norm,
-                                                           const float *__restrict__ step, double lr, double beta1, double beta2,
-                                                           float *__restrict__ scal) {
+                                                           const gvl_adam_desc *__restrict__ descs, int n_tensors, double lr,
+                                                           double beta1, double beta2, float *__restrict__ scal,
+                                                           float *__restrict__ corr) {
   __shared__ double sd[kOptThreads];
+  for (int i = threadIdx.x; i < n_tensors; i += kOptThreads) {
+    const double t = (double)*descs[i].step;
+    const float a = (float)(lr / (1.0 - pow(beta1, t))), b = (float)sqrt(1.0 - pow(beta2, t));
+    corr[2 * i] = a;
+    corr[2 * i + 1] = b;
+    if (i == 0) scal[2] = a, scal[3] = b;
+  }
   double s = 0.0;
   for (int i = threadIdx.x; i < n_chunks; i += kOptThreads) s += (double)partial[i];
   sd[threadIdx.x] = s;
@@ -63,12 +73,11 @@ __global__ void __launch_bounds__(kOptThreads) k_adam_prep(const float *__restri
   }
   if (threadIdx.x == 0) {
     const float total = (float)sqrt(sd[0]);
+    // clip_grad_norm_'s own coefficient, max_norm passed straight through: max_norm = 0 scales every gradient to 0, as the
+    // reference's unconditional call does (train.py:407) -- the fallback and this path agree for every value
     const float c = max_norm / (total + 1e-6f);
-    const double t = (double)step[0];
     scal[0] = total;
-    scal[1] = max_norm > 0.f ? (c < 1.f ? c : 1.f) : 1.f;
-    scal[2] = (float)(lr / (1.0 - pow(beta1, t)));
-    scal[3] = (float)sqrt(1.0 - pow(beta2, t));
+    scal[1] = c < 1.f ? c : 1.f;
   }
 }
 
@@ -84,13 +93,13 @@ __device__ __forceinline__ void adam1(float &p, float &gc, float &m, float &v, f
 }
 
 __global__ void __launch_bounds__(kOptThreads) k_adam(const gvl_adam_desc *__restrict__ descs, const int2 *__restrict__ chunk_map,
-                                                      const float *__restrict__ scal, float w1, float beta2, float w2, float eps,
-                                                      float wd) {
+                                                      const float *__restrict__ scal, const float *__restrict__ corr, float w1,
+                                                      float beta2, float w2, float eps, float wd) {
   const int2 cm = chunk_map[blockIdx.x];
   const gvl_adam_desc d = descs[cm.x];
   const int64_t base = (int64_t)cm.y * kOptChunk, n = d.n - base < kOptChunk ? d.n - base : kOptChunk;
   float *p = d.p + base, *m = d.m + base, *v = d.v + base, *g = const_cast<float *>(d.g) + base;
-  const float coef = scal[1], step_size = scal[2], bc2s = scal[3];
+  const float coef = scal[1], step_size = corr[2 * cm.x], bc2s = corr[2 * cm.x + 1];
   if (d.vec) {
     for (int i = threadIdx.x * 4; i < n; i += kOptThreads * 4) {
       float4 pp = *reinterpret_cast<float4 *>(p + i), mm = *reinterpret_cast<float4 *>(m + i), vv = *reinterpret_cast<float4 *>(v + i);
@@ -141,10 +150,10 @@ extern "C" int gvl_adam_set_grads(gvl_adam_desc *descs_device, int n_tensors, co
   return e == hipSuccess ? 0 : fail((int)e, "gvl_adam_set_grads: launch failed: %s", hipGetErrorString(e));
 }
 
-extern "C" int gvl_clip_adam_step_f32(const gvl_adam_desc *descs_device, const int *chunk_map_device, int n_chunks,
-                                      float *partial_device, float *scal_device, const float *step_device, double max_norm,
+extern "C" int gvl_clip_adam_step_f32(const gvl_adam_desc *descs_device, int n_tensors, const int *chunk_map_device, int n_chunks,
+                                      float *partial_device, float *scal_device, float *corr_device, double max_norm,
                                       double lr, double beta1, double beta2, double eps, double weight_decay, void *stream) {
-  if (!descs_device || !chunk_map_device || !partial_device || !scal_device || !step_device || n_chunks <= 0)
+  if (!descs_device || !chunk_map_device || !partial_device || !scal_device || !corr_device || n_chunks <= 0 || n_tensors <= 0)
     return fail(GVL_EINVAL, "gvl_clip_adam_step_f32: null pointer / empty launch");
   if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
     return fail(GVL_EINVAL, "gvl_clip_adam_step_f32: lr, eps >= 0 and betas in [0, 1) (got %g %g %g %g)", lr, beta1, beta2, eps);
@@ -152,10 +161,10 @@ extern "C" int gvl_clip_adam_step_f32(const gvl_adam_desc *descs_device, const i
   const int2 *cm = reinterpret_cast<const int2 *>(chunk_map_device);
   hipLaunchKernelGGL(k_grad_sqnorm, dim3(n_chunks), dim3(kOptThreads), 0, st, descs_device, cm, partial_device);
   hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(kOptThreads), 0, st, (const float *)partial_device, n_chunks, (float)max_norm,
-                     step_device, lr, beta1, beta2, scal_device);
+                     descs_device, n_tensors, lr, beta1, beta2, scal_device, corr_device);
   // (1 - beta in double, as torch's kernel forms it: 1.f - 0.999f is 1.3e-5 away from 0.001)
   hipLaunchKernelGGL(k_adam, dim3(n_chunks), dim3(kOptThreads), 0, st, descs_device, cm, (const float *)scal_device,
-                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
+                     (const float *)corr_device, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, "gvl_clip_adam_step_f32: launch failed: %s", hipGetErrorString(e));
 }

@@ -18,12 +18,22 @@ _ENABLED = os.environ.get("GVL_OPTIM", "") != "torch"
 
 class _Desc(ctypes.Structure):                      # include/gvl_msda.h: gvl_adam_desc
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
-                ("n", ctypes.c_int64), ("vec", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("step", ctypes.c_void_p), ("n", ctypes.c_int64), ("vec", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+def bump_versions(tensors):
+    """The kernels of this file -- and every hipGraph replay of a captured update -- write parameters through raw pointers, so
+    torch's version counters do not move by themselves.  Every weight-derived cache of the package (split-fp16 planes, the
+    captioner's stacked matrices, captured eval / decode graphs, reference-point tables) is keyed on (data_ptr, _version): without
+    this bump an evaluation after training would run on the planes of the weights it saw first.  No launch, no
+    synchronisation: the counter is host-side metadata, as torch's own in-place update would have moved it."""
+    torch.autograd.graph.increment_version(tensors)
 
 
 class ClipAdam:
     def __init__(self, optimizer, max_norm):
-        self.opt, self.max_norm = optimizer, float(max_norm) if max_norm else 0.0
+        # max_norm reaches clip_grad_norm_'s formula unchanged (0 zeroes the gradients, as torch's own call with 0 does)
+        self.opt, self.max_norm = optimizer, float(max_norm)
         self.tables = {}
         self.last = None                                     # scal tensor of the last step: [total norm, clip coefficient, ...]
 
@@ -59,13 +69,14 @@ class ClipAdam:
         for i, (p, g, m, v, _) in enumerate(rows):
             n = p.numel()
             vec = int(vec_grads and n % 4 == 0 and all(x.data_ptr() % 16 == 0 for x in (p, m, v)))
-            descs.append(_Desc(p.data_ptr(), None, m.data_ptr(), v.data_ptr(), n, vec, 0))
+            descs.append(_Desc(p.data_ptr(), None, m.data_ptr(), v.data_ptr(), rows[i][4].data_ptr(), n, vec, 0))
             cmap.extend((i, c) for c in range((n + chunk - 1) // chunk))
         arr = (_Desc * len(descs))(*descs)
         raw = np.frombuffer(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)), dtype=np.uint8).copy()
         return {"descs": torch.from_numpy(raw).to(dev), "cmap": torch.tensor(cmap, dtype=torch.int32, device=dev).contiguous(),
                 "partial": torch.empty(len(cmap), dtype=torch.float32, device=dev),
-                "scal": torch.zeros(4, dtype=torch.float32, device=dev), "n_chunks": len(cmap),
+                "scal": torch.zeros(4, dtype=torch.float32, device=dev),
+                "corr": torch.zeros(2 * len(rows), dtype=torch.float32, device=dev), "n_chunks": len(cmap),
                 "ptrs": tuple(x.data_ptr() for r in rows for x in (r[0], r[2], r[3], r[4])), "steps": [r[4] for r in rows],
                 "n": len(rows)}
 
@@ -95,10 +106,11 @@ class ClipAdam:
         torch._foreach_add_(tab["steps"], 1.0)
         b1, b2 = g["betas"]
         with torch.cuda.device(params[0].device):
-            rc = _lib.lib().gvl_clip_adam_step_f32(tab["descs"].data_ptr(), tab["cmap"].data_ptr(), tab["n_chunks"],
-                                                   tab["partial"].data_ptr(), tab["scal"].data_ptr(), tab["steps"][0].data_ptr(),
+            rc = _lib.lib().gvl_clip_adam_step_f32(tab["descs"].data_ptr(), tab["n"], tab["cmap"].data_ptr(), tab["n_chunks"],
+                                                   tab["partial"].data_ptr(), tab["scal"].data_ptr(), tab["corr"].data_ptr(),
                                                    self.max_norm, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
                                                    float(g["weight_decay"]), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "clip_adam_step")
+        bump_versions([r[0] for r in rows] + [r[1] for r in rows])          # parameters updated, gradients clipped in place
         self.last = tab["scal"]
         return True

@@ -20,6 +20,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from .optim import bump_versions
 from .targets import PaddedTargets, needed_capacity, round_up_pow2, total_events
 
 
@@ -686,6 +687,9 @@ class GraphedTrainStep(TrainStep):
                 if len(self._exchange_events) > 64:
                     self._exchange_events.pop(0)
             graphs[2].replay()
+        # a replay updates the parameters through the addresses the graph recorded: torch's version counters do not see it, and
+        # every weight-derived cache (operand planes, captured eval / decode graphs) is keyed on them
+        bump_versions(self.params)
         self.replays += 1
         return outs
 

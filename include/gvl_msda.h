@@ -48,7 +48,36 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 13  /* 13: + gvl_cap_attend_pre_f32 / _applicable (the offsets' hidden-state product arrives precomputed; half of the sample reads from LDS); 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch), gvl_gemm_f16x3_gates_f32 / _applicable (both halves of the LSTM gate product + cell in one launch), gvl_greedy_step_partials_gemm_f32 (greedy reduction + an independent product in one launch), gvl_clip_adam_step_f32 (gradient clipping + Adam over a tensor table), gvl_group_norm_rows_backward_f32 / gvl_conv_taps_to_rows_f32 (training form of the base encoder's levels); 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step), gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training), gvl_relu_dropout_rows_*; 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, + gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step / gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation); 9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies; 8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32; 7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers); 6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32, gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32; 2: + bf16 storage twins; 3: + training-time captioner step, matcher cost, set criterion; 4: + gvl_col_sum_f32; 5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count / num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32 */
+#define GVL_MSDA_ABI_VERSION 14
+/* ABI history (newest first):
+ * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
+ *      step pointer: torch.optim.Adam counts steps per parameter; max_norm is passed straight to clip_grad_norm_'s
+ *      formula (0 scales the gradients to 0, as torch does)
+ * 13: + gvl_cap_attend_pre_f32 / _applicable (the offsets' hidden-state product arrives precomputed; half of the sample reads
+ *      from LDS)
+ * 12: + gvl_reload_env (the GVL_* switches are read once per process, not on every launch), gvl_gemm_f16x3_gates_f32 /
+ *      _applicable (both halves of the LSTM gate product + cell in one launch), gvl_greedy_step_partials_gemm_f32 (greedy
+ *      reduction + an independent product in one launch), gvl_clip_adam_step_f32 (gradient clipping + Adam over a tensor table),
+ *      gvl_group_norm_rows_backward_f32 / gvl_conv_taps_to_rows_f32 (training form of the base encoder's levels)
+ * 11: + gvl_wgrad_f16x3_f32 / gvl_wgrad_workspace_bytes (weight + bias gradient of every nn.Linear of the training step),
+ *      gvl_planes_refresh_f16 / gvl_planes_chunk_elems (operand planes of all weights, both orientations, two launches per
+ *      step), gvl_mha_train_{forward,backward}_f32 (attention core of nn.MultiheadAttention in training),
+ *      gvl_relu_dropout_rows_*
+ * 10: + gvl_f16_products (one fp16 product per fp32 product: inference under autocast), operand planes K-stage-major, +
+ *      gvl_residual_dropout_layer_norm_{forward,backward}_f32 / gvl_rdln_backward_blocks / gvl_advance_step /
+ *      gvl_relu_dropout_{forward,backward}_f32 (training residual chains and FFN activation)
+ *  9: + gvl_msda_last_kernel (diagnostic); - gvl_skinny_gemm_f16x3_f32 / gvl_skinny_pack_f16 (round 3's few-row product: slower
+ *      than the tuned library kernels, removed); the temporal backward needs no workspace where the row-ownership form applies
+ *  8: + gvl_gemm_f16x3_lstm_f32, gvl_cap_attend_split_levels_f32, gvl_ce_rows_*_f32
+ *  7: + gvl_linear_f16x3_f32, gvl_layer_norm_rows_f32, gvl_row_absmax_f32, gvl_msda1d_fused_forward_amax_f32 (inference layers)
+ *  6: + gvl_split_rows_f16, gvl_gemm_f16x3_f32, gvl_gemm_f16x3_argmax_f32, gvl_greedy_step_partials_f32,
+ *      gvl_cap_attend_split_f32, gvl_lstm_cell_split_f32
+ *  5: + padded (layout-independent) targets: gvl_match_cost_padded_f32, gvl_set_criterion_* take video_pair_count /
+ *      num_boxes_dev, gvl_cap_attend_train_* take row_video; + gvl_proj_f32
+ *  4: + gvl_col_sum_f32
+ *  3: + training-time captioner step, matcher cost, set criterion
+ *  2: + bf16 storage twins
+ */
 
 #define GVL_PAD_ZEROS 0
 #define GVL_PAD_BORDER 1
@@ -765,13 +794,17 @@ int gvl_linear_f16x3_splitk_f32(const float *a, int64_t lda, const float *amax_a
  *    tensors, three launches (sum of squares per chunk; total norm, clip coefficient, bias corrections; update) -- gvl_optim.hip.
  *    descs: device array of gvl_adam_desc (p, g, m, v: fp32 device tensors of n elements; vec = 1 when all four are 16-byte aligned
  *    and n % 4 == 0); chunk_map: (tensor, chunk) per workgroup, chunks of gvl_adam_chunk_elems() elements; partial: n_chunks floats;
- *    scal: 4 floats, on return {total norm, clip coefficient, lr / (1 - beta1^t), sqrt(1 - beta2^t)}; step: the step count t AFTER
- *    this update (torch's state['step'], a device float).  max_norm <= 0: no clipping.  The gradients are scaled in place by the
+ *    scal: 4 floats, on return {total norm, clip coefficient, and tensor 0's two bias corrections}; corr: 2 * n_tensors floats, on
+ *    return {lr / (1 - beta1^t_i), sqrt(1 - beta2^t_i)} per tensor; desc.step: tensor i's step count t_i AFTER this update (torch's
+ *    state['step'], a device float -- torch.optim.Adam counts per parameter, and the counts differ once a parameter sat out a step).
+ *    max_norm goes into clip_grad_norm_'s formula as it is: coefficient min(1, max_norm / (total + 1e-6)), so 0 scales the
+ *    gradients to 0 exactly as the reference's unconditional call (train.py:407) would.  The gradients are scaled in place by the
  *    clip coefficient, as clip_grad_norm_ leaves them. */
 typedef struct gvl_adam_desc {
   float *p;
   const float *g;
   float *m, *v;
+  const float *step;
   int64_t n;
   int vec, pad_;
 } gvl_adam_desc;
@@ -781,9 +814,9 @@ int gvl_adam_chunk_elems(void);
  * A desc's `vec` then asserts 16-byte alignment of p, m, v only: gradients are read 16 bytes at a time when THEY are aligned too
  * (checked by the caller per call: pass vec = 0 tables otherwise). */
 int gvl_adam_set_grads(gvl_adam_desc *descs_device, int n_tensors, const void *const *grads_host, void *stream);
-int gvl_clip_adam_step_f32(const gvl_adam_desc *descs_device, const int *chunk_map_device, int n_chunks, float *partial_device,
-                           float *scal_device, const float *step_device, double max_norm, double lr, double beta1, double beta2,
-                           double eps, double weight_decay, void *stream);
+int gvl_clip_adam_step_f32(const gvl_adam_desc *descs_device, int n_tensors, const int *chunk_map_device, int n_chunks,
+                           float *partial_device, float *scal_device, float *corr_device, double max_norm, double lr, double beta1,
+                           double beta2, double eps, double weight_decay, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,8 +40,11 @@ def _ref_attention(x, pos, w, b, wo, bo, H, key_keep, drop_keep, p):
     return o @ wo.t() + bo
 
 
-@pytest.mark.parametrize("B,Q,p", [(16, 300, 0.0), (16, 300, 0.1), (2, 300, 0.25), (4, 170, 0.1), (16, 64, 0.0)])
-def test_self_attention_matches_float64(B, Q, p):
+@pytest.mark.parametrize("B,Q,p,lead", [(16, 300, 0.0, 0), (16, 300, 0.1, 0), (2, 300, 0.25, 0), (4, 170, 0.1, 0), (16, 64, 0.0, 0),
+                                        (4, 300, 0.0, 40), (4, 170, 0.1, 32)])
+def test_self_attention_matches_float64(B, Q, p, lead):
+    """lead > 0: the first `lead` keys of some videos are padded -- a whole leading 32-key tile without a valid key, which the
+    online softmax must survive (torch's MHA returns finite values there)"""
     from gvl_amd import train_layers as TL
     from gvl_amd import train_mha as TM
     C, H = 512, 8
@@ -57,6 +60,8 @@ def test_self_attention_matches_float64(B, Q, p):
     for i in range(B):
         mask[i, Q - 1 - 7 * i % Q // 3:] = i % 3 == 0                              # ragged key masks, some videos unmasked
     mask[:, 0] = True
+    if lead:
+        mask[::2, :lead] = False                                                   # non-prefix key masks
     assert TM.eligible(mha, tgt, pos)
     TL.advance(DEV)
     step = int(TL.step_counter(DEV).item())
