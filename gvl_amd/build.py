@@ -67,12 +67,12 @@ def build(force=False, verbose=False, save_temps=None):
     return OUT
 
 
-OUT_DEV = os.path.join(HERE, "libgvl_msda_dev.so")
+OUT_DEV = os.path.join(ROOT, "tools", "_bin", "libgvl_msda_dev.so")     # (git-ignored, outside the package: never beside the product library)
 
 
 def build_dev(sources, defs, verbose=False):
     """Timing / ablation builds of single kernels (`tools/*_ablate.sh`, `*_stamps.sh`): the named source files compiled with `defs`
-    (-DGVL_...) into build/obj_dev, linked with the SHIPPED library's other objects into gvl_amd/libgvl_msda_dev.so -- the shipped
+    (-DGVL_...) into build/obj_dev, linked with the SHIPPED library's other objects into tools/_bin/libgvl_msda_dev.so -- the shipped
     library and its objects are never touched.  A process uses it through GVL_LIB_PATH (gvl_amd/_lib.py)."""
     objdir, devdir = os.path.join(ROOT, "build", "obj"), os.path.join(ROOT, "build", "obj_dev")
     cc = hipcc()

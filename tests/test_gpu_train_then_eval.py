@@ -19,8 +19,8 @@ def _eval(model, criterion, dt, graphed=None):
     with torch.no_grad():
         out, _ = graphed(dt) if graphed is not None else model(dt, criterion, None, "queries", eval_mode=True)
     res = {k: out[k].detach().clone() for k in KEYS}
-    res["seq"] = out["seq"].detach().clone() if isinstance(out["seq"], torch.Tensor) else out["seq"]
-    res["cap_prob"] = out["caption_probs"]["cap_prob_eval"].detach().clone()
+    # (a model whose every caption ends at once returns seq = [], LSTM_DSA.py:186-187)
+    res["seq"] = out["seq"].detach().clone() if isinstance(out["seq"], torch.Tensor) else torch.zeros(0, device=DEV)
     return res
 
 
@@ -33,7 +33,8 @@ def _fresh_eval(model, dt, kw):
 def _same(a, b, what):
     for k in KEYS:
         assert maxerr(a[k], b[k]) <= 2e-5 * max(1.0, float(b[k].abs().max())), (what, k, maxerr(a[k], b[k]))
-    assert a["seq"].shape == b["seq"].shape and float((a["seq"] == b["seq"]).float().mean()) >= 0.999, what
+    assert a["seq"].shape == b["seq"].shape, (what, a["seq"].shape, b["seq"].shape)
+    assert a["seq"].numel() == 0 or float((a["seq"] == b["seq"]).float().mean()) >= 0.999, what
 
 
 def _moved(a, b):
@@ -43,7 +44,7 @@ def _moved(a, b):
 @pytest.mark.parametrize("graphed_train", [False, True])
 def test_evaluation_after_training_runs_on_the_updated_weights(graphed_train):
     from gvl_amd.parallel import GraphedEvalForward, GraphedTrainStep, TrainStep
-    kw = dict(transformer_dropout_prob=0.0, drop_prob=0.0, lr=2e-4, weight_decay=1e-4, grad_clip=100.0)
+    kw = dict(transformer_dropout_prob=0.0, drop_prob=0.0, lr=5e-5, weight_decay=1e-4, grad_clip=100.0)
     f, opt, model, criterion = build_anet(True, **kw)
     dt = train_batch(f, load("pdvc_anet_full_train"))
     graphed_eval = GraphedEvalForward(model, criterion)

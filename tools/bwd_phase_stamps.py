@@ -21,6 +21,9 @@ value = torch.randn(16, 188, 8, 64, device=dev)
 for name, Q, rd in (("dec (Lq=300, ref-dim 2)", 300, 2), ("enc (Lq=188, ref-dim 1)", 188, 1)):
     proj = torch.randn(16, Q, 256, device=dev)
     ref = torch.rand(16, Q, 4, rd, device=dev) * (0.5 if rd == 2 else 1.0)
+    if os.environ.get("PROBE_SAME_ROW"):     # every sample of a level at one location: the lane = sample reads meet no bank conflicts
+        proj[..., :128] = 0
+        ref = torch.full_like(ref, 0.37)
     gout = torch.randn(16, Q, 512, device=dev)
     for _ in range(5):
         MSDA.msda1d_fused_backward(value, sh2, lsi, proj, ref, gout, 4, 4, need_ref_grad=True)

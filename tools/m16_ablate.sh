@@ -5,5 +5,5 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 for d in "" "-DGVL_ABLATE_EPI" "-DGVL_ABLATE_EPI -DGVL_ABLATE_DMA" "-DGVL_ABLATE_EPI -DGVL_ABLATE_BARRIER" "-DGVL_ABLATE_EPI -DGVL_ABLATE_DMA -DGVL_ABLATE_BARRIER" "-DGVL_ABLATE_EPI -DGVL_ABLATE_LDS" "-DGVL_ABLATE_EPI -DGVL_ABLATE_LDS -DGVL_ABLATE_DMA -DGVL_ABLATE_BARRIER" ""; do
   python -m gvl_amd.build --dev gvl_gemm16.hip $d > /dev/null 2>&1
   echo "== defs '$d'"
-  GVL_LIB_PATH=gvl_amd/libgvl_msda_dev.so python tools/x1_probe.py 2>&1 | grep "argmax form" | cut -c1-30
+  GVL_LIB_PATH=tools/_bin/libgvl_msda_dev.so python tools/x1_probe.py 2>&1 | grep "argmax form" | cut -c1-30
 done
