@@ -396,7 +396,8 @@ def main():
     ap.add_argument("--cfg", default="anet_tsp_ssvg", help="gvl_amd.config.CONFIGS entry (BASELINE config 4: "
                     "--cfg yc2_tsn_dvc --T 512 --queries 100 --dtype bf16)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="bf16 = torch.autocast(bfloat16): bf16 GEMMs + bf16-storage deformable attention, fp32 captioner")
+                    help="bf16 = the step and the forward under torch.autocast(bfloat16); what that runs on: gvl_amd.pdvc.autocast_training_policy / "
+                         "autocast_inference_policy")
     ap.add_argument("--no-captioner", action="store_true", help="eval_disable_captioning=True (diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true", help="skip the supplementary kernel / GEMM probes after the timed "
@@ -705,15 +706,20 @@ def main():
                 + ("one fixed batch, 3 events per video" if a.fixed_layout else
                    f"{len(batches)} rotating batches with 0-10 events per video and 3-20-word captions"))
     from gvl_amd.linear import split_gemm_enabled as _sge
-    from gvl_amd.pdvc import autocast_inference_policy
-    _pol = autocast_inference_policy()
+    from gvl_amd.pdvc import autocast_inference_policy, autocast_training_policy
+    _pol, _tpol = autocast_inference_policy(), autocast_training_policy()
     island = a.dtype == "bf16" and _pol != "bf16"                # eval forward under autocast = the fp32-storage path
     gemm16_on = _sge() and (a.dtype == "f32" or island)
     from gvl_amd import layers as _lay
     _lay_on = _lay.enabled() and (a.dtype == "f32" or island)
     line = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.dtype == "f32" else (
-                "torch.autocast(bfloat16): train step on bf16 storage + bf16 GEMMs (f32 accumulate / locations / captioner); "
+                "torch.autocast(bfloat16): "
+                + {"f16": "train step on the hand-written fp32-storage training path with ONE fp16 product per fp32 product in the "
+                          "forward, input-gradient and weight-gradient products (11-bit operands, fp32 accumulate, fp32 master "
+                          "weights; GVL_AUTOCAST_TRAINING=bf16 for torch's bf16 formulation); ",
+                   "fp32": "train step on the hand-written fp32-storage training path, exact products (GVL_AUTOCAST_TRAINING=fp32); ",
+                   "bf16": "train step on bf16 storage + bf16 library GEMMs (f32 accumulate / locations / captioner); "}[_tpol]
                 + (("eval forward on the hand-written fp32-storage inference path with ONE fp16 product per fp32 product "
                     "(11-bit operands, fp32 accumulate; GVL_AUTOCAST_INFERENCE=fp32 for the exact products, =bf16 for bf16 "
                     "storage)" if _pol == "f16" else

@@ -842,6 +842,27 @@ class f16_products:
         return False
 
 
+def keeps_products(cls):
+    """Class decorator for an autograd Function whose BACKWARD launches split-fp16 products: the backward runs with the product
+    count its forward ran with.  ``f16_products`` is thread-local and the backward runs later, on autograd's device thread --
+    without this a training step under the autocast policy (gvl_amd/pdvc.py: one product per fp32 product) would take its input-
+    and weight-gradient products at three."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kwargs):
+        ctx._gvl_products = f16_products_now()
+        return fwd(ctx, *args, **kwargs)
+
+    def backward(ctx, *grads):
+        n = getattr(ctx, "_gvl_products", 3)
+        if n == f16_products_now():
+            return bwd(ctx, *grads)
+        with f16_products(n):
+            return bwd(ctx, *grads)
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 def profile_enable(on=True):
     """on: False / 0 = off; True / 1 = per-dispatch stamps of the sampling-path kernels; 2 = additionally the projection
     kernel in front of them (stamping two consecutive launches inflates the second one's interval, see gvl_common.hpp)"""

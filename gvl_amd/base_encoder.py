@@ -79,6 +79,12 @@ class PositionEmbeddingSine(nn.Module):
         return torch.cat((pos_x, dur), dim=2).permute(0, 2, 1)
 
 
+def _keeps_products(cls):
+    from . import MultiScaleDeformableAttention as MSDA                  # (imported late, as everywhere in this module)
+    return MSDA.keeps_products(cls)
+
+
+@_keeps_products
 class _PyramidTrainFunction(torch.autograd.Function):
     """TRAINING form of the feature pyramid (base_encoder.py:60-80): Conv1d(k = 1) / Conv1d(k = 3, stride 2, padding 1) + GroupNorm of
     every level -> the levels' rows of the flattened (N, S, C) encoder input, on the kernels of the inference form (forward_flat)

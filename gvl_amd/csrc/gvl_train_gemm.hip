@@ -122,6 +122,9 @@ __device__ __forceinline__ float block_max(const float *__restrict__ v, int n, f
   return r;
 }
 
+// X1 (gvl_f16_products(1): training under autocast): the leading fp16 product only -- no lo planes are formed, stored or read, one
+// MFMA per fragment pair instead of three; operands rounded to 11 significant bits at their tensor scale, fp32 accumulation.
+template <bool X1>
 __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,10 +185,10 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
       uint2 hi, lo;
       split4s(s.a[i], mul_a, hi, lo);
       *reinterpret_cast<uint2 *>(st + 16 * i * kWgRowB) = hi;
-      *reinterpret_cast<uint2 *>(st + kWgPlaneB + 16 * i * kWgRowB) = lo;
+      if constexpr (!X1) *reinterpret_cast<uint2 *>(st + kWgPlaneB + 16 * i * kWgRowB) = lo;
       split4s(s.b[i], mul_b, hi, lo);
       *reinterpret_cast<uint2 *>(st + 2 * kWgPlaneB + 16 * i * kWgRowB) = hi;
-      *reinterpret_cast<uint2 *>(st + 3 * kWgPlaneB + 16 * i * kWgRowB) = lo;
+      if constexpr (!X1) *reinterpret_cast<uint2 *>(st + 3 * kWgPlaneB + 16 * i * kWgRowB) = lo;
       bsum.x += s.a[i].x; bsum.y += s.a[i].y; bsum.z += s.a[i].z; bsum.w += s.a[i].w;
     }
   };
@@ -239,8 +242,10 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
 #define GVL_WG_MFMA()                                                                                   \
   _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int j = 0; j < 2; ++j) {         \
     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[h], bh[h][j], acc[j], 0, 0, 0);                  \
-    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[h], bl[h][j], acc[j], 0, 0, 0);                  \
-    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[h], bh[h][j], acc[j], 0, 0, 0);                  \
+    if constexpr (!X1) {                                                                                \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[h], bl[h][j], acc[j], 0, 0, 0);                \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[h], bh[h][j], acc[j], 0, 0, 0);                \
+    }                                                                                                   \
   }
 #endif
   // one stage: SET holds the rows of stage S + 1 and is re-requested for stage S + 4 as soon as they are in LDS.  FIRST / SECOND:
@@ -257,10 +262,10 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
     _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
       const uint32_t ro = sb + (uint32_t)(16 * h * kWgRowB);                                             \
       ah[h] = frag(ro + fa);                                                                             \
-      al[h] = frag(ro + kWgPlaneB + fa);                                                                 \
+      if constexpr (!X1) al[h] = frag(ro + kWgPlaneB + fa);                                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
         bh[h][j] = frag(ro + fb + 64 * j);                                                               \
-        bl[h][j] = frag(ro + kWgPlaneB + fb + 64 * j);                                                   \
+        if constexpr (!X1) bl[h][j] = frag(ro + kWgPlaneB + fb + 64 * j);                                \
       }                                                                                                  \
     }                                                                                                    \
     FIRST(SET, S)                                                                                        \
@@ -532,9 +537,10 @@ extern "C" int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *
 #ifdef GVL_WG_STAMPS
   p.stamps = g_wg_stamps;
 #endif
-  if (int rc = gvl::ensure_lds(k_wgrad_f16x3, kWgLds)) return rc;
-  if (int rc = gvl::launch(GVL_PROF_WGRAD, N, K, "k_wgrad_f16x3", k_wgrad_f16x3, dim3(8 * ((pl.tiles_n * pl.tiles_k * pl.SK + 7) / 8)),
-                           dim3(kWgThreads), kWgLds, st, p))
+  auto kern = gvl16::g_f16_products == 1 ? k_wgrad_f16x3<true> : k_wgrad_f16x3<false>;
+  if (int rc = gvl::ensure_lds(kern, kWgLds)) return rc;
+  if (int rc = gvl::launch(GVL_PROF_WGRAD, N, K, gvl16::g_f16_products == 1 ? "k_wgrad_f16x1" : "k_wgrad_f16x3", kern,
+                           dim3(8 * ((pl.tiles_n * pl.tiles_k * pl.SK + 7) / 8)), dim3(kWgThreads), kWgLds, st, p))
     return rc;
   if (pl.SK > 1) {
     const int64_t n4 = (int64_t)N * K / 4;

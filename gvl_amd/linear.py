@@ -94,6 +94,7 @@ def split_linear(x, weight, bias):
     return _SplitLinearFunction.forward(_NoCtx(), x, weight, bias)
 
 
+@MSDA.keeps_products
 class _VocabNLLFunction(torch.autograd.Function):
     """weight[r] * log_softmax(x W^T + b)[r, target[r]] for every (caption row, token step) r, without the (R, V)
     log-prob tensor: product (fp16 matrix cores at fp32 accuracy when in the kernel's domain), one pass for log-sum-exp
@@ -245,6 +246,7 @@ def _row_amax(t2, src=None):
     return L.row_absmax(t2)[0]
 
 
+@MSDA.keeps_products
 class _TrainLinearFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, nblk, *params):

@@ -61,6 +61,25 @@ def autocast_inference_policy():
     return v if v in ("bf16", "fp32") else "f16"
 
 
+def autocast_training_policy():
+    """What a TRAINING step under torch.autocast runs on (GVL_AUTOCAST_TRAINING; BASELINE config 5 names bf16, the reference has
+    only the flag, pdvc.py:214-215):
+    "f16"  (default) the hand-written fp32-storage training path -- fused layer kernels, split-fp16 Linear products forward,
+           input gradient and weight gradient, the owned attention core -- with ONE fp16 matrix-core product per fp32 product
+           (MSDA.f16_products(1), recorded per autograd node so that the backward takes the same): operands rounded to fp16 at
+           their row / tensor scale -- 11 significant bits where autocast's bf16 carries 8 --, fp32 accumulation, fp32 master
+           weights, moments and optimizer.  Through round 5 autocast sent every training Linear / attention / LayerNorm chain
+           to the bf16 library GEMMs + ATen casts and the step was SLOWER than the fp32 step (cfg A 10.0 against 7.4 ms, yc2
+           T = 512 11.7 against 9.7: profiles/r05_other_configs.json).
+    "fp32" the same path with the exact three-product split: autocast may lower precision, it need not;
+    "bf16" torch's own autocast formulation (bf16 library GEMMs, bf16-storage deformable attention), as in rounds 1-5."""
+    import os
+    pol = os.environ.get("GVL_AUTOCAST_TRAINING", "f16")
+    if pol not in ("f16", "fp32", "bf16"):
+        raise ValueError(f"GVL_AUTOCAST_TRAINING={pol!r}: expected f16, fp32 or bf16")
+    return pol
+
+
 def autocast_products():
     """fp16 products per fp32 product of the split-fp16 kernels under the current autocast inference policy"""
     return 1 if autocast_inference_policy() == "f16" else 3
@@ -209,6 +228,12 @@ class PDVC(nn.Module):
 
     def forward(self, dt, criterion, contrastive_criterion, transformer_input_type, eval_mode=False):
         from . import linear as _linear
+        if (self.training and torch.is_grad_enabled() and torch.is_autocast_enabled() and dt['video_tensor'].is_cuda
+                and _linear.train_linear_enabled() and autocast_training_policy() != "bf16"):
+            # TRAINING under torch.autocast: the hand-written training path at one (or three) fp16 products per fp32 product
+            from . import MultiScaleDeformableAttention as MSDA
+            with torch.autocast("cuda", enabled=False), MSDA.f16_products(1 if autocast_training_policy() == "f16" else 3):
+                return self.forward(dt, criterion, contrastive_criterion, transformer_input_type, eval_mode)
         if (self.training and torch.is_grad_enabled() and not torch.is_autocast_enabled() and dt['video_tensor'].is_cuda
                 and _linear.train_linear_enabled()):
             # TRAINING: the planes of every weight the hand-written Linear products read, for this forward's parameter values

@@ -41,6 +41,7 @@ class _Sub:
         self.hi, self.lo, self.scale = planes.hi[stage0:stage1], planes.lo[stage0:stage1], planes.scale
 
 
+@MSDA.keeps_products
 class _InProj(torch.autograd.Function):
     """qkv = [ (x + pos) W_qk^T | x W_v^T ] + b   ->  (qkv (R, 3C), row maxima of the q | k columns, of the v columns)"""
 

@@ -1,15 +1,15 @@
 #!/bin/bash
-# the bench at the other BASELINE configurations -> gpurun_out/r05_other_configs.json (one JSON object of bench lines)
+# the bench at the other BASELINE configurations -> gpurun_out/r06_other_configs.json (one JSON object of bench lines)
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 python - <<'PY'
 import json, subprocess, sys
 runs = {
-    "r05_yc2_f32": ["--cfg", "yc2_tsn_dvc", "--T", "512", "--queries", "100"],
-    "r05_yc2_bf16": ["--cfg", "yc2_tsn_dvc", "--T", "512", "--queries", "100", "--dtype", "bf16"],
-    "r05_cfgA_bf16": ["--dtype", "bf16"],
-    "r05_cfgA_T512": ["--T", "512"],
-    "r05_cfgA_fixed_layout": ["--fixed-layout"],
+    "r06_yc2_f32": ["--cfg", "yc2_tsn_dvc", "--T", "512", "--queries", "100"],
+    "r06_yc2_bf16": ["--cfg", "yc2_tsn_dvc", "--T", "512", "--queries", "100", "--dtype", "bf16"],
+    "r06_cfgA_bf16": ["--dtype", "bf16"],
+    "r06_cfgA_T512": ["--T", "512"],
+    "r06_cfgA_fixed_layout": ["--fixed-layout"],
 }
 out = {}
 for name, args in runs.items():
@@ -23,7 +23,7 @@ for name, args in runs.items():
         out[name] = keep
     except Exception as e:                                  # noqa: BLE001
         out[name] = {"error": str(e), "stderr": p.stderr[-400:]}
-json.dump(out, open("gpurun_out/r05_other_configs.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r06_other_configs.json", "w"), indent=1)
 for k, v in out.items():
     print(k, v.get("value"), v.get("ms_per_step"), v.get("train_step_ms"), (v.get("fwd_roofline") or {}).get("frac"))
 PY
