@@ -1,0 +1,85 @@
+"""Worker of tests/test_gpu_dp_graphed.py (one process per rank, started fresh by the test): three data-parallel GraphedTrainStep
+updates at the REAL cfg A dimensions (cfgs/anet_tsp_ssvg.yml: 300 queries, vocabulary 8517, T = 100) on this rank's shard of three
+global batches with uneven events per video (videos without events included), collectives over gloo on one shared GPU or RCCL with
+a GPU per rank.  mode "dp": the captured three-graph step with the eager bucketed exchange (gvl_amd.parallel.GraphedTrainStep);
+mode "serial": ONE process that computes what data parallelism defines -- every shard's forward / backward with the criterion
+normalised by the mean target count over the shards (criterion.py:178-180), gradients averaged over the shards, one clip + Adam --
+the oracle the ranks' parameters are compared with.  Writes the parameters after each step to an .npz."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def main():
+    mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bench import synth_batch
+    from helpers import load, pdvc_state
+    from gvl_amd.config import make_opt
+    from gvl_amd.parallel import GraphedTrainStep, TrainStep, shard_batch
+    from gvl_amd.pdvc import build
+    dev = torch.device("cuda", int(os.environ.get("GVL_TEST_DEVICE", "0")))
+    torch.cuda.set_device(dev)
+    if mode == "dp":
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        dist.init_process_group(os.environ.get("GVL_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+    f = load("pdvc_anet_full")
+    opt = make_opt("anet_tsp_ssvg", num_queries=300, frame_embedding_num=100, device="cuda", transformer_dropout_prob=0.0,
+                   drop_prob=0.0, lr=1e-4)
+    model, criterion, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f, seed=100), strict=True)
+    model = model.to(dev).train()
+    # three global batches of 8 videos, events per video uneven, two videos without events (one on each rank's shard in batch 0)
+    layouts = [[0, 5, 3, 0, 1, 7, 2, 4], [2, 0, 0, 6, 3, 1, 9, 1], [4, 4, 1, 2, 0, 3, 5, 8]]
+    batches = [synth_batch(8, 100, opt.feature_dim, opt.vocab_size, ns, dev, seed=40 + i, cap_words=(3, 9))
+               for i, ns in enumerate(layouts)]
+    names = [n for n, _ in model.named_parameters()]
+    keep = [n for n in names if any(k in n for k in ("query_embed", "class_head", "bbox_head.2.layers.2", "input_proj.0.0.weight",
+                                                     "encoder.layers.0.linear1.weight", "caption_head.1.logit.bias",
+                                                     "decoder.layers.1.cross_attn.sampling_offsets.bias", "count_head"))]
+    params = dict(model.named_parameters())
+    rec = {}
+
+    def snapshot(step):
+        torch.cuda.synchronize()
+        for n in keep:
+            rec[f"s{step}.{n}"] = params[n].detach().cpu().numpy().copy()
+        rec[f"s{step}.checksum"] = np.array([float(sum(p.detach().double().sum() for p in params.values()))])
+    if mode == "dp":
+        step = GraphedTrainStep(model, criterion, opt, world_size=world, warmup=1, max_gt=16, max_cap_len=12, max_events=64)
+        for i, dt in enumerate(batches):
+            step(shard_batch(dt, rank, world))
+            snapshot(i)
+        rec["captures"] = np.array([step.captures])
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ts = TrainStep(model, criterion, opt, capturable=True)
+        for i, dt in enumerate(batches):
+            shards = [shard_batch(dt, r, world) for r in range(world)]
+            nb = torch.tensor([max(1.0, sum(len(t_["labels"]) for t_ in dt["video_target"]) / world)], device=dev)
+            ts.buckets.zero()
+            model.zero_grad(set_to_none=True)
+            criterion.num_boxes_override = nb
+            try:
+                for sh in shards:
+                    final, _ = ts._forward_loss(sh)
+                    final.backward()
+            finally:
+                criterion.num_boxes_override = None
+            for p in ts.params:
+                if p.grad is not None:
+                    p.grad.div_(world)
+            ts._clip_and_step()
+            snapshot(i)
+    np.savez(out, **rec)
+
+
+if __name__ == "__main__":
+    main()

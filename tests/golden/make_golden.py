@@ -174,6 +174,30 @@ def make_module():
     save("module_cap", tshapes=tshapes, lsi=lsi, mask=mask, out=out, meta=np.array([B, Qc, C, 1, L, P, 2]))
 
 
+def make_module_cap3c():
+    """MSDeformAttnCap with enable_pos_emb_for_captioner (3C-wide queries: ms_deform_attn_for_caption.py:54-56), the shipped
+    (border) core as the reference calls it, same inputs as module_cap otherwise"""
+    import types
+    B, T, C, L, P = 2, 37, 64, 4, 4
+    lens = level_lengths(T, L)
+    S = sum(lens)
+    tshapes = torch.tensor(lens, dtype=torch.long)
+    lsi = torch.cat([tshapes.new_zeros(1), tshapes.cumsum(0)[:-1]])
+    torch.manual_seed(0)
+    Qc = 5
+    cap = MSDeformAttnCap(C, L, 1, P, opt=types.SimpleNamespace(enable_pos_emb_for_captioner=True)).eval()
+    assert cap.sampling_offsets.in_features == 3 * C
+    load_synth(cap, seed=210, prefix="cap3.")
+    query = torch.from_numpy(synth_array("cap3.query", (B, Qc, 3 * C), 1))
+    inp = torch.from_numpy(synth_array("cap3.input", (B, S, C), 1))
+    ref = torch.from_numpy(synth_array("cap3.ref", (B, Qc, L, 2), 1, 0.05, 0.95))
+    ref[..., 1] *= 0.5
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[1, S - 3:] = True
+    out = cap(query, ref, inp, tshapes, lsi, mask)
+    save("module_cap3c", tshapes=tshapes, lsi=lsi, mask=mask, out=out, meta=np.array([B, Qc, C, 1, L, P, 2]))
+
+
 # ---------------------------------------------------------------------------------------------- matcher
 def make_matcher():
     rec = {}
@@ -931,7 +955,7 @@ def make_train():
     save("pdvc_train", **rec)
 
 
-def make_switches():
+def make_switches(only=None):
     """The reference's configuration switches on the path that no other fixture exercises: the eval forward
     with eval_disable_captioning, with_box_refine = 0, share_caption_head = 0, and a TRAINING forward / backward with
     caption_loss_coef = 0 (pdvc.py:262-275 then routes training through parallel_prediction_full).  Small dimensions, CUDA-op
@@ -939,7 +963,12 @@ def make_switches():
     global PDVC_OVERRIDES
     B, T = 2, 24
     cases = {"nocap": dict(eval_disable_captioning=True), "norefine": dict(with_box_refine=0), "unshared": dict(share_caption_head=0),
-             "nocaploss": dict(caption_loss_coef=0, transformer_dropout_prob=0.0, drop_prob=0.0)}
+             "nocaploss": dict(caption_loss_coef=0, transformer_dropout_prob=0.0, drop_prob=0.0),
+             # round 6: the captioner sees [hs | query_embed] -- 3C-wide MSDeformAttnCap projections
+             # (ms_deform_attn_for_caption.py:54-56), 3C LSTM input (LSTM_DSA.py), pdvc.py:344
+             "posemb": dict(enable_pos_emb_for_captioner=True)}
+    if only:
+        cases = {k: v for k, v in cases.items() if k in only}
     for name, over in cases.items():
         saved = dict(PDVC_OVERRIDES)
         PDVC_OVERRIDES.update(over)
@@ -1045,6 +1074,10 @@ if __name__ == "__main__":
     if "--only-train" in sys.argv:
         make_train()
         sys.exit(0)
+    if "--only-posemb" in sys.argv:                   # the round-6 additions alone (the older fixtures are left untouched)
+        make_module_cap3c()
+        make_switches(only=("posemb",))
+        sys.exit(0)
     for flag, fn in (("--only-dataset", make_dataset), ("--only-anet-c3d", make_anet_c3d), ("--only-f64", make_f64),
                      ("--only-anet-full-train", make_anet_full_train), ("--only-anet-full-b16", make_anet_full_b16),
                      ("--only-anet-full-train-b16", make_anet_full_train_b16), ("--only-yc2-train", make_yc2_train),
@@ -1054,6 +1087,7 @@ if __name__ == "__main__":
             sys.exit(0)
     make_op()
     make_module()
+    make_module_cap3c()
     make_matcher()
     make_collate()
     if FULL:

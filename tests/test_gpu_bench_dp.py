@@ -27,8 +27,21 @@ def test_two_ranks_on_one_gpu(mode, launcher):
     """launcher=True: started the way the driver starts N > 1 (`python -m torch.distributed.run ... bench.py --gpus 2`);
     launcher=False: plain `python bench.py --gpus 2` -- the parent, which never touches the GPU, starts the two ranks as
     a child job itself and relays rank 0's line"""
+    _run_ranks(2, mode, launcher)
+
+
+@pytest.mark.parametrize("launcher", [True, False])
+def test_eight_ranks_the_command_a_scaling_run_issues(launcher):
+    """`bench.py --gpus 8` exactly as the driver's N = 8 scaling run starts it (torch.distributed.run with eight ranks), and
+    through the self-launch path -- eight fresh processes, rendezvous, per-rank shards, the bucketed exchange between the captured
+    graphs, max-over-ranks timing, ONE line from rank 0.  With fewer than eight GPUs the ranks share the
+    visible one(s) and talk over gloo; with eight they take one each and talk over RCCL."""
+    _run_ranks(8, "both", launcher)
+
+
+def _run_ranks(world, mode, launcher):
     import torch
-    rccl = torch.cuda.device_count() >= 2
+    rccl = torch.cuda.device_count() >= world
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
@@ -37,16 +50,16 @@ def test_two_ranks_on_one_gpu(mode, launcher):
     out = None
     for attempt in range(2):        # (one retry on a rendezvous that never completes: seen once in ~10 runs on the test boxes,
         #                              where the two ranks normally need 20 s; a hang must not cost the 15-minute budget)
-        head = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+        head = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                  "127.0.0.1", "--master-port", str(_free_port())] if launcher else [sys.executable])
-        cmd = head + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+        cmd = head + [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps",
                       "3", "--warmup", "1", "--batch", "4", "--queries", "40", "--rotate", "3", "--no-cpu-baseline",
                       "--no-probes"] + (["--mode", "train"] if mode == "train" else []) + (
-                          [] if launcher else ["--launch-timeout", "280"])
+                          [] if launcher else ["--launch-timeout", "280" if world == 2 else "560"])
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
                                 start_new_session=True)                  # own process group: a timeout takes the ranks too
         try:
-            stdout, stderr = proc.communicate(timeout=300)
+            stdout, stderr = proc.communicate(timeout=300 if world == 2 else 600)
             out = subprocess.CompletedProcess(cmd, proc.returncode, stdout, stderr)
             break
         except subprocess.TimeoutExpired:
@@ -58,19 +71,19 @@ def test_two_ranks_on_one_gpu(mode, launcher):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 8
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["config"]["global_batch"] == 4 * world
     assert d["value"] > 0 and d["scaling"] == "weak" and d["train_step_ms"] > 0
-    assert len(d["train_seconds_per_rank"]) == 2 and d["train_graphs"]["captures_in_timed_region"] == 0
+    assert len(d["train_seconds_per_rank"]) == world and d["train_graphs"]["captures_in_timed_region"] == 0
     ex = d["grad_exchange_ms_per_step"]                      # the eager exchange between the captured graphs, timed per step
     assert ex["total"] >= ex["exposed"] >= 0 and ex["bytes"] > 0
     if rccl:
-        assert d["rccl_ranks"] == 2
+        assert d["rccl_ranks"] == world
         # two GPUs, RCCL: the buckets' all-reduces are launched from the backward's hooks / between the two captured halves, so
         # part of the exchange must run UNDER the backward -- the time the step waits for it is less than the exchange takes
         assert ex["exposed"] < ex["total"], ex
         for key in ("train_seconds_per_rank",) + (("eval_seconds_per_rank",) if mode == "both" else ()):
-            assert len(d[key]) == 2 and min(d[key]) > 0, (key, d[key])     # (no timing band: 3 steps on a shared box)
+            assert len(d[key]) == world and min(d[key]) > 0, (key, d[key])     # (no timing band: 3 steps on a shared box)
     else:
-        assert d["rccl_ranks"] == "2 (gloo)"
+        assert d["rccl_ranks"] == f"{world} (gloo)"
     if mode == "both":
         assert d["metric"].startswith("videos/sec") and d["eval_graphs"]["cached"] == 1

@@ -314,6 +314,41 @@ def test_anet_full_eval_error_is_at_the_fp32_noise_floor():
     print("error vs fp64 (gvl_amd, reference fp32 floor):", report)
 
 
+def test_anet_tsp_msvg_dvc_config_runs_the_headline_model():
+    """BASELINE config 4 names cfgs/anet_tsp_msvg_dvc.yml (the 8-GPU data-parallel case).  Against cfgs/anet_tsp_ssvg.yml that file
+    changes three switches of the frozen-RoBERTa text branch only (enable_layer_diff_text_feature, enable_sentence_context_modeling,
+    enable_sentence_pos_embedding: SURVEY section 2 #15, out of scope) -- on the hot path it IS the headline model: the same
+    parameters, and the reference-generated B = 16-class eval golden holds under its name, eager and through the captured forward
+    that the data-parallel eval shards use."""
+    from gvl_amd.config import make_opt
+    from gvl_amd.parallel import GraphedEvalForward, shard_batch
+    from gvl_amd.pdvc import build
+    f = load("pdvc_anet_full")
+    opt = make_opt("anet_tsp_msvg_dvc", num_queries=300, frame_embedding_num=100, device="cuda")
+    ref_opt = make_opt("anet_tsp_ssvg", num_queries=300, frame_embedding_num=100, device="cuda")
+    assert {k: v for k, v in vars(opt).items() if k != "id"} == {k: v for k, v in vars(ref_opt).items() if k != "id"}
+    model, criterion, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f, seed=100), strict=True)
+    model = model.to(DEV).eval()
+    dt = to_dev(pdvc_dt(f, feat=int(f["feature_dim"]), seed=6))
+    graphed = GraphedEvalForward(model, criterion)
+    with torch.no_grad():
+        out, _ = model(dt, criterion, None, "queries", eval_mode=True)
+        out_g, _ = graphed(dt)
+    for o in (out, out_g):
+        assert maxerr(o["pred_boxes"], f["pred_boxes"]) <= 2e-4
+        assert maxerr(o["pred_logits"], f["pred_logits"]) <= 3e-4
+        assert maxerr(o["pred_count"], f["pred_count"]) <= 3e-4
+    # the shard a rank of a 2-way data-parallel eval takes reproduces its videos' rows of the full batch
+    B = dt["video_tensor"].shape[0]
+    if B >= 2:
+        sh = shard_batch(dt, 1, 2)
+        with torch.no_grad():
+            out_s, _ = model(sh, criterion, None, "queries", eval_mode=True)
+        assert maxerr(out_s["pred_boxes"], out["pred_boxes"][1::2]) <= 2e-5
+        assert maxerr(out_s["pred_logits"], out["pred_logits"][1::2]) <= 2e-5
+
+
 def test_anet_c3d_config_eval_matches_reference():
     """BASELINE config 0 (cfgs/anet_c3d_ssvg.yml: 500-d C3D features, 30 queries) on the GPU path.  The reference runs
     this config through its CPU fallback; gvl_amd has no CPU path by design, the model is the same."""

@@ -68,6 +68,28 @@ def test_msdeformattncap_module_golden():
     assert maxerr(out, f["out"]) < 1e-4
 
 
+def test_msdeformattncap_3c_query_branch_golden():
+    """enable_pos_emb_for_captioner: the captioner's queries are [hidden | state | query_embed], 3C wide
+    (ms_deform_attn_for_caption.py:54-56) -- tests/golden/module_cap3c.npz from the reference module built with that option"""
+    import types
+    from gvl_amd.ops.modules import MSDeformAttnCap
+    dev = torch.device("cuda:0")
+    f = load("module_cap3c")
+    B, Q, C, M, L, P, _ = [int(v) for v in f["meta"]]
+    S = int(f["tshapes"].sum())
+    mod = MSDeformAttnCap(C, L, 1, P, opt=types.SimpleNamespace(enable_pos_emb_for_captioner=True))
+    assert mod.sampling_offsets.in_features == mod.attention_weights.in_features == 3 * C
+    mod.load_state_dict(strip(module_state("cap3.", C=C, M=1, qdim=3 * C, seed=210), "cap3."), strict=True)
+    mod = mod.to(dev).eval()
+    query = t(synth_array("cap3.query", (B, Q, 3 * C), 1)).to(dev)
+    inp = t(synth_array("cap3.input", (B, S, C), 1)).to(dev)
+    ref = t(synth_array("cap3.ref", (B, Q, L, 2), 1, 0.05, 0.95))
+    ref[..., 1] *= 0.5
+    with torch.no_grad():
+        out = mod(query, ref.to(dev), inp, t(f["tshapes"]).to(dev), t(f["lsi"]).to(dev), t(f["mask"]).to(dev))
+    assert tuple(out.shape) == tuple(f["out"].shape) and maxerr(out, f["out"]) < 1e-4
+
+
 def test_hand_written_projection_kernel_matches_fp64_and_library(monkeypatch):
     """gvl_proj_f32 (MSDeformAttn's offset / attention-logit projection, ms_deform_attn.py:99-100, as a hand-written fp32
     MFMA GEMM): exact-fp32 arithmetic -- its error against an fp64 product is the library's (a k-ordered fmaf chain) --
