@@ -542,6 +542,42 @@ def wgrad(dy, x, amax_dy, amax_x, grad_w=None, grad_b=None, want_bias=True, accu
     return grad_w, grad_b
 
 
+class _WgradDesc(ctypes.Structure):                  # include/gvl_msda.h: gvl_wgrad_desc
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("amax_dy", ctypes.c_void_p), ("amax_x", ctypes.c_void_p),
+                ("grad_w", ctypes.c_void_p), ("grad_b", ctypes.c_void_p), ("ld_dy", ctypes.c_int64), ("ld_x", ctypes.c_int64),
+                ("n_amax_dy", ctypes.c_int), ("n_amax_x", ctypes.c_int), ("R", ctypes.c_int), ("N", ctypes.c_int),
+                ("K", ctypes.c_int), ("accumulate", ctypes.c_int)]
+
+
+def wgrad_group_max():
+    return int(_lib.lib().gvl_wgrad_group_max())
+
+
+def wgrad_group(items):
+    """the weight / bias gradients of several Linears in ONE launch (+ one reduction): items = [(dy, x, amax_dy, amax_x, grad_w,
+    grad_b | None)], at most wgrad_group_max() of them, every operand as wgrad() takes it; grad_w / grad_b are written in place
+    (include/gvl_msda.h: gvl_wgrad_group_f16x3_f32)."""
+    n = len(items)
+    _require(0 < n <= wgrad_group_max(), "wgrad_group: 1 .. wgrad_group_max() problems")
+    arr = (_WgradDesc * n)()
+    for d, (dy, x, am_dy, am_x, gw, gb) in zip(arr, items):
+        _require(wgrad_eligible(dy, x), "wgrad_group: dy (R, N), x (R, K) fp32 CUDA matrices, unit column stride, strides % 4 == 0")
+        _require(gw.dtype == torch.float32 and gw.is_contiguous() and tuple(gw.shape) == (dy.shape[1], x.shape[1])
+                 and (gb is None or (gb.dtype == torch.float32 and gb.is_contiguous() and gb.numel() == dy.shape[1])),
+                 "wgrad_group: grad_w (N, K) / grad_b (N) must be contiguous fp32")
+        d.dy, d.x, d.amax_dy, d.amax_x = dy.data_ptr(), x.data_ptr(), am_dy.data_ptr(), am_x.data_ptr()
+        d.grad_w, d.grad_b = gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
+        d.ld_dy, d.ld_x, d.n_amax_dy, d.n_amax_x = dy.stride(0), x.stride(0), am_dy.numel(), am_x.numel()
+        d.R, d.N, d.K, d.accumulate = dy.shape[0], dy.shape[1], x.shape[1], 0
+    L = _lib.lib()
+    dev = items[0][0].device
+    nbytes = L.gvl_wgrad_group_workspace_bytes(ctypes.byref(arr), n)
+    ws = torch.empty(max(nbytes, 16) // 4, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        rc = L.gvl_wgrad_group_f16x3_f32(ctypes.byref(arr), n, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "wgrad_group_f16x3")
+
+
 def lstm_cell_train_forward(gates_a, gates_b, gates_c, c_prev, act, h_out, c_out):
     n, H = c_prev.shape
     for name, t_ in (("gates_a", gates_a), ("gates_b", gates_b), ("gates_c", gates_c)):

@@ -6,7 +6,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GVL_LIB_PATH: a dev build (gvl_amd.build.build_dev: timing / ablation variants of single kernels) instead of the shipped library
 LIB_PATH = os.environ.get("GVL_LIB_PATH") or os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 14          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 15          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -104,6 +104,9 @@ SIGNATURES = {
     "gvl_msda1d_fused_forward_bf16": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_bf16": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_wgrad_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "gvl_wgrad_group_max": (_I, []),
+    "gvl_wgrad_group_workspace_bytes": (_SZ, [_P, _I]),
+    "gvl_wgrad_group_f16x3_f32": (_I, [_P, _I, _P, _SZ, _P]),
     "gvl_wgrad_f16x3_f32": (_I, [_P, _I64, _P, _I, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _I, _P, _SZ, _P]),
     "gvl_planes_chunk_elems": (_I, []),
     "gvl_planes_refresh_f16": (_I, [_P, _P, _I, _P, _I, _P, _P]),

@@ -59,8 +59,8 @@ struct WgParams {
 #ifdef GVL_WG_STAMPS
 #define GVL_WG_STAMP(i)                                                                                         \
   if (threadIdx.x == 0) {                                                                                       \
-    p.stamps[blockIdx.x * 8 + 2 * (i)] = __builtin_amdgcn_s_memtime();                                          \
-    p.stamps[blockIdx.x * 8 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                                  \
+    p.stamps[blk * 8 + 2 * (i)] = __builtin_amdgcn_s_memtime();                                                 \
+    p.stamps[blk * 8 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                                         \
   }
 #else
 #define GVL_WG_STAMP(i)
@@ -124,16 +124,11 @@ __device__ __forceinline__ float block_max(const float *__restrict__ v, int n, f
 
 // X1 (gvl_f16_products(1): training under autocast): the leading fp16 product only -- no lo planes are formed, stored or read, one
 // MFMA per fragment pair instead of three; operands rounded to 11 significant bits at their tensor scale, fp32 accumulation.
+// one work item (row range sk, tile) of one weight gradient; `blk`: the workgroup's index for the timing stamps
 template <bool X1>
-__global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void wgrad_item(const WgParams &p, const int item, const int blk, unsigned char *smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // workgroup id -> (row range, tile): the work items in the order (row range, tile row, tile column) are cut into 8 contiguous
-  // runs, run x on XCD x (= workgroup id % 8; speed only).  Neighbours in that order read the same rows of dy and x (each tile
-  // a quarter of them at N = K = 512), so an XCD's L2 fetches them once instead of every XCD fetching everything.
-  const int tiles = p.tiles_n * p.tiles_k, total = tiles * p.SK, per = (total + 7) >> 3;
-  const int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (((int)blockIdx.x >> 3) >= per || item >= total) return;
+  const int tiles = p.tiles_n * p.tiles_k;
   const int sk = item / tiles, tile = item % tiles;
   const int tn = tile / p.tiles_k, tk = tile % p.tiles_k;
   const int n0 = tn * kWgT, k0 = tk * kWgT;
@@ -332,6 +327,71 @@ __global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p)
   GVL_WG_STAMP(3)
 }
 
+template <bool X1>
+__global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_f16x3(const WgParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // workgroup id -> (row range, tile): the work items in the order (row range, tile row, tile column) are cut into 8 contiguous
+  // runs, run x on XCD x (= workgroup id % 8; speed only).  Neighbours in that order read the same rows of dy and x (each tile
+  // a quarter of them at N = K = 512), so an XCD's L2 fetches them once instead of every XCD fetching everything.
+  const int total = p.tiles_n * p.tiles_k * p.SK, per = (total + 7) >> 3;
+  const int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per || item >= total) return;
+  wgrad_item<X1>(p, item, (int)blockIdx.x, smem);
+}
+
+// GROUPED form (round 6): the weight gradients of SEVERAL Linear layers in one launch.  Alone, a 512 x 512 gradient has 16 output
+// tiles; to cover the chip it was cut into ~15 row ranges whose partial tiles (15 MB written, 15 MB read back by k_wgrad_reduce)
+// cost as much HBM traffic as the operands, in workgroups of ten K stages each.  A backward pass owes the gradients of 5-9
+// Linears per layer at nearly the same time and none of them is on its critical path (nobody reads dW before the optimizer): taken
+// together they fill the chip with 2-4 row ranges each -- a quarter of the partial traffic, workgroups of 40-75 stages, one launch
+// and one reduction instead of a pair per Linear.  Work items of all problems form one list, cut into 8 runs for the XCDs as above.
+constexpr int kWgGroupMax = 10;
+struct WgGroup {
+  int n, total;
+  int first[kWgGroupMax + 1];            // first work item of problem i; first[n] = total
+  WgParams p[kWgGroupMax];
+};
+template <bool X1>
+__global__ void __launch_bounds__(kWgThreads, 2) k_wgrad_group_f16x3(const WgGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int per = (g.total + 7) >> 3;
+  const int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per || item >= g.total) return;
+  int i = 0;
+#pragma unroll 1
+  while (i + 1 < g.n && item >= g.first[i + 1]) ++i;
+  wgrad_item<X1>(g.p[i], item - g.first[i], (int)blockIdx.x, smem);
+}
+
+// the grouped reduction: every problem's partial slabs summed in slab order into its gradient (and bias row); thread blocks of 256
+// float4 / bias elements, `first` counts blocks
+struct WgReduceGroup {
+  int n;
+  int first[kWgGroupMax + 1];
+  struct Item { const float4 *part; float4 *grad; const float *part_b; float *grad_b; int64_t n4; int SK, N, accumulate; } r[kWgGroupMax];
+};
+__global__ void __launch_bounds__(256) k_wgrad_reduce_group(const WgReduceGroup g) {
+  int i = 0;
+#pragma unroll 1
+  while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+  const WgReduceGroup::Item &r = g.r[i];
+  const int64_t e = (int64_t)((int)blockIdx.x - g.first[i]) * 256 + threadIdx.x;
+  if (e < r.n4) {
+    float4 t = r.accumulate ? r.grad[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s_ = 0; s_ < r.SK; ++s_) {
+      const float4 u = r.part[(int64_t)s_ * r.n4 + e];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    r.grad[e] = t;
+  } else if (r.grad_b && e - r.n4 < r.N) {
+    const int64_t b = e - r.n4;
+    const int stride = (r.N + 3) & ~3;
+    float t = r.accumulate ? r.grad_b[b] : 0.f;
+    for (int s_ = 0; s_ < r.SK; ++s_) t += r.part_b[(int64_t)s_ * stride + b];
+    r.grad_b[b] = t;
+  }
+}
+
 // grad (+)= sum over the SK partial slabs, in slab order; the same for the bias row
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float4 *__restrict__ part, int64_t n4, int SK, float4 *__restrict__ grad,
                                                       const float *__restrict__ part_b, int N, float *__restrict__ grad_b,
@@ -499,6 +559,103 @@ extern "C" int gvl_planes_refresh_f16(const gvl_plane_desc *descs_device, const 
                      reinterpret_cast<const int2 *>(wg_map_device), chunk_amax_device);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, "gvl_planes_refresh_f16: launch failed: %s", hipGetErrorString(e));
+}
+
+namespace {
+// row ranges per problem of a group: about two workgroups per compute unit over the whole group, ranges of at least four stages
+WgPlan wgrad_group_plan(int R, int N, int K, int group_tiles) {
+  WgPlan pl;
+  pl.tiles_n = (N + kWgT - 1) / kWgT;
+  pl.tiles_k = (K + kWgT - 1) / kWgT;
+  const int stages = (R + kWgR - 1) / kWgR;
+  int sk = (512 + group_tiles / 2) / (group_tiles > 0 ? group_tiles : 1);
+  sk = max(1, min(sk, stages / 4));
+  const int per = (stages + sk - 1) / sk;
+  pl.rows_per_split = per * kWgR;
+  pl.SK = (stages + per - 1) / per;
+  return pl;
+}
+int wgrad_group_tiles(const gvl_wgrad_desc *d, int n) {
+  int t = 0;
+  for (int i = 0; i < n; ++i) t += ((d[i].N + kWgT - 1) / kWgT) * ((d[i].K + kWgT - 1) / kWgT);
+  return t;
+}
+size_t wgrad_part_bytes(const WgPlan &pl, int N, int K) {
+  return pl.SK == 1 ? 0 : ((size_t)pl.SK * ((size_t)N * K + ((N + 3) & ~3)) * sizeof(float) + 15) & ~(size_t)15;
+}
+}  // namespace
+
+extern "C" int gvl_wgrad_group_max(void) { return kWgGroupMax; }
+
+extern "C" size_t gvl_wgrad_group_workspace_bytes(const gvl_wgrad_desc *descs, int n) {
+  if (!descs || n <= 0 || n > kWgGroupMax) return 0;
+  const int tiles = wgrad_group_tiles(descs, n);
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += wgrad_part_bytes(wgrad_group_plan(descs[i].R, descs[i].N, descs[i].K, tiles), descs[i].N, descs[i].K);
+  return total;
+}
+
+extern "C" int gvl_wgrad_group_f16x3_f32(const gvl_wgrad_desc *descs, int n, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!descs || n <= 0 || n > kWgGroupMax) return fail(GVL_EINVAL, "gvl_wgrad_group_f16x3_f32: 1 .. %d problems (got %d)", kWgGroupMax, n);
+  const int tiles = wgrad_group_tiles(descs, n);
+  WgGroup g;
+  WgReduceGroup rg;
+  g.n = n;
+  rg.n = 0;
+  int items = 0, rblocks = 0;
+  size_t used = 0;
+  for (int i = 0; i < n; ++i) {
+    const gvl_wgrad_desc &d = descs[i];
+    if (!d.dy || !d.x || !d.amax_dy || !d.amax_x || !d.grad_w) return fail(GVL_EINVAL, "gvl_wgrad_group_f16x3_f32: null pointer (problem %d)", i);
+    if (d.R <= 0 || d.N <= 0 || d.K <= 0 || (d.K & 3) || (d.ld_dy & 3) || (d.ld_x & 3) || d.ld_dy < ((d.N + 3) & ~3) || d.ld_x < d.K ||
+        d.n_amax_dy < 1 || d.n_amax_x < 1)
+      return fail(GVL_EINVAL, "gvl_wgrad_group_f16x3_f32: problem %d: R, N, K > 0, K and both row strides multiples of 4 (R=%d N=%d K=%d)", i, d.R, d.N, d.K);
+    if ((int64_t)d.R * d.ld_dy >= ((int64_t)1 << 29) || (int64_t)d.R * d.ld_x >= ((int64_t)1 << 29))
+      return fail(GVL_EINVAL, "gvl_wgrad_group_f16x3_f32: operands of 2 GB or more are not addressed (32-bit buffer offsets)");
+    if (((uintptr_t)d.dy | (uintptr_t)d.x | (uintptr_t)d.grad_w | (uintptr_t)d.grad_b | (uintptr_t)workspace) & 15)
+      return fail(GVL_EINVAL, "gvl_wgrad_group_f16x3_f32: pointers must be 16-byte aligned");
+    const WgPlan pl = wgrad_group_plan(d.R, d.N, d.K, tiles);
+    WgParams &p = g.p[i];
+    p.dy = d.dy; p.x = d.x; p.ld_dy = d.ld_dy; p.ld_x = d.ld_x;
+    p.amax_dy = d.amax_dy; p.amax_x = d.amax_x; p.n_amax_dy = d.n_amax_dy; p.n_amax_x = d.n_amax_x;
+    p.R = d.R; p.N = d.N; p.K = d.K; p.tiles_n = pl.tiles_n; p.tiles_k = pl.tiles_k; p.SK = pl.SK; p.rows_per_split = pl.rows_per_split;
+    p.accumulate = d.accumulate;
+#ifdef GVL_WG_STAMPS
+    p.stamps = g_wg_stamps;
+#endif
+    if (pl.SK == 1) {
+      p.part = d.grad_w;
+      p.part_b = d.grad_b;
+    } else {
+      const size_t need = wgrad_part_bytes(pl, d.N, d.K);
+      if (!workspace || used + need > workspace_bytes) return fail(GVL_ENOSPC, "gvl_wgrad_group_f16x3_f32: workspace of %zu bytes needed", gvl_wgrad_group_workspace_bytes(descs, n));
+      p.part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + used);
+      p.part_b = d.grad_b ? p.part + (size_t)pl.SK * d.N * d.K : nullptr;
+      used += need;
+      WgReduceGroup::Item &r = rg.r[rg.n];
+      r.part = reinterpret_cast<const float4 *>(p.part); r.grad = reinterpret_cast<float4 *>(d.grad_w);
+      r.part_b = p.part_b; r.grad_b = d.grad_b; r.n4 = (int64_t)d.N * d.K / 4; r.SK = pl.SK; r.N = d.N; r.accumulate = d.accumulate;
+      rg.first[rg.n++] = rblocks;
+      rblocks += (int)((r.n4 + (d.grad_b ? d.N : 0) + 255) / 256);
+    }
+    g.first[i] = items;
+    items += pl.tiles_n * pl.tiles_k * pl.SK;
+  }
+  g.first[n] = g.total = items;
+  rg.first[rg.n] = rblocks;
+  hipStream_t st = (hipStream_t)stream;
+  const bool x1 = gvl16::g_f16_products == 1;
+  auto kern = x1 ? k_wgrad_group_f16x3<true> : k_wgrad_group_f16x3<false>;
+  if (int rc = gvl::ensure_lds(kern, kWgLds)) return rc;
+  if (int rc = gvl::launch(GVL_PROF_WGRAD, n, items, x1 ? "k_wgrad_group_f16x1" : "k_wgrad_group_f16x3", kern, dim3(8 * ((items + 7) / 8)),
+                           dim3(kWgThreads), kWgLds, st, g))
+    return rc;
+  if (rg.n > 0) {
+    hipLaunchKernelGGL(k_wgrad_reduce_group, dim3((unsigned)rblocks), dim3(256), 0, st, rg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "gvl_wgrad_group_f16x3_f32: reduce launch failed: %s", hipGetErrorString(e));
+  }
+  return 0;
 }
 
 extern "C" size_t gvl_wgrad_workspace_bytes(int R, int N, int K) {

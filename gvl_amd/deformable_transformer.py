@@ -246,6 +246,14 @@ class DeformableTransformer(nn.Module):
         self.pos_trans_norm = nn.LayerNorm(d_model * 2)
         self.reference_points = nn.Linear(d_model, 1)
         self._reset_parameters()
+        # the layers' Linears own their weights alone (a layer runs once per step, nothing is tied into it): their weight
+        # gradients may wait for the backward pass's grouped launches (gvl_amd/linear.py: _WgradQueue)
+        for layer in list(self.encoder.layers) + list(self.decoder.layers):
+            for m in layer.modules():
+                if isinstance(m, (Linear, MSDeformAttn)):
+                    m.defer_wgrad = True
+                elif isinstance(m, nn.MultiheadAttention):
+                    m.__dict__["_gvl_defer_wgrad"] = True
 
     def _reset_parameters(self):
         """:54-63 (same order of RNG consumption): xavier every matrix, then the MSDeformAttn-specific init."""

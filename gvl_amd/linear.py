@@ -210,6 +210,73 @@ def set_active_planes(planes):
     return prev
 
 
+class _WgradQueue:
+    """Weight gradients of the layers' Linears, owed during one backward pass and taken TOGETHER (gvl_wgrad_group_f16x3_f32: up to
+    ten gradients per launch -- 52 against 120 us for an encoder layer's five, 130 against 216 us for a decoder layer's eight,
+    tools/wgrad_group_probe.py).  Nobody reads dW before the optimizer, so a Linear's backward hands autograd the (still unwritten)
+    gradient tensors and the products run when the group is full or the pass ends.  What makes that safe:
+      * only Linears that own their weight alone are queued (`defer`: the encoder / decoder layers'); and should a parameter
+        get a second gradient in the same pass after all, autograd would ADD the two the moment the second is returned -- the
+        queue is flushed and that product taken at once;
+      * a parameter whose .grad already exists (gradient accumulation, the data-parallel flat buffer) is never queued:
+        AccumulateGrad reads the new gradient immediately;
+      * the queue keeps detached aliases: autograd finds the returned tensor unshared and adopts it without a copy."""
+
+    def __init__(self):
+        self.items, self.seen = [], set()
+
+    def push(self, dy, x, am_dy, am_x, want_bias, keys):
+        gw = torch.empty(dy.shape[1], x.shape[1], device=dy.device, dtype=torch.float32)
+        gb = torch.empty(dy.shape[1], device=dy.device, dtype=torch.float32) if want_bias else None
+        if any(k in self.seen for k in keys):
+            self.flush()
+            MSDA.wgrad(dy, x, am_dy, am_x, grad_w=gw, grad_b=gb, want_bias=want_bias)
+            return gw, gb
+        self.seen.update(keys)
+        self.items.append((dy, x, am_dy, am_x, gw.detach(), gb.detach() if gb is not None else None))
+        if len(self.items) >= MSDA.wgrad_group_max():
+            self.flush()
+        return gw, gb
+
+    def flush(self):
+        items, self.items = self.items, []
+        if len(items) == 1:
+            dy, x, am_dy, am_x, gw, gb = items[0]
+            MSDA.wgrad(dy, x, am_dy, am_x, grad_w=gw, grad_b=gb, want_bias=gb is not None)
+        elif items:
+            MSDA.wgrad_group(items)
+
+
+_WGRAD_QUEUE = None
+_DEFER_WGRAD = os.environ.get("GVL_WGRAD_GROUP", "") != "0"
+
+
+class deferred_wgrads:
+    """``with deferred_wgrads(): loss.backward()`` -- the layers' weight gradients of this backward pass in grouped launches
+    (see _WgradQueue); flushed on exit.  GVL_WGRAD_GROUP=0: one launch pair per Linear, as in round 5 (A/B switch)."""
+
+    def __enter__(self):
+        global _WGRAD_QUEUE
+        self.prev = _WGRAD_QUEUE
+        _WGRAD_QUEUE = _WgradQueue() if _DEFER_WGRAD else None
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _WGRAD_QUEUE
+        q, _WGRAD_QUEUE = _WGRAD_QUEUE, self.prev
+        if q is not None and exc_type is None:
+            q.flush()
+        return False
+
+
+def queued_wgrad(dy, x, am_dy, am_x, want_bias, params, defer):
+    """(grad_w, grad_b) of one Linear: through the active queue when `defer` and every parameter's .grad is still None, else now"""
+    q = _WGRAD_QUEUE
+    if defer and q is not None and all(p_ is None or p_.grad is None for p_ in params):
+        return q.push(dy, x, am_dy, am_x, want_bias, [id(p_) for p_ in params if p_ is not None])
+    return MSDA.wgrad(dy, x, am_dy, am_x, want_bias=want_bias)
+
+
 def _operands(weights, biases):
     """(forward operand, transposed operand) of the stacked weight"""
     from .train_planes import Operand
@@ -249,9 +316,10 @@ def _row_amax(t2, src=None):
 @MSDA.keeps_products
 class _TrainLinearFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, nblk, *params):
+    def forward(ctx, x, nblk, defer, *params):
         from . import layers as L
         weights, biases = params[:nblk], params[nblk:]
+        ctx.defer = bool(defer)
         K = weights[0].shape[1]
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
@@ -263,6 +331,7 @@ class _TrainLinearFunction(torch.autograd.Function):
         ctx.save_for_backward(x2, am, *weights)
         ctx.op_t, ctx.nblk, ctx.x_shape = op_t, nblk, x.shape
         ctx.has_bias = [b is not None for b in biases]
+        ctx.bias_params = tuple(biases)                       # (identity only: which parameters this node's gradients go to)
         return out.view(*x.shape[:-1], op.N)
 
     @staticmethod
@@ -282,20 +351,20 @@ class _TrainLinearFunction(torch.autograd.Function):
             gx = torch.empty(x2.shape[0], op_t.N, device=g2.device, dtype=torch.float32)
             L.linear(g2, op_t, [L.seg(0, gx, am_g)])
             gx = gx.view(ctx.x_shape)
-        need_w = any(ctx.needs_input_grad[2:2 + nblk])
-        need_b = any(n and h for n, h in zip(ctx.needs_input_grad[2 + nblk:], ctx.has_bias))
+        need_w = any(ctx.needs_input_grad[3:3 + nblk])
+        need_b = any(n and h for n, h in zip(ctx.needs_input_grad[3 + nblk:], ctx.has_bias))
         gws, gbs = [None] * nblk, [None] * nblk
         if need_w or need_b:
-            gw, gb = MSDA.wgrad(g2, x2, am_g, am_x, want_bias=need_b)
+            gw, gb = queued_wgrad(g2, x2, am_g, am_x, need_b, tuple(weights) + tuple(ctx.bias_params), ctx.defer)
             off = 0
             for i, w in enumerate(weights):
                 n = w.shape[0]
-                if ctx.needs_input_grad[2 + i]:
+                if ctx.needs_input_grad[3 + i]:
                     gws[i] = gw[off:off + n]
-                if ctx.has_bias[i] and ctx.needs_input_grad[2 + nblk + i]:
+                if ctx.has_bias[i] and ctx.needs_input_grad[3 + nblk + i]:
                     gbs[i] = gb[off:off + n]
                 off += n
-        return (gx, None, *gws, *gbs)
+        return (gx, None, None, *gws, *gbs)
 
 
 def train_linear_eligible(x, weights, biases):
@@ -316,15 +385,16 @@ def train_linear_eligible(x, weights, biases):
     return x.requires_grad or any(w.requires_grad for w in weights) or any(b is not None and b.requires_grad for b in biases)
 
 
-def train_linear(x, weights, biases):
+def train_linear(x, weights, biases, defer=False):
     """x (..., K) -> x [W_0; W_1; ..]^T + [b_0; ..]  (..., sum N_i) through the hand-written kernels, differentiable in x, every
-    W_i and every b_i; callers check train_linear_eligible first"""
-    return _TrainLinearFunction.apply(x, len(weights), *weights, *biases)
+    W_i and every b_i; callers check train_linear_eligible first.  defer: the weight / bias gradients may join the backward
+    pass's grouped launches (_WgradQueue: only for parameters no other node of the step uses)."""
+    return _TrainLinearFunction.apply(x, len(weights), defer, *weights, *biases)
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, defer=False):
     if train_linear_eligible(x, (weight,), (bias,)):
-        return train_linear(x, (weight,), (bias,))
+        return train_linear(x, (weight,), (bias,), defer)
     if (bias is None or not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32
             or bias.dtype != torch.float32 or torch.is_autocast_enabled()
             or not torch.is_grad_enabled() or not bias.requires_grad):
@@ -335,5 +405,7 @@ def linear(x, weight, bias=None):
 class Linear(nn.Linear):
     """Drop-in nn.Linear (same parameters, same state_dict keys)."""
 
+    defer_wgrad = False      # set by the owner of a Linear that nothing else in the step uses (DeformableTransformer's layers)
+
     def forward(self, input):                                             # noqa: A002
-        return linear(input, self.weight, self.bias)
+        return linear(input, self.weight, self.bias, self.defer_wgrad)

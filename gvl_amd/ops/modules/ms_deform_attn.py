@@ -138,7 +138,7 @@ class MSDeformAttn(nn.Module):
         if train_linear_eligible(q, ws, bs):
             # training: both projections as ONE hand-written product over the stacked weight (no torch.cat of the parameters:
             # the planes of the stack come from the model's TrainPlanes), dx / dW / db from the hand-written backward kernels
-            proj = train_linear(q, ws, bs)
+            proj = train_linear(q, ws, bs, getattr(self, "defer_wgrad", False))
         else:
             w_cat, b_cat = self._cat_projection()
             proj = projection(q, w_cat, b_cat)

@@ -20,6 +20,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from .linear import deferred_wgrads
 from .optim import bump_versions
 from .targets import PaddedTargets, needed_capacity, round_up_pow2, total_events
 
@@ -261,7 +262,8 @@ class TrainStep:
     def __call__(self, dt):
         self.buckets.zero()                                                    # optimizer.zero_grad(), flat
         final, loss = self._forward_loss(dt)
-        final.backward()
+        with deferred_wgrads():                                                # (the layers' weight gradients in grouped launches)
+            final.backward()
         self.buckets.finish()
         hidden = [(p, p.grad) for p in self.buckets.unused_params()]
         for p, _ in hidden:
@@ -507,14 +509,16 @@ class GraphedTrainStep(TrainStep):
             final, loss = self._forward_loss(dt)
         finally:
             self.model.memory_cut = None
-        final.backward()
+        with deferred_wgrads():
+            final.backward()
         self._cut = cut
         return final.detach(), _detached(loss)
 
     def _backward_encoder(self):
         """stage 2: the gradient of the encoder output through the deformable encoder and the base encoder"""
         if self.two_stage and self._cut:
-            self._cut["src"].backward(self._cut["leaf"].grad)
+            with deferred_wgrads():
+                self._cut["src"].backward(self._cut["leaf"].grad)
         self._cut = None
 
     def _update(self, unused=()):

@@ -46,7 +46,8 @@ class _InProj(torch.autograd.Function):
     """qkv = [ (x + pos) W_qk^T | x W_v^T ] + b   ->  (qkv (R, 3C), row maxima of the q | k columns, of the v columns)"""
 
     @staticmethod
-    def forward(ctx, x, pos, xq, weight, bias):
+    def forward(ctx, x, pos, xq, weight, bias, defer=False):
+        ctx.defer, ctx.params = bool(defer), (weight, bias)
         # x (B, Q, C) contiguous; pos (Q, C) (row stride arbitrary); xq = x + pos as a tensor (the weight gradient's operand)
         B, Q, C = x.shape
         R = B * Q
@@ -79,11 +80,29 @@ class _InProj(torch.autograd.Function):
         dxv = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
         L.linear(g_qk, Operand(_Sub(op_t.planes, 0, cut), C, 2 * C, None), [L.seg(0, dxq, am_gqk)])
         L.linear(g_v, Operand(_Sub(op_t.planes, cut, 3 * C // 32), C, C, None), [L.seg(0, dxv, am_gv)])
+        q = GL._WGRAD_QUEUE
+        if ctx.defer and q is not None and all(p_.grad is None for p_ in ctx.params):
+            # the two halves as ONE queued problem each would return two tensors per parameter; instead: one (3C, C) gradient whose
+            # row blocks are two entries of the queue (filled when the group runs)
+            gw = torch.empty(3 * C, C, device=dqkv.device, dtype=torch.float32)
+            gb = torch.empty(3 * C, device=dqkv.device, dtype=torch.float32)
+            gwd, gbd = gw.detach(), gb.detach()
+            if any(id(p_) in q.seen for p_ in ctx.params):
+                q.flush()
+                MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gwd[:2 * C], grad_b=gbd[:2 * C])
+                MSDA.wgrad(g_v, x2, am_gv, am_v, grad_w=gwd[2 * C:], grad_b=gbd[2 * C:])
+            else:
+                q.seen.update(id(p_) for p_ in ctx.params)
+                if len(q.items) + 2 > MSDA.wgrad_group_max():
+                    q.flush()
+                q.items.append((g_qk, xq2, am_gqk, am_qk, gwd[:2 * C], gbd[:2 * C]))
+                q.items.append((g_v, x2, am_gv, am_v, gwd[2 * C:], gbd[2 * C:]))
+            return dxv.view(B, Q, C), None, dxq.view(B, Q, C), gw, gb, None
         gw = torch.empty(3 * C, C, device=dqkv.device, dtype=torch.float32)
         gb = torch.empty(3 * C, device=dqkv.device, dtype=torch.float32)
         MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gw[:2 * C], grad_b=gb[:2 * C])
         MSDA.wgrad(g_v, x2, am_gv, am_v, grad_w=gw[2 * C:], grad_b=gb[2 * C:])
-        return dxv.view(B, Q, C), None, dxq.view(B, Q, C), gw, gb
+        return dxv.view(B, Q, C), None, dxq.view(B, Q, C), gw, gb, None
 
 
 class _Core(torch.autograd.Function):
@@ -144,7 +163,8 @@ def self_attention(mha, tgt, query_pos, query_mask):
     L_ = L
     if L_.amax_of(x, B * Q) is None and L_.amax_of(tgt, B * Q) is not None:
         L_.tag_amax(x, L_.amax_of(tgt, B * Q))
-    qkv, am = _InProj.apply(x, query_pos[0], xq, mha.in_proj_weight, mha.in_proj_bias)
+    defer = bool(mha.__dict__.get("_gvl_defer_wgrad", False))
+    qkv, am = _InProj.apply(x, query_pos[0], xq, mha.in_proj_weight, mha.in_proj_bias, defer)
     keep = query_mask.to(torch.uint8).contiguous() if query_mask is not None else None
     p = mha.dropout if mha.training else 0.0
     site = mha.__dict__.get("_gvl_site_drop")
@@ -153,5 +173,5 @@ def self_attention(mha, tgt, query_pos, query_mask):
     o = _Core.apply(qkv, am, keep, B, Q, mha.num_heads, p, TL._site_seed(site), TL.step_counter(tgt.device) if p > 0 else None)
     ob = mha.out_proj.bias
     if GL.train_linear_eligible(o, (mha.out_proj.weight,), (ob,)):
-        return GL.train_linear(o, (mha.out_proj.weight,), (ob,)).view(B, Q, C)
+        return GL.train_linear(o, (mha.out_proj.weight,), (ob,), defer).view(B, Q, C)
     return torch.nn.functional.linear(o, mha.out_proj.weight, ob).view(B, Q, C)

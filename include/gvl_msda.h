@@ -48,8 +48,10 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 14
+#define GVL_MSDA_ABI_VERSION 15
 /* ABI history (newest first):
+ * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
+ *      in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
  *      step pointer: torch.optim.Adam counts steps per parameter; max_norm is passed straight to clip_grad_norm_'s
  *      formula (0 scales the gradients to 0, as torch does)
@@ -729,6 +731,21 @@ int gvl_lsap_batch_device_f32(const float *C, const int64_t *problems, int n_pro
  *    workspace: gvl_wgrad_workspace_bytes(R, N, K) bytes (split-K partial tiles, summed in a fixed order: deterministic).
  *    |error| <= 2^-22 sum_r |dy||x| + R 2^-36 max|dy| max|x|. */
 size_t gvl_wgrad_workspace_bytes(int R, int N, int K);
+/*    GROUPED (ABI 15): the same gradients for up to gvl_wgrad_group_max() Linears in ONE launch (+ one reduction): the 5-9 weight
+ *    gradients a layer's backward owes at nearly the same time, none of them on the backward's critical path.  Together they
+ *    cover the chip with 2-4 row ranges each instead of ~15 -- a quarter of the split-K partial traffic, one launch pair instead
+ *    of one per Linear.  descs: HOST array (the fields of gvl_wgrad_f16x3_f32's arguments per problem); workspace:
+ *    gvl_wgrad_group_workspace_bytes(descs, n) bytes, 16-byte aligned.  Results equal the single form's to summation order
+ *    (other row ranges); deterministic. */
+typedef struct gvl_wgrad_desc {
+  const float *dy, *x, *amax_dy, *amax_x;
+  float *grad_w, *grad_b;
+  int64_t ld_dy, ld_x;
+  int n_amax_dy, n_amax_x, R, N, K, accumulate;
+} gvl_wgrad_desc;
+int gvl_wgrad_group_max(void);
+size_t gvl_wgrad_group_workspace_bytes(const gvl_wgrad_desc *descs, int n);
+int gvl_wgrad_group_f16x3_f32(const gvl_wgrad_desc *descs, int n, void *workspace, size_t workspace_bytes, void *stream);
 int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *amax_dy, int n_amax_dy, const float *x, int64_t ld_x,
                         const float *amax_x, int n_amax_x, int R, int N, int K, float *grad_w, float *grad_b, int accumulate,
                         void *workspace, size_t workspace_bytes, void *stream);

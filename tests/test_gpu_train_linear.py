@@ -174,3 +174,66 @@ def test_split_k_product_for_a_long_contraction_and_the_vocabulary_planes():
     ref = g.double() @ w.double()
     assert _err(out, ref) <= max(1.5 * _err(g @ w, ref), 5e-7)
     assert torch.equal(out, L.linear_splitk(buf, am, Operand(tr, K, ld, None)))          # fixed summation order
+
+
+def test_grouped_weight_gradients_equal_the_single_launches():
+    """gvl_wgrad_group_f16x3_f32 against one gvl_wgrad_f16x3_f32 per problem: ragged rows, N not a multiple of the tile, a problem
+    without bias, K = 1536 -- the same sums over other row ranges (<= 1e-6 of the largest element), and against float64"""
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd import layers as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    probs = [(4800, 512, 512, True), (4800, 256, 512, True), (3008, 512, 512, False), (777, 96, 1536, True), (4800, 1024, 512, True),
+             (130, 512, 64, True)]
+    items, singles = [], []
+    for R, N, K, bias in probs:
+        dy = torch.randn(R, N, device=dev, generator=g) * 0.3
+        x = torch.randn(R, K, device=dev, generator=g)
+        am_dy, am_x = L.row_absmax(dy)[0], L.row_absmax(x)[0]
+        items.append((dy, x, am_dy, am_x, torch.full((N, K), 7.0, device=dev), torch.full((N,), 7.0, device=dev) if bias else None))
+        singles.append(MSDA.wgrad(dy, x, am_dy, am_x, want_bias=bias))
+    MSDA.wgrad_group(items)
+    for (dy, x, _, _, gw, gb), (sw, sb) in zip(items, singles):
+        ref = dy.double().t() @ x.double()
+        assert float((gw - sw).abs().max()) <= 1e-6 * float(sw.abs().max())
+        assert float((gw.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        if gb is not None:
+            assert float((gb - sb).abs().max()) <= 1e-6 * float(sb.abs().max())
+            assert float((gb.double() - dy.double().sum(0)).abs().max()) <= 2e-6 * float(dy.double().sum(0).abs().max())
+        else:
+            assert sb is None
+
+
+def test_deferred_weight_gradients_of_a_train_step_equal_the_immediate_ones():
+    """the layers' weight gradients taken in grouped launches when the backward pass ends (gvl_amd.linear.deferred_wgrads, what
+    TrainStep does) against one launch pair per Linear inside each node's backward: every parameter's gradient equal to summation
+    order, fewer weight-gradient launches, and a parameter used TWICE in the step (tied heads) still gets the sum of both."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import load, path_census
+    from test_gpu_full_dims import build_anet, train_batch
+    from gvl_amd import linear as GL
+    kw = dict(transformer_dropout_prob=0.0, drop_prob=0.0)
+    f, opt, model, crit = build_anet(True, **kw)
+    dt = train_batch(f, load("pdvc_anet_full_train"))
+    wd = crit.weight_dict
+
+    def step(deferred):
+        model.zero_grad(set_to_none=True)
+        out, loss = model(dt, crit, None, "queries")
+        final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+        if deferred:
+            with GL.deferred_wgrads():
+                final.backward()
+        else:
+            final.backward()
+        return {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
+    ga, tags_a = path_census(lambda: step(False))
+    gb, tags_b = path_census(lambda: step(True))
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        tol = 2e-6 * max(1e-6, float(ga[n].abs().max()))
+        assert float((ga[n] - gb[n]).abs().max()) <= tol, (n, float((ga[n] - gb[n]).abs().max()), tol)
+    wg = [k for k in tags_a if "wgrad" in k]
+    assert wg and sum(tags_b[k] for k in wg) <= sum(tags_a[k] for k in wg) - 10, (tags_a, tags_b)

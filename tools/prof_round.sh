@@ -1,8 +1,8 @@
 #!/bin/bash
-# the round's profile set -> gpurun_out/r05p/ (copied into profiles/ afterwards): kernel stats + ordered per-step timelines of
+# the round's profile set -> gpurun_out/r06p/ (copied into profiles/ afterwards): kernel stats + ordered per-step timelines of
 # the train and eval steps from rocprofv3 kernel traces of `bench.py`, the MSDA launches inside the replayed graphs
 root=${GRAFT_REPO_ROOT:-/root/repo}
-out=$root/gpurun_out/r05p; mkdir -p $out
+out=$root/gpurun_out/r06p; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pe /tmp/pt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python3 $root/bench.py --mode train --no-cpu-baseline --no-probes --steps 20 --warmup 5 > $out/train_bench_line_under_rocprof.json 2> $out/train.err
