@@ -687,3 +687,79 @@ extern "C" int gvl_ce_rows_backward_f32(float *logits, int64_t ld, int R, int V,
   return gvl::launch(GVL_PROF_CRITERION, R, V, "k_ce_rows_bwd", k_ce_rows_bwd, dim3(R), dim3(kCeThreads), 0,
                      (hipStream_t)stream, logits, ld, V, target, weight, grad_out, lse, amax);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TRAINING: the compact (query, caption) pair rows of the captioner on padded targets (gvl_amd/pdvc.py:
+// caption_prediction_layers_padded; pdvc.py:540-573 of the reference gathers the matched queries' hidden states and captions
+// per layer).  Row r of layer k is the r-th matched pair in (video, slot) order: its video from the per-video pair counts, its
+// slot, the matched query and target of that layer, the caption row and its mask -- ~45 index operations of a few hundred
+// elements each as PyTorch ops (cumsum, searchsorted, gathers, cats, clamps, where, repeats), one launch here.
+namespace {
+constexpr int kCapRowLayers = 8;
+struct CapRowsParams {
+  const int64_t *pair_count;             // (N) matched pairs per video
+  const int64_t *q[kCapRowLayers];       // per layer: (N * G1) matched query of (video, slot)
+  const int64_t *t[kCapRowLayers];       //            (N * G1) matched video-local target
+  const int64_t *cap_tensor;             // (N, slots, cap_len)
+  const float *cap_mask;                 // (N, slots, cap_len)
+  int nl, N, G1, R, Nq, slots, cap_len;
+  int64_t *flat, *row_video, *seq;       // (nl * R), (nl * R), (nl * R, cap_len)
+  float *mask, *denom;                   // (nl * R, cap_len), (1): N * max(1, max pair count)
+};
+__global__ void __launch_bounds__(256) k_caption_rows(const CapRowsParams p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    int64_t mx = 1;
+    for (int v = 0; v < p.N; ++v) mx = p.pair_count[v] > mx ? p.pair_count[v] : mx;
+    *p.denom = (float)((int64_t)p.N * mx);
+  }
+  if (i >= p.nl * p.R) return;
+  const int k = i / p.R, r = i % p.R;
+  // the video of the r-th pair: the first v whose inclusive pair count exceeds r (searchsorted(right = True))
+  int64_t incl = 0, before = 0;
+  int v = 0;
+  for (; v < p.N; ++v) {
+    before = incl;
+    incl += p.pair_count[v];
+    if (incl > r) break;
+  }
+  const bool used = v < p.N;
+  if (!used) { v = p.N - 1; before = incl - p.pair_count[v]; }
+  int64_t slot = r - before;
+  slot = slot < 0 ? 0 : (slot > p.G1 - 1 ? p.G1 - 1 : slot);
+  const int64_t e = (int64_t)v * p.G1 + slot;
+  int64_t q = p.q[k][e], t = p.t[k][e];
+  q = q < 0 ? 0 : q;
+  t = t < 0 ? 0 : t;
+  p.flat[i] = ((int64_t)k * p.N + v) * p.Nq + q;
+  p.row_video[i] = used ? v : -1;
+  const int64_t src = ((int64_t)v * p.slots + t) * p.cap_len;
+  for (int c = 0; c < p.cap_len; ++c) {
+    p.seq[(int64_t)i * p.cap_len + c] = used ? p.cap_tensor[src + c] : 0;
+    p.mask[(int64_t)i * p.cap_len + c] = used ? p.cap_mask[src + c] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int gvl_caption_rows(const int64_t *pair_count, const int64_t *const *q_layers, const int64_t *const *t_layers, int n_layers,
+                                int N, int G1, int R, int Nq, int slots, int cap_len, const int64_t *cap_tensor, const float *cap_mask,
+                                int64_t *flat, int64_t *row_video, int64_t *seq, float *mask, float *denom, void *stream) {
+  if (!pair_count || !q_layers || !t_layers || !cap_tensor || !cap_mask || !flat || !row_video || !seq || !mask || !denom)
+    return gvl::fail(GVL_EINVAL, "gvl_caption_rows: null pointer");
+  if (n_layers < 1 || n_layers > kCapRowLayers || N < 1 || G1 < 1 || R < 1 || Nq < 1 || slots < 1 || cap_len < 1)
+    return gvl::fail(GVL_EINVAL, "gvl_caption_rows: 1 .. %d layers, positive sizes (got layers=%d N=%d G1=%d R=%d)", kCapRowLayers, n_layers, N, G1, R);
+  CapRowsParams p;
+  p.pair_count = pair_count;
+  for (int k = 0; k < n_layers; ++k) {
+    if (!q_layers[k] || !t_layers[k]) return gvl::fail(GVL_EINVAL, "gvl_caption_rows: null match array (layer %d)", k);
+    p.q[k] = q_layers[k];
+    p.t[k] = t_layers[k];
+  }
+  p.cap_tensor = cap_tensor; p.cap_mask = cap_mask;
+  p.nl = n_layers; p.N = N; p.G1 = G1; p.R = R; p.Nq = Nq; p.slots = slots; p.cap_len = cap_len;
+  p.flat = flat; p.row_video = row_video; p.seq = seq; p.mask = mask; p.denom = denom;
+  hipLaunchKernelGGL(k_caption_rows, dim3((unsigned)((n_layers * R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : gvl::fail((int)e, "gvl_caption_rows: launch failed: %s", hipGetErrorString(e));
+}
+

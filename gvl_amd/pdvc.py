@@ -516,32 +516,56 @@ class PDVC(nn.Module):
                                        torch.arange(nl, dtype=torch.int64, device=dev).repeat_interleave(R))
         r, lay = consts
         n1 = plan.pair_count
-        incl = n1.cumsum(0)
-        v = torch.searchsorted(incl, r, right=True)                     # video of the r-th pair
-        used = v < N_
-        v = v.clamp(max=N_ - 1)
-        e = v * G1 + (r - (incl - n1)[v]).clamp(min=0, max=G1 - 1)      # its slot in the padded match layout
-        q_all = torch.cat([m.q[e] for m in matches]).clamp(min=0)
-        t_all = torch.cat([m.t[e] for m in matches]).clamp(min=0)
-        v_all, used_all = v.repeat(nl), used.repeat(nl)
-        row_video = torch.where(used_all, v_all, torch.full_like(v_all, -1))
         hs_stack = torch.stack(hs_layers)
         ref_stack = torch.stack([r_ if r_.shape[-1] == 2 else torch.cat([r_, torch.full_like(r_, -1.0)], -1)
                                  for r_ in ref_layers])
+        import os
+        rows_kernel = (os.environ.get("GVL_CAPTION_ROWS", "") != "torch" and dev.type == "cuda" and nl <= 8 and pt.cap_mask.dtype == torch.float32 and n1.dtype == torch.int64
+                       and all(m.q.dtype == torch.int64 and m.q.is_contiguous() and m.t.is_contiguous() for m in matches))
+        if rows_kernel:
+            # the pair rows -- video, slot, matched query / target, caption row and mask of every (layer, r) -- in ONE launch
+            # (gvl_caption_rows) instead of the ~45 small index operations of the formulation below
+            import ctypes
+            from . import _lib
+            cl = pt.cap_len
+            flat = torch.empty(nl * R, dtype=torch.int64, device=dev)
+            row_video = torch.empty(nl * R, dtype=torch.int64, device=dev)
+            seq_flat = torch.empty(nl * R, cl, dtype=torch.int64, device=dev)
+            mask_flat = torch.empty(nl * R, cl, dtype=torch.float32, device=dev)
+            denom = torch.empty(1, dtype=torch.float32, device=dev)
+            qs = (ctypes.c_void_p * nl)(*[m.q.data_ptr() for m in matches])
+            ts = (ctypes.c_void_p * nl)(*[m.t.data_ptr() for m in matches])
+            n1c, ct, cm = n1.contiguous(), pt.cap_tensor.contiguous(), pt.cap_mask.contiguous()
+            with torch.cuda.device(dev):
+                rc = _lib.lib().gvl_caption_rows(n1c.data_ptr(), qs, ts, nl, N_, G1, R, N_q, pt.slots, cl, ct.data_ptr(), cm.data_ptr(),
+                                                 flat.data_ptr(), row_video.data_ptr(), seq_flat.data_ptr(), mask_flat.data_ptr(),
+                                                 denom.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "caption_rows")
+        else:
+            incl = n1.cumsum(0)
+            v = torch.searchsorted(incl, r, right=True)                     # video of the r-th pair
+            used = v < N_
+            v = v.clamp(max=N_ - 1)
+            e = v * G1 + (r - (incl - n1)[v]).clamp(min=0, max=G1 - 1)      # its slot in the padded match layout
+            q_all = torch.cat([m.q[e] for m in matches]).clamp(min=0)
+            t_all = torch.cat([m.t[e] for m in matches]).clamp(min=0)
+            v_all, used_all = v.repeat(nl), used.repeat(nl)
+            row_video = torch.where(used_all, v_all, torch.full_like(v_all, -1))
+            flat = (lay * N_ + v_all) * N_q + q_all
+            seq_flat = pt.cap_tensor[v_all, t_all] * used_all[:, None]
+            mask_flat = pt.cap_mask[v_all, t_all] * used_all[:, None]
+            denom = N_ * n1.max().clamp(min=1)
         # index_select on the flattened (layer, video, query) axis: its backward is an atomic index_add.  Advanced
         # indexing (hs_stack[lay, vid, q]) differentiates into index_put_(accumulate=True), a rocPRIM radix sort -- the
         # same sort inside nn.Embedding's backward faulted when replayed from a hipGraph on MI355X / ROCm 7.2
-        flat = (lay * N_ + v_all) * N_q + q_all
         hs_m = hs_stack.view(-1, C).index_select(0, flat)
         ref_m = ref_stack.view(-1, 2).index_select(0, flat)
-        seq_flat = pt.cap_tensor[v_all, t_all] * used_all[:, None]
-        mask_flat = pt.cap_mask[v_all, t_all] * used_all[:, None]
         cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=pt.cap_len - 1, row_video=row_video,
                             nll=(seq_flat[:, 1:], mask_flat[:, 1:]))
         row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
         # (a batch without a single event: every row is masked, the sum is exactly 0 -- 0 / 1, not 0 / 0: a NaN here would
         #  flow through clip_grad_norm_ into the captured Adam and poison parameters and moments for good)
-        per_layer = row_loss.view(nl, R).sum(dim=1) / (N_ * n1.max().clamp(min=1))
+        per_layer = row_loss.view(nl, R).sum(dim=1) / denom
         return per_layer.unbind(0), {}, pt.cap_tensor[plan.vid_of_entry, matches[-1].t.clamp(min=0)]
 
     def caption_prediction_layers(self, cap_head, dt, hs_layers, ref_layers, others, matches):

@@ -51,7 +51,7 @@ extern "C" {
 #define GVL_MSDA_ABI_VERSION 15
 /* ABI history (newest first):
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
- *      in one launch)
+ *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
  *      step pointer: torch.optim.Adam counts steps per parameter; max_norm is passed straight to clip_grad_norm_'s
  *      formula (0 scales the gradients to 0, as torch does)
@@ -718,6 +718,19 @@ int gvl_hungarian_batch_f32(const float *C, int B, int Q, int G, const int *size
  *   max_rows / max_cols: the largest min(Q, n*tile) and max(Q, n*tile) over the problems (<= 256 / <= 1024). */
 int gvl_lsap_batch_device_f32(const float *C, const int64_t *problems, int n_problems, int max_rows, int max_cols,
                               int64_t *rows_out, int64_t *cols_out, int *status, void *stream);
+
+/* -- TRAINING (ABI 15): the compact (query, caption) pair rows of the captioner on padded targets -- what pdvc.py:540-573 gathers
+ *    per decoder layer (matched queries' hidden states, their captions and masks), for the fixed-capacity layout of
+ *    gvl_amd/pdvc.py: caption_prediction_layers_padded.  Row r of layer k = the r-th matched pair in (video, slot) order:
+ *      flat[k R + r]      = (k N + video) Nq + matched query      (row of the stacked (layers, N, Nq) hidden states)
+ *      row_video[k R + r] = video, or -1 for rows beyond the batch's pair count (their caption is all <pad>, mask 0)
+ *      seq / mask         = cap_tensor / cap_mask [video][matched target]  (cap_len columns)
+ *      denom[0]           = N max(1, max_v pair_count[v])          (the divisor of pdvc.py:868's mean)
+ *    pair_count (N) int64; q_layers / t_layers: HOST arrays of n_layers device pointers to (N G1) int64 match arrays (negative =
+ *    unmatched, read as 0); cap_tensor (N, slots, cap_len) int64, cap_mask fp32.  One launch for ~45 small index operations. */
+int gvl_caption_rows(const int64_t *pair_count, const int64_t *const *q_layers, const int64_t *const *t_layers, int n_layers, int N,
+                     int G1, int R, int Nq, int slots, int cap_len, const int64_t *cap_tensor, const float *cap_mask, int64_t *flat,
+                     int64_t *row_video, int64_t *seq, float *mask, float *denom, void *stream);
 
 /* -- TRAINING: the weight / bias gradient of an nn.Linear -- what autograd's AddmmBackward computes as `grad_output.t().mm(input)`
  *    and `grad_output.sum(0)` for every Linear of the encoder / decoder layers (pdvc/deformable_transformer.py:189-199,257-280),

@@ -286,3 +286,28 @@ def test_graphed_eval_forward_beyond_the_padded_capacity_falls_back_and_returns(
     # capture 1: padded graph; capture 2: the layout-keyed graph of the big batch; then both are replayed
     assert [c for c, _ in seen] == [1, 2, 2, 2], seen
     assert seen[-1][1] == ["layout", "padded"], seen
+
+
+def test_caption_rows_kernel_equals_the_index_formulation(monkeypatch):
+    """gvl_caption_rows (the captioner's pair rows on padded targets in one launch) against the PyTorch index formulation it
+    replaces (GVL_CAPTION_ROWS=torch): every loss term and every gradient of the padded training forward, bit for bit -- over
+    batches with 0 .. 8 events per video (unused rows, videos without events)."""
+    opt, model, crit, T = toy(True)
+    wd = crit.weight_dict
+    for dt in batches(T, seed=70)[:4]:
+        res = {}
+        for mode in ("kernel", "torch"):
+            monkeypatch.setenv("GVL_CAPTION_ROWS", "" if mode == "kernel" else "torch")
+            model.zero_grad(set_to_none=True)
+            out, loss = model(_loaded(dt), crit, None, "queries")
+            final = sum(loss[k] * wd[k] for k in loss.keys() if k in wd)
+            final.backward()
+            res[mode] = ({k: v.detach().clone() for k, v in loss.items() if isinstance(v, torch.Tensor)},
+                         {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None})
+        (la, ga), (lb, gb) = res["kernel"], res["torch"]
+        assert la.keys() == lb.keys() and ga.keys() == gb.keys()
+        for k in la:
+            assert torch.equal(la[k], lb[k]) or (torch.isnan(la[k]).all() and torch.isnan(lb[k]).all()), k
+        for n in ga:
+            # (the captioner's backward scatters with float atomics: equal to summation order)
+            assert maxerr(ga[n], gb[n]) <= 1e-5 * max(1e-6, float(gb[n].abs().max())), n
