@@ -104,6 +104,7 @@ SIGNATURES = {
     "gvl_msda1d_fused_forward_bf16": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_bf16": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_wgrad_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "gvl_box_refine_backward_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "gvl_caption_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gvl_wgrad_group_max": (_I, []),
     "gvl_wgrad_group_workspace_bytes": (_SZ, [_P, _I]),

@@ -911,6 +911,32 @@ __global__ void __launch_bounds__(256) k_box_refine(const float *__restrict__ de
   }
 }
 
+// the gradient of k_box_refine's new_ref = sigmoid(delta + inverse_sigmoid(ref)): d delta = g o (1 - o); d ref (the first decoder
+// layer's reference points come from a Linear) = d delta[c] / (clamped x) + d delta[c] / (clamped 1 - x) where the clamps pass
+__global__ void __launch_bounds__(256) k_box_refine_bwd(const float *__restrict__ g, const float *__restrict__ o,
+                                                        const float *__restrict__ ref, int RD, int R, float *__restrict__ gdelta,
+                                                        float *__restrict__ gref) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  constexpr float eps = 1e-5f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float ov = o[2 * (int64_t)r + c];
+    const float gd = g[2 * (int64_t)r + c] * ov * (1.f - ov);
+    gdelta[2 * (int64_t)r + c] = gd;
+    if (gref && c < RD) {
+      // prior = log(max(x, eps)) - log(max(1 - x, eps)) with x = clamp(ref, 0, 1): each term differentiates to 1 / value where
+      // its clamp is inactive (torch's clamp passes the gradient at the boundary itself: min <= x <= max)
+      const float x0 = ref[(int64_t)r * RD + c];
+      const float x = fminf(fmaxf(x0, 0.f), 1.f);
+      float d = 0.f;
+      if (x >= eps) d += 1.f / x;
+      if (1.f - x >= eps) d += 1.f / (1.f - x);
+      gref[(int64_t)r * RD + c] = (x0 >= 0.f && x0 <= 1.f) ? gd * d : 0.f;
+    }
+  }
+}
+
 // out[b] = W . max_q hs[b][q][:] + bias: one workgroup (16 wavefronts) per video.  Wavefront w pools rows w, w + 16, ...
 // (four rows' loads in flight at a time: the pooling is a chain of load latencies, not of bytes), lane = float4 columns
 // lane, lane + 64, ...; the wavefronts' partial maxima meet in LDS.
@@ -1051,6 +1077,15 @@ extern "C" int gvl_box_refine_f32(const float *delta, int64_t ldd, const float *
   const int R = B * Q;
   return gvl::launch(GVL_PROF_LAYER_NORM, R, L, "k_box_refine", k_box_refine, dim3((R + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, delta, ldd, ref, RD, valid_ratios, R, Q, L, new_ref, ref_in);
+}
+
+extern "C" int gvl_box_refine_backward_f32(const float *grad_new_ref, const float *new_ref, const float *ref, int RD, int R,
+                                           float *grad_delta, float *grad_ref, void *stream) {
+  if (R < 0 || (RD != 1 && RD != 2)) return fail(GVL_EINVAL, "gvl_box_refine_backward_f32: bad sizes");
+  if (R == 0) return 0;
+  if (!grad_new_ref || !new_ref || !ref || !grad_delta) return fail(GVL_EINVAL, "gvl_box_refine_backward_f32: null pointer");
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, RD, "k_box_refine_bwd", k_box_refine_bwd, dim3((R + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, grad_new_ref, new_ref, ref, RD, R, grad_delta, grad_ref);
 }
 
 extern "C" int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight, const float *bias, int n_out,

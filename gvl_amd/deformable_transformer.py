@@ -198,8 +198,11 @@ class DeformableTransformerDecoder(nn.Module):
                                            query_padding_mask, disable_iterative_refine)
         out = tgt
         hs, refs, coords = [], [], []
+        next_in = None                                 # the next layer's scaled reference points, when the refinement kernel left them
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 2:                                       # (centre, length): :302-304
+            if next_in is not None:
+                ref_in, next_in = next_in, None
+            elif reference_points.shape[-1] == 2:                                     # (centre, length): :302-304
                 ref_in = reference_points[:, :, None] * torch.stack([src_valid_ratios] * 2, -1)[:, None]
             else:
                 assert reference_points.shape[-1] == 1
@@ -208,11 +211,17 @@ class DeformableTransformerDecoder(nn.Module):
                         query_padding_mask)
             if not disable_iterative_refine and self.bbox_head is not None:           # :314-324
                 delta = self.bbox_head[lid](out)
-                prior = inverse_sigmoid(reference_points)
-                if reference_points.shape[-1] == 2:
-                    new_ref = (delta + prior).sigmoid()
+                if _layers.box_refine_train_eligible(delta, reference_points):
+                    # sigmoid(delta + inverse_sigmoid(reference)) and the next layer's reference points in one launch, one
+                    # more for the gradient (gvl_amd/layers.py: _BoxRefineTrain)
+                    new_ref, next_in = _layers.box_refine_train(delta, reference_points, src_valid_ratios,
+                                                                lid + 1 < len(self.layers))
                 else:
-                    new_ref = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
+                    prior = inverse_sigmoid(reference_points)
+                    if reference_points.shape[-1] == 2:
+                        new_ref = (delta + prior).sigmoid()
+                    else:
+                        new_ref = torch.cat([delta[..., :1] + prior, delta[..., 1:]], -1).sigmoid()
                 reference_points = new_ref.detach()
                 coords.append(new_ref)
             if self.return_intermediate:

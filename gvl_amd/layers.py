@@ -373,6 +373,60 @@ def box_refine(delta, ref, valid_ratios, B, Q, want_ref_in=True):
     return new_ref, ref_in
 
 
+class _BoxRefineTrain(torch.autograd.Function):
+    """sigmoid(delta + inverse_sigmoid(ref)) of the decoder's iterative refinement (deformable_transformer.py:314-324) as ONE
+    node on gvl_box_refine_f32 / gvl_box_refine_backward_f32, with the next layer's scaled reference points (:301-304, computed
+    from the detached result as there) as a by-product: 2 launches forward + backward where the PyTorch formulation takes ~21
+    (four clamps, rsub, div, log, add, cat, sigmoid, stack, mul and their gradients)."""
+
+    @staticmethod
+    def forward(ctx, delta, ref, valid_ratios, want_ref_in):
+        B, Q = ref.shape[:2]
+        d2 = delta.reshape(B * Q, delta.shape[-1])
+        if d2.stride(1) != 1:
+            d2 = d2.contiguous()
+        refc = ref.contiguous()
+        new_ref, ref_in = box_refine(d2, refc, valid_ratios, B, Q, want_ref_in)
+        ctx.save_for_backward(new_ref, refc)
+        ctx.dshape = delta.shape
+        if ref_in is None:
+            ref_in = new_ref.new_empty(0)
+        ctx.mark_non_differentiable(ref_in)
+        return new_ref, ref_in
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_new, _g_in):
+        new_ref, ref = ctx.saved_tensors
+        R, RD = new_ref.shape[0] * new_ref.shape[1], ref.shape[-1]
+        g = g_new.contiguous()
+        gd = torch.empty(R, 2, device=g.device, dtype=torch.float32)
+        gr = torch.empty_like(ref) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().gvl_box_refine_backward_f32(g.data_ptr(), new_ref.data_ptr(), ref.data_ptr(), RD, R, gd.data_ptr(),
+                                                        gr.data_ptr() if gr is not None else None,
+                                                        torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "box_refine_backward")
+        gdelta = gd.view(*ctx.dshape[:-1], 2)
+        if ctx.dshape[-1] != 2:                                        # (a wider head output: only its first two columns are read)
+            full = gd.new_zeros(ctx.dshape)
+            full[..., :2] = gdelta
+            gdelta = full
+        return gdelta, gr, None, None
+
+
+def box_refine_train_eligible(delta, ref):
+    return (delta.is_cuda and delta.dtype == torch.float32 and ref.dtype == torch.float32 and torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and delta.dim() == 3 and ref.dim() == 3 and ref.shape[-1] in (1, 2)
+            and delta.shape[-1] >= 2 and delta.shape[:2] == ref.shape[:2] and os.environ.get("GVL_BOX_REFINE", "") != "torch")
+
+
+def box_refine_train(delta, ref, valid_ratios, want_ref_in):
+    """-> (new_ref (B, Q, 2) attached to delta / ref, the next layer's reference points (B, Q, L, 2) or None)"""
+    new_ref, ref_in = _BoxRefineTrain.apply(delta, ref, valid_ratios, want_ref_in)
+    return new_ref, (ref_in if want_ref_in else None)
+
+
 def count_head_eligible(counter, hs):
     return (enabled() and _plain(hs) and hs.dim() == 3 and hs.is_contiguous() and isinstance(counter, torch.nn.Linear)
             and counter.weight.dtype == torch.float32 and hs.shape[-1] % 4 == 0 and hs.shape[-1] <= 2048)

@@ -264,6 +264,11 @@ int gvl_encoder_geometry_f32(const unsigned char *mask, int B, int S, int L, con
                              const int64_t *starts_host, float *valid_ratios, float *ref, void *stream);
 int gvl_box_refine_f32(const float *delta, int64_t ldd, const float *ref, int RD, const float *valid_ratios, int B, int Q,
                        int L, float *new_ref, float *ref_in, void *stream);
+/*    TRAINING (ABI 15): its gradient -- grad_delta (R, 2) = g o (1 - o) with o = new_ref; grad_ref (R, RD) or NULL (only the first
+ *    decoder layer's reference points carry a gradient: every later layer reads them detached, deformable_transformer.py:322) =
+ *    grad_delta[c] times the derivative of inverse_sigmoid where its clamps are inactive (misc/detr_utils/misc.py:582-586). */
+int gvl_box_refine_backward_f32(const float *grad_new_ref, const float *new_ref, const float *ref, int RD, int R, float *grad_delta,
+                                float *grad_ref, void *stream);
 int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight, const float *bias, int n_out, float *out,
                        void *stream);
 

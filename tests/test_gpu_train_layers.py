@@ -210,3 +210,33 @@ def test_row_maxima_ride_on_the_results_forward_and_backward():
         assert bool((am >= true * (1 - 1e-6)).all()) and bool((am <= true / (1 - p) * (1 + 1e-6) + 1e-30).all() or k == "dy")
     y.add_(1.0)                                                              # an in-place edit invalidates the tag
     assert L.amax_of(y, B * Q) is None
+
+
+@pytest.mark.parametrize("RD", [1, 2])
+def test_box_refine_train_node_equals_the_torch_formulation(RD):
+    """sigmoid(delta + inverse_sigmoid(ref)) (deformable_transformer.py:314-324, misc/detr_utils/misc.py:582-586) as one node on
+    gvl_box_refine_f32 / gvl_box_refine_backward_f32: values, the next layer's scaled reference points and both gradients
+    against the PyTorch expression -- reference points at 0, 1, outside [0, 1] and within eps of the ends included (the clamps'
+    gradient rules)"""
+    from gvl_amd import layers as L
+    from gvl_amd.deformable_transformer import inverse_sigmoid
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(RD)
+    B, Q, Lv = 3, 50, 4
+    delta = (torch.randn(B, Q, 2, device=dev, generator=g) * 2).requires_grad_()
+    ref = torch.rand(B, Q, RD, device=dev, generator=g)
+    ref[0, :8, 0] = torch.tensor([0.0, 1.0, -0.2, 1.3, 5e-6, 1 - 5e-6, 1e-5, 0.5], device=dev)
+    ref.requires_grad_()
+    vr = torch.rand(B, Lv, device=dev, generator=g) * 0.5 + 0.5
+    assert L.box_refine_train_eligible(delta, ref)
+    new_ref, ref_in = L.box_refine_train(delta, ref, vr, True)
+    d2, r2 = delta.detach().clone().requires_grad_(), ref.detach().clone().requires_grad_()
+    prior = inverse_sigmoid(r2)
+    want = (d2 + prior).sigmoid() if RD == 2 else torch.cat([d2[..., :1] + prior, d2[..., 1:]], -1).sigmoid()
+    want_in = want.detach()[:, :, None] * torch.stack([vr] * 2, -1)[:, None]
+    assert float((new_ref - want).abs().max()) <= 2e-6 and float((ref_in - want_in).abs().max()) <= 2e-6
+    go = torch.randn(B, Q, 2, device=dev, generator=g)
+    new_ref.backward(go)
+    want.backward(go)
+    assert float((delta.grad - d2.grad).abs().max()) <= 1e-6 * max(1.0, float(d2.grad.abs().max()))
+    assert float((ref.grad - r2.grad).abs().max()) <= 1e-5 * max(1.0, float(r2.grad.abs().max()))
