@@ -182,7 +182,7 @@ def kernel_times(entries):
 def kernel_probe(dev, B, T=512, Q=300, M=8, L=4, P=4, iters=20, backward=False):
     """The same kernels at other launch sizes -- cfg L (T = 512, S = 960; level 0 read from global memory) and the
     latency-free batch B = 64: `iters` fused decoder-shaped launches on synthetic operands, timed with the library's
-    per-dispatch stamps.  Supplementary data points (DESIGN.md sections 4.1 / 4.2 / 4.7: at cfg A one launch moves
+    per-dispatch stamps.  Supplementary data points (at cfg A one launch moves
     23-37 MB, i.e. 3-5 us of HBM time against a ~5 us floor of launch ramp + one staging round trip + the VALU-bound
     sample loop) -- not part of the timed region, not part of `value`."""
     from gvl_amd import MultiScaleDeformableAttention as MSDA
@@ -898,7 +898,7 @@ def main():
                           f"log-sum-exp fused, logits never written), hand-written",
                 "note": "the matrix pipe is power-limited under this load (clock 1.87 GHz, issue throttled by the operands' "
                         "switching activity): with real operands and NO data movement the same MFMA stream reaches 0.63 of "
-                        "the nominal peak (DESIGN.md 4.4, tools/vocab_clocks.sh)",
+                        "the nominal peak (DESIGN_LOG.md 4.4, tools/vocab_clocks.sh)",
                 "bound": "mfma", "achieved": round(tf16, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, 3 "
                 "partial products per fp32 product)", "frac": round(tf16 / F16_MFMA_PEAK_TFLOPS, 4),
                 "fp32_equivalent_tflops": round(tf16 / 3, 1), "kernel_us": round(us, 1), "launches_timed": mine[0][1],

@@ -1000,7 +1000,7 @@ __global__ void __launch_bounds__(512, 1)
 // ---- the vocabulary product on 256 x 320 tiles, ONE accumulator per output (round 5).
 // Why: the 128 x 256 tiles of k_gemm_f16x3_m16 keep the CU's LDS pipe 89 % occupied (83 B/clk of fragment reads + 31 B/clk of
 // DMA writes against 128 B/clk) and ask the vector-memory path for 48 KB per 1536 MFMA cycles, close to the ~ 39 B/clk a CU
-// sustains (the kernel ran 74 instead of 104 us without the fragment reads).  Both shrink with the tile:
+// sustains (DESIGN_LOG.md 4.4: the kernel ran 74 instead of 104 us without the fragment reads).  Both shrink with the tile:
 //   workgroup tile   256 vocabulary rows (A) x 320 hidden rows (B): 34 x 15 = 510 tiles at (8518, 4800) = 1.99 rounds of 256 CUs;
 //                    a K stage is 72 KB, TWO stage buffers (the three-stage ring of the smaller tile does not fit)
 //   wavefront tile   64 (A) x 160 (B) = 4 x 10 tiles of v_mfma_f32_16x16x32_f16: 28 ds_read_b128 per 120 MFMAs (m16: 16 per 48),

@@ -62,7 +62,7 @@ def test_bf16_storage_equals_rounded_fp32_and_oracle(name, B, T, M, Q, P, pad, d
     assert gv.dtype == BF and gl.dtype == torch.float32 and gw.dtype == torch.float32 and last_impl() == "fast"
     gv32, gl32, gw32 = MSDA.ms_deform_attn_backward(v_bf.float(), sh, ls, lc, w, g_bf.float(), 64, pad_mode=pad)
     # grad_value: same fp32 gather, but the order of one slab row's entries may differ between two kernel
-    # instantiations -> equal before rounding up to fp32 summation order, i.e. within one bf16 ulp
+    # instantiations (DESIGN_LOG.md 4.10) -> equal before rounding up to fp32 summation order, i.e. within one bf16 ulp
     assert maxerr(gv.float(), gv32) <= 2.0 ** -8 * scale(gv32.cpu().numpy())
     assert float((gv != gv32.to(BF)).float().mean()) < 2e-3
     assert torch.equal(gl, gl32) and torch.equal(gw, gw32)

@@ -480,7 +480,7 @@ def _check_yc2(f, out, loss, memory, tol, seq_exact):
     """tol bounds the encoder memory (relative to its scale) and, x5, the sigmoid box heads; logits / counts / decoder
     features get 25x: at T = 512 the decoder's sampling amplifies position noise (d sample / d loc = T_l * dv), so
     even the reference's own fp32 run sits 1.4e-4 (boxes) / 1.3e-3 (logits) away from an fp64 evaluation of the same
-    model, and gvl_amd's fp32 run 3.1e-4 / 2.6e-3 (tools/stage_times.py-style probe recorded in DESIGN.md section 6)."""
+    model, and gvl_amd's fp32 run 3.1e-4 / 2.6e-3 (tools/stage_times.py-style probe recorded in DESIGN_LOG.md section 5)."""
     ms = float(np.abs(f["memory_rows"]).max())
     assert maxerr(memory[:, ::8], f["memory_rows"]) <= tol * max(1.0, ms)
     assert abs(float(memory.double().sum()) - float(f["memory_sum"])) <= tol * 960 * 2 * 512 ** 0.5

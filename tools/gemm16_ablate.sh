@@ -1,5 +1,5 @@
 #!/bin/bash
-# Timing-only builds of the eight-wavefront k_gemm_f16x3 (which part of a K stage costs what):
+# Timing-only builds of the eight-wavefront k_gemm_f16x3 (which part of a K stage costs what; DESIGN_LOG.md section 4.4):
 #   base | nodma (no LDS-DMA in the loop) | nolds (operands from registers) | nobar | mfmaonly | nogroups (compiler's own
 #   instruction order).  Build here (hipcc cross-compiles), run on the GPU box:  for v in tools/_bin/*; do $v; done
 set -e
