@@ -1224,25 +1224,7 @@ __host__ __device__ inline size_t bwd_split_lds_bytes(int S, int qper) {
   const int rowsA = bwd_split_rows_a(S, qper);
   return (size_t)rowsA * 256 + (size_t)qper * 256 + (size_t)(S + 2) * 2 * sizeof(int) + (size_t)(2 * qper * 8) * 4 * sizeof(int);
 }
-// FLAT gather (round 6): the histogram gains a third array (record offsets), the entry table loses `sorted`, and the row-ordered
-// RECORD list -- every entry twice (its lower and its upper row), one zero record for an owned row without entries -- is 4 + 2
-// bytes per record (coefficient, LDS row of the query's grad_out | last-record flag).  The open sums of the gather's shares (one
-// slot per DPP row) lie over the entry table, which is dead once the records exist.
-constexpr int kFlatPartBytes = (kBwdThreads / 16) * 256;
-__host__ __device__ inline int bwd_flat_hist_ints(int S) { return (3 * (S + 2) + 3) & ~3; }
-__host__ __device__ inline int bwd_flat_records(int S, int qper) { return 2 * (2 * qper * 8) + (S + 1); }
-__host__ __device__ inline size_t bwd_flat_ent_bytes(int qper) {
-  const size_t e = (size_t)(2 * qper * 8) * 3 * sizeof(int);
-  return e > (size_t)kFlatPartBytes ? e : (size_t)kFlatPartBytes;
-}
-__host__ __device__ inline size_t bwd_split_flat_lds_bytes(int S, int qper) {
-  const int rowsA = bwd_split_rows_a(S, qper);
-  const size_t nrec = (size_t)bwd_flat_records(S, qper);
-  return (size_t)rowsA * 256 + (size_t)qper * 256 + (size_t)bwd_flat_hist_ints(S) * sizeof(int) + bwd_flat_ent_bytes(qper) +
-         nrec * sizeof(float) + ((nrec * sizeof(unsigned short) + 15) & ~(size_t)15);
-}
-
-template <int PAD, bool FUSED, typename VT, bool FLAT = false>
+template <int PAD, bool FUSED, typename VT>
 __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restrict__ value,
                                                                const int64_t *__restrict__ shapes,
                                                                const int64_t *__restrict__ lsi,
@@ -1260,18 +1242,11 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   float4 *G_oth = slab4 + (size_t)rowsV * 16;                          // grad_out rows of the foreign queries
   int *cnt = reinterpret_cast<int *>(G_oth + (size_t)qper * 16);       // [S+2] histogram
   int *off = cnt + (S + 2);                                            // [S+2] exclusive prefix
-  int *voff = off + (S + 2);                                           // FLAT: [S+2] first record of the row's padded list
   const int nent = 2 * qper * 8;                                       // 8 samples of the owned levels per query
-  int *ent_rp = FLAT ? cnt + bwd_flat_hist_ints(S) : off + (S + 2);    // slab row | slot in the row << 12, or -1
+  int *ent_rp = off + (S + 2);                                         // slab row | slot in the row << 12, or -1
   float *ent_lo = reinterpret_cast<float *>(ent_rp + nent);
   float *ent_hi = ent_lo + nent;
-  int *sorted = reinterpret_cast<int *>(ent_hi + nent);               // (!FLAT)
-  // FLAT: the record list (coefficient | LDS row of the query's grad_out + last-step flag) behind the entry table; the gather's
-  // partial rows over the entry table
-  float *rec_c = reinterpret_cast<float *>(reinterpret_cast<char *>(ent_rp) + bwd_flat_ent_bytes(qper));
-  unsigned short *rec_q = reinterpret_cast<unsigned short *>(rec_c + bwd_flat_records(S, qper));
-  float4 *part4 = reinterpret_cast<float4 *>(ent_rp);
-  __shared__ int part_tag[kBwdThreads / 16], first_row_s[kBwdThreads / 16];
+  int *sorted = reinterpret_cast<int *>(ent_hi + nent);
 
   const int BM = B * M;
   const int bm = slab_of_block(blockIdx.x % BM, BM), g = blockIdx.x / BM;   // g in {0, 1}
@@ -1522,175 +1497,6 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   }
   for (int i = threadIdx.x + kG * blockDim.x; i < nq * 16; i += blockDim.x)
     G4[i] = ld4(gout, gsrc + (int64_t)(i >> 4) * M * 16 + (i & 15));
-  if constexpr (FLAT) {
-    // ---- FLAT (round 6): the gather as ONE row-ordered list of records, cut into 64 equal shares ----------------------------
-    // The dynamic-unit gather below walks four rows per wavefront in lockstep: every step costs what the LONGEST of the four
-    // lists costs, lists are consumed in groups of 4 / 4 / 8 steps, and a workgroup whose samples crowd a few rows finishes late
-    // (cfg A decoder: 2 100 wavefront steps for 4 800 row visits = 1 200 full steps; the kernel ends with its slowest workgroup,
-    // 2.4 us after the mean).  Here every entry becomes two RECORDS -- (LDS row of the query's grad_out, coefficient) for its
-    // lower row r and for r + 1 -- written in output-row order (an owned row without entries gets one zero record, so every
-    // owned row appears).  Each of the workgroup's 64 DPP rows takes an equal share of CONSECUTIVE records, whatever the rows'
-    // lengths: per step a record is broadcast over the DPP row, the query's grad_out row is read (one conflict-free
-    // ds_read_b128 per lane) and accumulated; a flag on a row's last record makes the DPP row store its sum (final) and start
-    // the next row.  A row cut by a share boundary: the share it BEGINS in leaves its open sum in an LDS slot (one per DPP
-    // row), the share it ENDS in keeps that row's sum in registers and, after a barrier, adds the slots of the shares before
-    // it that carry the same row -- a fixed order.  The work per workgroup no longer depends on where the samples fall.
-    const int T0f = (int)shapes[1], s2f = (int)lsi[2], s3f = (int)lsi[3];
-    auto owned = [&](int i) { return g == 0 ? (i < T0f || (i >= s3f && i < S)) : (i >= T0f && i < s3f); };
-    auto level_start = [&](int i) { return i == 0 || i == T0f || i == s2f || i == s3f || i >= S; };
-    {
-      __shared__ int wave_tot[kBwdThreads / 64], wave_totv[kBwdThreads / 64];
-      __shared__ int carry_s, carry_v;
-      if (threadIdx.x == 0) { carry_s = 0; carry_v = 0; }
-      __syncthreads();
-      for (int base = 0; base < S + 1; base += blockDim.x) {
-        const int i = base + threadIdx.x;
-        const int v = (i < S + 1) ? cnt[i] : 0;
-        // records of output row i: its own entries (lower row = i) and those of row i - 1 of the same level (upper row = i)
-        int pv = 0;
-        if (i < S && owned(i)) {
-          const int n_i = v + (level_start(i) ? 0 : cnt[i - 1]);
-          pv = n_i > 0 ? n_i : 1;
-        }
-        int incl = v, inclv = pv;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int t_ = __shfl_up(incl, o, 64), tv_ = __shfl_up(inclv, o, 64);
-          if (lane >= o) { incl += t_; inclv += tv_; }
-        }
-        if (lane == 63) { wave_tot[wave] = incl; wave_totv[wave] = inclv; }
-        __syncthreads();
-        int pre_ = carry_s, prev_ = carry_v;
-        for (int k = 0; k < wave; ++k) { pre_ += wave_tot[k]; prev_ += wave_totv[k]; }
-        if (i < S + 1) { off[i] = pre_ + incl - v; voff[i] = prev_ + inclv - pv; }
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) { carry_s = pre_ + incl; carry_v = prev_ + inclv; }
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) { off[S + 1] = carry_s; voff[S + 1] = carry_v; }
-      __syncthreads();
-    }
-    constexpr int kShares = kBwdThreads / 16;                              // one per DPP row of the workgroup
-    const int n_rec = voff[S + 1];
-    const int share = (n_rec + kShares - 1) / kShares;
-    const int oth_rows = rowsV - qper;          // entry query index ql >= qper lives at LDS row ql + oth_rows (G_oth)
-    for (int e = threadIdx.x; e < nent; e += blockDim.x) {
-      const int rp = ent_rp[e];
-      if (rp < 0) continue;
-      const int r = rp & 4095, pos = rp >> 12, ql = e >> 3;
-      const unsigned grow = (unsigned)(ql < qper ? ql : ql + oth_rows);
-      {
-        const int pl = voff[r] + pos;
-        rec_c[pl] = ent_lo[e];
-        rec_q[pl] = (unsigned short)(grow | (pl == voff[r + 1] - 1 ? 0x8000u : 0u));
-      }
-      if (!level_start(r + 1)) {                                            // (a one-row level has no upper row)
-        const int ph = voff[r + 1] + cnt[r + 1] + pos;
-        rec_c[ph] = ent_hi[e];
-        rec_q[ph] = (unsigned short)(grow | (ph == voff[r + 2] - 1 ? 0x8000u : 0u));
-      }
-    }
-    // the zero record of a row without entries, and the row each share starts in
-    for (int i = threadIdx.x; i < S; i += blockDim.x) {
-      if (!owned(i)) continue;
-      const int a = voff[i], b_ = voff[i + 1];
-      if (cnt[i] + (level_start(i) ? 0 : cnt[i - 1]) == 0) {
-        rec_c[a] = 0.f;
-        rec_q[a] = (unsigned short)0x8000u;
-      }
-      for (int d = (a + share - 1) / share; d < kShares && d * share < b_; ++d) first_row_s[d] = i;
-    }
-    __syncthreads();
-    if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = wall_clock64();
-
-    const char *G_b = reinterpret_cast<const char *>(G4);
-    const int lane_off = j * 16;
-    const int did = (int)(threadIdx.x >> 4);                                // this DPP row's share
-    const int ra = did * share, rb = min(n_rec, ra + share);               // its records [ra, rb)
-    const bool any_rec = ra < rb;
-    int srow = any_rec ? first_row_s[did] : 0;
-    bool head = any_rec && voff[srow] < ra;                                // the share starts inside a row: that row's sum is partial
-    f2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-    f2v h01 = {0.f, 0.f}, h23 = {0.f, 0.f};
-    int hrow = -1;
-    auto load_batch = [&](int kb, unsigned &rq, float &rc) {
-      const int idx = ra + kb + j;
-      const bool have = idx < rb;
-      rq = have ? (unsigned)rec_q[have ? idx : 0] : 0u;
-      rc = have ? rec_c[have ? idx : 0] : 0.f;
-    };
-    unsigned rq_n;
-    float rc_n;
-    load_batch(0, rq_n, rc_n);
-    for (int kb = 0; kb < share; kb += 16) {
-      const unsigned rq = rq_n;
-      const float rc = rc_n;
-      load_batch(kb + 16, rq_n, rc_n);                                     // (the next batch's records travel under this one)
-      const f2v tc = {__builtin_bit_cast(float, (int)((rq & 0x7FFFu) << 8)), rc};
-      const unsigned long long fm = __ballot((rq & 0x8000u) != 0u);
-      // bit k of `mine`: this DPP row's record k ends a row; bit k of `any`: some DPP row's does
-      const unsigned mine = (unsigned)(fm >> (16 * tq)) & 0xFFFFu;
-      const unsigned any = (unsigned)__builtin_amdgcn_readfirstlane((int)((fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xFFFFull));
-      const int nst = min(16, share - kb);
-#ifdef GVL_FLAT_NOREAD        // timing build: the steps without their LDS row reads
-#define GVL_FLAT_LD(T) make_float4(T.x, T.y, T.x, T.y)
-#else
-#define GVL_FLAT_LD(T) (*reinterpret_cast<const float4 *>(G_b + __builtin_bit_cast(int, T.x) + lane_off))
-#endif
-#ifdef GVL_FLAT_NOFLUSH       // timing build: rows are neither kept nor stored
-#define GVL_FLAT_FLUSH(K) if (__builtin_expect((any >> (K)) & 1u, 0)) { if ((mine >> (K)) & 1u) { a01 = (f2v){0.f, 0.f}; a23 = a01; ++srow; } }
-#else
-#define GVL_FLAT_FLUSH(K)                                                       \
-  if (__builtin_expect((any >> (K)) & 1u, 0)) {                                 \
-    if ((mine >> (K)) & 1u) {                                                   \
-      if (head) { h01 = a01; h23 = a23; hrow = srow; head = false; }            \
-      else st4_stream(gvalue, ((int64_t)b * S + srow) * M * 16 + (int64_t)m * 16 + j, make_float4(a01.x, a01.y, a23.x, a23.y)); \
-      a01 = (f2v){0.f, 0.f};                                                    \
-      a23 = (f2v){0.f, 0.f};                                                    \
-      srow = (g == 0 && srow + 1 == T0f) ? s3f : srow + 1;                      \
-    }                                                                           \
-  }
-#endif
-#define GVL_FLAT_ACC(T, G, K)                                                   \
-  {                                                                             \
-    const f2v cf = __builtin_shufflevector(T, T, 1, 1);                         \
-    a01 = __builtin_elementwise_fma(cf, (f2v){G.x, G.y}, a01);                  \
-    a23 = __builtin_elementwise_fma(cf, (f2v){G.z, G.w}, a23);                  \
-    GVL_FLAT_FLUSH(K)                                                           \
-  }
-#define GVL_FLAT_QUAD(S0)                                                       \
-  if (nst > (S0)) {                                                             \
-    const f2v t0 = row_bcast_f2<S0>(tc), t1 = row_bcast_f2<S0 + 1>(tc), t2 = row_bcast_f2<S0 + 2>(tc),  \
-              t3 = row_bcast_f2<S0 + 3>(tc);                                    \
-    const float4 g0 = GVL_FLAT_LD(t0), g1 = GVL_FLAT_LD(t1), g2 = GVL_FLAT_LD(t2), g3 = GVL_FLAT_LD(t3);   \
-    GVL_FLAT_ACC(t0, g0, S0) GVL_FLAT_ACC(t1, g1, S0 + 1) GVL_FLAT_ACC(t2, g2, S0 + 2) GVL_FLAT_ACC(t3, g3, S0 + 3)  \
-  }
-      GVL_FLAT_QUAD(0) GVL_FLAT_QUAD(4) GVL_FLAT_QUAD(8) GVL_FLAT_QUAD(12)
-#undef GVL_FLAT_QUAD
-#undef GVL_FLAT_ACC
-#undef GVL_FLAT_FLUSH
-#undef GVL_FLAT_LD
-    }
-    // the share ends inside a row (its last record carries no flag): the open sum goes to the share's slot
-    {
-      const bool open = any_rec && (rec_q[any_rec ? rb - 1 : 0] & 0x8000u) == 0u;
-      if (open) part4[did * 16 + j] = make_float4(a01.x, a01.y, a23.x, a23.y);
-      if (j == 0) part_tag[did] = open ? srow : -1;
-    }
-    __syncthreads();
-    if (hrow >= 0) {                                                       // a row that ended here and began in earlier shares
-      float4 sum = make_float4(h01.x, h01.y, h23.x, h23.y);
-      for (int u = did - 1; u >= 0 && part_tag[u] == hrow; --u) {
-        const float4 x = part4[u * 16 + j];
-        sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
-      }
-      st4_stream(gvalue, ((int64_t)b * S + hrow) * M * 16 + (int64_t)m * 16 + j, sum);
-    }
-    if (stamps) {                                                          // diagnostics only: gather done (before the store drain)
-      __syncthreads();
-      if (threadIdx.x == 0) stamps[(1024 + blockIdx.x) * 4] = wall_clock64();
-    }
-  } else {
   {
     __shared__ int wave_tot[kBwdThreads / 64];
     __shared__ int carry_s;
@@ -1800,7 +1606,6 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
   if (stamps) {                                                          // diagnostics only: gather done (before the store drain)
     __syncthreads();
     if (threadIdx.x == 0) stamps[(1024 + blockIdx.x) * 4] = wall_clock64();
-  }
   }
 }
 
@@ -2404,12 +2209,8 @@ int run_bwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
   constexpr bool kBf16 = !std::is_same<VT, float>::value;
   const int qper = (Q + nchunk - 1) / nchunk;
   if (bwd_split_ok(B, S, M, L, P, Q, plan, nchunk)) {
-    // the flat gather (equal shares of one row-ordered record list) wherever its larger carve-up fits beside the kernel's static LDS
-    const bool flat = env_int("GVL_MSDA_BWD_FLAT", 0) && bwd_split_flat_lds_bytes(S, qper) + 1024 <= kLdsMax &&
-                      bwd_split_rows_a(S, qper) + qper < 0x7FFF;
-    auto kern = pad == kPadZeros ? (flat ? k_bwd_t1d_split<kPadZeros, FUSED, VT, true> : k_bwd_t1d_split<kPadZeros, FUSED, VT, false>)
-                                 : (flat ? k_bwd_t1d_split<kPadBorder, FUSED, VT, true> : k_bwd_t1d_split<kPadBorder, FUSED, VT, false>);
-    const size_t lds = flat ? bwd_split_flat_lds_bytes(S, qper) : bwd_split_lds_bytes(S, qper);
+    auto kern = pad == kPadZeros ? k_bwd_t1d_split<kPadZeros, FUSED, VT> : k_bwd_t1d_split<kPadBorder, FUSED, VT>;
+    const size_t lds = bwd_split_lds_bytes(S, qper);
     if (int rc = ensure_lds(kern, lds)) return rc;
     g_last_impl = FUSED ? 3 : 2;
     g_last_kernel = "k_bwd_t1d_split";
