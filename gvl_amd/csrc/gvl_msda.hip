@@ -909,6 +909,82 @@ __device__ inline void gather8(const f2v tc, const char *G_b, int lane_off, f2v 
 #undef GVL_ACC
 }
 
+// LANE = SAMPLE own pass (round 6, GVL_BWD_LS; -DGVL_BWD_LS=0 is the lane = channels form of rounds 2-5).
+#ifndef GVL_BWD_LS
+#define GVL_BWD_LS 1
+#endif
+#ifndef GVL_BWD_LS_GROUP
+#define GVL_BWD_LS_GROUP 2
+#endif
+// ------------------------------------------------------------------------------------------------------
+// The two dot products of ONE sample per lane -- g[q] . V[r_j] and g[q] . V[r_j + 1] over all 64 channels (round 6; shared by
+// the temporal backward kernels wherever the sample's rows are in LDS).  The query's grad_out row lives four channels per lane
+// (as loaded).  At step K the lane reads the 16-byte column (j -+ K) mod 16 of ITS two rows -- the sixteen lanes of a DPP row
+// then read sixteen DIFFERENT columns whatever their rows: no bank conflicts -- and multiplies with the grad_out channels of
+// that column, which arrive from the lane that holds them by the same row rotation as the column's offset.  Against lane =
+// channels (every lane a 4-channel slice of ALL sixteen samples' products, then two 16-value reduce-scatters over the DPP row
+// to bring sample j's sums to lane j): 128 FMAs + ~90 instructions of reduce-scatter + 32 of broadcasts / addresses become 80
+// row rotations + 64 packed FMAs + 2 adds (own pass of k_bwd_t1d_split 7.05 -> 6.35 us, profiles/r06_bwd_experiments.txt).
+// The same products, added in another order (channel pairs in two chains, joined at the end).
+// FENCED: the row requests of step group n + 1 in front of the products of group n, held in that order by scheduling fences (the
+// level-split kernel: own pass 6.51 -> 6.34 us); without, the compiler's own order (the other kernels, where the fences cost
+// registers the kernels do not have).
+template <bool FENCED>
+__device__ __forceinline__ void ls_dot_pair(const float4 *slab4, const int row, const float4 g, const int j, float &d0, float &d1) {
+  f2v s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+  {
+      const int vaddr = (int)(uintptr_t)(lds_cbyte *)reinterpret_cast<const char *>(slab4) + row * 256;
+      const int jo = j * 16;
+      // (the column's offset travels by the same rotation as the channels: the direction of row_ror does not matter)
+#define GVL_ROR(K, V) ((K) == 0 ? (V) : dpp_f<(K) ? 0x120 + (K) : 0x121>(V))
+      // Software pipeline in groups of GVL_BWD_LS_GROUP steps: the rows of group n + 1 are requested before the products of
+      // group n are taken (left to itself the compiler requests two rows, waits for both, multiplies, and only then requests the
+      // next two: sixteen exposed LDS round trips per pass with four wavefronts per SIMD to hide them).  The scheduling fences keep
+      // the order; the waits the compiler inserts are counted ones (the newer group stays in flight).
+#define GVL_LS_ISSUE(K)                                                       \
+  const int co##K = (K) == 0 ? jo : dpp_i<(K) ? 0x120 + (K) : 0x121>(jo);     \
+  lds_cbyte *vc##K = (lds_cbyte *)(uintptr_t)(unsigned)(vaddr + co##K);       \
+  const float4 va##K = lds_ld4(vc##K), vb##K = lds_ld4(vc##K + 256);
+#define GVL_LS_USE(K)                                                         \
+  {                                                                           \
+    const f2v bxy = {GVL_ROR(K, g.x), GVL_ROR(K, g.y)}, bzw = {GVL_ROR(K, g.z), GVL_ROR(K, g.w)};  \
+    s0 = __builtin_elementwise_fma(bxy, (f2v){va##K.x, va##K.y}, s0);         \
+    s0 = __builtin_elementwise_fma(bzw, (f2v){va##K.z, va##K.w}, s0);         \
+    s1 = __builtin_elementwise_fma(bxy, (f2v){vb##K.x, vb##K.y}, s1);         \
+    s1 = __builtin_elementwise_fma(bzw, (f2v){vb##K.z, vb##K.w}, s1);         \
+  }
+#define GVL_LS_FENCE if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);
+#ifdef GVL_ABL_NODOT          // timing build: the own pass without its dot products
+      s0 = (f2v){g.x, g.y} + (f2v){__builtin_bit_cast(float, vaddr), 0.f}; s1 = (f2v){g.z, g.w};
+#elif GVL_BWD_LS_GROUP == 4
+      GVL_LS_ISSUE(0) GVL_LS_ISSUE(1) GVL_LS_ISSUE(2) GVL_LS_ISSUE(3) GVL_LS_FENCE
+      GVL_LS_ISSUE(4) GVL_LS_ISSUE(5) GVL_LS_ISSUE(6) GVL_LS_ISSUE(7) GVL_LS_FENCE
+      GVL_LS_USE(0) GVL_LS_USE(1) GVL_LS_USE(2) GVL_LS_USE(3) GVL_LS_FENCE
+      GVL_LS_ISSUE(8) GVL_LS_ISSUE(9) GVL_LS_ISSUE(10) GVL_LS_ISSUE(11) GVL_LS_FENCE
+      GVL_LS_USE(4) GVL_LS_USE(5) GVL_LS_USE(6) GVL_LS_USE(7) GVL_LS_FENCE
+      GVL_LS_ISSUE(12) GVL_LS_ISSUE(13) GVL_LS_ISSUE(14) GVL_LS_ISSUE(15) GVL_LS_FENCE
+      GVL_LS_USE(8) GVL_LS_USE(9) GVL_LS_USE(10) GVL_LS_USE(11) GVL_LS_FENCE
+      GVL_LS_USE(12) GVL_LS_USE(13) GVL_LS_USE(14) GVL_LS_USE(15) GVL_LS_FENCE
+#else
+      GVL_LS_ISSUE(0) GVL_LS_ISSUE(1) GVL_LS_FENCE
+      GVL_LS_ISSUE(2) GVL_LS_ISSUE(3) GVL_LS_FENCE GVL_LS_USE(0) GVL_LS_USE(1) GVL_LS_FENCE
+      GVL_LS_ISSUE(4) GVL_LS_ISSUE(5) GVL_LS_FENCE GVL_LS_USE(2) GVL_LS_USE(3) GVL_LS_FENCE
+      GVL_LS_ISSUE(6) GVL_LS_ISSUE(7) GVL_LS_FENCE GVL_LS_USE(4) GVL_LS_USE(5) GVL_LS_FENCE
+      GVL_LS_ISSUE(8) GVL_LS_ISSUE(9) GVL_LS_FENCE GVL_LS_USE(6) GVL_LS_USE(7) GVL_LS_FENCE
+      GVL_LS_ISSUE(10) GVL_LS_ISSUE(11) GVL_LS_FENCE GVL_LS_USE(8) GVL_LS_USE(9) GVL_LS_FENCE
+      GVL_LS_ISSUE(12) GVL_LS_ISSUE(13) GVL_LS_FENCE GVL_LS_USE(10) GVL_LS_USE(11) GVL_LS_FENCE
+      GVL_LS_ISSUE(14) GVL_LS_ISSUE(15) GVL_LS_FENCE GVL_LS_USE(12) GVL_LS_USE(13) GVL_LS_FENCE
+      GVL_LS_USE(14) GVL_LS_USE(15) GVL_LS_FENCE
+#endif
+#undef GVL_LS_FENCE
+#undef GVL_LS_USE
+#undef GVL_LS_ISSUE
+#undef GVL_ROR
+    }
+  d0 = s0.x + s0.y;
+  d1 = s1.x + s1.y;
+}
+
 constexpr int kBwdThreads = 1024;
 constexpr int kEntStride = 16;       // entry slot = q_local * 16 + sample
 
@@ -1032,6 +1108,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
         atomicAdd(&cnt[roff], 1);
       }
     }
+    float d0, d1;
+    if constexpr (GVL_BWD_LS && FUSED && FULL16 && !L0G) {
+      ls_dot_pair<false>(slab4, roff, g, j, d0, d1);      // one sample per lane (every row in LDS, sixteen samples per query)
+    } else {
     // per sample the two dot products g . V[r], g . V[r+1]: every lane accumulates its 4-channel part for all 16
     // samples, then two DPP-row reduce-scatters leave sample j's sums on lane j (the lane that holds its coefficients)
     float p0[16], p1[16];
@@ -1057,7 +1137,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_d64(const VT *__restric
     GVL_BWD_STEP(8) GVL_BWD_STEP(9) GVL_BWD_STEP(10) GVL_BWD_STEP(11)
     GVL_BWD_STEP(12) GVL_BWD_STEP(13) GVL_BWD_STEP(14) GVL_BWD_STEP(15)
 #undef GVL_BWD_STEP
-    const float d0 = row_reduce_scatter16(p0, j), d1 = row_reduce_scatter16(p1, j);
+    d0 = row_reduce_scatter16(p0, j);
+    d1 = row_reduce_scatter16(p1, j);
+    }
     const float keep_w = fmaf(clo, d0, chi * d1);
     const float keep_x = fmaf(dxlo, d0, dxhi * d1);
     const float keep_y = fmaf(dylo, d0, dyhi * d1);
@@ -1207,13 +1289,6 @@ gather4<0>(tc, G_b, lane_off, a01, a23);
 // (workgroup ids B*M apart), so the second read is an L2 hit.  The counting sort keeps the slot each entry drew from
 // the integer histogram in phase 1 (packed beside the row), so the scatter needs no second round of LDS atomics.
 // ------------------------------------------------------------------------------------------------------
-// LANE = SAMPLE own pass (round 6, GVL_BWD_LS; -DGVL_BWD_LS=0 is the lane = channels form of rounds 2-5).
-#ifndef GVL_BWD_LS
-#define GVL_BWD_LS 1
-#endif
-#ifndef GVL_BWD_LS_GROUP
-#define GVL_BWD_LS_GROUP 2
-#endif
 constexpr int kSplitStride4 = 16;                                      // float4 per staged slab row of k_bwd_t1d_split
 __host__ __device__ inline int bwd_split_rows_a(int S, int qper) {     // region A in 256-byte rows: slab, later the own grad_out rows
   const int v = ((S + 1) * kSplitStride4 + 15) / 16;
@@ -1365,70 +1440,13 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
       const float elo = clo * w, ehi = chi * w;
       if (act && mine && (elo != 0.f || ehi != 0.f)) record(q - q0, roff, elo, ehi);
     }
-#if GVL_BWD_LS
-    // LANE = SAMPLE: lane j takes the two dot products of ITS sample -- g[q] . V[r_j] and g[q] . V[r_j + 1] over all 64 channels.
-    // The query's grad_out row lives four channels per lane (as loaded); channel group K reaches every lane of the DPP row as two
-    // 64-bit row broadcasts, the lane reads the 16-byte column K of its own two rows (immediate offsets from one per-lane
-    // address: no address arithmetic per step) and accumulates two packed FMAs per row.  Against lane = channels (every lane a
-    // 4-channel slice of ALL sixteen samples' products, then two reduce-scatters over the DPP row to bring sample j's sums to
-    // lane j): 128 dot FMAs + ~90 instructions of reduce-scatter + 32 of row broadcasts / addresses become 32 broadcasts + 64
-    // packed FMAs + 2 adds -- the pass is bound by the issue of its vector instructions.  The sums are the same products added
-    // in another order (channel pairs 4K, 4K+1 | 4K+2, 4K+3 in two chains, joined at the end).
-    f2v s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
-    {
-      const int vaddr = (int)(uintptr_t)(lds_cbyte *)reinterpret_cast<const char *>(slab4) + roff * 256;
-      const int jo = j * 16;
-      // step K: the lane reads column (j -+ K) mod 16 of its two rows -- the sixteen lanes of a DPP row then read sixteen DIFFERENT
-      // 16-byte columns, whatever their rows: no bank conflicts -- and multiplies with the grad_out channels of that column,
-      // which arrive from the lane that holds them by the same row rotation as the column's offset (so the direction of
-      // row_ror does not matter here).
-#define GVL_ROR(K, V) ((K) == 0 ? (V) : dpp_f<(K) ? 0x120 + (K) : 0x121>(V))
-      // Software pipeline in groups of GVL_BWD_LS_GROUP steps: the rows of group n + 1 are requested before the products of
-      // group n are taken (left to itself the compiler requests two rows, waits for both, multiplies, and only then requests the
-      // next two: sixteen exposed LDS round trips per pass with four wavefronts per SIMD to hide them).  The scheduling fences keep
-      // the order; the waits the compiler inserts are counted ones (the newer group stays in flight).
-#define GVL_LS_ISSUE(K)                                                       \
-  const int co##K = (K) == 0 ? jo : dpp_i<(K) ? 0x120 + (K) : 0x121>(jo);     \
-  lds_cbyte *vc##K = (lds_cbyte *)(uintptr_t)(unsigned)(vaddr + co##K);       \
-  const float4 va##K = lds_ld4(vc##K), vb##K = lds_ld4(vc##K + 256);
-#define GVL_LS_USE(K)                                                         \
-  {                                                                           \
-    const f2v bxy = {GVL_ROR(K, gq.x), GVL_ROR(K, gq.y)}, bzw = {GVL_ROR(K, gq.z), GVL_ROR(K, gq.w)};  \
-    s0 = __builtin_elementwise_fma(bxy, (f2v){va##K.x, va##K.y}, s0);         \
-    s0 = __builtin_elementwise_fma(bzw, (f2v){va##K.z, va##K.w}, s0);         \
-    s1 = __builtin_elementwise_fma(bxy, (f2v){vb##K.x, vb##K.y}, s1);         \
-    s1 = __builtin_elementwise_fma(bzw, (f2v){vb##K.z, vb##K.w}, s1);         \
-  }
-#define GVL_LS_FENCE __builtin_amdgcn_sched_barrier(0);
-#ifdef GVL_ABL_NODOT          // timing build: the own pass without its dot products
-      s0 = (f2v){gq.x, gq.y} + (f2v){__builtin_bit_cast(float, vaddr), 0.f}; s1 = (f2v){gq.z, gq.w};
-#elif GVL_BWD_LS_GROUP == 4
-      GVL_LS_ISSUE(0) GVL_LS_ISSUE(1) GVL_LS_ISSUE(2) GVL_LS_ISSUE(3) GVL_LS_FENCE
-      GVL_LS_ISSUE(4) GVL_LS_ISSUE(5) GVL_LS_ISSUE(6) GVL_LS_ISSUE(7) GVL_LS_FENCE
-      GVL_LS_USE(0) GVL_LS_USE(1) GVL_LS_USE(2) GVL_LS_USE(3) GVL_LS_FENCE
-      GVL_LS_ISSUE(8) GVL_LS_ISSUE(9) GVL_LS_ISSUE(10) GVL_LS_ISSUE(11) GVL_LS_FENCE
-      GVL_LS_USE(4) GVL_LS_USE(5) GVL_LS_USE(6) GVL_LS_USE(7) GVL_LS_FENCE
-      GVL_LS_ISSUE(12) GVL_LS_ISSUE(13) GVL_LS_ISSUE(14) GVL_LS_ISSUE(15) GVL_LS_FENCE
-      GVL_LS_USE(8) GVL_LS_USE(9) GVL_LS_USE(10) GVL_LS_USE(11) GVL_LS_FENCE
-      GVL_LS_USE(12) GVL_LS_USE(13) GVL_LS_USE(14) GVL_LS_USE(15) GVL_LS_FENCE
-#else
-      GVL_LS_ISSUE(0) GVL_LS_ISSUE(1) GVL_LS_FENCE
-      GVL_LS_ISSUE(2) GVL_LS_ISSUE(3) GVL_LS_FENCE GVL_LS_USE(0) GVL_LS_USE(1) GVL_LS_FENCE
-      GVL_LS_ISSUE(4) GVL_LS_ISSUE(5) GVL_LS_FENCE GVL_LS_USE(2) GVL_LS_USE(3) GVL_LS_FENCE
-      GVL_LS_ISSUE(6) GVL_LS_ISSUE(7) GVL_LS_FENCE GVL_LS_USE(4) GVL_LS_USE(5) GVL_LS_FENCE
-      GVL_LS_ISSUE(8) GVL_LS_ISSUE(9) GVL_LS_FENCE GVL_LS_USE(6) GVL_LS_USE(7) GVL_LS_FENCE
-      GVL_LS_ISSUE(10) GVL_LS_ISSUE(11) GVL_LS_FENCE GVL_LS_USE(8) GVL_LS_USE(9) GVL_LS_FENCE
-      GVL_LS_ISSUE(12) GVL_LS_ISSUE(13) GVL_LS_FENCE GVL_LS_USE(10) GVL_LS_USE(11) GVL_LS_FENCE
-      GVL_LS_ISSUE(14) GVL_LS_ISSUE(15) GVL_LS_FENCE GVL_LS_USE(12) GVL_LS_USE(13) GVL_LS_FENCE
-      GVL_LS_USE(14) GVL_LS_USE(15) GVL_LS_FENCE
-#endif
-#undef GVL_LS_FENCE
-#undef GVL_LS_USE
-#undef GVL_LS_ISSUE
-#undef GVL_ROR
-    }
-    const float d0 = s0.x + s0.y, d1 = s1.x + s1.y;
-#else
+    // (the unfused instantiations keep lane = channels: with the plain loc / attn operands hipcc hoists all sixteen steps' row
+    //  reads above the products and spills ~140 registers at the kernel's 128-register cap)
+    float d0, d1;
+    if constexpr (GVL_BWD_LS && FUSED) {
+      ls_dot_pair<true>(slab4, roff, gq, j, d0, d1);
+    } else {
+
     float p0[16], p1[16];
 #define GVL_BWD_STEP(SI)                                                      \
   {                                                                           \
@@ -1442,8 +1460,9 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_split(const VT *__restr
     GVL_BWD_STEP(8) GVL_BWD_STEP(9) GVL_BWD_STEP(10) GVL_BWD_STEP(11)
     GVL_BWD_STEP(12) GVL_BWD_STEP(13) GVL_BWD_STEP(14) GVL_BWD_STEP(15)
 #undef GVL_BWD_STEP
-    const float d0 = row_reduce_scatter16(p0, j), d1 = row_reduce_scatter16(p1, j);
-#endif
+    d0 = row_reduce_scatter16(p0, j);
+    d1 = row_reduce_scatter16(p1, j);
+    }
     const float keep_w = fmaf(clo, d0, chi * d1);
     const float keep_x = fmaf(dxlo, d0, dxhi * d1);
     const float keep_y = fmaf(dylo, d0, dyhi * d1);
@@ -1747,6 +1766,12 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
       const float dxlo = c.dx_lo * c.wy * w, dxhi = c.dx_hi * c.wy * w;
       const float dylo = c.c_lo * c.dy * w, dyhi = c.c_hi * c.dy * w;
       GVL_T(0)                                                               // operand hand-over + coefficients
+      float d0, d1;
+      if constexpr (false && GVL_BWD_LS && FUSED && !L0G) {   // (not here: the kernel sits at its register cap, +80 bytes of scratch)
+        ls_dot_pair<false>(slab4, roff - row0, gq, j, d0, d1);               // one sample per lane: every row is in LDS
+        GVL_T(1)
+        GVL_T(2)
+      } else {
       float p0[16], p1[16];
       // L0G: the eight level-0 rows of this pass are requested first and consumed last -- the twelve LDS steps run
       // while they travel
@@ -1805,8 +1830,10 @@ __global__ void __launch_bounds__(kBwdThreads) k_bwd_t1d_own(const VT *__restric
         }
       }
       GVL_T(1)                                                               // 16 sample steps: 32 row reads + 32 dot products
-      const float d0 = row_reduce_scatter16(p0, j), d1 = row_reduce_scatter16(p1, j);
+      d0 = row_reduce_scatter16(p0, j);
+      d1 = row_reduce_scatter16(p1, j);
       GVL_T(2)                                                               // two reduce-scatters
+      }
       const float keep_w = fmaf(clo, d0, chi * d1);
       const float keep_x = fmaf(dxlo, d0, dxhi * d1);
       const float keep_y = fmaf(dylo, d0, dyhi * d1);
