@@ -11,5 +11,5 @@ for cfg in "100 f32" "100 f32 amax" "512 f32" "512 bf16"; do
   done
 done
 cd $root
-python tools/pmc_traffic3.py /tmp > gpurun_out/r05_pmc_traffic.json
-cat gpurun_out/r05_pmc_traffic.json | head -80
+python tools/pmc_traffic3.py /tmp > gpurun_out/r06_pmc_traffic.json
+cat gpurun_out/r06_pmc_traffic.json | head -80
