@@ -954,9 +954,7 @@ __device__ __forceinline__ void ls_dot_pair(const float4 *slab4, const int row, 
     s1 = __builtin_elementwise_fma(bzw, (f2v){vb##K.z, vb##K.w}, s1);         \
   }
 #define GVL_LS_FENCE if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);
-#ifdef GVL_ABL_NODOT          // timing build: the own pass without its dot products
-      s0 = (f2v){g.x, g.y} + (f2v){__builtin_bit_cast(float, vaddr), 0.f}; s1 = (f2v){g.z, g.w};
-#elif GVL_BWD_LS_GROUP == 4
+#if GVL_BWD_LS_GROUP == 4
       GVL_LS_ISSUE(0) GVL_LS_ISSUE(1) GVL_LS_ISSUE(2) GVL_LS_ISSUE(3) GVL_LS_FENCE
       GVL_LS_ISSUE(4) GVL_LS_ISSUE(5) GVL_LS_ISSUE(6) GVL_LS_ISSUE(7) GVL_LS_FENCE
       GVL_LS_USE(0) GVL_LS_USE(1) GVL_LS_USE(2) GVL_LS_USE(3) GVL_LS_FENCE
