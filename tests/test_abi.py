@@ -177,3 +177,48 @@ def test_library_binds_to_the_hip_runtime_pytorch_ships():
         "assert len(libs) == 1, libs\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_descriptor_structs_match_the_header(tmp_path):
+    """the ctypes mirrors of the C ABI's descriptor structs (the update table, the grouped weight-gradient problems, the
+    segments of the layer product) have the header's size and field offsets: a plain-C program that includes
+    include/gvl_msda.h prints them (gcc; no GPU)."""
+    import shutil
+    import subprocess
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from gvl_amd import layers, optim
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    mirrors = {"gvl_adam_desc": optim._Desc, "gvl_wgrad_desc": MSDA._WgradDesc, "gvl_lin_seg": layers._Seg}
+    hdr = open(os.path.join(ROOT, "include", "gvl_msda.h")).read()
+    fields = {}
+    for name in mirrors:
+        body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                names += [re.sub(r"[\s\*]", "", p).split("[")[0] for p in re.sub(r"^.*?[\s\*](?=[\w\*]+(\s*,|$))", "", decl).split(",")]
+        fields[name] = [n for n in names if n]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "gvl_msda.h"', 'int main(void) {']
+    for name, fs in fields.items():
+        src.append(f'  printf("{name} size %zu\\n", sizeof({name}));')
+        for f_ in fs:
+            src.append(f'  printf("{name} {f_} %zu\\n", offsetof({name}, {f_}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "sizes.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
+    out = subprocess.check_output([str(exe)], text=True)
+    got = {}
+    for line in out.splitlines():
+        s_, f_, v = line.split()
+        got[(s_, f_)] = int(v)
+    for name, mirror in mirrors.items():
+        assert ctypes.sizeof(mirror) == got[(name, "size")], (name, ctypes.sizeof(mirror), got[(name, "size")])
+        py = {n: getattr(mirror, n).offset for n, _ in mirror._fields_}
+        for f_ in fields[name]:
+            assert f_ in py and py[f_] == got[(name, f_)], (name, f_, py.get(f_), got[(name, f_)])
+        assert len(py) == len(fields[name]), (name, sorted(py), fields[name])

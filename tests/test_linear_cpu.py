@@ -88,3 +88,58 @@ def test_row_maxima_tag_is_dropped_after_an_in_place_write():
     assert enc_ref_of(vr) is not None
     vr[0, 0] = 0.5
     assert enc_ref_of(vr) is None and enc_ref_of(torch.ones(2, 4)) is None
+
+
+def test_autocast_policies_and_version_bump(monkeypatch):
+    """host logic without a GPU: the autocast policy switches accept exactly their three values, and gvl_amd.optim.bump_versions
+    moves the version counters the weight-derived caches are keyed on"""
+    import pytest
+    import torch
+    from gvl_amd import pdvc
+    from gvl_amd.optim import bump_versions
+    for fn, var in ((pdvc.autocast_training_policy, "GVL_AUTOCAST_TRAINING"), (pdvc.autocast_inference_policy, "GVL_AUTOCAST_INFERENCE")):
+        monkeypatch.delenv(var, raising=False)
+        assert fn() == "f16"
+        for v in ("fp32", "bf16", "f16"):
+            monkeypatch.setenv(var, v)
+            assert fn() == v
+        monkeypatch.setenv(var, "fp8")
+        if fn is pdvc.autocast_training_policy:
+            with pytest.raises(ValueError):
+                fn()
+        else:
+            assert fn() == "f16"                                # (the inference switch falls back to its default)
+        monkeypatch.delenv(var, raising=False)
+    ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.ones(2, 2))]
+    before = [p._version for p in ps]
+    bump_versions(ps)
+    assert [p._version for p in ps] == [b + 1 for b in before]
+
+
+def test_wgrad_queue_takes_a_second_gradient_of_the_same_parameter_at_once(monkeypatch):
+    """gvl_amd.linear._WgradQueue (host logic, kernels stubbed): problems wait for the group; a parameter that already has a
+    queued gradient in this backward pass is flushed and taken immediately (autograd adds the two as soon as the second is
+    returned); a full group is flushed; the queue keeps detached aliases of the returned tensors"""
+    import torch
+    from gvl_amd import linear as GL
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    calls = []
+    monkeypatch.setattr(MSDA, "wgrad_group_max", lambda: 3)
+    monkeypatch.setattr(MSDA, "wgrad_group", lambda items: calls.append(("group", len(items))))
+    monkeypatch.setattr(MSDA, "wgrad", lambda dy, x, a, b, grad_w=None, grad_b=None, want_bias=True, accumulate=False:
+                        (calls.append(("single", 1)), (grad_w, grad_b))[1])
+    q = GL._WgradQueue()
+    dy, x, am = torch.zeros(8, 4), torch.zeros(8, 6), torch.zeros(8)
+    w = [torch.nn.Parameter(torch.zeros(4, 6)) for _ in range(5)]
+    gw0, gb0 = q.push(dy, x, am, am, True, [id(w[0])])
+    assert calls == [] and tuple(gw0.shape) == (4, 6) and tuple(gb0.shape) == (4,)
+    assert q.items[0][4].data_ptr() == gw0.data_ptr() and q.items[0][4] is not gw0          # a detached alias, not the tensor itself
+    q.push(dy, x, am, am, False, [id(w[1])])
+    q.push(dy, x, am, am, True, [id(w[0])])                    # the same parameter again: flush (2 queued), then at once
+    assert calls == [("group", 2), ("single", 1)] and q.items == []
+    for k in (2, 3, 4):
+        q.push(dy, x, am, am, True, [id(w[k])])
+    assert calls[-1] == ("group", 3) and q.items == []         # a full group leaves by itself
+    q.push(dy, x, am, am, True, [id(torch.nn.Parameter(torch.zeros(1)))])
+    q.flush()
+    assert calls[-1] == ("single", 1)                          # a lone problem takes the single launch
