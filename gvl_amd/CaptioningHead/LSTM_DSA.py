@@ -136,14 +136,19 @@ class ShowAttendTellCore(nn.Module):
         w_ih = self.rnn.weight_ih_l0
         E = self.input_encoding_size
         weights = self._inference_weights(slab.dtype) if not torch.is_grad_enabled() else {}
-        w_hs = w_ih[:, E + self.att_feat_size:]
+        # the three column blocks of W_ih -- embedding | attention | event features (LSTM_DSA.py:267-269 concatenates its input in that
+        # order) -- and the two of the offsets' weight, each taken by ONE split: its backward is one cat of the blocks' gradients,
+        # where three separate slices differentiate into three zero-filled full-size matrices (12.6 MB each), three copies and two adds
+        parts = w_ih.split([E, self.att_feat_size, w_ih.shape[1] - E - self.att_feat_size], 1)
+        ow_parts = att.sampling_offsets.weight.split([self.rnn_size, att.sampling_offsets.weight.shape[1] - self.rnn_size], 1)
+        w_hs = parts[2]
         if weights.get("gate_perm") is not None:                                  # fused cell: gates as 4 unit + gate
             w_hs = w_hs[weights["gate_perm"]]
         gates_hs = F.linear(query.reshape(-1, C), w_hs)                           # hs part of the LSTM input
         # the offsets projection splits into an h part (per step) and an hs part (constant)
-        ow = att.sampling_offsets.weight
-        off_hs = F.linear(query, ow[:, self.rnn_size:], att.sampling_offsets.bias)     # (B,Q,16)
-        const = {"slab": slab, "gates_hs": gates_hs, "off_hs": off_hs.float().contiguous()}    # offsets stay fp32
+        off_hs = F.linear(query, ow_parts[1], att.sampling_offsets.bias)               # (B,Q,16)
+        const = {"slab": slab, "gates_hs": gates_hs, "off_hs": off_hs.float().contiguous(),    # offsets stay fp32
+                 "w_ih_parts": parts, "ow_parts": ow_parts}
         if not torch.is_grad_enabled():
             # inference: everything the fused token-step kernel (gvl_cap_attend_f32) needs, laid out once
             bias = self.alpha_net.bias
@@ -165,14 +170,16 @@ class ShowAttendTellCore(nn.Module):
         att = self.deformable_att
         H, E, C = self.rnn_size, self.input_encoding_size, self.att_feat_size
         K = self.n_levels * self.n_points
-        ow = att.sampling_offsets.weight
-        w_hcat = torch.cat([self.h2att.weight, self.rnn.weight_hh_l0, ow[:, :H]], 0)
+        ow_h = const["ow_parts"][0] if "ow_parts" in const else att.sampling_offsets.weight[:, :H]
+        w_hcat = torch.cat([self.h2att.weight, self.rnn.weight_hh_l0, ow_h], 0)
         b_hcat = torch.cat([self.h2att.bias, self.h2att.bias.new_zeros(4 * H + K)])
         slab = const["slab"]
         B, S = slab.shape[:2]
         return TeacherForcedLoop.apply(
             slab.view(B, S, -1), reference_points.contiguous(), const["off_hs"].reshape(-1, K), const["gates_hs"],
-            xt_all, w_hcat, b_hcat, self.rnn.weight_ih_l0[:, E:E + C].contiguous(), self.alpha_net.weight.reshape(-1),
+            xt_all, w_hcat, b_hcat,
+            (const["w_ih_parts"][1] if "w_ih_parts" in const else self.rnn.weight_ih_l0[:, E:E + C]).contiguous(),
+            self.alpha_net.weight.reshape(-1),
             self.alpha_net.bias.reshape(1), temporal_shapes_2d(temporal_shapes, level_start_index), level_start_index,
             self.n_levels, self.n_points, row_video)
 
@@ -577,9 +584,8 @@ class Captioner(nn.Module):
             n = vid_num * query_num
         memory, tshapes, lsi, mask, ref_in = self._level_inputs(others, ref_in)
         const = self.core.prepare(hs, memory, mask)
-        h = hs.new_zeros(n, self.rnn_size)
-        c = hs.new_zeros(n, self.rnn_size)
-        w_x = self.core.rnn.weight_ih_l0[:, :self.input_encoding_size]
+        h = c = None                                   # (zero states: built where the step-by-step loop below needs them)
+        w_x = const["w_ih_parts"][0] if "w_ih_parts" in const else self.core.rnn.weight_ih_l0[:, :self.input_encoding_size]
         outputs = []
         # the reference leaves the loop at the first step i >= 1 whose input column is all <pad> (:110-112), testing
         # it on the host every step; the same cut computed with ONE read (or none: pass `steps` when the caller
@@ -608,11 +614,13 @@ class Captioner(nn.Module):
                     return RowLoss(-picked.sum(1) / (tmask.sum(1) + 1e-6))               # build_loss (:48-52)
                 return F.log_softmax(split_linear(self.dropout(hidden), self.logit.weight, self.logit.bias), dim=2)
             hidden = []
+            h, c = hs.new_zeros(n, self.rnn_size), hs.new_zeros(n, self.rnn_size)
             for i in range(steps):
                 out, (h, c) = self.core.step(xt_all[:, i], (h, c), hs, ref_in, tshapes, lsi, const)
                 hidden.append(out)
             hidden = torch.stack(hidden, 1)                                       # (n, steps, H)
             return F.log_softmax(split_linear(self.dropout(hidden), self.logit.weight, self.logit.bias), dim=2)
+        h, c = hs.new_zeros(n, self.rnn_size), hs.new_zeros(n, self.rnn_size)
         for i in range(steps):                                                    # scheduled sampling (:92-105)
             it = seq[:, i].clone()
             if i >= 1:
