@@ -165,8 +165,9 @@ class ShowAttendTellCore(nn.Module):
                 and self.n_levels * self.n_points == 16)
 
     def teacher_forced(self, xt_all, query, reference_points, temporal_shapes, level_start_index, const,
-                       row_video=None):
-        """every teacher-forced token step as one autograd node (TeacherForcedLoop) -> hidden (n, steps, H)"""
+                       row_video=None, time_major=False):
+        """every teacher-forced token step as one autograd node (TeacherForcedLoop) -> hidden (n, steps, H); time_major:
+        xt_all and hidden are (steps, n, .) -- the loop's own layout, no transposed copies either way"""
         att = self.deformable_att
         H, E, C = self.rnn_size, self.input_encoding_size, self.att_feat_size
         K = self.n_levels * self.n_points
@@ -181,7 +182,7 @@ class ShowAttendTellCore(nn.Module):
             (const["w_ih_parts"][1] if "w_ih_parts" in const else self.rnn.weight_ih_l0[:, E:E + C]).contiguous(),
             self.alpha_net.weight.reshape(-1),
             self.alpha_net.bias.reshape(1), temporal_shapes_2d(temporal_shapes, level_start_index), level_start_index,
-            self.n_levels, self.n_points, row_video)
+            self.n_levels, self.n_points, row_video, time_major)
 
     def _inference_weights(self, gemm_dtype=torch.float32):
         """Weight-only operands of the fused token step (re-laid-out / concatenated weights): rebuilt only when a
@@ -393,12 +394,18 @@ class TeacherForcedLoop(torch.autograd.Function):
     Inputs: slab (B,S,2C); ref_in (B,Q,L,RD); off_hs (n,16) and gates_hs (n,4H) the token-independent parts of the
     offsets / gate pre-activations; xt_all (n,steps,4H) embedding part of the gates; w_hcat (A+4H+16, H) =
     [h2att.weight; W_hh; sampling_offsets.weight[:, :H]] with bias b_hcat; w_att (4H, C) = W_ih[:, E:E+C];
-    alpha_w (A,), alpha_b (1,)."""
+    alpha_w (A,), alpha_b (1,).
+    time_major: xt_all is (steps, n, 4H) and the result (steps, n, H) -- the layout the loop keeps its per-step buffers in, so
+    neither the result nor the two gradients crossing the node's boundary (9 + 9 + 18 MB at 192 rows x 23 tokens) is transposed
+    into a copy; the caller orders its token ids / targets / weights (steps, n) instead, which are a few KB."""
 
     @staticmethod
     def forward(ctx, slab, ref_in, off_hs, gates_hs, xt_all, w_hcat, b_hcat, w_att, alpha_w, alpha_b, shapes2d, lsi,
-                n_levels, n_points, row_video=None):
-        n, steps, H4 = xt_all.shape
+                n_levels, n_points, row_video=None, time_major=False):
+        if time_major:
+            steps, n, H4 = xt_all.shape
+        else:
+            n, steps, H4 = xt_all.shape
         H = H4 // 4
         C = w_att.shape[1]
         W = w_hcat.shape[0]
@@ -406,7 +413,7 @@ class TeacherForcedLoop(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, device=slab.device, dtype=torch.float32)      # noqa: E731
         # the token-independent gate part joins the per-token embedding part ONCE (one pass over (n, steps, 4H)); as the
         # matrix addend of the attention product below it cost a (n, 4H) copy into `out` per token (addmm with beta = 1)
-        xt_all = xt_all + gates_hs[:, None, :]
+        xt_all = xt_all + (gates_hs[None] if time_major else gates_hs[:, None, :])
         g_h, hc_all = new(steps, n, W), new(2, steps + 1, n, H)
         h_all, c_all = hc_all[0], hc_all[1]
         att, alpha, act, g_x = new(steps, n, C), new(steps, n, 16), new(steps, n, H4), new(n, H4)
@@ -418,13 +425,13 @@ class TeacherForcedLoop(torch.autograd.Function):
                                           alpha_w, alpha_b, n_levels, n_points, att_res=att[i], alpha_out=alpha[i],
                                           row_video=row_video)
             torch.mm(att[i], w_att_t, out=g_x)                                    # attention part of W_ih x
-            MSDA.lstm_cell_train_forward(g_x, g_h[i][:, A:A + H4], xt_all[:, i], c_all[i], act[i], h_all[i + 1],
-                                         c_all[i + 1])
+            MSDA.lstm_cell_train_forward(g_x, g_h[i][:, A:A + H4], xt_all[i] if time_major else xt_all[:, i], c_all[i], act[i],
+                                         h_all[i + 1], c_all[i + 1])
         ctx.save_for_backward(slab, ref_in, off_hs, w_hcat, w_att, alpha_w, shapes2d, lsi, g_h, h_all, c_all, att,
                               alpha, act)
         ctx.cfg = (n_levels, n_points, A)
-        ctx.row_video = row_video
-        return h_all[1:].permute(1, 0, 2).contiguous()
+        ctx.row_video, ctx.time_major = row_video, time_major
+        return h_all[1:] if time_major else h_all[1:].permute(1, 0, 2).contiguous()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -436,7 +443,7 @@ class TeacherForcedLoop(torch.autograd.Function):
         H, C = h_all.shape[-1], att.shape[-1]
         H4 = 4 * H
         new = lambda *shape: torch.empty(shape, device=slab.device, dtype=torch.float32)      # noqa: E731
-        d_h = d_hidden.permute(1, 0, 2).contiguous()
+        d_h = (d_hidden if ctx.time_major else d_hidden.permute(1, 0, 2)).contiguous()
         dg = new(steps, n, W)                          # per step [d h2att(h) | d gates | d offsets]: fully overwritten
         g_slab = torch.zeros_like(slab)
         n_r, n_a = (ref_in.numel() + 3) // 4 * 4, (alpha_w.numel() + 3) // 4 * 4      # (16-byte aligned pieces)
@@ -471,8 +478,8 @@ class TeacherForcedLoop(torch.autograd.Function):
             d_w_hcat = dgf.t().mm(h_prev)
             d_b_hcat = MSDA.col_sum(dgf)
             d_w_att = d_gates.reshape(steps * n, H4).t().mm(att2)
-        return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates.sum(0), d_gates.permute(1, 0, 2), d_w_hcat, d_b_hcat,
-                d_w_att, g_aw, g_ab, None, None, None, None, None)
+        return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates.sum(0), d_gates if ctx.time_major else d_gates.permute(1, 0, 2),
+                d_w_hcat, d_b_hcat, d_w_att, g_aw, g_ab, None, None, None, None, None, None)
 
 
 def _fp32_island(fn):
@@ -602,16 +609,26 @@ class Captioner(nn.Module):
             # embedding rows by index_select: its backward is an atomic index_add.  nn.Embedding's backward switches to
             # a rocPRIM radix sort above 3072 indices (512 padded rows x 11 steps), and that path faulted when replayed
             # from a hipGraph on MI355X / ROCm 7.2 (eager was fine)
-            ids = seq[:, :steps]
+            fused = torch.is_grad_enabled() and self.core.fused_train_eligible(hs)
+            # loss-only on the fused path: everything per token is laid out (steps, n, .) as the token loop keeps it, and the
+            # few KB of ids / targets / weights are transposed instead of the 9-18 MB activations and gradients
+            tm = (fused and nll is not None and vocab_nll_eligible(hs, self.logit.weight, self.logit.bias)
+                  and os.environ.get("GVL_CAP_TIME_MAJOR", "1") != "0")
+            ids = seq[:, :steps].t() if tm else seq[:, :steps]
             emb = self.embed.weight.index_select(0, ids.reshape(-1)).view(*ids.shape, -1)
-            xt_all = F.linear(emb, w_x)                                           # (n, steps, 4H)
-            if torch.is_grad_enabled() and self.core.fused_train_eligible(hs):
-                hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const, row_video)
+            xt_all = F.linear(emb, w_x)                                           # (n, steps, 4H); tm: (steps, n, 4H)
+            if fused:
+                hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const, row_video, time_major=tm)
+                if tm:
+                    target, tmask = nll
+                    picked = vocab_nll(self.dropout(hidden), self.logit.weight, self.logit.bias, target[:, :steps].t(),
+                                       tmask[:, :steps].t()).view(steps, n)
+                    return RowLoss(-picked.sum(0) / (tmask.sum(1) + 1e-6))               # build_loss (:48-52)
                 if nll is not None and vocab_nll_eligible(hidden, self.logit.weight, self.logit.bias):
                     target, tmask = nll
                     picked = vocab_nll(self.dropout(hidden), self.logit.weight, self.logit.bias, target[:, :steps],
                                        tmask[:, :steps]).view(n, steps)
-                    return RowLoss(-picked.sum(1) / (tmask.sum(1) + 1e-6))               # build_loss (:48-52)
+                    return RowLoss(-picked.sum(1) / (tmask.sum(1) + 1e-6))
                 return F.log_softmax(split_linear(self.dropout(hidden), self.logit.weight, self.logit.bias), dim=2)
             hidden = []
             h, c = hs.new_zeros(n, self.rnn_size), hs.new_zeros(n, self.rnn_size)
