@@ -344,7 +344,9 @@ class DeformableTransformer(nn.Module):
                 hit = self.__dict__["_gvl_query_ref"] = (key, lin(query_pos).sigmoid())
             reference_points = hit[1]
         else:
-            reference_points = self.reference_points(query_pos).sigmoid()
+            # (training: the Linear on the Q rows of the embedding, THEN the batch expansion -- the same arithmetic per row as the
+            #  reference's Linear over the batch-expanded rows, without materialising them and their gradient)
+            reference_points = self.reference_points(query_pos[0]).sigmoid().unsqueeze(0).expand(bs, -1, -1)
         return reference_points, tgt, reference_points, query_pos
 
     def prepare_decoder_input_proposal(self, gt_reference_points, inversed_input=False):

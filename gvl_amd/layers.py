@@ -392,6 +392,7 @@ class _BoxRefineTrain(torch.autograd.Function):
         if ref_in is None:
             ref_in = new_ref.new_empty(0)
         ctx.mark_non_differentiable(ref_in)
+        ctx.set_materialize_grads(False)          # (the non-differentiable by-product would otherwise get a zeros() launch in backward)
         return new_ref, ref_in
 
     @staticmethod

@@ -129,6 +129,7 @@ class MSDeformAttnFusedFunction(Function):
         ctx.save_for_backward(value, proj, reference_points, spatial_shapes, level_start_index)
         if amax is not None:
             ctx.mark_non_differentiable(amax)
+            ctx.set_materialize_grads(False)          # (the non-differentiable by-product would otherwise get a zeros() launch in backward)
             return out, amax
         return out, None
 

@@ -26,6 +26,9 @@ from .deformable_transformer import build_deforamble_transformer, inverse_sigmoi
 from .linear import Linear
 from .matcher import build_matcher
 from .postprocess import PostProcess
+from . import train_layers as _train_layers
+
+_NO_DROP = nn.Dropout(0.0)
 
 
 def _clones(module, n):
@@ -45,7 +48,9 @@ class MLP(nn.Module):
         for i, layer in enumerate(self.layers):
             x = layer(x)
             if i < self.num_layers - 1:
-                x = F.relu(x)
+                # training: ReLU as the row kernel that leaves max |row| for the next Linear's operand split (and, in backward,
+                # for the previous one's) -- two passes over the activation fewer per ReLU
+                x = _train_layers.relu_dropout(x, F.relu, _NO_DROP) if torch.is_grad_enabled() and x.requires_grad else F.relu(x)
         return x
 
 

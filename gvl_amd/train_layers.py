@@ -147,6 +147,7 @@ class ResidualDropoutLayerNorm(torch.autograd.Function):
         ctx.save_for_backward(z, stats, weight, used if used is not None else x.new_empty(0))
         ctx.p, ctx.seed, ctx.has_step = float(p), int(seed), step is not None
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)          # (the non-differentiable by-product would otherwise get a zeros() launch in backward)
         return y, stats
 
     @staticmethod
@@ -226,6 +227,7 @@ class ReluDropout(torch.autograd.Function):
         ctx.save_for_backward(y)
         ctx.p = float(p)
         ctx.mark_non_differentiable(am)
+        ctx.set_materialize_grads(False)          # (the non-differentiable by-product would otherwise get a zeros() launch in backward)
         return y, am
 
     @staticmethod

@@ -62,6 +62,7 @@ class _InProj(torch.autograd.Function):
         ctx.save_for_backward(x2, xq.reshape(R, C), am_v, am_qk, weight)
         ctx.op_t, ctx.shape = op_t, (B, Q, C)
         ctx.mark_non_differentiable(am_out)
+        ctx.set_materialize_grads(False)          # (the non-differentiable by-product would otherwise get a zeros() launch in backward)
         return qkv, am_out
 
     @staticmethod
