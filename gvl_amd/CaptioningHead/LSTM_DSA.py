@@ -57,7 +57,8 @@ class ShowAttendTellCore(nn.Module):
         self.n_points = opt.cap_dec_n_points
         self.deformable_att = MSDeformAttnCap(opt.hidden_dim, self.n_levels, self.n_heads, self.n_points, opt)
         if self.att_hid_size > 0:
-            self.ctx2att = nn.Linear(self.att_feat_size, self.att_hid_size)
+            self.ctx2att = Linear(self.att_feat_size, self.att_hid_size)       # (training: the hand-written product, as value_proj)
+            self.ctx2att.defer_wgrad = True
             self.h2att = nn.Linear(self.rnn_size, self.att_hid_size)
             self.alpha_net = nn.Linear(self.att_hid_size, 1)
         if self.num_layers != 1 or self.n_heads != 1 or self.att_hid_size <= 0:
@@ -173,13 +174,14 @@ class ShowAttendTellCore(nn.Module):
         K = self.n_levels * self.n_points
         ow_h = const["ow_parts"][0] if "ow_parts" in const else att.sampling_offsets.weight[:, :H]
         w_hcat = torch.cat([self.h2att.weight, self.rnn.weight_hh_l0, ow_h], 0)
-        b_hcat = torch.cat([self.h2att.bias, self.h2att.bias.new_zeros(4 * H + K)])
+        from .. import train_layers as _tl
+        b_hcat = torch.cat([self.h2att.bias, _tl.step_zeros(4 * H + K, query.device)])       # (zeros: the step's one fill)
         slab = const["slab"]
         B, S = slab.shape[:2]
         return TeacherForcedLoop.apply(
             slab.view(B, S, -1), reference_points.contiguous(), const["off_hs"].reshape(-1, K), const["gates_hs"],
             xt_all, w_hcat, b_hcat,
-            (const["w_ih_parts"][1] if "w_ih_parts" in const else self.rnn.weight_ih_l0[:, E:E + C]).contiguous(),
+            const["w_ih_parts"][1] if "w_ih_parts" in const else self.rnn.weight_ih_l0[:, E:E + C],    # (a column block: strided)
             self.alpha_net.weight.reshape(-1),
             self.alpha_net.bias.reshape(1), temporal_shapes_2d(temporal_shapes, level_start_index), level_start_index,
             self.n_levels, self.n_points, row_video, time_major)

@@ -6,7 +6,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GVL_LIB_PATH: a dev build (gvl_amd.build.build_dev: timing / ablation variants of single kernels) instead of the shipped library
 LIB_PATH = os.environ.get("GVL_LIB_PATH") or os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 15          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 16          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -99,6 +99,8 @@ SIGNATURES = {
     "gvl_greedy_step_partials_gemm_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _I64, _P]),
     "gvl_box_refine_f32": (_I, [_P, _I64, _P, _I, _P, _I, _I, _I, _P, _P, _P]),
     "gvl_count_head_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "gvl_count_pool_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "gvl_count_pool_backward_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),
     "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gvl_msda1d_fused_forward_bf16": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),

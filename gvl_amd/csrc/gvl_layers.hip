@@ -979,7 +979,89 @@ __global__ void __launch_bounds__(64 * kCountWaves) k_count_head(const float *__
   }
 }
 
+// TRAINING form of the pooling alone: pooled[b][c] = max_q hs[b][q][c] and the FIRST row that attains it.  One workgroup per
+// (video, 256 columns): wavefront w pools rows w, w + 16, ... (ascending, strict >: its first maximum), the wavefronts' pairs meet
+// in LDS (equal maxima: the smaller row).
+__global__ void __launch_bounds__(64 * kCountWaves) k_count_pool(const float *__restrict__ hs, int Q, int C,
+                                                                 float *__restrict__ pooled, int *__restrict__ arg) {
+  __shared__ float4 s_m[kCountWaves][64];
+  __shared__ int4 s_a[kCountWaves][64];
+  const int chunks = (C + 255) >> 8;
+  const int b = blockIdx.x / chunks, c4 = (blockIdx.x % chunks) * 64 + (threadIdx.x & 63);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n4 = C >> 2;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  int4 a = make_int4(0, 0, 0, 0);
+  if (c4 < n4) {
+    const float4 *base = reinterpret_cast<const float4 *>(hs + (int64_t)b * Q * C) + c4;
+    for (int q = wave; q < Q; q += 4 * kCountWaves) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qq = q + u * kCountWaves;
+        v[u] = qq < Q ? base[(int64_t)qq * n4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qq = q + u * kCountWaves;
+        if (v[u].x > m.x) { m.x = v[u].x; a.x = qq; }
+        if (v[u].y > m.y) { m.y = v[u].y; a.y = qq; }
+        if (v[u].z > m.z) { m.z = v[u].z; a.z = qq; }
+        if (v[u].w > m.w) { m.w = v[u].w; a.w = qq; }
+      }
+    }
+  }
+  s_m[wave][lane] = m; s_a[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c4 < n4) {
+    for (int w = 1; w < kCountWaves; ++w) {
+      const float4 v = s_m[w][lane];
+      const int4 i = s_a[w][lane];
+      if (v.x > m.x || (v.x == m.x && i.x < a.x)) { m.x = v.x; a.x = i.x; }
+      if (v.y > m.y || (v.y == m.y && i.y < a.y)) { m.y = v.y; a.y = i.y; }
+      if (v.z > m.z || (v.z == m.z && i.z < a.z)) { m.z = v.z; a.z = i.z; }
+      if (v.w > m.w || (v.w == m.w && i.w < a.w)) { m.w = v.w; a.w = i.w; }
+    }
+    reinterpret_cast<float4 *>(pooled + (int64_t)b * C)[c4] = m;
+    reinterpret_cast<int4 *>(arg + (int64_t)b * C)[c4] = a;
+  }
+}
+
+// its gradient, dense: dx[b][q][c] = g[b][c] where q == arg[b][c], 0 elsewhere (one float4 per thread)
+__global__ void __launch_bounds__(256) k_count_pool_bwd(const float4 *__restrict__ g, const int4 *__restrict__ arg, int Q, int n4,
+                                                        int64_t total4, float4 *__restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % n4);
+  const int64_t r = i / n4;
+  const int q = (int)(r % Q);
+  const int64_t bc = (r / Q) * n4 + c4;
+  const float4 v = g[bc];
+  const int4 a = arg[bc];
+  dx[i] = make_float4(a.x == q ? v.x : 0.f, a.y == q ? v.y : 0.f, a.z == q ? v.z : 0.f, a.w == q ? v.w : 0.f);
+}
+
 }  // namespace
+
+extern "C" int gvl_count_pool_f32(const float *hs, int B, int Q, int C, float *pooled, int *arg, void *stream) {
+  if (B < 0 || Q <= 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "gvl_count_pool_f32: bad sizes (C %% 4 == 0)");
+  if (B == 0) return 0;
+  if (!hs || !pooled || !arg || (((uintptr_t)hs | (uintptr_t)pooled | (uintptr_t)arg) & 15))
+    return fail(GVL_EINVAL, "gvl_count_pool_f32: null / unaligned pointer");
+  return gvl::launch(GVL_PROF_LAYER_NORM, B, Q, "k_count_pool", k_count_pool, dim3(B * ((C + 255) / 256)), dim3(64 * kCountWaves), 0,
+                     (hipStream_t)stream, hs, Q, C, pooled, arg);
+}
+
+extern "C" int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, float *grad_hs,
+                                           void *stream) {
+  if (B < 0 || Q <= 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "gvl_count_pool_backward_f32: bad sizes (C %% 4 == 0)");
+  if (B == 0) return 0;
+  if (!grad_pooled || !arg || !grad_hs || (((uintptr_t)grad_pooled | (uintptr_t)arg | (uintptr_t)grad_hs) & 15))
+    return fail(GVL_EINVAL, "gvl_count_pool_backward_f32: null / unaligned pointer");
+  const int64_t total4 = (int64_t)B * Q * (C >> 2);
+  return gvl::launch(GVL_PROF_LAYER_NORM, B, Q, "k_count_pool_bwd", k_count_pool_bwd, dim3((unsigned)((total4 + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, (const float4 *)grad_pooled, (const int4 *)arg, Q, C >> 2, total4,
+                     (float4 *)grad_hs);
+}
 
 extern "C" int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, int B, int Q, int H, float *out,
                                 float *amax_out, void *stream) {

@@ -445,6 +445,48 @@ def count_head(counter, hs):
     return out
 
 
+class _CountPoolTrain(torch.autograd.Function):
+    """max over the queries of hs (B, Q, C) -> (B, C) (pdvc.py:317, `torch.max(hs_lid, dim=1)`) on gvl_count_pool_f32, and its
+    gradient -- the selected row of each column alone -- as ONE dense write (gvl_count_pool_backward_f32) where amax's backward is
+    eq, sum, div and mul over the (B, Q, C) tensor"""
+
+    @staticmethod
+    def forward(ctx, hs):
+        B, Q, C = hs.shape
+        pooled = torch.empty(B, C, device=hs.device, dtype=torch.float32)
+        arg = torch.empty(B, C, device=hs.device, dtype=torch.int32)
+        with torch.cuda.device(hs.device):
+            rc = _lib.lib().gvl_count_pool_f32(hs.data_ptr(), B, Q, C, pooled.data_ptr(), arg.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "count_pool")
+        ctx.save_for_backward(arg)
+        ctx.Q = Q
+        return pooled
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        arg, = ctx.saved_tensors
+        B, C = arg.shape
+        g = g.contiguous()
+        dx = torch.empty(B, ctx.Q, C, device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().gvl_count_pool_backward_f32(g.data_ptr(), arg.data_ptr(), B, ctx.Q, C, dx.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "count_pool_backward")
+        return dx
+
+
+def count_pool_train_eligible(hs):
+    return (hs.is_cuda and hs.dtype == torch.float32 and hs.dim() == 3 and hs.is_contiguous() and hs.shape[-1] % 4 == 0
+            and torch.is_grad_enabled() and hs.requires_grad and not torch.is_autocast_enabled() and hs.data_ptr() % 16 == 0
+            and os.environ.get("GVL_COUNT_POOL", "") != "torch")
+
+
+def count_pool_train(hs):
+    return _CountPoolTrain.apply(hs)
+
+
 def mha_core(qkv, B, Q, H, key_keep=None, amax_out=None):
     """gvl_mha_core_f32: qkv (B*Q, 3*H*64) rows [q | k | v] -> softmax(q k^T / 8) v per head, (B*Q, H*64); key_keep (B, Q)
     bool, True = the key takes part (the complement of nn.MultiheadAttention's key_padding_mask)"""

@@ -232,6 +232,8 @@ class _WgradQueue:
             self.flush()
             MSDA.wgrad(dy, x, am_dy, am_x, grad_w=gw, grad_b=gb, want_bias=want_bias)
             return gw, gb
+        if len(self.items) >= MSDA.wgrad_group_max():                 # (another node may have filled the group exactly: _InProj)
+            self.flush()
         self.seen.update(keys)
         self.items.append((dy, x, am_dy, am_x, gw.detach(), gb.detach() if gb is not None else None))
         if len(self.items) >= MSDA.wgrad_group_max():
@@ -294,7 +296,9 @@ def _operands(weights, biases):
         from .train_planes import TrainPlanes
         cached = owner.__dict__["_gvl_train_planes"] = TrainPlanes(owner.device)
         cached.register([w for w in weights], [b for b in biases])
-    if not cached.is_fresh():
+    # (under stream capture ALWAYS: a forward captured right after an eager one at the same parameter versions would otherwise
+    #  record no refresh, and every replay would multiply by the planes of the capture-time weights)
+    if not cached.is_fresh() or torch.cuda.is_current_stream_capturing():
         with torch.no_grad():
             cached.refresh()
     hit = cached.lookup(weights)

@@ -12,6 +12,7 @@ from torch import nn
 
 from .ms_deform_attn import _power_of_two, offset_bias_init, temporal_shapes_2d
 from ... import MultiScaleDeformableAttention as MSDA
+from ...linear import Linear
 
 
 class MSDeformAttnCap(nn.Module):
@@ -27,7 +28,10 @@ class MSDeformAttnCap(nn.Module):
         qdim = (3 if (opt is not None and vars(opt).get('enable_pos_emb_for_captioner')) else 2) * d_model
         self.sampling_offsets = nn.Linear(qdim, n_heads * n_levels * n_points)
         self.attention_weights = nn.Linear(qdim, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
+        # (gvl_amd Linear: in training at >= 512 rows the hand-written product on the model's operand planes, its weight gradient
+        #  in the backward pass's grouped launch)
+        self.value_proj = Linear(d_model, d_model)
+        self.value_proj.defer_wgrad = True
         self.output_proj = nn.Linear(d_model, d_model)
         self._reset_parameters()
 

@@ -319,6 +319,8 @@ class PDVC(nn.Module):
         from . import layers as _layers
         if _layers.count_head_eligible(counter, hs_lid):
             return _layers.count_head(counter, hs_lid)                  # pooling + Linear in one launch (inference)
+        if _layers.count_pool_train_eligible(hs_lid):
+            return counter(_layers.count_pool_train(hs_lid))            # (training: pooling node with a one-launch gradient)
         return counter(torch.amax(hs_lid, dim=1))
 
     def _layer_heads(self, l_id, hs_lid, reference, disable_refine):

@@ -44,11 +44,13 @@ class _ZeroArena:
 
     def __init__(self):
         self.buf, self.off, self.want, self.cap = None, 0, 0, 0
+        self.snap = None                 # (step_snapshot below)
 
     def reset(self, device):
         self.cap = max(self.cap, self.want)
         self.buf = torch.zeros(self.cap, dtype=torch.float32, device=device) if self.cap else None
         self.off, self.want = 0, 0
+        self.snap = None
 
     def zeros(self, n, device):
         need = (n + 63) // 64 * 64
@@ -89,11 +91,25 @@ def step_zeros(n, device):
     return arena(device).zeros(n, device)
 
 
+def step_snapshot(device):
+    """the step counter's CURRENT value as a tensor of its own, for nodes whose backward must redraw the masks of their forward
+    after the live counter has moved on: one copy per training step (taken at its first use after arena_reset / advance) shared
+    by every such node, a copy per call when no step is open"""
+    device = _norm_device(device)
+    a = arena(device)
+    if a.buf is None:
+        return step_counter(device).clone()
+    if a.snap is None:
+        a.snap = step_counter(device).clone()
+    return a.snap
+
+
 def advance(device):
     """one training forward begins: the dropout masks of its residual chains change (graph-capturable)"""
     if torch.device(device).type != "cuda" or not enabled():
         return
     t = step_counter(device)
+    arena(t.device).snap = None
     with torch.cuda.device(t.device):
         _lib.check(_lib.lib().gvl_advance_step(t.data_ptr(), torch.cuda.current_stream().cuda_stream), "advance_step")
 

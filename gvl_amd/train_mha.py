@@ -112,7 +112,7 @@ class _Core(torch.autograd.Function):
         R = B * Q
         out = torch.empty(R, H * 64, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(B, H, Q, device=qkv.device, dtype=torch.float32)
-        used = step.clone() if step is not None else None        # the step whose masks this forward drew (as train_layers.py)
+        used = TL.step_snapshot(qkv.device) if step is not None else None   # the step whose masks this forward drew
         with torch.cuda.device(qkv.device):
             rc = _lib.lib().gvl_mha_train_forward_f32(
                 qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if keep is not None else None, am[0].data_ptr(), am[1].data_ptr(),

@@ -48,8 +48,9 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 15
+#define GVL_MSDA_ABI_VERSION 16
 /* ABI history (newest first):
+ * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
@@ -271,6 +272,12 @@ int gvl_box_refine_backward_f32(const float *grad_new_ref, const float *new_ref,
                                 float *grad_ref, void *stream);
 int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight, const float *bias, int n_out, float *out,
                        void *stream);
+/*    TRAINING (ABI 16): the pooling of predict_event_num alone (pdvc/pdvc.py:317 `torch.max(hs_lid, dim=1)`) with its argument,
+ *    and its gradient -- pooled (B, C) = max_q hs[b][q][:], arg (B, C) int32 = the first row attaining it; grad_hs (B, Q, C) =
+ *    grad_pooled[b][c] at row arg[b][c], 0 elsewhere (torch.max's gradient: the selected element alone).  The Linear on the pooled
+ *    vector stays with the caller (16 rows). */
+int gvl_count_pool_f32(const float *hs, int B, int Q, int C, float *pooled, int *arg, void *stream);
+int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, float *grad_hs, void *stream);
 
 /* -- fp32 products of the captioner's token loop on the fp16 matrix cores at fp32 accuracy (gvl_gemm16.hip): the
  *    nn.Linear calls `self.logit(output)` (pdvc/CaptioningHead/LSTM_DSA.py:121,165), `h2att(h)` and the two halves of

@@ -240,3 +240,29 @@ def test_box_refine_train_node_equals_the_torch_formulation(RD):
     want.backward(go)
     assert float((delta.grad - d2.grad).abs().max()) <= 1e-6 * max(1.0, float(d2.grad.abs().max()))
     assert float((ref.grad - r2.grad).abs().max()) <= 1e-5 * max(1.0, float(r2.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,Q,C", [(16, 300, 512), (3, 7, 64), (2, 129, 1028), (1, 1, 4), (5, 33, 260)])
+def test_count_pool_train_node_is_torch_max_over_the_queries(B, Q, C):
+    """predict_event_num's pooling (pdvc.py:317 `torch.max(hs_lid, dim=1)`) as one node on gvl_count_pool_f32 /
+    gvl_count_pool_backward_f32: the values bit for bit, the gradient on the selected row of every column alone -- with repeated
+    maxima in some columns (the first such row takes it, the rows' gradients still sum to the incoming one)"""
+    from gvl_amd import layers as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + Q)
+    hs = torch.randn(B, Q, C, device=dev, generator=g)
+    if Q > 4:
+        hs[0, 3, :4] = 9.0
+        hs[0, Q - 1, :4] = 9.0                               # ties: rows 3 and Q - 1
+    hs.requires_grad_()
+    assert L.count_pool_train_eligible(hs)
+    pooled = L.count_pool_train(hs)
+    want_v, want_i = hs.detach().max(dim=1)
+    assert torch.equal(pooled, want_v)
+    go = torch.randn(B, C, device=dev, generator=g)
+    pooled.backward(go)
+    first = (hs.detach() == want_v[:, None, :]).int().argmax(dim=1)          # first row attaining the maximum
+    want_g = torch.zeros_like(hs).scatter_(1, first[:, None, :], go[:, None, :])
+    assert torch.equal(hs.grad, want_g)
+    if Q > 4:
+        assert int(first[0, 0]) == 3

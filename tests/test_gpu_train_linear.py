@@ -237,3 +237,31 @@ def test_deferred_weight_gradients_of_a_train_step_equal_the_immediate_ones():
         assert float((ga[n] - gb[n]).abs().max()) <= tol, (n, float((ga[n] - gb[n]).abs().max()), tol)
     wg = [k for k in tags_a if "wgrad" in k]
     assert wg and sum(tags_b[k] for k in wg) <= sum(tags_a[k] for k in wg) - 10, (tags_a, tags_b)
+
+
+def test_a_captured_forward_of_a_stand_alone_linear_refreshes_its_planes_on_every_replay():
+    """A Linear outside any model's TrainPlanes keeps private operand planes, refreshed when a parameter version moves.  A forward
+    CAPTURED right after an eager forward at the same versions used to record no refresh: every replay then multiplied by the
+    planes of the capture-time weights (found when the captioner's value_proj / ctx2att moved onto this path: data-parallel
+    replicas drifted from the serial step).  Under capture the refresh is always recorded."""
+    from gvl_amd.linear import Linear
+    torch.manual_seed(3)
+    lin = Linear(64, 128).to(DEV)
+    x = torch.randn(768, 64, device=DEV, requires_grad=True)
+    lin(x).sum().backward()                                   # eager: the private planes are built and fresh
+    lin.zero_grad(set_to_none=True)
+    static_x = x.detach().clone().requires_grad_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            y = lin(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.no_grad():
+        lin.weight.mul_(-2.0)                                 # (an optimizer step: in place, version bumped)
+        lin.bias.add_(1.0)
+    g.replay()
+    torch.cuda.synchronize()
+    want = torch.nn.functional.linear(static_x.detach().double(), lin.weight.detach().double(), lin.bias.detach().double())
+    assert float((y.detach().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())

@@ -143,3 +143,8 @@ def test_wgrad_queue_takes_a_second_gradient_of_the_same_parameter_at_once(monke
     q.push(dy, x, am, am, True, [id(torch.nn.Parameter(torch.zeros(1)))])
     q.flush()
     assert calls[-1] == ("single", 1)                          # a lone problem takes the single launch
+    # a group another node filled exactly (train_mha._InProj appends two entries itself) leaves before the next problem joins
+    q.items.extend([(dy, x, am, am, torch.zeros(4, 6), None)] * 3)
+    fresh = torch.nn.Parameter(torch.zeros(1))
+    q.push(dy, x, am, am, True, [id(fresh)])
+    assert calls[-1] == ("group", 3) and len(q.items) == 1
