@@ -140,7 +140,8 @@ def test_wgrad_queue_takes_a_second_gradient_of_the_same_parameter_at_once(monke
     for k in (2, 3, 4):
         q.push(dy, x, am, am, True, [id(w[k])])
     assert calls[-1] == ("group", 3) and q.items == []         # a full group leaves by itself
-    q.push(dy, x, am, am, True, [id(torch.nn.Parameter(torch.zeros(1)))])
+    lone = torch.nn.Parameter(torch.zeros(1))                  # (kept alive: a freed parameter's id() may be handed out again)
+    q.push(dy, x, am, am, True, [id(lone)])
     q.flush()
     assert calls[-1] == ("single", 1)                          # a lone problem takes the single launch
     # a group another node filled exactly (train_mha._InProj appends two entries itself) leaves before the next problem joins
