@@ -110,6 +110,16 @@ class SetCriterionFunction(torch.autograd.Function):
         return (g_logits, g_counts, g_boxes) + (None,) * 16
 
 
+def unbind_tagged(vec):
+    """vec.unbind(0) whose scalars remember where they came from (`_gvl_vec` = (vec, index)): a weighted sum of loss terms can then
+    be ONE dot product with the vector itself (gvl_amd.parallel.TrainStep._forward_loss) -- autograd sees no unbind, whose backward
+    is a zeros() per unused entry and a stack"""
+    parts = vec.unbind(0)
+    for i, t_ in enumerate(parts):
+        t_._gvl_vec = (vec, i)
+    return parts
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, losses, focal_alpha=0.25, focal_gamma=2, opt={}):
         super().__init__()
@@ -233,7 +243,7 @@ class SetCriterion(nn.Module):
             self._tgt_cat[1], self._gt_counts, ccr, num_boxes, self.focal_alpha, self.focal_gamma,
             getattr(self.opt, "lloss_beta", 1), getattr(self.opt, "lloss_gau_mask", 1),
             plan.pair_count if padded else None, num_boxes if isinstance(num_boxes, torch.Tensor) else None)
-        flat = table.flatten().unbind(0)
+        flat = unbind_tagged(table.flatten())
         losses = {}
         for l in range(nl):
             suffix = "" if l == 0 else f"_{l - 1}"

@@ -1040,7 +1040,46 @@ __global__ void __launch_bounds__(256) k_count_pool_bwd(const float4 *__restrict
   dx[i] = make_float4(a.x == q ? v.x : 0.f, a.y == q ? v.y : 0.f, a.z == q ? v.z : 0.f, a.w == q ? v.w : 0.f);
 }
 
+// out[q][h * C + c] = sum_b g_h[b][q][c] for up to four (B, Q, C) gradients g_h: the gradient of a (Q, parts * C) embedding whose
+// column blocks were batch-expanded (one float4 of one part per thread, the B addends loaded together)
+struct BatchSumParams { const float4 *g[4]; };
+__global__ void __launch_bounds__(256) k_batch_sum(const BatchSumParams p, int parts, int B, int64_t qc4, int c4n,
+                                                   float4 *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // over (part, q, c4)
+  if (i >= qc4 * parts) return;
+  const int h = (int)(i / qc4);
+  const int64_t r = i % qc4;
+  const float4 *g = p.g[h];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g)
+    for (int b = 0; b < B; b += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = b + u < B ? g[(int64_t)(b + u) * qc4 + r] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+  const int64_t q = r / c4n;
+  const int c4 = (int)(r % c4n);
+  out[(q * parts + h) * c4n + c4] = acc;
+}
+
 }  // namespace
+
+extern "C" int gvl_batch_sum_f32(const float *const *grads, int parts, int B, int Q, int C, float *out, void *stream) {
+  if (parts < 1 || parts > 4 || B <= 0 || Q < 0 || C <= 0 || (C & 3))
+    return fail(GVL_EINVAL, "gvl_batch_sum_f32: 1..4 parts, C %% 4 == 0 (got parts=%d B=%d Q=%d C=%d)", parts, B, Q, C);
+  if (Q == 0) return 0;
+  if (!grads || !out || ((uintptr_t)out & 15)) return fail(GVL_EINVAL, "gvl_batch_sum_f32: null / unaligned pointer");
+  BatchSumParams p{};
+  for (int h = 0; h < parts; ++h) {
+    if ((uintptr_t)grads[h] & 15) return fail(GVL_EINVAL, "gvl_batch_sum_f32: gradient %d is not 16-byte aligned", h);
+    p.g[h] = (const float4 *)grads[h];
+  }
+  const int64_t qc4 = (int64_t)Q * (C >> 2);
+  return gvl::launch(GVL_PROF_LAYER_NORM, Q, B, "k_batch_sum", k_batch_sum, dim3((unsigned)((qc4 * parts + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, p, parts, B, qc4, C >> 2, (float4 *)out);
+}
 
 extern "C" int gvl_count_pool_f32(const float *hs, int B, int Q, int C, float *pooled, int *arg, void *stream) {
   if (B < 0 || Q <= 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "gvl_count_pool_f32: bad sizes (C %% 4 == 0)");

@@ -329,9 +329,12 @@ class DeformableTransformer(nn.Module):
     def prepare_decoder_input_query(self, memory, query_embed):
         """:128-135 -- query_embed (Q, 2C) is chunked into (query_pos, tgt) in that order."""
         bs = memory.shape[0]
-        query_pos, tgt = torch.chunk(query_embed, 2, dim=1)
-        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
-        tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
+        pos_rows, tgt = torch.chunk(query_embed, 2, dim=1)
+        if _layers.expand_parts_eligible(query_embed, 2):
+            query_pos, tgt = _layers.expand_parts(query_embed, bs, 2)          # (training: the two gradients batch-summed in one launch)
+        else:
+            query_pos = pos_rows.unsqueeze(0).expand(bs, -1, -1)
+            tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
         if not torch.is_grad_enabled() and query_embed.is_cuda and isinstance(self.reference_points, nn.Linear):
             # inference: sigmoid(reference_points(query_pos)) depends on parameters only -- kept until one of them changes (the
             # reference evaluates the Linear on the batch-expanded rows: the same arithmetic per row)
@@ -346,7 +349,7 @@ class DeformableTransformer(nn.Module):
         else:
             # (training: the Linear on the Q rows of the embedding, THEN the batch expansion -- the same arithmetic per row as the
             #  reference's Linear over the batch-expanded rows, without materialising them and their gradient)
-            reference_points = self.reference_points(query_pos[0]).sigmoid().unsqueeze(0).expand(bs, -1, -1)
+            reference_points = self.reference_points(pos_rows).sigmoid().unsqueeze(0).expand(bs, -1, -1)
         return reference_points, tgt, reference_points, query_pos
 
     def prepare_decoder_input_proposal(self, gt_reference_points, inversed_input=False):

@@ -477,6 +477,45 @@ class _CountPoolTrain(torch.autograd.Function):
         return dx
 
 
+class _ExpandParts(torch.autograd.Function):
+    """the column blocks of an embedding (Q, parts * C), each expanded over the batch -> parts views (B, Q, C) (batch stride 0, as
+    `chunk(...)[h].unsqueeze(0).expand(B, -1, -1)` of deformable_transformer.py:128-135); their gradients are summed over the
+    batch into the embedding's in ONE launch (gvl_batch_sum_f32) where expand's backward is a sum(0) per block -- 28 us each at
+    (16, 300, 512) -- and a cat"""
+
+    @staticmethod
+    def forward(ctx, embed, B, parts):
+        Q, PC = embed.shape
+        C = PC // parts
+        ctx.cfg = (B, parts, Q, C)
+        ctx.set_materialize_grads(False)
+        return tuple(embed[:, h * C:(h + 1) * C].unsqueeze(0).expand(B, -1, -1) for h in range(parts))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        import ctypes
+        B, parts, Q, C = ctx.cfg
+        grads = [g.contiguous() if g is not None else None for g in grads]
+        ref = next(g for g in grads if g is not None)
+        out = torch.empty(Q, parts * C, device=ref.device, dtype=torch.float32)
+        ptrs = (ctypes.c_void_p * parts)(*[g.data_ptr() if g is not None else None for g in grads])
+        with torch.cuda.device(ref.device):
+            rc = _lib.lib().gvl_batch_sum_f32(ptrs, parts, B, Q, C, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "batch_sum")
+        return out, None, None
+
+
+def expand_parts_eligible(embed, parts):
+    return (embed.is_cuda and embed.dtype == torch.float32 and embed.dim() == 2 and embed.is_contiguous()
+            and torch.is_grad_enabled() and embed.requires_grad and not torch.is_autocast_enabled()
+            and embed.shape[1] % (4 * parts) == 0 and os.environ.get("GVL_EXPAND_PARTS", "") != "torch")
+
+
+def expand_parts(embed, B, parts):
+    return _ExpandParts.apply(embed, B, parts)
+
+
 def count_pool_train_eligible(hs):
     return (hs.is_cuda and hs.dtype == torch.float32 and hs.dim() == 3 and hs.is_contiguous() and hs.shape[-1] % 4 == 0
             and torch.is_grad_enabled() and hs.requires_grad and not torch.is_autocast_enabled() and hs.data_ptr() % 16 == 0

@@ -21,7 +21,7 @@ from torch import nn
 
 from .base_encoder import build_base_encoder
 from .CaptioningHead import build_captioner
-from .criterion import SetCriterion
+from .criterion import SetCriterion, unbind_tagged
 from .deformable_transformer import build_deforamble_transformer, inverse_sigmoid
 from .linear import Linear
 from .matcher import build_matcher
@@ -573,7 +573,7 @@ class PDVC(nn.Module):
         # (a batch without a single event: every row is masked, the sum is exactly 0 -- 0 / 1, not 0 / 0: a NaN here would
         #  flow through clip_grad_norm_ into the captured Adam and poison parameters and moments for good)
         per_layer = row_loss.view(nl, R).sum(dim=1) / denom
-        return per_layer.unbind(0), {}, pt.cap_tensor[plan.vid_of_entry, matches[-1].t.clamp(min=0)]
+        return unbind_tagged(per_layer), {}, pt.cap_tensor[plan.vid_of_entry, matches[-1].t.clamp(min=0)]
 
     def caption_prediction_layers(self, cap_head, dt, hs_layers, ref_layers, others, matches):
         """caption_prediction for all decoder layers at once (shared head): the matched queries of layer k of video v
@@ -615,7 +615,7 @@ class PDVC(nn.Module):
         cap_prob = cap_head(hs_m, ref_m, others, seq_flat, steps=steps, nll=(seq_flat[:, 1:], mask_flat[:, 1:]))
         row_loss = cap_head.build_loss(cap_prob, seq_flat[:, 1:], mask_flat[:, 1:])
         per_layer = row_loss.view(N_, nl, mp).mean(dim=(0, 2))
-        return per_layer.unbind(0), {}, dt['cap_tensor'][matches[-1].t_global]
+        return unbind_tagged(per_layer), {}, dt['cap_tensor'][matches[-1].t_global]
 
     def caption_prediction(self, cap_head, dt, hs, reference, others, indices):
         """Teacher-forced caption loss on the matched (query, caption) pairs (pdvc.py:743-884, 'standard' head):

@@ -50,7 +50,8 @@ extern "C" {
 
 #define GVL_MSDA_ABI_VERSION 16
 /* ABI history (newest first):
- * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training)
+ * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training),
+ *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
@@ -277,6 +278,11 @@ int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight
  *    grad_pooled[b][c] at row arg[b][c], 0 elsewhere (torch.max's gradient: the selected element alone).  The Linear on the pooled
  *    vector stays with the caller (16 rows). */
 int gvl_count_pool_f32(const float *hs, int B, int Q, int C, float *pooled, int *arg, void *stream);
+/*    gvl_batch_sum_f32 (ABI 16): the gradient of the query embedding (Q, parts * C) whose column blocks the decoder expands over
+ *    the batch (pdvc/deformable_transformer.py:128-135: query_pos, tgt = chunk(query_embed), each .expand(bs, -1, -1)):
+ *    out[q][h * C + c] = sum_b grads[h][b][q][c], grads: `parts` (1..4) host-side pointers to contiguous (B, Q, C) tensors (NULL =
+ *    no gradient reached that block: zeros). */
+int gvl_batch_sum_f32(const float *const *grads, int parts, int B, int Q, int C, float *out, void *stream);
 int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, float *grad_hs, void *stream);
 
 /* -- fp32 products of the captioner's token loop on the fp16 matrix cores at fp32 accuracy (gvl_gemm16.hip): the

@@ -266,3 +266,29 @@ def test_count_pool_train_node_is_torch_max_over_the_queries(B, Q, C):
     assert torch.equal(hs.grad, want_g)
     if Q > 4:
         assert int(first[0, 0]) == 3
+
+
+@pytest.mark.parametrize("B,Q,C,parts", [(16, 300, 512, 2), (3, 7, 8, 2), (1, 5, 4, 1), (9, 33, 36, 3)])
+def test_expand_parts_node_is_chunk_expand_with_a_one_launch_gradient(B, Q, C, parts):
+    """query_pos, tgt = chunk(query_embed), each .expand(bs, -1, -1) (deformable_transformer.py:128-135) as one node: the same
+    stride-0 views forward, the embedding's gradient = the blocks' gradients summed over the batch (gvl_batch_sum_f32), also when
+    no gradient reaches one block"""
+    from gvl_amd import layers as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(B + Q)
+    emb = torch.randn(Q, parts * C, device=dev, generator=g, requires_grad=True)
+    assert L.expand_parts_eligible(emb, parts)
+    outs = L.expand_parts(emb, B, parts)
+    ref = emb.detach().clone().requires_grad_()
+    want = [c.unsqueeze(0).expand(B, -1, -1) for c in torch.chunk(ref, parts, dim=1)]
+    for o, w_ in zip(outs, want):
+        assert o.shape == w_.shape and o.stride() == w_.stride() and torch.equal(o, w_)
+    ws = [torch.randn(B, Q, C, device=dev, generator=g) for _ in range(parts)]
+    sum((o * w_).sum() for o, w_ in zip(outs, ws)).backward()
+    sum((o * w_).sum() for o, w_ in zip(want, ws)).backward()
+    assert float((emb.grad - ref.grad).abs().max()) <= 1e-5 * float(ref.grad.abs().max())
+    if parts > 1:                                             # only the last block is used
+        emb.grad = None
+        L.expand_parts(emb, B, parts)[-1].mul(ws[-1]).sum().backward()
+        assert float(emb.grad[:, :(parts - 1) * C].abs().max()) == 0.0
+        assert float((emb.grad[:, (parts - 1) * C:] - ws[-1].sum(0)).abs().max()) <= 1e-5 * float(ws[-1].sum(0).abs().max())

@@ -28,6 +28,7 @@ class Sites(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.count = collections.Counter()
+        self.order = []
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.__name__.split(".")[0]
@@ -43,6 +44,12 @@ class Sites(TorchDispatchMode):
                     shape = "x".join(map(str, a.shape))
                     break
             self.count[(PHASE[0], site, name, shape)] += 1
+            if PHASE[0] == "backward" and not name.startswith(("empty", "new_empty")):
+                shapes = ["x".join(map(str, a.shape)) for a in args if isinstance(a, torch.Tensor)]
+                rest = [a for a in args if (isinstance(a, int) and not isinstance(a, bool)) or (isinstance(a, (list, tuple)) and all(isinstance(e, int) for e in a))][:2]
+                if name in ('stack', 'cat') and args and isinstance(args[0], (list, tuple)):
+                    shapes = ['x'.join(map(str, t_.shape)) for t_ in args[0]]
+                self.order.append(f"{name:24s} {' | '.join(shapes):60s} {rest} {site}")
         return func(*args, **(kwargs or {}))
 
 
@@ -102,3 +109,6 @@ for phase in ("backward", "optimizer"):
             agg[(name, shape)] += n
     for (name, shape), n in agg.most_common(60):
         print(f"  {name:28s} {shape:24s} {n:4d}")
+print("backward in order (no empties):")
+for i, l in enumerate(s.order):
+    print(f"  {i:4d} {l}")
