@@ -113,15 +113,17 @@ class MSDeformAttnFusedFunction(Function):
     location arithmetic and their backward live inside the HIP kernels; loc / attn never exist in HBM."""
 
     @staticmethod
-    def forward(ctx, value, proj, reference_points, spatial_shapes, level_start_index, n_levels, n_points, pad_mode):
+    def forward(ctx, value, proj, reference_points, spatial_shapes, level_start_index, n_levels, n_points, pad_mode,
+                want_amax=False):
         ctx.cfg = (n_levels, n_points, pad_mode)
         ctx.host = MSDA.host_shapes(spatial_shapes, level_start_index)
         ctx.in_dtypes = (proj.dtype, reference_points.dtype)
         proj = _like(proj, value.dtype)                              # bf16 value <-> bf16 projection rows
         reference_points = _like(reference_points, torch.float32)    # positions are never rounded to bf16
-        # fp32: the kernel also leaves max |out row| (one atomic max per row and head) -- the row scale output_proj's split needs
+        # fp32, want_amax (the caller is a training forward; grad mode is OFF in here whatever the caller's, so it cannot be asked):
+        # the kernel also leaves max |out row| (one atomic max per row and head) -- the row scale output_proj's split needs
         amax = None
-        if value.dtype == torch.float32 and torch.is_grad_enabled():
+        if value.dtype == torch.float32 and want_amax:
             from ... import train_layers as _tl
             amax = _tl.step_zeros(proj.shape[0] * proj.shape[1], value.device)
         out = MSDA.msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, reference_points, n_levels,
@@ -143,7 +145,7 @@ class MSDeformAttnFusedFunction(Function):
         gv, gp, gr = MSDA.msda1d_fused_backward(value, shapes, lsi, proj, ref,
                                                 _like(grad_output, value.dtype).contiguous(), n_levels, n_points,
                                                 pad_mode, need_ref_grad=ctx.needs_input_grad[2])
-        return gv, _like(gp, ctx.in_dtypes[0]), _like(gr, ctx.in_dtypes[1]), None, None, None, None, None
+        return gv, _like(gp, ctx.in_dtypes[0]), _like(gr, ctx.in_dtypes[1]), None, None, None, None, None, None
 
 
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights, return_value=False):

@@ -143,7 +143,9 @@ class MSDeformAttn(nn.Module):
             w_cat, b_cat = self._cat_projection()
             proj = projection(q, w_cat, b_cat)
         out, amax = _fn.MSDeformAttnFusedFunction.apply(value, proj, reference_points.contiguous(), shapes2d,
-                                                        level_start_index, self.n_levels, self.n_points, self.pad_mode)
+                                                        level_start_index, self.n_levels, self.n_points, self.pad_mode,
+                                                        torch.is_grad_enabled() and train_linear_eligible(
+                                                            query, (self.output_proj.weight,), (self.output_proj.bias,)))
         if amax is not None:
             from ... import layers as _layers
             _layers.tag_amax(out, amax)

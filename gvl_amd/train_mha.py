@@ -112,21 +112,24 @@ class _Core(torch.autograd.Function):
         R = B * Q
         out = torch.empty(R, H * 64, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(B, H, Q, device=qkv.device, dtype=torch.float32)
+        am_o = TL.step_zeros(R, qkv.device)                     # max |out row|: the row scale of the out-projection behind it
         used = TL.step_snapshot(qkv.device) if step is not None else None   # the step whose masks this forward drew
         with torch.cuda.device(qkv.device):
             rc = _lib.lib().gvl_mha_train_forward_f32(
                 qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if keep is not None else None, am[0].data_ptr(), am[1].data_ptr(),
                 B, Q, H, float(p), int(seed), used.data_ptr() if used is not None else None, out.data_ptr(), lse.data_ptr(),
-                None, torch.cuda.current_stream().cuda_stream)
+                am_o.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mha_train_forward")
         ctx.save_for_backward(qkv, am, keep if keep is not None else qkv.new_empty(0), out, lse,
                               used if used is not None else qkv.new_empty(0))
         ctx.cfg = (B, Q, H, float(p), int(seed), keep is not None, used is not None)
-        return out
+        ctx.mark_non_differentiable(am_o)
+        ctx.set_materialize_grads(False)
+        return out, am_o
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dam=None):
         qkv, am, keep, out, lse, used = ctx.saved_tensors
         B, Q, H, p, seed, has_keep, has_step = ctx.cfg
         dout = dout.contiguous()
@@ -171,7 +174,9 @@ def self_attention(mha, tgt, query_pos, query_mask):
     site = mha.__dict__.get("_gvl_site_drop")
     if site is None:
         site = mha.__dict__["_gvl_site_drop"] = torch.nn.Dropout(mha.dropout)
-    o = _Core.apply(qkv, am, keep, B, Q, mha.num_heads, p, TL._site_seed(site), TL.step_counter(tgt.device) if p > 0 else None)
+    o, am_o = _Core.apply(qkv, am, keep, B, Q, mha.num_heads, p, TL._site_seed(site),
+                          TL.step_counter(tgt.device) if p > 0 else None)
+    L.tag_amax(o, am_o)
     ob = mha.out_proj.bias
     if GL.train_linear_eligible(o, (mha.out_proj.weight,), (ob,)):
         return GL.train_linear(o, (mha.out_proj.weight,), (ob,), defer).view(B, Q, C)
