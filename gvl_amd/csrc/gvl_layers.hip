@@ -1026,18 +1026,30 @@ __global__ void __launch_bounds__(64 * kCountWaves) k_count_pool(const float *__
   }
 }
 
-// its gradient, dense: dx[b][q][c] = g[b][c] where q == arg[b][c], 0 elsewhere (one float4 per thread)
+// its gradient, dense: dx[b][q][c] = g[b][c] where q == arg[b][c], 0 elsewhere (one float4 per thread) -- plus, when given, the
+// input gradient of a ONE-output Linear on the same rows (the class head: g_row[b][q] w_row[c]), so that the two heads' gradients
+// reach hs as one tensor
 __global__ void __launch_bounds__(256) k_count_pool_bwd(const float4 *__restrict__ g, const int4 *__restrict__ arg, int Q, int n4,
-                                                        int64_t total4, float4 *__restrict__ dx) {
+                                                        int64_t total4, const float *__restrict__ g_row,
+                                                        const float4 *__restrict__ w_row, float4 *__restrict__ dx) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int c4 = (int)(i % n4);
   const int64_t r = i / n4;
   const int q = (int)(r % Q);
   const int64_t bc = (r / Q) * n4 + c4;
-  const float4 v = g[bc];
-  const int4 a = arg[bc];
-  dx[i] = make_float4(a.x == q ? v.x : 0.f, a.y == q ? v.y : 0.f, a.z == q ? v.z : 0.f, a.w == q ? v.w : 0.f);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g) {
+    const float4 v = g[bc];
+    const int4 a = arg[bc];
+    o = make_float4(a.x == q ? v.x : 0.f, a.y == q ? v.y : 0.f, a.z == q ? v.z : 0.f, a.w == q ? v.w : 0.f);
+  }
+  if (g_row) {
+    const float s = g_row[r];
+    const float4 w = w_row[c4];
+    o.x = fmaf(s, w.x, o.x); o.y = fmaf(s, w.y, o.y); o.z = fmaf(s, w.z, o.z); o.w = fmaf(s, w.w, o.w);
+  }
+  dx[i] = o;
 }
 
 // out[q][h * C + c] = sum_b g_h[b][q][c] for up to four (B, Q, C) gradients g_h: the gradient of a (Q, parts * C) embedding whose
@@ -1090,16 +1102,17 @@ extern "C" int gvl_count_pool_f32(const float *hs, int B, int Q, int C, float *p
                      (hipStream_t)stream, hs, Q, C, pooled, arg);
 }
 
-extern "C" int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, float *grad_hs,
-                                           void *stream) {
+extern "C" int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, const float *grad_row,
+                                           const float *w_row, float *grad_hs, void *stream) {
   if (B < 0 || Q <= 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "gvl_count_pool_backward_f32: bad sizes (C %% 4 == 0)");
   if (B == 0) return 0;
-  if (!grad_pooled || !arg || !grad_hs || (((uintptr_t)grad_pooled | (uintptr_t)arg | (uintptr_t)grad_hs) & 15))
+  if ((grad_pooled && !arg) || (grad_row && !w_row) || !grad_hs ||
+      (((uintptr_t)grad_pooled | (uintptr_t)arg | (uintptr_t)grad_hs | (uintptr_t)w_row) & 15))
     return fail(GVL_EINVAL, "gvl_count_pool_backward_f32: null / unaligned pointer");
   const int64_t total4 = (int64_t)B * Q * (C >> 2);
   return gvl::launch(GVL_PROF_LAYER_NORM, B, Q, "k_count_pool_bwd", k_count_pool_bwd, dim3((unsigned)((total4 + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, (const float4 *)grad_pooled, (const int4 *)arg, Q, C >> 2, total4,
-                     (float4 *)grad_hs);
+                     dim3(256), 0, (hipStream_t)stream, (const float4 *)grad_pooled, (const int4 *)arg, Q, C >> 2, total4, grad_row,
+                     (const float4 *)w_row, (float4 *)grad_hs);
 }
 
 extern "C" int gvl_mha_core_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, int B, int Q, int H, float *out,

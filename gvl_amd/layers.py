@@ -471,10 +471,69 @@ class _CountPoolTrain(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty(B, ctx.Q, C, device=g.device, dtype=torch.float32)
         with torch.cuda.device(g.device):
-            rc = _lib.lib().gvl_count_pool_backward_f32(g.data_ptr(), arg.data_ptr(), B, ctx.Q, C, dx.data_ptr(),
+            rc = _lib.lib().gvl_count_pool_backward_f32(g.data_ptr(), arg.data_ptr(), B, ctx.Q, C, None, None, dx.data_ptr(),
                                                         torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "count_pool_backward")
         return dx
+
+
+class _ClassCountHeads(torch.autograd.Function):
+    """the two heads that read hs (B, Q, C) row by row without a matrix product worth the name -- the single-class head
+    (pdvc.py:455: Linear(C, 1)) and the count head's pooling (pdvc.py:317) -- as ONE node: (logits (B, Q, 1), pooled (B, C)).
+    Backward: both input gradients leave as one tensor from one launch (gvl_count_pool_backward_f32 with grad_row / w_row) where
+    the class head's alone is a rank-1 product written out (9.8 MB at cfg A) and added to the pooling's by autograd."""
+
+    @staticmethod
+    def forward(ctx, hs, weight, bias):
+        B, Q, C = hs.shape
+        logits = torch.addmm(bias, hs.view(B * Q, C), weight.t()).view(B, Q, 1) if bias is not None \
+            else torch.mm(hs.view(B * Q, C), weight.t()).view(B, Q, 1)
+        pooled = torch.empty(B, C, device=hs.device, dtype=torch.float32)
+        arg = torch.empty(B, C, device=hs.device, dtype=torch.int32)
+        with torch.cuda.device(hs.device):
+            rc = _lib.lib().gvl_count_pool_f32(hs.data_ptr(), B, Q, C, pooled.data_ptr(), arg.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "count_pool")
+        ctx.save_for_backward(hs, weight, arg)
+        ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)
+        return logits, pooled
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_logits, g_pooled):
+        hs, weight, arg = ctx.saved_tensors
+        B, Q, C = hs.shape
+        if g_logits is None and g_pooled is None:
+            return None, None, None
+        gl = g_logits.contiguous() if g_logits is not None else None
+        gp = g_pooled.contiguous() if g_pooled is not None else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, Q, C, device=hs.device, dtype=torch.float32)
+            with torch.cuda.device(hs.device):
+                rc = _lib.lib().gvl_count_pool_backward_f32(
+                    gp.data_ptr() if gp is not None else None, arg.data_ptr(), B, Q, C, gl.data_ptr() if gl is not None else None,
+                    weight.data_ptr() if gl is not None else None, dx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "count_pool_backward")
+        gw = gb = None
+        if gl is not None:
+            if ctx.needs_input_grad[1]:
+                gw = torch.mm(gl.view(1, B * Q), hs.view(B * Q, C))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = gl.sum().view(1)
+        return dx, gw, gb
+
+
+def class_count_heads_eligible(class_head, hs):
+    return (count_pool_train_eligible(hs) and isinstance(class_head, torch.nn.Linear) and class_head.out_features == 1
+            and class_head.weight.dtype == torch.float32 and class_head.weight.is_contiguous()
+            and class_head.weight.data_ptr() % 16 == 0 and os.environ.get("GVL_CLASS_COUNT_HEADS", "") != "torch")
+
+
+def class_count_heads(class_head, hs):
+    """-> (class logits (B, Q, 1), max over the queries (B, C))"""
+    return _ClassCountHeads.apply(hs, class_head.weight, class_head.bias)
 
 
 class _ExpandParts(torch.autograd.Function):

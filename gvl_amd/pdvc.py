@@ -26,6 +26,7 @@ from .deformable_transformer import build_deforamble_transformer, inverse_sigmoi
 from .linear import Linear
 from .matcher import build_matcher
 from .postprocess import PostProcess
+from . import layers as _layers_mod
 from . import train_layers as _train_layers
 
 _NO_DROP = nn.Dropout(0.0)
@@ -335,8 +336,13 @@ class PDVC(nn.Module):
             not torch.is_grad_enabled() or os.environ.get("GVL_SHARE_COORDS", "1") != "0")
         shared = {k: (dec.get("_gvl_" + k) if take else None) for k in ("cls", "coords", "deltas")}
         same = lambda t_: t_ is not None and t_[l_id].shape[:2] == hs_lid.shape[:2]          # noqa: E731
-        cls = shared["cls"][l_id] if same(shared["cls"]) else self.class_head[l_id](hs_lid)
-        cnt = self.predict_event_num(self.count_head[l_id], hs_lid)
+        if not same(shared["cls"]) and _layers_mod.class_count_heads_eligible(self.class_head[l_id], hs_lid):
+            # training, one class: the class head and the count head's pooling as one node (their gradients reach hs together)
+            cls, pooled = _layers_mod.class_count_heads(self.class_head[l_id], hs_lid)
+            cnt = self.count_head[l_id](pooled)
+        else:
+            cls = shared["cls"][l_id] if same(shared["cls"]) else self.class_head[l_id](hs_lid)
+            cnt = self.predict_event_num(self.count_head[l_id], hs_lid)
         if same(shared["coords"]):
             return cls, cnt, shared["coords"][l_id]
         delta = shared["deltas"][l_id] if same(shared["deltas"]) else self.bbox_head[l_id](hs_lid)

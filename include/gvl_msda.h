@@ -276,14 +276,17 @@ int gvl_count_head_f32(const float *hs, int B, int Q, int C, const float *weight
 /*    TRAINING (ABI 16): the pooling of predict_event_num alone (pdvc/pdvc.py:317 `torch.max(hs_lid, dim=1)`) with its argument,
  *    and its gradient -- pooled (B, C) = max_q hs[b][q][:], arg (B, C) int32 = the first row attaining it; grad_hs (B, Q, C) =
  *    grad_pooled[b][c] at row arg[b][c], 0 elsewhere (torch.max's gradient: the selected element alone).  The Linear on the pooled
- *    vector stays with the caller (16 rows). */
+ *    vector stays with the caller (16 rows).  grad_row (B Q) + w_row (C), both or neither: the input gradient of a ONE-output
+ *    Linear on the same rows (the class head of a single-class config, pdvc/pdvc.py:455) is added, grad_row[b][q] w_row[c];
+ *    grad_pooled may then be NULL. */
 int gvl_count_pool_f32(const float *hs, int B, int Q, int C, float *pooled, int *arg, void *stream);
 /*    gvl_batch_sum_f32 (ABI 16): the gradient of the query embedding (Q, parts * C) whose column blocks the decoder expands over
  *    the batch (pdvc/deformable_transformer.py:128-135: query_pos, tgt = chunk(query_embed), each .expand(bs, -1, -1)):
  *    out[q][h * C + c] = sum_b grads[h][b][q][c], grads: `parts` (1..4) host-side pointers to contiguous (B, Q, C) tensors (NULL =
  *    no gradient reached that block: zeros). */
 int gvl_batch_sum_f32(const float *const *grads, int parts, int B, int Q, int C, float *out, void *stream);
-int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, float *grad_hs, void *stream);
+int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, const float *grad_row,
+                                const float *w_row, float *grad_hs, void *stream);
 
 /* -- fp32 products of the captioner's token loop on the fp16 matrix cores at fp32 accuracy (gvl_gemm16.hip): the
  *    nn.Linear calls `self.logit(output)` (pdvc/CaptioningHead/LSTM_DSA.py:121,165), `h2att(h)` and the two halves of

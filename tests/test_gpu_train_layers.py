@@ -292,3 +292,33 @@ def test_expand_parts_node_is_chunk_expand_with_a_one_launch_gradient(B, Q, C, p
         L.expand_parts(emb, B, parts)[-1].mul(ws[-1]).sum().backward()
         assert float(emb.grad[:, :(parts - 1) * C].abs().max()) == 0.0
         assert float((emb.grad[:, (parts - 1) * C:] - ws[-1].sum(0)).abs().max()) <= 1e-5 * float(ws[-1].sum(0).abs().max())
+
+
+@pytest.mark.parametrize("B,Q,C", [(16, 300, 512), (2, 9, 64)])
+def test_class_and_count_heads_node_equals_linear_and_max(B, Q, C):
+    """class head (Linear(C, 1), pdvc.py:455) + the count head's pooling (pdvc.py:317) as one node: values and every gradient
+    against the PyTorch formulation, also when only one of the two outputs is used"""
+    from gvl_amd import layers as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B)
+    head = torch.nn.Linear(C, 1).to(dev)
+    hs = torch.randn(B, Q, C, device=dev, requires_grad=True)
+    assert L.class_count_heads_eligible(head, hs)
+    for use in ((True, True), (True, False), (False, True)):
+        hs.grad = None
+        head.zero_grad(set_to_none=True)
+        logits, pooled = L.class_count_heads(head, hs)
+        ref_h = hs.detach().clone().requires_grad_()
+        ref_head = torch.nn.Linear(C, 1).to(dev)
+        ref_head.load_state_dict(head.state_dict())
+        want_l, want_p = ref_head(ref_h), ref_h.max(dim=1)[0]
+        assert float((logits - want_l).abs().max()) <= 1e-5 and torch.equal(pooled, want_p)
+        gl, gp = torch.randn_like(want_l), torch.randn_like(want_p)
+        loss = (logits * gl).sum() * use[0] + (pooled * gp).sum() * use[1]
+        want = (want_l * gl).sum() * use[0] + (want_p * gp).sum() * use[1]
+        loss.backward()
+        want.backward()
+        assert float((hs.grad - ref_h.grad).abs().max()) <= 1e-5 * max(1.0, float(ref_h.grad.abs().max()))
+        if use[0]:
+            assert float((head.weight.grad - ref_head.weight.grad).abs().max()) <= 2e-4 * float(ref_head.weight.grad.abs().max())
+            assert float((head.bias.grad - ref_head.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(ref_head.bias.grad.abs().max()))
