@@ -87,16 +87,20 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_ffn(self, src, pos=None):
+    def forward_ffn(self, src, pos=None, resid=None):
         # (norm(x + dropout(sub)): one hand-written forward / backward kernel in training, gvl_amd/train_layers.py; `pos`: the
-        #  result also carries the row maxima of result + pos for the next layer's attention query)
-        return _tl.residual_dropout_norm(src, self.linear2(_tl.relu_dropout(self.linear1(src), self.activation, self.dropout2)),
+        #  result also carries the row maxima of result + pos for the next layer's attention query.  resid: the handle of `src` the
+        #  residual reads -- see residual_dropout_norm(fan=2))
+        return _tl.residual_dropout_norm(src if resid is None else resid,
+                                         self.linear2(_tl.relu_dropout(self.linear1(src), self.activation, self.dropout2)),
                                          self.dropout3, self.norm2, pos)
 
     def forward(self, src, pos, reference_points, temporal_shapes, level_start_index, padding_mask=None):
         attn = self.self_attn(_tl.add_pos(src, pos), reference_points, src, temporal_shapes,
                               level_start_index, padding_mask)
-        return self.forward_ffn(_tl.residual_dropout_norm(src, attn, self.dropout1, self.norm1), pos)
+        # (two handles of norm1's result, for the FFN and for the residual around it: their gradients meet inside norm1's backward)
+        a, b = _tl.residual_dropout_norm(src, attn, self.dropout1, self.norm1, fan=2)
+        return self.forward_ffn(a, pos, resid=b)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -155,8 +159,9 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_ffn(self, tgt, pos=None):
-        return _tl.residual_dropout_norm(tgt, self.linear2(_tl.relu_dropout(self.linear1(tgt), self.activation, self.dropout3)),
+    def forward_ffn(self, tgt, pos=None, resid=None):
+        return _tl.residual_dropout_norm(tgt if resid is None else resid,
+                                         self.linear2(_tl.relu_dropout(self.linear1(tgt), self.activation, self.dropout3)),
                                          self.dropout4, self.norm3, pos)
 
     def forward(self, tgt, query_pos, reference_points, src, src_temporal_shapes, level_start_index,
@@ -173,11 +178,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
             # (average_attn_weights=False: the unfused path without the mean over the heads of a (B, 8, Q, Q) map nobody reads)
             sa = self.self_attn(qk, qk, tgt.transpose(0, 1), key_padding_mask=~query_mask, need_weights=self.training,
                                 average_attn_weights=False)[0].transpose(0, 1)
-        tgt = _tl.residual_dropout_norm(tgt, sa, self.dropout2, self.norm2, query_pos)   # (sa: a transposed view, read in place)
-        ca = self.cross_attn(_tl.add_pos(tgt, query_pos), reference_points, src, src_temporal_shapes,
+        # (sa: a transposed view, read in place.  Two handles of each norm's result -- one for the sublayer that follows, one for
+        #  the residual around it: residual_dropout_norm(fan=2))
+        tq, tr = _tl.residual_dropout_norm(tgt, sa, self.dropout2, self.norm2, query_pos, fan=2)
+        ca = self.cross_attn(_tl.add_pos(tq, query_pos), reference_points, src, src_temporal_shapes,
                              level_start_index, src_padding_mask)
-        tgt = _tl.residual_dropout_norm(tgt, ca, self.dropout1, self.norm1)
-        return self.forward_ffn(tgt, query_pos)
+        tf, tr = _tl.residual_dropout_norm(tr, ca, self.dropout1, self.norm1, fan=2)
+        return self.forward_ffn(tf, query_pos, resid=tr)
 
 
 class DeformableTransformerDecoder(nn.Module):

@@ -141,7 +141,7 @@ def _pos_strides(pos, B, Q, C):
 
 class ResidualDropoutLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, sub, weight, bias, eps, p, seed, step, pos):
+    def forward(ctx, x, sub, weight, bias, eps, p, seed, step, pos, fan=1):
         from . import layers as L
         B, Q, C = x.shape
         R = B * Q
@@ -164,15 +164,21 @@ class ResidualDropoutLayerNorm(torch.autograd.Function):
         ctx.p, ctx.seed, ctx.has_step = float(p), int(seed), step is not None
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)          # (the non-differentiable by-product would otherwise get a zeros() launch in backward)
-        return y, stats
+        # fan > 1: the result once per consumer (aliases of one storage) -- each consumer's gradient arrives in its own slot and the
+        # backward kernel sums them as it loads them, where autograd would add them with a launch per extra consumer
+        ctx.fan = int(fan)
+        return (y,) + tuple(y.view_as(y) for _ in range(ctx.fan - 1)) + (stats,)
 
     @staticmethod
-    def backward(ctx, dy, _dstats):
+    def backward(ctx, *grads):
         from . import layers as L
         z, stats, weight, step = ctx.saved_tensors
         B, Q, C = z.shape
         R = B * Q
-        dy = dy.contiguous()
+        dys = [g.contiguous() for g in grads[:ctx.fan] if g is not None]
+        if not dys:
+            return (None,) * 10
+        dy = dys[0]
         lib = _lib.lib()
         dz = torch.empty_like(z)
         dsub = torch.empty_like(z) if ctx.p > 0 else None
@@ -180,8 +186,9 @@ class ResidualDropoutLayerNorm(torch.autograd.Function):
         dgb = torch.empty(2, C, device=z.device, dtype=torch.float32)
         am = torch.empty(R, device=z.device, dtype=torch.float32)
         with torch.cuda.device(z.device):
-            rc = lib.gvl_residual_dropout_layer_norm_backward_f32(
-                dy.data_ptr(), z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), R, C, weight.data_ptr(), ctx.p,
+            rc = lib.gvl_residual_dropout_layer_norm_backward3_f32(
+                dy.data_ptr(), dys[1].data_ptr() if len(dys) > 1 else None, dys[2].data_ptr() if len(dys) > 2 else None,
+                z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), R, C, weight.data_ptr(), ctx.p,
                 ctx.seed, step.data_ptr() if ctx.has_step else None, dz.data_ptr(),
                 dsub.data_ptr() if dsub is not None else None, part.data_ptr(), dgb.data_ptr(), am.data_ptr(),
                 torch.cuda.current_stream().cuda_stream)
@@ -190,25 +197,30 @@ class ResidualDropoutLayerNorm(torch.autograd.Function):
         L.tag_amax(dz, am)
         if dsub is not None:
             L.tag_amax(dsub, am)
-        return dz, (dsub if dsub is not None else dz), dgb[0], dgb[1], None, None, None, None, None
+        return dz, (dsub if dsub is not None else dz), dgb[0], dgb[1], None, None, None, None, None, None
 
 
-def residual_dropout_norm(x, sub, drop, norm, pos=None):
+def residual_dropout_norm(x, sub, drop, norm, pos=None, fan=1):
     """norm(x + drop(sub)) -- the fused kernels when they apply, PyTorch's formulation otherwise.  pos: the positional addend
     of the attention that consumes the result next; the result then also carries the row maxima of `result + pos`
-    (add_pos below hands them to the sum), so the attention's projection needs no pass of its own over its query"""
-    if not eligible(x, sub, norm, drop):
-        return norm(x + drop(sub))
+    (add_pos below hands them to the sum), so the attention's projection needs no pass of its own over its query.
+    fan = 2 | 3: a tuple of that many handles of the result, ONE PER CONSUMER (the next sublayer, the next residual, ...): on the
+    fused path they are aliases whose gradients the backward kernel sums in its load path; otherwise the same tensor repeated"""
     p = drop.p if drop.training else 0.0
-    if p >= 1.0:
-        return norm(x + drop(sub))
+    if not eligible(x, sub, norm, drop) or p >= 1.0:
+        y = norm(x + drop(sub))
+        return y if fan == 1 else (y,) * fan
     from . import layers as L
-    y, stats = ResidualDropoutLayerNorm.apply(x, sub, norm.weight, norm.bias, norm.eps, p, _site_seed(drop),
-                                              step_counter(x.device) if p > 0 else None, pos)
-    L.tag_amax(y, stats[2])
-    if _pos_strides(pos, *x.shape) is not None:
-        y._gvl_amax_pos = (stats[3], y._version, pos.data_ptr(), pos._version)
-    return y
+    assert 1 <= fan <= 3
+    if fan > 1 and os.environ.get("GVL_RDLN_FAN", "1") == "0":               # (A/B switch: one handle, autograd adds the gradients)
+        return (residual_dropout_norm(x, sub, drop, norm, pos),) * fan
+    *ys, stats = ResidualDropoutLayerNorm.apply(x, sub, norm.weight, norm.bias, norm.eps, p, _site_seed(drop),
+                                                step_counter(x.device) if p > 0 else None, pos, fan)
+    for y in ys:
+        L.tag_amax(y, stats[2])
+        if _pos_strides(pos, *x.shape) is not None:
+            y._gvl_amax_pos = (stats[3], y._version, pos.data_ptr(), pos._version)
+    return ys[0] if fan == 1 else tuple(ys)
 
 
 def add_pos(t, pos):

@@ -322,3 +322,31 @@ def test_class_and_count_heads_node_equals_linear_and_max(B, Q, C):
         if use[0]:
             assert float((head.weight.grad - ref_head.weight.grad).abs().max()) <= 2e-4 * float(ref_head.weight.grad.abs().max())
             assert float((head.bias.grad - ref_head.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(ref_head.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("fan", [2, 3])
+def test_fan_out_handles_sum_their_gradients_inside_the_backward_kernel(fan):
+    """residual_dropout_norm(fan=k): k handles of one result (one per consumer); the backward kernel adds the gradients that
+    arrive on them as it loads them -- the same input gradients as one handle consumed k times (autograd's own adds), also when
+    one handle stays unused"""
+    from gvl_amd import train_layers as TL
+    torch.manual_seed(fan)
+    B, Q, C = 4, 150, 512
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    drop = torch.nn.Dropout(0.0)
+    x0, s0 = _rand(B, Q, C, seed=1), _rand(B, Q, C, seed=2)
+    ws = [_rand(B, Q, C, seed=10 + i) for i in range(fan)]
+    for used in (fan, fan - 1):
+        grads = []
+        for mode in ("fan", "plain"):
+            x, s = x0.clone().requires_grad_(), s0.clone().requires_grad_()
+            norm.zero_grad(set_to_none=True)
+            if mode == "fan":
+                ys = TL.residual_dropout_norm(x, s, drop, norm, fan=fan)
+                assert len(ys) == fan and all(y.data_ptr() == ys[0].data_ptr() for y in ys)
+            else:
+                ys = (TL.residual_dropout_norm(x, s, drop, norm),) * fan
+            sum((y * w_).sum() for y, w_ in list(zip(ys, ws))[:used]).backward()
+            grads.append((x.grad, s.grad, norm.weight.grad.clone(), norm.bias.grad.clone()))
+        for a, b in zip(*grads):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))

@@ -21,7 +21,9 @@ def _hash32(x):
 def _keep_mask(B, H, Q, p, seed, step):
     key = _hash32(torch.tensor((seed + step * 0x9E3779B9) & 0xFFFFFFFF, dtype=torch.int64, device=DEV))
     idx = torch.arange(B * H * Q * Q, dtype=torch.int64, device=DEV)
-    thr = min(int(p * 4294967296.0), 0xFFFFFFFF)
+    # (the kernel receives p as a C float: 0.1f 2^32 is 7 above 0.1 2^32 -- one mask element in 6e8 would differ, which fails
+    #  this test at about one (seed, step) pair in fifty)
+    thr = min(int(float(torch.tensor(p, dtype=torch.float32)) * 4294967296.0), 0xFFFFFFFF)
     return (_hash32(idx ^ key) >= thr).view(B, H, Q, Q)
 
 
