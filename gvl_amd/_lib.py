@@ -40,8 +40,9 @@ SIGNATURES = {
                                                          ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "gvl_residual_dropout_layer_norm_backward_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, ctypes.c_float, ctypes.c_uint32, _P, _P, _P,
                                                           _P, _P, _P, _P]),
-    "gvl_residual_dropout_layer_norm_backward3_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, ctypes.c_float, ctypes.c_uint32, _P, _P,
+    "gvl_residual_dropout_layer_norm_backwardn_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, ctypes.c_float, ctypes.c_uint32, _P, _P,
                                                            _P, _P, _P, _P, _P]),
+    "gvl_rdln_backward_max_grads": (_I, []),
     "gvl_relu_dropout_rows_forward_f32": (_I, [_P, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P, _P]),
     "gvl_relu_dropout_rows_backward_f32": (_I, [_P, _P, _I, _I, ctypes.c_float, _P, _P, _P]),
     "gvl_rdln_backward_blocks": (_I, [_I]),

@@ -157,10 +157,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_fwd(
 }
 
 // part: (gridDim.x, 2 C): [sum_r dy xh | sum_r dy] over the rows of the workgroup
-// dy2 / dy3 (NULL = absent): further gradients of the same output, summed with dy as they are loaded -- a result that feeds
-// two or three consumers gets one gradient from each, and autograd would add them with a launch (three passes) per addend
+// more.p[] (NULL = absent): further gradients of the same output, summed with dy as they are loaded -- a result that feeds
+// several consumers gets one gradient from each, and autograd would add them with a launch (three passes) per addend
+constexpr int kRdlnMoreDy = 5;
+struct RdlnMoreDy { const float *p[kRdlnMoreDy]; };
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_bwd(
-    const float *__restrict__ dy, const float *__restrict__ dy2, const float *__restrict__ dy3,
+    const float *__restrict__ dy, const RdlnMoreDy more,
     const float *__restrict__ z, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, int R, int C, const float *__restrict__ gamma, float p, uint32_t seed,
     const int64_t *__restrict__ step, float *__restrict__ dz, float *__restrict__ dsub, float *__restrict__ part,
@@ -179,8 +181,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_bwd(
   const float invC = 1.f / (float)C;
   for (int row = blockIdx.x * kWavesPerBlock + wave; row < R; row += gridDim.x * kWavesPerBlock) {
     const float4 *dr = reinterpret_cast<const float4 *>(dy + (int64_t)row * C);
-    const float4 *dr2 = dy2 ? reinterpret_cast<const float4 *>(dy2 + (int64_t)row * C) : nullptr;
-    const float4 *dr3 = dy3 ? reinterpret_cast<const float4 *>(dy3 + (int64_t)row * C) : nullptr;
     const float4 *zr = reinterpret_cast<const float4 *>(z + (int64_t)row * C);
     const float mean = mean_in[row], rstd = rstd_in[row];
     float4 g[kMaxV], xh[kMaxV];
@@ -192,8 +192,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_rdln_bwd(
       if (i < n4) {
         float4 a = dr[i];
         const float4 zz = zr[i];
-        if (dr2) { const float4 b = dr2[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-        if (dr3) { const float4 b = dr3[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+#pragma unroll
+        for (int j = 0; j < kRdlnMoreDy; ++j)
+          if (more.p[j]) {                                                // (wavefront-uniform; the absent ones cost a scalar test)
+            const float4 b = reinterpret_cast<const float4 *>(more.p[j] + (int64_t)row * C)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+          }
         xh[k] = make_float4((zz.x - mean) * rstd, (zz.y - mean) * rstd, (zz.z - mean) * rstd, (zz.w - mean) * rstd);
         acc_g[k].x += a.x * xh[k].x; acc_g[k].y += a.y * xh[k].y; acc_g[k].z += a.z * xh[k].z; acc_g[k].w += a.w * xh[k].w;
         acc_b[k].x += a.x; acc_b[k].y += a.y; acc_b[k].z += a.z; acc_b[k].w += a.w;
@@ -409,27 +413,34 @@ extern "C" int gvl_residual_dropout_layer_norm_backward_f32(const float *dy, con
                                                             const float *rstd, int R, int C, const float *gamma, float p,
                                                             uint32_t seed, const int64_t *step, float *dz, float *dsub,
                                                             float *part, float *dgamma_dbeta, float *amax_dz, void *stream) {
-  return gvl_residual_dropout_layer_norm_backward3_f32(dy, nullptr, nullptr, z, mean, rstd, R, C, gamma, p, seed, step, dz, dsub, part,
-                                                       dgamma_dbeta, amax_dz, stream);
+  return gvl_residual_dropout_layer_norm_backwardn_f32(&dy, 1, z, mean, rstd, R, C, gamma, p, seed, step, dz, dsub, part, dgamma_dbeta,
+                                                       amax_dz, stream);
 }
 
-extern "C" int gvl_residual_dropout_layer_norm_backward3_f32(const float *dy, const float *dy2, const float *dy3, const float *z,
-                                                             const float *mean, const float *rstd, int R, int C, const float *gamma,
-                                                             float p, uint32_t seed, const int64_t *step, float *dz, float *dsub,
-                                                             float *part, float *dgamma_dbeta, float *amax_dz, void *stream) {
-  const char *what = "gvl_residual_dropout_layer_norm_backward3_f32";
+extern "C" int gvl_rdln_backward_max_grads(void) { return 1 + kRdlnMoreDy; }
+
+extern "C" int gvl_residual_dropout_layer_norm_backwardn_f32(const float *const *dys, int n_dy, const float *z, const float *mean,
+                                                             const float *rstd, int R, int C, const float *gamma, float p,
+                                                             uint32_t seed, const int64_t *step, float *dz, float *dsub, float *part,
+                                                             float *dgamma_dbeta, float *amax_dz, void *stream) {
+  const char *what = "gvl_residual_dropout_layer_norm_backwardn_f32";
+  if (!dys || n_dy < 1 || n_dy > 1 + kRdlnMoreDy) return fail(GVL_EINVAL, "%s: 1..%d output gradients", what, 1 + kRdlnMoreDy);
+  const float *dy = dys[0];
+  RdlnMoreDy more{};
+  for (int j = 1; j < n_dy; ++j) {
+    if (!dys[j] || ((uintptr_t)dys[j] & 15)) return fail(GVL_EINVAL, "%s: gradient %d is null / not 16-byte aligned", what, j);
+    more.p[j - 1] = dys[j];
+  }
   if (int rc = check_shape(what, R, C, p)) return rc;
   if (!dgamma_dbeta) return fail(GVL_EINVAL, "%s: null pointer", what);
   if (R == 0) return gvl::zero_fill(dgamma_dbeta, sizeof(float) * 2 * C, (hipStream_t)stream);
   if (!dy || !z || !mean || !rstd || !gamma || !dz || !part) return fail(GVL_EINVAL, "%s: null pointer", what);
   if (p > 0.f && !dsub) return fail(GVL_EINVAL, "%s: dsub is needed when p > 0 (p = 0: dsub == dz)", what);
-  if (((uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)dy3 | (uintptr_t)z | (uintptr_t)gamma | (uintptr_t)dz | (uintptr_t)dsub |
-       (uintptr_t)part) & 15)
+  if (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)gamma | (uintptr_t)dz | (uintptr_t)dsub | (uintptr_t)part) & 15)
     return fail(GVL_EINVAL, "%s: every tensor must be 16-byte aligned", what);
-  if (!dy2 && dy3) { dy2 = dy3; dy3 = nullptr; }
   const int nb = blocks_for(R);
   if (int rc = gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_rdln_bwd", k_rdln_bwd, dim3(nb), dim3(64 * kWavesPerBlock), 0,
-                           (hipStream_t)stream, dy, dy2, dy3, z, mean, rstd, R, C, gamma, p, seed, step, dz, p > 0.f ? dsub : nullptr,
+                           (hipStream_t)stream, dy, more, z, mean, rstd, R, C, gamma, p, seed, step, dz, p > 0.f ? dsub : nullptr,
                            part, amax_dz))
     return rc;
   return gvl::launch(GVL_PROF_LAYER_NORM, nb, 2 * C, "k_rdln_finish", k_rdln_finish, dim3((2 * C / 4 + 15) / 16), dim3(16 * kFinGroups), 0,

@@ -87,20 +87,22 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_ffn(self, src, pos=None, resid=None):
+    def forward_ffn(self, src, pos=None, resid=None, fan=1):
         # (norm(x + dropout(sub)): one hand-written forward / backward kernel in training, gvl_amd/train_layers.py; `pos`: the
         #  result also carries the row maxima of result + pos for the next layer's attention query.  resid: the handle of `src` the
-        #  residual reads -- see residual_dropout_norm(fan=2))
+        #  residual reads, fan: the number of handles of the result -- see residual_dropout_norm(fan=...))
         return _tl.residual_dropout_norm(src if resid is None else resid,
                                          self.linear2(_tl.relu_dropout(self.linear1(src), self.activation, self.dropout2)),
-                                         self.dropout3, self.norm2, pos)
+                                         self.dropout3, self.norm2, pos, fan=fan)
 
-    def forward(self, src, pos, reference_points, temporal_shapes, level_start_index, padding_mask=None):
-        attn = self.self_attn(_tl.add_pos(src, pos), reference_points, src, temporal_shapes,
-                              level_start_index, padding_mask)
+    def forward(self, src, pos, reference_points, temporal_shapes, level_start_index, padding_mask=None, out_fan=1):
+        """src: a tensor, or the three handles (attention query, attention input, residual) the previous layer returned for
+        out_fan=3; out_fan > 1: the result as that many handles (one per consumer: residual_dropout_norm(fan=...))"""
+        sq, sv, sr = src if isinstance(src, tuple) else (src, src, src)
+        attn = self.self_attn(_tl.add_pos(sq, pos), reference_points, sv, temporal_shapes, level_start_index, padding_mask)
         # (two handles of norm1's result, for the FFN and for the residual around it: their gradients meet inside norm1's backward)
-        a, b = _tl.residual_dropout_norm(src, attn, self.dropout1, self.norm1, fan=2)
-        return self.forward_ffn(a, pos, resid=b)
+        a, b = _tl.residual_dropout_norm(sr, attn, self.dropout1, self.norm1, fan=2)
+        return self.forward_ffn(a, pos, resid=b, fan=out_fan)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -131,8 +133,10 @@ class DeformableTransformerEncoder(nn.Module):
         if ref is None or ref.shape[:2] != src.shape[:2]:
             ref = self.get_reference_points(temporal_shapes, valid_ratios, device=src.device)
         out = src
-        for layer in self.layers:
-            out = layer(out, pos, ref, temporal_shapes, level_start_index, padding_mask)
+        for i, layer in enumerate(self.layers):
+            # (a layer's result has three consumers in the next layer: one handle each)
+            out = layer(out, pos, ref, temporal_shapes, level_start_index, padding_mask,
+                        out_fan=3 if i + 1 < len(self.layers) else 1)
         return out
 
 
@@ -159,19 +163,22 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_ffn(self, tgt, pos=None, resid=None):
+    def forward_ffn(self, tgt, pos=None, resid=None, fan=1):
         return _tl.residual_dropout_norm(tgt if resid is None else resid,
                                          self.linear2(_tl.relu_dropout(self.linear1(tgt), self.activation, self.dropout3)),
-                                         self.dropout4, self.norm3, pos)
+                                         self.dropout4, self.norm3, pos, fan=fan)
 
     def forward(self, tgt, query_pos, reference_points, src, src_temporal_shapes, level_start_index,
-                src_padding_mask=None, query_mask=None):
+                src_padding_mask=None, query_mask=None, out_fan=1):
+        """tgt: a tensor, or the three handles (attention values, attention query, residual) the previous layer returned;
+        out_fan > 1: the result as that many handles (one per consumer: residual_dropout_norm(fan=...))"""
+        tgt, tgt_q, tgt_r = tgt if isinstance(tgt, tuple) else (tgt, tgt, tgt)
         if _mha.eligible(self.self_attn, tgt, query_pos):
             # training: in-projection (one launch, the positional addend applied in its load path), attention core and
             # out-projection on the hand-written kernels (gvl_amd/train_mha.py); same parameters, same result
-            sa = _mha.self_attention(self.self_attn, tgt, query_pos, query_mask)
+            sa = _mha.self_attention(self.self_attn, tgt, query_pos, query_mask, tgt_q=tgt_q)
         else:
-            qk = _tl.add_pos(tgt, query_pos).transpose(0, 1)
+            qk = _tl.add_pos(tgt_q, query_pos).transpose(0, 1)
             # The reference discards the averaged attention map ([0] at pdvc/deformable_transformer.py:267-268).  Not asking for
             # it lets nn.MultiheadAttention take its fused attention path: measured 0.4 % of the eval step; in training the
             # fused forward + backward kernels are slower than bmm / softmax / bmm at this size (300 queries): +0.9 % of the step
@@ -180,11 +187,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
                                 average_attn_weights=False)[0].transpose(0, 1)
         # (sa: a transposed view, read in place.  Two handles of each norm's result -- one for the sublayer that follows, one for
         #  the residual around it: residual_dropout_norm(fan=2))
-        tq, tr = _tl.residual_dropout_norm(tgt, sa, self.dropout2, self.norm2, query_pos, fan=2)
+        tq, tr = _tl.residual_dropout_norm(tgt_r, sa, self.dropout2, self.norm2, query_pos, fan=2)
         ca = self.cross_attn(_tl.add_pos(tq, query_pos), reference_points, src, src_temporal_shapes,
                              level_start_index, src_padding_mask)
         tf, tr = _tl.residual_dropout_norm(tr, ca, self.dropout1, self.norm1, fan=2)
-        return self.forward_ffn(tf, query_pos, resid=tr)
+        return self.forward_ffn(tf, query_pos, resid=tr, fan=out_fan)
 
 
 class DeformableTransformerDecoder(nn.Module):
@@ -214,10 +221,19 @@ class DeformableTransformerDecoder(nn.Module):
             else:
                 assert reference_points.shape[-1] == 1
                 ref_in = reference_points[:, :, None] * src_valid_ratios[:, None, :, None]
-            out = layer(out, query_pos, ref_in, src, src_temporal_shapes, src_level_start_index, src_padding_mask,
-                        query_padding_mask)
-            if not disable_iterative_refine and self.bbox_head is not None:           # :314-324
-                delta = self.bbox_head[lid](out)
+            # one handle of the layer's result per consumer (three in the next layer, the box head, the returned stack): their
+            # gradients meet inside norm3's backward kernel instead of in a chain of autograd adds
+            refine = not disable_iterative_refine and self.bbox_head is not None
+            n_next = 3 if lid + 1 < len(self.layers) else 0
+            k = n_next + int(refine) + int(self.return_intermediate)
+            outs = layer(out, query_pos, ref_in, src, src_temporal_shapes, src_level_start_index, src_padding_mask,
+                         query_padding_mask, out_fan=max(k, 1))
+            outs = list(outs) if isinstance(outs, tuple) else [outs] * max(k, 1)
+            out = tuple(outs[:3]) if n_next else outs[0]
+            out_box = outs[n_next] if refine else None
+            out_hs = outs[-1]
+            if refine:                                                                # :314-324
+                delta = self.bbox_head[lid](out_box)
                 if _layers.box_refine_train_eligible(delta, reference_points):
                     # sigmoid(delta + inverse_sigmoid(reference)) and the next layer's reference points in one launch, one
                     # more for the gradient (gvl_amd/layers.py: _BoxRefineTrain)
@@ -232,14 +248,14 @@ class DeformableTransformerDecoder(nn.Module):
                 reference_points = new_ref.detach()
                 coords.append(new_ref)
             if self.return_intermediate:
-                hs.append(out)
+                hs.append(out_hs)
                 refs.append(reference_points)
         # pdvc.py:452-474 applies the SAME box MLP to the same rows and adds the same inverse_sigmoid(reference): PDVC's
         # heads take these (attached) results instead of repeating ~23 launches per layer (as the inference path does)
         self.__dict__["_gvl_coords"] = coords if len(coords) == len(self.layers) else None
         if self.return_intermediate:
             return torch.stack(hs), torch.stack(refs)
-        return out, reference_points
+        return out_hs, reference_points
 
 
 class DeformableTransformer(nn.Module):

@@ -10,6 +10,7 @@ draws new masks every replay and the backward regenerates the mask instead of st
 With p = 0 (every golden of tests/golden is generated that way) the result is exactly LayerNorm(x + sub).
 
 ``GVL_TRAIN_LAYERS=torch`` keeps the PyTorch formulation (A/B switch)."""
+import ctypes
 import itertools
 import os
 
@@ -139,6 +140,9 @@ def _pos_strides(pos, B, Q, C):
     return pos.data_ptr(), pos.stride(0), pos.stride(1)
 
 
+MAX_FAN = 6                 # gvl_rdln_backward_max_grads()
+
+
 class ResidualDropoutLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sub, weight, bias, eps, p, seed, step, pos, fan=1):
@@ -186,9 +190,8 @@ class ResidualDropoutLayerNorm(torch.autograd.Function):
         dgb = torch.empty(2, C, device=z.device, dtype=torch.float32)
         am = torch.empty(R, device=z.device, dtype=torch.float32)
         with torch.cuda.device(z.device):
-            rc = lib.gvl_residual_dropout_layer_norm_backward3_f32(
-                dy.data_ptr(), dys[1].data_ptr() if len(dys) > 1 else None, dys[2].data_ptr() if len(dys) > 2 else None,
-                z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), R, C, weight.data_ptr(), ctx.p,
+            rc = lib.gvl_residual_dropout_layer_norm_backwardn_f32(
+                (ctypes.c_void_p * len(dys))(*[g.data_ptr() for g in dys]), len(dys), z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), R, C, weight.data_ptr(), ctx.p,
                 ctx.seed, step.data_ptr() if ctx.has_step else None, dz.data_ptr(),
                 dsub.data_ptr() if dsub is not None else None, part.data_ptr(), dgb.data_ptr(), am.data_ptr(),
                 torch.cuda.current_stream().cuda_stream)
@@ -204,14 +207,14 @@ def residual_dropout_norm(x, sub, drop, norm, pos=None, fan=1):
     """norm(x + drop(sub)) -- the fused kernels when they apply, PyTorch's formulation otherwise.  pos: the positional addend
     of the attention that consumes the result next; the result then also carries the row maxima of `result + pos`
     (add_pos below hands them to the sum), so the attention's projection needs no pass of its own over its query.
-    fan = 2 | 3: a tuple of that many handles of the result, ONE PER CONSUMER (the next sublayer, the next residual, ...): on the
+    fan = 2 .. MAX_FAN: a tuple of that many handles of the result, ONE PER CONSUMER (the next sublayer, the next residual, ...): on the
     fused path they are aliases whose gradients the backward kernel sums in its load path; otherwise the same tensor repeated"""
     p = drop.p if drop.training else 0.0
     if not eligible(x, sub, norm, drop) or p >= 1.0:
         y = norm(x + drop(sub))
         return y if fan == 1 else (y,) * fan
     from . import layers as L
-    assert 1 <= fan <= 3
+    assert 1 <= fan <= MAX_FAN
     if fan > 1 and os.environ.get("GVL_RDLN_FAN", "1") == "0":               # (A/B switch: one handle, autograd adds the gradients)
         return (residual_dropout_norm(x, sub, drop, norm, pos),) * fan
     *ys, stats = ResidualDropoutLayerNorm.apply(x, sub, norm.weight, norm.bias, norm.eps, p, _site_seed(drop),

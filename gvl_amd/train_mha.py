@@ -158,12 +158,14 @@ def eligible(mha, tgt, query_pos):
             and query_pos.dtype == torch.float32)
 
 
-def self_attention(mha, tgt, query_pos, query_mask):
+def self_attention(mha, tgt, query_pos, query_mask, tgt_q=None):
     """nn.MultiheadAttention(q = k = tgt + query_pos, v = tgt, key_padding_mask = ~query_mask)[0] for batch-major tgt (B, Q, C)
     -> (B, Q, C); callers check `eligible` first.  query_pos: the batch-expanded (stride 0) query embedding."""
     B, Q, C = tgt.shape
     x = tgt.contiguous()
-    xq = TL.add_pos(x if x is tgt else tgt, query_pos)                  # (carries the row maxima of the sum when norm3 left them)
+    # (tgt_q: another handle of tgt for the query -- residual_dropout_norm(fan=...); the sum carries its row maxima when norm3
+    #  left them)
+    xq = TL.add_pos(tgt_q if tgt_q is not None else tgt, query_pos)
     L_ = L
     if L_.amax_of(x, B * Q) is None and L_.amax_of(tgt, B * Q) is not None:
         L_.tag_amax(x, L_.amax_of(tgt, B * Q))

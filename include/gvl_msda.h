@@ -51,8 +51,8 @@ extern "C" {
 #define GVL_MSDA_ABI_VERSION 16
 /* ABI history (newest first):
  * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training),
- *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backward3_f32 (up to three
- *      output gradients summed in the load path)
+ *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
+ *      gvl_rdln_backward_max_grads (several output gradients summed in the load path)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
@@ -434,12 +434,14 @@ int gvl_residual_dropout_layer_norm_backward_f32(const float *dy, const float *z
  *    masks the backward regenerates; amax_y[r] = max |y[r][.]| and amax_ypos[r] = max |y[r][.] + pos[row r][.]| (pos addressed
  *    like x: b * pos_sb + q * pos_sq) -- the row maxima the next Linear product's split needs for `y` and for the attention query
  *    `y + pos` (gvl_linear_f16x3_f32); amax_dz[r] = max |dz[r][.]| / (1 - p), a bound of row r of dz AND of dsub. */
-/*    ABI 16: ..._backward3_f32 -- the same with up to three gradients of the output (dy2 / dy3 may be NULL), summed as they are
- *    loaded: the norm's result feeds the next sublayer AND the next residual, and each hands back a gradient. */
-int gvl_residual_dropout_layer_norm_backward3_f32(const float *dy, const float *dy2, const float *dy3, const float *z,
-                                                  const float *mean, const float *rstd, int R, int C, const float *gamma, float p,
-                                                  uint32_t seed, const int64_t *step, float *dz, float *dsub, float *part,
-                                                  float *dgamma_dbeta, float *amax_dz, void *stream);
+/*    ABI 16: ..._backwardn_f32 -- the same with n_dy = 1 .. gvl_rdln_backward_max_grads() gradients of the output (dys: host-side
+ *    array of pointers), summed as they are loaded: the norm's result feeds the next sublayer, the next residual, heads ..., and
+ *    each hands back a gradient. */
+int gvl_residual_dropout_layer_norm_backwardn_f32(const float *const *dys, int n_dy, const float *z, const float *mean,
+                                                  const float *rstd, int R, int C, const float *gamma, float p, uint32_t seed,
+                                                  const int64_t *step, float *dz, float *dsub, float *part, float *dgamma_dbeta,
+                                                  float *amax_dz, void *stream);
+int gvl_rdln_backward_max_grads(void);
 int gvl_rdln_backward_blocks(int R);
 /*    y = dropout(relu(x)) of the FFNs (deformable_transformer.py:189-191, 257-259), n elements (n % 4 == 0, < 2^32), y == x
  *    allowed; same mask rule as above.  backward: dx = y > 0 ? dy / (1 - p) : 0 -- no mask tensor (y > 0 exactly

@@ -324,7 +324,7 @@ def test_class_and_count_heads_node_equals_linear_and_max(B, Q, C):
             assert float((head.bias.grad - ref_head.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(ref_head.bias.grad.abs().max()))
 
 
-@pytest.mark.parametrize("fan", [2, 3])
+@pytest.mark.parametrize("fan", [2, 3, 6])
 def test_fan_out_handles_sum_their_gradients_inside_the_backward_kernel(fan):
     """residual_dropout_norm(fan=k): k handles of one result (one per consumer); the backward kernel adds the gradients that
     arrive on them as it loads them -- the same input gradients as one handle consumed k times (autograd's own adds), also when
