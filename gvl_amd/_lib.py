@@ -104,6 +104,7 @@ SIGNATURES = {
     "gvl_count_head_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "gvl_count_pool_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "gvl_batch_sum_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "gvl_level_sums_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "gvl_count_pool_backward_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),
     "gvl_msda1d_fused_backward_f32": (_I, [_P] * 6 + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -1076,7 +1076,54 @@ __global__ void __launch_bounds__(256) k_batch_sum(const BatchSumParams p, int p
   out[(q * parts + h) * c4n + c4] = acc;
 }
 
+// part[b][l][c] = sum over the rows of level l of video b of g[b][s][c] (g (B, S, C), the levels consecutive row ranges of S): the
+// per-video half of the level embedding's gradient (deformable_transformer.py:100: lvl_pos_embed = pos + level_embed[l]); the sum over
+// the videos follows as k_batch_sum.  One workgroup per (video, level, 256 columns), 4 wavefronts interleaved over the level's rows.
+constexpr int kMaxLevelsSum = 8;
+struct LevelRanges { int start[kMaxLevelsSum], len[kMaxLevelsSum]; };
+__global__ void __launch_bounds__(256) k_level_sums(const float *__restrict__ g, int S, int C, int L, const LevelRanges lv,
+                                                    float *__restrict__ part) {
+  __shared__ float4 red[3][64];
+  const int chunks = (C + 255) >> 8, n4 = C >> 2;
+  const int chunk = blockIdx.x % chunks, l = (blockIdx.x / chunks) % L, b = blockIdx.x / (chunks * L);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c4 = chunk * 64 + lane;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < n4) {
+    const float4 *base = reinterpret_cast<const float4 *>(g + ((int64_t)b * S + lv.start[l]) * C) + c4;
+    for (int t = wave; t < lv.len[l]; t += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = t + 4 * u < lv.len[l] ? base[(int64_t)(t + 4 * u) * n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+  }
+  if (wave) red[wave - 1][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c4 < n4) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { const float4 v = red[w][lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    reinterpret_cast<float4 *>(part + ((int64_t)b * L + l) * C)[c4] = acc;
+  }
+}
+
 }  // namespace
+
+extern "C" int gvl_level_sums_f32(const float *g, int B, int S, int C, const int *starts, const int *lengths, int L, float *part,
+                                  void *stream) {
+  if (B < 0 || S <= 0 || C <= 0 || (C & 3) || L < 1 || L > kMaxLevelsSum || !starts || !lengths)
+    return fail(GVL_EINVAL, "gvl_level_sums_f32: C %% 4 == 0, 1..%d levels (got B=%d S=%d C=%d L=%d)", kMaxLevelsSum, B, S, C, L);
+  if (B == 0) return 0;
+  if (!g || !part || (((uintptr_t)g | (uintptr_t)part) & 15)) return fail(GVL_EINVAL, "gvl_level_sums_f32: null / unaligned pointer");
+  LevelRanges lv{};
+  for (int l = 0; l < L; ++l) {
+    if (starts[l] < 0 || lengths[l] < 0 || starts[l] + lengths[l] > S)
+      return fail(GVL_EINVAL, "gvl_level_sums_f32: level %d = rows [%d, %d) of %d", l, starts[l], starts[l] + lengths[l], S);
+    lv.start[l] = starts[l]; lv.len[l] = lengths[l];
+  }
+  return gvl::launch(GVL_PROF_LAYER_NORM, B, S, "k_level_sums", k_level_sums, dim3(B * L * ((C + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, g, S, C, L, lv, part);
+}
 
 extern "C" int gvl_batch_sum_f32(const float *const *grads, int parts, int B, int Q, int C, float *out, void *stream) {
   if (parts < 1 || parts > 4 || B <= 0 || Q < 0 || C <= 0 || (C & 3))

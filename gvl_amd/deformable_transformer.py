@@ -317,8 +317,11 @@ class DeformableTransformer(nn.Module):
         if src_flatten is None:
             src_flatten = torch.cat([s.transpose(1, 2) for s in srcs], 1)
         mask_flatten = torch.cat(masks, 1)
-        lvl_embed = self.level_embed.unbind(0)        # (one UnbindBackward instead of a zero-filled SelectBackward per level)
-        lvl_pos = torch.cat([p.transpose(1, 2) + lvl_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
+        if _layers.level_pos_embed_eligible(self.level_embed, pos_embeds):
+            lvl_pos = _layers.level_pos_embed(self.level_embed, pos_embeds)       # (training: the embedding's gradient in two launches)
+        else:
+            lvl_embed = self.level_embed.unbind(0)    # (one UnbindBackward instead of a zero-filled SelectBackward per level)
+            lvl_pos = torch.cat([p.transpose(1, 2) + lvl_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
         temporal_shapes, level_start_index = make_level_tensors(lengths, src_flatten.device)
         if (_layers.enabled() and mask_flatten.is_cuda and not self.no_encoder and len(lengths) <= 8
                 and mask_flatten.dtype == torch.bool):

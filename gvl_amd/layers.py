@@ -565,6 +565,53 @@ class _ExpandParts(torch.autograd.Function):
         return out, None, None
 
 
+class _LevelPosEmbed(torch.autograd.Function):
+    """lvl_pos_embed_flatten of deformable_transformer.py:96-103 -- cat_l(pos_embed_l^T + level_embed[l]) (B, S, C) -- as one node
+    (the position embeddings' gradients -- their learned duration half -- are slices of the incoming one).  The level embedding's is the per-level sum of the (B, S, C)
+    gradient over videos and rows in TWO launches (gvl_level_sums_f32 + gvl_batch_sum_f32); the PyTorch formulation reduces each
+    level's slice over (0, 1) with a 512-wide output -- 18-31 us apiece at (16, 13..100, 512) -- and stacks the four."""
+
+    @staticmethod
+    def forward(ctx, level_embed, *pos_embeds):
+        lengths = [int(p.shape[-1]) for p in pos_embeds]
+        ctx.lengths, ctx.n_embed = lengths, level_embed.shape[0]
+        return torch.cat([p.transpose(1, 2) + level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        import ctypes
+        g = g.contiguous()
+        B, S, C = g.shape
+        Lv = len(ctx.lengths)
+        starts = [sum(ctx.lengths[:l]) for l in range(Lv)]
+        part = torch.empty(B, Lv, C, device=g.device, dtype=torch.float32)
+        out = torch.empty(Lv, C, device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            st = torch.cuda.current_stream().cuda_stream
+            rc = _lib.lib().gvl_level_sums_f32(g.data_ptr(), B, S, C, (ctypes.c_int * Lv)(*starts), (ctypes.c_int * Lv)(*ctx.lengths),
+                                               Lv, part.data_ptr(), st)
+            _lib.check(rc, "level_sums")
+            rc = _lib.lib().gvl_batch_sum_f32((ctypes.c_void_p * 1)(part.data_ptr()), 1, B, Lv, C, out.data_ptr(), st)
+            _lib.check(rc, "batch_sum")
+        if ctx.n_embed > Lv:                                             # (levels of the embedding that this forward did not use)
+            out = torch.cat([out, out.new_zeros(ctx.n_embed - Lv, C)])
+        return (out,) + tuple(g[:, s:s + n].transpose(1, 2) if need else None
+                              for s, n, need in zip(starts, ctx.lengths, ctx.needs_input_grad[1:]))
+
+
+def level_pos_embed_eligible(level_embed, pos_embeds):
+    return (level_embed.is_cuda and level_embed.dtype == torch.float32 and torch.is_grad_enabled() and level_embed.requires_grad
+            and not torch.is_autocast_enabled() and level_embed.shape[1] % 4 == 0 and 1 <= len(pos_embeds) <= 8
+            and level_embed.shape[0] >= len(pos_embeds)
+            and all(p.dtype == torch.float32 and p.dim() == 3 for p in pos_embeds)
+            and os.environ.get("GVL_LEVEL_POS", "") != "torch")
+
+
+def level_pos_embed(level_embed, pos_embeds):
+    return _LevelPosEmbed.apply(level_embed, *pos_embeds)
+
+
 def expand_parts_eligible(embed, parts):
     return (embed.is_cuda and embed.dtype == torch.float32 and embed.dim() == 2 and embed.is_contiguous()
             and torch.is_grad_enabled() and embed.requires_grad and not torch.is_autocast_enabled()

@@ -52,7 +52,8 @@ extern "C" {
 /* ABI history (newest first):
  * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training),
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
- *      gvl_rdln_backward_max_grads (several output gradients summed in the load path)
+ *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
+ *      gradient)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
@@ -286,6 +287,10 @@ int gvl_count_pool_f32(const float *hs, int B, int Q, int C, float *pooled, int 
  *    out[q][h * C + c] = sum_b grads[h][b][q][c], grads: `parts` (1..4) host-side pointers to contiguous (B, Q, C) tensors (NULL =
  *    no gradient reached that block: zeros). */
 int gvl_batch_sum_f32(const float *const *grads, int parts, int B, int Q, int C, float *out, void *stream);
+/*    gvl_level_sums_f32 (ABI 16): the per-video half of the level embedding's gradient (pdvc/deformable_transformer.py:100,
+ *    `lvl_pos_embed = pos_embed + level_embed[lvl]`): part[b][l][c] = sum of g[b][s][c] over the rows s of level l (starts / lengths:
+ *    host arrays of the L <= 8 levels' row ranges in S); the sum over b is gvl_batch_sum_f32(parts = 1, Q = L). */
+int gvl_level_sums_f32(const float *g, int B, int S, int C, const int *starts, const int *lengths, int L, float *part, void *stream);
 int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, const float *grad_row,
                                 const float *w_row, float *grad_hs, void *stream);
 

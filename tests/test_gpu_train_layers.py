@@ -350,3 +350,27 @@ def test_fan_out_handles_sum_their_gradients_inside_the_backward_kernel(fan):
             grads.append((x.grad, s.grad, norm.weight.grad.clone(), norm.bias.grad.clone()))
         for a, b in zip(*grads):
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,lengths", [(16, 512, [100, 50, 25, 13]), (3, 64, [7, 1]), (2, 260, [5, 4, 3, 2, 1])])
+def test_level_pos_embed_node_equals_the_torch_formulation(B, C, lengths):
+    """cat_l(pos_l^T + level_embed[l]) (deformable_transformer.py:96-103) as one node: same values, the level embedding's gradient
+    (per-level sums over videos and rows, gvl_level_sums_f32 + gvl_batch_sum_f32) against autograd's"""
+    from gvl_amd import layers as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(B + C)
+    emb = torch.randn(len(lengths) + 1, C, device=dev, generator=g, requires_grad=True)   # (one level more than used)
+    pos = [torch.randn(B, C, T, device=dev, generator=g).requires_grad_(l % 2 == 0) for l, T in enumerate(lengths)]
+    assert L.level_pos_embed_eligible(emb, pos)
+    out = L.level_pos_embed(emb, pos)
+    ref = emb.detach().clone().requires_grad_()
+    pos_ref = [p.detach().clone().requires_grad_(p.requires_grad) for p in pos]
+    want = torch.cat([p.transpose(1, 2) + ref[l].view(1, 1, -1) for l, p in enumerate(pos_ref)], 1)
+    assert torch.equal(out, want)
+    go = torch.randn(B, sum(lengths), C, device=dev, generator=g)
+    out.backward(go)
+    want.backward(go)
+    assert float((emb.grad - ref.grad).abs().max()) <= 1e-5 * max(1.0, float(ref.grad.abs().max()))
+    assert float(emb.grad[len(lengths)].abs().max()) == 0.0
+    for p, r in zip(pos, pos_ref):                            # (the learned half of the position embedding: its slice of the gradient)
+        assert (p.grad is None) == (r.grad is None) and (p.grad is None or torch.equal(p.grad, r.grad))
