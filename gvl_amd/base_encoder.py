@@ -31,6 +31,9 @@ class _SinePosFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        hit = getattr(grad_out, "_gvl_time_sum", None)       # (N, C) sums over time left by gvl_amd.layers._LevelPosEmbed's backward
+        if hit is not None and hit[1] == grad_out._version and hit[0].shape == grad_out.shape[:2]:
+            return None, None, hit[0][:, ctx.n_sine:], None
         return None, None, grad_out[:, ctx.n_sine:].sum(-1), None
 
 

@@ -596,8 +596,15 @@ class _LevelPosEmbed(torch.autograd.Function):
             _lib.check(rc, "batch_sum")
         if ctx.n_embed > Lv:                                             # (levels of the embedding that this forward did not use)
             out = torch.cat([out, out.new_zeros(ctx.n_embed - Lv, C)])
-        return (out,) + tuple(g[:, s:s + n].transpose(1, 2) if need else None
-                              for s, n, need in zip(starts, ctx.lengths, ctx.needs_input_grad[1:]))
+        grads = []
+        for l, (s, n, need) in enumerate(zip(starts, ctx.lengths, ctx.needs_input_grad[1:])):
+            gp = g[:, s:s + n].transpose(1, 2) if need else None
+            if gp is not None:
+                # its sum over the level's rows is at hand: left on the tensor for the position embedding's backward, whose
+                # learned half wants exactly that (gvl_amd.base_encoder._PosEmbedSine); versioned like the row maxima
+                gp._gvl_time_sum = (part[:, l], gp._version)
+            grads.append(gp)
+        return (out,) + tuple(grads)
 
 
 def level_pos_embed_eligible(level_embed, pos_embeds):
