@@ -454,10 +454,12 @@ class TeacherForcedLoop(torch.autograd.Function):
         g_aw = small[n_r:n_r + alpha_w.numel()].view(alpha_w.shape)
         g_ab = small[n_r + n_a:n_r + n_a + 1]
         d_att, dh_carry, dc = new(n, C), None, None
+        d_gates_sum = new(n, H4)                       # sum over the steps of the gate gradients: kept by the cell's backward kernel
         dh_buf, dc_buf = (new(n, H), new(n, H)), (new(n, H), new(n, H))
         for i in range(steps - 1, -1, -1):
             dgates = dg[i][:, A:A + H4]
-            MSDA.lstm_cell_train_backward(d_h[i], dh_carry, dc, act[i], c_all[i], c_all[i + 1], dgates, dc_buf[i & 1])
+            MSDA.lstm_cell_train_backward(d_h[i], dh_carry, dc, act[i], c_all[i], c_all[i + 1], dgates, dc_buf[i & 1],
+                                          gates_sum=d_gates_sum, first=i == steps - 1)
             dc = dc_buf[i & 1]
             torch.mm(dgates, w_att, out=d_att)
             MSDA.cap_attend_train_backward(slab, shapes2d, lsi, ref_in, off_hs, g_h[i][:, A + H4:], g_h[i][:, :A],
@@ -480,7 +482,7 @@ class TeacherForcedLoop(torch.autograd.Function):
             d_w_hcat = dgf.t().mm(h_prev)
             d_b_hcat = MSDA.col_sum(dgf)
             d_w_att = d_gates.reshape(steps * n, H4).t().mm(att2)
-        return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates.sum(0), d_gates if ctx.time_major else d_gates.permute(1, 0, 2),
+        return (g_slab, g_ref, dg[:, :, A + H4:].sum(0), d_gates_sum, d_gates if ctx.time_major else d_gates.permute(1, 0, 2),
                 d_w_hcat, d_b_hcat, d_w_att, g_aw, g_ab, None, None, None, None, None, None)
 
 

@@ -592,7 +592,8 @@ def lstm_cell_train_forward(gates_a, gates_b, gates_c, c_prev, act, h_out, c_out
     _lib.check(rc, "lstm_cell_train_forward")
 
 
-def lstm_cell_train_backward(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, grad_gates, grad_c_prev):
+def lstm_cell_train_backward(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, grad_gates, grad_c_prev, gates_sum=None, first=False):
+    """gates_sum (n, 4H) contiguous: the running sum of grad_gates over the steps (first: this call starts it)"""
     n, H = c_prev.shape
     _f32_rows("lstm_cell_train: grad_gates", grad_gates, 4 * H)
     for name, t_ in (("grad_h_a", grad_h_a), ("grad_h_b", grad_h_b), ("grad_c", grad_c), ("act", act),
@@ -601,9 +602,11 @@ def lstm_cell_train_backward(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, gra
                  f"lstm_cell_train: {name} must be a contiguous fp32 CUDA tensor")
     ptr = lambda t_: None if t_ is None else t_.data_ptr()      # noqa: E731
     with torch.cuda.device(c_prev.device):
-        rc = _lib.lib().gvl_lstm_cell_train_backward_f32(
+        _require(gates_sum is None or (gates_sum.is_cuda and gates_sum.is_contiguous() and gates_sum.dtype == torch.float32
+                                       and tuple(gates_sum.shape) == (n, 4 * H)), "lstm_cell_train: gates_sum must be (n, 4H) fp32")
+        rc = _lib.lib().gvl_lstm_cell_train_backward_sum_f32(
             ptr(grad_h_a), ptr(grad_h_b), ptr(grad_c), act.data_ptr(), c_prev.data_ptr(), c_new.data_ptr(), n, H,
-            grad_gates.data_ptr(), grad_gates.stride(0), grad_c_prev.data_ptr(),
+            grad_gates.data_ptr(), grad_gates.stride(0), grad_c_prev.data_ptr(), ptr(gates_sum), int(bool(first)),
             torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "lstm_cell_train_backward")
 

@@ -64,6 +64,7 @@ SIGNATURES = {
                                           + [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "gvl_lstm_cell_train_forward_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
     "gvl_lstm_cell_train_backward_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P]),
+    "gvl_lstm_cell_train_backward_sum_f32": (_I, [_P] * 6 + [_I, _I, _P, _I, _P, _P, _I, _P]),
     "gvl_col_sum_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "gvl_ce_rows_forward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P]),
     "gvl_ce_rows_backward_f32": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P]),

@@ -166,12 +166,13 @@ class _PyramidTrainFunction(torch.autograd.Function):
         dsrc = dsrc.contiguous()
         grads = [None] * (4 * nl)
         dnext = None                                                   # input gradient of level l + 1, padded layout (N, 2 T1, C)
+        part_all = torch.empty(nl, 2, N, C, device=dev, dtype=torch.float32)        # per-video d gamma | d beta of every level
         for l in range(nl - 1, -1, -1):
             a, am, y = saved[3 * l], saved[3 * l + 1], saved[3 * l + 2]
             rows = shapes[l]
             norm = enc.input_proj[l][1]
             dy = torch.empty(N * rows, C, device=dev, dtype=torch.float32)
-            part = torch.empty(2, N, C, device=dev, dtype=torch.float32)
+            part = part_all[l]
             with torch.cuda.device(dev):
                 rc = _lib.lib().gvl_group_norm_rows_backward_f32(
                     y.data_ptr(), y.stride(0), rows, N, lengths[l], C, norm.num_groups, params[4 * l + 2].data_ptr(), float(norm.eps),
@@ -179,8 +180,6 @@ class _PyramidTrainFunction(torch.autograd.Function):
                     dnext.data_ptr() + 4 * C if dnext is not None else None, dnext.shape[1] * C if dnext is not None else 0,
                     dy.data_ptr(), C, part[0].data_ptr(), part[1].data_ptr(), stream)
             _lib.check(rc, "group_norm_rows_backward")
-            gb = part.sum(1)                                           # (2, C): d gamma, d beta -- the videos in index order
-            grads[4 * l + 2], grads[4 * l + 3] = gb[0], gb[1]
             am_dy = L.row_absmax(dy)[0]
             gw, gbias = MSDA.wgrad(dy, a, am_dy, am)
             w = params[4 * l]
@@ -196,6 +195,9 @@ class _PyramidTrainFunction(torch.autograd.Function):
                     rc = _lib.lib().gvl_conv_taps_to_rows_f32(dcols.data_ptr(), N, rows, C, dnext.data_ptr(), stream)
                 _lib.check(rc, "conv_taps_to_rows")
             assert w.shape[0] == C
+        gb = part_all.sum(2)                                           # (nl, 2, C): the videos in index order, ONE reduction
+        for l in range(nl):
+            grads[4 * l + 2], grads[4 * l + 3] = gb[l, 0], gb[l, 1]
         return (None, None, *grads)
 
 

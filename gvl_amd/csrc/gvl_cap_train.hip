@@ -399,12 +399,14 @@ __global__ void __launch_bounds__(256) k_lstm_train_fwd(const float *__restrict_
   }
 }
 
-// dh = dh_a + dh_b (either may be null), dc_in may be null; writes d(pre-activation gates) (row stride ldg) and dc_prev
+// dh = dh_a + dh_b (either may be null), dc_in may be null; writes d(pre-activation gates) (row stride ldg) and dc_prev.
+// acc (n, 4H) or null: the running sum of the gate gradients over the token steps (acc_first: this launch starts it) -- the
+// gradient of the token-independent gate part, which would otherwise be a reduction over (steps, n, 4H) after the loop
 __global__ void __launch_bounds__(256) k_lstm_train_bwd(const float *__restrict__ dh_a, const float *__restrict__ dh_b,
                                                         const float *__restrict__ dc_in, const float *__restrict__ act,
                                                         const float *__restrict__ c_prev, const float *__restrict__ c_new,
                                                         int n, int H, float *__restrict__ dgates, int ldg,
-                                                        float *__restrict__ dc_prev) {
+                                                        float *__restrict__ dc_prev, float *__restrict__ acc, int acc_first) {
   const int64_t total = (int64_t)n * H;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(idx / H), j = (int)(idx % H);
@@ -414,11 +416,15 @@ __global__ void __launch_bounds__(256) k_lstm_train_bwd(const float *__restrict_
     const float tc = fast_tanh(c_new[idx]);
     const float dc = (dc_in ? dc_in[idx] : 0.f) + dh * o_ * (1.f - tc * tc);
     float *d = dgates + (int64_t)row * ldg + j;
-    d[0] = dc * g_ * i_ * (1.f - i_);
-    d[H] = dc * c_prev[idx] * f_ * (1.f - f_);
-    d[2 * H] = dc * i_ * (1.f - g_ * g_);
-    d[3 * H] = dh * tc * o_ * (1.f - o_);
+    const float gi = dc * g_ * i_ * (1.f - i_), gf = dc * c_prev[idx] * f_ * (1.f - f_), gg = dc * i_ * (1.f - g_ * g_),
+                go = dh * tc * o_ * (1.f - o_);
+    d[0] = gi; d[H] = gf; d[2 * H] = gg; d[3 * H] = go;
     dc_prev[idx] = dc * f_;
+    if (acc) {
+      float *s = acc + (int64_t)row * 4 * H + j;
+      if (acc_first) { s[0] = gi; s[H] = gf; s[2 * H] = gg; s[3 * H] = go; }
+      else { s[0] += gi; s[H] += gf; s[2 * H] += gg; s[3 * H] += go; }
+    }
   }
 }
 
@@ -493,6 +499,13 @@ int gvl_lstm_cell_train_forward_f32(const float *gates_a, int lda, const float *
 int gvl_lstm_cell_train_backward_f32(const float *grad_h_a, const float *grad_h_b, const float *grad_c, const float *act,
                                      const float *c_prev, const float *c_new, int n, int H, float *grad_gates,
                                      int grad_gates_ld, float *grad_c_prev, void *stream) {
+  return gvl_lstm_cell_train_backward_sum_f32(grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, n, H, grad_gates, grad_gates_ld,
+                                              grad_c_prev, nullptr, 0, stream);
+}
+
+int gvl_lstm_cell_train_backward_sum_f32(const float *grad_h_a, const float *grad_h_b, const float *grad_c, const float *act,
+                                         const float *c_prev, const float *c_new, int n, int H, float *grad_gates,
+                                         int grad_gates_ld, float *grad_c_prev, float *grad_gates_sum, int first, void *stream) {
   if (n < 0 || H <= 0 || grad_gates_ld < 4 * H)
     return fail(GVL_EINVAL, "gvl_lstm_cell_train_backward_f32: bad sizes n=%d H=%d", n, H);
   if (n == 0) return 0;
@@ -502,7 +515,7 @@ int gvl_lstm_cell_train_backward_f32(const float *grad_h_a, const float *grad_h_
   if (blocks > 4096) blocks = 4096;
   return gvl::launch(GVL_PROF_LSTM_TRAIN, n, H, "k_lstm_train_bwd", k_lstm_train_bwd, dim3((unsigned)blocks), dim3(256),
                      0, (hipStream_t)stream, grad_h_a, grad_h_b, grad_c, act, c_prev, c_new, n, H, grad_gates,
-                     grad_gates_ld, grad_c_prev);
+                     grad_gates_ld, grad_c_prev, grad_gates_sum, first);
 }
 
 }  // extern "C"

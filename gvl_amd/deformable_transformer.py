@@ -357,7 +357,8 @@ class DeformableTransformer(nn.Module):
         bs = memory.shape[0]
         pos_rows, tgt = torch.chunk(query_embed, 2, dim=1)
         if _layers.expand_parts_eligible(query_embed, 2):
-            query_pos, tgt = _layers.expand_parts(query_embed, bs, 2)          # (training: the two gradients batch-summed in one launch)
+            # (training: the two gradients batch-summed in one launch; pos_rows: the node's own handle of the first block)
+            query_pos, tgt, pos_rows, _ = _layers.expand_parts(query_embed, bs, 2, rows=True)
         else:
             query_pos = pos_rows.unsqueeze(0).expand(bs, -1, -1)
             tgt = tgt.unsqueeze(0).expand(bs, -1, -1)

@@ -548,20 +548,32 @@ class _ExpandParts(torch.autograd.Function):
         C = PC // parts
         ctx.cfg = (B, parts, Q, C)
         ctx.set_materialize_grads(False)
-        return tuple(embed[:, h * C:(h + 1) * C].unsqueeze(0).expand(B, -1, -1) for h in range(parts))
+        # (+ the blocks themselves, un-expanded, for a reader of the embedding's rows: the reference-point head)
+        return tuple(embed[:, h * C:(h + 1) * C].unsqueeze(0).expand(B, -1, -1) for h in range(parts)) + tuple(
+            embed[:, h * C:(h + 1) * C] for h in range(parts))
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         import ctypes
         B, parts, Q, C = ctx.cfg
-        grads = [g.contiguous() if g is not None else None for g in grads]
-        ref = next(g for g in grads if g is not None)
+        rows = grads[parts:]
+        grads = [g.contiguous() if g is not None else None for g in grads[:parts]]
+        ref = next((g for g in grads if g is not None), None)
+        if ref is None:                                                  # (only the un-expanded blocks were used)
+            out = next(g for g in rows if g is not None).new_zeros(Q, parts * C)
+            for h, g in enumerate(rows):
+                if g is not None:
+                    out[:, h * C:(h + 1) * C] = g
+            return out, None, None
         out = torch.empty(Q, parts * C, device=ref.device, dtype=torch.float32)
         ptrs = (ctypes.c_void_p * parts)(*[g.data_ptr() if g is not None else None for g in grads])
         with torch.cuda.device(ref.device):
             rc = _lib.lib().gvl_batch_sum_f32(ptrs, parts, B, Q, C, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "batch_sum")
+        for h, g in enumerate(rows):
+            if g is not None:
+                out[:, h * C:(h + 1) * C] += g
         return out, None, None
 
 
@@ -625,8 +637,11 @@ def expand_parts_eligible(embed, parts):
             and embed.shape[1] % (4 * parts) == 0 and os.environ.get("GVL_EXPAND_PARTS", "") != "torch")
 
 
-def expand_parts(embed, B, parts):
-    return _ExpandParts.apply(embed, B, parts)
+def expand_parts(embed, B, parts, rows=False):
+    """-> the `parts` batch-expanded blocks; rows=True: + the `parts` un-expanded blocks (Q, C) (their gradients join the same
+    embedding gradient without a zero-padded cat)"""
+    out = _ExpandParts.apply(embed, B, parts)
+    return out if rows else out[:parts]
 
 
 def count_pool_train_eligible(hs):

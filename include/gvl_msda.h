@@ -53,7 +53,7 @@ extern "C" {
  * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training),
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
- *      gradient)
+ *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
@@ -695,6 +695,12 @@ int gvl_lstm_cell_train_forward_f32(const float *gates_a, int lda, const float *
 int gvl_lstm_cell_train_backward_f32(const float *grad_h_a, const float *grad_h_b, const float *grad_c, const float *act,
                                      const float *c_prev, const float *c_new, int n, int H, float *grad_gates,
                                      int grad_gates_ld, float *grad_c_prev, void *stream);
+/*    ..._sum_f32 (ABI 16): additionally keeps the running sum of the gate gradients over the token steps in grad_gates_sum
+ *    (n, 4H contiguous; first != 0: this step starts the sum, else it is added to) -- the gradient of the token-independent gate
+ *    part (W_ih's event-feature block times hs, LSTM_DSA.py:267-269), a (steps, n, 4H) reduction after the loop otherwise. */
+int gvl_lstm_cell_train_backward_sum_f32(const float *grad_h_a, const float *grad_h_b, const float *grad_c, const float *act,
+                                         const float *c_prev, const float *c_new, int n, int H, float *grad_gates,
+                                         int grad_gates_ld, float *grad_c_prev, float *grad_gates_sum, int first, void *stream);
 
 /* -- greedy decoding epilogue: idx[r] = argmax_v logits[r, v] (first maximal index), logp[r] = log_softmax(logits[r])
  *    at that index (LSTM_DSA.py:123 + :166-167), one read of the logits. */

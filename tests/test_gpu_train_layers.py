@@ -287,6 +287,17 @@ def test_expand_parts_node_is_chunk_expand_with_a_one_launch_gradient(B, Q, C, p
     sum((o * w_).sum() for o, w_ in zip(outs, ws)).backward()
     sum((o * w_).sum() for o, w_ in zip(want, ws)).backward()
     assert float((emb.grad - ref.grad).abs().max()) <= 1e-5 * float(ref.grad.abs().max())
+    # rows=True: the un-expanded blocks too; their gradients land in the same embedding gradient
+    emb.grad, ref.grad = None, None
+    outs = L.expand_parts(emb, B, parts, rows=True)
+    assert len(outs) == 2 * parts and all(torch.equal(outs[parts + h], emb.detach()[:, h * C:(h + 1) * C]) for h in range(parts))
+    wr = torch.randn(Q, C, device=dev, generator=g)
+    ((outs[0] * ws[0]).sum() + (outs[parts] * wr).sum()).backward()
+    ((want[0] * ws[0]).sum() + (ref[:, :C] * wr).sum()).backward()
+    assert float((emb.grad - ref.grad).abs().max()) <= 1e-5 * float(ref.grad.abs().max())
+    emb.grad = None
+    (L.expand_parts(emb, B, parts, rows=True)[parts] * wr).sum().backward()          # the rows alone
+    assert torch.equal(emb.grad[:, :C], wr) and float(emb.grad[:, C:].abs().sum()) == 0.0
     if parts > 1:                                             # only the last block is used
         emb.grad = None
         L.expand_parts(emb, B, parts)[-1].mul(ws[-1]).sum().backward()
