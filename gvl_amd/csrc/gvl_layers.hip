@@ -1107,7 +1107,54 @@ __global__ void __launch_bounds__(256) k_level_sums(const float *__restrict__ g,
   }
 }
 
+// rows with mask[r] != 0 set to zero IN PLACE (`value.masked_fill(padding_mask[..., None], 0)` of ms_deform_attn.py:100 on the fresh
+// output of value_proj): one wavefront per row, only the masked rows are written -- where the out-of-place ATen op is a copy of the
+// whole tensor plus a pass over it
+__global__ void __launch_bounds__(256) k_mask_rows(float *__restrict__ y, const unsigned char *__restrict__ mask, int R, int n4) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R || !mask[row]) return;
+  float4 *o = reinterpret_cast<float4 *>(y) + (int64_t)row * n4;
+  for (int i = lane; i < n4; i += 64) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// its gradient, out of place, with the row maxima of the result in the same pass (the Linear behind it splits its operand by them)
+__global__ void __launch_bounds__(256) k_mask_rows_bwd(const float *__restrict__ dy, const unsigned char *__restrict__ mask, int R,
+                                                       int n4, float *__restrict__ dx, float *__restrict__ amax) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const bool dead = mask[row] != 0;
+  const float4 *g = reinterpret_cast<const float4 *>(dy) + (int64_t)row * n4;
+  float4 *o = reinterpret_cast<float4 *>(dx) + (int64_t)row * n4;
+  float am = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    const float4 v = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : g[i];
+    o[i] = v;
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int s = 32; s; s >>= 1) am = fmaxf(am, __shfl_xor(am, s, 64));
+  if (lane == 0) amax[row] = am;
+}
+
 }  // namespace
+
+extern "C" int gvl_mask_rows_f32(float *y, const unsigned char *mask, int R, int C, void *stream) {
+  if (R < 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "gvl_mask_rows_f32: C %% 4 == 0 (got R=%d C=%d)", R, C);
+  if (R == 0) return 0;
+  if (!y || !mask || ((uintptr_t)y & 15)) return fail(GVL_EINVAL, "gvl_mask_rows_f32: null / unaligned pointer");
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_mask_rows", k_mask_rows, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, mask,
+                     R, C >> 2);
+}
+
+extern "C" int gvl_mask_rows_backward_f32(const float *dy, const unsigned char *mask, int R, int C, float *dx, float *amax,
+                                          void *stream) {
+  if (R < 0 || C <= 0 || (C & 3)) return fail(GVL_EINVAL, "gvl_mask_rows_backward_f32: C %% 4 == 0 (got R=%d C=%d)", R, C);
+  if (R == 0) return 0;
+  if (!dy || !mask || !dx || !amax || (((uintptr_t)dy | (uintptr_t)dx) & 15))
+    return fail(GVL_EINVAL, "gvl_mask_rows_backward_f32: null / unaligned pointer");
+  return gvl::launch(GVL_PROF_LAYER_NORM, R, C, "k_mask_rows_bwd", k_mask_rows_bwd, dim3((R + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, dy, mask, R, C >> 2, dx, amax);
+}
 
 extern "C" int gvl_level_sums_f32(const float *g, int B, int S, int C, const int *starts, const int *lengths, int L, float *part,
                                   void *stream) {

@@ -577,6 +577,49 @@ class _ExpandParts(torch.autograd.Function):
         return out, None, None
 
 
+class _MaskRows(torch.autograd.Function):
+    """value.masked_fill(padding_mask[..., None], 0) (ms_deform_attn.py:100) on the FRESH output of value_proj, in place: only the
+    padded rows are written (gvl_mask_rows_f32) where the out-of-place op copies the tensor and passes over it again; backward: the
+    gradient with the same rows zeroed and its row maxima in one pass (copy + masked_fill_ + row_absmax before)."""
+
+    @staticmethod
+    def forward(ctx, value, mask_u8):
+        C = value.shape[-1]
+        with torch.cuda.device(value.device):
+            rc = _lib.lib().gvl_mask_rows_f32(value.data_ptr(), mask_u8.data_ptr(), value.numel() // C, C,
+                                              torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mask_rows")
+        ctx.mark_dirty(value)
+        ctx.save_for_backward(mask_u8)
+        return value
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        mask_u8, = ctx.saved_tensors
+        g = g.contiguous()
+        C = g.shape[-1]
+        R = g.numel() // C
+        dx = torch.empty_like(g)
+        am = torch.empty(R, device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().gvl_mask_rows_backward_f32(g.data_ptr(), mask_u8.data_ptr(), R, C, dx.data_ptr(), am.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mask_rows_backward")
+        return tag_amax(dx, am), None
+
+
+def mask_rows(value, padding_mask):
+    """value (B, S, C) with the rows where padding_mask (B, S) is True set to zero.  Training on fp32 CUDA tensors that own their
+    storage (the result of a Linear): in place through _MaskRows; anything else: masked_fill"""
+    if (value.is_cuda and value.dtype == torch.float32 and torch.is_grad_enabled() and value.requires_grad and not value.is_leaf
+            and value.is_contiguous() and value._base is None and value.dim() == 3 and value.shape[-1] % 4 == 0
+            and padding_mask.dtype == torch.bool and padding_mask.shape == value.shape[:2] and value.data_ptr() % 16 == 0
+            and not torch.is_autocast_enabled() and os.environ.get("GVL_MASK_ROWS", "") != "torch"):
+        return _MaskRows.apply(value, padding_mask.contiguous().view(torch.uint8))
+    return value.masked_fill(padding_mask[..., None], float(0))
+
+
 class _LevelPosEmbed(torch.autograd.Function):
     """lvl_pos_embed_flatten of deformable_transformer.py:96-103 -- cat_l(pos_embed_l^T + level_embed[l]) (B, S, C) -- as one node
     (the position embeddings' gradients -- their learned duration half -- are slices of the incoming one).  The level embedding's is the per-level sum of the (B, S, C)

@@ -330,13 +330,15 @@ class _TrainLinearFunction(torch.autograd.Function):
             x2 = x2.contiguous()
         am = _row_amax(x2, x)
         op, op_t = _operands(weights, biases)
-        out = torch.empty(x2.shape[0], op.N, device=x.device, dtype=torch.float32)
-        L.linear(x2, op, [L.seg(0, out, am)])
+        # (allocated in the shape it is returned in: a view created in here could not be edited in place by the caller --
+        #  gvl_amd.layers.mask_rows zeroes the padded rows of a value projection that way)
+        out = torch.empty(*x.shape[:-1], op.N, device=x.device, dtype=torch.float32)
+        L.linear(x2, op, [L.seg(0, out.view(x2.shape[0], op.N), am)])
         ctx.save_for_backward(x2, am, *weights)
         ctx.op_t, ctx.nblk, ctx.x_shape = op_t, nblk, x.shape
         ctx.has_bias = [b is not None for b in biases]
         ctx.bias_params = tuple(biases)                       # (identity only: which parameters this node's gradients go to)
-        return out.view(*x.shape[:-1], op.N)
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable

@@ -17,6 +17,12 @@ from ... import MultiScaleDeformableAttention as MSDA
 from ...linear import Linear, linear, projection, train_linear, train_linear_eligible
 
 
+def _mask_rows(value, padding_mask):
+    """value with its padded rows zeroed (:100) -- gvl_amd.layers.mask_rows (imported late: layers imports this package)"""
+    from ... import layers
+    return layers.mask_rows(value, padding_mask)
+
+
 def _power_of_two(n):
     if not isinstance(n, int) or n < 0:
         raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
@@ -86,7 +92,7 @@ class MSDeformAttn(nn.Module):
         _, Len_in, _ = input_flatten.shape
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
+            value = _mask_rows(value, input_padding_mask)
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         off = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         aw = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
@@ -129,7 +135,7 @@ class MSDeformAttn(nn.Module):
         N, Len_in, _ = input_flatten.shape
         value = self.value_proj(input_flatten)
         if padding_mask is not None:
-            value = value.masked_fill(padding_mask[..., None], float(0))
+            value = _mask_rows(value, padding_mask)
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         # one GEMM for both projections: columns [0,128) raw offsets, [128,256) attention logits
         q = query.contiguous()

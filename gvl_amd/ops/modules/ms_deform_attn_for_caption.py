@@ -10,7 +10,7 @@ import warnings
 import torch
 from torch import nn
 
-from .ms_deform_attn import _power_of_two, offset_bias_init, temporal_shapes_2d
+from .ms_deform_attn import _mask_rows, _power_of_two, offset_bias_init, temporal_shapes_2d
 from ... import MultiScaleDeformableAttention as MSDA
 from ...linear import Linear
 
@@ -52,7 +52,7 @@ class MSDeformAttnCap(nn.Module):
         N, Len_in, _ = input_flatten.shape
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
+            value = _mask_rows(value, input_padding_mask)
         return value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
 
     def sampling_locations(self, query, reference_points, input_spatial_shapes):

@@ -53,7 +53,8 @@ extern "C" {
  * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training),
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
- *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps)
+ *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps),
+ *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
@@ -291,6 +292,11 @@ int gvl_batch_sum_f32(const float *const *grads, int parts, int B, int Q, int C,
  *    `lvl_pos_embed = pos_embed + level_embed[lvl]`): part[b][l][c] = sum of g[b][s][c] over the rows s of level l (starts / lengths:
  *    host arrays of the L <= 8 levels' row ranges in S); the sum over b is gvl_batch_sum_f32(parts = 1, Q = L). */
 int gvl_level_sums_f32(const float *g, int B, int S, int C, const int *starts, const int *lengths, int L, float *part, void *stream);
+/*    gvl_mask_rows_f32 / _backward_f32 (ABI 16): `value = value.masked_fill(input_padding_mask[..., None], 0)` (pdvc/ops/modules/
+ *    ms_deform_attn.py:100) on the fresh (R, C) output of value_proj: rows r with mask[r] != 0 are zeroed IN PLACE (only those rows
+ *    are written); backward: dx = dy with the same rows zeroed, out of place, and amax[r] = max |dx[r][.]| from the same pass. */
+int gvl_mask_rows_f32(float *y, const unsigned char *mask, int R, int C, void *stream);
+int gvl_mask_rows_backward_f32(const float *dy, const unsigned char *mask, int R, int C, float *dx, float *amax, void *stream);
 int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, const float *grad_row,
                                 const float *w_row, float *grad_hs, void *stream);
 

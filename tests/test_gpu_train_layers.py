@@ -385,3 +385,38 @@ def test_level_pos_embed_node_equals_the_torch_formulation(B, C, lengths):
     assert float(emb.grad[len(lengths)].abs().max()) == 0.0
     for p, r in zip(pos, pos_ref):                            # (the learned half of the position embedding: its slice of the gradient)
         assert (p.grad is None) == (r.grad is None) and (p.grad is None or torch.equal(p.grad, r.grad))
+
+
+def test_mask_rows_node_is_masked_fill_in_place_with_row_maxima_backward():
+    """gvl_amd.layers.mask_rows on a Linear's fresh output: the padded rows zeroed in place (the tensor returned IS the Linear's),
+    the gradient with the same rows zeroed and tagged with its row maxima; leaves / views / other dtypes take masked_fill"""
+    from gvl_amd import layers as L
+    from gvl_amd import linear as GL
+    torch.manual_seed(5)
+    B, S, C = 16, 188, 512
+    lin = GL.Linear(C, C).to(DEV)
+    x = torch.randn(B, S, C, device=DEV, requires_grad=True)
+    mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+    for b in range(B):
+        mask[b, S - 3 * b:] = True                              # ragged padding, video 0 unpadded
+    y = lin(x)
+    ptr = y.data_ptr()
+    out = L.mask_rows(y, mask)
+    assert out.data_ptr() == ptr
+    ref_x = x.detach().clone().requires_grad_()
+    ref_lin = GL.Linear(C, C).to(DEV)
+    ref_lin.load_state_dict(lin.state_dict())
+    want = ref_lin(ref_x).masked_fill(mask[..., None], 0.0)
+    assert torch.equal(out, want)
+    go = torch.randn(B, S, C, device=DEV)
+    out.backward(go)
+    want.backward(go)
+    assert float((x.grad - ref_x.grad).abs().max()) <= 2e-6 * float(ref_x.grad.abs().max())
+    assert float((lin.weight.grad - ref_lin.weight.grad).abs().max()) <= 2e-6 * float(ref_lin.weight.grad.abs().max())
+    # the node's own backward: zeroed rows + row maxima
+    g = torch.randn(B, S, C, device=DEV)
+    dx, _ = L._MaskRows.backward(type("C", (), {"saved_tensors": (mask.view(torch.uint8),)})(), g)
+    assert torch.equal(dx, g.masked_fill(mask[..., None], 0.0))
+    assert torch.equal(L.amax_of(dx, B * S), dx.abs().amax(-1).flatten())
+    leaf = torch.randn(B, S, C, device=DEV, requires_grad=True)
+    assert L.mask_rows(leaf, mask).data_ptr() != leaf.data_ptr()                  # (a leaf: out of place)
