@@ -171,7 +171,9 @@ def self_attention(mha, tgt, query_pos, query_mask, tgt_q=None):
         L_.tag_amax(x, L_.amax_of(tgt, B * Q))
     defer = bool(mha.__dict__.get("_gvl_defer_wgrad", False))
     qkv, am = _InProj.apply(x, query_pos[0], xq, mha.in_proj_weight, mha.in_proj_bias, defer)
-    keep = query_mask.to(torch.uint8).contiguous() if query_mask is not None else None
+    keep = None
+    if query_mask is not None:                          # (a bool mask's bytes ARE 0 / 1: no cast launch)
+        keep = query_mask.contiguous().view(torch.uint8) if query_mask.dtype == torch.bool else query_mask.to(torch.uint8).contiguous()
     p = mha.dropout if mha.training else 0.0
     site = mha.__dict__.get("_gvl_site_drop")
     if site is None:
