@@ -619,7 +619,8 @@ class Captioner(nn.Module):
             tm = (fused and nll is not None and vocab_nll_eligible(hs, self.logit.weight, self.logit.bias)
                   and os.environ.get("GVL_CAP_TIME_MAJOR", "1") != "0")
             ids = seq[:, :steps].t() if tm else seq[:, :steps]
-            emb = self.embed.weight.index_select(0, ids.reshape(-1)).view(*ids.shape, -1)
+            from .. import layers as _layers
+            emb = _layers.embed_rows(self.embed.weight, ids.reshape(-1)).view(*ids.shape, -1)
             xt_all = F.linear(emb, w_x)                                           # (n, steps, 4H); tm: (steps, n, 4H)
             if fused:
                 hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const, row_video, time_major=tm)

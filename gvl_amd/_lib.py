@@ -107,6 +107,7 @@ SIGNATURES = {
     "gvl_batch_sum_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "gvl_level_sums_f32": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "gvl_mask_rows_f32": (_I, [_P, _P, _I, _I, _P]),
+    "gvl_index_add_rows_f32": (_I, [_P, _I64, _P, _I, _I, _P, _I64, _I, _P]),
     "gvl_mask_rows_backward_f32": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "gvl_count_pool_backward_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "gvl_msda1d_fused_backward_workspace_bytes": (_SZ, [_I] * 7 + [_P]),

@@ -577,6 +577,41 @@ class _ExpandParts(torch.autograd.Function):
         return out, None, None
 
 
+class _EmbedRows(torch.autograd.Function):
+    """weight.index_select(0, ids) (the captioner's `self.embed(it)`, LSTM_DSA.py:96, for all teacher-forced steps at once) whose
+    backward skips the all-zero gradient rows (gvl_index_add_rows_f32): about half of a padded caption batch's positions are <pad>,
+    carry no gradient, and all land on ONE row of the table -- 50 us of serialised atomics in index_add at cfg A."""
+
+    @staticmethod
+    def forward(ctx, weight, ids):
+        ctx.save_for_backward(ids)
+        ctx.shape = weight.shape
+        return weight.index_select(0, ids)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        ids, = ctx.saved_tensors
+        V, E = ctx.shape
+        if g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16:
+            g = g.contiguous()
+        out = torch.zeros(V, E, device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().gvl_index_add_rows_f32(g.data_ptr(), g.stride(0), ids.data_ptr(), ids.numel(), E, out.data_ptr(), E, V,
+                                                   torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "index_add_rows")
+        return out, None
+
+
+def embed_rows(weight, ids):
+    """weight (V, E)[ids (n)] -> (n, E); training on fp32 CUDA tables: through _EmbedRows"""
+    if (weight.is_cuda and weight.dtype == torch.float32 and torch.is_grad_enabled() and weight.requires_grad and weight.dim() == 2
+            and weight.is_contiguous() and weight.shape[1] % 4 == 0 and ids.dtype == torch.int64 and ids.dim() == 1
+            and not torch.is_autocast_enabled() and os.environ.get("GVL_EMBED_ROWS", "") != "torch"):
+        return _EmbedRows.apply(weight, ids.contiguous())
+    return weight.index_select(0, ids)
+
+
 class _MaskRows(torch.autograd.Function):
     """value.masked_fill(padding_mask[..., None], 0) (ms_deform_attn.py:100) on the FRESH output of value_proj, in place: only the
     padded rows are written (gvl_mask_rows_f32) where the out-of-place op copies the tensor and passes over it again; backward: the

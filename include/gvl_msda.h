@@ -54,7 +54,8 @@ extern "C" {
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
  *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps),
- *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection)
+ *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_index_add_rows_f32 (an embedding
+ *      lookup's gradient without the additions of zero rows)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
  * 14: gvl_adam_desc carries each tensor's OWN step pointer and gvl_clip_adam_step_f32 takes (n_tensors, corr) instead of one
@@ -296,6 +297,12 @@ int gvl_level_sums_f32(const float *g, int B, int S, int C, const int *starts, c
  *    ms_deform_attn.py:100) on the fresh (R, C) output of value_proj: rows r with mask[r] != 0 are zeroed IN PLACE (only those rows
  *    are written); backward: dx = dy with the same rows zeroed, out of place, and amax[r] = max |dx[r][.]| from the same pass. */
 int gvl_mask_rows_f32(float *y, const unsigned char *mask, int R, int C, void *stream);
+/*    gvl_index_add_rows_f32 (ABI 16): dst[idx[r]][:] += src[r][:] (float atomics) for the rows of src that are not all zero -- the
+ *    gradient of the captioner's embedding lookup (pdvc/CaptioningHead/LSTM_DSA.py:96, `self.embed(it)`): the padded positions of a
+ *    caption batch all index <pad> and carry zero gradients; skipping them removes the serialised additions on that one row.
+ *    src (n, ld >= E), idx (n) int64 in [0, V) (others skipped), dst (V, ld_dst) already initialised (zeros for a fresh gradient). */
+int gvl_index_add_rows_f32(const float *src, int64_t ld, const int64_t *idx, int n, int E, float *dst, int64_t ld_dst, int V,
+                           void *stream);
 int gvl_mask_rows_backward_f32(const float *dy, const unsigned char *mask, int R, int C, float *dx, float *amax, void *stream);
 int gvl_count_pool_backward_f32(const float *grad_pooled, const int *arg, int B, int Q, int C, const float *grad_row,
                                 const float *w_row, float *grad_hs, void *stream);

@@ -420,3 +420,24 @@ def test_mask_rows_node_is_masked_fill_in_place_with_row_maxima_backward():
     assert torch.equal(L.amax_of(dx, B * S), dx.abs().amax(-1).flatten())
     leaf = torch.randn(B, S, C, device=DEV, requires_grad=True)
     assert L.mask_rows(leaf, mask).data_ptr() != leaf.data_ptr()                  # (a leaf: out of place)
+
+
+def test_embed_rows_node_is_index_select_with_a_gradient_that_skips_zero_rows():
+    """gvl_amd.layers.embed_rows: the captioner's embedding lookup; its backward (gvl_index_add_rows_f32) equals index_add -- with
+    half of the gradient rows zero and pointing at one entry (the padded positions), repeated indices, an odd width"""
+    from gvl_amd import layers as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    for V, E, n in ((8518, 512, 4416), (50, 68, 300), (7, 1028, 5)):
+        w = torch.randn(V, E, device=dev, generator=g, requires_grad=True)
+        ids = torch.randint(0, V, (n,), device=dev, generator=g)
+        ids[: n // 2] = 0                                         # <pad>
+        ids[n // 2: n // 2 + n // 8] = 1                          # a hot word
+        out = L.embed_rows(w, ids)
+        assert torch.equal(out, w.detach()[ids])
+        go = torch.randn(n, E, device=dev, generator=g)
+        go[: n // 2] = 0.0
+        go[-1, ::2] = 0.0                                         # (zeros inside a live row are skipped element-wise)
+        out.backward(go)
+        want = torch.zeros(V, E, device=dev, dtype=torch.float64).index_add_(0, ids, go.double())
+        assert float((w.grad.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
