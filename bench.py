@@ -103,19 +103,29 @@ def in_graph_kernel_us(a, mode):
         files = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)
         if p.returncode != 0 or not files:
             return {"error": f"rocprofv3 child failed (rc {p.returncode}): {p.stderr[-300:]}"}
-        rows = {"fwd": [], "fwd_train": [], "bwd": []}
+        rows = {"fwd": [], "bwd": []}
         with open(files[0]) as f:
             for r in csv.DictReader(f):
                 n = r["Kernel_Name"]
                 if "k_fwd_t1d_d64" in n:
-                    # the EVAL forward's launches: the instantiation that also leaves the output rows' maxima (last template
-                    # argument AMAX = true: the inference layers' form); the train step's forward uses the plain one
-                    targs = n[n.find("k_fwd_t1d_d64<") + 14:].split(">")[0].replace(" ", "").split(",")
-                    rows["fwd" if targs[-1] in ("true", "1") else "fwd_train"].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+                    rows["fwd"].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
                 elif "k_bwd_t1d_split" in n or "k_bwd_t1d_own" in n or "k_bwd_t1d_d64" in n:
                     rows["bwd"].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-        if not rows["fwd"]:
-            rows["fwd"] = rows["fwd_train"]
+        # the EVAL forward's launches (what `value` is made of): groups of four forward launches that no backward launch follows
+        # before the next group -- a train step's four are followed by its backward's (both steps launch the same instantiation
+        # since the training forward also leaves the output rows' maxima)
+        fw, bw_starts = sorted(rows["fwd"]), sorted(t0 for t0, _ in rows["bwd"])
+        if len(fw) % 4 == 0 and bw_starts:
+            import bisect
+            groups = [fw[i:i + 4] for i in range(0, len(fw), 4)]
+            eval_groups = []
+            for gi, grp in enumerate(groups):
+                nxt = groups[gi + 1][0][0] if gi + 1 < len(groups) else float("inf")
+                j = bisect.bisect_right(bw_starts, grp[-1][1])
+                if not (j < len(bw_starts) and bw_starts[j] < nxt):
+                    eval_groups += grp
+            if eval_groups:
+                rows["fwd"] = eval_groups
         res = {}
         for kind, dec_pos in (("fwd", (2, 3)), ("bwd", (0, 1))):
             rs = sorted(rows[kind])
