@@ -128,11 +128,17 @@ class ShowAttendTellCore(nn.Module):
             const = {"slab": slab, "gates_hs": gates_hs, "off_hs": off_hs}
             const.update(slab3=slab.view(B, S, -1), alpha_b=self._alpha_b, **weights)
             return const
-        value = att.project_value(input_flatten, input_padding_mask)              # (B,S,1,C)
-        B, S = value.shape[:2]
-        v2 = value.reshape(B, S, -1)
-        va = self.ctx2att(v2)                                                     # ctx2att pushed through sampling
-        slab = torch.cat([v2, va], -1).view(B, S, 1, -1).contiguous()            # (B,S,1,C+A)
+        if torch.is_grad_enabled() and _cap_slab_eligible(self, input_flatten, input_padding_mask):
+            B, S = input_flatten.shape[:2]
+            mask_u8 = input_padding_mask.contiguous().view(torch.uint8) if input_padding_mask is not None else None
+            slab = _CapSlab.apply(input_flatten, mask_u8, att.value_proj.weight, att.value_proj.bias, self.ctx2att.weight,
+                                  self.ctx2att.bias).view(B, S, 1, -1)           # (training: both halves written in place)
+        else:
+            value = att.project_value(input_flatten, input_padding_mask)          # (B,S,1,C)
+            B, S = value.shape[:2]
+            v2 = value.reshape(B, S, -1)
+            va = self.ctx2att(v2)                                                 # ctx2att pushed through sampling
+            slab = torch.cat([v2, va], -1).view(B, S, 1, -1).contiguous()        # (B,S,1,C+A)
         C = query.shape[-1]
         w_ih = self.rnn.weight_ih_l0
         E = self.input_encoding_size
@@ -360,6 +366,82 @@ class ShowAttendTellCore(nn.Module):
         out, (h, c) = self.step(xt_gates, (state[0][-1].contiguous(), state[1][-1].contiguous()), query,
                                 reference_points, input_spatial_shapes, input_level_start_index, const)
         return out, (h[None], c[None])
+
+
+class _CapSlab(torch.autograd.Function):
+    """The captioner's sampling slab [value_proj(memory) with padded rows zeroed | ctx2att(of that)] (B, S, C + A) in TRAINING as one
+    node (ms_deform_attn_for_caption.py:98-101 + LSTM_DSA.py:253, ctx2att pushed through the sampling): both products write their
+    half of the slab in place (row mask and row maxima in the first one's epilogue) -- no masked copy, no row-maximum pass, no cat;
+    backward: the ctx2att input gradient lands ON the value half's gradient in the product's epilogue (no add), the padded rows'
+    zeroing and the row maxima in one pass, both weight gradients through the backward pass's grouped launches."""
+
+    @staticmethod
+    def forward(ctx, mem, mask_u8, wv, bv, wc, bc):
+        from .. import layers as L
+        from .. import train_layers as TL
+        from ..linear import _operands, _row_amax
+        B, S, C = mem.shape
+        R, Cf, A = B * S, wv.shape[0], wc.shape[0]
+        x2 = mem.reshape(R, C)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        am_x = _row_amax(x2, mem)
+        opv, opv_t = _operands((wv,), (bv,))
+        opc, opc_t = _operands((wc,), (bc,))
+        slab = torch.empty(B, S, Cf + A, device=mem.device, dtype=torch.float32)
+        s2 = slab.view(R, Cf + A)
+        am_v = TL.step_zeros(R, mem.device)
+        L.linear(x2, opv, [L.seg(0, s2[:, :Cf], am_x, rowmask=mask_u8, amax_out=am_v)])
+        L.linear(s2[:, :Cf], opc, [L.seg(0, s2[:, Cf:], am_v)])
+        ctx.save_for_backward(x2, am_x, slab, am_v, mask_u8 if mask_u8 is not None else x2.new_empty(0), wv, wc)
+        ctx.ops, ctx.params, ctx.has_mask, ctx.in_shape = (opv_t, opc_t), (wv, bv, wc, bc), mask_u8 is not None, mem.shape
+        return slab
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import _lib
+        from .. import layers as L
+        from ..linear import queued_wgrad
+        x2, am_x, slab, am_v, mask_u8, wv, wc = ctx.saved_tensors
+        opv_t, opc_t = ctx.ops
+        R, Cf = x2.shape[0], wv.shape[0]
+        g2 = g.reshape(R, slab.shape[-1])
+        if g2.stride(1) != 1 or g2.stride(0) % 4 or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        g_v, g_a = g2[:, :Cf], g2[:, Cf:]
+        am_ga = L.row_absmax(g_a)[0]
+        dv = torch.empty(R, Cf, device=g.device, dtype=torch.float32)
+        L.linear(g_a, opc_t, [L.seg(0, dv, am_ga, resid=g_v)])                    # d value = d(value half) + d(ctx2att half) Wc
+        if ctx.has_mask:
+            dvm = torch.empty_like(dv)
+            am_dv = torch.empty(R, device=g.device, dtype=torch.float32)
+            with torch.cuda.device(g.device):
+                rc = _lib.lib().gvl_mask_rows_backward_f32(dv.data_ptr(), mask_u8.data_ptr(), R, Cf, dvm.data_ptr(), am_dv.data_ptr(),
+                                                           torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "mask_rows_backward")
+        else:
+            dvm, am_dv = dv, L.row_absmax(dv)[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(R, x2.shape[1], device=g.device, dtype=torch.float32)
+            L.linear(dvm, opv_t, [L.seg(0, dx, am_dv)])
+            dx = dx.view(ctx.in_shape)
+        s2 = slab.view(R, slab.shape[-1])
+        gwc, gbc = queued_wgrad(g_a, s2[:, :Cf], am_ga, am_v, True, (ctx.params[2], ctx.params[3]), True)
+        gwv, gbv = queued_wgrad(dvm, x2, am_dv, am_x, True, (ctx.params[0], ctx.params[1]), True)
+        return dx, None, gwv, gbv, gwc, gbc
+
+
+def _cap_slab_eligible(core, mem, mask):
+    from ..linear import train_linear_eligible
+    att = core.deformable_att
+    vp, ca = att.value_proj, core.ctx2att
+    return (mem.dim() == 3 and vp.bias is not None and ca.bias is not None and att.n_heads == 1
+            and train_linear_eligible(mem, (vp.weight,), (vp.bias,))
+            and train_linear_eligible(mem.new_empty(1).expand(mem.shape[0] * mem.shape[1], vp.weight.shape[0]), (ca.weight,), (ca.bias,))
+            and (mask is None or (mask.dtype == torch.bool and mask.shape == mem.shape[:2]))
+            and vp.weight.shape[0] % 4 == 0 and os.environ.get("GVL_CAP_SLAB", "") != "torch")
 
 
 def _bf16_decode(fn):

@@ -441,3 +441,42 @@ def test_embed_rows_node_is_index_select_with_a_gradient_that_skips_zero_rows():
         out.backward(go)
         want = torch.zeros(V, E, device=dev, dtype=torch.float64).index_add_(0, ids, go.double())
         assert float((w.grad.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_captioner_slab_node_equals_project_value_ctx2att_cat(monkeypatch):
+    """gvl_amd.CaptioningHead.LSTM_DSA._CapSlab -- [value_proj(memory) masked | ctx2att(.)] with both halves written in place and a
+    hand-written backward -- against the formulation it replaces (project_value, ctx2att, cat), at the cfg A memory shape: the slab,
+    the memory gradient and the four parameter gradients"""
+    from gvl_amd.config import make_opt
+    from gvl_amd.CaptioningHead.LSTM_DSA import ShowAttendTellCore
+    torch.manual_seed(7)
+    opt = make_opt("anet_tsp_ssvg", device="cuda")
+    core = ShowAttendTellCore(opt).to(DEV).train()
+    with torch.no_grad():
+        core.deformable_att.value_proj.bias.normal_(0, 0.1)
+        core.ctx2att.bias.normal_(0, 0.1)
+    B, S, C = 16, 188, 512
+    mem0 = torch.randn(B, S, C, device=DEV)
+    mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+    for b in range(B):
+        mask[b, S - 2 * b:] = True
+    query = torch.randn(B, 12, C * 2 if core.deformable_att.sampling_offsets.weight.shape[1] == core.rnn_size + 2 * C else C, device=DEV)
+    query = query[..., :core.deformable_att.sampling_offsets.weight.shape[1] - core.rnn_size]
+    go = torch.randn(B, S, 1, 1024, device=DEV)
+    from gvl_amd.CaptioningHead.LSTM_DSA import _cap_slab_eligible
+    assert _cap_slab_eligible(core, mem0.clone().requires_grad_(), mask)
+    res = {}
+    ps = [core.deformable_att.value_proj.weight, core.deformable_att.value_proj.bias, core.ctx2att.weight, core.ctx2att.bias]
+    for mode in ("node", "torch"):
+        if mode == "torch":
+            monkeypatch.setenv("GVL_CAP_SLAB", "torch")
+        mem = mem0.clone().requires_grad_()
+        for p_ in core.parameters():
+            p_.grad = None
+        slab = core.prepare(query, mem, mask)["slab"]
+        (slab * go).sum().backward()
+        res[mode] = [slab.detach().clone(), mem.grad.clone()] + [p_.grad.clone() for p_ in ps]
+    for a, b in zip(res["node"], res["torch"]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), (a.shape, float((a - b).abs().max()))
+    assert float(res["node"][0][0, S - 1, 0, :512].abs().max()) > 0.0              # (video 0 has no padded row)
+    assert float(res["node"][0][5, S - 1, 0, :512].abs().max()) == 0.0              # a padded row: the value half is zero
