@@ -387,60 +387,63 @@ class PDVC(nn.Module):
     def parallel_prediction_full(self, dt, criterion, contrastive_criterion, hs, query_embed, init_reference,
                                  inter_references, others, disable_iterative_refine, disable_captioning=False):
         num_pred = hs.shape[0]
-        classes, counts, coords, cap_probs, seqs = [], [], [], [], []
-        # Inference: matching + losses (a one-workgroup assignment kernel and ~30 small launches, 0.2 ms) depend on the heads only,
-        # the greedy token loop (6 ms) on neither -- the criterion runs on a side stream UNDER the token loop instead of behind
-        # it (inside a hipGraph capture: a parallel branch of the graph).  GVL_EVAL_OVERLAP=0: one stream, as before.
+        # Inference: the count heads (one workgroup per video), matching (a one-workgroup assignment kernel) and the losses --
+        # ~35 small launches, 0.25 ms -- depend on the decoder's output only, the greedy token loop (6 ms) on none of them: they run
+        # on a side stream UNDER the token loop instead of in front of / behind it (inside a hipGraph capture: a parallel branch
+        # of the graph).  GVL_EVAL_OVERLAP=0: one stream, as before.
         overlap = (criterion is not None and not torch.is_grad_enabled() and hs.is_cuda and not disable_captioning
                    and self.opt.caption_decoder_type == 'standard' and os.environ.get("GVL_EVAL_OVERLAP", "1") != "0")
-        pending = None
-        for l_id in range(num_pred):
-            reference = init_reference if l_id == 0 else inter_references[l_id - 1]
-            hs_lid = hs[l_id]
-            if l_id == num_pred - 1 and getattr(hs, "_gvl_amax", None) is not None:
-                hs_lid._gvl_amax = hs._gvl_amax          # row maxima of the last layer's rows (gvl_amd/layers.py); a view
-                #                                          shares its base's version counter, so the tag stays checkable
-            cls, cnt, coord = self._layer_heads(l_id, hs_lid, reference, disable_iterative_refine)
-            hs_cap = torch.cat([hs_lid, query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
-                                                                                    False) else hs_lid
-            classes.append(cls); counts.append(cnt); coords.append(coord)
-            if l_id != num_pred - 1 or disable_captioning:
-                probs, seq = self._no_caption(hs_cap)
-            elif overlap:
-                probs, seq = self._no_caption(hs_cap)             # placeholders: replaced below, after the fork
-                pending = (l_id, hs_cap, reference)
-            else:
-                probs, seq = self.caption_prediction_eval(self.caption_head[l_id], dt, hs_cap, reference, others,
-                                                          self.opt.caption_decoder_type)
-            cap_probs.append(probs); seqs.append(seq)
-        if torch.is_grad_enabled():
-            self.transformer.decoder.__dict__["_gvl_coords"] = None       # (see parallel_prediction_matched)
-        all_out = self._pack(hs, classes, counts, coords, cap_probs, seqs)
-        all_out['event_embed'] = others['event_embed']
-        all_out['event_feat'] = hs
-        out = {k: v[-1] for k, v in all_out.items()}
-        if self.aux_loss:
-            keys = list(all_out.keys())
-            out['aux_outputs'] = [{k: all_out[k][j] for k in keys} for j in range(num_pred - 1)]
-        if criterion is None:                                   # pure-inference use (bench / graph capture)
-            return out, {}
-        if pending is None:
-            loss, last_indices, *_ = criterion(out, self._targets(dt))
+
+        def heads_and_losses(with_captions):
+            classes, counts, coords, cap_probs, seqs = [], [], [], [], []
+            for l_id in range(num_pred):
+                reference = init_reference if l_id == 0 else inter_references[l_id - 1]
+                hs_lid = hs[l_id]
+                if l_id == num_pred - 1 and getattr(hs, "_gvl_amax", None) is not None:
+                    hs_lid._gvl_amax = hs._gvl_amax      # row maxima of the last layer's rows (gvl_amd/layers.py); a view
+                    #                                      shares its base's version counter, so the tag stays checkable
+                cls, cnt, coord = self._layer_heads(l_id, hs_lid, reference, disable_iterative_refine)
+                hs_cap = torch.cat([hs_lid, query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
+                                                                                        False) else hs_lid
+                if l_id != num_pred - 1 or disable_captioning or not with_captions:
+                    probs, seq = self._no_caption(hs_cap)         # (overlap: placeholders, replaced after the join)
+                else:
+                    probs, seq = self.caption_prediction_eval(self.caption_head[l_id], dt, hs_cap, reference, others,
+                                                              self.opt.caption_decoder_type)
+                classes.append(cls); counts.append(cnt); coords.append(coord); cap_probs.append(probs); seqs.append(seq)
+            if torch.is_grad_enabled():
+                self.transformer.decoder.__dict__["_gvl_coords"] = None       # (see parallel_prediction_matched)
+            all_out = self._pack(hs, classes, counts, coords, cap_probs, seqs)
+            all_out['event_embed'] = others['event_embed']
+            all_out['event_feat'] = hs
+            out = {k: v[-1] for k, v in all_out.items()}
+            if self.aux_loss:
+                keys = list(all_out.keys())
+                out['aux_outputs'] = [{k: all_out[k][j] for k in keys} for j in range(num_pred - 1)]
+            if criterion is None:                               # pure-inference use (bench / graph capture)
+                return out, {}
+            loss, last_indices, *_ = criterion(out, targets)
             return out, loss
-        targets = self._targets(dt)
+
+        targets = self._targets(dt) if criterion is not None else None
+        if not overlap:
+            return heads_and_losses(True)
         main = torch.cuda.current_stream(hs.device)
         side = self.__dict__.get("_gvl_side_stream")
         if side is None or side.device != hs.device:
             side = self.__dict__["_gvl_side_stream"] = torch.cuda.Stream(device=hs.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            loss, last_indices, *_ = criterion(out, targets)     # (reads the heads' outputs only; leaves out['matched_indices'])
-        l_id, hs_cap, reference = pending
+            out, loss = heads_and_losses(False)                 # (the criterion reads the heads' outputs only)
+        l_id = num_pred - 1
+        reference = init_reference if l_id == 0 else inter_references[l_id - 1]
+        hs_cap = torch.cat([hs[l_id], query_embed], dim=-1) if vars(self.opt).get('enable_pos_emb_for_captioner',
+                                                                                  False) else hs[l_id]
         probs, seq = self.caption_prediction_eval(self.caption_head[l_id], dt, hs_cap, reference, others,
                                                   self.opt.caption_decoder_type)
         main.wait_stream(side)
         if not torch.cuda.is_current_stream_capturing():          # (a captured graph's memory is static: nothing to record)
-            for v in loss.values():
+            for v in list(loss.values()) + [out['pred_logits'], out['pred_count'], out['pred_boxes']]:
                 if isinstance(v, torch.Tensor) and v.is_cuda:
                     v.record_stream(main)                         # (allocated on the side stream, read on this one from here on)
         out['caption_probs'], out['seq'] = probs, seq
