@@ -194,6 +194,12 @@ class PDVC(nn.Module):
         memory = self.transformer.forward_encoder(src, tshapes, lsi, valid_ratios, lvl_pos, mask_flat)
         return memory, tshapes, lsi, valid_ratios, mask_flat
 
+    def _side_stream(self, device):
+        side = self.__dict__.get("_gvl_side_stream")
+        if side is None or side.device != torch.device(device):
+            side = self.__dict__["_gvl_side_stream"] = torch.cuda.Stream(device=device)
+        return side
+
     def supports_padded_targets(self, criterion, eval_mode, batch=None, slots=None):
         """Can a step on this model run in the layout-independent form (dt['_gvl_targets'] = PaddedTargets; what
         gvl_amd.parallel's captured steps use)?  Eval: whenever the criterion can.  Train: additionally the caption
@@ -245,6 +251,8 @@ class PDVC(nn.Module):
             # TRAINING: the planes of every weight the hand-written Linear products read, for this forward's parameter values
             # (two launches); the products' autograd nodes keep what their backward needs
             tp = self.train_planes()
+            # (tried: the refresh on a side stream under the feature pyramid, which needs none of these planes -- a parallel branch
+            #  in the captured TRAIN graph cost +0.7 ms per replay, 6.20 -> 6.88 ms; the inference graph gains from its branch)
             tp.refresh()
             from . import train_layers as _tl
             _tl.arena_reset(dt['video_tensor'].device)                    # one fill for the step's row-maxima vectors
@@ -429,9 +437,7 @@ class PDVC(nn.Module):
         if not overlap:
             return heads_and_losses(True)
         main = torch.cuda.current_stream(hs.device)
-        side = self.__dict__.get("_gvl_side_stream")
-        if side is None or side.device != hs.device:
-            side = self.__dict__["_gvl_side_stream"] = torch.cuda.Stream(device=hs.device)
+        side = self._side_stream(hs.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             out, loss = heads_and_losses(False)                 # (the criterion reads the heads' outputs only)
