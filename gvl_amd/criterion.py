@@ -120,6 +120,47 @@ def unbind_tagged(vec):
     return parts
 
 
+def weighted_loss_sum(loss, weight_dict, cache=None):
+    """train.py:403 -- `sum(loss[k] * weight_dict[k] for k in loss.keys() if k in weight_dict)` -- for scalar tensor terms as ONE dot
+    product: 2-3 launches forward and one backward instead of a mul + add per term and their backward (30 launches for the 10
+    terms of cfg A).  Terms that are entries of a loss VECTOR (unbind_tagged: the criterion's table, the captioner's per-layer
+    losses) are taken from the vector itself -- dot(cat(vectors)[weighted entries], weights) --, so autograd sees no unbind; the
+    rest are stacked.  The unweighted entries are SELECTED away, never multiplied by 0: loss_self_iou is 0/0 for a single match,
+    as the reference's.  cache: a dict the caller keeps (weights / indices per term layout AND weight values)."""
+    wd = weight_dict
+    keys = tuple(k for k in loss.keys() if k in wd)
+    if not (len(keys) > 2 and all(isinstance(loss[k], torch.Tensor) and loss[k].dim() == 0 for k in keys)
+            and len({loss[k].device for k in keys}) == 1):
+        return sum(loss[k].float() * wd[k] for k in keys)
+    cache = {} if cache is None else cache
+    dev = loss[keys[0]].device
+    vecs, offs, where, loose, total = [], {}, [], [], 0
+    for k in keys:
+        tag = getattr(loss[k], "_gvl_vec", None)
+        if tag is None or tag[0].dim() != 1 or tag[0].dtype != torch.float32 or tag[0].device != dev:
+            loose.append(k)
+            continue
+        if id(tag[0]) not in offs:
+            offs[id(tag[0])] = total
+            vecs.append(tag[0])
+            total += tag[0].numel()
+        where.append((k, offs[id(tag[0])] + tag[1]))
+    if loose:
+        vecs.append(torch.stack([loss[k].float() for k in loose]))
+        where += [(k, total + i) for i, k in enumerate(loose)]
+        total += len(loose)
+    weights = tuple(float(wd[k]) for k, _ in where)
+    sig = (keys, tuple(v.numel() for v in vecs), tuple(i for _, i in where), weights, str(dev))
+    hit = cache.get(sig)
+    if hit is None:
+        hit = cache[sig] = (torch.tensor(weights, dtype=torch.float32, device=dev),
+                            torch.tensor([i for _, i in where], dtype=torch.int64, device=dev))
+    full = vecs[0] if len(vecs) == 1 else torch.cat(vecs)
+    if [i for _, i in where] != list(range(total)):
+        full = full.index_select(0, hit[1])
+    return torch.dot(full, hit[0])
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, losses, focal_alpha=0.25, focal_gamma=2, opt={}):
         super().__init__()

@@ -247,41 +247,8 @@ class TrainStep:
         with torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None,
                             cache_enabled=False):
             out, loss = self.model(dt, self.criterion, None, self.opt.transformer_input_type)
-        wd = self.criterion.weight_dict
-        keys = tuple(k for k in loss.keys() if k in wd)
-        if len(keys) > 2 and all(isinstance(loss[k], torch.Tensor) and loss[k].dim() == 0 and loss[k].is_cuda for k in keys):
-            # the weighted sum of train.py:403 (`sum(loss[k] * weight_dict[k] ...)`) as stack + dot: 2 launches forward and 1
-            # backward instead of a mul + add per loss term and their backward (30 launches for the 10 terms of cfg A)
-            cache = self.__dict__.setdefault("_loss_weights", {})
-            dev = loss[keys[0]].device
-            # terms that are entries of a loss VECTOR (criterion.unbind_tagged: the criterion's table, the captioner's per-layer
-            # losses) are taken from the vector itself -- dot(cat(vectors)[weighted entries], weights); the rest are stacked.  The
-            # unweighted entries are SELECTED away, not multiplied by 0: loss_self_iou is 0/0 for a single match, as the reference's
-            vecs, offs, where, loose, total = [], {}, [], [], 0
-            for k in keys:
-                tag = getattr(loss[k], "_gvl_vec", None)
-                if tag is None or tag[0].dim() != 1 or tag[0].dtype != torch.float32:
-                    loose.append(k)
-                    continue
-                if id(tag[0]) not in offs:
-                    offs[id(tag[0])] = total
-                    vecs.append(tag[0])
-                    total += tag[0].numel()
-                where.append((k, offs[id(tag[0])] + tag[1]))
-            if loose:
-                vecs.append(torch.stack([loss[k].float() for k in loose]))
-                where += [(k, total + i) for i, k in enumerate(loose)]
-                total += len(loose)
-            sig = (keys, tuple(v.numel() for v in vecs), tuple(i for _, i in where))
-            hit = cache.get(sig)
-            if hit is None or hit[0].device != dev:
-                hit = cache[sig] = (torch.tensor([float(wd[k]) for k, _ in where], dtype=torch.float32, device=dev),
-                                    torch.tensor([i for _, i in where], dtype=torch.int64, device=dev))
-            full = vecs[0] if len(vecs) == 1 else torch.cat(vecs)
-            if [i for _, i in where] != list(range(total)):
-                full = full.index_select(0, hit[1])
-            return torch.dot(full, hit[0]), loss
-        return sum(loss[k].float() * wd[k] for k in keys), loss
+        from .criterion import weighted_loss_sum
+        return weighted_loss_sum(loss, self.criterion.weight_dict, self.__dict__.setdefault("_loss_weights", {})), loss
 
     def __call__(self, dt):
         self.buckets.zero()                                                    # optimizer.zero_grad(), flat

@@ -149,3 +149,36 @@ def test_wgrad_queue_takes_a_second_gradient_of_the_same_parameter_at_once(monke
     fresh = torch.nn.Parameter(torch.zeros(1))
     q.push(dy, x, am, am, True, [id(fresh)])
     assert calls[-1] == ("group", 3) and len(q.items) == 1
+
+
+def test_weighted_loss_sum_is_the_plain_weighted_sum_and_never_multiplies_an_unweighted_entry():
+    """gvl_amd.criterion.weighted_loss_sum (train.py:403 as one dot product over the loss vectors): equals the term-by-term sum for
+    tagged vector entries, loose scalars and a mix; a NaN in an UNWEIGHTED vector entry (loss_self_iou is 0/0 for a single match)
+    does not reach the sum; gradients flow to the vectors; a changed weight is not served from the cache"""
+    import torch
+    from gvl_amd.criterion import unbind_tagged, weighted_loss_sum
+    torch.manual_seed(0)
+    table = torch.randn(12, requires_grad=True)
+    caps = torch.randn(2, requires_grad=True)
+    loose = torch.randn((), requires_grad=True)
+    with torch.no_grad():
+        table[4] = float("nan")                                        # an unweighted entry
+    names = [f"t{i}" for i in range(12)]
+    loss = dict(zip(names, unbind_tagged(table)))
+    loss.update(zip(("cap", "cap_0"), unbind_tagged(caps)))
+    loss["loose"] = loose * 2.0
+    loss["not_a_loss"] = 3                                            # (ints and unweighted keys are ignored)
+    wd = {n: 0.5 + 0.1 * i for i, n in enumerate(names) if i not in (4, 5)}
+    wd.update(cap=2.0, cap_0=1.5, loose=0.25, absent=7.0)
+    cache = {}
+    got = weighted_loss_sum(loss, wd, cache)
+    want = sum(loss[k].float() * wd[k] for k in loss if k in wd)
+    assert torch.isfinite(got) and abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    got.backward()
+    g = table.grad.clone()
+    assert g[4] == 0 and g[5] == 0 and abs(float(g[0]) - 0.5) < 1e-6 and abs(float(caps.grad[1]) - 1.5) < 1e-6
+    assert abs(float(loose.grad) - 0.5) < 1e-6
+    wd["t0"] = 9.0                                                    # (criterion.weight_dict is edited in place by gt_proposals mode)
+    got2 = weighted_loss_sum(loss, wd, cache)
+    assert abs(float(got2) - float(got) - (9.0 - 0.5) * float(table[0])) <= 1e-4
+    assert float(weighted_loss_sum({"a": torch.tensor(1.0), "b": torch.tensor(2.0)}, {"a": 2.0, "b": 3.0})) == 8.0    # (few terms: plain)
