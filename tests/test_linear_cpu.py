@@ -182,3 +182,35 @@ def test_weighted_loss_sum_is_the_plain_weighted_sum_and_never_multiplies_an_unw
     got2 = weighted_loss_sum(loss, wd, cache)
     assert abs(float(got2) - float(got) - (9.0 - 0.5) * float(table[0])) <= 1e-4
     assert float(weighted_loss_sum({"a": torch.tensor(1.0), "b": torch.tensor(2.0)}, {"a": 2.0, "b": 3.0})) == 8.0    # (few terms: plain)
+
+
+def test_training_nodes_fall_back_to_their_pytorch_formulation_off_the_device():
+    """the round-6 training nodes (gvl_amd/layers.py, train_layers.py) are eligibility-gated: on CPU tensors every one of them is
+    its PyTorch formulation (nothing here may touch the library); the per-step snapshot of the step counter is taken once per
+    open step and again after the next one opens"""
+    import torch
+    from gvl_amd import layers as L
+    from gvl_amd import train_layers as TL
+    x, sub = torch.randn(2, 5, 8, requires_grad=True), torch.randn(2, 5, 8)
+    norm, drop = torch.nn.LayerNorm(8), torch.nn.Dropout(0.0)
+    ys = TL.residual_dropout_norm(x, sub, drop, norm, fan=3)
+    assert len(ys) == 3 and ys[0] is ys[1] is ys[2] and torch.allclose(ys[0], norm(x + sub))
+    assert TL.residual_dropout_norm(x, sub, drop, norm).shape == x.shape
+    emb = torch.randn(5, 16, requires_grad=True)
+    assert not L.expand_parts_eligible(emb, 2) and not L.level_pos_embed_eligible(emb, [torch.randn(2, 16, 3)])
+    assert not L.count_pool_train_eligible(x) and not L.class_count_heads_eligible(torch.nn.Linear(8, 1), x)
+    mask = torch.tensor([[False, True, False, False, True]] * 2)
+    y = torch.nn.Linear(8, 8)(x)
+    assert torch.equal(L.mask_rows(y, mask), y.masked_fill(mask[..., None], 0.0))
+    ids = torch.tensor([0, 3, 3, 1])
+    assert torch.equal(L.embed_rows(emb, ids), emb.index_select(0, ids))
+    TL.arena("cpu").buf = None
+    a, b = TL.step_snapshot("cpu"), TL.step_snapshot("cpu")
+    assert a is not b                                                  # no open step: a copy per call
+    TL.arena("cpu").want = 64
+    TL.arena_reset("cpu")
+    a, b = TL.step_snapshot("cpu"), TL.step_snapshot("cpu")
+    assert a is b                                                      # one per open step
+    TL.arena_reset("cpu")
+    assert TL.step_snapshot("cpu") is not a                            # the next step takes its own
+    TL.arena("cpu").buf = None
