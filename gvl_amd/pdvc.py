@@ -449,9 +449,18 @@ class PDVC(nn.Module):
                                                   self.opt.caption_decoder_type)
         main.wait_stream(side)
         if not torch.cuda.is_current_stream_capturing():          # (a captured graph's memory is static: nothing to record)
-            for v in list(loss.values()) + [out['pred_logits'], out['pred_count'], out['pred_boxes']]:
-                if isinstance(v, torch.Tensor) and v.is_cuda:
-                    v.record_stream(main)                         # (allocated on the side stream, read on this one from here on)
+            def hand_over(v):                                     # everything the side stream allocated is read on this one from here on
+                if isinstance(v, torch.Tensor):
+                    if v.is_cuda:
+                        v.record_stream(main)
+                elif isinstance(v, dict):
+                    for w in v.values():
+                        hand_over(w)
+                elif isinstance(v, (list, tuple)):
+                    for w in v:
+                        hand_over(w)
+            hand_over(loss)
+            hand_over({k: v for k, v in out.items() if k not in ('event_embed', 'event_feat')})
         out['caption_probs'], out['seq'] = probs, seq
         return out, loss
 
