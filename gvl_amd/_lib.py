@@ -125,6 +125,8 @@ SIGNATURES = {
     "gvl_planes_refresh_f16": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "gvl_mha_train_forward_f32": (_I, [_P, _I64, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P, _P]),
     "gvl_mha_train_backward_f32": (_I, [_P, _I64, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gvl_mha_train_backward_amax_f32": (_I, [_P, _I64, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P,
+                                             _P, _P, _P]),
     "gvl_linear_f16x3_splitk_workspace_bytes": (_SZ, [_I, _I, _I]),
     "gvl_linear_f16x3_splitk_f32": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "gvl_adam_chunk_elems": (_I, []),

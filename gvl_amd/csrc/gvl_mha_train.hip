@@ -168,6 +168,7 @@ struct MhaParams {
   const float *dout, *amax_dout;  // (B Q, H 64), (B Q)
   const float *delta;             // (B, H, Q): dO . out per row
   float *dqkv;                    // (B Q, ld)
+  float *amax_dqk, *amax_dv;      // (B Q) zero-initialised or NULL: max |row| of the [dq | dk] and of the dv columns (atomic max)
 };
 
 struct DropKey { uint32_t key, thr; float scale; };
@@ -397,6 +398,17 @@ __global__ void __launch_bounds__(kThreads) k_mha_bwd_q(const MhaParams p) {
         *reinterpret_cast<float4 *>(op + 32 * t + 8 * g + 4 * half) =
             make_float4(dq[t][4 * g] * f, dq[t][4 * g + 1] * f, dq[t][4 * g + 2] * f, dq[t][4 * g + 3] * f);
   }
+  if (p.amax_dqk) {
+    // the row scale the in-projection's backward products split dqkv by (as amax_out in the forward: two lanes hold a row's 64)
+    float mx = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(dq[t][r]));
+    mx *= fabsf(back_qk * 0.125f);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (half == 0 && q < p.Q) atomicMax(reinterpret_cast<unsigned *>(p.amax_dqk) + (int64_t)b * p.Q + q, __float_as_uint(mx));
+  }
 }
 
 // =====================================================================================================================
@@ -508,6 +520,21 @@ __global__ void __launch_bounds__(kThreads) k_mha_bwd_kv(const MhaParams p) {
             make_float4(dvT[t][4 * g] * fv_, dvT[t][4 * g + 1] * fv_, dvT[t][4 * g + 2] * fv_, dvT[t][4 * g + 3] * fv_);
       }
   }
+  if (p.amax_dqk) {
+    float mk = 0.f, mv = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { mk = fmaxf(mk, fabsf(dkT[t][r])); mv = fmaxf(mv, fabsf(dvT[t][r])); }
+    mk *= fabsf(back_qk * 0.125f);
+    mv *= fabsf(back_g * (1.f / 2048.f));
+    mk = fmaxf(mk, __shfl_xor(mk, 32, 64));
+    mv = fmaxf(mv, __shfl_xor(mv, 32, 64));
+    if (half == 0 && key < p.Q) {
+      atomicMax(reinterpret_cast<unsigned *>(p.amax_dqk) + (int64_t)b * p.Q + key, __float_as_uint(mk));
+      atomicMax(reinterpret_cast<unsigned *>(p.amax_dv) + (int64_t)b * p.Q + key, __float_as_uint(mv));
+    }
+  }
 }
 
 // delta[b][h][q] = dO[q] . out[q] over the head's 64 channels, and (optionally) max |dO row|: one wavefront per row
@@ -559,7 +586,17 @@ extern "C" int gvl_mha_train_backward_f32(const float *qkv, int64_t ld, const un
                                           const float *amax_v, int B, int Q, int H, float p, uint32_t seed, const int64_t *step,
                                           const float *out, const float *lse, const float *dout, float *delta_ws,
                                           float *amax_dout_ws, float *dqkv, void *stream) {
-  const char *what = "gvl_mha_train_backward_f32";
+  return gvl_mha_train_backward_amax_f32(qkv, ld, key_keep, amax_qk, amax_v, B, Q, H, p, seed, step, out, lse, dout, delta_ws,
+                                         amax_dout_ws, dqkv, nullptr, nullptr, stream);
+}
+
+extern "C" int gvl_mha_train_backward_amax_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk,
+                                               const float *amax_v, int B, int Q, int H, float p, uint32_t seed,
+                                               const int64_t *step, const float *out, const float *lse, const float *dout,
+                                               float *delta_ws, float *amax_dout_ws, float *dqkv, float *amax_dqk, float *amax_dv,
+                                               void *stream) {
+  const char *what = "gvl_mha_train_backward_amax_f32";
+  if ((amax_dqk == nullptr) != (amax_dv == nullptr)) return fail(GVL_EINVAL, "%s: amax_dqk and amax_dv come together", what);
   if (int rc = check(what, qkv, ld, B, Q, H, p)) return rc;
   if (!qkv || !amax_qk || !amax_v || !out || !lse || !dout || !delta_ws || !amax_dout_ws || !dqkv ||
       (((uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15))
@@ -569,6 +606,7 @@ extern "C" int gvl_mha_train_backward_f32(const float *qkv, int64_t ld, const un
   MhaParams a = {};
   a.qkv = qkv; a.ld = ld; a.keep = key_keep; a.amax_qk = amax_qk; a.amax_v = amax_v; a.B = B; a.Q = Q; a.H = H; a.p = p; a.seed = seed;
   a.step = step; a.lse = const_cast<float *>(lse); a.dout = dout; a.amax_dout = amax_dout_ws; a.delta = delta_ws; a.dqkv = dqkv;
+  a.amax_dqk = amax_dqk; a.amax_dv = amax_dv;
   const int nb = (Q + 32 * kWaves - 1) / (32 * kWaves);
   if (int rc = gvl::launch(GVL_PROF_MHA_TRAIN, B, Q, "k_mha_bwd_kv", k_mha_bwd_kv, dim3(B * H * nb), dim3(kThreads), 0, st, a)) return rc;
   return gvl::launch(GVL_PROF_MHA_TRAIN, B, Q, "k_mha_bwd_q", k_mha_bwd_q, dim3(B * H * nb), dim3(kThreads), 0, st, a);

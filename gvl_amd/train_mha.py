@@ -72,9 +72,13 @@ class _InProj(torch.autograd.Function):
         B, Q, C = ctx.shape
         R = B * Q
         op_t = ctx.op_t
+        hit = getattr(dqkv, "_gvl_amax_qk_v", None)                       # (row maxima left by the attention backward kernels)
         dqkv = dqkv.contiguous()
         g_qk, g_v = dqkv[:, :2 * C], dqkv[:, 2 * C:]
-        am_gqk, am_gv = L.row_absmax(g_qk)[0], L.row_absmax(g_v)[0]
+        if hit is not None and hit[1] == dqkv._version and hit[0].shape == (2, R):
+            am_gqk, am_gv = hit[0][0], hit[0][1]
+        else:
+            am_gqk, am_gv = L.row_absmax(g_qk)[0], L.row_absmax(g_v)[0]
         # dx of the two operand groups: the transposed planes cut at contraction stage 2C / 32
         cut = 2 * C // 32
         dxq = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
@@ -136,12 +140,14 @@ class _Core(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(B, H, Q, device=qkv.device, dtype=torch.float32)
         am_g = torch.empty(B * Q, device=qkv.device, dtype=torch.float32)
+        am_d = TL.step_zeros(2 * B * Q, qkv.device).view(2, B * Q)       # max |row| of [dq | dk] and of dv: left by the kernels
         with torch.cuda.device(qkv.device):
-            rc = _lib.lib().gvl_mha_train_backward_f32(
+            rc = _lib.lib().gvl_mha_train_backward_amax_f32(
                 qkv.data_ptr(), qkv.stride(0), keep.data_ptr() if has_keep else None, am[0].data_ptr(), am[1].data_ptr(), B, Q, H,
                 p, seed, used.data_ptr() if has_step else None, out.data_ptr(), lse.data_ptr(), dout.data_ptr(), delta.data_ptr(),
-                am_g.data_ptr(), dqkv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                am_g.data_ptr(), dqkv.data_ptr(), am_d[0].data_ptr(), am_d[1].data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mha_train_backward")
+        dqkv._gvl_amax_qk_v = (am_d, dqkv._version)                       # (for the in-projection's backward: versioned like tag_amax)
         return dqkv, None, None, None, None, None, None, None, None
 
 

@@ -54,7 +54,8 @@ extern "C" {
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
  *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps),
- *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_index_add_rows_f32 (an embedding
+ *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_mha_train_backward_amax_f32 (dqkv's row
+ *      maxima from the attention backward kernels), gvl_index_add_rows_f32 (an embedding
  *      lookup's gradient without the additions of zero rows)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
@@ -864,6 +865,12 @@ int gvl_mha_train_forward_f32(const float *qkv, int64_t ld, const unsigned char 
 int gvl_mha_train_backward_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk, const float *amax_v,
                                int B, int Q, int H, float p, uint32_t seed, const int64_t *step, const float *out, const float *lse,
                                const float *dout, float *delta_ws, float *amax_dout_ws, float *dqkv, void *stream);
+/*    ..._amax_f32 (ABI 16): additionally amax_dqk / amax_dv (B Q, zero-initialised, both or neither) receive max |row| of the
+ *    [dq | dk] and of the dv columns of dqkv -- the row scales the in-projection's backward products split dqkv by. */
+int gvl_mha_train_backward_amax_f32(const float *qkv, int64_t ld, const unsigned char *key_keep, const float *amax_qk,
+                                    const float *amax_v, int B, int Q, int H, float p, uint32_t seed, const int64_t *step,
+                                    const float *out, const float *lse, const float *dout, float *delta_ws, float *amax_dout_ws,
+                                    float *dqkv, float *amax_dqk, float *amax_dv, void *stream);
 
 /* -- the same product as gvl_linear_f16x3_f32 for FEW outputs and a LONG contraction, split over the K stages: the vocabulary layer's
  *    input gradient `grad_logits.mm(logit.weight)` (AddmmBackward of pdvc/CaptioningHead/LSTM_DSA.py:121: 2208 x 512 outputs,
