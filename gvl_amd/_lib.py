@@ -95,6 +95,8 @@ SIGNATURES = {
     "gvl_row_absmax_f32": (_I, [_P, _I64, _I, _I, _P, _I64, _I, _P, _P, _P]),
     "gvl_mha_core_f32": (_I, [_P, _I64, _P, _I, _I, _I, _P, _P, _P]),
     "gvl_group_norm_rows_backward_f32": (_I, [_P, _I64, _I, _I, _I, _I, _I, _P, ctypes.c_float, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P]),
+    "gvl_group_norm_rows_backward_amax_f32": (_I, [_P, _I64, _I, _I, _I, _I, _I, _P, ctypes.c_float, _P, _I64, _P, _I64, _P, _I64, _P, _P,
+                                                   _P, _P]),
     "gvl_conv_taps_to_rows_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "gvl_group_norm_rows_f32": (_I, [_P, _I64, _I, _I, _I, _I, _I, _P, _P, ctypes.c_float, _P, _I64, _P, _I64, _P]),
     "gvl_pyramid_geometry_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _P, _P]),

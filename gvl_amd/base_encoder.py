@@ -156,6 +156,7 @@ class _PyramidTrainFunction(torch.autograd.Function):
         from . import _lib
         from . import layers as L
         from . import MultiScaleDeformableAttention as MSDA
+        from . import train_layers as TL
         from .train_planes import Operand
         enc, tp, mats = ctx.enc, ctx.tp, ctx.mats
         N, T, Cin, C, nl, lengths, starts, S, shapes = ctx.geom
@@ -172,15 +173,15 @@ class _PyramidTrainFunction(torch.autograd.Function):
             rows = shapes[l]
             norm = enc.input_proj[l][1]
             dy = torch.empty(N * rows, C, device=dev, dtype=torch.float32)
+            am_dy = TL.step_zeros(N * rows, dev)                       # max |dy row|: left by the group norm's backward kernel
             part = part_all[l]
             with torch.cuda.device(dev):
-                rc = _lib.lib().gvl_group_norm_rows_backward_f32(
+                rc = _lib.lib().gvl_group_norm_rows_backward_amax_f32(
                     y.data_ptr(), y.stride(0), rows, N, lengths[l], C, norm.num_groups, params[4 * l + 2].data_ptr(), float(norm.eps),
                     dsrc.data_ptr() + 4 * starts[l] * C, S * C,
                     dnext.data_ptr() + 4 * C if dnext is not None else None, dnext.shape[1] * C if dnext is not None else 0,
-                    dy.data_ptr(), C, part[0].data_ptr(), part[1].data_ptr(), stream)
+                    dy.data_ptr(), C, part[0].data_ptr(), part[1].data_ptr(), am_dy.data_ptr(), stream)
             _lib.check(rc, "group_norm_rows_backward")
-            am_dy = L.row_absmax(dy)[0]
             gw, gbias = MSDA.wgrad(dy, a, am_dy, am)
             w = params[4 * l]
             grads[4 * l] = gw.view(C, 1, a.shape[1]).permute(0, 2, 1) if l == 0 else gw.view(C, 3, a.shape[1] // 3).permute(0, 2, 1)

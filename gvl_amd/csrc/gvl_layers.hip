@@ -750,7 +750,7 @@ __global__ void __launch_bounds__(256) k_group_norm_rows_bwd(const float *__rest
                                                              const float *__restrict__ dout, int64_t dout_vs,
                                                              const float *__restrict__ dout2, int64_t dout2_vs,
                                                              float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dgamma_part,
-                                                             float *__restrict__ dbeta_part) {
+                                                             float *__restrict__ dbeta_part, float *__restrict__ amax_dy) {
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (unit >= N * G) return;
   const int n = unit / G, g = unit % G, cg = C / G;
@@ -803,6 +803,14 @@ __global__ void __launch_bounds__(256) k_group_norm_rows_bwd(const float *__rest
       v = rstd * (go * gm - k1 - xh * k2);
     }
     dst[(int64_t)t * ld_dy] = v;
+    if (amax_dy) {
+      // max |dy row| (zero-initialised, atomic max over the row's G groups): the row scale of the convolution's weight / input
+      // gradient products.  The cg lanes of a row's group are adjacent; every lane of the wavefront is in the loop together
+      // (rows_per_video rounds to whole passes only when tstep divides it: the shuffles below stay within a row's cg lanes)
+      float m = fabsf(v);
+      for (int o = 1; o < cg; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if (lane % cg == 0) atomicMax(reinterpret_cast<unsigned *>(amax_dy) + (int64_t)n * rows_per_video + t, __float_as_uint(m));
+    }
   }
 }
 
@@ -1284,13 +1292,21 @@ extern "C" int gvl_group_norm_rows_backward_f32(const float *y, int64_t ldy, int
                                                 const float *gamma, float eps, const float *dout, int64_t dout_video_stride,
                                                 const float *dout2, int64_t dout2_video_stride, float *dy, int64_t ld_dy,
                                                 float *dgamma_part, float *dbeta_part, void *stream) {
+  return gvl_group_norm_rows_backward_amax_f32(y, ldy, rows_per_video, N, T, C, G, gamma, eps, dout, dout_video_stride, dout2,
+                                               dout2_video_stride, dy, ld_dy, dgamma_part, dbeta_part, nullptr, stream);
+}
+
+extern "C" int gvl_group_norm_rows_backward_amax_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G,
+                                                     const float *gamma, float eps, const float *dout, int64_t dout_video_stride,
+                                                     const float *dout2, int64_t dout2_video_stride, float *dy, int64_t ld_dy,
+                                                     float *dgamma_part, float *dbeta_part, float *amax_dy, void *stream) {
   if (N < 0 || T <= 0 || C <= 0 || G <= 0 || C % G || 64 % (C / G) || ldy < C || ld_dy < C || rows_per_video < T)
     return fail(GVL_EINVAL, "gvl_group_norm_rows_backward_f32: needs C / G in {1, 2, 4, ..., 64} (got N=%d T=%d C=%d G=%d)", N, T, C, G);
   if (N == 0) return 0;
   if (!y || !gamma || !dout || !dy || !dgamma_part || !dbeta_part) return fail(GVL_EINVAL, "gvl_group_norm_rows_backward_f32: null pointer");
   return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows_bwd", k_group_norm_rows_bwd, dim3((N * G + 3) / 4), dim3(256), 0,
                      (hipStream_t)stream, y, ldy, rows_per_video, T, C, G, N, gamma, eps, dout, dout_video_stride, dout2,
-                     dout2_video_stride, dy, ld_dy, dgamma_part, dbeta_part);
+                     dout2_video_stride, dy, ld_dy, dgamma_part, dbeta_part, amax_dy);
 }
 
 extern "C" int gvl_conv_taps_to_rows_f32(const float *dcols, int N, int T1, int C, float *dx, void *stream) {

@@ -54,8 +54,8 @@ extern "C" {
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
  *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps),
- *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_mha_train_backward_amax_f32 (dqkv's row
- *      maxima from the attention backward kernels), gvl_index_add_rows_f32 (an embedding
+ *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_mha_train_backward_amax_f32 / gvl_group_norm_rows_backward_amax_f32
+ *      (row maxima of dqkv / of the pyramid's dy from the kernels that write them), gvl_index_add_rows_f32 (an embedding
  *      lookup's gradient without the additions of zero rows)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
  *      in one launch), gvl_caption_rows (the captioner's pair rows on padded targets in one launch)
@@ -259,6 +259,12 @@ int gvl_group_norm_rows_backward_f32(const float *y, int64_t ldy, int rows_per_v
                                      float eps, const float *dout, int64_t dout_video_stride, const float *dout2,
                                      int64_t dout2_video_stride, float *dy, int64_t ld_dy, float *dgamma_part, float *dbeta_part,
                                      void *stream);
+/*    ..._amax_f32 (ABI 16): amax_dy (N * rows_per_video, zero-initialised) or NULL additionally receives max |dy row| (atomic max over
+ *    the row's groups): the row scale of the level's weight- and input-gradient products. */
+int gvl_group_norm_rows_backward_amax_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G,
+                                          const float *gamma, float eps, const float *dout, int64_t dout_video_stride,
+                                          const float *dout2, int64_t dout2_video_stride, float *dy, int64_t ld_dy,
+                                          float *dgamma_part, float *dbeta_part, float *amax_dy, void *stream);
 int gvl_conv_taps_to_rows_f32(const float *dcols, int N, int T1, int C, float *dx, void *stream);
 int gvl_group_norm_rows_f32(const float *y, int64_t ldy, int rows_per_video, int N, int T, int C, int G, const float *gamma,
                             const float *beta, float eps, float *dst, int64_t dst_video_stride, float *dst2,
