@@ -297,6 +297,7 @@ class PDVC(nn.Module):
             disable_refine = False
             query_embed = self.query_embed.weight
             proposals_mask = torch.ones(N, query_embed.shape[0], device=query_embed.device).bool()
+            proposals_mask._gvl_all_true = (True, proposals_mask._version)      # (known without reading it back: gvl_amd/layers.py)
             init_reference, tgt, reference_points, query_embed = \
                 self.transformer.prepare_decoder_input_query(memory, query_embed)
         else:

@@ -308,3 +308,39 @@ def test_query_constants_kept_for_inference_follow_their_parameters():
         assert rows2 is not rows and torch.equal(rows2[0].view(B, Q, C), tgt)
     with torch.enable_grad():                                          # training keeps the reference's own evaluation
         assert L._query_rows(dec, tgt, qpos, B, Q, C) is None
+
+
+def test_first_decoder_layer_constants_are_kept_and_equal_the_recomputed_forward(monkeypatch):
+    """'queries' input, no padded query: the first decoder layer's self-attention block and offsets / weights projection depend on
+    parameters only and are kept across inference forwards (gvl_amd.layers._first_layer_constants) -- bit for bit the forward
+    that recomputes them (GVL_FIRST_LAYER_CACHE=0), for a second batch too, and recomputed after a parameter changes"""
+    from helpers import load, pdvc_dt, pdvc_state
+    from gvl_amd.config import make_opt
+    from gvl_amd.pdvc import build
+    f = load("pdvc_anet_full")
+    opt = make_opt("anet_tsp_ssvg", num_queries=300, frame_embedding_num=100, device="cuda")
+    model, criterion, _, _ = build(opt)
+    model.load_state_dict(pdvc_state(f, seed=100), strict=True)
+    model = model.to(DEV).eval()
+    from bench import synth_batch
+    dts = [synth_batch(4, 100, opt.feature_dim, opt.vocab_size, [2, 0, 3, 1], DEV, seed=70 + i) for i in range(2)]
+    dec = model.transformer.decoder
+
+    def run(dt):
+        with torch.no_grad():
+            out, _ = model(dt, None, None, "queries", eval_mode=True)
+        return out["pred_logits"].clone(), out["pred_boxes"].clone(), out["seq"].clone()
+    monkeypatch.setenv("GVL_FIRST_LAYER_CACHE", "0")
+    want = [run(dt) for dt in dts]
+    monkeypatch.setenv("GVL_FIRST_LAYER_CACHE", "1")
+    dec.__dict__.pop("_gvl_first_layer", None)
+    got = [run(dt) for dt in dts] + [run(dts[0])]
+    assert len(dec.__dict__["_gvl_first_layer"]) == 1
+    for g_, w_ in zip(got, want + [want[0]]):
+        assert all(torch.equal(a, b) for a, b in zip(g_, w_))
+    with torch.no_grad():
+        dec.layers[0].norm2.bias.add_(0.01)                        # a parameter of the kept block changes: recomputed
+    kept = dict(dec.__dict__["_gvl_first_layer"])
+    moved = run(dts[0])
+    assert not torch.equal(moved[0], want[0][0])
+    assert len(dec.__dict__["_gvl_first_layer"]) == 1 and set(dec.__dict__["_gvl_first_layer"]) != set(kept)
