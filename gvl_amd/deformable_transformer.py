@@ -358,7 +358,9 @@ class DeformableTransformer(nn.Module):
         pos_rows, tgt = torch.chunk(query_embed, 2, dim=1)
         if _layers.expand_parts_eligible(query_embed, 2):
             # (training: the two gradients batch-summed in one launch; pos_rows: the node's own handle of the first block)
-            query_pos, tgt, pos_rows, _ = _layers.expand_parts(query_embed, bs, 2, rows=True)
+            query_pos, tgt, pos_rows, tgt_rows = _layers.expand_parts(query_embed, bs, 2, rows=True)
+            # (the first decoder layer's in-projection runs on these Q rows: gvl_amd/train_mha.py _InProjShared)
+            query_pos._gvl_rows, tgt._gvl_rows = pos_rows, tgt_rows
         else:
             query_pos = pos_rows.unsqueeze(0).expand(bs, -1, -1)
             tgt = tgt.unsqueeze(0).expand(bs, -1, -1)

@@ -79,35 +79,87 @@ class _InProj(torch.autograd.Function):
             am_gqk, am_gv = hit[0][0], hit[0][1]
         else:
             am_gqk, am_gv = L.row_absmax(g_qk)[0], L.row_absmax(g_v)[0]
-        # dx of the two operand groups: the transposed planes cut at contraction stage 2C / 32
-        cut = 2 * C // 32
-        dxq = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
-        dxv = torch.empty(R, C, device=dqkv.device, dtype=torch.float32)
-        L.linear(g_qk, Operand(_Sub(op_t.planes, 0, cut), C, 2 * C, None), [L.seg(0, dxq, am_gqk)])
-        L.linear(g_v, Operand(_Sub(op_t.planes, cut, 3 * C // 32), C, C, None), [L.seg(0, dxv, am_gv)])
-        q = GL._WGRAD_QUEUE
-        if ctx.defer and q is not None and all(p_.grad is None for p_ in ctx.params):
-            # the two halves as ONE queued problem each would return two tensors per parameter; instead: one (3C, C) gradient whose
-            # row blocks are two entries of the queue (filled when the group runs)
-            gw = torch.empty(3 * C, C, device=dqkv.device, dtype=torch.float32)
-            gb = torch.empty(3 * C, device=dqkv.device, dtype=torch.float32)
-            gwd, gbd = gw.detach(), gb.detach()
-            if any(id(p_) in q.seen for p_ in ctx.params):
-                q.flush()
-                MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gwd[:2 * C], grad_b=gbd[:2 * C])
-                MSDA.wgrad(g_v, x2, am_gv, am_v, grad_w=gwd[2 * C:], grad_b=gbd[2 * C:])
-            else:
-                q.seen.update(id(p_) for p_ in ctx.params)
-                if len(q.items) + 2 > MSDA.wgrad_group_max():
-                    q.flush()
-                q.items.append((g_qk, xq2, am_gqk, am_qk, gwd[:2 * C], gbd[:2 * C]))
-                q.items.append((g_v, x2, am_gv, am_v, gwd[2 * C:], gbd[2 * C:]))
-            return dxv.view(B, Q, C), None, dxq.view(B, Q, C), gw, gb, None
-        gw = torch.empty(3 * C, C, device=dqkv.device, dtype=torch.float32)
-        gb = torch.empty(3 * C, device=dqkv.device, dtype=torch.float32)
-        MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gw[:2 * C], grad_b=gb[:2 * C])
-        MSDA.wgrad(g_v, x2, am_gv, am_v, grad_w=gw[2 * C:], grad_b=gb[2 * C:])
+        dxq, dxv, gw, gb = _in_proj_gradients(ctx, g_qk, g_v, am_gqk, am_gv, x2, xq2, am_v, am_qk, C)
         return dxv.view(B, Q, C), None, dxq.view(B, Q, C), gw, gb, None
+
+
+def _in_proj_gradients(ctx, g_qk, g_v, am_gqk, am_gv, x2, xq2, am_v, am_qk, C):
+    """(d (x + pos), d x [v path], d in_proj_weight, d in_proj_bias) from the gradients of the q | k and the v columns"""
+    op_t, R, dev = ctx.op_t, g_qk.shape[0], g_qk.device
+    # dx of the two operand groups: the transposed planes cut at contraction stage 2C / 32
+    cut = 2 * C // 32
+    dxq = torch.empty(R, C, device=dev, dtype=torch.float32)
+    dxv = torch.empty(R, C, device=dev, dtype=torch.float32)
+    L.linear(g_qk, Operand(_Sub(op_t.planes, 0, cut), C, 2 * C, None), [L.seg(0, dxq, am_gqk)])
+    L.linear(g_v, Operand(_Sub(op_t.planes, cut, 3 * C // 32), C, C, None), [L.seg(0, dxv, am_gv)])
+    gw = torch.empty(3 * C, C, device=dev, dtype=torch.float32)
+    gb = torch.empty(3 * C, device=dev, dtype=torch.float32)
+    q = GL._WGRAD_QUEUE
+    if ctx.defer and q is not None and all(p_.grad is None for p_ in ctx.params):
+        # the two halves as ONE queued problem each would return two tensors per parameter; instead: one (3C, C) gradient whose
+        # row blocks are two entries of the queue (filled when the group runs)
+        gwd, gbd = gw.detach(), gb.detach()
+        if any(id(p_) in q.seen for p_ in ctx.params):
+            q.flush()
+            MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gwd[:2 * C], grad_b=gbd[:2 * C])
+            MSDA.wgrad(g_v, x2, am_gv, am_v, grad_w=gwd[2 * C:], grad_b=gbd[2 * C:])
+        else:
+            q.seen.update(id(p_) for p_ in ctx.params)
+            if len(q.items) + 2 > MSDA.wgrad_group_max():
+                q.flush()
+            q.items.append((g_qk, xq2, am_gqk, am_qk, gwd[:2 * C], gbd[:2 * C]))
+            q.items.append((g_v, x2, am_gv, am_v, gwd[2 * C:], gbd[2 * C:]))
+        return dxq, dxv, gw, gb
+    MSDA.wgrad(g_qk, xq2, am_gqk, am_qk, grad_w=gw[:2 * C], grad_b=gb[:2 * C])
+    MSDA.wgrad(g_v, x2, am_gv, am_v, grad_w=gw[2 * C:], grad_b=gb[2 * C:])
+    return dxq, dxv, gw, gb
+
+
+@MSDA.keeps_products
+class _InProjShared(torch.autograd.Function):
+    """_InProj for the FIRST decoder layer under the 'queries' input: every video's rows are the same Q rows of the query embedding
+    (deformable_transformer.py:128-135), so q, k, v are computed for those Q rows once and copied to the B videos (the attention
+    core and what follows differ per video: dropout), and the backward sums dqkv over the videos first -- the products run on Q rows
+    instead of B Q.  x_rows, pos_rows (Q, C): the embedding's two blocks; -> (qkv (B Q, 3C), row maxima (2, B Q))"""
+
+    @staticmethod
+    def forward(ctx, x_rows, pos_rows, weight, bias, B, defer=False):
+        ctx.defer, ctx.params = bool(defer), (weight, bias)
+        Q, C = x_rows.shape
+        x2 = x_rows.contiguous()
+        p2 = pos_rows if pos_rows.stride(1) == 1 and pos_rows.stride(0) % 4 == 0 and pos_rows.data_ptr() % 16 == 0 \
+            else pos_rows.contiguous()
+        xq2 = x2 + p2
+        op, op_t = GL._operands((weight,), (bias,))
+        am_v, am_qk = L.row_absmax(x2, p2)
+        q1 = torch.empty(Q, 3 * C, device=x2.device, dtype=torch.float32)
+        am1 = TL.step_zeros(2 * Q, x2.device).view(2, Q)
+        L.linear(x2, op, [L.seg(0, q1[:, :2 * C], am_qk, amax_out=am1[0], addend=True),
+                          L.seg(2 * C, q1[:, 2 * C:], am_v, amax_out=am1[1])], a2=p2)
+        qkv = q1.unsqueeze(0).expand(B, Q, 3 * C).reshape(B * Q, 3 * C)
+        am_out = am1.unsqueeze(1).expand(2, B, Q).reshape(2, B * Q)
+        ctx.save_for_backward(x2, xq2, am_v, am_qk, weight)
+        ctx.op_t, ctx.shape = op_t, (B, Q, C)
+        ctx.mark_non_differentiable(am_out)
+        ctx.set_materialize_grads(False)
+        return qkv, am_out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dqkv, _dam):
+        import ctypes
+        x2, xq2, am_v, am_qk, weight = ctx.saved_tensors
+        B, Q, C = ctx.shape
+        dqkv = dqkv.contiguous()
+        d1 = torch.empty(Q, 3 * C, device=dqkv.device, dtype=torch.float32)
+        with torch.cuda.device(dqkv.device):
+            rc = _lib.lib().gvl_batch_sum_f32((ctypes.c_void_p * 1)(dqkv.data_ptr()), 1, B, Q, 3 * C, d1.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "batch_sum")
+        g_qk, g_v = d1[:, :2 * C], d1[:, 2 * C:]
+        am_gqk, am_gv = L.row_absmax(g_qk)[0], L.row_absmax(g_v)[0]
+        dxq, dxv, gw, gb = _in_proj_gradients(ctx, g_qk, g_v, am_gqk, am_gv, x2, xq2, am_v, am_qk, C)
+        return dxv + dxq, dxq, gw, gb, None, None
 
 
 class _Core(torch.autograd.Function):
@@ -168,15 +220,21 @@ def self_attention(mha, tgt, query_pos, query_mask, tgt_q=None):
     """nn.MultiheadAttention(q = k = tgt + query_pos, v = tgt, key_padding_mask = ~query_mask)[0] for batch-major tgt (B, Q, C)
     -> (B, Q, C); callers check `eligible` first.  query_pos: the batch-expanded (stride 0) query embedding."""
     B, Q, C = tgt.shape
-    x = tgt.contiguous()
-    # (tgt_q: another handle of tgt for the query -- residual_dropout_norm(fan=...); the sum carries its row maxima when norm3
-    #  left them)
-    xq = TL.add_pos(tgt_q if tgt_q is not None else tgt, query_pos)
-    L_ = L
-    if L_.amax_of(x, B * Q) is None and L_.amax_of(tgt, B * Q) is not None:
-        L_.tag_amax(x, L_.amax_of(tgt, B * Q))
     defer = bool(mha.__dict__.get("_gvl_defer_wgrad", False))
-    qkv, am = _InProj.apply(x, query_pos[0], xq, mha.in_proj_weight, mha.in_proj_bias, defer)
+    rows, pos_rows = getattr(tgt, "_gvl_rows", None), getattr(query_pos, "_gvl_rows", None)
+    if (rows is not None and pos_rows is not None and tgt.stride(0) == 0 and (tgt_q is None or tgt_q is tgt) and tuple(rows.shape) == (Q, C)
+            and tuple(pos_rows.shape) == (Q, C) and os.environ.get("GVL_INPROJ_SHARED", "1") != "0"):
+        # the first layer under the 'queries' input: the same Q rows for every video (deformable_transformer.py:128-135)
+        qkv, am = _InProjShared.apply(rows, pos_rows, mha.in_proj_weight, mha.in_proj_bias, B, defer)
+    else:
+        x = tgt.contiguous()
+        # (tgt_q: another handle of tgt for the query -- residual_dropout_norm(fan=...); the sum carries its row maxima when norm3
+        #  left them)
+        xq = TL.add_pos(tgt_q if tgt_q is not None else tgt, query_pos)
+        L_ = L
+        if L_.amax_of(x, B * Q) is None and L_.amax_of(tgt, B * Q) is not None:
+            L_.tag_amax(x, L_.amax_of(tgt, B * Q))
+        qkv, am = _InProj.apply(x, query_pos[0], xq, mha.in_proj_weight, mha.in_proj_bias, defer)
     keep = None
     if query_mask is not None:                          # (a bool mask's bytes ARE 0 / 1: no cast launch)
         keep = query_mask.contiguous().view(torch.uint8) if query_mask.dtype == torch.bool else query_mask.to(torch.uint8).contiguous()

@@ -145,3 +145,35 @@ def test_decoder_layer_routes_training_attention_to_the_hand_written_kernels():
         MSDA.profile_enable(0)
     assert names.count("mha_train") == 3, names                  # forward, dk / dv, dq
     assert torch.isfinite(tgt.grad).all()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_first_layer_in_projection_on_the_embedding_rows_equals_the_batch_expanded_one(p, monkeypatch):
+    """the first decoder layer under the 'queries' input: q, k, v from the Q embedding rows, copied to the B videos, dqkv summed
+    over the videos before the backward products (_InProjShared) -- against the same call on the batch-expanded rows
+    (GVL_INPROJ_SHARED=0): output and every gradient, with and without attention dropout (same masks: same step)"""
+    from gvl_amd import layers as LY
+    from gvl_amd import train_layers as TL
+    from gvl_amd import train_mha as TM
+    torch.manual_seed(9)
+    B, Q, C, H = 16, 300, 512, 8
+    mha = torch.nn.MultiheadAttention(C, H, dropout=p).to(DEV).train()
+    mask = torch.ones(B, Q, dtype=torch.bool, device=DEV)
+    g = torch.randn(B, Q, C, device=DEV)
+    res = []
+    for shared in ("1", "0"):
+        monkeypatch.setenv("GVL_INPROJ_SHARED", shared)
+        emb = torch.randn(Q, 2 * C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4)).requires_grad_()
+        pos, tgt, pos_rows, tgt_rows = LY.expand_parts(emb, B, 2, rows=True)
+        pos._gvl_rows, tgt._gvl_rows = pos_rows, tgt_rows
+        mha.zero_grad(set_to_none=True)
+        assert TM.eligible(mha, tgt, pos)
+        TL.step_counter(DEV).fill_(7)
+        TL.arena(DEV).snap = None
+        out = TM.self_attention(mha, tgt, pos, mask)
+        out.backward(g)
+        res.append([out.detach().clone(), emb.grad.clone(), mha.in_proj_weight.grad.clone(), mha.in_proj_bias.grad.clone(),
+                    mha.out_proj.weight.grad.clone()])
+    for name, a, b in zip(("out", "d query_embed", "d in_proj_weight", "d in_proj_bias", "d out_proj.weight"), *res):
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err < (1e-6 if name == "out" else 2e-5), (name, err)
