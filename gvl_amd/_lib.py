@@ -131,6 +131,7 @@ SIGNATURES = {
                                              _P, _P, _P]),
     "gvl_linear_f16x3_splitk_workspace_bytes": (_SZ, [_I, _I, _I]),
     "gvl_linear_f16x3_splitk_f32": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P, _I, _P, _P, _SZ, _P]),
+    "gvl_linear_f16x3_splitk_bias_f32": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "gvl_adam_chunk_elems": (_I, []),
     "gvl_adam_set_grads": (_I, [_P, _I, _P, _P]),
     "gvl_clip_adam_step_f32": (_I, [_P, _I, _P, _I, _P, _P, _P] + [ctypes.c_double] * 6 + [_P]),

@@ -3,6 +3,7 @@ pdvc/position_encoding.py:38-64.  Plain PyTorch-ROCm ops (conv1d / GroupNorm): S
 of hand-kernel scope (row f2 "next").  Parameter names: ``input_proj.{l}.{0,1}``, ``pos_embed.duration_embed_layer``.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -128,7 +129,12 @@ class _PyramidTrainFunction(torch.autograd.Function):
             am = L.row_absmax(a)[0]
             fwd, _, bias = tp.lookup((mats[l],))
             y = torch.empty(a.shape[0], C, device=dev, dtype=torch.float32)
-            L.linear(a, Operand(fwd, C, a.shape[1], bias), [L.seg(0, y, am)])
+            op = Operand(fwd, C, a.shape[1], bias)
+            if (l > 0 and a.shape[0] <= 1024 and op.K <= 4096 and L.splitk_pays(a.shape[0], op.N, op.K)
+                    and os.environ.get("GVL_CONV_SPLITK", "1") != "0"):
+                L.linear_splitk(a, am, op, out=y, bias=True)          # (few rows of taps, contraction 3 C_in: as forward_flat)
+            else:
+                L.linear(a, op, [L.seg(0, y, am)])
             norm_w, norm_b = params[4 * l + 2], params[4 * l + 3]
             nxt = None
             if l + 1 < nl:                                             # next level's zero-padded input: (N + 1, 2 (T'' + 1), C)
@@ -379,7 +385,16 @@ class BaseEncoder(nn.Module):
             a = xp.as_strided((N * (t_out + 1), 3 * ch), (2 * ch, 1))           # row (n, t'): taps 2 t' - 1 .. 2 t' + 1
             am, _ = L.row_absmax(a)
             y = torch.empty(N * (t_out + 1), C, device=dev, dtype=torch.float32)
-            L.linear(a, self._conv_weights(l), [L.seg(0, y, am)])
+            w = self._conv_weights(l)
+            if (a.shape[0] <= 1024 and w.K <= 4096 and L.splitk_pays(a.shape[0], w.N, w.K)
+                    and os.environ.get("GVL_CONV_SPLITK", "1") != "0"):
+                # a few hundred rows of taps against a contraction of 3 C_in: 13-52 tiles of 48 K stages -- split over K.  (Not for
+                # thousands of rows per level -- long videos: their tiles fill the chip as they are -- nor for the 9216-long
+                # contraction of 3072-d features: the T = 512 parity test sits within 2 % of its tolerance and the partial sums'
+                # different rounding moves it across)
+                L.linear_splitk(a, am, w, out=y, bias=True)
+            else:
+                L.linear(a, w, [L.seg(0, y, am)])
             return y
 
         x = vf.reshape(N * T, Cin)

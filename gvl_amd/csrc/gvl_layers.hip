@@ -1467,13 +1467,18 @@ extern "C" int gvl_linear_f16x3_f32(const float *a, int64_t lda, const float *a2
 }
 
 // partial slabs of a split-K product summed in slab order (deterministic)
-static __global__ void __launch_bounds__(256) k_lin_splitk_reduce(const float4 *__restrict__ part, int64_t n4, int SK, float4 *__restrict__ out) {
+static __global__ void __launch_bounds__(256) k_lin_splitk_reduce(const float4 *__restrict__ part, int64_t n4, int SK, float4 *__restrict__ out,
+                                                                  const float4 *__restrict__ bias4, int row4) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   float4 t = part[i];
   for (int s = 1; s < SK; ++s) {
     const float4 u = part[(int64_t)s * n4 + i];
     t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+  }
+  if (bias4) {                                                        // (the bias joins the finished sum: row4 = N / 4)
+    const float4 b = bias4[i % row4];
+    t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
   }
   out[i] = t;
 }
@@ -1488,11 +1493,20 @@ extern "C" size_t gvl_linear_f16x3_splitk_workspace_bytes(int R, int N, int K) {
 extern "C" int gvl_linear_f16x3_splitk_f32(const float *a, int64_t lda, const float *amax_a, int R, int K, const void *w_hi,
                                            const void *w_lo, const float *w_scale, int N, float *out, void *workspace,
                                            size_t workspace_bytes, void *stream) {
-  const char *what = "gvl_linear_f16x3_splitk_f32";
+  if (lda < K) return fail(GVL_EINVAL, "gvl_linear_f16x3_splitk_f32: lda >= K (overlapping rows: gvl_linear_f16x3_splitk_bias_f32)");
+  return gvl_linear_f16x3_splitk_bias_f32(a, lda, amax_a, R, K, w_hi, w_lo, w_scale, nullptr, N, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gvl_linear_f16x3_splitk_bias_f32(const float *a, int64_t lda, const float *amax_a, int R, int K, const void *w_hi,
+                                                const void *w_lo, const float *w_scale, const float *bias, int N, float *out,
+                                                void *workspace, size_t workspace_bytes, void *stream) {
+  const char *what = "gvl_linear_f16x3_splitk_bias_f32";
   if (R <= 0 || N <= 0 || K <= 0 || (K % kBK) || (N % 128)) return fail(GVL_EINVAL, "%s: needs K %% 32 == 0 and N %% 128 == 0 (got R=%d N=%d K=%d)", what, R, N, K);
   if (!a || !amax_a || !w_hi || !w_lo || !w_scale || !out) return fail(GVL_EINVAL, "%s: null pointer", what);
-  if (lda < K || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15) || ((uintptr_t)out & 15))
-    return fail(GVL_EINVAL, "%s: a (lda >= K, lda %% 4 == 0), the weight planes and out must be 16-byte aligned", what);
+  // (lda < K is allowed, as in gvl_linear_f16x3_f32: overlapping rows -- the tap rows of a strided convolution over a padded input)
+  if (lda <= 0 || (lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15) || ((uintptr_t)out & 15) ||
+      ((uintptr_t)bias & 15))
+    return fail(GVL_EINVAL, "%s: a (lda %% 4 == 0), the weight planes, bias and out must be 16-byte aligned", what);
   const int tiles_m = (R + kBM - 1) / kBM, tiles_n = N / 128, stages = K / kBK;
   int sk = max(1, min(512 / (tiles_m * tiles_n), stages / 8));
   const int per = (stages + sk - 1) / sk;
@@ -1501,7 +1515,7 @@ extern "C" int gvl_linear_f16x3_splitk_f32(const float *a, int64_t lda, const fl
   if (need > workspace_bytes || (need && (!workspace || ((uintptr_t)workspace & 15)))) return fail(GVL_ENOSPC, "%s: workspace of %zu bytes needed", what, need);
   LinParams p;
   p.A = a; p.lda = lda; p.A2 = nullptr; p.lda2 = 0; p.a2_rows = 1;
-  p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = nullptr;
+  p.Wh = (const _Float16 *)w_hi; p.Wl = (const _Float16 *)w_lo; p.Ws = w_scale; p.bias = sk > 1 ? nullptr : bias;
   p.R = R; p.N = N; p.K = K; p.nseg = 1;
   gvl_lin_seg sg = {};
   sg.n_begin = 0; sg.flags = 0; sg.out = sk > 1 ? reinterpret_cast<float *>(workspace) : out; sg.ldo = N; sg.amax_in = amax_a;
@@ -1516,7 +1530,8 @@ extern "C" int gvl_linear_f16x3_splitk_f32(const float *a, int64_t lda, const fl
   if (sk > 1) {
     const int64_t n4 = (int64_t)R * N / 4;
     hipLaunchKernelGGL(k_lin_splitk_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float4 *>(workspace), n4, sk, reinterpret_cast<float4 *>(out));
+                       reinterpret_cast<const float4 *>(workspace), n4, sk, reinterpret_cast<float4 *>(out),
+                       reinterpret_cast<const float4 *>(bias), N / 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, "%s: reduce launch failed: %s", what, hipGetErrorString(e));
   }

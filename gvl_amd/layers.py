@@ -110,23 +110,31 @@ def linear(a, w, segs, a2=None, flags=0):
     _lib.check(rc, "linear_f16x3")
 
 
-def linear_splitk(a, amax_a, w, out=None):
-    """gvl_linear_f16x3_splitk_f32: out (R, N) = a (R, K) . w^T for few outputs and a long contraction (w: operand planes of N
-    rows, N % 128 == 0; a's row stride may exceed K: the padding must be finite and multiplies zero planes)"""
+def linear_splitk(a, amax_a, w, out=None, bias=False):
+    """gvl_linear_f16x3_splitk_bias_f32: out (R, N) = a (R, K) . w^T (+ w.bias when bias=True) for few outputs and a long
+    contraction (w: operand planes of N rows, N % 128 == 0; a's row stride may exceed K -- the padding must be finite and
+    multiplies zero planes -- or, with overlapping rows, fall short of it)"""
     R = a.shape[0]
     K = w.K
-    assert a.dtype == torch.float32 and a.stride(1) == 1 and a.stride(0) >= K and amax_a.numel() == R
+    assert a.dtype == torch.float32 and a.stride(1) == 1 and a.stride(0) > 0 and amax_a.numel() == R
     if out is None:
         out = torch.empty(R, w.N, device=a.device, dtype=torch.float32)
     L_ = _lib.lib()
     nbytes = L_.gvl_linear_f16x3_splitk_workspace_bytes(R, w.N, K)
     ws = torch.empty(max(nbytes, 16) // 4, device=a.device, dtype=torch.float32)
+    b = w.bias if bias and w.bias is not None else None
     with torch.cuda.device(a.device):
-        rc = L_.gvl_linear_f16x3_splitk_f32(a.data_ptr(), a.stride(0), amax_a.data_ptr(), R, K, w.planes.hi.data_ptr(),
-                                            w.planes.lo.data_ptr(), w.planes.scale.data_ptr(), w.N, out.data_ptr(), ws.data_ptr(),
-                                            nbytes, torch.cuda.current_stream().cuda_stream)
+        rc = L_.gvl_linear_f16x3_splitk_bias_f32(a.data_ptr(), a.stride(0), amax_a.data_ptr(), R, K, w.planes.hi.data_ptr(),
+                                                 w.planes.lo.data_ptr(), w.planes.scale.data_ptr(),
+                                                 b.data_ptr() if b is not None else None, w.N, out.data_ptr(), ws.data_ptr(),
+                                                 nbytes, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "linear_f16x3_splitk")
     return out
+
+
+def splitk_pays(R, N, K):
+    """whether gvl_linear_f16x3_splitk_* would split this product at all (few tiles, a long contraction)"""
+    return N % 128 == 0 and K % 32 == 0 and _lib.lib().gvl_linear_f16x3_splitk_workspace_bytes(R, N, K) > 0
 
 
 def layer_norm(x, norm, pos=None, want_amax=True):

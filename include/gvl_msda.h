@@ -54,7 +54,8 @@ extern "C" {
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
  *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps),
- *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_mha_train_backward_amax_f32 / gvl_group_norm_rows_backward_amax_f32
+ *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_linear_f16x3_splitk_bias_f32 (split-K with a bias, overlapping rows), gvl_mha_train_backward_amax_f32 /
+ *      gvl_group_norm_rows_backward_amax_f32
  *      (row maxima of dqkv / of the pyramid's dy from the kernels that write them), gvl_index_add_rows_f32 (an embedding
  *      lookup's gradient without the additions of zero rows)
  * 15: + gvl_wgrad_group_f16x3_f32 / gvl_wgrad_group_workspace_bytes / gvl_wgrad_group_max (the weight gradients of several Linears
@@ -886,6 +887,12 @@ int gvl_mha_train_backward_amax_f32(const float *qkv, int64_t ld, const unsigned
 size_t gvl_linear_f16x3_splitk_workspace_bytes(int R, int N, int K);
 int gvl_linear_f16x3_splitk_f32(const float *a, int64_t lda, const float *amax_a, int R, int K, const void *w_hi, const void *w_lo,
                                 const float *w_scale, int N, float *out, void *workspace, size_t workspace_bytes, void *stream);
+/*    ..._bias_f32 (ABI 16): the same with a bias (N, 16-byte aligned, may be NULL) added to the finished sum, and rows that may
+ *    OVERLAP (0 < lda < K, as gvl_linear_f16x3_f32 allows): the k = 3, stride 2 convolutions of the feature pyramid as products over
+ *    rows of taps (a few hundred rows, contraction 3 C_in: 13-52 tiles of 48 K stages otherwise). */
+int gvl_linear_f16x3_splitk_bias_f32(const float *a, int64_t lda, const float *amax_a, int R, int K, const void *w_hi,
+                                     const void *w_lo, const float *w_scale, const float *bias, int N, float *out, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* -- the update of the training step: clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() (train.py:405-409) over a table of
  *    tensors, three launches (sum of squares per chunk; total norm, clip coefficient, bias corrections; update) -- gvl_optim.hip.

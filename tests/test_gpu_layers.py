@@ -344,3 +344,25 @@ def test_first_decoder_layer_constants_are_kept_and_equal_the_recomputed_forward
     moved = run(dts[0])
     assert not torch.equal(moved[0], want[0][0])
     assert len(dec.__dict__["_gvl_first_layer"]) == 1 and set(dec.__dict__["_gvl_first_layer"]) != set(kept)
+
+
+def test_split_k_product_with_bias_over_overlapping_rows_matches_float64():
+    """gvl_linear_f16x3_splitk_bias_f32: the k = 3, stride 2 convolution of the feature pyramid as a product over rows of taps that
+    OVERLAP (row stride 2 C_in < 3 C_in) with the bias added to the finished sum -- against float64, and the plain kernel"""
+    from gvl_amd import layers as L
+    torch.manual_seed(2)
+    N, T1, ch, C = 16, 51, 512, 512
+    xp = torch.randn(N + 1, 2 * T1, ch, device=DEV)
+    a = xp.as_strided((N * T1, 3 * ch), (2 * ch, 1))
+    w = torch.randn(C, 3 * ch, device=DEV) * 0.03
+    b = torch.randn(C, device=DEV)
+    W = L.Weights([(w, b)])
+    assert L.splitk_pays(a.shape[0], W.N, W.K)
+    am, _ = L.row_absmax(a)
+    y = L.linear_splitk(a, am, W, bias=True)
+    y0 = torch.empty_like(y)
+    L.linear(a, W, [L.seg(0, y0, am)])
+    ref = a.double() @ w.double().t() + b.double()
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * scale and float((y0.double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((L.linear_splitk(a, am, W) .double() - (ref - b.double())).abs().max()) <= 2e-6 * scale       # without the bias
