@@ -31,6 +31,7 @@ from ..ops.functions import MSDASampleFunction
 from ..ops.modules import MSDeformAttnCap
 from ..ops.modules.ms_deform_attn import temporal_shapes_2d
 from .. import MultiScaleDeformableAttention as MSDA
+from ..linear import mirror_linear as _mirror_linear, mirror_linear_eligible as _mirror_ok
 from ..linear import Linear, split_gemm_enabled, split_linear, vocab_nll, vocab_nll_eligible
 
 
@@ -703,7 +704,14 @@ class Captioner(nn.Module):
             ids = seq[:, :steps].t() if tm else seq[:, :steps]
             from .. import layers as _layers
             emb = _layers.embed_rows(self.embed.weight, ids.reshape(-1)).view(*ids.shape, -1)
-            xt_all = F.linear(emb, w_x)                                           # (n, steps, 4H); tm: (steps, n, 4H)
+            mirror = self.core.__dict__.get("_gvl_wx_mirror")
+            if (mirror is not None and torch.is_grad_enabled() and os.environ.get("GVL_XT_MIRROR", "1") != "0"
+                    and _mirror_ok(emb, w_x, mirror)):
+                # the embedding part of every token's gate pre-activations on the hand-written products (planes of W_ih's
+                # embedding columns: gvl_amd/train_planes.py register_mirror) instead of the fp32 library GEMMs
+                xt_all = _mirror_linear(emb, w_x, mirror)
+            else:
+                xt_all = F.linear(emb, w_x)                                       # (n, steps, 4H); tm: (steps, n, 4H)
             if fused:
                 hidden = self.core.teacher_forced(xt_all, hs, ref_in, tshapes, lsi, const, row_video, time_major=tm)
                 if tm:

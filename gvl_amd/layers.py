@@ -110,6 +110,22 @@ def linear(a, w, segs, a2=None, flags=0):
     _lib.check(rc, "linear_f16x3")
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(n_floats, device):
+    """the partial slabs of a split-K product: ONE buffer per device, grown on demand and kept (successive products on a stream
+    use it in turn; nothing else ever aliases it).  Not during a stream capture: a captured product gets a buffer of the graph's
+    own pool, as every other temporary of the capture."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n_floats, device=device, dtype=torch.float32)
+    key = str(device)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < n_floats:
+        ws = _SPLITK_WS[key] = torch.empty(n_floats, device=device, dtype=torch.float32)
+    return ws
+
+
 def linear_splitk(a, amax_a, w, out=None, bias=False):
     """gvl_linear_f16x3_splitk_bias_f32: out (R, N) = a (R, K) . w^T (+ w.bias when bias=True) for few outputs and a long
     contraction (w: operand planes of N rows, N % 128 == 0; a's row stride may exceed K -- the padding must be finite and
@@ -121,7 +137,7 @@ def linear_splitk(a, amax_a, w, out=None, bias=False):
         out = torch.empty(R, w.N, device=a.device, dtype=torch.float32)
     L_ = _lib.lib()
     nbytes = L_.gvl_linear_f16x3_splitk_workspace_bytes(R, w.N, K)
-    ws = torch.empty(max(nbytes, 16) // 4, device=a.device, dtype=torch.float32)
+    ws = _splitk_workspace(max(nbytes, 16) // 4, a.device)
     b = w.bias if bias and w.bias is not None else None
     with torch.cuda.device(a.device):
         rc = L_.gvl_linear_f16x3_splitk_bias_f32(a.data_ptr(), a.stride(0), amax_a.data_ptr(), R, K, w.planes.hi.data_ptr(),

