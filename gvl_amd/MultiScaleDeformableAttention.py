@@ -512,10 +512,11 @@ def wgrad_eligible(dy, x):
             and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def wgrad(dy, x, amax_dy, amax_x, grad_w=None, grad_b=None, want_bias=True, accumulate=False):
+def wgrad(dy, x, amax_dy, amax_x, grad_w=None, grad_b=None, want_bias=True, accumulate=False, skip_zero_rows=False):
     """dy (R, N), x (R, K) fp32 -> (grad_w (N, K) = dy^T x, grad_b (N) = column sums of dy) on the fp16 matrix cores at fp32
     accuracy (include/gvl_msda.h: gvl_wgrad_f16x3_f32).  amax_*: fp32 vectors (or one number) whose maximum bounds |dy| / |x|.
-    grad_w / grad_b given: written in place, with accumulate=True ON TOP of their contents."""
+    grad_w / grad_b given: written in place, with accumulate=True ON TOP of their contents.  skip_zero_rows (amax_dy per row):
+    rows of dy whose bound is 0 -- all-zero rows -- are left out of the product (gvl_wgrad_f16x3_live_f32)."""
     _require(wgrad_eligible(dy, x), "wgrad: dy (R, N), x (R, K) fp32 CUDA matrices, unit column stride, N, K, strides % 4 == 0")
     R, N = dy.shape
     K = x.shape[1]
@@ -533,11 +534,15 @@ def wgrad(dy, x, amax_dy, amax_x, grad_w=None, grad_b=None, want_bias=True, accu
     L = _lib.lib()
     nbytes = L.gvl_wgrad_workspace_bytes(R, N, K)
     ws = torch.empty(max(nbytes, 16) // 4, device=dy.device, dtype=torch.float32)
+    live = None
+    if skip_zero_rows and amax_dy.numel() == R:
+        live = torch.empty(L.gvl_wgrad_live_ints(R), device=dy.device, dtype=torch.int32)
     with torch.cuda.device(dy.device):
-        rc = L.gvl_wgrad_f16x3_f32(dy.data_ptr(), dy.stride(0), amax_dy.data_ptr(), amax_dy.numel(), x.data_ptr(), x.stride(0),
-                                   amax_x.data_ptr(), amax_x.numel(), R, N, K, grad_w.data_ptr(),
-                                   grad_b.data_ptr() if grad_b is not None else None, 1 if accumulate else 0,
-                                   ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+        rc = L.gvl_wgrad_f16x3_live_f32(dy.data_ptr(), dy.stride(0), amax_dy.data_ptr(), amax_dy.numel(), x.data_ptr(), x.stride(0),
+                                        amax_x.data_ptr(), amax_x.numel(), R, N, K, grad_w.data_ptr(),
+                                        grad_b.data_ptr() if grad_b is not None else None, 1 if accumulate else 0,
+                                        ws.data_ptr(), nbytes, live.data_ptr() if live is not None else None,
+                                        torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "wgrad_f16x3")
     return grad_w, grad_b
 

@@ -123,6 +123,8 @@ SIGNATURES = {
     "gvl_wgrad_group_workspace_bytes": (_SZ, [_P, _I]),
     "gvl_wgrad_group_f16x3_f32": (_I, [_P, _I, _P, _SZ, _P]),
     "gvl_wgrad_f16x3_f32": (_I, [_P, _I64, _P, _I, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _I, _P, _SZ, _P]),
+    "gvl_wgrad_f16x3_live_f32": (_I, [_P, _I64, _P, _I, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _I, _P, _SZ, _P, _P]),
+    "gvl_wgrad_live_ints": (_I, [_I]),
     "gvl_planes_chunk_elems": (_I, []),
     "gvl_planes_refresh_f16": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "gvl_mha_train_forward_f32": (_I, [_P, _I64, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_uint32, _P, _P, _P, _P, _P]),

@@ -52,6 +52,8 @@ struct WgParams {
   float *part;                             // (SK, N, K) or, with SK == 1, the gradient itself
   float *part_b;                           // (SK, N) or NULL
   int accumulate;                          // SK == 1 only: add to what `part` / `part_b` hold
+  const int *live;                         // NULL, or [0] = number of LIVE rows of dy, [1 ..] their indices ascending (k_live_rows): the
+                                           // other rows are all zeros; a stage then multiplies 32 consecutive LIST entries
 #ifdef GVL_WG_STAMPS
   unsigned long long *stamps;              // timing builds only: [workgroup][8] {memtime, memrealtime} x {start, loop, loop end, end}
 #endif
@@ -132,7 +134,10 @@ __device__ __forceinline__ void wgrad_item(const WgParams &p, const int item, co
   const int sk = item / tiles, tile = item % tiles;
   const int tn = tile / p.tiles_k, tk = tile % p.tiles_k;
   const int n0 = tn * kWgT, k0 = tk * kWgT;
-  const int r_begin = sk * p.rows_per_split, r_end = min(p.R, r_begin + p.rows_per_split);
+  // (live list: the row range of a split is a range of LIST entries, whole stages of 32; the descriptors then span all rows)
+  const int n_live = p.live ? p.live[0] : 0;
+  const int per_live = ((n_live + p.SK - 1) / p.SK + kWgR - 1) / kWgR * kWgR, first_live = sk * per_live;
+  const int r_begin = p.live ? 0 : sk * p.rows_per_split, r_end = p.live ? p.R : min(p.R, r_begin + p.rows_per_split);
 
   GVL_WG_STAMP(0)
   float mul_a, back_a, mul_b, back_b;
@@ -151,10 +156,16 @@ __device__ __forceinline__ void wgrad_item(const WgParams &p, const int item, co
   const int a_tail = p.N - (n0 + 4 * c4);            // valid columns of this thread's 16-byte piece of dy (>= 4: all)
   const uint32_t st_off = (uint32_t)(lr * kWgRowB + c4 * 8);
   struct Set { float4 a[2], b[2]; };
-  auto load = [&](Set &s, int stage) {
+  auto load = [&](Set &s, int stage_i) {
+    // (stage_i counts this item's stages; with a live list it indexes the list -- past its end: a stage beyond the last row, whose
+    //  loads fall outside the descriptors and come back as zeros, like the pipeline's look-ahead past a plain range)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const uint32_t r = (uint32_t)(stage * kWgR + lr + 16 * i);
+      uint32_t r = (uint32_t)(stage_i * kWgR + lr + 16 * i);
+      if (p.live) {                                  // entry r of this item's part of the list -> its row (past the end: no row)
+        const int e = first_live + (int)r;
+        r = ((int)r < per_live && e < n_live) ? (uint32_t)p.live[1 + e] : (uint32_t)p.R;
+      }
 #ifdef GVL_WG_NO_LOAD
       s.a[i] = make_float4((float)r, 1.f, 2.f, 3.f); s.b[i] = make_float4(1.f, (float)r, 2.f, 3.f);
 #else
@@ -219,7 +230,7 @@ __device__ __forceinline__ void wgrad_item(const WgParams &p, const int item, co
   // SIMD would run the same phases in lockstep behind the stage barrier (fragment reads, split + LDS writes, MFMAs): wavefronts
   // 4-7 therefore run their MFMAs FIRST and split afterwards, wavefronts 0-3 the other way round -- while one half occupies the
   // matrix pipe the other occupies the vector / LDS-write path (MI355X_MICROARCH.md, two waves per SIMD, item 9).
-  const int nst = (r_end - r_begin + kWgR - 1) / kWgR;
+  const int nst = p.live ? (max(0, min(per_live, n_live - first_live)) + kWgR - 1) / kWgR : (r_end - r_begin + kWgR - 1) / kWgR;
   const bool mfma_first = __builtin_amdgcn_readfirstlane(wave) >= 4;
   Set set0, set1, set2;
   load(set0, 0);
@@ -325,6 +336,22 @@ __device__ __forceinline__ void wgrad_item(const WgParams &p, const int item, co
     }
   }
   GVL_WG_STAMP(3)
+}
+
+// live[0] = number of rows of dy with a non-zero bound, live[1 ..] = their indices, ascending (one wavefront; a ballot per 64 rows keeps
+// the order).  A row whose bound is 0 is all zeros: the padded positions of a teacher-forced caption batch -- most rows of the
+// vocabulary layer's (4416, 8518) gradient at cfg A.
+__global__ void __launch_bounds__(64) k_live_rows(const float *__restrict__ amax, int R, int *__restrict__ live) {
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int r0 = 0; r0 < R; r0 += 64) {
+    const int r = r0 + lane;
+    const bool any = r < R && amax[r] != 0.f;
+    const unsigned long long m = __ballot(any);
+    if (any) live[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    base += __popcll(m);
+  }
+  if (lane == 0) live[0] = base;
 }
 
 template <bool X1>
@@ -620,6 +647,7 @@ extern "C" int gvl_wgrad_group_f16x3_f32(const gvl_wgrad_desc *descs, int n, voi
     p.amax_dy = d.amax_dy; p.amax_x = d.amax_x; p.n_amax_dy = d.n_amax_dy; p.n_amax_x = d.n_amax_x;
     p.R = d.R; p.N = d.N; p.K = d.K; p.tiles_n = pl.tiles_n; p.tiles_k = pl.tiles_k; p.SK = pl.SK; p.rows_per_split = pl.rows_per_split;
     p.accumulate = d.accumulate;
+    p.live = nullptr;
 #ifdef GVL_WG_STAMPS
     p.stamps = g_wg_stamps;
 #endif
@@ -667,7 +695,17 @@ extern "C" size_t gvl_wgrad_workspace_bytes(int R, int N, int K) {
 extern "C" int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *amax_dy, int n_amax_dy, const float *x, int64_t ld_x,
                                    const float *amax_x, int n_amax_x, int R, int N, int K, float *grad_w, float *grad_b,
                                    int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+  return gvl_wgrad_f16x3_live_f32(dy, ld_dy, amax_dy, n_amax_dy, x, ld_x, amax_x, n_amax_x, R, N, K, grad_w, grad_b, accumulate,
+                                  workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int gvl_wgrad_live_ints(int R) { return R > 0 ? 1 + R : 0; }
+
+extern "C" int gvl_wgrad_f16x3_live_f32(const float *dy, int64_t ld_dy, const float *amax_dy, int n_amax_dy, const float *x, int64_t ld_x,
+                                        const float *amax_x, int n_amax_x, int R, int N, int K, float *grad_w, float *grad_b,
+                                        int accumulate, void *workspace, size_t workspace_bytes, int *live_ws, void *stream) {
   if (!dy || !x || !amax_dy || !amax_x || !grad_w) return fail(GVL_EINVAL, "gvl_wgrad_f16x3_f32: null pointer");
+  if (live_ws && n_amax_dy != R) return fail(GVL_EINVAL, "gvl_wgrad_f16x3_live_f32: the live-stage list needs one bound per row of dy");
   if (R <= 0 || N <= 0 || K <= 0 || (K & 3) || (ld_dy & 3) || (ld_x & 3) || ld_dy < ((N + 3) & ~3) || ld_x < K || n_amax_dy < 1 ||
       n_amax_x < 1)
     return fail(GVL_EINVAL, "gvl_wgrad_f16x3_f32: R, N, K > 0, K and both row strides multiples of 4, ld_dy >= N rounded up to 4 (got R=%d N=%d K=%d)", R, N, K);
@@ -684,6 +722,12 @@ extern "C" int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *
   p.amax_dy = amax_dy; p.amax_x = amax_x; p.n_amax_dy = n_amax_dy; p.n_amax_x = n_amax_x;
   p.R = R; p.N = N; p.K = K; p.tiles_n = pl.tiles_n; p.tiles_k = pl.tiles_k; p.SK = pl.SK; p.rows_per_split = pl.rows_per_split;
   p.accumulate = accumulate;
+  p.live = live_ws;
+  if (live_ws) {
+    hipLaunchKernelGGL(k_live_rows, dim3(1), dim3(64), 0, st, amax_dy, R, live_ws);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "gvl_wgrad_f16x3_live_f32: list launch failed: %s", hipGetErrorString(e));
+  }
   if (pl.SK == 1) {
     p.part = grad_w;
     p.part_b = grad_b;

@@ -54,7 +54,8 @@ extern "C" {
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
  *      gradient), gvl_lstm_cell_train_backward_sum_f32 (the gate gradients' running sum over the token steps),
- *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_linear_f16x3_splitk_bias_f32 (split-K with a bias, overlapping rows), gvl_mha_train_backward_amax_f32 /
+ *      gvl_mask_rows_f32 / _backward_f32 (the padded rows of a value projection), gvl_linear_f16x3_splitk_bias_f32 (split-K with a bias, overlapping rows), gvl_wgrad_f16x3_live_f32 / gvl_wgrad_live_ints
+ *      (a weight gradient that visits only the row stages with non-zero rows), gvl_mha_train_backward_amax_f32 /
  *      gvl_group_norm_rows_backward_amax_f32
  *      (row maxima of dqkv / of the pyramid's dy from the kernels that write them), gvl_index_add_rows_f32 (an embedding
  *      lookup's gradient without the additions of zero rows)
@@ -824,6 +825,14 @@ int gvl_wgrad_group_f16x3_f32(const gvl_wgrad_desc *descs, int n, void *workspac
 int gvl_wgrad_f16x3_f32(const float *dy, int64_t ld_dy, const float *amax_dy, int n_amax_dy, const float *x, int64_t ld_x,
                         const float *amax_x, int n_amax_x, int R, int N, int K, float *grad_w, float *grad_b, int accumulate,
                         void *workspace, size_t workspace_bytes, void *stream);
+/*    ..._live_f32 (ABI 16): live_ws (gvl_wgrad_live_ints(R) ints of device scratch) or NULL: a list of the rows of dy with a non-zero
+ *    bound is built first (amax_dy must then be per row, n_amax_dy == R) and only those are multiplied, 32 list entries per stage --
+ *    rows whose bound is 0 are all zeros, e.g. the padded positions of a teacher-forced caption batch in the vocabulary layer's
+ *    gradient. */
+int gvl_wgrad_f16x3_live_f32(const float *dy, int64_t ld_dy, const float *amax_dy, int n_amax_dy, const float *x, int64_t ld_x,
+                             const float *amax_x, int n_amax_x, int R, int N, int K, float *grad_w, float *grad_b, int accumulate,
+                             void *workspace, size_t workspace_bytes, int *live_ws, void *stream);
+int gvl_wgrad_live_ints(int R);
 
 /* -- TRAINING: operand planes of all weights of the step in two launches.  The forward product of an nn.Linear needs the planes
  *    of W (N, K), its input gradient `grad_output.mm(weight)` (AddmmBackward) those of W^T; the weights change with every

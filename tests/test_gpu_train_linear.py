@@ -265,3 +265,28 @@ def test_a_captured_forward_of_a_stand_alone_linear_refreshes_its_planes_on_ever
     torch.cuda.synchronize()
     want = torch.nn.functional.linear(static_x.detach().double(), lin.weight.detach().double(), lin.bias.detach().double())
     assert float((y.detach().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("R,N,K", [(4416, 8518, 512), (1000, 512, 512), (96, 200, 64), (4416, 512, 2048)])
+def test_wgrad_that_skips_the_stages_of_zero_rows_equals_the_full_pass(R, N, K):
+    """gvl_wgrad_f16x3_live_f32: rows of dy whose bound is 0 are all zeros (the padded positions of a caption batch in the vocabulary
+    layer's gradient); the product runs over the list of the other rows, 32 list entries per stage.  Same gradient as the full pass
+    to rounding (the rows meet in other groups of 32) -- with most rows dead, with every row dead, with none"""
+    torch.manual_seed(R + N)
+    x = torch.randn(R, K, device=DEV)
+    am_x = x.abs().amax(1)
+    for frac_dead in (0.8, 1.0, 0.0):
+        dy = torch.randn(R, N + (-N) % 4, device=DEV)[:, :N]
+        dead = torch.rand(R, device=DEV) < frac_dead
+        dead[: R // 3] = True if frac_dead > 0 else False                  # whole dead stages, not only scattered rows
+        dy[dead] = 0.0
+        am = dy.abs().amax(1)
+        gw0, gb0 = MSDA.wgrad(dy, x, am, am_x)
+        gw1, gb1 = MSDA.wgrad(dy, x, am, am_x, skip_zero_rows=True)
+        ref = dy.double().t() @ x.double()
+        scale = max(1e-30, float(ref.abs().max()))
+        assert float((gw1.double() - ref).abs().max()) <= 3e-6 * max(scale, 1.0) and float((gw0.double() - ref).abs().max()) <= 3e-6 * max(scale, 1.0)
+        assert float((gw1 - gw0).abs().max()) <= 2e-6 * max(scale, 1.0)
+        assert float((gb1 - gb0).abs().max()) <= 1e-5 * max(1.0, float(gb0.abs().max()))
+        if frac_dead == 1.0:
+            assert float(gw1.abs().max()) == 0.0 and float(gb1.abs().max()) == 0.0
