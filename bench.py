@@ -908,7 +908,8 @@ def main():
                           f"log-sum-exp fused, logits never written), hand-written",
                 "note": "the matrix pipe is power-limited under this load (clock 1.87 GHz, issue throttled by the operands' "
                         "switching activity): with real operands and NO data movement the same MFMA stream reaches 0.63 of "
-                        "the nominal peak (DESIGN_LOG.md 4.4, tools/vocab_clocks.sh)",
+                        "the nominal peak (DESIGN_LOG.md 4.4, tools/vocab_clocks.sh); profiles/r06_gemm16_pmc.txt: MFMA pipe busy 0.66 of a "
+                        "wavefront's resident cycles at >= 1.76 GHz",
                 "bound": "mfma", "achieved": round(tf16, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, 3 "
                 "partial products per fp32 product)", "frac": round(tf16 / F16_MFMA_PEAK_TFLOPS, 4),
                 "fp32_equivalent_tflops": round(tf16 / 3, 1), "kernel_us": round(us, 1), "launches_timed": mine[0][1],
