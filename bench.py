@@ -674,7 +674,7 @@ def main():
             torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------------------------------------- train half
-    if a.mode in ("both", "train"):
+    def train_half():
         model.train()
         # one process: the whole step is ONE hipGraph; several processes: forward/backward graph, eager bucketed RCCL
         # all-reduce of the flat gradient buffer, clip/Adam graph (no collective inside a graph) -- GraphedTrainStep
@@ -715,6 +715,18 @@ def main():
                             "form": ("three graphs (forward + backward to the encoder output | encoder backward | clip + Adam) with "
                                      "the bucketed gradient exchange posted eagerly between them") if trainer.split
                             else ("one graph per caption-width bucket" if trainer.capacity.cap_len_policy == "bucket" else "one graph")}}
+
+    if a.mode in ("both", "train"):
+        if world > 1 and "eval" in res:
+            # several processes: a failure of the gradient exchange must not take the measured eval line with it -- it is reported
+            # in the line instead (one process: raise, loudly)
+            try:
+                train_half()
+            except Exception as e:                 # noqa: BLE001
+                res["train_error"] = f"{type(e).__name__}: {e}"[:400]
+                print(f"[bench] rank {rank}: train half failed: {res['train_error']}", file=sys.stderr, flush=True)
+        else:
+            train_half()
 
     # ---------------------------------------------------------------------------------------------- the line
     src_note = ("per-dispatch stamps (hipExtLaunchKernel events) of the launches inside the timed region" if a.no_graph
@@ -857,6 +869,8 @@ def main():
                 "value": round(world * B * a.steps / e2, 3), "unit": "videos/s", "ms_per_step": round(e2 * 1e3 / a.steps, 3),
                 "note": "the same step with GVL_GEMM=f32: the captioner's three token-loop products on hipBLASLt fp32 "
                         "GEMMs + gvl_greedy_step_f32 over written logits (round 2's path until gvl_gemm_f16x3)"}
+    if "train_error" in res:
+        line["train_error"] = res["train_error"]
     if "train" in res:
         t_ = res["train"]
         ms = t_["elapsed"] * 1e3 / a.steps
