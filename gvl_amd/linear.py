@@ -252,6 +252,9 @@ class _WgradQueue:
 
 _WGRAD_QUEUE = None
 _DEFER_WGRAD = os.environ.get("GVL_WGRAD_GROUP", "") != "0"
+# products over this many rows or more are taken one by one (long videos: the encoder's 15 360 rows at T = 512 -- a launch of its
+# own already fills the chip, and the group's two co-resident workgroups per CU lose to it: tools/switch_sweep.sh)
+_GROUP_MAX_ROWS = int(os.environ.get("GVL_WGRAD_GROUP_MAX_ROWS", "8192"))
 
 
 class deferred_wgrads:
@@ -275,7 +278,7 @@ class deferred_wgrads:
 def queued_wgrad(dy, x, am_dy, am_x, want_bias, params, defer):
     """(grad_w, grad_b) of one Linear: through the active queue when `defer` and every parameter's .grad is still None, else now"""
     q = _WGRAD_QUEUE
-    if defer and q is not None and all(p_ is None or p_.grad is None for p_ in params):
+    if defer and q is not None and dy.shape[0] < _GROUP_MAX_ROWS and all(p_ is None or p_.grad is None for p_ in params):
         return q.push(dy, x, am_dy, am_x, want_bias, [id(p_) for p_ in params if p_ is not None])
     return MSDA.wgrad(dy, x, am_dy, am_x, want_bias=want_bias)
 
