@@ -707,40 +707,89 @@ __global__ void __launch_bounds__(256) k_encoder_geometry(const unsigned char *_
 //                        embedding + duration embedding + level embedding, flattened: mask (B, S), lvl_pos (B, S, C).
 // ~60 PyTorch launches per forward otherwise (transposes, cats, interpolate, cumsum, sin / cos, group-norm passes).
 
-// one wavefront per (video, group): rows y[(n rows_per_video + t) ldy + c], t < T, c in the group's cg channels
+// one WORKGROUP (4 wavefronts) per (video, group): rows y[(n rows_per_video + t) ldy + c], t < T, c in the group's cg channels; a
+// thread owns channel c = threadIdx % cg of the rows t = threadIdx / cg (mod 256 / cg), four rows' loads in flight per pass.  (Round 6:
+// one wavefront per unit walked a level-0 group of a 512-frame video in 128 dependent steps per pass -- 225 us for 16 MB.)
+__device__ __forceinline__ float gn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sums of a and b over the workgroup's 256 threads (sh: 8 floats), every thread gets both
+__device__ __forceinline__ void gn_block_sum2(float &a, float &b, float *sh) {
+  a = gn_wave_sum(a);
+  b = gn_wave_sum(b);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();                                                      // (the previous use of sh is over)
+  if ((threadIdx.x & 63) == 0) {
+    sh[wave] = a;
+    sh[4 + wave] = b;
+  }
+  __syncthreads();
+  a = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  b = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+}
+// mean and 1 / sqrt(var + eps) of the unit's T x cg values (two passes: the variance from the centred values)
+__device__ __forceinline__ void gn_stats(const float *__restrict__ src, int64_t ldy, int T, int tr, int tstep, float cnt, float eps,
+                                         float *sh, float &mean, float &rstd) {
+  float sum = 0.f, zero = 0.f;
+  int t = tr;
+  for (; t + 3 * tstep < T; t += 4 * tstep) {
+    const float a0 = src[(int64_t)t * ldy], a1 = src[(int64_t)(t + tstep) * ldy], a2 = src[(int64_t)(t + 2 * tstep) * ldy],
+                a3 = src[(int64_t)(t + 3 * tstep) * ldy];
+    sum += (a0 + a1) + (a2 + a3);
+  }
+  for (; t < T; t += tstep) sum += src[(int64_t)t * ldy];
+  gn_block_sum2(sum, zero, sh);
+  mean = sum / cnt;
+  float sq = 0.f;
+  t = tr;
+  for (; t + 3 * tstep < T; t += 4 * tstep) {
+    const float d0 = src[(int64_t)t * ldy] - mean, d1 = src[(int64_t)(t + tstep) * ldy] - mean,
+                d2 = src[(int64_t)(t + 2 * tstep) * ldy] - mean, d3 = src[(int64_t)(t + 3 * tstep) * ldy] - mean;
+    sq += fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3);
+  }
+  for (; t < T; t += tstep) {
+    const float d = src[(int64_t)t * ldy] - mean;
+    sq = fmaf(d, d, sq);
+  }
+  zero = 0.f;
+  gn_block_sum2(sq, zero, sh);
+  rstd = 1.f / sqrtf(sq / cnt + eps);
+}
+
 __global__ void __launch_bounds__(256) k_group_norm_rows(const float *__restrict__ y, int64_t ldy, int rows_per_video, int T,
                                                          int C, int G, int N, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, float eps, float *__restrict__ dst,
                                                          int64_t dst_vs, float *__restrict__ dst2, int64_t dst2_vs) {
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (unit >= N * G) return;
-  const int n = unit / G, g = unit % G, cg = C / G;
-  const int c = g * cg + lane % cg, tr = lane / cg, tstep = 64 / cg;
+  __shared__ float sh[8];
+  const int unit = blockIdx.x, n = unit / G, g = unit % G, cg = C / G;
+  const int c = g * cg + (int)threadIdx.x % cg, tr = (int)threadIdx.x / cg, tstep = 256 / cg;
   const float *src = y + (int64_t)n * rows_per_video * ldy + c;
-  float sum = 0.f;
-  for (int t = tr; t < T; t += tstep) sum += src[(int64_t)t * ldy];
-#pragma unroll
-  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
-  const float cnt = (float)T * (float)cg, mean = sum / cnt;
-  float sq = 0.f;
-  for (int t = tr; t < T; t += tstep) {
-    const float d = src[(int64_t)t * ldy] - mean;
-    sq = fmaf(d, d, sq);
-  }
-#pragma unroll
-  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
-  const float rstd = 1.f / sqrtf(sq / cnt + eps);
+  const float cnt = (float)T * (float)cg;
+  float mean, rstd;
+  gn_stats(src, ldy, T, tr, tstep, cnt, eps, sh, mean, rstd);
   const float a = rstd * gamma[c], b2 = beta[c] - mean * rstd * gamma[c];
   float *d1 = dst + (int64_t)n * dst_vs + c;
   float *d2 = dst2 ? dst2 + (int64_t)n * dst2_vs + c : nullptr;
-  for (int t = tr; t < T; t += tstep) {
+  int t = tr;
+  for (; t + tstep < T; t += 2 * tstep) {
+    const float v0 = fmaf(src[(int64_t)t * ldy], a, b2), v1 = fmaf(src[(int64_t)(t + tstep) * ldy], a, b2);
+    d1[(int64_t)t * C] = v0;
+    d1[(int64_t)(t + tstep) * C] = v1;
+    if (d2) {
+      d2[(int64_t)t * C] = v0;
+      d2[(int64_t)(t + tstep) * C] = v1;
+    }
+  }
+  for (; t < T; t += tstep) {
     const float v = fmaf(src[(int64_t)t * ldy], a, b2);
     d1[(int64_t)t * C] = v;
     if (d2) d2[(int64_t)t * C] = v;
   }
 }
 
-// backward of k_group_norm_rows (TRAINING: base_encoder.py:60-80's GroupNorm of a level, rows layout), one wavefront per
+// backward of k_group_norm_rows (TRAINING: base_encoder.py:60-80's GroupNorm of a level, rows layout), one workgroup per
 // (video, group): x^ = (y - mean) rstd, g = dout gamma (dout = the gradient of the level's rows of the flattened encoder input, plus
 // the next level's input gradient where there is one), dy = rstd (g - (sum g + x^ sum g x^) / count); per-video partial sums of the
 // affine parameters' gradients (dgamma_part, dbeta_part: (N, C), summed over the videos by the caller: fixed order).  dy covers the
@@ -751,28 +800,32 @@ __global__ void __launch_bounds__(256) k_group_norm_rows_bwd(const float *__rest
                                                              const float *__restrict__ dout2, int64_t dout2_vs,
                                                              float *__restrict__ dy, int64_t ld_dy, float *__restrict__ dgamma_part,
                                                              float *__restrict__ dbeta_part, float *__restrict__ amax_dy) {
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (unit >= N * G) return;
-  const int n = unit / G, g = unit % G, cg = C / G;
-  const int c = g * cg + lane % cg, tr = lane / cg, tstep = 64 / cg;
+  __shared__ float sh[8];
+  __shared__ float sh_c[4][2][64];
+  const int unit = blockIdx.x, n = unit / G, g = unit % G, cg = C / G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = g * cg + (int)threadIdx.x % cg, tr = (int)threadIdx.x / cg, tstep = 256 / cg;
   const float *src = y + (int64_t)n * rows_per_video * ldy + c;
   const float *d1 = dout + (int64_t)n * dout_vs + c;
   const float *d2 = dout2 ? dout2 + (int64_t)n * dout2_vs + c : nullptr;
-  float sum = 0.f;
-  for (int t = tr; t < T; t += tstep) sum += src[(int64_t)t * ldy];
-#pragma unroll
-  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
-  const float cnt = (float)T * (float)cg, mean = sum / cnt;
-  float sq = 0.f;
-  for (int t = tr; t < T; t += tstep) {
-    const float d = src[(int64_t)t * ldy] - mean;
-    sq = fmaf(d, d, sq);
-  }
-#pragma unroll
-  for (int o = 32; o; o >>= 1) sq += __shfl_xor(sq, o, 64);
-  const float rstd = 1.f / sqrtf(sq / cnt + eps), gm = gamma[c];
+  const float cnt = (float)T * (float)cg;
+  float mean, rstd;
+  gn_stats(src, ldy, T, tr, tstep, cnt, eps, sh, mean, rstd);
+  const float gm = gamma[c];
   float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f;
-  for (int t = tr; t < T; t += tstep) {
+  int t = tr;
+  for (; t + tstep < T; t += 2 * tstep) {
+    const float y0 = src[(int64_t)t * ldy], y1 = src[(int64_t)(t + tstep) * ldy];
+    float g0 = d1[(int64_t)t * C], g1 = d1[(int64_t)(t + tstep) * C];
+    if (d2) {
+      g0 += d2[(int64_t)t * C];
+      g1 += d2[(int64_t)(t + tstep) * C];
+    }
+    const float x0 = (y0 - mean) * rstd, x1 = (y1 - mean) * rstd;
+    s1 = fmaf(g0, gm, s1); s2 = fmaf(g0 * gm, x0, s2); dg = fmaf(g0, x0, dg); db += g0;
+    s1 = fmaf(g1, gm, s1); s2 = fmaf(g1 * gm, x1, s2); dg = fmaf(g1, x1, dg); db += g1;
+  }
+  for (; t < T; t += tstep) {
     const float xh = (src[(int64_t)t * ldy] - mean) * rstd;
     const float go = d1[(int64_t)t * C] + (d2 ? d2[(int64_t)t * C] : 0.f);
     s1 = fmaf(go, gm, s1);
@@ -780,22 +833,22 @@ __global__ void __launch_bounds__(256) k_group_norm_rows_bwd(const float *__rest
     dg = fmaf(go, xh, dg);
     db += go;
   }
-  for (int o = cg; o < 64; o <<= 1) {                                  // the channel's rows sit in the lanes cg apart
+  for (int o = cg; o < 64; o <<= 1) {                                  // the channel's rows sit in the lanes cg apart ...
     dg += __shfl_xor(dg, o, 64);
     db += __shfl_xor(db, o, 64);
   }
-#pragma unroll
-  for (int o = 32; o; o >>= 1) {
-    s1 += __shfl_xor(s1, o, 64);
-    s2 += __shfl_xor(s2, o, 64);
+  if (lane < cg) {                                                     // ... and in the four wavefronts
+    sh_c[wave][0][lane] = dg;
+    sh_c[wave][1][lane] = db;
   }
-  if (tr == 0) {
-    dgamma_part[(int64_t)n * C + c] = dg;
-    dbeta_part[(int64_t)n * C + c] = db;
+  gn_block_sum2(s1, s2, sh);                                           // (its barriers also publish sh_c)
+  if ((int)threadIdx.x < cg) {
+    dgamma_part[(int64_t)n * C + c] = (sh_c[0][0][lane] + sh_c[1][0][lane]) + (sh_c[2][0][lane] + sh_c[3][0][lane]);
+    dbeta_part[(int64_t)n * C + c] = (sh_c[0][1][lane] + sh_c[1][1][lane]) + (sh_c[2][1][lane] + sh_c[3][1][lane]);
   }
   const float k1 = s1 / cnt, k2 = s2 / cnt;
   float *dst = dy + (int64_t)n * rows_per_video * ld_dy + c;
-  for (int t = tr; t < rows_per_video; t += tstep) {
+  for (t = tr; t < rows_per_video; t += tstep) {
     float v = 0.f;
     if (t < T) {
       const float xh = (src[(int64_t)t * ldy] - mean) * rstd;
@@ -805,8 +858,7 @@ __global__ void __launch_bounds__(256) k_group_norm_rows_bwd(const float *__rest
     dst[(int64_t)t * ld_dy] = v;
     if (amax_dy) {
       // max |dy row| (zero-initialised, atomic max over the row's G groups): the row scale of the convolution's weight / input
-      // gradient products.  The cg lanes of a row's group are adjacent; every lane of the wavefront is in the loop together
-      // (rows_per_video rounds to whole passes only when tstep divides it: the shuffles below stay within a row's cg lanes)
+      // gradient products.  The cg lanes of a row's group are adjacent and leave the loop together: the shuffles below stay within them
       float m = fabsf(v);
       for (int o = 1; o < cg; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
       if (lane % cg == 0) atomicMax(reinterpret_cast<unsigned *>(amax_dy) + (int64_t)n * rows_per_video + t, __float_as_uint(m));
@@ -1283,7 +1335,7 @@ extern "C" int gvl_group_norm_rows_f32(const float *y, int64_t ldy, int rows_per
     return fail(GVL_EINVAL, "gvl_group_norm_rows_f32: needs C / G in {1, 2, 4, ..., 64} (got N=%d T=%d C=%d G=%d)", N, T, C, G);
   if (N == 0) return 0;
   if (!y || !gamma || !beta || !dst) return fail(GVL_EINVAL, "gvl_group_norm_rows_f32: null pointer");
-  return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows", k_group_norm_rows, dim3((N * G + 3) / 4), dim3(256), 0,
+  return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows", k_group_norm_rows, dim3(N * G), dim3(256), 0,
                      (hipStream_t)stream, y, ldy, rows_per_video, T, C, G, N, gamma, beta, eps, dst, dst_video_stride, dst2,
                      dst2_video_stride);
 }
@@ -1304,7 +1356,7 @@ extern "C" int gvl_group_norm_rows_backward_amax_f32(const float *y, int64_t ldy
     return fail(GVL_EINVAL, "gvl_group_norm_rows_backward_f32: needs C / G in {1, 2, 4, ..., 64} (got N=%d T=%d C=%d G=%d)", N, T, C, G);
   if (N == 0) return 0;
   if (!y || !gamma || !dout || !dy || !dgamma_part || !dbeta_part) return fail(GVL_EINVAL, "gvl_group_norm_rows_backward_f32: null pointer");
-  return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows_bwd", k_group_norm_rows_bwd, dim3((N * G + 3) / 4), dim3(256), 0,
+  return gvl::launch(GVL_PROF_LAYER_NORM, T, N, "k_group_norm_rows_bwd", k_group_norm_rows_bwd, dim3(N * G), dim3(256), 0,
                      (hipStream_t)stream, y, ldy, rows_per_video, T, C, G, N, gamma, eps, dout, dout_video_stride, dout2,
                      dout2_video_stride, dy, ld_dy, dgamma_part, dbeta_part, amax_dy);
 }
