@@ -152,14 +152,16 @@ def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_
                          amax_out=None):
     """include/gvl_msda.h: gvl_msda1d_fused_forward_{f32,bf16}.  value (B,S,M,64) | proj (B,Q,2*M*L*P) | ref (B,Q,L,1|2);
     value / proj fp32 or both bf16, ref always fp32.  amax_out (B*Q) fp32, zero-initialised: additionally receives
-    max |out| of every output row (gvl_msda1d_fused_forward_amax_f32; fp32 only)."""
+    max |out| of every output row (gvl_msda1d_fused_forward_amax_f32; fp32 only).  proj (1, Q, 2*M*L*P) with amax_out: the same
+    rows for every video (gvl_msda1d_fused_forward_shared_amax_f32)."""
     _require(value.dtype in (torch.float32, torch.bfloat16), "msda1d_fused: value must be fp32 or bf16")
     for name, t_, dt_ in (("value", value, value.dtype), ("proj", proj, value.dtype), ("ref", ref, torch.float32)):
         _require(t_.is_cuda and t_.is_contiguous() and t_.dtype == dt_,
                  f"msda1d_fused: {name} must be a contiguous {dt_} CUDA tensor")
     B, S, M, D = value.shape
     Q, RD = ref.shape[1], ref.shape[-1]
-    _require(tuple(proj.shape) == (B, Q, 2 * M * n_levels * n_points) and tuple(ref.shape) == (B, Q, n_levels, RD),
+    shared = B > 1 and proj.shape[0] == 1 and amax_out is not None
+    _require(tuple(proj.shape) == (1 if shared else B, Q, 2 * M * n_levels * n_points) and tuple(ref.shape) == (B, Q, n_levels, RD),
              "msda1d_fused: proj / ref have wrong shapes")
     sh, ls = host_shapes(spatial_shapes, level_start_index)
     out = value.new_empty((B, Q, M * D))
@@ -167,7 +169,8 @@ def msda1d_fused_forward(value, spatial_shapes, level_start_index, proj, ref, n_
         _require(value.dtype == torch.float32 and amax_out.is_cuda and amax_out.dtype == torch.float32
                  and amax_out.is_contiguous() and amax_out.numel() == B * Q, "msda1d_fused: amax_out must be (B*Q) fp32")
         with torch.cuda.device(value.device):
-            rc = _lib.lib().gvl_msda1d_fused_forward_amax_f32(
+            entry = _lib.lib().gvl_msda1d_fused_forward_shared_amax_f32 if shared else _lib.lib().gvl_msda1d_fused_forward_amax_f32
+            rc = entry(
                 value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
                 ref.data_ptr(), B, S, M, D, n_levels, Q, n_points, RD, PAD_MODES[pad_mode], _hp(sh), _hp(ls),
                 out.data_ptr(), amax_out.data_ptr(), torch.cuda.current_stream().cuda_stream)

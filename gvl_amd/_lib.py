@@ -6,7 +6,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GVL_LIB_PATH: a dev build (gvl_amd.build.build_dev: timing / ablation variants of single kernels) instead of the shipped library
 LIB_PATH = os.environ.get("GVL_LIB_PATH") or os.path.join(_HERE, "libgvl_msda.so")
-ABI_VERSION = 16          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
+ABI_VERSION = 17          # include/gvl_msda.h GVL_MSDA_ABI_VERSION
 _lock = threading.Lock()
 _lib = None
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "gvl_greedy_step_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gvl_msda1d_fused_forward_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P]),
     "gvl_msda1d_fused_forward_amax_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P, _P]),
+    "gvl_msda1d_fused_forward_shared_amax_f32": (_I, [_P] * 5 + [_I] * 9 + [_P, _P, _P, _P, _P]),
     "gvl_linear_f16x3_f32": (_I, [_P, _I64, _P, _I64, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "gvl_layer_norm_rows_f32": (_I, [_P, _I, _I, _P, _P, ctypes.c_float, _P, _I, _P, _P, _P, _P]),
     "gvl_row_absmax_f32": (_I, [_P, _I64, _I, _I, _P, _I64, _I, _P, _P, _P]),

@@ -583,7 +583,10 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
                                                      const float *__restrict__ attn, int B, int S, int M, int L, int Q,
                                                      int P, int RD, int nchunk, VT *__restrict__ out,
                                                      unsigned long long *__restrict__ stamps,
-                                                     unsigned *__restrict__ amax_out, int qper, int m_shift, float invP) {
+                                                     unsigned *__restrict__ amax_out, int qper, int m_shift, float invP,
+                                                     int Qp) {
+  // Qp (FUSED): rows of `loc` (= proj) per video -- Q, or 0 when every video reads the SAME Q rows (the first decoder layer under the
+  // 'queries' input in inference: its offsets / logits depend on parameters only, gvl_amd/layers.py _first_layer_constants)
   extern __shared__ float4 slab4[];
   // grid = (B*M, nchunk): workgroups are dispatched x first, so the linear id (what the XCD round-robin sees) is
   // chunk * B*M + slab as before -- but neither a modulo nor a division by B*M is computed here, the chunk length comes from
@@ -622,7 +625,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
   // operand cursor: query index of the next fetch and the lane's element offsets for it, advanced by a constant per pass
   int qf = qb + tq;
   const int MLP = M * LP;
-  int64_t o0 = FUSED ? ((int64_t)b * Q + qf) * (2 * MLP) + m * LP + j : (((int64_t)b * Q + qf) * M + m) * LP + j;
+  int64_t o0 = FUSED ? ((int64_t)b * Qp + qf) * (2 * MLP) + m * LP + j : (((int64_t)b * Q + qf) * M + m) * LP + j;
   int64_t o1 = FUSED ? (((int64_t)b * Q + qf) * L + lvl) * RD : 0;
   const int64_t step0 = (int64_t)nw * 4 * (FUSED ? 2 * MLP : MLP), step1 = FUSED ? (int64_t)nw * 4 * L * RD : 0;
   // FULL16: no branch around the loads -- lanes past the end of the list re-read the list's last query (their results are
@@ -639,7 +642,7 @@ __global__ void __launch_bounds__(1024) k_fwd_t1d_d64(const VT *__restrict__ val
       const int64_t bq = (int64_t)b * Q + qc;
       // (byte offsets in 32-bit arithmetic: scalar base + zero-extended 32-bit offset is an addressing mode of the load)
       if constexpr (FUSED) {
-        const char *u0 = reinterpret_cast<const char *>(reinterpret_cast<const VT *>(loc) + bq * (2 * MLP) + m * LP);
+        const char *u0 = reinterpret_cast<const char *>(reinterpret_cast<const VT *>(loc) + ((int64_t)b * Qp + qc) * (2 * MLP) + m * LP);
         const unsigned e0 = (unsigned)(dq * (2 * MLP) + j) * (unsigned)sizeof(VT);
         r.a = (float)*reinterpret_cast<const VT *>(u0 + e0);
         r.b = (float)*reinterpret_cast<const VT *>(u0 + (e0 + (unsigned)MLP * (unsigned)sizeof(VT)));
@@ -2120,7 +2123,7 @@ int pick_chunks(const char *env, int BM, int Q, int target_wgs) {
 template <typename VT, bool FUSED>
 int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, const void *p0, const float *p1, int B,
                 int S, int M, int L, int Q, int P, int RD, int pad, const SlabPlan &plan, VT *out, hipStream_t st,
-                float *amax_out = nullptr) {
+                float *amax_out = nullptr, bool shared_proj = false) {
   // one 1024-thread workgroup per CU (measured best on MI355X: the 47 KB slab is staged once per CU and 16
   // wavefronts hide the LDS latency); GVL_MSDA_FWD_{THREADS,CHUNKS} override for tuning sweeps
   const int threads = env_int("GVL_MSDA_FWD_THREADS", 1024);
@@ -2152,7 +2155,7 @@ int run_fwd_t1d(const VT *value, const int64_t *shapes, const int64_t *lsi, cons
                      dim3(B * M, nchunk), dim3(threads), lds, st, value, shapes, lsi, p0, p1, B, S, M, L, Q, P, RD,
                      env_int("GVL_MSDA_XCD_PAIRS", 1) ? nchunk : -nchunk, out, g_fwd_stamps,
                      reinterpret_cast<unsigned *>(amax_out), (Q + nchunk - 1) / nchunk,
-                     (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1, 1.f / (float)P);
+                     (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1, 1.f / (float)P, shared_proj ? 0 : Q);
 }
 
 // number of query chunks per (b,m) slab for the backward: enough workgroups to cover the chip, and few enough
@@ -2392,14 +2395,14 @@ template <typename VT>
 int fused_forward(const VT *value, const int64_t *shapes, const int64_t *lsi, const VT *proj, const float *ref,
                          int B, int S, int M, int D, int L, int Q, int P, int RD, int pad_mode,
                          const int64_t *shapes_host, const int64_t *lsi_host, VT *out, void *stream,
-                         float *amax_out = nullptr) {
+                         float *amax_out = nullptr, bool shared_proj = false) {
   if (int rc = fused_eligible(B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host)) return rc;
   if ((int64_t)B * Q == 0) return 0;
   if (!value || !shapes || !lsi || !proj || !ref || !out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: null pointer");
   const SlabPlan plan = slab_plan(S, L, P, shapes_host);
   if (!plan.ok) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward: slab of %d rows does not fit LDS", S);
   return run_fwd_t1d<VT, true>(value, shapes, lsi, proj, ref, B, S, M, L, Q, P, RD, pad_mode, plan, out,
-                               (hipStream_t)stream, amax_out);
+                               (hipStream_t)stream, amax_out, shared_proj);
 }
 
 template <typename VT>
@@ -2555,6 +2558,14 @@ int gvl_msda1d_fused_forward_amax_f32(const float *value, const int64_t *shapes,
   if (!amax_out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward_amax_f32: null pointer");
   return fused_forward<float>(value, shapes, lsi, proj, ref, B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host,
                               out, stream, amax_out);
+}
+int gvl_msda1d_fused_forward_shared_amax_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj_q,
+                                             const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
+                                             int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
+                                             float *amax_out, void *stream) {
+  if (!amax_out) return fail(GVL_EINVAL, "gvl_msda1d_fused_forward_shared_amax_f32: null pointer");
+  return fused_forward<float>(value, shapes, lsi, proj_q, ref, B, S, M, D, L, Q, P, RD, pad_mode, shapes_host, lsi_host,
+                              out, stream, amax_out, true);
 }
 int gvl_msda1d_fused_forward_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                                   const uint16_t *proj, const float *ref, int B, int S, int M, int D, int L, int Q,

@@ -298,7 +298,9 @@ def encoder_geometry(mask_flatten, lengths, starts, want_ref=True):
 def _msda(att, value, proj, ref, shapes2d, lsi, B, Lq, arena):
     am_o = arena.take(B * Lq)
     M = att.n_heads
-    o = MSDA.msda1d_fused_forward(value.view(B, -1, M, att.d_model // M), shapes2d, lsi, proj.view(B, Lq, -1),
+    # (proj of Lq rows only: the same offsets / logits for every video -- _first_layer_constants)
+    o = MSDA.msda1d_fused_forward(value.view(B, -1, M, att.d_model // M), shapes2d, lsi,
+                                  proj.view(1 if proj.shape[0] == Lq and B > 1 else B, Lq, -1),
                                   ref.contiguous(), att.n_levels, att.n_points, att.pad_mode, amax_out=am_o)
     return o.view(B * Lq, -1), am_o
 
@@ -935,7 +937,10 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
                 table = dec.__dict__["_gvl_first_layer"]
                 for k_ in [k_ for k_ in table if k_[0] != first[0][0]]:
                     del table[k_]
-                table[first[0]] = (x2, am2, am2p, proj)
+                # (the projection's rows are the same for every video -- same inputs, every output element its own dot product: the
+                #  first video's Q rows are kept and every video reads them, 0.3 instead of 4.9 MB per launch at cfg A)
+                keep_q = os.environ.get("GVL_FIRST_LAYER_SHARED_PROJ", "1") != "0" and B > 1
+                table[first[0]] = (x2, am2, am2p, proj[:Q].clone() if keep_q else proj)
         o, am_o = _msda(att, values[lid], proj, ref_in, shapes2d, src_level_start_index, B, Q, arena)
         y = _new(R, C, x)
         linear(o, cached(att, "op", [(att.output_proj.weight, att.output_proj.bias)]), [seg(0, y, am_o, resid=x2)])

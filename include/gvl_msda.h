@@ -48,8 +48,9 @@
 extern "C" {
 #endif
 
-#define GVL_MSDA_ABI_VERSION 16
+#define GVL_MSDA_ABI_VERSION 17
 /* ABI history (newest first):
+ * 17: + gvl_msda1d_fused_forward_shared_amax_f32 (one set of offsets / logits rows for every video: the first decoder layer in inference)
  * 16: + gvl_count_pool_f32 / gvl_count_pool_backward_f32 (the count head's pooling over the queries and its gradient, training),
  *      gvl_batch_sum_f32 (the batch-expanded query embedding's gradient), gvl_residual_dropout_layer_norm_backwardn_f32 /
  *      gvl_rdln_backward_max_grads (several output gradients summed in the load path), gvl_level_sums_f32 (the level embedding's
@@ -619,6 +620,14 @@ int gvl_msda1d_fused_forward_amax_f32(const float *value, const int64_t *shapes,
                                       const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
                                       int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
                                       float *amax_out, void *stream);
+/*    ..._shared_amax_f32: proj_q (Q, 2*M*L*P) -- the SAME offsets / logits rows for every video (inference with the 'queries'
+ *    input, deformable_transformer.py:128-135: the first decoder layer's self-attention block and the projection behind it see the
+ *    batch-expanded query embedding and no video; gvl_amd/layers.py keeps their result per parameter set).  Everything else as
+ *    ..._amax_f32; the launch reads Q instead of B*Q operand rows. */
+int gvl_msda1d_fused_forward_shared_amax_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj_q,
+                                             const float *ref, int B, int S, int M, int D, int L, int Q, int P, int RD,
+                                             int pad_mode, const int64_t *shapes_host, const int64_t *lsi_host, float *out,
+                                             float *amax_out, void *stream);
 size_t gvl_msda1d_fused_backward_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P,
                                                  const int64_t *shapes_host);
 int gvl_msda1d_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *proj,

@@ -136,6 +136,26 @@ def test_sampling_kernel_leaves_exact_row_maxima():
     assert torch.equal(am, out.abs().amax(-1).reshape(-1))
 
 
+@pytest.mark.parametrize("B,Q,T", [(16, 300, 100), (3, 37, 64), (2, 300, 512)])
+def test_sampling_kernel_with_one_set_of_operand_rows_for_every_video(B, Q, T):
+    """gvl_msda1d_fused_forward_shared_amax_f32: proj (1, Q, .) read by every video == the launch on the rows copied B times"""
+    from gvl_amd import MultiScaleDeformableAttention as MSDA
+    from helpers import level_lengths
+    M, D, L_, P = 8, 64, 4, 4
+    lens = level_lengths(T)
+    S = sum(lens)
+    value = _rand(B, S, M, D, seed=43)
+    proj_q = _rand(1, Q, 2 * M * L_ * P, seed=44, scale=0.7)
+    ref = torch.rand(B, Q, L_, 1, generator=torch.Generator().manual_seed(45)).to(DEV)
+    shapes = torch.tensor([(1, x) for x in lens], dtype=torch.long, device=DEV)
+    lsi = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.long, device=DEV)
+    MSDA.attach_host_shapes(shapes, lsi, [(1, x) for x in lens], [int(v) for v in lsi.tolist()])
+    am_w, am_g = torch.zeros(B * Q, device=DEV), torch.zeros(B * Q, device=DEV)
+    want = MSDA.msda1d_fused_forward(value, shapes, lsi, proj_q.expand(B, -1, -1).contiguous(), ref, L_, P, amax_out=am_w)
+    got = MSDA.msda1d_fused_forward(value, shapes, lsi, proj_q, ref, L_, P, amax_out=am_g)
+    assert torch.equal(got, want) and torch.equal(am_g, am_w)
+
+
 @pytest.mark.parametrize("B,Q,H,masked", [(16, 300, 8, False), (3, 300, 8, True), (2, 37, 4, True), (1, 320, 2, False)])
 def test_attention_core_matches_fp64(B, Q, H, masked):
     """gvl_mha_core_f32 vs softmax(q k^T / sqrt(64)) v in fp64 (nn.MultiheadAttention's core, deformable_transformer.py:266-270)"""
