@@ -203,7 +203,7 @@ def test_encoder_geometry_equals_the_pytorch_formulation():
     assert ref.shape == want_ref.shape and maxerr(ref, want_ref) <= 1e-7
 
 
-@pytest.mark.parametrize("N,T,Cin", [(16, 100, 512), (3, 61, 96)])
+@pytest.mark.parametrize("N,T,Cin", [(16, 100, 512), (3, 61, 96), (2, 512, 96)])
 def test_flat_base_encoder_equals_the_pytorch_formulation(N, T, Cin, monkeypatch):
     """BaseEncoder.forward_flat (conv1d levels as strided-view products, GroupNorm into the flattened layout, one geometry
     launch) == BaseEncoder.forward + DeformableTransformer.prepare_encoder_inputs (base_encoder.py:55-82,

@@ -7,7 +7,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,T,Cin,C,nl", [(16, 100, 512, 512, 4), (3, 37, 128, 256, 3), (5, 16, 64, 64, 4)])
+@pytest.mark.parametrize("N,T,Cin,C,nl", [(16, 100, 512, 512, 4), (3, 37, 128, 256, 3), (5, 16, 64, 64, 4), (2, 512, 128, 512, 4),
+                                          (2, 257, 64, 128, 4)])       # (long videos: a group norm unit walks hundreds of rows)
 def test_training_pyramid_equals_the_pytorch_formulation(N, T, Cin, C, nl):
     from gvl_amd.base_encoder import BaseEncoder
     dev = torch.device("cuda:0")
