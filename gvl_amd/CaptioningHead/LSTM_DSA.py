@@ -304,7 +304,7 @@ class ShowAttendTellCore(nn.Module):
         """whether this step's gate product runs as gvl_gemm_f16x3_gates_f32 (the product over h in front of the attention is
         then h2att(h) alone)"""
         return ("w_gate_cat_p" in const and h.dtype == torch.float32 and const["slab3"].dtype == torch.float32
-                and MSDA.f16_products_now() == 3 and MSDA.gates_applicable(h.shape[0], self.rnn_size))
+                and MSDA.f16_products_now() in (1, 3) and MSDA.gates_applicable(h.shape[0], self.rnn_size))
 
     def cell_part(self, g_x, g_h, xt_gates, c, const):
         """(gate parts, input token) -> (h', c')"""

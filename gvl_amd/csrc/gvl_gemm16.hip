@@ -1328,6 +1328,9 @@ struct GatesEpi {
   int H;
 };
 
+// X1 (gvl_f16_products(1): inference under autocast): the leading product only -- the lo fragments are neither read from LDS nor
+// multiplied (their planes still travel with the stage: the DMA schedule of seven units per wavefront is the counted one)
+template <bool X1>
 __global__ void __launch_bounds__(512, 1)
     k_gates_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                   const _Float16 *__restrict__ B1h, const _Float16 *__restrict__ B1l, const float *__restrict__ B1s,
@@ -1403,18 +1406,20 @@ __global__ void __launch_bounds__(512, 1)
 #define GVL_G_RDA(ST, I)                                                                                             \
   {                                                                                                                  \
     ah[I] = *reinterpret_cast<const h8 *>(&(ST)[fa0 + 64 * (I)]);                                                    \
-    al[I] = *reinterpret_cast<const h8 *>(&(ST)[kASlots + fa0 + 64 * (I)]);                                          \
+    if constexpr (!X1) al[I] = *reinterpret_cast<const h8 *>(&(ST)[kASlots + fa0 + 64 * (I)]);                       \
   }
 #define GVL_G_RDB(ST, J, H_, L_)                                                                                     \
   {                                                                                                                  \
     H_ = *reinterpret_cast<const h8 *>(&(ST)[fb0 + 64 * (J)]);                                                       \
-    L_ = *reinterpret_cast<const h8 *>(&(ST)[kBSlots + fb0 + 64 * (J)]);                                             \
+    if constexpr (!X1) L_ = *reinterpret_cast<const h8 *>(&(ST)[kBSlots + fb0 + 64 * (J)]);                          \
   }
 #define GVL_G_MFMA3(I, J, BS)                                                                                        \
   {                                                                                                                  \
     acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], BS, acc[I][J], 0, 0, 0);                               \
-    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], bl[J], acc[I][J], 0, 0, 0);                            \
-    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[I], BS, acc[I][J], 0, 0, 0);                               \
+    if constexpr (!X1) {                                                                                             \
+      acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], bl[J], acc[I][J], 0, 0, 0);                          \
+      acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[I], BS, acc[I][J], 0, 0, 0);                             \
+    }                                                                                                                \
   }
 #define GVL_G_BLOCK(J, PRE, MID, POST)                                                                               \
   {                                                                                                                  \
@@ -1695,12 +1700,13 @@ struct GemmArgs {
   int tiles_m, tiles_n, blocks;
 };
 
+template <bool X1>
 __global__ void __launch_bounds__(256, 2) k_greedy_and_gemm(const GemmArgs ga, const float4 *__restrict__ part, int R, int chunks,
                                                             int64_t *__restrict__ idx, float *__restrict__ logp,
                                                             GreedyBook book) {
   if ((int)blockIdx.x < ga.blocks) {
     const LstmEpi none = {};
-    gemm4_body<64, kStore, false, true>((int)blockIdx.x, ga.Ah, ga.Al, ga.As, ga.Bh, ga.Bl, ga.Bs, ga.bias, ga.R, ga.N, ga.K, ga.out,
+    gemm4_body<64, kStore, X1, true>((int)blockIdx.x, ga.Ah, ga.Al, ga.As, ga.Bh, ga.Bl, ga.Bs, ga.bias, ga.R, ga.N, ga.K, ga.out,
                                   ga.ldo, ga.tiles_m, ga.tiles_n, none);
   } else {
     greedy_body((int)blockIdx.x - ga.blocks, part, R, chunks, idx, logp, book);
@@ -1871,7 +1877,6 @@ extern "C" int gvl_gemm_f16x3_gates_f32(const void *a_hi, const void *a_lo, cons
   if (H <= 0 || (H & 31)) return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: H must be a positive multiple of 32 (got %d)", H);
   if (K_h < kBK || K_a < kBK || (K_h % kBK) || (K_a % kBK) || K < 3 * kBK)
     return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: K_h and K_a must be positive multiples of 32, three stages in all (got %d, %d)", K_h, K_a);
-  if (gvl16::g_f16_products != 3) return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: the exact (three-product) form only");
   if (int rc = check_operands("gvl_gemm_f16x3_gates_f32", w_hi, w_lo, w_scale, N4, a_hi, a_lo, a_scale, n, K)) return rc;
   if (gates_c && (ld_c < N4 || (ld_c & 3)))
     return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: gates_c needs a row stride >= 4H, a multiple of 4");
@@ -1885,7 +1890,9 @@ extern "C" int gvl_gemm_f16x3_gates_f32(const void *a_hi, const void *a_lo, cons
     return fail(GVL_EINVAL, "gvl_gemm_f16x3_gates_f32: planes, gate operands and outputs must be 16-byte aligned");
   const GatesEpi ge = {gates_c, ld_c, emb_gates, it, c, h_out, c_out, (_Float16 *)h_hi, (_Float16 *)h_lo, h_scale, H};
   const int tiles_m = (N4 + 255) / 256, tiles_n = (n + 159) / 160;
-  return gvl::launch(GVL_PROF_GEMM16, n, N4, "k_gates_f16x3", k_gates_f16x3, dim3(persistent_grid(tiles_m * tiles_n)), dim3(512),
+  const bool x1 = gvl16::g_f16_products == 1;
+  return gvl::launch(GVL_PROF_GEMM16, n, N4, x1 ? "k_gates_f16x1" : "k_gates_f16x3", x1 ? k_gates_f16x3<true> : k_gates_f16x3<false>,
+                     dim3(persistent_grid(tiles_m * tiles_n)), dim3(512),
                      0, (hipStream_t)stream, (const _Float16 *)w_hi, (const _Float16 *)w_lo, w_scale, (const _Float16 *)hp_hi,
                      (const _Float16 *)hp_lo, hp_scale, (const _Float16 *)a_hi, (const _Float16 *)a_lo, a_scale, N4, n, K_h, K_a,
                      tiles_m, tiles_n, ge);
@@ -1906,7 +1913,7 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   const char *aform = gvl::env_str("GVL_ARGMAX_FORM");                // (4: the four-wavefront kernel, A/B runs)
   if (R >= 1024 && K >= 3 * kBK && !(aform && atoi(aform) == 4)) {
     const int tiles_n = (R + 255) / 256;
-    if (use_m16(K) && !x1) {
+    if (use_m16(K) && !x1) {                                           // (one product: the 128 x 256 form is the faster one, 5.58 against 5.70 ms per eval step)
       // 256 x 320 tiles with one accumulator (k_vocab_f16x3) when their rounds over the chip cost less than the 128 x 256
       // tiles': a round of the large tile takes 2.3 x a round of the small one (49 against 21 us at K = 512, one box)
       const int vm = (V + 255) / 256, vn = (R + 319) / 320, cus = persistent_grid(1 << 20);
@@ -1958,7 +1965,6 @@ extern "C" int gvl_greedy_step_partials_gemm_f32(const float *partials, int R, i
   if (R <= 0 || V <= 0 || (unfinished && seq_ld <= 0)) return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: bad sizes");
   if (!partials || !token || !logp || (unfinished && (!seq_col || !seq_lp_col)))
     return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: null pointer");
-  if (gvl16::g_f16_products != 3) return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: the exact (three-product) form only");
   if (int rc = check_operands("gvl_greedy_step_partials_gemm_f32", a_hi, a_lo, a_scale, Ra, b_hi, b_lo, b_scale, Nb, K)) return rc;
   if (Ra <= 0 || !out || ldo < Nb) return fail(GVL_EINVAL, "gvl_greedy_step_partials_gemm_f32: product output missing / ldo < N");
   const GreedyBook book = {unfinished, seq_col, seq_lp_col, seq_ld, first_step != 0, unfinished ? alive : nullptr};
@@ -1968,7 +1974,7 @@ extern "C" int gvl_greedy_step_partials_gemm_f32(const float *partials, int R, i
   ga.R = Ra; ga.N = Nb; ga.K = K; ga.out = out; ga.ldo = ldo;
   ga.tiles_m = (Ra + kBM - 1) / kBM; ga.tiles_n = (Nb + 63) / 64;
   ga.blocks = (ga.tiles_m * ga.tiles_n + 7) / 8 * 8;
-  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_and_gemm", k_greedy_and_gemm,
+  return gvl::launch(GVL_PROF_ROW_ARGMAX, R, V, "k_greedy_and_gemm", gvl16::g_f16_products == 1 ? k_greedy_and_gemm<true> : k_greedy_and_gemm<false>,
                      dim3(ga.blocks + (R + kRedRows - 1) / kRedRows), dim3(256), 0, (hipStream_t)stream, ga,
                      (const float4 *)partials, R, gvl_gemm_f16x3_argmax_chunks(V), token, logp, book);
 }

@@ -328,6 +328,39 @@ def test_both_halves_of_the_gate_product_in_one_launch(n, Ka, H, with_c):
     assert torch.equal(p2.hi, p1.hi) and torch.equal(p2.lo, p1.lo) and torch.equal(p2.scale, p1.scale)
 
 
+@pytest.mark.parametrize("n,Ka,H", [(4800, 512, 512), (333, 64, 32)])
+def test_one_launch_gate_product_with_one_fp16_product(n, Ka, H):
+    """gvl_f16_products(1) (inference under autocast): k_gates_f16x3's one-product instance multiplies the leading planes only --
+    the cell of sum_k hi_a[r, k] hi_w[j, k] scale_a[r] scale_w[j] (both halves) in float64, to fp32 rounding; and it stays within
+    the 11-bit operand model of the three-product launch"""
+    MSDA = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(n + H)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)                         # noqa: E731
+    att, h_prev = rnd(n, Ka), torch.tanh(rnd(n, H))
+    w_att, w_hh = rnd(4 * H, Ka) * Ka ** -0.5, rnd(4 * H, H) * H ** -0.5
+    gates_c, emb, c = rnd(n, 4 * H), rnd(50, 4 * H), rnd(n, H)
+    it = torch.randint(0, 50, (n,), device=dev, generator=g)
+    perm = MSDA.gate_permutation(H, dev)
+    ap, hp = MSDA.split_rows(att), MSDA.split_rows(h_prev)
+    w_cat = MSDA.split_rows(torch.cat([w_hh[perm], w_att[perm]], 1).contiguous())
+    gc_p, emb_p = gates_c[:, perm].contiguous(), emb[:, perm].contiguous()
+    h3, c3 = MSDA.gemm_f16x3_gates(ap, hp, w_cat, gc_p, emb_p, it, c)
+    with MSDA.f16_products(1):
+        h1, c1 = MSDA.gemm_f16x3_gates(ap, hp, w_cat, gc_p, emb_p, it, c)
+    torch.cuda.synchronize()
+    lead = lambda p_: p_.dense()[0].double() * p_.scale.double()[:, None]             # noqa: E731   (x = scale (hi + 2^-11 lo))
+    wl = lead(w_cat)
+    gates = lead(hp) @ wl[:, :H].t() + lead(ap) @ wl[:, H:].t() + gc_p.double() + emb_p.double()[it]
+    gi, gf, gg, go = gates.view(n, H, 4).unbind(2)                                    # (columns in the order 4 unit + gate)
+    c_ref = torch.sigmoid(gf) * c.double() + torch.sigmoid(gi) * torch.tanh(gg)
+    h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+    tol = 2e-5 * max(1.0, float(gates.abs().max()))
+    assert float((c1.double() - c_ref).abs().max()) < tol and float((h1.double() - h_ref).abs().max()) < tol
+    # 11-bit operands: relative 2^-11 per factor on sums of ~K terms of magnitude ~1
+    assert float((c1 - c3).abs().max()) < 2.0 ** -9 * (H + Ka) ** 0.5 and float((c1 - c3).abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("R,V,Ra,Nb", [(4800, 8518, 4800, 512), (4800, 8518, 4800, 528), (100, 300, 77, 64), (33, 70, 1100, 200)])
 def test_greedy_reduction_and_an_independent_product_in_one_launch(R, V, Ra, Nb):
     """gvl_greedy_step_partials_gemm_f32 = gvl_greedy_step_partials_alive_f32 + gvl_gemm_f16x3_f32 (its four-wavefront form) as ONE
