@@ -1082,6 +1082,9 @@ __device__ __forceinline__ void epilogue_v(f4acc4 (&acc)[4][NJ], int row0, int c
   }
 }
 
+// X1 (gvl_f16_products(1): inference under autocast): the leading product only -- the lo planes are neither fetched (their DMA
+// units are skipped: the stage waits are vmcnt(0), not counted) nor read from LDS nor multiplied
+template <bool X1>
 __global__ void __launch_bounds__(512, 1)
     k_vocab_f16x3(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al, const float *__restrict__ As,
                   const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl, const float *__restrict__ Bs,
@@ -1124,9 +1127,10 @@ __global__ void __launch_bounds__(512, 1)
     const int rows = isA ? R : N, row0 = isA ? (TM) * kRowsA : (TN) * kRowsB;                                        \
     const uint32_t soff = 2u * (uint32_t)((K0) * rows + (row0 + blk * 16) * 32);                                     \
     const int dst = (isA ? (lo ? kASlots : 0) : 2 * kASlots + (lo ? kBSlots : 0)) + blk * 64;                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? (lo ? rs_al : rs_ah) : (lo ? rs_bl : rs_bh),                      \
-                                             (__attribute__((address_space(3))) void *)((ST) + dst), 16,             \
-                                             GVL_V_SRC(lane_off + soff), 0, 0, 0);                                   \
+    if (!(X1 && lo))                                                                                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? (lo ? rs_al : rs_ah) : (lo ? rs_bl : rs_bh),                    \
+                                               (__attribute__((address_space(3))) void *)((ST) + dst), 16,           \
+                                               GVL_V_SRC(lane_off + soff), 0, 0, 0);                                 \
   }
 
   f4acc4 acc[4][NJ];
@@ -1143,12 +1147,12 @@ __global__ void __launch_bounds__(512, 1)
 #define GVL_V_RDA(ST, I)                                                                                             \
   {                                                                                                                  \
     ah[I] = *reinterpret_cast<const h8 *>(&(ST)[fa + 64 * (I)]);                                                     \
-    al[I] = *reinterpret_cast<const h8 *>(&(ST)[kASlots + fa + 64 * (I)]);                                           \
+    if constexpr (!X1) al[I] = *reinterpret_cast<const h8 *>(&(ST)[kASlots + fa + 64 * (I)]);                        \
   }
 #define GVL_V_RDB(ST, J, S)                                                                                          \
   {                                                                                                                  \
     bh[S] = *reinterpret_cast<const h8 *>(&(ST)[fb + 64 * (J)]);                                                     \
-    bl[S] = *reinterpret_cast<const h8 *>(&(ST)[kBSlots + fb + 64 * (J)]);                                           \
+    if constexpr (!X1) bl[S] = *reinterpret_cast<const h8 *>(&(ST)[kBSlots + fb + 64 * (J)]);                        \
   }
 #ifdef GVL_V_NO_VMWAIT
 #define GVL_V_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -1175,8 +1179,10 @@ __global__ void __launch_bounds__(512, 1)
 #define GVL_V_MFMA3(I, J, BS, S)                                                                                     \
   {                                                                                                                  \
     acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], BS, acc[I][J], 0, 0, 0);                               \
-    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], bl[S], acc[I][J], 0, 0, 0);                            \
-    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[I], BS, acc[I][J], 0, 0, 0);                               \
+    if constexpr (!X1) {                                                                                             \
+      acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[I], bl[S], acc[I][J], 0, 0, 0);                          \
+      acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[I], BS, acc[I][J], 0, 0, 0);                             \
+    }                                                                                                                \
   }
   // B block J of stage parity P: its fragments sit in register set (2 P + J) & 3; the block two further is requested first.
   // HALVES: the A blocks 0-1 and 2-3 as two scheduling regions -- the stage's first block scales the A fragments that arrived
@@ -1913,13 +1919,13 @@ extern "C" int gvl_gemm_f16x3_argmax_f32(const void *x_hi, const void *x_lo, con
   const char *aform = gvl::env_str("GVL_ARGMAX_FORM");                // (4: the four-wavefront kernel, A/B runs)
   if (R >= 1024 && K >= 3 * kBK && !(aform && atoi(aform) == 4)) {
     const int tiles_n = (R + 255) / 256;
-    if (use_m16(K) && !x1) {                                           // (one product: the 128 x 256 form is the faster one, 5.58 against 5.70 ms per eval step)
+    if (use_m16(K)) {
       // 256 x 320 tiles with one accumulator (k_vocab_f16x3) when their rounds over the chip cost less than the 128 x 256
       // tiles': a round of the large tile takes 2.3 x a round of the small one (49 against 21 us at K = 512, one box)
       const int vm = (V + 255) / 256, vn = (R + 319) / 320, cus = persistent_grid(1 << 20);
       const int64_t cost_v = (int64_t)((vm * vn + cus - 1) / cus) * 23, cost_m = (int64_t)((tiles_m * tiles_n + cus - 1) / cus) * 10;
       if (vocab_form() == 2 || (vocab_form() == 0 && cost_v < cost_m))
-        return gvl::launch(GVL_PROF_GEMM16, R, V, "k_vocab_f16x3<argmax>", k_vocab_f16x3, dim3(persistent_grid(vm * vn)), dim3(512),
+        return gvl::launch(GVL_PROF_GEMM16, R, V, x1 ? "k_vocab_f16x1<argmax>" : "k_vocab_f16x3<argmax>", x1 ? k_vocab_f16x3<true> : k_vocab_f16x3<false>, dim3(persistent_grid(vm * vn)), dim3(512),
                            0, (hipStream_t)stream, wh, wl, w_scale, xh, xl, x_scale, bias, V, R, K, partials, vm, vn,
                            gvl_gemm_f16x3_argmax_chunks(V));
     }
