@@ -1806,7 +1806,8 @@ extern "C" int gvl_gemm_f16x3_f32(const void *a_hi, const void *a_lo, const floa
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
                          bl, b_scale, bias, R, N, K, out, ldo, tiles_m, tiles_n, LstmEpi{});
     }
-    if (t_mid >= 384 && !gvl::env_str("GVL_GEMM16_NO_MID")) {
+    const char *mid_min = gvl::env_str("GVL_GEMM16_MID_MIN");          // (experiments: the fewest 128 x 128 tiles that take this form)
+    if (t_mid >= (mid_min ? atoi(mid_min) : 384) && !gvl::env_str("GVL_GEMM16_NO_MID")) {
       const int tiles_m = (R + 127) / 128, tiles_n = (N + 127) / 128;
       return gvl::launch(GVL_PROF_GEMM16, R, N, "k_gemm_f16x3_w8", (x1 ? k_gemm_f16x3_w8<2, 4, 1, kStore, true> : k_gemm_f16x3_w8<2, 4, 1, kStore, false>),
                          dim3(persistent_grid(tiles_m * tiles_n)), dim3(512), 0, (hipStream_t)stream, ah, al, a_scale, bh,
