@@ -887,6 +887,17 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
     mask = src_padding_mask.reshape(Rs).contiguous().view(torch.uint8) if src_padding_mask is not None else None
     nl = len(dec.layers)
     arena = _Arena((7 * nl + 2) * (R + 4), tgt.device)          # (+ the row maxima of the q | k and v columns per layer)
+    # the first layer's scaled reference points (:302-306) BEFORE the value product: with the first layer's self-attention block kept
+    # across forwards (_first_layer_constants) the sampling launch would otherwise directly follow this few-workgroup launch, and a
+    # launch behind one that left most of the chip idle runs 0.5-1 us longer (8.3 against 9.2 us inside the replayed graph, same box,
+    # GVL_REF_FIRST=0; tools/fwd_layer_stamps.py shows the two layers' launches)
+    first_ref_in = None
+    if os.environ.get("GVL_REF_FIRST", "1") != "0":
+        if reference_points.shape[-1] == 2:
+            first_ref_in = reference_points[:, :, None] * torch.stack([src_valid_ratios] * 2, -1)[:, None]
+        else:
+            assert reference_points.shape[-1] == 1
+            first_ref_in = reference_points[:, :, None] * src_valid_ratios[:, None, :, None]
     # value_proj(memory) of every layer: one product against the concatenated weights
     wv = cached(dec, "values", [(l_.cross_attn.value_proj.weight, l_.cross_attn.value_proj.bias) for l_ in dec.layers])
     values = [_new(Rs, C, mem) for _ in dec.layers]
@@ -910,6 +921,8 @@ def decoder_forward(dec, tgt, reference_points, src, src_temporal_shapes, src_le
     for lid, layer in enumerate(dec.layers):
         if next_ref_in is not None:                                               # left by the previous layer's refinement
             ref_in = next_ref_in
+        elif lid == 0 and first_ref_in is not None:
+            ref_in = first_ref_in
         elif reference_points.shape[-1] == 2:                                     # :302-304
             ref_in = reference_points[:, :, None] * torch.stack([src_valid_ratios] * 2, -1)[:, None]
         else:
